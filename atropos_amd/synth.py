@@ -1,0 +1,217 @@
+"""Counter-based synthetic read generator for the benchmark workloads C1..C5
+(BASELINE.json `configs`).
+
+Every base is a pure function of (seed, read index, column, stream) through a
+splitmix64 finaliser evaluated with wrapping int64 torch arithmetic, so the same
+reads come out on the CPU (tests, golden-vector generation) and on the GPU
+(bench.py, parity tests at full size) without moving data between them.
+
+Model (single-end): fragment length f ~ U[0.4 n, 1.6 n); the read is
+(fragment + adapter + random tail)[:n], so the adapter is present iff f < n.
+Per-base noise: substitution 1 %, 'N' 0.1 % (C5: 1 %); per read, one inserted
+base with probability n * 0.05 % and one deleted base with the same probability.
+Paired-end: read1 as above with adapter A1, read2 = (revcomp(fragment) + A2 +
+random tail)[:n] with independent noise.
+"""
+import torch
+
+TRUSEQ_33 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"          # C1
+TRUSEQ_34 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"         # C2 (TruSeq prefix)
+PE_ADAPTER1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCACACAGTGATCTCGTATGCCGTCTTCTGCTTG"   # C3/C5 read 1
+PE_ADAPTER2 = "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGTAGATCTCGGTGGTCGCCGTATCATT"         # C3/C5 read 2
+# C4: four linked adapters, pairwise-distant anchored 5' parts + one 3' part each.
+LINKED_FRONTS = ("ACGTACGTACGTAGCTAGCA", "TGCATGCATGGATCCATGGT", "GGTTCCAAGGTTCCAAGTGA", "CATCATCATTAGTAGTAGCC")
+LINKED_BACKS = (TRUSEQ_34, "CTGTCTCTTATACACATCTCCGAGCCCACGAGAC",
+                "TGGAATTCTCGGGTGCCAAGGAACTCCAGTCAC", "AATGATACGGCGACCACCGAGATCTACACTCTTT")
+
+SEEDS = {"C1": 0xA72050001, "C2": 0xA72050002, "C3": 0xA72050003, "C4": 0xA72050004, "C5": 0xA72050005}
+
+_K1 = -7046029254386353131      # 0x9E3779B97F4A7C15 as int64
+_K2 = -4658895280553007687      # 0xBF58476D1CE4E5B9
+_K3 = -7723592293110705685      # 0x94D049BB133111EB
+_K4 = 0x2545F4914F6CDD1D
+
+_BASES = b"ACGT"
+_COMP = {65: 84, 67: 71, 71: 67, 84: 65}
+
+
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def _mix(x):
+    """splitmix64 finaliser on an int64 tensor (wrapping arithmetic)."""
+    x = (x ^ _lsr(x, 30)) * _K2
+    x = (x ^ _lsr(x, 27)) * _K3
+    return x ^ _lsr(x, 31)
+
+
+def _wrap64(v):
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _h(seed, r, c, stream):
+    """63-bit non-negative hash of (seed, read, column, stream)."""
+    x = r * _K1 + c * _K2 + _wrap64(seed + stream * _K4)
+    return _mix(_mix(x) + stream) & 0x7FFFFFFFFFFFFFFF
+
+
+def _u(seed, r, c, stream):
+    """Uniform integer in [0, 2^24)."""
+    return _h(seed, r, c, stream) >> 39
+
+
+_ONE = 1 << 24
+
+
+def _adapter_tensor(adapter, device):
+    return torch.tensor(list(adapter.encode("ascii")), dtype=torch.int64, device=device)
+
+
+def _template(seed, r, s, f, adapter_t, base_stream, rc=False):
+    """ASCII code (int64) of template position s of read r: fragment (or its
+    reverse complement) for s < f, then the adapter, then a random tail."""
+    alen = adapter_t.numel()
+    lut = torch.tensor(list(_BASES), dtype=torch.int64, device=s.device)
+    if rc:
+        # reverse complement of the fragment: base f-1-s complemented (A<->T, C<->G == 3 - code)
+        fs = (f - 1 - s).clamp(min=0)
+        frag = 3 - (_h(seed, r, fs, base_stream) & 3)
+    else:
+        frag = _h(seed, r, s, base_stream) & 3
+    tail = _h(seed, r, s, base_stream + 50) & 3
+    code = torch.where(s < f, frag, tail)
+    out = lut[code]
+    in_ad = (s >= f) & (s < f + alen)
+    ad = adapter_t[(s - f).clamp(0, alen - 1)]
+    return torch.where(in_ad, ad, out)
+
+
+def _noisy_read(seed, r, n, f, adapter_t, stream0, n_rate, rc=False, frag_stream=0):
+    """[R, n] uint8 ASCII reads with the noise model applied."""
+    dev = r.device
+    c = torch.arange(n, dtype=torch.int64, device=dev)[None, :]
+    rr = r[:, None]
+    # one optional insertion and one optional deletion per read
+    has_ins = _u(seed, r, 0 * r, stream0 + 1) < int(n * 0.0005 * _ONE)
+    has_del = _u(seed, r, 0 * r, stream0 + 2) < int(n * 0.0005 * _ONE)
+    p_ins = (_h(seed, r, 0 * r, stream0 + 3) % n)[:, None]
+    p_del = (_h(seed, r, 0 * r, stream0 + 4) % n)[:, None]
+    shift = (has_del[:, None] & (c >= p_del)).to(torch.int64) - (has_ins[:, None] & (c > p_ins)).to(torch.int64)
+    s = c + shift
+    base = _template(seed, rr, s, f[:, None], adapter_t, frag_stream, rc=rc)
+    lut = torch.tensor(list(_BASES), dtype=torch.int64, device=dev)
+    rnd = lut[_h(seed, rr, c, stream0 + 5) & 3]
+    base = torch.where(has_ins[:, None] & (c == p_ins), rnd, base)
+    sub = _u(seed, rr, c, stream0 + 6) < int(0.01 * _ONE)
+    base = torch.where(sub, lut[_h(seed, rr, c, stream0 + 7) & 3], base)
+    isn = _u(seed, rr, c, stream0 + 8) < int(n_rate * _ONE)
+    base = torch.where(isn, torch.full_like(base, 78), base)
+    return base.to(torch.uint8)
+
+
+def _fragment_len(seed, r, n):
+    lo, hi = int(0.4 * n), int(1.6 * n)
+    return lo + _h(seed, r, 0 * r, 90) % (hi - lo)
+
+
+def single_end(start, count, n, adapter, seed, device="cpu", n_rate=0.001, chunk=1 << 18):
+    """Reads [start, start+count) of a single-end workload as a uint8 tensor
+    [count, n] of ASCII codes (all reads have length n)."""
+    dev = torch.device(device)
+    adapter_t = _adapter_tensor(adapter, dev)
+    out = torch.empty((count, n), dtype=torch.uint8, device=dev)
+    for lo in range(0, count, chunk):
+        hi = min(count, lo + chunk)
+        r = torch.arange(start + lo, start + hi, dtype=torch.int64, device=dev)
+        f = _fragment_len(seed, r, n)
+        out[lo:hi] = _noisy_read(seed, r, n, f, adapter_t, 10, n_rate)
+    return out
+
+
+def paired_end(start, count, n, adapter1, adapter2, seed, device="cpu", n_rate=0.001, chunk=1 << 18,
+               with_qualities=False):
+    """(read1, read2[, qual1, qual2]) uint8 tensors [count, n]; read2 is the
+    reverse strand of the same fragment followed by adapter2."""
+    dev = torch.device(device)
+    a1, a2 = _adapter_tensor(adapter1, dev), _adapter_tensor(adapter2, dev)
+    r1 = torch.empty((count, n), dtype=torch.uint8, device=dev)
+    r2 = torch.empty((count, n), dtype=torch.uint8, device=dev)
+    q1 = torch.empty((count, n), dtype=torch.uint8, device=dev) if with_qualities else None
+    q2 = torch.empty((count, n), dtype=torch.uint8, device=dev) if with_qualities else None
+    for lo in range(0, count, chunk):
+        hi = min(count, lo + chunk)
+        r = torch.arange(start + lo, start + hi, dtype=torch.int64, device=dev)
+        f = _fragment_len(seed, r, n)
+        r1[lo:hi] = _noisy_read(seed, r, n, f, a1, 10, n_rate)
+        r2[lo:hi] = _noisy_read(seed, r, n, f, a2, 30, n_rate, rc=True)
+        if with_qualities:
+            c = torch.arange(n, dtype=torch.int64, device=dev)[None, :]
+            q1[lo:hi] = (35 + _h(seed, r[:, None], c, 70) % 39).to(torch.uint8)   # U[2,40] + 33
+            q2[lo:hi] = (35 + _h(seed, r[:, None], c, 71) % 39).to(torch.uint8)
+    return (r1, r2, q1, q2) if with_qualities else (r1, r2)
+
+
+def linked(start, count, n, fronts, backs, seed, device="cpu", n_rate=0.001, chunk=1 << 18):
+    """C4: each read starts with one of the anchored 5' adapters (chosen per
+    read; about one read in five has none), followed by the fragment and that
+    adapter's 3' partner."""
+    dev = torch.device(device)
+    out = torch.empty((count, n), dtype=torch.uint8, device=dev)
+    fl = len(fronts[0])
+    assert all(len(x) == fl for x in fronts)
+    fronts_t = torch.stack([_adapter_tensor(x, dev) for x in fronts])
+    maxb = max(len(b) for b in backs)
+    backs_t = torch.stack([_adapter_tensor(b + "A" * (maxb - len(b)), dev) for b in backs])
+    blen = torch.tensor([len(b) for b in backs], dtype=torch.int64, device=dev)
+    lut = torch.tensor(list(_BASES), dtype=torch.int64, device=dev)
+    for lo in range(0, count, chunk):
+        hi = min(count, lo + chunk)
+        r = torch.arange(start + lo, start + hi, dtype=torch.int64, device=dev)
+        which = _h(seed, r, 0 * r, 91) % (len(fronts) + 1)          # == len(fronts): no 5' adapter
+        has_front = which < len(fronts)
+        wi = which.clamp(max=len(fronts) - 1)
+        f = _fragment_len(seed, r, n - fl)
+        c = torch.arange(n, dtype=torch.int64, device=dev)[None, :]
+        rr = r[:, None]
+        off = torch.where(has_front, torch.full_like(f, fl), torch.zeros_like(f))[:, None]
+        s = c - off                                                  # position within fragment+back+tail
+        frag = lut[_h(seed, rr, s.clamp(min=0), 0) & 3]
+        tail = lut[_h(seed, rr, s.clamp(min=0), 50) & 3]
+        bl = blen[wi][:, None]
+        fcol = f[:, None]
+        in_back = (s >= fcol) & (s < fcol + bl)
+        back = torch.gather(backs_t[wi], 1, (s - fcol).clamp(0, maxb - 1))
+        base = torch.where(s < fcol, frag, torch.where(in_back, back, tail))
+        front = torch.gather(fronts_t[wi], 1, c.clamp(max=fl - 1).expand(hi - lo, n))
+        base = torch.where(has_front[:, None] & (c < fl), front, base)
+        sub = _u(seed, rr, c, 16) < int(0.01 * _ONE)
+        base = torch.where(sub, lut[_h(seed, rr, c, 17) & 3], base)
+        isn = _u(seed, rr, c, 18) < int(n_rate * _ONE)
+        base = torch.where(isn, torch.full_like(base, 78), base)
+        out[lo:hi] = base.to(torch.uint8)
+    return out
+
+
+def workload(name, start, count, device="cpu"):
+    """Named BASELINE.json workloads. Returns a dict with the read tensors and
+    the adapter/aligner parameters the config is quoted on."""
+    if name == "C1":
+        return dict(reads=single_end(start, count, 100, TRUSEQ_33, SEEDS["C1"], device), n=100,
+                    adapter=TRUSEQ_33, max_error_rate=0.1, min_overlap=3, indel_cost=1, where="back")
+    if name == "C2":
+        return dict(reads=single_end(start, count, 150, TRUSEQ_34, SEEDS["C2"], device), n=150,
+                    adapter=TRUSEQ_34, max_error_rate=0.1, min_overlap=3, indel_cost=1, where="back")
+    if name == "C3":
+        r1, r2 = paired_end(start, count, 150, PE_ADAPTER1, PE_ADAPTER2, SEEDS["C3"], device)
+        return dict(reads1=r1, reads2=r2, n=150, adapter1=PE_ADAPTER1, adapter2=PE_ADAPTER2)
+    if name == "C4":
+        return dict(reads=linked(start, count, 150, LINKED_FRONTS, LINKED_BACKS, SEEDS["C4"], device), n=150,
+                    fronts=LINKED_FRONTS, backs=LINKED_BACKS, max_error_rate=0.12, min_overlap=3, indel_cost=1)
+    if name == "C5":
+        r1, r2, q1, q2 = paired_end(start, count, 250, PE_ADAPTER1, PE_ADAPTER2, SEEDS["C5"], device,
+                                    n_rate=0.01, with_qualities=True)
+        return dict(reads1=r1, reads2=r2, quals1=q1, quals2=q2, n=250,
+                    adapter1=PE_ADAPTER1, adapter2=PE_ADAPTER2)
+    raise KeyError(name)
