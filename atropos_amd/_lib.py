@@ -1,0 +1,169 @@
+"""Loader for libatropos_hip.so (the C ABI in include/atropos_hip.h) and the
+backend object the Python layer talks to.
+
+There is exactly one product backend: the HIP library running on an MI355X.  If the
+shared library has not been built, or no GPU is visible, every entry point raises --
+there is no CPU fallback.  (The CPU test-suite injects a lock-step emulation of the
+kernel built from the same per-lane source via ``set_backend``; that object lives
+under tests/ and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libatropos_hip.so")
+
+ATR_OK = 0
+ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "HIP runtime error",
+          -4: "out of memory", -5: "no HIP device"}
+TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
+MAX_REF_LEN = 128
+MAX_READ_LEN = 736
+
+# prototypes of every symbol include/atropos_hip.h declares
+PROTOTYPES = {
+    "atr_version": (C.c_int, []),
+    "atr_device_count": (C.c_int, []),
+    "atr_last_error": (C.c_char_p, []),
+    "atr_translate_table": (C.c_int, [C.c_int, C.c_char_p]),
+    "atr_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "atr_pack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
+                                 C.c_void_p, C.c_void_p]),
+    "atr_aligner_create": (C.c_int, [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.POINTER(C.c_void_p)]),
+    "atr_aligner_destroy": (None, [C.c_void_p]),
+    "atr_aligner_set_min_overlap": (C.c_int, [C.c_void_p, C.c_int]),
+    "atr_aligner_set_indel_cost": (C.c_int, [C.c_void_p, C.c_int]),
+    "atr_aligner_query_table": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                   C.c_void_p]),
+}
+
+
+class AtroposHipError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the C-ABI library and attach prototypes.  Raises if it is missing."""
+    if not os.path.exists(path):
+        raise AtroposHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C atropos_amd/csrc`). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc >= 0:
+        return rc
+    if rc == -1:
+        raise ValueError("%s: invalid argument" % what)
+    if rc == -4:
+        raise MemoryError(what)
+    detail = ERRORS.get(rc, "error %d" % rc)
+    if rc == -3:
+        detail += ": " + (lib.atr_last_error() or b"").decode("ascii", "replace")
+    raise AtroposHipError("%s: %s" % (what, detail))
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class HipBackend(object):
+    """Thin object view of the C ABI; all buffers are torch tensors on one GPU."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise AtroposHipError("no HIP device visible to torch; the alignment kernels need an MI355X")
+        ndev = _check(self.lib, self.lib.atr_device_count(), "atr_device_count")
+        if ndev < 1:
+            raise AtroposHipError("atr_device_count() == 0: no HIP device")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+
+    # -- helpers ---------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    # -- C ABI -----------------------------------------------------------------
+    def translate_table(self, kind):
+        buf = C.create_string_buffer(256)
+        _check(self.lib, self.lib.atr_translate_table(kind, buf), "atr_translate_table")
+        return buf.raw
+
+    def packed_bytes(self, nreads, max_len):
+        return self.lib.atr_packed_bytes(nreads, max_len)
+
+    def pack_reads(self, ascii_2d, lens, max_len, table):
+        """ascii_2d: uint8 [nreads, >=max_len] on self.device (row stride arbitrary);
+        lens: int32 [nreads] or None; table: 256 bytes.  Returns the packed uint8 tensor."""
+        nreads = ascii_2d.shape[0]
+        packed = self.empty((max(self.packed_bytes(nreads, max_len), 16),), torch.uint8)
+        if nreads and max_len:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads,
+                                                         max_len, table, _ptr(packed), self._stream()),
+                       "atr_pack_reads")
+        return packed
+
+    def aligner_create(self, ref, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+        h = C.c_void_p()
+        _check(self.lib, self.lib.atr_aligner_create(ref, len(ref), e, flags, int(wildcard_ref),
+                                                     int(wildcard_query), min_overlap, indel_cost, C.byref(h)),
+               "atr_aligner_create")
+        return h
+
+    def aligner_destroy(self, h):
+        self.lib.atr_aligner_destroy(h)
+
+    def aligner_set_min_overlap(self, h, v):
+        _check(self.lib, self.lib.atr_aligner_set_min_overlap(h, v), "atr_aligner_set_min_overlap")
+
+    def aligner_set_indel_cost(self, h, v):
+        _check(self.lib, self.lib.atr_aligner_set_indel_cost(h, v), "atr_aligner_set_indel_cost")
+
+    def aligner_query_table(self, h):
+        buf = C.create_string_buffer(256)
+        kind = _check(self.lib, self.lib.atr_aligner_query_table(h, buf), "atr_aligner_query_table")
+        return kind, buf.raw
+
+    def locate_batch(self, h, packed, lens, nreads, max_len):
+        out = self.empty((nreads, 8), torch.int16)
+        if nreads:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
+                                                           self._stream()), "atr_locate_batch")
+        return out
+
+
+_backend = None
+
+
+def get_backend():
+    """The process-wide backend; created on first use.  Raises (never falls back)
+    when the HIP library or the GPU is missing."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+def set_backend(backend):
+    """Install a backend object (used by bench.py to pin a device per rank, and by the
+    CPU test-suite to inject its kernel emulation).  Returns the previous one."""
+    global _backend
+    prev, _backend = _backend, backend
+    return prev

@@ -1,0 +1,110 @@
+"""Device-resident read batches and result arrays.
+
+The reference hands one Python ``str`` per call to ``Aligner.locate``
+(atropos/align/_align.pyx:266); the batched twins here take a ``ReadBatch``:
+ASCII reads translated through a 256-entry table and packed to 4 bits per base in
+the tile64 layout (include/atropos_hip.h), resident in GPU memory.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_ascii_matrix(reads):
+    """list of str/bytes -> (uint8 ndarray [n, max_len], int32 lens)."""
+    rows = [r.encode("ascii") if isinstance(r, str) else bytes(r) for r in reads]
+    lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+    max_len = int(lens.max()) if len(rows) else 0
+    mat = np.zeros((len(rows), max(max_len, 1)), dtype=np.uint8)
+    for i, r in enumerate(rows):
+        if r:
+            mat[i, :len(r)] = np.frombuffer(r, dtype=np.uint8)
+    return mat, lens
+
+
+class ReadBatch(object):
+    """4-bit packed reads on the device.
+
+    Attributes:
+        packed: uint8 tensor, tile64 layout.
+        lens: int32 tensor [nreads] or None (all reads ``max_len`` long).
+        nreads, max_len: batch shape.
+        table_kind, table: which translate table the reads were packed with.
+    """
+
+    def __init__(self, packed, lens, nreads, max_len, table_kind, table):
+        self.packed, self.lens = packed, lens
+        self.nreads, self.max_len = int(nreads), int(max_len)
+        self.table_kind, self.table = table_kind, bytes(table)
+
+    def __len__(self):
+        return self.nreads
+
+    @classmethod
+    def from_ascii(cls, ascii_2d, lens=None, max_len=None, table_kind=_lib.TABLE_DNA15, table=None,
+                   backend=None):
+        """ascii_2d: uint8 tensor/ndarray [nreads, width] of ASCII codes; lens: per-read
+        lengths (None = every read is ``width`` long)."""
+        be = backend or _lib.get_backend()
+        if isinstance(ascii_2d, np.ndarray):
+            ascii_2d = torch.from_numpy(np.ascontiguousarray(ascii_2d, dtype=np.uint8))
+        if ascii_2d.dtype != torch.uint8 or ascii_2d.dim() != 2:
+            raise ValueError("reads must be a uint8 [nreads, width] array")
+        ascii_2d = ascii_2d.to(be.device)
+        if ascii_2d.stride(1) != 1:
+            ascii_2d = ascii_2d.contiguous()
+        nreads, width = ascii_2d.shape
+        if lens is not None:
+            if isinstance(lens, np.ndarray):
+                lens = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32))
+            lens = lens.to(device=be.device, dtype=torch.int32).contiguous()
+            if lens.numel() != nreads:
+                raise ValueError("lens must have one entry per read")
+        if max_len is None:
+            max_len = width if lens is None else (int(lens.max().item()) if nreads else 0)
+        if max_len > width and nreads:
+            raise ValueError("max_len exceeds the row width")
+        if max_len > _lib.MAX_READ_LEN:
+            raise ValueError("reads longer than %d bases are outside the device kernels' envelope"
+                             % _lib.MAX_READ_LEN)
+        if table is None:
+            if table_kind == _lib.TABLE_CUSTOM:
+                raise ValueError("a custom table must be given explicitly")
+            table = be.translate_table(table_kind)
+        packed = be.pack_reads(ascii_2d, lens, max_len, bytes(table))
+        return cls(packed, lens, nreads, max_len, table_kind, table)
+
+    @classmethod
+    def from_strings(cls, reads, table_kind=_lib.TABLE_DNA15, table=None, backend=None):
+        """reads: sequence of ``str`` (ASCII) or ``bytes``."""
+        mat, lens = _as_ascii_matrix(reads)
+        if len(reads) == 0:
+            be = backend or _lib.get_backend()
+            if table is None:
+                table = be.translate_table(table_kind)
+            return cls(be.empty((16,), torch.uint8), None, 0, 0, table_kind, table)
+        return cls.from_ascii(mat, lens, None, table_kind, table, backend)
+
+
+class LocateResult(object):
+    """Result records of a batched ``locate``: int16 tensor [nreads, 8] on the device,
+    columns (refstart, refstop, querystart, querystop, matches, errors, 0, 0);
+    ``refstop == -1`` marks "no match" (the reference returns ``None``)."""
+
+    def __init__(self, records):
+        self.records = records
+
+    def __len__(self):
+        return self.records.shape[0]
+
+    def numpy(self):
+        return self.records.cpu().numpy()
+
+    def found(self):
+        return self.records[:, 1] >= 0
+
+    def tuples(self):
+        """List of 6-tuples / None, exactly what per-read ``locate`` calls return."""
+        arr = self.numpy()
+        return [None if row[1] < 0 else tuple(int(v) for v in row[:6]) for row in arr]

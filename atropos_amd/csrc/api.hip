@@ -1,0 +1,134 @@
+// api.hip -- the C ABI of libatropos_hip.so (include/atropos_hip.h) and the
+// ASCII -> 4-bit tile64 pack kernel.
+#include <hip/hip_runtime.h>
+#include <string>
+
+#include "atropos_hip.h"
+#include "aligner_host.hpp"
+#include "locate_kernel.hpp"
+
+namespace atr {
+
+locate_launcher locate_group_0(int), locate_group_1(int), locate_group_2(int), locate_group_3(int),
+    locate_group_4(int), locate_group_5(int), locate_group_6(int), locate_group_7(int);
+
+static thread_local std::string g_err;
+
+static int hip_fail(hipError_t e, const char *what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return ATR_ERR_HIP;
+}
+
+struct PackTable { uint8_t t[256]; };
+
+// The reference does bytes.translate(table) per read (_align.pyx:243-248, :292-297);
+// here one lane translates and packs its read, 32 bases (one 16-byte chunk) at a time,
+// and the wavefront stores each chunk as one contiguous 1 KiB burst.
+__global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, long long row_stride,
+                                                   const int32_t *__restrict__ lens, long long nreads,
+                                                   int max_len, int nchunks, const PackTable tab,
+                                                   uint4 *__restrict__ packed) {
+    __shared__ uint8_t s_tab[256];
+    s_tab[threadIdx.x] = tab.t[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ntiles = (nreads + 63) >> 6;
+    if (tile >= ntiles) return;
+    const long long r = tile * 64 + lane;
+    const int n = (r < nreads) ? min(lens ? lens[r] : max_len, max_len) : 0;
+    const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride;
+    uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
+    for (int c = 0; c < nchunks; ++c) {
+        uint4 v;
+        v.x = pack_word(row, c * 32, n, s_tab);
+        v.y = pack_word(row, c * 32 + 8, n, s_tab);
+        v.z = pack_word(row, c * 32 + 16, n, s_tab);
+        v.w = pack_word(row, c * 32 + 24, n, s_tab);
+        dst[(size_t)c * 64] = v;
+    }
+}
+
+}  // namespace atr
+
+using namespace atr;
+
+extern "C" {
+
+int atr_version(void) { return 100; }
+
+int atr_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice) return 0;
+    if (e != hipSuccess) return hip_fail(e, "hipGetDeviceCount");
+    return n;
+}
+
+const char *atr_last_error(void) { return g_err.c_str(); }
+
+int atr_translate_table(int kind, uint8_t table[256]) {
+    if (!table) return ATR_ERR_INVALID;
+    const Tables &T = tables();
+    switch (kind) {
+        case ATR_TABLE_DNA15: memcpy(table, T.dna15, 256); return ATR_OK;
+        case ATR_TABLE_ACGT:  memcpy(table, T.acgt, 256);  return ATR_OK;
+        case ATR_TABLE_IUPAC: memcpy(table, T.iupac, 256); return ATR_OK;
+        default: return ATR_ERR_INVALID;
+    }
+}
+
+size_t atr_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
+
+int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, int64_t nreads,
+                   int max_len, const uint8_t table[256], uint8_t *d_packed, void *stream) {
+    if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
+    if (nreads == 0 || max_len == 0) return ATR_OK;
+    if (!d_ascii || !d_packed) return ATR_ERR_INVALID;
+    PackTable tab;
+    memcpy(tab.t, table, 256);
+    const int nchunks = (max_len + 31) / 32;
+    const long long ntiles = (nreads + 63) / 64;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       d_ascii, (long long)row_stride, d_lens, (long long)nreads, max_len, nchunks, tab,
+                       (uint4 *)d_packed);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ATR_OK : hip_fail(e, "pack_kernel launch");
+}
+
+int atr_aligner_create(const char *ref, int m, double max_error_rate, int flags, int wildcard_ref,
+                       int wildcard_query, int min_overlap, int indel_cost, atr_aligner **out) {
+    return aligner_create(ref, m, max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap,
+                          indel_cost, out);
+}
+
+void atr_aligner_destroy(atr_aligner *a) { delete a; }
+
+int atr_aligner_set_min_overlap(atr_aligner *a, int min_overlap) { return aligner_set_min_overlap(a, min_overlap); }
+
+int atr_aligner_set_indel_cost(atr_aligner *a, int indel_cost) { return aligner_set_indel_cost(a, indel_cost); }
+
+int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
+    if (!a) return ATR_ERR_INVALID;
+    if (table) memcpy(table, a->qtable, 256);
+    return a->table_kind;
+}
+
+int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
+                     int max_len, atr_result *d_out, void *stream) {
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    if (!d_out || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
+    typedef locate_launcher (*group_fn)(int);
+    static const group_fn groups[LOCATE_GROUPS] = {
+        locate_group_0, locate_group_1, locate_group_2, locate_group_3,
+        locate_group_4, locate_group_5, locate_group_6, locate_group_7};
+    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    const locate_launcher fn = groups[idx / LOCATE_PER_GROUP](idx % LOCATE_PER_GROUP);
+    const int nchunks = (max_len + 31) / 32;
+    const int rc = fn(a, (const uint4 *)d_packed, d_lens, nreads, nchunks, max_len, (uint4 *)d_out,
+                      (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_kernel launch");
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// locate_core.hpp -- per-lane arithmetic of the batched Aligner.locate kernel
+// (reference: atropos/align/_align.pyx:266-491).
+//
+// Everything here is written once and compiled twice:
+//   * by hipcc for gfx950 (ATR_DEV = __device__ __forceinline__), where one lane of
+//     a wavefront owns one read and `LaneState` lives entirely in VGPRs;
+//   * by g++ with -DATR_HOST_EMU for tests/emu (a lock-step 64-lane emulation of the
+//     kernel's control flow that lets the CPU test-suite check the kernel logic
+//     against the oracle without a GPU).  It is test infrastructure only: the
+//     product library (libatropos_hip.so) contains the GPU build and nothing else.
+//
+// Cell word (one 32-bit VGPR per DP cell):
+//     [31:20] cost | [19:18] tie-break priority | [17:10] matches | [9:0] origin + 256
+// The reference's three-way choice with its tie order (mismatch <= insertion <=
+// deletion, _align.pyx:405-419) becomes ONE v_min3_u32: the three candidates carry
+// priority 0/1/2 just below the cost field, the payload (matches, origin) rides in
+// the low bits and never decides a comparison because the priorities differ.
+#ifndef ATR_LOCATE_CORE_HPP
+#define ATR_LOCATE_CORE_HPP
+
+#include <stdint.h>
+#include "atropos_hip.h"
+
+#ifdef ATR_HOST_EMU
+#define ATR_DEV static inline
+static inline int atr_min(int a, int b) { return a < b ? a : b; }
+static inline int atr_max(int a, int b) { return a > b ? a : b; }
+static inline uint32_t atr_minu(uint32_t a, uint32_t b) { return a < b ? a : b; }
+#else
+#define ATR_DEV __device__ __forceinline__
+#define atr_min min
+#define atr_max max
+#define atr_minu min
+#endif
+
+namespace atr {
+
+constexpr int MSH = 10, PSH = 18, CSH = 20;
+constexpr uint32_t ORG_BIAS = 256;
+constexpr uint32_t ORG_MASK = 0x3FFu, MAT_MASK = 0xFFu;
+constexpr uint32_t COST1 = 1u << CSH, MATCH1 = 1u << MSH;
+constexpr uint32_t PRIO_INS = 1u << PSH, PRIO_DEL = 2u << PSH, PRIO_MASK = 3u << PSH;
+constexpr int COST_FIELD_MAX = 4095;
+constexpr int INIT_COST_CAP = 2047;       // saturated initial-column cost (always > k)
+constexpr int ROW_GRAN = 4;               // register-column sizes come in multiples of this
+
+// Wave-uniform description of one aligner; passed by value as a kernel argument so
+// that the adapter codes sit in SGPRs.
+struct LocateParams {
+    uint8_t ref[ATR_MAX_REF_LEN];         // 4-bit codes by column position (front-padded, see column_step)
+    int16_t thr[ATR_MAX_REF_LEN + 2];     // thr[L] = floor(L * max_error_rate), clamped; -1 = accept nothing
+    int m, flags, k, min_overlap, indel;  // indel = effective cost, min(indel_cost, k+1)
+};
+
+struct Best {
+    int key;            // (matches << 12) | (4095 - cost): "more matches, then fewer errors"
+    uint32_t word;      // winning cell
+    int ref_stop, query_stop;
+};
+
+// Candidate test of _align.pyx:440-455 / :464-474.
+ATR_DEV void consider(Best &b, uint32_t w, int ref_stop, int query_stop, int min_overlap,
+                      const int16_t *thr) {
+    const int cost = (int)(w >> CSH);
+    const int origin = (int)(w & ORG_MASK) - (int)ORG_BIAS;
+    const int matches = (int)((w >> MSH) & MAT_MASK);
+    const int length = ref_stop + atr_min(origin, 0);
+    if (length >= min_overlap && cost <= (int)thr[atr_max(length, 0)]) {
+        const int key = (matches << 12) | (COST_FIELD_MAX - cost);
+        if (key > b.key) {                                    // strict: first seen wins ties
+            b.key = key; b.word = w; b.ref_stop = ref_stop; b.query_stop = query_stop;
+        }
+    }
+}
+
+// Initial column (_align.pyx:333-352) for row i at column min_n; rows < 0 are padding.
+ATR_DEV uint32_t init_word(int i, int min_n, bool sr, bool sq, int indel) {
+    int cost, origin;
+    if (!sr && !sq)      { cost = atr_max(i, min_n) * indel; origin = 0; }
+    else if (sr && !sq)  { cost = min_n * indel;             origin = atr_min(0, min_n - i); }
+    else if (!sr && sq)  { cost = i * indel;                 origin = atr_max(0, min_n - i); }
+    else                 { cost = atr_min(i, min_n) * indel; origin = min_n - i; }
+    if (i < 0) { cost = INIT_COST_CAP; origin = 0; }
+    return ((uint32_t)atr_min(cost, INIT_COST_CAP) << CSH) | (uint32_t)(origin + (int)ORG_BIAS);
+}
+
+// One DP column over MT register-resident positions.  The adapter occupies the LAST m
+// positions (row i sits at position p0 + i, p0 = MT - m in 0..ROW_GRAN-1), so row m is
+// always col[MT] and the code is straight-line: positions below p0 compute don't-care
+// cells that nothing above depends on, and position p0 is overwritten with the row-0
+// word.  The diagonal candidate of row i+1 is formed from the OLD col[i] before row i
+// overwrites it, so every cell is updated in place (no register rotation).
+// Equal characters take the diagonal unconditionally (_align.pyx:394-398).  Because
+// neighbouring cells differ by at most one indel, diag.cost <= left/up cost + indel,
+// and the priority bits break that tie for the diagonal, so one v_min3 serves both
+// the "equal" and the "three-way choice" case.  Returns the new cell of row m.
+template <int MT, bool EQ, bool NOINDEL>
+ATR_DEV uint32_t column_step(uint32_t (&col)[MT + 1], const LocateParams &p, int p0, uint32_t q,
+                             uint32_t row0, uint32_t insw, uint32_t delw) {
+    uint32_t cd;
+    {
+        const uint32_t rc = p.ref[0];
+        const bool same = EQ ? (rc == q) : ((rc & q) != 0);   // _align.pyx:390-393
+        cd = col[0] + (same ? MATCH1 : COST1);
+    }
+    col[0] = row0;
+#pragma unroll
+    for (int i = 1; i <= MT; ++i) {
+        uint32_t cd_next = 0;
+        if (i < MT) {
+            const uint32_t rc = p.ref[i];                    // SGPR (kernel argument)
+            const bool same = EQ ? (rc == q) : ((rc & q) != 0);
+            cd_next = col[i] + (same ? MATCH1 : COST1);
+        }
+        uint32_t nw;
+        if (NOINDEL) {
+            nw = cd;
+        } else {
+            const uint32_t cl = col[i] + delw;               // deletion:  (i, j-1) -> (i, j)
+            const uint32_t cu = col[i - 1] + insw;           // insertion: (i-1, j) -> (i, j)
+            nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+        }
+        if (i < ROW_GRAN) nw = (i == p0) ? row0 : nw;        // wave-uniform select, first positions only
+        col[i] = nw;
+        cd = cd_next;
+    }
+    return col[MT];
+}
+
+// Last-column candidates (_align.pyx:461-474): every row from first_i on, increasing.
+template <int MT>
+ATR_DEV void scan_last_column(Best &best, const uint32_t (&col)[MT + 1], int p0, int first_p, int n,
+                              int min_overlap, const int16_t *thr) {
+#pragma unroll
+    for (int i = 0; i <= MT; ++i) {
+        if (i >= first_p) consider(best, col[i], i - p0, n, min_overlap, thr);
+    }
+}
+
+// Everything one lane carries through the sweep.
+template <int MT>
+struct LaneState {
+    uint32_t col[MT + 1];
+    Best best;
+    int n, min_n, max_n;
+    bool scan;
+};
+
+// Wave-uniform constants derived from LocateParams once per kernel.
+struct Uniform {
+    int m, k, p0, first_p, indel, min_overlap;
+    bool sr, sq, er, eq;
+    uint32_t insw, delw, klimit;
+};
+
+ATR_DEV Uniform make_uniform(const LocateParams &p, int MT) {
+    Uniform u;
+    u.m = p.m; u.k = p.k; u.p0 = MT - p.m; u.indel = p.indel; u.min_overlap = p.min_overlap;
+    u.sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0; u.sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
+    u.er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0;  u.eq = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;
+    u.first_p = u.p0 + (u.er ? 0 : u.m);
+    u.insw = (uint32_t)u.indel * COST1 + PRIO_INS;
+    u.delw = (uint32_t)u.indel * COST1 + PRIO_DEL;
+    u.klimit = (uint32_t)(u.k + 1) << CSH;                   // cost <= k  <=>  word < klimit
+    return u;
+}
+
+// Window, initial column and "no match yet" state of one read of length n.
+// s_init holds the min_n == 0 initial column (by position).
+template <int MT>
+ATR_DEV void lane_init(LaneState<MT> &L, const Uniform &u, int n, const uint32_t *s_init, const int16_t *thr) {
+    L.n = n;
+    L.max_n = u.sq ? n : atr_min(n, u.m + u.k);              // _align.pyx:314-321
+    L.min_n = u.eq ? 0 : atr_max(0, n - u.m - u.k);
+    L.scan = (L.max_n == n);                                 // :461
+    if (u.eq) {
+#pragma unroll
+        for (int i = 0; i <= MT; ++i) L.col[i] = s_init[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, L.min_n, u.sr, u.sq, u.indel);
+    }
+    L.best.key = COST_FIELD_MAX - (u.m + n);                 // (matches 0, cost m+n): :358-363
+    L.best.word = (uint32_t)(u.m + n) << CSH;
+    L.best.ref_stop = u.m; L.best.query_stop = n;
+    // Empty reads never enter the column loop: their "last column" is the initial one.
+    if (L.scan && n == 0) scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr);
+}
+
+// Column j of the wave-uniform sweep, query code q.  Every lane of the wave executes
+// the column update unmasked; a lane whose own window (min_n, max_n] is narrower than
+// the wave's range
+//   * is re-initialised when the sweep reaches its min_n (only without STOP_WITHIN_SEQ2),
+//   * takes its last-column candidates when the sweep reaches its max_n,
+//   * ignores row-m candidates outside its window,
+// and whatever it computes past max_n is never looked at.
+template <int MT, bool EQ, bool NOINDEL>
+ATR_DEV void lane_step(LaneState<MT> &L, const LocateParams &p, const Uniform &u, int j, uint32_t q,
+                       const int16_t *thr) {
+    // row 0 (:385-388): origin j, or cost j*indel (saturated: it is > k long before).
+    // Matches 0; without START_WITHIN_SEQ2 the row-0 origin is 0 in every init case.
+    const uint32_t row0 = u.sq ? (ORG_BIAS + (uint32_t)j)
+                               : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
+    const uint32_t wm = column_step<MT, EQ, NOINDEL>(L.col, p, u.p0, q, row0, u.insw, u.delw);
+    if (u.eq) {
+        // row-m candidate: the reference looks at it only when the band reached row m,
+        // i.e. cost <= k (:433-455); min_n is 0 here.
+        if (wm < u.klimit && j <= L.max_n) consider(L.best, wm, u.m, j, u.min_overlap, thr);
+    } else if (j == L.min_n && L.max_n > L.min_n) {
+        int mn = L.min_n;
+#ifndef ATR_HOST_EMU
+        asm volatile("" : "+v"(mn));                         // keep the re-init out of the loop preheader
+#endif
+#pragma unroll
+        for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, mn, u.sr, u.sq, u.indel);
+    }
+    if (L.scan && j == L.max_n && L.max_n > L.min_n)
+        scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr);
+}
+
+// (refstart, refstop, querystart, querystop, matches, errors, 0, 0) as 8 x int16.
+template <int MT>
+ATR_DEV void lane_result(const LaneState<MT> &L, const Uniform &u, uint32_t rec[4]) {
+    const int cost = (int)(L.best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != u.m + L.n) {                                 // :476-480
+        const int origin = (int)(L.best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = L.best.ref_stop; querystop = L.best.query_stop;
+        matches = (int)((L.best.word >> MSH) & MAT_MASK); errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
+// ---- tile64 packing arithmetic (shared by the pack kernel and the emulation) -------
+
+// One 32-bit word = 8 bases, base b in bits 4b..4b+3.
+ATR_DEV uint32_t pack_word(const uint8_t *row, int j0, int n, const uint8_t *table) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const int j = j0 + b;
+        const uint32_t code = (j < n) ? (uint32_t)table[row[j]] : 0u;
+        w |= (code & 15u) << (4 * b);
+    }
+    return w;
+}
+
+}  // namespace atr
+#endif

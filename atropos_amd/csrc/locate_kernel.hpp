@@ -1,0 +1,115 @@
+// locate_kernel.hpp -- the gfx950 kernel around locate_core.hpp and its launcher.
+//
+// Mapping: one read per lane, 64 reads (one tile64 of the packed layout) per
+// wavefront, 4 wavefronts per workgroup; a launch needs nreads/256 workgroups, i.e.
+// tens of thousands for a 10 M-read batch on 256 CUs.  The only global traffic is
+// one coalesced 1 KiB chunk load per wave per 32 columns (prefetched one chunk
+// ahead) and one coalesced 16-byte result store per read; there is no reuse between
+// workgroups, so no XCD-specific block mapping is needed.
+#ifndef ATR_LOCATE_KERNEL_HPP
+#define ATR_LOCATE_KERNEL_HPP
+
+#include <hip/hip_runtime.h>
+#include "aligner_host.hpp"
+
+namespace atr {
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int MT, bool EQ, bool NOINDEL>
+__global__ __launch_bounds__(256) void locate_kernel(const LocateParams p, const uint4 *__restrict__ packed,
+                                                     const int32_t *__restrict__ lens, long long nreads,
+                                                     int nchunks, int max_len, uint4 *__restrict__ out) {
+    __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
+    __shared__ uint32_t s_init[ATR_MAX_REF_LEN + 1];        // by position
+
+    const Uniform u = make_uniform(p, MT);
+
+    // Stage the wave-uniform column-init state (min_n == 0) and the thresholds in LDS.
+    for (int i = threadIdx.x; i <= MT + 1; i += 256) {
+        if (i <= u.m + 1) s_thr[i] = p.thr[i];
+        if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ntiles = (nreads + 63) >> 6;
+    if (tile >= ntiles) return;                              // whole wave
+    const long long r = tile * 64 + lane;
+    const bool live = r < nreads;
+    const int n = live ? (lens ? lens[r] : max_len) : 0;
+
+    LaneState<MT> L;
+    lane_init<MT>(L, u, n, s_init, s_thr);
+
+    // Wave-uniform column range (jlo, jhi]: the union of the lanes' windows.
+    const bool has_window = live && L.max_n > L.min_n;
+    const int jlo = wave_min_i32(has_window ? L.min_n : 0x7fffffff);
+    const int jhi = wave_max_i32(has_window ? L.max_n : 0);
+    const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
+
+    if (jhi > jlo) {
+        const int c0 = jlo >> 5, c1 = (jhi + 31) >> 5;       // chunks [c0, c1)
+        uint4 nxt = tp[(size_t)c0 * 64];
+        for (int c = c0; c < c1; ++c) {
+            uint4 cur = nxt;
+            if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];  // prefetch the next 1 KiB burst
+            int j = c * 32;
+#pragma unroll 1
+            for (int d = 0; d < 4; ++d) {
+                uint32_t w = cur.x;
+                cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+#pragma unroll 1
+                for (int b = 0; b < 8; ++b) {
+                    ++j;
+                    const uint32_t q = w & 15u;
+                    w >>= 4;
+                    if (j <= jlo || j > jhi) continue;       // wave-uniform (first / last chunk only)
+                    lane_step<MT, EQ, NOINDEL>(L, p, u, j, q, s_thr);
+                }
+            }
+        }
+    }
+
+    if (live) {
+        uint32_t rec[4];
+        lane_result<MT>(L, u, rec);
+        out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+}
+
+typedef int (*locate_launcher)(const atr_aligner *, const uint4 *, const int32_t *, long long, int, int,
+                               uint4 *, hipStream_t);
+
+template <int MT>
+int launch_locate_mt(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
+                     int nchunks, int max_len, uint4 *out, hipStream_t st) {
+    const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
+    const bool noindel = a->indel_cost > a->p.k;
+    const long long ntiles = (nreads + 63) / 64;
+    const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+    if (eqmode) {
+        if (noindel) hipLaunchKernelGGL((locate_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+        else         hipLaunchKernelGGL((locate_kernel<MT, true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    } else {
+        if (noindel) hipLaunchKernelGGL((locate_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+        else         hipLaunchKernelGGL((locate_kernel<MT, false, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    }
+    return (int)hipGetLastError();
+}
+
+constexpr int LOCATE_GROUPS = 8;                             // instantiation units (parallel compilation)
+constexpr int LOCATE_PER_GROUP = ATR_MAX_REF_LEN / ROW_GRAN / LOCATE_GROUPS;   // 4 sizes each
+
+}  // namespace atr
+#endif

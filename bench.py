@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Headline benchmark: reads/s of 150 bp single-end adapter alignment
+(BASELINE.json configs[1], "C2": 10 M synthetic 150 bp reads, one TruSeq 3' adapter,
+e = 0.1) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path (atr_locate_batch) over one batch of 10 M packed
+reads resident in HBM; with N GPUs every rank owns its own 10 M-read shard (weak
+scaling, no data-path collective: reads are independent, results stay per GPU).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_READ = 75 + 16      # ceil(150/2) packed-nibble bytes in + 16-byte result out
+HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(workload, sample_reads):
+    """The oracle ("port" of the reference's Cython loop) timed on this box's host cores,
+    on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    lens = np.full(len(sample_reads), sample_reads.shape[1], np.int32)
+    O.locate_many(workload["adapter"], sample_reads[:1000], lens[:1000], 0.1, 14, False, False, 3, 1, 1)
+    t0 = time.perf_counter()
+    O.locate_many(workload["adapter"], sample_reads, lens, workload["max_error_rate"], 14, False, False,
+                  workload["min_overlap"], workload["indel_cost"], cores)
+    dt = time.perf_counter() - t0
+    return {"value": len(sample_reads) / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "first %d reads of the same C2 batch, oracle/align_oracle.c on %d threads, %.1f s"
+                      % (len(sample_reads), cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C2: 10 M)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from atropos_amd import _lib, synth
+    from atropos_amd.align import Aligner
+    _lib.set_backend(_lib.HipBackend(local_rank))
+
+    # this rank's shard of the synthetic read set: reads [rank*R, (rank+1)*R)
+    w = synth.workload("C2", rank * args.reads, args.reads, device="cuda:%d" % local_rank)
+    al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    batch = al.pack(w["reads"])
+    sample = w["reads"][:min(args.reads, 2_000_000)].cpu().numpy() if rank == 0 else None
+    del w["reads"]
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = al.locate_batch(batch)
+    # timed region: EXACTLY `steps` passes, bracketed by barrier + synchronize; the HIP events
+    # sit on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        res = al.locate_batch(batch)
+        ev[s][1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    n_found = int(res.found().sum().item())
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        total_reads = args.reads * world * args.steps
+        achieved = ALGO_BYTES_PER_READ * args.reads / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "reads/s (whole node) 150 bp SE adapter-align",
+            "value": total_reads / dt_max, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "C2: %d x 150 bp SE reads per GPU, TruSeq 34-mer 3' adapter, e=0.1, O=3, "
+                                   "indel cost 1, 4-bit packed reads resident in HBM" % args.reads,
+                       "reads_per_gpu": args.reads, "read_len": 150, "adapter_len": len(w["adapter"]),
+                       "parallelism": "shard%d" % world, "matched_fraction": n_found / args.reads},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "locate_kernel<36,eq,indel>", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
+                         "note": "integer-ALU bound DP: %.1f G cell updates/s"
+                                 % (args.reads * 150 * 36 / (kernel_ms * 1e-3) / 1e9)},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, sample)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -152,15 +152,35 @@ def rmp(matches, size, match_prob=0.25, mismatch_prob=0.75):
     return prob
 
 
+_TABLE_CACHE = {}
+
+
 def rmp_table(max_size, match_prob=0.25, mismatch_prob=0.75):
-    """[size][matches] table, leading dimension max_size+1; entries with
-    matches > size are 0."""
+    """[size][matches] table of rmp(), leading dimension max_size+1; entries with
+    matches > size are 0.  Every entry is the same left-to-right float sum rmp()
+    computes (term_k + term_k+1 + ...), evaluated for all k of one size at once."""
     import numpy as np
+    key = (max_size, match_prob, mismatch_prob)
+    if key in _TABLE_CACHE:
+        return _TABLE_CACHE[key]
     ld = max_size + 1
     t = np.zeros((ld, ld), dtype=np.float64)
     for size in range(ld):
-        for k in range(size + 1):
-            t[size, k] = rmp(k, size, match_prob, mismatch_prob)
+        nfac = _fact(size)
+        terms = np.empty(size + 1, dtype=np.float64)
+        for i in range(size + 1):
+            j = size - i
+            try:
+                div = nfac / _fact(i) / _fact(j)
+            except OverflowError:
+                div = nfac // _fact(i) // _fact(j)
+            terms[i] = (mismatch_prob ** j) * (match_prob ** i) * div
+        acc = 0.0 + terms                      # prob = 0.0; prob += term_k
+        for d in range(1, size + 1):
+            acc[:size + 1 - d] += terms[d:]
+        acc[size] = match_prob ** size         # matches == size shortcut
+        t[size, :size + 1] = acc
+    _TABLE_CACHE[key] = t
     return t
 
 

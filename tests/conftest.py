@@ -1,0 +1,57 @@
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    path = os.path.join(GOLDEN, name)
+    if name.endswith(".gz"):
+        with gzip.open(path, "rb") as fh:
+            return json.loads(fh.read().decode())
+    with open(path, "rb") as fh:
+        return json.loads(fh.read().decode())
+
+
+def tup(x):
+    return None if x is None else tuple(x)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture()
+def emu_backend():
+    """Install the CPU lock-step emulation of the gfx950 kernels (tests/emu) as the
+    package backend for one test; restores the previous backend afterwards."""
+    from atropos_amd import _lib
+    from tests.emu.backend import EmuBackend
+    prev = _lib.set_backend(EmuBackend())
+    yield _lib.get_backend()
+    _lib.set_backend(prev)
+
+
+@pytest.fixture()
+def hip_backend():
+    """The real thing; GPU tests fail (not skip) if the HIP library is not loadable."""
+    from atropos_amd import _lib
+    prev = _lib.set_backend(None)
+    be = _lib.get_backend()
+    assert be.name == "hip"
+    yield be
+    _lib.set_backend(prev)

@@ -1,0 +1,115 @@
+"""TEST INFRASTRUCTURE: a backend object with the interface of
+``atropos_amd._lib.HipBackend`` that runs the lock-step CPU emulation of the gfx950
+kernels (tests/emu/emu_locate.cpp, compiled from the product's own per-lane source
+with -DATR_HOST_EMU).  Installed by the CPU test-suite through
+``atropos_amd._lib.set_backend``; never importable from the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_SO = os.path.join(_HERE, "libemu_locate.so")
+_SRCS = [os.path.join(_HERE, "emu_locate.cpp")] + [
+    os.path.join(_ROOT, "atropos_amd", "csrc", f) for f in ("locate_core.hpp", "aligner_host.hpp")] + [
+    os.path.join(_ROOT, "include", "atropos_hip.h")]
+
+
+def build():
+    if not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DATR_HOST_EMU",
+                               "-I" + os.path.join(_ROOT, "include"),
+                               "-I" + os.path.join(_ROOT, "atropos_amd", "csrc"),
+                               _SRCS[0], "-o", _SO])
+    return _SO
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _check(rc, what):
+    if rc >= 0:
+        return rc
+    if rc == -1:
+        raise ValueError("%s: invalid argument" % what)
+    if rc == -4:
+        raise MemoryError(what)
+    from atropos_amd._lib import AtroposHipError
+    raise AtroposHipError("%s: error %d" % (what, rc))
+
+
+class EmuBackend(object):
+    name = "emu"
+
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.emu_aligner_create.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.POINTER(C.c_void_p)]
+        L.emu_aligner_destroy.argtypes = [C.c_void_p]
+        L.emu_aligner_destroy.restype = None
+        L.emu_aligner_set_min_overlap.argtypes = [C.c_void_p, C.c_int]
+        L.emu_aligner_set_indel_cost.argtypes = [C.c_void_p, C.c_int]
+        L.emu_aligner_query_table.argtypes = [C.c_void_p, C.c_char_p]
+        L.emu_packed_bytes.argtypes = [C.c_int64, C.c_int]
+        L.emu_packed_bytes.restype = C.c_size_t
+        L.emu_pack_reads.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p]
+        L.emu_locate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        self.device = torch.device("cpu")
+        from atropos_amd import _lib
+        self._kinds = {}
+        # fixed tables come from the same aligner_host.hpp code via throw-away aligners
+        for kind, args in ((_lib.TABLE_DNA15, (b"A", 0, 0)), (_lib.TABLE_ACGT, (b"A", 1, 0)),
+                           (_lib.TABLE_IUPAC, (b"A", 0, 1))):
+            h = self.aligner_create(args[0], 0.1, 15, args[1], args[2], 1, 1)
+            k, tab = self.aligner_query_table(h)
+            assert k == kind
+            self._kinds[kind] = tab
+            self.aligner_destroy(h)
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def translate_table(self, kind):
+        return self._kinds[kind]
+
+    def packed_bytes(self, nreads, max_len):
+        return self.lib.emu_packed_bytes(nreads, max_len)
+
+    def pack_reads(self, ascii_2d, lens, max_len, table):
+        nreads = ascii_2d.shape[0]
+        packed = torch.zeros((max(self.packed_bytes(nreads, max_len), 16),), dtype=torch.uint8)
+        if nreads and max_len:
+            _check(self.lib.emu_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads, max_len, table,
+                                           _ptr(packed)), "emu_pack_reads")
+        return packed
+
+    def aligner_create(self, ref, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+        h = C.c_void_p()
+        _check(self.lib.emu_aligner_create(ref, len(ref), e, flags, int(wildcard_ref), int(wildcard_query),
+                                           min_overlap, indel_cost, C.byref(h)), "atr_aligner_create")
+        return h
+
+    def aligner_destroy(self, h):
+        self.lib.emu_aligner_destroy(h)
+
+    def aligner_set_min_overlap(self, h, v):
+        _check(self.lib.emu_aligner_set_min_overlap(h, v), "atr_aligner_set_min_overlap")
+
+    def aligner_set_indel_cost(self, h, v):
+        _check(self.lib.emu_aligner_set_indel_cost(h, v), "atr_aligner_set_indel_cost")
+
+    def aligner_query_table(self, h):
+        buf = C.create_string_buffer(256)
+        kind = _check(self.lib.emu_aligner_query_table(h, buf), "atr_aligner_query_table")
+        return kind, buf.raw
+
+    def locate_batch(self, h, packed, lens, nreads, max_len):
+        out = torch.zeros((nreads, 8), dtype=torch.int16)
+        if nreads:
+            _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out)),
+                   "atr_locate_batch")
+        return out

@@ -1,0 +1,127 @@
+// emu_locate.cpp -- TEST INFRASTRUCTURE.  A lock-step CPU emulation of the gfx950
+// locate kernel's control flow (atropos_amd/csrc/locate_kernel.hpp) built from the
+// SAME per-lane source (locate_core.hpp, compiled with -DATR_HOST_EMU) and the same
+// host parameter derivation (aligner_host.hpp).  It lets the CPU test-suite check the
+// kernel arithmetic -- packed cell words, v_min3 tie-breaking, end-aligned rows,
+// wave-uniform sweep with per-lane windows -- against the oracle without a GPU.
+// It is never loaded by the product package.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "aligner_host.hpp"
+
+using namespace atr;
+
+namespace {
+
+template <int MT, bool EQ, bool NOINDEL>
+void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, long long nreads,
+               int nchunks, int max_len, uint32_t *out) {
+    const LocateParams &p = a->p;
+    const Uniform u = make_uniform(p, MT);
+    int16_t s_thr[ATR_MAX_REF_LEN + 2];
+    uint32_t s_init[ATR_MAX_REF_LEN + 1];
+    for (int i = 0; i <= MT + 1; ++i) {
+        if (i <= u.m + 1) s_thr[i] = p.thr[i];
+        if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
+    }
+    const long long ntiles = (nreads + 63) / 64;
+    std::vector<LaneState<MT>> L(64);
+    for (long long tile = 0; tile < ntiles; ++tile) {
+        int jlo = 0x7fffffff, jhi = 0;
+        bool live[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            const long long r = tile * 64 + lane;
+            live[lane] = r < nreads;
+            const int n = live[lane] ? (lens ? lens[r] : max_len) : 0;
+            lane_init<MT>(L[lane], u, n, s_init, s_thr);
+            const bool has_window = live[lane] && L[lane].max_n > L[lane].min_n;
+            jlo = std::min(jlo, has_window ? L[lane].min_n : 0x7fffffff);
+            jhi = std::max(jhi, has_window ? L[lane].max_n : 0);
+        }
+        if (jhi > jlo) {
+            const int c0 = jlo >> 5, c1 = (jhi + 31) >> 5;
+            for (int c = c0; c < c1; ++c) {
+                for (int d = 0; d < 4; ++d) {
+                    for (int b = 0; b < 8; ++b) {
+                        const int j = c * 32 + d * 8 + b + 1;
+                        if (j <= jlo || j > jhi) continue;
+                        for (int lane = 0; lane < 64; ++lane) {   // every lane, unmasked, like the wave
+                            const uint32_t w = packed[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d];
+                            const uint32_t q = (w >> (4 * b)) & 15u;
+                            lane_step<MT, EQ, NOINDEL>(L[lane], p, u, j, q, s_thr);
+                        }
+                    }
+                }
+            }
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            if (!live[lane]) continue;
+            lane_result<MT>(L[lane], u, out + (tile * 64 + lane) * 4);
+        }
+    }
+}
+
+typedef void (*emu_fn)(const atr_aligner *, const uint32_t *, const int32_t *, long long, int, int, uint32_t *);
+
+template <int MT>
+emu_fn pick(bool eqmode, bool noindel) {
+    if (eqmode) return noindel ? &emu_tiles<MT, true, true> : &emu_tiles<MT, true, false>;
+    return noindel ? &emu_tiles<MT, false, true> : &emu_tiles<MT, false, false>;
+}
+
+template <int... I>
+emu_fn pick_mt(int idx, bool eqmode, bool noindel, std::integer_sequence<int, I...>) {
+    emu_fn fns[] = {pick<(I + 1) * ROW_GRAN>(eqmode, noindel)...};
+    return fns[idx];
+}
+
+}  // namespace
+
+extern "C" {
+
+int emu_aligner_create(const char *ref, int m, double e, int flags, int wr, int wq, int min_overlap,
+                       int indel_cost, atr_aligner **out) {
+    return aligner_create(ref, m, e, flags, wr, wq, min_overlap, indel_cost, out);
+}
+void emu_aligner_destroy(atr_aligner *a) { delete a; }
+int emu_aligner_set_min_overlap(atr_aligner *a, int v) { return aligner_set_min_overlap(a, v); }
+int emu_aligner_set_indel_cost(atr_aligner *a, int v) { return aligner_set_indel_cost(a, v); }
+int emu_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
+    if (table) memcpy(table, a->qtable, 256);
+    return a->table_kind;
+}
+size_t emu_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
+
+int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens, int64_t nreads, int max_len,
+                   const uint8_t table[256], uint8_t *packed) {
+    const int nchunks = (max_len + 31) / 32;
+    const long long ntiles = (nreads + 63) / 64;
+    uint32_t *dst = (uint32_t *)packed;
+    for (long long tile = 0; tile < ntiles; ++tile)
+        for (int lane = 0; lane < 64; ++lane) {
+            const long long r = tile * 64 + lane;
+            const int n = (r < nreads) ? std::min(lens ? lens[r] : max_len, max_len) : 0;
+            const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride;
+            for (int c = 0; c < nchunks; ++c)
+                for (int d = 0; d < 4; ++d)
+                    dst[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] = pack_word(row, c * 32 + d * 8, n, table);
+        }
+    return ATR_OK;
+}
+
+int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t *lens, int64_t nreads,
+                     int max_len, int16_t *out) {
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
+    const bool noindel = a->indel_cost > a->p.k;
+    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    emu_fn fn = pick_mt(idx, eqmode, noindel, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
+    fn(a, (const uint32_t *)packed, lens, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
+    return ATR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+"""CPU check of the gfx950 locate kernel's arithmetic and control flow through the
+lock-step emulation in tests/emu (same per-lane source as the GPU build), against
+the golden vectors and the oracle.  The GPU parity tests proper are in
+test_gpu_locate.py (-m gpu)."""
+import pytest
+
+from . import _cases
+from .conftest import load_golden, tup
+
+
+def test_golden_locate(emu_backend):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    checked, unsupported = _cases.check_golden_locate(Aligner, _lib.AtroposHipError)
+    assert checked > 6000
+    assert unsupported < 200          # only ">15 distinct symbols compared literally"
+
+
+def test_batches_all_flags(emu_backend, oracle):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_batches_against_oracle(Aligner, oracle, _lib.AtroposHipError, 11, 150) > 10000
+
+
+def test_synthetic_heads(emu_backend):
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    heads = load_golden("synth_heads.json.gz")
+    for name in ("C1", "C2"):
+        w = synth.workload(name, 0, heads[name]["count"])
+        al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+        got = al.locate_batch(w["reads"]).tuples()
+        assert got == [tup(x) for x in heads[name]["out"]]
+
+
+def test_api_surface(emu_backend, oracle):
+    from atropos_amd import align
+    # reference tests/test_align.py:13-22 (smoke calls, incl. a 100 % error rate)
+    a = align.Aligner("CTCCAGCTTAGACATATC", 0.1, flags=14)
+    assert a.locate("CC") == oracle.locate("CTCCAGCTTAGACATATC", "CC", 0.1, 14)
+    assert align.Aligner("GCTTAGACATATC", 1.0, flags=14).locate("CAA") == oracle.locate("GCTTAGACATATC", "CAA", 1.0, 14)
+    with pytest.raises(ValueError):
+        align.Aligner("ACGT", 0.1, min_overlap=0)
+    with pytest.raises(ValueError):
+        align.Aligner("ACGT", 0.1, indel_cost=0)
+    a = align.Aligner("ACGT", 0.1)
+    with pytest.raises(ValueError):
+        a.min_overlap = 0
+    with pytest.raises(ValueError):
+        a.indel_cost = 0
+    with pytest.raises(UnicodeEncodeError):
+        a.locate("ACé")
+    a.min_overlap = 3
+    assert a.min_overlap == 3
+    import pickle
+    b = pickle.loads(pickle.dumps(align.Aligner("TCGTATGCCGTCTTC", 0.2, 14, False, False, 3, 1)))
+    assert b.locate("TCGTATGCCCTCC") == (0, 15, 0, 12, 12, 3)
+    assert align.locate("TCGTATGCCGTCTTC", "TCGTATGCCCTCC", 0.2, 14) == (0, 15, 0, 12, 12, 3)
+    assert align.Aligner("", 0.1).locate("ACGT") is None
+    assert align.Aligner("ACGT", 0.1).locate("") is None
+    assert a.reference == b"ACGT"
+    assert align.Aligner("ACGN", 0.1, wildcard_ref=True).reference == bytes([1, 2, 4, 15])
+    # changing the indel cost changes the result (issue #80 alignment needs indels)
+    c = align.Aligner("TCGTATGCCGTCTTC", 0.2, 14, min_overlap=3)
+    c.indel_cost = 100000
+    assert c.locate("TCGTATGCCCTCC") != (0, 15, 0, 12, 12, 3)
+    # batches packed for one table are rejected by an aligner that needs another
+    batch = a.pack(["ACGT", "TTTT"])
+    with pytest.raises(ValueError):
+        align.Aligner("ACGN", 0.1, wildcard_ref=True).locate_batch(batch)
+    assert len(a.locate_batch([])) == 0

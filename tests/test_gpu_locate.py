@@ -1,0 +1,120 @@
+"""GPU parity tests proper: the HIP kernels, called through the C ABI, against the
+oracle and the committed golden vectors.  Bit-exact (integer work)."""
+import numpy as np
+import pytest
+import torch
+
+from . import _cases
+from .conftest import load_golden, tup
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_loaded(hip_backend):
+    import ctypes  # noqa: F401
+    from atropos_amd import _lib
+    assert hip_backend.name == "hip" and hip_backend.device.type == "cuda"
+    with open("/proc/self/maps") as fh:
+        assert "libatropos_hip.so" in fh.read()
+    assert "MI355" in torch.cuda.get_device_name(0) or "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    assert _lib.get_backend() is hip_backend
+
+
+def test_golden_locate(hip_backend):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    checked, unsupported = _cases.check_golden_locate(Aligner, _lib.AtroposHipError)
+    assert checked > 6000 and unsupported < 200
+
+
+def test_batches_all_flags(hip_backend, oracle):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_batches_against_oracle(Aligner, oracle, _lib.AtroposHipError, 23, 300) > 20000
+
+
+def test_every_column_size(hip_backend, oracle):
+    """One batch per register-column size (m = 1..128), indel and no-indel kernels,
+    equality and wildcard compare modes."""
+    import random
+    from atropos_amd.align import Aligner
+    rng = random.Random(99)
+    for m in range(1, 129):
+        ref = _cases.rseq(rng, m)
+        for ic, wr in ((1, False), (100000, False), (1, True), (100000, True)):
+            e = 0.1 if m >= 10 else 0.34
+            al = Aligner(ref, e, 14, wr, False, 3, ic)
+            reads = _cases.planted_reads(rng, ref, 96, 220)
+            got = al.locate_batch(reads).tuples()
+            for q, g in zip(reads, got):
+                assert g == oracle.locate(ref, q, e, 14, wr, False, 3, ic), (m, ic, wr, q)
+
+
+def test_synthetic_heads(hip_backend):
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    heads = load_golden("synth_heads.json.gz")
+    for name in ("C1", "C2"):
+        w = synth.workload(name, 0, heads[name]["count"], device="cuda")
+        al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+        assert al.locate_batch(w["reads"]).tuples() == [tup(x) for x in heads[name]["out"]]
+
+
+def test_c1_full_against_oracle(hip_backend, oracle):
+    """BASELINE config C1 in full: 10 k x 100 bp, 33-bp adapter, e=0.1."""
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    w = synth.workload("C1", 0, 10000, device="cuda")
+    al = Aligner(w["adapter"], 0.1, 14, False, False, 3, 1)
+    got = al.locate_batch(w["reads"]).numpy()[:, :6].astype(np.int32)
+    reads = w["reads"].cpu().numpy()
+    exp = oracle.locate_many(w["adapter"], reads, np.full(len(reads), 100, np.int32), 0.1, 14, False, False, 3, 1, 4)
+    assert np.array_equal(got, exp)
+    assert (exp[:, 1] >= 0).sum() > 3000
+
+
+def test_c2_sample_and_full_size_properties(hip_backend, oracle):
+    """BASELINE config C2 at full size (10 M x 150 bp on the device): a 200 k-read
+    slice bit-exact against the oracle, plus size-independent properties over all
+    10 M records."""
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    n_total = 10_000_000
+    w = synth.workload("C2", 0, n_total, device="cuda")
+    reads = w["reads"]
+    al = Aligner(w["adapter"], 0.1, 14, False, False, 3, 1)
+    batch = al.pack(reads)
+    rec = al.locate_batch(batch).records
+    torch.cuda.synchronize()
+    # (1) slice parity
+    lo = 4_321_000
+    sl = reads[lo:lo + 200_000].cpu().numpy()
+    exp = oracle.locate_many(w["adapter"], sl, np.full(len(sl), 150, np.int32), 0.1, 14, False, False, 3, 1, 8)
+    assert np.array_equal(rec[lo:lo + 200_000, :6].cpu().numpy().astype(np.int32), exp)
+    # (2) invariants of every record
+    r = rec.to(torch.int32)
+    found = r[:, 1] >= 0
+    f = r[found]
+    m = len(w["adapter"])
+    assert 0.45 < found.float().mean().item() < 0.60
+    assert bool((f[:, 0] == 0).all())                        # BACK adapter: refstart is always 0
+    assert bool(((f[:, 1] > 0) & (f[:, 1] <= m)).all())
+    assert bool(((f[:, 2] >= 0) & (f[:, 2] <= f[:, 3]) & (f[:, 3] <= 150)).all())
+    assert bool(((f[:, 1] < m) <= (f[:, 3] == 150)).all())   # partial adapter only at the read's end
+    assert bool((f[:, 5] <= (f[:, 1] * 0.1).floor().to(torch.int32)).all())   # errors <= floor(length*e)
+    assert bool((f[:, 4] + f[:, 5] >= f[:, 1]).all()) and bool((f[:, 4] <= f[:, 1]).all())
+    assert bool((r[~found][:, [0, 2, 3, 4, 5]] == 0).all())
+    # (3) determinism / idempotence: same batch, same records; independent of batch split
+    rec2 = al.locate_batch(batch).records
+    assert torch.equal(rec, rec2)
+    part = al.locate_batch(reads[lo:lo + 100_037]).records
+    assert torch.equal(part, rec[lo:lo + 100_037])
+    # (4) exact-occurrence property: reads containing the whole adapter verbatim match it with 0 errors
+    ad = torch.tensor(list(w["adapter"].encode()), dtype=torch.uint8, device="cuda")
+    sub = reads[:1_000_000]
+    win = sub.unfold(1, m, 1)                                # [N, 117, 34]
+    hit = (win == ad).all(dim=2)
+    has = hit.any(dim=1)
+    first = hit.float().argmax(dim=1).to(torch.int32)
+    rs = r[:1_000_000][has]
+    assert bool((rs[:, 5] == 0).all()) and bool((rs[:, 4] == m).all()) and bool((rs[:, 2] == first[has]).all())
