@@ -1,0 +1,56 @@
+#!/bin/bash
+# Profiling recipe run on the GPU box (via gpurun): kernel trace + stats, then PMC
+# passes in separate runs (rocprofv3 must not combine --pmc with trace domains), then
+# keep only the locate_kernel rows so the merged gpurun_out/ stays small.
+# usage: tools/profile_r.sh <tag>
+set -u
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+rm -rf "$OUT" && mkdir -p "$OUT"
+BENCH="python bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 10 --warmup 2 > $OUT/trace.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum"; do
+  N=$(echo $C | cut -d' ' -f1)
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$N -- $BENCH --steps 3 --warmup 1 > $OUT/pmc_$N.log 2>&1
+done
+# reduce
+python - "$OUT" <<'PY'
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+def find(pat):
+    return glob.glob(os.path.join(out, pat), recursive=True)
+with open(os.path.join(out, "summary.txt"), "w") as fh:
+    for f in find("trace/**/*kernel_stats.csv"):
+        fh.write("== kernel_stats (%s)\n" % f)
+        fh.write(open(f).read())
+    for f in find("trace/**/*kernel_trace.csv"):
+        rows = list(csv.DictReader(open(f)))
+        durs = collections.defaultdict(list)
+        meta = {}
+        for r in rows:
+            name = r["Kernel_Name"]
+            if "locate_kernel" in name or "pack_kernel" in name:
+                durs[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                meta[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
+        fh.write("== kernel_trace reduced\n")
+        for name, d in durs.items():
+            fh.write("%s\n  launches=%d avg_ns=%.0f min_ns=%d max_ns=%d %s\n" % (name, len(d), sum(d) / len(d), min(d), max(d), meta[name]))
+    for f in find("pmc_*/**/*counter_collection.csv"):
+        rows = list(csv.DictReader(open(f)))
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in rows:
+            if "locate_kernel" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        fh.write("== pmc %s\n" % f)
+        for name, cs in acc.items():
+            fh.write("%s\n" % name)
+            for c, v in cs.items():
+                fh.write("  %s: launches=%d avg=%.1f\n" % (c, len(v), sum(v) / len(v)))
+PY
+# drop the bulky raw files
+find $OUT -name "*.csv" -size +200k -delete
+find $OUT -name "*.csv" | grep -v -e kernel_stats -e domain_stats | xargs rm -f
+cat $OUT/summary.txt | head -80
+du -sh $OUT
