@@ -21,6 +21,23 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
+INSERT_MAX_ADAPTER = 64
+INSERT_MAX_READ = 256
+
+
+class InsertConfig(C.Structure):
+    """atr_insert_config (include/atropos_hip.h)."""
+    _fields_ = [
+        ("adapter1", C.c_char_p), ("alen1", C.c_int),
+        ("adapter2", C.c_char_p), ("alen2", C.c_int),
+        ("insert_max_rmp", C.c_double), ("adapter_max_rmp", C.c_double),
+        ("min_insert_overlap", C.c_int), ("max_insert_mismatch_frac", C.c_double),
+        ("min_adapter_overlap", C.c_int), ("max_adapter_mismatch_frac", C.c_double),
+        ("adapter_check_cutoff", C.c_int),
+        ("adapter_wildcards", C.c_int), ("read_wildcards", C.c_int),
+        ("rmp_insert", C.c_void_p), ("rmp_adapter", C.c_void_p), ("rmp_ld", C.c_int),
+        ("max_mismatch_by_alen", C.c_void_p), ("n_mismatch", C.c_int),
+    ]
 
 # prototypes of every symbol include/atropos_hip.h declares
 PROTOTYPES = {
@@ -30,7 +47,17 @@ PROTOTYPES = {
     "atr_translate_table": (C.c_int, [C.c_int, C.c_char_p]),
     "atr_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "atr_pack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
-                                 C.c_void_p, C.c_void_p]),
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_multi_locate_work_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "atr_multi_locate_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                         C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_int, C.c_void_p]),
+    "atr_compare_batch": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_insert_aligner_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "atr_insert_aligner_destroy": (None, [C.c_void_p]),
+    "atr_insert_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                         C.c_int, C.c_void_p, C.c_void_p]),
     "atr_aligner_create": (C.c_int, [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.POINTER(C.c_void_p)]),
     "atr_aligner_destroy": (None, [C.c_void_p]),
@@ -107,17 +134,66 @@ class HipBackend(object):
     def packed_bytes(self, nreads, max_len):
         return self.lib.atr_packed_bytes(nreads, max_len)
 
-    def pack_reads(self, ascii_2d, lens, max_len, table):
+    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False):
         """ascii_2d: uint8 [nreads, >=max_len] on self.device (row stride arbitrary);
-        lens: int32 [nreads] or None; table: 256 bytes.  Returns the packed uint8 tensor."""
+        lens: int32 [nreads] or None; table: 256 bytes.  Returns the packed uint8 tensor
+        (and, with count_invalid, the number of reads holding a byte the table maps to 0)."""
         nreads = ascii_2d.shape[0]
         packed = self.empty((max(self.packed_bytes(nreads, max_len), 16),), torch.uint8)
+        invalid = torch.zeros((1,), dtype=torch.int32, device=self.device) if count_invalid else None
         if nreads and max_len:
             with torch.cuda.device(self.device):
                 _check(self.lib, self.lib.atr_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads,
-                                                         max_len, table, _ptr(packed), self._stream()),
-                       "atr_pack_reads")
-        return packed
+                                                         max_len, table, _ptr(packed), _ptr(invalid),
+                                                         self._stream()), "atr_pack_reads")
+        return (packed, int(invalid.item())) if count_invalid else packed
+
+    def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,
+                           max_ref_len, out_stride):
+        """refs/queries: uint8 [npairs, width] raw ASCII on the device; returns
+        (records int16 [npairs, out_stride, 8], counts int32 [npairs])."""
+        npairs = refs.shape[0]
+        out = self.empty((npairs, out_stride, 8), torch.int16)
+        counts = self.empty((npairs,), torch.int32)
+        work = self.empty((max(self.lib.atr_multi_locate_work_bytes(npairs, max_ref_len), 4),), torch.uint8)
+        if npairs:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_multi_locate_batch(
+                    _ptr(refs), refs.stride(0), _ptr(ref_lens), _ptr(queries), queries.stride(0), _ptr(query_lens),
+                    npairs, e, flags, min_overlap, max_matches, max_ref_len, _ptr(work), _ptr(out), _ptr(counts),
+                    out_stride, self._stream()), "atr_multi_locate_batch")
+        return out, counts
+
+    def compare_batch(self, ref, queries, lens, max_len, wildcard_ref, wildcard_query, suffix):
+        """ref: bytes; queries: uint8 [n, width] raw ASCII on the device."""
+        n = queries.shape[0]
+        out = self.empty((n, 8), torch.int16)
+        if n:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_compare_batch(ref, len(ref), _ptr(queries), queries.stride(0), _ptr(lens),
+                                                            n, max_len, int(wildcard_ref), int(wildcard_query),
+                                                            int(suffix), _ptr(out), self._stream()),
+                       "atr_compare_batch")
+        return out
+
+    def insert_aligner_create(self, cfg):
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_insert_aligner_create(C.addressof(cfg), C.byref(h)),
+                   "atr_insert_aligner_create")
+        return h
+
+    def insert_aligner_destroy(self, h):
+        self.lib.atr_insert_aligner_destroy(h)
+
+    def insert_match_batch(self, h, packed1, lens1, packed2, lens2, npairs, max_len):
+        out = self.empty((npairs, 3, 8), torch.int16)
+        if npairs:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_insert_match_batch(h, _ptr(packed1), _ptr(lens1), _ptr(packed2),
+                                                                 _ptr(lens2), npairs, max_len, _ptr(out),
+                                                                 self._stream()), "atr_insert_match_batch")
+        return out
 
     def aligner_create(self, ref, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
         h = C.c_void_p()

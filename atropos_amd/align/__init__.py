@@ -10,11 +10,15 @@ constants.  Every per-read call is a batch of one on the GPU (there is no CPU
 implementation behind this module); the batched twins (``Aligner.locate_batch`` ...)
 are the ones to use for throughput.
 """
+import ctypes as _C
 from collections import namedtuple
 
+import numpy as np
+import torch
+
 from .. import _lib
-from ..batch import ReadBatch, LocateResult
-from ..util import RandomMatchProbability, reverse_complement
+from ..batch import ReadBatch, LocateResult, _as_ascii_matrix
+from ..util import RandomMatchProbability, reverse_complement, rmp_table, BASE_COMPLEMENTS
 
 # flags for global alignment (reference align/__init__.py:17-26)
 START_WITHIN_SEQ1 = 1
@@ -189,6 +193,93 @@ def locate(reference, query, max_error_rate, flags=SEMIGLOBAL, wildcard_ref=Fals
     return aligner.locate(query)
 
 
+def _ascii_tensor(strings, backend):
+    """list of str -> (uint8 tensor [n, width] on the backend's device, int32 lens tensor)."""
+    mat, lens = _as_ascii_matrix(strings)
+    return (torch.from_numpy(mat).to(backend.device), torch.from_numpy(lens).to(backend.device))
+
+
+def compare_prefixes(ref, query, wildcard_ref=False, wildcard_query=False):
+    """Find out whether one string is the prefix of the other one, allowing IUPAC
+    wildcards in ref and/or query if the appropriate flag is set; returns a tuple
+    compatible with ``Aligner.locate`` (reference: _align.pyx:501-544)."""
+    return _compare(ref, query, wildcard_ref, wildcard_query, False)
+
+
+def compare_suffixes(suffix_ref, suffix_query, wildcard_ref=False, wildcard_query=False):
+    """Suffix twin of compare_prefixes, used for anchored 3' adapters without indels
+    (reference: align/__init__.py:28-44)."""
+    return _compare(suffix_ref, suffix_query, wildcard_ref, wildcard_query, True)
+
+
+def _compare(ref, query, wildcard_ref, wildcard_query, suffix):
+    rec = compare_batch(ref, [query], wildcard_ref, wildcard_query, suffix).cpu().numpy()[0]
+    return tuple(int(v) for v in rec[:6])
+
+
+def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix=False, lens=None):
+    """compare_prefixes (or compare_suffixes) of one reference against a batch of
+    queries: list of str, or a uint8 [n, width] ASCII tensor (+ optional int32 ``lens``).
+    Returns the int16 [n, 8] record tensor on the device."""
+    be = _lib.get_backend()
+    ref_b = ref.encode('ascii')
+    if len(ref_b) > 1024:
+        raise _lib.AtroposHipError("compare_prefixes: references longer than 1024 are outside the device envelope")
+    if isinstance(queries, (list, tuple)):
+        for q in queries:
+            q.encode('ascii')
+        q_t, lens = _ascii_tensor(queries, be)
+    else:
+        q_t = queries.to(be.device)
+        lens = None if lens is None else lens.to(device=be.device, dtype=torch.int32)
+    return be.compare_batch(ref_b, q_t, lens, q_t.shape[1], wildcard_ref, wildcard_query, suffix)
+
+
+class MultiAligner(object):
+    """Same as Aligner, but 1) returns up to ``max_matches`` matches rather than a single
+    best match, and 2) does not allow indels or wildcards (reference: cdef class
+    MultiAligner, _align.pyx:548-787)."""
+
+    def __init__(self, max_error_rate, flags=SEMIGLOBAL, min_overlap=1):
+        self.max_error_rate = float(max_error_rate)
+        self.flags = int(flags)
+        self._min_overlap = int(min_overlap)
+
+    def __reduce__(self):
+        return (MultiAligner, (self.max_error_rate, self.flags, self._min_overlap))
+
+    def locate_batch(self, references, queries, max_matches=100):
+        """One (reference, query) pair per entry; returns a list with, per pair, None or
+        the list of 6-tuples ``locate`` returns."""
+        be = _lib.get_backend()
+        if len(references) != len(queries):
+            raise ValueError("need as many references as queries")
+        if len(references) == 0:
+            return []
+        for s_ in references:
+            s_.encode('ascii')
+        for s_ in queries:
+            s_.encode('ascii')
+        r_t, r_l = _ascii_tensor(references, be)
+        q_t, q_l = _ascii_tensor(queries, be)
+        max_m = int(r_l.max().item())
+        stride = max_matches + max_m + 2          # the last-column scan appends past max_matches (:750-763)
+        out, counts = be.multi_locate_batch(r_t, r_l, q_t, q_l, self.max_error_rate, self.flags, self._min_overlap,
+                                            max_matches, max_m, stride)
+        out = out.cpu().numpy()
+        counts = counts.cpu().numpy()
+        res = []
+        for p in range(len(references)):
+            c = int(counts[p])
+            res.append(None if c == 0 else [tuple(int(v) for v in out[p, t, :6]) for t in range(c)])
+        return res
+
+    def locate(self, reference, query, max_matches=100):
+        """locate(reference, query) -> list of (refstart, refstop, querystart, querystop,
+        matches, errors), or None."""
+        return self.locate_batch([reference], [query], max_matches)[0]
+
+
 # Common match-result object returned by aligners (reference align/__init__.py:51-175)
 
 class Match(object):
@@ -270,3 +361,202 @@ class Match(object):
 MatchInfo = namedtuple("MatchInfo", (
     "read_name", "errors", "rstart", "rstop", "seq_before", "seq_adapter", "seq_after", "adapter_name",
     "qual_before", "qual_adapter", "qual_after", "is_front", "asize", "rsize_adapter", "rsize_total"))
+
+
+class InsertResult(object):
+    """Result records of a batched ``match_insert``: int16 tensor [npairs, 3, 8] on the
+    device -- per pair the insert match tuple, Match 1 and Match 2 (see
+    include/atropos_hip.h, atr_insert_match_batch)."""
+
+    def __init__(self, records):
+        self.records = records
+
+    def __len__(self):
+        return self.records.shape[0]
+
+    def numpy(self):
+        return self.records.cpu().numpy()
+
+    def found(self):
+        return self.records[:, 0, 1] >= 0
+
+    def results(self):
+        """What per-pair ``match_insert`` calls return: None or (insert_match_tuple,
+        Match | None, Match | None)."""
+        out = []
+        for rec in self.numpy():
+            if rec[0, 1] < 0:
+                out.append(None)
+                continue
+            ins = tuple(int(v) for v in rec[0, :6])
+            ms = [None if rec[t, 1] < 0 else Match(*(int(v) for v in rec[t, :6])) for t in (1, 2)]
+            out.append((ins, ms[0], ms[1]))
+        return out
+
+
+class InsertAligner(object):
+    """Insert matching: align read 1 to the reverse complement of read 2; if the inserts
+    overlap, look for the adapters in the overhangs (reference: InsertAligner,
+    align/__init__.py:178-377).  Only works with paired-end reads with 3' adapters.
+
+    Args (same as the reference): adapter1, adapter2, match_probability
+    (``callable(matches, size, **base_probs)``), insert_max_rmp, adapter_max_rmp,
+    min_insert_overlap, max_insert_mismatch_frac, min_adapter_overlap,
+    max_adapter_mismatch_frac, adapter_check_cutoff, base_probs, adapter_wildcards,
+    read_wildcards.
+
+    Device envelope: adapters up to 64 bases, reads up to 256 bases, read 2 upper-case
+    (every base needs a complement anyway -- ``KeyError`` as in the reference; lower-case
+    complements are the one thing the 4-bit device alphabet does not carry).
+    """
+
+    def __init__(self, adapter1, adapter2, match_probability=None, insert_max_rmp=1E-6, adapter_max_rmp=0.001,
+                 min_insert_overlap=1, max_insert_mismatch_frac=0.2, min_adapter_overlap=1,
+                 max_adapter_mismatch_frac=0.2, adapter_check_cutoff=9, base_probs=None, adapter_wildcards=True,
+                 read_wildcards=False):
+        self._backend = _lib.get_backend()
+        self._handle = None
+        self.adapter1 = adapter1
+        self.adapter1_len = len(adapter1)
+        self.adapter2 = adapter2
+        self.adapter2_len = len(adapter2)
+        self.match_probability = match_probability if match_probability is not None else _default_rmp()
+        self.insert_max_rmp = insert_max_rmp
+        self.adapter_max_rmp = adapter_max_rmp
+        self.min_insert_overlap = min_insert_overlap
+        self.max_insert_mismatch_frac = float(max_insert_mismatch_frac)
+        self.min_adapter_overlap = min_adapter_overlap
+        self.max_adapter_mismatch_frac = float(max_adapter_mismatch_frac)
+        self.adapter_check_cutoff = adapter_check_cutoff
+        self.base_probs = base_probs or dict(match_prob=0.25, mismatch_prob=0.75)
+        self.adapter_wildcards = adapter_wildcards
+        self.read_wildcards = read_wildcards
+        self.aligner = MultiAligner(max_insert_mismatch_frac, START_WITHIN_SEQ1 | STOP_WITHIN_SEQ2, min_insert_overlap)
+        self._build()
+
+    def _build(self):
+        a1, a2 = self.adapter1.encode('ascii'), self.adapter2.encode('ascii')
+        if max(len(a1), len(a2)) > _lib.INSERT_MAX_ADAPTER:
+            raise _lib.AtroposHipError("InsertAligner: adapters longer than %d bases are outside the device "
+                                       "envelope" % _lib.INSERT_MAX_ADAPTER)
+        if not (self.adapter_wildcards or self.read_wildcards):
+            valid = set("ACGTRYSWKMBDHVN")
+            if not (set(self.adapter1) <= valid and set(self.adapter2) <= valid):
+                raise _lib.AtroposHipError("InsertAligner without wildcard matching needs upper-case IUPAC adapters")
+        ld = _lib.INSERT_MAX_READ + 1
+        # host-side tables, evaluated with the reference's Python semantics
+        self._rmp_insert = np.ascontiguousarray(rmp_table(self.match_probability, ld - 1, **self.base_probs))
+        if self.base_probs == dict(match_prob=0.25, mismatch_prob=0.75):
+            self._rmp_adapter = self._rmp_insert                      # match_probability(m, n) uses the defaults
+        else:
+            self._rmp_adapter = np.ascontiguousarray(rmp_table(self.match_probability, ld - 1))
+        self._mm = np.array([round(a * self.max_adapter_mismatch_frac) for a in range(_lib.INSERT_MAX_ADAPTER + 1)],
+                            dtype=np.int32)                          # align/__init__.py:290
+        cfg = _lib.InsertConfig()
+        cfg.adapter1, cfg.alen1 = a1, len(a1)
+        cfg.adapter2, cfg.alen2 = a2, len(a2)
+        cfg.insert_max_rmp, cfg.adapter_max_rmp = float(self.insert_max_rmp), float(self.adapter_max_rmp)
+        cfg.min_insert_overlap = int(self.min_insert_overlap)
+        cfg.max_insert_mismatch_frac = self.max_insert_mismatch_frac
+        cfg.min_adapter_overlap = int(self.min_adapter_overlap)
+        cfg.max_adapter_mismatch_frac = self.max_adapter_mismatch_frac
+        cfg.adapter_check_cutoff = int(self.adapter_check_cutoff)
+        cfg.adapter_wildcards, cfg.read_wildcards = int(bool(self.adapter_wildcards)), int(bool(self.read_wildcards))
+        cfg.rmp_insert = self._rmp_insert.ctypes.data
+        cfg.rmp_adapter = self._rmp_adapter.ctypes.data
+        cfg.rmp_ld = ld
+        cfg.max_mismatch_by_alen = self._mm.ctypes.data
+        cfg.n_mismatch = len(self._mm)
+        self._cfg = cfg
+        self._handle = self._backend.insert_aligner_create(cfg)
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._backend.insert_aligner_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def pack(self, reads, check=False):
+        """Pack one side of the pairs (DNA15 table).  With ``check`` (read 2) every base
+        must be an upper-case IUPAC letter."""
+        if isinstance(reads, ReadBatch):
+            if reads.table_kind != _lib.TABLE_DNA15:
+                raise ValueError("the insert aligner needs reads packed with the DNA15 table")
+            return reads
+        be = self._backend
+        table = be.translate_table(_lib.TABLE_DNA15)
+        if isinstance(reads, (list, tuple)):
+            mat, lens = _as_ascii_matrix(reads)
+            ascii_t, lens_t = torch.from_numpy(mat).to(be.device), torch.from_numpy(lens).to(be.device)
+            max_len = int(lens.max()) if len(reads) else 0
+        else:
+            ascii_t = reads.to(be.device)
+            lens_t, max_len = None, ascii_t.shape[1]
+        if max_len > _lib.INSERT_MAX_READ:
+            raise _lib.AtroposHipError("InsertAligner: reads longer than %d bases are outside the device envelope"
+                                       % _lib.INSERT_MAX_READ)
+        if check:
+            packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True)
+            if bad:
+                raise ValueError("%d read(s) contain bases without an upper-case IUPAC code; the device insert "
+                                 "aligner cannot reverse-complement them" % bad)
+        else:
+            packed = be.pack_reads(ascii_t, lens_t, max_len, table)
+        return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_DNA15, table)
+
+    def match_insert_batch(self, reads1, reads2):
+        """Batched ``match_insert``; reads1/reads2: ReadBatch (DNA15), list of str, or
+        uint8 [n, width] ASCII tensors of equal-length reads."""
+        b1 = self.pack(reads1)
+        b2 = self.pack(reads2, check=True)
+        if b1.nreads != b2.nreads:
+            raise ValueError("need as many first reads as second reads")
+        max_len = max(b1.max_len, b2.max_len)
+        if b1.max_len != b2.max_len:
+            raise ValueError("both read batches must be packed with the same max_len (got %d and %d)"
+                             % (b1.max_len, b2.max_len))
+        rec = self._backend.insert_match_batch(self._handle, b1.packed, b1.lens, b2.packed, b2.lens, b1.nreads, max_len)
+        return InsertResult(rec)
+
+    def match_insert(self, seq1, seq2):
+        """Use the insert overlap to find the adapters of one pair.
+
+        Returns None if the inserts do not match, else ``(insert_match, Match1, Match2)``
+        where the Matches are None when the overhang is too short for an adapter match
+        (reference: align/__init__.py:250-377)."""
+        n = min(len(seq1), len(seq2))
+        seq1.encode('ascii')
+        for base in reversed(seq2[:n]):           # reverse_complement(seq2): KeyError on unknown bases
+            BASE_COMPLEMENTS[base]
+        if seq2[:n] != seq2[:n].upper():
+            raise ValueError("lower-case bases in read 2 are not supported by the device insert aligner")
+        if max(len(seq1), len(seq2)) > _lib.INSERT_MAX_READ:
+            raise _lib.AtroposHipError("InsertAligner: reads longer than %d bases are outside the device envelope"
+                                       % _lib.INSERT_MAX_READ)
+        be = self._backend
+        table = be.translate_table(_lib.TABLE_DNA15)
+        width = max(len(seq1), len(seq2), 1)
+        mat = np.zeros((2, width), dtype=np.uint8)
+        mat[0, :len(seq1)] = np.frombuffer(seq1.encode('ascii'), dtype=np.uint8)
+        mat[1, :len(seq2)] = np.frombuffer(seq2.encode('ascii'), dtype=np.uint8)
+        t = torch.from_numpy(mat).to(be.device)
+        l1 = torch.tensor([len(seq1)], dtype=torch.int32, device=be.device)
+        l2 = torch.tensor([len(seq2)], dtype=torch.int32, device=be.device)
+        p1 = be.pack_reads(t[0:1], l1, width, table)
+        p2 = be.pack_reads(t[1:2], l2, width, table)
+        rec = be.insert_match_batch(self._handle, p1, l1, p2, l2, 1, width)
+        return InsertResult(rec).results()[0]
+
+
+_DEFAULT_RMP = None
+
+
+def _default_rmp():
+    """The shared default ``RandomMatchProbability()`` (the reference evaluates its default
+    argument once at import, align/__init__.py:208)."""
+    global _DEFAULT_RMP
+    if _DEFAULT_RMP is None:
+        _DEFAULT_RMP = RandomMatchProbability()
+    return _DEFAULT_RMP

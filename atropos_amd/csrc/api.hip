@@ -6,8 +6,19 @@
 #include "atropos_hip.h"
 #include "aligner_host.hpp"
 #include "locate_kernel.hpp"
+#include "insert_host.hpp"
 
 namespace atr {
+
+int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
+                  const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st);
+
+int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
+                 long long q_stride, const int32_t *q_lens, long long npairs, double e, int flags, int min_overlap,
+                 int max_matches, int *work, int16_t *out, int32_t *counts, int out_stride, hipStream_t st);
+int launch_compare(const uint8_t *ref, int m, const uint8_t *queries, long long q_stride, const int32_t *q_lens,
+                   long long n, int max_len, int wildcard_ref, int wildcard_query, int suffix, int16_t *out,
+                   hipStream_t st);
 
 locate_launcher locate_group_0(int), locate_group_1(int), locate_group_2(int), locate_group_3(int),
     locate_group_4(int), locate_group_5(int), locate_group_6(int), locate_group_7(int);
@@ -27,7 +38,7 @@ struct PackTable { uint8_t t[256]; };
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, long long row_stride,
                                                    const int32_t *__restrict__ lens, long long nreads,
                                                    int max_len, int nchunks, const PackTable tab,
-                                                   uint4 *__restrict__ packed) {
+                                                   uint4 *__restrict__ packed, int32_t *__restrict__ invalid) {
     __shared__ uint8_t s_tab[256];
     s_tab[threadIdx.x] = tab.t[threadIdx.x];
     __syncthreads();
@@ -39,14 +50,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     const int n = (r < nreads) ? min(lens ? lens[r] : max_len, max_len) : 0;
     const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride;
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
+    bool zero_seen = false;
     for (int c = 0; c < nchunks; ++c) {
         uint4 v;
-        v.x = pack_word(row, c * 32, n, s_tab);
-        v.y = pack_word(row, c * 32 + 8, n, s_tab);
-        v.z = pack_word(row, c * 32 + 16, n, s_tab);
-        v.w = pack_word(row, c * 32 + 24, n, s_tab);
+        v.x = pack_word(row, c * 32, n, s_tab, zero_seen);
+        v.y = pack_word(row, c * 32 + 8, n, s_tab, zero_seen);
+        v.z = pack_word(row, c * 32 + 16, n, s_tab, zero_seen);
+        v.w = pack_word(row, c * 32 + 24, n, s_tab, zero_seen);
         dst[(size_t)c * 64] = v;
     }
+    if (invalid && zero_seen) atomicAdd(invalid, 1);           // one atomic per wave after hipcc's coalescing
 }
 
 }  // namespace atr
@@ -81,7 +94,8 @@ int atr_translate_table(int kind, uint8_t table[256]) {
 size_t atr_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
 
 int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, int64_t nreads,
-                   int max_len, const uint8_t table[256], uint8_t *d_packed, void *stream) {
+                   int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
+                   void *stream) {
     if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
     if (nreads == 0 || max_len == 0) return ATR_OK;
     if (!d_ascii || !d_packed) return ATR_ERR_INVALID;
@@ -91,7 +105,7 @@ int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_
     const long long ntiles = (nreads + 63) / 64;
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        d_ascii, (long long)row_stride, d_lens, (long long)nreads, max_len, nchunks, tab,
-                       (uint4 *)d_packed);
+                       (uint4 *)d_packed, d_invalid);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ATR_OK : hip_fail(e, "pack_kernel launch");
 }
@@ -129,6 +143,79 @@ int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_
     const int rc = fn(a, (const uint4 *)d_packed, d_lens, nreads, nchunks, max_len, (uint4 *)d_out,
                       (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_kernel launch");
+}
+
+int atr_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner **out) {
+    if (!out) return ATR_ERR_INVALID;
+    *out = nullptr;
+    atr_insert_aligner *h = new (std::nothrow) atr_insert_aligner();
+    if (!h) return ATR_ERR_NOMEM;
+    h->d_tables = nullptr;
+    int rc = insert_fill(h, cfg);
+    if (rc != ATR_OK) { delete h; return rc; }
+    const size_t bytes = h->rmp_insert.size() * sizeof(double);
+    hipError_t e = hipMalloc(&h->d_tables, 2 * bytes);
+    if (e != hipSuccess) { delete h; return e == hipErrorOutOfMemory ? ATR_ERR_NOMEM : hip_fail(e, "hipMalloc(rmp tables)"); }
+    e = hipMemcpy(h->d_tables, h->rmp_insert.data(), bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy((char *)h->d_tables + bytes, h->rmp_adapter.data(), bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(h->d_tables); delete h; return hip_fail(e, "hipMemcpy(rmp tables)"); }
+    h->p.rmp_insert = (const double *)h->d_tables;
+    h->p.rmp_adapter = (const double *)((char *)h->d_tables + bytes);
+    *out = h;
+    return ATR_OK;
+}
+
+void atr_insert_aligner_destroy(atr_insert_aligner *a) {
+    if (!a) return;
+    if (a->d_tables) (void)hipFree(a->d_tables);
+    delete a;
+}
+
+int atr_insert_match_batch(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
+                           const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
+                           atr_result *d_out, void *stream) {
+    if (!a || npairs < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (max_len > ATR_INSERT_MAX_READ) return ATR_ERR_UNSUPPORTED;
+    if (npairs == 0) return ATR_OK;
+    if (!d_out || (max_len > 0 && (!d_packed1 || !d_packed2))) return ATR_ERR_INVALID;
+    const int nchunks = (max_len + 31) / 32;
+    const int rc = launch_insert(a, (const uint4 *)d_packed1, d_lens1, (const uint4 *)d_packed2, d_lens2,
+                                 npairs, nchunks, max_len, (uint4 *)d_out, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "insert_kernel launch");
+}
+
+size_t atr_multi_locate_work_bytes(int64_t npairs, int max_ref_len) {
+    if (npairs < 0 || max_ref_len < 0) return 0;
+    return (size_t)npairs * 3 * ((size_t)max_ref_len + 1) * sizeof(int32_t);
+}
+
+int atr_multi_locate_batch(const uint8_t *d_refs, int64_t ref_stride, const int32_t *d_ref_lens,
+                           const uint8_t *d_queries, int64_t query_stride, const int32_t *d_query_lens,
+                           int64_t npairs, double max_error_rate, int flags, int min_overlap, int max_matches,
+                           int max_ref_len, void *d_work, atr_result *d_out, int32_t *d_counts, int out_stride,
+                           void *stream) {
+    if (npairs < 0 || flags < 0 || flags > 15 || max_matches < 1 || out_stride < 1 || max_ref_len < 0)
+        return ATR_ERR_INVALID;
+    if (max_ref_len > 20000) return ATR_ERR_UNSUPPORTED;           // int16 coordinates / overhang costs
+    if (npairs == 0) return ATR_OK;
+    if (!d_refs || !d_ref_lens || !d_queries || !d_query_lens || !d_work || !d_out || !d_counts) return ATR_ERR_INVALID;
+    const int rc = launch_multi(d_refs, ref_stride, d_ref_lens, d_queries, query_stride, d_query_lens, npairs,
+                                max_error_rate, flags, min_overlap, max_matches, (int *)d_work, (int16_t *)d_out,
+                                d_counts, out_stride, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "multi_locate_kernel launch");
+}
+
+int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t query_stride,
+                      const int32_t *d_lens, int64_t n, int max_len, int wildcard_ref, int wildcard_query,
+                      int suffix, atr_result *d_out, void *stream) {
+    if (!ref || m < 0 || n < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (m > 1024 || max_len > 32000) return ATR_ERR_UNSUPPORTED;
+    if (n == 0) return ATR_OK;
+    if (!d_out || (!d_queries && max_len > 0)) return ATR_ERR_INVALID;
+    const int rc = launch_compare((const uint8_t *)ref, m, d_queries, query_stride, d_lens, n, max_len, wildcard_ref,
+                                  wildcard_query, suffix, (int16_t *)d_out, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "compare_kernel launch");
 }
 
 }  // extern "C"

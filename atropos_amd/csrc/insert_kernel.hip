@@ -1,0 +1,78 @@
+// insert_kernel.hip -- gfx950 kernel around insert_core.hpp: one read pair per lane,
+// 64 pairs per wavefront.  Each lane loads both packed reads completely (2*D dwords,
+// D = 4*nchunks, coalesced 1 KiB bursts per chunk), then runs the overlap sweep; the
+// only other global traffic is the occasional double-precision table lookup for a hit
+// (L2 resident, 2 x 528 KB) and three coalesced 16-byte result stores.
+#include <hip/hip_runtime.h>
+#include "insert_host.hpp"
+
+namespace atr {
+
+static __device__ __forceinline__ int wave_max_i32_ins(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, const uint4 *__restrict__ packed1,
+                                                     const int32_t *__restrict__ lens1,
+                                                     const uint4 *__restrict__ packed2,
+                                                     const int32_t *__restrict__ lens2, long long npairs,
+                                                     int max_len, uint4 *__restrict__ out) {
+    constexpr int D = 4 * NCH;
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ntiles = (npairs + 63) >> 6;
+    if (tile >= ntiles) return;
+    const long long r = tile * 64 + lane;
+    const bool live = r < npairs;
+    const int len1 = live ? (lens1 ? lens1[r] : max_len) : 0;
+    const int len2 = live ? (lens2 ? lens2[r] : max_len) : 0;
+
+    PairState<D> P;
+    pair_init<D>(P, ip, len1, len2);
+    const uint4 *t1 = packed1 + (size_t)tile * NCH * 64 + lane;
+    const uint4 *t2 = packed2 + (size_t)tile * NCH * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const uint4 a = t1[(size_t)c * 64], b = t2[(size_t)c * 64];
+        P.s1[4 * c] = a.x; P.s1[4 * c + 1] = a.y; P.s1[4 * c + 2] = a.z; P.s1[4 * c + 3] = a.w;
+        P.s2[4 * c] = b.x; P.s2[4 * c + 1] = b.y; P.s2[4 * c + 2] = b.z; P.s2[4 * c + 3] = b.w;
+    }
+    const int jmax = wave_max_i32_ins(P.L);
+    InsertSweep<D, 0>::run(P, ip, jmax);
+    if (live) {
+        uint32_t rec[12];
+        pair_result<D>(P, ip, rec);
+        uint4 *o = out + 3 * r;
+        o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
+        o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
+    }
+}
+
+template <int NCH>
+static int launch_nch(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
+                      const int32_t *l2, long long npairs, int max_len, uint4 *out, hipStream_t st) {
+    const long long ntiles = (npairs + 63) / 64;
+    hipLaunchKernelGGL((insert_kernel<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
+                       p2, l2, npairs, max_len, out);
+    return (int)hipGetLastError();
+}
+
+int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
+                  const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st) {
+    switch (nchunks) {
+        case 0: case 1: return launch_nch<1>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 2: return launch_nch<2>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 3: return launch_nch<3>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 4: return launch_nch<4>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 5: return launch_nch<5>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 6: return launch_nch<6>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 7: return launch_nch<7>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        default: return launch_nch<8>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+    }
+}
+
+}  // namespace atr

@@ -237,14 +237,18 @@ ATR_DEV void lane_result(const LaneState<MT> &L, const Uniform &u, uint32_t rec[
 
 // ---- tile64 packing arithmetic (shared by the pack kernel and the emulation) -------
 
-// One 32-bit word = 8 bases, base b in bits 4b..4b+3.
-ATR_DEV uint32_t pack_word(const uint8_t *row, int j0, int n, const uint8_t *table) {
+// One 32-bit word = 8 bases, base b in bits 4b..4b+3.  `zero_seen` is set when a base
+// inside the read translates to code 0.
+ATR_DEV uint32_t pack_word(const uint8_t *row, int j0, int n, const uint8_t *table, bool &zero_seen) {
     uint32_t w = 0;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
         const int j = j0 + b;
-        const uint32_t code = (j < n) ? (uint32_t)table[row[j]] : 0u;
-        w |= (code & 15u) << (4 * b);
+        if (j < n) {
+            const uint32_t code = (uint32_t)table[row[j]] & 15u;
+            zero_seen = zero_seen || code == 0;
+            w |= code << (4 * b);
+        }
     }
     return w;
 }

@@ -1,0 +1,68 @@
+// misc_kernels.hip -- gfx950 kernels around misc_core.hpp (general MultiAligner.locate,
+// compare_prefixes/compare_suffixes), one pair per thread.
+#include <hip/hip_runtime.h>
+#include "aligner_host.hpp"
+#include "misc_core.hpp"
+
+namespace atr {
+
+__global__ __launch_bounds__(256) void multi_locate_kernel(const uint8_t *__restrict__ refs, long long ref_stride,
+                                                           const int32_t *__restrict__ ref_lens,
+                                                           const uint8_t *__restrict__ queries, long long q_stride,
+                                                           const int32_t *__restrict__ q_lens, long long npairs,
+                                                           double e, int flags, int min_overlap, int max_matches,
+                                                           int *__restrict__ work, int16_t *__restrict__ out,
+                                                           int32_t *__restrict__ counts, int out_stride) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npairs) return;
+    // column scratch is interleaved across pairs (element i of pair p at work[i*npairs + p]):
+    // the threads of a wave touch consecutive words
+    counts[p] = multi_locate_one(refs + p * ref_stride, ref_lens[p], queries + p * q_stride, q_lens[p], e, flags,
+                                 min_overlap, max_matches, work + p, npairs, out + (size_t)p * out_stride * 8,
+                                 out_stride);
+}
+
+struct CompareRef { uint8_t r[1024]; uint8_t tr[256]; uint8_t tq[256]; };
+
+__global__ __launch_bounds__(256) void compare_kernel(const CompareRef cr, int m, const uint8_t *__restrict__ queries,
+                                                      long long q_stride, const int32_t *__restrict__ q_lens,
+                                                      long long n, int max_len, int use_tables, int suffix,
+                                                      int16_t *__restrict__ out) {
+    __shared__ uint8_t s_ref[1024], s_tr[256], s_tq[256];
+    for (int i = threadIdx.x; i < 1024; i += 256) s_ref[i] = cr.r[i];
+    s_tr[threadIdx.x] = cr.tr[threadIdx.x];
+    s_tq[threadIdx.x] = cr.tq[threadIdx.x];
+    __syncthreads();
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    compare_one(s_ref, m, queries + p * q_stride, q_lens ? q_lens[p] : max_len, use_tables ? s_tr : nullptr,
+                use_tables ? s_tq : nullptr, suffix != 0, out + p * 8);
+}
+
+int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
+                 long long q_stride, const int32_t *q_lens, long long npairs, double e, int flags, int min_overlap,
+                 int max_matches, int *work, int16_t *out, int32_t *counts, int out_stride, hipStream_t st) {
+    hipLaunchKernelGGL(multi_locate_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, refs, ref_stride,
+                       ref_lens, queries, q_stride, q_lens, npairs, e, flags, min_overlap, max_matches, work, out,
+                       counts, out_stride);
+    return (int)hipGetLastError();
+}
+
+int launch_compare(const uint8_t *ref, int m, const uint8_t *queries, long long q_stride, const int32_t *q_lens,
+                   long long n, int max_len, int wildcard_ref, int wildcard_query, int suffix, int16_t *out,
+                   hipStream_t st) {
+    CompareRef cr;
+    memset(&cr, 0, sizeof(cr));
+    memcpy(cr.r, ref, (size_t)m);
+    const Tables &T = tables();
+    const int use_tables = (wildcard_ref || wildcard_query) ? 1 : 0;
+    if (use_tables) {                                                  // _align.pyx:521-530
+        memcpy(cr.tr, wildcard_ref ? T.iupac : T.acgt, 256);
+        memcpy(cr.tq, wildcard_query ? T.iupac : T.acgt, 256);
+    }
+    hipLaunchKernelGGL(compare_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, cr, m, queries, q_stride,
+                       q_lens, n, max_len, use_tables, suffix, out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace atr

@@ -79,3 +79,41 @@ class RandomMatchProbability(object):
             idx = next_i
             next_i += 1
         self.max_n = idx
+
+
+def rmp_table(match_probability, max_size, **probs):
+    """``table[size, matches] = match_probability(matches, size, **probs)`` for
+    ``0 <= matches <= size <= max_size`` as a float64 array (entries above the diagonal
+    are 0) -- the table the device insert aligner looks probabilities up in.
+
+    For a ``RandomMatchProbability`` the sums are evaluated for all ``matches`` of one
+    ``size`` at once with numpy, in the same left-to-right order as ``__call__`` (term_k
+    + term_k+1 + ...), so every entry is bit-identical to the per-call value; any other
+    callable is simply called entry by entry."""
+    import numpy as np
+    ld = max_size + 1
+    table = np.zeros((ld, ld), dtype=np.float64)
+    if not isinstance(match_probability, RandomMatchProbability):
+        for size in range(ld):
+            for k in range(size + 1):
+                table[size, k] = match_probability(k, size, **probs)
+        return table
+    match_prob = probs.get("match_prob", 0.25)
+    mismatch_prob = probs.get("mismatch_prob", 0.75)
+    fac = match_probability.factorial
+    for size in range(ld):
+        nfac = fac(size)
+        terms = np.empty(size + 1, dtype=np.float64)
+        for i in range(size + 1):
+            j = size - i
+            try:
+                div = nfac / fac(i) / fac(j)
+            except OverflowError:
+                div = nfac // fac(i) // fac(j)
+            terms[i] = (mismatch_prob ** j) * (match_prob ** i) * div
+        acc = 0.0 + terms
+        for d in range(1, size + 1):
+            acc[:size + 1 - d] += terms[d:]
+        acc[size] = match_prob ** size
+        table[size, :size + 1] = acc
+    return table

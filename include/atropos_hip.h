@@ -86,10 +86,13 @@ size_t atr_packed_bytes(int64_t nreads, int max_len);
 
 /* ASCII -> 4-bit tile64.  `table` is a HOST pointer to the 256-entry translate
  * table (the reference does bytes.translate(table) per read: _align.pyx:243-248,
- * :292-297).  d_lens may be NULL (all reads max_len long). */
+ * :292-297).  d_lens may be NULL (all reads max_len long).  d_invalid may be NULL;
+ * otherwise *d_invalid (device int32, zeroed by the caller) is incremented once per
+ * read that contains a byte the table maps to 0 -- the insert aligner needs every base
+ * to have a complement (reverse_complement raises KeyError, util/__init__.py:479-482). */
 int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
                    int64_t nreads, int max_len, const uint8_t table[256],
-                   uint8_t *d_packed, void *stream);
+                   uint8_t *d_packed, int32_t *d_invalid, void *stream);
 
 /* ---- Aligner (atropos/align/_align.pyx:121-494) -------------------------- */
 
@@ -117,6 +120,68 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]);
  * with. */
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                      int64_t nreads, int max_len, atr_result *d_out, void *stream);
+
+/* ---- InsertAligner (atropos/align/__init__.py:178-377) -------------------- */
+
+#define ATR_INSERT_MAX_ADAPTER  64   /* adapter length handled by the insert kernel */
+#define ATR_INSERT_MAX_READ    256   /* read length handled by the insert kernel */
+
+/* InsertAligner.__init__ arguments (align/__init__.py:206-233) plus the host-built
+ * tables.  All pointers are HOST pointers; the library copies what it needs.
+ *   rmp_insert[size*rmp_ld + matches]  = match_probability(matches, size, **base_probs)  (:359)
+ *   rmp_adapter[size*rmp_ld + matches] = match_probability(matches, size)                (:303-304)
+ *   max_mismatch_by_alen[a]            = round(a * max_adapter_mismatch_frac)            (:290)
+ * computed by the caller with Python's float/bigint/round semantics (rmp_ld >= 257,
+ * n_mismatch >= 65). */
+typedef struct {
+    const char *adapter1; int alen1;
+    const char *adapter2; int alen2;
+    double insert_max_rmp, adapter_max_rmp;
+    int min_insert_overlap; double max_insert_mismatch_frac;
+    int min_adapter_overlap; double max_adapter_mismatch_frac;
+    int adapter_check_cutoff;
+    int adapter_wildcards, read_wildcards;
+    const double *rmp_insert; const double *rmp_adapter; int rmp_ld;
+    const int32_t *max_mismatch_by_alen; int n_mismatch;
+} atr_insert_config;
+
+/* Allocates two small device tables on the current device (freed by _destroy).
+ * ATR_ERR_UNSUPPORTED: an adapter longer than ATR_INSERT_MAX_ADAPTER. */
+int atr_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner **out);
+void atr_insert_aligner_destroy(atr_insert_aligner *a);
+
+/* InsertAligner.match_insert(seq1, seq2) for a batch (align/__init__.py:250-377).
+ * Both read sets are tile64 buffers packed with ATR_TABLE_DNA15 and the same max_len
+ * (<= ATR_INSERT_MAX_READ).  d_out receives THREE records per pair:
+ *   d_out[3p+0] = the insert match tuple (refstop == -1: match_insert returns None),
+ *   d_out[3p+1] = Match 1 as (astart, astop, rstart, rstop, matches, errors), astop == -1: None,
+ *   d_out[3p+2] = Match 2, likewise. */
+int atr_insert_match_batch(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
+                           const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
+                           atr_result *d_out, void *stream);
+
+/* ---- MultiAligner.locate, compare_prefixes / compare_suffixes (general) --- */
+
+/* MultiAligner(max_error_rate, flags, min_overlap).locate(reference, query, max_matches)
+ * (_align.pyx:548-787) for npairs independent pairs of raw ASCII strings (row-major,
+ * refs at d_refs + p*ref_stride with length d_ref_lens[p], likewise the queries).
+ * d_out holds out_stride records per pair; d_counts[p] receives the number of hits the
+ * reference returns (0 == None; hits beyond out_stride are counted but not stored).
+ * d_work: caller scratch of atr_multi_locate_work_bytes(npairs, max_ref_len) bytes. */
+size_t atr_multi_locate_work_bytes(int64_t npairs, int max_ref_len);
+int atr_multi_locate_batch(const uint8_t *d_refs, int64_t ref_stride, const int32_t *d_ref_lens,
+                           const uint8_t *d_queries, int64_t query_stride, const int32_t *d_query_lens,
+                           int64_t npairs, double max_error_rate, int flags, int min_overlap, int max_matches,
+                           int max_ref_len, void *d_work, atr_result *d_out, int32_t *d_counts, int out_stride,
+                           void *stream);
+
+/* compare_prefixes(ref, query, wildcard_ref, wildcard_query) (_align.pyx:501-544), or
+ * compare_suffixes (align/__init__.py:28-44) when suffix != 0, of ONE reference (host
+ * pointer, m <= 1024 raw ASCII bytes) against n queries (device, raw ASCII).  d_lens may
+ * be NULL (all queries max_len long). */
+int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t query_stride,
+                      const int32_t *d_lens, int64_t n, int max_len, int wildcard_ref, int wildcard_query,
+                      int suffix, atr_result *d_out, void *stream);
 
 #ifdef __cplusplus
 }

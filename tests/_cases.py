@@ -82,3 +82,104 @@ def check_batches_against_oracle(Aligner, oracle, unsupported_exc, seed, rounds,
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1
     return total
+
+
+def norm_insert(res):
+    """(tuple, Match|None, Match|None) | None -> the JSON shape of the golden files."""
+    if res is None:
+        return None
+
+    def f(m):
+        return None if m is None else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+    return [list(res[0]), f(res[1]), f(res[2])]
+
+
+def check_golden_insert(InsertAligner):
+    kats = load_golden("kats.json")["match_insert"]
+    cases = kats + load_golden("insert_fuzz.json.gz")
+    cache = {}
+    for c in cases:
+        key = (c["a1"], c["a2"], repr(sorted(c["kw"].items())))
+        if key not in cache:
+            cache[key] = InsertAligner(c["a1"], c["a2"], **c["kw"])
+        assert norm_insert(cache[key].match_insert(c["r1"], c["r2"])) == c["out"], c
+    # the same cases again as batches (one per configuration, ragged lengths; a dummy
+    # full-width pair pins both sides to one layout width)
+    by_cfg = {}
+    for c in cases:
+        by_cfg.setdefault((c["a1"], c["a2"], repr(sorted(c["kw"].items()))), []).append(c)
+    for key, cs in by_cfg.items():
+        width = max(max(len(c["r1"]), len(c["r2"])) for c in cs)
+        ia = cache[key]
+        b1 = ia.pack([c["r1"] for c in cs] + ["A" * width])
+        b2 = ia.pack([c["r2"] for c in cs] + ["A" * width], check=True)
+        res = ia.match_insert_batch(b1, b2).results()[:-1]
+        assert [norm_insert(r) for r in res] == [c["out"] for c in cs]
+    return len(cases)
+
+
+def check_golden_multi_compare(align):
+    kats = load_golden("kats.json")
+    n = 0
+    for c in kats["multi_locate"] + load_golden("multi_fuzz.json.gz"):
+        got = align.MultiAligner(c["e"], c["flags"], c["mo"]).locate(c["ref"], c["query"], c["mx"])
+        assert got == (None if c["out"] is None else [tup(x) for x in c["out"]]), c
+        n += 1
+    for c in load_golden("prefix_fuzz.json.gz"):
+        assert align.compare_prefixes(c["ref"], c["query"], c["wr"], c["wq"]) == tup(c["prefix"]), c
+        assert align.compare_suffixes(c["ref"], c["query"], c["wr"], c["wq"]) == tup(c["suffix"]), c
+        n += 1
+    for c in kats["compare_prefixes"]:
+        assert align.compare_prefixes(c["ref"], c["query"], c["wr"], c["wq"]) == tup(c["out"]), c
+    for c in kats["compare_suffixes"]:
+        assert align.compare_suffixes(c["ref"], c["query"], c["wr"], c["wq"]) == tup(c["out"]), c
+    return n
+
+
+def check_insert_batches_against_oracle(InsertAligner, oracle, seed, rounds):
+    """Random insert-aligner settings, batches of synthetic pairs (with and without a
+    true overlap, ragged lengths), every result against the oracle."""
+    from atropos_amd import synth
+    from atropos_amd.util import reverse_complement
+    rng = random.Random(seed)
+    cfgs = [dict(), dict(max_insert_mismatch_frac=0.1, max_adapter_mismatch_frac=0.1), dict(read_wildcards=True),
+            dict(adapter_wildcards=False), dict(adapter_wildcards=False, read_wildcards=True),
+            dict(min_insert_overlap=5, min_adapter_overlap=3), dict(insert_max_rmp=1e-3, adapter_max_rmp=1e-2),
+            dict(adapter_check_cutoff=3), dict(base_probs=dict(match_prob=0.33, mismatch_prob=0.67))]
+    total = 0
+    for it in range(rounds):
+        cfg = cfgs[it % len(cfgs)]
+        a1, a2 = synth.PE_ADAPTER1, synth.PE_ADAPTER2
+        if it % 2 and cfg.get("adapter_wildcards", True):
+            a1 = a1[:20].replace("G", "N", 1)
+        ia = InsertAligner(a1, a2, **cfg)
+        orc = oracle.InsertOracle(a1, a2, **cfg)
+        n = rng.choice([20, 50, 100, 150, 250])
+        r1s, r2s = [], []
+        for _ in range(rng.choice([1, 64, 65, 130])):
+            f = rng.randint(0, int(1.6 * n))
+            F = rseq(rng, f)
+            r1 = (F + a1.replace("N", "A") + rseq(rng, n))[:rng.choice([n, n, n, n - 3])]
+            r2 = (reverse_complement(F) + a2 + rseq(rng, n))[:rng.choice([n, n, n - 1])]
+            p = rng.choice([0, 0.01, 0.03, 0.1])
+            r1 = "".join((rng.choice("ACGTN") if rng.random() < p else c) for c in r1)
+            r2 = "".join((rng.choice("ACGTN") if rng.random() < p else c) for c in r2)
+            if rng.random() < 0.1:
+                r1 = rseq(rng, n)
+            if rng.random() < 0.05:
+                r1 = "A" * len(r1)
+                r2 = "T" * len(r2)          # low complexity: many hits
+            r1s.append(r1)
+            r2s.append(r2)
+        # pad both sides to one layout width
+        width = max(max(len(x) for x in r1s), max(len(x) for x in r2s))
+        b1 = ia.pack(r1s + ["A" * width])
+        b2 = ia.pack(r2s + ["A" * width], check=True)
+        got = ia.match_insert_batch(b1, b2).results()[:-1]
+        for x, y, g in zip(r1s, r2s, got):
+            exp = orc.match_insert(x, y)
+            exp = None if exp is None else [list(exp[0]), None if exp[1] is None else list(exp[1]),
+                                            None if exp[2] is None else list(exp[2])]
+            assert norm_insert(g) == exp, (cfg, x, y, norm_insert(g), exp)
+            total += 1
+    return total

@@ -12,8 +12,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "libemu_locate.so")
-_SRCS = [os.path.join(_HERE, "emu_locate.cpp")] + [
-    os.path.join(_ROOT, "atropos_amd", "csrc", f) for f in ("locate_core.hpp", "aligner_host.hpp")] + [
+_CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "emu_misc.cpp")]
+_SRCS = _CPPS + [
+    os.path.join(_ROOT, "atropos_amd", "csrc", f)
+    for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -22,7 +24,7 @@ def build():
         subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DATR_HOST_EMU",
                                "-I" + os.path.join(_ROOT, "include"),
                                "-I" + os.path.join(_ROOT, "atropos_amd", "csrc"),
-                               _SRCS[0], "-o", _SO])
+                               ] + _CPPS + ["-o", _SO])
     return _SO
 
 
@@ -56,7 +58,20 @@ class EmuBackend(object):
         L.emu_aligner_query_table.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_packed_bytes.argtypes = [C.c_int64, C.c_int]
         L.emu_packed_bytes.restype = C.c_size_t
-        L.emu_pack_reads.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p]
+        L.emu_pack_reads.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p,
+                                     C.c_void_p]
+        L.emu_multi_locate_work_bytes.argtypes = [C.c_int64, C.c_int]
+        L.emu_multi_locate_work_bytes.restype = C.c_size_t
+        L.emu_multi_locate_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int]
+        L.emu_compare_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.emu_insert_aligner_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.emu_insert_aligner_destroy.argtypes = [C.c_void_p]
+        L.emu_insert_aligner_destroy.restype = None
+        L.emu_insert_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                             C.c_int, C.c_void_p]
         L.emu_locate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         self.device = torch.device("cpu")
         from atropos_amd import _lib
@@ -79,13 +94,51 @@ class EmuBackend(object):
     def packed_bytes(self, nreads, max_len):
         return self.lib.emu_packed_bytes(nreads, max_len)
 
-    def pack_reads(self, ascii_2d, lens, max_len, table):
+    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False):
         nreads = ascii_2d.shape[0]
         packed = torch.zeros((max(self.packed_bytes(nreads, max_len), 16),), dtype=torch.uint8)
+        invalid = torch.zeros((1,), dtype=torch.int32) if count_invalid else None
         if nreads and max_len:
             _check(self.lib.emu_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads, max_len, table,
-                                           _ptr(packed)), "emu_pack_reads")
-        return packed
+                                           _ptr(packed), _ptr(invalid)), "emu_pack_reads")
+        return (packed, int(invalid.item())) if count_invalid else packed
+
+    def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,
+                           max_ref_len, out_stride):
+        npairs = refs.shape[0]
+        out = torch.zeros((npairs, out_stride, 8), dtype=torch.int16)
+        counts = torch.zeros((npairs,), dtype=torch.int32)
+        work = torch.zeros((max(self.lib.emu_multi_locate_work_bytes(npairs, max_ref_len), 4),), dtype=torch.uint8)
+        if npairs:
+            _check(self.lib.emu_multi_locate_batch(_ptr(refs), refs.stride(0), _ptr(ref_lens), _ptr(queries),
+                                                   queries.stride(0), _ptr(query_lens), npairs, e, flags, min_overlap,
+                                                   max_matches, max_ref_len, _ptr(work), _ptr(out), _ptr(counts),
+                                                   out_stride), "atr_multi_locate_batch")
+        return out, counts
+
+    def compare_batch(self, ref, queries, lens, max_len, wildcard_ref, wildcard_query, suffix):
+        n = queries.shape[0]
+        out = torch.zeros((n, 8), dtype=torch.int16)
+        if n:
+            _check(self.lib.emu_compare_batch(ref, len(ref), _ptr(queries), queries.stride(0), _ptr(lens), n, max_len,
+                                              int(wildcard_ref), int(wildcard_query), int(suffix), _ptr(out)),
+                   "atr_compare_batch")
+        return out
+
+    def insert_aligner_create(self, cfg):
+        h = C.c_void_p()
+        _check(self.lib.emu_insert_aligner_create(C.addressof(cfg), C.byref(h)), "atr_insert_aligner_create")
+        return h
+
+    def insert_aligner_destroy(self, h):
+        self.lib.emu_insert_aligner_destroy(h)
+
+    def insert_match_batch(self, h, packed1, lens1, packed2, lens2, npairs, max_len):
+        out = torch.zeros((npairs, 3, 8), dtype=torch.int16)
+        if npairs:
+            _check(self.lib.emu_insert_match_batch(h, _ptr(packed1), _ptr(lens1), _ptr(packed2), _ptr(lens2), npairs,
+                                                   max_len, _ptr(out)), "atr_insert_match_batch")
+        return out
 
     def aligner_create(self, ref, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
         h = C.c_void_p()

@@ -1,0 +1,82 @@
+// emu_insert.cpp -- TEST INFRASTRUCTURE.  CPU emulation of the gfx950 insert-match
+// kernel (atropos_amd/csrc/insert_kernel.hip) from the same per-lane source
+// (insert_core.hpp, -DATR_HOST_EMU) and the same host parameter builder
+// (insert_host.hpp).  Lanes are independent in this kernel, so each pair is simply run
+// through the block sweep with jmax = the tile's maximum overlap length, as on the GPU.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "insert_host.hpp"
+
+using namespace atr;
+
+namespace {
+
+template <int NCH>
+void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int32_t *l1, const uint32_t *p2,
+                      const int32_t *l2, long long npairs, int max_len, uint32_t *out) {
+    constexpr int D = 4 * NCH;
+    const long long ntiles = (npairs + 63) / 64;
+    for (long long tile = 0; tile < ntiles; ++tile) {
+        int jmax = 0;
+        for (int lane = 0; lane < 64; ++lane) {
+            const long long r = tile * 64 + lane;
+            if (r < npairs) jmax = std::max(jmax, std::min(l1 ? l1[r] : max_len, l2 ? l2[r] : max_len));
+        }
+        for (int lane = 0; lane < 64; ++lane) {
+            const long long r = tile * 64 + lane;
+            if (r >= npairs) continue;
+            PairState<D> P;
+            pair_init<D>(P, a->p, l1 ? l1[r] : max_len, l2 ? l2[r] : max_len);
+            for (int c = 0; c < NCH; ++c)
+                for (int d = 0; d < 4; ++d) {
+                    P.s1[4 * c + d] = p1[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
+                    P.s2[4 * c + d] = p2[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
+                }
+            InsertSweep<D, 0>::run(P, a->p, jmax);
+            pair_result<D>(P, a->p, out + 12 * r);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int emu_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner **out) {
+    *out = nullptr;
+    atr_insert_aligner *h = new atr_insert_aligner();
+    h->d_tables = nullptr;
+    int rc = insert_fill(h, cfg);
+    if (rc != ATR_OK) { delete h; return rc; }
+    h->p.rmp_insert = h->rmp_insert.data();
+    h->p.rmp_adapter = h->rmp_adapter.data();
+    *out = h;
+    return ATR_OK;
+}
+
+void emu_insert_aligner_destroy(atr_insert_aligner *a) { delete a; }
+
+int emu_insert_match_batch(const atr_insert_aligner *a, const uint8_t *p1, const int32_t *l1, const uint8_t *p2,
+                           const int32_t *l2, int64_t npairs, int max_len, int16_t *out) {
+    if (!a || npairs < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (max_len > ATR_INSERT_MAX_READ) return ATR_ERR_UNSUPPORTED;
+    if (npairs == 0) return ATR_OK;
+    const uint32_t *a1 = (const uint32_t *)p1, *a2 = (const uint32_t *)p2;
+    uint32_t *o = (uint32_t *)out;
+    switch ((max_len + 31) / 32) {
+        case 0: case 1: emu_insert_tiles<1>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 2: emu_insert_tiles<2>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 3: emu_insert_tiles<3>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 4: emu_insert_tiles<4>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 5: emu_insert_tiles<5>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 6: emu_insert_tiles<6>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 7: emu_insert_tiles<7>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        default: emu_insert_tiles<8>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+    }
+    return ATR_OK;
+}
+
+}  // extern "C"

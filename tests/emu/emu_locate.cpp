@@ -96,7 +96,7 @@ int emu_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
 size_t emu_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
 
 int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens, int64_t nreads, int max_len,
-                   const uint8_t table[256], uint8_t *packed) {
+                   const uint8_t table[256], uint8_t *packed, int32_t *invalid) {
     const int nchunks = (max_len + 31) / 32;
     const long long ntiles = (nreads + 63) / 64;
     uint32_t *dst = (uint32_t *)packed;
@@ -105,9 +105,12 @@ int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens
             const long long r = tile * 64 + lane;
             const int n = (r < nreads) ? std::min(lens ? lens[r] : max_len, max_len) : 0;
             const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride;
+            bool zero_seen = false;
             for (int c = 0; c < nchunks; ++c)
                 for (int d = 0; d < 4; ++d)
-                    dst[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] = pack_word(row, c * 32 + d * 8, n, table);
+                    dst[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] =
+                        pack_word(row, c * 32 + d * 8, n, table, zero_seen);
+            if (invalid && zero_seen) *invalid += 1;
         }
     return ATR_OK;
 }

@@ -1,0 +1,44 @@
+// emu_misc.cpp -- TEST INFRASTRUCTURE.  CPU run of the per-thread code of
+// atropos_amd/csrc/misc_kernels.hip (misc_core.hpp, -DATR_HOST_EMU).
+#include <cstdint>
+#include <cstring>
+
+#include "aligner_host.hpp"
+#include "misc_core.hpp"
+
+using namespace atr;
+
+extern "C" {
+
+size_t emu_multi_locate_work_bytes(int64_t npairs, int max_ref_len) {
+    return (size_t)npairs * 3 * ((size_t)max_ref_len + 1) * sizeof(int32_t);
+}
+
+int emu_multi_locate_batch(const uint8_t *refs, int64_t ref_stride, const int32_t *ref_lens, const uint8_t *queries,
+                           int64_t q_stride, const int32_t *q_lens, int64_t npairs, double e, int flags,
+                           int min_overlap, int max_matches, int max_ref_len, void *work, int16_t *out,
+                           int32_t *counts, int out_stride) {
+    if (npairs < 0 || flags < 0 || flags > 15 || max_matches < 1 || out_stride < 1) return ATR_ERR_INVALID;
+    (void)max_ref_len;
+    for (int64_t p = 0; p < npairs; ++p)
+        counts[p] = multi_locate_one(refs + p * ref_stride, ref_lens[p], queries + p * q_stride, q_lens[p], e, flags,
+                                     min_overlap, max_matches, (int *)work + p, npairs,
+                                     out + (size_t)p * out_stride * 8, out_stride);
+    return ATR_OK;
+}
+
+int emu_compare_batch(const char *ref, int m, const uint8_t *queries, int64_t q_stride, const int32_t *lens,
+                      int64_t n, int max_len, int wildcard_ref, int wildcard_query, int suffix, int16_t *out) {
+    if (!ref || m < 0 || n < 0) return ATR_ERR_INVALID;
+    if (m > 1024) return ATR_ERR_UNSUPPORTED;
+    const Tables &T = tables();
+    const bool use = wildcard_ref || wildcard_query;
+    const uint8_t *tr = use ? (wildcard_ref ? T.iupac : T.acgt) : nullptr;
+    const uint8_t *tq = use ? (wildcard_query ? T.iupac : T.acgt) : nullptr;
+    for (int64_t p = 0; p < n; ++p)
+        compare_one((const uint8_t *)ref, m, queries + p * q_stride, lens ? lens[p] : max_len, tr, tq, suffix != 0,
+                    out + p * 8);
+    return ATR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+"""CPU check (lock-step emulation, same per-lane source as the GPU build) of the insert
+aligner kernel, the general MultiAligner kernel and compare_prefixes/suffixes."""
+from . import _cases
+from .conftest import load_golden
+
+
+def test_golden_insert(emu_backend):
+    from atropos_amd.align import InsertAligner
+    assert _cases.check_golden_insert(InsertAligner) > 2000
+
+
+def test_golden_multi_and_compare(emu_backend):
+    from atropos_amd import align
+    assert _cases.check_golden_multi_compare(align) > 3000
+
+
+def test_insert_batches(emu_backend, oracle):
+    from atropos_amd.align import InsertAligner
+    assert _cases.check_insert_batches_against_oracle(InsertAligner, oracle, 5, 27) > 1000
+
+
+def test_synthetic_heads_c3_c5(emu_backend):
+    from atropos_amd import synth
+    from atropos_amd.align import InsertAligner
+    heads = load_golden("synth_heads.json.gz")
+    for name in ("C3", "C5"):
+        w = synth.workload(name, 0, heads[name]["count"])
+        ia = InsertAligner(w["adapter1"], w["adapter2"], **heads[name]["kw"])
+        res = ia.match_insert_batch(w["reads1"], w["reads2"]).results()
+        assert [_cases.norm_insert(r) for r in res] == heads[name]["out"]
+        assert sum(r is not None for r in res) > heads[name]["count"] // 4
+
+
+def test_insert_errors(emu_backend):
+    import pytest
+    from atropos_amd import _lib
+    from atropos_amd.align import InsertAligner
+    ia = InsertAligner("TTAGACATATGG", "CAGTGGAGTATA")
+    with pytest.raises(KeyError):
+        ia.match_insert("ACGTACGT", "ACGTXCGT")          # no complement for X (reference: KeyError)
+    with pytest.raises(ValueError):
+        ia.match_insert("ACGTACGT", "acgtacgt")          # lower-case read 2: outside the device alphabet
+    with pytest.raises(ValueError):
+        ia.match_insert_batch(["ACGT"], ["ACXT"])
+    with pytest.raises(_lib.AtroposHipError):
+        InsertAligner("A" * 65, "ACGT")
+    assert ia.match_insert("", "") is None
+    assert ia.match_insert("ACGT", "") is None
