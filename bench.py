@@ -27,13 +27,26 @@ ALGO_BYTES_PER_READ = 75 + 16      # ceil(150/2) packed-nibble bytes in + 16-byt
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity capped by the
+    cgroup CPU quota (the GPU boxes expose 256 logical CPUs but grant a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(workload, sample_reads):
     """The oracle ("port" of the reference's Cython loop: same one-column DP with the
     Ukkonen cut-off, -O2) timed on this box's host cores, all of them, on a bounded
     sample of the same workload: the sample is aligned repeatedly until about 8 s of
     wall time (so thread start-up does not dominate on a many-core host)."""
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     lens = np.full(len(sample_reads), sample_reads.shape[1], np.int32)
     args = (workload["max_error_rate"], 14, False, False, workload["min_overlap"], workload["indel_cost"], cores)
     O.locate_many(workload["adapter"], sample_reads[:4096], lens[:4096], *args)
