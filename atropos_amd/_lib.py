@@ -54,6 +54,9 @@ PROTOTYPES = {
                                          C.c_void_p, C.c_int, C.c_void_p]),
     "atr_compare_batch": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_correct_errors_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_insert_aligner_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "atr_insert_aligner_destroy": (None, [C.c_void_p]),
     "atr_insert_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -175,6 +178,23 @@ class HipBackend(object):
                                                             int(suffix), _ptr(out), self._stream()),
                        "atr_compare_batch")
         return out
+
+    def correct_errors_batch(self, seq1, qual1, lens1, seq2, qual2, lens2, insert, mask, action, min_qual_diff,
+                             truncate, comp):
+        """In-place error correction of the overlaps (uint8 [n, width] ASCII tensors on
+        the device, same row stride); returns (changed int32 [n, 2], newlen int32 [n, 2])."""
+        n = seq1.shape[0]
+        changed = self.empty((n, 2), torch.int32)
+        newlen = self.empty((n, 2), torch.int32)
+        if n:
+            if seq1.stride(0) != seq2.stride(0):
+                raise ValueError("both reads need the same row stride")
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_correct_errors_batch(
+                    _ptr(seq1), _ptr(qual1), _ptr(lens1), _ptr(seq2), _ptr(qual2), _ptr(lens2), seq1.stride(0),
+                    _ptr(insert), _ptr(mask), n, seq1.shape[1], action, min_qual_diff, int(truncate), comp,
+                    _ptr(changed), _ptr(newlen), self._stream()), "atr_correct_errors_batch")
+        return changed, newlen
 
     def insert_aligner_create(self, cfg):
         h = C.c_void_p()

@@ -1,0 +1,490 @@
+# coding: utf-8
+"""Adapters: the boundary objects that call the aligner (reference
+atropos/adapters/__init__.py: ADAPTER_TYPES :41-73, AdapterParser :80-229, Adapter
+:231-505, LinkedMatch/LinkedAdapter :612-745, parse_braces :933-970).
+
+Same classes, arguments and behaviour; ``match_to`` keeps its per-read form and gains a
+batched twin (``match_to_batch``) that sends the whole batch through the GPU kernels in
+one call and applies the reference's post-filters to the result records.
+ColorspaceAdapter and AdapterCache are out of scope.
+"""
+import itertools
+import re
+from collections import defaultdict
+
+import numpy as np
+
+from . import align
+from .align import Match
+from .util import IUPAC_BASES, GC_BASES, rmp_table
+
+START_WITHIN_SEQ1, START_WITHIN_SEQ2 = align.START_WITHIN_SEQ1, align.START_WITHIN_SEQ2
+STOP_WITHIN_SEQ1, STOP_WITHIN_SEQ2 = align.STOP_WITHIN_SEQ1, align.STOP_WITHIN_SEQ2
+
+
+class AdapterType(object):
+    """Adapter type name, description and alignment flags."""
+
+    def __init__(self, name, desc, *flags):
+        self.name = name
+        self.desc = desc
+        self.flags = flags[0]
+        for flag in flags[1:]:
+            self.flags |= flag
+
+    def asdict(self):
+        return dict(name=self.name, desc=self.desc, flags=self.flags)
+
+
+ADAPTER_TYPES = dict(
+    back=AdapterType('back', "regular 3'", START_WITHIN_SEQ2, STOP_WITHIN_SEQ2, STOP_WITHIN_SEQ1),
+    front=AdapterType('front', "regular 5'", START_WITHIN_SEQ2, STOP_WITHIN_SEQ2, START_WITHIN_SEQ1),
+    prefix=AdapterType('prefix', "anchored 5'", STOP_WITHIN_SEQ2),
+    suffix=AdapterType('suffix', "anchored 3'", START_WITHIN_SEQ2),
+    anywhere=AdapterType('anywhere', "variable 5'/3'", align.SEMIGLOBAL),
+    linked=AdapterType('linked', 'linked', 'linked'))
+
+BACK = ADAPTER_TYPES['back'].flags              # 14
+FRONT = ADAPTER_TYPES['front'].flags            # 11
+PREFIX = ADAPTER_TYPES['prefix'].flags          # 8
+SUFFIX = ADAPTER_TYPES['suffix'].flags          # 2
+ANYWHERE = ADAPTER_TYPES['anywhere'].flags      # 15
+LINKED = ADAPTER_TYPES['linked'].flags
+
+
+def where_int_to_dict(where):
+    for adapter_type in ADAPTER_TYPES.values():
+        if where == adapter_type.flags:
+            return adapter_type.asdict()
+    raise ValueError("Invalid WHERE value: {}".format(where))
+
+
+ADAPTER_ID_GENERATOR = itertools.count(1)
+
+
+def _generate_adapter_name():
+    return str(next(ADAPTER_ID_GENERATOR))
+
+
+def parse_braces(sequence):
+    """Replace all occurrences of ``x{n}`` (x any character) with n occurrences of x;
+    ``ValueError`` if the expression cannot be parsed.  ``TGA{5}CT`` -> ``TGAAAAACT``."""
+    result = ''
+    state = None            # None | a plain token | '{' | repeat count (int)
+    for token in re.split(r'(\{|\})', sequence):
+        if token == '':
+            continue
+        if state is None:
+            if token == '{':
+                raise ValueError('"{" must be used after a character')
+            if token == '}':
+                raise ValueError('"}" cannot be used here')
+            state = token
+            result += token
+        elif state == '{':
+            state = int(token)
+            if not 0 <= state <= 10000:
+                raise ValueError('Value {} invalid'.format(state))
+        elif isinstance(state, int):
+            if token != '}':
+                raise ValueError('"}" expected')
+            result = result[:-1] + result[-1] * state
+            state = None
+        else:
+            if token != '{':
+                raise ValueError('Expected "{"')
+            state = '{'
+    if isinstance(state, int) or state == '{':
+        raise ValueError("Unterminated expression")
+    return result
+
+
+def _extract_name_from_spec(spec):
+    fields = spec.split('=', 1)
+    name = None
+    if len(fields) > 1:
+        name, spec = fields
+        name = name.strip()
+    return name, spec.strip()
+
+
+def _seq_of(read):
+    return read if isinstance(read, str) else read.sequence
+
+
+class Adapter(object):
+    """An adapter knows how to match itself to a read: where it may sit within the read
+    and how wildcard characters are interpreted.
+
+    Args (as in the reference): sequence (upper-cased, U -> T, ``x{n}`` expanded), where
+    (BACK, FRONT, PREFIX, SUFFIX or ANYWHERE), max_error_rate, min_overlap,
+    read_wildcards, adapter_wildcards, name, indels, indel_cost, match_probability
+    (``callable(matches, size)``), max_rmp, gc_content.
+    """
+
+    def __init__(self, sequence, where, max_error_rate=0.1, min_overlap=3, read_wildcards=False,
+                 adapter_wildcards=True, name=None, indels=True, indel_cost=1, match_probability=None, max_rmp=None,
+                 gc_content=0.5, alphabet=None):
+        if len(sequence) == 0:
+            raise ValueError("Empty adapter sequence")
+        sequence = parse_braces(sequence.upper().replace('U', 'T'))
+        seq_set = set(sequence)
+        if seq_set <= set('ACGT'):
+            adapter_wildcards = False
+        if adapter_wildcards and not seq_set <= IUPAC_BASES:
+            raise ValueError("Invalid character(s) in adapter sequence: {}".format(','.join(seq_set - IUPAC_BASES)))
+        if alphabet is not None:
+            for character in sequence:
+                if character not in alphabet:
+                    raise ValueError("Character {!r} is not in the alphabet".format(character))
+        self.debug = False
+        self.name = _generate_adapter_name() if name is None else name
+        self.sequence = sequence
+        self.where = where
+        self.max_error_rate = max_error_rate
+        self.min_overlap = min(min_overlap, len(self.sequence))
+        self.match_probability = match_probability
+        self.max_rmp = max_rmp
+        self.gc_content = gc_content
+        self.indels = indels
+        self.adapter_wildcards = adapter_wildcards
+        self.read_wildcards = read_wildcards
+        trimmers = {FRONT: self._trimmed_front, PREFIX: self._trimmed_front, BACK: self._trimmed_back,
+                    SUFFIX: self._trimmed_back, ANYWHERE: self._trimmed_anywhere}
+        self.trimmed = trimmers[where]
+        self._front_flag = None if where == ANYWHERE else where not in (BACK, SUFFIX)
+        # statistics about the removed sequences
+        self.lengths_front = defaultdict(int)
+        self.lengths_back = defaultdict(int)
+        self.errors_front = defaultdict(lambda: defaultdict(int))
+        self.errors_back = defaultdict(lambda: defaultdict(int))
+        self.adjacent_bases = {'A': 0, 'C': 0, 'G': 0, 'T': 0, '': 0}
+        self.aligner = align.Aligner(self.sequence, self.max_error_rate, flags=self.where,
+                                     wildcard_ref=self.adapter_wildcards, wildcard_query=self.read_wildcards)
+        self.aligner.min_overlap = self.min_overlap
+        # when indels are disallowed the aligner simply prices them out (:316-322)
+        self._indel_cost = indel_cost if self.indels else 100000
+        self.aligner.indel_cost = self._indel_cost
+        self._exact_aligner = None
+        self._rmp_cache = None
+
+    def __repr__(self):
+        return ('<Adapter(name="{name}", sequence="{sequence}", where={where}, max_error_rate={max_error_rate}, '
+                'min_overlap={min_overlap}, read_wildcards={read_wildcards}, '
+                'adapter_wildcards={adapter_wildcards}, indels={indels})>').format(**vars(self))
+
+    def enable_debug(self):
+        self.debug = True
+        self.aligner.enable_debug()
+
+    # ------------------------------------------------------------------ matching
+    def _exact_position(self, read_seq):
+        """The exact-match shortcut of match_to (:351-367): first literal occurrence."""
+        if self.where == PREFIX:
+            return 0 if read_seq.startswith(self.sequence) else -1
+        if self.where == SUFFIX:
+            return len(read_seq) - len(self.sequence) if read_seq.endswith(self.sequence) else -1
+        return read_seq.find(self.sequence)
+
+    def _accept(self, astart, astop, matches, errors):
+        """The post-filter of match_to (:386-398); note the DIVISION, not the DP's product."""
+        size = astop - astart
+        return ((size >= self.min_overlap and errors / size <= self.max_error_rate) and
+                (self.max_rmp is None or self.match_probability(matches, size) <= self.max_rmp))
+
+    def match_to(self, read):
+        """Attempt to match this adapter to the given read; returns a Match or None if
+        the criteria (minimum overlap, maximum error rate, random-match probability) are
+        not met."""
+        read_seq = read.sequence.upper()
+        # try to find an exact match first unless wildcards are allowed
+        if not self.adapter_wildcards:
+            pos = self._exact_position(read_seq)
+            if pos >= 0:
+                seqlen = len(self.sequence)
+                return Match(0, seqlen, pos, pos + seqlen, seqlen, 0, self._front_flag, self, read)
+        # approximate matching
+        if not self.indels and self.where in (PREFIX, SUFFIX):
+            compare = align.compare_prefixes if self.where == PREFIX else align.compare_suffixes
+            alignment = compare(self.sequence, read_seq, wildcard_ref=self.adapter_wildcards,
+                                wildcard_query=self.read_wildcards)
+        else:
+            alignment = self.aligner.locate(read_seq)
+        if alignment:
+            astart, astop, rstart, rstop, matches, errors = alignment
+            if self._accept(astart, astop, matches, errors):
+                return Match(astart, astop, rstart, rstop, matches, errors, self._front_flag, self, read)
+        return None
+
+    def _rmp_by_size(self):
+        if self._rmp_cache is None:
+            self._rmp_cache = rmp_table(self.match_probability, len(self.sequence))
+        return self._rmp_cache
+
+    def locate_records(self, reads_upper):
+        """Raw device step of the batched match: the alignment records (int16 [n, 8]
+        numpy) for already upper-cased reads (list of str or uint8 [n, width] tensor)
+        plus, when the literal exact-match shortcut cannot be read off those records, the
+        records of the literal search."""
+        if not self.indels and self.where in (PREFIX, SUFFIX):
+            rec = align.compare_batch(self.sequence, reads_upper, self.adapter_wildcards, self.read_wildcards,
+                                      suffix=(self.where == SUFFIX)).cpu().numpy()
+        else:
+            rec = self.aligner.locate_batch(reads_upper).numpy()
+        exact = None
+        if not self.adapter_wildcards and self.read_wildcards:
+            # with read wildcards the DP may prefer an earlier wildcard match over the first
+            # literal occurrence the shortcut returns: search literally as well
+            if self._exact_aligner is None:
+                self._exact_aligner = align.Aligner(self.sequence, 0.0, flags=self.where,
+                                                    min_overlap=len(self.sequence))
+            exact = self._exact_aligner.locate_batch(reads_upper).numpy()
+        return rec, exact
+
+    def match_to_batch(self, reads):
+        """Batched ``match_to``: one GPU call for the whole batch, then the reference's
+        shortcut/post-filter rules on the records.  ``reads``: list of read objects (or
+        plain str).  Returns a list of Match / None."""
+        seqs = [_seq_of(r).upper() for r in reads]
+        if not seqs:
+            return []
+        rec, exact = self.locate_records(seqs)
+        m = len(self.sequence)
+        rec = rec.astype(np.int64)
+        found = rec[:, 1] >= 0
+        astart, astop, matches, errors = rec[:, 0], rec[:, 1], rec[:, 4], rec[:, 5]
+        size = np.where(found, astop - astart, 1)
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ok = found & (size >= self.min_overlap) & (errors / size <= self.max_error_rate)
+        if self.max_rmp is not None:
+            table = self._rmp_by_size()
+            probs = table[np.clip(size, 0, m), np.clip(matches, 0, m)]
+            ok &= probs <= self.max_rmp
+        use_exact = np.zeros(len(seqs), dtype=bool)
+        if not self.adapter_wildcards:
+            if exact is None:
+                # literal compare mode: an exact full-length occurrence is what the DP returns
+                # for it (most matches, zero errors, leftmost); the shortcut bypasses the filters
+                if not self.indels and self.where in (PREFIX, SUFFIX):
+                    full = found & (matches == m) & (errors == 0) & (astop - astart == m)
+                else:
+                    full = found & (matches == m) & (errors == 0)
+                ok |= full
+            else:
+                use_exact = exact[:, 1] >= 0
+        out = []
+        for i, read in enumerate(reads):
+            if use_exact[i]:
+                row = exact[i]
+            elif ok[i]:
+                row = rec[i]
+            else:
+                out.append(None)
+                continue
+            out.append(Match(int(row[0]), int(row[1]), int(row[2]), int(row[3]), int(row[4]), int(row[5]),
+                             self._front_flag, self, None if isinstance(read, str) else read))
+        return out
+
+    # ------------------------------------------------------------------ trimming
+    def _trimmed_anywhere(self, match):
+        return self._trimmed_front(match) if match.front else self._trimmed_back(match)
+
+    def _trimmed_front(self, match):
+        self.lengths_front[match.rstop] += 1
+        self.errors_front[match.rstop][match.errors] += 1
+        return match.read[match.rstop:]
+
+    def _trimmed_back(self, match):
+        self.lengths_back[len(match.read) - match.rstart] += 1
+        self.errors_back[len(match.read) - match.rstart][match.errors] += 1
+        adjacent_base = match.read.sequence[match.rstart - 1:match.rstart]
+        if adjacent_base not in 'ACGT':
+            adjacent_base = ''
+        self.adjacent_bases[adjacent_base] += 1
+        return match.read[:match.rstart]
+
+    def __len__(self):
+        return len(self.sequence)
+
+    def random_match_probabilities(self):
+        """Probability that the first i bases of this adapter match a random sequence
+        (indels not taken into account), for i = 0..len."""
+        seq = self.sequence[::-1] if self._front_flag else self.sequence
+        base_probs = (self.gc_content / 2.0, (1 - self.gc_content) / 2.0)
+        probabilities = [1.0] + ([0] * len(seq))
+        c_bases = frozenset(GC_BASES if self.adapter_wildcards else 'GC')
+        cur_p = 1.0
+        for idx, base in enumerate(seq, 1):
+            cur_p *= base_probs[0 if base in c_bases else 1]
+            probabilities[idx] = cur_p
+        return probabilities
+
+    def summarize(self):
+        total_front = sum(self.lengths_front.values())
+        total_back = sum(self.lengths_back.values())
+        where = self.where
+        assert (where in (ANYWHERE, LINKED) or (where in (BACK, SUFFIX) and total_front == 0) or
+                (where in (FRONT, PREFIX) and total_back == 0))
+        stats = dict(adapter_class=self.__class__.__name__, total_front=total_front, total_back=total_back,
+                     total=total_front + total_back, match_probabilities=self.random_match_probabilities(),
+                     where=where_int_to_dict(where), sequence=self.sequence, max_error_rate=self.max_error_rate)
+        if where in (ANYWHERE, FRONT, PREFIX):
+            stats["lengths_front"] = dict(self.lengths_front)
+            stats["errors_front"] = {k: dict(v) for k, v in self.errors_front.items()}
+        if where in (ANYWHERE, BACK, SUFFIX):
+            stats["lengths_back"] = dict(self.lengths_back)
+            stats["errors_back"] = {k: dict(v) for k, v in self.errors_back.items()}
+        if where in (BACK, SUFFIX):
+            stats["adjacent_bases"] = dict(self.adjacent_bases)
+        return stats
+
+
+class LinkedMatch(object):
+    """A match of a LinkedAdapter: the front match and (possibly None) the back match."""
+
+    def __init__(self, front_match, back_match, adapter):
+        self.front_match = front_match
+        self.back_match = back_match
+        self.adapter = adapter
+        assert front_match is not None
+
+    def get_info_record(self):
+        if self.back_match:
+            return self.back_match.get_info_record()
+        return self.front_match.get_info_record()
+
+
+class LinkedAdapter(object):
+    """An adapter with linked front (anchored 5') and back (3') sequences; the back
+    adapter is only searched for when the front adapter was found, in the read with the
+    front match removed."""
+
+    def __init__(self, front_sequence, back_sequence, front_anchored=True, back_anchored=False, name=None, **kwargs):
+        assert front_anchored and not back_anchored
+        where1 = PREFIX if front_anchored else FRONT
+        where2 = SUFFIX if back_anchored else BACK
+        self.front_anchored = front_anchored
+        self.back_anchored = back_anchored
+        self.where = LINKED
+        self.name = _generate_adapter_name() if name is None else name
+        self.front_adapter = Adapter(front_sequence, where=where1, name=None, **kwargs)
+        self.back_adapter = Adapter(back_sequence, where=where2, name=None, **kwargs)
+
+    def enable_debug(self):
+        self.front_adapter.enable_debug()
+        self.back_adapter.enable_debug()
+
+    def match_to(self, read):
+        front_match = self.front_adapter.match_to(read)
+        if front_match is None:
+            return None
+        read = read[front_match.rstop:]
+        back_match = self.back_adapter.match_to(read)
+        return LinkedMatch(front_match, back_match, self)
+
+    def match_to_batch(self, reads):
+        """Batched ``match_to``: the front adapter over the whole batch, then the back
+        adapter over the remainders of the reads that had a front match."""
+        fronts = self.front_adapter.match_to_batch(reads)
+        idx = [i for i, fm in enumerate(fronts) if fm is not None]
+        rest = [reads[i][fronts[i].rstop:] for i in idx]
+        backs = self.back_adapter.match_to_batch(rest) if rest else []
+        out = [None] * len(reads)
+        for i, bm in zip(idx, backs):
+            out[i] = LinkedMatch(fronts[i], bm, self)
+        return out
+
+    def trimmed(self, match):
+        front_trimmed = self.front_adapter.trimmed(match.front_match)
+        if match.back_match:
+            return self.back_adapter.trimmed(match.back_match)
+        return front_trimmed
+
+    def summarize(self):
+        fa, ba = self.front_adapter, self.back_adapter
+        total_front = sum(fa.lengths_front.values())
+        total_back = sum(ba.lengths_back.values())
+        return dict(total_front=total_front, total_back=total_back, total=total_front + total_back,
+                    where=where_int_to_dict(self.where), front_sequence=fa.sequence, back_sequence=ba.sequence,
+                    front_match_probabilities=fa.random_match_probabilities(),
+                    back_match_probabilities=ba.random_match_probabilities(),
+                    front_max_error_rate=fa.max_error_rate, back_max_error_rate=ba.max_error_rate,
+                    front_lengths_front=dict(fa.lengths_front), front_lengths_back=dict(fa.lengths_back),
+                    back_lengths_front=dict(ba.lengths_front), back_lengths_back=dict(ba.lengths_back))
+
+
+class AdapterParser(object):
+    """Factory for Adapter objects that all share the same parameters (error rate, indels
+    ...); ``**kwargs`` go to the Adapter constructors.  Supports the command-line
+    notation: ``name=SEQ``, ``^SEQ`` (anchored 5'), ``SEQ$`` (anchored 3'),
+    ``SEQ1...SEQ2`` (linked).  (``file:`` specs, colorspace and the adapter cache are out
+    of scope.)"""
+
+    def __init__(self, **kwargs):
+        self.constructor_args = kwargs
+
+    def parse(self, spec, cmdline_type='back'):
+        if spec.startswith('file:'):
+            raise NotImplementedError("file: adapter specs need the FASTA reader, which is out of scope")
+        yield self.parse_from_spec(spec, cmdline_type)
+
+    def parse_from_spec(self, spec, cmdline_type='back', name=None):
+        if cmdline_type not in ADAPTER_TYPES:
+            raise ValueError('cmdline_type cannot be {0!r}'.format(cmdline_type))
+        if spec is None:
+            raise ValueError('Either name or spec must be given')
+        orig_spec = spec
+        where = ADAPTER_TYPES[cmdline_type].flags
+        if name is None:
+            name, spec = _extract_name_from_spec(spec)
+        front_anchored = back_anchored = False
+        if spec.startswith('^'):
+            spec = spec[1:]
+            front_anchored = True
+        if spec.endswith('$'):
+            spec = spec[:-1]
+            back_anchored = True
+        sequence1, middle, sequence2 = spec.partition('...')
+        if where == ANYWHERE:
+            if front_anchored or back_anchored:
+                raise ValueError("'anywhere' (-b) adapters may not be anchored")
+            if middle == '...':
+                raise ValueError("'anywhere' (-b) adapters may not be linked")
+            return Adapter(sequence=spec, where=where, name=name, **self.constructor_args)
+        assert where == FRONT or where == BACK
+        if middle == '...':
+            if not sequence1:
+                if where == BACK:           # -a ...ADAPTER
+                    spec = sequence2
+                else:                       # -g ...ADAPTER
+                    raise ValueError('Invalid adapter specification')
+            elif not sequence2:
+                if where == BACK:           # -a ADAPTER...
+                    spec = sequence1
+                    where = FRONT
+                    front_anchored = True
+                else:                       # -g ADAPTER...
+                    spec = sequence1
+            else:
+                if where == BACK:           # the 5' adapter is anchored automatically with -a
+                    front_anchored = True
+                return LinkedAdapter(sequence1, sequence2, name=name, front_anchored=front_anchored,
+                                     back_anchored=back_anchored, **self.constructor_args)
+        if front_anchored and back_anchored:
+            raise ValueError('Trying to use both "^" and "$" in adapter specification {!r}'.format(orig_spec))
+        if front_anchored:
+            if where == BACK:
+                raise ValueError("Cannot anchor the 3' adapter at its 5' end")
+            where = PREFIX
+        elif back_anchored:
+            if where == FRONT:
+                raise ValueError("Cannot anchor 5' adapter at 3' end")
+            where = SUFFIX
+        return Adapter(sequence=spec, where=where, name=name, **self.constructor_args)
+
+    def parse_multi(self, back=None, anywhere=None, front=None):
+        adapters = []
+        for specs, cmdline_type in ((back, 'back'), (anywhere, 'anywhere'), (front, 'front')):
+            for spec in specs or ():
+                adapters.extend(self.parse(spec, cmdline_type))
+        return adapters

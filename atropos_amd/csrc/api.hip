@@ -13,6 +13,10 @@ namespace atr {
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                   const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st);
 
+int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
+                   long long stride, const int16_t *im, const uint8_t *mask, long long n, int max_len, int action,
+                   int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
+                   hipStream_t st);
 int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
                  long long q_stride, const int32_t *q_lens, long long npairs, double e, int flags, int min_overlap,
                  int max_matches, int *work, int16_t *out, int32_t *counts, int out_stride, hipStream_t st);
@@ -216,6 +220,22 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
     const int rc = launch_compare((const uint8_t *)ref, m, d_queries, query_stride, d_lens, n, max_len, wildcard_ref,
                                   wildcard_query, suffix, (int16_t *)d_out, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "compare_kernel launch");
+}
+
+int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d_lens1, uint8_t *d_seq2,
+                             uint8_t *d_qual2, const int32_t *d_lens2, int64_t stride, const int16_t *d_insert,
+                             const uint8_t *d_mask, int64_t n, int max_len, int action, int min_qual_difference,
+                             int truncate_seqs, const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen,
+                             void *stream) {
+    if (n < 0 || max_len < 0 || action < 0 || action > 2 || !comp) return ATR_ERR_INVALID;
+    if ((d_qual1 == nullptr) != (d_qual2 == nullptr)) return ATR_ERR_INVALID;
+    if (action != ATR_CORRECT_N && !d_qual1) return ATR_ERR_INVALID;      /* modifiers.py:245-248 */
+    if (n == 0) return ATR_OK;
+    if (!d_seq1 || !d_seq2 || !d_insert || !d_changed || !d_newlen) return ATR_ERR_INVALID;
+    const int rc = launch_correct(d_seq1, d_qual1, d_lens1, d_seq2, d_qual2, d_lens2, stride, d_insert, d_mask, n,
+                                  max_len, action, min_qual_difference, truncate_seqs, comp, d_changed, d_newlen,
+                                  (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "correct_kernel launch");
 }
 
 }  // extern "C"

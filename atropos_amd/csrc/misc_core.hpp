@@ -131,5 +131,116 @@ ATR_DEV void compare_one(const uint8_t *ref, int m, const uint8_t *query, int n,
     rec[4] = (int16_t)matches; rec[5] = (int16_t)(len - matches); rec[6] = 0; rec[7] = 0;
 }
 
+// Python list indexing / slicing semantics (negative indices wrap once).
+ATR_DEV int py_index(int idx, int n) {            // returns -1 when Python raises IndexError
+    if (idx < 0) idx += n;
+    return (idx < 0 || idx >= n) ? -1 : idx;
+}
+ATR_DEV void py_slice(int start, int stop, int n, int &a, int &b) {
+    if (start < 0) start = mc_max(start + n, 0); else start = mc_min(start, n);
+    if (stop < 0) stop = mc_max(stop + n, 0); else stop = mc_min(stop, n);
+    a = start; b = mc_max(start, stop);
+}
+
+// ErrorCorrectorMixin.correct_errors for one pair (atropos/commands/trim/modifiers.py:
+// 219-350), on raw ASCII sequences and qualities, in place.
+//   im[4]   = insert_match[0..3] (ref start/stop in rc(read2), query start/stop in read1)
+//   action  : 0 = 'N', 1 = 'conservative', 2 = 'liberal'
+//   comp    : 256-entry complement table (BASE_COMPLEMENTS, 0 = no complement -> KeyError)
+//   q1/q2   : may be NULL (no qualities; only action 'N' and the N-fill rules apply)
+// Writes changed[0..1] = bases changed in read1 / read2 and newlen[0..1] = the sequence
+// lengths after the call.  changed[0] < 0 reports the exception the reference raises for
+// this pair: -1 KeyError (base without complement), -2 IndexError (overlap outside a
+// read), -3 ValueError (mean of an empty quality slice).  Index arithmetic follows
+// Python's list semantics (negative indices wrap), because the reference feeds
+// synthesized overlaps of unequal-length reads through them.  Reference quirk kept: with
+// truncate_seqs a corrected read1 that is longer than read2 comes back truncated to len2
+// (update_read is handed the un-truncated len1, modifiers.py:343-345); read2 keeps its tail.
+ATR_DEV void correct_errors_one(uint8_t *s1, uint8_t *q1, int len1, uint8_t *s2, uint8_t *q2, int len2,
+                                const int16_t *im, int action, int min_qual_diff, bool truncate,
+                                const uint8_t *comp, int32_t *changed, int32_t *newlen) {
+    const bool has_quals = q1 != nullptr && q2 != nullptr;
+    const int orig_len2 = len2;
+    int n1 = len1, n2 = len2;                      // lengths of the working lists r1_seq / r2_seq
+    if (truncate) {                                // :250-259
+        if (len1 > len2) n1 = len2;
+        else if (len2 > len1) { n2 = len1; len2 = len1; }
+    }
+    const int r1_start = im[2], r1_end = im[3];
+    const int r2_start = len2 - im[1], r2_end = len2 - im[0];
+    int c1 = 0, c2 = 0, err = 0, npend = 0;
+    // zip(range(r1_start, r1_end), range(r2_end - 1, r2_start - 1, -1))
+    const int steps = mc_max(0, mc_min(r1_end - r1_start, r2_end - r2_start));
+    for (int t = 0; t < steps && !err; ++t) {
+        const int i = py_index(r1_start + t, n1), j = py_index(r2_end - 1 - t, n2);
+        if (i < 0 || j < 0) { err = -2; break; }
+        const uint8_t base1 = s1[i];
+        const uint8_t base2 = comp[s2[j]];
+        if (base2 == 0) { err = -1; break; }
+        if (base1 == base2) continue;
+        if (action == 0) {                         // 'N'
+            s1[i] = 'N'; s2[j] = 'N'; ++c1; ++c2;
+        } else if (base1 == 'N') {
+            s1[i] = base2;
+            if (has_quals) q1[i] = q2[j];
+            ++c1;
+        } else if (base2 == 'N') {
+            const uint8_t cb = comp[base1];
+            if (cb == 0) { err = -1; break; }
+            s2[j] = cb;
+            if (has_quals) q2[j] = q1[i];
+            ++c2;
+        } else if (has_quals) {
+            const int diff = (int)q1[i] - (int)q2[j];
+            if (diff >= min_qual_diff) {
+                const uint8_t cb = comp[base1];
+                if (cb == 0) { err = -1; break; }
+                s2[j] = cb; q2[j] = q1[i]; ++c2;
+            } else if (diff <= -min_qual_diff) {
+                s1[i] = base2; q1[i] = q2[j]; ++c1;
+            } else if (action == 2) {
+                ++npend;                           // quals_equal.append(...)
+            }
+        }
+    }
+    if (!err && npend > 0) {                       // :301-322
+        int a1, b1, a2, b2;
+        py_slice(r1_start, r1_end, n1, a1, b1);
+        py_slice(r2_start, r2_end, n2, a2, b2);
+        if (b1 <= a1 || b2 <= a2) {
+            err = -3;                              // mean([]) raises ValueError
+        } else {
+            long long sum1 = 0, sum2 = 0;
+            for (int i = a1; i < b1; ++i) sum1 += q1[i];
+            for (int j = a2; j < b2; ++j) sum2 += q2[j];
+            const double diff = (double)sum1 / (double)(b1 - a1) - (double)sum2 / (double)(b2 - a2);
+            if (diff > 1.0 || diff < -1.0) {
+                // Re-walk: after the first pass every handled position compares equal, so
+                // the positions still unequal are exactly the recorded quals_equal entries
+                // (neither base N, quality difference inside the dead band); their bases and
+                // qualities are untouched since they were recorded.
+                for (int t = 0; t < steps; ++t) {
+                    const int i = py_index(r1_start + t, n1), j = py_index(r2_end - 1 - t, n2);
+                    const uint8_t base1 = s1[i], base2 = comp[s2[j]];
+                    if (base1 == base2 || base1 == 'N' || base2 == 'N') continue;
+                    const int qd = (int)q1[i] - (int)q2[j];
+                    if (qd >= min_qual_diff || qd <= -min_qual_diff) continue;
+                    if (diff > 1.0) {
+                        const uint8_t cb = comp[base1];
+                        if (cb == 0) { err = -1; break; }
+                        s2[j] = cb; q2[j] = q1[i]; ++c2;
+                    } else {
+                        s1[i] = base2; q1[i] = q2[j]; ++c1;
+                    }
+                }
+            }
+        }
+    }
+    changed[0] = err ? err : c1;
+    changed[1] = err ? 0 : c2;
+    newlen[0] = (c1 > 0 && !err) ? n1 : len1;      // the truncation quirk (see above)
+    newlen[1] = orig_len2;                         // read2 keeps its tail (partial update, :336-339)
+}
+
 }  // namespace atr
 #endif

@@ -183,6 +183,26 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
                       const int32_t *d_lens, int64_t n, int max_len, int wildcard_ref, int wildcard_query,
                       int suffix, atr_result *d_out, void *stream);
 
+/* ---- ErrorCorrectorMixin.correct_errors (commands/trim/modifiers.py:219-350) ---- */
+
+#define ATR_CORRECT_N             0   /* mismatch_action 'N' */
+#define ATR_CORRECT_CONSERVATIVE  1
+#define ATR_CORRECT_LIBERAL       2
+
+/* Correct mismatches in the overlap of n read pairs IN PLACE.  d_seq1/d_qual1/d_seq2/
+ * d_qual2: raw ASCII, row stride `stride` (qualities may both be NULL); d_insert: 4 x int16
+ * per pair = insert_match[0..3]; d_mask (may be NULL) selects the pairs to touch;
+ * comp: HOST 256-entry complement table (BASE_COMPLEMENTS; 0 = no complement).
+ * d_changed receives 2 x int32 per pair (bases changed in read1, read2; changed[0] == -1:
+ * -1 KeyError, -2 IndexError, -3 ValueError: the exception the reference raises), d_newlen the
+ * 2 x int32 sequence lengths afterwards (the reference truncates a corrected, longer
+ * read 1 to read 2's length when truncate_seqs is set). */
+int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d_lens1,
+                             uint8_t *d_seq2, uint8_t *d_qual2, const int32_t *d_lens2, int64_t stride,
+                             const int16_t *d_insert, const uint8_t *d_mask, int64_t n, int max_len,
+                             int action, int min_qual_difference, int truncate_seqs, const uint8_t comp[256],
+                             int32_t *d_changed, int32_t *d_newlen, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

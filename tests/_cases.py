@@ -183,3 +183,147 @@ def check_insert_batches_against_oracle(InsertAligner, oracle, seed, rounds):
             assert norm_insert(g) == exp, (cfg, x, y, norm_insert(g), exp)
             total += 1
     return total
+
+
+def read_state(r):
+    m = r.match if (r.match is not None and hasattr(r.match, "astart")) else None
+    return dict(seq=r.sequence, qual=r.qualities, corrected=r.corrected, overlap=bool(r.insert_overlap),
+                match=None if m is None else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors],
+                adapter=None if m is None else m.adapter.name, n_info=len(r.match_info) if r.match_info else 0)
+
+
+def check_cutter_golden(limit=None):
+    """AdapterCutter (per read and batched) against the reference's outputs."""
+    from atropos_amd.adapters import Adapter
+    from atropos_amd.modifiers import AdapterCutter
+    from atropos_amd.reads import Sequence
+    cases = load_golden("cutter_fuzz.json.gz")
+    if limit:
+        cases = cases[:limit]
+    n = 0
+    for c in cases:
+        def mk():
+            ads = [Adapter(sp["seq"], sp["where"], name=sp["name"], **c["kw"]) for sp in c["specs"]]
+            return AdapterCutter(ads, times=c["times"], action=c["action"])
+        cutter = mk()
+        got = [read_state(cutter(Sequence("r", q, qual))) for q, qual in c["reads"]]
+        assert got == c["out"], (c["specs"], c["kw"], c["times"], c["action"])
+        assert cutter.with_adapters == c["with_adapters"]
+        cutter = mk()
+        got = [read_state(r) for r in cutter.call_batch([Sequence("r", q, qual) for q, qual in c["reads"]])]
+        assert got == c["out"], ("batch", c["specs"], c["kw"], c["times"], c["action"])
+        assert cutter.with_adapters == c["with_adapters"]
+        n += len(c["reads"])
+    return n
+
+
+def check_insert_cutter_golden(limit=None):
+    from atropos_amd import synth
+    from atropos_amd.adapters import Adapter, BACK
+    from atropos_amd.modifiers import InsertAdapterCutter
+    from atropos_amd.reads import Sequence
+    from atropos_amd.util import RandomMatchProbability
+    cases = load_golden("insert_cutter_fuzz.json.gz")
+    if limit:
+        cases = cases[:limit]
+    rmp = RandomMatchProbability()
+    n = 0
+    for c in cases:
+        def mk():
+            kw = dict(max_error_rate=0.2, min_overlap=1, indel_cost=3, match_probability=rmp, max_rmp=1e-6)
+            return InsertAdapterCutter(Adapter(synth.PE_ADAPTER1, BACK, name="a1", **kw),
+                                       Adapter(synth.PE_ADAPTER2, BACK, name="a2", **kw),
+                                       action=c["trim_action"], **c["kw"])
+        cutter = mk()
+        got = []
+        for r1, q1, r2, q2 in c["pairs"]:
+            a, b = cutter(Sequence("p", r1, q1), Sequence("p", r2, q2))
+            got.append([read_state(a), read_state(b)])
+        assert got == c["out"], (c["kw"], c["trim_action"])
+        assert list(cutter.with_adapters) == c["with_adapters"]
+        assert cutter.corrected_pairs == c["corrected_pairs"] and list(cutter.corrected_bp) == c["corrected_bp"]
+        cutter = mk()
+        res = cutter.call_batch([Sequence("p", p[0], p[1]) for p in c["pairs"]],
+                                [Sequence("p", p[2], p[3]) for p in c["pairs"]])
+        assert [[read_state(a), read_state(b)] for a, b in res] == c["out"], ("batch", c["kw"], c["trim_action"])
+        assert list(cutter.with_adapters) == c["with_adapters"]
+        assert cutter.corrected_pairs == c["corrected_pairs"] and list(cutter.corrected_bp) == c["corrected_bp"]
+        n += len(c["pairs"])
+    return n
+
+
+def check_caller_kats():
+    from atropos_amd import synth
+    from atropos_amd.adapters import Adapter, AdapterParser, BACK
+    from atropos_amd.align import InsertAligner
+    from atropos_amd.modifiers import AdapterCutter, ErrorCorrectorMixin, InsertAdapterCutter
+    from atropos_amd.reads import Sequence
+    k = load_golden("caller_kats.json")
+    c = k["mismatched_adapter_overlaps"]
+    parser = AdapterParser()
+    cutter = InsertAdapterCutter(parser.parse_from_spec(c["a1"]), parser.parse_from_spec(c["a2"]),
+                                 max_insert_mismatch_frac=0.3, max_adapter_mismatch_frac=0.3)
+    n1, n2 = cutter(Sequence('foo', c["r1"], '#' * 125), Sequence('foo', c["r2"], '#' * 125))
+    assert len(n1) == 91 and len(n2) == 91
+    for got, exp in zip((n1, n2), c["out"]):
+        g = read_state(got)
+        g["adapter"] = exp["adapter"]               # auto-generated adapter names are process-global counters
+        assert g == exp
+    i = k["unequal_lengths_in"]
+    e1, e2 = Sequence('read1', i["s1"], i["q1"]), Sequence('read1', i["s2"], i["q2"])
+    im, _, _ = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2).match_insert(e1.sequence, e2.sequence)
+    assert list(im) == k["unequal_lengths_out"]["insert"]
+    ec = ErrorCorrectorMixin('N')
+    ec.correct_errors(e1, e2, im, truncate_seqs=True)
+    assert e1.corrected == 3 and e2.corrected == 3
+    for pos in (80, 86, 104):
+        assert e1.sequence[pos] == 'N' and e2.sequence[104 - pos] == 'N'
+    assert read_state(e1) == k["unequal_lengths_out"]["r1"] and read_state(e2) == k["unequal_lengths_out"]["r2"]
+    ad = Adapter('CCCC', BACK, 0.1)
+    t = AdapterCutter([ad], times=3)(Sequence('name', 'AAAACCCCAAAA'))
+    g = read_state(t)
+    g["adapter"] = k["statistics"]["out"]["adapter"]
+    assert g == k["statistics"]["out"]
+    assert {str(a): b for a, b in ad.lengths_back.items()} == k["statistics"]["lengths_back"]
+
+
+def check_match_to_golden():
+    from atropos_amd.adapters import Adapter
+    from atropos_amd.reads import Sequence
+    from atropos_amd.util import RandomMatchProbability
+    rmp = RandomMatchProbability()
+    cases = load_golden("match_to_fuzz.json.gz") + load_golden("kats.json")["match_to"]
+
+    def f(m):
+        return None if m is None else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+    for c in cases:
+        use = c.get("use_rmp", False)
+        ad = Adapter(c["seq"], c["where"], match_probability=rmp if use else None, max_rmp=1e-6 if use else None,
+                     **c["kw"])
+        assert f(ad.match_to(Sequence("r", c["read"]))) == c["out"], c
+        assert f(ad.match_to_batch([Sequence("r", c["read"])])[0]) == c["out"], ("batch", c)
+    return len(cases)
+
+
+def check_linked_c4():
+    from atropos_amd import synth
+    from atropos_amd.adapters import LinkedAdapter
+    from atropos_amd.reads import Sequence
+    heads = load_golden("synth_heads.json.gz")["C4"]
+    w = synth.workload("C4", 0, heads["count"])
+    reads = [Sequence("r", bytes(x.tolist()).decode("ascii")) for x in w["reads"]]
+    linked = [LinkedAdapter(fr, bk, front_anchored=True, back_anchored=False, max_error_rate=w["max_error_rate"],
+                            min_overlap=w["min_overlap"], indel_cost=w["indel_cost"])
+              for fr, bk in zip(w["fronts"], w["backs"])]
+
+    def f(m):
+        return None if m is None else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+    per = [la.match_to_batch(reads) for la in linked]
+    for i in range(len(reads)):
+        got = [None if per[a][i] is None else [f(per[a][i].front_match), f(per[a][i].back_match)] for a in range(4)]
+        assert got == heads["out"][i]
+    for i in range(0, len(reads), 7):                # the per-read path on a sample
+        lm = linked[i % 4].match_to(reads[i])
+        got = None if lm is None else [f(lm.front_match), f(lm.back_match)]
+        assert got == heads["out"][i][i % 4]
+    return len(reads)

@@ -67,6 +67,9 @@ class EmuBackend(object):
                                              C.c_void_p, C.c_void_p, C.c_int]
         L.emu_compare_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.emu_correct_errors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_char_p, C.c_void_p, C.c_void_p]
         L.emu_insert_aligner_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.emu_insert_aligner_destroy.argtypes = [C.c_void_p]
         L.emu_insert_aligner_destroy.restype = None
@@ -124,6 +127,19 @@ class EmuBackend(object):
                                               int(wildcard_ref), int(wildcard_query), int(suffix), _ptr(out)),
                    "atr_compare_batch")
         return out
+
+    def correct_errors_batch(self, seq1, qual1, lens1, seq2, qual2, lens2, insert, mask, action, min_qual_diff,
+                             truncate, comp):
+        n = seq1.shape[0]
+        changed = torch.zeros((n, 2), dtype=torch.int32)
+        newlen = torch.zeros((n, 2), dtype=torch.int32)
+        if n:
+            assert seq1.stride(0) == seq2.stride(0)
+            _check(self.lib.emu_correct_errors_batch(_ptr(seq1), _ptr(qual1), _ptr(lens1), _ptr(seq2), _ptr(qual2),
+                                                     _ptr(lens2), seq1.stride(0), _ptr(insert), _ptr(mask), n,
+                                                     seq1.shape[1], action, min_qual_diff, int(truncate), comp,
+                                                     _ptr(changed), _ptr(newlen)), "atr_correct_errors_batch")
+        return changed, newlen
 
     def insert_aligner_create(self, cfg):
         h = C.c_void_p()

@@ -41,4 +41,25 @@ int emu_compare_batch(const char *ref, int m, const uint8_t *queries, int64_t q_
     return ATR_OK;
 }
 
+int emu_correct_errors_batch(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2,
+                             const int32_t *l2, int64_t stride, const int16_t *im, const uint8_t *mask, int64_t n,
+                             int max_len, int action, int min_qual_diff, int truncate, const uint8_t comp[256],
+                             int32_t *changed, int32_t *newlen) {
+    if (n < 0 || action < 0 || action > 2 || !comp) return ATR_ERR_INVALID;
+    if ((q1 == nullptr) != (q2 == nullptr)) return ATR_ERR_INVALID;
+    if (action != 0 && !q1) return ATR_ERR_INVALID;
+    for (int64_t p = 0; p < n; ++p) {
+        const int len1 = l1 ? l1[p] : max_len, len2 = l2 ? l2[p] : max_len;
+        if (mask && !mask[p]) {
+            changed[2 * p] = changed[2 * p + 1] = 0;
+            newlen[2 * p] = len1; newlen[2 * p + 1] = len2;
+            continue;
+        }
+        correct_errors_one(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
+                           q2 ? q2 + p * stride : nullptr, len2, im + 4 * p, action, min_qual_diff, truncate != 0,
+                           comp, changed + 2 * p, newlen + 2 * p);
+    }
+    return ATR_OK;
+}
+
 }  // extern "C"

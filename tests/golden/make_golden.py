@@ -426,6 +426,131 @@ def main():
     heads["C4"] = dict(count=512, out=outs)
     dump("synth_heads.json.gz", heads)
 
+    # ------------------------------------------------------------------ callers (cutters)
+    from atropos.commands.trim.modifiers import AdapterCutter, InsertAdapterCutter, ErrorCorrectorMixin
+    from atropos.adapters import AdapterParser
+
+    def read_state(r):
+        return dict(seq=r.sequence, qual=r.qualities, corrected=r.corrected, overlap=bool(r.insert_overlap),
+                    match=match_fields(r.match) if r.match is not None and hasattr(r.match, "astart") else None,
+                    adapter=(r.match.adapter.name if r.match is not None and hasattr(r.match, "astart") else None),
+                    n_info=(len(r.match_info) if r.match_info else 0))
+
+    cutter_cases = []
+    for it in range(600):
+        nad = rng.choice([1, 2, 3])
+        specs = []
+        for a in range(nad):
+            m = rng.randint(6, 34)
+            seq = rseq(m, "ACGT" if rng.random() < 0.8 else "ACGTN")
+            where = rng.choice([BACK, BACK, FRONT, PREFIX, SUFFIX, ANYWHERE])
+            specs.append(dict(seq=seq, where=where, name="ad%d" % a))
+        kw = dict(max_error_rate=rng.choice([0.1, 0.12, 0.2]), min_overlap=rng.choice([1, 3, 5]),
+                  indels=rng.random() < 0.85)
+        times = rng.choice([1, 1, 2, 3])
+        action = rng.choice(['trim', 'trim', 'mask', None])
+        reads = []
+        for _ in range(12):
+            body = rseq(rng.randint(20, 90))
+            sp = rng.choice(specs)
+            a = mutate(sp["seq"].replace("N", "C"), rng.choice([0, 0, 0.05, 0.1]))
+            w = rng.random()
+            if sp["where"] in (BACK, SUFFIX):
+                q = body + (a if w < 0.6 else a[:rng.randint(0, len(a))]) + (rseq(rng.randint(0, 15)) if sp["where"] == BACK and w < 0.3 else "")
+            elif sp["where"] in (FRONT, PREFIX):
+                q = (a if w < 0.6 else a[rng.randint(0, len(a)):]) + body
+            else:
+                q = body + a + rseq(rng.randint(0, 10)) if w < 0.5 else a + body
+            if rng.random() < 0.3:
+                sp2 = rng.choice(specs)
+                q = q + sp2["seq"].replace("N", "G")[:rng.randint(3, len(sp2["seq"]))]
+            if rng.random() < 0.15:
+                q = rseq(rng.randint(0, 60), "ACGTN")
+            qual = "".join(chr(33 + rng.randint(2, 40)) for _ in q) if rng.random() < 0.7 else None
+            reads.append((q, qual))
+        ads = [Adapter(sp["seq"], sp["where"], name=sp["name"], **kw) for sp in specs]
+        cutter = AdapterCutter(ads, times=times, action=action)
+        outs = []
+        for q, qual in reads:
+            outs.append(read_state(cutter(Sequence(name="r", sequence=q, qualities=qual))))
+        cutter_cases.append(dict(specs=specs, kw=kw, times=times, action=action, reads=reads, out=outs,
+                                 with_adapters=cutter.with_adapters))
+    dump("cutter_fuzz.json.gz", cutter_cases)
+
+    icut_cases = []
+    parser_kw = dict(max_error_rate=0.2, min_overlap=1, indel_cost=3, match_probability=RandomMatchProbability(),
+                     max_rmp=1e-6)
+    for it in range(240):
+        action = rng.choice([None, None, 'liberal', 'conservative', 'N'])
+        kwc = dict(mismatch_action=action)
+        if rng.random() < 0.3:
+            kwc.update(max_insert_mismatch_frac=0.3, max_adapter_mismatch_frac=0.3)
+        if rng.random() < 0.2:
+            kwc.update(read_wildcards=True)
+        if rng.random() < 0.2:
+            kwc.update(symmetric=False)
+        trim_action = rng.choice(['trim', 'trim', 'mask', None])
+        ad1 = Adapter(A1, BACK, name="a1", **parser_kw)
+        ad2 = Adapter(A2, BACK, name="a2", **parser_kw)
+        cutter = InsertAdapterCutter(ad1, ad2, action=trim_action, **kwc)
+        pairs, outs = [], []
+        for _ in range(10):
+            n = rng.choice([40, 75, 100, 150])
+            f = rng.randint(5, int(1.6 * n))
+            F = rseq(f)
+            r1 = (F + A1 + rseq(n))[:rng.choice([n, n, n, n - 4])]
+            r2 = (reverse_complement(F) + A2 + rseq(n))[:rng.choice([n, n, n - 2])]
+            p = rng.choice([0, 0.01, 0.03, 0.08])
+            r1, r2 = noise(r1, p), noise(r2, p)
+            if rng.random() < 0.15:
+                r2 = (rseq(rng.randint(0, n)) + A2)[:n].ljust(n, "A")   # no overlap: adapter-only fallback
+            q1 = "".join(chr(33 + rng.randint(2, 40)) for _ in r1)
+            q2 = "".join(chr(33 + rng.randint(2, 40)) for _ in r2)
+            if rng.random() < 0.3:
+                q1, q2 = "I" * len(r1), "I" * len(r2)             # equal qualities: the 'liberal' mean rule
+            if action in (None, 'N') and rng.random() < 0.3:
+                q1 = q2 = None
+            try:
+                a, b = cutter(Sequence(name="p", sequence=r1, qualities=q1),
+                              Sequence(name="p", sequence=r2, qualities=q2))
+            except (ValueError, IndexError):
+                # the reference itself fails on some synthesized overlaps of unequal-length
+                # reads (empty quality slice in correct_errors); such pairs are not recorded
+                continue
+            pairs.append((r1, q1, r2, q2))
+            outs.append([read_state(a), read_state(b)])
+        icut_cases.append(dict(kw=kwc, trim_action=trim_action, pairs=pairs, out=outs,
+                               with_adapters=list(cutter.with_adapters), corrected_pairs=cutter.corrected_pairs,
+                               corrected_bp=list(cutter.corrected_bp)))
+    dump("insert_cutter_fuzz.json.gz", icut_cases)
+
+    # known answers of the reference's own caller tests (tests/test_modifiers.py:295-324, :444-471,
+    # tests/test_trim.py:17-28)
+    caller_kats = {}
+    r1 = 'TTGTTTTTATGGAGAGAGTTTTAAGGTTTATTTTAGTTTTAAAGGATATTGTAGGTTAGAGGGAAAGTGTATGATGAAGGTATATATTGGTAGATCGGAAGAGCACACGTCTGAACTTCAGTCAC'
+    r2 = 'ACCAATATTTTACTCCATCATACACTTACCCTCTAAACTATAATAACTTTTTTATCTATACTTAACCTTTATTTTCAACTCATCACAATAAAGATCCGAAGAGAGACGTGAAGGGAAAGAACATA'
+    a1 = "GATCGGAAGAGCACACGTCTGAACTCCAGTCACCAGATCATCTCGTATGCCGTCTTCTGCTTG"
+    parser = AdapterParser()
+    cutter = InsertAdapterCutter(parser.parse_from_spec(a1), parser.parse_from_spec(A2),
+                                 max_insert_mismatch_frac=0.3, max_adapter_mismatch_frac=0.3)
+    n1, n2 = cutter(Sequence('foo', r1, '#' * 125), Sequence('foo', r2, '#' * 125))
+    assert len(n1) == 91 and len(n2) == 91
+    caller_kats["mismatched_adapter_overlaps"] = dict(r1=r1, r2=r2, a1=a1, a2=A2, out=[read_state(n1), read_state(n2)])
+    e1 = Sequence('read1', 'TTTGCAGCTTTTGTAGACAAGTGCTGTGCAGCTGATGTCAAAGAGACCTGCTTTGCTCTGGAGGGTCCAAAACTTGTAGCCTCAACCCGAGAAGCCATAGCCTAA',
+                  'CCCCCFCGGGGGBFFAFC<?BEADCCF<FFFFGFFDFDFFGGGGCFGGC?DFFFEC;,===??DG==DDDFFFFG8DDD7+5;;DF*=)))10885D**58>6=0')
+    e2 = Sequence('read1', 'ATAGGCTATGGCTTCTCGAGTTGAAGCTACAAGTTTTGGACCCTCCAGAGCAAAGCAGGTCTCTTTGACATCAGCTGCACAGCACTTGTCTACAAAAGCTGCAAAAGATCGGAAGAGCGTCTCGGAAGAGCGTCGTGTAGGGAAAGAGTGTAGATCTCGGTGGTCGACGTATCATTAAAAAAAAAAACACATCACATCAACAAGATAACACGACTTCTCCATCCACAGTACCGATGACCTCAACATTAGT',
+                  'CCCCCG@FCFGGCFGGGGFEFGFGGFCFGGGFGFGGGGGGGGGGGGGGGGGGGGGGGGGGG9FGGGGGGGFGDFFGGGGGGGGGGGGGGGGG8;>@?@FEGGGGGGGGGGGGGGGGGGGGG=DDFAEFFFGF>B>EA):DFFBDFFB6CDEDDD9=99DD>55)580:A5)*)*;DD>**51:0118):)4))1***0:*)*)((***0*.(((((*)/.)1/(6((()1.)(((6).-----8<:C<73')
+    caller_kats["unequal_lengths_in"] = dict(s1=e1.sequence, q1=e1.qualities, s2=e2.sequence, q2=e2.qualities)
+    im, _, _ = InsertAligner(A1, A2).match_insert(e1.sequence, e2.sequence)
+    ec = ErrorCorrectorMixin('N')
+    ec.correct_errors(e1, e2, im, truncate_seqs=True)
+    assert e1.corrected == 3 and e2.corrected == 3
+    caller_kats["unequal_lengths_out"] = dict(insert=list(im), r1=read_state(e1), r2=read_state(e2))
+    ad = Adapter('CCCC', BACK, 0.1)
+    t = AdapterCutter([ad], times=3)(Sequence('name', 'AAAACCCCAAAA'))
+    caller_kats["statistics"] = dict(out=read_state(t), lengths_back=dict(ad.lengths_back))
+    dump("caller_kats.json", caller_kats)
+
     # ------------------------------------------------------------------ RMP values
     R = RandomMatchProbability()
     vals = []
