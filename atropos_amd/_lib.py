@@ -67,8 +67,9 @@ PROTOTYPES = {
     "atr_aligner_set_min_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "atr_aligner_set_indel_cost": (C.c_int, [C.c_void_p, C.c_int]),
     "atr_aligner_query_table": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
-                                   C.c_void_p]),
+                                   C.c_void_p, C.c_void_p]),
 }
 
 
@@ -120,6 +121,7 @@ class HipBackend(object):
         if ndev < 1:
             raise AtroposHipError("atr_device_count() == 0: no HIP device")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._work = None
 
     # -- helpers ---------------------------------------------------------------
     def _stream(self):
@@ -236,12 +238,20 @@ class HipBackend(object):
         kind = _check(self.lib, self.lib.atr_aligner_query_table(h, buf), "atr_aligner_query_table")
         return kind, buf.raw
 
-    def locate_batch(self, h, packed, lens, nreads, max_len):
+    def locate_batch(self, h, packed, lens, nreads, max_len, filtered=True):
+        """filtered: give the library its scratch so that it may run the filtered pipeline
+        (bit-parallel pre-pass + windowed DP); the records are identical either way."""
         out = self.empty((nreads, 8), torch.int16)
         if nreads:
+            work = None
+            if filtered:
+                need = self.lib.atr_locate_work_bytes(nreads)
+                if self._work is None or self._work.numel() < need:
+                    self._work = self.empty((need,), torch.uint8)
+                work = self._work
             with torch.cuda.device(self.device):
                 _check(self.lib, self.lib.atr_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
-                                                           self._stream()), "atr_locate_batch")
+                                                           _ptr(work), self._stream()), "atr_locate_batch")
         return out
 
 

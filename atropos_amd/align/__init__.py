@@ -162,8 +162,10 @@ class Aligner(object):
                              "(use aligner.pack(reads))" % (batch.table_kind, self._table_kind))
 
     # -- alignment ----------------------------------------------------------------------
-    def locate_batch(self, reads):
-        """Batched ``locate``: one result record per read (see LocateResult)."""
+    def locate_batch(self, reads, filtered=True):
+        """Batched ``locate``: one result record per read (see LocateResult).  ``filtered``
+        lets the library use its filtered pipeline (bit-parallel pre-pass + windowed DP)
+        where it applies; the records are identical either way."""
         batch = self.pack(reads)
         be = self._backend
         if self._handle is None:                      # empty reference: nothing ever matches
@@ -172,7 +174,8 @@ class Aligner(object):
             rec.zero_()
             rec[:, 1] = -1
             return LocateResult(rec)
-        return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len))
+        return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len,
+                                            filtered))
 
     def locate(self, query):
         """locate(query) -> (refstart, refstop, querystart, querystop, matches, errors)

@@ -15,6 +15,8 @@
 
 struct atr_aligner {
     atr::LocateParams p;
+    uint64_t peq[16];                 // Myers match masks by query code (filter_core.hpp)
+    int filterable;                   // the filtered pipeline applies to this aligner
     double max_error_rate;
     int flags, wildcard_ref, wildcard_query, min_overlap, indel_cost;
     int table_kind;
@@ -66,6 +68,19 @@ inline int aligner_refresh(atr_aligner *a) {
         const int p0 = round_up_rows(m) - m;
         memset(p.ref, 0, sizeof(p.ref));
         for (int i = 0; i < m; ++i) p.ref[p0 + i] = a->codes[i];
+    }
+    {   // match masks of the bit-parallel pre-pass, and whether it applies
+        const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
+        for (int c = 0; c < 16; ++c) {
+            uint64_t mask = 0;
+            for (int i = 0; i < m && i < 64; ++i) {
+                const int rc = a->codes[i];
+                if (eqmode ? (rc == c) : ((rc & c) != 0)) mask |= 1ull << i;
+            }
+            a->peq[c] = mask;
+        }
+        const int need = ATR_START_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ2;
+        a->filterable = (m <= 64 && (a->flags & need) == need && p.k >= 0) ? 1 : 0;
     }
     for (int L = 0; L <= m + 1; ++L) {
         // integer cost <= L*e  <=>  cost <= floor(L*e)   (_align.pyx:447, :468)

@@ -7,9 +7,12 @@
 #include "aligner_host.hpp"
 #include "locate_kernel.hpp"
 #include "insert_host.hpp"
+#include "locate_fast.hpp"
 
 namespace atr {
 
+int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
+                       int nchunks, int max_len, uint4 *out, void *work, hipStream_t st);
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                   const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st);
 
@@ -132,11 +135,18 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
     return a->table_kind;
 }
 
+size_t atr_locate_work_bytes(int64_t nreads) { return nreads < 0 ? 0 : fast_work_bytes(nreads); }
+
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
-                     int max_len, atr_result *d_out, void *stream) {
+                     int max_len, atr_result *d_out, void *d_work, void *stream) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
     if (!d_out || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
+    if (d_work && a->filterable && max_len > 0) {
+        const int rc = launch_locate_fast(a, (const uint4 *)d_packed, d_lens, nreads, (max_len + 31) / 32, max_len,
+                                          (uint4 *)d_out, d_work, (hipStream_t)stream);
+        return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "filtered locate launch");
+    }
     typedef locate_launcher (*group_fn)(int);
     static const group_fn groups[LOCATE_GROUPS] = {
         locate_group_0, locate_group_1, locate_group_2, locate_group_3,

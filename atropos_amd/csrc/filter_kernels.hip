@@ -1,0 +1,26 @@
+// filter_kernels.hip -- K1..K3 of the filtered locate pipeline and its driver.
+#define ATR_DEFINE_FILTER_KERNELS
+#include "locate_fast.hpp"
+
+namespace atr {
+
+window_launcher window_group_0(int), window_group_1(int), window_group_2(int), window_group_3(int);
+
+int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
+                       int nchunks, int max_len, uint4 *out, void *work, hipStream_t st) {
+    FastWork wk = fast_carve(work, nreads);
+    FilterParams fp;
+    memcpy(fp.peq, a->peq, sizeof(fp.peq));
+    hipLaunchKernelGGL(filter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, a->p, fp, packed, lens, nreads, nchunks,
+                       max_len, out, wk);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, wk);
+    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, wk);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    typedef window_launcher (*group_fn)(int);
+    static const group_fn groups[4] = {window_group_0, window_group_1, window_group_2, window_group_3};
+    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    return groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, st);
+}
+
+}  // namespace atr

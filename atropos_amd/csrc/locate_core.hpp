@@ -153,6 +153,8 @@ struct Uniform {
     uint32_t insw, delw, klimit;
 };
 
+ATR_DEV int round_up_rows_dev(int m) { return (m + ROW_GRAN - 1) / ROW_GRAN * ROW_GRAN; }
+
 ATR_DEV Uniform make_uniform(const LocateParams &p, int MT) {
     Uniform u;
     u.m = p.m; u.k = p.k; u.p0 = MT - p.m; u.indel = p.indel; u.min_overlap = p.min_overlap;
@@ -187,6 +189,32 @@ ATR_DEV void lane_init(LaneState<MT> &L, const Uniform &u, int n, const uint32_t
     if (L.scan && n == 0) scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr);
 }
 
+// Window mode (filter_core.hpp): the DP is started afresh at column j_lo as if row i had
+// been reached from (0, j_lo) by i insertions; column 0 keeps the aligner's own initial
+// column.  Only used with START_WITHIN_SEQ2 and STOP_WITHIN_SEQ2.
+ATR_DEV uint32_t window_init_word(int i, int j_lo, int indel) {
+    const int cost = i < 0 ? INIT_COST_CAP : atr_min(i * indel, INIT_COST_CAP);
+    return ((uint32_t)cost << CSH) | (uint32_t)(j_lo + (int)ORG_BIAS);
+}
+
+template <int MT>
+ATR_DEV void lane_init_window(LaneState<MT> &L, const Uniform &u, int n, int j_lo, int j_hi, bool scan,
+                              const uint32_t *s_init, const int16_t *thr) {
+    L.n = n; L.min_n = j_lo; L.max_n = j_hi; L.scan = scan;
+    if (j_lo == 0) {
+#pragma unroll
+        for (int i = 0; i <= MT; ++i) L.col[i] = s_init[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i <= MT; ++i) L.col[i] = window_init_word(i - u.p0, j_lo, u.indel);
+    }
+    L.best.key = COST_FIELD_MAX - (u.m + n);
+    L.best.word = (uint32_t)(u.m + n) << CSH;
+    L.best.ref_stop = u.m; L.best.query_stop = n;
+    // an empty window only arises for an empty read whose initial column already qualifies
+    if (scan && j_hi <= j_lo) scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr);
+}
+
 // Column j of the wave-uniform sweep, query code q.  Every lane of the wave executes
 // the column update unmasked; a lane whose own window (min_n, max_n] is narrower than
 // the wave's range
@@ -194,7 +222,7 @@ ATR_DEV void lane_init(LaneState<MT> &L, const Uniform &u, int n, const uint32_t
 //   * takes its last-column candidates when the sweep reaches its max_n,
 //   * ignores row-m candidates outside its window,
 // and whatever it computes past max_n is never looked at.
-template <int MT, bool EQ, bool NOINDEL>
+template <int MT, bool EQ, bool NOINDEL, bool WIN = false>
 ATR_DEV void lane_step(LaneState<MT> &L, const LocateParams &p, const Uniform &u, int j, uint32_t q,
                        const int16_t *thr) {
     // row 0 (:385-388): origin j, or cost j*indel (saturated: it is > k long before).
@@ -202,7 +230,19 @@ ATR_DEV void lane_step(LaneState<MT> &L, const LocateParams &p, const Uniform &u
     const uint32_t row0 = u.sq ? (ORG_BIAS + (uint32_t)j)
                                : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
     const uint32_t wm = column_step<MT, EQ, NOINDEL>(L.col, p, u.p0, q, row0, u.insw, u.delw);
-    if (u.eq) {
+    if (WIN) {
+        // window mode: candidates only inside (j_lo, j_hi]; a lane whose window starts later
+        // than the wave's sweep is restarted when the sweep reaches its j_lo
+        if (wm < u.klimit && j <= L.max_n && j > L.min_n) consider(L.best, wm, u.m, j, u.min_overlap, thr);
+        if (j == L.min_n) {
+            int lo = L.min_n;
+#ifndef ATR_HOST_EMU
+            asm volatile("" : "+v"(lo));
+#endif
+#pragma unroll
+            for (int i = 0; i <= MT; ++i) L.col[i] = window_init_word(i - u.p0, lo, u.indel);
+        }
+    } else if (u.eq) {
         // row-m candidate: the reference looks at it only when the band reached row m,
         // i.e. cost <= k (:433-455); min_n is 0 here.
         if (wm < u.klimit && j <= L.max_n) consider(L.best, wm, u.m, j, u.min_overlap, thr);

@@ -117,9 +117,13 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]);
 /* Aligner.locate(query) for a batch (_align.pyx:266-491): d_out[r] receives
  * (refstart, refstop, querystart, querystop, matches, errors) or refstop = -1.
  * d_lens may be NULL.  max_len is the layout parameter the buffer was packed
- * with. */
+ * with.  d_work: optional device scratch of atr_locate_work_bytes(nreads) bytes; when
+ * given (and the aligner qualifies: START/STOP_WITHIN_SEQ2 set, m <= 64) the filtered
+ * pipeline runs -- a bit-parallel pre-pass resolves most reads and the full DP only
+ * sweeps a short column window of the rest; results are identical either way. */
+size_t atr_locate_work_bytes(int64_t nreads);
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
-                     int64_t nreads, int max_len, atr_result *d_out, void *stream);
+                     int64_t nreads, int max_len, atr_result *d_out, void *d_work, void *stream);
 
 /* ---- InsertAligner (atropos/align/__init__.py:178-377) -------------------- */
 

@@ -76,8 +76,40 @@ def check_batches_against_oracle(Aligner, oracle, unsupported_exc, seed, rounds,
             continue
         fixed = rng.randint(0, 200) if rng.random() < 0.3 else None
         reads = planted_reads(rng, ref, rng.choice([1, 63, 64, 65, 130, 200]), 200, fixed)
+        got = al.locate_batch(reads).tuples()                       # filtered pipeline where it applies
+        plain = al.locate_batch(reads, filtered=False).tuples()      # full sweep
+        assert len(got) == len(reads) and plain == got
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
+            total += 1
+    return total
+
+
+def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds):
+    """The bit-parallel pre-pass + windowed DP against the oracle on the adapter types it
+    applies to (START_WITHIN_SEQ2 and STOP_WITHIN_SEQ2 set, m <= 64): every indel regime,
+    wildcard mode and overlap threshold, ragged and fixed-length batches, reads holding the
+    adapter several times (first-perfect-hit shortcut)."""
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        m = rng.randint(1, 64)
+        ref = rseq(rng, m, "ACGT" if rng.random() < 0.7 else "ACGTNRY")
+        flags = rng.choice([14, 14, 11, 15, 10])
+        e = rng.choice([0, 0.05, 0.1, 0.12, 0.2, 0.3, 0.5])
+        ic = rng.choice([1, 1, 1, 2, 3, 100000])
+        mo = rng.choice([1, 3, 5, 40])
+        wr, wq = rng.random() < 0.3, rng.random() < 0.3
+        try:
+            al = Aligner(ref, e, flags, wr, wq, mo, ic)
+        except unsupported_exc:
+            continue
+        fixed = rng.randint(0, 200) if rng.random() < 0.4 else None
+        reads = planted_reads(rng, ref, rng.choice([1, 64, 65, 130, 300]), 220, fixed)
+        if rng.random() < 0.2:
+            reads = [r if rng.random() < 0.5 else ref * 3 for r in reads]
         got = al.locate_batch(reads).tuples()
-        assert len(got) == len(reads)
+        assert got == al.locate_batch(reads, filtered=False).tuples()
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1

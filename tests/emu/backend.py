@@ -15,7 +15,8 @@ _SO = os.path.join(_HERE, "libemu_locate.so")
 _CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "emu_misc.cpp")]
 _SRCS = _CPPS + [
     os.path.join(_ROOT, "atropos_amd", "csrc", f)
-    for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp")] + [
+    for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp",
+              "filter_core.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -75,7 +76,7 @@ class EmuBackend(object):
         L.emu_insert_aligner_destroy.restype = None
         L.emu_insert_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                              C.c_int, C.c_void_p]
-        L.emu_locate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.emu_locate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         self.device = torch.device("cpu")
         from atropos_amd import _lib
         self._kinds = {}
@@ -176,9 +177,9 @@ class EmuBackend(object):
         kind = _check(self.lib.emu_aligner_query_table(h, buf), "atr_aligner_query_table")
         return kind, buf.raw
 
-    def locate_batch(self, h, packed, lens, nreads, max_len):
+    def locate_batch(self, h, packed, lens, nreads, max_len, filtered=True):
         out = torch.zeros((nreads, 8), dtype=torch.int16)
         if nreads:
-            _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out)),
+            _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), int(filtered)),
                    "atr_locate_batch")
         return out

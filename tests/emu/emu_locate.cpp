@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "aligner_host.hpp"
+#include "filter_core.hpp"
 
 using namespace atr;
 
@@ -64,17 +65,84 @@ void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens
     }
 }
 
+// The filtered pipeline (locate_fast.hpp): K1 per read, K2/K3 as a stable bucket order by
+// window-start bin, K4 in waves of 64 gathered reads, lock-step like the GPU wave.
+static uint32_t read_code(const uint32_t *packed, int nchunks, long long r, int j /*1-based*/) {
+    const long long tile = r >> 6;
+    const int lane = (int)(r & 63), c = (j - 1) >> 5, d = ((j - 1) >> 3) & 3, b = (j - 1) & 7;
+    return (packed[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] >> (4 * b)) & 15u;
+}
+
+template <int MT, bool EQ, bool NOINDEL>
+void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, long long nreads, int nchunks,
+              int max_len, uint32_t *out) {
+    const LocateParams &p = a->p;
+    const Uniform u = make_uniform(p, MT);
+    int16_t s_thr[ATR_MAX_REF_LEN + 2];
+    uint32_t s_init[ATR_MAX_REF_LEN + 1];
+    for (int i = 0; i <= MT + 1; ++i) {
+        if (i <= u.m + 1) s_thr[i] = p.thr[i];
+        if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
+    }
+    std::vector<uint32_t> win((size_t)nreads);
+    std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
+    for (long long r = 0; r < nreads; ++r) {                       // K1
+        const int n = lens ? lens[r] : max_len;
+        FilterState F;
+        filter_init(F, u);
+        for (int j = 1; j <= n; ++j) filter_step(F, u, a->peq[read_code(packed, nchunks, r, j)], j);
+        uint32_t rec[4];
+        const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
+        win[r] = ww;
+        if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
+        else bins[window_lo(ww) >> 3].push_back((uint32_t)r);
+    }
+    std::vector<uint32_t> order;                                   // K2 + K3
+    for (auto &b : bins) order.insert(order.end(), b.begin(), b.end());
+    const long long total = (long long)order.size();
+    std::vector<LaneState<MT>> L(64);
+    for (long long base = 0; base < total; base += 64) {           // K4, one wave at a time
+        int jlo = 0x7fffffff, jhi = 0;
+        long long rr[64];
+        bool live[64];
+        for (int lane = 0; lane < 64; ++lane) {
+            live[lane] = base + lane < total;
+            rr[lane] = live[lane] ? order[base + lane] : 0;
+            const uint32_t ww = live[lane] ? win[rr[lane]] : 0u;
+            const int n = live[lane] ? (lens ? lens[rr[lane]] : max_len) : 0;
+            const int lo = window_lo(ww), hi = live[lane] ? window_hi(ww) : 0;
+            lane_init_window<MT>(L[lane], u, n, lo, hi, live[lane] && window_scan(ww), s_init, s_thr);
+            const bool has_window = live[lane] && hi > lo;
+            jlo = std::min(jlo, has_window ? lo : 0x7fffffff);
+            jhi = std::max(jhi, has_window ? hi : 0);
+        }
+        if (jhi > jlo)
+        for (int j = jlo + 1; j <= jhi; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                // lanes past the end of `order` gather read 0 like the kernel does
+                const uint32_t q = (j <= nchunks * 32) ? read_code(packed, nchunks, rr[lane], j) : 0u;
+                lane_step<MT, EQ, NOINDEL, true>(L[lane], p, u, j, q, s_thr);
+            }
+        for (int lane = 0; lane < 64; ++lane)
+            if (live[lane]) lane_result<MT>(L[lane], u, out + 4 * rr[lane]);
+    }
+}
+
 typedef void (*emu_fn)(const atr_aligner *, const uint32_t *, const int32_t *, long long, int, int, uint32_t *);
 
 template <int MT>
-emu_fn pick(bool eqmode, bool noindel) {
+emu_fn pick(bool eqmode, bool noindel, bool fast) {
+    if (fast) {
+        if (eqmode) return noindel ? &emu_fast<MT, true, true> : &emu_fast<MT, true, false>;
+        return noindel ? &emu_fast<MT, false, true> : &emu_fast<MT, false, false>;
+    }
     if (eqmode) return noindel ? &emu_tiles<MT, true, true> : &emu_tiles<MT, true, false>;
     return noindel ? &emu_tiles<MT, false, true> : &emu_tiles<MT, false, false>;
 }
 
 template <int... I>
-emu_fn pick_mt(int idx, bool eqmode, bool noindel, std::integer_sequence<int, I...>) {
-    emu_fn fns[] = {pick<(I + 1) * ROW_GRAN>(eqmode, noindel)...};
+emu_fn pick_mt(int idx, bool eqmode, bool noindel, bool fast, std::integer_sequence<int, I...>) {
+    emu_fn fns[] = {pick<(I + 1) * ROW_GRAN>(eqmode, noindel, fast)...};
     return fns[idx];
 }
 
@@ -116,13 +184,14 @@ int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens
 }
 
 int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t *lens, int64_t nreads,
-                     int max_len, int16_t *out) {
+                     int max_len, int16_t *out, int filtered) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
     const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
     const bool noindel = a->indel_cost > a->p.k;
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
-    emu_fn fn = pick_mt(idx, eqmode, noindel, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
+    const bool fast = filtered && a->filterable && max_len > 0;
+    emu_fn fn = pick_mt(idx, eqmode, noindel, fast, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
     fn(a, (const uint32_t *)packed, lens, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
     return ATR_OK;
 }

@@ -22,6 +22,12 @@ def test_batches_all_flags(emu_backend, oracle):
     assert _cases.check_batches_against_oracle(Aligner, oracle, _lib.AtroposHipError, 11, 150) > 10000
 
 
+def test_filtered_pipeline(emu_backend, oracle):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 3, 250) > 20000
+
+
 def test_synthetic_heads(emu_backend):
     from atropos_amd import synth
     from atropos_amd.align import Aligner
@@ -29,8 +35,8 @@ def test_synthetic_heads(emu_backend):
     for name in ("C1", "C2"):
         w = synth.workload(name, 0, heads[name]["count"])
         al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
-        got = al.locate_batch(w["reads"]).tuples()
-        assert got == [tup(x) for x in heads[name]["out"]]
+        assert al.locate_batch(w["reads"]).tuples() == [tup(x) for x in heads[name]["out"]]
+        assert al.locate_batch(w["reads"], filtered=False).tuples() == [tup(x) for x in heads[name]["out"]]
 
 
 def test_api_surface(emu_backend, oracle):

@@ -33,6 +33,12 @@ def test_batches_all_flags(hip_backend, oracle):
     assert _cases.check_batches_against_oracle(Aligner, oracle, _lib.AtroposHipError, 23, 300) > 20000
 
 
+def test_filtered_pipeline(hip_backend, oracle):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 41, 600) > 50000
+
+
 def test_every_column_size(hip_backend, oracle):
     """One batch per register-column size (m = 1..128), indel and no-indel kernels,
     equality and wildcard compare modes."""
@@ -46,6 +52,7 @@ def test_every_column_size(hip_backend, oracle):
             al = Aligner(ref, e, 14, wr, False, 3, ic)
             reads = _cases.planted_reads(rng, ref, 96, 220)
             got = al.locate_batch(reads).tuples()
+            assert got == al.locate_batch(reads, filtered=False).tuples()
             for q, g in zip(reads, got):
                 assert g == oracle.locate(ref, q, e, 14, wr, False, 3, ic), (m, ic, wr, q)
 
@@ -86,6 +93,8 @@ def test_c2_sample_and_full_size_properties(hip_backend, oracle):
     batch = al.pack(reads)
     rec = al.locate_batch(batch).records
     torch.cuda.synchronize()
+    # (0) the filtered pipeline and the full sweep agree on all 10 M records
+    assert torch.equal(rec, al.locate_batch(batch, filtered=False).records)
     # (1) slice parity
     lo = 4_321_000
     sl = reads[lo:lo + 200_000].cpu().numpy()
