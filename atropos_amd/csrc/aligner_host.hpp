@@ -57,17 +57,25 @@ inline int aligner_refresh(atr_aligner *a) {
     const int m = p.m;
     const double e = a->max_error_rate;
     const double kd = e * m;
-    if (!(kd < 1000.0) || !(kd > -1.0e9)) return ATR_ERR_UNSUPPORTED;
+    if (!(kd < 256.0) || !(kd > -1.0e9)) return ATR_ERR_UNSUPPORTED;   // the 8-bit mismatch field must hold k
     p.k = (int)kd;                                        // _align.pyx:312
     if (p.k < 0) p.k = -1;                                // negative error rate: nothing can be accepted
     p.flags = a->flags;
     p.min_overlap = a->min_overlap;
     p.indel = a->indel_cost > p.k ? p.k + 1 : a->indel_cost;
     if (p.indel < 1) p.indel = 1;                         // k < 0 only for a negative error rate
-    {   // reference codes by register position: row i lives at position p0 + i
+    {   // mismatch masks by register position: row i (1-based) lives at position p0 + i, and
+        // the row at position p+1 owns bit p
         const int p0 = round_up_rows(m) - m;
-        memset(p.ref, 0, sizeof(p.ref));
-        for (int i = 0; i < m; ++i) p.ref[p0 + i] = a->codes[i];
+        const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
+        memset(p.nmask, 0, sizeof(p.nmask));
+        for (int c = 0; c < 16; ++c)
+            for (int i = 0; i < m; ++i) {
+                const int rc = a->codes[i];
+                const bool same = eqmode ? (rc == c) : ((rc & c) != 0);   // _align.pyx:390-393
+                const int pos = p0 + i;
+                if (!same) p.nmask[c][pos >> 5] |= 1u << (pos & 31);
+            }
     }
     {   // match masks of the bit-parallel pre-pass, and whether it applies
         const bool eqmode = !(a->wildcard_ref || a->wildcard_query);

@@ -35,24 +35,29 @@
 namespace atr {
 
 constexpr int FILTER_MAX_M = 64;
-constexpr int FILTER_BINS = 96;                    // window-start bins of 8 columns (n <= 736)
+constexpr int FILTER_BINS = 192;                   // 96 window-start bins of 8 columns (n <= 736) x {all rows, fewer rows}
 
 struct FilterParams {
     uint64_t peq[16];                               // peq[c] bit i: reference row i+1 matches query code c
 };
 
 // window word written per read by the pre-pass
-//   [9:0] j_lo   [19:10] j_hi   [20] take last-column candidates   [31] valid (needs the DP)
-ATR_DEV uint32_t window_word(int j_lo, int j_hi, bool scan) {
-    return 0x80000000u | (uint32_t)j_lo | ((uint32_t)j_hi << 10) | (scan ? (1u << 20) : 0u);
+//   [9:0] j_lo   [19:10] j_hi   [20] take last-column candidates   [27:21] highest row needed
+//   [31] valid (needs the DP)
+ATR_DEV uint32_t window_word(int j_lo, int j_hi, bool scan, int rows) {
+    return 0x80000000u | (uint32_t)j_lo | ((uint32_t)j_hi << 10) | (scan ? (1u << 20) : 0u) | ((uint32_t)rows << 21);
 }
+ATR_DEV int window_rows(uint32_t w) { return (int)((w >> 21) & 0x7Fu); }
 ATR_DEV int window_lo(uint32_t w) { return (int)(w & 0x3FFu); }
 ATR_DEV int window_hi(uint32_t w) { return (int)((w >> 10) & 0x3FFu); }
 ATR_DEV bool window_scan(uint32_t w) { return ((w >> 20) & 1u) != 0; }
 ATR_DEV bool window_valid(uint32_t w) { return (w >> 31) != 0; }
+// Scatter bin: reads that need every row first (by window start), then the row-limited ones,
+// so that a wave of the window kernel rarely mixes the two kinds.
+ATR_DEV int window_bin(uint32_t w, int m) { return (window_lo(w) >> 3) + (window_rows(w) >= m ? 0 : 96); }
 
 struct FilterState {
-    uint64_t pv, mv;                                // vertical +1 / -1 deltas of the current column
+    uint32_t pvl, pvh, mvl, mvh;                    // vertical +1 / -1 deltas of the current column (lo/hi words)
     int score;                                      // D[m][j]
     int j_first, j_last;                            // first / last column with D[m][j] <= k (0: none)
     int j_exact;                                    // first column with D[m][j] == 0 and j >= m (0: none)
@@ -60,23 +65,47 @@ struct FilterState {
 
 ATR_DEV void filter_init(FilterState &F, const Uniform &u) {
     // column 0: cost i per row (not START_WITHIN_SEQ1) or 0 everywhere (_align.pyx:333-352)
-    F.pv = u.sr ? 0ull : ~0ull;
-    F.mv = 0ull;
+    F.pvl = F.pvh = u.sr ? 0u : ~0u;
+    F.mvl = F.mvh = 0u;
     F.score = u.sr ? 0 : u.m;
     F.j_first = F.j_last = F.j_exact = 0;
 }
 
-// One column of Myers' recurrence (Hyyro's formulation), row-0 delta 0 (free start in the read).
-ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint64_t eq, int j) {
-    const uint64_t xv = eq | F.mv;
-    const uint64_t xh = (((eq & F.pv) + F.pv) ^ F.pv) | eq;
-    uint64_t ph = F.mv | ~(xh | F.pv);
-    uint64_t mh = F.pv & xh;
-    F.score += (int)((ph >> (u.m - 1)) & 1ull) - (int)((mh >> (u.m - 1)) & 1ull);
-    ph <<= 1;
-    mh <<= 1;
-    F.pv = mh | ~(xv | ph);
-    F.mv = ph & xv;
+// One column of Myers' recurrence (Hyyro's formulation), row-0 delta 0 (free start in the
+// read), written on explicit 32-bit halves: gfx950 has no full-rate 64-bit shift or add.
+// WIDE = adapter longer than 32 bases (both words live); otherwise only the low word.
+template <bool WIDE>
+ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, int j) {
+    const uint32_t xvl = eql | F.mvl;
+    const uint32_t tl = eql & F.pvl;
+    const uint32_t sl = tl + F.pvl;
+    const uint32_t xhl = ((sl ^ F.pvl) | eql);
+    uint32_t phl = F.mvl | ~(xhl | F.pvl);
+    uint32_t mhl = F.pvl & xhl;
+    uint32_t xvh = 0, phh = 0, mhh = 0;
+    if (WIDE) {
+        xvh = eqh | F.mvh;
+        const uint32_t th = eqh & F.pvh;
+        const uint32_t sh = th + F.pvh + (sl < tl ? 1u : 0u);          // carry of the low-word add
+        const uint32_t xhh = ((sh ^ F.pvh) | eqh);
+        phh = F.mvh | ~(xhh | F.pvh);
+        mhh = F.pvh & xhh;
+    }
+    const int bit = (u.m - 1) & 31;
+    const uint32_t pw = (WIDE ? phh : phl), mw = (WIDE ? mhh : mhl);
+    F.score += (int)((pw >> bit) & 1u) - (int)((mw >> bit) & 1u);
+    if (WIDE) {
+        phh = (phh << 1) | (phl >> 31);
+        mhh = (mhh << 1) | (mhl >> 31);
+    }
+    phl <<= 1;
+    mhl <<= 1;
+    F.pvl = mhl | ~(xvl | phl);
+    F.mvl = phl & xvl;
+    if (WIDE) {
+        F.pvh = mhh | ~(xvh | phh);
+        F.mvh = phh & xvh;
+    }
     if (F.score <= u.k) {
         if (F.j_first == 0) F.j_first = j;
         F.j_last = j;
@@ -84,16 +113,18 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint64_t eq, int j) {
     }
 }
 
-// Any last-column cell (row first_i..m, column n) that could pass the candidate test?
-// The alignment length is at most the row, the threshold is monotone in the length.
-ATR_DEV bool filter_last_column(const FilterState &F, const Uniform &u, const int16_t *thr) {
-    int d = 0;                                      // D[0][n] = 0
-    bool any = (u.er && 0 >= u.min_overlap && 0 <= (int)thr[0]);   // row 0 never qualifies (min_overlap >= 1)
+// Last column (column n): which rows could pass the candidate test?  The alignment length is
+// at most the row and the threshold is monotone in the length, so D[i][n] <= thr[i] is a
+// necessary condition.  Returns the largest such row (0: none) and its cost.
+ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const int16_t *thr, int &cost_of_largest) {
+    int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
+    cost_of_largest = 0;
     for (int i = 1; i <= u.m; ++i) {
-        d += (int)((F.pv >> (i - 1)) & 1ull) - (int)((F.mv >> (i - 1)) & 1ull);
-        if ((u.er || i == u.m) && i >= u.min_overlap && d <= (int)thr[i]) any = true;
+        const uint32_t pw = (i <= 32) ? F.pvl : F.pvh, mw = (i <= 32) ? F.mvl : F.mvh;
+        d += (int)((pw >> ((i - 1) & 31)) & 1u) - (int)((mw >> ((i - 1) & 31)) & 1u);
+        if ((u.er || i == u.m) && i >= u.min_overlap && d <= (int)thr[i]) { largest = i; cost_of_largest = d; }
     }
-    return any;
+    return largest;
 }
 
 // Decision for one read of length n after the sweep.  Returns the window word (0 when the
@@ -108,13 +139,34 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, int n, co
         rec[2] = (uint32_t)u.m;                                         // matches m, errors 0
         return 0;
     }
-    const bool lastcol = filter_last_column(F, u, thr);
+    int cost_l = 0;
+    const int row_l = filter_last_column(F, u, thr, cost_l);
+    const bool lastcol = row_l != 0;
     const bool rowm = F.j_first != 0 && u.m >= u.min_overlap;
     if (!lastcol && !rowm) return 0;
-    const int first = rowm ? F.j_first : n;
-    const int j_lo = atr_max(0, first - u.m - u.k);
+    if (!rowm && !u.sr && cost_l == 0) {
+        // The only acceptable cells sit in the last column, and the longest of them is a
+        // perfect overlap of row_l bases: a zero-cost cell is a pure diagonal, so its payload is
+        // (matches row_l, origin n - row_l); every other acceptable cell lies in a smaller
+        // row and therefore has fewer matches -> this cell wins (_align.pyx:464-474).
+        rec[0] = (uint32_t)row_l << 16;
+        rec[1] = (uint32_t)(n - row_l) | ((uint32_t)n << 16);
+        rec[2] = (uint32_t)row_l;
+        return 0;
+    }
+    // Window start: a cell (i, j) of cost c is reached from row 0 at a column >= j - i - (number
+    // of deletions on its path), and that number is at most c (unit indel cost: c is the
+    // exact D) or k.  Row-m candidates: the first one bounds them all (j - D[m][j] never
+    // decreases with j).  Last-column candidates: row + D never decreases with the row, so
+    // the largest acceptable row bounds them all.
+    int j_lo = 0x7fffffff;
+    if (rowm) j_lo = F.j_first - u.m - u.k;
+    if (lastcol) j_lo = atr_min(j_lo, n - row_l - (u.indel == 1 ? cost_l : u.k));
+    j_lo = atr_max(0, j_lo);
     const int j_hi = lastcol ? n : F.j_last;
-    return window_word(j_lo, j_hi, lastcol);
+    // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
+    // last-column row can matter (a row only depends on the rows before it)
+    return window_word(j_lo, j_hi, lastcol, rowm ? u.m : row_l);
 }
 
 }  // namespace atr

@@ -11,10 +11,18 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     FastWork wk = fast_carve(work, nreads);
     FilterParams fp;
     memcpy(fp.peq, a->peq, sizeof(fp.peq));
-    hipLaunchKernelGGL(filter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, a->p, fp, packed, lens, nreads, nchunks,
-                       max_len, out, wk);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, wk);
-    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, wk);
+    const bool wide = a->p.m > 32, ragged = lens != nullptr;
+    const dim3 grid(FAST_BLOCKS), block(256);
+    if (wide) {
+        if (ragged) hipLaunchKernelGGL((filter_kernel<true, true>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
+        else        hipLaunchKernelGGL((filter_kernel<true, false>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
+    } else {
+        if (ragged) hipLaunchKernelGGL((filter_kernel<false, true>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
+        else        hipLaunchKernelGGL((filter_kernel<false, false>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
+    }
+    hipLaunchKernelGGL(scan_bins_kernel, dim3(FILTER_BINS), dim3(1024), 0, st, wk);
+    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
+    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, wk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     typedef window_launcher (*group_fn)(int);

@@ -43,7 +43,9 @@
 #ifndef ATR_DEV
 #define ATR_DEV static inline
 #endif
+#ifndef ATR_DEV_MEMBER
 #define ATR_DEV_MEMBER inline
+#endif
 static inline uint32_t atr_bfrev(uint32_t v) {
     v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
     v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
@@ -58,7 +60,9 @@ static inline int atr_imax(int a, int b) { return a > b ? a : b; }
 #ifndef ATR_DEV
 #define ATR_DEV __device__ __forceinline__
 #endif
+#ifndef ATR_DEV_MEMBER
 #define ATR_DEV_MEMBER __device__ __forceinline__
+#endif
 #define atr_bfrev __brev
 #define atr_popc __popc
 #define atr_imin min

@@ -10,7 +10,14 @@
 //     product library (libatropos_hip.so) contains the GPU build and nothing else.
 //
 // Cell word (one 32-bit VGPR per DP cell):
-//     [31:20] cost | [19:18] tie-break priority | [17:10] matches | [9:0] origin + 256
+//     [31:20] cost | [19:18] tie-break priority | [17:10] matches OR mismatches | [9:0] origin + 256
+// With STOP_WITHIN_SEQ2 (every adapter type but the anchored 3' one) the payload counts the
+// diagonal MISMATCHES x of the chosen path instead of its matches: a matching diagonal step
+// then leaves the word unchanged and a mismatching one adds COST1 + X1, i.e. the diagonal
+// candidate is one v_bfe_u32 (the row's bit of the column's mismatch mask) and one
+// v_mad_u32_u24.  The matches are recovered only when a cell is actually considered as a
+// candidate: rows R and columns C consumed since the path's start, cost = x + c*(a + b),
+// R - C = a - b  =>  insertions a, diagonal steps R - a, matches R - a - x.
 // The reference's three-way choice with its tie order (mismatch <= insertion <=
 // deletion, _align.pyx:405-419) becomes ONE v_min3_u32: the three candidates carry
 // priority 0/1/2 just below the cost field, the payload (matches, origin) rides in
@@ -23,14 +30,34 @@
 
 #ifdef ATR_HOST_EMU
 #define ATR_DEV static inline
+#ifndef ATR_DEV_MEMBER
+#define ATR_DEV_MEMBER inline
+#endif
 static inline int atr_min(int a, int b) { return a < b ? a : b; }
 static inline int atr_max(int a, int b) { return a > b ? a : b; }
 static inline uint32_t atr_minu(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline uint32_t atr_mad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
+static inline uint32_t atr_bfe1(uint32_t w, int i) { return (w >> i) & 1u; }
 #else
 #define ATR_DEV __device__ __forceinline__
+#ifndef ATR_DEV_MEMBER
+#define ATR_DEV_MEMBER __device__ __forceinline__
+#endif
 #define atr_min min
 #define atr_max max
 #define atr_minu min
+// bit i of w as 0/1, and a*b+c with a 24-bit product: written as inline asm because hipcc
+// otherwise rewrites the 0/1 multiply into and + cmp + cndmask + add
+static __device__ __forceinline__ uint32_t atr_bfe1(uint32_t w, int i) {
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "i"(i));
+    return r;
+}
+static __device__ __forceinline__ uint32_t atr_mad24(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 #endif
 
 namespace atr {
@@ -39,6 +66,7 @@ constexpr int MSH = 10, PSH = 18, CSH = 20;
 constexpr uint32_t ORG_BIAS = 256;
 constexpr uint32_t ORG_MASK = 0x3FFu, MAT_MASK = 0xFFu;
 constexpr uint32_t COST1 = 1u << CSH, MATCH1 = 1u << MSH;
+constexpr uint32_t DIAG_DELTA = COST1 - MATCH1;      // mismatch instead of match on the diagonal (fits 24 bits)
 constexpr uint32_t PRIO_INS = 1u << PSH, PRIO_DEL = 2u << PSH, PRIO_MASK = 3u << PSH;
 constexpr int COST_FIELD_MAX = 4095;
 constexpr int INIT_COST_CAP = 2047;       // saturated initial-column cost (always > k)
@@ -47,7 +75,11 @@ constexpr int ROW_GRAN = 4;               // register-column sizes come in multi
 // Wave-uniform description of one aligner; passed by value as a kernel argument so
 // that the adapter codes sit in SGPRs.
 struct LocateParams {
-    uint8_t ref[ATR_MAX_REF_LEN];         // 4-bit codes by column position (front-padded, see column_step)
+    // nmask[c] : 128-bit mask over column positions, bit p set <=> the reference row sitting at
+    // position p+1 does NOT match query code c (byte equality or 4-bit AND, decided by the
+    // host).  Staged in LDS; a lane fetches the mask of its query code once per column and
+    // every row tests its own bit, so no per-row scalar state is needed.
+    uint32_t nmask[16][4];
     int16_t thr[ATR_MAX_REF_LEN + 2];     // thr[L] = floor(L * max_error_rate), clamped; -1 = accept nothing
     int m, flags, k, min_overlap, indel;  // indel = effective cost, min(indel_cost, k+1)
 };
@@ -55,20 +87,29 @@ struct LocateParams {
 struct Best {
     int key;            // (matches << 12) | (4095 - cost): "more matches, then fewer errors"
     uint32_t word;      // winning cell
-    int ref_stop, query_stop;
+    int ref_stop, query_stop, matches;
 };
 
-// Candidate test of _align.pyx:440-455 / :464-474.
+// Candidate test of _align.pyx:440-455 / :464-474.  XREP: the payload field holds the
+// diagonal mismatches (see the header); indel = the aligner's effective indel cost, 0 for
+// the no-indel kernels.
+template <bool XREP>
 ATR_DEV void consider(Best &b, uint32_t w, int ref_stop, int query_stop, int min_overlap,
-                      const int16_t *thr) {
+                      const int16_t *thr, int indel) {
     const int cost = (int)(w >> CSH);
     const int origin = (int)(w & ORG_MASK) - (int)ORG_BIAS;
-    const int matches = (int)((w >> MSH) & MAT_MASK);
     const int length = ref_stop + atr_min(origin, 0);
     if (length >= min_overlap && cost <= (int)thr[atr_max(length, 0)]) {
+        int matches = (int)((w >> MSH) & MAT_MASK);
+        if (XREP) {
+            const int x = matches;
+            const int cols = query_stop - atr_max(origin, 0);
+            const int a = indel > 0 ? (((cost - x) / indel + length - cols) >> 1) : 0;
+            matches = length - a - x;
+        }
         const int key = (matches << 12) | (COST_FIELD_MAX - cost);
         if (key > b.key) {                                    // strict: first seen wins ties
-            b.key = key; b.word = w; b.ref_stop = ref_stop; b.query_stop = query_stop;
+            b.key = key; b.word = w; b.ref_stop = ref_stop; b.query_stop = query_stop; b.matches = matches;
         }
     }
 }
@@ -84,7 +125,8 @@ ATR_DEV uint32_t init_word(int i, int min_n, bool sr, bool sq, int indel) {
     return ((uint32_t)atr_min(cost, INIT_COST_CAP) << CSH) | (uint32_t)(origin + (int)ORG_BIAS);
 }
 
-// One DP column over MT register-resident positions.  The adapter occupies the LAST m
+// One DP column over MT register-resident positions; nm = this lane's mismatch mask for the
+// column's query code (LocateParams::nmask).  The adapter occupies the LAST m
 // positions (row i sits at position p0 + i, p0 = MT - m in 0..ROW_GRAN-1), so row m is
 // always col[MT] and the code is straight-line: positions below p0 compute don't-care
 // cells that nothing above depends on, and position p0 is overwritten with the row-0
@@ -94,24 +136,23 @@ ATR_DEV uint32_t init_word(int i, int min_n, bool sr, bool sq, int indel) {
 // neighbouring cells differ by at most one indel, diag.cost <= left/up cost + indel,
 // and the priority bits break that tie for the diagonal, so one v_min3 serves both
 // the "equal" and the "three-way choice" case.  Returns the new cell of row m.
-template <int MT, bool EQ, bool NOINDEL>
-ATR_DEV uint32_t column_step(uint32_t (&col)[MT + 1], const LocateParams &p, int p0, uint32_t q,
-                             uint32_t row0, uint32_t insw, uint32_t delw) {
-    uint32_t cd;
-    {
-        const uint32_t rc = p.ref[0];
-        const bool same = EQ ? (rc == q) : ((rc & q) != 0);   // _align.pyx:390-393
-        cd = col[0] + (same ? MATCH1 : COST1);
-    }
+// Diagonal candidate of the row at position i+1: old cell i plus MATCH1, or plus COST1 when
+// bit i of the mismatch mask is set (v_bfe_u32 + v_mad_u32_u24).
+template <bool XREP, int W>
+ATR_DEV uint32_t diag_candidate(uint32_t cell, const uint32_t (&nm)[W], int i) {
+    const uint32_t bit = atr_bfe1(nm[i >> 5], i & 31);
+    return XREP ? atr_mad24(bit, COST1 + MATCH1, cell) : atr_mad24(bit, DIAG_DELTA, cell + MATCH1);
+}
+
+template <int MT, bool NOINDEL, bool XREP>
+ATR_DEV uint32_t column_step(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) / 32], int p0, uint32_t row0,
+                             uint32_t insw, uint32_t delw) {
+    uint32_t cd = diag_candidate<XREP>(col[0], nm, 0);
     col[0] = row0;
 #pragma unroll
     for (int i = 1; i <= MT; ++i) {
         uint32_t cd_next = 0;
-        if (i < MT) {
-            const uint32_t rc = p.ref[i];                    // SGPR (kernel argument)
-            const bool same = EQ ? (rc == q) : ((rc & q) != 0);
-            cd_next = col[i] + (same ? MATCH1 : COST1);
-        }
+        if (i < MT) cd_next = diag_candidate<XREP>(col[i], nm, i);
         uint32_t nw;
         if (NOINDEL) {
             nw = cd;
@@ -127,13 +168,51 @@ ATR_DEV uint32_t column_step(uint32_t (&col)[MT + 1], const LocateParams &p, int
     return col[MT];
 }
 
+// Row-limited variant for the window DP: rows above `plimit` (a wave-uniform POSITION) are
+// not needed -- rows only depend on the rows before them -- so the sweep stops at the first
+// block of four positions that starts beyond it.  Nested ifs (template recursion), so that
+// nothing is live across a skipped block and every cell is still updated in place.
+template <int MT, bool NOINDEL, bool XREP, int B>
+ATR_DEV void row_blocks(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) / 32], int p0, uint32_t row0,
+                        uint32_t insw, uint32_t delw, uint32_t cd, int plimit) {
+    if constexpr (B < MT / 4) {
+        if (4 * B + 1 > plimit) return;                          // wave-uniform
+#pragma unroll
+        for (int i = 4 * B + 1; i <= 4 * B + 4; ++i) {
+            uint32_t cd_next = 0;
+            if (i < MT) cd_next = diag_candidate<XREP>(col[i], nm, i);
+            uint32_t nw;
+            if (NOINDEL) {
+                nw = cd;
+            } else {
+                const uint32_t cl = col[i] + delw;
+                const uint32_t cu = col[i - 1] + insw;
+                nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+            }
+            if (i < ROW_GRAN) nw = (i == p0) ? row0 : nw;
+            col[i] = nw;
+            cd = cd_next;
+        }
+        row_blocks<MT, NOINDEL, XREP, B + 1>(col, nm, p0, row0, insw, delw, cd, plimit);
+    }
+}
+
+template <int MT, bool NOINDEL, bool XREP>
+ATR_DEV uint32_t column_step_limited(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) / 32], int p0,
+                                     uint32_t row0, uint32_t insw, uint32_t delw, int plimit) {
+    const uint32_t cd = diag_candidate<XREP>(col[0], nm, 0);
+    col[0] = row0;
+    row_blocks<MT, NOINDEL, XREP, 0>(col, nm, p0, row0, insw, delw, cd, plimit);
+    return col[MT];
+}
+
 // Last-column candidates (_align.pyx:461-474): every row from first_i on, increasing.
-template <int MT>
+template <int MT, bool XREP>
 ATR_DEV void scan_last_column(Best &best, const uint32_t (&col)[MT + 1], int p0, int first_p, int n,
-                              int min_overlap, const int16_t *thr) {
+                              int min_overlap, const int16_t *thr, int indel) {
 #pragma unroll
     for (int i = 0; i <= MT; ++i) {
-        if (i >= first_p) consider(best, col[i], i - p0, n, min_overlap, thr);
+        if (i >= first_p) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel);
     }
 }
 
@@ -169,13 +248,14 @@ ATR_DEV Uniform make_uniform(const LocateParams &p, int MT) {
 
 // Window, initial column and "no match yet" state of one read of length n.
 // s_init holds the min_n == 0 initial column (by position).
-template <int MT>
+// XREP (== STOP_WITHIN_SEQ2 set): min_n is 0 and the payload counts mismatches.
+template <int MT, bool NOINDEL, bool XREP>
 ATR_DEV void lane_init(LaneState<MT> &L, const Uniform &u, int n, const uint32_t *s_init, const int16_t *thr) {
     L.n = n;
     L.max_n = u.sq ? n : atr_min(n, u.m + u.k);              // _align.pyx:314-321
-    L.min_n = u.eq ? 0 : atr_max(0, n - u.m - u.k);
+    L.min_n = XREP ? 0 : atr_max(0, n - u.m - u.k);
     L.scan = (L.max_n == n);                                 // :461
-    if (u.eq) {
+    if (XREP) {
 #pragma unroll
         for (int i = 0; i <= MT; ++i) L.col[i] = s_init[i];
     } else {
@@ -184,9 +264,10 @@ ATR_DEV void lane_init(LaneState<MT> &L, const Uniform &u, int n, const uint32_t
     }
     L.best.key = COST_FIELD_MAX - (u.m + n);                 // (matches 0, cost m+n): :358-363
     L.best.word = (uint32_t)(u.m + n) << CSH;
-    L.best.ref_stop = u.m; L.best.query_stop = n;
+    L.best.ref_stop = u.m; L.best.query_stop = n; L.best.matches = 0;
     // Empty reads never enter the column loop: their "last column" is the initial one.
-    if (L.scan && n == 0) scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr);
+    if (L.scan && n == 0)
+        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel);
 }
 
 // Window mode (filter_core.hpp): the DP is started afresh at column j_lo as if row i had
@@ -197,22 +278,26 @@ ATR_DEV uint32_t window_init_word(int i, int j_lo, int indel) {
     return ((uint32_t)cost << CSH) | (uint32_t)(j_lo + (int)ORG_BIAS);
 }
 
-template <int MT>
-ATR_DEV void lane_init_window(LaneState<MT> &L, const Uniform &u, int n, int j_lo, int j_hi, bool scan,
+// All lanes of a wave start at the SAME column j_start (the smallest window start in the
+// wave): starting earlier than a read's own window start is just as exact, and it makes
+// the initial column wave-uniform.
+template <int MT, bool NOINDEL>
+ATR_DEV void lane_init_window(LaneState<MT> &L, const Uniform &u, int n, int j_start, int j_hi, bool scan,
                               const uint32_t *s_init, const int16_t *thr) {
-    L.n = n; L.min_n = j_lo; L.max_n = j_hi; L.scan = scan;
-    if (j_lo == 0) {
+    L.n = n; L.min_n = j_start; L.max_n = j_hi; L.scan = scan;
+    if (j_start == 0) {
 #pragma unroll
         for (int i = 0; i <= MT; ++i) L.col[i] = s_init[i];
     } else {
 #pragma unroll
-        for (int i = 0; i <= MT; ++i) L.col[i] = window_init_word(i - u.p0, j_lo, u.indel);
+        for (int i = 0; i <= MT; ++i) L.col[i] = window_init_word(i - u.p0, j_start, u.indel);
     }
     L.best.key = COST_FIELD_MAX - (u.m + n);
     L.best.word = (uint32_t)(u.m + n) << CSH;
-    L.best.ref_stop = u.m; L.best.query_stop = n;
+    L.best.ref_stop = u.m; L.best.query_stop = n; L.best.matches = 0;
     // an empty window only arises for an empty read whose initial column already qualifies
-    if (scan && j_hi <= j_lo) scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr);
+    if (scan && j_hi <= j_start)
+        scan_last_column<MT, true>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel);
 }
 
 // Column j of the wave-uniform sweep, query code q.  Every lane of the wave executes
@@ -222,30 +307,27 @@ ATR_DEV void lane_init_window(LaneState<MT> &L, const Uniform &u, int n, int j_l
 //   * takes its last-column candidates when the sweep reaches its max_n,
 //   * ignores row-m candidates outside its window,
 // and whatever it computes past max_n is never looked at.
-template <int MT, bool EQ, bool NOINDEL, bool WIN = false>
-ATR_DEV void lane_step(LaneState<MT> &L, const LocateParams &p, const Uniform &u, int j, uint32_t q,
-                       const int16_t *thr) {
+template <int MT, bool NOINDEL, bool XREP, bool WIN = false>
+ATR_DEV void lane_step(LaneState<MT> &L, const Uniform &u, int j, const uint32_t (&nm)[(MT + 31) / 32],
+                       const int16_t *thr, int plimit = MT) {
+    const int indel = NOINDEL ? 0 : u.indel;
     // row 0 (:385-388): origin j, or cost j*indel (saturated: it is > k long before).
     // Matches 0; without START_WITHIN_SEQ2 the row-0 origin is 0 in every init case.
     const uint32_t row0 = u.sq ? (ORG_BIAS + (uint32_t)j)
                                : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
-    const uint32_t wm = column_step<MT, EQ, NOINDEL>(L.col, p, u.p0, q, row0, u.insw, u.delw);
+    const uint32_t wm = WIN ? column_step_limited<MT, NOINDEL, XREP>(L.col, nm, u.p0, row0, u.insw, u.delw, plimit)
+                            : column_step<MT, NOINDEL, XREP>(L.col, nm, u.p0, row0, u.insw, u.delw);
     if (WIN) {
-        // window mode: candidates only inside (j_lo, j_hi]; a lane whose window starts later
-        // than the wave's sweep is restarted when the sweep reaches its j_lo
-        if (wm < u.klimit && j <= L.max_n && j > L.min_n) consider(L.best, wm, u.m, j, u.min_overlap, thr);
-        if (j == L.min_n) {
-            int lo = L.min_n;
-#ifndef ATR_HOST_EMU
-            asm volatile("" : "+v"(lo));
-#endif
-#pragma unroll
-            for (int i = 0; i <= MT; ++i) L.col[i] = window_init_word(i - u.p0, lo, u.indel);
-        }
-    } else if (u.eq) {
+        // window mode: the sweep starts at the wave's common start column; a read has no
+        // acceptable cell before its own window (the pre-pass saw none), so only the upper
+        // end needs a per-lane test.  Row m is only swept when some lane of the wave needs it;
+        // a lane that does not has no row-m candidate anyway.
+        if (plimit == MT && wm < u.klimit && j <= L.max_n)
+            consider<XREP>(L.best, wm, u.m, j, u.min_overlap, thr, indel);
+    } else if (XREP) {
         // row-m candidate: the reference looks at it only when the band reached row m,
         // i.e. cost <= k (:433-455); min_n is 0 here.
-        if (wm < u.klimit && j <= L.max_n) consider(L.best, wm, u.m, j, u.min_overlap, thr);
+        if (wm < u.klimit && j <= L.max_n) consider<XREP>(L.best, wm, u.m, j, u.min_overlap, thr, indel);
     } else if (j == L.min_n && L.max_n > L.min_n) {
         int mn = L.min_n;
 #ifndef ATR_HOST_EMU
@@ -255,7 +337,7 @@ ATR_DEV void lane_step(LaneState<MT> &L, const LocateParams &p, const Uniform &u
         for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, mn, u.sr, u.sq, u.indel);
     }
     if (L.scan && j == L.max_n && L.max_n > L.min_n)
-        scan_last_column<MT>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr);
+        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel);
 }
 
 // (refstart, refstop, querystart, querystop, matches, errors, 0, 0) as 8 x int16.
@@ -267,7 +349,7 @@ ATR_DEV void lane_result(const LaneState<MT> &L, const Uniform &u, uint32_t rec[
         const int origin = (int)(L.best.word & ORG_MASK) - (int)ORG_BIAS;
         if (origin >= 0) querystart = origin; else refstart = -origin;
         refstop = L.best.ref_stop; querystop = L.best.query_stop;
-        matches = (int)((L.best.word >> MSH) & MAT_MASK); errors = cost;
+        matches = L.best.matches; errors = cost;
     }
     rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
     rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);

@@ -15,6 +15,7 @@
 #ifndef ATR_LOCATE_FAST_HPP
 #define ATR_LOCATE_FAST_HPP
 
+#include <algorithm>
 #include "locate_kernel.hpp"
 #include "filter_core.hpp"
 
@@ -25,12 +26,13 @@ constexpr int FAST_BLOCKS = 2048;                   // persistent grid of K1 / K
 struct FastWork {                                    // carve-up of the caller's workspace
     uint32_t *win;                                   // [nreads]
     uint32_t *order;                                 // [nreads]
-    uint32_t *counts;                                // [FAST_BLOCKS][FILTER_BINS] -> offsets after K2
+    uint32_t *counts;                                // [FILTER_BINS][FAST_BLOCKS] -> in-bin offsets after K2a
+    uint32_t *binbase;                               // [FILTER_BINS] first slot of each bin after K2b
     uint32_t *total;                                 // [1] number of unresolved reads
 };
 
 inline size_t fast_work_bytes(long long nreads) {
-    return (size_t)nreads * 8 + (size_t)FAST_BLOCKS * FILTER_BINS * 4 + 256;
+    return (size_t)nreads * 8 + (size_t)FAST_BLOCKS * FILTER_BINS * 4 + FILTER_BINS * 4 + 256;
 }
 
 inline FastWork fast_carve(void *work, long long nreads) {
@@ -38,7 +40,8 @@ inline FastWork fast_carve(void *work, long long nreads) {
     w.win = (uint32_t *)work;
     w.order = w.win + nreads;
     w.counts = w.order + nreads;
-    w.total = w.counts + (size_t)FAST_BLOCKS * FILTER_BINS;
+    w.binbase = w.counts + (size_t)FAST_BLOCKS * FILTER_BINS;
+    w.total = w.binbase + FILTER_BINS;
     return w;
 }
 
@@ -50,16 +53,19 @@ __device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, lon
 }
 
 #ifdef ATR_DEFINE_FILTER_KERNELS   // K1..K3 are defined once, in filter_kernels.hip
+// WIDE: adapter longer than 32 bases.  RAGGED: reads of different lengths in the batch
+// (a lane stops updating its state after its own last column).
+template <bool WIDE, bool RAGGED>
 __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const FilterParams fp,
                                                      const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads, int nchunks,
                                                      int max_len, uint4 *__restrict__ out, FastWork wk) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
-    __shared__ uint64_t s_peq[16];
+    __shared__ uint2 s_peq[16];
     __shared__ uint32_t s_hist[FILTER_BINS];
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
     for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
-    if (threadIdx.x < 16) s_peq[threadIdx.x] = fp.peq[threadIdx.x];
+    if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
     if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
     __syncthreads();
 
@@ -70,10 +76,10 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
     for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
         const bool live = r < nreads;
-        const int n = live ? (lens ? lens[r] : max_len) : 0;
+        const int n = live ? (RAGGED ? lens[r] : max_len) : 0;
         FilterState F;
         filter_init(F, u);
-        const int jhi = wave_max_i32(n);
+        const int jhi = RAGGED ? wave_max_i32(n) : max_len;
         const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
         if (jhi > 0) {
             const int c1 = (jhi + 31) >> 5;
@@ -86,13 +92,17 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                 for (int d = 0; d < 4; ++d) {
                     uint32_t w = cur.x;
                     cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
-#pragma unroll 1
+                    // the eight match masks of this dword are fetched from LDS up front so that
+                    // their latency overlaps the (serially dependent) column updates
+                    uint2 e[8];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) e[b] = s_peq[(w >> (4 * b)) & 15u];
+#pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         ++j;
-                        const uint32_t q = w & 15u;
-                        w >>= 4;
-                        if (j <= n) filter_step(F, u, s_peq[q], j);
+                        if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, j);
                     }
+                    if (j >= jhi) break;                     // wave-uniform
                 }
             }
         }
@@ -101,110 +111,124 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
             const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
             wk.win[r] = ww;
             if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-            else atomicAdd(&s_hist[window_lo(ww) >> 3], 1u);
+            else atomicAdd(&s_hist[window_bin(ww, u.m)], 1u);
         }
     }
     __syncthreads();
-    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] = s_hist[threadIdx.x];
+    // counts are stored bin-major ([bin][block]) so that K2 scans contiguous runs
+    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)threadIdx.x * FAST_BLOCKS + blockIdx.x] = s_hist[threadIdx.x];
 }
 
-// offsets[block][bin] = number of unresolved reads in earlier bins, plus those of the same
-// bin in earlier blocks.  One block of FILTER_BINS*... threads is plenty (196 k counters).
-__global__ __launch_bounds__(1024) void scan_kernel(FastWork wk) {
-    __shared__ uint32_t s_bin[FILTER_BINS];
-    // per-bin totals: thread b sums its column
-    for (int b = threadIdx.x; b < FILTER_BINS; b += 1024) {
-        uint32_t tot = 0;
-        for (int k = 0; k < FAST_BLOCKS; ++k) tot += wk.counts[(size_t)k * FILTER_BINS + b];
-        s_bin[b] = tot;
-    }
+// K2a: one block per bin: exclusive scan of that bin's FAST_BLOCKS per-block counts (in
+// place) and the bin's total.  K2b: exclusive scan of the bin totals -> bin bases.
+__global__ __launch_bounds__(1024) void scan_bins_kernel(FastWork wk) {
+    __shared__ uint32_t s_part[1024];
+    constexpr int PER = FAST_BLOCKS / 1024;
+    uint32_t *row = wk.counts + (size_t)blockIdx.x * FAST_BLOCKS;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { v[t] = row[threadIdx.x * PER + t]; sum += v[t]; }
+    s_part[threadIdx.x] = sum;
     __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
+        const uint32_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;
+#pragma unroll
+    for (int t = 0; t < PER; ++t) { row[threadIdx.x * PER + t] = run; run += v[t]; }
+    if (threadIdx.x == 1023) wk.binbase[blockIdx.x] = s_part[1023];     // bin total (rebased by K2b)
+}
+
+__global__ __launch_bounds__(256) void scan_total_kernel(FastWork wk) {
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int b = 0; b < FILTER_BINS; ++b) { const uint32_t t = s_bin[b]; s_bin[b] = run; run += t; }
+        for (int b = 0; b < FILTER_BINS; ++b) { const uint32_t t = wk.binbase[b]; wk.binbase[b] = run; run += t; }
         wk.total[0] = run;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < FILTER_BINS; b += 1024) {
-        uint32_t run = s_bin[b];
-        for (int k = 0; k < FAST_BLOCKS; ++k) {
-            const uint32_t c = wk.counts[(size_t)k * FILTER_BINS + b];
-            wk.counts[(size_t)k * FILTER_BINS + b] = run;
-            run += c;
-        }
     }
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(long long nreads, FastWork wk) {
+__global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, FastWork wk) {
     __shared__ uint32_t s_cur[FILTER_BINS];
-    if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] = wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x];
+    if (threadIdx.x < FILTER_BINS)
+        s_cur[threadIdx.x] = wk.binbase[threadIdx.x] + wk.counts[(size_t)threadIdx.x * FAST_BLOCKS + blockIdx.x];
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
     block_tiles(ntiles, t0, t1);
     for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
         const uint32_t ww = wk.win[r];
-        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_lo(ww) >> 3], 1u)] = (uint32_t)r;
+        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m)], 1u)] = (uint32_t)r;
     }
 }
-
 #endif  // ATR_DEFINE_FILTER_KERNELS
 
-template <int MT, bool EQ, bool NOINDEL>
+template <int MT, bool NOINDEL>
 __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads,
                                                      int nchunks, int max_len, uint4 *__restrict__ out, FastWork wk) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_init[ATR_MAX_REF_LEN + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t s_nm[16][4];
     const Uniform u = make_uniform(p, MT);
+    if (threadIdx.x < 64) s_nm[threadIdx.x >> 2][threadIdx.x & 3] = p.nmask[threadIdx.x >> 2][threadIdx.x & 3];
     for (int i = threadIdx.x; i <= MT + 1; i += 256) {
         if (i <= u.m + 1) s_thr[i] = p.thr[i];
         if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
     }
     __syncthreads();
     const long long total = (long long)wk.total[0];
-    const long long slot = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 >= total) return;     // whole wave
-    const bool live = slot < total;
-    const long long r = live ? (long long)wk.order[slot] : 0;
-    const uint32_t ww = live ? wk.win[r] : 0u;
-    const int n = live ? (lens ? lens[r] : max_len) : 0;
-    const int j_lo = window_lo(ww), j_hi = live ? window_hi(ww) : 0;
+    const int lane = threadIdx.x & 63;
+    const long long nwaves = (total + 63) >> 6;
+    // persistent grid: each wave takes every (gridDim*4)-th group of 64 slots of `order`
+    for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwaves; wv += (long long)gridDim.x * 4) {
+        const long long slot = wv * 64 + lane;
+        const bool live = slot < total;
+        const long long r = live ? (long long)wk.order[slot] : 0;
+        const uint32_t ww = live ? wk.win[r] : 0u;
+        const int n = live ? (lens ? lens[r] : max_len) : 0;
+        const int j_lo = window_lo(ww), j_hi = live ? window_hi(ww) : 0;
+        const bool has_window = live && j_hi > j_lo;
+        const int jlo = wave_min_i32(live ? j_lo : 0x7fffffff);          // common start column
+        const int jhi = wave_max_i32(has_window ? j_hi : 0);
+        const int plimit = u.p0 + wave_max_i32(live ? window_rows(ww) : 0);   // highest position any lane needs
 
-    LaneState<MT> L;
-    lane_init_window<MT>(L, u, n, j_lo, j_hi, live && window_scan(ww), s_init, s_thr);
+        LaneState<MT> L;
+        lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
 
-    const bool has_window = live && j_hi > j_lo;
-    const int jlo = wave_min_i32(has_window ? j_lo : 0x7fffffff);
-    const int jhi = wave_max_i32(has_window ? j_hi : 0);
-    // this lane's read inside the tile64 layout (gathered: 16 bytes per lane per chunk)
-    const uint4 *tp = packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63);
-    if (jhi > jlo) {
-        const int c0 = jlo >> 5, c1 = (jhi + 31) >> 5;
-        uint4 nxt = tp[(size_t)c0 * 64];
-        for (int c = c0; c < c1; ++c) {
-            uint4 cur = nxt;
-            if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
-            int j = c * 32;
+        // this lane's read inside the tile64 layout (gathered: 16 bytes per lane per chunk)
+        const uint4 *tp = packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63);
+        if (jhi > jlo) {
+            const int c0 = jlo >> 5, c1 = (jhi + 31) >> 5;
+            uint4 nxt = tp[(size_t)c0 * 64];
+            for (int c = c0; c < c1; ++c) {
+                uint4 cur = nxt;
+                if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
+                int j = c * 32;
 #pragma unroll 1
-            for (int d = 0; d < 4; ++d) {
-                uint32_t w = cur.x;
-                cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+                for (int d = 0; d < 4; ++d) {
+                    uint32_t w = cur.x;
+                    cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
 #pragma unroll 1
-                for (int b = 0; b < 8; ++b) {
-                    ++j;
-                    const uint32_t q = w & 15u;
-                    w >>= 4;
-                    if (j <= jlo || j > jhi) continue;
-                    lane_step<MT, EQ, NOINDEL, true>(L, p, u, j, q, s_thr);
+                    for (int b = 0; b < 8; ++b) {
+                        ++j;
+                        const uint32_t q = w & 15u;
+                        w >>= 4;
+                        if (j <= jlo || j > jhi) continue;
+                        uint32_t nm[(MT + 31) / 32];
+                        load_mask(nm, s_nm, q);
+                        lane_step<MT, NOINDEL, true, true>(L, u, j, nm, s_thr, plimit);
+                    }
                 }
             }
         }
-    }
-    if (live) {
-        uint32_t rec[4];
-        lane_result<MT>(L, u, rec);
-        out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        if (live) {
+            uint32_t rec[4];
+            lane_result<MT>(L, u, rec);
+            out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        }
     }
 }
 
@@ -214,16 +238,10 @@ typedef int (*window_launcher)(const atr_aligner *, const uint4 *, const int32_t
 template <int MT>
 int launch_window_mt(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                      int max_len, uint4 *out, FastWork wk, hipStream_t st) {
-    const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
     const bool noindel = a->indel_cost > a->p.k;
-    const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
-    if (eqmode) {
-        if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
-        else         hipLaunchKernelGGL((window_kernel<MT, true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
-    } else {
-        if (noindel) hipLaunchKernelGGL((window_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
-        else         hipLaunchKernelGGL((window_kernel<MT, false, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
-    }
+    const dim3 grid((unsigned)std::min<long long>((nreads + 255) / 256, 4096)), block(256);
+    if (noindel) hipLaunchKernelGGL((window_kernel<MT, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
+    else         hipLaunchKernelGGL((window_kernel<MT, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
     return (int)hipGetLastError();
 }
 

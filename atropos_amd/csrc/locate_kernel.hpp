@@ -25,16 +25,25 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int MT, bool EQ, bool NOINDEL>
+template <int W>
+__device__ __forceinline__ void load_mask(uint32_t (&nm)[W], const uint32_t (*s_nm)[4], uint32_t q) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) nm[w] = s_nm[q][w];
+}
+
+template <int MT, bool NOINDEL, bool XREP>
 __global__ __launch_bounds__(256) void locate_kernel(const LocateParams p, const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads,
                                                      int nchunks, int max_len, uint4 *__restrict__ out) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_init[ATR_MAX_REF_LEN + 1];        // by position
+    __shared__ __attribute__((aligned(16))) uint32_t s_nm[16][4];
 
     const Uniform u = make_uniform(p, MT);
 
-    // Stage the wave-uniform column-init state (min_n == 0) and the thresholds in LDS.
+    // Stage the wave-uniform state in LDS: mismatch masks, column-init state (min_n == 0),
+    // thresholds.
+    if (threadIdx.x < 64) s_nm[threadIdx.x >> 2][threadIdx.x & 3] = p.nmask[threadIdx.x >> 2][threadIdx.x & 3];
     for (int i = threadIdx.x; i <= MT + 1; i += 256) {
         if (i <= u.m + 1) s_thr[i] = p.thr[i];
         if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(256) void locate_kernel(const LocateParams p, const
     const int n = live ? (lens ? lens[r] : max_len) : 0;
 
     LaneState<MT> L;
-    lane_init<MT>(L, u, n, s_init, s_thr);
+    lane_init<MT, NOINDEL, XREP>(L, u, n, s_init, s_thr);
 
     // Wave-uniform column range (jlo, jhi]: the union of the lanes' windows.
     const bool has_window = live && L.max_n > L.min_n;
@@ -75,7 +84,9 @@ __global__ __launch_bounds__(256) void locate_kernel(const LocateParams p, const
                     const uint32_t q = w & 15u;
                     w >>= 4;
                     if (j <= jlo || j > jhi) continue;       // wave-uniform (first / last chunk only)
-                    lane_step<MT, EQ, NOINDEL>(L, p, u, j, q, s_thr);
+                    uint32_t nm[(MT + 31) / 32];
+                    load_mask(nm, s_nm, q);
+                    lane_step<MT, NOINDEL, XREP>(L, u, j, nm, s_thr);
                 }
             }
         }
@@ -94,15 +105,15 @@ typedef int (*locate_launcher)(const atr_aligner *, const uint4 *, const int32_t
 template <int MT>
 int launch_locate_mt(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                      int nchunks, int max_len, uint4 *out, hipStream_t st) {
-    const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
     const bool noindel = a->indel_cost > a->p.k;
     const long long ntiles = (nreads + 63) / 64;
     const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-    if (eqmode) {
+    const bool xrep = (a->flags & ATR_STOP_WITHIN_SEQ2) != 0;     // mismatch-count payload (locate_core.hpp)
+    if (xrep) {
         if (noindel) hipLaunchKernelGGL((locate_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
-        else         hipLaunchKernelGGL((locate_kernel<MT, true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+        else         hipLaunchKernelGGL((locate_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
     } else {
-        if (noindel) hipLaunchKernelGGL((locate_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+        if (noindel) hipLaunchKernelGGL((locate_kernel<MT, true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
         else         hipLaunchKernelGGL((locate_kernel<MT, false, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
     }
     return (int)hipGetLastError();

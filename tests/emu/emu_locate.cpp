@@ -17,7 +17,7 @@ using namespace atr;
 
 namespace {
 
-template <int MT, bool EQ, bool NOINDEL>
+template <int MT, bool NOINDEL, bool XREP>
 void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, long long nreads,
                int nchunks, int max_len, uint32_t *out) {
     const LocateParams &p = a->p;
@@ -37,7 +37,7 @@ void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens
             const long long r = tile * 64 + lane;
             live[lane] = r < nreads;
             const int n = live[lane] ? (lens ? lens[r] : max_len) : 0;
-            lane_init<MT>(L[lane], u, n, s_init, s_thr);
+            lane_init<MT, NOINDEL, XREP>(L[lane], u, n, s_init, s_thr);
             const bool has_window = live[lane] && L[lane].max_n > L[lane].min_n;
             jlo = std::min(jlo, has_window ? L[lane].min_n : 0x7fffffff);
             jhi = std::max(jhi, has_window ? L[lane].max_n : 0);
@@ -52,7 +52,9 @@ void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens
                         for (int lane = 0; lane < 64; ++lane) {   // every lane, unmasked, like the wave
                             const uint32_t w = packed[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d];
                             const uint32_t q = (w >> (4 * b)) & 15u;
-                            lane_step<MT, EQ, NOINDEL>(L[lane], p, u, j, q, s_thr);
+                            uint32_t nm[(MT + 31) / 32];
+                            for (int w2 = 0; w2 < (MT + 31) / 32; ++w2) nm[w2] = p.nmask[q][w2];
+                            lane_step<MT, NOINDEL, XREP>(L[lane], u, j, nm, s_thr);
                         }
                     }
                 }
@@ -73,7 +75,7 @@ static uint32_t read_code(const uint32_t *packed, int nchunks, long long r, int 
     return (packed[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] >> (4 * b)) & 15u;
 }
 
-template <int MT, bool EQ, bool NOINDEL>
+template <int MT, bool NOINDEL>
 void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, long long nreads, int nchunks,
               int max_len, uint32_t *out) {
     const LocateParams &p = a->p;
@@ -90,38 +92,49 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         const int n = lens ? lens[r] : max_len;
         FilterState F;
         filter_init(F, u);
-        for (int j = 1; j <= n; ++j) filter_step(F, u, a->peq[read_code(packed, nchunks, r, j)], j);
+        for (int j = 1; j <= n; ++j) {
+            const uint64_t eq = a->peq[read_code(packed, nchunks, r, j)];
+            if (u.m > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), j);
+            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), j);
+        }
         uint32_t rec[4];
         const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
         win[r] = ww;
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
-        else bins[window_lo(ww) >> 3].push_back((uint32_t)r);
+        else bins[window_bin(ww, u.m)].push_back((uint32_t)r);
     }
     std::vector<uint32_t> order;                                   // K2 + K3
     for (auto &b : bins) order.insert(order.end(), b.begin(), b.end());
     const long long total = (long long)order.size();
     std::vector<LaneState<MT>> L(64);
     for (long long base = 0; base < total; base += 64) {           // K4, one wave at a time
-        int jlo = 0x7fffffff, jhi = 0;
+        int jlo = 0x7fffffff, jhi = 0, rows = 0;
         long long rr[64];
         bool live[64];
+        uint32_t wws[64];
         for (int lane = 0; lane < 64; ++lane) {
             live[lane] = base + lane < total;
             rr[lane] = live[lane] ? order[base + lane] : 0;
-            const uint32_t ww = live[lane] ? win[rr[lane]] : 0u;
-            const int n = live[lane] ? (lens ? lens[rr[lane]] : max_len) : 0;
-            const int lo = window_lo(ww), hi = live[lane] ? window_hi(ww) : 0;
-            lane_init_window<MT>(L[lane], u, n, lo, hi, live[lane] && window_scan(ww), s_init, s_thr);
-            const bool has_window = live[lane] && hi > lo;
-            jlo = std::min(jlo, has_window ? lo : 0x7fffffff);
-            jhi = std::max(jhi, has_window ? hi : 0);
+            wws[lane] = live[lane] ? win[rr[lane]] : 0u;
+            const int lo = window_lo(wws[lane]), hi = live[lane] ? window_hi(wws[lane]) : 0;
+            jlo = std::min(jlo, live[lane] ? lo : 0x7fffffff);
+            jhi = std::max(jhi, (live[lane] && hi > lo) ? hi : 0);
+            rows = std::max(rows, live[lane] ? window_rows(wws[lane]) : 0);
         }
+        for (int lane = 0; lane < 64; ++lane) {
+            const int n = live[lane] ? (lens ? lens[rr[lane]] : max_len) : 0;
+            lane_init_window<MT, NOINDEL>(L[lane], u, n, jlo, live[lane] ? window_hi(wws[lane]) : 0,
+                                 live[lane] && window_scan(wws[lane]), s_init, s_thr);
+        }
+        const int plimit = u.p0 + rows;
         if (jhi > jlo)
         for (int j = jlo + 1; j <= jhi; ++j)
             for (int lane = 0; lane < 64; ++lane) {
                 // lanes past the end of `order` gather read 0 like the kernel does
                 const uint32_t q = (j <= nchunks * 32) ? read_code(packed, nchunks, rr[lane], j) : 0u;
-                lane_step<MT, EQ, NOINDEL, true>(L[lane], p, u, j, q, s_thr);
+                uint32_t nm[(MT + 31) / 32];
+                for (int w2 = 0; w2 < (MT + 31) / 32; ++w2) nm[w2] = p.nmask[q][w2];
+                lane_step<MT, NOINDEL, true, true>(L[lane], u, j, nm, s_thr, plimit);
             }
         for (int lane = 0; lane < 64; ++lane)
             if (live[lane]) lane_result<MT>(L[lane], u, out + 4 * rr[lane]);
@@ -131,13 +144,10 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
 typedef void (*emu_fn)(const atr_aligner *, const uint32_t *, const int32_t *, long long, int, int, uint32_t *);
 
 template <int MT>
-emu_fn pick(bool eqmode, bool noindel, bool fast) {
-    if (fast) {
-        if (eqmode) return noindel ? &emu_fast<MT, true, true> : &emu_fast<MT, true, false>;
-        return noindel ? &emu_fast<MT, false, true> : &emu_fast<MT, false, false>;
-    }
-    if (eqmode) return noindel ? &emu_tiles<MT, true, true> : &emu_tiles<MT, true, false>;
-    return noindel ? &emu_tiles<MT, false, true> : &emu_tiles<MT, false, false>;
+emu_fn pick(bool xrep, bool noindel, bool fast) {
+    if (fast) return noindel ? &emu_fast<MT, true> : &emu_fast<MT, false>;
+    if (xrep) return noindel ? &emu_tiles<MT, true, true> : &emu_tiles<MT, false, true>;
+    return noindel ? &emu_tiles<MT, true, false> : &emu_tiles<MT, false, false>;
 }
 
 template <int... I>
@@ -191,7 +201,7 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
     const bool noindel = a->indel_cost > a->p.k;
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
     const bool fast = filtered && a->filterable && max_len > 0;
-    emu_fn fn = pick_mt(idx, eqmode, noindel, fast, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
+    emu_fn fn = pick_mt(idx, (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, noindel, fast, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
     fn(a, (const uint32_t *)packed, lens, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
     return ATR_OK;
 }

@@ -31,7 +31,7 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         meta = {}
         for r in rows:
             name = r["Kernel_Name"]
-            if "locate_kernel" in name or "pack_kernel" in name:
+            if "atr::" in name:
                 durs[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 meta[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
         fh.write("== kernel_trace reduced\n")
@@ -41,7 +41,7 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         rows = list(csv.DictReader(open(f)))
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
-            if "locate_kernel" in r["Kernel_Name"]:
+            if "atr::" in r["Kernel_Name"] and "pack_kernel" not in r["Kernel_Name"]:
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         fh.write("== pmc %s\n" % f)
         for name, cs in acc.items():
