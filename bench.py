@@ -27,6 +27,18 @@ ALGO_BYTES_PER_READ = 75 + 16      # ceil(150/2) packed-nibble bytes in + 16-byt
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def measured_traffic(reads, filtered):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in their
+    own rocprofv3 passes by tools/profile_r.sh and reduced into profiles/hbm_traffic.json with
+    the gfx950 correction of MI355X_MICROARCH.md), scaled to this launch's read count."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not filtered or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        t = json.load(fh)
+    return t["hbm_bytes_per_read"] * reads
+
+
 def usable_cores():
     """Host cores this process may actually use: the scheduler affinity capped by the
     cgroup CPU quota (the GPU boxes expose 256 logical CPUs but grant a 16-CPU quota)."""
@@ -139,7 +151,7 @@ def main():
                        "reads_per_gpu": args.reads, "read_len": 150, "adapter_len": len(w["adapter"]),
                        "parallelism": "shard%d" % world, "matched_fraction": n_found / args.reads},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, filtered),
                          "kernel": ("filter_kernel + scan + scatter + window_kernel<36,eq,indel> (one "
                                     "atr_locate_batch call)" if filtered else "locate_kernel<36,eq,indel>"),
                          "kernel_ms": kernel_ms,
