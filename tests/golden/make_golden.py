@@ -21,6 +21,9 @@ tests/test_modifiers.py):
     insert_fuzz.json.gz    InsertAligner.match_insert
     match_to_fuzz.json.gz  Adapter.match_to (boundary object, incl. exact shortcut)
     synth_heads.json.gz    first reads of workloads C1..C5 with reference outputs
+    cutter_fuzz.json.gz    AdapterCutter (several adapters, times, trim/mask/None)
+    insert_cutter_fuzz.json.gz  InsertAdapterCutter incl. error correction (N/liberal/conservative)
+    caller_kats.json       known answers of the reference's caller tests
     rmp.json               RandomMatchProbability values
 """
 import argparse
@@ -437,7 +440,7 @@ def main():
                     n_info=(len(r.match_info) if r.match_info else 0))
 
     cutter_cases = []
-    for it in range(600):
+    for it in range(260):
         nad = rng.choice([1, 2, 3])
         specs = []
         for a in range(nad):
@@ -480,7 +483,7 @@ def main():
     icut_cases = []
     parser_kw = dict(max_error_rate=0.2, min_overlap=1, indel_cost=3, match_probability=RandomMatchProbability(),
                      max_rmp=1e-6)
-    for it in range(240):
+    for it in range(130):
         action = rng.choice([None, None, 'liberal', 'conservative', 'N'])
         kwc = dict(mismatch_action=action)
         if rng.random() < 0.3:
