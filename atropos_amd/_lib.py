@@ -46,7 +46,7 @@ PROTOTYPES = {
     "atr_last_error": (C.c_char_p, []),
     "atr_translate_table": (C.c_int, [C.c_int, C.c_char_p]),
     "atr_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
-    "atr_pack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
+    "atr_pack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_multi_locate_work_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "atr_multi_locate_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -139,17 +139,18 @@ class HipBackend(object):
     def packed_bytes(self, nreads, max_len):
         return self.lib.atr_packed_bytes(nreads, max_len)
 
-    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False):
+    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False, starts=None):
         """ascii_2d: uint8 [nreads, >=max_len] on self.device (row stride arbitrary);
-        lens: int32 [nreads] or None; table: 256 bytes.  Returns the packed uint8 tensor
-        (and, with count_invalid, the number of reads holding a byte the table maps to 0)."""
+        lens: int32 [nreads] or None; starts: int32 [nreads] or None (pack read[start:]);
+        table: 256 bytes.  Returns the packed uint8 tensor (and, with count_invalid, the
+        number of reads holding a byte the table maps to 0)."""
         nreads = ascii_2d.shape[0]
         packed = self.empty((max(self.packed_bytes(nreads, max_len), 16),), torch.uint8)
         invalid = torch.zeros((1,), dtype=torch.int32, device=self.device) if count_invalid else None
         if nreads and max_len:
             with torch.cuda.device(self.device):
-                _check(self.lib, self.lib.atr_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads,
-                                                         max_len, table, _ptr(packed), _ptr(invalid),
+                _check(self.lib, self.lib.atr_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts),
+                                                         nreads, max_len, table, _ptr(packed), _ptr(invalid),
                                                          self._stream()), "atr_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 

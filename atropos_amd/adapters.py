@@ -13,8 +13,11 @@ import re
 from collections import defaultdict
 
 import numpy as np
+import torch
 
+from . import _lib
 from . import align
+from .batch import ReadBatch
 from .align import Match
 from .util import IUPAC_BASES, GC_BASES, rmp_table
 
@@ -285,6 +288,56 @@ class Adapter(object):
                              self._front_flag, self, None if isinstance(read, str) else read))
         return out
 
+    # ------------------------------------------------------------------ device-resident twin
+    def match_records(self, ascii_upper, lens=None, starts=None):
+        """``match_to`` for a batch that never leaves the GPU.  ``ascii_upper``: uint8
+        [n, width] tensor of UPPER-CASE ASCII reads on the device (``upper_ascii()``),
+        ``lens``/``starts``: optional int32 tensors (the read is ``row[start:len]``).
+        Returns the int16 [n, 8] record tensor with ``refstop = -1`` wherever ``match_to``
+        would return None: alignment, exact-match shortcut and post-filters
+        (adapters/__init__.py:338-400) are all evaluated on the device."""
+        be = _lib.get_backend()
+        m = len(self.sequence)
+        n = ascii_upper.shape[0]
+        if not self.indels and self.where in (PREFIX, SUFFIX):
+            if starts is not None:
+                raise NotImplementedError("sliced reads with anchored no-indel adapters")
+            rec = align.compare_batch(self.sequence, ascii_upper, self.adapter_wildcards, self.read_wildcards,
+                                      suffix=(self.where == SUFFIX), lens=lens)
+            full_needs_len = True
+        else:
+            batch = ReadBatch.from_ascii(ascii_upper, lens, None, self.aligner.table_kind,
+                                         self.aligner._table, be, starts=starts)
+            rec = self.aligner.locate_batch(batch).records
+            full_needs_len = False
+        r = rec.to(torch.int32)
+        found = r[:, 1] >= 0
+        size = torch.where(found, r[:, 1] - r[:, 0], torch.ones_like(r[:, 1]))
+        ok = found & (size >= self.min_overlap) & (r[:, 5].double() / size.double() <= self.max_error_rate)
+        if self.max_rmp is not None:
+            table = torch.from_numpy(self._rmp_by_size()).to(be.device)
+            probs = table[size.clamp(0, m).long(), r[:, 4].clamp(0, m).long()]
+            ok &= probs <= self.max_rmp
+        if not self.adapter_wildcards:
+            if self.read_wildcards:
+                # the literal first occurrence wins over whatever the wildcard DP found
+                if self._exact_aligner is None:
+                    self._exact_aligner = align.Aligner(self.sequence, 0.0, flags=self.where, min_overlap=m)
+                eb = ReadBatch.from_ascii(ascii_upper, lens, None, self._exact_aligner.table_kind,
+                                          self._exact_aligner._table, be, starts=starts)
+                ex = self._exact_aligner.locate_batch(eb).records
+                use = ex[:, 1] >= 0
+                rec = torch.where(use[:, None], ex, rec)
+                ok |= use
+            else:
+                full = found & (r[:, 4] == m) & (r[:, 5] == 0)
+                if full_needs_len:
+                    full &= (r[:, 1] - r[:, 0] == m)
+                ok |= full
+        none = torch.zeros(8, dtype=torch.int16, device=rec.device)
+        none[1] = -1
+        return torch.where(ok[:, None], rec, none[None, :])
+
     # ------------------------------------------------------------------ trimming
     def _trimmed_anywhere(self, match):
         return self._trimmed_front(match) if match.front else self._trimmed_back(match)
@@ -394,6 +447,19 @@ class LinkedAdapter(object):
             out[i] = LinkedMatch(fronts[i], bm, self)
         return out
 
+    def match_records(self, ascii_upper, lens=None):
+        """Device-resident twin of ``match_to``: returns (front_records, back_records), both
+        int16 [n, 8] on the device; the back records refer to the read with the front match
+        removed (coordinates relative to ``read[front.rstop:]``) and are -1 where the front
+        adapter did not match."""
+        front = self.front_adapter.match_records(ascii_upper, lens)
+        has_front = front[:, 1] >= 0
+        starts = torch.where(has_front, front[:, 3].to(torch.int32), torch.zeros_like(front[:, 3], dtype=torch.int32))
+        back = self.back_adapter.match_records(ascii_upper, lens, starts=starts)
+        none = torch.zeros(8, dtype=torch.int16, device=back.device)
+        none[1] = -1
+        return front, torch.where(has_front[:, None], back, none[None, :])
+
     def trimmed(self, match):
         front_trimmed = self.front_adapter.trimmed(match.front_match)
         if match.back_match:
@@ -488,3 +554,29 @@ class AdapterParser(object):
             for spec in specs or ():
                 adapters.extend(self.parse(spec, cmdline_type))
         return adapters
+
+
+def upper_ascii(ascii_2d):
+    """Device twin of ``read.sequence.upper()`` (match_to upper-cases every read,
+    adapters/__init__.py:349): ASCII a-z -> A-Z on a uint8 tensor."""
+    lower = (ascii_2d >= 97) & (ascii_2d <= 122)
+    return torch.where(lower, ascii_2d - 32, ascii_2d)
+
+
+def best_adapter_records(adapters, ascii_upper, lens=None):
+    """Device twin of ``AdapterCutter._best_match`` (commands/trim/modifiers.py:107-122) for
+    plain (non-linked) adapters: the records of the adapter with the most matches per read
+    (the first one wins ties) and its index (-1: no adapter matched)."""
+    best = None
+    which = None
+    for idx, adapter in enumerate(adapters):
+        rec = adapter.match_records(ascii_upper, lens)
+        if best is None:
+            best = rec
+            which = torch.where(rec[:, 1] >= 0, torch.zeros_like(rec[:, 1], dtype=torch.int32),
+                                torch.full_like(rec[:, 1], -1, dtype=torch.int32))
+            continue
+        better = (rec[:, 1] >= 0) & ((best[:, 1] < 0) | (rec[:, 4] > best[:, 4]))
+        best = torch.where(better[:, None], rec, best)
+        which = torch.where(better, torch.full_like(which, idx), which)
+    return best, which

@@ -235,6 +235,9 @@ def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix
     else:
         q_t = queries.to(be.device)
         lens = None if lens is None else lens.to(device=be.device, dtype=torch.int32)
+    if q_t.shape[0] and q_t.shape[1] == 0:
+        q_t = torch.zeros((q_t.shape[0], 1), dtype=torch.uint8, device=be.device)
+        lens = torch.zeros((q_t.shape[0],), dtype=torch.int32, device=be.device) if lens is None else lens
     return be.compare_batch(ref_b, q_t, lens, q_t.shape[1], wildcard_ref, wildcard_query, suffix)
 
 

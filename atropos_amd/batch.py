@@ -43,9 +43,10 @@ class ReadBatch(object):
 
     @classmethod
     def from_ascii(cls, ascii_2d, lens=None, max_len=None, table_kind=_lib.TABLE_DNA15, table=None,
-                   backend=None):
+                   backend=None, starts=None):
         """ascii_2d: uint8 tensor/ndarray [nreads, width] of ASCII codes; lens: per-read
-        lengths (None = every read is ``width`` long)."""
+        lengths (None = every read is ``width`` long); starts: per-read first base (int32
+        tensor): the batch then holds the slices ``read[start:]``."""
         be = backend or _lib.get_backend()
         if isinstance(ascii_2d, np.ndarray):
             ascii_2d = torch.from_numpy(np.ascontiguousarray(ascii_2d, dtype=np.uint8))
@@ -72,6 +73,11 @@ class ReadBatch(object):
             if table_kind == _lib.TABLE_CUSTOM:
                 raise ValueError("a custom table must be given explicitly")
             table = be.translate_table(table_kind)
+        if starts is not None:
+            starts = starts.to(device=be.device, dtype=torch.int32).contiguous()
+            full = lens if lens is not None else torch.full((nreads,), width, dtype=torch.int32, device=be.device)
+            packed = be.pack_reads(ascii_2d, full, max_len, bytes(table), starts=starts)
+            return cls(packed, (full - starts).clamp_(min=0), nreads, max_len, table_kind, table)
         packed = be.pack_reads(ascii_2d, lens, max_len, bytes(table))
         return cls(packed, lens, nreads, max_len, table_kind, table)
 

@@ -51,7 +51,8 @@ constexpr int PACK_STAGE_MAX = 256;
 
 template <bool STAGED>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, long long row_stride,
-                                                   const int32_t *__restrict__ lens, long long nreads,
+                                                   const int32_t *__restrict__ lens,
+                                                   const int32_t *__restrict__ starts, long long nreads,
                                                    int max_len, int nchunks, const PackTable tab,
                                                    uint4 *__restrict__ packed, int32_t *__restrict__ invalid) {
     __shared__ uint8_t s_tab[256];
@@ -63,8 +64,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     const long long ntiles = (nreads + 63) >> 6;
     if (tile >= ntiles) return;
     const long long r = tile * 64 + lane;
-    const int n = (r < nreads) ? min(lens ? lens[r] : max_len, max_len) : 0;
-    const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride;
+    const int start = (r < nreads && starts) ? starts[r] : 0;
+    const int n = (r < nreads) ? max(0, min((lens ? lens[r] : max_len) - start, max_len)) : 0;
+    const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride + start;
     if (STAGED) {
         const size_t wave_bytes = (size_t)64 * row_stride + 16;
         uint8_t *stage = s_stage + (size_t)wave * ((wave_bytes + 15) & ~(size_t)15);
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         for (long long o = (long long)lane * 16; o < need; o += 64 * 16)
             *(uint4 *)(stage + o) = *(const uint4 *)(src_al + o);
         __builtin_amdgcn_wave_barrier();
-        row = stage + mis + (size_t)lane * row_stride;             // LDS is visible wave-wide after the stores land
+        row = stage + mis + (size_t)lane * row_stride + start;     // LDS is visible wave-wide after the stores land
         __builtin_amdgcn_s_waitcnt(0);
     }
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
@@ -123,8 +125,8 @@ int atr_translate_table(int kind, uint8_t table[256]) {
 
 size_t atr_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
 
-int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, int64_t nreads,
-                   int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
+int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, const int32_t *d_starts,
+                   int64_t nreads, int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
                    void *stream) {
     if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
     if (nreads == 0 || max_len == 0) return ATR_OK;
@@ -137,11 +139,11 @@ int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_
     if (row_stride > 0 && row_stride <= PACK_STAGE_MAX) {
         const size_t per_wave = (((size_t)64 * row_stride + 16) + 15) & ~(size_t)15;
         hipLaunchKernelGGL((pack_kernel<true>), grid, block, 4 * per_wave, (hipStream_t)stream, d_ascii,
-                           (long long)row_stride, d_lens, (long long)nreads, max_len, nchunks, tab,
+                           (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
                            (uint4 *)d_packed, d_invalid);
     } else {
         hipLaunchKernelGGL((pack_kernel<false>), grid, block, 0, (hipStream_t)stream, d_ascii,
-                           (long long)row_stride, d_lens, (long long)nreads, max_len, nchunks, tab,
+                           (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
                            (uint4 *)d_packed, d_invalid);
     }
     hipError_t e = hipGetLastError();

@@ -86,12 +86,15 @@ size_t atr_packed_bytes(int64_t nreads, int max_len);
 
 /* ASCII -> 4-bit tile64.  `table` is a HOST pointer to the 256-entry translate
  * table (the reference does bytes.translate(table) per read: _align.pyx:243-248,
- * :292-297).  d_lens may be NULL (all reads max_len long).  d_invalid may be NULL;
+ * :292-297).  d_lens may be NULL (all reads max_len long).  d_starts may be NULL; otherwise
+ * read r is packed from its base d_starts[r] on, i.e. the slice read[start:] of length
+ * d_lens[r] - d_starts[r] (what LinkedAdapter.match_to hands to the 3' adapter after
+ * removing the 5' match, adapters/__init__.py:683-690).  d_invalid may be NULL;
  * otherwise *d_invalid (device int32, zeroed by the caller) is incremented once per
  * read that contains a byte the table maps to 0 -- the insert aligner needs every base
  * to have a complement (reverse_complement raises KeyError, util/__init__.py:479-482). */
 int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
-                   int64_t nreads, int max_len, const uint8_t table[256],
+                   const int32_t *d_starts, int64_t nreads, int max_len, const uint8_t table[256],
                    uint8_t *d_packed, int32_t *d_invalid, void *stream);
 
 /* ---- Aligner (atropos/align/_align.pyx:121-494) -------------------------- */

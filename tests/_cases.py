@@ -359,3 +359,78 @@ def check_linked_c4():
         got = None if lm is None else [f(lm.front_match), f(lm.back_match)]
         assert got == heads["out"][i][i % 4]
     return len(reads)
+
+
+def check_device_resident_adapters():
+    """The device-resident twins (match_records, LinkedAdapter.match_records,
+    best_adapter_records) against the object-level batch path, which is itself pinned to the
+    reference's outputs."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib, synth
+    from atropos_amd.adapters import (Adapter, LinkedAdapter, best_adapter_records, upper_ascii,
+                                      BACK, FRONT, PREFIX, SUFFIX, ANYWHERE)
+    from atropos_amd.reads import Sequence
+    from atropos_amd.util import RandomMatchProbability
+    be = _lib.get_backend()
+    rng = random.Random(123)
+
+    def recs(matches):
+        out = np.zeros((len(matches), 8), dtype=np.int16)
+        out[:, 1] = -1
+        for i, m in enumerate(matches):
+            if m is not None:
+                out[i, :6] = [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+        return out
+
+    total = 0
+    rmp = RandomMatchProbability()
+    for it in range(40):
+        m = rng.randint(4, 40)
+        seq = rseq(rng, m, "ACGT" if rng.random() < 0.7 else "ACGTN")
+        where = rng.choice([BACK, BACK, FRONT, PREFIX, SUFFIX, ANYWHERE])
+        use_rmp = rng.random() < 0.3
+        kw = dict(max_error_rate=rng.choice([0.1, 0.12, 0.2]), min_overlap=rng.choice([1, 3, 5]),
+                  read_wildcards=rng.random() < 0.25, adapter_wildcards=rng.random() < 0.8,
+                  indels=rng.random() < 0.8, indel_cost=rng.choice([1, 1, 3]),
+                  match_probability=rmp if use_rmp else None, max_rmp=1e-6 if use_rmp else None)
+        ad = Adapter(seq, where, **kw)
+        reads = planted_reads(rng, seq.replace("N", "A"), 130, 150)
+        reads = [r if rng.random() > 0.1 else r.lower() for r in reads]
+        reads = [r if r else "A" for r in reads]
+        width = max(len(r) for r in reads)
+        mat = np.zeros((len(reads), width), dtype=np.uint8)
+        for i, r in enumerate(reads):
+            mat[i, :len(r)] = np.frombuffer(r.encode(), dtype=np.uint8)
+        a_t = upper_ascii(torch.from_numpy(mat).to(be.device))
+        l_t = torch.tensor([len(r) for r in reads], dtype=torch.int32, device=be.device)
+        got = ad.match_records(a_t, l_t).cpu().numpy()
+        exp = recs(ad.match_to_batch([Sequence("r", r) for r in reads]))
+        assert np.array_equal(got[:, :6], exp[:, :6]), (seq, where, kw)
+        total += len(reads)
+    # linked adapters on the C4 head: device path == object path (== reference, see check_linked_c4)
+    w = synth.workload("C4", 0, 512)
+    reads = [Sequence("r", bytes(x.tolist()).decode("ascii")) for x in w["reads"]]
+    a_t = upper_ascii(w["reads"].to(be.device))
+    for fr, bk in zip(w["fronts"], w["backs"]):
+        la = LinkedAdapter(fr, bk, front_anchored=True, back_anchored=False, max_error_rate=w["max_error_rate"],
+                           min_overlap=w["min_overlap"], indel_cost=w["indel_cost"])
+        front, back = la.match_records(a_t)
+        lm = la.match_to_batch(reads)
+        assert np.array_equal(front.cpu().numpy()[:, :6], recs([None if x is None else x.front_match for x in lm])[:, :6])
+        assert np.array_equal(back.cpu().numpy()[:, :6], recs([None if x is None else x.back_match for x in lm])[:, :6])
+        total += len(reads)
+    # best-of-N
+    ads = [Adapter(b, BACK, max_error_rate=0.12, min_overlap=3) for b in w["backs"]]
+    best, which = best_adapter_records(ads, a_t)
+    per = [ad.match_to_batch(reads) for ad in ads]
+    for i in range(len(reads)):
+        choice, bi = None, -1
+        for k in range(len(ads)):
+            mt = per[k][i]
+            if mt is not None and (choice is None or mt.matches > choice.matches):
+                choice, bi = mt, k
+        assert int(which[i]) == bi
+        if choice is not None:
+            assert best[i, :6].tolist() == [choice.astart, choice.astop, choice.rstart, choice.rstop, choice.matches, choice.errors]
+    return total

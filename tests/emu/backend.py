@@ -59,8 +59,8 @@ class EmuBackend(object):
         L.emu_aligner_query_table.argtypes = [C.c_void_p, C.c_char_p]
         L.emu_packed_bytes.argtypes = [C.c_int64, C.c_int]
         L.emu_packed_bytes.restype = C.c_size_t
-        L.emu_pack_reads.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_void_p,
-                                     C.c_void_p]
+        L.emu_pack_reads.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
+                                     C.c_void_p, C.c_void_p]
         L.emu_multi_locate_work_bytes.argtypes = [C.c_int64, C.c_int]
         L.emu_multi_locate_work_bytes.restype = C.c_size_t
         L.emu_multi_locate_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -98,13 +98,13 @@ class EmuBackend(object):
     def packed_bytes(self, nreads, max_len):
         return self.lib.emu_packed_bytes(nreads, max_len)
 
-    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False):
+    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False, starts=None):
         nreads = ascii_2d.shape[0]
         packed = torch.zeros((max(self.packed_bytes(nreads, max_len), 16),), dtype=torch.uint8)
         invalid = torch.zeros((1,), dtype=torch.int32) if count_invalid else None
         if nreads and max_len:
-            _check(self.lib.emu_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads, max_len, table,
-                                           _ptr(packed), _ptr(invalid)), "emu_pack_reads")
+            _check(self.lib.emu_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts), nreads,
+                                           max_len, table, _ptr(packed), _ptr(invalid)), "emu_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 
     def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,

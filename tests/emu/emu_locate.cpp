@@ -173,16 +173,17 @@ int emu_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
 }
 size_t emu_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
 
-int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens, int64_t nreads, int max_len,
-                   const uint8_t table[256], uint8_t *packed, int32_t *invalid) {
+int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens, const int32_t *starts,
+                   int64_t nreads, int max_len, const uint8_t table[256], uint8_t *packed, int32_t *invalid) {
     const int nchunks = (max_len + 31) / 32;
     const long long ntiles = (nreads + 63) / 64;
     uint32_t *dst = (uint32_t *)packed;
     for (long long tile = 0; tile < ntiles; ++tile)
         for (int lane = 0; lane < 64; ++lane) {
             const long long r = tile * 64 + lane;
-            const int n = (r < nreads) ? std::min(lens ? lens[r] : max_len, max_len) : 0;
-            const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride;
+            const int start = (r < nreads && starts) ? starts[r] : 0;
+            const int n = (r < nreads) ? std::max(0, std::min((lens ? lens[r] : max_len) - start, max_len)) : 0;
+            const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride + start;
             bool zero_seen = false;
             for (int c = 0; c < nchunks; ++c)
                 for (int d = 0; d < 4; ++d)

@@ -55,3 +55,7 @@ def test_adapter_parser_specs(emu_backend):
     with pytest.raises(ValueError):
         p.parse_from_spec("^ACGT")
     assert len(p.parse_multi(back=["ACGT", "GGGG"], front=["TTTT"])) == 3
+
+
+def test_device_resident_adapters(emu_backend):
+    assert _cases.check_device_resident_adapters() > 5000

@@ -25,3 +25,7 @@ def test_insert_adapter_cutter(hip_backend):
 
 def test_reference_caller_kats(hip_backend):
     _cases.check_caller_kats()
+
+
+def test_device_resident_adapters(hip_backend):
+    assert _cases.check_device_resident_adapters() > 5000
