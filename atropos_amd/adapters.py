@@ -289,10 +289,11 @@ class Adapter(object):
         return out
 
     # ------------------------------------------------------------------ device-resident twin
-    def match_records(self, ascii_upper, lens=None, starts=None):
+    def match_records(self, ascii_upper, lens=None, starts=None, batch=None):
         """``match_to`` for a batch that never leaves the GPU.  ``ascii_upper``: uint8
         [n, width] tensor of UPPER-CASE ASCII reads on the device (``upper_ascii()``),
-        ``lens``/``starts``: optional int32 tensors (the read is ``row[start:len]``).
+        ``lens``/``starts``: optional int32 tensors (the read is ``row[start:len]``);
+        ``batch``: the same reads already packed with this aligner's table (saves the pack).
         Returns the int16 [n, 8] record tensor with ``refstop = -1`` wherever ``match_to``
         would return None: alignment, exact-match shortcut and post-filters
         (adapters/__init__.py:338-400) are all evaluated on the device."""
@@ -306,8 +307,9 @@ class Adapter(object):
                                       suffix=(self.where == SUFFIX), lens=lens)
             full_needs_len = True
         else:
-            batch = ReadBatch.from_ascii(ascii_upper, lens, None, self.aligner.table_kind,
-                                         self.aligner._table, be, starts=starts)
+            if batch is None or batch.table_kind != self.aligner.table_kind or starts is not None:
+                batch = ReadBatch.from_ascii(ascii_upper, lens, None, self.aligner.table_kind,
+                                             self.aligner._table, be, starts=starts)
             rec = self.aligner.locate_batch(batch).records
             full_needs_len = False
         r = rec.to(torch.int32)
@@ -554,6 +556,44 @@ class AdapterParser(object):
             for spec in specs or ():
                 adapters.extend(self.parse(spec, cmdline_type))
         return adapters
+
+
+def linked_best_records(linked_adapters, ascii_upper, lens=None):
+    """Device pipeline for a set of linked adapters whose anchored 5' parts are mutually
+    exclusive (BASELINE config C4): every 5' adapter is matched against all reads (one shared
+    packed batch), the reads are then grouped by the 5' adapter that matched and only that
+    adapter's 3' part is aligned against ``read[front.rstop:]``.  Returns (which, front, back):
+    the index of the matching linked adapter per read (-1: none, -2: more than one -- the
+    reference's AdapterCutter raises AttributeError in that case, modifiers.py:120) and the
+    two int16 [n, 8] record tensors."""
+    be = _lib.get_backend()
+    n = ascii_upper.shape[0]
+    first = linked_adapters[0].front_adapter
+    shared = None
+    if first.indels or first.where not in (PREFIX, SUFFIX):
+        shared = ReadBatch.from_ascii(ascii_upper, lens, None, first.aligner.table_kind, first.aligner._table, be)
+    none = torch.zeros(8, dtype=torch.int16, device=be.device)
+    none[1] = -1
+    front = none[None, :].repeat(n, 1)
+    back = none[None, :].repeat(n, 1)
+    which = torch.full((n,), -1, dtype=torch.int32, device=be.device)
+    count = torch.zeros((n,), dtype=torch.int32, device=be.device)
+    for k, la in enumerate(linked_adapters):
+        f = la.front_adapter.match_records(ascii_upper, lens, batch=shared)
+        has = f[:, 1] >= 0
+        front = torch.where(has[:, None], f, front)
+        which = torch.where(has, torch.full_like(which, k), which)
+        count += has.to(torch.int32)
+    for k, la in enumerate(linked_adapters):
+        idx = torch.nonzero(which == k, as_tuple=False).squeeze(1)
+        if idx.numel() == 0:
+            continue
+        sub = ascii_upper.index_select(0, idx)
+        sub_lens = None if lens is None else lens.index_select(0, idx)
+        starts = front.index_select(0, idx)[:, 3].to(torch.int32)
+        back[idx] = la.back_adapter.match_records(sub, sub_lens, starts=starts)
+    which = torch.where(count > 1, torch.full_like(which, -2), which)
+    return which, front, back
 
 
 def upper_ascii(ascii_2d):

@@ -420,6 +420,20 @@ def check_device_resident_adapters():
         assert np.array_equal(front.cpu().numpy()[:, :6], recs([None if x is None else x.front_match for x in lm])[:, :6])
         assert np.array_equal(back.cpu().numpy()[:, :6], recs([None if x is None else x.back_match for x in lm])[:, :6])
         total += len(reads)
+    # grouped pipeline over all four linked adapters
+    from atropos_amd.adapters import linked_best_records
+    las = [LinkedAdapter(fr, bk, front_anchored=True, back_anchored=False, max_error_rate=w["max_error_rate"],
+                         min_overlap=w["min_overlap"], indel_cost=w["indel_cost"])
+           for fr, bk in zip(w["fronts"], w["backs"])]
+    which, front, back = linked_best_records(las, a_t)
+    per_l = [la.match_to_batch(reads) for la in las]
+    for i in range(len(reads)):
+        hits = [k for k in range(4) if per_l[k][i] is not None]
+        assert int(which[i]) == (hits[0] if len(hits) == 1 else (-1 if not hits else -2))
+        if len(hits) == 1:
+            lm = per_l[hits[0]][i]
+            assert front[i, :6].tolist() == recs([lm.front_match])[0, :6].tolist()
+            assert back[i, :6].tolist() == recs([lm.back_match])[0, :6].tolist()
     # best-of-N
     ads = [Adapter(b, BACK, max_error_rate=0.12, min_overlap=3) for b in w["backs"]]
     best, which = best_adapter_records(ads, a_t)

@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     args = ap.parse_args()
     from atropos_amd import synth
-    from atropos_amd.adapters import LinkedAdapter, upper_ascii
+    from atropos_amd.adapters import LinkedAdapter, linked_best_records, upper_ascii
     chunks = []
     for lo in range(0, args.reads, 2_000_000):
         chunks.append(synth.workload("C4", lo, min(2_000_000, args.reads - lo), device="cuda")["reads"])
@@ -31,19 +31,8 @@ def main():
                             indel_cost=1) for f, b in zip(synth.LINKED_FRONTS, synth.LINKED_BACKS)]
 
     def step():
-        front_any = None
-        out_front = out_back = None
-        nmulti = None
-        for la in linked:
-            f, b = la.match_records(reads)
-            has = f[:, 1] >= 0
-            if out_front is None:
-                out_front, out_back, nmulti = f, b, has.to(torch.int32)
-            else:
-                out_front = torch.where(has[:, None], f, out_front)
-                out_back = torch.where(has[:, None], b, out_back)
-                nmulti = nmulti + has.to(torch.int32)
-        return out_front, out_back, nmulti
+        which, f, b = linked_best_records(linked, reads)
+        return f, b, (which == -2).to(torch.int32) * 2
 
     for _ in range(2):
         res = step()
