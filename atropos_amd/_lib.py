@@ -54,6 +54,8 @@ PROTOTYPES = {
                                          C.c_void_p, C.c_int, C.c_void_p]),
     "atr_compare_batch": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_adapter_postfilter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                         C.c_double, C.c_int, C.c_void_p]),
     "atr_correct_errors_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -181,6 +183,17 @@ class HipBackend(object):
                                                             int(suffix), _ptr(out), self._stream()),
                        "atr_compare_batch")
         return out
+
+    def adapter_postfilter(self, records, m, min_overlap, max_error_rate, rmp, max_rmp, accept_full):
+        """In-place acceptance test of Adapter.match_to on int16 [n, 8] records; rmp: float64
+        [ld, ld] device tensor or None."""
+        if records.shape[0]:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_adapter_postfilter(
+                    _ptr(records), records.shape[0], m, min_overlap, max_error_rate, _ptr(rmp),
+                    0 if rmp is None else rmp.shape[1], 0.0 if max_rmp is None else max_rmp, int(accept_full),
+                    self._stream()), "atr_adapter_postfilter")
+        return records
 
     def correct_errors_batch(self, seq1, qual1, lens1, seq2, qual2, lens2, insert, mask, action, min_qual_diff,
                              truncate, comp):

@@ -170,6 +170,7 @@ class Adapter(object):
         self.aligner.indel_cost = self._indel_cost
         self._exact_aligner = None
         self._rmp_cache = None
+        self._rmp_device = None
 
     def __repr__(self):
         return ('<Adapter(name="{name}", sequence="{sequence}", where={where}, max_error_rate={max_error_rate}, '
@@ -305,40 +306,30 @@ class Adapter(object):
                 raise NotImplementedError("sliced reads with anchored no-indel adapters")
             rec = align.compare_batch(self.sequence, ascii_upper, self.adapter_wildcards, self.read_wildcards,
                                       suffix=(self.where == SUFFIX), lens=lens)
-            full_needs_len = True
         else:
             if batch is None or batch.table_kind != self.aligner.table_kind or starts is not None:
                 batch = ReadBatch.from_ascii(ascii_upper, lens, None, self.aligner.table_kind,
                                              self.aligner._table, be, starts=starts)
             rec = self.aligner.locate_batch(batch).records
-            full_needs_len = False
-        r = rec.to(torch.int32)
-        found = r[:, 1] >= 0
-        size = torch.where(found, r[:, 1] - r[:, 0], torch.ones_like(r[:, 1]))
-        ok = found & (size >= self.min_overlap) & (r[:, 5].double() / size.double() <= self.max_error_rate)
+        rmp_t = None
         if self.max_rmp is not None:
-            table = torch.from_numpy(self._rmp_by_size()).to(be.device)
-            probs = table[size.clamp(0, m).long(), r[:, 4].clamp(0, m).long()]
-            ok &= probs <= self.max_rmp
-        if not self.adapter_wildcards:
-            if self.read_wildcards:
-                # the literal first occurrence wins over whatever the wildcard DP found
-                if self._exact_aligner is None:
-                    self._exact_aligner = align.Aligner(self.sequence, 0.0, flags=self.where, min_overlap=m)
-                eb = ReadBatch.from_ascii(ascii_upper, lens, None, self._exact_aligner.table_kind,
-                                          self._exact_aligner._table, be, starts=starts)
-                ex = self._exact_aligner.locate_batch(eb).records
-                use = ex[:, 1] >= 0
-                rec = torch.where(use[:, None], ex, rec)
-                ok |= use
-            else:
-                full = found & (r[:, 4] == m) & (r[:, 5] == 0)
-                if full_needs_len:
-                    full &= (r[:, 1] - r[:, 0] == m)
-                ok |= full
-        none = torch.zeros(8, dtype=torch.int16, device=rec.device)
-        none[1] = -1
-        return torch.where(ok[:, None], rec, none[None, :])
+            if self._rmp_device is None or self._rmp_device.device != be.device:
+                self._rmp_device = torch.from_numpy(np.ascontiguousarray(self._rmp_by_size())).to(be.device)
+            rmp_t = self._rmp_device
+        # the shortcut applies when the literal compare mode makes "full length, zero errors"
+        # exactly what str.find / startswith / endswith would have reported
+        accept_full = (not self.adapter_wildcards) and (not self.read_wildcards)
+        rec = be.adapter_postfilter(rec, m, self.min_overlap, float(self.max_error_rate), rmp_t, self.max_rmp,
+                                    accept_full)
+        if not self.adapter_wildcards and self.read_wildcards:
+            # the literal first occurrence wins over whatever the wildcard DP found
+            if self._exact_aligner is None:
+                self._exact_aligner = align.Aligner(self.sequence, 0.0, flags=self.where, min_overlap=m)
+            eb = ReadBatch.from_ascii(ascii_upper, lens, None, self._exact_aligner.table_kind,
+                                      self._exact_aligner._table, be, starts=starts)
+            ex = self._exact_aligner.locate_batch(eb).records
+            rec = torch.where((ex[:, 1] >= 0)[:, None], ex, rec)
+        return rec
 
     # ------------------------------------------------------------------ trimming
     def _trimmed_anywhere(self, match):

@@ -20,6 +20,8 @@ int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uin
                    long long stride, const int16_t *im, const uint8_t *mask, long long n, int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st);
+int launch_postfilter(int16_t *rec, long long n, int m, int min_overlap, double max_error_rate, const double *rmp,
+                      int rmp_ld, double max_rmp, int accept_full, hipStream_t st);
 int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
                  long long q_stride, const int32_t *q_lens, long long npairs, double e, int flags, int min_overlap,
                  int max_matches, int *work, int16_t *out, int32_t *counts, int out_stride, hipStream_t st);
@@ -263,6 +265,17 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
     const int rc = launch_compare((const uint8_t *)ref, m, d_queries, query_stride, d_lens, n, max_len, wildcard_ref,
                                   wildcard_query, suffix, (int16_t *)d_out, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "compare_kernel launch");
+}
+
+int atr_adapter_postfilter(atr_result *d_records, int64_t n, int adapter_len, int min_overlap,
+                           double max_error_rate, const double *d_rmp, int rmp_ld, double max_rmp, int accept_full,
+                           void *stream) {
+    if (n < 0 || adapter_len < 1 || (d_rmp && rmp_ld < 1)) return ATR_ERR_INVALID;
+    if (n == 0) return ATR_OK;
+    if (!d_records) return ATR_ERR_INVALID;
+    const int rc = launch_postfilter((int16_t *)d_records, n, adapter_len, min_overlap, max_error_rate, d_rmp, rmp_ld,
+                                     max_rmp, accept_full, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "postfilter_kernel launch");
 }
 
 int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d_lens1, uint8_t *d_seq2,

@@ -131,6 +131,22 @@ ATR_DEV void compare_one(const uint8_t *ref, int m, const uint8_t *query, int n,
     rec[4] = (int16_t)matches; rec[5] = (int16_t)(len - matches); rec[6] = 0; rec[7] = 0;
 }
 
+// Post-filter of Adapter.match_to (atropos/adapters/__init__.py:386-398) on one result
+// record, in place: keep the alignment iff size >= min_overlap and errors/size <=
+// max_error_rate (a DIVISION in double, unlike the DP's product) and, when a table is given,
+// rmp[size][matches] <= max_rmp.  accept_full: the exact-match shortcut (:351-367) -- a
+// full-length zero-error occurrence of an adapter without wildcards is returned without
+// passing the filters.  Rejected records get refstop = -1.
+ATR_DEV void adapter_postfilter_one(int16_t *rec, int m, int min_overlap, double max_error_rate,
+                                    const double *rmp, int rmp_ld, double max_rmp, bool accept_full) {
+    if (rec[1] < 0) return;
+    const int size = (int)rec[1] - (int)rec[0], matches = rec[4], errors = rec[5];
+    bool ok = size >= min_overlap && (double)errors / (double)size <= max_error_rate;
+    if (ok && rmp) ok = rmp[(size_t)mc_min(size, rmp_ld - 1) * rmp_ld + mc_min(mc_max(matches, 0), rmp_ld - 1)] <= max_rmp;
+    if (accept_full && matches == m && errors == 0 && size == m) ok = true;
+    if (!ok) { rec[0] = 0; rec[1] = -1; rec[2] = rec[3] = rec[4] = rec[5] = 0; }
+}
+
 // Python list indexing / slicing semantics (negative indices wrap once).
 ATR_DEV int py_index(int idx, int n) {            // returns -1 when Python raises IndexError
     if (idx < 0) idx += n;

@@ -76,6 +76,25 @@ int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uin
     return (int)hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void postfilter_kernel(int16_t *__restrict__ rec, long long n, int m,
+                                                         int min_overlap, double max_error_rate,
+                                                         const double *__restrict__ rmp, int rmp_ld, double max_rmp,
+                                                         int accept_full) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int16_t r[8];
+    *(uint4 *)r = *(const uint4 *)(rec + 8 * p);
+    adapter_postfilter_one(r, m, min_overlap, max_error_rate, rmp, rmp_ld, max_rmp, accept_full != 0);
+    *(uint4 *)(rec + 8 * p) = *(const uint4 *)r;
+}
+
+int launch_postfilter(int16_t *rec, long long n, int m, int min_overlap, double max_error_rate, const double *rmp,
+                      int rmp_ld, double max_rmp, int accept_full, hipStream_t st) {
+    hipLaunchKernelGGL(postfilter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, n, m, min_overlap,
+                       max_error_rate, rmp, rmp_ld, max_rmp, accept_full);
+    return (int)hipGetLastError();
+}
+
 int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
                  long long q_stride, const int32_t *q_lens, long long npairs, double e, int flags, int min_overlap,
                  int max_matches, int *work, int16_t *out, int32_t *counts, int out_stride, hipStream_t st) {

@@ -190,6 +190,17 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
                       const int32_t *d_lens, int64_t n, int max_len, int wildcard_ref, int wildcard_query,
                       int suffix, atr_result *d_out, void *stream);
 
+/* ---- Adapter.match_to post-filter (adapters/__init__.py:386-398) ---------- */
+
+/* Applies, in place on n result records, the acceptance test Adapter.match_to runs on an
+ * alignment: size >= min_overlap, errors/size <= max_error_rate (double division) and --
+ * when d_rmp is not NULL -- d_rmp[size*rmp_ld + matches] <= max_rmp (d_rmp: DEVICE table of
+ * match_probability(matches, size)).  accept_full != 0: a full-length zero-error occurrence
+ * (the exact-match shortcut, :351-367) is kept regardless.  Rejected records get refstop -1. */
+int atr_adapter_postfilter(atr_result *d_records, int64_t n, int adapter_len, int min_overlap,
+                           double max_error_rate, const double *d_rmp, int rmp_ld, double max_rmp,
+                           int accept_full, void *stream);
+
 /* ---- ErrorCorrectorMixin.correct_errors (commands/trim/modifiers.py:219-350) ---- */
 
 #define ATR_CORRECT_N             0   /* mismatch_action 'N' */

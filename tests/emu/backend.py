@@ -68,6 +68,8 @@ class EmuBackend(object):
                                              C.c_void_p, C.c_void_p, C.c_int]
         L.emu_compare_batch.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.emu_adapter_postfilter.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
+                                             C.c_double, C.c_int]
         L.emu_correct_errors_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                                C.c_int, C.c_char_p, C.c_void_p, C.c_void_p]
@@ -128,6 +130,14 @@ class EmuBackend(object):
                                               int(wildcard_ref), int(wildcard_query), int(suffix), _ptr(out)),
                    "atr_compare_batch")
         return out
+
+    def adapter_postfilter(self, records, m, min_overlap, max_error_rate, rmp, max_rmp, accept_full):
+        if records.shape[0]:
+            _check(self.lib.emu_adapter_postfilter(_ptr(records), records.shape[0], m, min_overlap, max_error_rate,
+                                                   _ptr(rmp), 0 if rmp is None else rmp.shape[1],
+                                                   0.0 if max_rmp is None else max_rmp, int(accept_full)),
+                   "atr_adapter_postfilter")
+        return records
 
     def correct_errors_batch(self, seq1, qual1, lens1, seq2, qual2, lens2, insert, mask, action, min_qual_diff,
                              truncate, comp):

@@ -41,6 +41,13 @@ int emu_compare_batch(const char *ref, int m, const uint8_t *queries, int64_t q_
     return ATR_OK;
 }
 
+int emu_adapter_postfilter(int16_t *rec, int64_t n, int m, int min_overlap, double max_error_rate,
+                           const double *rmp, int rmp_ld, double max_rmp, int accept_full) {
+    for (int64_t p = 0; p < n; ++p)
+        adapter_postfilter_one(rec + 8 * p, m, min_overlap, max_error_rate, rmp, rmp_ld, max_rmp, accept_full != 0);
+    return ATR_OK;
+}
+
 int emu_correct_errors_batch(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2,
                              const int32_t *l2, int64_t stride, const int16_t *im, const uint8_t *mask, int64_t n,
                              int max_len, int action, int min_qual_diff, int truncate, const uint8_t comp[256],
