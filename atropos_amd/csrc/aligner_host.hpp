@@ -85,6 +85,9 @@ inline int aligner_refresh(atr_aligner *a) {
                 const int rc = a->codes[i];
                 if (eqmode ? (rc == c) : ((rc & c) != 0)) mask |= 1ull << i;
             }
+            // top-aligned with always-matching pad rows below (filter_core.hpp, FilterState)
+            const int W = m > 32 ? 64 : 32, off = m <= 64 ? W - m : 0;
+            mask = off ? ((mask << off) | ((1ull << off) - 1)) : mask;
             a->peq[c] = mask;
         }
         const int need = ATR_START_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ2;

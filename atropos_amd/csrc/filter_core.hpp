@@ -38,7 +38,7 @@ constexpr int FILTER_MAX_M = 64;
 constexpr int FILTER_BINS = 192;                   // 96 window-start bins of 8 columns (n <= 736) x {all rows, fewer rows}
 
 struct FilterParams {
-    uint64_t peq[16];                               // peq[c] bit i: reference row i+1 matches query code c
+    uint64_t peq[16];                               // peq[c]: rows matching query code c, top-aligned (see FilterState); pad bits 1
 };
 
 // window word written per read by the pre-pass
@@ -59,23 +59,80 @@ ATR_DEV int window_bin(uint32_t w, int m) { return (window_lo(w) >> 3) + (window
 struct FilterState {
     uint32_t pvl, pvh, mvl, mvh;                    // vertical +1 / -1 deltas of the current column (lo/hi words)
     int score;                                      // D[m][j]
-    int j_first, j_last;                            // first / last column with D[m][j] <= k (0: none)
-    int j_exact;                                    // first column with D[m][j] == 0 and j >= m (0: none)
+    uint32_t hits;                                  // bit b: D[m][j - b] <= k, over the columns swept since the last fold
+    uint32_t best;                                  // min over the swept columns j >= m of (D[m][j] << 10 | j)
+    int j_first, j_last;                            // first / last column with D[m][j] <= k (0: none), as of the last fold
 };
+
+// Rows are TOP-ALIGNED in the bit-vector: row i (1-based) is bit off + i - 1 with
+// off = W - m, W = 64 (adapter longer than 32 bases) or 32.  Row m is then the sign bit of
+// the top word, so the bit that a left shift by one pushes out IS row m's horizontal delta:
+// the shift is an add-with-carry-out and the score update an add/sub-with-carry-in.  The pad
+// rows below row 1 match every base (peq pad bits = 1) and start with zero deltas; they stay
+// at cost 0 in every column and play the part of the free row 0 (START_WITHIN_SEQ2).
+ATR_DEV int filter_row_offset(int m) { return (m > 32 ? 64 : 32) - m; }
 
 ATR_DEV void filter_init(FilterState &F, const Uniform &u) {
     // column 0: cost i per row (not START_WITHIN_SEQ1) or 0 everywhere (_align.pyx:333-352)
-    F.pvl = F.pvh = u.sr ? 0u : ~0u;
+    const int off = filter_row_offset(u.m);
+    const uint32_t low = off >= 32 ? 0u : ~0u << (off & 31);           // rows living in the low word
+    if (u.m > 32) { F.pvl = u.sr ? 0u : low; F.pvh = u.sr ? 0u : ~0u; }
+    else { F.pvl = u.sr ? 0u : low; F.pvh = 0u; }
     F.mvl = F.mvh = 0u;
     F.score = u.sr ? 0 : u.m;
-    F.j_first = F.j_last = F.j_exact = 0;
+    F.hits = 0u;
+    F.best = ~0u;
+    F.j_first = F.j_last = 0;
+}
+
+// Column tag of the exact-hit tracker: the column number, plus a penalty that keeps columns
+// j < m (where a zero cost is only possible with START_WITHIN_SEQ1 and is no full-length
+// occurrence, _align.pyx:456-458 needs the whole reference inside the read) from ever winning.
+ATR_DEV uint32_t filter_column_tag(const Uniform &u, int j) { return (uint32_t)j | (j < u.m ? 1u << 20 : 0u); }
+
+// x <<= 1 on a one- or two-word vector; the bit shifted out of the top is added to
+// (SIGN = +1) or subtracted from (SIGN = -1) score.
+template <bool WIDE, int SIGN>
+ATR_DEV void filter_shift_out(uint32_t &lo, uint32_t &hi, int &score) {
+#ifdef ATR_HOST_EMU
+    const uint32_t out = WIDE ? hi >> 31 : lo >> 31;
+    if (WIDE) hi = (hi << 1) | (lo >> 31);
+    lo <<= 1;
+    score += SIGN * (int)out;
+#else
+    // VALU write of VCC -> VALU read of VCC needs two wait states on gfx950 (hipcc pads its own
+    // add/addc pairs with the same s_nop 1)
+    if (WIDE) {
+        if (SIGN > 0)
+            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\ts_nop 1\n\t"
+                "v_addc_co_u32 %2, vcc, 0, %2, vcc" : "+v"(lo), "+v"(hi), "+v"(score) : : "vcc");
+        else
+            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\ts_nop 1\n\t"
+                "v_subbrev_co_u32 %2, vcc, 0, %2, vcc" : "+v"(lo), "+v"(hi), "+v"(score) : : "vcc");
+    } else {
+        if (SIGN > 0)
+            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(score) : : "vcc");
+        else
+            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(score) : : "vcc");
+    }
+#endif
+}
+
+// hits = hits << 1 | (score <= k)
+ATR_DEV void filter_push_hit(uint32_t &hits, int score, int k) {
+#ifdef ATR_HOST_EMU
+    hits = (hits << 1) | (score <= k ? 1u : 0u);
+#else
+    asm("v_cmp_ge_i32 vcc, %2, %1\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(score), "s"(k) : "vcc");
+#endif
 }
 
 // One column of Myers' recurrence (Hyyro's formulation), row-0 delta 0 (free start in the
 // read), written on explicit 32-bit halves: gfx950 has no full-rate 64-bit shift or add.
 // WIDE = adapter longer than 32 bases (both words live); otherwise only the low word.
+// tag = filter_column_tag(u, j).  ~28 VALU ops (WIDE) / ~17 per column.
 template <bool WIDE>
-ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, int j) {
+ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
     const uint32_t xvl = eql | F.mvl;
     const uint32_t tl = eql & F.pvl;
     const uint32_t sl = tl + F.pvl;
@@ -91,25 +148,26 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
         phh = F.mvh | ~(xhh | F.pvh);
         mhh = F.pvh & xhh;
     }
-    const int bit = (u.m - 1) & 31;
-    const uint32_t pw = (WIDE ? phh : phl), mw = (WIDE ? mhh : mhl);
-    F.score += (int)((pw >> bit) & 1u) - (int)((mw >> bit) & 1u);
-    if (WIDE) {
-        phh = (phh << 1) | (phl >> 31);
-        mhh = (mhh << 1) | (mhl >> 31);
-    }
-    phl <<= 1;
-    mhl <<= 1;
+    filter_shift_out<WIDE, +1>(phl, phh, F.score);
+    filter_shift_out<WIDE, -1>(mhl, mhh, F.score);
     F.pvl = mhl | ~(xvl | phl);
     F.mvl = phl & xvl;
     if (WIDE) {
         F.pvh = mhh | ~(xvh | phh);
         F.mvh = phh & xvh;
     }
-    if (F.score <= u.k) {
-        if (F.j_first == 0) F.j_first = j;
-        F.j_last = j;
-        if (F.score == 0 && j >= u.m && F.j_exact == 0) F.j_exact = j;
+    filter_push_hit(F.hits, F.score, u.k);
+    F.best = atr_minu(F.best, ((uint32_t)F.score << 10) + tag);
+}
+
+// Fold the hit bits of the (at most 32) columns swept since the last fold into j_first /
+// j_last; j = the last column this read has swept.
+ATR_DEV void filter_fold(FilterState &F, int j) {
+    if (F.hits != 0u) {
+        const int hi = 31 - atr_clz(F.hits), lo = atr_ctz(F.hits);
+        if (F.j_first == 0) F.j_first = j - hi;
+        F.j_last = j - lo;
+        F.hits = 0u;
     }
 }
 
@@ -119,9 +177,11 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
 ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const int16_t *thr, int &cost_of_largest) {
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
     cost_of_largest = 0;
+    const int off = filter_row_offset(u.m);
     for (int i = 1; i <= u.m; ++i) {
-        const uint32_t pw = (i <= 32) ? F.pvl : F.pvh, mw = (i <= 32) ? F.mvl : F.mvh;
-        d += (int)((pw >> ((i - 1) & 31)) & 1u) - (int)((mw >> ((i - 1) & 31)) & 1u);
+        const int b = off + i - 1;
+        const uint32_t pw = (b < 32) ? F.pvl : F.pvh, mw = (b < 32) ? F.mvl : F.mvh;
+        d += (int)((pw >> (b & 31)) & 1u) - (int)((mw >> (b & 31)) & 1u);
         if ((u.er || i == u.m) && i >= u.min_overlap && d <= (int)thr[i]) { largest = i; cost_of_largest = d; }
     }
     return largest;
@@ -131,9 +191,9 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const int
 // read is resolved here, in which case rec[] holds its result record).
 ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, int n, const int16_t *thr, uint32_t rec[4]) {
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
-    if (F.j_exact != 0 && u.m >= u.min_overlap) {
+    if ((F.best >> 10) == 0u && u.m >= u.min_overlap) {
         // first perfect full-length occurrence: the reference breaks out here (:456-458)
-        const int j = F.j_exact;
+        const int j = (int)(F.best & 1023u);
         rec[0] = (uint32_t)u.m << 16;                                   // refstart 0, refstop m
         rec[1] = (uint32_t)(j - u.m) | ((uint32_t)j << 16);             // querystart, querystop
         rec[2] = (uint32_t)u.m;                                         // matches m, errors 0

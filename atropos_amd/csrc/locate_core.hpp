@@ -38,6 +38,8 @@ static inline int atr_max(int a, int b) { return a > b ? a : b; }
 static inline uint32_t atr_minu(uint32_t a, uint32_t b) { return a < b ? a : b; }
 static inline uint32_t atr_mad24(uint32_t a, uint32_t b, uint32_t c) { return a * b + c; }
 static inline uint32_t atr_bfe1(uint32_t w, int i) { return (w >> i) & 1u; }
+static inline int atr_clz(uint32_t w) { return __builtin_clz(w); }     // w != 0
+static inline int atr_ctz(uint32_t w) { return __builtin_ctz(w); }     // w != 0
 #else
 #define ATR_DEV __device__ __forceinline__
 #ifndef ATR_DEV_MEMBER
@@ -46,6 +48,8 @@ static inline uint32_t atr_bfe1(uint32_t w, int i) { return (w >> i) & 1u; }
 #define atr_min min
 #define atr_max max
 #define atr_minu min
+static __device__ __forceinline__ int atr_clz(uint32_t w) { return __clz((int)w); }
+static __device__ __forceinline__ int atr_ctz(uint32_t w) { return __ffs((int)w) - 1; }
 // bit i of w as 0/1, and a*b+c with a 24-bit product: written as inline asm because hipcc
 // otherwise rewrites the 0/1 multiply into and + cmp + cndmask + add
 static __device__ __forceinline__ uint32_t atr_bfe1(uint32_t w, int i) {

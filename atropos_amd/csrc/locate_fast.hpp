@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         ++j;
-                        if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, j);
+                        if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, j));
                     }
                     if (j >= jhi) break;                     // wave-uniform
                 }
+                filter_fold(F, RAGGED ? min(n, min(j, jhi)) : min(j, jhi));   // at most 32 columns since the last fold
             }
         }
         if (live) {

@@ -94,8 +94,9 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         filter_init(F, u);
         for (int j = 1; j <= n; ++j) {
             const uint64_t eq = a->peq[read_code(packed, nchunks, r, j)];
-            if (u.m > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), j);
-            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), j);
+            if (u.m > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, j));
+            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, j));
+            if ((j & 31) == 0 || j == n) filter_fold(F, j);        // as the kernel: once per 32-column chunk
         }
         uint32_t rec[4];
         const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
