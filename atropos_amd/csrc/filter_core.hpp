@@ -58,7 +58,7 @@ ATR_DEV int window_bin(uint32_t w, int m) { return (window_lo(w) >> 3) + (window
 
 struct FilterState {
     uint32_t pvl, pvh, mvl, mvh;                    // vertical +1 / -1 deltas of the current column (lo/hi words)
-    int score;                                      // D[m][j]
+    int score;                                      // D[m][j] - (k + 1): negative <=> row m is a candidate in this column
     uint32_t hits;                                  // bit b: D[m][j - b] <= k, over the columns swept since the last fold
     uint32_t best;                                  // min over the swept columns j >= m of (D[m][j] << 10 | j)
     int j_first, j_last;                            // first / last column with D[m][j] <= k (0: none), as of the last fold
@@ -79,16 +79,19 @@ ATR_DEV void filter_init(FilterState &F, const Uniform &u) {
     if (u.m > 32) { F.pvl = u.sr ? 0u : low; F.pvh = u.sr ? 0u : ~0u; }
     else { F.pvl = u.sr ? 0u : low; F.pvh = 0u; }
     F.mvl = F.mvh = 0u;
-    F.score = u.sr ? 0 : u.m;
+    F.score = (u.sr ? 0 : u.m) - (u.k + 1);
     F.hits = 0u;
     F.best = ~0u;
     F.j_first = F.j_last = 0;
 }
 
-// Column tag of the exact-hit tracker: the column number, plus a penalty that keeps columns
-// j < m (where a zero cost is only possible with START_WITHIN_SEQ1 and is no full-length
-// occurrence, _align.pyx:456-458 needs the whole reference inside the read) from ever winning.
-ATR_DEV uint32_t filter_column_tag(const Uniform &u, int j) { return (uint32_t)j | (j < u.m ? 1u << 20 : 0u); }
+// Column tag of the exact-hit tracker: the column number, the bias of the stored score, plus a
+// penalty that keeps columns j < m (where a zero cost is only possible with START_WITHIN_SEQ1
+// and is no full-length occurrence: _align.pyx:456-458 needs the whole reference inside the
+// read) from ever winning.
+ATR_DEV uint32_t filter_column_tag(const Uniform &u, int j) {
+    return (uint32_t)j + ((uint32_t)(u.k + 1) << 10) + (j < u.m ? 1u << 20 : 0u);
+}
 
 // x <<= 1 on a one- or two-word vector; the bit shifted out of the top is added to
 // (SIGN = +1) or subtracted from (SIGN = -1) score.
@@ -118,19 +121,19 @@ ATR_DEV void filter_shift_out(uint32_t &lo, uint32_t &hi, int &score) {
 #endif
 }
 
-// hits = hits << 1 | (score <= k)
-ATR_DEV void filter_push_hit(uint32_t &hits, int score, int k) {
+// hits = hits << 1 | (D <= k): the sign bit of the biased score, one v_alignbit_b32
+ATR_DEV void filter_push_hit(uint32_t &hits, int score) {
 #ifdef ATR_HOST_EMU
-    hits = (hits << 1) | (score <= k ? 1u : 0u);
+    hits = (hits << 1) | ((uint32_t)score >> 31);
 #else
-    asm("v_cmp_ge_i32 vcc, %2, %1\n\ts_nop 1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(hits) : "v"(score), "s"(k) : "vcc");
+    hits = __builtin_amdgcn_alignbit(hits, (uint32_t)score, 31);
 #endif
 }
 
 // One column of Myers' recurrence (Hyyro's formulation), row-0 delta 0 (free start in the
 // read), written on explicit 32-bit halves: gfx950 has no full-rate 64-bit shift or add.
 // WIDE = adapter longer than 32 bases (both words live); otherwise only the low word.
-// tag = filter_column_tag(u, j).  ~28 VALU ops (WIDE) / ~17 per column.
+// tag = filter_column_tag(u, j).  ~27 VALU ops (WIDE) / ~16 per column, mask fetch included.
 template <bool WIDE>
 ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
     const uint32_t xvl = eql | F.mvl;
@@ -156,7 +159,7 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
         F.pvh = mhh | ~(xvh | phh);
         F.mvh = phh & xvh;
     }
-    filter_push_hit(F.hits, F.score, u.k);
+    filter_push_hit(F.hits, F.score);
     F.best = atr_minu(F.best, ((uint32_t)F.score << 10) + tag);
 }
 

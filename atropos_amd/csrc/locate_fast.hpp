@@ -94,9 +94,15 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                     cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
                     // the eight match masks of this dword are fetched from LDS up front so that
                     // their latency overlaps the (serially dependent) column updates
+                    // (byte offsets of the eight entries: even / odd nibbles pre-scaled by 8, 12 ops per dword)
+                    uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
+                    asm("" : "+v"(ev), "+v"(od));            // keep hipcc from re-deriving each offset from w (2 ops apiece)
                     uint2 e[8];
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) e[b] = s_peq[(w >> (4 * b)) & 15u];
+                    for (int b = 0; b < 8; ++b) {
+                        const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
+                        e[b] = *(const uint2 *)((const char *)s_peq + off);
+                    }
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         ++j;
