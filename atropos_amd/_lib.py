@@ -72,7 +72,30 @@ PROTOTYPES = {
     "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "atr_fastq_work_bytes": (C.c_size_t, [C.c_int64]),
+    "atr_fastq_count_lines": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_fastq_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "atr_pack_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_clip_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "atr_quality_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_void_p]),
+    "atr_nend_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int64, C.c_void_p]),
+    "atr_match_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p]),
+    "atr_read_filter_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p]),
+    "atr_fastq_emit_work_bytes": (C.c_size_t, [C.c_int64]),
+    "atr_fastq_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
+
+FASTQ_ERR_AT, FASTQ_ERR_PLUS, FASTQ_ERR_NAME2, FASTQ_ERR_LENGTH = 1, 2, 3, 4
+DEST_KEEP, DEST_TOO_SHORT, DEST_TOO_LONG, DEST_TOO_MANY_N, DEST_TRIMMED, DEST_UNTRIMMED = range(6)
+INT64_MAX = (1 << 63) - 1
 
 
 class AtroposHipError(RuntimeError):
@@ -267,6 +290,85 @@ class HipBackend(object):
                 _check(self.lib, self.lib.atr_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
                                                            _ptr(work), self._stream()), "atr_locate_batch")
         return out
+
+
+    # -- device-resident FASTQ batch --------------------------------------------
+    def fastq_index(self, data, nbytes, strip):
+        """data: uint8 device tensor holding nbytes of FASTQ text (16-byte aligned, readable up
+        to the next multiple of 16).  Returns (records uint32 [nrec, 8], nlines, error word)."""
+        work = self.empty((max(self.lib.atr_fastq_work_bytes(nbytes), 16),), torch.uint8)
+        info = self.empty((2,), torch.int64)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_fastq_count_lines(_ptr(data), nbytes, _ptr(work), _ptr(info), self._stream()),
+                   "atr_fastq_count_lines")
+            nlines = int(info[0].item())
+            line_ends = self.empty((max(nlines, 1),), torch.int32)
+            records = self.empty((nlines // 4, 8), torch.int32)
+            _check(self.lib, self.lib.atr_fastq_index(_ptr(data), nbytes, strip, _ptr(work), _ptr(line_ends), nlines,
+                                                      _ptr(records), C.c_void_p(info.data_ptr() + 8), self._stream()),
+                   "atr_fastq_index")
+            err = int(info[1].item())
+        return records, line_ends, nlines, err
+
+    def pack_records(self, data, records, begin, end, max_len, table, count_invalid=False):
+        n = records.shape[0]
+        packed = self.empty((max(self.packed_bytes(n, max_len), 16),), torch.uint8)
+        lens = self.empty((n,), torch.int32)
+        invalid = torch.zeros((1,), dtype=torch.int32, device=self.device) if count_invalid else None
+        if n:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_pack_records(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), n, max_len,
+                                                           table, _ptr(packed), _ptr(lens), _ptr(invalid),
+                                                           self._stream()), "atr_pack_records")
+        return (packed, lens, int(invalid.item())) if count_invalid else (packed, lens)
+
+    def clip_batch(self, records, begin, end, front, back):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_clip_batch(_ptr(records), _ptr(begin), _ptr(end), begin.shape[0], front, back,
+                                                     self._stream()), "atr_clip_batch")
+
+    def quality_trim_batch(self, data, records, begin, end, cutoff_front, cutoff_back, base, nextseq):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_quality_trim_batch(_ptr(data), _ptr(records), _ptr(begin), _ptr(end),
+                                                             begin.shape[0], cutoff_front, cutoff_back, base,
+                                                             int(nextseq), self._stream()), "atr_quality_trim_batch")
+
+    def nend_trim_batch(self, data, records, begin, end, ubegin=None, uend=None):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_nend_trim_batch(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin),
+                                                          _ptr(uend), begin.shape[0], self._stream()),
+                   "atr_nend_trim_batch")
+
+    def match_trim_batch(self, matches, front, default_front, begin, end, active, matched):
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_match_trim_batch(_ptr(matches), _ptr(front), default_front, _ptr(begin),
+                                                           _ptr(end), _ptr(active), _ptr(matched), begin.shape[0],
+                                                           self._stream()), "atr_match_trim_batch")
+
+    def read_filter_batch(self, data, records, begin, end, ubegin, uend, matched, min_len, max_len, max_n,
+                          discard_trimmed, discard_untrimmed):
+        dest = self.empty((begin.shape[0],), torch.uint8)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_read_filter_batch(
+                _ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend), _ptr(matched),
+                begin.shape[0], min_len, max_len, max_n, int(discard_trimmed), int(discard_untrimmed), _ptr(dest),
+                self._stream()), "atr_read_filter_batch")
+        return dest
+
+    def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
+        """Formatted FASTQ text (uint8 device tensor) of the records with dest == which."""
+        n = records.shape[0]
+        offsets = self.empty((n + 1,), torch.int64)
+        work = self.empty((max(self.lib.atr_fastq_emit_work_bytes(n), 16),), torch.uint8)
+        with torch.cuda.device(self.device):
+            args = (_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend), _ptr(dest), which, n,
+                    _ptr(offsets), _ptr(work))
+            _check(self.lib, self.lib.atr_fastq_emit(*args, None, self._stream()), "atr_fastq_emit")
+            total = int(offsets[n].item())
+            out = self.empty((max(total, 1),), torch.uint8)
+            if total:
+                _check(self.lib, self.lib.atr_fastq_emit(*args, _ptr(out), self._stream()), "atr_fastq_emit")
+        return out[:total]
 
 
 _backend = None

@@ -115,6 +115,30 @@ def _seq_of(read):
     return read if isinstance(read, str) else read.sequence
 
 
+class AsciiSource(object):
+    """Read source of the device-resident matchers: an upper-case ASCII matrix on the GPU
+    (optionally sliced per read by ``starts``), packed on demand once per translate table."""
+
+    def __init__(self, ascii_upper, lens=None, starts=None, batch=None):
+        self.ascii_upper, self.lens, self.starts = ascii_upper, lens, starts
+        self.n = ascii_upper.shape[0]
+        self._batches = {}
+        if batch is not None and starts is None:
+            self._batches[(batch.table_kind, batch.table)] = batch
+
+    def batch(self, table_kind, table):
+        key = (table_kind, bytes(table))
+        if key not in self._batches:
+            self._batches[key] = ReadBatch.from_ascii(self.ascii_upper, self.lens, None, table_kind, table,
+                                                      _lib.get_backend(), starts=self.starts)
+        return self._batches[key]
+
+    def ascii(self):
+        if self.starts is not None:
+            raise NotImplementedError("sliced reads with anchored no-indel adapters")
+        return self.ascii_upper, self.lens
+
+
 class Adapter(object):
     """An adapter knows how to match itself to a read: where it may sit within the read
     and how wildcard characters are interpreted.
@@ -298,19 +322,20 @@ class Adapter(object):
         Returns the int16 [n, 8] record tensor with ``refstop = -1`` wherever ``match_to``
         would return None: alignment, exact-match shortcut and post-filters
         (adapters/__init__.py:338-400) are all evaluated on the device."""
+        return self.match_source(AsciiSource(ascii_upper, lens, starts, batch))
+
+    def match_source(self, source):
+        """``match_records`` over any read source: an object with ``n``, ``batch(table_kind,
+        table)`` (the reads 4-bit packed with that table) and ``ascii()`` ((uint8 [n, width]
+        upper-case matrix, lens) -- only anchored no-indel adapters need it)."""
         be = _lib.get_backend()
         m = len(self.sequence)
-        n = ascii_upper.shape[0]
         if not self.indels and self.where in (PREFIX, SUFFIX):
-            if starts is not None:
-                raise NotImplementedError("sliced reads with anchored no-indel adapters")
+            ascii_upper, lens = source.ascii()
             rec = align.compare_batch(self.sequence, ascii_upper, self.adapter_wildcards, self.read_wildcards,
                                       suffix=(self.where == SUFFIX), lens=lens)
         else:
-            if batch is None or batch.table_kind != self.aligner.table_kind or starts is not None:
-                batch = ReadBatch.from_ascii(ascii_upper, lens, None, self.aligner.table_kind,
-                                             self.aligner._table, be, starts=starts)
-            rec = self.aligner.locate_batch(batch).records
+            rec = self.aligner.locate_batch(source.batch(self.aligner.table_kind, self.aligner._table)).records
         rmp_t = None
         if self.max_rmp is not None:
             if self._rmp_device is None or self._rmp_device.device != be.device:
@@ -325,9 +350,8 @@ class Adapter(object):
             # the literal first occurrence wins over whatever the wildcard DP found
             if self._exact_aligner is None:
                 self._exact_aligner = align.Aligner(self.sequence, 0.0, flags=self.where, min_overlap=m)
-            eb = ReadBatch.from_ascii(ascii_upper, lens, None, self._exact_aligner.table_kind,
-                                      self._exact_aligner._table, be, starts=starts)
-            ex = self._exact_aligner.locate_batch(eb).records
+            ex = self._exact_aligner.locate_batch(
+                source.batch(self._exact_aligner.table_kind, self._exact_aligner._table)).records
             rec = torch.where((ex[:, 1] >= 0)[:, None], ex, rec)
         return rec
 

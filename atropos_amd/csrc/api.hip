@@ -34,7 +34,7 @@ locate_launcher locate_group_0(int), locate_group_1(int), locate_group_2(int), l
 
 static thread_local std::string g_err;
 
-static int hip_fail(hipError_t e, const char *what) {
+int hip_fail(hipError_t e, const char *what) {             // shared with fastq_kernels.hip
     g_err = std::string(what) + ": " + hipGetErrorString(e);
     return ATR_ERR_HIP;
 }

@@ -1,0 +1,180 @@
+// fastq_core.hpp -- per-record arithmetic of the device-resident FASTQ batch: record
+// indexing/validation, quality trimming, N-end trimming, read filters.
+//
+// The reference reads FASTQ into one Python `Sequence` object per record
+// (atropos/io/_seqio.pyx:163-245), runs each modifier per read
+// (commands/trim/modifiers.py) and formats each surviving read back to text
+// (io/seqio.py:686-700).  Here a batch is the raw file bytes in HBM plus one 32-byte
+// record descriptor per read and a kept interval [begin, end) of its sequence line;
+// every trimming modifier of the single-end path only ever clips the ends, so it is an
+// interval update, and the writer slices the original bytes.
+//
+// Compiled for gfx950 and, with -DATR_HOST_EMU, for the CPU test emulation (tests/emu).
+#ifndef ATR_FASTQ_CORE_HPP
+#define ATR_FASTQ_CORE_HPP
+
+#include <stdint.h>
+#include "atropos_hip.h"
+
+#ifdef ATR_HOST_EMU
+#ifndef ATR_DEV
+#define ATR_DEV static inline
+#endif
+#else
+#ifndef ATR_DEV
+#define ATR_DEV __device__ __forceinline__
+#endif
+#endif
+
+namespace atr {
+
+// Descriptor of one record; same layout as atr_fastq_record.
+struct FastqRecord {
+    uint32_t name_off, name_len;                     // the description after '@' (line end stripped)
+    uint32_t seq_off, seq_len;
+    uint32_t qual_off, qual_len;
+    uint32_t flags;                                  // bit 0: the '+' line repeats the description (name2 = name)
+    uint32_t reserved;
+};
+
+// Line L (0-based) is bytes [start, end] where end = line_ends[L] is the position of its
+// '\n' and start = L ? line_ends[L-1] + 1 : 0.  `strip` is the reference's per-file line-end
+// width (1, or 2 when the FIRST line of the file ends in "\r\n": _seqio.pyx:205).
+// Returns 0 or an ATR_FASTQ_ERR_* code (the record is still written, for the message).
+ATR_DEV int fastq_record_one(const uint8_t *bytes, const uint32_t *line_ends, long long r, int strip, FastqRecord &rec) {
+    const long long L = 4 * r;
+    const uint32_t s0 = L ? line_ends[L - 1] + 1 : 0u;
+    const uint32_t e0 = line_ends[L], e1 = line_ends[L + 1], e2 = line_ends[L + 2], e3 = line_ends[L + 3];
+    const uint32_t s1 = e0 + 1, s2 = e1 + 1, s3 = e2 + 1;
+    const uint32_t len0 = e0 - s0 + 1, len1 = e1 - s1 + 1, len2 = e2 - s2 + 1, len3 = e3 - s3 + 1;   // with '\n'
+    int err = 0;
+    // line 1: '@' + name                                            (_seqio.pyx:208-216)
+    if (bytes[s0] != '@') err = ATR_FASTQ_ERR_AT;
+    rec.name_off = s0 + 1;
+    rec.name_len = len0 > 1u + (uint32_t)strip ? len0 - 1u - (uint32_t)strip : 0u;          // line[1:strip]
+    // line 2: sequence = line[:strip]                               (:217-218)
+    rec.seq_off = s1;
+    rec.seq_len = len1 > (uint32_t)strip ? len1 - (uint32_t)strip : 0u;
+    // line 3: '+' or '+' + name                                     (:219-238)
+    rec.flags = 0;
+    if (!(len2 == 2 && bytes[s2] == '+')) {                          // not the common "+\n"
+        const uint32_t l2 = len2 > (uint32_t)strip ? len2 - (uint32_t)strip : 0u;            // line[:strip]
+        if (l2 == 0 || bytes[s2] != '+') {
+            if (!err) err = ATR_FASTQ_ERR_PLUS;
+        } else if (l2 > 1) {
+            bool same = (l2 - 1 == rec.name_len);
+            for (uint32_t i = 0; same && i < rec.name_len; ++i) same = bytes[s2 + 1 + i] == bytes[rec.name_off + i];
+            if (!same) { if (!err) err = ATR_FASTQ_ERR_NAME2; }
+            else rec.flags = 1;
+        }
+    }
+    // line 4: qualities                                             (:239-243)
+    rec.qual_off = s3;
+    if (len3 == rec.seq_len + (uint32_t)strip) {
+        rec.qual_len = rec.seq_len;
+    } else {
+        uint32_t q = len3;                                           // rstrip('\r\n')
+        while (q > 0 && (bytes[s3 + q - 1] == '\n' || bytes[s3 + q - 1] == '\r')) --q;
+        rec.qual_len = q;
+    }
+    if (rec.qual_len != rec.seq_len && !err) err = ATR_FASTQ_ERR_LENGTH;                      // _seqio.pyx:33-43
+    rec.reserved = 0;
+    return err;
+}
+
+// quality_trim_index on qualities[begin:end]  (commands/trim/_qualtrim.pyx:7-48).
+ATR_DEV void quality_trim_one(const uint8_t *qual, int len, int cutoff_front, int cutoff_back, int base,
+                              int &start, int &stop) {
+    start = 0;
+    stop = len;
+    int s = 0, max_qual = 0;
+    for (int i = 0; i < len; ++i) {
+        s += cutoff_front - ((int)qual[i] - base);
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; start = i + 1; }
+    }
+    max_qual = 0;
+    s = 0;
+    for (int i = len - 1; i >= 0; --i) {
+        s += cutoff_back - ((int)qual[i] - base);
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; stop = i; }
+    }
+    if (start >= stop) { start = 0; stop = 0; }
+}
+
+// nextseq_trim_index  (_qualtrim.pyx:51-84): as the 3' part above, but a 'G' counts as
+// quality cutoff - 1.
+ATR_DEV int nextseq_trim_one(const uint8_t *seq, const uint8_t *qual, int len, int cutoff, int base) {
+    int s = 0, max_qual = 0, max_i = len;
+    for (int i = len - 1; i >= 0; --i) {
+        int q = (int)qual[i] - base;
+        if (seq[i] == 'G') q = cutoff - 1;
+        s += cutoff - q;
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; max_i = i; }
+    }
+    return max_i;
+}
+
+// Base i of the current read seq[0:len) when AdapterCutter's action is 'mask': positions
+// outside [ub, ue) were replaced by 'N' (modifiers.py:155-172).  ub = 0, ue = len: no mask.
+ATR_DEV uint8_t masked_base(const uint8_t *seq, int i, int ub, int ue) { return (i >= ub && i < ue) ? seq[i] : (uint8_t)'N'; }
+
+// NEndTrimmer (modifiers.py:766-784): regexes ^N+ and N+$ on the sequence -- upper-case N only.
+ATR_DEV void nend_trim_one(const uint8_t *seq, int len, int ub, int ue, int &start, int &stop) {
+    int a = 0;
+    while (a < len && masked_base(seq, a, ub, ue) == 'N') ++a;
+    // `N+$` is searched on the whole string: for an all-N read both regexes match everything
+    int b = len;
+    while (b > 0 && masked_base(seq, b - 1, ub, ue) == 'N') --b;
+    start = a;
+    stop = b;
+}
+
+// Python's read[begin:end] on a read of length len, end may be "None" (= len) -- slice
+// clamping for a non-negative begin and any end (negative counts from the end).
+ATR_DEV void py_clip(int len, int begin, int end_or_neg, bool has_end, int &a, int &b) {
+    a = begin > len ? len : begin;
+    b = len;
+    if (has_end) {
+        int e = end_or_neg;
+        if (e < 0) e += len;
+        if (e < 0) e = 0;
+        if (e > len) e = len;
+        b = e;
+    }
+    if (b < a) b = a;
+}
+
+// The destination of a read after all modifiers (commands/trim/filters.py:109-184, in the
+// order trim/__init__.py:566-601 adds them): the first filter that fires wins.
+//   too short, too long, too many N, discard-trimmed, (then) discard-untrimmed.
+ATR_DEV int read_filter_one(const uint8_t *seq, int len, int ub, int ue, bool matched, int min_len, int max_len,
+                            double max_n, int discard_trimmed, int discard_untrimmed) {
+    if (min_len > 0 && len < min_len) return ATR_DEST_TOO_SHORT;
+    if (max_len >= 0 && len > max_len) return ATR_DEST_TOO_LONG;
+    if (max_n >= 0.0) {
+        int n_count = 0;
+        for (int i = 0; i < len; ++i) {
+            const uint8_t c = masked_base(seq, i, ub, ue);
+            n_count += (c == 'N' || c == 'n') ? 1 : 0;
+        }
+        if (max_n < 1.0) {
+            if (len != 0 && (double)n_count / (double)len > max_n) return ATR_DEST_TOO_MANY_N;
+        } else if ((double)n_count > max_n) {
+            return ATR_DEST_TOO_MANY_N;
+        }
+    }
+    if (discard_trimmed && matched) return ATR_DEST_TRIMMED;
+    if (discard_untrimmed && !matched) return ATR_DEST_UNTRIMMED;
+    return ATR_DEST_KEEP;
+}
+
+// Bytes of a formatted record (io/seqio.py:690-699): '@' name '\n' seq '\n+' name2 '\n' qual '\n'
+ATR_DEV uint32_t fastq_record_bytes(const FastqRecord &rec, int kept) {
+    return 1u + rec.name_len + 1u + (uint32_t)kept + 2u + ((rec.flags & 1u) ? rec.name_len : 0u) + 1u + (uint32_t)kept + 1u;
+}
+
+}  // namespace atr
+#endif

@@ -1,0 +1,170 @@
+"""Device-resident FASTQ batches: the MI355X replacement for the reference's per-record
+``FastqReader`` / ``Sequence`` / ``FastqFormat`` path (atropos/io/_seqio.pyx:163-245,
+atropos/io/seqio.py:686-700).
+
+A chunk of the file is uploaded as raw bytes; the library finds and validates the records
+(``atr_fastq_index``), every trimming step is an update of a kept interval per read, and the
+surviving records are formatted on the device (``atr_fastq_emit``).  No per-read Python
+object exists anywhere on this path.
+"""
+import torch
+
+from . import _lib
+
+
+class FormatError(Exception):
+    """Malformed input file (atropos/io/seqio.py FormatError)."""
+
+
+def _strip_width(first_line):
+    """The reference fixes the line-end width once per file from its first line
+    (_seqio.pyx:205): 2 for "\\r\\n", else 1."""
+    return 2 if first_line.endswith(b"\r\n") else 1
+
+
+def _text(b):
+    return bytes(b).decode("utf-8", "replace")
+
+
+class FastqBatch(object):
+    """Whole FASTQ records in device memory.
+
+    Attributes:
+        data: uint8 tensor with the chunk's bytes (padded to a multiple of 16).
+        nbytes: bytes of text in ``data``.
+        records: int32 [n, 8] descriptors (``atr_fastq_record``): name_off, name_len,
+            seq_off, seq_len, qual_off, qual_len, flags, reserved.
+        strip: the file's line-end width (1 or 2).
+    """
+
+    def __init__(self, data, nbytes, records, strip, backend):
+        self.data, self.nbytes, self.records, self.strip, self.backend = data, nbytes, records, strip, backend
+
+    def __len__(self):
+        return self.records.shape[0]
+
+    @property
+    def seq_lens(self):
+        return self.records[:, 3].contiguous()
+
+    @classmethod
+    def from_bytes(cls, buf, final=True, strip=None, backend=None):
+        """Index ``buf`` (bytes-like FASTQ text that starts at a record boundary).
+
+        final=True: ``buf`` is the rest of the file -- a missing last newline is tolerated
+        and leftover lines raise "FASTQ file ended prematurely" (_seqio.pyx:244-245).
+        final=False: only whole records are taken; the number of bytes consumed is returned
+        so that the caller can prepend the remainder to its next chunk.
+        Returns (batch, consumed_bytes)."""
+        be = backend or _lib.get_backend()
+        buf = bytes(buf) if not isinstance(buf, (bytes, bytearray)) else buf
+        if strip is None:
+            nl = buf.find(b"\n")
+            strip = _strip_width(buf[:nl + 1] if nl >= 0 else buf)
+        if final and len(buf) and not buf.endswith(b"\n"):
+            buf = bytes(buf) + b"\n"
+        nbytes = len(buf)
+        if nbytes >= (1 << 32) - 16:
+            raise ValueError("a FASTQ batch must be smaller than 4 GiB; read the file in chunks")
+        padded = (nbytes + 15) // 16 * 16 + 16
+        host = torch.zeros((padded,), dtype=torch.uint8)
+        if nbytes:
+            host[:nbytes] = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
+        data = be.empty((padded,), torch.uint8)
+        data.copy_(host)
+        return cls.from_device(data, nbytes, strip, final, be, host_text=buf)
+
+    @classmethod
+    def from_device(cls, data, nbytes, strip=1, final=True, backend=None, host_text=None):
+        """Index FASTQ text that already sits in device memory: ``data`` is a uint8 tensor,
+        16-byte aligned, readable up to the next multiple of 16 beyond ``nbytes``, whose
+        text ends in a newline.  Returns (batch, consumed_bytes)."""
+        be = backend or _lib.get_backend()
+        records, line_ends, nlines, err = be.fastq_index(data, nbytes, strip)
+        nrec = nlines // 4
+        if err != _lib.INT64_MAX:
+            if host_text is None:
+                host_text = bytes(data[:nbytes].cpu().numpy().tobytes())
+            cls._raise_format_error(host_text, line_ends, err, strip)
+        if final and nlines % 4 != 0:
+            raise FormatError("FASTQ file ended prematurely")
+        consumed = nbytes
+        if not final:
+            consumed = int(line_ends[4 * nrec - 1].item()) + 1 if nrec else 0
+        return cls(data, nbytes, records[:nrec], strip, be), consumed
+
+    @staticmethod
+    def _raise_format_error(buf, line_ends, err, strip):
+        """Re-create the reference's message for the first invalid record."""
+        r, code = err // 8, err % 8
+        ends = [int(v) for v in line_ends[max(4 * r - 1, 0):4 * r + 4].cpu().tolist()]
+        if r == 0:
+            ends = [-1] + ends
+        lines = [buf[ends[i] + 1:ends[i + 1] + 1] for i in range(4)]
+        name = _text(lines[0][1:-strip])
+        if code == _lib.FASTQ_ERR_AT:                                      # _seqio.pyx:209-211 / :199-201
+            raise FormatError("Line {0} in FASTQ file is expected to start with '@', but found {1!r}".format(
+                1, _text(lines[0])[:10]))
+        if code == _lib.FASTQ_ERR_PLUS:                                    # :224-227
+            raise FormatError("Line {0} in FASTQ file is expected to start with '+', but found {1!r}".format(
+                3, _text(lines[2][:-strip])[:10]))
+        if code == _lib.FASTQ_ERR_NAME2:                                   # :229-235
+            raise FormatError(
+                "At line {0}: Sequence descriptions in the FASTQ file don't match "
+                "({1!r} != {2!r}).\n"
+                "The second sequence description must be either empty "
+                "or equal to the first description.".format(3, name, _text(lines[2][:-strip])[1:]))
+        seq = lines[1][:-strip]
+        qual = lines[3][:-strip] if len(lines[3]) == len(seq) + strip else lines[3].rstrip(b"\r\n")
+        rname = name if len(name) <= 100 else name[:97] + "..."            # util.truncate_string
+        cause = FormatError(
+            "In read named {0!r}: length of quality sequence ({1}) and "
+            "length  of read ({2}) do not match".format(rname, len(qual), len(seq)))
+        raise FormatError("Error creating sequence record at line {}".format(4)) from cause
+
+    # ------------------------------------------------------------------ views for tests / small batches
+    def to_records(self, begin=None, end=None):
+        """Host copies [(name, sequence, qualities, name2), ...] -- test helper, not a product path."""
+        raw = bytes(self.data[:self.nbytes].cpu().numpy().tobytes())
+        out = []
+        rec = self.records.cpu().tolist()
+        b0 = None if begin is None else begin.cpu().tolist()
+        e0 = None if end is None else end.cpu().tolist()
+        for i, (no, nl, so, sl, qo, ql, fl, _) in enumerate(rec):
+            a = 0 if b0 is None else b0[i]
+            b = sl if e0 is None else max(a, e0[i])
+            name = raw[no:no + nl].decode("ascii", "replace")
+            out.append((name, raw[so + a:so + b].decode("ascii", "replace"),
+                        raw[qo + a:qo + b].decode("ascii", "replace"), name if fl & 1 else ""))
+        return out
+
+
+class RecordSource(object):
+    """Read source of the device-resident adapter matchers (``Adapter.match_source``) over the
+    kept intervals of a FastqBatch: packs ``sequence[begin:end]`` once per translate table."""
+
+    def __init__(self, batch, begin, end):
+        self.fq, self.begin, self.end = batch, begin, end
+        self.n = len(batch)
+        self._batches = {}
+
+    def batch(self, table_kind, table):
+        from .batch import ReadBatch
+        key = (table_kind, bytes(table))
+        if key not in self._batches:
+            be = self.fq.backend
+            max_len = int((self.end - self.begin).clamp_(min=0).max().item()) if self.n else 0
+            if max_len > _lib.MAX_READ_LEN:
+                raise ValueError("reads longer than %d bases are outside the device kernels' envelope"
+                                 % _lib.MAX_READ_LEN)
+            # Adapter.match_to upper-cases the read first (adapters/__init__.py:349): fold that
+            # into the translate table instead of touching the bytes
+            folded = bytearray(table)
+            for c in range(ord("a"), ord("z") + 1):
+                folded[c] = table[c - 32]
+            packed, lens = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(folded))
+            self._batches[key] = ReadBatch(packed, lens, self.n, max_len, table_kind, table)
+        return self._batches[key]
+
+    def ascii(self):
+        raise NotImplementedError("anchored adapters without indels are not supported by the device FASTQ pipeline")

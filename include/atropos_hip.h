@@ -221,6 +221,94 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
                              int action, int min_qual_difference, int truncate_seqs, const uint8_t comp[256],
                              int32_t *d_changed, int32_t *d_newlen, void *stream);
 
+/* ---- device-resident FASTQ batch (io/_seqio.pyx:163-245, io/seqio.py:686-700) ---- */
+
+/* One chunk of FASTQ text (whole records, < 4 GiB, 16-byte aligned, ending in '\n') is
+ * uploaded as raw bytes; the records are found, validated, trimmed and formatted on the
+ * device.  Every trimming modifier of the single-end path only clips read ends, so its
+ * state is the kept interval [d_begin[r], d_end[r]) of each record's sequence line. */
+typedef struct {
+    uint32_t name_off, name_len;   /* description after '@', line end stripped (FastqReader, _seqio.pyx:208-216) */
+    uint32_t seq_off, seq_len;     /* :217-218 */
+    uint32_t qual_off, qual_len;   /* :239-243 */
+    uint32_t flags;                /* bit 0: the '+' line repeats the description (name2 = name, :228-236) */
+    uint32_t reserved;
+} atr_fastq_record;
+
+#define ATR_FASTQ_ERR_AT      1    /* FormatError "... expected to start with '@'" (:209-211) */
+#define ATR_FASTQ_ERR_PLUS    2    /* "... expected to start with '+'" (:224-227) */
+#define ATR_FASTQ_ERR_NAME2   3    /* "Sequence descriptions in the FASTQ file don't match" (:229-235) */
+#define ATR_FASTQ_ERR_LENGTH  4    /* "length of quality sequence ... and length of read ... do not match" (:33-43) */
+
+/* Count the lines ('\n' bytes) of the chunk: *d_nlines (device int64).  d_work: caller
+ * scratch of atr_fastq_work_bytes(nbytes) bytes, to be handed unchanged to atr_fastq_index. */
+size_t atr_fastq_work_bytes(int64_t nbytes);
+int atr_fastq_count_lines(const uint8_t *d_bytes, int64_t nbytes, void *d_work, int64_t *d_nlines, void *stream);
+
+/* Positions of the line ends (d_line_ends[nlines], uint32) and the descriptors of the
+ * nlines / 4 records.  strip: 1, or 2 when the first line of the FILE ends in "\r\n" (the
+ * reference decides the line-end width once per file, :205).  *d_error (device int64)
+ * receives min over invalid records of (record * 8 + ATR_FASTQ_ERR_*), or INT64_MAX. */
+int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, int strip, const void *d_work, uint32_t *d_line_ends,
+                    int64_t nlines, atr_fastq_record *d_records, int64_t *d_error, void *stream);
+
+/* 4-bit tile64 pack (as atr_pack_reads) of sequence[begin:end] of every record; d_begin /
+ * d_end may be NULL (the whole sequence line).  d_lens receives the packed lengths. */
+int atr_pack_records(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
+                     const int32_t *d_end, int64_t nreads, int max_len, const uint8_t table[256],
+                     uint8_t *d_packed, int32_t *d_lens, int32_t *d_invalid, void *stream);
+
+/* Interval updates, each the device twin of one reference modifier applied to
+ * read[begin:end] (records with begin == end are left alone, as `if len(read) == 0`):
+ *   atr_clip_batch          UnconditionalCutter.clip(front, back <= 0)   (modifiers.py:565-585, :69-82)
+ *   atr_quality_trim_batch  QualityTrimmer / quality_trim_index          (:748-764, _qualtrim.pyx:7-48)
+ *                           nextseq != 0: NextseqQualityTrimmer with cutoff_back  (:732-746, _qualtrim.pyx:51-84)
+ *   atr_nend_trim_batch     NEndTrimmer                                   (:766-784)
+ *                           (d_unmasked_begin/end, may be NULL: AdapterCutter action 'mask' -- the
+ *                           bases of [begin, end) outside [unmasked_begin, unmasked_end) read as 'N',
+ *                           modifiers.py:155-172; the same pair is honoured by the filter and the writer)
+ *   atr_match_trim_batch    Adapter.trimmed(match) for the best match of the round: front != 0
+ *                           removes read[:querystop] (adapters/__init__.py:453-457), else keeps
+ *                           read[:querystart] (:459-471); d_front[r] selects per read (may be NULL
+ *                           = guess rstart == 0, align/__init__.py:108-114 -- 'anywhere' adapters);
+ *                           only records with refstop >= 0 and d_active[r] != 0 are touched,
+ *                           d_active[r] is cleared for reads without a match (AdapterCutter stops
+ *                           at the first failed round, modifiers.py:133-139) and d_matched[r] set. */
+int atr_clip_batch(const atr_fastq_record *d_records, int32_t *d_begin, int32_t *d_end, int64_t n, int front,
+                   int back, void *stream);
+int atr_quality_trim_batch(const uint8_t *d_bytes, const atr_fastq_record *d_records, int32_t *d_begin,
+                           int32_t *d_end, int64_t n, int cutoff_front, int cutoff_back, int base, int nextseq,
+                           void *stream);
+int atr_nend_trim_batch(const uint8_t *d_bytes, const atr_fastq_record *d_records, int32_t *d_begin,
+                        int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end, int64_t n,
+                        void *stream);
+int atr_match_trim_batch(const atr_result *d_matches, const uint8_t *d_front, int default_front, int32_t *d_begin,
+                         int32_t *d_end, uint8_t *d_active, uint8_t *d_matched, int64_t n, void *stream);
+
+/* Filters (commands/trim/filters.py:109-184) in the order trim/__init__.py:566-601 installs
+ * them; d_dest[r] = the first that fires.  min_len <= 0 / max_len < 0 / max_n < 0: off. */
+#define ATR_DEST_KEEP        0
+#define ATR_DEST_TOO_SHORT   1
+#define ATR_DEST_TOO_LONG    2
+#define ATR_DEST_TOO_MANY_N  3
+#define ATR_DEST_TRIMMED     4
+#define ATR_DEST_UNTRIMMED   5
+int atr_read_filter_batch(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
+                          const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
+                          const uint8_t *d_matched, int64_t n, int min_len, int max_len, double max_n,
+                          int discard_trimmed, int discard_untrimmed, uint8_t *d_dest, void *stream);
+
+/* FastqFormat.format_entry (io/seqio.py:690-699) of every record with d_dest[r] == dest, in
+ * input order, into d_out.  First call with d_out == NULL: d_offsets[n + 1] (device int64)
+ * receives the exclusive prefix sums of the formatted sizes (d_offsets[n] = total bytes);
+ * second call with d_out of that many bytes writes the text.  d_work: scratch of
+ * atr_fastq_emit_work_bytes(n) bytes. */
+size_t atr_fastq_emit_work_bytes(int64_t n);
+int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
+                   const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
+                   const uint8_t *d_dest, int dest, int64_t n, int64_t *d_offsets, void *d_work, uint8_t *d_out,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

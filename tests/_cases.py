@@ -448,3 +448,68 @@ def check_device_resident_adapters():
         if choice is not None:
             assert best[i, :6].tolist() == [choice.astart, choice.astop, choice.rstart, choice.rstop, choice.matches, choice.errors]
     return total
+
+
+# ---------------------------------------------------------------------------------------------
+# device-resident FASTQ pipeline (atropos_amd.trim) against outputs of the reference's
+# `atropos trim` command line (tests/golden/make_trim_golden.py)
+def check_trim_golden(select=None):
+    import base64
+    import hashlib
+    from atropos_amd.fastq import FormatError
+    from atropos_amd.trim import pipeline_from_args
+    doc = load_golden("trim_cases.json.gz")
+    inputs = {k: base64.b64decode(v) for k, v in doc["inputs"].items()}
+    done = 0
+    for case in doc["cases"]:
+        if select is not None and not select(case):
+            continue
+        data = inputs[case["input"]]
+        label = "%s: %s" % (case["input"], case["args"])
+        pipe = pipeline_from_args(case["args"])
+        if case["error"]:
+            try:
+                pipe.trim_bytes(data)
+            except FormatError as err:
+                assert type(err).__name__ == case["error"][0], label
+                assert str(err) == case["error"][1], (label, str(err), case["error"][1])
+                if len(case["error"]) > 2:
+                    assert str(err.__cause__) == case["error"][2], (label, str(err.__cause__), case["error"][2])
+            else:
+                raise AssertionError("no FormatError raised for " + label)
+        else:
+            out = pipe.trim_bytes(data)
+            want = base64.b64decode(case["output"])
+            if case["size"] <= 20000:
+                assert out == want, (label, out[:300], want[:300])
+            else:
+                head = out[:len(want)]
+                assert head == want, (label, _first_diff(head, want))
+            assert len(out) == case["size"], (label, len(out), case["size"])
+            assert hashlib.sha256(out).hexdigest() == case["sha256"], label
+        done += 1
+    return done
+
+
+def _first_diff(a, b):
+    for i in range(min(len(a), len(b))):
+        if a[i] != b[i]:
+            lo = max(0, i - 200)
+            return i, a[lo:i + 100], b[lo:i + 100]
+    return min(len(a), len(b)), None, None
+
+
+def check_fastq_chunking(tmp_path):
+    """trim_file in small chunks == one batch (records straddling chunk borders are carried over)."""
+    import base64
+    from atropos_amd.trim import pipeline_from_args
+    doc = load_golden("trim_cases.json.gz")
+    data = base64.b64decode(doc["inputs"]["synth.fastq"])
+    pipe = pipeline_from_args("-a AGATCGGAAGAGCACACGTCTGAACTCCAGTCA -q 20 -m 20")
+    whole = pipe.trim_bytes(data)
+    src, dst = tmp_path / "in.fastq", tmp_path / "out.fastq"
+    src.write_bytes(data)
+    counts = pipe.trim_file(str(src), str(dst), chunk_bytes=50000)
+    assert dst.read_bytes() == whole
+    assert sum(counts.values()) == data.count(b"\n") // 4
+    return counts

@@ -12,11 +12,11 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _SO = os.path.join(_HERE, "libemu_locate.so")
-_CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "emu_misc.cpp")]
+_CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "emu_misc.cpp", "emu_fastq.cpp")]
 _SRCS = _CPPS + [
     os.path.join(_ROOT, "atropos_amd", "csrc", f)
     for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp",
-              "filter_core.hpp")] + [
+              "filter_core.hpp", "fastq_core.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -193,3 +193,63 @@ class EmuBackend(object):
             _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), int(filtered)),
                    "atr_locate_batch")
         return out
+
+    # -- device-resident FASTQ batch (CPU twin) ----------------------------------
+    def fastq_index(self, data, nbytes, strip):
+        L = self.lib
+        info = torch.zeros((2,), dtype=torch.int64)
+        _check(L.emu_fastq_count_lines(_ptr(data), C.c_int64(nbytes), _ptr(info)), "emu_fastq_count_lines")
+        nlines = int(info[0])
+        line_ends = torch.zeros((max(nlines, 1),), dtype=torch.int32)
+        records = torch.zeros((nlines // 4, 8), dtype=torch.int32)
+        _check(L.emu_fastq_index(_ptr(data), C.c_int64(nbytes), strip, _ptr(line_ends), C.c_int64(nlines), _ptr(records),
+                                 C.c_void_p(info.data_ptr() + 8)), "emu_fastq_index")
+        return records, line_ends, nlines, int(info[1])
+
+    def pack_records(self, data, records, begin, end, max_len, table, count_invalid=False):
+        n = records.shape[0]
+        packed = torch.zeros((max(self.packed_bytes(n, max_len), 16),), dtype=torch.uint8)
+        lens = torch.zeros((n,), dtype=torch.int32)
+        invalid = torch.zeros((1,), dtype=torch.int32)
+        _check(self.lib.emu_pack_records(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), C.c_int64(n), max_len, table,
+                                         _ptr(packed), _ptr(lens), _ptr(invalid)), "emu_pack_records")
+        return (packed, lens, int(invalid.item())) if count_invalid else (packed, lens)
+
+    def clip_batch(self, records, begin, end, front, back):
+        _check(self.lib.emu_clip_batch(_ptr(records), _ptr(begin), _ptr(end), C.c_int64(begin.shape[0]), front, back),
+               "emu_clip_batch")
+
+    def quality_trim_batch(self, data, records, begin, end, cutoff_front, cutoff_back, base, nextseq):
+        _check(self.lib.emu_quality_trim_batch(_ptr(data), _ptr(records), _ptr(begin), _ptr(end),
+                                               C.c_int64(begin.shape[0]), cutoff_front, cutoff_back, base, int(nextseq)),
+               "emu_quality_trim_batch")
+
+    def nend_trim_batch(self, data, records, begin, end, ubegin=None, uend=None):
+        _check(self.lib.emu_nend_trim_batch(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend),
+                                            C.c_int64(begin.shape[0])), "emu_nend_trim_batch")
+
+    def match_trim_batch(self, matches, front, default_front, begin, end, active, matched):
+        _check(self.lib.emu_match_trim_batch(_ptr(matches), _ptr(front), default_front, _ptr(begin), _ptr(end),
+                                             _ptr(active), _ptr(matched), C.c_int64(begin.shape[0])),
+               "emu_match_trim_batch")
+
+    def read_filter_batch(self, data, records, begin, end, ubegin, uend, matched, min_len, max_len, max_n,
+                          discard_trimmed, discard_untrimmed):
+        dest = torch.zeros((begin.shape[0],), dtype=torch.uint8)
+        _check(self.lib.emu_read_filter_batch(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend),
+                                              _ptr(matched), C.c_int64(begin.shape[0]), min_len, max_len,
+                                              C.c_double(max_n), int(discard_trimmed), int(discard_untrimmed),
+                                              _ptr(dest)), "emu_read_filter_batch")
+        return dest
+
+    def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
+        n = records.shape[0]
+        offsets = torch.zeros((n + 1,), dtype=torch.int64)
+        args = (_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend), _ptr(dest), which,
+                C.c_int64(n), _ptr(offsets))
+        _check(self.lib.emu_fastq_emit(*args, None), "emu_fastq_emit")
+        total = int(offsets[n])
+        out = torch.zeros((max(total, 1),), dtype=torch.uint8)
+        if total:
+            _check(self.lib.emu_fastq_emit(*args, _ptr(out)), "emu_fastq_emit")
+        return out[:total]

@@ -1,0 +1,184 @@
+// TEST INFRASTRUCTURE: CPU twin of atropos_amd/csrc/fastq_kernels.hip, built from the same
+// per-record source (fastq_core.hpp, locate_core.hpp::pack_word) with -DATR_HOST_EMU so that
+// the CPU test-suite can check the FASTQ batch logic without a GPU.  One loop iteration
+// here = one thread (or one wave iteration) of the kernel of the same name.
+#include <stdint.h>
+#include <string.h>
+#include <limits.h>
+#include <vector>
+
+#include "atropos_hip.h"
+#include "locate_core.hpp"
+#include "fastq_core.hpp"
+
+using namespace atr;
+
+extern "C" {
+
+int emu_fastq_count_lines(const uint8_t *bytes, int64_t nbytes, int64_t *nlines) {
+    if (nbytes < 0 || nbytes >= (int64_t)0xFFFFFFF0ll || !nlines) return ATR_ERR_INVALID;
+    int64_t c = 0;
+    for (int64_t i = 0; i < nbytes; ++i) c += bytes[i] == '\n';
+    *nlines = c;
+    return ATR_OK;
+}
+
+int emu_fastq_index(const uint8_t *bytes, int64_t nbytes, int strip, uint32_t *line_ends, int64_t nlines,
+                    atr_fastq_record *records, int64_t *error) {
+    if (nbytes < 0 || nlines < 0 || (strip != 1 && strip != 2) || !error) return ATR_ERR_INVALID;
+    *error = LLONG_MAX;
+    int64_t k = 0;
+    for (int64_t i = 0; i < nbytes && k < nlines; ++i)
+        if (bytes[i] == '\n') line_ends[k++] = (uint32_t)i;
+    for (int64_t r = 0; r < nlines / 4; ++r) {
+        FastqRecord rec;
+        const int err = fastq_record_one(bytes, line_ends, r, strip, rec);
+        memcpy(&records[r], &rec, sizeof(rec));
+        if (err && r * 8 + err < *error) *error = r * 8 + err;
+    }
+    return ATR_OK;
+}
+
+int emu_pack_records(const uint8_t *bytes, const atr_fastq_record *records, const int32_t *begin, const int32_t *end,
+                     int64_t nreads, int max_len, const uint8_t table[256], uint8_t *packed, int32_t *lens,
+                     int32_t *invalid) {
+    if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
+    const int nchunks = (max_len + 31) / 32;
+    uint32_t *out = (uint32_t *)packed;
+    for (int64_t r = 0; r < nreads; ++r) {
+        const FastqRecord &rec = *(const FastqRecord *)&records[r];
+        int a = begin ? begin[r] : 0, b = end ? end[r] : (int)rec.seq_len;
+        a = a < 0 ? 0 : (a > (int)rec.seq_len ? (int)rec.seq_len : a);
+        b = b > (int)rec.seq_len ? (int)rec.seq_len : b;
+        b = b < a ? a : b;
+        const int n = b - a < max_len ? b - a : max_len;
+        if (lens) lens[r] = n;
+        const uint8_t *row = bytes + rec.seq_off + a;
+        const int64_t tile = r >> 6;
+        const int lane = (int)(r & 63);
+        bool zero_seen = false;
+        for (int c = 0; c < nchunks; ++c)
+            for (int d = 0; d < 4; ++d)
+                out[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] = pack_word(row, c * 32 + d * 8, n, table, zero_seen);
+        if (invalid && zero_seen) *invalid += 1;
+    }
+    return ATR_OK;
+}
+
+int emu_clip_batch(const atr_fastq_record *, int32_t *begin, int32_t *end, int64_t n, int front, int back) {
+    if (n < 0 || front < 0 || back > 0) return ATR_ERR_INVALID;
+    for (int64_t r = 0; r < n; ++r) {
+        const int a = begin[r], b = end[r];
+        if (b <= a || (front == 0 && back == 0)) continue;
+        int na, nb;
+        py_clip(b - a, front, back, back < 0, na, nb);
+        begin[r] = a + na;
+        end[r] = a + nb;
+    }
+    return ATR_OK;
+}
+
+int emu_quality_trim_batch(const uint8_t *bytes, const atr_fastq_record *records, int32_t *begin, int32_t *end,
+                           int64_t n, int cutoff_front, int cutoff_back, int base, int nextseq) {
+    for (int64_t r = 0; r < n; ++r) {
+        const FastqRecord &rec = *(const FastqRecord *)&records[r];
+        const int a = begin[r], b = end[r];
+        if (b <= a) continue;
+        const uint8_t *qual = bytes + rec.qual_off + a;
+        if (nextseq) {
+            end[r] = a + nextseq_trim_one(bytes + rec.seq_off + a, qual, b - a, cutoff_back, base);
+        } else {
+            int s, e;
+            quality_trim_one(qual, b - a, cutoff_front, cutoff_back, base, s, e);
+            begin[r] = a + s;
+            end[r] = a + e;
+        }
+    }
+    return ATR_OK;
+}
+
+int emu_nend_trim_batch(const uint8_t *bytes, const atr_fastq_record *records, int32_t *begin, int32_t *end,
+                        const int32_t *ubegin, const int32_t *uend, int64_t n) {
+    for (int64_t r = 0; r < n; ++r) {
+        const FastqRecord &rec = *(const FastqRecord *)&records[r];
+        const int a = begin[r], b = end[r];
+        if (b <= a) continue;
+        const int ub = ubegin ? ubegin[r] - a : 0, ue = uend ? uend[r] - a : b - a;
+        int s, e;
+        nend_trim_one(bytes + rec.seq_off + a, b - a, ub, ue, s, e);
+        begin[r] = a + s;
+        end[r] = a + (e < s ? s : e);
+    }
+    return ATR_OK;
+}
+
+int emu_match_trim_batch(const int16_t *matches, const uint8_t *front, int default_front, int32_t *begin, int32_t *end,
+                         uint8_t *active, uint8_t *matched, int64_t n) {
+    for (int64_t r = 0; r < n; ++r) {
+        if (active && !active[r]) continue;
+        const int16_t *m = matches + 8 * r;
+        if (m[1] < 0) { if (active) active[r] = 0; continue; }
+        const int rstart = m[2], rstop = m[3];
+        int f = front ? (int)front[r] : default_front;
+        if (f > 1) f = rstart == 0 ? 1 : 0;
+        const int a = begin[r], b = end[r];
+        if (f) begin[r] = a + rstop < b ? a + rstop : b;
+        else { int e = a + rstart < b ? a + rstart : b; end[r] = e > a ? e : a; }
+        if (matched) matched[r] = 1;
+    }
+    return ATR_OK;
+}
+
+int emu_read_filter_batch(const uint8_t *bytes, const atr_fastq_record *records, const int32_t *begin,
+                          const int32_t *end, const int32_t *ubegin, const int32_t *uend, const uint8_t *matched,
+                          int64_t n, int min_len, int max_len, double max_n, int discard_trimmed, int discard_untrimmed,
+                          uint8_t *dest) {
+    for (int64_t r = 0; r < n; ++r) {
+        const FastqRecord &rec = *(const FastqRecord *)&records[r];
+        const int a = begin[r], b = end[r] > a ? end[r] : a;
+        const int ub = ubegin ? ubegin[r] - a : 0, ue = uend ? uend[r] - a : b - a;
+        dest[r] = (uint8_t)read_filter_one(bytes + rec.seq_off + a, b - a, ub, ue, matched ? matched[r] != 0 : false,
+                                           min_len, max_len, max_n, discard_trimmed, discard_untrimmed);
+    }
+    return ATR_OK;
+}
+
+int emu_fastq_emit(const uint8_t *bytes, const atr_fastq_record *records, const int32_t *begin, const int32_t *end,
+                   const int32_t *ubegin, const int32_t *uend, const uint8_t *dest, int which, int64_t n,
+                   int64_t *offsets, uint8_t *out) {
+    if (!out) {
+        int64_t run = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            offsets[r] = run;
+            if (!dest || dest[r] == which) {
+                const int kept = end[r] > begin[r] ? end[r] - begin[r] : 0;
+                run += fastq_record_bytes(*(const FastqRecord *)&records[r], kept);
+            }
+        }
+        offsets[n] = run;
+        return ATR_OK;
+    }
+    for (int64_t r = 0; r < n; ++r) {
+        if (dest && dest[r] != which) continue;
+        const FastqRecord &rec = *(const FastqRecord *)&records[r];
+        const int a = begin[r], b = end[r] > a ? end[r] : a;
+        const uint32_t kept = (uint32_t)(b - a);
+        uint8_t *o = out + offsets[r];
+        *o++ = '@';
+        memcpy(o, bytes + rec.name_off, rec.name_len); o += rec.name_len;
+        *o++ = '\n';
+        for (uint32_t k = 0; k < kept; ++k) {
+            const int pos = a + (int)k;
+            o[k] = (!ubegin || (pos >= ubegin[r] && pos < uend[r])) ? bytes[rec.seq_off + pos] : (uint8_t)'N';
+        }
+        o += kept;
+        *o++ = '\n'; *o++ = '+';
+        if (rec.flags & 1u) { memcpy(o, bytes + rec.name_off, rec.name_len); o += rec.name_len; }
+        *o++ = '\n';
+        memcpy(o, bytes + rec.qual_off + a, kept); o += kept;
+        *o++ = '\n';
+    }
+    return ATR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/trim_cases.json.gz: FASTQ inputs and the exact output text of the
+REFERENCE's `atropos trim` command for each of a list of command lines.  Run in this container
+only (the reference is imported from a scratch build, see make_golden.py --scratch); the
+committed file holds data only: input text, argument strings, expected output text / error.
+
+usage: python tests/golden/make_trim_golden.py [--scratch /tmp/oracle_ref]
+"""
+import argparse
+import base64
+import gzip
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def synth_fastq(nreads, seed, dos=False, repeat_name=False):
+    """C2-like reads (adapter-containing 100 bp reads) with qualities that decay towards the
+    3' end, some low-quality 5' starts, N ends and lower-case stretches."""
+    sys.path.insert(0, ROOT)
+    from atropos_amd import synth
+    w = synth.workload("C1", 0, nreads, device="cpu")
+    reads = w["reads"].numpy()
+    rng = np.random.RandomState(seed)
+    eol = "\r\n" if dos else "\n"
+    out = []
+    for i in range(nreads):
+        seq = bytes(reads[i]).decode("ascii")
+        n = len(seq)
+        if rng.rand() < 0.1:
+            n = int(rng.randint(0, n + 1))                      # ragged lengths, including empty reads
+        seq = seq[:n]
+        q = 38 - (np.arange(n) * rng.uniform(0.0, 0.45)).astype(int) + rng.randint(-3, 4, size=n)
+        if rng.rand() < 0.15:
+            q[:rng.randint(1, 8)] = rng.randint(2, 12)
+        if rng.rand() < 0.2:
+            k = rng.randint(1, 6)
+            seq = "N" * min(k, n) + seq[k:]
+        if rng.rand() < 0.2:
+            k = rng.randint(1, 6)
+            seq = seq[:max(0, n - k)] + "N" * min(k, n)
+        if rng.rand() < 0.05:
+            seq = seq.lower()
+        if rng.rand() < 0.05 and n > 20:
+            seq = seq[:n - 9] + "GGGGGGGGG"                     # NextSeq dark cycles
+        q = np.clip(q, 2, 40)
+        qual = "".join(chr(int(v) + 33) for v in q)
+        name = "read%d/1 comment=%d" % (i, rng.randint(0, 1000))
+        plus = "+" + (name if (repeat_name or rng.rand() < 0.05) else "")
+        out.append("@%s%s%s%s%s%s%s%s" % (name, eol, seq, eol, plus, eol, qual, eol))
+    return "".join(out)
+
+
+TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+
+# (input name, argument string) -- the reference's own CLI tests (tests/test_atropos.py) that
+# take FASTQ input and stay inside the device pipeline's envelope, plus parameter sweeps on
+# synthetic reads
+CASES = [
+    ("small.fastq", "-b TTAGACATATCTCCGTCG"),
+    ("small.fastq", "-a TTAGACATATCTCCGTCG"),
+    ("empty.fastq", "-a TTAGACATATCTCCGTCG"),
+    ("dos.fastq", "-e 0.12 -b TTAGACATATCTCCGTCG"),
+    ("small.fastq", "-b ttagacatatctccgtcg"),
+    ("small.fastq", "-b TTAGACATATCTCCGTCG --discard"),
+    ("small.fastq", "-b CAAGAT --discard-untrimmed"),
+    ("plus.fastq", "-e 0.12 -b TTAGACATATCTCCGTCG"),
+    ("lowqual.fastq", "-q 10 -a XXXXXX"),
+    ("illumina64.fastq", "-q 10 --quality-base 64 -a XXXXXX"),
+    ("illumina64.fastq", "-q 10 --quality-base 64"),
+    ("anywhere_repeat.fastq", "-b CAAG -n 3 --mask-adapter"),
+    ("illumina.fastq", "-a VCCGAMCYUCKHRKDCUBBCNUWNSGHCGU"),
+    ("illumina.fastq", "-a GCCGAACTTCTTAGACTGCCTTAAGGACGT"),
+    ("illumina.fastq", "-a GCCGAACUUCUUAGACUGCCUUAAGGACGU"),
+    ("illumina.fastq", "--times 2 -a adapt=GCCGAACTTCTTA -a TTAGACTGCC"),
+    ("small.fastq", "--no-trim --discard-untrimmed -a CCCTAGTTAAAC"),
+    ("small.fastq", "-u 5"),
+    ("small.fastq", "-u -5"),
+    ("small.fastq", "-u -5 -u 5"),
+    ("small.fastq", "-q 10 --trim-n -m 5 -a TTAGACATATCTCCGTCG"),
+    ("nextseq.fastq", "--nextseq-trim 22"),
+    ("illumina5.fastq", "-a CCGCCTTGGCCGT -m 10 -q 5,20"),
+    ("synth.fastq", "-a " + TRUSEQ),
+    ("synth.fastq", "-a " + TRUSEQ + " -q 20 -m 20"),
+    ("synth.fastq", "-a " + TRUSEQ + " -q 15,25 --trim-n -m 30 -M 90"),
+    ("synth.fastq", "-b " + TRUSEQ + " -e 0.2 -O 5 -n 2"),
+    ("synth.fastq", "-g " + TRUSEQ[:20] + " -a " + TRUSEQ + " --trim-n"),
+    ("synth.fastq", "-a " + TRUSEQ + " --mask-adapter --trim-n"),
+    ("synth.fastq", "-a " + TRUSEQ + " --mask-adapter --max-n 0.3"),
+    ("synth.fastq", "-a " + TRUSEQ + " --no-trim --discard"),
+    ("synth.fastq", "-a " + TRUSEQ + " --discard-untrimmed -u 3 -u -2"),
+    ("synth.fastq", "-a " + TRUSEQ + " --match-read-wildcards -N"),
+    ("synth.fastq", "-a " + TRUSEQ + " -N --no-indels"),
+    ("synth.fastq", "--nextseq-trim 20 -a " + TRUSEQ + " -m 1"),
+    ("synth.fastq", "--max-n 2 --trim-n"),
+    ("synth.fastq", "--max-n 0.05"),
+    ("synth.fastq", "-a " + TRUSEQ + " --op-order AQCGW -q 20 -u 4"),
+    ("synth.fastq", "-a ^ACGTACGT..." + TRUSEQ + " -e 0.15"),
+    ("synth.fastq", "-a " + TRUSEQ + "$ -q 12"),
+    ("synth.fastq", "-g ^" + "ACGTAC" + " -O 4 -e 0.2"),
+    ("synth_dos.fastq", "-a " + TRUSEQ + " -q 20 -m 20"),
+    ("synth_name2.fastq", "-a " + TRUSEQ + " --trim-n"),
+    ("nofinalnewline.fastq", "-a TTAGACATATCTCCGTCG"),
+    # malformed inputs: the reference raises FormatError
+    ("bad_at.fastq", "-a ACGT"),
+    ("bad_plus.fastq", "-a ACGT"),
+    ("bad_name2.fastq", "-a ACGT"),
+    ("bad_length.fastq", "-a ACGT"),
+    ("bad_truncated.fastq", "-a ACGT"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scratch", default="/tmp/oracle_ref")
+    args = ap.parse_args()
+    sys.path.insert(0, args.scratch)
+    from atropos.commands import get_command
+    data_dir = os.path.join(args.scratch, "tests", "data")
+
+    inputs = {}
+    for name in sorted({c[0] for c in CASES}):
+        path = os.path.join(data_dir, name)
+        if os.path.exists(path):
+            inputs[name] = open(path, "rb").read()
+        elif os.path.exists(path + ".gz"):
+            inputs[name] = gzip.open(path + ".gz", "rb").read()
+    inputs["synth.fastq"] = synth_fastq(1200, 11).encode()
+    inputs["synth_dos.fastq"] = synth_fastq(100, 12, dos=True).encode()
+    inputs["synth_name2.fastq"] = synth_fastq(100, 13, repeat_name=True).encode()
+    small = inputs["small.fastq"]
+    inputs["nofinalnewline.fastq"] = small.rstrip(b"\n")
+    lines = small.split(b"\n")
+    inputs["bad_at.fastq"] = b"\n".join(lines[:4] + [b"X" + lines[4][1:]] + lines[5:])
+    inputs["bad_plus.fastq"] = b"\n".join(lines[:6] + [b"-"] + lines[7:])
+    inputs["bad_name2.fastq"] = b"\n".join(lines[:2] + [b"+other name"] + lines[3:])
+    inputs["bad_length.fastq"] = b"\n".join(lines[:7] + [lines[7][:-3]] + lines[8:])
+    inputs["bad_truncated.fastq"] = b"\n".join(lines[:6]) + b"\n"
+
+    cases = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for idx, (name, argstr) in enumerate(CASES):
+            in_path = os.path.join(tmp, "in_%d.fastq" % idx)
+            out_path = os.path.join(tmp, "out_%d.fastq" % idx)
+            open(in_path, "wb").write(inputs[name])
+            params = argstr.split() + ["-se", in_path, "-o", out_path, "--quiet", "--no-default-adapters",
+                                       "--no-cache-adapters"]
+            retcode, summary = get_command("trim").execute(params)
+            case = dict(input=name, args=argstr, output=None, error=None)
+            if retcode != 0:
+                # the command only logs the exception: re-raise it by iterating the reference's reader
+                from atropos.io._seqio import FastqReader
+                try:
+                    list(FastqReader(in_path))
+                    raise AssertionError("reference failed outside the reader: " + argstr)
+                except Exception as err:                                  # noqa: BLE001 (recorded, not handled)
+                    if isinstance(err, AssertionError):
+                        raise
+                    case["error"] = [type(err).__name__, str(err)]
+                    if err.__cause__ is not None:
+                        case["error"].append(str(err.__cause__))
+            else:
+                text = open(out_path, "rb").read()
+                case["size"] = len(text)
+                case["sha256"] = hashlib.sha256(text).hexdigest()
+                # full text for small outputs; the head (for a readable diff) for the large ones
+                case["output"] = base64.b64encode(text if len(text) <= 20000 else text[:3000]).decode()
+            cases.append(case)
+            print("%-24s %-70s -> %s" % (name, argstr, "ERROR " + case["error"][1][:50] if case["error"] else
+                                         "%d bytes" % case["size"]))
+    doc = dict(inputs={k: base64.b64encode(v).decode() for k, v in inputs.items()}, cases=cases)
+    out = os.path.join(HERE, "trim_cases.json.gz")
+    with gzip.GzipFile(out, "wb", mtime=0) as fh:
+        fh.write(json.dumps(doc, sort_keys=True).encode())
+    print("wrote", out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

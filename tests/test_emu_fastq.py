@@ -1,0 +1,25 @@
+"""Device-resident FASTQ pipeline (index -> trim stages -> filters -> formatter) against the
+output text of the reference's `atropos trim` command, with the device work done by the CPU
+twins of the kernels (tests/emu/emu_fastq.cpp + the alignment emulation)."""
+from . import _cases
+
+
+def test_trim_pipeline_reference_cli_cases(emu_backend):
+    assert _cases.check_trim_golden() >= 48
+
+
+def test_trim_file_chunking(emu_backend, tmp_path):
+    counts = _cases.check_fastq_chunking(tmp_path)
+    assert counts["keep"] > 0 and counts["too_short"] > 0
+
+
+def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
+    import pytest
+    from atropos_amd.trim import pipeline_from_args
+    pipe = pipeline_from_args("-g ^ACGTACGT --no-indels")                # anchored without indels: compare_prefixes path
+    with pytest.raises(NotImplementedError):
+        pipe.trim_bytes(b"@r\nACGTACGTAA\n+\nIIIIIIIIII\n")
+    with pytest.raises(NotImplementedError):
+        pipeline_from_args("-a AAAA...TTTT -a GGGG")                     # linked + plain adapters mixed
+    with pytest.raises(SystemExit):
+        pipeline_from_args("--length-tag length=")                       # modifier outside the pipeline
