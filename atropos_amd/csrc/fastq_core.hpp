@@ -14,6 +14,7 @@
 #define ATR_FASTQ_CORE_HPP
 
 #include <stdint.h>
+#include <string.h>
 #include "atropos_hip.h"
 
 #ifdef ATR_HOST_EMU
@@ -82,23 +83,65 @@ ATR_DEV int fastq_record_one(const uint8_t *bytes, const uint32_t *line_ends, lo
     return err;
 }
 
-// quality_trim_index on qualities[begin:end]  (commands/trim/_qualtrim.pyx:7-48).
-ATR_DEV void quality_trim_one(const uint8_t *qual, int len, int cutoff_front, int cutoff_back, int base,
+// 16 bytes at the 16-byte aligned offset blk of the chunk, as four little-endian dwords
+ATR_DEV void load_block16(const uint8_t *bytes, uint32_t blk, uint32_t w[4]) {
+#ifdef ATR_HOST_EMU
+    memcpy(w, bytes + blk, 16);
+#else
+    const uint4 v = *(const uint4 *)(bytes + blk);
+    w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+#endif
+}
+
+// quality_trim_index on the qualities at bytes[qoff : qoff + len]
+// (commands/trim/_qualtrim.pyx:7-48).  `bytes` is the 16-byte aligned chunk: the scans fetch
+// the quality line one aligned 16-byte block at a time instead of one dependent byte load per
+// base (both scans stop at the first negative running sum, typically within a block or two).
+ATR_DEV void quality_trim_one(const uint8_t *bytes, uint32_t qoff, int len, int cutoff_front, int cutoff_back, int base,
                               int &start, int &stop) {
     start = 0;
     stop = len;
-    int s = 0, max_qual = 0;
-    for (int i = 0; i < len; ++i) {
-        s += cutoff_front - ((int)qual[i] - base);
-        if (s < 0) break;
-        if (s > max_qual) { max_qual = s; start = i + 1; }
+    int s = 0, max_qual = 0, i = 0;
+    bool done = false;
+    while (i < len && !done) {                                    // 5' end: i ascending
+        const uint32_t addr = qoff + (uint32_t)i, blk = addr & ~15u;
+        uint32_t w[4];
+        load_block16(bytes, blk, w);
+        const int k0 = (int)(addr - blk);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k >= k0 && i < len && !done) {
+                const int q = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                s += cutoff_front - (q - base);
+                if (s < 0) done = true;
+                else {
+                    if (s > max_qual) { max_qual = s; start = i + 1; }
+                    ++i;
+                }
+            }
+        }
     }
     max_qual = 0;
     s = 0;
-    for (int i = len - 1; i >= 0; --i) {
-        s += cutoff_back - ((int)qual[i] - base);
-        if (s < 0) break;
-        if (s > max_qual) { max_qual = s; stop = i; }
+    i = len - 1;
+    done = false;
+    while (i >= 0 && !done) {                                     // 3' end: i descending
+        const uint32_t addr = qoff + (uint32_t)i, blk = addr & ~15u;
+        uint32_t w[4];
+        load_block16(bytes, blk, w);
+        const int k0 = (int)(addr - blk);
+#pragma unroll
+        for (int k = 15; k >= 0; --k) {
+            if (k <= k0 && i >= 0 && !done) {
+                const int q = (int)((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+                s += cutoff_back - (q - base);
+                if (s < 0) done = true;
+                else {
+                    if (s > max_qual) { max_qual = s; stop = i; }
+                    --i;
+                }
+            }
+        }
     }
     if (start >= stop) { start = 0; stop = 0; }
 }

@@ -8,10 +8,11 @@
 //     (offsets into the chunk), modifier state is two int32 per read;
 //   * line ends are found with 16-byte loads + a SWAR zero-byte test, positions come from
 //     a two-level exclusive scan (no atomics, input order preserved);
-//   * the packer stages the contiguous byte span of a wave's 64 records in LDS with
-//     coalesced 16-byte loads before the lanes pick their own sequence lines apart;
-//   * the formatter copies one record per wave iteration, a byte per lane, so that both the
-//     reads and the writes of a segment are one contiguous burst.
+//   * the packer copies each sequence line into an LDS row with one direct-to-LDS load
+//     (global_load_lds_dword) and lets every lane re-align its row in registers (v_alignbyte_b32);
+//   * the formatter stages the contiguous byte span of a wave's 64 records in LDS with
+//     coalesced 16-byte loads, lets every lane assemble its record in an LDS image of the
+//     output span, and writes that image with aligned 16-byte stores.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <string.h>
@@ -166,26 +167,50 @@ __global__ void set_i64_kernel(long long *p, long long v) { *p = v; }
 
 // ------------------------------------------------------------------------- pack from records
 struct PackTable256 { uint8_t t[256]; };
-constexpr int PACKREC_WAVES = 2;
-constexpr int PACKREC_STAGE = 31 * 1024;                     // bytes of LDS per wave for the staged span
 
-__global__ __launch_bounds__(64 * PACKREC_WAVES) void pack_records_kernel(
+// 8 bases (two dwords of ASCII, already shifted to the read's own alignment) -> one packed word
+__device__ __forceinline__ uint32_t pack_two_words(uint32_t w0, uint32_t w1, int j0, int n, const uint8_t *tab,
+                                                   bool &zero_seen) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const uint32_t byte = ((b < 4 ? w0 : w1) >> (8 * (b & 3))) & 0xFFu;
+        if (j0 + b < n) {
+            const uint32_t code = (uint32_t)tab[byte] & 15u;
+            zero_seen = zero_seen || code == 0;
+            w |= code << (4 * b);
+        }
+    }
+    return w;
+}
+
+// The sequence lines sit at arbitrary byte offsets of the file chunk, ~300 bytes apart.  A
+// wave first copies the aligned dwords of its 64 lines into 64 LDS rows -- one
+// global_load_lds_dword per line, lanes = consecutive dwords, so every line is fetched as one
+// contiguous burst and the 64 copies are all in flight together (no VGPR round trip) -- and
+// then every lane packs its own row, re-aligning the dwords with v_alignbyte_b32.
+// Row stride is odd (in dwords): lanes reading dword d of their own rows hit 64 different banks.
+__device__ __forceinline__ void glds_dword(const uint8_t *gsrc, uint32_t *lds_dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                     (__attribute__((address_space(3))) void *)lds_dst_wave_uniform, 4, 0, 0);
+}
+
+__global__ void pack_records_kernel(
     const uint8_t *__restrict__ bytes, const FastqRecord *__restrict__ records, const int32_t *__restrict__ begin,
-    const int32_t *__restrict__ end, long long nreads, int max_len, int nchunks, const PackTable256 tab,
+    const int32_t *__restrict__ end, long long nreads, int max_len, int nchunks, int stride_dw, const PackTable256 tab,
     uint4 *__restrict__ packed, int32_t *__restrict__ lens, int32_t *__restrict__ invalid) {
     __shared__ uint8_t s_tab[256];
-    extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];
-    for (int i = threadIdx.x; i < 256; i += 64 * PACKREC_WAVES) s_tab[i] = tab.t[i];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tab[i] = tab.t[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long tile = (long long)blockIdx.x * PACKREC_WAVES + wave;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const long long tile = (long long)blockIdx.x * waves + wave;
     const long long ntiles = (nreads + 63) >> 6;
     if (tile >= ntiles) return;
     const long long r = tile * 64 + lane;
-    const bool live = r < nreads;
     uint32_t soff = 0;
     int n = 0;
-    if (live) {
+    if (r < nreads) {
         const FastqRecord rec = records[r];
         int a = begin ? begin[r] : 0, b = end ? end[r] : (int)rec.seq_len;
         a = max(0, min(a, (int)rec.seq_len));
@@ -194,32 +219,38 @@ __global__ __launch_bounds__(64 * PACKREC_WAVES) void pack_records_kernel(
         n = min(b - a, max_len);
         if (lens) lens[r] = n;
     }
-    // contiguous span of the tile's sequence slices: [first lane's start, last live lane's end)
-    const int last = (int)min<long long>(63, nreads - 1 - tile * 64);
-    const uint32_t span_lo = __shfl(soff, 0, 64);
-    const uint32_t span_hi = __shfl(soff + (uint32_t)n, last, 64);
-    // the records of a file are in increasing offset order; anything else takes the slow path
-    const bool ordered = __all(!live || (soff >= span_lo && soff + (uint32_t)n <= span_hi));
-    const uint8_t *row = bytes + soff;
-    const uint32_t mis = span_lo & 15u;
-    if (ordered && span_hi - span_lo + mis <= (uint32_t)PACKREC_STAGE - 16u) {
-        uint8_t *stage = s_stage + (size_t)wave * PACKREC_STAGE;
-        const uint8_t *src_al = bytes + (span_lo - mis);
-        const uint32_t need = span_hi - span_lo + mis;
-        for (uint32_t o = (uint32_t)lane * 16u; o < need; o += 64u * 16u) *(uint4 *)(stage + o) = *(const uint4 *)(src_al + o);
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0);
-        row = stage + mis + (soff - span_lo);
+    const uint32_t sh = soff & 3u;
+    const int nd = (n + (int)sh + 3) >> 2;                      // aligned dwords that hold the read
+    uint32_t *rows = s_rows + (size_t)wave * 64 * stride_dw;
+    const int cnt = (int)min<long long>(64, nreads - tile * 64);
+    for (int i = 0; i < cnt; ++i) {                             // wave-uniform: row i <- line i
+        const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)(soff - sh), i);
+        const int nd_i = __builtin_amdgcn_readlane(nd, i);
+        for (int d0 = 0; d0 < nd_i; d0 += 64)
+            if (d0 + lane < nd_i) glds_dword(bytes + so + (size_t)(d0 + lane) * 4, rows + (size_t)i * stride_dw + d0);
     }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t *p = rows + (size_t)lane * stride_dw;
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;
+    uint32_t prev = nd > 0 ? p[0] : 0u;
+    int t = 0;                                                  // prev == p[t]
     for (int c = 0; c < nchunks; ++c) {
-        uint4 v;
-        v.x = pack_word(row, c * 32, n, s_tab, zero_seen);
-        v.y = pack_word(row, c * 32 + 8, n, s_tab, zero_seen);
-        v.z = pack_word(row, c * 32 + 16, n, s_tab, zero_seen);
-        v.w = pack_word(row, c * 32 + 24, n, s_tab, zero_seen);
-        dst[(size_t)c * 64] = v;
+        uint32_t v[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t sw[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t next = (t + 1 < nd) ? p[t + 1] : 0u;
+                sw[h] = __builtin_amdgcn_alignbyte(next, prev, sh);
+                prev = next;
+                ++t;
+            }
+            v[w] = pack_two_words(sw[0], sw[1], c * 32 + w * 8, n, s_tab, zero_seen);
+        }
+        dst[(size_t)c * 64] = make_uint4(v[0], v[1], v[2], v[3]);
     }
     if (invalid && zero_seen) atomicAdd(invalid, 1);
 }
@@ -261,7 +292,7 @@ __global__ __launch_bounds__(256) void quality_trim_kernel(const uint8_t *__rest
         end[r] = a + stop;                                                // subseq(read, end=stop)
     } else {
         int s, e;
-        quality_trim_one(qual, b - a, cutoff_front, cutoff_back, base, s, e);
+        quality_trim_one(bytes, rec.qual_off + (uint32_t)a, b - a, cutoff_front, cutoff_back, base, s, e);
         begin[r] = a + s;
         end[r] = a + e;
     }
@@ -387,6 +418,168 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint8_t *__restrict__ b
     }
 }
 
+// ---- staged formatter -------------------------------------------------------------------
+// One wave formats a tile of EMIT_TILE consecutive records through LDS:
+//   1. the tile's input span (first '@' .. end of the last quality line, ~10 KB for 150 bp
+//      reads) is copied to LDS with coalesced 16-byte loads;
+//   2. every lane pair assembles ITS record's output bytes at the record's place in an LDS image
+//      of the tile's output span (LDS -> LDS, dword copies re-aligned in registers);
+//   3. the image is written out with 16-byte stores aligned to the output buffer; the ragged
+//      first / last bytes of the span with byte stores (neighbouring tiles never touch them).
+// Output is never larger than input (same record layout, bases only removed), so one size
+// bounds both stages.  Tiles that do not fit (very long names / reads) or whose records
+// are not in file order take emit_kernel's path.
+constexpr int EMIT_STAGE = 13 * 1024;                        // per stage; 2 stages per wave -> 6 waves per CU
+constexpr int EMIT_TILE = 32;                                // records per wave: two lanes share a record
+
+// LDS -> LDS copy of len bytes at arbitrary alignments: byte steps until dst is dword
+// aligned, then one aligned ds_read_b32 + v_alignbyte_b32 + ds_write_b32 per 4 bytes (four
+// dwords per batch so that the reads of a batch are in flight together), byte steps for the
+// tail.  May read up to 3 bytes beyond src + len (the stages are padded).
+__device__ __forceinline__ void lds_copy(uint8_t *dst, const uint8_t *src, uint32_t len) {
+    uint32_t k = 0;
+    const uint32_t head = min(len, (4u - ((uint32_t)(uintptr_t)dst & 3u)) & 3u);
+    for (; k < head; ++k) dst[k] = src[k];
+    const uint32_t sm = (uint32_t)(uintptr_t)(src + k) & 3u;
+    const uint32_t *sp = (const uint32_t *)(src + k - sm);        // aligned dwords holding the source
+    uint32_t *dp = (uint32_t *)(dst + k);
+    const uint32_t nd = (len - k) >> 2;
+    uint32_t prev = nd ? sp[0] : 0u, t = 0;
+    for (; t + 4 <= nd; t += 4) {
+        const uint32_t n1 = sp[t + 1], n2 = sp[t + 2], n3 = sp[t + 3], n4 = sp[t + 4];
+        dp[t] = __builtin_amdgcn_alignbyte(n1, prev, sm);
+        dp[t + 1] = __builtin_amdgcn_alignbyte(n2, n1, sm);
+        dp[t + 2] = __builtin_amdgcn_alignbyte(n3, n2, sm);
+        dp[t + 3] = __builtin_amdgcn_alignbyte(n4, n3, sm);
+        prev = n4;
+    }
+    for (; t < nd; ++t) {
+        const uint32_t nx = sp[t + 1];
+        dp[t] = __builtin_amdgcn_alignbyte(nx, prev, sm);
+        prev = nx;
+    }
+    for (k += nd * 4u; k < len; ++k) dst[k] = src[k];
+}
+
+__global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restrict__ bytes,
+                                                         const FastqRecord *__restrict__ records,
+                                                         const int32_t *__restrict__ begin, const int32_t *__restrict__ end,
+                                                         const int32_t *__restrict__ ubegin, const int32_t *__restrict__ uend,
+                                                         const uint8_t *__restrict__ dest, int which, long long n,
+                                                         const long long *__restrict__ offsets, uint8_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_emit[];
+    uint8_t *s_in = s_emit, *s_out = s_emit + EMIT_STAGE;
+    const int lane = threadIdx.x, slot = lane >> 1, part = lane & 1;
+    const long long r0 = (long long)blockIdx.x * EMIT_TILE;
+    const int cnt = (int)min<long long>(EMIT_TILE, n - r0);
+    const long long r = r0 + slot;
+    const bool live = slot < cnt;
+    FastqRecord rec = {0, 0, 0, 0, 0, 0, 0, 0};
+    int a = 0, b = 0, ub = 0, ue = 0;
+    long long off = 0;
+    bool keep = false;
+    if (live) {
+        rec = records[r];
+        a = begin[r];
+        b = max(a, end[r]);
+        ub = ubegin ? ubegin[r] : a;
+        ue = uend ? uend[r] : b;
+        off = offsets[r];
+        keep = !dest || dest[r] == which;
+    }
+    const uint32_t rec_lo = rec.name_off - 1u, rec_hi = rec.qual_off + rec.qual_len;     // '@' .. last quality byte
+    const uint32_t in_lo = __shfl(rec_lo, 0, 64), in_hi = __shfl(rec_hi, 2 * (cnt - 1), 64);
+    const long long out_lo = offsets[r0], out_hi = offsets[r0 + cnt];
+    const bool ordered = __all(!live || (rec_lo >= in_lo && rec_hi <= in_hi && rec.seq_off >= rec_lo &&
+                                         rec.seq_off + rec.seq_len <= rec.qual_off && rec.name_off + rec.name_len <= rec.seq_off));
+    const uint32_t mis_in = in_lo & 15u, mis_out = (uint32_t)(out_lo & 15);
+    const bool fits = ordered && (in_hi - in_lo) + mis_in + 16u <= (uint32_t)EMIT_STAGE &&
+                      (uint32_t)(out_hi - out_lo) + mis_out + 16u <= (uint32_t)EMIT_STAGE;
+    if (out_hi == out_lo) return;
+    if (!fits) {                                           // slow path: a byte per lane straight from / to global
+        for (int i = 0; i < cnt; ++i) {
+            const long long ri = r0 + i;
+            if (dest && dest[ri] != which) continue;
+            const FastqRecord rc = records[ri];
+            const int ai = begin[ri], bi = max(ai, end[ri]);
+            const uint32_t kept = (uint32_t)(bi - ai);
+            uint8_t *o = out + offsets[ri];
+            if (lane == 0) o[0] = '@';
+            wave_copy(o + 1, bytes + rc.name_off, rc.name_len, lane);
+            o += 1 + rc.name_len;
+            if (lane == 0) o[0] = '\n';
+            o += 1;
+            const int ubi = ubegin ? ubegin[ri] : ai, uei = uend ? uend[ri] : bi;
+            for (uint32_t k = (uint32_t)lane; k < kept; k += 64u) {
+                const int pos = ai + (int)k;
+                o[k] = (pos >= ubi && pos < uei) ? bytes[rc.seq_off + pos] : (uint8_t)'N';
+            }
+            o += kept;
+            if (lane == 0) { o[0] = '\n'; o[1] = '+'; }
+            o += 2;
+            if (rc.flags & 1u) { wave_copy(o, bytes + rc.name_off, rc.name_len, lane); o += rc.name_len; }
+            if (lane == 0) o[0] = '\n';
+            o += 1;
+            wave_copy(o, bytes + rc.qual_off + ai, kept, lane);
+            o += kept;
+            if (lane == 0) o[0] = '\n';
+        }
+        return;
+    }
+    // 1. stage the input span
+    {
+        const uint8_t *src_al = bytes + (in_lo - mis_in);
+        const uint32_t need = in_hi - in_lo + mis_in;
+        for (uint32_t o = (uint32_t)lane * 16u; o < need; o += 64u * 16u) *(uint4 *)(s_in + o) = *(const uint4 *)(src_al + o);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // 2. two lanes format one record inside the output image: the even lane "@name\nSEQ\n",
+    //    the odd lane "+[name]\nQUAL\n"
+    if (keep) {
+        const uint8_t *in = s_in + mis_in;                  // in[x - in_lo] = bytes[x]
+        uint8_t *o = s_out + mis_out + (uint32_t)(off - out_lo);
+        const uint32_t kept = (uint32_t)(b - a);
+        if (part == 0) {
+            *o++ = '@';
+            lds_copy(o, in + (rec.name_off - in_lo), rec.name_len);
+            o += rec.name_len;
+            *o++ = '\n';
+            const uint8_t *sq = in + (rec.seq_off - in_lo) + a;
+            if (ub <= a && ue >= b) {
+                lds_copy(o, sq, kept);
+            } else {
+                for (uint32_t k = 0; k < kept; ++k) {
+                    const int pos = a + (int)k;
+                    o[k] = (pos >= ub && pos < ue) ? sq[k] : (uint8_t)'N';
+                }
+            }
+            o[kept] = '\n';
+        } else {
+            o += 1u + rec.name_len + 1u + kept + 1u;
+            *o++ = '+';
+            if (rec.flags & 1u) { lds_copy(o, in + (rec.name_off - in_lo), rec.name_len); o += rec.name_len; }
+            *o++ = '\n';
+            lds_copy(o, in + (rec.qual_off - in_lo) + a, kept);
+            o[kept] = '\n';
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    // 3. write the image: aligned 16-byte blocks, byte stores at the ragged ends
+    {
+        uint8_t *dst_al = out + (out_lo - mis_out);          // 16-byte aligned when `out` is
+        const uint32_t lo = mis_out, hi = mis_out + (uint32_t)(out_hi - out_lo);
+        for (uint32_t o = (uint32_t)lane * 16u; o < hi; o += 64u * 16u) {
+            if (o >= lo && o + 16u <= hi) {
+                *(uint4 *)(dst_al + o) = *(const uint4 *)(s_out + o);
+            } else {
+                for (uint32_t k = max(o, lo); k < min(o + 16u, hi); ++k) dst_al[k] = s_out[k];
+            }
+        }
+    }
+}
+
 static long long scan_blocks(long long n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
 
 // exclusive prefix sums of v[n] -> out[n] (int64); `sums` holds scan_blocks(n) uint64
@@ -461,15 +654,17 @@ int atr_pack_records(const uint8_t *d_bytes, const atr_fastq_record *d_records, 
                      uint8_t *d_packed, int32_t *d_lens, int32_t *d_invalid, void *stream) {
     if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
-    if (!d_bytes || !d_records || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
+    if (!d_bytes || !d_records || (max_len > 0 && !d_packed) || ((uintptr_t)d_bytes & 15)) return ATR_ERR_INVALID;
     PackTable256 tab;
     memcpy(tab.t, table, 256);
     const int nchunks = (max_len + 31) / 32;
     const long long ntiles = (nreads + 63) / 64;
-    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((ntiles + PACKREC_WAVES - 1) / PACKREC_WAVES)),
-                       dim3(64 * PACKREC_WAVES), (size_t)PACKREC_WAVES * PACKREC_STAGE, (hipStream_t)stream, d_bytes,
-                       (const FastqRecord *)d_records, d_begin, d_end, (long long)nreads, max_len, nchunks, tab,
-                       (uint4 *)d_packed, d_lens, d_invalid);
+    const int stride_dw = ((max_len + 6) / 4) | 1;              // dwords per LDS row (odd)
+    const size_t per_wave = (size_t)64 * stride_dw * 4;
+    const int waves = per_wave * 4 <= 65536 - 256 ? 4 : (per_wave * 2 <= 65536 - 256 ? 2 : 1);
+    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((ntiles + waves - 1) / waves)), dim3(64 * waves),
+                       per_wave * waves, (hipStream_t)stream, d_bytes, (const FastqRecord *)d_records, d_begin, d_end,
+                       (long long)nreads, max_len, nchunks, stride_dw, tab, (uint4 *)d_packed, d_lens, d_invalid);
     return launched("pack_records_kernel launch");
 }
 
@@ -488,7 +683,7 @@ int atr_quality_trim_batch(const uint8_t *d_bytes, const atr_fastq_record *d_rec
                            void *stream) {
     if (n < 0) return ATR_ERR_INVALID;
     if (n == 0) return ATR_OK;
-    if (!d_bytes || !d_records || !d_begin || !d_end) return ATR_ERR_INVALID;
+    if (!d_bytes || !d_records || !d_begin || !d_end || ((uintptr_t)d_bytes & 15)) return ATR_ERR_INVALID;
     hipLaunchKernelGGL(quality_trim_kernel, dim3(grid256(n)), dim3(256), 0, (hipStream_t)stream, d_bytes,
                        (const FastqRecord *)d_records, d_begin, d_end, (long long)n, cutoff_front, cutoff_back, base, nextseq);
     return launched("quality_trim_kernel launch");
@@ -555,6 +750,12 @@ int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, co
         return launched("fastq emit sizes launch");
     }
     const long long ntiles = (n + 63) / 64;
+    if (((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_bytes & 15) == 0) {
+        hipLaunchKernelGGL(emit_staged_kernel, dim3((unsigned)((n + EMIT_TILE - 1) / EMIT_TILE)), dim3(64), 2 * EMIT_STAGE, st, d_bytes,
+                           (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest,
+                           dest, (long long)n, (const long long *)d_offsets, d_out);
+        return launched("emit_staged_kernel launch");
+    }
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_bytes,
                        (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest, dest,
                        (long long)n, (const long long *)d_offsets, d_out);

@@ -89,7 +89,7 @@ int emu_quality_trim_batch(const uint8_t *bytes, const atr_fastq_record *records
             end[r] = a + nextseq_trim_one(bytes + rec.seq_off + a, qual, b - a, cutoff_back, base);
         } else {
             int s, e;
-            quality_trim_one(qual, b - a, cutoff_front, cutoff_back, base, s, e);
+            quality_trim_one(bytes, rec.qual_off + (uint32_t)a, b - a, cutoff_front, cutoff_back, base, s, e);
             begin[r] = a + s;
             end[r] = a + e;
         }
