@@ -21,6 +21,7 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
+PAIRS_MAX_LEN = 255
 INSERT_MAX_ADAPTER = 64
 INSERT_MAX_READ = 256
 
@@ -72,6 +73,9 @@ PROTOTYPES = {
     "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "atr_locate_pairs_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
     "atr_fastq_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_fastq_count_lines": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_fastq_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -291,6 +295,17 @@ class HipBackend(object):
                                                            _ptr(work), self._stream()), "atr_locate_batch")
         return out
 
+
+    def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                           query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+        """Aligner.locate with a per-pair reference; both sides tile64-packed.  int16 [npairs, 8]."""
+        out = self.empty((npairs, 8), torch.int16)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_locate_pairs_batch(
+                _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
+                query_max_len, npairs, e, flags, int(wildcard_ref), int(wildcard_query), min_overlap, indel_cost,
+                _ptr(out), self._stream()), "atr_locate_pairs_batch")
+        return out
 
     # -- device-resident FASTQ batch --------------------------------------------
     def fastq_index(self, data, nbytes, strip):

@@ -241,6 +241,76 @@ def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix
     return be.compare_batch(ref_b, q_t, lens, q_t.shape[1], wildcard_ref, wildcard_query, suffix)
 
 
+class PairAligner(object):
+    """``Aligner(ref_p, max_error_rate, flags, ...).locate(query_p)`` for many independent
+    (reference, query) pairs in one GPU call -- the aligner ``MergeOverlapping`` constructs per
+    read pair (commands/trim/modifiers.py:889-894), where the reference changes with every
+    call.  ``revcomp_ref``: the reference of a pair is the reverse complement of the given
+    sequence (``reverse_complement(read2.sequence)``), formed on the device.
+    Sequences of up to 255 bases; results are the reference's 6-tuples / None."""
+
+    def __init__(self, max_error_rate, flags=SEMIGLOBAL, wildcard_ref=False, wildcard_query=False, min_overlap=1,
+                 indel_cost=1, revcomp_ref=False):
+        if min_overlap < 1:
+            raise ValueError("Minimum overlap must be at least 1")          # _align.pyx:219-220
+        if indel_cost < 1:
+            raise ValueError("Insertion/deletion cost must be at leat 1")   # :229-230
+        self.max_error_rate, self.flags = float(max_error_rate), int(flags)
+        self.wildcard_ref, self.wildcard_query = bool(wildcard_ref), bool(wildcard_query)
+        self.min_overlap, self.indel_cost, self.revcomp_ref = int(min_overlap), int(indel_cost), bool(revcomp_ref)
+
+    def _table_kinds(self):
+        """Translate tables of (reference, query): _align.pyx:243-248, :292-297."""
+        if not (self.wildcard_ref or self.wildcard_query):
+            return _lib.TABLE_DNA15, _lib.TABLE_DNA15
+        return (_lib.TABLE_IUPAC if self.wildcard_ref else _lib.TABLE_ACGT,
+                _lib.TABLE_IUPAC if self.wildcard_query else _lib.TABLE_ACGT)
+
+    def _pack(self, seqs, kind, be, literal):
+        if isinstance(seqs, ReadBatch):
+            if seqs.table_kind != kind:
+                raise ValueError("batch packed with table %d, this side needs %d" % (seqs.table_kind, kind))
+            return seqs
+        table = be.translate_table(kind)
+        if isinstance(seqs, (list, tuple)):
+            mat, lens = _as_ascii_matrix(seqs)
+            ascii_t, lens_t = torch.from_numpy(mat).to(be.device), torch.from_numpy(lens).to(be.device)
+            max_len = int(lens.max()) if len(seqs) else 0
+        else:
+            ascii_t = seqs.to(be.device)
+            lens_t, max_len = None, ascii_t.shape[1]
+        if max_len > _lib.PAIRS_MAX_LEN:
+            raise _lib.AtroposHipError("PairAligner: sequences longer than %d bases are outside the device envelope"
+                                       % _lib.PAIRS_MAX_LEN)
+        if literal or self.revcomp_ref:
+            # the literal compare works on 4-bit codes: every base needs one (and a complement)
+            packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True)
+            if bad and (literal or kind == _lib.TABLE_DNA15):
+                raise ValueError("%d sequence(s) contain characters without an upper-case IUPAC code; the device "
+                                 "pair aligner compares 4-bit codes" % bad)
+        else:
+            packed = be.pack_reads(ascii_t, lens_t, max_len, table)
+        return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, kind, table)
+
+    def locate_batch(self, references, queries):
+        """references/queries: lists of str, uint8 [n, width] ASCII tensors, or ReadBatches
+        packed with the right tables.  Returns a LocateResult (int16 [n, 8] records)."""
+        be = _lib.get_backend()
+        rk, qk = self._table_kinds()
+        literal = not (self.wildcard_ref or self.wildcard_query)
+        rb = self._pack(references, rk, be, literal)
+        qb = self._pack(queries, qk, be, literal)
+        if rb.nreads != qb.nreads:
+            raise ValueError("need as many references as queries")
+        rec = be.locate_pairs_batch(rb.packed, rb.lens, rb.max_len, self.revcomp_ref, qb.packed, qb.lens, qb.max_len,
+                                    rb.nreads, self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query,
+                                    self.min_overlap, self.indel_cost)
+        return LocateResult(rec)
+
+    def locate(self, reference, query):
+        return self.locate_batch([reference], [query]).tuples()[0]
+
+
 class MultiAligner(object):
     """Same as Aligner, but 1) returns up to ``max_matches`` matches rather than a single
     best match, and 2) does not allow indels or wildcards (reference: cdef class

@@ -1,0 +1,186 @@
+// pairs_core.hpp -- Aligner.locate for independent (reference, query) PAIRS: the aligner
+// MergeOverlapping builds per read pair (commands/trim/modifiers.py:889-894:
+// `Aligner(read2_rc, error_rate, flags).locate(read1.sequence)`, i.e. _align.pyx:266-491
+// with a different reference for every call).
+//
+// One lane owns one pair.  The register-column kernel of locate_core.hpp needs a
+// wave-uniform reference (its mismatch masks live in LDS/SGPRs), so here the DP column of a
+// lane sits in LDS instead -- same packed cell word, same one-v_min3 tie-break, payload =
+// matches -- strided by 64 so that lane l touches bank l, and the lane's reference is a
+// second LDS array of 4-bit codes, eight rows per dword.  A column costs, per eight rows:
+// one ds_read of reference codes, ~6 VALU ops to turn them into eight mismatch bits, and per
+// row ds_read + 6 VALU + ds_write.  The sweep is the full (unbanded) matrix: Ukkonen's band is
+// a CPU shortcut that does not change the result.
+// Limits: m, n <= 255 (8-bit matches field, 10-bit origin field), int(e*m) < 256.
+//
+// Compiled for gfx950 and, with -DATR_HOST_EMU, for the CPU test emulation.
+#ifndef ATR_PAIRS_CORE_HPP
+#define ATR_PAIRS_CORE_HPP
+
+#include <cmath>
+#include "locate_core.hpp"
+
+namespace atr {
+
+constexpr int PAIRS_MAX_LEN = ATR_PAIRS_MAX_LEN;
+
+struct PairParams {
+    int16_t thr[PAIRS_MAX_LEN + 3];       // thr[L] = floor(L * max_error_rate), -1 = accept nothing
+    double e;
+    int flags, min_overlap, indel_cost, and_mode;
+};
+
+// 4-bit code j (0-based) of a tile64-packed read; q points at the lane's chunk 0 (uint32 view)
+ATR_DEV uint32_t packed_code(const uint32_t *q, int j) {
+    return (q[(size_t)(j >> 5) * 256 + ((j >> 3) & 3)] >> (4 * (j & 7))) & 15u;
+}
+
+ATR_DEV uint32_t bitrev4(uint32_t c) { return ((c & 1u) << 3) | ((c & 2u) << 1) | ((c & 4u) >> 1) | ((c & 8u) >> 3); }
+
+// Reference codes of one pair, 8 rows per dword, into refw[d * rs]; revcomp: the reference is
+// the reverse complement of the packed sequence (complement of a DNA/IUPAC bit code = its
+// bit reversal: util/__init__.py:67-88).
+ATR_DEV void stage_reference(uint32_t *refw, int rs, const uint32_t *rp, int m, bool revcomp) {
+    for (int d = 0; d * 8 < m; ++d) {
+        uint32_t w = 0;
+        for (int b = 0; b < 8; ++b) {
+            const int i = d * 8 + b;
+            if (i < m) {
+                uint32_t c = packed_code(rp, revcomp ? m - 1 - i : i);
+                if (revcomp) c = bitrev4(c);
+                w |= c << (4 * b);
+            }
+        }
+        refw[(size_t)d * rs] = w;
+    }
+}
+
+// Aligner(ref, e, flags, ..., min_overlap, indel_cost).locate(query) for one pair.
+// col: m + 1 cell words (stride cs); refw: staged reference (stride rs); qp: the lane's
+// packed query.  rec: (refstart, refstop, querystart, querystop, matches, errors) as int16 x 8,
+// refstop = -1 for None.
+template <bool AND_MODE>
+ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs, int m, const uint32_t *qp, int n,
+                             const PairParams &p, const int16_t *thr, uint32_t rec[4]) {
+    const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
+    const bool er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0, eq = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;
+    int k = (int)(p.e * m);                                            // _align.pyx:312
+    if (k < 0) k = -1;
+    int indel = p.indel_cost > k ? k + 1 : p.indel_cost;              // beyond k + 1 every indel is unaffordable alike
+    if (indel < 1) indel = 1;
+    const uint32_t insw = (uint32_t)indel * COST1 + PRIO_INS, delw = (uint32_t)indel * COST1 + PRIO_DEL;
+    const uint32_t klimit = (uint32_t)(k + 1) << CSH;
+    const int max_n = sq ? n : atr_min(n, m + k);                      // :314-321
+    const int min_n = eq ? 0 : atr_max(0, n - m - k);
+    for (int i = 0; i <= m; ++i) col[(size_t)i * cs] = init_word(i, min_n, sr, sq, indel);   // :333-352
+    Best best;
+    best.key = COST_FIELD_MAX - (m + n);                               // (matches 0, cost m + n): :358-363
+    best.word = (uint32_t)(m + n) << CSH;
+    best.ref_stop = m; best.query_stop = n; best.matches = 0;
+    uint32_t qword = 0;
+    for (int j = min_n + 1; j <= max_n; ++j) {
+        if (((j - 1) & 7) == 0 || j == min_n + 1) qword = qp[(size_t)((j - 1) >> 5) * 256 + (((j - 1) >> 3) & 3)];
+        const uint32_t qrep = ((qword >> (4 * ((j - 1) & 7))) & 15u) * 0x11111111u;
+        // row 0 (:385-388)
+        const uint32_t row0 = sq ? (ORG_BIAS + (uint32_t)j)
+                                 : (ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
+        uint32_t old_prev = col[0];                                    // old cell of the row above (diagonal source)
+        uint32_t new_prev = row0;                                      // new cell of the row above (insertion source)
+        col[0] = row0;
+        // Full blocks of eight rows: the eight old cells are fetched up front (and the next
+        // block's while this block's chain runs), so the serial min3 chain never waits for LDS.
+        const int full = m >> 3;
+        uint32_t oldc[8], nxt[8];
+        if (full > 0) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) nxt[b] = col[(size_t)(b + 1) * cs];
+        }
+        for (int d = 0; d < full; ++d) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) oldc[b] = nxt[b];
+            if (d + 1 < full) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) nxt[b] = col[(size_t)((d + 1) * 8 + b + 1) * cs];
+            }
+            const uint32_t rw = refw[(size_t)d * rs];
+            const uint32_t v = AND_MODE ? (rw & qrep) : (rw ^ qrep);
+            const uint32_t nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;     // nibble != 0
+            const uint32_t mis = AND_MODE ? (nz ^ 0x11111111u) : nz;                    // :390-393
+            uint32_t nw[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t bit = (mis >> (4 * b)) & 1u;
+                const uint32_t cd = old_prev + MATCH1 + bit * DIAG_DELTA;               // :394-404
+                const uint32_t cl = oldc[b] + delw, cu = new_prev + insw;               // :405-419
+                nw[b] = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+                old_prev = oldc[b];
+                new_prev = nw[b];
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) col[(size_t)(d * 8 + b + 1) * cs] = nw[b];
+        }
+        if (full * 8 < m) {                                             // the ragged last block, row by row
+            const int d = full;
+            const uint32_t rw = refw[(size_t)d * rs];
+            const uint32_t v = AND_MODE ? (rw & qrep) : (rw ^ qrep);
+            const uint32_t nz = (v | (v >> 1) | (v >> 2) | (v >> 3)) & 0x11111111u;
+            const uint32_t mis = AND_MODE ? (nz ^ 0x11111111u) : nz;
+            for (int b = 0; d * 8 + b < m; ++b) {
+                const int i = d * 8 + b + 1;
+                const uint32_t old = col[(size_t)i * cs];
+                const uint32_t bit = (mis >> (4 * b)) & 1u;
+                const uint32_t cd = old_prev + MATCH1 + bit * DIAG_DELTA;
+                const uint32_t cl = old + delw, cu = new_prev + insw;
+                const uint32_t nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+                col[(size_t)i * cs] = nw;
+                old_prev = old;
+                new_prev = nw;
+            }
+        }
+        // row-m candidate: looked at only when the band reached row m, i.e. cost <= k (:433-455)
+        if (eq && new_prev < klimit) consider<false>(best, new_prev, m, j, p.min_overlap, thr, indel);
+    }
+    if (max_n == n) {                                                   // :461-474
+        for (int i = er ? 0 : m; i <= m; ++i) consider<false>(best, col[(size_t)i * cs], i, n, p.min_overlap, thr, indel);
+    }
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != m + n) {                                                // :476-480
+        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
+// Host side: thresholds and envelope check shared by the library and the emulation.
+inline int pairs_params(double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                        int ref_max_len, int query_max_len, PairParams &p) {
+    if (flags < 0 || flags > 15 || min_overlap < 1 || indel_cost < 1) return ATR_ERR_INVALID;
+    if (ref_max_len < 0 || query_max_len < 0) return ATR_ERR_INVALID;
+    if (ref_max_len > PAIRS_MAX_LEN || query_max_len > PAIRS_MAX_LEN) return ATR_ERR_UNSUPPORTED;
+    const double kd = e * (double)ref_max_len;
+    if (!(kd < 256.0) || !(kd > -1.0e9)) return ATR_ERR_UNSUPPORTED;
+    // worst computed cost: an initial value (<= (m + k) * indel) plus m insertions; indel is
+    // capped at k + 1 inside the kernel
+    {
+        const int k = (int)kd < 0 ? 0 : (int)kd;
+        const long long ind = indel_cost > k ? k + 1 : indel_cost;
+        if ((long long)(ref_max_len + k + ref_max_len + 1) * ind > INIT_COST_CAP) return ATR_ERR_UNSUPPORTED;
+    }
+    for (int L = 0; L < PAIRS_MAX_LEN + 3; ++L) {
+        double t = std::floor((double)L * e);                           // cost <= L*e  <=>  cost <= floor(L*e)
+        if (t > COST_FIELD_MAX) t = COST_FIELD_MAX;
+        p.thr[L] = t < 0 ? (int16_t)-1 : (int16_t)t;
+    }
+    p.e = e; p.flags = flags; p.min_overlap = min_overlap; p.indel_cost = indel_cost;
+    p.and_mode = (wildcard_ref || wildcard_query) ? 1 : 0;
+    return ATR_OK;
+}
+
+}  // namespace atr
+#endif

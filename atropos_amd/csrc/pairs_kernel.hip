@@ -1,0 +1,73 @@
+// pairs_kernel.hip -- atr_locate_pairs_batch: Aligner.locate with a per-pair reference
+// (pairs_core.hpp).  One wave = 64 pairs; the wave's DP columns and staged references live in
+// dynamic LDS ((max_m + 1) + ceil(max_m / 8) dwords per lane), so occupancy is LDS-bound:
+// 3 waves per CU at 150 bp, 2 at 250 bp.  VALU-bound like every DP here (no MFMA: the
+// recurrence is a min-plus chain along the column, not a contraction).
+#include <hip/hip_runtime.h>
+
+#include "atropos_hip.h"
+#include "pairs_core.hpp"
+
+namespace atr {
+
+int hip_fail(hipError_t e, const char *what);             // api.hip
+
+template <bool AND_MODE>
+__global__ __launch_bounds__(64) void pairs_kernel(const PairParams p, const uint32_t *__restrict__ ref_packed,
+                                                   const int32_t *__restrict__ ref_lens, int ref_chunks,
+                                                   int ref_max_len, int revcomp,
+                                                   const uint32_t *__restrict__ qry_packed,
+                                                   const int32_t *__restrict__ qry_lens, int qry_chunks, int qry_max_len,
+                                                   long long npairs, uint4 *__restrict__ out) {
+    __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pairs[];
+    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 3; i += 64) s_thr[i] = p.thr[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const long long tile = blockIdx.x, r = tile * 64 + lane;
+    if (r >= npairs) return;
+    uint32_t *col = s_pairs + lane;                                   // (max_m + 1) x 64
+    uint32_t *refw = s_pairs + (size_t)(ref_max_len + 1) * 64 + lane; // ceil(max_m / 8) x 64
+    const int m = min(ref_lens ? ref_lens[r] : ref_max_len, ref_max_len);
+    const int n = min(qry_lens ? qry_lens[r] : qry_max_len, qry_max_len);
+    const uint32_t *rp = ref_packed + ((size_t)tile * ref_chunks * 64 + lane) * 4;
+    const uint32_t *qp = qry_packed + ((size_t)tile * qry_chunks * 64 + lane) * 4;
+    stage_reference(refw, 64, rp, m, revcomp != 0);
+    uint32_t rec[4];
+    locate_pair_one<AND_MODE>(col, 64, refw, 64, m, qp, n, p, s_thr, rec);
+    out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+}
+
+}  // namespace atr
+
+using namespace atr;
+
+extern "C" int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len,
+                                      int revcomp_ref, const uint8_t *d_query_packed, const int32_t *d_query_lens,
+                                      int query_max_len, int64_t npairs, double max_error_rate, int flags,
+                                      int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                                      atr_result *d_out, void *stream) {
+    if (npairs < 0) return ATR_ERR_INVALID;
+    PairParams p;
+    const int rc = pairs_params(max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost, ref_max_len,
+                                query_max_len, p);
+    if (rc != ATR_OK) return rc;
+    if (npairs == 0) return ATR_OK;
+    if (!d_out || (ref_max_len > 0 && !d_ref_packed) || (query_max_len > 0 && !d_query_packed)) return ATR_ERR_INVALID;
+    const size_t lds = ((size_t)(ref_max_len + 1) + (size_t)(ref_max_len + 7) / 8) * 64 * 4;
+    const dim3 grid((unsigned)((npairs + 63) / 64)), block(64);
+    hipError_t e;
+#define ATR_LAUNCH_PAIRS(MODE)                                                                                         \
+    do {                                                                                                               \
+        e = hipFuncSetAttribute((const void *)pairs_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return hip_fail(e, "pairs_kernel LDS size");                                              \
+        hipLaunchKernelGGL((pairs_kernel<MODE>), grid, block, lds, (hipStream_t)stream, p,                             \
+                           (const uint32_t *)d_ref_packed, d_ref_lens, (ref_max_len + 31) / 32, ref_max_len, revcomp_ref, \
+                           (const uint32_t *)d_query_packed, d_query_lens, (query_max_len + 31) / 32, query_max_len,   \
+                           (long long)npairs, (uint4 *)d_out);                                                         \
+    } while (0)
+    if (p.and_mode) ATR_LAUNCH_PAIRS(true); else ATR_LAUNCH_PAIRS(false);
+#undef ATR_LAUNCH_PAIRS
+    e = hipGetLastError();
+    return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_kernel launch");
+}

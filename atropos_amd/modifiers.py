@@ -5,10 +5,12 @@ AdapterCutter :91-195, ErrorCorrectorMixin :201-357, InsertAdapterCutter :359-50
 Same classes and per-read ``__call__`` behaviour as the reference; in addition every
 cutter has a batched twin (``call_batch``) that runs each alignment stage once over the
 whole batch on the GPU and then does the per-read bookkeeping (trimming, statistics,
-``match``/``match_info``) from the result arrays -- SURVEY section 8(f1).  The other ~15
-modifiers of the reference (quality/NextSeq/bisulfite trimmers, clippers, name editors,
-MergeOverlapping) are cheap string operations that are not on the alignment path and are
-out of scope.
+``match``/``match_info``) from the result arrays -- SURVEY section 8(f1).
+``MergeOverlapping`` (:864-931, section 8(f3)) is here too: its per-pair aligner is a batched
+GPU call.  Quality / NextSeq / N-end trimming, clipping and the read filters live in the
+device-resident FASTQ pipeline (``atropos_amd.trim``); the remaining modifiers of the reference
+(bisulfite trimmers, name editors, ...) are cheap string operations off the alignment path
+and out of scope.
 """
 from collections import OrderedDict
 
@@ -16,8 +18,9 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import align
 from .align import InsertAligner, Match
-from .util import BASE_COMPLEMENTS
+from .util import BASE_COMPLEMENTS, reverse_complement
 
 _ACTIONS = {'N': 0, 'conservative': 1, 'liberal': 2}
 
@@ -377,3 +380,80 @@ class InsertAdapterCutter(ReadPairModifier, ErrorCorrectorMixin):
         if self.mismatch_action:
             summary.update(ErrorCorrectorMixin.summarize(self))
         return summary
+
+
+class MergeOverlapping(ReadPairModifier, ErrorCorrectorMixin):
+    """Merge overlapping reads; the merged read is stored in read1 and read2 becomes None
+    (reference: commands/trim/modifiers.py:864-931).  The per-pair alignment
+    ``Aligner(reverse_complement(read2), error_rate, flags).locate(read1)`` runs on the GPU for
+    the whole batch (``PairAligner``, atr_locate_pairs_batch); reverse complement included."""
+
+    def __init__(self, min_overlap=0.9, error_rate=0.1, mismatch_action=None):
+        ErrorCorrectorMixin.__init__(self, mismatch_action)
+        self.min_overlap = int(min_overlap) if min_overlap > 1 else min_overlap
+        self.error_rate = error_rate
+        self._aligners = {}
+
+    def _aligner(self, flags):
+        if flags not in self._aligners:
+            self._aligners[flags] = align.PairAligner(self.error_rate, flags, revcomp_ref=True)
+        return self._aligners[flags]
+
+    def __call__(self, read1, read2):
+        return self.call_batch([read1], [read2])[0]
+
+    def call_batch(self, reads1, reads2):
+        """Batched twin of ``__call__``: returns the list of (read1, read2-or-None) pairs."""
+        out = [(r1, r2) for r1, r2 in zip(reads1, reads2)]
+        plan = {}                                            # flags -> [(index, min_overlap)]
+        for i, (read1, read2) in enumerate(out):
+            len1, len2 = len(read1.sequence), len(read2.sequence)
+            min_overlap = self.min_overlap
+            if min_overlap <= 1:
+                min_overlap = max(2, round(self.min_overlap * min(len1, len2)))
+            if len1 < min_overlap or len2 < min_overlap:
+                continue
+            insert_matched = read1.insert_overlap and read2.insert_overlap
+            # an insert overlap with a 3' overhang was already found: constrain the alignment
+            flags = (align.START_WITHIN_SEQ1 | align.STOP_WITHIN_SEQ2) if insert_matched else align.SEMIGLOBAL
+            plan.setdefault(flags, []).append((i, min_overlap, bool(insert_matched)))
+        for flags, todo in plan.items():
+            idx = [t[0] for t in todo]
+            for i in idx:
+                reverse_complement(out[i][1].sequence)       # KeyError on a base without complement, as the reference
+            # reference = reverse_complement(read2) (formed on the device), query = read1
+            alignments = self._aligner(flags).locate_batch([out[i][1].sequence for i in idx],
+                                                           [out[i][0].sequence for i in idx]).tuples()
+            for (i, min_overlap, insert_matched), alignment in zip(todo, alignments):
+                if alignment:
+                    out[i] = self._merge(out[i][0], out[i][1], alignment, min_overlap, insert_matched)
+        return out
+
+    def _merge(self, read1, read2, alignment, min_overlap, insert_matched):
+        len1, len2 = len(read1.sequence), len(read2.sequence)
+        read2_rc = reverse_complement(read2.sequence)
+        r2_start, r2_stop, r1_start, r1_stop, matches, errors = alignment
+        if matches < min_overlap:
+            return (read1, read2)
+        # only correct errors if that was not already done by the insert aligner
+        if self.mismatch_action and errors > 0 and not insert_matched:
+            self.correct_errors(read1, read2, alignment)
+        if r2_start == 0 and r2_stop == len2:
+            pass                                             # r2 is fully contained in r1
+        elif r1_start == 0 and r1_stop == len1:
+            read1.sequence = read2_rc                        # r1 is fully contained in r2
+            read1.qualities = "".join(reversed(read2.qualities))
+        elif r1_start > 0:
+            read1.sequence += read2_rc[r2_stop:]
+            if read1.qualities and read2.qualities:
+                read1.qualities += "".join(reversed(read2.qualities))[r2_stop:]
+        elif r2_start > 0:
+            read1.sequence = read2_rc + read1.sequence[r1_stop:]
+            if read1.qualities and read2.qualities:
+                read1.qualities = "".join(reversed(read2.qualities)) + read1.qualities[r1_stop:]
+        else:
+            raise ValueError("Invalid alignment while trying to merge read {}: {}".format(
+                read1.name, ",".join(str(i) for i in alignment)))
+        read1.merged = True
+        return (read1, None)
+

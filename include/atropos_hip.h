@@ -221,6 +221,24 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
                              int action, int min_qual_difference, int truncate_seqs, const uint8_t comp[256],
                              int32_t *d_changed, int32_t *d_newlen, void *stream);
 
+/* ---- Aligner.locate with a per-pair reference (MergeOverlapping) ----------- */
+
+/* `Aligner(ref_p, max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap,
+ * indel_cost).locate(query_p)` (_align.pyx:197-491) for npairs independent pairs: the
+ * aligner MergeOverlapping constructs per read pair with reference = reverse complement of
+ * read 2 and query = read 1 (commands/trim/modifiers.py:889-894).  Both sides are 4-bit
+ * tile64 batches (atr_pack_reads / atr_pack_records) packed with the tables Aligner would
+ * translate with: ATR_TABLE_DNA15 on both sides for the literal compare (every base must be
+ * one of the 15 upper-case IUPAC letters), ATR_TABLE_ACGT / ATR_TABLE_IUPAC per wildcard flag
+ * otherwise (_align.pyx:243-248, :292-297).  revcomp_ref != 0: the reference of a pair is the
+ * reverse complement of the packed sequence (util/__init__.py:479-482).  d_*_lens may be NULL.
+ * ATR_ERR_UNSUPPORTED: a side longer than ATR_PAIRS_MAX_LEN or int(e * m) >= 256. */
+#define ATR_PAIRS_MAX_LEN 255
+int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
+                           const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,
+                           int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
+                           int min_overlap, int indel_cost, atr_result *d_out, void *stream);
+
 /* ---- device-resident FASTQ batch (io/_seqio.pyx:163-245, io/seqio.py:686-700) ---- */
 
 /* One chunk of FASTQ text (whole records, < 4 GiB, 16-byte aligned, ending in '\n') is

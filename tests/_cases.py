@@ -1,4 +1,5 @@
 """Shared case generators / checkers for the emulation (CPU) and GPU parity tests."""
+import json
 import random
 
 from .conftest import load_golden, tup
@@ -513,3 +514,96 @@ def check_fastq_chunking(tmp_path):
     assert dst.read_bytes() == whole
     assert sum(counts.values()) == data.count(b"\n") // 4
     return counts
+
+
+# ---------------------------------------------------------------------------------------------
+# PairAligner (Aligner.locate with a per-pair reference) against the oracle
+def check_pairs_against_oracle(PairAligner, oracle, unsupported_exc, seed, rounds, max_len=255):
+    """Random settings (all flag sets, indel regimes, wildcard modes, with and without the
+    on-device reverse complement); pairs are overlapping fragments with errors, unrelated
+    sequences, and ragged / empty ones."""
+    from atropos_amd.util import reverse_complement
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        flags = rng.randint(0, 15) if rng.random() < 0.4 else rng.choice([15, 9, 14, 11])
+        e = rng.choice([0, 0.05, 0.1, 0.2, 0.2, 0.3])
+        ic = rng.choice([1, 1, 1, 2, 3, 100000])
+        mo = rng.choice([1, 1, 3, 20])
+        wr, wq = (rng.random() < 0.2, rng.random() < 0.2)
+        rc = rng.random() < 0.5
+        top = rng.choice([12, 40, 100, 150, max_len])
+        npairs = rng.choice([1, 5, 64, 65, 130])
+        refs, qrys = [], []
+        for _p in range(npairs):
+            m, n = rng.randint(0, top), rng.randint(0, top)
+            alpha = "ACGT" if rng.random() < 0.8 else "ACGTN"
+            frag = rseq(rng, m + n, alpha)
+            kind = rng.random()
+            if kind < 0.6:                                   # overlapping pair: both cut from one fragment
+                off = rng.randint(0, max(0, m // 2))
+                ref = frag[off:off + m]
+                q0 = rng.randint(0, m + n - n) if n else 0
+                qry = mutate(rng, frag[q0:q0 + n], rng.choice([0, 0.02, 0.1]), "ACGT")[:n]
+            else:
+                ref, qry = frag[:m], rseq(rng, n, alpha)
+            refs.append(ref[:top])
+            qrys.append(qry[:top])
+        given = [reverse_complement(r) for r in refs] if rc else refs     # what the device is handed
+        try:
+            pa = PairAligner(e, flags, wr, wq, mo, ic, revcomp_ref=rc)
+            got = pa.locate_batch(given, qrys).tuples()
+        except unsupported_exc:
+            continue
+        for ref, qry, g in zip(refs, qrys, got):
+            assert g == oracle.locate(ref, qry, e, flags, wr, wq, mo, ic), (ref, qry, e, flags, wr, wq, mo, ic, rc, g)
+            total += 1
+    return total
+
+
+# ---------------------------------------------------------------------------------------------
+# MergeOverlapping against the reference's outputs (tests/golden/make_merge_golden.py)
+def check_merge_golden(batch=True):
+    from atropos_amd.modifiers import MergeOverlapping
+    from atropos_amd.reads import Sequence
+    cases = load_golden("merge_fuzz.json.gz")
+    groups = {}
+    for k, case in enumerate(cases):
+        groups.setdefault(json.dumps(case["cfg"], sort_keys=True), []).append(k)
+    done = 0
+    for key, idxs in groups.items():
+        cfg = json.loads(key)
+        good = [k for k in idxs if "error" not in cases[k]]
+        bad = [k for k in idxs if "error" in cases[k]]
+        def mk(k):
+            c = cases[k]
+            a, b = Sequence("p/1", c["r1"], c["q1"]), Sequence("p/2", c["r2"], c["q2"])
+            a.insert_overlap = b.insert_overlap = c["insert"]
+            return a, b
+        pairs = [mk(k) for k in good]
+        if batch:
+            # counters are per modifier in the reference fixtures: one modifier per pair for those,
+            # one shared modifier for the batched call
+            mod = MergeOverlapping(**cfg)
+            outs = mod.call_batch([p[0] for p in pairs], [p[1] for p in pairs])
+            assert mod.corrected_pairs == sum(cases[k]["out"]["corrected_pairs"] for k in good)
+        else:
+            outs = [MergeOverlapping(**cfg)(a, b) for a, b in pairs]
+        for k, (o1, o2) in zip(good, outs):
+            want = cases[k]["out"]
+            got = dict(seq1=o1.sequence, qual1=o1.qualities, merged=bool(o1.merged), read2_none=o2 is None,
+                       seq2=None if o2 is None else o2.sequence, qual2=None if o2 is None else o2.qualities,
+                       corrected=[int(o1.corrected), 0 if o2 is None else int(o2.corrected)])
+            for f in got:
+                assert got[f] == want[f], (k, f, got[f], want[f], cases[k])
+            done += 1
+        for k in bad:                                         # the reference raises for these pairs
+            a, b = mk(k)
+            try:
+                MergeOverlapping(**cfg)(a, b)
+            except Exception as err:                          # noqa: BLE001
+                assert type(err).__name__ in (cases[k]["error"], "ValueError"), (k, type(err).__name__, cases[k]["error"])
+            else:
+                raise AssertionError("pair %d: the reference raises %s" % (k, cases[k]["error"]))
+            done += 1
+    return done

@@ -16,7 +16,7 @@ _CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "e
 _SRCS = _CPPS + [
     os.path.join(_ROOT, "atropos_amd", "csrc", f)
     for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp",
-              "filter_core.hpp", "fastq_core.hpp")] + [
+              "filter_core.hpp", "fastq_core.hpp", "pairs_core.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -192,6 +192,15 @@ class EmuBackend(object):
         if nreads:
             _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), int(filtered)),
                    "atr_locate_batch")
+        return out
+
+    def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                           query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+        out = torch.zeros((npairs, 8), dtype=torch.int16)
+        _check(self.lib.emu_locate_pairs_batch(
+            _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
+            query_max_len, C.c_int64(npairs), C.c_double(e), flags, int(wildcard_ref), int(wildcard_query), min_overlap,
+            indel_cost, _ptr(out)), "emu_locate_pairs_batch")
         return out
 
     # -- device-resident FASTQ batch (CPU twin) ----------------------------------

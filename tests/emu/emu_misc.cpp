@@ -2,9 +2,11 @@
 // atropos_amd/csrc/misc_kernels.hip (misc_core.hpp, -DATR_HOST_EMU).
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "aligner_host.hpp"
 #include "misc_core.hpp"
+#include "pairs_core.hpp"
 
 using namespace atr;
 
@@ -65,6 +67,33 @@ int emu_correct_errors_batch(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_
         correct_errors_one(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
                            q2 ? q2 + p * stride : nullptr, len2, im + 4 * p, action, min_qual_diff, truncate != 0,
                            comp, changed + 2 * p, newlen + 2 * p);
+    }
+    return ATR_OK;
+}
+
+// atr_locate_pairs_batch: one pair after the other, column and staged reference in plain arrays
+int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
+                           const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
+                           double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                           uint32_t *out) {
+    if (npairs < 0) return ATR_ERR_INVALID;
+    atr::PairParams p;
+    const int rc = atr::pairs_params(e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost, ref_max_len,
+                                     qry_max_len, p);
+    if (rc != ATR_OK) return rc;
+    const int rch = (ref_max_len + 31) / 32, qch = (qry_max_len + 31) / 32;
+    std::vector<uint32_t> col((size_t)ref_max_len + 1), refw((size_t)(ref_max_len + 7) / 8 + 1);
+    for (int64_t r = 0; r < npairs; ++r) {
+        const int64_t tile = r >> 6;
+        const int lane = (int)(r & 63);
+        int m = ref_lens ? ref_lens[r] : ref_max_len, n = qry_lens ? qry_lens[r] : qry_max_len;
+        if (m > ref_max_len) m = ref_max_len;
+        if (n > qry_max_len) n = qry_max_len;
+        const uint32_t *rp = ref_packed + ((size_t)tile * rch * 64 + lane) * 4;
+        const uint32_t *qp = qry_packed + ((size_t)tile * qch * 64 + lane) * 4;
+        atr::stage_reference(refw.data(), 1, rp, m, revcomp != 0);
+        if (p.and_mode) atr::locate_pair_one<true>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
+        else atr::locate_pair_one<false>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
     }
     return ATR_OK;
 }

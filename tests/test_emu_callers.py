@@ -59,3 +59,8 @@ def test_adapter_parser_specs(emu_backend):
 
 def test_device_resident_adapters(emu_backend):
     assert _cases.check_device_resident_adapters() > 5000
+
+
+def test_merge_overlapping(emu_backend):
+    assert _cases.check_merge_golden(batch=True) == 1000
+    assert _cases.check_merge_golden(batch=False) == 1000

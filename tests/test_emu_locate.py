@@ -75,3 +75,9 @@ def test_api_surface(emu_backend, oracle):
     with pytest.raises(ValueError):
         align.Aligner("ACGN", 0.1, wildcard_ref=True).locate_batch(batch)
     assert len(a.locate_batch([])) == 0
+
+
+def test_pair_aligner_against_oracle(emu_backend, oracle):
+    from atropos_amd.align import PairAligner
+    from atropos_amd._lib import AtroposHipError
+    assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=77, rounds=60) > 1500

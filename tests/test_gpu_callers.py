@@ -29,3 +29,7 @@ def test_reference_caller_kats(hip_backend):
 
 def test_device_resident_adapters(hip_backend):
     assert _cases.check_device_resident_adapters() > 5000
+
+
+def test_merge_overlapping(hip_backend):
+    assert _cases.check_merge_golden(batch=True) == 1000

@@ -127,3 +127,9 @@ def test_c2_sample_and_full_size_properties(hip_backend, oracle):
     first = hit.float().argmax(dim=1).to(torch.int32)
     rs = r[:1_000_000][has]
     assert bool((rs[:, 5] == 0).all()) and bool((rs[:, 4] == m).all()) and bool((rs[:, 2] == first[has]).all())
+
+
+def test_pair_aligner_against_oracle(hip_backend, oracle):
+    from atropos_amd.align import PairAligner
+    from atropos_amd._lib import AtroposHipError
+    assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=78, rounds=120) > 3000
