@@ -49,6 +49,8 @@ PROTOTYPES = {
     "atr_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "atr_pack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_pack_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_multi_locate_work_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "atr_multi_locate_batch": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                          C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -168,19 +170,20 @@ class HipBackend(object):
     def packed_bytes(self, nreads, max_len):
         return self.lib.atr_packed_bytes(nreads, max_len)
 
-    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False, starts=None):
+    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False, starts=None, planes=False):
         """ascii_2d: uint8 [nreads, >=max_len] on self.device (row stride arbitrary);
         lens: int32 [nreads] or None; starts: int32 [nreads] or None (pack read[start:]);
-        table: 256 bytes.  Returns the packed uint8 tensor (and, with count_invalid, the
-        number of reads holding a byte the table maps to 0)."""
+        table: 256 bytes; planes: plane64 layout (the insert aligner's) instead of tile64.
+        Returns the packed uint8 tensor (and, with count_invalid, the number of reads
+        holding a byte the table maps to 0)."""
         nreads = ascii_2d.shape[0]
         packed = self.empty((max(self.packed_bytes(nreads, max_len), 16),), torch.uint8)
         invalid = torch.zeros((1,), dtype=torch.int32, device=self.device) if count_invalid else None
         if nreads and max_len:
             with torch.cuda.device(self.device):
-                _check(self.lib, self.lib.atr_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts),
-                                                         nreads, max_len, table, _ptr(packed), _ptr(invalid),
-                                                         self._stream()), "atr_pack_reads")
+                fn = self.lib.atr_pack_planes if planes else self.lib.atr_pack_reads
+                _check(self.lib, fn(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts), nreads, max_len, table,
+                                    _ptr(packed), _ptr(invalid), self._stream()), "atr_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 
     def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,

@@ -555,11 +555,11 @@ class InsertAligner(object):
             pass
 
     def pack(self, reads, check=False):
-        """Pack one side of the pairs (DNA15 table).  With ``check`` (read 2) every base
-        must be an upper-case IUPAC letter."""
+        """Pack one side of the pairs (DNA15 codes as bit planes, the "plane64" layout of
+        atr_pack_planes).  With ``check`` (read 2) every base must be an upper-case IUPAC letter."""
         if isinstance(reads, ReadBatch):
-            if reads.table_kind != _lib.TABLE_DNA15:
-                raise ValueError("the insert aligner needs reads packed with the DNA15 table")
+            if reads.table_kind != _lib.TABLE_DNA15 or reads.layout != "plane64":
+                raise ValueError("the insert aligner needs reads packed by InsertAligner.pack (DNA15 codes, plane64 layout)")
             return reads
         be = self._backend
         table = be.translate_table(_lib.TABLE_DNA15)
@@ -574,13 +574,13 @@ class InsertAligner(object):
             raise _lib.AtroposHipError("InsertAligner: reads longer than %d bases are outside the device envelope"
                                        % _lib.INSERT_MAX_READ)
         if check:
-            packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True)
+            packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True, planes=True)
             if bad:
                 raise ValueError("%d read(s) contain bases without an upper-case IUPAC code; the device insert "
                                  "aligner cannot reverse-complement them" % bad)
         else:
-            packed = be.pack_reads(ascii_t, lens_t, max_len, table)
-        return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_DNA15, table)
+            packed = be.pack_reads(ascii_t, lens_t, max_len, table, planes=True)
+        return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_DNA15, table, layout="plane64")
 
     def match_insert_batch(self, reads1, reads2):
         """Batched ``match_insert``; reads1/reads2: ReadBatch (DNA15), list of str, or
@@ -620,8 +620,8 @@ class InsertAligner(object):
         t = torch.from_numpy(mat).to(be.device)
         l1 = torch.tensor([len(seq1)], dtype=torch.int32, device=be.device)
         l2 = torch.tensor([len(seq2)], dtype=torch.int32, device=be.device)
-        p1 = be.pack_reads(t[0:1], l1, width, table)
-        p2 = be.pack_reads(t[1:2], l2, width, table)
+        p1 = be.pack_reads(t[0:1], l1, width, table, planes=True)
+        p2 = be.pack_reads(t[1:2], l2, width, table, planes=True)
         rec = be.insert_match_batch(self._handle, p1, l1, p2, l2, 1, width)
         return InsertResult(rec).results()[0]
 

@@ -33,10 +33,11 @@ class ReadBatch(object):
         table_kind, table: which translate table the reads were packed with.
     """
 
-    def __init__(self, packed, lens, nreads, max_len, table_kind, table):
+    def __init__(self, packed, lens, nreads, max_len, table_kind, table, layout="tile64"):
         self.packed, self.lens = packed, lens
         self.nreads, self.max_len = int(nreads), int(max_len)
         self.table_kind, self.table = table_kind, bytes(table)
+        self.layout = layout            # "tile64" (4-bit codes) or "plane64" (bit planes; insert aligner)
 
     def __len__(self):
         return self.nreads

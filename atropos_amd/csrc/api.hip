@@ -51,15 +51,17 @@ struct PackTable { uint8_t t[256]; };
 // apart.  Needs 64 * row_stride + 16 bytes of LDS per wave (row_stride <= PACK_STAGE_MAX).
 constexpr int PACK_STAGE_MAX = 256;
 
-template <bool STAGED>
+template <bool STAGED, bool PLANES>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, long long row_stride,
                                                    const int32_t *__restrict__ lens,
                                                    const int32_t *__restrict__ starts, long long nreads,
                                                    int max_len, int nchunks, const PackTable tab,
                                                    uint4 *__restrict__ packed, int32_t *__restrict__ invalid) {
     __shared__ uint8_t s_tab[256];
+    __shared__ uint32_t s_spread[PLANES ? 256 : 1];
     extern __shared__ __attribute__((aligned(16))) uint8_t s_stage[];
     s_tab[threadIdx.x] = tab.t[threadIdx.x];
+    if (PLANES) s_spread[threadIdx.x] = spread_code((uint32_t)tab.t[threadIdx.x] & 15u);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long tile = (long long)blockIdx.x * 4 + wave;
@@ -87,10 +89,16 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     bool zero_seen = false;
     for (int c = 0; c < nchunks; ++c) {
         uint4 v;
-        v.x = pack_word(row, c * 32, n, s_tab, zero_seen);
-        v.y = pack_word(row, c * 32 + 8, n, s_tab, zero_seen);
-        v.z = pack_word(row, c * 32 + 16, n, s_tab, zero_seen);
-        v.w = pack_word(row, c * 32 + 24, n, s_tab, zero_seen);
+        if (PLANES) {
+            uint32_t pl[4];
+            pack_planes_chunk(row, c * 32, n, s_spread, zero_seen, pl);
+            v = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        } else {
+            v.x = pack_word(row, c * 32, n, s_tab, zero_seen);
+            v.y = pack_word(row, c * 32 + 8, n, s_tab, zero_seen);
+            v.z = pack_word(row, c * 32 + 16, n, s_tab, zero_seen);
+            v.w = pack_word(row, c * 32 + 24, n, s_tab, zero_seen);
+        }
         dst[(size_t)c * 64] = v;
     }
     if (invalid && zero_seen) atomicAdd(invalid, 1);           // one atomic per wave after hipcc's coalescing
@@ -99,6 +107,32 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
 }  // namespace atr
 
 using namespace atr;
+
+template <bool PLANES>
+static int pack_launch(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, const int32_t *d_starts,
+                       int64_t nreads, int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
+                       void *stream) {
+    if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
+    if (nreads == 0 || max_len == 0) return ATR_OK;
+    if (!d_ascii || !d_packed) return ATR_ERR_INVALID;
+    PackTable tab;
+    memcpy(tab.t, table, 256);
+    const int nchunks = (max_len + 31) / 32;
+    const long long ntiles = (nreads + 63) / 64;
+    const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
+    if (row_stride > 0 && row_stride <= PACK_STAGE_MAX) {
+        const size_t per_wave = (((size_t)64 * row_stride + 16) + 15) & ~(size_t)15;
+        hipLaunchKernelGGL((pack_kernel<true, PLANES>), grid, block, 4 * per_wave, (hipStream_t)stream, d_ascii,
+                           (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
+                           (uint4 *)d_packed, d_invalid);
+    } else {
+        hipLaunchKernelGGL((pack_kernel<false, PLANES>), grid, block, 0, (hipStream_t)stream, d_ascii,
+                           (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
+                           (uint4 *)d_packed, d_invalid);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? ATR_OK : hip_fail(e, "pack_kernel launch");
+}
 
 extern "C" {
 
@@ -130,26 +164,13 @@ size_t atr_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nread
 int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, const int32_t *d_starts,
                    int64_t nreads, int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
                    void *stream) {
-    if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
-    if (nreads == 0 || max_len == 0) return ATR_OK;
-    if (!d_ascii || !d_packed) return ATR_ERR_INVALID;
-    PackTable tab;
-    memcpy(tab.t, table, 256);
-    const int nchunks = (max_len + 31) / 32;
-    const long long ntiles = (nreads + 63) / 64;
-    const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-    if (row_stride > 0 && row_stride <= PACK_STAGE_MAX) {
-        const size_t per_wave = (((size_t)64 * row_stride + 16) + 15) & ~(size_t)15;
-        hipLaunchKernelGGL((pack_kernel<true>), grid, block, 4 * per_wave, (hipStream_t)stream, d_ascii,
-                           (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
-                           (uint4 *)d_packed, d_invalid);
-    } else {
-        hipLaunchKernelGGL((pack_kernel<false>), grid, block, 0, (hipStream_t)stream, d_ascii,
-                           (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
-                           (uint4 *)d_packed, d_invalid);
-    }
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? ATR_OK : hip_fail(e, "pack_kernel launch");
+    return pack_launch<false>(d_ascii, row_stride, d_lens, d_starts, nreads, max_len, table, d_packed, d_invalid, stream);
+}
+
+int atr_pack_planes(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, const int32_t *d_starts,
+                    int64_t nreads, int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
+                    void *stream) {
+    return pack_launch<true>(d_ascii, row_stride, d_lens, d_starts, nreads, max_len, table, d_packed, d_invalid, stream);
 }
 
 int atr_aligner_create(const char *ref, int m, double max_error_rate, int flags, int wildcard_ref,

@@ -25,14 +25,20 @@
 //     mismatches or if the product of the two adapter RMPs exceeds adapter_max_rmp
 //     (only when min(alen1, alen2) > adapter_check_cutoff).
 //
-// On the device both reads are 4-bit packed with the DNA15 table (upper-case IUPAC
-// letters -> bit codes).  Complement == bit reversal of a nibble and reverse ==
-// nibble order reversal, so rc2 is v_bfrev_b32 of read2's dwords taken in reverse
-// order.  For overlap length j the alignment of rc2 against read1 is a shift by
-// (D*8 - j) bases regardless of L, so one shift register X (fed one base per step
-// from the top of bfrev(read2)) serves every lane of the wave; mismatches are counted
-// 8 bases per dword with xor / nibble-collapse / v_bcnt.  The sweep is unrolled by
-// dword block B (compile time) x base r (run time), so every register index is static.
+// On the device both reads are packed as BIT PLANES of their 4-bit DNA15 codes (plane64:
+// word p of a 16-byte chunk, bit b = bit p of the code of base 32c + b; atr_pack_planes).
+// Complement == bit reversal of the nibble == plane p <-> plane 3-p, reverse == bit reversal
+// of the multiword plane, so with R = bitrev(complement planes of read 2) over 32*W bits
+//     Rv_j = R >> (32*W - j)   holds rc2[L-j:L] at bits 0..j-1, for every L >= j,
+// and  cost_j = popcount( OR_p (A_p xor Rv_j,p) & lowmask(j) ),  32 bases per boolean op.
+// The shift 32*W - j = 32*q + s is split into a bit shift s (run-time loop: 4*W
+// v_alignbit_b32 per s) and a word shift q (compile-time unrolled: static register indices),
+// so a pair costs about 32 * (4W + 6 * W(W+1)/2) VALU ops instead of one shift and one
+// nibble-compare of every live dword for every j.  The offsets are therefore NOT visited in
+// increasing j; the reference's order-dependent rules are restated order-free (the hit with
+// the smallest probability, earliest j on ties; a perfect full overlap is the only hit) and
+// the one rule that cannot be -- "stop after 100 hits" -- is handled by re-running the rare
+// pair with more than 100 hits in increasing j (ORDERED sweep below).
 #ifndef ATR_INSERT_CORE_HPP
 #define ATR_INSERT_CORE_HPP
 
@@ -72,9 +78,9 @@ static inline int atr_imax(int a, int b) { return a > b ? a : b; }
 namespace atr {
 
 constexpr int INS_MAX_ADAPTER = 64;                 // adapter length handled by the insert kernel
-constexpr int INS_AW = INS_MAX_ADAPTER / 8;         // adapter words
 constexpr int INS_MAX_LEN = 256;                    // read length handled by the insert kernel
 constexpr int INS_MAX_MATCHES = 100;                // MultiAligner.locate(max_matches=100)
+constexpr int INS_CAND = 4;                         // recorded hits per pair in the unordered sweep (more: ordered redo)
 
 // adapter compare modes (compare_prefixes(read_overhang, adapter, wildcard_ref=adapter_wildcards,
 // wildcard_query=read_wildcards), align/__init__.py:285-288)
@@ -83,129 +89,315 @@ enum { INS_CMP_EQ = 0,        // neither flag: byte equality
        INS_CMP_AND_READ_ACGT = 2 };   // read_wildcards only: read bases that are not A/C/G/T become 0
 
 struct InsertParams {
-    uint32_t a1[INS_AW], a2[INS_AW];                // adapter codes (table chosen by the host per mode)
+    uint32_t a1[4][2], a2[4][2];                    // adapter code PLANES, 64 bases (table chosen by the host per mode)
     int16_t mm_by_alen[INS_MAX_ADAPTER + 1];        // round(alen * max_adapter_mismatch_frac)
     int16_t thr_ins[INS_MAX_LEN + 1];               // floor(j * max_insert_mismatch_frac)
     int16_t k_by_len[INS_MAX_LEN + 1];              // int(max_insert_mismatch_frac * L)
     int alen1, alen2, cmp_mode;
     int min_insert_overlap, min_adapter_overlap, adapter_check_cutoff;
+    int min_hit_j;                                  // smallest j whose PERFECT overlap passes insert_max_rmp (host)
     int rmp_ld;
     double insert_max_rmp, adapter_max_rmp;
     const double *rmp_insert, *rmp_adapter;         // device pointers, [size][matches], ld = rmp_ld
 };
 
-// nibble != 0  ->  bit 0 of that nibble
-ATR_DEV uint32_t nibble_nonzero(uint32_t d) {
-    uint32_t t = d | (d >> 2);
-    t |= t >> 1;
-    return t & 0x11111111u;
+ATR_DEV uint32_t low_mask(int nb) {                 // nb low bits set, nb in (-inf, 32]
+    return nb >= 32 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
 }
 
-// one bit per base for the first nb (0..8) bases of a dword
-ATR_DEV uint32_t base_mask(int nb) {
-    return nb >= 8 ? 0x11111111u : (nb <= 0 ? 0u : (0x11111111u & ((1u << (4 * nb)) - 1u)));
-}
+// word `idx` of a W-word plane, 0 beyond it (idx is a compile-time constant after unrolling)
+template <int W>
+ATR_DEV uint32_t word_or_zero(const uint32_t (&v)[W], int idx) { return (idx >= 0 && idx < W) ? v[(idx >= 0 && idx < W) ? idx : 0] : 0u; }
 
-// Keep only A/C/G/T codes (one-hot nibbles), zero everything else (the _acgt_table view
-// of an IUPAC-coded read).
-ATR_DEV uint32_t acgt_only(uint32_t x) {
-    // per-nibble popcount == 1  <=>  x != 0 and (x & (x-1)) == 0, done without borrows:
-    const uint32_t b0 = x & 0x11111111u, b1 = (x >> 1) & 0x11111111u, b2 = (x >> 2) & 0x11111111u,
-                   b3 = (x >> 3) & 0x11111111u;
-    const uint32_t sum2 = (b0 & b1) | (b0 & b2) | (b0 & b3) | (b1 & b2) | (b1 & b3) | (b2 & b3);  // >= 2 bits
-    const uint32_t one = (b0 | b1 | b2 | b3) & ~sum2;                                             // exactly 1
-    return x & (one * 15u);
-}
-
-template <int D>
+template <int W>
 struct PairState {
-    uint32_t s1[D], s2[D], x[D];
+    uint32_t a[4][W];                                // read 1, code planes
+    uint32_t r[4][W];                                // bit-reversed complement planes of read 2 (R above)
     int L, len1, len2, k;
     int nhits;
     double best_prob;
     int best_j, best_cost, best_e1, best_e2;        // best_e1 < 0: no adapter matches attached
     bool has_best;
+    // unordered sweep: hits that can pass the insert RMP filter are only recorded during the
+    // sweep (j << 16 | cost) and evaluated afterwards, all lanes together
+    uint32_t cand[INS_CAND];
+    int ncand;
 };
 
-template <int D>
-ATR_DEV void pair_init(PairState<D> &P, const InsertParams &ip, int len1, int len2) {
+// b1, b2: the plane64 chunks of the two reads (word p of chunk c at [4*c + p]).
+template <int W>
+ATR_DEV void pair_init(PairState<W> &P, const InsertParams &ip, int len1, int len2, const uint32_t *b1, const uint32_t *b2) {
     P.len1 = len1; P.len2 = len2;
     P.L = atr_imin(len1, len2);                                       // align/__init__.py:259-265
     P.k = ip.k_by_len[atr_imin(P.L, INS_MAX_LEN)];
-    P.nhits = 0; P.has_best = false; P.best_prob = 0.0;
-    P.best_j = P.best_cost = 0; P.best_e1 = P.best_e2 = -1;
 #pragma unroll
-    for (int w = 0; w < D; ++w) P.x[w] = 0;
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            P.a[p][w] = b1[4 * w + p];
+            P.r[p][w] = atr_bfrev(b2[4 * (W - 1 - w) + (3 - p)]);     // complement: plane 3-p; reverse: bit reversal
+        }
 }
 
-// Mismatches of the read overhang starting at base j = 8*B + r against an adapter.
-template <int D, int B>
-ATR_DEV int overhang_mismatches(const uint32_t (&s)[D], int r, const uint32_t (&a)[INS_AW], int alen, int mode) {
+template <int W>
+ATR_DEV void pair_reset(PairState<W> &P) {
+    P.nhits = 0; P.has_best = false; P.best_prob = 0.0;
+    P.best_j = P.best_cost = 0; P.best_e1 = P.best_e2 = -1;
+    P.ncand = 0;
+#pragma unroll
+    for (int c = 0; c < INS_CAND; ++c) P.cand[c] = 0u;
+}
+
+// Mismatches of 64 bases of read overhang (planes ov[p][0..1]) against an adapter.
+ATR_DEV int overhang_mismatches(const uint32_t (&ov)[4][2], const uint32_t (&ad)[4][2], int alen, int mode) {
     int mism = 0;
 #pragma unroll
-    for (int w = 0; w < INS_AW; ++w) {
-        const uint32_t lo = (B + w < D) ? s[(B + w < D) ? B + w : 0] : 0u;
-        const uint32_t hi = (B + w + 1 < D) ? s[(B + w + 1 < D) ? B + w + 1 : 0] : 0u;
-        uint32_t ov = (r >= 8) ? hi : ((lo >> (4 * r)) | (hi << (32 - 4 * r)));   // r in 1..8
+    for (int t = 0; t < 2; ++t) {
+        uint32_t x0 = ov[0][t], x1 = ov[1][t], x2 = ov[2][t], x3 = ov[3][t];
         uint32_t bad;
         if (mode == INS_CMP_EQ) {
-            bad = nibble_nonzero(ov ^ a[w]);
+            bad = (x0 ^ ad[0][t]) | (x1 ^ ad[1][t]) | (x2 ^ ad[2][t]) | (x3 ^ ad[3][t]);
         } else {
-            if (mode == INS_CMP_AND_READ_ACGT) ov = acgt_only(ov);
-            bad = nibble_nonzero(ov & a[w]) ^ 0x11111111u;
+            if (mode == INS_CMP_AND_READ_ACGT) {
+                // keep only A/C/G/T codes (exactly one plane bit), zero everything else: the
+                // _acgt_table view of an IUPAC-coded read
+                const uint32_t one = ((x0 ^ x1) ^ (x2 ^ x3)) & ~((x0 & x1) | (x2 & x3));
+                x0 &= one; x1 &= one; x2 &= one; x3 &= one;
+            }
+            bad = ~((x0 & ad[0][t]) | (x1 & ad[1][t]) | (x2 & ad[2][t]) | (x3 & ad[3][t]));
         }
-        mism += atr_popc(bad & base_mask(alen - 8 * w));
+        mism += atr_popc(bad & low_mask(alen - 32 * t));
     }
     return mism;
 }
 
-// Overlap length j = 8*B + r (r = 1..8).  ycur holds the not-yet-consumed bases of
-// bfrev(read2 dword B), next base in its top nibble.
-template <int D, int B>
-ATR_DEV void pair_step(PairState<D> &P, const InsertParams &ip, int r, uint32_t &ycur) {
-    const int j = 8 * B + r;
-    // X <<= one base, bringing in the next base of rc2 at the bottom
+// The 64 bases from base j = 32*WI + sh on of a W-word plane set (WI compile time, sh run time).
+template <int W, int WI>
+ATR_DEV void planes_from(const uint32_t (&v)[4][W], int sh, uint32_t (&ov)[4][2]) {
 #pragma unroll
-    for (int w = B; w >= 1; --w) P.x[w] = (P.x[w] << 4) | (P.x[w - 1] >> 28);
-    P.x[0] = (P.x[0] << 4) | (ycur >> 28);
-    ycur <<= 4;
-    // Hamming(read1[0:j], rc2[L-j:L]), byte-equality semantics (_align.pyx:690)
-    int cost = 0;
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int w = 0; w <= B; ++w) {
-        uint32_t bad = nibble_nonzero(P.x[w] ^ P.s1[w]);
-        if (w == B) bad &= base_mask(r);
-        cost += atr_popc(bad);
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t lo = word_or_zero<W>(v[p], WI + t), hi = word_or_zero<W>(v[p], WI + t + 1);
+            ov[p][t] = sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+        }
+}
+
+// Everything that happens to a hit of MultiAligner.locate (overlap j, `cost` mismatches):
+// insert RMP filter and InsertAligner._match.  WI = j >> 5 as a compile-time constant.
+// Returns whether the hit survives; prob, e1, e2 describe it.
+template <int W, int WI>
+ATR_DEV bool evaluate_hit(const PairState<W> &P, const InsertParams &ip, int j, int cost, double &prob, int &e1, int &e2) {
+    const int matches = j - cost;
+    prob = ip.rmp_insert[(size_t)j * ip.rmp_ld + matches];            // align/__init__.py:359
+    e1 = e2 = -1;
+    if (!(prob <= ip.insert_max_rmp)) return false;
+    const int offset = P.L - j;
+    if (offset >= ip.min_adapter_overlap) {                           // align/__init__.py:270-276
+        const int al1 = atr_imin(offset, ip.alen1), al2 = atr_imin(offset, ip.alen2);
+        uint32_t ov[4][2];
+        planes_from<W, WI>(P.a, j & 31, ov);
+        e1 = overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode);
+        // read 2 in natural order: plane p word w = bitrev(R[3-p][W-1-w])
+        uint32_t b2[4][W];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int w = 0; w < W; ++w) b2[p][w] = atr_bfrev(P.r[3 - p][W - 1 - w]);
+        planes_from<W, WI>(b2, j & 31, ov);
+        e2 = overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode);
+        if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return false;   // :297-300
+        if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                               // :302-306
+            const double p1 = ip.rmp_adapter[(size_t)al1 * ip.rmp_ld + (al1 - e1)];
+            const double p2 = ip.rmp_adapter[(size_t)al2 * ip.rmp_ld + (al2 - e2)];
+            if (p1 * p2 > ip.adapter_max_rmp) return false;
+        }
     }
+    return true;
+}
+
+// Overlap length j = 32*(W - Q) - s with `cost` mismatches, for one lane, in the reference's
+// order (increasing j).
+template <int W, int Q>
+ATR_DEV void pair_hit_ordered(PairState<W> &P, const InsertParams &ip, int s, int j, int cost) {
     if (j > P.L || P.nhits >= INS_MAX_MATCHES) return;
     // the hit test of MultiAligner.locate (_align.pyx:713-745)
     if (cost > P.k || j < ip.min_insert_overlap || cost > (int)ip.thr_ins[j]) return;
     P.nhits += 1;
-    if (cost == 0 && j == P.L) P.has_best = false;             // exact full overlap: the only hit (:737-741, :767-768)
-    const int matches = j - cost;
-    const double prob = ip.rmp_insert[(size_t)j * ip.rmp_ld + matches];   // align/__init__.py:359
-    if (!(prob <= ip.insert_max_rmp)) return;
+    if (cost == 0 && j == P.L) P.has_best = false;      // exact full overlap: the only hit (:737-741, :767-768)
+    double prob;
+    int e1, e2;
+    bool ok;
+    if (s == 0) ok = evaluate_hit<W, W - Q>(P, ip, j, cost, prob, e1, e2);      // j >> 5 == W - Q
+    else ok = evaluate_hit<W, W - Q - 1>(P, ip, j, cost, prob, e1, e2);         // j >> 5 == W - Q - 1
+    if (!ok) return;
     if (P.has_best && !(prob < P.best_prob)) return;            // stable ascending-probability order
+    P.has_best = true; P.best_prob = prob; P.best_j = j; P.best_cost = cost; P.best_e1 = e1; P.best_e2 = e2;
+}
+
+// The same hit in the unordered sweep: count it; if its overlap is long enough to pass the
+// insert RMP filter at all, remember it for the evaluation pass.
+template <int W>
+ATR_DEV void pair_hit_record(PairState<W> &P, const InsertParams &ip, int j, int cost) {
+    if (j > P.L) return;
+    if (cost > P.k || j < ip.min_insert_overlap || cost > (int)ip.thr_ins[j]) return;
+    P.nhits += 1;
+    if (j < ip.min_hit_j) return;                       // rmp(matches <= j, j) >= rmp(j, j) > insert_max_rmp
+#pragma unroll
+    for (int c = INS_CAND - 1; c >= 1; --c) P.cand[c] = P.cand[c - 1];
+    P.cand[0] = ((uint32_t)j << 16) | (uint32_t)cost;
+    P.ncand += 1;
+}
+
+// 64 bases of a plane64-packed read from base j on, fetched from memory (per-lane j):
+// g = the lane's chunk 0, chunk stride `cstride` dwords, nchunks chunks.
+ATR_DEV void planes_from_memory(const uint32_t *g, int cstride, int nchunks, int j, uint32_t (&ov)[4][2]) {
+    const int wi = j >> 5, sh = j & 31;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t w3[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w3[t] = (wi + t < nchunks) ? g[(size_t)(wi + t) * cstride + p] : 0u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) ov[p][t] = sh ? ((w3[t] >> sh) | (w3[t + 1] << (32 - sh))) : w3[t];
+    }
+}
+
+// Evaluation of one recorded hit (insert RMP filter + InsertAligner._match) with a per-lane j.
+template <int W>
+ATR_DEV bool evaluate_candidate(const PairState<W> &P, const InsertParams &ip, int j, int cost, const uint32_t *g1,
+                                const uint32_t *g2, int cstride, double &prob, int &e1, int &e2) {
+    prob = ip.rmp_insert[(size_t)j * ip.rmp_ld + (j - cost)];         // align/__init__.py:359
+    e1 = e2 = -1;
+    if (!(prob <= ip.insert_max_rmp)) return false;
     const int offset = P.L - j;
-    int e1 = -1, e2 = -1;
-    if (offset >= ip.min_adapter_overlap) {                     // align/__init__.py:270-276
+    if (offset >= ip.min_adapter_overlap) {                           // align/__init__.py:270-276
         const int al1 = atr_imin(offset, ip.alen1), al2 = atr_imin(offset, ip.alen2);
-        e1 = overhang_mismatches<D, B>(P.s1, r, ip.a1, al1, ip.cmp_mode);
-        e2 = overhang_mismatches<D, B>(P.s2, r, ip.a2, al2, ip.cmp_mode);
-        if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return;    // :297-300
-        if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                           // :302-306
+        uint32_t ov[4][2];
+        planes_from_memory(g1, cstride, W, j, ov);
+        e1 = overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode);
+        planes_from_memory(g2, cstride, W, j, ov);
+        e2 = overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode);
+        if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return false;   // :297-300
+        if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                               // :302-306
             const double p1 = ip.rmp_adapter[(size_t)al1 * ip.rmp_ld + (al1 - e1)];
             const double p2 = ip.rmp_adapter[(size_t)al2 * ip.rmp_ld + (al2 - e2)];
-            if (p1 * p2 > ip.adapter_max_rmp) return;
+            if (p1 * p2 > ip.adapter_max_rmp) return false;
         }
     }
-    P.has_best = true; P.best_prob = prob; P.best_j = j; P.best_cost = cost; P.best_e1 = e1; P.best_e2 = e2;
+    return true;
+}
+
+// cost of overlap j = 32*(W-Q) - s: read-1 words 0 .. W-1-Q against Rs words Q .. W-1
+// (Rs = R >> s); the top word keeps only its 32 - s valid bits.
+template <int W, int Q>
+ATR_DEV int overlap_cost(const PairState<W> &P, const uint32_t (&rs)[4][W], uint32_t topmask) {
+    int cost = 0;
+#pragma unroll
+    for (int w = 0; w + Q < W; ++w) {
+        uint32_t m = ((P.a[0][w] ^ rs[0][w + Q]) | (P.a[1][w] ^ rs[1][w + Q])) |
+                     ((P.a[2][w] ^ rs[2][w + Q]) | (P.a[3][w] ^ rs[3][w + Q]));
+        if (w + Q == W - 1) m &= topmask;
+        cost += atr_popc(m);
+    }
+    return cost;
+}
+
+template <int W, int Q, bool ORDERED>
+struct WordShift {
+    // unordered sweep: one bit shift s, all word shifts
+    static ATR_DEV_MEMBER void all(PairState<W> &P, const InsertParams &ip, int s, const uint32_t (&rs)[4][W],
+                                   uint32_t topmask, int jmax) {
+        const int j = 32 * (W - Q) - s;
+        if (j >= 1 && j <= jmax) pair_hit_record<W>(P, ip, j, overlap_cost<W, Q>(P, rs, topmask));
+        WordShift<W, Q + 1, ORDERED>::all(P, ip, s, rs, topmask, jmax);
+    }
+    // ordered sweep: word shifts from W-1 down (j ascending), all bit shifts from 31 down inside
+    static ATR_DEV_MEMBER void descending(PairState<W> &P, const InsertParams &ip, int jmax) {
+        if (32 * (W - Q) - 31 <= jmax) {                              // wave-uniform
+#ifndef ATR_HOST_EMU
+#pragma unroll 1
+#endif
+            for (int s = 31; s >= 0; --s) {
+                const int j = 32 * (W - Q) - s;
+                if (j > jmax) break;
+                uint32_t rs[4][W];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int w = 0; w < W; ++w) {
+                        const uint32_t lo = P.r[p][w], hi = (w + 1 < W) ? P.r[p][(w + 1 < W) ? w + 1 : 0] : 0u;
+                        rs[p][w] = (w >= Q) ? (s ? ((lo >> s) | (hi << (32 - s))) : lo) : 0u;
+                    }
+                pair_hit_ordered<W, Q>(P, ip, s, j, overlap_cost<W, Q>(P, rs, 0xFFFFFFFFu >> s));
+            }
+        }
+        if constexpr (Q > 0) WordShift<W, Q - 1, ORDERED>::descending(P, ip, jmax);
+    }
+};
+template <int W, bool ORDERED>
+struct WordShift<W, W, ORDERED> {
+    static ATR_DEV_MEMBER void all(PairState<W> &, const InsertParams &, int, const uint32_t (&)[4][W], uint32_t, int) {}
+    static ATR_DEV_MEMBER void descending(PairState<W> &, const InsertParams &, int) {}
+};
+
+// The unordered sweep of one lane; jmax = the wave-uniform upper bound of the overlap length.
+// g1, g2: the lane's plane64 chunks in memory (chunk stride cstride dwords), for the evaluation pass.
+template <int W>
+ATR_DEV void sweep_unordered(PairState<W> &P, const InsertParams &ip, int jmax, const uint32_t *g1, const uint32_t *g2,
+                             int cstride) {
+    pair_reset<W>(P);
+#ifndef ATR_HOST_EMU
+#pragma unroll 1
+#endif
+    for (int s = 0; s < 32; ++s) {
+        if (32 * W - s < 1) break;
+        uint32_t rs[4][W];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t lo = P.r[p][w], hi = (w + 1 < W) ? P.r[p][(w + 1 < W) ? w + 1 : 0] : 0u;
+                rs[p][w] = s ? ((lo >> s) | (hi << (32 - s))) : lo;
+            }
+        WordShift<W, 0, false>::all(P, ip, s, rs, 0xFFFFFFFFu >> s, jmax);
+    }
+    // evaluation pass: every lane looks at its c-th recorded hit.  Order-free restatement of
+    // "try the hits in ascending probability (stable)": smallest probability, earliest j on ties;
+    // a perfect full overlap is the only hit (:737-741).
+    bool exact = false;
+    for (int c = 0; c < INS_CAND; ++c) {
+        if (c >= P.ncand) continue;
+        const int j = (int)(P.cand[c] >> 16), cost = (int)(P.cand[c] & 0xFFFFu);
+        double prob;
+        int e1, e2;
+        const bool ok = evaluate_candidate<W>(P, ip, j, cost, g1, g2, cstride, prob, e1, e2);
+        const bool full = (cost == 0 && j == P.L);
+        if (exact && !full) continue;
+        if (full) { exact = true; P.has_best = false; }
+        if (!ok) continue;
+        if (!full && P.has_best && !(prob < P.best_prob || (prob == P.best_prob && j < P.best_j))) continue;
+        P.has_best = true; P.best_prob = prob; P.best_j = j; P.best_cost = cost; P.best_e1 = e1; P.best_e2 = e2;
+    }
+}
+
+// Whether the unordered sweep's answer stands: at most 100 hits (the reference stops after
+// 100, in increasing j) and no more recorded hits than there are slots.
+template <int W>
+ATR_DEV bool unordered_is_exact(const PairState<W> &P) { return P.nhits <= INS_MAX_MATCHES && P.ncand <= INS_CAND; }
+
+// The reference's own order (increasing j, at most 100 hits): only for the rare pairs whose
+// unordered sweep does not stand (low-complexity reads).
+template <int W>
+ATR_DEV void sweep_ordered(PairState<W> &P, const InsertParams &ip, int jmax) {
+    pair_reset<W>(P);
+    WordShift<W, W - 1, true>::descending(P, ip, jmax);
 }
 
 // Three 16-byte records per pair: the insert match, Match 1, Match 2
 // (refstop / astop == -1: absent).
-template <int D>
-ATR_DEV void pair_result(const PairState<D> &P, const InsertParams &ip, uint32_t rec[12]) {
+template <int W>
+ATR_DEV void pair_result(const PairState<W> &P, const InsertParams &ip, uint32_t rec[12]) {
     int v[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) v[i] = 0;
@@ -230,28 +422,6 @@ ATR_DEV void pair_result(const PairState<D> &P, const InsertParams &ip, uint32_t
         rec[4 * t + 3] = 0;
     }
 }
-
-// The whole sweep for one lane: blocks B = 0..D-1 (compile time), bases r = 1..8.
-// jmax is the wave-uniform upper bound of the overlap length (max L over the lanes).
-template <int D, int B>
-struct InsertSweep {
-    static ATR_DEV_MEMBER void run(PairState<D> &P, const InsertParams &ip, int jmax) {
-        if (8 * B >= jmax) return;                                    // wave-uniform
-        uint32_t ycur = atr_bfrev(P.s2[B]);                           // rc2 dword D-1-B
-#ifndef ATR_HOST_EMU
-#pragma unroll 1
-#endif
-        for (int r = 1; r <= 8; ++r) {
-            if (8 * B + r > jmax) break;
-            pair_step<D, B>(P, ip, r, ycur);
-        }
-        InsertSweep<D, B + 1>::run(P, ip, jmax);
-    }
-};
-template <int D>
-struct InsertSweep<D, D> {
-    static ATR_DEV_MEMBER void run(PairState<D> &, const InsertParams &, int) {}
-};
 
 }  // namespace atr
 #endif

@@ -41,9 +41,11 @@ inline int insert_fill(atr_insert_aligner *h, const atr_insert_config *c) {
     else if (c->read_wildcards) { p.cmp_mode = INS_CMP_AND_READ_ACGT; at = T.iupac; }
     else { p.cmp_mode = INS_CMP_EQ; at = T.dna15; }
     for (int i = 0; i < c->alen1; ++i)
-        p.a1[i / 8] |= (uint32_t)(at[(unsigned char)c->adapter1[i]] & 15) << (4 * (i % 8));
+        for (int pl = 0; pl < 4; ++pl)
+            p.a1[pl][i / 32] |= (uint32_t)((at[(unsigned char)c->adapter1[i]] >> pl) & 1) << (i % 32);
     for (int i = 0; i < c->alen2; ++i)
-        p.a2[i / 8] |= (uint32_t)(at[(unsigned char)c->adapter2[i]] & 15) << (4 * (i % 8));
+        for (int pl = 0; pl < 4; ++pl)
+            p.a2[pl][i / 32] |= (uint32_t)((at[(unsigned char)c->adapter2[i]] >> pl) & 1) << (i % 32);
     for (int a = 0; a <= INS_MAX_ADAPTER; ++a) {
         int v = c->max_mismatch_by_alen[a];
         p.mm_by_alen[a] = (int16_t)(v < -1 ? -1 : (v > 30000 ? 30000 : v));
@@ -70,6 +72,11 @@ inline int insert_fill(atr_insert_aligner *h, const atr_insert_config *c) {
             h->rmp_insert[(size_t)s * ld + k] = c->rmp_insert[(size_t)s * c->rmp_ld + k];
             h->rmp_adapter[(size_t)s * ld + k] = c->rmp_adapter[(size_t)s * c->rmp_ld + k];
         }
+    // hits shorter than this cannot pass the insert RMP filter even when perfect
+    // (rmp(matches, size) decreases with matches): the unordered sweep only counts them
+    p.min_hit_j = INS_MAX_LEN + 1;
+    for (int j = 1; j <= INS_MAX_LEN; ++j)
+        if (h->rmp_insert[(size_t)j * ld + j] <= p.insert_max_rmp) { p.min_hit_j = j; break; }
     return ATR_OK;
 }
 

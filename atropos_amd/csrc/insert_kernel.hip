@@ -1,6 +1,6 @@
 // insert_kernel.hip -- gfx950 kernel around insert_core.hpp: one read pair per lane,
-// 64 pairs per wavefront.  Each lane loads both packed reads completely (2*D dwords,
-// D = 4*nchunks, coalesced 1 KiB bursts per chunk), then runs the overlap sweep; the
+// 64 pairs per wavefront.  Each lane loads both plane64-packed reads completely (2 * 4W
+// dwords, coalesced 1 KiB bursts per chunk), then runs the bit-sliced overlap sweep; the
 // only other global traffic is the occasional double-precision table lookup for a hit
 // (L2 resident, 2 x 528 KB) and three coalesced 16-byte result stores.
 #include <hip/hip_runtime.h>
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, cons
                                                      const uint4 *__restrict__ packed2,
                                                      const int32_t *__restrict__ lens2, long long npairs,
                                                      int max_len, uint4 *__restrict__ out) {
-    constexpr int D = 4 * NCH;
+    constexpr int W = NCH;
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long ntiles = (npairs + 63) >> 6;
@@ -30,21 +30,25 @@ __global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, cons
     const int len1 = live ? (lens1 ? lens1[r] : max_len) : 0;
     const int len2 = live ? (lens2 ? lens2[r] : max_len) : 0;
 
-    PairState<D> P;
-    pair_init<D>(P, ip, len1, len2);
+    uint32_t b1[4 * W], b2[4 * W];
     const uint4 *t1 = packed1 + (size_t)tile * NCH * 64 + lane;
     const uint4 *t2 = packed2 + (size_t)tile * NCH * 64 + lane;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const uint4 a = t1[(size_t)c * 64], b = t2[(size_t)c * 64];
-        P.s1[4 * c] = a.x; P.s1[4 * c + 1] = a.y; P.s1[4 * c + 2] = a.z; P.s1[4 * c + 3] = a.w;
-        P.s2[4 * c] = b.x; P.s2[4 * c + 1] = b.y; P.s2[4 * c + 2] = b.z; P.s2[4 * c + 3] = b.w;
+        b1[4 * c] = a.x; b1[4 * c + 1] = a.y; b1[4 * c + 2] = a.z; b1[4 * c + 3] = a.w;
+        b2[4 * c] = b.x; b2[4 * c + 1] = b.y; b2[4 * c + 2] = b.z; b2[4 * c + 3] = b.w;
     }
+    PairState<W> P;
+    pair_init<W>(P, ip, len1, len2, b1, b2);
     const int jmax = wave_max_i32_ins(P.L);
-    InsertSweep<D, 0>::run(P, ip, jmax);
+    sweep_unordered<W>(P, ip, jmax, (const uint32_t *)t1, (const uint32_t *)t2, 64 * 4);
+    // "stop after 100 hits" depends on the order of the hits: redo such (low-complexity) pairs
+    // in the reference's order; the other lanes of the wave get the same result again
+    if (__any(!unordered_is_exact<W>(P))) sweep_ordered<W>(P, ip, jmax);
     if (live) {
         uint32_t rec[12];
-        pair_result<D>(P, ip, rec);
+        pair_result<W>(P, ip, rec);
         uint4 *o = out + 3 * r;
         o[0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
         o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);

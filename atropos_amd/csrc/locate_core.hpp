@@ -379,5 +379,37 @@ ATR_DEV uint32_t pack_word(const uint8_t *row, int j0, int n, const uint8_t *tab
     return w;
 }
 
+// ---- plane64 packing (insert aligner) ---------------------------------------------------
+// Same tiles and chunk addresses as tile64, but the 16 bytes of a chunk are FOUR BIT PLANES of
+// its 32 bases: word p, bit b = bit p of the 4-bit code of base 32c + b.  The insert kernel
+// compares reads 32 bases per boolean op in this form (insert_core.hpp).
+// spread[c]: the code of byte c with bit p moved to bit 8p (one plane per byte).
+ATR_DEV uint32_t spread_code(uint32_t code) {
+    return (code & 1u) | ((code & 2u) << 7) | ((code & 4u) << 14) | ((code & 8u) << 21);
+}
+
+// The four plane words of the 32 bases starting at j0 (bases >= n read as code 0).
+ATR_DEV void pack_planes_chunk(const uint8_t *row, int j0, int n, const uint32_t *spread, bool &zero_seen, uint32_t out[4]) {
+    uint32_t acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int j = j0 + 8 * g + b;
+            if (j < n) {
+                const uint32_t sp = spread[row[j]];
+                zero_seen = zero_seen || sp == 0;
+                a |= sp << b;                                  // byte p of a: plane-p bits of bases 8g .. 8g+7
+            }
+        }
+        acc[g] = a;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        out[p] = ((acc[0] >> (8 * p)) & 0xFFu) | (((acc[1] >> (8 * p)) & 0xFFu) << 8) |
+                 (((acc[2] >> (8 * p)) & 0xFFu) << 16) | (((acc[3] >> (8 * p)) & 0xFFu) << 24);
+}
+
 }  // namespace atr
 #endif

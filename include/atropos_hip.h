@@ -97,6 +97,13 @@ int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_
                    const int32_t *d_starts, int64_t nreads, int max_len, const uint8_t table[256],
                    uint8_t *d_packed, int32_t *d_invalid, void *stream);
 
+/* Same arguments, same tiles and chunk addresses, but each 16-byte chunk holds the FOUR BIT
+ * PLANES of its 32 bases (word p, bit b = bit p of the code of base 32c + b): the layout the
+ * insert aligner consumes (atr_insert_match_batch), which compares 32 bases per boolean op. */
+int atr_pack_planes(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
+                   const int32_t *d_starts, int64_t nreads, int max_len, const uint8_t table[256],
+                   uint8_t *d_packed, int32_t *d_invalid, void *stream);
+
 /* ---- Aligner (atropos/align/_align.pyx:121-494) -------------------------- */
 
 /* Aligner.__cinit__(reference, max_error_rate, flags, wildcard_ref,

@@ -100,13 +100,15 @@ class EmuBackend(object):
     def packed_bytes(self, nreads, max_len):
         return self.lib.emu_packed_bytes(nreads, max_len)
 
-    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False, starts=None):
+    def pack_reads(self, ascii_2d, lens, max_len, table, count_invalid=False, starts=None, planes=False):
         nreads = ascii_2d.shape[0]
         packed = torch.zeros((max(self.packed_bytes(nreads, max_len), 16),), dtype=torch.uint8)
         invalid = torch.zeros((1,), dtype=torch.int32) if count_invalid else None
         if nreads and max_len:
-            _check(self.lib.emu_pack_reads(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts), nreads,
-                                           max_len, table, _ptr(packed), _ptr(invalid)), "emu_pack_reads")
+            fn = self.lib.emu_pack_planes if planes else self.lib.emu_pack_reads
+            fn.argtypes = self.lib.emu_pack_reads.argtypes
+            _check(fn(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts), nreads,
+                      max_len, table, _ptr(packed), _ptr(invalid)), "emu_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 
     def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,

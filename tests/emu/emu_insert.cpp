@@ -17,7 +17,7 @@ namespace {
 template <int NCH>
 void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int32_t *l1, const uint32_t *p2,
                       const int32_t *l2, long long npairs, int max_len, uint32_t *out) {
-    constexpr int D = 4 * NCH;
+    constexpr int W = NCH;
     const long long ntiles = (npairs + 63) / 64;
     for (long long tile = 0; tile < ntiles; ++tile) {
         int jmax = 0;
@@ -28,15 +28,18 @@ void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int
         for (int lane = 0; lane < 64; ++lane) {
             const long long r = tile * 64 + lane;
             if (r >= npairs) continue;
-            PairState<D> P;
-            pair_init<D>(P, a->p, l1 ? l1[r] : max_len, l2 ? l2[r] : max_len);
+            uint32_t b1[4 * W], b2[4 * W];
             for (int c = 0; c < NCH; ++c)
                 for (int d = 0; d < 4; ++d) {
-                    P.s1[4 * c + d] = p1[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
-                    P.s2[4 * c + d] = p2[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
+                    b1[4 * c + d] = p1[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
+                    b2[4 * c + d] = p2[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
                 }
-            InsertSweep<D, 0>::run(P, a->p, jmax);
-            pair_result<D>(P, a->p, out + 12 * r);
+            PairState<W> P;
+            pair_init<W>(P, a->p, l1 ? l1[r] : max_len, l2 ? l2[r] : max_len, b1, b2);
+            sweep_unordered<W>(P, a->p, jmax, p1 + (((size_t)tile * NCH) * 64 + lane) * 4,
+                               p2 + (((size_t)tile * NCH) * 64 + lane) * 4, 64 * 4);
+            if (!unordered_is_exact<W>(P)) sweep_ordered<W>(P, a->p, jmax);
+            pair_result<W>(P, a->p, out + 12 * r);
         }
     }
 }

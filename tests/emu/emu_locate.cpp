@@ -195,6 +195,28 @@ int emu_pack_reads(const uint8_t *ascii, int64_t row_stride, const int32_t *lens
     return ATR_OK;
 }
 
+// atr_pack_planes: plane64 layout (bit planes of the codes, 32 bases per 16-byte chunk)
+int emu_pack_planes(const uint8_t *ascii, int64_t row_stride, const int32_t *lens, const int32_t *starts,
+                    int64_t nreads, int max_len, const uint8_t table[256], uint8_t *packed, int32_t *invalid) {
+    const int nchunks = (max_len + 31) / 32;
+    const long long ntiles = (nreads + 63) / 64;
+    uint32_t *dst = (uint32_t *)packed;
+    uint32_t spread[256];
+    for (int c = 0; c < 256; ++c) spread[c] = spread_code((uint32_t)table[c] & 15u);
+    for (long long tile = 0; tile < ntiles; ++tile)
+        for (int lane = 0; lane < 64; ++lane) {
+            const long long r = tile * 64 + lane;
+            const int start = (r < nreads && starts) ? starts[r] : 0;
+            const int n = (r < nreads) ? std::max(0, std::min((lens ? lens[r] : max_len) - start, max_len)) : 0;
+            const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride + start;
+            bool zero_seen = false;
+            for (int c = 0; c < nchunks; ++c)
+                pack_planes_chunk(row, c * 32, n, spread, zero_seen, dst + (((size_t)tile * nchunks + c) * 64 + lane) * 4);
+            if (invalid && zero_seen) *invalid += 1;
+        }
+    return ATR_OK;
+}
+
 int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t *lens, int64_t nreads,
                      int max_len, int16_t *out, int filtered) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
