@@ -165,8 +165,8 @@ int atr_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner *
 void atr_insert_aligner_destroy(atr_insert_aligner *a);
 
 /* InsertAligner.match_insert(seq1, seq2) for a batch (align/__init__.py:250-377).
- * Both read sets are tile64 buffers packed with ATR_TABLE_DNA15 and the same max_len
- * (<= ATR_INSERT_MAX_READ).  d_out receives THREE records per pair:
+ * Both read sets are PLANE64 buffers (atr_pack_planes) packed with ATR_TABLE_DNA15 and the
+ * same max_len (<= ATR_INSERT_MAX_READ).  d_out receives THREE records per pair:
  *   d_out[3p+0] = the insert match tuple (refstop == -1: match_insert returns None),
  *   d_out[3p+1] = Match 1 as (astart, astop, rstart, rstop, matches, errors), astop == -1: None,
  *   d_out[3p+2] = Match 2, likewise. */
