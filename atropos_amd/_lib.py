@@ -83,7 +83,11 @@ PROTOTYPES = {
     "atr_fastq_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "atr_pack_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
-                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_pair_filter_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_insert_plan_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_clip_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "atr_quality_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]),
@@ -93,7 +97,7 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_int64, C.c_void_p]),
     "atr_read_filter_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_fastq_emit_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_fastq_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -328,7 +332,7 @@ class HipBackend(object):
             err = int(info[1].item())
         return records, line_ends, nlines, err
 
-    def pack_records(self, data, records, begin, end, max_len, table, count_invalid=False):
+    def pack_records(self, data, records, begin, end, max_len, table, count_invalid=False, planes=False):
         n = records.shape[0]
         packed = self.empty((max(self.packed_bytes(n, max_len), 16),), torch.uint8)
         lens = self.empty((n,), torch.int32)
@@ -336,7 +340,7 @@ class HipBackend(object):
         if n:
             with torch.cuda.device(self.device):
                 _check(self.lib, self.lib.atr_pack_records(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), n, max_len,
-                                                           table, _ptr(packed), _ptr(lens), _ptr(invalid),
+                                                           table, int(planes), _ptr(packed), _ptr(lens), _ptr(invalid),
                                                            self._stream()), "atr_pack_records")
         return (packed, lens, int(invalid.item())) if count_invalid else (packed, lens)
 
@@ -364,14 +368,33 @@ class HipBackend(object):
                                                            self._stream()), "atr_match_trim_batch")
 
     def read_filter_batch(self, data, records, begin, end, ubegin, uend, matched, min_len, max_len, max_n,
-                          discard_trimmed, discard_untrimmed):
-        dest = self.empty((begin.shape[0],), torch.uint8)
+                          discard_trimmed, discard_untrimmed, masks=False):
+        """The destination byte per read, or (masks=True) the bit mask of the filters that fire."""
+        out = self.empty((begin.shape[0],), torch.uint8)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_read_filter_batch(
                 _ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend), _ptr(matched),
-                begin.shape[0], min_len, max_len, max_n, int(discard_trimmed), int(discard_untrimmed), _ptr(dest),
-                self._stream()), "atr_read_filter_batch")
+                begin.shape[0], min_len, max_len, max_n, int(discard_trimmed), int(discard_untrimmed),
+                None if masks else _ptr(out), _ptr(out) if masks else None, self._stream()), "atr_read_filter_batch")
+        return out
+
+    def pair_filter_batch(self, mask1, mask2, min_affected):
+        dest = self.empty((mask1.shape[0],), torch.uint8)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_pair_filter_batch(_ptr(mask1), _ptr(mask2), mask1.shape[0], min_affected,
+                                                            _ptr(dest), self._stream()), "atr_pair_filter_batch")
         return dest
+
+    def insert_plan_batch(self, insert, fb1, fb2, begin1, end1, begin2, end2, uend1, uend2, min_insert_len, symmetric,
+                          trim_action):
+        n = begin1.shape[0]
+        m1, m2 = self.empty((n,), torch.uint8), self.empty((n,), torch.uint8)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_insert_plan_batch(
+                _ptr(insert), _ptr(fb1), _ptr(fb2), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), _ptr(uend1),
+                _ptr(uend2), n, min_insert_len, int(symmetric), trim_action, _ptr(m1), _ptr(m2), self._stream()),
+                "atr_insert_plan_batch")
+        return m1, m2
 
     def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
         """Formatted FASTQ text (uint8 device tensor) of the records with dest == which."""

@@ -190,13 +190,13 @@ ATR_DEV void py_clip(int len, int begin, int end_or_neg, bool has_end, int &a, i
     if (b < a) b = a;
 }
 
-// The destination of a read after all modifiers (commands/trim/filters.py:109-184, in the
-// order trim/__init__.py:566-601 adds them): the first filter that fires wins.
-//   too short, too long, too many N, discard-trimmed, (then) discard-untrimmed.
-ATR_DEV int read_filter_one(const uint8_t *seq, int len, int ub, int ue, bool matched, int min_len, int max_len,
-                            double max_n, int discard_trimmed, int discard_untrimmed) {
-    if (min_len > 0 && len < min_len) return ATR_DEST_TOO_SHORT;
-    if (max_len >= 0 && len > max_len) return ATR_DEST_TOO_LONG;
+// Which filters fire for a read after all modifiers (commands/trim/filters.py:109-184):
+// bit d of the result is set when the filter with destination code d (ATR_DEST_*) fires.
+ATR_DEV uint32_t read_filter_mask(const uint8_t *seq, int len, int ub, int ue, bool matched, int min_len, int max_len,
+                                  double max_n, int discard_trimmed, int discard_untrimmed) {
+    uint32_t mask = 0;
+    if (min_len > 0 && len < min_len) mask |= 1u << ATR_DEST_TOO_SHORT;
+    if (max_len >= 0 && len > max_len) mask |= 1u << ATR_DEST_TOO_LONG;
     if (max_n >= 0.0) {
         int n_count = 0;
         for (int i = 0; i < len; ++i) {
@@ -204,14 +204,56 @@ ATR_DEV int read_filter_one(const uint8_t *seq, int len, int ub, int ue, bool ma
             n_count += (c == 'N' || c == 'n') ? 1 : 0;
         }
         if (max_n < 1.0) {
-            if (len != 0 && (double)n_count / (double)len > max_n) return ATR_DEST_TOO_MANY_N;
+            if (len != 0 && (double)n_count / (double)len > max_n) mask |= 1u << ATR_DEST_TOO_MANY_N;
         } else if ((double)n_count > max_n) {
-            return ATR_DEST_TOO_MANY_N;
+            mask |= 1u << ATR_DEST_TOO_MANY_N;
         }
     }
-    if (discard_trimmed && matched) return ATR_DEST_TRIMMED;
-    if (discard_untrimmed && !matched) return ATR_DEST_UNTRIMMED;
+    if (discard_trimmed && matched) mask |= 1u << ATR_DEST_TRIMMED;
+    if (discard_untrimmed && !matched) mask |= 1u << ATR_DEST_UNTRIMMED;
+    return mask;
+}
+
+// The destination: the first filter that fires, in the order trim/__init__.py:566-601 installs
+// them (too short, too long, too many N, discard-trimmed, then discard-untrimmed).  For pairs
+// (PairedWrapper, filters.py:66-90) a filter fires when it fires for at least min_affected of
+// the two reads.
+ATR_DEV int filter_destination(uint32_t mask1, uint32_t mask2, bool paired, int min_affected) {
+    for (int d = ATR_DEST_TOO_SHORT; d <= ATR_DEST_UNTRIMMED; ++d) {
+        const int f = (int)((mask1 >> d) & 1u) + (paired ? (int)((mask2 >> d) & 1u) : 0);
+        if (f >= (paired ? min_affected : 1)) return d;
+    }
     return ATR_DEST_KEEP;
+}
+
+ATR_DEV int read_filter_one(const uint8_t *seq, int len, int ub, int ue, bool matched, int min_len, int max_len,
+                            double max_n, int discard_trimmed, int discard_untrimmed) {
+    return filter_destination(read_filter_mask(seq, len, ub, ue, matched, min_len, max_len, max_n, discard_trimmed,
+                                               discard_untrimmed), 0u, false, 1);
+}
+
+// InsertAdapterCutter.__call__ after the alignments (commands/trim/modifiers.py:391-496),
+// without error correction: pick the adapter matches (from the insert match, else the two
+// adapters' own semi-global matches), mirror a lone match onto the other read (`symmetric`,
+// :419-446) and trim (`trim`, :455-496).  ins: the three records of atr_insert_match_batch for
+// this pair; fb1/fb2: Adapter.match_to records of the two reads.  len1/len2: current read
+// lengths.  Returns the new lengths in cut1/cut2 (== len: untouched) and the `read.match is
+// not None` flags.
+ATR_DEV void insert_plan_one(const int16_t *ins, const int16_t *fb1, const int16_t *fb2, int len1, int len2,
+                             int min_insert_len, int symmetric, int trim_action, int &cut1, int &cut2, bool &matched1,
+                             bool &matched2) {
+    cut1 = len1; cut2 = len2; matched1 = matched2 = false;
+    if (len1 < min_insert_len || len2 < min_insert_len) return;          // :392-394
+    const bool has_insert = ins[1] >= 0;
+    const int16_t *m1 = has_insert ? ins + 8 : fb1, *m2 = has_insert ? ins + 16 : fb2;
+    bool h1 = m1[1] >= 0, h2 = m2[1] >= 0;
+    int rstart1 = m1[2], rstart2 = m2[2];
+    if (symmetric && (h1 != h2)) {                                        // :419-437
+        if (h1) { if (rstart1 <= len2) { h2 = true; rstart2 = rstart1; } }
+        else if (rstart2 <= len1) { h1 = true; rstart1 = rstart2; }
+    }
+    if (h1) { matched1 = true; if (trim_action && rstart1 < len1) cut1 = rstart1; }     // :455-496 (rstart >= len: no trim)
+    if (h2) { matched2 = true; if (trim_action && rstart2 < len2) cut2 = rstart2; }
 }
 
 // Bytes of a formatted record (io/seqio.py:690-699): '@' name '\n' seq '\n+' name2 '\n' qual '\n'

@@ -195,13 +195,18 @@ __device__ __forceinline__ void glds_dword(const uint8_t *gsrc, uint32_t *lds_ds
                                      (__attribute__((address_space(3))) void *)lds_dst_wave_uniform, 4, 0, 0);
 }
 
+template <bool PLANES>
 __global__ void pack_records_kernel(
     const uint8_t *__restrict__ bytes, const FastqRecord *__restrict__ records, const int32_t *__restrict__ begin,
     const int32_t *__restrict__ end, long long nreads, int max_len, int nchunks, int stride_dw, const PackTable256 tab,
     uint4 *__restrict__ packed, int32_t *__restrict__ lens, int32_t *__restrict__ invalid) {
     __shared__ uint8_t s_tab[256];
+    __shared__ uint32_t s_spread[PLANES ? 256 : 1];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_rows[];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_tab[i] = tab.t[i];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        s_tab[i] = tab.t[i];
+        if (PLANES) s_spread[i] = spread_code((uint32_t)tab.t[i] & 15u);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
     const long long tile = (long long)blockIdx.x * waves + wave;
@@ -234,6 +239,16 @@ __global__ void pack_records_kernel(
     const uint32_t *p = rows + (size_t)lane * stride_dw;
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;
+    if (PLANES) {                                               // plane64: byte reads of the lane's LDS row
+        const uint8_t *row = (const uint8_t *)p + sh;
+        for (int c = 0; c < nchunks; ++c) {
+            uint32_t pl[4];
+            pack_planes_chunk(row, c * 32, n, s_spread, zero_seen, pl);
+            dst[(size_t)c * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+        if (invalid && zero_seen) atomicAdd(invalid, 1);
+        return;
+    }
     uint32_t prev = nd > 0 ? p[0] : 0u;
     int t = 0;                                                  // prev == p[t]
     for (int c = 0; c < nchunks; ++c) {
@@ -342,14 +357,51 @@ __global__ __launch_bounds__(256) void read_filter_kernel(const uint8_t *__restr
                                                           const int32_t *__restrict__ uend,
                                                           const uint8_t *__restrict__ matched, long long n, int min_len,
                                                           int max_len, double max_n, int discard_trimmed,
-                                                          int discard_untrimmed, uint8_t *__restrict__ dest) {
+                                                          int discard_untrimmed, uint8_t *__restrict__ dest,
+                                                          uint8_t *__restrict__ fail_mask) {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const FastqRecord rec = records[r];
     const int a = begin[r], b = max(a, end[r]);
     const int ub = ubegin ? ubegin[r] - a : 0, ue = uend ? uend[r] - a : b - a;
-    dest[r] = (uint8_t)read_filter_one(bytes + rec.seq_off + a, b - a, ub, ue, matched ? matched[r] != 0 : false,
-                                       min_len, max_len, max_n, discard_trimmed, discard_untrimmed);
+    const uint32_t mask = read_filter_mask(bytes + rec.seq_off + a, b - a, ub, ue, matched ? matched[r] != 0 : false,
+                                           min_len, max_len, max_n, discard_trimmed, discard_untrimmed);
+    if (dest) dest[r] = (uint8_t)filter_destination(mask, 0u, false, 1);
+    if (fail_mask) fail_mask[r] = (uint8_t)mask;
+}
+
+__global__ __launch_bounds__(256) void pair_filter_kernel(const uint8_t *__restrict__ mask1,
+                                                          const uint8_t *__restrict__ mask2, long long n,
+                                                          int min_affected, uint8_t *__restrict__ dest) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    dest[r] = (uint8_t)filter_destination(mask1[r], mask2[r], true, min_affected);
+}
+
+__global__ __launch_bounds__(256) void insert_plan_kernel(const int16_t *__restrict__ ins, const int16_t *__restrict__ fb1,
+                                                          const int16_t *__restrict__ fb2, int32_t *__restrict__ begin1,
+                                                          int32_t *__restrict__ end1, int32_t *__restrict__ begin2,
+                                                          int32_t *__restrict__ end2, int32_t *__restrict__ uend1,
+                                                          int32_t *__restrict__ uend2, long long n, int min_insert_len,
+                                                          int symmetric, int trim_action, uint8_t *__restrict__ matched1,
+                                                          uint8_t *__restrict__ matched2) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int a1 = begin1[r], a2 = begin2[r];
+    const int len1 = max(0, end1[r] - a1), len2 = max(0, end2[r] - a2);
+    int cut1, cut2;
+    bool m1, m2;
+    insert_plan_one(ins + 24 * r, fb1 + 8 * r, fb2 + 8 * r, len1, len2, min_insert_len, symmetric, trim_action, cut1,
+                    cut2, m1, m2);
+    if (trim_action == 2) {                                            // mask: keep the length, remember the cut
+        uend1[r] = a1 + cut1;
+        uend2[r] = a2 + cut2;
+    } else {
+        end1[r] = a1 + cut1;
+        end2[r] = a2 + cut2;
+    }
+    matched1[r] = m1 ? 1 : 0;
+    matched2[r] = m2 ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------- formatter
@@ -650,7 +702,7 @@ int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, int strip, const voi
 }
 
 int atr_pack_records(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
-                     const int32_t *d_end, int64_t nreads, int max_len, const uint8_t table[256],
+                     const int32_t *d_end, int64_t nreads, int max_len, const uint8_t table[256], int planes,
                      uint8_t *d_packed, int32_t *d_lens, int32_t *d_invalid, void *stream) {
     if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
@@ -662,9 +714,14 @@ int atr_pack_records(const uint8_t *d_bytes, const atr_fastq_record *d_records, 
     const int stride_dw = ((max_len + 6) / 4) | 1;              // dwords per LDS row (odd)
     const size_t per_wave = (size_t)64 * stride_dw * 4;
     const int waves = per_wave * 4 <= 65536 - 256 ? 4 : (per_wave * 2 <= 65536 - 256 ? 2 : 1);
-    hipLaunchKernelGGL(pack_records_kernel, dim3((unsigned)((ntiles + waves - 1) / waves)), dim3(64 * waves),
-                       per_wave * waves, (hipStream_t)stream, d_bytes, (const FastqRecord *)d_records, d_begin, d_end,
-                       (long long)nreads, max_len, nchunks, stride_dw, tab, (uint4 *)d_packed, d_lens, d_invalid);
+    if (planes)
+        hipLaunchKernelGGL(pack_records_kernel<true>, dim3((unsigned)((ntiles + waves - 1) / waves)), dim3(64 * waves),
+                           per_wave * waves, (hipStream_t)stream, d_bytes, (const FastqRecord *)d_records, d_begin, d_end,
+                           (long long)nreads, max_len, nchunks, stride_dw, tab, (uint4 *)d_packed, d_lens, d_invalid);
+    else
+        hipLaunchKernelGGL(pack_records_kernel<false>, dim3((unsigned)((ntiles + waves - 1) / waves)), dim3(64 * waves),
+                           per_wave * waves, (hipStream_t)stream, d_bytes, (const FastqRecord *)d_records, d_begin, d_end,
+                           (long long)nreads, max_len, nchunks, stride_dw, tab, (uint4 *)d_packed, d_lens, d_invalid);
     return launched("pack_records_kernel launch");
 }
 
@@ -713,14 +770,41 @@ int atr_match_trim_batch(const atr_result *d_matches, const uint8_t *d_front, in
 int atr_read_filter_batch(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
                           const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
                           const uint8_t *d_matched, int64_t n, int min_len, int max_len, double max_n,
-                          int discard_trimmed, int discard_untrimmed, uint8_t *d_dest, void *stream) {
+                          int discard_trimmed, int discard_untrimmed, uint8_t *d_dest, uint8_t *d_fail_mask,
+                          void *stream) {
     if (n < 0 || ((d_unmasked_begin == nullptr) != (d_unmasked_end == nullptr))) return ATR_ERR_INVALID;
     if (n == 0) return ATR_OK;
-    if (!d_bytes || !d_records || !d_begin || !d_end || !d_dest) return ATR_ERR_INVALID;
+    if (!d_bytes || !d_records || !d_begin || !d_end || (!d_dest && !d_fail_mask)) return ATR_ERR_INVALID;
     hipLaunchKernelGGL(read_filter_kernel, dim3(grid256(n)), dim3(256), 0, (hipStream_t)stream, d_bytes,
                        (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_matched,
-                       (long long)n, min_len, max_len, max_n, discard_trimmed, discard_untrimmed, d_dest);
+                       (long long)n, min_len, max_len, max_n, discard_trimmed, discard_untrimmed, d_dest, d_fail_mask);
     return launched("read_filter_kernel launch");
+}
+
+int atr_pair_filter_batch(const uint8_t *d_fail_mask1, const uint8_t *d_fail_mask2, int64_t n, int min_affected,
+                          uint8_t *d_dest, void *stream) {
+    if (n < 0 || (min_affected != 1 && min_affected != 2)) return ATR_ERR_INVALID;
+    if (n == 0) return ATR_OK;
+    if (!d_fail_mask1 || !d_fail_mask2 || !d_dest) return ATR_ERR_INVALID;
+    hipLaunchKernelGGL(pair_filter_kernel, dim3(grid256(n)), dim3(256), 0, (hipStream_t)stream, d_fail_mask1, d_fail_mask2,
+                       (long long)n, min_affected, d_dest);
+    return launched("pair_filter_kernel launch");
+}
+
+int atr_insert_plan_batch(const atr_result *d_insert, const atr_result *d_fallback1, const atr_result *d_fallback2,
+                          int32_t *d_begin1, int32_t *d_end1, int32_t *d_begin2, int32_t *d_end2,
+                          int32_t *d_unmasked_end1, int32_t *d_unmasked_end2, int64_t n, int min_insert_len,
+                          int symmetric, int trim_action, uint8_t *d_matched1, uint8_t *d_matched2, void *stream) {
+    if (n < 0 || trim_action < 0 || trim_action > 2) return ATR_ERR_INVALID;
+    if (n == 0) return ATR_OK;
+    if (!d_insert || !d_fallback1 || !d_fallback2 || !d_begin1 || !d_end1 || !d_begin2 || !d_end2 || !d_matched1 ||
+        !d_matched2 || (trim_action == 2 && (!d_unmasked_end1 || !d_unmasked_end2)))
+        return ATR_ERR_INVALID;
+    hipLaunchKernelGGL(insert_plan_kernel, dim3(grid256(n)), dim3(256), 0, (hipStream_t)stream, (const int16_t *)d_insert,
+                       (const int16_t *)d_fallback1, (const int16_t *)d_fallback2, d_begin1, d_end1, d_begin2, d_end2,
+                       d_unmasked_end1, d_unmasked_end2, (long long)n, min_insert_len, symmetric, trim_action, d_matched1,
+                       d_matched2);
+    return launched("insert_plan_kernel launch");
 }
 
 // work layout: [sizes u32 x n][sums u64 x scan_blocks(n)]

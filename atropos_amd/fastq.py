@@ -166,5 +166,21 @@ class RecordSource(object):
             self._batches[key] = ReadBatch(packed, lens, self.n, max_len, table_kind, table)
         return self._batches[key]
 
+    def planes(self, max_len, table_kind, table, check=False):
+        """plane64 pack (insert aligner) of the kept intervals with a given max_len; no case
+        folding (InsertAligner compares the reads as they are).  check: every base must have a code."""
+        from .batch import ReadBatch
+        be = self.fq.backend
+        if check:
+            packed, lens, bad = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(table),
+                                                count_invalid=True, planes=True)
+            if bad:
+                raise ValueError("%d read(s) contain bases without an upper-case IUPAC code; the device insert "
+                                 "aligner cannot reverse-complement them" % bad)
+        else:
+            packed, lens = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(table),
+                                           planes=True)
+        return ReadBatch(packed, lens, self.n, max_len, table_kind, table, layout="plane64")
+
     def ascii(self):
         raise NotImplementedError("anchored adapters without indels are not supported by the device FASTQ pipeline")

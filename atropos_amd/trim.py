@@ -159,32 +159,43 @@ class TrimPipeline(object):
         return matched, ubegin, uend
 
     # ------------------------------------------------------------------ whole pipeline
+    def _simple_stage(self, op, batch, begin, end):
+        """The C, G, Q stages (interval updates without alignment)."""
+        be = batch.backend
+        if op == "C" and (self.cut_front or self.cut_back):
+            be.clip_batch(batch.records, begin, end, self.cut_front, self.cut_back)
+        elif op == "G" and self.nextseq_trim is not None:
+            be.quality_trim_batch(batch.data, batch.records, begin, end, 0, int(self.nextseq_trim),
+                                  self.quality_base, True)
+        elif op == "Q" and self.quality_cutoff:
+            be.quality_trim_batch(batch.data, batch.records, begin, end, int(self.quality_cutoff[0]),
+                                  int(self.quality_cutoff[1]), self.quality_base, False)
+
+    def _filter_stage(self, batch, begin, end, ubegin, uend, matched, masks=False):
+        """--trim-n, then the read filters: destination byte per read (or the fail masks)."""
+        be = batch.backend
+        if self.trim_n:
+            be.nend_trim_batch(batch.data, batch.records, begin, end, ubegin, uend)
+        min_len = self.minimum_length if self.minimum_length is not None and self.minimum_length > 0 else 0
+        max_len = self.maximum_length if self.maximum_length is not None else -1
+        max_n = float(self.max_n) if self.max_n is not None else -1.0
+        return be.read_filter_batch(batch.data, batch.records, begin, end, ubegin, uend, matched, min_len, max_len,
+                                    max_n, self.discard_trimmed, self.discard_untrimmed, masks=masks)
+
     def run(self, batch):
         """All stages over one FastqBatch; returns a TrimResult."""
-        be = batch.backend
         n = len(batch)
         begin = torch.zeros((n,), dtype=torch.int32, device=batch.records.device)
         end = batch.seq_lens.clone()
         matched = torch.zeros((n,), dtype=torch.uint8, device=begin.device)
         ubegin = uend = None
         for op in self.op_order:
-            if op == "C" and (self.cut_front or self.cut_back):
-                be.clip_batch(batch.records, begin, end, self.cut_front, self.cut_back)
-            elif op == "G" and self.nextseq_trim is not None:
-                be.quality_trim_batch(batch.data, batch.records, begin, end, 0, int(self.nextseq_trim),
-                                      self.quality_base, True)
-            elif op == "Q" and self.quality_cutoff:
-                be.quality_trim_batch(batch.data, batch.records, begin, end, int(self.quality_cutoff[0]),
-                                      int(self.quality_cutoff[1]), self.quality_base, False)
-            elif op == "A" and self.adapters:
-                matched, ubegin, uend = self._adapter_stage(batch, begin, end)
-        if self.trim_n:
-            be.nend_trim_batch(batch.data, batch.records, begin, end, ubegin, uend)
-        min_len = self.minimum_length if self.minimum_length is not None and self.minimum_length > 0 else 0
-        max_len = self.maximum_length if self.maximum_length is not None else -1
-        max_n = float(self.max_n) if self.max_n is not None else -1.0
-        dest = be.read_filter_batch(batch.data, batch.records, begin, end, ubegin, uend, matched, min_len, max_len,
-                                    max_n, self.discard_trimmed, self.discard_untrimmed)
+            if op == "A":
+                if self.adapters:
+                    matched, ubegin, uend = self._adapter_stage(batch, begin, end)
+            else:
+                self._simple_stage(op, batch, begin, end)
+        dest = self._filter_stage(batch, begin, end, ubegin, uend, matched)
         return TrimResult(batch, begin, end, ubegin, uend, matched, dest)
 
     def trim_bytes(self, data, which=_lib.DEST_KEEP):
@@ -217,10 +228,120 @@ class TrimPipeline(object):
         return totals
 
 
+class PairedTrimResult(object):
+    """Result of the paired-end pipeline: one TrimResult per read, sharing the destination."""
+
+    def __init__(self, res1, res2):
+        self.read1, self.read2, self.dest = res1, res2, res1.dest
+
+    def counts(self):
+        return self.read1.counts()
+
+    def text(self, which=_lib.DEST_KEEP):
+        return self.read1.text(which), self.read2.text(which)
+
+
+class PairedTrimPipeline(object):
+    """Paired-end trimming in "both" mode (both reads are modified; trim/cli.py:633-648) as
+    whole-batch device stages.  ``aligner``: 'adapter' -- one AdapterCutter per read
+    (``adapters1`` / ``adapters2``), or 'insert' -- InsertAdapterCutter with exactly one 3'
+    adapter per read (trim/__init__.py:406-456).  ``pair_filter``: 'any' or 'both'.
+    Error correction and merging are not part of the device pipeline (they rewrite bases)."""
+
+    def __init__(self, adapters1=(), adapters2=(), aligner="adapter", times=1, action="trim", cut=(), cut2=(),
+                 nextseq_trim=None, quality_cutoff=None, quality_base=33, trim_n=False, minimum_length=None,
+                 maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
+                 op_order="CGQAW", insert_args=None):
+        common = dict(times=times, action=action, nextseq_trim=nextseq_trim, quality_cutoff=quality_cutoff,
+                      quality_base=quality_base, trim_n=trim_n, minimum_length=minimum_length,
+                      maximum_length=maximum_length, max_n=max_n, discard_trimmed=discard_trimmed,
+                      discard_untrimmed=discard_untrimmed, op_order=op_order)
+        self.p1 = TrimPipeline(adapters=adapters1, cut=cut, **common)
+        self.p2 = TrimPipeline(adapters=adapters2, cut=cut2, **common)
+        self.aligner, self.action, self.op_order = aligner, action, op_order
+        if pair_filter not in ("any", "both"):
+            raise ValueError("pair_filter must be 'any' or 'both'")
+        self.min_affected = 2 if pair_filter == "both" else 1            # trim/__init__.py:549
+        self.insert = None
+        if aligner == "insert":
+            from .adapters import BACK
+            from .align import InsertAligner
+            if len(self.p1.adapters) != 1 or len(self.p2.adapters) != 1 or any(
+                    isinstance(a, LinkedAdapter) or a.where != BACK for a in self.p1.adapters + self.p2.adapters):
+                raise ValueError("Insert aligner requires a single 3' adapter for each read")   # trim/__init__.py:406-411
+            self.insert = InsertAligner(self.p1.adapters[0].sequence, self.p2.adapters[0].sequence, **(insert_args or {}))
+        elif aligner != "adapter":
+            raise ValueError("aligner must be 'adapter' or 'insert'")
+
+    def _insert_stage(self, b1, b2, st1, st2):
+        """InsertAdapterCutter over the batch (commands/trim/modifiers.py:391-496, no error correction)."""
+        be = b1.backend
+        n = len(b1)
+        src1, src2 = RecordSource(b1, st1[0], st1[1]), RecordSource(b2, st2[0], st2[1])
+        max_len = 0
+        if n:
+            max_len = int(torch.maximum((st1[1] - st1[0]).max(), (st2[1] - st2[0]).max()).clamp_(min=0).item())
+        if max_len > _lib.INSERT_MAX_READ:
+            raise _lib.AtroposHipError("InsertAligner: reads longer than %d bases are outside the device envelope"
+                                       % _lib.INSERT_MAX_READ)
+        table = be.translate_table(_lib.TABLE_DNA15)
+        pb1 = src1.planes(max_len, _lib.TABLE_DNA15, table)
+        pb2 = src2.planes(max_len, _lib.TABLE_DNA15, table, check=True)
+        ins = self.insert.match_insert_batch(pb1, pb2).records
+        fb1 = self.p1.adapters[0].match_source(src1)                       # semi-global fallback (modifiers.py:405-407)
+        fb2 = self.p2.adapters[0].match_source(src2)
+        action = {None: 0, "trim": 1, "mask": 2}[self.action]
+        uend1 = uend2 = None
+        if action == 2:
+            uend1, uend2 = st1[1].clone(), st2[1].clone()
+        m1, m2 = be.insert_plan_batch(ins.contiguous(), fb1.contiguous(), fb2.contiguous(), st1[0], st1[1], st2[0], st2[1],
+                                      uend1, uend2, self.insert.min_insert_overlap, True, action)
+        if action == 2:
+            return (m1, st1[0].clone(), uend1), (m2, st2[0].clone(), uend2)
+        return (m1, None, None), (m2, None, None)
+
+    def run(self, batch1, batch2):
+        if len(batch1) != len(batch2):
+            raise ValueError("the two FASTQ batches hold different numbers of records")
+        be = batch1.backend
+        n = len(batch1)
+        dev = batch1.records.device
+        st = []
+        for b in (batch1, batch2):
+            st.append([torch.zeros((n,), dtype=torch.int32, device=dev), b.seq_lens.clone()])
+        extra = [(torch.zeros((n,), dtype=torch.uint8, device=dev), None, None) for _ in range(2)]
+        pipes, batches = (self.p1, self.p2), (batch1, batch2)
+        for op in self.op_order:
+            if op == "A":
+                if self.aligner == "insert":
+                    extra = list(self._insert_stage(batch1, batch2, st[0], st[1]))
+                else:
+                    for k in range(2):
+                        if pipes[k].adapters:
+                            extra[k] = pipes[k]._adapter_stage(batches[k], st[k][0], st[k][1])
+            else:
+                for k in range(2):
+                    pipes[k]._simple_stage(op, batches[k], st[k][0], st[k][1])
+        masks = []
+        for k in range(2):
+            matched, ub, ue = extra[k]
+            masks.append(pipes[k]._filter_stage(batches[k], st[k][0], st[k][1], ub, ue, matched, masks=True))
+        dest = be.pair_filter_batch(masks[0], masks[1], self.min_affected)
+        res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
+        return PairedTrimResult(res[0], res[1])
+
+    def trim_bytes(self, data1, data2, which=_lib.DEST_KEEP):
+        """Two FASTQ texts in (same number of records), the two trimmed texts out."""
+        b1, _ = FastqBatch.from_bytes(data1, final=True)
+        b2, _ = FastqBatch.from_bytes(data2, final=True)
+        return self.run(b1, b2).text(which)
+
+
 def pipeline_from_args(argv):
-    """Build a TrimPipeline from the subset of ``atropos trim`` command-line options the device
-    pipeline covers (same spellings and defaults as trim/cli.py:57-335, :655-803).  Anything
-    else raises -- the caller then uses the per-read object path."""
+    """Build a TrimPipeline (or, when paired-end options are present, a PairedTrimPipeline) from
+    the subset of ``atropos trim`` command-line options the device pipeline covers (same
+    spellings and defaults as trim/cli.py:57-335, :455-530, :655-803).  Anything else raises --
+    the caller then uses the per-read object path."""
     import argparse
     from .adapters import AdapterParser
     if isinstance(argv, str):
@@ -229,6 +350,10 @@ def pipeline_from_args(argv):
     ap.add_argument("-a", "--adapter", action="append", default=[], dest="adapters")
     ap.add_argument("-g", "--front", action="append", default=[])
     ap.add_argument("-b", "--anywhere", action="append", default=[])
+    ap.add_argument("-A", action="append", default=[], dest="adapters2")
+    ap.add_argument("-G", action="append", default=[], dest="front2")
+    ap.add_argument("-B", action="append", default=[], dest="anywhere2")
+    ap.add_argument("--aligner", choices=("adapter", "insert"), default="adapter")
     ap.add_argument("-e", "--error-rate", type=float, default=None)
     ap.add_argument("-O", "--overlap", type=int, default=None)
     ap.add_argument("-n", "--times", type=int, default=1)
@@ -237,10 +362,15 @@ def pipeline_from_args(argv):
     ap.add_argument("--match-read-wildcards", action="store_true", default=False)
     ap.add_argument("--no-indels", action="store_false", dest="indels", default=True)
     ap.add_argument("--indel-cost", type=int, default=None)
+    ap.add_argument("--adapter-max-rmp", type=float, default=None)
+    ap.add_argument("--insert-max-rmp", type=float, default=1E-6)
+    ap.add_argument("--insert-match-error-rate", type=float, default=None)
+    ap.add_argument("--insert-match-adapter-error-rate", type=float, default=None)
     ap.add_argument("--no-trim", action="store_true", default=False)
     ap.add_argument("--mask-adapter", action="store_true", default=False)
     ap.add_argument("--op-order", default="CGQAW")
     ap.add_argument("-u", "--cut", type=int, action="append", default=[])
+    ap.add_argument("-U", type=int, action="append", default=[], dest="cut2")
     ap.add_argument("-q", "--quality-cutoff", default=None)
     ap.add_argument("--quality-base", type=int, default=33)
     ap.add_argument("--nextseq-trim", type=int, default=None)
@@ -250,15 +380,34 @@ def pipeline_from_args(argv):
     ap.add_argument("--max-n", type=float, default=None)
     ap.add_argument("--discard-trimmed", "--discard", action="store_true", default=False)
     ap.add_argument("--discard-untrimmed", "--trimmed-only", action="store_true", default=False)
+    ap.add_argument("--pair-filter", choices=("any", "both"), default=None)
     o = ap.parse_args(argv)
+    paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert")
+    insert_args = None
+    if o.aligner == "adapter":                                            # cli.py:659-666
+        if o.indels and o.indel_cost is None:
+            o.indel_cost = 1
+        if o.overlap is None:
+            o.overlap = 3 if o.adapter_max_rmp is None else 1
+    else:                                                                 # cli.py:667-684
+        if o.indels and o.indel_cost is None:
+            o.indel_cost = 3
+        if o.overlap is None:
+            o.overlap = 1
+            if o.adapter_max_rmp is None:
+                o.adapter_max_rmp = 1E-6
+        if o.insert_match_error_rate is None:
+            o.insert_match_error_rate = o.error_rate or 0.2
+        if o.insert_match_adapter_error_rate is None:
+            o.insert_match_adapter_error_rate = o.insert_match_error_rate
+        insert_args = dict(insert_max_rmp=o.insert_max_rmp, max_insert_mismatch_frac=o.insert_match_error_rate,
+                           max_adapter_mismatch_frac=o.insert_match_adapter_error_rate,
+                           read_wildcards=o.match_read_wildcards, adapter_wildcards=o.match_adapter_wildcards)
     if o.error_rate is None:
         o.error_rate = 0.1                                                # cli.py:801-802
-    if o.indels and o.indel_cost is None:
-        o.indel_cost = 1                                                  # :660-661
-    if o.overlap is None:
-        o.overlap = 3                                                     # :662-666 (no --adapter-max-rmp here)
-    if len(o.cut) > 2 or (len(o.cut) == 2 and o.cut[0] * o.cut[1] > 0):
-        raise ValueError("You cannot remove bases from the same end twice.")
+    for cut in (o.cut, o.cut2):
+        if len(cut) > 2 or (len(cut) == 2 and cut[0] * cut[1] > 0):
+            raise ValueError("You cannot remove bases from the same end twice.")
     qc = None
     if o.quality_cutoff is not None:
         qc = [int(x) for x in str(o.quality_cutoff).split(",")]
@@ -266,14 +415,23 @@ def pipeline_from_args(argv):
             qc = None                                                     # :750-754
         elif len(qc) == 1:
             qc = [0] + qc
+    from .util import RandomMatchProbability
     kwargs = dict(max_error_rate=o.error_rate, min_overlap=o.overlap, read_wildcards=o.match_read_wildcards,
-                  adapter_wildcards=o.match_adapter_wildcards, indels=o.indels)
+                  adapter_wildcards=o.match_adapter_wildcards, indels=o.indels,
+                  match_probability=RandomMatchProbability())             # trim/__init__.py:345, :364
     if o.indel_cost is not None:
         kwargs["indel_cost"] = o.indel_cost
-    adapters = AdapterParser(**kwargs).parse_multi(o.adapters, o.anywhere, o.front)
+    if o.adapter_max_rmp:
+        kwargs["max_rmp"] = o.adapter_max_rmp                             # trim/__init__.py:367-368
+    parser = AdapterParser(**kwargs)
+    adapters = parser.parse_multi(o.adapters, o.anywhere, o.front)
     action = None if o.no_trim else ("mask" if o.mask_adapter else "trim")    # trim/cli.py:103-111
-    return TrimPipeline(adapters=adapters, times=o.times, action=action, cut=o.cut, nextseq_trim=o.nextseq_trim,
-                        quality_cutoff=qc, quality_base=o.quality_base, trim_n=o.trim_n,
-                        minimum_length=o.minimum_length, maximum_length=o.maximum_length, max_n=o.max_n,
-                        discard_trimmed=o.discard_trimmed, discard_untrimmed=o.discard_untrimmed,
-                        op_order=o.op_order)
+    common = dict(times=o.times, action=action, nextseq_trim=o.nextseq_trim, quality_cutoff=qc,
+                  quality_base=o.quality_base, trim_n=o.trim_n, minimum_length=o.minimum_length,
+                  maximum_length=o.maximum_length, max_n=o.max_n, discard_trimmed=o.discard_trimmed,
+                  discard_untrimmed=o.discard_untrimmed, op_order=o.op_order)
+    if not paired:
+        return TrimPipeline(adapters=adapters, cut=o.cut, **common)
+    adapters2 = parser.parse_multi(o.adapters2, o.anywhere2, o.front2)
+    return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
+                              pair_filter=o.pair_filter or "any", insert_args=insert_args, **common)

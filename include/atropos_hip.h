@@ -278,9 +278,10 @@ int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, int strip, const voi
                     int64_t nlines, atr_fastq_record *d_records, int64_t *d_error, void *stream);
 
 /* 4-bit tile64 pack (as atr_pack_reads) of sequence[begin:end] of every record; d_begin /
- * d_end may be NULL (the whole sequence line).  d_lens receives the packed lengths. */
+ * d_end may be NULL (the whole sequence line).  d_lens receives the packed lengths.
+ * planes != 0: plane64 layout (atr_pack_planes) instead of tile64. */
 int atr_pack_records(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
-                     const int32_t *d_end, int64_t nreads, int max_len, const uint8_t table[256],
+                     const int32_t *d_end, int64_t nreads, int max_len, const uint8_t table[256], int planes,
                      uint8_t *d_packed, int32_t *d_lens, int32_t *d_invalid, void *stream);
 
 /* Interval updates, each the device twin of one reference modifier applied to
@@ -321,7 +322,27 @@ int atr_match_trim_batch(const atr_result *d_matches, const uint8_t *d_front, in
 int atr_read_filter_batch(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
                           const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
                           const uint8_t *d_matched, int64_t n, int min_len, int max_len, double max_n,
-                          int discard_trimmed, int discard_untrimmed, uint8_t *d_dest, void *stream);
+                          int discard_trimmed, int discard_untrimmed, uint8_t *d_dest, uint8_t *d_fail_mask,
+                          void *stream);
+
+/* Paired-end filtering (PairedWrapper, commands/trim/filters.py:66-90): d_fail_mask1/2 are the
+ * per-read masks atr_read_filter_batch writes (bit d: the filter with destination d fires;
+ * d_dest may be NULL there); a filter fires for the pair when it fires for at least
+ * min_affected (1: --pair-filter=any, 2: both) of its reads; d_dest[p] = the first such. */
+int atr_pair_filter_batch(const uint8_t *d_fail_mask1, const uint8_t *d_fail_mask2, int64_t n, int min_affected,
+                          uint8_t *d_dest, void *stream);
+
+/* InsertAdapterCutter.__call__ after the alignments, without error correction
+ * (commands/trim/modifiers.py:391-496): d_insert = the 3 records per pair of
+ * atr_insert_match_batch; d_fallback1/2 = the Adapter.match_to records of read 1 / read 2
+ * (used for pairs without an insert match); the kept intervals of both reads are updated in
+ * place, d_matched1/2 receive `read.match is not None`.  symmetric: mirror a lone adapter match
+ * onto the other read (:419-446); trim_action: 0 = --no-trim (match only), 1 = trim, 2 = mask
+ * (the trimmed interval goes to d_unmasked_*, begin/end stay). */
+int atr_insert_plan_batch(const atr_result *d_insert, const atr_result *d_fallback1, const atr_result *d_fallback2,
+                          int32_t *d_begin1, int32_t *d_end1, int32_t *d_begin2, int32_t *d_end2,
+                          int32_t *d_unmasked_end1, int32_t *d_unmasked_end2, int64_t n, int min_insert_len,
+                          int symmetric, int trim_action, uint8_t *d_matched1, uint8_t *d_matched2, void *stream);
 
 /* FastqFormat.format_entry (io/seqio.py:690-699) of every record with d_dest[r] == dest, in
  * input order, into d_out.  First call with d_out == NULL: d_offsets[n + 1] (device int64)

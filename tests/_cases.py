@@ -607,3 +607,26 @@ def check_merge_golden(batch=True):
                 raise AssertionError("pair %d: the reference raises %s" % (k, cases[k]["error"]))
             done += 1
     return done
+
+
+def check_trim_golden_paired():
+    """PairedTrimPipeline against the two output files of the reference's paired-end command."""
+    import base64
+    import hashlib
+    from atropos_amd.trim import pipeline_from_args, PairedTrimPipeline
+    doc = load_golden("trim_cases.json.gz")
+    inputs = {k: base64.b64decode(v) for k, v in doc["inputs"].items()}
+    done = 0
+    for case in doc["paired"]:
+        label = "%s: %s" % (case["input1"], case["args"])
+        pipe = pipeline_from_args(case["args"])
+        assert isinstance(pipe, PairedTrimPipeline), label
+        outs = pipe.trim_bytes(inputs[case["input1"]], inputs[case["input2"]])
+        for k, (out, want) in enumerate(zip(outs, case["outputs"])):
+            text = base64.b64decode(want["text"])
+            head = out[:len(text)] if want["size"] > 20000 else out
+            assert head == text, (label, k, _first_diff(head, text))
+            assert len(out) == want["size"], (label, k, len(out), want["size"])
+            assert hashlib.sha256(out).hexdigest() == want["sha256"], (label, k)
+        done += 1
+    return done

@@ -217,13 +217,13 @@ class EmuBackend(object):
                                  C.c_void_p(info.data_ptr() + 8)), "emu_fastq_index")
         return records, line_ends, nlines, int(info[1])
 
-    def pack_records(self, data, records, begin, end, max_len, table, count_invalid=False):
+    def pack_records(self, data, records, begin, end, max_len, table, count_invalid=False, planes=False):
         n = records.shape[0]
         packed = torch.zeros((max(self.packed_bytes(n, max_len), 16),), dtype=torch.uint8)
         lens = torch.zeros((n,), dtype=torch.int32)
         invalid = torch.zeros((1,), dtype=torch.int32)
         _check(self.lib.emu_pack_records(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), C.c_int64(n), max_len, table,
-                                         _ptr(packed), _ptr(lens), _ptr(invalid)), "emu_pack_records")
+                                         int(planes), _ptr(packed), _ptr(lens), _ptr(invalid)), "emu_pack_records")
         return (packed, lens, int(invalid.item())) if count_invalid else (packed, lens)
 
     def clip_batch(self, records, begin, end, front, back):
@@ -245,13 +245,29 @@ class EmuBackend(object):
                "emu_match_trim_batch")
 
     def read_filter_batch(self, data, records, begin, end, ubegin, uend, matched, min_len, max_len, max_n,
-                          discard_trimmed, discard_untrimmed):
-        dest = torch.zeros((begin.shape[0],), dtype=torch.uint8)
+                          discard_trimmed, discard_untrimmed, masks=False):
+        out = torch.zeros((begin.shape[0],), dtype=torch.uint8)
         _check(self.lib.emu_read_filter_batch(_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend),
                                               _ptr(matched), C.c_int64(begin.shape[0]), min_len, max_len,
                                               C.c_double(max_n), int(discard_trimmed), int(discard_untrimmed),
-                                              _ptr(dest)), "emu_read_filter_batch")
+                                              None if masks else _ptr(out), _ptr(out) if masks else None),
+               "emu_read_filter_batch")
+        return out
+
+    def pair_filter_batch(self, mask1, mask2, min_affected):
+        dest = torch.zeros((mask1.shape[0],), dtype=torch.uint8)
+        _check(self.lib.emu_pair_filter_batch(_ptr(mask1), _ptr(mask2), C.c_int64(mask1.shape[0]), min_affected,
+                                              _ptr(dest)), "emu_pair_filter_batch")
         return dest
+
+    def insert_plan_batch(self, insert, fb1, fb2, begin1, end1, begin2, end2, uend1, uend2, min_insert_len, symmetric,
+                          trim_action):
+        n = begin1.shape[0]
+        m1, m2 = torch.zeros((n,), dtype=torch.uint8), torch.zeros((n,), dtype=torch.uint8)
+        _check(self.lib.emu_insert_plan_batch(_ptr(insert), _ptr(fb1), _ptr(fb2), _ptr(begin1), _ptr(end1), _ptr(begin2),
+                                              _ptr(end2), _ptr(uend1), _ptr(uend2), C.c_int64(n), min_insert_len,
+                                              int(symmetric), trim_action, _ptr(m1), _ptr(m2)), "emu_insert_plan_batch")
+        return m1, m2
 
     def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
         n = records.shape[0]

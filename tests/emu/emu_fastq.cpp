@@ -40,11 +40,13 @@ int emu_fastq_index(const uint8_t *bytes, int64_t nbytes, int strip, uint32_t *l
 }
 
 int emu_pack_records(const uint8_t *bytes, const atr_fastq_record *records, const int32_t *begin, const int32_t *end,
-                     int64_t nreads, int max_len, const uint8_t table[256], uint8_t *packed, int32_t *lens,
+                     int64_t nreads, int max_len, const uint8_t table[256], int planes, uint8_t *packed, int32_t *lens,
                      int32_t *invalid) {
     if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
     const int nchunks = (max_len + 31) / 32;
     uint32_t *out = (uint32_t *)packed;
+    uint32_t spread[256];
+    for (int c = 0; c < 256; ++c) spread[c] = spread_code((uint32_t)table[c] & 15u);
     for (int64_t r = 0; r < nreads; ++r) {
         const FastqRecord &rec = *(const FastqRecord *)&records[r];
         int a = begin ? begin[r] : 0, b = end ? end[r] : (int)rec.seq_len;
@@ -57,9 +59,12 @@ int emu_pack_records(const uint8_t *bytes, const atr_fastq_record *records, cons
         const int64_t tile = r >> 6;
         const int lane = (int)(r & 63);
         bool zero_seen = false;
-        for (int c = 0; c < nchunks; ++c)
-            for (int d = 0; d < 4; ++d)
-                out[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] = pack_word(row, c * 32 + d * 8, n, table, zero_seen);
+        for (int c = 0; c < nchunks; ++c) {
+            uint32_t *dst = out + (((size_t)tile * nchunks + c) * 64 + lane) * 4;
+            if (planes) pack_planes_chunk(row, c * 32, n, spread, zero_seen, dst);
+            else
+                for (int d = 0; d < 4; ++d) dst[d] = pack_word(row, c * 32 + d * 8, n, table, zero_seen);
+        }
         if (invalid && zero_seen) *invalid += 1;
     }
     return ATR_OK;
@@ -132,13 +137,39 @@ int emu_match_trim_batch(const int16_t *matches, const uint8_t *front, int defau
 int emu_read_filter_batch(const uint8_t *bytes, const atr_fastq_record *records, const int32_t *begin,
                           const int32_t *end, const int32_t *ubegin, const int32_t *uend, const uint8_t *matched,
                           int64_t n, int min_len, int max_len, double max_n, int discard_trimmed, int discard_untrimmed,
-                          uint8_t *dest) {
+                          uint8_t *dest, uint8_t *fail_mask) {
     for (int64_t r = 0; r < n; ++r) {
         const FastqRecord &rec = *(const FastqRecord *)&records[r];
         const int a = begin[r], b = end[r] > a ? end[r] : a;
         const int ub = ubegin ? ubegin[r] - a : 0, ue = uend ? uend[r] - a : b - a;
-        dest[r] = (uint8_t)read_filter_one(bytes + rec.seq_off + a, b - a, ub, ue, matched ? matched[r] != 0 : false,
-                                           min_len, max_len, max_n, discard_trimmed, discard_untrimmed);
+        const uint32_t mask = read_filter_mask(bytes + rec.seq_off + a, b - a, ub, ue, matched ? matched[r] != 0 : false,
+                                               min_len, max_len, max_n, discard_trimmed, discard_untrimmed);
+        if (dest) dest[r] = (uint8_t)filter_destination(mask, 0u, false, 1);
+        if (fail_mask) fail_mask[r] = (uint8_t)mask;
+    }
+    return ATR_OK;
+}
+
+int emu_pair_filter_batch(const uint8_t *mask1, const uint8_t *mask2, int64_t n, int min_affected, uint8_t *dest) {
+    if (min_affected != 1 && min_affected != 2) return ATR_ERR_INVALID;
+    for (int64_t r = 0; r < n; ++r) dest[r] = (uint8_t)filter_destination(mask1[r], mask2[r], true, min_affected);
+    return ATR_OK;
+}
+
+int emu_insert_plan_batch(const int16_t *ins, const int16_t *fb1, const int16_t *fb2, int32_t *begin1, int32_t *end1,
+                          int32_t *begin2, int32_t *end2, int32_t *uend1, int32_t *uend2, int64_t n, int min_insert_len,
+                          int symmetric, int trim_action, uint8_t *matched1, uint8_t *matched2) {
+    for (int64_t r = 0; r < n; ++r) {
+        const int a1 = begin1[r], a2 = begin2[r];
+        const int len1 = end1[r] > a1 ? end1[r] - a1 : 0, len2 = end2[r] > a2 ? end2[r] - a2 : 0;
+        int cut1, cut2;
+        bool m1, m2;
+        insert_plan_one(ins + 24 * r, fb1 + 8 * r, fb2 + 8 * r, len1, len2, min_insert_len, symmetric, trim_action, cut1,
+                        cut2, m1, m2);
+        if (trim_action == 2) { uend1[r] = a1 + cut1; uend2[r] = a2 + cut2; }
+        else { end1[r] = a1 + cut1; end2[r] = a2 + cut2; }
+        matched1[r] = m1 ? 1 : 0;
+        matched2[r] = m2 ? 1 : 0;
     }
     return ATR_OK;
 }

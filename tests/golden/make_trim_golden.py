@@ -117,6 +117,53 @@ CASES = [
 ]
 
 
+PE1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCACACAGTGATCTCGTATGCCGTCTTCTGCTTG"
+PE2 = "AGATCGGAAGAGCGTCGTGTAGGGAAAGAGTGTAGATCTCGGTGGTCGCCGTATCATT"
+
+# paired-end: (input 1, input 2, argument string); outputs are the -o and -p files
+PAIRED_CASES = [
+    ("paired.1.fastq", "paired.2.fastq", "--aligner insert -a TTAGACATATCTCCGTCG -A CAGTGGAGTA"),
+    ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -A CAGTGGAGTA -m 14"),
+    ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -A CAGTGGAGTA -q 10 --pair-filter both -m 20 --trim-n"),
+    ("paired.1.fastq", "paired.2.fastq", "--aligner insert -a TTAGACATATCTCCGTCG -A CAGTGGAGTA --mask-adapter -U 2"),
+    ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -A CAGTGGAGTA --discard-untrimmed"),
+    ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -A CAGTGGAGTA --discard-trimmed --pair-filter both"),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s -q 20 -m 30" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --mask-adapter --trim-n --max-n 0.3" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --no-trim --discard-untrimmed" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --insert-match-error-rate 0.1 -e 0.15 -u 3 -U -4" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --match-read-wildcards -q 10,15 --pair-filter both -m 60" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 40 -M 140 --trim-n" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -n 2 --discard-trimmed" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --adapter-max-rmp 0.001 --nextseq-trim 20" % (PE1, PE2)),
+]
+
+
+def synth_pairs(npairs, seed):
+    """C3-like pairs (2 x 150 bp, fragment shorter or longer than the reads) with qualities."""
+    sys.path.insert(0, ROOT)
+    from atropos_amd import synth
+    w = synth.workload("C3", 0, npairs, device="cpu")
+    rng = np.random.RandomState(seed)
+    texts = []
+    for reads in (w["reads1"].numpy(), w["reads2"].numpy()):
+        out = []
+        for i in range(npairs):
+            seq = bytes(reads[i]).decode("ascii")
+            n = len(seq)
+            if rng.rand() < 0.08:
+                n = int(rng.randint(0, n + 1))
+                seq = seq[:n]
+            q = np.clip(38 - (np.arange(n) * rng.uniform(0.0, 0.3)).astype(int) + rng.randint(-3, 4, size=n), 2, 40)
+            if rng.rand() < 0.1 and n > 8:
+                seq = seq[:n - 4] + "NNNN"
+            out.append("@pair%d/x\n%s\n+\n%s\n" % (i, seq, "".join(chr(int(v) + 33) for v in q)))
+        texts.append("".join(out).encode())
+    return texts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scratch", default="/tmp/oracle_ref")
@@ -175,7 +222,27 @@ def main():
             cases.append(case)
             print("%-24s %-70s -> %s" % (name, argstr, "ERROR " + case["error"][1][:50] if case["error"] else
                                          "%d bytes" % case["size"]))
-    doc = dict(inputs={k: base64.b64encode(v).decode() for k, v in inputs.items()}, cases=cases)
+    for name in ("paired.1.fastq", "paired.2.fastq"):
+        inputs[name] = open(os.path.join(data_dir, name), "rb").read()
+    inputs["synth_pe.1.fastq"], inputs["synth_pe.2.fastq"] = synth_pairs(500, 21)
+    paired = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for idx, (n1, n2, argstr) in enumerate(PAIRED_CASES):
+            paths = [os.path.join(tmp, "pe_%d_%s.fastq" % (idx, t)) for t in ("in1", "in2", "out1", "out2")]
+            open(paths[0], "wb").write(inputs[n1])
+            open(paths[1], "wb").write(inputs[n2])
+            params = argstr.split() + ["-pe1", paths[0], "-pe2", paths[1], "-o", paths[2], "-p", paths[3], "--quiet",
+                                       "--no-default-adapters", "--no-cache-adapters"]
+            retcode, _summary = get_command("trim").execute(params)
+            assert retcode == 0, (argstr, retcode)
+            case = dict(input1=n1, input2=n2, args=argstr, outputs=[])
+            for path in paths[2:]:
+                text = open(path, "rb").read()
+                case["outputs"].append(dict(size=len(text), sha256=hashlib.sha256(text).hexdigest(),
+                                            text=base64.b64encode(text if len(text) <= 20000 else text[:3000]).decode()))
+            paired.append(case)
+            print("%-18s %-90s -> %d + %d bytes" % (n1, argstr[:90], case["outputs"][0]["size"], case["outputs"][1]["size"]))
+    doc = dict(inputs={k: base64.b64encode(v).decode() for k, v in inputs.items()}, cases=cases, paired=paired)
     out = os.path.join(HERE, "trim_cases.json.gz")
     with gzip.GzipFile(out, "wb", mtime=0) as fh:
         fh.write(json.dumps(doc, sort_keys=True).encode())

@@ -23,3 +23,7 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
         pipeline_from_args("-a AAAA...TTTT -a GGGG")                     # linked + plain adapters mixed
     with pytest.raises(SystemExit):
         pipeline_from_args("--length-tag length=")                       # modifier outside the pipeline
+
+
+def test_paired_pipeline_reference_cli_cases(emu_backend):
+    assert _cases.check_trim_golden_paired() >= 16

@@ -56,3 +56,7 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
         _lib.set_backend(prev)
     assert len(got) == len(want) and got == want, _cases._first_diff(got, want)
     assert len(got) > 20000
+
+
+def test_paired_pipeline_reference_cli_cases(hip_backend):
+    assert _cases.check_trim_golden_paired() >= 16
