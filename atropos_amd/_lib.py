@@ -86,8 +86,9 @@ PROTOTYPES = {
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_pair_filter_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_insert_plan_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_clip_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "atr_quality_trim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]),
@@ -100,7 +101,7 @@ PROTOTYPES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_fastq_emit_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_fastq_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                 C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                 C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 FASTQ_ERR_AT, FASTQ_ERR_PLUS, FASTQ_ERR_NAME2, FASTQ_ERR_LENGTH = 1, 2, 3, 4
@@ -385,16 +386,21 @@ class HipBackend(object):
                                                             _ptr(dest), self._stream()), "atr_pair_filter_batch")
         return dest
 
-    def insert_plan_batch(self, insert, fb1, fb2, begin1, end1, begin2, end2, uend1, uend2, min_insert_len, symmetric,
-                          trim_action):
+    def insert_plan_batch(self, insert, fb1, fb2, batch1, batch2, begin1, end1, begin2, end2, uend1, uend2,
+                          min_insert_len, symmetric, trim_action, correct_action=-1, min_qual_difference=1, comp=None):
+        """InsertAdapterCutter's decision logic (+ optional in-place error correction of the two
+        FASTQ chunks).  Returns (matched1, matched2, corrected int32 [n, 2], error word)."""
         n = begin1.shape[0]
         m1, m2 = self.empty((n,), torch.uint8), self.empty((n,), torch.uint8)
+        corrected = self.empty((n, 2), torch.int32)
+        err = self.empty((1,), torch.int64)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_insert_plan_batch(
-                _ptr(insert), _ptr(fb1), _ptr(fb2), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), _ptr(uend1),
-                _ptr(uend2), n, min_insert_len, int(symmetric), trim_action, _ptr(m1), _ptr(m2), self._stream()),
-                "atr_insert_plan_batch")
-        return m1, m2
+                _ptr(insert), _ptr(fb1), _ptr(fb2), _ptr(batch1.data), _ptr(batch1.records), _ptr(batch2.data),
+                _ptr(batch2.records), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), _ptr(uend1), _ptr(uend2), n,
+                min_insert_len, int(symmetric), trim_action, correct_action, min_qual_difference, comp, _ptr(m1),
+                _ptr(m2), _ptr(corrected), _ptr(err), self._stream()), "atr_insert_plan_batch")
+        return m1, m2, corrected, int(err.item())
 
     def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
         """Formatted FASTQ text (uint8 device tensor) of the records with dest == which."""
@@ -402,8 +408,9 @@ class HipBackend(object):
         offsets = self.empty((n + 1,), torch.int64)
         work = self.empty((max(self.lib.atr_fastq_emit_work_bytes(n), 16),), torch.uint8)
         with torch.cuda.device(self.device):
+            hint = int(data.numel() // max(n, 1))
             args = (_ptr(data), _ptr(records), _ptr(begin), _ptr(end), _ptr(ubegin), _ptr(uend), _ptr(dest), which, n,
-                    _ptr(offsets), _ptr(work))
+                    hint, _ptr(offsets), _ptr(work))
             _check(self.lib, self.lib.atr_fastq_emit(*args, None, self._stream()), "atr_fastq_emit")
             total = int(offsets[n].item())
             out = self.empty((max(total, 1),), torch.uint8)

@@ -232,28 +232,60 @@ ATR_DEV int read_filter_one(const uint8_t *seq, int len, int ub, int ue, bool ma
                                                discard_untrimmed), 0u, false, 1);
 }
 
-// InsertAdapterCutter.__call__ after the alignments (commands/trim/modifiers.py:391-496),
-// without error correction: pick the adapter matches (from the insert match, else the two
-// adapters' own semi-global matches), mirror a lone match onto the other read (`symmetric`,
-// :419-446) and trim (`trim`, :455-496).  ins: the three records of atr_insert_match_batch for
-// this pair; fb1/fb2: Adapter.match_to records of the two reads.  len1/len2: current read
-// lengths.  Returns the new lengths in cut1/cut2 (== len: untouched) and the `read.match is
-// not None` flags.
-ATR_DEV void insert_plan_one(const int16_t *ins, const int16_t *fb1, const int16_t *fb2, int len1, int len2,
-                             int min_insert_len, int symmetric, int trim_action, int &cut1, int &cut2, bool &matched1,
-                             bool &matched2) {
-    cut1 = len1; cut2 = len2; matched1 = matched2 = false;
-    if (len1 < min_insert_len || len2 < min_insert_len) return;          // :392-394
+// InsertAdapterCutter.__call__ after the alignments (commands/trim/modifiers.py:391-496), in
+// two steps around the optional error correction:
+//   plan: pick the adapter matches (from the insert match, else the two adapters' own
+//         semi-global matches), mirror a lone match onto the other read (`symmetric`, :419-446)
+//         and decide whether -- and over which overlap -- errors are to be corrected (:397-446);
+//   trim: `trim` (:455-496) with the read lengths as they are AFTER the correction.
+// ins: the three records of atr_insert_match_batch for this pair; fb1/fb2: Adapter.match_to
+// records of the two reads; len1/len2: current read lengths.
+struct InsertPlan {
+    bool active;                  // both reads at least min_insert_len long (:392-394)
+    bool h1, h2;                  // adapter match present for read 1 / read 2
+    int rstart1, rstart2;
+    bool correct;                 // run correct_errors with corr[] as the insert match
+    int16_t corr[4];
+};
+
+ATR_DEV void insert_plan_matches(const int16_t *ins, const int16_t *fb1, const int16_t *fb2, int len1, int len2,
+                                 int min_insert_len, int symmetric, bool mismatch_action, InsertPlan &P) {
+    P.active = !(len1 < min_insert_len || len2 < min_insert_len);
+    P.h1 = P.h2 = P.correct = false;
+    P.rstart1 = P.rstart2 = 0;
+    P.corr[0] = P.corr[1] = P.corr[2] = P.corr[3] = 0;
+    if (!P.active) return;
     const bool has_insert = ins[1] >= 0;
+    bool have_tuple = false;
     const int16_t *m1 = has_insert ? ins + 8 : fb1, *m2 = has_insert ? ins + 16 : fb2;
-    bool h1 = m1[1] >= 0, h2 = m2[1] >= 0;
-    int rstart1 = m1[2], rstart2 = m2[2];
-    if (symmetric && (h1 != h2)) {                                        // :419-437
-        if (h1) { if (rstart1 <= len2) { h2 = true; rstart2 = rstart1; } }
-        else if (rstart2 <= len1) { h1 = true; rstart1 = rstart2; }
+    P.h1 = m1[1] >= 0; P.h2 = m2[1] >= 0;
+    P.rstart1 = m1[2]; P.rstart2 = m2[2];
+    if (has_insert) {                                                     // :397-403
+        have_tuple = true;
+        P.corr[0] = ins[0]; P.corr[1] = ins[1]; P.corr[2] = ins[2]; P.corr[3] = ins[3];
+        P.correct = mismatch_action && ins[5] > 0;
+    } else if (mismatch_action && P.h1 && P.h2 && P.rstart1 == P.rstart2) {   // :408-415: complementary adapter matches
+        have_tuple = true;
+        P.corr[0] = (int16_t)(len2 - P.rstart1); P.corr[1] = (int16_t)len2; P.corr[2] = 0; P.corr[3] = (int16_t)P.rstart1;
+        P.correct = true;
     }
-    if (h1) { matched1 = true; if (trim_action && rstart1 < len1) cut1 = rstart1; }     // :455-496 (rstart >= len: no trim)
-    if (h2) { matched2 = true; if (trim_action && rstart2 < len2) cut2 = rstart2; }
+    if (symmetric && (P.h1 != P.h2)) {                                    // :419-446
+        if (P.h1) { if (P.rstart1 <= len2) { P.h2 = true; P.rstart2 = P.rstart1; } }
+        else if (P.rstart2 <= len1) { P.h1 = true; P.rstart1 = P.rstart2; }
+        if (mismatch_action && !have_tuple && P.h1 && P.h2) {
+            P.corr[0] = (int16_t)(len2 - P.rstart1); P.corr[1] = (int16_t)len2; P.corr[2] = 0; P.corr[3] = (int16_t)P.rstart1;
+            P.correct = true;
+        }
+    }
+}
+
+// Returns the new lengths in cut1/cut2 (== len: untouched) and the `read.match is not None` flags.
+ATR_DEV void insert_plan_trim(const InsertPlan &P, int len1, int len2, int trim_action, int &cut1, int &cut2,
+                              bool &matched1, bool &matched2) {
+    cut1 = len1; cut2 = len2; matched1 = matched2 = false;
+    if (!P.active) return;
+    if (P.h1) { matched1 = true; if (trim_action && P.rstart1 < len1) cut1 = P.rstart1; }   // rstart >= len: no trim
+    if (P.h2) { matched2 = true; if (trim_action && P.rstart2 < len2) cut2 = P.rstart2; }
 }
 
 // Bytes of a formatted record (io/seqio.py:690-699): '@' name '\n' seq '\n+' name2 '\n' qual '\n'

@@ -20,6 +20,7 @@
 #include "atropos_hip.h"
 #include "locate_core.hpp"
 #include "fastq_core.hpp"
+#include "misc_core.hpp"
 
 namespace atr {
 
@@ -378,21 +379,42 @@ __global__ __launch_bounds__(256) void pair_filter_kernel(const uint8_t *__restr
     dest[r] = (uint8_t)filter_destination(mask1[r], mask2[r], true, min_affected);
 }
 
-__global__ __launch_bounds__(256) void insert_plan_kernel(const int16_t *__restrict__ ins, const int16_t *__restrict__ fb1,
-                                                          const int16_t *__restrict__ fb2, int32_t *__restrict__ begin1,
-                                                          int32_t *__restrict__ end1, int32_t *__restrict__ begin2,
-                                                          int32_t *__restrict__ end2, int32_t *__restrict__ uend1,
-                                                          int32_t *__restrict__ uend2, long long n, int min_insert_len,
-                                                          int symmetric, int trim_action, uint8_t *__restrict__ matched1,
-                                                          uint8_t *__restrict__ matched2) {
+struct CompTable256 { uint8_t c[256]; };
+
+__global__ __launch_bounds__(256) void insert_plan_kernel(
+    const int16_t *__restrict__ ins, const int16_t *__restrict__ fb1, const int16_t *__restrict__ fb2,
+    uint8_t *bytes1, const FastqRecord *__restrict__ records1, uint8_t *bytes2, const FastqRecord *__restrict__ records2,
+    int32_t *__restrict__ begin1, int32_t *__restrict__ end1, int32_t *__restrict__ begin2, int32_t *__restrict__ end2,
+    int32_t *__restrict__ uend1, int32_t *__restrict__ uend2, long long n, int min_insert_len, int symmetric,
+    int trim_action, int correct_action, int min_qual_diff, const CompTable256 ct, uint8_t *__restrict__ matched1,
+    uint8_t *__restrict__ matched2, int32_t *__restrict__ corrected, unsigned long long *__restrict__ error) {
+    __shared__ uint8_t s_comp[256];
+    s_comp[threadIdx.x] = ct.c[threadIdx.x];
+    __syncthreads();
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     const int a1 = begin1[r], a2 = begin2[r];
-    const int len1 = max(0, end1[r] - a1), len2 = max(0, end2[r] - a2);
+    int len1 = max(0, end1[r] - a1), len2 = max(0, end2[r] - a2);
+    InsertPlan P;
+    insert_plan_matches(ins + 24 * r, fb1 + 8 * r, fb2 + 8 * r, len1, len2, min_insert_len, symmetric, correct_action >= 0, P);
+    if (corrected) corrected[2 * r] = corrected[2 * r + 1] = 0;
+    if (P.correct) {                                                   // correct_errors(..., truncate_seqs=True), :448-449
+        const FastqRecord r1 = records1[r], r2 = records2[r];
+        int32_t changed[2], newlen[2];
+        correct_errors_one(bytes1 + r1.seq_off + a1, bytes1 + r1.qual_off + a1, len1, bytes2 + r2.seq_off + a2,
+                           bytes2 + r2.qual_off + a2, len2, P.corr, correct_action, min_qual_diff, true, s_comp, changed,
+                           newlen);
+        if (changed[0] < 0) {
+            atomicMin(error, (unsigned long long)r * 8ull + (unsigned long long)(-changed[0]));
+        } else {
+            len1 = newlen[0]; len2 = newlen[1];
+            end1[r] = a1 + len1; end2[r] = a2 + len2;
+            if (corrected) { corrected[2 * r] = changed[0]; corrected[2 * r + 1] = changed[1]; }
+        }
+    }
     int cut1, cut2;
     bool m1, m2;
-    insert_plan_one(ins + 24 * r, fb1 + 8 * r, fb2 + 8 * r, len1, len2, min_insert_len, symmetric, trim_action, cut1,
-                    cut2, m1, m2);
+    insert_plan_trim(P, len1, len2, trim_action, cut1, cut2, m1, m2);
     if (trim_action == 2) {                                            // mask: keep the length, remember the cut
         uend1[r] = a1 + cut1;
         uend2[r] = a2 + cut2;
@@ -482,7 +504,8 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint8_t *__restrict__ b
 // bounds both stages.  Tiles that do not fit (very long names / reads) or whose records
 // are not in file order take emit_kernel's path.
 constexpr int EMIT_STAGE = 13 * 1024;                        // per stage; 2 stages per wave -> 6 waves per CU
-constexpr int EMIT_TILE = 32;                                // records per wave: two lanes share a record
+// records per wave: 32 (two lanes share a record) for short-read files, 16 for records of
+// more than ~400 bytes so that a tile still fits the stages
 
 // LDS -> LDS copy of len bytes at arbitrary alignments: byte steps until dst is dword
 // aligned, then one aligned ds_read_b32 + v_alignbyte_b32 + ds_write_b32 per 4 bytes (four
@@ -513,6 +536,7 @@ __device__ __forceinline__ void lds_copy(uint8_t *dst, const uint8_t *src, uint3
     for (k += nd * 4u; k < len; ++k) dst[k] = src[k];
 }
 
+template <int EMIT_TILE>
 __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restrict__ bytes,
                                                          const FastqRecord *__restrict__ records,
                                                          const int32_t *__restrict__ begin, const int32_t *__restrict__ end,
@@ -521,7 +545,8 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
                                                          const long long *__restrict__ offsets, uint8_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_emit[];
     uint8_t *s_in = s_emit, *s_out = s_emit + EMIT_STAGE;
-    const int lane = threadIdx.x, slot = lane >> 1, part = lane & 1;
+    constexpr int LPR = 64 / EMIT_TILE;                       // lanes per record (the first two do the work)
+    const int lane = threadIdx.x, slot = lane / LPR, part = lane % LPR;
     const long long r0 = (long long)blockIdx.x * EMIT_TILE;
     const int cnt = (int)min<long long>(EMIT_TILE, n - r0);
     const long long r = r0 + slot;
@@ -540,7 +565,7 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
         keep = !dest || dest[r] == which;
     }
     const uint32_t rec_lo = rec.name_off - 1u, rec_hi = rec.qual_off + rec.qual_len;     // '@' .. last quality byte
-    const uint32_t in_lo = __shfl(rec_lo, 0, 64), in_hi = __shfl(rec_hi, 2 * (cnt - 1), 64);
+    const uint32_t in_lo = __shfl(rec_lo, 0, 64), in_hi = __shfl(rec_hi, LPR * (cnt - 1), 64);
     const long long out_lo = offsets[r0], out_hi = offsets[r0 + cnt];
     const bool ordered = __all(!live || (rec_lo >= in_lo && rec_hi <= in_hi && rec.seq_off >= rec_lo &&
                                          rec.seq_off + rec.seq_len <= rec.qual_off && rec.name_off + rec.name_len <= rec.seq_off));
@@ -607,7 +632,7 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
                 }
             }
             o[kept] = '\n';
-        } else {
+        } else if (part == 1) {
             o += 1u + rec.name_len + 1u + kept + 1u;
             *o++ = '+';
             if (rec.flags & 1u) { lds_copy(o, in + (rec.name_off - in_lo), rec.name_len); o += rec.name_len; }
@@ -792,18 +817,30 @@ int atr_pair_filter_batch(const uint8_t *d_fail_mask1, const uint8_t *d_fail_mas
 }
 
 int atr_insert_plan_batch(const atr_result *d_insert, const atr_result *d_fallback1, const atr_result *d_fallback2,
-                          int32_t *d_begin1, int32_t *d_end1, int32_t *d_begin2, int32_t *d_end2,
-                          int32_t *d_unmasked_end1, int32_t *d_unmasked_end2, int64_t n, int min_insert_len,
-                          int symmetric, int trim_action, uint8_t *d_matched1, uint8_t *d_matched2, void *stream) {
-    if (n < 0 || trim_action < 0 || trim_action > 2) return ATR_ERR_INVALID;
-    if (n == 0) return ATR_OK;
+                          uint8_t *d_bytes1, const atr_fastq_record *d_records1, uint8_t *d_bytes2,
+                          const atr_fastq_record *d_records2, int32_t *d_begin1, int32_t *d_end1, int32_t *d_begin2,
+                          int32_t *d_end2, int32_t *d_unmasked_end1, int32_t *d_unmasked_end2, int64_t n,
+                          int min_insert_len, int symmetric, int trim_action, int correct_action, int min_qual_difference,
+                          const uint8_t comp[256], uint8_t *d_matched1, uint8_t *d_matched2, int32_t *d_corrected,
+                          int64_t *d_error, void *stream) {
+    if (n < 0 || trim_action < 0 || trim_action > 2 || correct_action < -1 || correct_action > 2) return ATR_ERR_INVALID;
+    if (correct_action >= 0 && (!d_bytes1 || !d_records1 || !d_bytes2 || !d_records2 || !comp || !d_error))
+        return ATR_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_error) hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, (long long *)d_error, (long long)LLONG_MAX);
+    if (n == 0) return launched("insert_plan_kernel launch");
     if (!d_insert || !d_fallback1 || !d_fallback2 || !d_begin1 || !d_end1 || !d_begin2 || !d_end2 || !d_matched1 ||
         !d_matched2 || (trim_action == 2 && (!d_unmasked_end1 || !d_unmasked_end2)))
         return ATR_ERR_INVALID;
-    hipLaunchKernelGGL(insert_plan_kernel, dim3(grid256(n)), dim3(256), 0, (hipStream_t)stream, (const int16_t *)d_insert,
-                       (const int16_t *)d_fallback1, (const int16_t *)d_fallback2, d_begin1, d_end1, d_begin2, d_end2,
-                       d_unmasked_end1, d_unmasked_end2, (long long)n, min_insert_len, symmetric, trim_action, d_matched1,
-                       d_matched2);
+    CompTable256 ct;
+    memset(ct.c, 0, 256);
+    if (comp) memcpy(ct.c, comp, 256);
+    hipLaunchKernelGGL(insert_plan_kernel, dim3(grid256(n)), dim3(256), 0, st, (const int16_t *)d_insert,
+                       (const int16_t *)d_fallback1, (const int16_t *)d_fallback2, d_bytes1,
+                       (const FastqRecord *)d_records1, d_bytes2, (const FastqRecord *)d_records2, d_begin1, d_end1,
+                       d_begin2, d_end2, d_unmasked_end1, d_unmasked_end2, (long long)n, min_insert_len, symmetric,
+                       trim_action, correct_action, min_qual_difference, ct, d_matched1, d_matched2, d_corrected,
+                       (unsigned long long *)d_error);
     return launched("insert_plan_kernel launch");
 }
 
@@ -815,8 +852,8 @@ size_t atr_fastq_emit_work_bytes(int64_t n) {
 
 int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
                    const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
-                   const uint8_t *d_dest, int dest, int64_t n, int64_t *d_offsets, void *d_work, uint8_t *d_out,
-                   void *stream) {
+                   const uint8_t *d_dest, int dest, int64_t n, int record_bytes_hint, int64_t *d_offsets, void *d_work,
+                   uint8_t *d_out, void *stream) {
     if (n < 0 || !d_offsets || ((d_unmasked_begin == nullptr) != (d_unmasked_end == nullptr))) return ATR_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (n == 0) {
@@ -835,9 +872,14 @@ int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, co
     }
     const long long ntiles = (n + 63) / 64;
     if (((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_bytes & 15) == 0) {
-        hipLaunchKernelGGL(emit_staged_kernel, dim3((unsigned)((n + EMIT_TILE - 1) / EMIT_TILE)), dim3(64), 2 * EMIT_STAGE, st, d_bytes,
-                           (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest,
-                           dest, (long long)n, (const long long *)d_offsets, d_out);
+        if (record_bytes_hint > 400)
+            hipLaunchKernelGGL(emit_staged_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(64), 2 * EMIT_STAGE, st, d_bytes,
+                               (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest,
+                               dest, (long long)n, (const long long *)d_offsets, d_out);
+        else
+            hipLaunchKernelGGL(emit_staged_kernel<32>, dim3((unsigned)((n + 31) / 32)), dim3(64), 2 * EMIT_STAGE, st, d_bytes,
+                               (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest,
+                               dest, (long long)n, (const long long *)d_offsets, d_out);
         return launched("emit_staged_kernel launch");
     }
     hipLaunchKernelGGL(emit_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, d_bytes,

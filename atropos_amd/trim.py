@@ -246,12 +246,14 @@ class PairedTrimPipeline(object):
     whole-batch device stages.  ``aligner``: 'adapter' -- one AdapterCutter per read
     (``adapters1`` / ``adapters2``), or 'insert' -- InsertAdapterCutter with exactly one 3'
     adapter per read (trim/__init__.py:406-456).  ``pair_filter``: 'any' or 'both'.
-    Error correction and merging are not part of the device pipeline (they rewrite bases)."""
+    ``correct_mismatches`` ('liberal' | 'conservative' | 'N', insert aligner only): error
+    correction of the overlaps, written IN PLACE into the two FASTQ chunks in device memory
+    (a batch is consumed by ``run``).  Merging is not part of the device pipeline."""
 
     def __init__(self, adapters1=(), adapters2=(), aligner="adapter", times=1, action="trim", cut=(), cut2=(),
                  nextseq_trim=None, quality_cutoff=None, quality_base=33, trim_n=False, minimum_length=None,
                  maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
-                 op_order="CGQAW", insert_args=None):
+                 op_order="CGQAW", insert_args=None, correct_mismatches=None):
         common = dict(times=times, action=action, nextseq_trim=nextseq_trim, quality_cutoff=quality_cutoff,
                       quality_base=quality_base, trim_n=trim_n, minimum_length=minimum_length,
                       maximum_length=maximum_length, max_n=max_n, discard_trimmed=discard_trimmed,
@@ -262,6 +264,12 @@ class PairedTrimPipeline(object):
         if pair_filter not in ("any", "both"):
             raise ValueError("pair_filter must be 'any' or 'both'")
         self.min_affected = 2 if pair_filter == "both" else 1            # trim/__init__.py:549
+        if correct_mismatches not in (None, "liberal", "conservative", "N"):
+            raise ValueError("correct_mismatches must be 'liberal', 'conservative' or 'N'")
+        if correct_mismatches and aligner != "insert":
+            raise NotImplementedError("error correction is part of the insert aligner stage only")
+        self.correct_mismatches = correct_mismatches
+        self.corrected_pairs, self.corrected_bp = 0, [0, 0]               # ErrorCorrectorMixin counters
         self.insert = None
         if aligner == "insert":
             from .adapters import BACK
@@ -294,8 +302,22 @@ class PairedTrimPipeline(object):
         uend1 = uend2 = None
         if action == 2:
             uend1, uend2 = st1[1].clone(), st2[1].clone()
-        m1, m2 = be.insert_plan_batch(ins.contiguous(), fb1.contiguous(), fb2.contiguous(), st1[0], st1[1], st2[0], st2[1],
-                                      uend1, uend2, self.insert.min_insert_overlap, True, action)
+        from .modifiers import COMP_TABLE, _ACTIONS
+        correct = _ACTIONS[self.correct_mismatches] if self.correct_mismatches else -1
+        # NB: with error correction the bases / qualities of both FASTQ chunks are rewritten in place
+        m1, m2, corrected, err = be.insert_plan_batch(
+            ins.contiguous(), fb1.contiguous(), fb2.contiguous(), b1, b2, st1[0], st1[1], st2[0], st2[1], uend1, uend2,
+            self.insert.min_insert_overlap, True, action, correct, 1, COMP_TABLE)
+        if err != _lib.INT64_MAX:                                          # the exception the reference raises
+            exc = {1: KeyError, 2: IndexError, 3: ValueError}[err % 8]
+            raise exc("error correction of pair %d: %s" % (err // 8, {
+                1: "base without a complement", 2: "overlap outside a read",
+                3: "Cannot determine the mode of an empty sequence"}[err % 8]))
+        if correct >= 0:
+            self.corrected_pairs += int((corrected.sum(dim=1) > 0).sum().item())
+            tot = corrected.sum(dim=0).cpu().tolist()
+            self.corrected_bp[0] += int(tot[0])
+            self.corrected_bp[1] += int(tot[1])
         if action == 2:
             return (m1, st1[0].clone(), uend1), (m2, st2[0].clone(), uend2)
         return (m1, None, None), (m2, None, None)
@@ -381,6 +403,7 @@ def pipeline_from_args(argv):
     ap.add_argument("--discard-trimmed", "--discard", action="store_true", default=False)
     ap.add_argument("--discard-untrimmed", "--trimmed-only", action="store_true", default=False)
     ap.add_argument("--pair-filter", choices=("any", "both"), default=None)
+    ap.add_argument("--correct-mismatches", choices=("liberal", "conservative", "N"), default=None)
     o = ap.parse_args(argv)
     paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert")
     insert_args = None
@@ -434,4 +457,5 @@ def pipeline_from_args(argv):
         return TrimPipeline(adapters=adapters, cut=o.cut, **common)
     adapters2 = parser.parse_multi(o.adapters2, o.anywhere2, o.front2)
     return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
-                              pair_filter=o.pair_filter or "any", insert_args=insert_args, **common)
+                              pair_filter=o.pair_filter or "any", insert_args=insert_args,
+                              correct_mismatches=o.correct_mismatches, **common)

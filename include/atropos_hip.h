@@ -332,28 +332,37 @@ int atr_read_filter_batch(const uint8_t *d_bytes, const atr_fastq_record *d_reco
 int atr_pair_filter_batch(const uint8_t *d_fail_mask1, const uint8_t *d_fail_mask2, int64_t n, int min_affected,
                           uint8_t *d_dest, void *stream);
 
-/* InsertAdapterCutter.__call__ after the alignments, without error correction
- * (commands/trim/modifiers.py:391-496): d_insert = the 3 records per pair of
- * atr_insert_match_batch; d_fallback1/2 = the Adapter.match_to records of read 1 / read 2
- * (used for pairs without an insert match); the kept intervals of both reads are updated in
- * place, d_matched1/2 receive `read.match is not None`.  symmetric: mirror a lone adapter match
- * onto the other read (:419-446); trim_action: 0 = --no-trim (match only), 1 = trim, 2 = mask
- * (the trimmed interval goes to d_unmasked_*, begin/end stay). */
+/* InsertAdapterCutter.__call__ after the alignments (commands/trim/modifiers.py:391-496):
+ * d_insert = the 3 records per pair of atr_insert_match_batch; d_fallback1/2 = the
+ * Adapter.match_to records of read 1 / read 2 (used for pairs without an insert match); the
+ * kept intervals of both reads are updated in place, d_matched1/2 receive `read.match is not
+ * None`.  symmetric: mirror a lone adapter match onto the other read (:419-446); trim_action:
+ * 0 = --no-trim (match only), 1 = trim, 2 = mask (the trimmed end goes to d_unmasked_end*,
+ * begin/end stay).  correct_action: -1 = no error correction, else ATR_CORRECT_* -- the
+ * overlap of the pairs the reference would correct (:397-446) is corrected IN PLACE in the two
+ * FASTQ chunks (bases and qualities, correct_errors(..., truncate_seqs=True), :219-350) before
+ * trimming; d_corrected (may be NULL) receives the 2 x int32 changed-base counts per pair and
+ * *d_error min over failing pairs of (pair * 8 + code), code 1 KeyError, 2 IndexError,
+ * 3 ValueError (the exception the reference raises), or INT64_MAX. */
 int atr_insert_plan_batch(const atr_result *d_insert, const atr_result *d_fallback1, const atr_result *d_fallback2,
-                          int32_t *d_begin1, int32_t *d_end1, int32_t *d_begin2, int32_t *d_end2,
-                          int32_t *d_unmasked_end1, int32_t *d_unmasked_end2, int64_t n, int min_insert_len,
-                          int symmetric, int trim_action, uint8_t *d_matched1, uint8_t *d_matched2, void *stream);
+                          uint8_t *d_bytes1, const atr_fastq_record *d_records1, uint8_t *d_bytes2,
+                          const atr_fastq_record *d_records2, int32_t *d_begin1, int32_t *d_end1, int32_t *d_begin2,
+                          int32_t *d_end2, int32_t *d_unmasked_end1, int32_t *d_unmasked_end2, int64_t n,
+                          int min_insert_len, int symmetric, int trim_action, int correct_action, int min_qual_difference,
+                          const uint8_t comp[256], uint8_t *d_matched1, uint8_t *d_matched2, int32_t *d_corrected,
+                          int64_t *d_error, void *stream);
 
 /* FastqFormat.format_entry (io/seqio.py:690-699) of every record with d_dest[r] == dest, in
  * input order, into d_out.  First call with d_out == NULL: d_offsets[n + 1] (device int64)
  * receives the exclusive prefix sums of the formatted sizes (d_offsets[n] = total bytes);
  * second call with d_out of that many bytes writes the text.  d_work: scratch of
- * atr_fastq_emit_work_bytes(n) bytes. */
+ * atr_fastq_emit_work_bytes(n) bytes.  record_bytes_hint: average bytes per input record (0:
+ * unknown) -- only picks how many records a wave stages at once. */
 size_t atr_fastq_emit_work_bytes(int64_t n);
 int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, const int32_t *d_begin,
                    const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
-                   const uint8_t *d_dest, int dest, int64_t n, int64_t *d_offsets, void *d_work, uint8_t *d_out,
-                   void *stream);
+                   const uint8_t *d_dest, int dest, int64_t n, int record_bytes_hint, int64_t *d_offsets, void *d_work,
+                   uint8_t *d_out, void *stream);
 
 #ifdef __cplusplus
 }

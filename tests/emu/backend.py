@@ -260,14 +260,18 @@ class EmuBackend(object):
                                               _ptr(dest)), "emu_pair_filter_batch")
         return dest
 
-    def insert_plan_batch(self, insert, fb1, fb2, begin1, end1, begin2, end2, uend1, uend2, min_insert_len, symmetric,
-                          trim_action):
+    def insert_plan_batch(self, insert, fb1, fb2, batch1, batch2, begin1, end1, begin2, end2, uend1, uend2,
+                          min_insert_len, symmetric, trim_action, correct_action=-1, min_qual_difference=1, comp=None):
         n = begin1.shape[0]
         m1, m2 = torch.zeros((n,), dtype=torch.uint8), torch.zeros((n,), dtype=torch.uint8)
-        _check(self.lib.emu_insert_plan_batch(_ptr(insert), _ptr(fb1), _ptr(fb2), _ptr(begin1), _ptr(end1), _ptr(begin2),
-                                              _ptr(end2), _ptr(uend1), _ptr(uend2), C.c_int64(n), min_insert_len,
-                                              int(symmetric), trim_action, _ptr(m1), _ptr(m2)), "emu_insert_plan_batch")
-        return m1, m2
+        corrected = torch.zeros((n, 2), dtype=torch.int32)
+        err = torch.zeros((1,), dtype=torch.int64)
+        _check(self.lib.emu_insert_plan_batch(
+            _ptr(insert), _ptr(fb1), _ptr(fb2), _ptr(batch1.data), _ptr(batch1.records), _ptr(batch2.data),
+            _ptr(batch2.records), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), _ptr(uend1), _ptr(uend2),
+            C.c_int64(n), min_insert_len, int(symmetric), trim_action, correct_action, min_qual_difference, comp,
+            _ptr(m1), _ptr(m2), _ptr(corrected), _ptr(err)), "emu_insert_plan_batch")
+        return m1, m2, corrected, int(err.item())
 
     def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
         n = records.shape[0]

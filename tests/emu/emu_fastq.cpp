@@ -10,6 +10,7 @@
 #include "atropos_hip.h"
 #include "locate_core.hpp"
 #include "fastq_core.hpp"
+#include "misc_core.hpp"
 
 using namespace atr;
 
@@ -156,16 +157,37 @@ int emu_pair_filter_batch(const uint8_t *mask1, const uint8_t *mask2, int64_t n,
     return ATR_OK;
 }
 
-int emu_insert_plan_batch(const int16_t *ins, const int16_t *fb1, const int16_t *fb2, int32_t *begin1, int32_t *end1,
-                          int32_t *begin2, int32_t *end2, int32_t *uend1, int32_t *uend2, int64_t n, int min_insert_len,
-                          int symmetric, int trim_action, uint8_t *matched1, uint8_t *matched2) {
+int emu_insert_plan_batch(const int16_t *ins, const int16_t *fb1, const int16_t *fb2, uint8_t *bytes1,
+                          const atr_fastq_record *records1, uint8_t *bytes2, const atr_fastq_record *records2,
+                          int32_t *begin1, int32_t *end1, int32_t *begin2, int32_t *end2, int32_t *uend1, int32_t *uend2,
+                          int64_t n, int min_insert_len, int symmetric, int trim_action, int correct_action,
+                          int min_qual_diff, const uint8_t *comp, uint8_t *matched1, uint8_t *matched2,
+                          int32_t *corrected, int64_t *error) {
+    if (error) *error = LLONG_MAX;
     for (int64_t r = 0; r < n; ++r) {
         const int a1 = begin1[r], a2 = begin2[r];
-        const int len1 = end1[r] > a1 ? end1[r] - a1 : 0, len2 = end2[r] > a2 ? end2[r] - a2 : 0;
+        int len1 = end1[r] > a1 ? end1[r] - a1 : 0, len2 = end2[r] > a2 ? end2[r] - a2 : 0;
+        InsertPlan P;
+        insert_plan_matches(ins + 24 * r, fb1 + 8 * r, fb2 + 8 * r, len1, len2, min_insert_len, symmetric,
+                            correct_action >= 0, P);
+        if (corrected) corrected[2 * r] = corrected[2 * r + 1] = 0;
+        if (P.correct) {
+            const FastqRecord &r1 = *(const FastqRecord *)&records1[r], &r2 = *(const FastqRecord *)&records2[r];
+            int32_t changed[2], newlen[2];
+            correct_errors_one(bytes1 + r1.seq_off + a1, bytes1 + r1.qual_off + a1, len1, bytes2 + r2.seq_off + a2,
+                               bytes2 + r2.qual_off + a2, len2, P.corr, correct_action, min_qual_diff, true, comp, changed,
+                               newlen);
+            if (changed[0] < 0) {
+                if (r * 8 - changed[0] < *error) *error = r * 8 - changed[0];
+            } else {
+                len1 = newlen[0]; len2 = newlen[1];
+                end1[r] = a1 + len1; end2[r] = a2 + len2;
+                if (corrected) { corrected[2 * r] = changed[0]; corrected[2 * r + 1] = changed[1]; }
+            }
+        }
         int cut1, cut2;
         bool m1, m2;
-        insert_plan_one(ins + 24 * r, fb1 + 8 * r, fb2 + 8 * r, len1, len2, min_insert_len, symmetric, trim_action, cut1,
-                        cut2, m1, m2);
+        insert_plan_trim(P, len1, len2, trim_action, cut1, cut2, m1, m2);
         if (trim_action == 2) { uend1[r] = a1 + cut1; uend2[r] = a2 + cut2; }
         else { end1[r] = a1 + cut1; end2[r] = a2 + cut2; }
         matched1[r] = m1 ? 1 : 0;

@@ -134,6 +134,10 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --no-trim --discard-untrimmed" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --insert-match-error-rate 0.1 -e 0.15 -u 3 -U -4" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --match-read-wildcards -q 10,15 --pair-filter both -m 60" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --correct-mismatches liberal" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --correct-mismatches conservative -q 15 -m 25" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --correct-mismatches N --match-read-wildcards --trim-n" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --correct-mismatches liberal --mask-adapter" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 40 -M 140 --trim-n" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -n 2 --discard-trimmed" % (PE1, PE2)),
