@@ -281,6 +281,22 @@ class PairedTrimPipeline(object):
         elif aligner != "adapter":
             raise ValueError("aligner must be 'adapter' or 'insert'")
 
+    @staticmethod
+    def _fallback(adapter, batch, st, miss, n):
+        """Adapter.match_to records for the reads listed in ``miss`` (-1 records elsewhere)."""
+        none = torch.zeros((n, 8), dtype=torch.int16, device=st[0].device)
+        none[:, 1] = -1
+        if miss.numel() == 0:
+            return none
+        if miss.numel() == n:
+            return adapter.match_source(RecordSource(batch, st[0], st[1]))
+        sub = FastqBatch(batch.data, batch.nbytes, batch.records.index_select(0, miss).contiguous(), batch.strip,
+                         batch.backend)
+        rec = adapter.match_source(RecordSource(sub, st[0].index_select(0, miss).contiguous(),
+                                                st[1].index_select(0, miss).contiguous()))
+        none[miss] = rec
+        return none
+
     def _insert_stage(self, b1, b2, st1, st2):
         """InsertAdapterCutter over the batch (commands/trim/modifiers.py:391-496, no error correction)."""
         be = b1.backend
@@ -296,8 +312,10 @@ class PairedTrimPipeline(object):
         pb1 = src1.planes(max_len, _lib.TABLE_DNA15, table)
         pb2 = src2.planes(max_len, _lib.TABLE_DNA15, table, check=True)
         ins = self.insert.match_insert_batch(pb1, pb2).records
-        fb1 = self.p1.adapters[0].match_source(src1)                       # semi-global fallback (modifiers.py:405-407)
-        fb2 = self.p2.adapters[0].match_source(src2)
+        # semi-global fallback (modifiers.py:405-407): only the pairs without an insert match need it
+        miss = torch.nonzero(ins[:, 0, 1] < 0).squeeze(1)
+        fb1 = self._fallback(self.p1.adapters[0], b1, st1, miss, n)
+        fb2 = self._fallback(self.p2.adapters[0], b2, st2, miss, n)
         action = {None: 0, "trim": 1, "mask": 2}[self.action]
         uend1 = uend2 = None
         if action == 2:
