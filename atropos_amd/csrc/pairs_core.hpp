@@ -157,6 +157,117 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
     rec[3] = 0;
 }
 
+// ---- register-column variant (references of up to PAIRS_REG_MAX rows) -----------------------
+// The same alignment with the DP column in VGPRs (locate_core.hpp's column layout, row i at
+// position i) and the lane's reference turned into per-query-code MATCH masks in LDS
+// (tab[(code * NW + w) * ts], NW = ceil(MT / 32) words; bit i-1 <=> row i matches): a column
+// then costs NW ds_reads and six VALU ops per cell, with no LDS traffic per cell.  Row m sits at
+// a per-lane position, so its cell is picked up by a select in the rows from the wave's
+// smallest m on (mlo, wave-uniform); rows beyond a lane's m compute don't-care cells.
+constexpr int PAIRS_REG_MAX = 152;
+
+template <int MT, bool AND_MODE>
+ATR_DEV void build_match_masks(uint32_t *tab, int ts, const uint32_t *rp, int m, bool revcomp) {
+    constexpr int NW = (MT + 31) / 32;
+    for (int t = 0; t < 16 * NW; ++t) tab[(size_t)t * ts] = 0u;
+    for (int i = 0; i < m; ++i) {
+        uint32_t c = packed_code(rp, revcomp ? m - 1 - i : i);
+        if (revcomp) c = bitrev4(c);
+        const uint32_t bit = 1u << (i & 31);
+        if (AND_MODE) {
+            for (uint32_t q = 1; q < 16; ++q)
+                if (q & c) tab[(size_t)(q * NW + (i >> 5)) * ts] |= bit;                // _align.pyx:392-393
+        } else {
+            tab[(size_t)(c * NW + (i >> 5)) * ts] |= bit;                               // :390-391 on 4-bit codes
+        }
+    }
+}
+
+// One column; returns the new cell of row m (position m, per lane).
+template <int MT>
+ATR_DEV uint32_t column_step_pairs(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) / 32], uint32_t row0,
+                                   uint32_t insw, uint32_t delw, int mlo, int m) {
+    uint32_t cd = diag_candidate<false>(col[0], nm, 0);
+    col[0] = row0;
+    uint32_t wm = row0;
+#pragma unroll
+    for (int i = 1; i <= MT; ++i) {
+        uint32_t cd_next = 0;
+        if (i < MT) cd_next = diag_candidate<false>(col[i], nm, i);
+        const uint32_t cl = col[i] + delw;                   // deletion:  (i, j-1) -> (i, j)
+        const uint32_t cu = col[i - 1] + insw;               // insertion: (i-1, j) -> (i, j)
+        const uint32_t nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+        col[i] = nw;
+        wm = (i == m) ? nw : wm;                             // per-lane select (straight-line code; mlo unused)
+        cd = cd_next;
+    }
+    return wm;
+}
+
+template <int MT, bool AND_MODE>
+ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, const uint32_t *qp, int n, const PairParams &p,
+                             const int16_t *thr, uint32_t rec[4]) {
+    constexpr int NW = (MT + 31) / 32;
+    const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
+    const bool er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0, eq = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;
+    int k = (int)(p.e * m);                                            // _align.pyx:312
+    if (k < 0) k = -1;
+    int indel = p.indel_cost > k ? k + 1 : p.indel_cost;
+    if (indel < 1) indel = 1;
+    const uint32_t insw = (uint32_t)indel * COST1 + PRIO_INS, delw = (uint32_t)indel * COST1 + PRIO_DEL;
+    const uint32_t klimit = (uint32_t)(k + 1) << CSH;
+    const int max_n = sq ? n : atr_min(n, m + k);                      // :314-321
+    const int min_n = eq ? 0 : atr_max(0, n - m - k);
+    uint32_t col[MT + 1];
+#pragma unroll
+    for (int i = 0; i <= MT; ++i) {
+        // init_word(i, min_n, sr, sq, indel) (:333-352) as straight-line selects on the wave-uniform
+        // flags -- 153 unrolled copies of its if-chain would be 153 branch diamonds (rows > m: don't care)
+        const int d = min_n - i;
+        const int cost = (sr ? (sq ? atr_min(i, min_n) : min_n) : (sq ? i : atr_max(i, min_n))) * indel;
+        const int origin = sr ? (sq ? d : atr_min(0, d)) : (sq ? atr_max(0, d) : 0);
+        col[i] = ((uint32_t)atr_min(cost, INIT_COST_CAP) << CSH) | (uint32_t)(origin + (int)ORG_BIAS);
+    }
+    Best best;
+    best.key = COST_FIELD_MAX - (m + n);
+    best.word = (uint32_t)(m + n) << CSH;
+    best.ref_stop = m; best.query_stop = n; best.matches = 0;
+    uint32_t qword = 0;
+    for (int j = min_n + 1; j <= max_n; ++j) {
+        if (((j - 1) & 7) == 0 || j == min_n + 1) qword = qp[(size_t)((j - 1) >> 5) * 256 + (((j - 1) >> 3) & 3)];
+        const uint32_t qc = (qword >> (4 * ((j - 1) & 7))) & 15u;
+        uint32_t nm[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) nm[w] = ~tab[(size_t)(qc * NW + w) * ts];
+        const uint32_t row0 = sq ? (ORG_BIAS + (uint32_t)j)
+                                 : (ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
+        int mrow = m;
+#ifndef ATR_HOST_EMU
+        asm volatile("" : "+v"(mrow));                       // keep the 152 (i == m) lane masks out of the loop preheader
+#endif
+        const uint32_t wm = column_step_pairs<MT>(col, nm, row0, insw, delw, mlo, mrow);
+        if (eq && wm < klimit) consider<false>(best, wm, m, j, p.min_overlap, thr, indel);   // :433-455
+    }
+    if (max_n == n) {                                                   // :461-474
+        const int first = er ? 0 : m;
+#pragma unroll
+        for (int i = 0; i <= MT; ++i)
+            if (i >= first && i <= m) consider<false>(best, col[i], i, n, p.min_overlap, thr, indel);
+    }
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != m + n) {                                                // :476-480
+        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
 // Host side: thresholds and envelope check shared by the library and the emulation.
 inline int pairs_params(double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
                         int ref_max_len, int query_max_len, PairParams &p) {

@@ -38,6 +38,60 @@ __global__ __launch_bounds__(64) void pairs_kernel(const PairParams p, const uin
     out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 
+// Register-column variant (pairs_core.hpp): references of up to PAIRS_REG_MAX rows.
+template <int MT, bool AND_MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pairs_reg_kernel(const PairParams p, const uint32_t *__restrict__ ref_packed,
+                                                        const int32_t *__restrict__ ref_lens, int ref_chunks,
+                                                        int ref_max_len, int revcomp,
+                                                        const uint32_t *__restrict__ qry_packed,
+                                                        const int32_t *__restrict__ qry_lens, int qry_chunks,
+                                                        int qry_max_len, long long npairs, uint4 *__restrict__ out) {
+    constexpr int NW = (MT + 31) / 32;
+    __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pairs[];
+    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 3; i += 256) s_thr[i] = p.thr[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile = (long long)blockIdx.x * 4 + wave, r = tile * 64 + lane;
+    if (tile * 64 >= npairs) return;
+    const bool live = r < npairs;
+    uint32_t *tab = s_pairs + (size_t)wave * 16 * NW * 64 + lane;     // [code][word][lane]
+    const int m = live ? min(ref_lens ? ref_lens[r] : ref_max_len, ref_max_len) : 0;
+    const int n = live ? min(qry_lens ? qry_lens[r] : qry_max_len, qry_max_len) : 0;
+    const uint32_t *rp = ref_packed + ((size_t)tile * ref_chunks * 64 + lane) * 4;
+    const uint32_t *qp = qry_packed + ((size_t)tile * qry_chunks * 64 + lane) * 4;
+    build_match_masks<MT, AND_MODE>(tab, 64, rp, m, revcomp != 0);
+    int mlo = live ? m : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mlo = min(mlo, __shfl_xor(mlo, o, 64));
+    mlo = __builtin_amdgcn_readfirstlane(mlo);
+    uint32_t rec[4];
+    locate_pair_reg<MT, AND_MODE>(tab, 64, m, mlo, qp, n, p, s_thr, rec);
+    if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+}
+
+template <int MT>
+static hipError_t launch_pairs_reg(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
+                                   const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out,
+                                   hipStream_t st) {
+    constexpr int NW = (MT + 31) / 32;
+    const size_t lds = (size_t)4 * 16 * NW * 64 * 4;
+    const dim3 grid((unsigned)((npairs + 255) / 256)), block(256);
+    hipError_t e;
+    if (p.and_mode) {
+        e = hipFuncSetAttribute((const void *)pairs_reg_kernel<MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((pairs_reg_kernel<MT, true>), grid, block, lds, st, p, rp, rl, (rmax + 31) / 32, rmax, revcomp, qp,
+                           ql, (qmax + 31) / 32, qmax, npairs, out);
+    } else {
+        e = hipFuncSetAttribute((const void *)pairs_reg_kernel<MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((pairs_reg_kernel<MT, false>), grid, block, lds, st, p, rp, rl, (rmax + 31) / 32, rmax, revcomp, qp,
+                           ql, (qmax + 31) / 32, qmax, npairs, out);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace atr
 
 using namespace atr;
@@ -54,9 +108,16 @@ extern "C" int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t
     if (rc != ATR_OK) return rc;
     if (npairs == 0) return ATR_OK;
     if (!d_out || (ref_max_len > 0 && !d_ref_packed) || (query_max_len > 0 && !d_query_packed)) return ATR_ERR_INVALID;
+    hipError_t e;
+    if (ref_max_len <= PAIRS_REG_MAX) {                       // register-column kernel, smallest fitting size
+        const uint32_t *rp = (const uint32_t *)d_ref_packed, *qp = (const uint32_t *)d_query_packed;
+        if (ref_max_len <= 64) e = launch_pairs_reg<64>(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len, npairs, (uint4 *)d_out, (hipStream_t)stream);
+        else if (ref_max_len <= 104) e = launch_pairs_reg<104>(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len, npairs, (uint4 *)d_out, (hipStream_t)stream);
+        else e = launch_pairs_reg<152>(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len, npairs, (uint4 *)d_out, (hipStream_t)stream);
+        return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_reg_kernel launch");
+    }
     const size_t lds = ((size_t)(ref_max_len + 1) + (size_t)(ref_max_len + 7) / 8) * 64 * 4;
     const dim3 grid((unsigned)((npairs + 63) / 64)), block(64);
-    hipError_t e;
 #define ATR_LAUNCH_PAIRS(MODE)                                                                                         \
     do {                                                                                                               \
         e = hipFuncSetAttribute((const void *)pairs_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

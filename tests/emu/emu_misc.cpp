@@ -1,6 +1,7 @@
 // emu_misc.cpp -- TEST INFRASTRUCTURE.  CPU run of the per-thread code of
 // atropos_amd/csrc/misc_kernels.hip (misc_core.hpp, -DATR_HOST_EMU).
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -91,6 +92,25 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
         if (n > qry_max_len) n = qry_max_len;
         const uint32_t *rp = ref_packed + ((size_t)tile * rch * 64 + lane) * 4;
         const uint32_t *qp = qry_packed + ((size_t)tile * qch * 64 + lane) * 4;
+        if (ref_max_len <= atr::PAIRS_REG_MAX) {                     // as the library: register-column variant
+            // the wave's smallest m (select range of the row-m pick-up)
+            int mlo = 0x7fffffff;
+            for (int64_t t = tile * 64; t < std::min<int64_t>(npairs, tile * 64 + 64); ++t)
+                mlo = std::min(mlo, std::min(ref_lens ? ref_lens[t] : ref_max_len, ref_max_len));
+            uint32_t tab[16 * 5];
+#define ATR_EMU_REG(MT)                                                                                            \
+            do {                                                                                                       \
+                if (p.and_mode) { atr::build_match_masks<MT, true>(tab, 1, rp, m, revcomp != 0);                       \
+                                  atr::locate_pair_reg<MT, true>(tab, 1, m, mlo, qp, n, p, p.thr, out + 4 * r); }      \
+                else { atr::build_match_masks<MT, false>(tab, 1, rp, m, revcomp != 0);                                 \
+                       atr::locate_pair_reg<MT, false>(tab, 1, m, mlo, qp, n, p, p.thr, out + 4 * r); }                \
+            } while (0)
+            if (ref_max_len <= 64) ATR_EMU_REG(64);
+            else if (ref_max_len <= 104) ATR_EMU_REG(104);
+            else ATR_EMU_REG(152);
+#undef ATR_EMU_REG
+            continue;
+        }
         atr::stage_reference(refw.data(), 1, rp, m, revcomp != 0);
         if (p.and_mode) atr::locate_pair_one<true>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
         else atr::locate_pair_one<false>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
