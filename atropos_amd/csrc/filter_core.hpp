@@ -35,7 +35,7 @@
 namespace atr {
 
 constexpr int FILTER_MAX_M = 64;
-constexpr int FILTER_BINS = 192;                   // 96 window-start bins of 8 columns (n <= 736) x {all rows, fewer rows}
+constexpr int FILTER_BINS = 256;                   // 96 window-start bins of 8 columns (n <= 736) x 2 classes + 64 row-count bins
 
 struct FilterParams {
     uint64_t peq[16];                               // peq[c]: rows matching query code c, top-aligned (see FilterState); pad bits 1
@@ -52,9 +52,18 @@ ATR_DEV int window_lo(uint32_t w) { return (int)(w & 0x3FFu); }
 ATR_DEV int window_hi(uint32_t w) { return (int)((w >> 10) & 0x3FFu); }
 ATR_DEV bool window_scan(uint32_t w) { return ((w >> 20) & 1u) != 0; }
 ATR_DEV bool window_valid(uint32_t w) { return (w >> 31) != 0; }
-// Scatter bin: reads that need every row first (by window start), then the row-limited ones,
-// so that a wave of the window kernel rarely mixes the two kinds.
-ATR_DEV int window_bin(uint32_t w, int m) { return (window_lo(w) >> 3) + (window_rows(w) >= m ? 0 : 96); }
+// Scatter bin, chosen so that the 64 reads of a window-kernel wave sweep nearly the same
+// columns and rows.  Batches of equal-length reads (by_rows): [0, 96) reads with row-m
+// candidates only, by window start / 8 (their windows end ~m + 2k columns later); [96, 192)
+// reads that also have last-column candidates (windows reach the read end); [192, 256) the
+// row-limited partial overlaps at the read end (window = [n - rows - errors, n]) by row count,
+// which makes a wave uniform in rows AND window.  Ragged batches: all-rows reads by window
+// start in [0, 96), row-limited ones by window start in [96, 192).
+ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
+    const int rows = window_rows(w), start = window_lo(w) >> 3;
+    if (rows >= m) return start + ((by_rows && window_scan(w)) ? 96 : 0);
+    return by_rows ? 192 + atr_min(rows, 63) : 96 + start;
+}
 
 struct FilterState {
     uint32_t pvl, pvh, mvl, mvh;                    // vertical +1 / -1 deltas of the current column (lo/hi words)

@@ -22,7 +22,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     }
     hipLaunchKernelGGL(scan_bins_kernel, dim3(FILTER_BINS), dim3(1024), 0, st, wk);
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
-    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, wk);
+    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     typedef window_launcher (*group_fn)(int);

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
             const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
             wk.win[r] = ww;
             if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-            else atomicAdd(&s_hist[window_bin(ww, u.m)], 1u);
+            else atomicAdd(&s_hist[window_bin(ww, u.m, !RAGGED)], 1u);
         }
     }
     __syncthreads();
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void scan_total_kernel(FastWork wk) {
     }
 }
 
-__global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, FastWork wk) {
+__global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, int by_rows, FastWork wk) {
     __shared__ uint32_t s_cur[FILTER_BINS];
     if (threadIdx.x < FILTER_BINS)
         s_cur[threadIdx.x] = wk.binbase[threadIdx.x] + wk.counts[(size_t)threadIdx.x * FAST_BLOCKS + blockIdx.x];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, F
     block_tiles(ntiles, t0, t1);
     for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
         const uint32_t ww = wk.win[r];
-        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m)], 1u)] = (uint32_t)r;
+        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m, by_rows != 0)], 1u)] = (uint32_t)r;
     }
 }
 #endif  // ATR_DEFINE_FILTER_KERNELS

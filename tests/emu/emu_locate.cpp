@@ -102,7 +102,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
         win[r] = ww;
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
-        else bins[window_bin(ww, u.m)].push_back((uint32_t)r);
+        else bins[window_bin(ww, u.m, lens == nullptr)].push_back((uint32_t)r);
     }
     std::vector<uint32_t> order;                                   // K2 + K3
     for (auto &b : bins) order.insert(order.end(), b.begin(), b.end());
