@@ -57,3 +57,43 @@ def test_host_only_entry_points():
     assert lib.atr_aligner_query_table(h, buf) == _lib.TABLE_CUSTOM
     assert buf.raw[ord("F")] == 1 and buf.raw[ord("Z")] == 0
     lib.atr_aligner_destroy(h)
+
+
+def test_argument_validation_without_device():
+    """Every batch entry point validates its arguments before it touches the device, so bad
+    calls return ATR_ERR_INVALID / ATR_ERR_UNSUPPORTED even on a machine without a GPU."""
+    from atropos_amd import _lib
+    lib = _lib.load_library()
+    INVALID, UNSUPPORTED = -1, -2
+    tab = ctypes.create_string_buffer(256)
+    # nothing to do is fine, without pointers
+    assert lib.atr_pack_reads(None, 0, None, None, 0, 100, tab, None, None, None) == 0
+    assert lib.atr_pack_planes(None, 0, None, None, 0, 100, tab, None, None, None) == 0
+    assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 0, 0.2, 15, 0, 0, 1, 1, None, None) == 0
+    # negative sizes, missing tables, sizes beyond the envelope
+    assert lib.atr_pack_reads(None, 0, None, None, -1, 100, tab, None, None, None) == INVALID
+    assert lib.atr_pack_reads(None, 0, None, None, 1, 100, None, None, None, None) == INVALID
+    assert lib.atr_pack_reads(None, 0, None, None, 1, _lib.MAX_READ_LEN + 1, tab, None, None, None) == INVALID
+    assert lib.atr_locate_batch(None, None, None, 1, 100, None, None, None) == INVALID
+    assert lib.atr_insert_match_batch(None, None, None, None, None, 1, 100, None, None) == INVALID
+    assert lib.atr_locate_pairs_batch(None, None, 300, 0, None, None, 150, 1, 0.2, 15, 0, 0, 1, 1, None, None) == UNSUPPORTED
+    assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 0.2, 16, 0, 0, 1, 1, None, None) == INVALID
+    assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 0.2, 15, 0, 0, 0, 1, None, None) == INVALID
+    assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 2.0, 15, 0, 0, 1, 1, None, None) == UNSUPPORTED
+    assert lib.atr_fastq_count_lines(None, -1, None, None, None) == INVALID
+    assert lib.atr_fastq_count_lines(None, 1 << 33, None, None, None) == INVALID                 # chunk >= 4 GiB
+    assert lib.atr_fastq_index(None, 10, 3, None, None, 4, None, None, None) == INVALID           # strip is 1 or 2
+    assert lib.atr_pack_records(None, None, None, None, 1, 100, None, 0, None, None, None, None) == INVALID
+    assert lib.atr_clip_batch(None, None, None, 1, -1, 0, None) == INVALID
+    assert lib.atr_clip_batch(None, None, None, 1, 0, 1, None) == INVALID                         # back must be <= 0
+    assert lib.atr_quality_trim_batch(None, None, None, None, 1, 0, 20, 33, 0, None) == INVALID
+    assert lib.atr_nend_trim_batch(None, None, None, None, None, None, 1, None) == INVALID
+    assert lib.atr_match_trim_batch(None, None, 0, None, None, None, None, 1, None) == INVALID
+    assert lib.atr_read_filter_batch(None, None, None, None, None, None, None, 1, 0, -1, -1.0, 0, 0, None, None, None) == INVALID
+    assert lib.atr_pair_filter_batch(None, None, 1, 3, None, None) == INVALID                     # min_affected is 1 or 2
+    assert lib.atr_insert_plan_batch(None, None, None, None, None, None, None, None, None, None, None, None, None, 1, 1,
+                                     1, 3, -1, 1, None, None, None, None, None, None) == INVALID  # trim_action 0..2
+    assert lib.atr_fastq_emit(None, None, None, None, None, None, None, 0, 1, 0, None, None, None, None) == INVALID
+    assert lib.atr_adapter_postfilter(None, 0, 10, 3, 0.1, None, 0, 0.0, 0, None) == 0
+    assert lib.atr_fastq_work_bytes(-5) == 0 and lib.atr_fastq_emit_work_bytes(-5) == 0
+    assert lib.atr_fastq_work_bytes(1 << 20) > 0 and lib.atr_locate_work_bytes(1000) > 8000
