@@ -37,8 +37,16 @@ class FastqBatch(object):
         strip: the file's line-end width (1 or 2).
     """
 
-    def __init__(self, data, nbytes, records, strip, backend):
+    def __init__(self, data, nbytes, records, strip, backend, line_ends=None):
         self.data, self.nbytes, self.records, self.strip, self.backend = data, nbytes, records, strip, backend
+        self.line_ends = line_ends
+
+    def head(self, nrec):
+        """The first ``nrec`` records as a batch of their own, and the number of bytes of text
+        they occupy (paired files are consumed in lock step: the shorter chunk decides)."""
+        nrec = min(int(nrec), len(self))
+        consumed = int(self.line_ends[4 * nrec - 1].item()) + 1 if nrec else 0
+        return FastqBatch(self.data, self.nbytes, self.records[:nrec], self.strip, self.backend, self.line_ends), consumed
 
     def __len__(self):
         return self.records.shape[0]
@@ -91,7 +99,7 @@ class FastqBatch(object):
         consumed = nbytes
         if not final:
             consumed = int(line_ends[4 * nrec - 1].item()) + 1 if nrec else 0
-        return cls(data, nbytes, records[:nrec], strip, be), consumed
+        return cls(data, nbytes, records[:nrec], strip, be, line_ends), consumed
 
     @staticmethod
     def _raise_format_error(buf, line_ends, err, strip):

@@ -370,6 +370,42 @@ class PairedTrimPipeline(object):
         res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
         return PairedTrimResult(res[0], res[1])
 
+    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20):
+        """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
+        same number from each file); returns the destination counts."""
+        totals = {name: 0 for name in DEST_NAMES.values()}
+        strips, carry = [None, None], [b"", b""]
+        with open(in1, "rb") as f1, open(in2, "rb") as f2, open(out1, "wb") as o1, open(out2, "wb") as o2:
+            files = (f1, f2)
+            while True:
+                bufs, finals = [], []
+                for k in range(2):
+                    block = files[k].read(chunk_bytes)
+                    finals.append(len(block) < chunk_bytes)
+                    bufs.append(carry[k] + block)
+                    if strips[k] is None and bufs[k]:
+                        nl = bufs[k].find(b"\n")
+                        strips[k] = 2 if (bufs[k][:nl + 1] if nl >= 0 else bufs[k]).endswith(b"\r\n") else 1
+                batches = [FastqBatch.from_bytes(bufs[k], final=finals[k], strip=strips[k])[0] for k in range(2)]
+                nrec = min(len(batches[0]), len(batches[1]))
+                done = all(finals)
+                if done and len(batches[0]) != len(batches[1]):
+                    raise ValueError("the two input files hold different numbers of records")
+                heads = [batches[k].head(nrec) for k in range(2)]
+                for k in range(2):
+                    carry[k] = bufs[k][heads[k][1]:]
+                res = self.run(heads[0][0], heads[1][0])
+                t1, t2 = res.text(_lib.DEST_KEEP)
+                o1.write(t1)
+                o2.write(t2)
+                for name, v in res.counts().items():
+                    totals[name] += v
+                if done:
+                    break
+                if nrec == 0 and not any(len(b) for b in bufs):
+                    break
+        return totals
+
     def trim_bytes(self, data1, data2, which=_lib.DEST_KEEP):
         """Two FASTQ texts in (same number of records), the two trimmed texts out."""
         b1, _ = FastqBatch.from_bytes(data1, final=True)

@@ -630,3 +630,21 @@ def check_trim_golden_paired():
             assert hashlib.sha256(out).hexdigest() == want["sha256"], (label, k)
         done += 1
     return done
+
+
+def check_paired_file_chunking(tmp_path):
+    """PairedTrimPipeline.trim_files in small lock-step chunks == one batch."""
+    import base64
+    from atropos_amd.trim import pipeline_from_args
+    doc = load_golden("trim_cases.json.gz")
+    d1, d2 = (base64.b64decode(doc["inputs"][k]) for k in ("synth_pe.1.fastq", "synth_pe.2.fastq"))
+    case = [c for c in doc["paired"] if c["input1"] == "synth_pe.1.fastq" and "-q 20 -m 30" in c["args"]][0]
+    w1, w2 = pipeline_from_args(case["args"]).trim_bytes(d1, d2)
+    paths = [tmp_path / n for n in ("a1.fastq", "a2.fastq", "o1.fastq", "o2.fastq")]
+    paths[0].write_bytes(d1)
+    paths[1].write_bytes(d2)
+    counts = pipeline_from_args(case["args"]).trim_files(str(paths[0]), str(paths[1]), str(paths[2]), str(paths[3]),
+                                                         chunk_bytes=30000)
+    assert paths[2].read_bytes() == w1 and paths[3].read_bytes() == w2
+    assert sum(counts.values()) == d1.count(b"\n") // 4
+    return counts

@@ -27,3 +27,8 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
 
 def test_paired_pipeline_reference_cli_cases(emu_backend):
     assert _cases.check_trim_golden_paired() >= 20
+
+
+def test_paired_file_chunking(emu_backend, tmp_path):
+    counts = _cases.check_paired_file_chunking(tmp_path)
+    assert counts["keep"] > 0 and counts["too_short"] > 0
