@@ -43,26 +43,32 @@ struct FilterParams {
 
 // window word written per read by the pre-pass
 //   [9:0] j_lo   [19:10] j_hi   [20] take last-column candidates   [27:21] highest row needed
+//   [28] band: only row-m candidates, all of them inside BAND_W diagonals from j_lo on
 //   [31] valid (needs the DP)
-ATR_DEV uint32_t window_word(int j_lo, int j_hi, bool scan, int rows) {
-    return 0x80000000u | (uint32_t)j_lo | ((uint32_t)j_hi << 10) | (scan ? (1u << 20) : 0u) | ((uint32_t)rows << 21);
+constexpr int BAND_W = 16;
+ATR_DEV uint32_t window_word(int j_lo, int j_hi, bool scan, int rows, bool band) {
+    return 0x80000000u | (uint32_t)j_lo | ((uint32_t)j_hi << 10) | (scan ? (1u << 20) : 0u) | ((uint32_t)rows << 21) |
+           (band ? (1u << 28) : 0u);
 }
+ATR_DEV bool window_band(uint32_t w) { return ((w >> 28) & 1u) != 0; }
 ATR_DEV int window_rows(uint32_t w) { return (int)((w >> 21) & 0x7Fu); }
 ATR_DEV int window_lo(uint32_t w) { return (int)(w & 0x3FFu); }
 ATR_DEV int window_hi(uint32_t w) { return (int)((w >> 10) & 0x3FFu); }
 ATR_DEV bool window_scan(uint32_t w) { return ((w >> 20) & 1u) != 0; }
 ATR_DEV bool window_valid(uint32_t w) { return (w >> 31) != 0; }
-// Scatter bin, chosen so that the 64 reads of a window-kernel wave sweep nearly the same
-// columns and rows.  Batches of equal-length reads (by_rows): [0, 96) reads with row-m
-// candidates only, by window start / 8 (their windows end ~m + 2k columns later); [96, 192)
-// reads that also have last-column candidates (windows reach the read end); [192, 256) the
-// row-limited partial overlaps at the read end (window = [n - rows - errors, n]) by row count,
-// which makes a wave uniform in rows AND window.  Ragged batches: all-rows reads by window
-// start in [0, 96), row-limited ones by window start in [96, 192).
+// Scatter bin, chosen so that the 64 reads of a wave sweep nearly the same cells.
+//   [0, 96)    band reads (band_locate below), by window start / 8;
+//   [96, 192)  reads that need every row of the column sweep, by window start / 8 -- and, in
+//              ragged batches, the row-limited ones too;
+//   [192, 256) equal-length batches (by_rows): the row-limited partial overlaps at the read end
+//              (window = [n - rows - errors, n]) by row count, which makes a wave uniform in
+//              rows AND window.
+constexpr int BAND_BINS = 96;
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
-    if (rows >= m) return start + ((by_rows && window_scan(w)) ? 96 : 0);
-    return by_rows ? 192 + atr_min(rows, 63) : 96 + start;
+    if (window_band(w)) return start;
+    if (rows >= m || !by_rows) return 96 + start;
+    return 192 + atr_min(rows, 63);
 }
 
 struct FilterState {
@@ -236,10 +242,124 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, int n, co
     if (lastcol) j_lo = atr_min(j_lo, n - row_l - (u.indel == 1 ? cost_l : u.k));
     j_lo = atr_max(0, j_lo);
     const int j_hi = lastcol ? n : F.j_last;
+    // Band: with row-m candidates only, a candidate ending in column j (j_first <= j <= j_last,
+    // cost <= k) keeps to the diagonals j - m - k .. j - m + k (at most k of its steps are
+    // indels), so every traceback lies on the diagonals j_lo .. j_last - m + k -- provided j_lo
+    // was not clamped at 0 (no traceback then touches column 0).
+    const bool band = rowm && !lastcol && (F.j_first - u.m - u.k >= 0) &&
+                      (F.j_last - F.j_first + 2 * u.k <= BAND_W - 1);
     // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
     // last-column row can matter (a row only depends on the rows before it)
-    return window_word(j_lo, j_hi, lastcol, rowm ? u.m : row_l);
+    return window_word(j_lo, j_hi, lastcol, rowm ? u.m : row_l, band);
 }
+
+// ---- banded DP for the band reads --------------------------------------------------------
+// Row-major sweep over the BAND_W diagonals d = j - i = j_lo + c, c = 0 .. BAND_W-1, of one read:
+// the state is one register per diagonal, cell (i, c) is computed from (i-1, c) [diagonal
+// step], (i-1, c+1) [insertion] and (i, c-1) [deletion], in place and in increasing c; cells
+// outside the band count as unreachable, which is exact for the same reason the column
+// window is (every traceback of an acceptable candidate lies inside; a neighbour that is too
+// large never wins a comparison it would have lost).  Same packed cell word and v_min3
+// tie-break as locate_core.hpp, payload = diagonal mismatches (XREP).  The reference row is
+// wave-uniform, the read is a 16-base window sliding by one base per row.  About 9 VALU ops
+// per cell, but m * (S + 1) cells instead of m * (m + 2k + S) in the column sweep.
+struct BandParams {
+    uint8_t codes[FILTER_MAX_M];                     // reference code of row i at codes[i - 1]
+    int and_mode, noindel;
+};
+
+// 4-bit code of base j (1-based) of a tile64-packed read (q = the lane's chunk 0, uint32 view), 0 beyond it
+ATR_DEV uint32_t read_base(const uint32_t *q, int nchunks, int j) {
+    const int z = j - 1;
+    if (z < 0 || z >= nchunks * 32) return 0u;
+    return (q[(size_t)(z >> 5) * 256 + ((z >> 3) & 3)] >> (4 * (z & 7))) & 15u;
+}
+
+// The bases dlo + 1 .. dlo + 8 * BAND_STREAM of the read as BAND_STREAM dwords of eight
+// bases (ns[k * nss] = bases dlo + 1 + 8k ..): the aligned dwords that hold them are gathered
+// with independent loads and re-aligned to the band start with a per-lane funnel shift, so
+// that the row loop never waits for memory.
+constexpr int BAND_STREAM = (FILTER_MAX_M + BAND_W + 7) / 8 + 1;      // 11 dwords: rows 1 .. 64, 16 diagonals
+
+ATR_DEV uint32_t read_dword(const uint32_t *q, int nchunks, int z8) {          // dword z8 (bases 8*z8 + 1 ..), 0 beyond the read
+    if (z8 < 0 || z8 >= nchunks * 4) return 0u;
+    return q[(size_t)(z8 >> 2) * 256 + (z8 & 3)];
+}
+
+ATR_DEV void band_stage(const uint32_t *q, int nchunks, int dlo, uint32_t *ns, int nss) {
+    const int z0 = dlo >> 3;                          // dlo + 1 is base (dlo & 7) of dword z0 (0-based base index dlo)
+    const uint32_t sh = 4u * (uint32_t)(dlo & 7);
+    uint32_t raw[BAND_STREAM + 1];
+#pragma unroll
+    for (int k = 0; k <= BAND_STREAM; ++k) raw[k] = read_dword(q, nchunks, z0 + k);
+#pragma unroll
+    for (int k = 0; k < BAND_STREAM; ++k)
+        ns[(size_t)k * nss] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
+}
+
+// ns: the staged read (band_stage), stride nss.
+template <bool AND_MODE>
+ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
+                         uint32_t ww, int smax, const int16_t *thr, uint32_t rec[4]) {
+    const int dlo = window_lo(ww), j_hi = window_hi(ww);
+    const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
+    uint32_t band[BAND_W];
+#pragma unroll
+    for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
+    // bases dlo + i + c of the read, c = 0 .. 15, for row i = 1: stream nibbles 0 .. 15
+    uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
+    uint32_t feed = ns[(size_t)2 * nss];              // the dword the next bases come from
+    for (int i = 1; i <= u.m; ++i) {
+        const uint32_t rrep = (uint32_t)codes[i - 1] * 0x11111111u;
+        const uint32_t v0 = AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep), v1 = AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep);
+        uint32_t m0 = (v0 | (v0 >> 1) | (v0 >> 2) | (v0 >> 3)) & 0x11111111u;       // nibble != 0
+        uint32_t m1 = (v1 | (v1 >> 1) | (v1 >> 2) | (v1 >> 3)) & 0x11111111u;
+        if (AND_MODE) { m0 ^= 0x11111111u; m1 ^= 0x11111111u; }                   // mismatch = no common bit
+        uint32_t left = inf;
+#pragma unroll
+        for (int c = 0; c < BAND_W; ++c) {
+            if (c <= smax) {                                                        // wave-uniform
+                const uint32_t bit = ((c < 8 ? m0 : m1) >> (4 * (c & 7))) & 1u;
+                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
+                const uint32_t up = (c + 1 < BAND_W && c + 1 <= smax) ? band[(c + 1 < BAND_W) ? c + 1 : 0] : inf;
+                const uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
+                band[c] = nw;
+                left = nw;
+            }
+        }
+        // slide the window by one base: stream nibble i + 15 comes in at the top
+        qw0 = (qw0 >> 4) | (qw1 << 28);
+        qw1 = (qw1 >> 4) | (feed << 28);
+        feed >>= 4;
+        if ((i & 7) == 0) {                           // wave-uniform: the next stream dword
+            const int k = 2 + (i >> 3);
+            feed = k < BAND_STREAM ? ns[(size_t)k * nss] : 0u;
+        }
+    }
+    Best best;
+    best.key = COST_FIELD_MAX - (u.m + n);
+    best.word = (uint32_t)(u.m + n) << CSH;
+    best.ref_stop = u.m; best.query_stop = n; best.matches = 0;
+    const int cindel = noindel ? 0 : u.indel;
+#pragma unroll
+    for (int c = 0; c < BAND_W; ++c) {
+        const int j = dlo + u.m + c;
+        if (c <= smax && band[c] < u.klimit && j <= j_hi) consider<true>(best, band[c], u.m, j, u.min_overlap, thr, cindel);
+    }
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != u.m + n) {
+        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
 
 }  // namespace atr
 #endif

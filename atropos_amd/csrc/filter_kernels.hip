@@ -23,6 +23,16 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     hipLaunchKernelGGL(scan_bins_kernel, dim3(FILTER_BINS), dim3(1024), 0, st, wk);
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
     hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
+    {   // K4a: banded DP over the band reads
+        BandParams bp;
+        memset(&bp, 0, sizeof(bp));
+        for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.codes[i] = (uint8_t)a->codes[i];
+        bp.and_mode = (a->wildcard_ref || a->wildcard_query) ? 1 : 0;
+        bp.noindel = a->indel_cost > a->p.k ? 1 : 0;
+        const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 2048));
+        if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
+        else             hipLaunchKernelGGL((band_kernel<false>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     typedef window_launcher (*group_fn)(int);

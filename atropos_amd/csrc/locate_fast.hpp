@@ -170,6 +170,39 @@ __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, i
         if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m, by_rows != 0)], 1u)] = (uint32_t)r;
     }
 }
+// K4a: the banded DP over the band reads = the slots [0, binbase[BAND_BINS]) of `order`
+// (persistent grid like K4; reads gathered by index).
+template <bool AND_MODE>
+__global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const BandParams bp,
+                                                   const uint4 *__restrict__ packed, const int32_t *__restrict__ lens,
+                                                   long long nreads, int nchunks, int max_len, uint4 *__restrict__ out,
+                                                   FastWork wk) {
+    __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
+    __shared__ uint8_t s_codes[FILTER_MAX_M];
+    __shared__ uint32_t s_stream[4][BAND_STREAM][64];              // per wave: the staged reads, [dword][lane]
+    const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
+    for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
+    if (threadIdx.x < FILTER_MAX_M) s_codes[threadIdx.x] = bp.codes[threadIdx.x];
+    __syncthreads();
+    const long long total = (long long)wk.binbase[BAND_BINS];          // band reads come first in `order`
+    const int lane = threadIdx.x & 63;
+    const long long nwaves = (total + 63) >> 6;
+    for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwaves; wv += (long long)gridDim.x * 4) {
+        const long long slot = wv * 64 + lane;
+        const bool live = slot < total;
+        const long long r = live ? (long long)wk.order[slot] : 0;
+        const uint32_t ww = live ? wk.win[r] : 0u;
+        const int n = live ? (lens ? lens[r] : max_len) : 0;
+        const int s_lane = live ? window_hi(ww) - u.m + u.k - window_lo(ww) : 0;
+        const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
+        const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
+        uint32_t *ns = &s_stream[threadIdx.x >> 6][0][lane];
+        band_stage(q, nchunks, window_lo(ww), ns, 64);
+        uint32_t rec[4];
+        band_locate<AND_MODE>(u, s_codes, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
+        if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+}
 #endif  // ATR_DEFINE_FILTER_KERNELS
 
 template <int MT, bool NOINDEL>
@@ -186,12 +219,13 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
     }
     __syncthreads();
-    const long long total = (long long)wk.total[0];
+    // the slots [first, total) of `order`: everything but the band reads (K4a)
+    const long long first = (long long)wk.binbase[BAND_BINS], total = (long long)wk.total[0];
     const int lane = threadIdx.x & 63;
-    const long long nwaves = (total + 63) >> 6;
+    const long long nwaves = (total - first + 63) >> 6;
     // persistent grid: each wave takes every (gridDim*4)-th group of 64 slots of `order`
     for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwaves; wv += (long long)gridDim.x * 4) {
-        const long long slot = wv * 64 + lane;
+        const long long slot = first + wv * 64 + lane;
         const bool live = slot < total;
         const long long r = live ? (long long)wk.order[slot] : 0;
         const uint32_t ww = live ? wk.win[r] : 0u;

@@ -152,7 +152,7 @@ def main():
                        "parallelism": "shard%d" % world, "matched_fraction": n_found / args.reads},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, filtered),
-                         "kernel": ("filter_kernel + scan + scatter + window_kernel<36,eq,indel> (one "
+                         "kernel": ("filter_kernel + scan + scatter + band_kernel + window_kernel<36,eq,indel> (one "
                                     "atr_locate_batch call)" if filtered else "locate_kernel<36,eq,indel>"),
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,

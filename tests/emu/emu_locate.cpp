@@ -107,8 +107,32 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
     std::vector<uint32_t> order;                                   // K2 + K3
     for (auto &b : bins) order.insert(order.end(), b.begin(), b.end());
     const long long total = (long long)order.size();
+    long long nband = 0;                                           // band reads come first (bins [0, BAND_BINS))
+    for (int b = 0; b < BAND_BINS; ++b) nband += (long long)bins[b].size();
+    {                                                              // K4a: banded DP, one wave at a time
+        uint8_t codes[FILTER_MAX_M] = {0};
+        for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint8_t)a->codes[i];
+        const bool and_mode = a->wildcard_ref || a->wildcard_query, noindel = a->indel_cost > p.k;
+        for (long long base = 0; base < nband; base += 64) {
+            int smax = 0;
+            for (int lane = 0; lane < 64 && base + lane < nband; ++lane) {
+                const uint32_t ww = win[order[base + lane]];
+                smax = std::max(smax, window_hi(ww) - u.m + u.k - window_lo(ww));
+            }
+            smax = std::min(smax, BAND_W - 1);
+            for (int lane = 0; lane < 64 && base + lane < nband; ++lane) {
+                const long long r = order[base + lane];
+                const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
+                const int n = lens ? lens[r] : max_len;
+                uint32_t ns[BAND_STREAM];
+                band_stage(q, nchunks, window_lo(win[r]), ns, 1);
+                if (and_mode) band_locate<true>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
+                else band_locate<false>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
+            }
+        }
+    }
     std::vector<LaneState<MT>> L(64);
-    for (long long base = 0; base < total; base += 64) {           // K4, one wave at a time
+    for (long long base = nband; base < total; base += 64) {       // K4, one wave at a time
         int jlo = 0x7fffffff, jhi = 0, rows = 0;
         long long rr[64];
         bool live[64];
