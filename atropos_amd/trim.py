@@ -205,26 +205,87 @@ class TrimPipeline(object):
 
     def trim_file(self, path_in, path_out, chunk_bytes=256 << 20):
         """Stream a FASTQ file through the GPU in chunks of whole records; returns the
-        destination counts.  (Plain files; compressed input is the caller's business.)"""
+        destination counts.  (Plain files; compressed input is the caller's business.)
+
+        Host side: the file is read straight into page-locked staging buffers (no intermediate
+        bytes objects), the next chunk is read and the previous result written by two helper
+        threads while the GPU works on the current one, and results come back into page-locked
+        memory that is handed to ``write`` as a memoryview."""
+        from concurrent.futures import ThreadPoolExecutor
+        import os
+        be = _lib.get_backend()
+        on_gpu = getattr(be, "name", "") == "hip"
         totals = {name: 0 for name in DEST_NAMES.values()}
+        cap = chunk_bytes + (64 << 20)                       # room for the carried-over tail of the previous chunk
+        # page-locked staging buffers are expensive to create: keep them with the pipeline
+        stage = getattr(self, "_staging", None)
+        if stage is None or stage[0].numel() < cap + 32:
+            def staging(nbytes):
+                t = torch.empty((nbytes,), dtype=torch.uint8)
+                return t.pin_memory() if on_gpu else t
+            stage = self._staging = [staging(cap + 32) for _ in range(4)]     # 2 x input, 2 x output
+        inbuf, outbuf = stage[:2], stage[2:]
+        readers = ThreadPoolExecutor(4)
+        file_size = os.path.getsize(path_in)
+        state = {"pos": 0}
+
+        def read_chunk(fd, k, carry):
+            """carry: bytes left over from the previous chunk; returns (bytes in buffer, final).
+            The chunk is read by four threads (pread into slices of the page-locked buffer)."""
+            view = memoryview(inbuf[k].numpy())
+            n0 = len(carry)
+            if n0:
+                view[:n0] = carry
+            want = min(chunk_bytes, file_size - state["pos"])
+            step = (want + 3) // 4
+            jobs = []
+            for t in range(4):
+                lo, hi = t * step, min(want, (t + 1) * step)
+                if hi > lo:
+                    jobs.append(readers.submit(os.preadv, fd, [view[n0 + lo:n0 + hi]], state["pos"] + lo))
+            got = sum(j.result() for j in jobs)
+            state["pos"] += got
+            return n0 + got, state["pos"] >= file_size
+
         strip = None
-        carry = b""
-        with open(path_in, "rb") as fin, open(path_out, "wb") as fout:
+        with open(path_in, "rb") as fin_obj, open(path_out, "wb") as fout, ThreadPoolExecutor(2) as pool:
+            fin = fin_obj.fileno()
+            k = 0
+            nbytes, final = read_chunk(fin, k, b"")
+            pending_write = None
             while True:
-                block = fin.read(chunk_bytes)
-                final = len(block) < chunk_bytes
-                buf = carry + block
-                if strip is None and buf:
-                    nl = buf.find(b"\n")
-                    strip = 2 if (buf[:nl + 1] if nl >= 0 else buf).endswith(b"\r\n") else 1
-                batch, consumed = FastqBatch.from_bytes(buf, final=final, strip=strip)
-                carry = buf[consumed:] if not final else b""
+                host = inbuf[k]
+                if strip is None and nbytes:
+                    head = bytes(host[:min(nbytes, 1 << 16)].numpy().tobytes())
+                    nl = head.find(b"\n")
+                    strip = 2 if (head[:nl + 1] if nl >= 0 else head).endswith(b"\r\n") else 1
+                if final and nbytes and int(host[nbytes - 1]) != 10:
+                    host[nbytes] = 10                         # tolerate a missing last newline (_seqio.pyx:240-243)
+                    nbytes += 1
+                padded = (nbytes + 15) // 16 * 16 + 16
+                data = be.empty((padded,), torch.uint8)
+                data[:nbytes].copy_(host[:nbytes], non_blocking=True)
+                data[nbytes:].zero_()
+                batch, consumed = FastqBatch.from_device(data, nbytes, strip or 1, final, be)
+                carry = b"" if final else bytes(host[consumed:nbytes].numpy().tobytes())
+                nxt = None if final else pool.submit(read_chunk, fin, 1 - k, carry)     # overlaps the GPU work below
                 res = self.run(batch)
-                fout.write(res.text(_lib.DEST_KEEP))
-                for k, v in res.counts().items():
-                    totals[k] += v
+                text = be.fastq_emit(batch.data, batch.records, res.begin, res.end, res.ubegin, res.uend, res.dest,
+                                     _lib.DEST_KEEP)
+                if pending_write is not None:
+                    pending_write.result()                    # the other output buffer is free again after this
+                out_host = outbuf[k]
+                out_host[:text.numel()].copy_(text)
+                pending_write = pool.submit(fout.write, memoryview(out_host.numpy())[:int(text.numel())])
+                for name, v in res.counts().items():
+                    totals[name] += v
                 if final:
                     break
+                nbytes, final = nxt.result()
+                k = 1 - k
+            if pending_write is not None:
+                pending_write.result()
+        readers.shutdown()
         return totals
 
 
