@@ -80,7 +80,7 @@ PROTOTYPES = {
                                          C.c_void_p]),
     "atr_fastq_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_fastq_count_lines": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "atr_fastq_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+    "atr_fastq_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
     "atr_pack_records": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
                                    C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -316,7 +316,7 @@ class HipBackend(object):
         return out
 
     # -- device-resident FASTQ batch --------------------------------------------
-    def fastq_index(self, data, nbytes, strip):
+    def fastq_index(self, data, nbytes):
         """data: uint8 device tensor holding nbytes of FASTQ text (16-byte aligned, readable up
         to the next multiple of 16).  Returns (records uint32 [nrec, 8], nlines, error word)."""
         work = self.empty((max(self.lib.atr_fastq_work_bytes(nbytes), 16),), torch.uint8)
@@ -327,7 +327,7 @@ class HipBackend(object):
             nlines = int(info[0].item())
             line_ends = self.empty((max(nlines, 1),), torch.int32)
             records = self.empty((nlines // 4, 8), torch.int32)
-            _check(self.lib, self.lib.atr_fastq_index(_ptr(data), nbytes, strip, _ptr(work), _ptr(line_ends), nlines,
+            _check(self.lib, self.lib.atr_fastq_index(_ptr(data), nbytes, _ptr(work), _ptr(line_ends), nlines,
                                                       _ptr(records), C.c_void_p(info.data_ptr() + 8), self._stream()),
                    "atr_fastq_index")
             err = int(info[1].item())

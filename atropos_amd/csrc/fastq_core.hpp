@@ -38,46 +38,51 @@ struct FastqRecord {
     uint32_t reserved;
 };
 
-// Line L (0-based) is bytes [start, end] where end = line_ends[L] is the position of its
-// '\n' and start = L ? line_ends[L-1] + 1 : 0.  `strip` is the reference's per-file line-end
-// width (1, or 2 when the FIRST line of the file ends in "\r\n": _seqio.pyx:205).
+// Line terminators follow Python's universal-newline text mode, which is how the reference
+// reads its input (xopen(..., 'r')): "\n", "\r\n" and a lone "\r" each end a line.  Line L
+// (0-based) is the bytes [start, end] where end = line_ends[L] is the position of the LAST byte
+// of its terminator and start = L ? line_ends[L-1] + 1 : 0.
+ATR_DEV bool is_line_end(uint8_t c, uint8_t next) { return c == '\n' || (c == '\r' && next != '\n'); }
+
+// content length of the line [start, end]: without its terminator ("\r\n" counts as one).
+// A '\r' in front of the terminator's last byte can only be the first half of "\r\n" (a lone
+// one would have ended the line itself).  has_cr: whether the chunk holds any '\r' at all.
+ATR_DEV uint32_t line_content(const uint8_t *bytes, uint32_t start, uint32_t end, bool has_cr) {
+    uint32_t len = end - start;                                      // drop the terminator's last byte
+    if (has_cr && len > 0 && bytes[end - 1] == '\r') --len;
+    return len;
+}
+
 // Returns 0 or an ATR_FASTQ_ERR_* code (the record is still written, for the message).
-ATR_DEV int fastq_record_one(const uint8_t *bytes, const uint32_t *line_ends, long long r, int strip, FastqRecord &rec) {
+// (After newline translation every line the reference sees ends in "\n", so its `strip` is -1.)
+ATR_DEV int fastq_record_one(const uint8_t *bytes, const uint32_t *line_ends, long long r, bool has_cr, FastqRecord &rec) {
     const long long L = 4 * r;
     const uint32_t s0 = L ? line_ends[L - 1] + 1 : 0u;
     const uint32_t e0 = line_ends[L], e1 = line_ends[L + 1], e2 = line_ends[L + 2], e3 = line_ends[L + 3];
     const uint32_t s1 = e0 + 1, s2 = e1 + 1, s3 = e2 + 1;
-    const uint32_t len0 = e0 - s0 + 1, len1 = e1 - s1 + 1, len2 = e2 - s2 + 1, len3 = e3 - s3 + 1;   // with '\n'
+    const uint32_t c0 = line_content(bytes, s0, e0, has_cr), c1 = line_content(bytes, s1, e1, has_cr),
+                   c2 = line_content(bytes, s2, e2, has_cr), c3 = line_content(bytes, s3, e3, has_cr);
     int err = 0;
-    // line 1: '@' + name                                            (_seqio.pyx:208-216)
-    if (bytes[s0] != '@') err = ATR_FASTQ_ERR_AT;
+    // line 1: '@' + name = line[1:-1]                               (_seqio.pyx:208-216)
+    if (c0 == 0 || bytes[s0] != '@') err = ATR_FASTQ_ERR_AT;
     rec.name_off = s0 + 1;
-    rec.name_len = len0 > 1u + (uint32_t)strip ? len0 - 1u - (uint32_t)strip : 0u;          // line[1:strip]
-    // line 2: sequence = line[:strip]                               (:217-218)
+    rec.name_len = c0 > 0 ? c0 - 1 : 0u;
+    // line 2: sequence = line[:-1]                                  (:217-218)
     rec.seq_off = s1;
-    rec.seq_len = len1 > (uint32_t)strip ? len1 - (uint32_t)strip : 0u;
+    rec.seq_len = c1;
     // line 3: '+' or '+' + name                                     (:219-238)
     rec.flags = 0;
-    if (!(len2 == 2 && bytes[s2] == '+')) {                          // not the common "+\n"
-        const uint32_t l2 = len2 > (uint32_t)strip ? len2 - (uint32_t)strip : 0u;            // line[:strip]
-        if (l2 == 0 || bytes[s2] != '+') {
-            if (!err) err = ATR_FASTQ_ERR_PLUS;
-        } else if (l2 > 1) {
-            bool same = (l2 - 1 == rec.name_len);
-            for (uint32_t i = 0; same && i < rec.name_len; ++i) same = bytes[s2 + 1 + i] == bytes[rec.name_off + i];
-            if (!same) { if (!err) err = ATR_FASTQ_ERR_NAME2; }
-            else rec.flags = 1;
-        }
+    if (c2 == 0 || bytes[s2] != '+') {
+        if (!err) err = ATR_FASTQ_ERR_PLUS;
+    } else if (c2 > 1) {
+        bool same = (c2 - 1 == rec.name_len);
+        for (uint32_t i = 0; same && i < rec.name_len; ++i) same = bytes[s2 + 1 + i] == bytes[rec.name_off + i];
+        if (!same) { if (!err) err = ATR_FASTQ_ERR_NAME2; }
+        else rec.flags = 1;
     }
     // line 4: qualities                                             (:239-243)
     rec.qual_off = s3;
-    if (len3 == rec.seq_len + (uint32_t)strip) {
-        rec.qual_len = rec.seq_len;
-    } else {
-        uint32_t q = len3;                                           // rstrip('\r\n')
-        while (q > 0 && (bytes[s3 + q - 1] == '\n' || bytes[s3 + q - 1] == '\r')) --q;
-        rec.qual_len = q;
-    }
+    rec.qual_len = c3;
     if (rec.qual_len != rec.seq_len && !err) err = ATR_FASTQ_ERR_LENGTH;                      // _seqio.pyx:33-43
     rec.reserved = 0;
     return err;

@@ -96,29 +96,51 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_add_kernel(long long *__restr
 // ------------------------------------------------------------------------- line index
 constexpr int NL_THREADS = 256, NL_BLOCK_BYTES = NL_THREADS * 16;
 
-// bit i set <=> byte i of the 16 bytes at `off` is '\n' (bytes at or beyond nbytes masked out)
-__device__ __forceinline__ uint32_t newline_mask16(const uint8_t *bytes, long long off, long long nbytes) {
+// one bit per byte of a dword: 0x80 in every byte equal to c, gathered into the low 4 bits
+__device__ __forceinline__ uint32_t byte_eq_mask4(uint32_t w, uint32_t crep) {
+    const uint32_t x = w ^ crep;
+    const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);     // 0x80 in every zero byte
+    const uint32_t m = z >> 7;
+    return (m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu;
+}
+
+// bit i set <=> byte i of the 16 bytes at `off` ends a line (universal newlines: "\n", or a
+// "\r" that is not followed by "\n"); bytes at or beyond nbytes are masked out
+__device__ __forceinline__ uint32_t newline_mask16(const uint8_t *bytes, long long off, long long nbytes, bool &saw_cr) {
+    saw_cr = false;
     if (off >= nbytes) return 0u;
     const uint4 v = *(const uint4 *)(bytes + off);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t mask = 0;
+    uint32_t nl = 0, anycr = 0;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        const uint32_t x = w[d] ^ 0x0A0A0A0Au;
-        const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);     // 0x80 in every zero byte
-        const uint32_t m = z >> 7;
-        mask |= ((m | (m >> 7) | (m >> 14) | (m >> 21)) & 0xFu) << (4 * d);
+        nl |= byte_eq_mask4(w[d], 0x0A0A0A0Au) << (4 * d);
+        const uint32_t x = w[d] ^ 0x0D0D0D0Du;
+        anycr |= (x - 0x01010101u) & ~x & 0x80808080u;          // nonzero <=> some byte of the dword is '\r'
     }
+    uint32_t cr = 0;
+    if (anycr) {                                                // rare (no '\r' at all in Unix files)
+        saw_cr = true;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) cr |= byte_eq_mask4(w[d], 0x0D0D0D0Du) << (4 * d);
+        // a '\r' ends a line unless a '\n' follows
+        const uint32_t next_nl = (off + 16 < nbytes && bytes[off + 16] == '\n') ? 1u : 0u;
+        cr &= ~((nl >> 1) | (next_nl << 15));
+    }
+    uint32_t mask = nl | cr;
     const long long valid = nbytes - off;
     if (valid < 16) mask &= (1u << valid) - 1u;
     return mask;
 }
 
 __global__ __launch_bounds__(NL_THREADS) void count_newlines_kernel(const uint8_t *__restrict__ bytes, long long nbytes,
-                                                                     uint32_t *__restrict__ block_counts) {
+                                                                     uint32_t *__restrict__ block_counts,
+                                                                     uint32_t *__restrict__ has_cr) {
     __shared__ uint32_t s_cnt[NL_THREADS / 64];
     const long long off = ((long long)blockIdx.x * NL_THREADS + threadIdx.x) * 16;
-    uint32_t c = __popc(newline_mask16(bytes, off, nbytes));
+    bool saw_cr;
+    uint32_t c = __popc(newline_mask16(bytes, off, nbytes, saw_cr));
+    if (__any(saw_cr) && (threadIdx.x & 63) == 0) atomicOr(has_cr, 1u);    // the chunk holds '\r': records check for "\r\n"
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
@@ -131,7 +153,8 @@ __global__ __launch_bounds__(NL_THREADS) void line_ends_kernel(const uint8_t *__
                                                                 uint32_t *__restrict__ line_ends) {
     __shared__ uint32_t s_cnt[NL_THREADS / 64];
     const long long off = ((long long)blockIdx.x * NL_THREADS + threadIdx.x) * 16;
-    uint32_t mask = newline_mask16(bytes, off, nbytes);
+    bool saw_cr;
+    uint32_t mask = newline_mask16(bytes, off, nbytes, saw_cr);
     const uint32_t c = __popc(mask);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t x = c;
@@ -153,13 +176,14 @@ __global__ __launch_bounds__(NL_THREADS) void line_ends_kernel(const uint8_t *__
 }
 
 __global__ __launch_bounds__(256) void records_kernel(const uint8_t *__restrict__ bytes,
-                                                      const uint32_t *__restrict__ line_ends, long long nrec, int strip,
+                                                      const uint32_t *__restrict__ line_ends, long long nrec,
+                                                      const uint32_t *__restrict__ has_cr,
                                                       FastqRecord *__restrict__ records,
                                                       unsigned long long *__restrict__ error) {
     const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrec) return;
     FastqRecord rec;
-    const int err = fastq_record_one(bytes, line_ends, r, strip, rec);
+    const int err = fastq_record_one(bytes, line_ends, r, *has_cr != 0, rec);
     records[r] = rec;
     if (err) atomicMin(error, (unsigned long long)r * 8ull + (unsigned long long)err);
 }
@@ -682,7 +706,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" {
 
-// work layout: [block_counts u32 x nblk][block_base i64 x (nblk + 1)][sums u64 x scan_blocks(nblk)]
+// work layout: [block_counts u32 x nblk][block_base i64 x (nblk + 1)][sums u64 x scan_blocks(nblk)][has_cr u32]
 size_t atr_fastq_work_bytes(int64_t nbytes) {
     if (nbytes < 0) return 0;
     const long long nblk = (nbytes + NL_BLOCK_BYTES - 1) / NL_BLOCK_BYTES;
@@ -701,26 +725,30 @@ int atr_fastq_count_lines(const uint8_t *d_bytes, int64_t nbytes, void *d_work, 
     uint32_t *counts = (uint32_t *)d_work;
     long long *base = (long long *)((char *)d_work + align256((size_t)nblk * 4));
     unsigned long long *sums = (unsigned long long *)((char *)base + align256((size_t)(nblk + 1) * 8));
-    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)nblk), dim3(NL_THREADS), 0, st, d_bytes, (long long)nbytes, counts);
+    uint32_t *has_cr = (uint32_t *)((char *)sums + align256((size_t)scan_blocks(nblk) * 8));
+    hipError_t me = hipMemsetAsync(has_cr, 0, 4, st);
+    if (me != hipSuccess) return hip_fail(me, "hipMemsetAsync");
+    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)nblk), dim3(NL_THREADS), 0, st, d_bytes, (long long)nbytes, counts, has_cr);
     launch_scan(counts, nblk, base, sums, (long long *)d_nlines, st);
     return launched("fastq count launch");
 }
 
-int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, int strip, const void *d_work, uint32_t *d_line_ends,
-                    int64_t nlines, atr_fastq_record *d_records, int64_t *d_error, void *stream) {
-    if (nbytes < 0 || nbytes >= (int64_t)0xFFFFFFF0ll || nlines < 0 || (strip != 1 && strip != 2) || !d_error)
-        return ATR_ERR_INVALID;
+int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, const void *d_work, uint32_t *d_line_ends, int64_t nlines,
+                    atr_fastq_record *d_records, int64_t *d_error, void *stream) {
+    if (nbytes < 0 || nbytes >= (int64_t)0xFFFFFFF0ll || nlines < 0 || !d_error) return ATR_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, (long long *)d_error, (long long)LLONG_MAX);
     if (nlines == 0 || nbytes == 0) return launched("fastq index launch");
     if (!d_bytes || !d_work || !d_line_ends || ((uintptr_t)d_bytes & 15)) return ATR_ERR_INVALID;
     const long long nblk = (nbytes + NL_BLOCK_BYTES - 1) / NL_BLOCK_BYTES;
     const long long *base = (const long long *)((const char *)d_work + align256((size_t)nblk * 4));
+    const uint32_t *has_cr = (const uint32_t *)((const char *)base + align256((size_t)(nblk + 1) * 8) +
+                                                align256((size_t)scan_blocks(nblk) * 8));
     hipLaunchKernelGGL(line_ends_kernel, dim3((unsigned)nblk), dim3(NL_THREADS), 0, st, d_bytes, (long long)nbytes, base, d_line_ends);
     const long long nrec = nlines / 4;
     if (nrec > 0) {
         if (!d_records) return ATR_ERR_INVALID;
-        hipLaunchKernelGGL(records_kernel, dim3(grid256(nrec)), dim3(256), 0, st, d_bytes, d_line_ends, nrec, strip,
+        hipLaunchKernelGGL(records_kernel, dim3(grid256(nrec)), dim3(256), 0, st, d_bytes, d_line_ends, nrec, has_cr,
                            (FastqRecord *)d_records, (unsigned long long *)d_error);
     }
     return launched("fastq index launch");

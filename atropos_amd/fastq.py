@@ -16,10 +16,9 @@ class FormatError(Exception):
     """Malformed input file (atropos/io/seqio.py FormatError)."""
 
 
-def _strip_width(first_line):
-    """The reference fixes the line-end width once per file from its first line
-    (_seqio.pyx:205): 2 for "\\r\\n", else 1."""
-    return 2 if first_line.endswith(b"\r\n") else 1
+def _universal_newlines(raw):
+    """What Python's text mode (the reference's xopen(..., 'r')) makes of a line's bytes."""
+    return raw.replace(b"\r\n", b"\n").replace(b"\r", b"\n")
 
 
 def _text(b):
@@ -34,11 +33,14 @@ class FastqBatch(object):
         nbytes: bytes of text in ``data``.
         records: int32 [n, 8] descriptors (``atr_fastq_record``): name_off, name_len,
             seq_off, seq_len, qual_off, qual_len, flags, reserved.
-        strip: the file's line-end width (1 or 2).
+        line_ends: uint32 positions of the line terminators (kept for ``head``).
+
+    Line ends follow Python's universal newlines ("\\n", "\\r\\n", lone "\\r"), which is how
+    the reference reads its input.
     """
 
-    def __init__(self, data, nbytes, records, strip, backend, line_ends=None):
-        self.data, self.nbytes, self.records, self.strip, self.backend = data, nbytes, records, strip, backend
+    def __init__(self, data, nbytes, records, backend, line_ends=None):
+        self.data, self.nbytes, self.records, self.backend = data, nbytes, records, backend
         self.line_ends = line_ends
 
     def head(self, nrec):
@@ -46,7 +48,7 @@ class FastqBatch(object):
         they occupy (paired files are consumed in lock step: the shorter chunk decides)."""
         nrec = min(int(nrec), len(self))
         consumed = int(self.line_ends[4 * nrec - 1].item()) + 1 if nrec else 0
-        return FastqBatch(self.data, self.nbytes, self.records[:nrec], self.strip, self.backend, self.line_ends), consumed
+        return FastqBatch(self.data, self.nbytes, self.records[:nrec], self.backend, self.line_ends), consumed
 
     def __len__(self):
         return self.records.shape[0]
@@ -56,7 +58,7 @@ class FastqBatch(object):
         return self.records[:, 3].contiguous()
 
     @classmethod
-    def from_bytes(cls, buf, final=True, strip=None, backend=None):
+    def from_bytes(cls, buf, final=True, backend=None):
         """Index ``buf`` (bytes-like FASTQ text that starts at a record boundary).
 
         final=True: ``buf`` is the rest of the file -- a missing last newline is tolerated
@@ -66,10 +68,8 @@ class FastqBatch(object):
         Returns (batch, consumed_bytes)."""
         be = backend or _lib.get_backend()
         buf = bytes(buf) if not isinstance(buf, (bytes, bytearray)) else buf
-        if strip is None:
-            nl = buf.find(b"\n")
-            strip = _strip_width(buf[:nl + 1] if nl >= 0 else buf)
-        if final and len(buf) and not buf.endswith(b"\n"):
+        unterminated = bool(final and len(buf) and not buf.endswith((b"\n", b"\r")))
+        if unterminated:
             buf = bytes(buf) + b"\n"
         nbytes = len(buf)
         if nbytes >= (1 << 32) - 16:
@@ -80,50 +80,76 @@ class FastqBatch(object):
             host[:nbytes] = torch.frombuffer(bytearray(buf), dtype=torch.uint8)
         data = be.empty((padded,), torch.uint8)
         data.copy_(host)
-        return cls.from_device(data, nbytes, strip, final, be, host_text=buf)
+        return cls.from_device(data, nbytes, final, be, host_text=buf, unterminated=unterminated)
 
     @classmethod
-    def from_device(cls, data, nbytes, strip=1, final=True, backend=None, host_text=None):
+    def from_device(cls, data, nbytes, final=True, backend=None, host_text=None, unterminated=False):
         """Index FASTQ text that already sits in device memory: ``data`` is a uint8 tensor,
-        16-byte aligned, readable up to the next multiple of 16 beyond ``nbytes``, whose
-        text ends in a newline.  Returns (batch, consumed_bytes)."""
+        16-byte aligned, readable up to the next multiple of 16 beyond ``nbytes`` plus one
+        byte, whose text ends in a line end.  Returns (batch, consumed_bytes)."""
         be = backend or _lib.get_backend()
-        records, line_ends, nlines, err = be.fastq_index(data, nbytes, strip)
+        records, line_ends, nlines, err = be.fastq_index(data, nbytes)
         nrec = nlines // 4
         if err != _lib.INT64_MAX:
             if host_text is None:
                 host_text = bytes(data[:nbytes].cpu().numpy().tobytes())
-            cls._raise_format_error(host_text, line_ends, err, strip)
+            cls._raise_format_error(host_text, line_ends, err)
         if final and nlines % 4 != 0:
+            # the reference validates the lines of the incomplete last record as it reads them
+            # (_seqio.pyx:208-238) before it runs out of input (:244-245)
+            tail = [int(v) for v in line_ends[max(4 * nrec - 1, 0):nlines].cpu().tolist()]
+            if nrec == 0:
+                tail = [-1] + tail
+            if host_text is None:
+                host_text = bytes(data[:nbytes].cpu().numpy().tobytes())
+            lines = [_universal_newlines(bytes(host_text[tail[i] + 1:tail[i + 1] + 1])) for i in range(len(tail) - 1)]
+            if unterminated:
+                # the file's last line had no line end: the reference still drops its last
+                # character (line[:strip]); give the line a "\n" in place of that character
+                lines[-1] = lines[-1][:-2] + b"\n" if len(lines[-1]) > 1 else lines[-1]
+            if not lines[0].startswith(b"@"):
+                raise FormatError("Line {0} in FASTQ file is expected to start with '@', but found {1!r}".format(
+                    1, _text(lines[0])[:10]))
+            if len(lines) >= 3 and lines[2] != b"+\n":
+                plus, name = lines[2][:-1], lines[0][1:-1]
+                if not plus.startswith(b"+"):
+                    raise FormatError("Line {0} in FASTQ file is expected to start with '+', but found {1!r}".format(
+                        3, _text(plus)[:10]))
+                if len(plus) > 1 and plus[1:] != name:
+                    raise FormatError(
+                        "At line {0}: Sequence descriptions in the FASTQ file don't match "
+                        "({1!r} != {2!r}).\n"
+                        "The second sequence description must be either empty "
+                        "or equal to the first description.".format(3, _text(name), _text(plus[1:])))
             raise FormatError("FASTQ file ended prematurely")
         consumed = nbytes
         if not final:
             consumed = int(line_ends[4 * nrec - 1].item()) + 1 if nrec else 0
-        return cls(data, nbytes, records[:nrec], strip, be, line_ends), consumed
+        return cls(data, nbytes, records[:nrec], be, line_ends), consumed
 
     @staticmethod
-    def _raise_format_error(buf, line_ends, err, strip):
+    def _raise_format_error(buf, line_ends, err):
         """Re-create the reference's message for the first invalid record."""
         r, code = err // 8, err % 8
         ends = [int(v) for v in line_ends[max(4 * r - 1, 0):4 * r + 4].cpu().tolist()]
         if r == 0:
             ends = [-1] + ends
-        lines = [buf[ends[i] + 1:ends[i + 1] + 1] for i in range(4)]
-        name = _text(lines[0][1:-strip])
+        # the lines as the reference sees them: newline-translated, each ending in "\n"
+        lines = [_universal_newlines(bytes(buf[ends[i] + 1:ends[i + 1] + 1])) for i in range(4)]
+        name = _text(lines[0][1:-1])
         if code == _lib.FASTQ_ERR_AT:                                      # _seqio.pyx:209-211 / :199-201
             raise FormatError("Line {0} in FASTQ file is expected to start with '@', but found {1!r}".format(
                 1, _text(lines[0])[:10]))
         if code == _lib.FASTQ_ERR_PLUS:                                    # :224-227
             raise FormatError("Line {0} in FASTQ file is expected to start with '+', but found {1!r}".format(
-                3, _text(lines[2][:-strip])[:10]))
+                3, _text(lines[2][:-1])[:10]))
         if code == _lib.FASTQ_ERR_NAME2:                                   # :229-235
             raise FormatError(
                 "At line {0}: Sequence descriptions in the FASTQ file don't match "
                 "({1!r} != {2!r}).\n"
                 "The second sequence description must be either empty "
-                "or equal to the first description.".format(3, name, _text(lines[2][:-strip])[1:]))
-        seq = lines[1][:-strip]
-        qual = lines[3][:-strip] if len(lines[3]) == len(seq) + strip else lines[3].rstrip(b"\r\n")
+                "or equal to the first description.".format(3, name, _text(lines[2][:-1])[1:]))
+        seq, qual = lines[1][:-1], lines[3][:-1]
         rname = name if len(name) <= 100 else name[:97] + "..."            # util.truncate_string
         cause = FormatError(
             "In read named {0!r}: length of quality sequence ({1}) and "

@@ -247,7 +247,6 @@ class TrimPipeline(object):
             state["pos"] += got
             return n0 + got, state["pos"] >= file_size
 
-        strip = None
         with open(path_in, "rb") as fin_obj, open(path_out, "wb") as fout, ThreadPoolExecutor(2) as pool:
             fin = fin_obj.fileno()
             k = 0
@@ -255,18 +254,14 @@ class TrimPipeline(object):
             pending_write = None
             while True:
                 host = inbuf[k]
-                if strip is None and nbytes:
-                    head = bytes(host[:min(nbytes, 1 << 16)].numpy().tobytes())
-                    nl = head.find(b"\n")
-                    strip = 2 if (head[:nl + 1] if nl >= 0 else head).endswith(b"\r\n") else 1
-                if final and nbytes and int(host[nbytes - 1]) != 10:
+                if final and nbytes and int(host[nbytes - 1]) not in (10, 13):
                     host[nbytes] = 10                         # tolerate a missing last newline (_seqio.pyx:240-243)
                     nbytes += 1
                 padded = (nbytes + 15) // 16 * 16 + 16
                 data = be.empty((padded,), torch.uint8)
                 data[:nbytes].copy_(host[:nbytes], non_blocking=True)
                 data[nbytes:].zero_()
-                batch, consumed = FastqBatch.from_device(data, nbytes, strip or 1, final, be)
+                batch, consumed = FastqBatch.from_device(data, nbytes, final, be)
                 carry = b"" if final else bytes(host[consumed:nbytes].numpy().tobytes())
                 nxt = None if final else pool.submit(read_chunk, fin, 1 - k, carry)     # overlaps the GPU work below
                 res = self.run(batch)
@@ -351,8 +346,7 @@ class PairedTrimPipeline(object):
             return none
         if miss.numel() == n:
             return adapter.match_source(RecordSource(batch, st[0], st[1]))
-        sub = FastqBatch(batch.data, batch.nbytes, batch.records.index_select(0, miss).contiguous(), batch.strip,
-                         batch.backend)
+        sub = FastqBatch(batch.data, batch.nbytes, batch.records.index_select(0, miss).contiguous(), batch.backend)
         rec = adapter.match_source(RecordSource(sub, st[0].index_select(0, miss).contiguous(),
                                                 st[1].index_select(0, miss).contiguous()))
         none[miss] = rec
@@ -435,7 +429,7 @@ class PairedTrimPipeline(object):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
         same number from each file); returns the destination counts."""
         totals = {name: 0 for name in DEST_NAMES.values()}
-        strips, carry = [None, None], [b"", b""]
+        carry = [b"", b""]
         with open(in1, "rb") as f1, open(in2, "rb") as f2, open(out1, "wb") as o1, open(out2, "wb") as o2:
             files = (f1, f2)
             while True:
@@ -444,10 +438,7 @@ class PairedTrimPipeline(object):
                     block = files[k].read(chunk_bytes)
                     finals.append(len(block) < chunk_bytes)
                     bufs.append(carry[k] + block)
-                    if strips[k] is None and bufs[k]:
-                        nl = bufs[k].find(b"\n")
-                        strips[k] = 2 if (bufs[k][:nl + 1] if nl >= 0 else bufs[k]).endswith(b"\r\n") else 1
-                batches = [FastqBatch.from_bytes(bufs[k], final=finals[k], strip=strips[k])[0] for k in range(2)]
+                batches = [FastqBatch.from_bytes(bufs[k], final=finals[k])[0] for k in range(2)]
                 nrec = min(len(batches[0]), len(batches[1]))
                 done = all(finals)
                 if done and len(batches[0]) != len(batches[1]):

@@ -248,7 +248,7 @@ int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_len
 
 /* ---- device-resident FASTQ batch (io/_seqio.pyx:163-245, io/seqio.py:686-700) ---- */
 
-/* One chunk of FASTQ text (whole records, < 4 GiB, 16-byte aligned, ending in '\n') is
+/* One chunk of FASTQ text (whole records, < 4 GiB, 16-byte aligned, ending in a line end) is
  * uploaded as raw bytes; the records are found, validated, trimmed and formatted on the
  * device.  Every trimming modifier of the single-end path only clips read ends, so its
  * state is the kept interval [d_begin[r], d_end[r]) of each record's sequence line. */
@@ -265,17 +265,18 @@ typedef struct {
 #define ATR_FASTQ_ERR_NAME2   3    /* "Sequence descriptions in the FASTQ file don't match" (:229-235) */
 #define ATR_FASTQ_ERR_LENGTH  4    /* "length of quality sequence ... and length of read ... do not match" (:33-43) */
 
-/* Count the lines ('\n' bytes) of the chunk: *d_nlines (device int64).  d_work: caller
- * scratch of atr_fastq_work_bytes(nbytes) bytes, to be handed unchanged to atr_fastq_index. */
+/* Count the lines of the chunk: *d_nlines (device int64).  Line ends follow Python's universal
+ * newlines, which is how the reference reads its input (text mode): "\n", "\r\n" and a lone
+ * "\r".  d_work: caller scratch of atr_fastq_work_bytes(nbytes) bytes, to be handed unchanged
+ * to atr_fastq_index.  The buffer must be readable up to the next multiple of 16 plus one byte. */
 size_t atr_fastq_work_bytes(int64_t nbytes);
 int atr_fastq_count_lines(const uint8_t *d_bytes, int64_t nbytes, void *d_work, int64_t *d_nlines, void *stream);
 
-/* Positions of the line ends (d_line_ends[nlines], uint32) and the descriptors of the
- * nlines / 4 records.  strip: 1, or 2 when the first line of the FILE ends in "\r\n" (the
- * reference decides the line-end width once per file, :205).  *d_error (device int64)
- * receives min over invalid records of (record * 8 + ATR_FASTQ_ERR_*), or INT64_MAX. */
-int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, int strip, const void *d_work, uint32_t *d_line_ends,
-                    int64_t nlines, atr_fastq_record *d_records, int64_t *d_error, void *stream);
+/* Positions of the line ends (d_line_ends[nlines], uint32: the last byte of each terminator)
+ * and the descriptors of the nlines / 4 records.  *d_error (device int64) receives min over
+ * invalid records of (record * 8 + ATR_FASTQ_ERR_*), or INT64_MAX. */
+int atr_fastq_index(const uint8_t *d_bytes, int64_t nbytes, const void *d_work, uint32_t *d_line_ends, int64_t nlines,
+                    atr_fastq_record *d_records, int64_t *d_error, void *stream);
 
 /* 4-bit tile64 pack (as atr_pack_reads) of sequence[begin:end] of every record; d_begin /
  * d_end may be NULL (the whole sequence line).  d_lens receives the packed lengths.

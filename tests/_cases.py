@@ -648,3 +648,30 @@ def check_paired_file_chunking(tmp_path):
     assert paths[2].read_bytes() == w1 and paths[3].read_bytes() == w2
     assert sum(counts.values()) == d1.count(b"\n") // 4
     return counts
+
+
+def check_fastq_reader_golden():
+    """FastqBatch.from_bytes against the reference's FastqReader on fuzzed FASTQ texts: same record
+    tuples, or the same FormatError (type, message, cause)."""
+    import base64
+    from atropos_amd.fastq import FastqBatch, FormatError
+    cases = load_golden("fastq_fuzz.json.gz")
+    errors = 0
+    for k, case in enumerate(cases):
+        text = base64.b64decode(case["text"])
+        if "error" in case:
+            try:
+                FastqBatch.from_bytes(text, final=True)
+            except FormatError as err:
+                assert case["error"][0] == "FormatError", (k, case["error"])
+                assert str(err) == case["error"][1], (k, str(err), case["error"][1])
+                if len(case["error"]) > 2:
+                    assert str(err.__cause__) == case["error"][2], (k, str(err.__cause__), case["error"][2])
+                errors += 1
+            else:
+                raise AssertionError("text %d: the reference raises %s" % (k, case["error"]))
+        else:
+            batch, consumed = FastqBatch.from_bytes(text, final=True)
+            got = [list(r) for r in batch.to_records()]
+            assert got == case["records"], (k, got[:3], case["records"][:3])
+    return len(cases), errors

@@ -206,14 +206,14 @@ class EmuBackend(object):
         return out
 
     # -- device-resident FASTQ batch (CPU twin) ----------------------------------
-    def fastq_index(self, data, nbytes, strip):
+    def fastq_index(self, data, nbytes):
         L = self.lib
         info = torch.zeros((2,), dtype=torch.int64)
         _check(L.emu_fastq_count_lines(_ptr(data), C.c_int64(nbytes), _ptr(info)), "emu_fastq_count_lines")
         nlines = int(info[0])
         line_ends = torch.zeros((max(nlines, 1),), dtype=torch.int32)
         records = torch.zeros((nlines // 4, 8), dtype=torch.int32)
-        _check(L.emu_fastq_index(_ptr(data), C.c_int64(nbytes), strip, _ptr(line_ends), C.c_int64(nlines), _ptr(records),
+        _check(L.emu_fastq_index(_ptr(data), C.c_int64(nbytes), _ptr(line_ends), C.c_int64(nlines), _ptr(records),
                                  C.c_void_p(info.data_ptr() + 8)), "emu_fastq_index")
         return records, line_ends, nlines, int(info[1])
 

@@ -19,21 +19,21 @@ extern "C" {
 int emu_fastq_count_lines(const uint8_t *bytes, int64_t nbytes, int64_t *nlines) {
     if (nbytes < 0 || nbytes >= (int64_t)0xFFFFFFF0ll || !nlines) return ATR_ERR_INVALID;
     int64_t c = 0;
-    for (int64_t i = 0; i < nbytes; ++i) c += bytes[i] == '\n';
+    for (int64_t i = 0; i < nbytes; ++i) c += is_line_end(bytes[i], i + 1 < nbytes ? bytes[i + 1] : 0) ? 1 : 0;
     *nlines = c;
     return ATR_OK;
 }
 
-int emu_fastq_index(const uint8_t *bytes, int64_t nbytes, int strip, uint32_t *line_ends, int64_t nlines,
+int emu_fastq_index(const uint8_t *bytes, int64_t nbytes, uint32_t *line_ends, int64_t nlines,
                     atr_fastq_record *records, int64_t *error) {
-    if (nbytes < 0 || nlines < 0 || (strip != 1 && strip != 2) || !error) return ATR_ERR_INVALID;
+    if (nbytes < 0 || nlines < 0 || !error) return ATR_ERR_INVALID;
     *error = LLONG_MAX;
     int64_t k = 0;
     for (int64_t i = 0; i < nbytes && k < nlines; ++i)
-        if (bytes[i] == '\n') line_ends[k++] = (uint32_t)i;
+        if (is_line_end(bytes[i], i + 1 < nbytes ? bytes[i + 1] : 0)) line_ends[k++] = (uint32_t)i;
     for (int64_t r = 0; r < nlines / 4; ++r) {
         FastqRecord rec;
-        const int err = fastq_record_one(bytes, line_ends, r, strip, rec);
+        const int err = fastq_record_one(bytes, line_ends, r, true, rec);
         memcpy(&records[r], &rec, sizeof(rec));
         if (err && r * 8 + err < *error) *error = r * 8 + err;
     }

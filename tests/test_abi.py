@@ -82,7 +82,7 @@ def test_argument_validation_without_device():
     assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 2.0, 15, 0, 0, 1, 1, None, None) == UNSUPPORTED
     assert lib.atr_fastq_count_lines(None, -1, None, None, None) == INVALID
     assert lib.atr_fastq_count_lines(None, 1 << 33, None, None, None) == INVALID                 # chunk >= 4 GiB
-    assert lib.atr_fastq_index(None, 10, 3, None, None, 4, None, None, None) == INVALID           # strip is 1 or 2
+    assert lib.atr_fastq_index(None, 10, None, None, -4, None, None, None) == INVALID
     assert lib.atr_pack_records(None, None, None, None, 1, 100, None, 0, None, None, None, None) == INVALID
     assert lib.atr_clip_batch(None, None, None, 1, -1, 0, None) == INVALID
     assert lib.atr_clip_batch(None, None, None, 1, 0, 1, None) == INVALID                         # back must be <= 0

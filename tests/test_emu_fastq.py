@@ -32,3 +32,8 @@ def test_paired_pipeline_reference_cli_cases(emu_backend):
 def test_paired_file_chunking(emu_backend, tmp_path):
     counts = _cases.check_paired_file_chunking(tmp_path)
     assert counts["keep"] > 0 and counts["too_short"] > 0
+
+
+def test_fastq_reader_fuzz_vs_reference(emu_backend):
+    total, errors = _cases.check_fastq_reader_golden()
+    assert total == 300 and errors > 40

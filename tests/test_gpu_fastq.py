@@ -60,3 +60,8 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
 
 def test_paired_pipeline_reference_cli_cases(hip_backend):
     assert _cases.check_trim_golden_paired() >= 20
+
+
+def test_fastq_reader_fuzz_vs_reference(hip_backend):
+    total, errors = _cases.check_fastq_reader_golden()
+    assert total == 300 and errors > 40

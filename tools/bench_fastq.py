@@ -66,7 +66,7 @@ def main():
     args = "-a AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC -q 20 --trim-n -m 20"
     pipe = pipeline_from_args(args)
     stages = {}
-    stages["index_ms"], (batch, _) = timed(lambda: FastqBatch.from_device(data, nbytes, 1, True, be), steps)
+    stages["index_ms"], (batch, _) = timed(lambda: FastqBatch.from_device(data, nbytes, True, be), steps)
     stages["run_ms"], res = timed(lambda: pipe.run(batch), steps)
     stages["emit_ms"], out = timed(lambda: be.fastq_emit(batch.data, batch.records, res.begin, res.end, None, None,
                                                          res.dest, _lib.DEST_KEEP), steps)

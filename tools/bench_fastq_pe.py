@@ -75,8 +75,8 @@ def main():
             synth.PE_ADAPTER1, synth.PE_ADAPTER2)
     pipe = pipeline_from_args(args)
     stages = {}
-    stages["index_ms"], (b1, b2) = timed(lambda: (FastqBatch.from_device(d1, n1, 1, True, be)[0],
-                                                  FastqBatch.from_device(d2, n2, 1, True, be)[0]), steps)
+    stages["index_ms"], (b1, b2) = timed(lambda: (FastqBatch.from_device(d1, n1, True, be)[0],
+                                                  FastqBatch.from_device(d2, n2, True, be)[0]), steps)
     stages["run_ms"], res = timed(lambda: pipe.run(b1, b2), steps)
     stages["emit_ms"], outs = timed(lambda: tuple(
         be.fastq_emit(r.batch.data, r.batch.records, r.begin, r.end, None, None, r.dest, _lib.DEST_KEEP)
