@@ -268,13 +268,6 @@ struct BandParams {
     int and_mode, noindel;
 };
 
-// 4-bit code of base j (1-based) of a tile64-packed read (q = the lane's chunk 0, uint32 view), 0 beyond it
-ATR_DEV uint32_t read_base(const uint32_t *q, int nchunks, int j) {
-    const int z = j - 1;
-    if (z < 0 || z >= nchunks * 32) return 0u;
-    return (q[(size_t)(z >> 5) * 256 + ((z >> 3) & 3)] >> (4 * (z & 7))) & 15u;
-}
-
 // The bases dlo + 1 .. dlo + 8 * BAND_STREAM of the read as BAND_STREAM dwords of eight
 // bases (ns[k * nss] = bases dlo + 1 + 8k ..): the aligned dwords that hold them are gathered
 // with independent loads and re-aligned to the band start with a per-lane funnel shift, so
