@@ -575,38 +575,15 @@ class AdapterParser(object):
 
 def linked_best_records(linked_adapters, ascii_upper, lens=None):
     """Device pipeline for a set of linked adapters whose anchored 5' parts are mutually
-    exclusive (BASELINE config C4): every 5' adapter is matched against all reads (one shared
-    packed batch), the reads are then grouped by the 5' adapter that matched and only that
-    adapter's 3' part is aligned against ``read[front.rstop:]``.  Returns (which, front, back):
-    the index of the matching linked adapter per read (-1: none, -2: more than one -- the
-    reference's AdapterCutter raises AttributeError in that case, modifiers.py:120) and the
-    two int16 [n, 8] record tensors."""
-    be = _lib.get_backend()
-    n = ascii_upper.shape[0]
-    first = linked_adapters[0].front_adapter
-    shared = None
-    if first.indels or first.where not in (PREFIX, SUFFIX):
-        shared = ReadBatch.from_ascii(ascii_upper, lens, None, first.aligner.table_kind, first.aligner._table, be)
-    none = torch.zeros(8, dtype=torch.int16, device=be.device)
-    none[1] = -1
-    front = none[None, :].repeat(n, 1)
-    back = none[None, :].repeat(n, 1)
-    which = torch.full((n,), -1, dtype=torch.int32, device=be.device)
-    count = torch.zeros((n,), dtype=torch.int32, device=be.device)
-    for k, la in enumerate(linked_adapters):
-        f = la.front_adapter.match_records(ascii_upper, lens, batch=shared)
-        has = f[:, 1] >= 0
-        front = torch.where(has[:, None], f, front)
-        which = torch.where(has, torch.full_like(which, k), which)
-        count += has.to(torch.int32)
-    for k, la in enumerate(linked_adapters):
-        idx = torch.nonzero(which == k, as_tuple=False).squeeze(1)
-        if idx.numel() == 0:
-            continue
-        sub = ascii_upper.index_select(0, idx)
-        sub_lens = None if lens is None else lens.index_select(0, idx)
-        starts = front.index_select(0, idx)[:, 3].to(torch.int32)
-        back[idx] = la.back_adapter.match_records(sub, sub_lens, starts=starts)
+    exclusive (BASELINE config C4) on a uint8 [n, width] matrix of reads: see
+    ``linked_records_from_source``.  Returns (which, front, back): the index of the matching
+    linked adapter per read (-1: none, -2: more than one -- the reference's AdapterCutter
+    raises AttributeError in that case, modifiers.py:120) and the two int16 [n, 8] record tensors."""
+    from .fastq import FastqBatch
+    batch = FastqBatch.from_matrix(ascii_upper, lens)
+    begin = torch.zeros((len(batch),), dtype=torch.int32, device=batch.records.device)
+    end = batch.seq_lens.clone()
+    which, count, front, back = linked_records_from_source(linked_adapters, batch, begin, end)
     which = torch.where(count > 1, torch.full_like(which, -2), which)
     return which, front, back
 
@@ -635,3 +612,52 @@ def best_adapter_records(adapters, ascii_upper, lens=None):
         best = torch.where(better[:, None], rec, best)
         which = torch.where(better, torch.full_like(which, idx), which)
     return best, which
+
+
+def linked_records_from_source(linked_adapters, batch, begin, end, active=None):
+    """Device twin of ``LinkedAdapter.match_to`` for a set of linked adapters whose anchored 5'
+    parts are mutually exclusive, on the kept intervals of a FastqBatch (``atropos_amd.fastq``):
+    every 5' adapter is matched against all reads (one packed batch per translate table), the
+    reads are then compacted by the 5' adapter that matched (32-byte descriptors are gathered,
+    never the bases) and only that adapter's 3' part is aligned against ``read[front.rstop:]``.
+    Returns (which, front, back): the index of the first matching linked adapter per read (-1:
+    none), the number of 5' adapters that matched, and the int16 [n, 8] record tensors (3'
+    records relative to the read with the 5' match removed)."""
+    from .fastq import FastqBatch, RecordSource
+    n = len(batch)
+    dev = begin.device
+    none = torch.zeros((n, 8), dtype=torch.int16, device=dev)
+    none[:, 1] = -1
+    front, back = none.clone(), none.clone()
+    which = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    count = torch.zeros((n,), dtype=torch.int32, device=dev)
+    fsrc = RecordSource(batch, begin.clone(), end.clone())
+    for k, la in enumerate(linked_adapters):
+        f = la.front_adapter.match_source(fsrc)
+        has = f[:, 1] >= 0
+        if active is not None:
+            has &= active != 0
+        count += has.to(torch.int32)
+        first = has & (which < 0)                                      # the first matching adapter claims the read
+        front = torch.where(first[:, None], f, front)
+        which = torch.where(first, torch.full_like(which, k), which)
+    # compact once: the reads ordered by the adapter that claimed them, then one contiguous
+    # slice per adapter (three gathers and one scatter in total, of descriptors, not of bases)
+    idxs = [torch.nonzero(which == k).squeeze(1) for k in range(len(linked_adapters))]
+    sizes = [int(i.numel()) for i in idxs]
+    if sum(sizes):
+        order = torch.cat(idxs)
+        recs = batch.records.index_select(0, order).contiguous()
+        sb = (begin + torch.where(which >= 0, front[:, 3].to(torch.int32), torch.zeros_like(begin))).index_select(0, order)
+        se = torch.maximum(end.index_select(0, order), sb)                 # read[front.rstop:]
+        parts, lo = [], 0
+        for k, la in enumerate(linked_adapters):
+            if sizes[k] == 0:
+                continue
+            hi = lo + sizes[k]
+            sub = FastqBatch(batch.data, batch.nbytes, recs[lo:hi], batch.backend)
+            parts.append(la.back_adapter.match_source(RecordSource(sub, sb[lo:hi].contiguous(), se[lo:hi].contiguous())))
+            lo = hi
+        back[order] = torch.cat(parts)
+    return which, count, front, back
+

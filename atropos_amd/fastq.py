@@ -58,6 +58,25 @@ class FastqBatch(object):
         return self.records[:, 3].contiguous()
 
     @classmethod
+    def from_matrix(cls, ascii_2d, lens=None, backend=None):
+        """A batch over a uint8 [n, width] matrix of sequences already on the device (no names,
+        no qualities): lets the record-based packer and the compacting adapter stages run on
+        reads that did not come from a FASTQ file."""
+        be = backend or _lib.get_backend()
+        n, width = ascii_2d.shape
+        nbytes = n * width
+        if nbytes >= (1 << 32) - 16:
+            raise ValueError("the matrix must be smaller than 4 GiB")
+        data = be.empty(((nbytes + 15) // 16 * 16 + 16,), torch.uint8)
+        data[:nbytes].view(n, width).copy_(ascii_2d)
+        data[nbytes:].zero_()
+        records = torch.zeros((n, 8), dtype=torch.int32, device=data.device)
+        off = torch.arange(n, device=data.device, dtype=torch.int64) * width
+        records[:, 2] = off.to(torch.int32) if nbytes < (1 << 31) else (off - (off >= (1 << 31)) * (1 << 32)).to(torch.int32)
+        records[:, 3] = width if lens is None else lens.to(torch.int32)
+        return cls(data, nbytes, records, be)
+
+    @classmethod
     def from_bytes(cls, buf, final=True, backend=None):
         """Index ``buf`` (bytes-like FASTQ text that starts at a record boundary).
 

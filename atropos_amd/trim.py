@@ -117,21 +117,12 @@ class TrimPipeline(object):
     def _round_linked(self, batch, begin, end, active, matched):
         """LinkedAdapter.match_to + trimmed (adapters/__init__.py:648-706) for linked adapters
         whose 5' parts are mutually exclusive: the first one whose 5' part matches is used."""
+        from .adapters import linked_records_from_source
         be = batch.backend
-        n = len(batch)
-        claimed = torch.zeros((n,), dtype=torch.uint8, device=begin.device)
-        for la in self.adapters:
-            fsrc = RecordSource(batch, begin, end)
-            frec = la.front_adapter.match_source(fsrc)
-            has = ((frec[:, 1] >= 0) & (claimed == 0) & (active != 0)).to(torch.uint8)
-            claimed |= has
-            fb, fe = begin.clone(), end.clone()
-            be.match_trim_batch(frec.contiguous(), None, 1, fb, fe, has.clone(), None)      # read[front.rstop:]
-            brec = la.back_adapter.match_source(RecordSource(batch, fb, fe))
-            be.match_trim_batch(brec.contiguous(), None, 0, fb, fe, has.clone(), None)      # then read[:back.rstart]
-            sel = has != 0
-            begin.copy_(torch.where(sel, fb, begin))
-            end.copy_(torch.where(sel, fe, end))
+        which, _count, front, back = linked_records_from_source(self.adapters, batch, begin, end, active)
+        claimed = (which >= 0).to(torch.uint8)
+        be.match_trim_batch(front.contiguous(), None, 1, begin, end, claimed.clone(), None)    # read[front.rstop:]
+        be.match_trim_batch(back.contiguous(), None, 0, begin, end, claimed.clone(), None)     # then read[:back.rstart]
         matched |= claimed
         active &= claimed                                                 # no 5' match: the loop over `times` stops
 
@@ -555,13 +546,20 @@ def pipeline_from_args(argv):
     parser = AdapterParser(**kwargs)
     adapters = parser.parse_multi(o.adapters, o.anywhere, o.front)
     action = None if o.no_trim else ("mask" if o.mask_adapter else "trim")    # trim/cli.py:103-111
+    adapters2 = parser.parse_multi(o.adapters2, o.anywhere2, o.front2) if paired else []
+    if (not adapters and not adapters2 and not qc and o.nextseq_trim is None and not o.cut and not o.cut2 and
+            (o.minimum_length is None or o.minimum_length <= 0) and o.maximum_length is None and not o.trim_n and
+            o.max_n is None):
+        raise ValueError("You need to provide at least one adapter sequence.")        # trim/__init__.py:386-404
+    if action == "mask" and any(isinstance(a, LinkedAdapter) for a in adapters + adapters2):
+        raise NotImplementedError("--mask-adapter with a linked adapter: the reference's AdapterCutter fails on it "
+                                  "(LinkedMatch has no astart, modifiers.py:158)")
     common = dict(times=o.times, action=action, nextseq_trim=o.nextseq_trim, quality_cutoff=qc,
                   quality_base=o.quality_base, trim_n=o.trim_n, minimum_length=o.minimum_length,
                   maximum_length=o.maximum_length, max_n=o.max_n, discard_trimmed=o.discard_trimmed,
                   discard_untrimmed=o.discard_untrimmed, op_order=o.op_order)
     if not paired:
         return TrimPipeline(adapters=adapters, cut=o.cut, **common)
-    adapters2 = parser.parse_multi(o.adapters2, o.anywhere2, o.front2)
     return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, **common)
