@@ -13,6 +13,8 @@ namespace atr {
 
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st);
+int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                       int max_len, uint4 *out, hipStream_t st);
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                   const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st);
 
@@ -198,6 +200,12 @@ int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
     if (!d_out || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
+    if (d_work && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k)) {
+        // anchored 5' adapter: banded DP over the 2k + 1 diagonals around the main one
+        const int rc = launch_prefix_band(a, (const uint4 *)d_packed, d_lens, nreads, (max_len + 31) / 32, max_len,
+                                          (uint4 *)d_out, (hipStream_t)stream);
+        return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "prefix band launch");
+    }
     if (d_work && a->filterable && max_len > 0) {
         const int rc = launch_locate_fast(a, (const uint4 *)d_packed, d_lens, nreads, (max_len + 31) / 32, max_len,
                                           (uint4 *)d_out, d_work, (hipStream_t)stream);

@@ -354,5 +354,91 @@ ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, c
 }
 
 
+// ---- anchored 5' adapters (PREFIX: only STOP_WITHIN_SEQ2) -------------------------------------
+// The alignment must start at (0, 0), so with at most k indels every traceback stays on the
+// diagonals j - i in [-k, k]: the same banded row-major DP, without any pre-pass, over the
+// 2k + 1 diagonals around the main one (c = j - i + k).  Cells left of column 0 do not exist,
+// column 0 and row 0 hold the reference's initial values (_align.pyx:333-352, :385-388).
+inline bool prefix_band_applies(int flags, int m, int k) {          // host side
+    return flags == ATR_STOP_WITHIN_SEQ2 && m <= FILTER_MAX_M && k >= 0 && 2 * k + 1 <= BAND_W;
+}
+
+// ns: the read staged from base 1 - k on (band_stage with dlo = -k), stride nss.
+template <bool AND_MODE>
+ATR_DEV void band_locate_prefix(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
+                                const int16_t *thr, uint32_t rec[4]) {
+    const int k = u.k, smax = 2 * k;
+    const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
+    const int max_n = atr_min(n, u.m + k);                               // :317-319 (START_WITHIN_SEQ2 not set)
+    uint32_t band[BAND_W];
+#pragma unroll
+    for (int c = 0; c < BAND_W; ++c) {                                   // row 0: cell (0, j = c - k): j deletions
+        const int j = c - k;
+        band[c] = j < 0 ? inf : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
+    }
+    uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
+    uint32_t feed = ns[(size_t)2 * nss];
+    for (int i = 1; i <= u.m; ++i) {
+        const uint32_t rrep = (uint32_t)codes[i - 1] * 0x11111111u;
+        const uint32_t v0 = AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep), v1 = AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep);
+        uint32_t m0 = (v0 | (v0 >> 1) | (v0 >> 2) | (v0 >> 3)) & 0x11111111u;
+        uint32_t m1 = (v1 | (v1 >> 1) | (v1 >> 2) | (v1 >> 3)) & 0x11111111u;
+        if (AND_MODE) { m0 ^= 0x11111111u; m1 ^= 0x11111111u; }
+        // column 0 of this row sits at c = k - i while i <= k: cost i insertions, origin 0 (:340-342)
+        const uint32_t col0 = ORG_BIAS | ((uint32_t)atr_min(i * u.indel, INIT_COST_CAP) << CSH);
+        uint32_t left = inf;
+#pragma unroll
+        for (int c = 0; c < BAND_W; ++c) {
+            if (c <= smax) {                                             // wave-uniform
+                const int j = i + c - k;                                 // wave-uniform
+                const uint32_t bit = ((c < 8 ? m0 : m1) >> (4 * (c & 7))) & 1u;
+                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
+                const uint32_t up = (c + 1 < BAND_W && c + 1 <= smax) ? band[(c + 1 < BAND_W) ? c + 1 : 0] : inf;
+                uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
+                if (j <= 0) nw = j == 0 ? col0 : inf;
+                band[c] = nw;
+                left = nw;
+            }
+        }
+        qw0 = (qw0 >> 4) | (qw1 << 28);
+        qw1 = (qw1 >> 4) | (feed << 28);
+        feed >>= 4;
+        if ((i & 7) == 0) {
+            const int w = 2 + (i >> 3);
+            feed = w < BAND_STREAM ? ns[(size_t)w * nss] : 0u;
+        }
+    }
+    Best best;
+    best.key = COST_FIELD_MAX - (u.m + n);
+    best.word = (uint32_t)(u.m + n) << CSH;
+    best.ref_stop = u.m; best.query_stop = n; best.matches = 0;
+    const int cindel = noindel ? 0 : u.indel;
+    uint32_t last = inf;
+    bool have_last = false;
+#pragma unroll
+    for (int c = 0; c < BAND_W; ++c) {
+        const int j = u.m + c - k;
+        if (c <= smax && j >= 0 && j <= max_n) {
+            if (band[c] < u.klimit) consider<true>(best, band[c], u.m, j, u.min_overlap, thr, cindel);   // :433-455
+            if (j == n) { last = band[c]; have_last = true; }
+        }
+    }
+    // last column (:461-474): only row m without STOP_WITHIN_SEQ1; (m, n) lies in the band unless
+    // n < m - k, where its cost exceeds k anyway
+    if (max_n == n && have_last) consider<true>(best, last, u.m, n, u.min_overlap, thr, cindel);
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != u.m + n) {
+        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
 }  // namespace atr
 #endif

@@ -41,4 +41,22 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     return groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, st);
 }
 
+static BandParams band_params(const atr_aligner *a) {
+    BandParams bp;
+    memset(&bp, 0, sizeof(bp));
+    for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.codes[i] = (uint8_t)a->codes[i];
+    bp.and_mode = (a->wildcard_ref || a->wildcard_query) ? 1 : 0;
+    bp.noindel = a->indel_cost > a->p.k ? 1 : 0;
+    return bp;
+}
+
+int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                       int max_len, uint4 *out, hipStream_t st) {
+    const BandParams bp = band_params(a);
+    const dim3 grid((unsigned)((nreads + 255) / 256)), block(256);
+    if (bp.and_mode) hipLaunchKernelGGL((prefix_band_kernel<true>), grid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out);
+    else             hipLaunchKernelGGL((prefix_band_kernel<false>), grid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out);
+    return (int)hipGetLastError();
+}
+
 }  // namespace atr

@@ -1,14 +1,19 @@
 // locate_fast.hpp -- the filtered locate pipeline (see filter_core.hpp for why it is exact):
 //
-//   K1 filter_kernel   one read per lane: Myers bit-vector sweep over the whole read
-//                      (~30 VALU ops per column instead of ~7 per CELL); writes the result
-//                      record of every read it can resolve (None / first perfect hit) and a
-//                      window word for the rest; per-block histogram of window starts.
-//   K2 scan_kernel     exclusive scan of the (bin, block) histogram -> scatter offsets.
-//   K3 scatter_kernel  read indices of the unresolved reads, ordered by window start, so
-//                      that the 64 lanes of a K4 wave sweep nearly the same columns.
-//   K4 window_kernel   the packed-word DP (locate_core.hpp, window mode) over each read's
-//                      window only; reads are gathered by index (16-byte chunk loads).
+//   K1  filter_kernel   one read per lane: Myers bit-vector sweep over the whole read
+//                       (~28 VALU ops per column instead of ~7 per CELL); writes the result
+//                       record of every read it can resolve (None / first perfect hit / perfect
+//                       overlap at the read end) and a window word for the rest; per-block
+//                       histogram of the scatter bins.
+//   K2  scan kernels    exclusive scan of the (bin, block) histogram -> scatter offsets.
+//   K3  scatter_kernel  read indices of the unresolved reads, ordered by bin (filter_core.hpp,
+//                       window_bin), so that the 64 lanes of a K4 wave sweep nearly the same
+//                       cells.
+//   K4a band_kernel     reads whose candidates all sit on <= 16 neighbouring diagonals: row-major
+//                       banded DP (filter_core.hpp, band_locate).
+//   K4  window_kernel   everything else: the packed-word DP (locate_core.hpp, window mode) over
+//                       each read's window only; reads are gathered by index (16-byte chunk
+//                       loads).
 //
 // Blocks of K1/K3 own contiguous tile ranges, so K3 needs no global atomics: its offsets
 // come from K2's scan and an LDS cursor per bin.
@@ -202,6 +207,33 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         band_locate<AND_MODE>(u, s_codes, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
         if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     }
+}
+// Anchored 5' adapters: the banded DP over all reads of the batch, no pre-pass
+// (filter_core.hpp, band_locate_prefix).  One read per lane, tile64 order.
+template <bool AND_MODE>
+__global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, const BandParams bp,
+                                                          const uint4 *__restrict__ packed,
+                                                          const int32_t *__restrict__ lens, long long nreads,
+                                                          int nchunks, int max_len, uint4 *__restrict__ out) {
+    __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
+    __shared__ uint8_t s_codes[FILTER_MAX_M];
+    __shared__ uint32_t s_stream[4][BAND_STREAM][64];
+    const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
+    for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
+    if (threadIdx.x < FILTER_MAX_M) s_codes[threadIdx.x] = bp.codes[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile * 64 >= nreads) return;
+    const long long r = tile * 64 + lane;
+    const bool live = r < nreads;
+    const int n = live ? (lens ? lens[r] : max_len) : 0;
+    const uint32_t *q = (const uint32_t *)(packed + (size_t)tile * nchunks * 64 + lane);
+    uint32_t *ns = &s_stream[threadIdx.x >> 6][0][lane];
+    band_stage(q, nchunks, -u.k, ns, 64);
+    uint32_t rec[4];
+    band_locate_prefix<AND_MODE>(u, s_codes, bp.noindel != 0, ns, 64, n, s_thr, rec);
+    if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 #endif  // ATR_DEFINE_FILTER_KERNELS
 

@@ -248,6 +248,23 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
     const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
     const bool noindel = a->indel_cost > a->p.k;
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    if (filtered && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k)) {   // as atr_locate_batch
+        const LocateParams &p = a->p;
+        const Uniform u = make_uniform(p, round_up_rows(p.m));
+        uint8_t codes[FILTER_MAX_M] = {0};
+        for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint8_t)a->codes[i];
+        const int nchunks = (max_len + 31) / 32;
+        const uint32_t *pk = (const uint32_t *)packed;
+        for (long long r = 0; r < nreads; ++r) {
+            const uint32_t *q = pk + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
+            uint32_t ns[BAND_STREAM];
+            band_stage(q, nchunks, -u.k, ns, 1);
+            const int n = lens ? lens[r] : max_len;
+            if (!eqmode) band_locate_prefix<true>(u, codes, noindel, ns, 1, n, p.thr, (uint32_t *)out + 4 * r);
+            else band_locate_prefix<false>(u, codes, noindel, ns, 1, n, p.thr, (uint32_t *)out + 4 * r);
+        }
+        return ATR_OK;
+    }
     const bool fast = filtered && a->filterable && max_len > 0;
     emu_fn fn = pick_mt(idx, (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, noindel, fast, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
     fn(a, (const uint32_t *)packed, lens, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
