@@ -237,3 +237,134 @@ class RecordSource(object):
 
     def ascii(self):
         raise NotImplementedError("anchored adapters without indels are not supported by the device FASTQ pipeline")
+
+
+# ---------------------------------------------------------------------------------------------
+# file streaming: page-locked staging, threaded reads, read-ahead and write-behind
+_STAGING_POOL = []           # page-locked buffers are expensive to create: released ones are kept for reuse
+
+
+def _staging(nbytes, pinned):
+    for i, t in enumerate(_STAGING_POOL):
+        if t.numel() >= nbytes and t.is_pinned() == bool(pinned):
+            return _STAGING_POOL.pop(i)
+    t = torch.empty((nbytes,), dtype=torch.uint8)
+    return t.pin_memory() if pinned else t
+
+
+def _release(buffers):
+    _STAGING_POOL.extend(buffers)
+    del _STAGING_POOL[:-8]                                    # keep at most eight
+
+
+class ChunkedFastqReader(object):
+    """Feeds a FASTQ file to the GPU in chunks of whole records.  The file is read straight into
+    two page-locked staging buffers (four ``pread`` threads per chunk, no intermediate bytes
+    objects); the next chunk is read while the caller works on the current one."""
+
+    def __init__(self, path, chunk_bytes, backend=None):
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        self.be = backend or _lib.get_backend()
+        self.chunk_bytes = int(chunk_bytes)
+        cap = self.chunk_bytes + (64 << 20)                  # room for the carried-over tail of the previous chunk
+        pinned = getattr(self.be, "name", "") == "hip"
+        self.buf = [_staging(cap + 32, pinned), _staging(cap + 32, pinned)]
+        self.file = open(path, "rb")
+        self.fd = self.file.fileno()
+        self.size = os.path.getsize(path)
+        self.pos = 0
+        self.readers = ThreadPoolExecutor(4)
+        self.ahead = ThreadPoolExecutor(1)
+        self.k = 0
+        self.pending = self.ahead.submit(self._fill, 0, b"")
+        self.host = None
+        self.nbytes = 0
+        self.final = False
+
+    def _fill(self, k, carry):
+        import os
+        view = memoryview(self.buf[k].numpy())
+        n0 = len(carry)
+        if n0:
+            view[:n0] = carry
+        want = min(self.chunk_bytes, self.size - self.pos)
+        step = (want + 3) // 4
+        jobs = []
+        for t in range(4):
+            lo, hi = t * step, min(want, (t + 1) * step)
+            if hi > lo:
+                jobs.append(self.readers.submit(os.preadv, self.fd, [view[n0 + lo:n0 + hi]], self.pos + lo))
+        got = sum(j.result() for j in jobs)
+        self.pos += got
+        return n0 + got, self.pos >= self.size
+
+    def next_batch(self):
+        """Upload and index the next chunk; returns the FastqBatch of its whole records."""
+        self.nbytes, self.final = self.pending.result()
+        self.host = host = self.buf[self.k]
+        nbytes = self.nbytes
+        unterminated = bool(self.final and nbytes and int(host[nbytes - 1]) not in (10, 13))
+        if unterminated:
+            host[nbytes] = 10                                 # tolerate a missing last newline (_seqio.pyx:240-243)
+            nbytes += 1
+            self.nbytes = nbytes
+        data = self.be.empty(((nbytes + 15) // 16 * 16 + 16,), torch.uint8)
+        data[:nbytes].copy_(host[:nbytes], non_blocking=True)
+        data[nbytes:].zero_()
+        batch, self.consumed = FastqBatch.from_device(data, nbytes, self.final, self.be, unterminated=unterminated)
+        return batch
+
+    def advance(self, consumed=None):
+        """The caller took ``consumed`` bytes of the current chunk (default: all whole records);
+        the rest is carried over and the read of the next chunk starts.  Returns True when the
+        file is exhausted and nothing is carried over."""
+        consumed = self.consumed if consumed is None else consumed
+        carry = bytes(self.host[consumed:self.nbytes].numpy().tobytes())
+        if self.final and not carry:
+            return True
+        self.k = 1 - self.k
+        self.pending = self.ahead.submit(self._fill, self.k, carry)
+        return False
+
+    def close(self):
+        self.readers.shutdown()
+        self.ahead.shutdown()
+        self.file.close()
+        _release(self.buf)
+        self.buf = []
+
+
+class FastqSink(object):
+    """Writes device text to a file through two page-locked buffers; the write of one chunk
+    overlaps the GPU work on the next."""
+
+    def __init__(self, path, capacity, backend=None):
+        from concurrent.futures import ThreadPoolExecutor
+        be = backend or _lib.get_backend()
+        pinned = getattr(be, "name", "") == "hip"
+        self.buf = [_staging(capacity, pinned), _staging(capacity, pinned)]
+        self.file = open(path, "wb")
+        self.pool = ThreadPoolExecutor(1)
+        self.pending = None
+        self.k = 0
+
+    def write(self, text):
+        n = int(text.numel())
+        if self.pending is not None:
+            self.pending.result()                             # the other buffer is free again after this
+        if n > self.buf[self.k].numel():
+            self.buf[self.k] = _staging(n, self.buf[self.k].is_pinned())
+        host = self.buf[self.k]
+        host[:n].copy_(text)
+        self.pending = self.pool.submit(self.file.write, memoryview(host.numpy())[:n])
+        self.k = 1 - self.k
+
+    def close(self):
+        if self.pending is not None:
+            self.pending.result()
+        self.pool.shutdown()
+        self.file.close()
+        _release(self.buf)
+        self.buf = []
+

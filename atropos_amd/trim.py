@@ -197,81 +197,27 @@ class TrimPipeline(object):
     def trim_file(self, path_in, path_out, chunk_bytes=256 << 20):
         """Stream a FASTQ file through the GPU in chunks of whole records; returns the
         destination counts.  (Plain files; compressed input is the caller's business.)
-
-        Host side: the file is read straight into page-locked staging buffers (no intermediate
-        bytes objects), the next chunk is read and the previous result written by two helper
-        threads while the GPU works on the current one, and results come back into page-locked
-        memory that is handed to ``write`` as a memoryview."""
-        from concurrent.futures import ThreadPoolExecutor
-        import os
+        Host side: ``ChunkedFastqReader`` / ``FastqSink`` (page-locked staging buffers, threaded
+        reads, read-ahead and write-behind around the GPU work)."""
+        from .fastq import ChunkedFastqReader, FastqSink
         be = _lib.get_backend()
-        on_gpu = getattr(be, "name", "") == "hip"
         totals = {name: 0 for name in DEST_NAMES.values()}
-        cap = chunk_bytes + (64 << 20)                       # room for the carried-over tail of the previous chunk
-        # page-locked staging buffers are expensive to create: keep them with the pipeline
-        stage = getattr(self, "_staging", None)
-        if stage is None or stage[0].numel() < cap + 32:
-            def staging(nbytes):
-                t = torch.empty((nbytes,), dtype=torch.uint8)
-                return t.pin_memory() if on_gpu else t
-            stage = self._staging = [staging(cap + 32) for _ in range(4)]     # 2 x input, 2 x output
-        inbuf, outbuf = stage[:2], stage[2:]
-        readers = ThreadPoolExecutor(4)
-        file_size = os.path.getsize(path_in)
-        state = {"pos": 0}
-
-        def read_chunk(fd, k, carry):
-            """carry: bytes left over from the previous chunk; returns (bytes in buffer, final).
-            The chunk is read by four threads (pread into slices of the page-locked buffer)."""
-            view = memoryview(inbuf[k].numpy())
-            n0 = len(carry)
-            if n0:
-                view[:n0] = carry
-            want = min(chunk_bytes, file_size - state["pos"])
-            step = (want + 3) // 4
-            jobs = []
-            for t in range(4):
-                lo, hi = t * step, min(want, (t + 1) * step)
-                if hi > lo:
-                    jobs.append(readers.submit(os.preadv, fd, [view[n0 + lo:n0 + hi]], state["pos"] + lo))
-            got = sum(j.result() for j in jobs)
-            state["pos"] += got
-            return n0 + got, state["pos"] >= file_size
-
-        with open(path_in, "rb") as fin_obj, open(path_out, "wb") as fout, ThreadPoolExecutor(2) as pool:
-            fin = fin_obj.fileno()
-            k = 0
-            nbytes, final = read_chunk(fin, k, b"")
-            pending_write = None
+        reader = ChunkedFastqReader(path_in, chunk_bytes, be)
+        sink = FastqSink(path_out, chunk_bytes + (64 << 20) + 32, be)
+        try:
             while True:
-                host = inbuf[k]
-                if final and nbytes and int(host[nbytes - 1]) not in (10, 13):
-                    host[nbytes] = 10                         # tolerate a missing last newline (_seqio.pyx:240-243)
-                    nbytes += 1
-                padded = (nbytes + 15) // 16 * 16 + 16
-                data = be.empty((padded,), torch.uint8)
-                data[:nbytes].copy_(host[:nbytes], non_blocking=True)
-                data[nbytes:].zero_()
-                batch, consumed = FastqBatch.from_device(data, nbytes, final, be)
-                carry = b"" if final else bytes(host[consumed:nbytes].numpy().tobytes())
-                nxt = None if final else pool.submit(read_chunk, fin, 1 - k, carry)     # overlaps the GPU work below
+                batch = reader.next_batch()
+                done = reader.advance()                       # starts reading the next chunk
                 res = self.run(batch)
-                text = be.fastq_emit(batch.data, batch.records, res.begin, res.end, res.ubegin, res.uend, res.dest,
-                                     _lib.DEST_KEEP)
-                if pending_write is not None:
-                    pending_write.result()                    # the other output buffer is free again after this
-                out_host = outbuf[k]
-                out_host[:text.numel()].copy_(text)
-                pending_write = pool.submit(fout.write, memoryview(out_host.numpy())[:int(text.numel())])
+                sink.write(be.fastq_emit(batch.data, batch.records, res.begin, res.end, res.ubegin, res.uend,
+                                         res.dest, _lib.DEST_KEEP))
                 for name, v in res.counts().items():
                     totals[name] += v
-                if final:
+                if done:
                     break
-                nbytes, final = nxt.result()
-                k = 1 - k
-            if pending_write is not None:
-                pending_write.result()
-        readers.shutdown()
+        finally:
+            reader.close()
+            sink.close()
         return totals
 
 
@@ -419,34 +365,32 @@ class PairedTrimPipeline(object):
     def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
         same number from each file); returns the destination counts."""
+        from .fastq import ChunkedFastqReader, FastqSink
+        be = _lib.get_backend()
         totals = {name: 0 for name in DEST_NAMES.values()}
-        carry = [b"", b""]
-        with open(in1, "rb") as f1, open(in2, "rb") as f2, open(out1, "wb") as o1, open(out2, "wb") as o2:
-            files = (f1, f2)
+        readers = [ChunkedFastqReader(p, chunk_bytes, be) for p in (in1, in2)]
+        sinks = [FastqSink(p, chunk_bytes + (64 << 20) + 32, be) for p in (out1, out2)]
+        try:
             while True:
-                bufs, finals = [], []
-                for k in range(2):
-                    block = files[k].read(chunk_bytes)
-                    finals.append(len(block) < chunk_bytes)
-                    bufs.append(carry[k] + block)
-                batches = [FastqBatch.from_bytes(bufs[k], final=finals[k])[0] for k in range(2)]
+                batches = [r.next_batch() for r in readers]
                 nrec = min(len(batches[0]), len(batches[1]))
-                done = all(finals)
-                if done and len(batches[0]) != len(batches[1]):
-                    raise ValueError("the two input files hold different numbers of records")
                 heads = [batches[k].head(nrec) for k in range(2)]
-                for k in range(2):
-                    carry[k] = bufs[k][heads[k][1]:]
+                done = [readers[k].advance(heads[k][1]) for k in range(2)]
+                if all(r.final for r in readers) and len(batches[0]) != len(batches[1]):
+                    raise ValueError("the two input files hold different numbers of records")
                 res = self.run(heads[0][0], heads[1][0])
-                t1, t2 = res.text(_lib.DEST_KEEP)
-                o1.write(t1)
-                o2.write(t2)
+                for k, r in enumerate((res.read1, res.read2)):
+                    sinks[k].write(be.fastq_emit(r.batch.data, r.batch.records, r.begin, r.end, r.ubegin, r.uend,
+                                                 r.dest, _lib.DEST_KEEP))
                 for name, v in res.counts().items():
                     totals[name] += v
-                if done:
+                if all(done):
                     break
-                if nrec == 0 and not any(len(b) for b in bufs):
-                    break
+                if any(done):
+                    raise ValueError("the two input files hold different numbers of records")
+        finally:
+            for obj in readers + sinks:
+                obj.close()
         return totals
 
     def trim_bytes(self, data1, data2, which=_lib.DEST_KEEP):

@@ -45,4 +45,27 @@ res["trim_file"] = {"ms": ms2, "reads_per_s": nreads / ms2 * 1e3, "host_GBps": (
                     "chunk_bytes": 256 << 20, "counts": counts}
 os.remove(src)
 os.remove(dst)
+# paired-end, insert aligner: two files in lock step
+from bench_fastq_pe import device_fastq as device_fastq_pe
+npairs = nreads // 2
+w = synth.workload("C3", 0, npairs, device="cuda")
+paths = ["/tmp/atr_e2e_%s.fastq" % t for t in ("i1", "i2", "o1", "o2")]
+sizes = 0
+for k, key in enumerate(("reads1", "reads2")):
+    d, nb = device_fastq_pe(w[key], "12"[k])
+    with open(paths[k], "wb") as fh:
+        fh.write(bytes(d[:nb].cpu().numpy().tobytes()))
+    sizes += nb
+del w
+pe = pipeline_from_args("--aligner insert -a %s -A %s -q 20 -m 30" % (synth.PE_ADAPTER1, synth.PE_ADAPTER2))
+pe.trim_files(*paths, chunk_bytes=128 << 20)
+t0 = time.perf_counter()
+for _ in range(steps):
+    pe.trim_files(*paths, chunk_bytes=128 << 20)
+ms3 = (time.perf_counter() - t0) / steps * 1e3
+out_bytes = os.path.getsize(paths[2]) + os.path.getsize(paths[3])
+res["trim_files_paired"] = {"npairs": npairs, "ms": ms3, "pairs_per_s": npairs / ms3 * 1e3,
+                            "host_GBps": (sizes + out_bytes) / ms3 / 1e6}
+for p in paths:
+    os.remove(p)
 print(json.dumps(res))
