@@ -63,3 +63,71 @@ def sharded_locate(aligner, reads, host_group=None):
     total = reads.shape[0]
     local = aligner.locate_batch(local_shard(reads, rank, world))
     return local, gather_records_on_host(local.records, total, host_group)
+
+
+# ---------------------------------------------------------------------------------------------
+# sharding a FASTQ file: every rank trims its own byte range of the file, no exchange step
+def fastq_record_start(path, offset, probe=1 << 20):
+    """The first record boundary at or after byte ``offset`` of a (single-line) FASTQ file: a line
+    that starts with '@', whose line after next starts with '+' and whose sequence and quality
+    lines have the same length -- a quality line may itself start with '@', the record shape
+    does not."""
+    import os
+    size = os.path.getsize(path)
+    if offset <= 0:
+        return 0
+    if offset >= size:
+        return size
+    with open(path, "rb") as fh:
+        fh.seek(offset - 1)
+        buf = fh.read(probe + 1)
+    # line starts inside buf (a line starts after every line end; offset itself only if the byte before is one)
+    starts = [i + 1 for i in range(len(buf) - 1) if buf[i:i + 1] == b"\n" or
+              (buf[i:i + 1] == b"\r" and buf[i + 1:i + 2] != b"\n")]
+    lines = []
+    for a, b in zip(starts, starts[1:]):
+        lines.append((a, buf[a:b].rstrip(b"\r\n")))
+    for k in range(len(lines) - 3):
+        a, l0 = lines[k]
+        if l0.startswith(b"@") and lines[k + 2][1].startswith(b"+") and len(lines[k + 1][1]) == len(lines[k + 3][1]):
+            # (a quality line that starts with '@' fails here: two lines on comes a sequence line, not '+')
+            return offset - 1 + a
+    return size
+
+
+def fastq_shard_ranges(path, world):
+    """[lo, hi) byte ranges of ``world`` contiguous shards of whole records."""
+    import os
+    size = os.path.getsize(path)
+    cuts = [fastq_record_start(path, size * r // world) for r in range(world)] + [size]
+    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
+
+
+def sharded_trim_file(pipeline, path_in, path_out, rank=None, world=None, chunk_bytes=256 << 20):
+    """Every rank runs ``pipeline`` (atropos_amd.trim.TrimPipeline) over its own shard of
+    ``path_in`` and writes ``path_out + ".part%d" % rank``; the parts concatenated in rank order are
+    the output of a single-process run.  Returns this rank's destination counts."""
+    import torch.distributed as dist
+    from . import _lib
+    from .fastq import FastqBatch
+    if rank is None:
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    lo, hi = fastq_shard_ranges(path_in, world)[rank]
+    totals = None
+    with open(path_in, "rb") as fin, open("%s.part%d" % (path_out, rank), "wb") as fout:
+        fin.seek(lo)
+        left, carry = hi - lo, b""
+        while True:
+            block = fin.read(min(chunk_bytes, left))
+            left -= len(block)
+            final = left == 0
+            batch, consumed = FastqBatch.from_bytes(carry + block, final=final)
+            carry = b"" if final else (carry + block)[consumed:]
+            res = pipeline.run(batch)
+            fout.write(res.text(_lib.DEST_KEEP))
+            counts = res.counts()
+            totals = counts if totals is None else {k: totals[k] + v for k, v in counts.items()}
+            if final:
+                break
+    return totals
+

@@ -64,3 +64,59 @@ def test_shard_range_partition():
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert all(lo <= hi for lo, hi in spans)
+
+
+def _trim_worker(rank, world, port, path_in, path_out, args):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from atropos_amd import _lib, shard
+    from atropos_amd.trim import pipeline_from_args
+    from tests.emu.backend import EmuBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _lib.set_backend(EmuBackend())
+    counts = shard.sharded_trim_file(pipeline_from_args(args), path_in, path_out, chunk_bytes=40000)
+    total = torch.tensor([sum(counts.values())], dtype=torch.int64)
+    dist.all_reduce(total)                      # host-side sum of the per-rank summaries (multicore.py:389)
+    if rank == 0:
+        open(path_out + ".total", "w").write(str(int(total.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_trim_file_matches_single_process(tmp_path, emu_backend, world):
+    """Each rank trims its own byte range of the FASTQ file; the parts in rank order are the
+    single-process output (no data-path collective)."""
+    import base64
+    from atropos_amd.trim import pipeline_from_args
+    from .conftest import load_golden
+    data = base64.b64decode(load_golden("trim_cases.json.gz")["inputs"]["synth.fastq"])
+    args = "-a AGATCGGAAGAGCACACGTCTGAACTCCAGTCA -q 20 --trim-n -m 20"
+    path_in, path_out = str(tmp_path / "in.fastq"), str(tmp_path / "out.fastq")
+    open(path_in, "wb").write(data)
+    mp.spawn(_trim_worker, args=(world, _free_port(), path_in, path_out, args), nprocs=world, join=True)
+    parts = b"".join(open("%s.part%d" % (path_out, r), "rb").read() for r in range(world))
+    assert parts == pipeline_from_args(args).trim_bytes(data)
+    assert int(open(path_out + ".total").read()) == data.count(b"\n") // 4
+
+
+def test_fastq_shard_ranges_are_record_aligned(tmp_path):
+    from atropos_amd.shard import fastq_shard_ranges
+    recs = []
+    for i in range(200):
+        n = 10 + (i * 7) % 40
+        q = ("@" + "I" * (n - 1)) if i % 3 == 0 else "I" * n       # quality lines that start with '@'
+        recs.append("@r%d\n%s\n+\n%s\n" % (i, "A" * n, q))
+    text = "".join(recs).encode()
+    path = str(tmp_path / "x.fastq")
+    open(path, "wb").write(text)
+    for world in (1, 2, 3, 5, 8):
+        ranges = fastq_shard_ranges(path, world)
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(text)
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        for lo, hi in ranges:
+            shard = text[lo:hi]
+            assert shard.count(b"\n") % 4 == 0
+            assert not shard or shard.startswith(b"@r")
