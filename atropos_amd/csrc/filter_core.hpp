@@ -39,7 +39,44 @@ constexpr int FILTER_BINS = 256;                   // 96 window-start bins of 8 
 
 struct FilterParams {
     uint64_t peq[16];                               // peq[c]: rows matching query code c, top-aligned (see FilterState); pad bits 1
+    int rows;                                       // rows the bit-vector sweeps: m, or 32 in NARROW mode (below)
+    int and_mode;                                   // wildcard comparison (code & code) instead of equality
+    uint32_t tail;                                  // NARROW mode: the codes of rows rows + 1 .. m, one nibble each
 };
+
+// NARROW mode.  A 33 .. 40-base adapter needs two 32-bit words per bit-vector and ~28 VALU ops per
+// column; its first 32 rows alone need one word and ~17.  An alignment of all m rows that ends in
+// (m, j) with cost c <= k passes through row 32 in a cell (32, j') of cost <= c, j - T - k <= j' <= j
+// (T = m - 32 tail rows, at most k of the remaining steps are deletions), so the columns where the
+// 32-ROW matrix has D' <= k bracket every row-m candidate:
+//   * window start: the alignment starts where its 32-row part starts, >= j'_first - 32 - k;
+//   * window end: j <= j'_last + T + k;
+//   * band: two cells of one traceback differ in diagonal by at most the indels between them, so
+//     every traceback stays within k diagonals of its row-32 cell: diagonals
+//     j'_first - 32 - k .. j'_last - 32 + k, the same span formula as with all rows;
+//   * first perfect occurrence: D[m][j] == 0 implies D'[32][j - T] == 0, so if the first zero of
+//     the 32-row matrix is followed by T matching tail bases that IS the first perfect occurrence;
+//     if it is not, the read goes to the DP;
+//   * last column: rows <= 32 are exact; a longer row i is kept when the lower bound
+//     D'[32][n] - (i - 32) passes its threshold (a vertical delta is >= -1).
+// All of it only widens what the exact DP kernels are asked to look at.  Not used with
+// START_WITHIN_SEQ1 (an alignment may then start in column 0 below row 32).
+constexpr int FILTER_NARROW_ROWS = 32, FILTER_NARROW_TAIL = 8;
+inline bool filter_narrow_applies(int m, int flags) {          // host side
+    return m > FILTER_NARROW_ROWS && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && !(flags & ATR_START_WITHIN_SEQ1);
+}
+// peq64: the aligner's match masks (top-aligned in 64 bits when m > 32, in 32 bits otherwise)
+inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, int m, int flags, bool and_mode) {
+    FilterParams fp;
+    fp.rows = m; fp.and_mode = and_mode ? 1 : 0; fp.tail = 0u;
+    for (int c = 0; c < 16; ++c) fp.peq[c] = peq64[c];
+    if (filter_narrow_applies(m, flags)) {
+        fp.rows = FILTER_NARROW_ROWS;
+        for (int c = 0; c < 16; ++c) fp.peq[c] = (peq64[c] >> (64 - m)) & 0xFFFFFFFFull;      // rows 1 .. 32 at bits 0 .. 31
+        for (int t = 0; t < m - FILTER_NARROW_ROWS; ++t) fp.tail |= (uint32_t)(codes[FILTER_NARROW_ROWS + t] & 15u) << (4 * t);
+    }
+    return fp;
+}
 
 // window word written per read by the pre-pass
 //   [9:0] j_lo   [19:10] j_hi   [20] take last-column candidates   [27:21] highest row needed
@@ -63,12 +100,19 @@ ATR_DEV bool window_valid(uint32_t w) { return (w >> 31) != 0; }
 //   [192, 256) equal-length batches (by_rows): the row-limited partial overlaps at the read end
 //              (window = [n - rows - errors, n]) by row count, which makes a wave uniform in
 //              rows AND window.
-constexpr int BAND_BINS = 96;
+constexpr int BAND_BINS = 96, ROWS_BIN0 = 192;
+// A wave made of [192, 256) reads only (equal read length n, last-column candidates only, at
+// most `rows` rows) can skip the rows above rows - (n - j) + k in column j: a cell (i, j) on a
+// path that ends in (i', n), i' <= rows, with b <= k deletions and a insertions has
+// i = i' - (n - j) + b - a.  The skipped cells keep their initial value (cost i * indel, an upper
+// bound of any cell of row i -- except in a real column 0 with START_WITHIN_SEQ1, where the
+// window DP does not use the triangle), so they never win a comparison they would have lost.
+ATR_DEV int triangle_rows(int rows, int n, int j, int k) { return rows - (n - j) + k; }
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
     if (window_band(w)) return start;
     if (rows >= m || !by_rows) return 96 + start;
-    return 192 + atr_min(rows, 63);
+    return ROWS_BIN0 + atr_min(rows, 63);
 }
 
 struct FilterState {
@@ -87,14 +131,15 @@ struct FilterState {
 // at cost 0 in every column and play the part of the free row 0 (START_WITHIN_SEQ2).
 ATR_DEV int filter_row_offset(int m) { return (m > 32 ? 64 : 32) - m; }
 
-ATR_DEV void filter_init(FilterState &F, const Uniform &u) {
+// mf = FilterParams::rows in all of the following.
+ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf) {
     // column 0: cost i per row (not START_WITHIN_SEQ1) or 0 everywhere (_align.pyx:333-352)
-    const int off = filter_row_offset(u.m);
+    const int off = filter_row_offset(mf);
     const uint32_t low = off >= 32 ? 0u : ~0u << (off & 31);           // rows living in the low word
-    if (u.m > 32) { F.pvl = u.sr ? 0u : low; F.pvh = u.sr ? 0u : ~0u; }
+    if (mf > 32) { F.pvl = u.sr ? 0u : low; F.pvh = u.sr ? 0u : ~0u; }
     else { F.pvl = u.sr ? 0u : low; F.pvh = 0u; }
     F.mvl = F.mvh = 0u;
-    F.score = (u.sr ? 0 : u.m) - (u.k + 1);
+    F.score = (u.sr ? 0 : mf) - (u.k + 1);
     F.hits = 0u;
     F.best = ~0u;
     F.j_first = F.j_last = 0;
@@ -104,8 +149,8 @@ ATR_DEV void filter_init(FilterState &F, const Uniform &u) {
 // penalty that keeps columns j < m (where a zero cost is only possible with START_WITHIN_SEQ1
 // and is no full-length occurrence: _align.pyx:456-458 needs the whole reference inside the
 // read) from ever winning.
-ATR_DEV uint32_t filter_column_tag(const Uniform &u, int j) {
-    return (uint32_t)j + ((uint32_t)(u.k + 1) << 10) + (j < u.m ? 1u << 20 : 0u);
+ATR_DEV uint32_t filter_column_tag(const Uniform &u, int mf, int j) {
+    return (uint32_t)j + ((uint32_t)(u.k + 1) << 10) + (j < mf ? 1u << 20 : 0u);
 }
 
 // x <<= 1 on a one- or two-word vector; the bit shifted out of the top is added to
@@ -175,7 +220,15 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
         F.mvh = phh & xvh;
     }
     filter_push_hit(F.hits, F.score);
-    F.best = atr_minu(F.best, ((uint32_t)F.score << 10) + tag);
+#ifdef ATR_HOST_EMU
+    const uint32_t key = ((uint32_t)F.score << 10) + tag;
+#else
+    // tag is wave-uniform (the column number): one v_lshl_add_u32 with the tag in an SGPR; left to
+    // itself hipcc re-associates the sum into three VALU ops
+    uint32_t key;
+    asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(key) : "v"(F.score), "s"(tag));
+#endif
+    F.best = atr_minu(F.best, key);
 }
 
 // Fold the hit bits of the (at most 32) columns swept since the last fold into j_first /
@@ -191,38 +244,65 @@ ATR_DEV void filter_fold(FilterState &F, int j) {
 
 // Last column (column n): which rows could pass the candidate test?  The alignment length is
 // at most the row and the threshold is monotone in the length, so D[i][n] <= thr[i] is a
-// necessary condition.  Returns the largest such row (0: none) and its cost.
-ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const int16_t *thr, int &cost_of_largest) {
+// necessary condition.  Returns the largest such row (0: none) and its cost; exact = false
+// when that row lies beyond the swept rows and was only kept by its lower bound (NARROW mode).
+ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, int mf, const int16_t *thr, int &cost_of_largest,
+                               bool &exact) {
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
-    cost_of_largest = 0;
-    const int off = filter_row_offset(u.m);
-    for (int i = 1; i <= u.m; ++i) {
+    exact = true;
+    const int off = filter_row_offset(mf);
+    for (int i = 1; i <= mf; ++i) {
         const int b = off + i - 1;
         const uint32_t pw = (b < 32) ? F.pvl : F.pvh, mw = (b < 32) ? F.mvl : F.mvh;
-        d += (int)((pw >> (b & 31)) & 1u) - (int)((mw >> (b & 31)) & 1u);
-        if ((u.er || i == u.m) && i >= u.min_overlap && d <= (int)thr[i]) { largest = i; cost_of_largest = d; }
+        d += (int)((pw >> (b & 31)) & 1u) + ((int)(mw << (31 - (b & 31))) >> 31);      // +1 / -1: bfe_u32, bfe_i32, add3
+        if ((u.er || i == u.m) && i >= u.min_overlap && d <= (int)thr[i]) largest = i;
     }
+    {   // its cost: the vertical deltas of rows 1 .. largest
+        const uint64_t rows = (largest >= 64 ? ~0ull : ((1ull << largest) - 1ull)) << off;
+        const uint64_t pv = ((uint64_t)F.pvh << 32) | F.pvl, mv = ((uint64_t)F.mvh << 32) | F.mvl;
+        cost_of_largest = atr_popc64(pv & rows) - atr_popc64(mv & rows);
+    }
+    for (int i = mf + 1; i <= u.m; ++i)
+        if ((u.er || i == u.m) && i >= u.min_overlap && d - (i - mf) <= (int)thr[i]) { largest = i; exact = false; }
     return largest;
+}
+
+// NARROW mode: do the T = m - mf bases after column jp equal the adapter's tail rows?
+// q: this read's dwords (read_dword below).
+ATR_DEV uint32_t read_dword(const uint32_t *q, int nchunks, int z8);
+ATR_DEV bool filter_tail_matches(const FilterParams &fp, int T, const uint32_t *q, int nchunks, int jp) {
+    const uint32_t lo = read_dword(q, nchunks, jp >> 3), hi = read_dword(q, nchunks, (jp >> 3) + 1);
+    const uint32_t sh = 4u * (uint32_t)(jp & 7);
+    const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;                 // bases jp + 1 .. jp + 8
+    const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
+    const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
+    const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;                // nibble != 0
+    return fp.and_mode ? nz == ones : nz == 0u;
 }
 
 // Decision for one read of length n after the sweep.  Returns the window word (0 when the
 // read is resolved here, in which case rec[] holds its result record).
-ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, int n, const int16_t *thr, uint32_t rec[4]) {
+ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const FilterParams &fp, const uint32_t *q,
+                               int nchunks, int n, const int16_t *thr, uint32_t rec[4]) {
+    const int mf = fp.rows, T = u.m - mf;                                // T > 0: NARROW mode
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
     if ((F.best >> 10) == 0u && u.m >= u.min_overlap) {
         // first perfect full-length occurrence: the reference breaks out here (:456-458)
-        const int j = (int)(F.best & 1023u);
-        rec[0] = (uint32_t)u.m << 16;                                   // refstart 0, refstop m
-        rec[1] = (uint32_t)(j - u.m) | ((uint32_t)j << 16);             // querystart, querystop
-        rec[2] = (uint32_t)u.m;                                         // matches m, errors 0
-        return 0;
+        const int j = (int)(F.best & 1023u) + T;
+        if (T == 0 || (j <= n && filter_tail_matches(fp, T, q, nchunks, j - T))) {
+            rec[0] = (uint32_t)u.m << 16;                                   // refstart 0, refstop m
+            rec[1] = (uint32_t)(j - u.m) | ((uint32_t)j << 16);             // querystart, querystop
+            rec[2] = (uint32_t)u.m;                                         // matches m, errors 0
+            return 0;
+        }
     }
     int cost_l = 0;
-    const int row_l = filter_last_column(F, u, thr, cost_l);
+    bool exact_l = true;
+    const int row_l = filter_last_column(F, u, mf, thr, cost_l, exact_l);
     const bool lastcol = row_l != 0;
     const bool rowm = F.j_first != 0 && u.m >= u.min_overlap;
     if (!lastcol && !rowm) return 0;
-    if (!rowm && !u.sr && cost_l == 0) {
+    if (!rowm && !u.sr && exact_l && cost_l == 0) {
         // The only acceptable cells sit in the last column, and the longest of them is a
         // perfect overlap of row_l bases: a zero-cost cell is a pure diagonal, so its payload is
         // (matches row_l, origin n - row_l); every other acceptable cell lies in a smaller
@@ -235,19 +315,20 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, int n, co
     // Window start: a cell (i, j) of cost c is reached from row 0 at a column >= j - i - (number
     // of deletions on its path), and that number is at most c (unit indel cost: c is the
     // exact D) or k.  Row-m candidates: the first one bounds them all (j - D[m][j] never
-    // decreases with j).  Last-column candidates: row + D never decreases with the row, so
-    // the largest acceptable row bounds them all.
+    // decreases with j); NARROW: see the note at FilterParams.  Last-column candidates: row + D
+    // never decreases with the row, so the largest acceptable row bounds them all.
     int j_lo = 0x7fffffff;
-    if (rowm) j_lo = F.j_first - u.m - u.k;
-    if (lastcol) j_lo = atr_min(j_lo, n - row_l - (u.indel == 1 ? cost_l : u.k));
+    if (rowm) j_lo = F.j_first - mf - u.k;
+    if (lastcol) j_lo = atr_min(j_lo, n - row_l - ((u.indel == 1 && exact_l) ? cost_l : u.k));
     j_lo = atr_max(0, j_lo);
-    const int j_hi = lastcol ? n : F.j_last;
     // Band: with row-m candidates only, a candidate ending in column j (j_first <= j <= j_last,
     // cost <= k) keeps to the diagonals j - m - k .. j - m + k (at most k of its steps are
     // indels), so every traceback lies on the diagonals j_lo .. j_last - m + k -- provided j_lo
-    // was not clamped at 0 (no traceback then touches column 0).
-    const bool band = rowm && !lastcol && (F.j_first - u.m - u.k >= 0) &&
+    // was not clamped at 0 (no traceback then touches column 0).  The window end of a band
+    // read is stored as (last diagonal) + m - k: j_last, or j'_last + T in NARROW mode.
+    const bool band = rowm && !lastcol && (F.j_first - mf - u.k >= 0) &&
                       (F.j_last - F.j_first + 2 * u.k <= BAND_W - 1);
+    const int j_hi = lastcol ? n : band ? F.j_last + T : atr_min(n, F.j_last + (T ? T + u.k : 0));
     // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
     // last-column row can matter (a row only depends on the rows before it)
     return window_word(j_lo, j_hi, lastcol, rowm ? u.m : row_l, band);
@@ -294,7 +375,7 @@ ATR_DEV void band_stage(const uint32_t *q, int nchunks, int dlo, uint32_t *ns, i
 template <bool AND_MODE>
 ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
                          uint32_t ww, int smax, const int16_t *thr, uint32_t rec[4]) {
-    const int dlo = window_lo(ww), j_hi = window_hi(ww);
+    const int dlo = window_lo(ww);
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
     uint32_t band[BAND_W];
 #pragma unroll
@@ -337,7 +418,7 @@ ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, c
 #pragma unroll
     for (int c = 0; c < BAND_W; ++c) {
         const int j = dlo + u.m + c;
-        if (c <= smax && band[c] < u.klimit && j <= j_hi) consider<true>(best, band[c], u.m, j, u.min_overlap, thr, cindel);
+        if (c <= smax && band[c] < u.klimit && j <= n) consider<true>(best, band[c], u.m, j, u.min_overlap, thr, cindel);
     }
     const int cost = (int)(best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;

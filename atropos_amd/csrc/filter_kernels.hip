@@ -6,12 +6,20 @@ namespace atr {
 
 window_launcher window_group_0(int), window_group_1(int), window_group_2(int), window_group_3(int);
 
+static BandParams band_params(const atr_aligner *a) {
+    BandParams bp;
+    memset(&bp, 0, sizeof(bp));
+    for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.codes[i] = (uint8_t)a->codes[i];
+    bp.and_mode = (a->wildcard_ref || a->wildcard_query) ? 1 : 0;
+    bp.noindel = a->indel_cost > a->p.k ? 1 : 0;
+    return bp;
+}
+
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st) {
     FastWork wk = fast_carve(work, nreads);
-    FilterParams fp;
-    memcpy(fp.peq, a->peq, sizeof(fp.peq));
-    const bool wide = a->p.m > 32, ragged = lens != nullptr;
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query);
+    const bool wide = fp.rows > 32, ragged = lens != nullptr;
     const dim3 grid(FAST_BLOCKS), block(256);
     if (wide) {
         if (ragged) hipLaunchKernelGGL((filter_kernel<true, true>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
@@ -24,11 +32,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
     hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
     {   // K4a: banded DP over the band reads
-        BandParams bp;
-        memset(&bp, 0, sizeof(bp));
-        for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.codes[i] = (uint8_t)a->codes[i];
-        bp.and_mode = (a->wildcard_ref || a->wildcard_query) ? 1 : 0;
-        bp.noindel = a->indel_cost > a->p.k ? 1 : 0;
+        const BandParams bp = band_params(a);
         const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 2048));
         if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
         else             hipLaunchKernelGGL((band_kernel<false>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
@@ -39,15 +43,6 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     static const group_fn groups[4] = {window_group_0, window_group_1, window_group_2, window_group_3};
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
     return groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, st);
-}
-
-static BandParams band_params(const atr_aligner *a) {
-    BandParams bp;
-    memset(&bp, 0, sizeof(bp));
-    for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.codes[i] = (uint8_t)a->codes[i];
-    bp.and_mode = (a->wildcard_ref || a->wildcard_query) ? 1 : 0;
-    bp.noindel = a->indel_cost > a->p.k ? 1 : 0;
-    return bp;
 }
 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,

@@ -40,6 +40,7 @@ static inline uint32_t atr_mad24(uint32_t a, uint32_t b, uint32_t c) { return a 
 static inline uint32_t atr_bfe1(uint32_t w, int i) { return (w >> i) & 1u; }
 static inline int atr_clz(uint32_t w) { return __builtin_clz(w); }     // w != 0
 static inline int atr_ctz(uint32_t w) { return __builtin_ctz(w); }     // w != 0
+static inline int atr_popc64(uint64_t w) { return __builtin_popcountll(w); }
 #else
 #define ATR_DEV __device__ __forceinline__
 #ifndef ATR_DEV_MEMBER
@@ -50,6 +51,7 @@ static inline int atr_ctz(uint32_t w) { return __builtin_ctz(w); }     // w != 0
 #define atr_minu min
 static __device__ __forceinline__ int atr_clz(uint32_t w) { return __clz((int)w); }
 static __device__ __forceinline__ int atr_ctz(uint32_t w) { return __ffs((int)w) - 1; }
+static __device__ __forceinline__ int atr_popc64(uint64_t w) { return __popcll(w); }
 // bit i of w as 0/1, and a*b+c with a 24-bit product: written as inline asm because hipcc
 // otherwise rewrites the 0/1 multiply into and + cmp + cndmask + add
 static __device__ __forceinline__ uint32_t atr_bfe1(uint32_t w, int i) {
@@ -211,12 +213,13 @@ ATR_DEV uint32_t column_step_limited(uint32_t (&col)[MT + 1], const uint32_t (&n
 }
 
 // Last-column candidates (_align.pyx:461-474): every row from first_i on, increasing.
+// last_p (wave-uniform): the highest position the sweep kept up to date (window DP).
 template <int MT, bool XREP>
 ATR_DEV void scan_last_column(Best &best, const uint32_t (&col)[MT + 1], int p0, int first_p, int n,
-                              int min_overlap, const int16_t *thr, int indel) {
+                              int min_overlap, const int16_t *thr, int indel, int last_p = MT) {
 #pragma unroll
     for (int i = 0; i <= MT; ++i) {
-        if (i >= first_p) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel);
+        if (i >= first_p && i <= last_p) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel);
     }
 }
 
@@ -341,7 +344,7 @@ ATR_DEV void lane_step(LaneState<MT> &L, const Uniform &u, int j, const uint32_t
         for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, mn, u.sr, u.sq, u.indel);
     }
     if (L.scan && j == L.max_n && L.max_n > L.min_n)
-        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel);
+        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel, WIN ? plimit : MT);
 }
 
 // (refstart, refstop, querystart, querystop, matches, errors, 0, 0) as 8 x int16.

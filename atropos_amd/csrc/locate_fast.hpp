@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
         const bool live = r < nreads;
         const int n = live ? (RAGGED ? lens[r] : max_len) : 0;
         FilterState F;
-        filter_init(F, u);
+        filter_init(F, u, fp.rows);
         const int jhi = RAGGED ? wave_max_i32(n) : max_len;
         const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
         if (jhi > 0) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         ++j;
-                        if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, j));
+                        if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j));
                     }
                     if (j >= jhi) break;                     // wave-uniform
                 }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
         }
         if (live) {
             uint32_t rec[4];
-            const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
+            const uint32_t ww = filter_decide(F, u, fp, (const uint32_t *)tp, nchunks, n, s_thr, rec);
             wk.win[r] = ww;
             if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
             else atomicAdd(&s_hist[window_bin(ww, u.m, !RAGGED)], 1u);
@@ -266,7 +266,11 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         const bool has_window = live && j_hi > j_lo;
         const int jlo = wave_min_i32(live ? j_lo : 0x7fffffff);          // common start column
         const int jhi = wave_max_i32(has_window ? j_hi : 0);
-        const int plimit = u.p0 + wave_max_i32(live ? window_rows(ww) : 0);   // highest position any lane needs
+        const int rows_w = wave_max_i32(live ? window_rows(ww) : 0);
+        const int plimit = u.p0 + rows_w;                                // highest position any lane needs
+        // a wave of by-rows bins only; not from a real column 0 of zeros (START_WITHIN_SEQ1), which
+        // is no upper bound of the cells to its right
+        const bool tri = first + wv * 64 >= (long long)wk.binbase[ROWS_BIN0] && !(u.sr && jlo == 0);
 
         LaneState<MT> L;
         lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
@@ -292,7 +296,8 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
                         if (j <= jlo || j > jhi) continue;
                         uint32_t nm[(MT + 31) / 32];
                         load_mask(nm, s_nm, q);
-                        lane_step<MT, NOINDEL, true, true>(L, u, j, nm, s_thr, plimit);
+                        const int pl = tri ? min(plimit, u.p0 + triangle_rows(rows_w, max_len, j, u.k)) : plimit;
+                        lane_step<MT, NOINDEL, true, true>(L, u, j, nm, s_thr, pl);
                     }
                 }
             }

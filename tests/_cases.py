@@ -86,7 +86,8 @@ def check_batches_against_oracle(Aligner, oracle, unsupported_exc, seed, rounds,
     return total
 
 
-def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds):
+def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, m_range=(1, 64),
+                            flag_choices=(14, 14, 11, 15, 10)):
     """The bit-parallel pre-pass + windowed DP against the oracle on the adapter types it
     applies to (START_WITHIN_SEQ2 and STOP_WITHIN_SEQ2 set, m <= 64): every indel regime,
     wildcard mode and overlap threshold, ragged and fixed-length batches, reads holding the
@@ -94,9 +95,9 @@ def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds):
     rng = random.Random(seed)
     total = 0
     for _ in range(rounds):
-        m = rng.randint(1, 64)
+        m = rng.randint(*m_range)
         ref = rseq(rng, m, "ACGT" if rng.random() < 0.7 else "ACGTNRY")
-        flags = rng.choice([14, 14, 11, 15, 10])
+        flags = rng.choice(flag_choices)
         e = rng.choice([0, 0.05, 0.1, 0.12, 0.2, 0.3, 0.5])
         ic = rng.choice([1, 1, 1, 2, 3, 100000])
         mo = rng.choice([1, 3, 5, 40])
@@ -109,8 +110,63 @@ def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds):
         reads = planted_reads(rng, ref, rng.choice([1, 64, 65, 130, 300]), 220, fixed)
         if rng.random() < 0.2:
             reads = [r if rng.random() < 0.5 else ref * 3 for r in reads]
+        if m > 32 and fixed is None:
+            # the 32-row pre-pass of 33..40-base adapters: a perfect 32-base prefix with a broken
+            # tail before the real occurrence, and reads that end inside the tail rows
+            bad = ref[:32] + "".join(rng.choice([c for c in "ACGT" if c != x] or "A") for x in ref[32:])
+            for cut in range(30, m + 1):
+                reads.append(rseq(rng, rng.randint(0, 40)) + ref[:cut])
+            reads += [rseq(rng, 20) + bad + rseq(rng, 9) + ref + rseq(rng, 5), rseq(rng, 7) + bad,
+                      bad + ref[:33], rseq(rng, 3) + mutate(rng, ref[:32], 0.05) + ref[32:] + rseq(rng, 11)]
         got = al.locate_batch(reads).tuples()
         assert got == al.locate_batch(reads, filtered=False).tuples()
+        if fixed and all(len(r) == fixed for r in reads):
+            # the same reads as an equal-length batch (no lens array): the pre-pass then bins the
+            # partial overlaps by row count and the window DP sweeps a triangle only
+            import numpy as np
+            mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(len(reads), fixed).copy()
+            assert al.locate_batch(al.pack(mat)).tuples() == got
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
+            total += 1
+    return total
+
+
+def check_uniform_partial_overlaps(Aligner, oracle, unsupported_exc, seed, rounds, count=400,
+                                   flag_choices=(14, 14, 15, 10), short=False):
+    """Equal-length batches full of partial adapter occurrences at the read end (the row-binned
+    triangle sweep of the window DP) next to whole and absent adapters."""
+    import numpy as np
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        m = rng.randint(8, 64)
+        ref = rseq(rng, m, "ACGT" if rng.random() < 0.8 else "ACGTN")
+        flags = rng.choice(flag_choices)
+        e = rng.choice([0.05, 0.1, 0.1, 0.2, 0.3])
+        ic = rng.choice([1, 1, 2, 100000])
+        mo = rng.choice([1, 3, 5])
+        wr, wq = rng.random() < 0.2, rng.random() < 0.2
+        try:
+            al = Aligner(ref, e, flags, wr, wq, mo, ic)
+        except unsupported_exc:
+            continue
+        n = rng.randint(m // 2, m + 8 if short else 160)
+        reads = []
+        for _ in range(count):
+            w = rng.random()
+            if w < 0.7:
+                part = mutate(rng, ref, rng.choice([0, 0.03, 0.08, 0.15]))[:rng.randint(1, m)]
+                q = rseq(rng, n) + part
+                q = q[len(q) - n:] if rng.random() < 0.8 else (q + rseq(rng, rng.randint(1, 6)))[-n:]
+            elif w < 0.85:
+                q = (rseq(rng, rng.randint(0, n)) + mutate(rng, ref, 0.05) + rseq(rng, n))[:n]
+            else:
+                q = rseq(rng, n, "ACGTN")
+            reads.append(q)
+        mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(count, n).copy()
+        got = al.locate_batch(al.pack(mat)).tuples()
+        assert got == al.locate_batch(al.pack(mat), filtered=False).tuples()
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1

@@ -88,18 +88,20 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
     }
     std::vector<uint32_t> win((size_t)nreads);
     std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query);
     for (long long r = 0; r < nreads; ++r) {                       // K1
         const int n = lens ? lens[r] : max_len;
         FilterState F;
-        filter_init(F, u);
+        filter_init(F, u, fp.rows);
         for (int j = 1; j <= n; ++j) {
-            const uint64_t eq = a->peq[read_code(packed, nchunks, r, j)];
-            if (u.m > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, j));
-            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, j));
+            const uint64_t eq = fp.peq[read_code(packed, nchunks, r, j)];
+            if (fp.rows > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
+            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
             if ((j & 31) == 0 || j == n) filter_fold(F, j);        // as the kernel: once per 32-column chunk
         }
         uint32_t rec[4];
-        const uint32_t ww = filter_decide(F, u, n, s_thr, rec);
+        const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
+        const uint32_t ww = filter_decide(F, u, fp, q, nchunks, n, s_thr, rec);
         win[r] = ww;
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
         else bins[window_bin(ww, u.m, lens == nullptr)].push_back((uint32_t)r);
@@ -132,6 +134,8 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         }
     }
     std::vector<LaneState<MT>> L(64);
+    long long rows_bin0 = 0;                                       // binbase[ROWS_BIN0]
+    for (int b = 0; b < ROWS_BIN0; ++b) rows_bin0 += (long long)bins[b].size();
     for (long long base = nband; base < total; base += 64) {       // K4, one wave at a time
         int jlo = 0x7fffffff, jhi = 0, rows = 0;
         long long rr[64];
@@ -152,6 +156,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
                                  live[lane] && window_scan(wws[lane]), s_init, s_thr);
         }
         const int plimit = u.p0 + rows;
+        const bool tri = base >= rows_bin0 && !(u.sr && jlo == 0);
         if (jhi > jlo)
         for (int j = jlo + 1; j <= jhi; ++j)
             for (int lane = 0; lane < 64; ++lane) {
@@ -159,7 +164,8 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
                 const uint32_t q = (j <= nchunks * 32) ? read_code(packed, nchunks, rr[lane], j) : 0u;
                 uint32_t nm[(MT + 31) / 32];
                 for (int w2 = 0; w2 < (MT + 31) / 32; ++w2) nm[w2] = p.nmask[q][w2];
-                lane_step<MT, NOINDEL, true, true>(L[lane], u, j, nm, s_thr, plimit);
+                const int pl = tri ? std::min(plimit, u.p0 + triangle_rows(rows, max_len, j, u.k)) : plimit;
+                lane_step<MT, NOINDEL, true, true>(L[lane], u, j, nm, s_thr, pl);
             }
         for (int lane = 0; lane < 64; ++lane)
             if (live[lane]) lane_result<MT>(L[lane], u, out + 4 * rr[lane]);

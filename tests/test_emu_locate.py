@@ -28,6 +28,20 @@ def test_filtered_pipeline(emu_backend, oracle):
     assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 3, 250) > 20000
 
 
+def test_filtered_pipeline_narrow(emu_backend, oracle):
+    """33..40-base adapters without START_WITHIN_SEQ1: the pre-pass sweeps 32 rows only
+    (filter_core.hpp, NARROW mode)."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 5, 60, (33, 40), (14, 10, 6, 14)) > 5000
+
+
+def test_uniform_partial_overlaps(emu_backend, oracle):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_uniform_partial_overlaps(Aligner, oracle, _lib.AtroposHipError, 7, 25, 200) > 4000
+
+
 def test_synthetic_heads(emu_backend):
     from atropos_amd import synth
     from atropos_amd.align import Aligner

@@ -39,6 +39,20 @@ def test_filtered_pipeline(hip_backend, oracle):
     assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 41, 600) > 50000
 
 
+def test_filtered_pipeline_narrow(hip_backend, oracle):
+    """33..40-base adapters without START_WITHIN_SEQ1: the pre-pass sweeps 32 rows only
+    (filter_core.hpp, NARROW mode)."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 43, 300, (33, 40), (14, 10, 6, 14)) > 30000
+
+
+def test_uniform_partial_overlaps(hip_backend, oracle):
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_uniform_partial_overlaps(Aligner, oracle, _lib.AtroposHipError, 17, 120) > 40000
+
+
 def test_every_column_size(hip_backend, oracle):
     """One batch per register-column size (m = 1..128), indel and no-indel kernels,
     equality and wildcard compare modes."""
