@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Reduce the FETCH_SIZE / WRITE_SIZE sections of a tools/profile_r.sh summary into
+profiles/hbm_traffic.json (the `roofline.traffic` figure of bench.py).
+
+    python tools/reduce_traffic.py profiles/r13_locate_c2_rocprofv3_summary.txt
+
+Counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section):
+FETCH_SIZE reports half of a wide coalesced stream, so the streaming kernels (the pre-pass
+and the scan / scatter passes) count 2 x FETCH_SIZE; the band / window kernels gather 16-byte
+pieces per lane and count the raw value."""
+import json
+import os
+import re
+import sys
+
+STREAMING = ("filter_kernel", "scan_bins_kernel", "scan_total_kernel", "scatter_kernel")
+
+
+def short(name):
+    m = re.search(r"atr::(\w+)(<[^>]*>)?", name)
+    return "atr::" + m.group(1) + (m.group(2) or "")
+
+
+def main():
+    src = sys.argv[1]
+    per = {}
+    counter = None
+    kernel = None
+    for line in open(src):
+        if line.startswith("== pmc"):
+            counter = "FETCH_SIZE" if "pmc_FETCH_SIZE" in line else "WRITE_SIZE" if "pmc_WRITE_SIZE" in line else None
+            continue
+        if line.startswith("=="):
+            counter = None
+        if counter is None:
+            continue
+        if "atr::" in line and not line.startswith(" "):
+            kernel = short(line)
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE): launches=\d+ avg=([\d.]+)", line)
+        if m and kernel:
+            per.setdefault(kernel, {})[m.group(1)] = float(m.group(2))
+    total = 0.0
+    for k, v in per.items():
+        f = 2.0 if any(s in k for s in STREAMING) else 1.0
+        total += (f * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+    reads = 10_000_000
+    out = {"workload": "C2", "reads_per_launch": reads, "hbm_bytes_per_launch": total,
+           "hbm_bytes_per_read": total / reads,
+           "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % src,
+           "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB for the coalesced streaming kernels (gfx950 FETCH_SIZE counts "
+                     "half of a wide coalesced stream), raw FETCH_SIZE + WRITE_SIZE for the gathering band / window kernels",
+           "per_kernel": per}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "hbm_traffic.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "hbm_bytes_per_read")}))
+
+
+if __name__ == "__main__":
+    main()
