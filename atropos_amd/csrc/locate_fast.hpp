@@ -93,10 +93,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                 uint4 cur = nxt;
                 if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
                 int j = c * 32;
-#pragma unroll 1
+#pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    uint32_t w = cur.x;
-                    cur.x = cur.y; cur.y = cur.z; cur.z = cur.w;
+                    const uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
                     // the eight match masks of this dword are fetched from LDS up front so that
                     // their latency overlaps the (serially dependent) column updates
                     // (byte offsets of the eight entries: even / odd nibbles pre-scaled by 8, 12 ops per dword)
