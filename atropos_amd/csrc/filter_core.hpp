@@ -153,31 +153,37 @@ ATR_DEV uint32_t filter_column_tag(const Uniform &u, int mf, int j) {
     return (uint32_t)j + ((uint32_t)(u.k + 1) << 10) + (j < mf ? 1u << 20 : 0u);
 }
 
-// x <<= 1 on a one- or two-word vector; the bit shifted out of the top is added to
-// (SIGN = +1) or subtracted from (SIGN = -1) score.
-template <bool WIDE, int SIGN>
-ATR_DEV void filter_shift_out(uint32_t &lo, uint32_t &hi, int &score) {
+// ph <<= 1 and mh <<= 1 on one- or two-word vectors; the bit shifted out of the top of ph is
+// added to score, the one out of mh subtracted: the shift is an add-with-carry-out and the
+// score update an add/sub-with-carry-in.  A VALU write of a carry (VCC or an SGPR pair) needs
+// two wait states before a VALU reads it on gfx950 (hipcc pads its own add/addc pairs with
+// s_nop 1), so the two chains use two carry registers and fill each other's wait states.
+template <bool WIDE>
+ATR_DEV void filter_shift_out2(uint32_t &phl, uint32_t &phh, uint32_t &mhl, uint32_t &mhh, int &score) {
 #ifdef ATR_HOST_EMU
-    const uint32_t out = WIDE ? hi >> 31 : lo >> 31;
-    if (WIDE) hi = (hi << 1) | (lo >> 31);
-    lo <<= 1;
-    score += SIGN * (int)out;
+    const uint32_t pout = WIDE ? phh >> 31 : phl >> 31, mout = WIDE ? mhh >> 31 : mhl >> 31;
+    if (WIDE) { phh = (phh << 1) | (phl >> 31); mhh = (mhh << 1) | (mhl >> 31); }
+    phl <<= 1; mhl <<= 1;
+    score += (int)pout - (int)mout;
 #else
-    // VALU write of VCC -> VALU read of VCC needs two wait states on gfx950 (hipcc pads its own
-    // add/addc pairs with the same s_nop 1)
-    if (WIDE) {
-        if (SIGN > 0)
-            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\ts_nop 1\n\t"
-                "v_addc_co_u32 %2, vcc, 0, %2, vcc" : "+v"(lo), "+v"(hi), "+v"(score) : : "vcc");
-        else
-            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc\n\ts_nop 1\n\t"
-                "v_subbrev_co_u32 %2, vcc, 0, %2, vcc" : "+v"(lo), "+v"(hi), "+v"(score) : : "vcc");
-    } else {
-        if (SIGN > 0)
-            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(score) : : "vcc");
-        else
-            asm("v_add_co_u32 %0, vcc, %0, %0\n\ts_nop 1\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(score) : : "vcc");
-    }
+    uint64_t carry;                                   // the second carry register (an SGPR pair)
+    if (WIDE)
+        asm("v_add_co_u32 %0, %5, %0, %0\n\t"
+            "v_add_co_u32 %2, vcc, %2, %2\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %1, %5, %1, %1, %5\n\t"
+            "v_addc_co_u32 %3, vcc, %3, %3, vcc\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %4, %5, 0, %4, %5\n\t"
+            "v_subbrev_co_u32 %4, vcc, 0, %4, vcc"
+            : "+v"(phl), "+v"(phh), "+v"(mhl), "+v"(mhh), "+v"(score), "=&s"(carry) : : "vcc");
+    else
+        asm("v_add_co_u32 %0, %3, %0, %0\n\t"
+            "v_add_co_u32 %1, vcc, %1, %1\n\t"
+            "s_nop 0\n\t"
+            "v_addc_co_u32 %2, %3, 0, %2, %3\n\t"
+            "v_subbrev_co_u32 %2, vcc, 0, %2, vcc"
+            : "+v"(phl), "+v"(mhl), "+v"(score), "=&s"(carry) : : "vcc");
 #endif
 }
 
@@ -211,8 +217,7 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
         phh = F.mvh | ~(xhh | F.pvh);
         mhh = F.pvh & xhh;
     }
-    filter_shift_out<WIDE, +1>(phl, phh, F.score);
-    filter_shift_out<WIDE, -1>(mhl, mhh, F.score);
+    filter_shift_out2<WIDE>(phl, phh, mhl, mhh, F.score);
     F.pvl = mhl | ~(xvl | phl);
     F.mvl = phl & xvl;
     if (WIDE) {
