@@ -62,6 +62,8 @@ static inline uint32_t atr_bfrev(uint32_t v) {
 static inline int atr_popc(uint32_t v) { return __builtin_popcount(v); }
 static inline int atr_imin(int a, int b) { return a < b ? a : b; }
 static inline int atr_imax(int a, int b) { return a > b ? a : b; }
+static inline uint32_t atr_funnel(uint32_t hi, uint32_t lo, int s) { return s ? ((lo >> s) | (hi << (32 - s))) : lo; }   // s in 0..31
+static inline uint32_t atr_or_xor(uint32_t x, uint32_t a, uint32_t b) { return x | (a ^ b); }
 #else
 #ifndef ATR_DEV
 #define ATR_DEV __device__ __forceinline__
@@ -73,6 +75,15 @@ static inline int atr_imax(int a, int b) { return a > b ? a : b; }
 #define atr_popc __popc
 #define atr_imin min
 #define atr_imax max
+// ({hi, lo} >> s)[31:0], s in 0..31: ONE v_alignbit_b32 (s == 0 yields lo; written as C the
+// shift-by-32 case costs a compare and a select per word)
+static __device__ __forceinline__ uint32_t atr_funnel(uint32_t hi, uint32_t lo, int s) {
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)s);
+}
+// x | (a ^ b) as one v_bitop3_b32 (truth table 0xF0 | (0xCC ^ 0xAA))
+static __device__ __forceinline__ uint32_t atr_or_xor(uint32_t x, uint32_t a, uint32_t b) {
+    return __builtin_amdgcn_bitop3_b32(x, a, b, 0xF6);
+}
 #endif
 
 namespace atr {
@@ -93,6 +104,8 @@ struct InsertParams {
     int16_t mm_by_alen[INS_MAX_ADAPTER + 1];        // round(alen * max_adapter_mismatch_frac)
     int16_t thr_ins[INS_MAX_LEN + 1];               // floor(j * max_insert_mismatch_frac)
     int16_t k_by_len[INS_MAX_LEN + 1];              // int(max_insert_mismatch_frac * L)
+    int32_t thr_hit[INS_MAX_LEN + 1];               // thr_ins[j] for j >= min_insert_overlap, else -1; 32-bit so that the
+                                                    // sweep fetches its (wave-uniform) entry with a scalar load
     int alen1, alen2, cmp_mode;
     int min_insert_overlap, min_adapter_overlap, adapter_check_cutoff;
     int min_hit_j;                                  // smallest j whose PERFECT overlap passes insert_max_rmp (host)
@@ -239,13 +252,16 @@ ATR_DEV void pair_hit_ordered(PairState<W> &P, const InsertParams &ip, int s, in
 // insert RMP filter at all, remember it for the evaluation pass.
 template <int W>
 ATR_DEV void pair_hit_record(PairState<W> &P, const InsertParams &ip, int j, int cost) {
-    if (j > P.L) return;
-    if (cost > P.k || j < ip.min_insert_overlap || cost > (int)ip.thr_ins[j]) return;
+    if (j > P.L || cost > ip.thr_hit[j]) return;        // the common exit: two compares, threshold in an SGPR
+    if (cost > P.k) return;
     P.nhits += 1;
     if (j < ip.min_hit_j) return;                       // rmp(matches <= j, j) >= rmp(j, j) > insert_max_rmp
+    // slot ncand, written in place under the lane mask (a rotation of the slots would cost register
+    // copies on every offset, hit or not); the evaluation pass does not depend on the slot order
+    const uint32_t v = ((uint32_t)j << 16) | (uint32_t)cost;
 #pragma unroll
-    for (int c = INS_CAND - 1; c >= 1; --c) P.cand[c] = P.cand[c - 1];
-    P.cand[0] = ((uint32_t)j << 16) | (uint32_t)cost;
+    for (int c = 0; c < INS_CAND; ++c)
+        if (P.ncand == c) P.cand[c] = v;
     P.ncand += 1;
 }
 
@@ -295,8 +311,10 @@ ATR_DEV int overlap_cost(const PairState<W> &P, const uint32_t (&rs)[4][W], uint
     int cost = 0;
 #pragma unroll
     for (int w = 0; w + Q < W; ++w) {
-        uint32_t m = ((P.a[0][w] ^ rs[0][w + Q]) | (P.a[1][w] ^ rs[1][w + Q])) |
-                     ((P.a[2][w] ^ rs[2][w + Q]) | (P.a[3][w] ^ rs[3][w + Q]));
+        uint32_t m = P.a[0][w] ^ rs[0][w + Q];                        // four ops per 32 bases
+        m = atr_or_xor(m, P.a[1][w], rs[1][w + Q]);
+        m = atr_or_xor(m, P.a[2][w], rs[2][w + Q]);
+        m = atr_or_xor(m, P.a[3][w], rs[3][w + Q]);
         if (w + Q == W - 1) m &= topmask;
         cost += atr_popc(m);
     }
@@ -327,7 +345,7 @@ struct WordShift {
 #pragma unroll
                     for (int w = 0; w < W; ++w) {
                         const uint32_t lo = P.r[p][w], hi = (w + 1 < W) ? P.r[p][(w + 1 < W) ? w + 1 : 0] : 0u;
-                        rs[p][w] = (w >= Q) ? (s ? ((lo >> s) | (hi << (32 - s))) : lo) : 0u;
+                        rs[p][w] = (w >= Q) ? atr_funnel(hi, lo, s) : 0u;
                     }
                 pair_hit_ordered<W, Q>(P, ip, s, j, overlap_cost<W, Q>(P, rs, 0xFFFFFFFFu >> s));
             }
@@ -358,7 +376,7 @@ ATR_DEV void sweep_unordered(PairState<W> &P, const InsertParams &ip, int jmax, 
 #pragma unroll
             for (int w = 0; w < W; ++w) {
                 const uint32_t lo = P.r[p][w], hi = (w + 1 < W) ? P.r[p][(w + 1 < W) ? w + 1 : 0] : 0u;
-                rs[p][w] = s ? ((lo >> s) | (hi << (32 - s))) : lo;
+                rs[p][w] = atr_funnel(hi, lo, s);
             }
         WordShift<W, 0, false>::all(P, ip, s, rs, 0xFFFFFFFFu >> s, jmax);
     }

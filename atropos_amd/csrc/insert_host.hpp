@@ -58,6 +58,7 @@ inline int insert_fill(atr_insert_aligner *h, const atr_insert_config *c) {
         p.k_by_len[j] = (int16_t)(kd < 0 ? -1 : (kd > 30000 ? 30000 : (int)kd));
     }
     p.min_insert_overlap = c->min_insert_overlap;
+    for (int j = 0; j <= INS_MAX_LEN; ++j) p.thr_hit[j] = j >= c->min_insert_overlap ? (int32_t)p.thr_ins[j] : -1;
     p.min_adapter_overlap = c->min_adapter_overlap;
     p.adapter_check_cutoff = c->adapter_check_cutoff;
     p.insert_max_rmp = c->insert_max_rmp;
