@@ -251,8 +251,8 @@ ATR_DEV void pair_hit_ordered(PairState<W> &P, const InsertParams &ip, int s, in
 // The same hit in the unordered sweep: count it; if its overlap is long enough to pass the
 // insert RMP filter at all, remember it for the evaluation pass.
 template <int W>
-ATR_DEV void pair_hit_record(PairState<W> &P, const InsertParams &ip, int j, int cost) {
-    if (j > P.L || cost > ip.thr_hit[j]) return;        // the common exit: two compares, threshold in an SGPR
+ATR_DEV void pair_hit_record(PairState<W> &P, const InsertParams &ip, int j, int cost, int limit) {
+    if (j > P.L || cost > limit) return;                // the common exit; limit = ip.thr_hit[j], in an SGPR
     if (cost > P.k) return;
     P.nhits += 1;
     if (j < ip.min_hit_j) return;                       // rmp(matches <= j, j) >= rmp(j, j) > insert_max_rmp
@@ -304,19 +304,46 @@ ATR_DEV bool evaluate_candidate(const PairState<W> &P, const InsertParams &ip, i
     return true;
 }
 
-// cost of overlap j = 32*(W-Q) - s: read-1 words 0 .. W-1-Q against Rs words Q .. W-1
-// (Rs = R >> s); the top word keeps only its 32 - s valid bits.
+// mismatches of read-1 word w against Rs word w + Q (Rs = R >> s); the top word keeps only its
+// 32 - s valid bits.  Four ops per 32 bases.
+template <int W, int Q>
+ATR_DEV int word_cost(const PairState<W> &P, const uint32_t (&rs)[4][W], uint32_t topmask, int w) {
+    uint32_t m = P.a[0][w] ^ rs[0][w + Q];
+    m = atr_or_xor(m, P.a[1][w], rs[1][w + Q]);
+    m = atr_or_xor(m, P.a[2][w], rs[2][w + Q]);
+    m = atr_or_xor(m, P.a[3][w], rs[3][w + Q]);
+    if (w + Q == W - 1) m &= topmask;
+    return atr_popc(m);
+}
+
+// cost of overlap j = 32*(W-Q) - s: read-1 words 0 .. W-1-Q against Rs words Q .. W-1.
 template <int W, int Q>
 ATR_DEV int overlap_cost(const PairState<W> &P, const uint32_t (&rs)[4][W], uint32_t topmask) {
     int cost = 0;
 #pragma unroll
-    for (int w = 0; w + Q < W; ++w) {
-        uint32_t m = P.a[0][w] ^ rs[0][w + Q];                        // four ops per 32 bases
-        m = atr_or_xor(m, P.a[1][w], rs[1][w + Q]);
-        m = atr_or_xor(m, P.a[2][w], rs[2][w + Q]);
-        m = atr_or_xor(m, P.a[3][w], rs[3][w + Q]);
-        if (w + Q == W - 1) m &= topmask;
-        cost += atr_popc(m);
+    for (int w = 0; w + Q < W; ++w) cost += word_cost<W, Q>(P, rs, topmask, w);
+    return cost;
+}
+
+// The same for the unordered sweep, which only needs the cost of the offsets that can be hits
+// (cost <= limit, the wave-uniform threshold of this overlap length): two words of a random
+// overlap already hold ~48 mismatches, so the remaining words are compared only if some lane of
+// the wave is still below the limit after two.  A lane that returns early returns a partial
+// cost above the limit, which the hit test rejects like the full one.
+constexpr int INS_PROBE_WORDS = 2;
+template <int W, int Q>
+ATR_DEV int overlap_cost_limited(const PairState<W> &P, const uint32_t (&rs)[4][W], uint32_t topmask, int limit) {
+    int cost = 0;
+#pragma unroll
+    for (int w = 0; w + Q < W && w < INS_PROBE_WORDS; ++w) cost += word_cost<W, Q>(P, rs, topmask, w);
+    if constexpr (W - Q > INS_PROBE_WORDS) {
+#ifdef ATR_HOST_EMU
+        if (cost > limit) return cost;
+#else
+        if (!__any(cost <= limit)) return cost;                     // wave-uniform
+#endif
+#pragma unroll
+        for (int w = INS_PROBE_WORDS; w + Q < W; ++w) cost += word_cost<W, Q>(P, rs, topmask, w);
     }
     return cost;
 }
@@ -327,7 +354,10 @@ struct WordShift {
     static ATR_DEV_MEMBER void all(PairState<W> &P, const InsertParams &ip, int s, const uint32_t (&rs)[4][W],
                                    uint32_t topmask, int jmax) {
         const int j = 32 * (W - Q) - s;
-        if (j >= 1 && j <= jmax) pair_hit_record<W>(P, ip, j, overlap_cost<W, Q>(P, rs, topmask));
+        if (j >= 1 && j <= jmax) {
+            const int limit = ip.thr_hit[atr_imin(j, INS_MAX_LEN)];       // wave-uniform: a scalar load
+            pair_hit_record<W>(P, ip, j, overlap_cost_limited<W, Q>(P, rs, topmask, limit), limit);
+        }
         WordShift<W, Q + 1, ORDERED>::all(P, ip, s, rs, topmask, jmax);
     }
     // ordered sweep: word shifts from W-1 down (j ascending), all bit shifts from 31 down inside
