@@ -376,35 +376,35 @@ ATR_DEV void band_stage(const uint32_t *q, int nchunks, int dlo, uint32_t *ns, i
         ns[(size_t)k * nss] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
 }
 
-// ns: the staged read (band_stage), stride nss.
-template <bool AND_MODE>
-ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
-                         uint32_t ww, int smax, const int16_t *thr, uint32_t rec[4]) {
-    const int dlo = window_lo(ww);
+// bit 3 of every nibble = "the nibble is not zero": v | v << 1, then | << 2 (bits that cross into
+// the next nibble only land in its low three bits)
+ATR_DEV uint32_t nibble_any(uint32_t v) {
+    const uint32_t t = v | (v << 1);
+    return t | (t << 2);
+}
+
+// The row loop over ND diagonals (compile-time: no per-cell test, the neighbours are registers).
+// Diagonals smax + 1 .. ND - 1 are swept too; nothing on them is looked at afterwards.
+template <bool AND_MODE, int ND>
+ATR_DEV void band_rows(const Uniform &u, const uint8_t *codes, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W]) {
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
-    uint32_t band[BAND_W];
-#pragma unroll
-    for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
     // bases dlo + i + c of the read, c = 0 .. 15, for row i = 1: stream nibbles 0 .. 15
     uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
     uint32_t feed = ns[(size_t)2 * nss];              // the dword the next bases come from
     for (int i = 1; i <= u.m; ++i) {
         const uint32_t rrep = (uint32_t)codes[i - 1] * 0x11111111u;
-        const uint32_t v0 = AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep), v1 = AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep);
-        uint32_t m0 = (v0 | (v0 >> 1) | (v0 >> 2) | (v0 >> 3)) & 0x11111111u;       // nibble != 0
-        uint32_t m1 = (v1 | (v1 >> 1) | (v1 >> 2) | (v1 >> 3)) & 0x11111111u;
-        if (AND_MODE) { m0 ^= 0x11111111u; m1 ^= 0x11111111u; }                   // mismatch = no common bit
+        uint32_t m0 = nibble_any(AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep));          // nibble != 0, at bit 3
+        uint32_t m1 = ND > 8 ? nibble_any(AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep)) : 0u;
+        if (AND_MODE) { m0 = ~m0; m1 = ~m1; }                                     // mismatch = no common bit
         uint32_t left = inf;
 #pragma unroll
-        for (int c = 0; c < BAND_W; ++c) {
-            if (c <= smax) {                                                        // wave-uniform
-                const uint32_t bit = ((c < 8 ? m0 : m1) >> (4 * (c & 7))) & 1u;
-                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
-                const uint32_t up = (c + 1 < BAND_W && c + 1 <= smax) ? band[(c + 1 < BAND_W) ? c + 1 : 0] : inf;
-                const uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
-                band[c] = nw;
-                left = nw;
-            }
+        for (int c = 0; c < ND; ++c) {
+            const uint32_t bit = atr_bfe1(c < 8 ? m0 : m1, 4 * (c & 7) + 3);
+            const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
+            const uint32_t up = c + 1 < ND ? band[c + 1 < ND ? c + 1 : 0] : inf;
+            const uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
+            band[c] = nw;
+            left = nw;
         }
         // slide the window by one base: stream nibble i + 15 comes in at the top
         qw0 = (qw0 >> 4) | (qw1 << 28);
@@ -415,6 +415,21 @@ ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, c
             feed = k < BAND_STREAM ? ns[(size_t)k * nss] : 0u;
         }
     }
+}
+
+// ns: the staged read (band_stage), stride nss.
+template <bool AND_MODE>
+ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
+                         uint32_t ww, int smax, const int16_t *thr, uint32_t rec[4]) {
+    const int dlo = window_lo(ww);
+    uint32_t band[BAND_W];
+#pragma unroll
+    for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
+    if (smax < 8) band_rows<AND_MODE, 8>(u, codes, ns, nss, band);                 // wave-uniform
+    else if (smax < 10) band_rows<AND_MODE, 10>(u, codes, ns, nss, band);
+    else if (smax < 12) band_rows<AND_MODE, 12>(u, codes, ns, nss, band);
+    else if (smax < 14) band_rows<AND_MODE, 14>(u, codes, ns, nss, band);
+    else band_rows<AND_MODE, 16>(u, codes, ns, nss, band);
     Best best;
     best.key = COST_FIELD_MAX - (u.m + n);
     best.word = (uint32_t)(u.m + n) << CSH;
