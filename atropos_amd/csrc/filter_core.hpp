@@ -350,7 +350,9 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const Fil
 // wave-uniform, the read is a 16-base window sliding by one base per row.  About 9 VALU ops
 // per cell, but m * (S + 1) cells instead of m * (m + 2k + S) in the column sweep.
 struct BandParams {
-    uint8_t codes[FILTER_MAX_M];                     // reference code of row i at codes[i - 1]
+    uint32_t rrep[FILTER_MAX_M];                     // reference code of row i, in all eight nibbles, at rrep[i - 1]
+                                                     // (32-bit entries of a kernel argument: the row loop fetches its
+                                                     // wave-uniform entry with a scalar load)
     int and_mode, noindel;
 };
 
@@ -386,13 +388,13 @@ ATR_DEV uint32_t nibble_any(uint32_t v) {
 // The row loop over ND diagonals (compile-time: no per-cell test, the neighbours are registers).
 // Diagonals smax + 1 .. ND - 1 are swept too; nothing on them is looked at afterwards.
 template <bool AND_MODE, int ND>
-ATR_DEV void band_rows(const Uniform &u, const uint8_t *codes, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W]) {
+ATR_DEV void band_rows(const Uniform &u, const uint32_t *rreps, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W]) {
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
     // bases dlo + i + c of the read, c = 0 .. 15, for row i = 1: stream nibbles 0 .. 15
     uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
     uint32_t feed = ns[(size_t)2 * nss];              // the dword the next bases come from
     for (int i = 1; i <= u.m; ++i) {
-        const uint32_t rrep = (uint32_t)codes[i - 1] * 0x11111111u;
+        const uint32_t rrep = rreps[i - 1];
         uint32_t m0 = nibble_any(AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep));          // nibble != 0, at bit 3
         uint32_t m1 = ND > 8 ? nibble_any(AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep)) : 0u;
         if (AND_MODE) { m0 = ~m0; m1 = ~m1; }                                     // mismatch = no common bit
@@ -419,17 +421,17 @@ ATR_DEV void band_rows(const Uniform &u, const uint8_t *codes, const uint32_t *n
 
 // ns: the staged read (band_stage), stride nss.
 template <bool AND_MODE>
-ATR_DEV void band_locate(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
+ATR_DEV void band_locate(const Uniform &u, const uint32_t *rreps, bool noindel, const uint32_t *ns, int nss, int n,
                          uint32_t ww, int smax, const int16_t *thr, uint32_t rec[4]) {
     const int dlo = window_lo(ww);
     uint32_t band[BAND_W];
 #pragma unroll
     for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
-    if (smax < 8) band_rows<AND_MODE, 8>(u, codes, ns, nss, band);                 // wave-uniform
-    else if (smax < 10) band_rows<AND_MODE, 10>(u, codes, ns, nss, band);
-    else if (smax < 12) band_rows<AND_MODE, 12>(u, codes, ns, nss, band);
-    else if (smax < 14) band_rows<AND_MODE, 14>(u, codes, ns, nss, band);
-    else band_rows<AND_MODE, 16>(u, codes, ns, nss, band);
+    if (smax < 8) band_rows<AND_MODE, 8>(u, rreps, ns, nss, band);                 // wave-uniform
+    else if (smax < 10) band_rows<AND_MODE, 10>(u, rreps, ns, nss, band);
+    else if (smax < 12) band_rows<AND_MODE, 12>(u, rreps, ns, nss, band);
+    else if (smax < 14) band_rows<AND_MODE, 14>(u, rreps, ns, nss, band);
+    else band_rows<AND_MODE, 16>(u, rreps, ns, nss, band);
     Best best;
     best.key = COST_FIELD_MAX - (u.m + n);
     best.word = (uint32_t)(u.m + n) << CSH;
@@ -466,7 +468,7 @@ inline bool prefix_band_applies(int flags, int m, int k) {          // host side
 
 // ns: the read staged from base 1 - k on (band_stage with dlo = -k), stride nss.
 template <bool AND_MODE>
-ATR_DEV void band_locate_prefix(const Uniform &u, const uint8_t *codes, bool noindel, const uint32_t *ns, int nss, int n,
+ATR_DEV void band_locate_prefix(const Uniform &u, const uint32_t *rreps, bool noindel, const uint32_t *ns, int nss, int n,
                                 const int16_t *thr, uint32_t rec[4]) {
     const int k = u.k, smax = 2 * k;
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
@@ -480,7 +482,7 @@ ATR_DEV void band_locate_prefix(const Uniform &u, const uint8_t *codes, bool noi
     uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
     uint32_t feed = ns[(size_t)2 * nss];
     for (int i = 1; i <= u.m; ++i) {
-        const uint32_t rrep = (uint32_t)codes[i - 1] * 0x11111111u;
+        const uint32_t rrep = rreps[i - 1];
         const uint32_t v0 = AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep), v1 = AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep);
         uint32_t m0 = (v0 | (v0 >> 1) | (v0 >> 2) | (v0 >> 3)) & 0x11111111u;
         uint32_t m1 = (v1 | (v1 >> 1) | (v1 >> 2) | (v1 >> 3)) & 0x11111111u;

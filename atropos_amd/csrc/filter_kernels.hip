@@ -9,7 +9,7 @@ window_launcher window_group_0(int), window_group_1(int), window_group_2(int), w
 static BandParams band_params(const atr_aligner *a) {
     BandParams bp;
     memset(&bp, 0, sizeof(bp));
-    for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.codes[i] = (uint8_t)a->codes[i];
+    for (int i = 0; i < a->p.m && i < FILTER_MAX_M; ++i) bp.rrep[i] = (uint32_t)(a->codes[i] & 15u) * 0x11111111u;
     bp.and_mode = (a->wildcard_ref || a->wildcard_query) ? 1 : 0;
     bp.noindel = a->indel_cost > a->p.k ? 1 : 0;
     return bp;

@@ -182,11 +182,9 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
                                                    long long nreads, int nchunks, int max_len, uint4 *__restrict__ out,
                                                    FastWork wk) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
-    __shared__ uint8_t s_codes[FILTER_MAX_M];
     __shared__ uint32_t s_stream[4][BAND_STREAM][64];              // per wave: the staged reads, [dword][lane]
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
     for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
-    if (threadIdx.x < FILTER_MAX_M) s_codes[threadIdx.x] = bp.codes[threadIdx.x];
     __syncthreads();
     const long long total = (long long)wk.binbase[BAND_BINS];          // band reads come first in `order`
     const int lane = threadIdx.x & 63;
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         uint32_t *ns = &s_stream[threadIdx.x >> 6][0][lane];
         band_stage(q, nchunks, window_lo(ww), ns, 64);
         uint32_t rec[4];
-        band_locate<AND_MODE>(u, s_codes, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
+        band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
         if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     }
 }
@@ -215,11 +213,9 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
                                                           const int32_t *__restrict__ lens, long long nreads,
                                                           int nchunks, int max_len, uint4 *__restrict__ out) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
-    __shared__ uint8_t s_codes[FILTER_MAX_M];
     __shared__ uint32_t s_stream[4][BAND_STREAM][64];
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
     for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
-    if (threadIdx.x < FILTER_MAX_M) s_codes[threadIdx.x] = bp.codes[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -231,7 +227,7 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
     uint32_t *ns = &s_stream[threadIdx.x >> 6][0][lane];
     band_stage(q, nchunks, -u.k, ns, 64);
     uint32_t rec[4];
-    band_locate_prefix<AND_MODE>(u, s_codes, bp.noindel != 0, ns, 64, n, s_thr, rec);
+    band_locate_prefix<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, s_thr, rec);
     if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 #endif  // ATR_DEFINE_FILTER_KERNELS

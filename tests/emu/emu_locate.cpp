@@ -112,8 +112,8 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
     long long nband = 0;                                           // band reads come first (bins [0, BAND_BINS))
     for (int b = 0; b < BAND_BINS; ++b) nband += (long long)bins[b].size();
     {                                                              // K4a: banded DP, one wave at a time
-        uint8_t codes[FILTER_MAX_M] = {0};
-        for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint8_t)a->codes[i];
+        uint32_t codes[FILTER_MAX_M] = {0};
+        for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint32_t)(a->codes[i] & 15u) * 0x11111111u;
         const bool and_mode = a->wildcard_ref || a->wildcard_query, noindel = a->indel_cost > p.k;
         for (long long base = 0; base < nband; base += 64) {
             int smax = 0;
@@ -257,8 +257,8 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
     if (filtered && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k)) {   // as atr_locate_batch
         const LocateParams &p = a->p;
         const Uniform u = make_uniform(p, round_up_rows(p.m));
-        uint8_t codes[FILTER_MAX_M] = {0};
-        for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint8_t)a->codes[i];
+        uint32_t codes[FILTER_MAX_M] = {0};
+        for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint32_t)(a->codes[i] & 15u) * 0x11111111u;
         const int nchunks = (max_len + 31) / 32;
         const uint32_t *pk = (const uint32_t *)packed;
         for (long long r = 0; r < nreads; ++r) {
