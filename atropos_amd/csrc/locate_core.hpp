@@ -165,9 +165,13 @@ ATR_DEV uint32_t column_step(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT +
         } else {
             const uint32_t cl = col[i] + delw;               // deletion:  (i, j-1) -> (i, j)
             const uint32_t cu = col[i - 1] + insw;           // insertion: (i-1, j) -> (i, j)
-            nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+            nw = atr_minu(atr_minu(cd, cl), cu);
+            // position p0 holds the row-0 word (only the first positions can be p0): the select is folded
+            // into the priority-clearing AND as one v_and_or_b32 with wave-uniform operands
+            if (i < ROW_GRAN) nw = (nw & (i == p0 ? 0u : ~PRIO_MASK)) | (i == p0 ? row0 : 0u);
+            else nw &= ~PRIO_MASK;
         }
-        if (i < ROW_GRAN) nw = (i == p0) ? row0 : nw;        // wave-uniform select, first positions only
+        if (NOINDEL && i < ROW_GRAN) nw = (i == p0) ? row0 : nw;
         col[i] = nw;
         cd = cd_next;
     }
@@ -193,9 +197,11 @@ ATR_DEV void row_blocks(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) 
             } else {
                 const uint32_t cl = col[i] + delw;
                 const uint32_t cu = col[i - 1] + insw;
-                nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
+                nw = atr_minu(atr_minu(cd, cl), cu);
+                if (i < ROW_GRAN) nw = (nw & (i == p0 ? 0u : ~PRIO_MASK)) | (i == p0 ? row0 : 0u);
+                else nw &= ~PRIO_MASK;
             }
-            if (i < ROW_GRAN) nw = (i == p0) ? row0 : nw;
+            if (NOINDEL && i < ROW_GRAN) nw = (i == p0) ? row0 : nw;
             col[i] = nw;
             cd = cd_next;
         }

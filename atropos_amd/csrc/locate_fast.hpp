@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         const int plimit = u.p0 + rows_w;                                // highest position any lane needs
         // a wave of by-rows bins only; not from a real column 0 of zeros (START_WITHIN_SEQ1), which
         // is no upper bound of the cells to its right
-        const bool tri = first + wv * 64 >= (long long)wk.binbase[ROWS_BIN0] && !(u.sr && jlo == 0);
+        const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[ROWS_BIN0])) != 0 &&
+                         !(u.sr && jlo == 0);           // (wave-uniform by construction; tell the compiler)
 
         LaneState<MT> L;
         lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
