@@ -220,12 +220,14 @@ ATR_DEV uint32_t column_step_limited(uint32_t (&col)[MT + 1], const uint32_t (&n
 
 // Last-column candidates (_align.pyx:461-474): every row from first_i on, increasing.
 // last_p (wave-uniform): the highest position the sweep kept up to date (window DP).
+// klimit = (k + 1) << CSH: no threshold exceeds thr[m] = k, so a cell of cost > k is skipped with one
+// compare instead of the full test (threshold fetch, length, ...).
 template <int MT, bool XREP>
 ATR_DEV void scan_last_column(Best &best, const uint32_t (&col)[MT + 1], int p0, int first_p, int n,
-                              int min_overlap, const int16_t *thr, int indel, int last_p = MT) {
+                              int min_overlap, const int16_t *thr, int indel, uint32_t klimit, int last_p = MT) {
 #pragma unroll
     for (int i = 0; i <= MT; ++i) {
-        if (i >= first_p && i <= last_p) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel);
+        if (i >= first_p && i <= last_p && col[i] < klimit) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel);
     }
 }
 
@@ -280,7 +282,7 @@ ATR_DEV void lane_init(LaneState<MT> &L, const Uniform &u, int n, const uint32_t
     L.best.ref_stop = u.m; L.best.query_stop = n; L.best.matches = 0;
     // Empty reads never enter the column loop: their "last column" is the initial one.
     if (L.scan && n == 0)
-        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel);
+        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel, u.klimit);
 }
 
 // Window mode (filter_core.hpp): the DP is started afresh at column j_lo as if row i had
@@ -310,7 +312,7 @@ ATR_DEV void lane_init_window(LaneState<MT> &L, const Uniform &u, int n, int j_s
     L.best.ref_stop = u.m; L.best.query_stop = n; L.best.matches = 0;
     // an empty window only arises for an empty read whose initial column already qualifies
     if (scan && j_hi <= j_start)
-        scan_last_column<MT, true>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel);
+        scan_last_column<MT, true>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel, u.klimit);
 }
 
 // Column j of the wave-uniform sweep, query code q.  Every lane of the wave executes
@@ -350,7 +352,7 @@ ATR_DEV void lane_step(LaneState<MT> &L, const Uniform &u, int j, const uint32_t
         for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, mn, u.sr, u.sq, u.indel);
     }
     if (L.scan && j == L.max_n && L.max_n > L.min_n)
-        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel, WIN ? plimit : MT);
+        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel, u.klimit, WIN ? plimit : MT);
 }
 
 // (refstart, refstop, querystart, querystop, matches, errors, 0, 0) as 8 x int16.
