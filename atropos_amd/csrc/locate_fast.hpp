@@ -89,24 +89,28 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
         if (jhi > 0) {
             const int c1 = (jhi + 31) >> 5;
             uint4 nxt = tp[0];
+            // The eight match masks of a dword are fetched from LDS ONE DWORD AHEAD of the (serially
+            // dependent) column updates that use them: two sets of eight, swapped every dword.
+            // Byte offsets of the eight entries: even / odd nibbles pre-scaled by 8, 12 ops per dword.
+            uint2 ea[8], eb[8];
+            auto fetch_masks = [&](uint32_t w, uint2 (&e)[8]) {
+                uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
+                asm("" : "+v"(ev), "+v"(od));            // keep hipcc from re-deriving each offset from w (2 ops apiece)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
+                    e[b] = *(const uint2 *)((const char *)s_peq + off);
+                }
+            };
+            fetch_masks(nxt.x, ea);
             for (int c = 0; c < c1; ++c) {
                 uint4 cur = nxt;
                 if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
                 int j = c * 32;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
-                    // the eight match masks of this dword are fetched from LDS up front so that
-                    // their latency overlaps the (serially dependent) column updates
-                    // (byte offsets of the eight entries: even / odd nibbles pre-scaled by 8, 12 ops per dword)
-                    uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
-                    asm("" : "+v"(ev), "+v"(od));            // keep hipcc from re-deriving each offset from w (2 ops apiece)
-                    uint2 e[8];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
-                        e[b] = *(const uint2 *)((const char *)s_peq + off);
-                    }
+                    uint2 (&e)[8] = (d & 1) ? eb : ea;       // this dword's masks; the other set takes the next dword's
+                    fetch_masks(d == 0 ? cur.y : d == 1 ? cur.z : d == 2 ? cur.w : nxt.x, (d & 1) ? ea : eb);
 #pragma unroll
                     for (int b = 0; b < 8; ++b) {
                         ++j;
