@@ -387,7 +387,9 @@ ATR_DEV uint32_t nibble_any(uint32_t v) {
 
 // The row loop over ND diagonals (compile-time: no per-cell test, the neighbours are registers).
 // Diagonals smax + 1 .. ND - 1 are swept too; nothing on them is looked at afterwards.
-template <bool AND_MODE, int ND>
+// PREFIX (anchored 5' adapters, band_locate_prefix): diagonal c is j - i = c - k, and while i <= k the
+// cells left of column 0 do not exist and column 0 holds the reference's initial value.
+template <bool AND_MODE, int ND, bool PREFIX = false>
 ATR_DEV void band_rows(const Uniform &u, const uint32_t *rreps, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W]) {
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
     // bases dlo + i + c of the read, c = 0 .. 15, for row i = 1: stream nibbles 0 .. 15
@@ -399,14 +401,30 @@ ATR_DEV void band_rows(const Uniform &u, const uint32_t *rreps, const uint32_t *
         uint32_t m1 = ND > 8 ? nibble_any(AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep)) : 0u;
         if (AND_MODE) { m0 = ~m0; m1 = ~m1; }                                     // mismatch = no common bit
         uint32_t left = inf;
+        if (PREFIX && i <= u.k) {                     // wave-uniform: the first k rows touch column 0
+            // column 0 of this row sits at c = k - i: cost i insertions, origin 0 (:340-342)
+            const uint32_t col0 = ORG_BIAS | ((uint32_t)atr_min(i * u.indel, INIT_COST_CAP) << CSH);
 #pragma unroll
-        for (int c = 0; c < ND; ++c) {
-            const uint32_t bit = atr_bfe1(c < 8 ? m0 : m1, 4 * (c & 7) + 3);
-            const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
-            const uint32_t up = c + 1 < ND ? band[c + 1 < ND ? c + 1 : 0] : inf;
-            const uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
-            band[c] = nw;
-            left = nw;
+            for (int c = 0; c < ND; ++c) {
+                const int j = i + c - u.k;                                // wave-uniform
+                const uint32_t bit = atr_bfe1(c < 8 ? m0 : m1, 4 * (c & 7) + 3);
+                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
+                const uint32_t up = c + 1 < ND ? band[c + 1 < ND ? c + 1 : 0] : inf;
+                uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
+                if (j <= 0) nw = j == 0 ? col0 : inf;
+                band[c] = nw;
+                left = nw;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < ND; ++c) {
+                const uint32_t bit = atr_bfe1(c < 8 ? m0 : m1, 4 * (c & 7) + 3);
+                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
+                const uint32_t up = c + 1 < ND ? band[c + 1 < ND ? c + 1 : 0] : inf;
+                const uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
+                band[c] = nw;
+                left = nw;
+            }
         }
         // slide the window by one base: stream nibble i + 15 comes in at the top
         qw0 = (qw0 >> 4) | (qw1 << 28);
@@ -479,38 +497,11 @@ ATR_DEV void band_locate_prefix(const Uniform &u, const uint32_t *rreps, bool no
         const int j = c - k;
         band[c] = j < 0 ? inf : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
     }
-    uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
-    uint32_t feed = ns[(size_t)2 * nss];
-    for (int i = 1; i <= u.m; ++i) {
-        const uint32_t rrep = rreps[i - 1];
-        const uint32_t v0 = AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep), v1 = AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep);
-        uint32_t m0 = (v0 | (v0 >> 1) | (v0 >> 2) | (v0 >> 3)) & 0x11111111u;
-        uint32_t m1 = (v1 | (v1 >> 1) | (v1 >> 2) | (v1 >> 3)) & 0x11111111u;
-        if (AND_MODE) { m0 ^= 0x11111111u; m1 ^= 0x11111111u; }
-        // column 0 of this row sits at c = k - i while i <= k: cost i insertions, origin 0 (:340-342)
-        const uint32_t col0 = ORG_BIAS | ((uint32_t)atr_min(i * u.indel, INIT_COST_CAP) << CSH);
-        uint32_t left = inf;
-#pragma unroll
-        for (int c = 0; c < BAND_W; ++c) {
-            if (c <= smax) {                                             // wave-uniform
-                const int j = i + c - k;                                 // wave-uniform
-                const uint32_t bit = ((c < 8 ? m0 : m1) >> (4 * (c & 7))) & 1u;
-                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
-                const uint32_t up = (c + 1 < BAND_W && c + 1 <= smax) ? band[(c + 1 < BAND_W) ? c + 1 : 0] : inf;
-                uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
-                if (j <= 0) nw = j == 0 ? col0 : inf;
-                band[c] = nw;
-                left = nw;
-            }
-        }
-        qw0 = (qw0 >> 4) | (qw1 << 28);
-        qw1 = (qw1 >> 4) | (feed << 28);
-        feed >>= 4;
-        if ((i & 7) == 0) {
-            const int w = 2 + (i >> 3);
-            feed = w < BAND_STREAM ? ns[(size_t)w * nss] : 0u;
-        }
-    }
+    // the diagonals beyond 2k that a wider instantiation sweeps hold true DP cells; only c <= 2k is looked at
+    if (smax < 4) band_rows<AND_MODE, 4, true>(u, rreps, ns, nss, band);            // wave-uniform
+    else if (smax < 8) band_rows<AND_MODE, 8, true>(u, rreps, ns, nss, band);
+    else if (smax < 12) band_rows<AND_MODE, 12, true>(u, rreps, ns, nss, band);
+    else band_rows<AND_MODE, 16, true>(u, rreps, ns, nss, band);
     Best best;
     best.key = COST_FIELD_MAX - (u.m + n);
     best.word = (uint32_t)(u.m + n) << CSH;
