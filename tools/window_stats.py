@@ -48,3 +48,18 @@ pw = ro[:nw * 64].view(nw, 64).max(dim=1).values.float()
 print("per-wave row limit mean %.1f; waves with full rows %.3f" % (pw.mean().item(), (pw == 34).float().mean().item()))
 cells = (u * pw).sum().item() * 64
 print("swept cells per unresolved read %.0f" % (cells / order_total))
+# classes of the unresolved reads (window word bit 28 = band)
+band = ((win >> 28) & 1) == 1
+m = 34
+cls = {
+    "band (row-m only, <= 16 diagonals)": v & band,
+    "row-binned partial overlaps (rows < m)": v & ~band & (rows < m),
+    "full rows, last column too": v & ~band & (rows >= m) & (scan == 1),
+    "full rows, window clamped at column 0": v & ~band & (rows >= m) & (scan == 0) & (lo == 0),
+    "full rows, span too wide": v & ~band & (rows >= m) & (scan == 0) & (lo > 0),
+}
+for name, sel in cls.items():
+    k = int(sel.sum())
+    if k:
+        print("%-45s n=%7d (%.3f of unresolved) window mean %.1f lo mean %.1f" % (
+            name, k, k / int(v.sum()), (hi - lo)[sel].float().mean().item(), lo[sel].float().mean().item()))
