@@ -42,6 +42,9 @@ struct FilterParams {
     int rows;                                       // rows the bit-vector sweeps: m, or 32 in NARROW mode (below)
     int and_mode;                                   // wildcard comparison (code & code) instead of equality
     uint32_t tail;                                  // NARROW mode: the codes of rows rows + 1 .. m, one nibble each
+    int32_t thr_row[FILTER_MAX_M + 1];              // last-column test of row i: D[i][n] <= thr_row[i]; -1 for a row that is
+                                                    // no candidate at all (below min_overlap, or not row m without
+                                                    // STOP_WITHIN_SEQ1).  32-bit entries of a kernel argument: scalar loads.
 };
 
 // NARROW mode.  A 33 .. 40-base adapter needs two 32-bit words per bit-vector and ~28 VALU ops per
@@ -66,9 +69,12 @@ inline bool filter_narrow_applies(int m, int flags) {          // host side
     return m > FILTER_NARROW_ROWS && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && !(flags & ATR_START_WITHIN_SEQ1);
 }
 // peq64: the aligner's match masks (top-aligned in 64 bits when m > 32, in 32 bits otherwise)
-inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, int m, int flags, bool and_mode) {
+inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, int m, int flags, bool and_mode,
+                                  const int16_t *thr, int min_overlap) {
     FilterParams fp;
     fp.rows = m; fp.and_mode = and_mode ? 1 : 0; fp.tail = 0u;
+    for (int i = 0; i <= FILTER_MAX_M; ++i)
+        fp.thr_row[i] = (i >= 1 && i <= m && i >= min_overlap && ((flags & ATR_STOP_WITHIN_SEQ1) || i == m)) ? (int32_t)thr[i] : -1;
     for (int c = 0; c < 16; ++c) fp.peq[c] = peq64[c];
     if (filter_narrow_applies(m, flags)) {
         fp.rows = FILTER_NARROW_ROWS;
@@ -251,16 +257,26 @@ ATR_DEV void filter_fold(FilterState &F, int j) {
 // at most the row and the threshold is monotone in the length, so D[i][n] <= thr[i] is a
 // necessary condition.  Returns the largest such row (0: none) and its cost; exact = false
 // when that row lies beyond the swept rows and was only kept by its lower bound (NARROW mode).
-ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, int mf, const int16_t *thr, int &cost_of_largest,
+template <bool WIDE>
+ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const FilterParams &fp, int &cost_of_largest,
                                bool &exact) {
+    const int mf = fp.rows;
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
     exact = true;
     const int off = filter_row_offset(mf);
-    for (int i = 1; i <= mf; ++i) {
+    // per row: two bit-field extracts, an add3, a compare against an SGPR and a select
+    const int low_rows = WIDE ? atr_min(mf, 32 - off) : mf;             // rows that live in the low word
+    for (int i = 1; i <= low_rows; ++i) {
         const int b = off + i - 1;
-        const uint32_t pw = (b < 32) ? F.pvl : F.pvh, mw = (b < 32) ? F.mvl : F.mvh;
-        d += (int)((pw >> (b & 31)) & 1u) + ((int)(mw << (31 - (b & 31))) >> 31);      // +1 / -1: bfe_u32, bfe_i32, add3
-        if ((u.er || i == u.m) && i >= u.min_overlap && d <= (int)thr[i]) largest = i;
+        d += (int)((F.pvl >> b) & 1u) + ((int)(F.mvl << (31 - b)) >> 31);          // +1 / -1
+        if (d <= fp.thr_row[i]) largest = i;
+    }
+    if (WIDE) {
+        for (int i = low_rows + 1; i <= mf; ++i) {
+            const int b = off + i - 1 - 32;
+            d += (int)((F.pvh >> b) & 1u) + ((int)(F.mvh << (31 - b)) >> 31);
+            if (d <= fp.thr_row[i]) largest = i;
+        }
     }
     {   // its cost: the vertical deltas of rows 1 .. largest
         const uint64_t rows = (largest >= 64 ? ~0ull : ((1ull << largest) - 1ull)) << off;
@@ -268,7 +284,7 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, int mf, c
         cost_of_largest = atr_popc64(pv & rows) - atr_popc64(mv & rows);
     }
     for (int i = mf + 1; i <= u.m; ++i)
-        if ((u.er || i == u.m) && i >= u.min_overlap && d - (i - mf) <= (int)thr[i]) { largest = i; exact = false; }
+        if (d - (i - mf) <= fp.thr_row[i]) { largest = i; exact = false; }
     return largest;
 }
 
@@ -287,8 +303,9 @@ ATR_DEV bool filter_tail_matches(const FilterParams &fp, int T, const uint32_t *
 
 // Decision for one read of length n after the sweep.  Returns the window word (0 when the
 // read is resolved here, in which case rec[] holds its result record).
+template <bool WIDE>
 ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const FilterParams &fp, const uint32_t *q,
-                               int nchunks, int n, const int16_t *thr, uint32_t rec[4]) {
+                               int nchunks, int n, uint32_t rec[4]) {
     const int mf = fp.rows, T = u.m - mf;                                // T > 0: NARROW mode
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
     if ((F.best >> 10) == 0u && u.m >= u.min_overlap) {
@@ -303,7 +320,7 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const Fil
     }
     int cost_l = 0;
     bool exact_l = true;
-    const int row_l = filter_last_column(F, u, mf, thr, cost_l, exact_l);
+    const int row_l = filter_last_column<WIDE>(F, u, fp, cost_l, exact_l);
     const bool lastcol = row_l != 0;
     const bool rowm = F.j_first != 0 && u.m >= u.min_overlap;
     if (!lastcol && !rowm) return 0;

@@ -18,7 +18,7 @@ static BandParams band_params(const atr_aligner *a) {
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st) {
     FastWork wk = fast_carve(work, nreads);
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
     const bool wide = fp.rows > 32, ragged = lens != nullptr;
     const dim3 grid(FAST_BLOCKS), block(256);
     if (wide) {

@@ -65,11 +65,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                                                      const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads, int nchunks,
                                                      int max_len, uint4 *__restrict__ out, FastWork wk) {
-    __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint2 s_peq[16];
     __shared__ uint32_t s_hist[FILTER_BINS];
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
-    for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
     if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
     if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -123,7 +121,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
         }
         if (live) {
             uint32_t rec[4];
-            const uint32_t ww = filter_decide(F, u, fp, (const uint32_t *)tp, nchunks, n, s_thr, rec);
+            const uint32_t ww = filter_decide<WIDE>(F, u, fp, (const uint32_t *)tp, nchunks, n, rec);
             wk.win[r] = ww;
             if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
             else atomicAdd(&s_hist[window_bin(ww, u.m, !RAGGED)], 1u);

@@ -88,7 +88,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
     }
     std::vector<uint32_t> win((size_t)nreads);
     std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
     for (long long r = 0; r < nreads; ++r) {                       // K1
         const int n = lens ? lens[r] : max_len;
         FilterState F;
@@ -101,7 +101,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         }
         uint32_t rec[4];
         const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
-        const uint32_t ww = filter_decide(F, u, fp, q, nchunks, n, s_thr, rec);
+        const uint32_t ww = fp.rows > 32 ? filter_decide<true>(F, u, fp, q, nchunks, n, rec) : filter_decide<false>(F, u, fp, q, nchunks, n, rec);
         win[r] = ww;
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
         else bins[window_bin(ww, u.m, lens == nullptr)].push_back((uint32_t)r);
