@@ -266,6 +266,9 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const Fil
     const int off = filter_row_offset(mf);
     // per row: two bit-field extracts, an add3, a compare against an SGPR and a select
     const int low_rows = WIDE ? atr_min(mf, 32 - off) : mf;             // rows that live in the low word
+#ifndef ATR_HOST_EMU
+#pragma unroll 4
+#endif
     for (int i = 1; i <= low_rows; ++i) {
         const int b = off + i - 1;
         d += (int)((F.pvl >> b) & 1u) + ((int)(F.mvl << (31 - b)) >> 31);          // +1 / -1
