@@ -114,6 +114,9 @@ constexpr int BAND_BINS = 96, ROWS_BIN0 = 192;
 // bound of any cell of row i -- except in a real column 0 with START_WITHIN_SEQ1, where the
 // window DP does not use the triangle), so they never win a comparison they would have lost.
 ATR_DEV int triangle_rows(int rows, int n, int j, int k) { return rows - (n - j) + k; }
+// Every wave of the window DP also skips, in column j, the rows above (j - jlo) + k (jlo = the wave's
+// start column): a path that leaves row 0 at a column c0 >= jlo and reaches (i, j) with a insertions
+// and b deletions has i = (j - c0) - b + a <= (j - jlo) + k.
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
     if (window_band(w)) return start;

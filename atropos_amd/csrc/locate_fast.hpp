@@ -267,8 +267,9 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         const int plimit = u.p0 + rows_w;                                // highest position any lane needs
         // a wave of by-rows bins only; not from a real column 0 of zeros (START_WITHIN_SEQ1), which
         // is no upper bound of the cells to its right
+        const bool head = !(u.sr && jlo == 0);
         const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[ROWS_BIN0])) != 0 &&
-                         !(u.sr && jlo == 0);           // (wave-uniform by construction; tell the compiler)
+                         head;                          // (wave-uniform by construction; tell the compiler)
 
         LaneState<MT> L;
         lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
@@ -294,7 +295,10 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
                         if (j <= jlo || j > jhi) continue;
                         uint32_t nm[(MT + 31) / 32];
                         load_mask(nm, s_nm, q);
-                        const int pl = tri ? min(plimit, u.p0 + triangle_rows(rows_w, max_len, j, u.k)) : plimit;
+                        // rows above (j - jlo) + k cannot lie on a path that left row 0 at a column >= jlo with at
+                        // most k insertions (same stale-cell argument as the triangle at the read end)
+                        int pl = head ? min(plimit, u.p0 + (j - jlo) + u.k) : plimit;
+                        if (tri) pl = min(pl, u.p0 + triangle_rows(rows_w, max_len, j, u.k));
                         lane_step<MT, NOINDEL, true, true>(L, u, j, nm, s_thr, pl);
                     }
                 }

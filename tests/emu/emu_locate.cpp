@@ -156,7 +156,8 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
                                  live[lane] && window_scan(wws[lane]), s_init, s_thr);
         }
         const int plimit = u.p0 + rows;
-        const bool tri = base >= rows_bin0 && !(u.sr && jlo == 0);
+        const bool head = !(u.sr && jlo == 0);
+        const bool tri = base >= rows_bin0 && head;
         if (jhi > jlo)
         for (int j = jlo + 1; j <= jhi; ++j)
             for (int lane = 0; lane < 64; ++lane) {
@@ -164,7 +165,8 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
                 const uint32_t q = (j <= nchunks * 32) ? read_code(packed, nchunks, rr[lane], j) : 0u;
                 uint32_t nm[(MT + 31) / 32];
                 for (int w2 = 0; w2 < (MT + 31) / 32; ++w2) nm[w2] = p.nmask[q][w2];
-                const int pl = tri ? std::min(plimit, u.p0 + triangle_rows(rows, max_len, j, u.k)) : plimit;
+                int pl = head ? std::min(plimit, u.p0 + (j - jlo) + u.k) : plimit;
+                if (tri) pl = std::min(pl, u.p0 + triangle_rows(rows, max_len, j, u.k));
                 lane_step<MT, NOINDEL, true, true>(L[lane], u, j, nm, s_thr, pl);
             }
         for (int lane = 0; lane < 64; ++lane)
