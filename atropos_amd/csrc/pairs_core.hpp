@@ -163,7 +163,7 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
 // (tab[(code * NW + w) * ts], NW = ceil(MT / 32) words; bit i-1 <=> row i matches): a column
 // then costs NW ds_reads and six VALU ops per cell, with no LDS traffic per cell.  Row m sits at
 // a per-lane position, so its cell is picked up by a select in the rows from the wave's
-// smallest m on (mlo, wave-uniform); rows beyond a lane's m compute don't-care cells.
+// smallest / largest m on (mlo / mhi, wave-uniform); rows beyond a lane's m compute don't-care cells.
 constexpr int PAIRS_REG_MAX = 152;
 
 template <int MT, bool AND_MODE>
@@ -186,7 +186,7 @@ ATR_DEV void build_match_masks(uint32_t *tab, int ts, const uint32_t *rp, int m,
 // One column; returns the new cell of row m (position m, per lane).
 template <int MT>
 ATR_DEV uint32_t column_step_pairs(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) / 32], uint32_t row0,
-                                   uint32_t insw, uint32_t delw, int mlo, int m) {
+                                   uint32_t insw, uint32_t delw, int mlo, int mhi, int m) {
     uint32_t cd = diag_candidate<false>(col[0], nm, 0);
     col[0] = row0;
     uint32_t wm = row0;
@@ -198,14 +198,22 @@ ATR_DEV uint32_t column_step_pairs(uint32_t (&col)[MT + 1], const uint32_t (&nm)
         const uint32_t cu = col[i - 1] + insw;               // insertion: (i-1, j) -> (i, j)
         const uint32_t nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
         col[i] = nw;
-        wm = (i == m) ? nw : wm;                             // per-lane select (straight-line code; mlo unused)
         cd = cd_next;
+        // the row-m cell is a per-lane pick; only the blocks of eight rows that hold some lane's m
+        // (mlo .. mhi, wave-uniform) run the select chain -- one scalar test per block
+        if ((i & 7) == 0 || i == MT) {
+            const int b0 = ((i - 1) & ~7) + 1;                           // first row of this block
+            if (b0 <= mhi && i >= mlo) {
+#pragma unroll
+                for (int r = b0; r <= i; ++r) wm = (r == m) ? col[r] : wm;
+            }
+        }
     }
     return wm;
 }
 
 template <int MT, bool AND_MODE>
-ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, const uint32_t *qp, int n, const PairParams &p,
+ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, int mhi, const uint32_t *qp, int n, const PairParams &p,
                              const int16_t *thr, uint32_t rec[4]) {
     constexpr int NW = (MT + 31) / 32;
     const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
@@ -245,7 +253,7 @@ ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, const 
 #ifndef ATR_HOST_EMU
         asm volatile("" : "+v"(mrow));                       // keep the 152 (i == m) lane masks out of the loop preheader
 #endif
-        const uint32_t wm = column_step_pairs<MT>(col, nm, row0, insw, delw, mlo, mrow);
+        const uint32_t wm = column_step_pairs<MT>(col, nm, row0, insw, delw, mlo, mhi, mrow);
         if (eq && wm < klimit) consider<false>(best, wm, m, j, p.min_overlap, thr, indel);   // :433-455
     }
     if (max_n == n) {                                                   // :461-474

@@ -65,8 +65,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mlo = min(mlo, __shfl_xor(mlo, o, 64));
     mlo = __builtin_amdgcn_readfirstlane(mlo);
+    int mhi = m;                                        // (0 for the lanes past the end)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mhi = max(mhi, __shfl_xor(mhi, o, 64));
+    mhi = __builtin_amdgcn_readfirstlane(mhi);
     uint32_t rec[4];
-    locate_pair_reg<MT, AND_MODE>(tab, 64, m, mlo, qp, n, p, s_thr, rec);
+    locate_pair_reg<MT, AND_MODE>(tab, 64, m, mlo, mhi, qp, n, p, s_thr, rec);
     if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 

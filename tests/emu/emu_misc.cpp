@@ -94,16 +94,18 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
         const uint32_t *qp = qry_packed + ((size_t)tile * qch * 64 + lane) * 4;
         if (ref_max_len <= atr::PAIRS_REG_MAX) {                     // as the library: register-column variant
             // the wave's smallest m (select range of the row-m pick-up)
-            int mlo = 0x7fffffff;
-            for (int64_t t = tile * 64; t < std::min<int64_t>(npairs, tile * 64 + 64); ++t)
+            int mlo = 0x7fffffff, mhi = 0;
+            for (int64_t t = tile * 64; t < std::min<int64_t>(npairs, tile * 64 + 64); ++t) {
                 mlo = std::min(mlo, std::min(ref_lens ? ref_lens[t] : ref_max_len, ref_max_len));
+                mhi = std::max(mhi, std::min(ref_lens ? ref_lens[t] : ref_max_len, ref_max_len));
+            }
             uint32_t tab[16 * 5];
 #define ATR_EMU_REG(MT)                                                                                            \
             do {                                                                                                       \
                 if (p.and_mode) { atr::build_match_masks<MT, true>(tab, 1, rp, m, revcomp != 0);                       \
-                                  atr::locate_pair_reg<MT, true>(tab, 1, m, mlo, qp, n, p, p.thr, out + 4 * r); }      \
+                                  atr::locate_pair_reg<MT, true>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); }      \
                 else { atr::build_match_masks<MT, false>(tab, 1, rp, m, revcomp != 0);                                 \
-                       atr::locate_pair_reg<MT, false>(tab, 1, m, mlo, qp, n, p, p.thr, out + 4 * r); }                \
+                       atr::locate_pair_reg<MT, false>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); }                \
             } while (0)
             if (ref_max_len <= 64) ATR_EMU_REG(64);
             else if (ref_max_len <= 104) ATR_EMU_REG(104);
