@@ -184,16 +184,18 @@ ATR_DEV void build_match_masks(uint32_t *tab, int ts, const uint32_t *rp, int m,
 }
 
 // One column; returns the new cell of row m (position m, per lane).
-template <int MT>
+// XREP (== STOP_WITHIN_SEQ2 set): the payload counts mismatches, as in locate_core.hpp -- one op
+// less per cell.
+template <int MT, bool XREP>
 ATR_DEV uint32_t column_step_pairs(uint32_t (&col)[MT + 1], const uint32_t (&nm)[(MT + 31) / 32], uint32_t row0,
                                    uint32_t insw, uint32_t delw, int mlo, int mhi, int m) {
-    uint32_t cd = diag_candidate<false>(col[0], nm, 0);
+    uint32_t cd = diag_candidate<XREP>(col[0], nm, 0);
     col[0] = row0;
     uint32_t wm = row0;
 #pragma unroll
     for (int i = 1; i <= MT; ++i) {
         uint32_t cd_next = 0;
-        if (i < MT) cd_next = diag_candidate<false>(col[i], nm, i);
+        if (i < MT) cd_next = diag_candidate<XREP>(col[i], nm, i);
         const uint32_t cl = col[i] + delw;                   // deletion:  (i, j-1) -> (i, j)
         const uint32_t cu = col[i - 1] + insw;               // insertion: (i-1, j) -> (i, j)
         const uint32_t nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
@@ -212,7 +214,7 @@ ATR_DEV uint32_t column_step_pairs(uint32_t (&col)[MT + 1], const uint32_t (&nm)
     return wm;
 }
 
-template <int MT, bool AND_MODE>
+template <int MT, bool AND_MODE, bool XREP>
 ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, int mhi, const uint32_t *qp, int n, const PairParams &p,
                              const int16_t *thr, uint32_t rec[4]) {
     constexpr int NW = (MT + 31) / 32;
@@ -253,14 +255,14 @@ ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, int mh
 #ifndef ATR_HOST_EMU
         asm volatile("" : "+v"(mrow));                       // keep the 152 (i == m) lane masks out of the loop preheader
 #endif
-        const uint32_t wm = column_step_pairs<MT>(col, nm, row0, insw, delw, mlo, mhi, mrow);
-        if (eq && wm < klimit) consider<false>(best, wm, m, j, p.min_overlap, thr, indel);   // :433-455
+        const uint32_t wm = column_step_pairs<MT, XREP>(col, nm, row0, insw, delw, mlo, mhi, mrow);
+        if (eq && wm < klimit) consider<XREP>(best, wm, m, j, p.min_overlap, thr, indel);   // :433-455
     }
     if (max_n == n) {                                                   // :461-474
         const int first = er ? 0 : m;
 #pragma unroll
         for (int i = 0; i <= MT; ++i)
-            if (i >= first && i <= m) consider<false>(best, col[i], i, n, p.min_overlap, thr, indel);
+            if (i >= first && i <= m) consider<XREP>(best, col[i], i, n, p.min_overlap, thr, indel);
     }
     const int cost = (int)(best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;

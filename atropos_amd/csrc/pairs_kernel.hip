@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(const PairParams p, const uin
 }
 
 // Register-column variant (pairs_core.hpp): references of up to PAIRS_REG_MAX rows.
-template <int MT, bool AND_MODE>
+template <int MT, bool AND_MODE, bool XREP>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pairs_reg_kernel(const PairParams p, const uint32_t *__restrict__ ref_packed,
                                                         const int32_t *__restrict__ ref_lens, int ref_chunks,
                                                         int ref_max_len, int revcomp,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     for (int o = 32; o > 0; o >>= 1) mhi = max(mhi, __shfl_xor(mhi, o, 64));
     mhi = __builtin_amdgcn_readfirstlane(mhi);
     uint32_t rec[4];
-    locate_pair_reg<MT, AND_MODE>(tab, 64, m, mlo, mhi, qp, n, p, s_thr, rec);
+    locate_pair_reg<MT, AND_MODE, XREP>(tab, 64, m, mlo, mhi, qp, n, p, s_thr, rec);
     if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 
@@ -81,18 +81,18 @@ static hipError_t launch_pairs_reg(const PairParams &p, const uint32_t *rp, cons
     constexpr int NW = (MT + 31) / 32;
     const size_t lds = (size_t)4 * 16 * NW * 64 * 4;
     const dim3 grid((unsigned)((npairs + 255) / 256)), block(256);
-    hipError_t e;
-    if (p.and_mode) {
-        e = hipFuncSetAttribute((const void *)pairs_reg_kernel<MT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((pairs_reg_kernel<MT, true>), grid, block, lds, st, p, rp, rl, (rmax + 31) / 32, rmax, revcomp, qp,
-                           ql, (qmax + 31) / 32, qmax, npairs, out);
-    } else {
-        e = hipFuncSetAttribute((const void *)pairs_reg_kernel<MT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((pairs_reg_kernel<MT, false>), grid, block, lds, st, p, rp, rl, (rmax + 31) / 32, rmax, revcomp, qp,
-                           ql, (qmax + 31) / 32, qmax, npairs, out);
-    }
+    hipError_t e = hipSuccess;
+    const bool xrep = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;           // mismatch-counting payload (pairs_core.hpp)
+#define ATR_LAUNCH_PAIRS(AND, XR)                                                                                      \
+    do {                                                                                                               \
+        e = hipFuncSetAttribute((const void *)pairs_reg_kernel<MT, AND, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e != hipSuccess) return e;                                                                                 \
+        hipLaunchKernelGGL((pairs_reg_kernel<MT, AND, XR>), grid, block, lds, st, p, rp, rl, (rmax + 31) / 32, rmax,   \
+                           revcomp, qp, ql, (qmax + 31) / 32, qmax, npairs, out);                                      \
+    } while (0)
+    if (p.and_mode) { if (xrep) ATR_LAUNCH_PAIRS(true, true); else ATR_LAUNCH_PAIRS(true, false); }
+    else { if (xrep) ATR_LAUNCH_PAIRS(false, true); else ATR_LAUNCH_PAIRS(false, false); }
+#undef ATR_LAUNCH_PAIRS
     return hipGetLastError();
 }
 

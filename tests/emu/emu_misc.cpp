@@ -102,10 +102,13 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
             uint32_t tab[16 * 5];
 #define ATR_EMU_REG(MT)                                                                                            \
             do {                                                                                                       \
+                const bool xrep = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;                                               \
                 if (p.and_mode) { atr::build_match_masks<MT, true>(tab, 1, rp, m, revcomp != 0);                       \
-                                  atr::locate_pair_reg<MT, true>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); }      \
+                                  if (xrep) atr::locate_pair_reg<MT, true, true>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); \
+                                  else atr::locate_pair_reg<MT, true, false>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); } \
                 else { atr::build_match_masks<MT, false>(tab, 1, rp, m, revcomp != 0);                                 \
-                       atr::locate_pair_reg<MT, false>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); }                \
+                       if (xrep) atr::locate_pair_reg<MT, false, true>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); \
+                       else atr::locate_pair_reg<MT, false, false>(tab, 1, m, mlo, mhi, qp, n, p, p.thr, out + 4 * r); } \
             } while (0)
             if (ref_max_len <= 64) ATR_EMU_REG(64);
             else if (ref_max_len <= 104) ATR_EMU_REG(104);
