@@ -528,8 +528,9 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint8_t *__restrict__ b
 // bounds both stages.  Tiles that do not fit (very long names / reads) or whose records
 // are not in file order take emit_kernel's path.
 constexpr int EMIT_STAGE = 13 * 1024;                        // per stage; 2 stages per wave -> 6 waves per CU
-// records per wave: 32 (two lanes share a record) for short-read files, 16 for records of
-// more than ~400 bytes so that a tile still fits the stages
+// records per wave: 16; full-size stages for records of more than ~400 bytes, half-size stages (twice
+// the waves per CU: the kernel is latency bound) for short-read files; 32 records per wave with full
+// stages when the caller gives no hint
 
 // LDS -> LDS copy of len bytes at arbitrary alignments: byte steps until dst is dword
 // aligned, then one aligned ds_read_b32 + v_alignbyte_b32 + ds_write_b32 per 4 bytes (four
@@ -560,7 +561,7 @@ __device__ __forceinline__ void lds_copy(uint8_t *dst, const uint8_t *src, uint3
     for (k += nd * 4u; k < len; ++k) dst[k] = src[k];
 }
 
-template <int EMIT_TILE>
+template <int EMIT_TILE, int STAGE = EMIT_STAGE>
 __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restrict__ bytes,
                                                          const FastqRecord *__restrict__ records,
                                                          const int32_t *__restrict__ begin, const int32_t *__restrict__ end,
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
                                                          const uint8_t *__restrict__ dest, int which, long long n,
                                                          const long long *__restrict__ offsets, uint8_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) uint8_t s_emit[];
-    uint8_t *s_in = s_emit, *s_out = s_emit + EMIT_STAGE;
+    uint8_t *s_in = s_emit, *s_out = s_emit + STAGE;
     constexpr int LPR = 64 / EMIT_TILE;                       // lanes per record (the first two do the work)
     const int lane = threadIdx.x, slot = lane / LPR, part = lane % LPR;
     const long long r0 = (long long)blockIdx.x * EMIT_TILE;
@@ -594,8 +595,8 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
     const bool ordered = __all(!live || (rec_lo >= in_lo && rec_hi <= in_hi && rec.seq_off >= rec_lo &&
                                          rec.seq_off + rec.seq_len <= rec.qual_off && rec.name_off + rec.name_len <= rec.seq_off));
     const uint32_t mis_in = in_lo & 15u, mis_out = (uint32_t)(out_lo & 15);
-    const bool fits = ordered && (in_hi - in_lo) + mis_in + 16u <= (uint32_t)EMIT_STAGE &&
-                      (uint32_t)(out_hi - out_lo) + mis_out + 16u <= (uint32_t)EMIT_STAGE;
+    const bool fits = ordered && (in_hi - in_lo) + mis_in + 16u <= (uint32_t)STAGE &&
+                      (uint32_t)(out_hi - out_lo) + mis_out + 16u <= (uint32_t)STAGE;
     if (out_hi == out_lo) return;
     if (!fits) {                                           // slow path: a byte per lane straight from / to global
         for (int i = 0; i < cnt; ++i) {
@@ -902,6 +903,10 @@ int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, co
     if (((uintptr_t)d_out & 15) == 0 && ((uintptr_t)d_bytes & 15) == 0) {
         if (record_bytes_hint > 400)
             hipLaunchKernelGGL(emit_staged_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(64), 2 * EMIT_STAGE, st, d_bytes,
+                               (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest,
+                               dest, (long long)n, (const long long *)d_offsets, d_out);
+        else if (record_bytes_hint > 0)                    // short records: half-size tiles and stages, 12 waves per CU (-15 %)
+            hipLaunchKernelGGL((emit_staged_kernel<16, EMIT_STAGE / 2>), dim3((unsigned)((n + 15) / 16)), dim3(64), EMIT_STAGE, st, d_bytes,
                                (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest,
                                dest, (long long)n, (const long long *)d_offsets, d_out);
         else
