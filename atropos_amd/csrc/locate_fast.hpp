@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
         FilterState F;
         filter_init(F, u, fp.rows);
         const int jhi = RAGGED ? wave_max_i32(n) : max_len;
+        const int jfull = RAGGED ? wave_min_i32(live ? n : 0x7fffffff) : max_len;     // columns every live lane has
         const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
         if (jhi > 0) {
             const int c1 = (jhi + 31) >> 5;
@@ -109,10 +110,16 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                 for (int d = 0; d < 4; ++d) {
                     uint2 (&e)[8] = (d & 1) ? eb : ea;       // this dword's masks; the other set takes the next dword's
                     fetch_masks(d == 0 ? cur.y : d == 1 ? cur.z : d == 2 ? cur.w : nxt.x, (d & 1) ? ea : eb);
+                    if (RAGGED && j + 8 <= jfull) {          // wave-uniform: every lane of the wave owns all eight columns
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) {
-                        ++j;
-                        if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j));
+                        for (int b = 0; b < 8; ++b) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + b + 1));
+                        j += 8;
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            ++j;
+                            if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j));
+                        }
                     }
                     if (j >= jhi) break;                     // wave-uniform
                 }
