@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""GPU-vs-oracle fuzz campaign (run on the GPU box): every batched kernel path against
+oracle/align_oracle.c on random cases -- the filtered pipeline (all adapter types, the 32-row NARROW
+pre-pass, equal-length batches with partial overlaps), the full sweep over all 16 flag sets, the pair
+aligner and the insert aligner.  usage: tools/gpu_fuzz.py [first_seed] [seeds]"""
+import sys, time
+sys.path.insert(0, '.')
+from atropos_amd import _lib
+_lib.set_backend(_lib.HipBackend(0))
+from atropos_amd.align import Aligner, PairAligner, InsertAligner
+from oracle import oracle
+from tests import _cases
+t0 = time.time()
+tot = 0
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4)):
+    tot += _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, seed, 500)
+    tot += _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, seed + 100, 300, (33, 40), (14, 10, 6, 14))
+    tot += _cases.check_uniform_partial_overlaps(Aligner, oracle, _lib.AtroposHipError, seed + 200, 150)
+    tot += _cases.check_batches_against_oracle(Aligner, oracle, _lib.AtroposHipError, seed + 300, 300)
+    tot += _cases.check_pairs_against_oracle(PairAligner, oracle, _lib.AtroposHipError, seed + 400, 150)
+    tot += _cases.check_insert_batches_against_oracle(InsertAligner, oracle, seed + 500, 60)
+    print(seed, tot, "%.0f s" % (time.time() - t0), flush=True)
+print("cases", tot)
