@@ -1,6 +1,6 @@
 // valu_rates.hip -- issue rate of the 32-bit integer VALU ops the kernels use, measured on one
 // MI355X: every wave runs 32 independent ops (8 chains x 4) per loop iteration.
-// Generated by the table at the top of tools/micro/gen_valu_rates.py.
+// One kernel per op (machine-written from a list of op templates; the asm bodies are 32 copies of one line).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
