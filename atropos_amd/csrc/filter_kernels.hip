@@ -33,7 +33,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
     {   // K4a: banded DP over the band reads
         const BandParams bp = band_params(a);
-        const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 2048));
+        const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 4096));
         if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
         else             hipLaunchKernelGGL((band_kernel<false>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
     }
