@@ -28,7 +28,7 @@ print("window length mean %.1f median %.1f max %d" % (ln.mean().item(), ln.media
 print("with last-column scan: %.3f" % scan[v].float().mean().item())
 found = res.found()
 print("found fraction %.4f; found among unresolved %.4f" % (found.float().mean().item(), found[v].float().mean().item()))
-order_total = int(work[2 * n + 2048 * 256 + 256].item())     # FastWork layout: win, order, counts, binbase, total
+order_total = int(work[2 * n + 8192 * 256 + 256].item())     # FastWork layout: win, order, counts, binbase, total
 print("total word", order_total)
 # per-wave union window (as the window kernel sees it): waves of 64 consecutive slots of `order`
 order = work[n:n + order_total].to(torch.int64)
