@@ -15,6 +15,33 @@ static BandParams band_params(const atr_aligner *a) {
     return bp;
 }
 
+// A non-blocking side stream with its fork / join events, created on first use (per host thread, on
+// the device that is current then) and kept for the life of the thread (re-created when the thread
+// moves to another device).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+    bool ready() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (stream && dev == device) return true;
+        release();
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { release(); return false; }
+        device = dev;
+        return true;
+    }
+    void release() {
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr; fork = join = nullptr; device = -1;
+    }
+    // no destructor: at thread / process exit the HIP runtime may already be gone; the handles die with it
+};
+
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st) {
     FastWork wk = fast_carve(work, nreads);
@@ -31,18 +58,29 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     hipLaunchKernelGGL(scan_bins_kernel, dim3(FILTER_BINS), dim3(1024), 0, st, wk);
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
     hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
+    // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
+    // joined after K4, so that its waves (latency bound: three dependent gathers per task) share
+    // the SIMDs with K4's instead of running before them.
+    static thread_local SideStream side;
+    if (!side.ready()) return (int)hipErrorInvalidValue;
+    hipError_t e = hipEventRecord(side.fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side.stream, side.fork, 0);
+    if (e != hipSuccess) return (int)e;
     {   // K4a: banded DP over the band reads
         const BandParams bp = band_params(a);
         const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 4096));
-        if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
-        else             hipLaunchKernelGGL((band_kernel<false>), bgrid, block, 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
+        if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
+        else             hipLaunchKernelGGL((band_kernel<false>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
     }
-    hipError_t e = hipGetLastError();
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(side.join, side.stream);
     if (e != hipSuccess) return (int)e;
     typedef window_launcher (*group_fn)(int);
     static const group_fn groups[4] = {window_group_0, window_group_1, window_group_2, window_group_3};
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
-    return groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, st);
+    const int rc = groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, st);
+    e = hipStreamWaitEvent(st, side.join, 0);
+    return rc != 0 ? rc : (int)e;
 }
 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
