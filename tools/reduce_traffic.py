@@ -2,7 +2,7 @@
 """Reduce the FETCH_SIZE / WRITE_SIZE sections of a tools/profile_r.sh summary into
 profiles/hbm_traffic.json (the `roofline.traffic` figure of bench.py).
 
-    python tools/reduce_traffic.py profiles/r17_locate_c2_rocprofv3_summary.txt
+    python tools/reduce_traffic.py profiles/r18_locate_c2_rocprofv3_summary.txt
 
 Counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section):
 FETCH_SIZE reports half of a wide coalesced stream, so the streaming kernels (the pre-pass
