@@ -15,11 +15,10 @@ static __device__ __forceinline__ int wave_max_i32_ins(int v) {
 }
 
 template <int NCH>
-__global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, const uint4 *__restrict__ packed1,
-                                                     const int32_t *__restrict__ lens1,
-                                                     const uint4 *__restrict__ packed2,
-                                                     const int32_t *__restrict__ lens2, long long npairs,
-                                                     int max_len, uint4 *__restrict__ out) {
+__device__ __forceinline__ void insert_body(const InsertParams &ip, const uint4 *__restrict__ packed1,
+                                            const int32_t *__restrict__ lens1, const uint4 *__restrict__ packed2,
+                                            const int32_t *__restrict__ lens2, long long npairs, int max_len,
+                                            uint4 *__restrict__ out) {
     constexpr int W = NCH;
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -56,12 +55,35 @@ __global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, cons
     }
 }
 
+// Two entry points around the same body: reads of up to five chunks (160 bases) fit five waves per SIMD
+// with a few spilled dwords (96 VGPRs, -3 % on C3); longer reads would spill their planes, so they keep
+// the register count the compiler picks (three or four waves).
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void insert_kernel_dense(
+    const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
+    const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
+    uint4 *__restrict__ out) {
+    insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, const uint4 *__restrict__ packed1,
+                                                     const int32_t *__restrict__ lens1,
+                                                     const uint4 *__restrict__ packed2,
+                                                     const int32_t *__restrict__ lens2, long long npairs,
+                                                     int max_len, uint4 *__restrict__ out) {
+    insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
+}
+
 template <int NCH>
 static int launch_nch(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                       const int32_t *l2, long long npairs, int max_len, uint4 *out, hipStream_t st) {
     const long long ntiles = (npairs + 63) / 64;
-    hipLaunchKernelGGL((insert_kernel<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
-                       p2, l2, npairs, max_len, out);
+    if (NCH == 4 || NCH == 5)
+        hipLaunchKernelGGL((insert_kernel_dense<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
+                           p2, l2, npairs, max_len, out);
+    else
+        hipLaunchKernelGGL((insert_kernel<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
+                           p2, l2, npairs, max_len, out);
     return (int)hipGetLastError();
 }
 
