@@ -56,8 +56,8 @@ __device__ __forceinline__ void insert_body(const InsertParams &ip, const uint4 
 }
 
 // Two entry points around the same body: reads of up to five chunks (160 bases) fit five waves per SIMD
-// with a few spilled dwords (96 VGPRs, -3 % on C3); longer reads would spill their planes, so they keep
-// the register count the compiler picks (three or four waves).
+// with a few spilled dwords (96 VGPRs; C3 1.25 -> 1.08 ms); longer reads would spill their planes there
+// (C5: 1.0 -> 2.4 ms) and are compiled for four waves (128 VGPRs, C5 -7 %).
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void insert_kernel_dense(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
 }
 template <int NCH>
-__global__ __launch_bounds__(256) void insert_kernel(const InsertParams ip, const uint4 *__restrict__ packed1,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void insert_kernel(const InsertParams ip, const uint4 *__restrict__ packed1,
                                                      const int32_t *__restrict__ lens1,
                                                      const uint4 *__restrict__ packed2,
                                                      const int32_t *__restrict__ lens2, long long npairs,
