@@ -130,7 +130,12 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]);
  * with.  d_work: optional device scratch of atr_locate_work_bytes(nreads) bytes; when
  * given (and the aligner qualifies: START/STOP_WITHIN_SEQ2 set, m <= 64) the filtered
  * pipeline runs -- a bit-parallel pre-pass resolves most reads and the full DP only
- * sweeps a short column window of the rest; results are identical either way. */
+ * sweeps a short column window of the rest; results are identical either way.
+ * All work is enqueued on `stream` (a hipStream_t; NULL = the default stream) and is complete
+ * when the stream reaches the end of the call: the filtered pipeline forks one internal
+ * per-thread side stream after its scatter pass and joins it again before it returns (events,
+ * no host synchronisation; the pattern is legal inside a stream capture).  d_work must stay
+ * valid until then and must not be shared by calls that may overlap. */
 size_t atr_locate_work_bytes(int64_t nreads);
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                      int64_t nreads, int max_len, atr_result *d_out, void *d_work, void *stream);
