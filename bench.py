@@ -39,6 +39,26 @@ def measured_traffic(reads, filtered):
     return t["hbm_bytes_per_read"] * reads
 
 
+VALU_PEAK_T = 39.3                 # T lane-ops/s at 4 issue cycles per wave64 op: 1024 SIMDs x 64 lanes x 2.4 GHz / 4
+                                   # (tools/micro, profiles/r13_valu_issue_rates.txt: the rate of mixed integer streams)
+
+
+def measured_valu(reads, filtered, kernel_ms):
+    """The issue-bound view: VALU wave-instructions of one call (SQ_INSTS_VALU pass of tools/profile_r.sh,
+    reduced into profiles/hbm_traffic.json) over the live kernel time of THIS run."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not filtered or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        t = json.load(fh)
+    if "valu_wave_insts_per_launch" not in t:
+        return None
+    insts = t["valu_wave_insts_per_launch"] * reads / t["reads_per_launch"]
+    ach = insts * 64 / (kernel_ms * 1e-3) / 1e12
+    return {"wave_insts_per_launch": insts, "achieved": ach, "peak": VALU_PEAK_T, "unit": "T lane-ops/s",
+            "frac": ach / VALU_PEAK_T}
+
+
 def usable_cores():
     """Host cores this process may actually use: the scheduler affinity capped by the
     cgroup CPU quota (the GPU boxes expose 256 logical CPUs but grant a 16-CPU quota)."""
@@ -156,6 +176,7 @@ def main():
                                     "atr_locate_batch call)" if filtered else "locate_kernel<36,eq,indel>"),
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
+                         "valu": measured_valu(args.reads, filtered, kernel_ms),
                          "note": "integer-VALU bound, not HBM bound: %.2f G full-matrix cell-equivalents/s"
                                  % (args.reads * 150 * 34 / (kernel_ms * 1e-3) / 1e9)},
         }

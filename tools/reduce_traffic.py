@@ -39,6 +39,23 @@ def main():
         m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE): launches=\d+ avg=([\d.]+)", line)
         if m and kernel:
             per.setdefault(kernel, {})[m.group(1)] = float(m.group(2))
+    # VALU wave-instructions per launch (SQ_INSTS_VALU pass), for the issue-bound view of the roofline
+    valu = {}
+    kernel = None
+    section = False
+    for line in open(src):
+        if line.startswith("== pmc"):
+            section = "pmc_SQ_WAVES" in line
+            continue
+        if line.startswith("=="):
+            section = False
+        if not section:
+            continue
+        if "atr::" in line and not line.startswith(" "):
+            kernel = short(line)
+        m = re.match(r"\s+SQ_INSTS_VALU: launches=\d+ avg=([\d.]+)", line)
+        if m and kernel:
+            valu[kernel] = float(m.group(1))
     total = 0.0
     for k, v in per.items():
         f = 2.0 if any(s in k for s in STREAMING) else 1.0
@@ -49,7 +66,8 @@ def main():
            "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % src,
            "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB for the coalesced streaming kernels (gfx950 FETCH_SIZE counts "
                      "half of a wide coalesced stream), raw FETCH_SIZE + WRITE_SIZE for the gathering band / window kernels",
-           "per_kernel": per}
+           "per_kernel": per,
+           "valu_wave_insts_per_launch": sum(valu.values()), "valu_wave_insts_per_kernel": valu}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "hbm_traffic.json"), "w") as fh:
         json.dump(out, fh, indent=1)
