@@ -40,6 +40,18 @@ class InsertConfig(C.Structure):
         ("max_mismatch_by_alen", C.c_void_p), ("n_mismatch", C.c_int),
     ]
 
+class LinkedAdapterSpec(C.Structure):
+    """atr_linked_adapter (include/atropos_hip.h)."""
+    _fields_ = [
+        ("front", C.c_void_p), ("back", C.c_void_p),
+        ("front_exact_shortcut", C.c_int), ("back_exact_shortcut", C.c_int),
+        ("d_front_rmp", C.c_void_p), ("d_back_rmp", C.c_void_p), ("front_rmp_ld", C.c_int), ("back_rmp_ld", C.c_int),
+        ("front_max_rmp", C.c_double), ("back_max_rmp", C.c_double),
+    ]
+
+
+LINKED_MAX_ADAPTERS = 4
+
 # prototypes of every symbol include/atropos_hip.h declares
 PROTOTYPES = {
     "atr_version": (C.c_int, []),
@@ -62,6 +74,9 @@ PROTOTYPES = {
     "atr_correct_errors_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_insert_correct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_insert_aligner_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "atr_insert_aligner_destroy": (None, [C.c_void_p]),
     "atr_insert_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -75,6 +90,12 @@ PROTOTYPES = {
     "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "atr_linked_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "atr_linked_destroy": (None, [C.c_void_p]),
+    "atr_linked_query_table": (C.c_int, [C.c_void_p]),
+    "atr_linked_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "atr_linked_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_pairs_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p]),
@@ -113,6 +134,10 @@ class AtroposHipError(RuntimeError):
     pass
 
 
+class AtroposUnsupported(AtroposHipError):
+    """ATR_ERR_UNSUPPORTED: the request is outside the device kernels' envelope."""
+
+
 def load_library(path=LIB_PATH):
     """dlopen the C-ABI library and attach prototypes.  Raises if it is missing."""
     if not os.path.exists(path):
@@ -135,6 +160,8 @@ def _check(lib, rc, what):
     if rc == -4:
         raise MemoryError(what)
     detail = ERRORS.get(rc, "error %d" % rc)
+    if rc == -2:
+        raise AtroposUnsupported("%s: %s" % (what, detail))
     if rc == -3:
         detail += ": " + (lib.atr_last_error() or b"").decode("ascii", "replace")
     raise AtroposHipError("%s: %s" % (what, detail))
@@ -247,6 +274,23 @@ class HipBackend(object):
                     _ptr(changed), _ptr(newlen), self._stream()), "atr_correct_errors_batch")
         return changed, newlen
 
+    def insert_correct_batch(self, records, seq1, qual1, lens1, seq2, qual2, lens2, action, min_qual_diff, comp,
+                             changed=None, newlen=None):
+        """Error correction of the pairs whose insert match (records of insert_match_batch) has
+        errors, in place on uint8 [n, width] ASCII tensors; returns (changed, newlen) int32 [n, 2]."""
+        n = seq1.shape[0]
+        changed = self.empty((n, 2), torch.int32) if changed is None else changed
+        newlen = self.empty((n, 2), torch.int32) if newlen is None else newlen
+        if n:
+            if seq1.stride(0) != seq2.stride(0):
+                raise ValueError("both reads need the same row stride")
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_insert_correct_batch(
+                    _ptr(records), _ptr(seq1), _ptr(qual1), _ptr(lens1), _ptr(seq2), _ptr(qual2), _ptr(lens2),
+                    seq1.stride(0), n, seq1.shape[1], action, min_qual_diff, comp, _ptr(changed), _ptr(newlen),
+                    self._stream()), "atr_insert_correct_batch")
+        return changed, newlen
+
     def insert_aligner_create(self, cfg):
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -303,6 +347,34 @@ class HipBackend(object):
                                                            _ptr(work), self._stream()), "atr_locate_batch")
         return out
 
+    # -- linked adapters (one fused pipeline for the whole set) ---------------------
+    def linked_create(self, specs):
+        """specs: list of LinkedAdapterSpec.  Returns the set handle; AtroposHipError
+        ("unsupported") when the set is outside the fused kernels' envelope."""
+        arr = (LinkedAdapterSpec * len(specs))(*specs)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_linked_create(C.addressof(arr), len(specs), C.byref(h)), "atr_linked_create")
+        return h
+
+    def linked_destroy(self, h):
+        self.lib.atr_linked_destroy(h)
+
+    def linked_match_batch(self, h, packed, lens, nreads, max_len):
+        """(which int8 [n, 2] = (first matching adapter | -1, number of matching 5' parts),
+        front int16 [n, 8], back int16 [n, 8]) -- include/atropos_hip.h, atr_linked_match_batch."""
+        which = self.empty((nreads, 2), torch.int8)
+        front = self.empty((nreads, 8), torch.int16)
+        back = self.empty((nreads, 8), torch.int16)
+        if nreads:
+            need = self.lib.atr_linked_work_bytes(h, nreads)
+            if self._work is None or self._work.numel() < need:
+                self._work = self.empty((need,), torch.uint8)
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_linked_match_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(which),
+                                                                 _ptr(front), _ptr(back), _ptr(self._work), self._stream()),
+                       "atr_linked_match_batch")
+        return which, front, back
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                            query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):

@@ -138,6 +138,12 @@ class AsciiSource(object):
             raise NotImplementedError("sliced reads with anchored no-indel adapters")
         return self.ascii_upper, self.lens
 
+    def sliced(self, starts):
+        """The source of the reads ``read[start:]``."""
+        if self.starts is not None:
+            starts = starts + self.starts
+        return AsciiSource(self.ascii_upper, self.lens, starts)
+
 
 class Adapter(object):
     """An adapter knows how to match itself to a read: where it may sit within the read
@@ -469,13 +475,8 @@ class LinkedAdapter(object):
         int16 [n, 8] on the device; the back records refer to the read with the front match
         removed (coordinates relative to ``read[front.rstop:]``) and are -1 where the front
         adapter did not match."""
-        front = self.front_adapter.match_records(ascii_upper, lens)
-        has_front = front[:, 1] >= 0
-        starts = torch.where(has_front, front[:, 3].to(torch.int32), torch.zeros_like(front[:, 3], dtype=torch.int32))
-        back = self.back_adapter.match_records(ascii_upper, lens, starts=starts)
-        none = torch.zeros(8, dtype=torch.int16, device=back.device)
-        none[1] = -1
-        return front, torch.where(has_front[:, None], back, none[None, :])
+        _which, _count, front, back = _linked_set([self]).match_source(AsciiSource(ascii_upper, lens))
+        return front, back
 
     def trimmed(self, match):
         front_trimmed = self.front_adapter.trimmed(match.front_match)
@@ -573,17 +574,91 @@ class AdapterParser(object):
         return adapters
 
 
+class LinkedSet(object):
+    """Device matcher for a list of LinkedAdapters whose anchored 5' parts are mutually exclusive
+    (AdapterCutter._best_match over LinkedAdapter.match_to, modifiers.py:107-122 /
+    adapters/__init__.py:671-690): ONE fused kernel pipeline per batch (atr_linked_match_batch)
+    -- each read is loaded once, every 5' part is tried, and the 3' part of the one that matched
+    is located in ``read[front.rstop:]`` without re-packing.  ``fused`` is False when the set is
+    outside that pipeline's envelope (include/atropos_hip.h, atr_linked_create); the parts are then
+    matched one after the other with the per-adapter kernels."""
+
+    def __init__(self, linked_adapters):
+        self.adapters = list(linked_adapters)
+        self._backend = be = _lib.get_backend()
+        self._handle = None
+        self._tables = []                     # device RMP tables stay alive with the set
+        first = self.adapters[0].front_adapter.aligner
+        self.table_kind, self.table = first.table_kind, first._table
+        parts = [p for la in self.adapters for p in (la.front_adapter, la.back_adapter)]
+        if len(self.adapters) > _lib.LINKED_MAX_ADAPTERS or any(not p.indels for p in parts):
+            return                            # anchored parts without indels are plain prefix compares
+        specs = []
+        for la in self.adapters:
+            spec = _lib.LinkedAdapterSpec()
+            for side, part in (("front", la.front_adapter), ("back", la.back_adapter)):
+                setattr(spec, side, part.aligner._handle)
+                setattr(spec, side + "_exact_shortcut", int(not part.adapter_wildcards))
+                if part.max_rmp is not None:
+                    table = torch.from_numpy(np.ascontiguousarray(part._rmp_by_size())).to(be.device)
+                    self._tables.append(table)
+                    setattr(spec, "d_%s_rmp" % side, table.data_ptr())
+                    setattr(spec, side + "_rmp_ld", table.shape[1])
+                    setattr(spec, side + "_max_rmp", float(part.max_rmp))
+            specs.append(spec)
+        try:
+            self._handle = be.linked_create(specs)
+        except _lib.AtroposUnsupported:
+            self._handle = None
+
+    @property
+    def fused(self):
+        return self._handle is not None
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                self._backend.linked_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def match_source(self, source, active=None):
+        """(which, count, front, back) for a read source (``AsciiSource`` / ``RecordSource``):
+        int32 index of the first linked adapter whose 5' part matches (-1: none), the number of
+        5' parts that match, and the two int16 [n, 8] record tensors; the 3' records refer to
+        ``read[front.rstop:]`` and are None-records where no 5' part matched."""
+        if self._handle is None:
+            return _linked_records_stepwise(self.adapters, source, active)
+        batch = source.batch(self.table_kind, self.table)
+        wc, front, back = self._backend.linked_match_batch(self._handle, batch.packed, batch.lens, batch.nreads,
+                                                           batch.max_len)
+        which, count = wc[:, 0].to(torch.int32), wc[:, 1].to(torch.int32)
+        if active is not None:                # reads that already left the adapter rounds
+            off = active == 0
+            which = which.masked_fill(off, -1)
+            count = count.masked_fill(off, 0)
+            front[off, 1] = -1
+            back[off, 1] = -1
+        return which, count, front, back
+
+
+def _linked_set(linked_adapters):
+    """The LinkedSet of a list of linked adapters, built once and kept on its first member."""
+    key = tuple(id(la) for la in linked_adapters)
+    cached = getattr(linked_adapters[0], "_linked_set", None)
+    if cached is None or cached[0] != key or cached[1]._backend is not _lib.get_backend():
+        cached = (key, LinkedSet(linked_adapters))
+        linked_adapters[0]._linked_set = cached
+    return cached[1]
+
+
 def linked_best_records(linked_adapters, ascii_upper, lens=None):
-    """Device pipeline for a set of linked adapters whose anchored 5' parts are mutually
-    exclusive (BASELINE config C4) on a uint8 [n, width] matrix of reads: see
-    ``linked_records_from_source``.  Returns (which, front, back): the index of the matching
-    linked adapter per read (-1: none, -2: more than one -- the reference's AdapterCutter
+    """Linked adapters whose anchored 5' parts are mutually exclusive (BASELINE config C4) on a
+    uint8 [n, width] matrix of upper-case reads.  Returns (which, front, back): the index of the
+    matching linked adapter per read (-1: none, -2: more than one -- the reference's AdapterCutter
     raises AttributeError in that case, modifiers.py:120) and the two int16 [n, 8] record tensors."""
-    from .fastq import FastqBatch
-    batch = FastqBatch.from_matrix(ascii_upper, lens)
-    begin = torch.zeros((len(batch),), dtype=torch.int32, device=batch.records.device)
-    end = batch.seq_lens.clone()
-    which, count, front, back = linked_records_from_source(linked_adapters, batch, begin, end)
+    which, count, front, back = _linked_set(linked_adapters).match_source(AsciiSource(ascii_upper, lens))
     which = torch.where(count > 1, torch.full_like(which, -2), which)
     return which, front, back
 
@@ -615,25 +690,27 @@ def best_adapter_records(adapters, ascii_upper, lens=None):
 
 
 def linked_records_from_source(linked_adapters, batch, begin, end, active=None):
-    """Device twin of ``LinkedAdapter.match_to`` for a set of linked adapters whose anchored 5'
-    parts are mutually exclusive, on the kept intervals of a FastqBatch (``atropos_amd.fastq``):
-    every 5' adapter is matched against all reads (one packed batch per translate table), the
-    reads are then compacted by the 5' adapter that matched (32-byte descriptors are gathered,
-    never the bases) and only that adapter's 3' part is aligned against ``read[front.rstop:]``.
-    Returns (which, front, back): the index of the first matching linked adapter per read (-1:
-    none), the number of 5' adapters that matched, and the int16 [n, 8] record tensors (3'
-    records relative to the read with the 5' match removed)."""
-    from .fastq import FastqBatch, RecordSource
-    n = len(batch)
-    dev = begin.device
-    none = torch.zeros((n, 8), dtype=torch.int16, device=dev)
-    none[:, 1] = -1
-    front, back = none.clone(), none.clone()
-    which = torch.full((n,), -1, dtype=torch.int32, device=dev)
-    count = torch.zeros((n,), dtype=torch.int32, device=dev)
-    fsrc = RecordSource(batch, begin.clone(), end.clone())
+    """``LinkedSet.match_source`` on the kept intervals of a FastqBatch (``atropos_amd.fastq``)."""
+    from .fastq import RecordSource
+    return _linked_set(linked_adapters).match_source(RecordSource(batch, begin, end), active)
+
+
+def _linked_records_stepwise(linked_adapters, source, active=None):
+    """Sets outside the fused pipeline's envelope: every 5' adapter against all reads, then -- per
+    adapter -- its 3' part against the slices ``read[front.rstop:]`` of the reads it claimed
+    (``source.sliced``).  Same return value as ``LinkedSet.match_source``."""
+    n = source.n
+    front = back = None
+    which = count = None
     for k, la in enumerate(linked_adapters):
-        f = la.front_adapter.match_source(fsrc)
+        f = la.front_adapter.match_source(source)
+        if front is None:
+            dev = f.device
+            none = torch.zeros((n, 8), dtype=torch.int16, device=dev)
+            none[:, 1] = -1
+            front, back = none.clone(), none.clone()
+            which = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            count = torch.zeros((n,), dtype=torch.int32, device=dev)
         has = f[:, 1] >= 0
         if active is not None:
             has &= active != 0
@@ -641,23 +718,11 @@ def linked_records_from_source(linked_adapters, batch, begin, end, active=None):
         first = has & (which < 0)                                      # the first matching adapter claims the read
         front = torch.where(first[:, None], f, front)
         which = torch.where(first, torch.full_like(which, k), which)
-    # compact once: the reads ordered by the adapter that claimed them, then one contiguous
-    # slice per adapter (three gathers and one scatter in total, of descriptors, not of bases)
-    idxs = [torch.nonzero(which == k).squeeze(1) for k in range(len(linked_adapters))]
-    sizes = [int(i.numel()) for i in idxs]
-    if sum(sizes):
-        order = torch.cat(idxs)
-        recs = batch.records.index_select(0, order).contiguous()
-        sb = (begin + torch.where(which >= 0, front[:, 3].to(torch.int32), torch.zeros_like(begin))).index_select(0, order)
-        se = torch.maximum(end.index_select(0, order), sb)                 # read[front.rstop:]
-        parts, lo = [], 0
-        for k, la in enumerate(linked_adapters):
-            if sizes[k] == 0:
-                continue
-            hi = lo + sizes[k]
-            sub = FastqBatch(batch.data, batch.nbytes, recs[lo:hi], batch.backend)
-            parts.append(la.back_adapter.match_source(RecordSource(sub, sb[lo:hi].contiguous(), se[lo:hi].contiguous())))
-            lo = hi
-        back[order] = torch.cat(parts)
+    starts = torch.where(which >= 0, front[:, 3].to(torch.int32), torch.zeros_like(which))
+    rest = source.sliced(starts)
+    for k, la in enumerate(linked_adapters):
+        mine = which == k
+        if bool(mine.any()):
+            b = la.back_adapter.match_source(rest)
+            back = torch.where(mine[:, None], b, back)
     return which, count, front, back
-

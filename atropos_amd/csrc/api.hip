@@ -19,7 +19,8 @@ int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l
                   const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st);
 
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
-                   long long stride, const int16_t *im, const uint8_t *mask, long long n, int max_len, int action,
+                   long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
+                   int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st);
 int launch_postfilter(int16_t *rec, long long n, int m, int min_overlap, double max_error_rate, const double *rmp,
@@ -317,9 +318,24 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
     if (action != ATR_CORRECT_N && !d_qual1) return ATR_ERR_INVALID;      /* modifiers.py:245-248 */
     if (n == 0) return ATR_OK;
     if (!d_seq1 || !d_seq2 || !d_insert || !d_changed || !d_newlen) return ATR_ERR_INVALID;
-    const int rc = launch_correct(d_seq1, d_qual1, d_lens1, d_seq2, d_qual2, d_lens2, stride, d_insert, d_mask, n,
+    const int rc = launch_correct(d_seq1, d_qual1, d_lens1, d_seq2, d_qual2, d_lens2, stride, d_insert, 4, 0, d_mask, n,
                                   max_len, action, min_qual_difference, truncate_seqs, comp, d_changed, d_newlen,
                                   (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "correct_kernel launch");
+}
+
+int atr_insert_correct_batch(const atr_result *d_insert_records, uint8_t *d_seq1, uint8_t *d_qual1,
+                             const int32_t *d_lens1, uint8_t *d_seq2, uint8_t *d_qual2, const int32_t *d_lens2,
+                             int64_t stride, int64_t n, int max_len, int action, int min_qual_difference,
+                             const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream) {
+    if (n < 0 || max_len < 0 || action < 0 || action > 2 || !comp) return ATR_ERR_INVALID;
+    if ((d_qual1 == nullptr) != (d_qual2 == nullptr)) return ATR_ERR_INVALID;
+    if (action != ATR_CORRECT_N && !d_qual1) return ATR_ERR_INVALID;      /* modifiers.py:245-248 */
+    if (n == 0) return ATR_OK;
+    if (!d_insert_records || !d_seq1 || !d_seq2 || !d_changed || !d_newlen) return ATR_ERR_INVALID;
+    const int rc = launch_correct(d_seq1, d_qual1, d_lens1, d_seq2, d_qual2, d_lens2, stride,
+                                  (const int16_t *)d_insert_records, 24, 1, nullptr, n, max_len, action,
+                                  min_qual_difference, 1, comp, d_changed, d_newlen, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "correct_kernel launch");
 }
 

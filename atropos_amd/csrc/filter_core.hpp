@@ -138,14 +138,18 @@ struct FilterState {
 // the shift is an add-with-carry-out and the score update an add/sub-with-carry-in.  The pad
 // rows below row 1 match every base (peq pad bits = 1) and start with zero deltas; they stay
 // at cost 0 in every column and play the part of the free row 0 (START_WITHIN_SEQ2).
-ATR_DEV int filter_row_offset(int m) { return (m > 32 ? 64 : 32) - m; }
+// wide: the bit-vector has two words.  The single-aligner pipeline uses two words exactly when
+// mf > 32; the linked-adapter pipeline (linked_core.hpp) sweeps adapters of different lengths
+// side by side and gives all of them the same word count.
+ATR_DEV int filter_row_offset(int m, bool wide) { return (wide ? 64 : 32) - m; }
+ATR_DEV int filter_row_offset(int m) { return filter_row_offset(m, m > 32); }
 
 // mf = FilterParams::rows in all of the following.
-ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf) {
+ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf, bool wide) {
     // column 0: cost i per row (not START_WITHIN_SEQ1) or 0 everywhere (_align.pyx:333-352)
-    const int off = filter_row_offset(mf);
+    const int off = filter_row_offset(mf, wide);
     const uint32_t low = off >= 32 ? 0u : ~0u << (off & 31);           // rows living in the low word
-    if (mf > 32) { F.pvl = u.sr ? 0u : low; F.pvh = u.sr ? 0u : ~0u; }
+    if (wide) { F.pvl = u.sr ? 0u : low; F.pvh = u.sr ? 0u : (off > 32 ? ~0u << (off & 31) : ~0u); }
     else { F.pvl = u.sr ? 0u : low; F.pvh = 0u; }
     F.mvl = F.mvh = 0u;
     F.score = (u.sr ? 0 : mf) - (u.k + 1);
@@ -153,6 +157,7 @@ ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf) {
     F.best = ~0u;
     F.j_first = F.j_last = 0;
 }
+ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf) { filter_init(F, u, mf, mf > 32); }
 
 // Column tag of the exact-hit tracker: the column number, the bias of the stored score, plus a
 // penalty that keeps columns j < m (where a zero cost is only possible with START_WITHIN_SEQ1
@@ -209,7 +214,10 @@ ATR_DEV void filter_push_hit(uint32_t &hits, int score) {
 // read), written on explicit 32-bit halves: gfx950 has no full-rate 64-bit shift or add.
 // WIDE = adapter longer than 32 bases (both words live); otherwise only the low word.
 // tag = filter_column_tag(u, j).  ~27 VALU ops (WIDE) / ~16 per column, mask fetch included.
-template <bool WIDE>
+// SIGNED_KEY (linked-adapter pipeline: k differs from lane to lane, so the bias (k + 1) << 10 cannot
+// ride in the wave-uniform tag): the tracker keeps min over the columns of (score << 10) + tag as a
+// SIGNED number and the bias is added once after the sweep (filter_unbias_best).
+template <bool WIDE, bool SIGNED_KEY = false>
 ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
     const uint32_t xvl = eql | F.mvl;
     const uint32_t tl = eql & F.pvl;
@@ -242,7 +250,15 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
     uint32_t key;
     asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(key) : "v"(F.score), "s"(tag));
 #endif
-    F.best = atr_minu(F.best, key);
+    if (SIGNED_KEY) F.best = (uint32_t)atr_min((int)F.best, (int)key);
+    else F.best = atr_minu(F.best, key);
+}
+
+// SIGNED_KEY sweeps: start value of the tracker, and its conversion to the biased unsigned form
+// (D[m][j] << 10 | j, all ones when no column was swept) the decision below expects.
+constexpr uint32_t FILTER_BEST_NONE_SIGNED = 0x7fffffffu;
+ATR_DEV uint32_t filter_unbias_best(uint32_t best, int k) {
+    return best == FILTER_BEST_NONE_SIGNED ? ~0u : best + ((uint32_t)(k + 1) << 10);
 }
 
 // Fold the hit bits of the (at most 32) columns swept since the last fold into j_first /
@@ -260,15 +276,17 @@ ATR_DEV void filter_fold(FilterState &F, int j) {
 // at most the row and the threshold is monotone in the length, so D[i][n] <= thr[i] is a
 // necessary condition.  Returns the largest such row (0: none) and its cost; exact = false
 // when that row lies beyond the swept rows and was only kept by its lower bound (NARROW mode).
-template <bool WIDE>
-ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const FilterParams &fp, int &cost_of_largest,
+// P: FilterParams (wave-uniform kernel argument) or LaneFilterParams (linked_core.hpp: per lane,
+// thresholds behind a pointer into LDS).
+template <bool WIDE, class P>
+ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &fp, int &cost_of_largest,
                                bool &exact) {
     const int mf = fp.rows;
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
     exact = true;
-    const int off = filter_row_offset(mf);
+    const int off = filter_row_offset(mf, WIDE);
     // per row: two bit-field extracts, an add3, a compare against an SGPR and a select
-    const int low_rows = WIDE ? atr_min(mf, 32 - off) : mf;             // rows that live in the low word
+    const int low_rows = WIDE ? atr_max(0, atr_min(mf, 32 - off)) : mf;             // rows that live in the low word
 #ifndef ATR_HOST_EMU
 #pragma unroll 4
 #endif
@@ -297,7 +315,8 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const Fil
 // NARROW mode: do the T = m - mf bases after column jp equal the adapter's tail rows?
 // q: this read's dwords (read_dword below).
 ATR_DEV uint32_t read_dword(const uint32_t *q, int nchunks, int z8);
-ATR_DEV bool filter_tail_matches(const FilterParams &fp, int T, const uint32_t *q, int nchunks, int jp) {
+template <class P>
+ATR_DEV bool filter_tail_matches(const P &fp, int T, const uint32_t *q, int nchunks, int jp) {
     const uint32_t lo = read_dword(q, nchunks, jp >> 3), hi = read_dword(q, nchunks, (jp >> 3) + 1);
     const uint32_t sh = 4u * (uint32_t)(jp & 7);
     const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;                 // bases jp + 1 .. jp + 8
@@ -309,9 +328,13 @@ ATR_DEV bool filter_tail_matches(const FilterParams &fp, int T, const uint32_t *
 
 // Decision for one read of length n after the sweep.  Returns the window word (0 when the
 // read is resolved here, in which case rec[] holds its result record).
-template <bool WIDE>
-ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const FilterParams &fp, const uint32_t *q,
-                               int nchunks, int n, uint32_t rec[4]) {
+// s (linked adapters): the alignment is that of read[s:] -- the sweep saw the bases before s as
+// "match nothing" columns, which leave the initial column of an aligner without
+// START_WITHIN_SEQ1 unchanged (cost i in row i) -- so column s plays the part of column 0; all
+// coordinates stay those of the whole read (the caller re-bases the record).
+template <bool WIDE, class P>
+ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &fp, const uint32_t *q,
+                               int nchunks, int n, uint32_t rec[4], int s = 0) {
     const int mf = fp.rows, T = u.m - mf;                                // T > 0: NARROW mode
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
     if ((F.best >> 10) == 0u && u.m >= u.min_overlap) {
@@ -348,13 +371,13 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const Fil
     int j_lo = 0x7fffffff;
     if (rowm) j_lo = F.j_first - mf - u.k;
     if (lastcol) j_lo = atr_min(j_lo, n - row_l - ((u.indel == 1 && exact_l) ? cost_l : u.k));
-    j_lo = atr_max(0, j_lo);
+    j_lo = atr_max(s, j_lo);
     // Band: with row-m candidates only, a candidate ending in column j (j_first <= j <= j_last,
     // cost <= k) keeps to the diagonals j - m - k .. j - m + k (at most k of its steps are
     // indels), so every traceback lies on the diagonals j_lo .. j_last - m + k -- provided j_lo
     // was not clamped at 0 (no traceback then touches column 0).  The window end of a band
     // read is stored as (last diagonal) + m - k: j_last, or j'_last + T in NARROW mode.
-    const bool band = rowm && !lastcol && (F.j_first - mf - u.k >= 0) &&
+    const bool band = rowm && !lastcol && (F.j_first - mf - u.k >= s) &&
                       (F.j_last - F.j_first + 2 * u.k <= BAND_W - 1);
     const int j_hi = lastcol ? n : band ? F.j_last + T : atr_min(n, F.j_last + (T ? T + u.k : 0));
     // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
@@ -412,14 +435,16 @@ ATR_DEV uint32_t nibble_any(uint32_t v) {
 // Diagonals smax + 1 .. ND - 1 are swept too; nothing on them is looked at afterwards.
 // PREFIX (anchored 5' adapters, band_locate_prefix): diagonal c is j - i = c - k, and while i <= k the
 // cells left of column 0 do not exist and column 0 holds the reference's initial value.
-template <bool AND_MODE, int ND, bool PREFIX = false>
-ATR_DEV void band_rows(const Uniform &u, const uint32_t *rreps, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W]) {
+// rrep_of(i): the reference code of row i in all eight nibbles -- a wave-uniform table entry
+// (BandParams::rrep) or, in the linked-adapter pipeline, an LDS entry of the lane's own adapter.
+template <bool AND_MODE, int ND, bool PREFIX = false, class RR>
+ATR_DEV void band_rows(const Uniform &u, RR rrep_of, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W]) {
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
     // bases dlo + i + c of the read, c = 0 .. 15, for row i = 1: stream nibbles 0 .. 15
     uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
     uint32_t feed = ns[(size_t)2 * nss];              // the dword the next bases come from
     for (int i = 1; i <= u.m; ++i) {
-        const uint32_t rrep = rreps[i - 1];
+        const uint32_t rrep = rrep_of(i);
         uint32_t m0 = nibble_any(AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep));          // nibble != 0, at bit 3
         uint32_t m1 = ND > 8 ? nibble_any(AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep)) : 0u;
         if (AND_MODE) { m0 = ~m0; m1 = ~m1; }                                     // mismatch = no common bit
@@ -468,11 +493,12 @@ ATR_DEV void band_locate(const Uniform &u, const uint32_t *rreps, bool noindel, 
     uint32_t band[BAND_W];
 #pragma unroll
     for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
-    if (smax < 8) band_rows<AND_MODE, 8>(u, rreps, ns, nss, band);                 // wave-uniform
-    else if (smax < 10) band_rows<AND_MODE, 10>(u, rreps, ns, nss, band);
-    else if (smax < 12) band_rows<AND_MODE, 12>(u, rreps, ns, nss, band);
-    else if (smax < 14) band_rows<AND_MODE, 14>(u, rreps, ns, nss, band);
-    else band_rows<AND_MODE, 16>(u, rreps, ns, nss, band);
+    const auto rr = [rreps](int i) { return rreps[i - 1]; };
+    if (smax < 8) band_rows<AND_MODE, 8>(u, rr, ns, nss, band);                    // wave-uniform
+    else if (smax < 10) band_rows<AND_MODE, 10>(u, rr, ns, nss, band);
+    else if (smax < 12) band_rows<AND_MODE, 12>(u, rr, ns, nss, band);
+    else if (smax < 14) band_rows<AND_MODE, 14>(u, rr, ns, nss, band);
+    else band_rows<AND_MODE, 16>(u, rr, ns, nss, band);
     Best best;
     best.key = COST_FIELD_MAX - (u.m + n);
     best.word = (uint32_t)(u.m + n) << CSH;
@@ -503,14 +529,17 @@ ATR_DEV void band_locate(const Uniform &u, const uint32_t *rreps, bool noindel, 
 // diagonals j - i in [-k, k]: the same banded row-major DP, without any pre-pass, over the
 // 2k + 1 diagonals around the main one (c = j - i + k).  Cells left of column 0 do not exist,
 // column 0 and row 0 hold the reference's initial values (_align.pyx:333-352, :385-388).
+// k < m: with k >= m (max_error_rate >= 1) row m of COLUMN 0 would pass the cost test, and the
+// reference only looks at row m from column 1 on (_align.pyx:375, :433-455); such aligners take the
+// full sweep.
 inline bool prefix_band_applies(int flags, int m, int k) {          // host side
-    return flags == ATR_STOP_WITHIN_SEQ2 && m <= FILTER_MAX_M && k >= 0 && 2 * k + 1 <= BAND_W;
+    return flags == ATR_STOP_WITHIN_SEQ2 && m <= FILTER_MAX_M && k >= 0 && k < m && 2 * k + 1 <= BAND_W;
 }
 
 // ns: the read staged from base 1 - k on (band_stage with dlo = -k), stride nss.
-template <bool AND_MODE>
-ATR_DEV void band_locate_prefix(const Uniform &u, const uint32_t *rreps, bool noindel, const uint32_t *ns, int nss, int n,
-                                const int16_t *thr, uint32_t rec[4]) {
+template <bool AND_MODE, class RR>
+ATR_DEV void band_locate_prefix_rr(const Uniform &u, RR rr, bool noindel, const uint32_t *ns, int nss, int n,
+                                   const int16_t *thr, uint32_t rec[4]) {
     const int k = u.k, smax = 2 * k;
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
     const int max_n = atr_min(n, u.m + k);                               // :317-319 (START_WITHIN_SEQ2 not set)
@@ -521,10 +550,11 @@ ATR_DEV void band_locate_prefix(const Uniform &u, const uint32_t *rreps, bool no
         band[c] = j < 0 ? inf : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
     }
     // the diagonals beyond 2k that a wider instantiation sweeps hold true DP cells; only c <= 2k is looked at
-    if (smax < 4) band_rows<AND_MODE, 4, true>(u, rreps, ns, nss, band);            // wave-uniform
-    else if (smax < 8) band_rows<AND_MODE, 8, true>(u, rreps, ns, nss, band);
-    else if (smax < 12) band_rows<AND_MODE, 12, true>(u, rreps, ns, nss, band);
-    else band_rows<AND_MODE, 16, true>(u, rreps, ns, nss, band);
+    if (smax < 4) band_rows<AND_MODE, 4, true>(u, rr, ns, nss, band);               // wave-uniform
+    else if (smax < 6) band_rows<AND_MODE, 6, true>(u, rr, ns, nss, band);
+    else if (smax < 8) band_rows<AND_MODE, 8, true>(u, rr, ns, nss, band);
+    else if (smax < 12) band_rows<AND_MODE, 12, true>(u, rr, ns, nss, band);
+    else band_rows<AND_MODE, 16, true>(u, rr, ns, nss, band);
     Best best;
     best.key = COST_FIELD_MAX - (u.m + n);
     best.word = (uint32_t)(u.m + n) << CSH;
@@ -555,6 +585,12 @@ ATR_DEV void band_locate_prefix(const Uniform &u, const uint32_t *rreps, bool no
     rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
     rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
     rec[3] = 0;
+}
+
+template <bool AND_MODE>
+ATR_DEV void band_locate_prefix(const Uniform &u, const uint32_t *rreps, bool noindel, const uint32_t *ns, int nss, int n,
+                                const int16_t *thr, uint32_t rec[4]) {
+    band_locate_prefix_rr<AND_MODE>(u, [rreps](int i) { return rreps[i - 1]; }, noindel, ns, nss, n, thr, rec);
 }
 
 }  // namespace atr

@@ -42,6 +42,59 @@ struct SideStream {
     // no destructor: at thread / process exit the HIP runtime may already be gone; the handles die with it
 };
 
+static LinkedArgs no_linked_args() {
+    LinkedArgs la;
+    memset(&la, 0, sizeof(la));
+    return la;
+}
+
+typedef window_launcher (*window_group_fn)(int);
+static const window_group_fn window_groups[4] = {window_group_0, window_group_1, window_group_2, window_group_3};
+
+// K2a + K2b over wk.nbins bins
+void launch_fast_scan(FastWork wk, hipStream_t st) {
+    hipLaunchKernelGGL(scan_bins_kernel, dim3(wk.nbins), dim3(1024), 0, st, wk);
+    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
+}
+
+// K4a (side stream) and K4 (main stream) over the reads `order` lists for one aligner; la != nullptr:
+// the 3' part of one adapter of a linked set (bins la->bin0 ..).  fork: first call of a pipeline
+// (the side stream starts waiting for the main stream's scatter pass); join: last call.
+int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, bool fork, bool join, hipStream_t st) {
+    static thread_local SideStream side;
+    if (!side.ready()) return (int)hipErrorInvalidValue;
+    hipError_t e = hipSuccess;
+    if (fork) {
+        e = hipEventRecord(side.fork, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side.stream, side.fork, 0);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 block(256);
+    {   // K4a: banded DP over the band reads
+        const BandParams bp = band_params(a);
+        const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 4096));
+        if (la) {
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+            else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+        } else {
+            const LinkedArgs none = no_linked_args();
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+        }
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    const int rc = window_groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st);
+    if (rc != 0) return rc;
+    if (join) {
+        e = hipEventRecord(side.join, side.stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, side.join, 0);
+    }
+    return (int)e;
+}
+
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st) {
     FastWork wk = fast_carve(work, nreads);
@@ -55,32 +108,12 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
         if (ragged) hipLaunchKernelGGL((filter_kernel<false, true>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
         else        hipLaunchKernelGGL((filter_kernel<false, false>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
     }
-    hipLaunchKernelGGL(scan_bins_kernel, dim3(FILTER_BINS), dim3(1024), 0, st, wk);
-    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
+    launch_fast_scan(wk, st);
     hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
     // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
     // joined after K4, so that its waves (latency bound: three dependent gathers per task) share
     // the SIMDs with K4's instead of running before them.
-    static thread_local SideStream side;
-    if (!side.ready()) return (int)hipErrorInvalidValue;
-    hipError_t e = hipEventRecord(side.fork, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(side.stream, side.fork, 0);
-    if (e != hipSuccess) return (int)e;
-    {   // K4a: banded DP over the band reads
-        const BandParams bp = band_params(a);
-        const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 4096));
-        if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
-        else             hipLaunchKernelGGL((band_kernel<false>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk);
-    }
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipEventRecord(side.join, side.stream);
-    if (e != hipSuccess) return (int)e;
-    typedef window_launcher (*group_fn)(int);
-    static const group_fn groups[4] = {window_group_0, window_group_1, window_group_2, window_group_3};
-    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
-    const int rc = groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, st);
-    e = hipStreamWaitEvent(st, side.join, 0);
-    return rc != 0 ? rc : (int)e;
+    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, true, true, st);
 }
 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,

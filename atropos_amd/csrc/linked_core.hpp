@@ -1,0 +1,188 @@
+// linked_core.hpp -- per-lane arithmetic of the fused linked-adapter pipeline.
+//
+// The reference matches a set of linked adapters (`-a ^FRONT...BACK`) read by read:
+// AdapterCutter._best_match (atropos/commands/trim/modifiers.py:107-122) calls
+// LinkedAdapter.match_to (atropos/adapters/__init__.py:671-690) for every adapter, which is
+//     front = Adapter(FRONT, PREFIX).match_to(read)              (anchored 5': flags 8)
+//     back  = Adapter(BACK, BACK).match_to(read[front.rstop:])   (regular 3': flags 14) if front
+// with Adapter.match_to's exact-match shortcut and acceptance test around each alignment
+// (:338-400).  Here ONE pass over the packed batch does all of it per read (one read per lane):
+//
+//   front stage   every 5' adapter against the first m + k bases: literal compare (the shortcut),
+//                 then a 32-bit Myers sweep of the anchored unit-cost matrix (row 0 costs j: the
+//                 alignment must start at (0, 0)); only (read, adapter) pairs that have an
+//                 acceptable row-m cell but no literal occurrence run the exact banded DP
+//                 (filter_core.hpp, band_locate_prefix), each lane against its OWN adapter.
+//   back stage    the read keeps the lane; the 3' adapter of the front that matched is swept with
+//                 the bit-parallel pre-pass of filter_core.hpp, match masks and thresholds fetched
+//                 from the lane's own adapter block in LDS.  read[front.rstop:] is not re-packed:
+//                 the bases before s = front.rstop are fed to the sweep as "match nothing", which
+//                 leaves the initial column of a 3' adapter (cost i in row i) unchanged, so column
+//                 s plays the part of column 0 and all coordinates are re-based by s at the end.
+//   unresolved reads go to the banded / windowed DP kernels (locate_fast.hpp), binned per adapter.
+//
+// Compiled twice like the other *_core.hpp files (hipcc; g++ -DATR_HOST_EMU for tests/emu).
+#ifndef ATR_LINKED_CORE_HPP
+#define ATR_LINKED_CORE_HPP
+
+#include "filter_core.hpp"
+
+namespace atr {
+
+constexpr int LINKED_MAX = 4;                       // linked adapters per set
+constexpr int FRONT_MAX_M = 32;                     // 5' part: m + int(e*m) <= 32 -- chunk 0 holds every column it can touch
+
+// One anchored 5' adapter.  Plain data: uploaded once per set, copied to LDS by every workgroup.
+struct FrontParams {
+    uint32_t peq[16];                               // bit i - 1: row i matches query code c
+    uint32_t code[4], code_mask[4];                 // the adapter as packed nibbles + the mask of its m nibbles (literal compare)
+    uint32_t rrep[FRONT_MAX_M];                     // code of row i in all eight nibbles (banded DP)
+    int16_t thr[FRONT_MAX_M + 2];                   // floor(L * e): the DP's candidate test (_align.pyx:447, :468)
+    int16_t pf_thr[FRONT_MAX_M + 2];                // largest c with c / L <= e in double DIVISION: match_to's own test (:386-398)
+    int32_t m, k, min_overlap, indel;               // indel: effective cost min(indel_cost, k + 1)
+    int32_t noindel, accept_full, group, reserved;  // accept_full: the literal shortcut applies (:351-367)
+};
+
+// One regular 3' adapter as the pre-pass sees it (FilterParams with the thresholds in memory).
+struct BackParams {
+    uint32_t peq[16][2];                            // FilterParams::peq as (lo, hi) words
+    int32_t thr_row[FILTER_MAX_M + 1];              // FilterParams::thr_row
+    int16_t pf_thr[FILTER_MAX_M + 2];
+    uint32_t tail;                                  // FilterParams::tail (NARROW mode)
+    int32_t rows, m, k, min_overlap, indel, accept_full, reserved;
+};
+
+struct LinkedParams {
+    int32_t n, and_mode, wide, ngroups;             // wide: two-word bit-vectors in the back sweep
+    uint32_t group_mask[LINKED_MAX];                // adapters of DP group g (same length, thresholds, costs)
+    int32_t group_first[LINKED_MAX];                // a member of the group (its wave-uniform parameters)
+    FrontParams f[LINKED_MAX];
+    BackParams b[LINKED_MAX];
+};
+
+// Random-match-probability filter of Adapter.match_to (optional, device tables)
+struct LinkedRmp {
+    const double *front[LINKED_MAX];
+    const double *back[LINKED_MAX];
+    double front_max[LINKED_MAX], back_max[LINKED_MAX];
+    int32_t front_ld[LINKED_MAX], back_ld[LINKED_MAX];
+};
+
+// What the band / window kernels need to finish a record of ONE 3' adapter (wave-uniform).
+struct LinkedPost {
+    int16_t pf_thr[FILTER_MAX_M + 2];
+    int32_t m, min_overlap, accept_full, rmp_ld;
+    const double *rmp;
+    double max_rmp;
+};
+
+// per-lane view of a BackParams block (filter_decide's parameter type)
+struct LaneFilterParams {
+    int rows, and_mode;
+    uint32_t tail;
+    const int32_t *thr_row;
+};
+
+// ---- Adapter.match_to's acceptance test (adapters/__init__.py:386-398) ---------------------
+// size >= min_overlap, errors / size <= max_error_rate (as a per-size table built with the double
+// division), match_probability(matches, size) <= max_rmp; the literal shortcut (:351-367) returns a
+// full-length zero-error occurrence without any test.
+ATR_DEV bool linked_accept(int size, int matches, int errors, int m, int min_overlap, const int16_t *pf_thr,
+                           bool accept_full, const double *rmp, int rmp_ld, double max_rmp) {
+    if (accept_full && matches == m && errors == 0 && size == m) return true;
+    if (size < min_overlap || size < 1 || errors > (int)pf_thr[atr_min(size, m)]) return false;
+    if (rmp) return rmp[(size_t)atr_min(size, rmp_ld - 1) * rmp_ld + atr_min(atr_max(matches, 0), rmp_ld - 1)] <= max_rmp;
+    return true;
+}
+
+ATR_DEV void rec_none(uint32_t rec[4]) { rec[0] = 0xFFFF0000u; rec[1] = rec[2] = rec[3] = 0u; }
+ATR_DEV bool rec_found(const uint32_t rec[4]) { return (rec[0] >> 31) == 0u; }
+
+// Acceptance test + re-basing of a 3' record that was computed in whole-read coordinates.
+ATR_DEV void linked_finish(uint32_t rec[4], int s, int m, int min_overlap, const int16_t *pf_thr, bool accept_full,
+                           const double *rmp, int rmp_ld, double max_rmp) {
+    if (!rec_found(rec)) { rec_none(rec); return; }
+    const int refstart = (int)(rec[0] & 0xFFFFu), refstop = (int)(rec[0] >> 16);
+    const int matches = (int)(rec[2] & 0xFFFFu), errors = (int)(rec[2] >> 16);
+    if (!linked_accept(refstop - refstart, matches, errors, m, min_overlap, pf_thr, accept_full, rmp, rmp_ld, max_rmp)) {
+        rec_none(rec);
+        return;
+    }
+    const uint32_t qs = (rec[1] & 0xFFFFu) - (uint32_t)s, qe = (rec[1] >> 16) - (uint32_t)s;
+    rec[1] = (qs & 0xFFFFu) | (qe << 16);
+}
+
+// ---- front stage ---------------------------------------------------------------------------
+// Literal occurrence at the read start (str.startswith on the upper-cased read, :353-355): the
+// packed codes of the first m bases equal the adapter's.  Bases past the read end are code 0 and
+// equal no adapter base, so a read shorter than m never passes.
+ATR_DEV bool front_exact(const uint32_t *code, const uint32_t *code_mask, const uint32_t w[4]) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) x |= (w[d] ^ code[d]) & code_mask[d];
+    return x == 0u;
+}
+
+// Myers / Hyyro sweep of the ANCHORED unit-cost matrix: D[i][0] = i, D[0][j] = j (the horizontal
+// delta entering row 1 is +1 in every column), rows at bits 0 .. m - 1.  Lower bound of the
+// reference's costs for any indel cost, equal to them for indel cost 1.
+struct FrontState {
+    uint32_t pv, mv;
+    int score, best;                                // D[m][j], min over the swept columns
+};
+ATR_DEV void front_init(FrontState &S, int m) {
+    S.pv = m >= 32 ? ~0u : ((1u << m) - 1u);
+    S.mv = 0u;
+    S.score = m; S.best = m;
+}
+ATR_DEV void front_step(FrontState &S, uint32_t eq, int m) {
+    const uint32_t xv = eq | S.mv;
+    const uint32_t xh = (((eq & S.pv) + S.pv) ^ S.pv) | eq;
+    uint32_t ph = S.mv | ~(xh | S.pv);
+    uint32_t mh = S.pv & xh;
+    S.score += (int)((ph >> (m - 1)) & 1u) - (int)((mh >> (m - 1)) & 1u);
+    ph = (ph << 1) | 1u;
+    mh <<= 1;
+    S.pv = mh | ~(xv | ph);
+    S.mv = ph & xv;
+    S.best = atr_min(S.best, S.score);
+}
+// query code of column j (1-based) out of the read's first chunk
+ATR_DEV uint32_t chunk_code(const uint32_t w[4], int j) { return (w[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 15u; }
+
+// wave-uniform parameters of a front adapter's DP group
+ATR_DEV Uniform front_uniform(int m, int k, int indel, int min_overlap) {
+    Uniform u;
+    u.m = m; u.k = k; u.p0 = 0; u.first_p = m; u.indel = indel; u.min_overlap = min_overlap;
+    u.sr = false; u.sq = false; u.er = false; u.eq = true;                 // flags 8: STOP_WITHIN_SEQ2 only
+    u.insw = (uint32_t)indel * COST1 + PRIO_INS;
+    u.delw = (uint32_t)indel * COST1 + PRIO_DEL;
+    u.klimit = (uint32_t)(k + 1) << CSH;
+    return u;
+}
+
+// A front record passes Adapter.match_to's test?
+ATR_DEV bool front_accept(const uint32_t rec[4], int m, int min_overlap, const int16_t *pf_thr, bool accept_full,
+                          const double *rmp, int rmp_ld, double max_rmp) {
+    if (!rec_found(rec)) return false;
+    const int refstart = (int)(rec[0] & 0xFFFFu), refstop = (int)(rec[0] >> 16);
+    return linked_accept(refstop - refstart, (int)(rec[2] & 0xFFFFu), (int)(rec[2] >> 16), m, min_overlap, pf_thr,
+                         accept_full, rmp, rmp_ld, max_rmp);
+}
+ATR_DEV void front_exact_record(uint32_t rec[4], int m) {                   // Match(0, m, 0, m, m, 0)  (:355)
+    rec[0] = (uint32_t)m << 16; rec[1] = (uint32_t)m << 16; rec[2] = (uint32_t)m; rec[3] = 0u;
+}
+
+// ---- back stage ----------------------------------------------------------------------------
+// Bases before s read as code 0 ("match nothing"): dword z (bases 8z .. 8z + 7, 0-based) of a read
+// whose alignment starts at base s.
+ATR_DEV uint32_t start_mask(int z, int s) {
+    const int lo = s - 8 * z;                                                // nibbles of this dword before s
+    return lo <= 0 ? ~0u : lo >= 8 ? 0u : ~0u << (4 * lo);
+}
+
+// scatter bin of the fused pipeline: FILTER_BINS bins per adapter, adapter-major
+ATR_DEV int linked_bin(uint32_t ww, int which, int m, bool by_rows) { return which * FILTER_BINS + window_bin(ww, m, by_rows); }
+
+}  // namespace atr
+#endif

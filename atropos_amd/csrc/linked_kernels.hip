@@ -1,0 +1,316 @@
+// linked_kernels.hip -- the fused linked-adapter pipeline (linked_core.hpp) and its C ABI.
+//
+//   L1  linked_filter_kernel   one read per lane, the read is loaded once: every anchored 5' adapter
+//                              (literal compare, anchored Myers sweep, banded DP for the few that need
+//                              it), choice of the matching linked adapter, then the bit-parallel
+//                              pre-pass of that adapter's 3' part from column front.rstop on.  Writes
+//                              the `which` bytes, the 5' record, the 3' record of every read it can
+//                              resolve and a window word for the rest; per-block histogram of the
+//                              scatter bins (FILTER_BINS per adapter).
+//   L2  scan kernels           (locate_fast.hpp) over n * FILTER_BINS bins
+//   L3  linked_scatter_kernel  read indices of the unresolved reads, ordered by (adapter, bin)
+//   L4  band_kernel / window_kernel<.., LINKED> once per adapter over its own bins
+//
+// No torch kernel and no re-pack between the first load of a read and the last store of its records.
+#include <hip/hip_runtime.h>
+#include <string>
+
+#include "atropos_hip.h"
+#include "linked_host.hpp"
+#include "locate_fast.hpp"
+
+namespace atr {
+
+void launch_fast_scan(FastWork wk, hipStream_t st);
+int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, bool fork, bool join, hipStream_t st);
+int hip_fail(hipError_t e, const char *what);
+
+struct LinkedBlob {
+    LinkedParams p;
+    LinkedRmp rmp;
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
+
+template <bool WIDE, bool RAGGED, bool AND_MODE>
+__global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__restrict__ blob,
+                                                            const uint4 *__restrict__ packed,
+                                                            const int32_t *__restrict__ lens, long long nreads,
+                                                            int nchunks, int max_len, uint16_t *__restrict__ which_out,
+                                                            uint4 *__restrict__ front_out, uint4 *__restrict__ back_out,
+                                                            FastWork wk) {
+    __shared__ __attribute__((aligned(16))) LinkedBlob S;
+    __shared__ uint32_t s_hist[LINKED_MAX * FILTER_BINS];
+    __shared__ uint32_t s_stream[4][BAND_STREAM][64];              // per wave: the staged read of the 5' banded DP
+    for (int i = threadIdx.x; i < (int)(sizeof(LinkedBlob) / 4); i += 256) ((uint32_t *)&S)[i] = ((const uint32_t *)blob)[i];
+    for (int i = threadIdx.x; i < LINKED_MAX * FILTER_BINS; i += 256) s_hist[i] = 0;
+    __syncthreads();
+
+    const int nad = rfl(S.p.n), ngroups = rfl(S.p.ngroups);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long ntiles = (nreads + 63) >> 6;
+    long long t0, t1;
+    block_tiles(ntiles, t0, t1);
+    for (long long tile = t0 + wave; tile < t1; tile += 4) {
+        const long long r = tile * 64 + lane;
+        const bool live = r < nreads;
+        const int n = live ? (RAGGED ? lens[r] : max_len) : 0;
+        const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
+        const uint4 c0v = tp[0];
+        const uint32_t w0[4] = {c0v.x, c0v.y, c0v.z, c0v.w};
+
+        // ---- 5' parts ------------------------------------------------------------------------------
+        int which = -1, count = 0;
+        uint32_t frec[4];
+        rec_none(frec);
+        uint32_t dpmask = 0;
+        for (int a = 0; a < nad; ++a) {                            // wave-uniform
+            const FrontParams &fp = S.p.f[a];
+            const int m = rfl(fp.m), k = rfl(fp.k), mk = m + k;
+            FrontState st;
+            front_init(st, m);
+            int j = 0;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t w = w0[d];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    ++j;
+                    if (j <= mk) {                                 // wave-uniform
+                        front_step(st, fp.peq[w & 15u], m);
+                        w >>= 4;
+                    }
+                }
+            }
+            const bool exact = rfl(fp.accept_full) != 0 && front_exact(fp.code, fp.code_mask, w0);
+            if (live) {
+                if (exact) {
+                    ++count;
+                    if (which < 0) { which = a; front_exact_record(frec, m); }
+                } else if (st.best <= k) {
+                    dpmask |= 1u << a;
+                }
+            }
+        }
+        // (read, adapter) pairs with an acceptable cell but no literal occurrence: the exact banded DP,
+        // every lane against its own adapter of the group
+        for (int g = 0; g < ngroups; ++g) {
+            const uint32_t gm = (uint32_t)rfl((int)S.p.group_mask[g]);
+            const FrontParams &gp = S.p.f[rfl(S.p.group_first[g])];
+            const Uniform u = front_uniform(rfl(gp.m), rfl(gp.k), rfl(gp.indel), rfl(gp.min_overlap));
+            const bool noindel = rfl(gp.noindel) != 0;
+            while (wave_any((dpmask & gm) != 0u)) {
+                const uint32_t mine = dpmask & gm;
+                const int a_l = mine ? __ffs((int)mine) - 1 : rfl(S.p.group_first[g]);
+                const FrontParams &mp = S.p.f[a_l];
+                uint32_t *ns = &s_stream[wave][0][lane];
+                band_stage((const uint32_t *)tp, nchunks, -u.k, ns, 64);
+                uint32_t rec[4];
+                const uint32_t *rr = mp.rrep;
+                band_locate_prefix_rr<AND_MODE>(u, [rr](int i) { return rr[i - 1]; }, noindel, ns, 64, n, gp.thr, rec);
+                if (mine) {
+                    dpmask &= ~(1u << a_l);
+                    if (front_accept(rec, u.m, u.min_overlap, mp.pf_thr, mp.accept_full != 0, S.rmp.front[a_l], S.rmp.front_ld[a_l],
+                                     S.rmp.front_max[a_l])) {
+                        ++count;
+                        if (which < 0 || a_l < which) {
+                            which = a_l;
+                            frec[0] = rec[0]; frec[1] = rec[1]; frec[2] = rec[2]; frec[3] = 0u;
+                        }
+                    }
+                }
+            }
+        }
+        if (live) {
+            front_out[r] = make_uint4(frec[0], frec[1], frec[2], frec[3]);
+            which_out[r] = (uint16_t)((uint32_t)(which & 0xFF) | ((uint32_t)count << 8));
+        }
+
+        // ---- 3' part of the adapter whose 5' part matched, on read[front.rstop:] ---------------------
+        const bool has = live && which >= 0;
+        uint32_t ww = 0u;
+        uint32_t brec[4];
+        rec_none(brec);
+        int mb = 0;
+        if (wave_any(has)) {
+            const BackParams &bp = S.p.b[which < 0 ? 0 : which];
+            const int s = has ? (int)(frec[1] >> 16) : 0x3fff;             // lanes without a 5' match see no base at all
+            Uniform ub = front_uniform(bp.m, bp.k, bp.indel, bp.min_overlap);
+            ub.sq = true; ub.er = true;                                    // (only m, k, indel, min_overlap, sr are read)
+            mb = ub.m;
+            const int mf = bp.rows;
+            FilterState F;
+            filter_init(F, ub, mf, WIDE);
+            F.best = FILTER_BEST_NONE_SIGNED;
+            const int jhi = RAGGED ? wave_max_i32(has ? n : 0) : max_len;
+            const int jfull = RAGGED ? wave_min_i32(has ? n : 0x7fffffff) : max_len;   // columns every matched lane has
+            const int s_lo = wave_min_i32(has ? s : 0x7fffffff), s_hi = wave_max_i32(has ? s : 0);
+            const int z_first = s_lo >> 3;                                 // first dword holding a live base
+            const char *peq_base = (const char *)bp.peq;
+            if (jhi > 8 * z_first) {
+                const int cfirst = z_first >> 2, c1 = (jhi + 31) >> 5;
+                uint4 nxt = cfirst == 0 ? c0v : tp[(size_t)cfirst * 64];
+                int jlast = 8 * z_first;
+                for (int c = cfirst; c < c1; ++c) {
+                    const uint4 cur = nxt;
+                    if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int z = 4 * c + d;
+                        if (z < z_first || 8 * z >= jhi) continue;         // wave-uniform
+                        uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
+                        if (8 * z < s_hi) w &= start_mask(z, s);           // wave-uniform: only the first dwords
+                        // byte offsets of the eight mask entries (8 bytes each): even / odd nibbles pre-scaled
+                        uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
+                        uint2 e[8];
+#pragma unroll
+                        for (int b = 0; b < 8; ++b) {
+                            const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
+                            e[b] = *(const uint2 *)(peq_base + off);
+                        }
+                        const int j0 = 8 * z;
+                        if (j0 + 8 <= jhi && j0 + 8 <= jfull) {                 // wave-uniform
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)(j0 + b + 1));
+                        } else {
+#pragma unroll
+                            for (int b = 0; b < 8; ++b) {
+                                const int j = j0 + b + 1;
+                                if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)j);
+                            }
+                        }
+                        jlast = min(jhi, j0 + 8);
+                    }
+                    filter_fold(F, RAGGED ? min(n, jlast) : jlast);        // at most 32 columns since the last fold
+                }
+            }
+            F.best = filter_unbias_best(F.best, ub.k);
+            LaneFilterParams lf;
+            lf.rows = mf; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
+            ww = filter_decide<WIDE>(F, ub, lf, (const uint32_t *)tp, nchunks, n, brec, s);
+            if (!has) { ww = 0u; rec_none(brec); }
+            else if (!window_valid(ww))
+                linked_finish(brec, s, ub.m, ub.min_overlap, bp.pf_thr, bp.accept_full != 0, S.rmp.back[which], S.rmp.back_ld[which],
+                              S.rmp.back_max[which]);
+        }
+        if (live) {
+            wk.win[r] = ww;
+            if (!window_valid(ww)) back_out[r] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
+            else atomicAdd(&s_hist[linked_bin(ww, which, mb, !RAGGED)], 1u);
+        }
+    }
+    __syncthreads();
+    const int nbins = nad * FILTER_BINS;
+    for (int b = threadIdx.x; b < nbins; b += 256) wk.counts[(size_t)b * FAST_BLOCKS + blockIdx.x] = s_hist[b];
+}
+
+struct LinkedLens { int m[LINKED_MAX]; };
+
+__global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, const LinkedLens ms, int by_rows,
+                                                             const uint16_t *__restrict__ which_out, FastWork wk) {
+    __shared__ uint32_t s_cur[LINKED_MAX * FILTER_BINS];
+    for (int b = threadIdx.x; b < wk.nbins; b += 256)
+        s_cur[b] = wk.binbase[b] + wk.counts[(size_t)b * FAST_BLOCKS + blockIdx.x];
+    __syncthreads();
+    const long long ntiles = (nreads + 63) >> 6;
+    long long t0, t1;
+    block_tiles(ntiles, t0, t1);
+    for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
+        const uint32_t ww = wk.win[r];
+        if (window_valid(ww)) {
+            const int which = (int)(which_out[r] & 0xFFu);
+            wk.order[atomicAdd(&s_cur[linked_bin(ww, which, ms.m[which], by_rows != 0)], 1u)] = (uint32_t)r;
+        }
+    }
+}
+
+template <bool WIDE, bool RAGGED>
+static void launch_l1(bool and_mode, const LinkedBlob *blob, const uint4 *packed, const int32_t *lens, long long nreads,
+                      int nchunks, int max_len, uint16_t *which, uint4 *front, uint4 *back, FastWork wk, hipStream_t st) {
+    const dim3 grid(FAST_BLOCKS), block(256);
+    if (and_mode) hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, true>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk);
+    else          hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, false>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk);
+}
+
+}  // namespace atr
+
+using namespace atr;
+
+extern "C" {
+
+int atr_linked_create(const atr_linked_adapter *adapters, int n_adapters, atr_linked_set **out) {
+    if (!out) return ATR_ERR_INVALID;
+    *out = nullptr;
+    atr_linked_set *s = new (std::nothrow) atr_linked_set();
+    if (!s) return ATR_ERR_NOMEM;
+    const int rc = linked_fill(s, adapters, n_adapters);
+    if (rc != ATR_OK) { delete s; return rc; }
+    LinkedBlob blob;
+    blob.p = s->p;
+    blob.rmp = s->rmp;
+    hipError_t e = hipMalloc(&s->d_params, sizeof(LinkedBlob));
+    if (e != hipSuccess) { delete s; return e == hipErrorOutOfMemory ? ATR_ERR_NOMEM : hip_fail(e, "hipMalloc(linked set)"); }
+    e = hipMemcpy(s->d_params, &blob, sizeof(LinkedBlob), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(s->d_params); delete s; return hip_fail(e, "hipMemcpy(linked set)"); }
+    *out = s;
+    return ATR_OK;
+}
+
+void atr_linked_destroy(atr_linked_set *s) {
+    if (!s) return;
+    if (s->d_params) (void)hipFree(s->d_params);
+    delete s;
+}
+
+int atr_linked_query_table(const atr_linked_set *s) { return s ? s->table_kind : ATR_ERR_INVALID; }
+
+size_t atr_linked_work_bytes(const atr_linked_set *s, int64_t nreads) {
+    return (!s || nreads < 0) ? 0 : fast_work_bytes(nreads, s->p.n * FILTER_BINS);
+}
+
+int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
+                           int max_len, int8_t *d_which, atr_result *d_front, atr_result *d_back, void *d_work,
+                           void *stream) {
+    if (!s || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    if (!d_which || !d_front || !d_back || !d_work || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
+    if (max_len == 0) return ATR_ERR_UNSUPPORTED;                  // an all-empty batch has no packed chunk to read
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunks = (max_len + 31) / 32;
+    FastWork wk = fast_carve(d_work, nreads, s->p.n * FILTER_BINS);
+    const LinkedBlob *blob = (const LinkedBlob *)s->d_params;
+    const bool ragged = d_lens != nullptr, and_mode = s->p.and_mode != 0;
+    uint16_t *which = (uint16_t *)d_which;
+    uint4 *front = (uint4 *)d_front, *back = (uint4 *)d_back;
+    const uint4 *packed = (const uint4 *)d_packed;
+    if (s->p.wide) {
+        if (ragged) launch_l1<true, true>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
+        else        launch_l1<true, false>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
+    } else {
+        if (ragged) launch_l1<false, true>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
+        else        launch_l1<false, false>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "linked_filter_kernel launch");
+    launch_fast_scan(wk, st);
+    LinkedLens ms;
+    for (int a = 0; a < LINKED_MAX; ++a) ms.m[a] = a < s->p.n ? s->p.b[a].m : 0;
+    hipLaunchKernelGGL(linked_scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, (long long)nreads, ms, ragged ? 0 : 1,
+                       (const uint16_t *)which, wk);
+    e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "linked scatter launch");
+    for (int a = 0; a < s->p.n; ++a) {
+        LinkedArgs la;
+        la.bin0 = a * FILTER_BINS;
+        la.front = front;
+        la.post = s->post[a];
+        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a == 0,
+                                      a == s->p.n - 1, st);
+        if (rc != 0) return hip_fail((hipError_t)rc, "linked band / window launch");
+    }
+    return ATR_OK;
+}
+
+}  // extern "C"

@@ -315,6 +315,17 @@ ATR_DEV void lane_init_window(LaneState<MT> &L, const Uniform &u, int n, int j_s
         scan_last_column<MT, true>(L.best, L.col, u.p0, u.first_p, n, u.min_overlap, thr, NOINDEL ? 0 : u.indel, u.klimit);
 }
 
+// Linked adapters (linked_core.hpp): a lane whose own alignment starts at column j_start, later
+// than the wave's common start column, starts afresh there.
+template <int MT>
+ATR_DEV void lane_restart_window(LaneState<MT> &L, const Uniform &u, int j_start) {
+#pragma unroll
+    for (int i = 0; i <= MT; ++i) L.col[i] = window_init_word(i - u.p0, j_start, u.indel);
+    L.best.key = COST_FIELD_MAX - (u.m + L.n);
+    L.best.word = (uint32_t)(u.m + L.n) << CSH;
+    L.best.ref_stop = u.m; L.best.query_stop = L.n; L.best.matches = 0;
+}
+
 // Column j of the wave-uniform sweep, query code q.  Every lane of the wave executes
 // the column update unmasked; a lane whose own window (min_n, max_n] is narrower than
 // the wave's range

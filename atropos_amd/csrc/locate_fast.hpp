@@ -23,6 +23,7 @@
 #include <algorithm>
 #include "locate_kernel.hpp"
 #include "filter_core.hpp"
+#include "linked_core.hpp"
 
 namespace atr {
 
@@ -32,24 +33,35 @@ constexpr int FAST_BLOCKS = 8192;                   // grid of K1 / K3: four rou
 struct FastWork {                                    // carve-up of the caller's workspace
     uint32_t *win;                                   // [nreads]
     uint32_t *order;                                 // [nreads]
-    uint32_t *counts;                                // [FILTER_BINS][FAST_BLOCKS] -> in-bin offsets after K2a
-    uint32_t *binbase;                               // [FILTER_BINS] first slot of each bin after K2b
+    uint32_t *counts;                                // [nbins][FAST_BLOCKS] -> in-bin offsets after K2a
+    uint32_t *binbase;                               // [nbins + 1] first slot of each bin after K2b; [nbins] = total
     uint32_t *total;                                 // [1] number of unresolved reads
+    int nbins;                                       // FILTER_BINS, or FILTER_BINS per adapter of a linked set
 };
 
-inline size_t fast_work_bytes(long long nreads) {
-    return (size_t)nreads * 8 + (size_t)FAST_BLOCKS * FILTER_BINS * 4 + FILTER_BINS * 4 + 256;
+inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
+    return (size_t)nreads * 8 + (size_t)FAST_BLOCKS * nbins * 4 + (size_t)(nbins + 1) * 4 + 256;
 }
 
-inline FastWork fast_carve(void *work, long long nreads) {
+inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS) {
     FastWork w;
     w.win = (uint32_t *)work;
     w.order = w.win + nreads;
     w.counts = w.order + nreads;
-    w.binbase = w.counts + (size_t)FAST_BLOCKS * FILTER_BINS;
-    w.total = w.binbase + FILTER_BINS;
+    w.binbase = w.counts + (size_t)FAST_BLOCKS * nbins;
+    w.total = w.binbase + nbins + 1;
+    w.nbins = nbins;
     return w;
 }
+
+// Extra arguments of the band / window kernels when they finish the 3' part of ONE adapter of a
+// linked set (linked_core.hpp): its bins start at bin0, the read's alignment starts at front[r]'s
+// querystop, the record goes through Adapter.match_to's acceptance test and is re-based.
+struct LinkedArgs {
+    int bin0;
+    const uint4 *front;
+    LinkedPost post;
+};
 
 // tiles [t0, t1) owned by a block of the persistent grid
 __device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, long long &t1) {
@@ -166,7 +178,8 @@ __global__ __launch_bounds__(1024) void scan_bins_kernel(FastWork wk) {
 __global__ __launch_bounds__(256) void scan_total_kernel(FastWork wk) {
     if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int b = 0; b < FILTER_BINS; ++b) { const uint32_t t = wk.binbase[b]; wk.binbase[b] = run; run += t; }
+        for (int b = 0; b < wk.nbins; ++b) { const uint32_t t = wk.binbase[b]; wk.binbase[b] = run; run += t; }
+        wk.binbase[wk.nbins] = run;
         wk.total[0] = run;
     }
 }
@@ -186,21 +199,23 @@ __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, i
 }
 // K4a: the banded DP over the band reads = the slots [0, binbase[BAND_BINS]) of `order`
 // (persistent grid like K4; reads gathered by index).
-template <bool AND_MODE>
+template <bool AND_MODE, bool LINKED>
 __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const BandParams bp,
                                                    const uint4 *__restrict__ packed, const int32_t *__restrict__ lens,
                                                    long long nreads, int nchunks, int max_len, uint4 *__restrict__ out,
-                                                   FastWork wk) {
+                                                   FastWork wk, const LinkedArgs la) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_stream[4][BAND_STREAM][64];              // per wave: the staged reads, [dword][lane]
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
     for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
     __syncthreads();
-    const long long total = (long long)wk.binbase[BAND_BINS];          // band reads come first in `order`
+    // band reads come first in `order` (linked: first among the bins of this adapter)
+    const long long base = LINKED ? (long long)wk.binbase[la.bin0] : 0;
+    const long long total = (long long)wk.binbase[(LINKED ? la.bin0 : 0) + BAND_BINS];
     const int lane = threadIdx.x & 63;
-    const long long nwaves = (total + 63) >> 6;
+    const long long nwaves = (total - base + 63) >> 6;
     for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwaves; wv += (long long)gridDim.x * 4) {
-        const long long slot = wv * 64 + lane;
+        const long long slot = base + wv * 64 + lane;
         const bool live = slot < total;
         const long long r = live ? (long long)wk.order[slot] : 0;
         const uint32_t ww = live ? wk.win[r] : 0u;
@@ -212,6 +227,9 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         band_stage(q, nchunks, window_lo(ww), ns, 64);
         uint32_t rec[4];
         band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
+        if (LINKED && live)
+            linked_finish(rec, (int)(la.front[r].y >> 16), la.post.m, la.post.min_overlap, la.post.pf_thr,
+                          la.post.accept_full != 0, la.post.rmp, la.post.rmp_ld, la.post.max_rmp);
         if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     }
 }
@@ -242,10 +260,11 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
 }
 #endif  // ATR_DEFINE_FILTER_KERNELS
 
-template <int MT, bool NOINDEL>
+template <int MT, bool NOINDEL, bool LINKED>
 __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads,
-                                                     int nchunks, int max_len, uint4 *__restrict__ out, FastWork wk) {
+                                                     int nchunks, int max_len, uint4 *__restrict__ out, FastWork wk,
+                                                     const LinkedArgs la) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_init[ATR_MAX_REF_LEN + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_nm[16][4];
@@ -257,7 +276,8 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     }
     __syncthreads();
     // the slots [first, total) of `order`: everything but the band reads (K4a)
-    const long long first = (long long)wk.binbase[BAND_BINS], total = (long long)wk.total[0];
+    const int bin0 = LINKED ? la.bin0 : 0;
+    const long long first = (long long)wk.binbase[bin0 + BAND_BINS], total = (long long)wk.binbase[bin0 + FILTER_BINS];
     const int lane = threadIdx.x & 63;
     const long long nwaves = (total - first + 63) >> 6;
     // persistent grid: each wave takes every (gridDim*4)-th group of 64 slots of `order`
@@ -276,8 +296,13 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         // a wave of by-rows bins only; not from a real column 0 of zeros (START_WITHIN_SEQ1), which
         // is no upper bound of the cells to its right
         const bool head = !(u.sr && jlo == 0);
-        const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[ROWS_BIN0])) != 0 &&
+        const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0 &&
                          head;                          // (wave-uniform by construction; tell the compiler)
+        // linked: the alignment of a lane starts at its own column s (= front.rstop).  The wave's
+        // common start column may lie before that -- such a lane is re-initialised when the sweep
+        // reaches its s (its own window starts at or after s, so nothing of value was computed).
+        const int s_lane = (LINKED && live) ? (int)(la.front[r].y >> 16) : 0;
+        const int s_top = LINKED ? wave_max_i32(s_lane) : 0;
 
         LaneState<MT> L;
         lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
@@ -308,6 +333,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
                         int pl = head ? min(plimit, u.p0 + (j - jlo) + u.k) : plimit;
                         if (tri) pl = min(pl, u.p0 + triangle_rows(rows_w, max_len, j, u.k));
                         lane_step<MT, NOINDEL, true, true>(L, u, j, nm, s_thr, pl);
+                        if (LINKED && j <= s_top && s_lane == j) lane_restart_window<MT>(L, u, j);
                     }
                 }
             }
@@ -315,21 +341,32 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         if (live) {
             uint32_t rec[4];
             lane_result<MT>(L, u, rec);
+            if (LINKED)
+                linked_finish(rec, s_lane, la.post.m, la.post.min_overlap, la.post.pf_thr, la.post.accept_full != 0,
+                              la.post.rmp, la.post.rmp_ld, la.post.max_rmp);
             out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
         }
     }
 }
 
+// la == nullptr: the single-aligner pipeline
 typedef int (*window_launcher)(const atr_aligner *, const uint4 *, const int32_t *, long long, int, int, uint4 *,
-                               FastWork, hipStream_t);
+                               FastWork, const LinkedArgs *, hipStream_t);
 
 template <int MT>
 int launch_window_mt(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                     int max_len, uint4 *out, FastWork wk, hipStream_t st) {
+                     int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, hipStream_t st) {
     const bool noindel = a->indel_cost > a->p.k;
     const dim3 grid((unsigned)std::min<long long>((nreads + 255) / 256, 4096)), block(256);
-    if (noindel) hipLaunchKernelGGL((window_kernel<MT, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
-    else         hipLaunchKernelGGL((window_kernel<MT, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk);
+    if (la) {
+        if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+        else         hipLaunchKernelGGL((window_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+    } else {
+        LinkedArgs none;
+        memset(&none, 0, sizeof(none));
+        if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, none);
+        else         hipLaunchKernelGGL((window_kernel<MT, false, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, none);
+    }
     return (int)hipGetLastError();
 }
 

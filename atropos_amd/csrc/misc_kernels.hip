@@ -44,7 +44,8 @@ struct CompTable { uint8_t c[256]; };
 __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, uint8_t *__restrict__ q1,
                                                       const int32_t *__restrict__ l1, uint8_t *__restrict__ s2,
                                                       uint8_t *__restrict__ q2, const int32_t *__restrict__ l2,
-                                                      long long stride, const int16_t *__restrict__ im,
+                                                      long long stride, const int16_t *__restrict__ im, int im_stride,
+                                                      int gate_records,
                                                       const uint8_t *__restrict__ mask, long long n, int max_len,
                                                       int action, int min_qual_diff, int truncate,
                                                       const CompTable ct, int32_t *__restrict__ changed,
@@ -55,24 +56,29 @@ __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, 
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const int len1 = l1 ? l1[p] : max_len, len2 = l2 ? l2[p] : max_len;
-    if (mask && !mask[p]) {
+    // gate_records: `im` are the records of atr_insert_match_batch; a pair is corrected when its insert
+    // match exists and has errors (modifiers.py:397-404)
+    const int16_t *imp = im + (size_t)im_stride * p;
+    if ((mask && !mask[p]) || (gate_records && (imp[1] < 0 || imp[5] <= 0))) {
         changed[2 * p] = changed[2 * p + 1] = 0;
         newlen[2 * p] = len1; newlen[2 * p + 1] = len2;
         return;
     }
     correct_errors_one(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
-                       q2 ? q2 + p * stride : nullptr, len2, im + 4 * p, action, min_qual_diff, truncate != 0, s_comp,
+                       q2 ? q2 + p * stride : nullptr, len2, imp, action, min_qual_diff, truncate != 0, s_comp,
                        changed + 2 * p, newlen + 2 * p);
 }
 
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
-                   long long stride, const int16_t *im, const uint8_t *mask, long long n, int max_len, int action,
+                   long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
+                   int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st) {
     CompTable ct;
     memcpy(ct.c, comp, 256);
     hipLaunchKernelGGL(correct_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s1, q1, l1, s2, q2, l2,
-                       stride, im, mask, n, max_len, action, min_qual_diff, truncate, ct, changed, newlen);
+                       stride, im, im_stride, gate_records, mask, n, max_len, action, min_qual_diff, truncate, ct, changed,
+                       newlen);
     return (int)hipGetLastError();
 }
 

@@ -219,6 +219,11 @@ class RecordSource(object):
             self._batches[key] = ReadBatch(packed, lens, self.n, max_len, table_kind, table)
         return self._batches[key]
 
+    def sliced(self, starts):
+        """The source of the reads ``read[start:]`` (start relative to the kept interval)."""
+        begin = self.begin + starts.to(self.begin.dtype)
+        return RecordSource(self.fq, begin, torch.maximum(self.end, begin))
+
     def planes(self, max_len, table_kind, table, check=False):
         """plane64 pack (insert aligner) of the kept intervals with a given max_len; no case
         folding (InsertAligner compares the reads as they are).  check: every base must have a code."""

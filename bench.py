@@ -1,15 +1,19 @@
 #!/usr/bin/env python3
-"""Headline benchmark: reads/s of 150 bp single-end adapter alignment
-(BASELINE.json configs[1], "C2": 10 M synthetic 150 bp reads, one TruSeq 3' adapter,
-e = 0.1) on N MI355X GPUs of one node.
+"""Headline benchmark: reads/s of adapter alignment on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 3                 # C2, the headline (BASELINE.json configs[1])
+    python bench.py --config C3|C4|C5 ...                          # the other BASELINE configs, one GPU shard each
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-A step is one pass of the hot path (atr_locate_batch) over one batch of 10 M packed
-reads resident in HBM; with N GPUs every rank owns its own 10 M-read shard (weak
-scaling, no data-path collective: reads are independent, results stay per GPU).
-Prints ONE JSON line on rank 0.
+A step is one pass of the hot path over one batch of packed reads resident in HBM; with N GPUs
+every rank owns its own shard (weak scaling, no data-path collective: reads are independent,
+results stay per GPU).  Prints ONE JSON line on rank 0.
+
+  C2  10 M x 150 bp SE, one TruSeq 3' adapter, e = 0.1       atr_locate_batch (filtered pipeline)
+  C3  10 M pairs 2 x 150 bp, insert aligner                  atr_insert_match_batch
+  C4  12.5 M x 150 bp SE (100 M / 8 GPUs), 4 linked adapters atr_linked_match_batch
+  C5  2 x 250 bp pairs (100 M / 8 GPUs, streamed as sub-batches), insert aligner with read wildcards
+      + error correction of the overlap (liberal)            atr_insert_match_batch + atr_insert_correct_batch
 """
 import argparse
 import json
@@ -23,40 +27,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_READ = 75 + 16      # ceil(150/2) packed-nibble bytes in + 16-byte result out
 HBM_PEAK_GBS = 8000.0              # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_MEASURED_GBS = 6290.0          # float4 device copy measured on MI355X (same guide)
+VALU_NOMINAL_T = 78.6              # T lane-ops/s: 1024 SIMD-32s x 32 lanes x 2.4 GHz (wave64 op = 2 issue cycles)
+VALU_MIXED_MODEL_T = 39.3          # every op of a mixed integer stream at 4 issue cycles (profiles/r13_valu_issue_rates.txt): a MODEL
+PCIE_GBS = 63.0
 
 
-def measured_traffic(reads, filtered):
-    """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, collected in their
-    own rocprofv3 passes by tools/profile_r.sh and reduced into profiles/hbm_traffic.json with
-    the gfx950 correction of MI355X_MICROARCH.md), scaled to this launch's read count."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not filtered or not os.path.exists(path):
+def profile_counters(config):
+    """PMC figures of one launch from the committed rocprofv3 passes (tools/profile_r.sh ->
+    tools/reduce_traffic.py -> profiles/traffic_<config>.json).  They are NOT measured by this run."""
+    path = os.path.join(ROOT, "profiles", "traffic_%s.json" % config)
+    if not os.path.exists(path):
         return None
     with open(path) as fh:
-        t = json.load(fh)
-    return t["hbm_bytes_per_read"] * reads
-
-
-VALU_PEAK_T = 39.3                 # T lane-ops/s at 4 issue cycles per wave64 op: 1024 SIMDs x 64 lanes x 2.4 GHz / 4
-                                   # (tools/micro, profiles/r13_valu_issue_rates.txt: the rate of mixed integer streams)
-
-
-def measured_valu(reads, filtered, kernel_ms):
-    """The issue-bound view: VALU wave-instructions of one call (SQ_INSTS_VALU pass of tools/profile_r.sh,
-    reduced into profiles/hbm_traffic.json) over the live kernel time of THIS run."""
-    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not filtered or not os.path.exists(path):
-        return None
-    with open(path) as fh:
-        t = json.load(fh)
-    if "valu_wave_insts_per_launch" not in t:
-        return None
-    insts = t["valu_wave_insts_per_launch"] * reads / t["reads_per_launch"]
-    ach = insts * 64 / (kernel_ms * 1e-3) / 1e12
-    return {"wave_insts_per_launch": insts, "achieved": ach, "peak": VALU_PEAK_T, "unit": "T lane-ops/s",
-            "frac": ach / VALU_PEAK_T}
+        return json.load(fh)
 
 
 def usable_cores():
@@ -72,27 +57,276 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(workload, sample_reads):
-    """The oracle ("port" of the reference's Cython loop: same one-column DP with the
-    Ukkonen cut-off, -O2) timed on this box's host cores, all of them, on a bounded
-    sample of the same workload: the sample is aligned repeatedly until about 8 s of
-    wall time (so thread start-up does not dominate on a many-core host)."""
-    from oracle import oracle as O
-    cores = usable_cores()
-    lens = np.full(len(sample_reads), sample_reads.shape[1], np.int32)
-    args = (workload["max_error_rate"], 14, False, False, workload["min_overlap"], workload["indel_cost"], cores)
-    O.locate_many(workload["adapter"], sample_reads[:4096], lens[:4096], *args)
+def timed_cpu(fn, units, what, cores, target_s=8.0):
+    """Run fn() repeatedly for about target_s of wall time (after one untimed call)."""
+    fn()
     t0 = time.perf_counter()
-    O.locate_many(workload["adapter"], sample_reads, lens, *args)
+    fn()
     one = time.perf_counter() - t0
-    reps = int(max(1, min(200, 8.0 / max(one, 1e-3))))
+    reps = int(max(1, min(200, target_s / max(one, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        O.locate_many(workload["adapter"], sample_reads, lens, *args)
+        fn()
     dt = time.perf_counter() - t0
-    return {"value": reps * len(sample_reads) / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-            "sample": "first %d reads of the same C2 batch x %d passes, oracle/align_oracle.c on %d threads, "
-                      "%.1f s wall" % (len(sample_reads), reps, cores, dt)}
+    return {"value": reps * units / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "%s x %d passes on %d threads, %.1f s wall (oracle/align_oracle.c, the C restatement of the "
+                      "reference's Cython loop)" % (what, reps, cores, dt)}
+
+
+class C2(object):
+    name = "C2"
+    default_units = 10_000_000
+    unit_reads = 1
+    algo_bytes = 75 + 16               # ceil(150/2) packed-nibble bytes in + 16-byte result out (SURVEY 8d)
+    dtype = "int32"
+    metric = "reads/s (whole node) 150 bp SE adapter-align"
+
+    def __init__(self, args, rank, dev):
+        from atropos_amd import synth
+        from atropos_amd.align import Aligner
+        self.args, self.n = args, args.reads
+        self.w = w = synth.workload("C2", rank * self.n, self.n, device=dev)
+        self.al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+        self.ascii = w["reads"]
+        self.batch = self.al.pack(self.ascii)
+        self.sample = self.ascii[:min(self.n, 2_000_000)].cpu().numpy() if rank == 0 else None
+        self.filtered = not args.full_sweep
+        if not args.secondary:
+            self.ascii = None
+            del w["reads"]
+
+    def step(self, s):
+        self.res = self.al.locate_batch(self.batch, self.filtered)
+
+    def describe(self):
+        w = self.w
+        return {"workload": "C2: %d x 150 bp SE reads per GPU, TruSeq 34-mer 3' adapter, e=0.1, O=3, indel cost 1, "
+                            "4-bit packed reads resident in HBM" % self.n,
+                "reads_per_gpu": self.n, "read_len": 150, "adapter_len": len(w["adapter"]),
+                "matched_fraction": int(self.res.found().sum().item()) / self.n}
+
+    def kernel(self):
+        return ("filter_kernel + scan + scatter + band_kernel + window_kernel<36,eq,indel> (one atr_locate_batch call)"
+                if self.filtered else "locate_kernel<36,eq,indel>")
+
+    def note(self, kernel_ms):
+        return "integer-VALU bound, not HBM bound: %.2f G full-matrix cell-equivalents/s" % (
+            self.n * 150 * 34 / (kernel_ms * 1e-3) / 1e9)
+
+    def cpu_baseline(self):
+        from oracle import oracle as O
+        cores, w, sample = usable_cores(), self.w, self.sample
+        lens = np.full(len(sample), sample.shape[1], np.int32)
+        fn = lambda: O.locate_many(w["adapter"], sample, lens, w["max_error_rate"], 14, False, False, w["min_overlap"],
+                                   w["indel_cost"], cores)
+        return timed_cpu(fn, len(sample), "first %d reads of the same C2 batch" % len(sample), cores)
+
+    def secondary(self, kernel_ms):
+        """The other figures SURVEY 8(d) lists, measured outside the timed region."""
+        out = {"cell_updates_per_s_full_matrix": self.n * 150 * 35 / (kernel_ms * 1e-3)}
+
+        def run(fn, reps=5):
+            for _ in range(2):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+
+        if self.ascii is not None:
+            ms = run(lambda: self.al.locate_batch(self.al.pack(self.ascii), self.filtered))
+            out["pack_inclusive_reads_per_s"] = self.n / (ms * 1e-3)        # ASCII in HBM -> records
+            # ragged batch: the same reads cut to lengths 100..150 (what quality-trimmed data looks like)
+            from atropos_amd.batch import ReadBatch
+            g = torch.Generator(device=self.ascii.device).manual_seed(5)
+            lens = torch.randint(100, 151, (self.n,), generator=g, device=self.ascii.device, dtype=torch.int32)
+            rb = ReadBatch.from_ascii(self.ascii, lens, 150, self.al.table_kind, self.al._table)
+            ms = run(lambda: self.al.locate_batch(rb, self.filtered))
+            out["ragged_batch_reads_per_s"] = self.n / (ms * 1e-3)
+        out["pcie_inclusive_bound_reads_per_s"] = PCIE_GBS * 1e9 / (150 + 16)    # ASCII in + record out over PCIe Gen5 x16
+        return out
+
+
+class C3(object):
+    name = "C3"
+    default_units = 10_000_000
+    unit_reads = 2
+    read_len = 150
+    algo_bytes = 2 * 75 + 48           # two packed reads in + three 16-byte records out per pair
+    dtype = "u32 bit planes"
+    metric = "reads/s (whole node) 2x150 bp PE insert-align"
+    kw = {}
+    corrects = False
+
+    def __init__(self, args, rank, dev):
+        from atropos_amd import synth
+        from atropos_amd.align import InsertAligner
+        self.args, self.n = args, args.reads
+        self.ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, **self.kw)
+        self.nbatches = 1
+        p1, p2 = [], []
+        self.sample = None
+        chunk = 2_000_000
+        for lo in range(0, self.n, chunk):
+            w = synth.workload(self.name, rank * self.n + lo, min(chunk, self.n - lo), device=dev)
+            if self.sample is None and rank == 0:
+                k = 200_000
+                self.sample = (w["reads1"][:k].cpu().numpy(), w["reads2"][:k].cpu().numpy())
+            p1.append(w["reads1"])
+            p2.append(w["reads2"])
+        self.b1 = self.ia.pack(torch.cat(p1))
+        self.b2 = self.ia.pack(torch.cat(p2), check=True)
+
+    def step(self, s):
+        self.res = self.ia.match_insert_batch(self.b1, self.b2)
+
+    def describe(self):
+        return {"workload": "%s: %d pairs 2 x %d bp per GPU, insert aligner (overlap + adapter match)%s, plane64-packed "
+                            "reads resident in HBM" % (self.name, self.n, self.read_len,
+                                                       ", read wildcards" if self.kw else ""),
+                "pairs_per_gpu": self.n, "read_len": self.read_len,
+                "matched_fraction": float(self.res.found().float().mean().item())}
+
+    def kernel(self):
+        return "insert_kernel (one atr_insert_match_batch call)"
+
+    def note(self, kernel_ms):
+        L = self.read_len
+        return "integer-VALU bound: %.2f T diagonal cell-equivalents/s" % (self.n * L * (L + 1) / 2 / (kernel_ms * 1e-3) / 1e12)
+
+    def cpu_baseline(self):
+        from oracle import oracle as O
+        cores = usable_cores()
+        orc = O.InsertOracle(self.ia.adapter1, self.ia.adapter2, **self.kw)
+        r1, r2 = self.sample
+        lens = np.full(len(r1), r1.shape[1], np.int32)
+        fn = lambda: O.match_insert_many(orc, r1, lens, r2, lens, cores)
+        out = timed_cpu(fn, 2 * len(r1), "first %d pairs of the same %s batch (match_insert only)" % (len(r1), self.name), cores)
+        return out
+
+    def secondary(self, kernel_ms):
+        return {"pairs_per_s": self.n / (kernel_ms * 1e-3),
+                "pcie_inclusive_bound_reads_per_s": 2 * PCIE_GBS * 1e9 / (2 * self.read_len + 48)}
+
+
+class C5(C3):
+    """Insert aligner with read wildcards + liberal error correction of the overlap.  Correction is
+    in place and happens once per read pair, so every step gets its OWN sub-batch of the shard
+    (warmup + steps sub-batches of --reads pairs are generated and stay resident)."""
+    name = "C5"
+    default_units = 2_000_000
+    read_len = 250
+    algo_bytes = 2 * 125 + 48
+    metric = "reads/s (whole node) 2x250 bp PE insert-align + overlap error correction"
+    kw = dict(read_wildcards=True)
+    corrects = True
+
+    def __init__(self, args, rank, dev):
+        from atropos_amd import _lib, synth
+        from atropos_amd.align import InsertAligner
+        from atropos_amd.modifiers import COMP_TABLE
+        self.args, self.n = args, args.reads
+        self.ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, **self.kw)
+        self.be = _lib.get_backend()
+        self.comp = COMP_TABLE
+        self.nbatches = args.warmup + args.steps
+        self.batches = []
+        self.sample = None
+        for b in range(self.nbatches):
+            w = synth.workload("C5", (rank * self.nbatches + b) * self.n, self.n, device=dev)
+            if self.sample is None and rank == 0:
+                k = 100_000
+                self.sample = (w["reads1"][:k].cpu().numpy(), w["reads2"][:k].cpu().numpy())
+            self.batches.append(dict(b1=self.ia.pack(w["reads1"]), b2=self.ia.pack(w["reads2"], check=True),
+                                     s1=w["reads1"], s2=w["reads2"], q1=w["quals1"], q2=w["quals2"]))
+        self.changed = self.be.empty((self.n, 2), torch.int32)
+        self.newlen = self.be.empty((self.n, 2), torch.int32)
+        self.k = 0
+
+    def step(self, s):
+        d = self.batches[self.k]
+        self.k += 1
+        self.res = self.ia.match_insert_batch(d["b1"], d["b2"])
+        self.be.insert_correct_batch(self.res.records, d["s1"], d["q1"], None, d["s2"], d["q2"], None, 2, 1, self.comp,
+                                     self.changed, self.newlen)
+
+    def describe(self):
+        d = C3.describe(self)
+        d["workload"] = ("C5: %d pairs 2 x 250 bp per step and GPU (every step its own sub-batch of the 12.5 M-pair "
+                         "shard), insert aligner with read wildcards + liberal error correction of the overlap in "
+                         "place (ASCII bases + qualities resident in HBM)" % self.n)
+        d["corrected_pair_fraction"] = float(((self.changed[:, 0] > 0) | (self.changed[:, 1] > 0)).float().mean().item())
+        return d
+
+    def kernel(self):
+        return "insert_kernel + correct_kernel (atr_insert_match_batch + atr_insert_correct_batch)"
+
+
+class C4(object):
+    name = "C4"
+    default_units = 12_500_000
+    unit_reads = 1
+    algo_bytes = 75 + 16 + 16          # packed read in + 5' record + 3' record out
+    dtype = "int32"
+    metric = "reads/s (whole node) 150 bp SE, 4 linked adapters"
+
+    def __init__(self, args, rank, dev):
+        from atropos_amd import synth
+        from atropos_amd.adapters import AsciiSource, LinkedAdapter, LinkedSet, upper_ascii
+        self.args, self.n = args, args.reads
+        chunks = []
+        for lo in range(0, self.n, 2_500_000):
+            w = synth.workload("C4", rank * self.n + lo, min(2_500_000, self.n - lo), device=dev)
+            chunks.append(w["reads"])
+        self.w = w
+        reads = upper_ascii(torch.cat(chunks))
+        self.sample = reads[:min(self.n, 1_000_000)].cpu().numpy() if rank == 0 else None
+        linked = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=w["max_error_rate"],
+                                min_overlap=w["min_overlap"], indel_cost=w["indel_cost"])
+                  for f, b in zip(w["fronts"], w["backs"])]
+        self.lset = LinkedSet(linked)
+        if not self.lset.fused:
+            raise SystemExit("C4: the linked set is outside the fused pipeline's envelope")
+        self.batch = AsciiSource(reads).batch(self.lset.table_kind, self.lset.table)
+        del reads, chunks
+
+    def step(self, s):
+        be = self.lset._backend
+        self.res = be.linked_match_batch(self.lset._handle, self.batch.packed, self.batch.lens, self.batch.nreads,
+                                         self.batch.max_len)
+
+    def describe(self):
+        wc, front, back = self.res
+        return {"workload": "C4: %d x 150 bp SE reads per GPU (100 M / 8), four linked adapters (anchored 20-mer 5' part "
+                            "+ 33/34-mer 3' part), e=0.12, O=3, indel cost 1, 4-bit packed reads resident in HBM" % self.n,
+                "reads_per_gpu": self.n, "read_len": 150,
+                "front_matched_fraction": float((wc[:, 0] >= 0).float().mean().item()),
+                "back_matched_fraction": float((back[:, 1] >= 0).float().mean().item()),
+                "reads_with_two_fronts": int((wc[:, 1] > 1).sum().item())}
+
+    def kernel(self):
+        return ("linked_filter_kernel + scan + linked_scatter + 4 x (band_kernel + window_kernel<36>) "
+                "(one atr_linked_match_batch call)")
+
+    def note(self, kernel_ms):
+        return "integer-VALU bound: 4 anchored 5' sweeps + one 3' pre-pass per read in one kernel"
+
+    def cpu_baseline(self):
+        from oracle import oracle as O
+        cores, w, sample = usable_cores(), self.w, self.sample
+        lens = np.full(len(sample), sample.shape[1], np.int32)
+        fn = lambda: O.linked_many(w["fronts"], w["backs"], sample, lens, w["max_error_rate"], w["min_overlap"],
+                                   w["indel_cost"], True, False, cores)
+        return timed_cpu(fn, len(sample), "first %d reads of the same C4 batch" % len(sample), cores)
+
+    def secondary(self, kernel_ms):
+        return {"pcie_inclusive_bound_reads_per_s": PCIE_GBS * 1e9 / (150 + 34)}
+
+
+CONFIGS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
 
 def main():
@@ -100,11 +334,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU (C2: 10 M)")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--reads", type=int, default=None, help="reads (C2, C4) or pairs (C3, C5) per GPU and step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the pack-inclusive / ragged-batch side measurements (C2)")
     ap.add_argument("--full-sweep", action="store_true",
-                    help="time the unfiltered full-column DP kernel instead of the filtered pipeline")
+                    help="C2: time the unfiltered full-column DP kernel instead of the filtered pipeline")
     args = ap.parse_args()
+    cfg_cls = CONFIGS[args.config]
+    if args.reads is None:
+        args.reads = cfg_cls.default_units
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,16 +358,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from atropos_amd import _lib, synth
-    from atropos_amd.align import Aligner
+    from atropos_amd import _lib
     _lib.set_backend(_lib.HipBackend(local_rank))
-
-    # this rank's shard of the synthetic read set: reads [rank*R, (rank+1)*R)
-    w = synth.workload("C2", rank * args.reads, args.reads, device="cuda:%d" % local_rank)
-    al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
-    batch = al.pack(w["reads"])
-    sample = w["reads"][:min(args.reads, 2_000_000)].cpu().numpy() if rank == 0 else None
-    del w["reads"]
+    cfg = cfg_cls(args, rank, "cuda:%d" % local_rank)
     torch.cuda.synchronize()
 
     def barrier():
@@ -136,52 +369,63 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    filtered = not args.full_sweep
-    for _ in range(args.warmup):
-        res = al.locate_batch(batch, filtered)
+    for s in range(args.warmup):
+        cfg.step(s)
     # timed region: EXACTLY `steps` passes, bracketed by barrier + synchronize; the HIP events
-    # sit on the stream the kernel is launched on (torch's current stream)
+    # sit on the stream the kernels are launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
         ev[s][0].record()
-        res = al.locate_batch(batch, filtered)
+        cfg.step(args.warmup + s)
         ev[s][1].record()
     barrier()
     dt = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    n_found = int(res.found().sum().item())
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tall = torch.zeros((world,), dtype=torch.float64, device="cuda")
+    tall[rank] = dt
     if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt_max = float(tmax.item())
+        dist.all_reduce(tall, op=dist.ReduceOp.SUM)
+    per_rank = [float(x) for x in tall.tolist()]
+    dt_max = max(per_rank)
 
     if rank == 0:
-        total_reads = args.reads * world * args.steps
-        achieved = ALGO_BYTES_PER_READ * args.reads / (kernel_ms * 1e-3) / 1e9
+        units = args.reads * cfg.unit_reads                         # reads per step and GPU
+        achieved = cfg.algo_bytes * args.reads / (kernel_ms * 1e-3) / 1e9
+        prof = profile_counters(cfg.name) if not args.full_sweep else None
+        desc = cfg.describe()
+        desc["parallelism"] = "shard%d" % world
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS,
+                "frac_of_measured": achieved / HBM_MEASURED_GBS,
+                "traffic": None, "kernel": cfg.kernel(), "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_unit": cfg.algo_bytes, "note": cfg.note(kernel_ms)}
+        if prof:
+            scale = args.reads / prof["units_per_launch"]
+            roof["traffic"] = prof["hbm_bytes_per_launch"] * scale
+            roof["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 PMC passes of an earlier run, not this run)" % cfg.name
+            if prof.get("valu_wave_insts_per_launch"):
+                lane_ops = prof["valu_wave_insts_per_launch"] * scale * 64 / (kernel_ms * 1e-3) / 1e12
+                roof["valu"] = {"wave_insts_per_launch": prof["valu_wave_insts_per_launch"] * scale,
+                                "source": roof["traffic_source"], "achieved": lane_ops, "unit": "T lane-ops/s",
+                                "peak": VALU_NOMINAL_T, "frac": lane_ops / VALU_NOMINAL_T,
+                                "mixed_stream_model": VALU_MIXED_MODEL_T,
+                                "frac_of_mixed_stream_model": lane_ops / VALU_MIXED_MODEL_T,
+                                "model_note": "39.3 T = every VALU op of a mixed integer stream at 4 issue cycles; a "
+                                              "model of this instruction mix, not a hardware ceiling"}
         line = {
-            "metric": "reads/s (whole node) 150 bp SE adapter-align",
-            "value": total_reads / dt_max, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "C2: %d x 150 bp SE reads per GPU, TruSeq 34-mer 3' adapter, e=0.1, O=3, "
-                                   "indel cost 1, 4-bit packed reads resident in HBM" % args.reads,
-                       "reads_per_gpu": args.reads, "read_len": 150, "adapter_len": len(w["adapter"]),
-                       "parallelism": "shard%d" % world, "matched_fraction": n_found / args.reads},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(args.reads, filtered),
-                         "kernel": ("filter_kernel + scan + scatter + band_kernel + window_kernel<36,eq,indel> (one "
-                                    "atr_locate_batch call)" if filtered else "locate_kernel<36,eq,indel>"),
-                         "kernel_ms": kernel_ms,
-                         "algorithmic_bytes_per_read": ALGO_BYTES_PER_READ,
-                         "valu": measured_valu(args.reads, filtered, kernel_ms),
-                         "note": "integer-VALU bound, not HBM bound: %.2f G full-matrix cell-equivalents/s"
-                                 % (args.reads * 150 * 34 / (kernel_ms * 1e-3) / 1e9)},
+            "metric": cfg.metric, "value": units * world * args.steps / dt_max, "unit": "reads/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
+            "config": desc, "roofline": roof,
+            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         }
+        if args.secondary:
+            line["secondary"] = cfg.secondary(kernel_ms)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, sample)
+            line["cpu_baseline"] = cfg.cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -140,6 +140,57 @@ size_t atr_locate_work_bytes(int64_t nreads);
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                      int64_t nreads, int max_len, atr_result *d_out, void *d_work, void *stream);
 
+/* ---- linked adapters: LinkedAdapter.match_to under AdapterCutter._best_match ------------
+ * (atropos/adapters/__init__.py:648-690, atropos/commands/trim/modifiers.py:107-122) --------- */
+
+#define ATR_LINKED_MAX_ADAPTERS 4
+
+/* One `-a ^FRONT...BACK` adapter: Adapter(FRONT, PREFIX) and Adapter(BACK, BACK) with what
+ * Adapter.match_to wraps around each alignment (adapters/__init__.py:338-400).  The aligners
+ * carry sequence, max_error_rate, wildcard flags, min_overlap (Adapter sets aligner.min_overlap
+ * = min(min_overlap, len), :285, :313) and indel cost (:316-322).
+ *   *_exact_shortcut : the literal startswith / find shortcut is active (`not adapter_wildcards`,
+ *                      :351-367): a full-length zero-error occurrence bypasses the acceptance test;
+ *   d_*_rmp          : DEVICE table rmp[size * *_rmp_ld + matches] = match_probability(matches, size)
+ *                      with its bound *_max_rmp (:393-397), or NULL (max_rmp is None). */
+typedef struct {
+    const atr_aligner *front;      /* flags == ATR_STOP_WITHIN_SEQ2 (anchored 5') */
+    const atr_aligner *back;       /* flags == START_WITHIN_SEQ2 | STOP_WITHIN_SEQ1 | STOP_WITHIN_SEQ2 (regular 3') */
+    int front_exact_shortcut, back_exact_shortcut;
+    const double *d_front_rmp, *d_back_rmp;
+    int front_rmp_ld, back_rmp_ld;
+    double front_max_rmp, back_max_rmp;
+} atr_linked_adapter;
+
+typedef struct atr_linked_set atr_linked_set;
+
+/* Copies what it needs from the aligners (they may be destroyed afterwards; later setter calls on
+ * them are not seen) and uploads one parameter block to the current device.
+ * ATR_ERR_UNSUPPORTED: more than ATR_LINKED_MAX_ADAPTERS adapters; a 5' part with m + int(e*m) > 32
+ * or int(e*m) > 7; a 3' part outside the filtered pipeline (m > 64) or with START_WITHIN_SEQ1;
+ * int(e*m) >= m; aligners that need different translate tables; the literal shortcut together with
+ * a wildcard comparison (read wildcards on an ACGT-only adapter).  Callers then match the parts
+ * one by one (atr_locate_batch + atr_adapter_postfilter). */
+int atr_linked_create(const atr_linked_adapter *adapters, int n_adapters, atr_linked_set **out);
+void atr_linked_destroy(atr_linked_set *s);
+/* ATR_TABLE_* the reads must be packed with */
+int atr_linked_query_table(const atr_linked_set *s);
+
+/* For every read of a tile64 batch (whole reads, packed once): which linked adapter matches, its
+ * 5' match and its 3' match on read[front.rstop:].
+ *   d_which[2r]     = index of the first adapter whose 5' part matches, or -1 (LinkedAdapter.match_to
+ *                     returns None for every adapter);
+ *   d_which[2r + 1] = how many 5' parts match (with more than one the reference's _best_match raises
+ *                     AttributeError: LinkedMatch has no `matches`, modifiers.py:120);
+ *   d_front[r]      = front_match of that adapter as (astart, astop, rstart, rstop, matches, errors);
+ *   d_back[r]       = back_match, coordinates relative to read[front.rstop:] as in the reference
+ *                     (refstop == -1: None -- also when no 5' part matched).
+ * d_work: scratch of atr_linked_work_bytes() bytes; stream semantics as atr_locate_batch. */
+size_t atr_linked_work_bytes(const atr_linked_set *s, int64_t nreads);
+int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
+                           int max_len, int8_t *d_which, atr_result *d_front, atr_result *d_back, void *d_work,
+                           void *stream);
+
 /* ---- InsertAligner (atropos/align/__init__.py:178-377) -------------------- */
 
 #define ATR_INSERT_MAX_ADAPTER  64   /* adapter length handled by the insert kernel */
@@ -232,6 +283,15 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
                              const int16_t *d_insert, const uint8_t *d_mask, int64_t n, int max_len,
                              int action, int min_qual_difference, int truncate_seqs, const uint8_t comp[256],
                              int32_t *d_changed, int32_t *d_newlen, void *stream);
+
+/* The correction step of InsertAdapterCutter.__call__ right after the insert match
+ * (modifiers.py:397-404): d_insert_records are the 3 records per pair of atr_insert_match_batch;
+ * a pair is corrected (correct_errors(read1, read2, insert_match, truncate_seqs=True)) when its
+ * insert match exists and has errors > 0.  Other arguments as atr_correct_errors_batch. */
+int atr_insert_correct_batch(const atr_result *d_insert_records, uint8_t *d_seq1, uint8_t *d_qual1,
+                             const int32_t *d_lens1, uint8_t *d_seq2, uint8_t *d_qual2, const int32_t *d_lens2,
+                             int64_t stride, int64_t n, int max_len, int action, int min_qual_difference,
+                             const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream);
 
 /* ---- Aligner.locate with a per-pair reference (MergeOverlapping) ----------- */
 

@@ -20,7 +20,10 @@
  *   orc_multi_locate                  atropos/align/_align.pyx:593-783
  *   orc_reverse_complement            atropos/util/__init__.py:67-88,479-482
  *   orc_match_insert                  atropos/align/__init__.py:250-377
- *   orc_locate_many (threaded driver) -- bench harness only, no reference twin
+ *   orc_match_to                      atropos/adapters/__init__.py:338-400 (adapters with indels, no RMP filter)
+ *   orc_linked                        atropos/adapters/__init__.py:671-690 under
+ *                                     atropos/commands/trim/modifiers.py:107-122 (which adapter, both matches)
+ *   orc_locate_many / orc_linked_many / orc_match_insert_many (threaded drivers) -- harness only, no reference twin
  *
  * The DP keeps the reference's exact evaluation order: one column of
  * (cost, matches, origin) cells, Ukkonen's `last` cut-off, tie order
@@ -477,4 +480,161 @@ int orc_locate_many(const char *ref, int m, double e, int flags, int wc_ref, int
     if (nthreads > 1) for (int t = 0; t < nthreads; ++t) pthread_join(th[t], 0);
     free(th); free(jobs);
     return 0;
+}
+
+
+/* ---- Adapter.match_to (adapters/__init__.py:338-400), adapters with indels, max_rmp None ---- */
+
+/* seq: the adapter (upper case, as Adapter.__init__ stores it); flags: its `where`; min_overlap:
+ * already min(given, m) (:285); indel_cost: 100000 when the adapter was built with indels=False
+ * (:316-322; anchored no-indel adapters use compare_prefixes/suffixes instead and are NOT covered
+ * here); adapter_wildcards: after the ACGT-only override (:268-270).  The read is upper-cased
+ * first (:349).  Returns 1 and the Match fields (astart, astop, rstart, rstop, matches, errors), or
+ * 0 (None), or -2 (allocation failure). */
+int orc_match_to(const char *seq, int m, int flags, const char *read, int n, double e, int min_overlap,
+                 int indel_cost, int adapter_wildcards, int read_wildcards, int out[6]) {
+    char *up = (char *)malloc((size_t)n + 1);
+    if (!up) return -2;
+    for (int i = 0; i < n; ++i) up[i] = (read[i] >= 'a' && read[i] <= 'z') ? (char)(read[i] - 32) : read[i];
+    if (!adapter_wildcards) {                                         /* :351-367 */
+        int pos = -1;
+        if (flags == F_STOP_QRY) {                                    /* PREFIX: startswith */
+            if (n >= m && memcmp(up, seq, (size_t)m) == 0) pos = 0;
+        } else if (flags == F_START_QRY) {                            /* SUFFIX: endswith */
+            if (n >= m && memcmp(up + n - m, seq, (size_t)m) == 0) pos = n - m;
+        } else {
+            for (int i = 0; i + m <= n && pos < 0; ++i) if (memcmp(up + i, seq, (size_t)m) == 0) pos = i;
+        }
+        if (pos >= 0) {
+            out[0] = 0; out[1] = m; out[2] = pos; out[3] = pos + m; out[4] = m; out[5] = 0;
+            free(up);
+            return 1;
+        }
+    }
+    const int rc = orc_locate(seq, m, up, n, e, flags, adapter_wildcards, read_wildcards, min_overlap, indel_cost, out);
+    free(up);
+    if (rc != 1) return rc < 0 ? -2 : 0;
+    const int size = out[1] - out[0];                                 /* :386-398 */
+    if (size >= min_overlap && (double)out[5] / (double)size <= e) return 1;
+    return 0;
+}
+
+/* LinkedAdapter.match_to (:671-690) for every adapter of a set, as AdapterCutter._best_match walks
+ * them (modifiers.py:107-122): *which = the first adapter whose anchored 5' part matches (-1:
+ * none), *count = how many 5' parts match (> 1: the reference raises AttributeError), front /
+ * back = its two matches, back relative to read[front.rstop:]; back[1] == -1: None. */
+typedef struct {
+    int nad;
+    const char *const *fronts; const int *flens;
+    const char *const *backs; const int *blens;
+    double e; int min_overlap, indel_cost, read_wildcards;
+    const int *front_wildcards, *back_wildcards;                    /* adapter_wildcards per part */
+} orc_linked_params;
+
+int orc_linked(const orc_linked_params *p, const char *read, int n, int *which, int *count, int front[6], int back[6]) {
+    *which = -1; *count = 0;
+    front[0] = front[2] = front[3] = front[4] = front[5] = 0; front[1] = -1;
+    back[0] = back[2] = back[3] = back[4] = back[5] = 0; back[1] = -1;
+    for (int a = 0; a < p->nad; ++a) {
+        int f[6];
+        const int mo = imin(p->min_overlap, p->flens[a]);
+        const int rc = orc_match_to(p->fronts[a], p->flens[a], F_STOP_QRY, read, n, p->e, mo, p->indel_cost,
+                                    p->front_wildcards[a], p->read_wildcards, f);
+        if (rc < 0) return rc;
+        if (rc == 0) continue;                                        /* :672-673 */
+        ++*count;
+        if (*which >= 0) continue;
+        *which = a;
+        memcpy(front, f, sizeof(int) * 6);
+        const int rest = f[3];                                        /* read[front_match.rstop:]  (:683) */
+        int b[6];
+        const int rb = orc_match_to(p->backs[a], p->blens[a], F_START_QRY | F_STOP_REF | F_STOP_QRY, read + rest, n - rest,
+                                    p->e, imin(p->min_overlap, p->blens[a]), p->indel_cost, p->back_wildcards[a],
+                                    p->read_wildcards, b);
+        if (rb < 0) return rb;
+        if (rb == 1) memcpy(back, b, sizeof(int) * 6);
+    }
+    return 0;
+}
+
+typedef struct {
+    const orc_linked_params *p; const char *reads; const int *lens; int64_t stride, lo, hi;
+    signed char *which; int *front, *back;
+} ljob_t;
+
+static void *ljob_main(void *arg) {
+    ljob_t *jb = (ljob_t *)arg;
+    for (int64_t r = jb->lo; r < jb->hi; ++r) {
+        int w, c;
+        if (orc_linked(jb->p, jb->reads + r * jb->stride, jb->lens[r], &w, &c, jb->front + 6 * r, jb->back + 6 * r) != 0)
+            return (void *)1;
+        jb->which[2 * r] = (signed char)w;
+        jb->which[2 * r + 1] = (signed char)c;
+    }
+    return 0;
+}
+
+int orc_linked_many(const orc_linked_params *p, const char *reads, const int *lens, int64_t stride, int64_t nreads,
+                    signed char *which, int *front, int *back, int nthreads) {
+    tables_init();
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    ljob_t *jobs = (ljob_t *)malloc(sizeof(ljob_t) * nthreads);
+    if (!th || !jobs) { free(th); free(jobs); return -1; }
+    const int64_t per = (nreads + nthreads - 1) / nthreads;
+    int bad = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        ljob_t *jb = &jobs[t];
+        jb->p = p; jb->reads = reads; jb->lens = lens; jb->stride = stride; jb->which = which; jb->front = front; jb->back = back;
+        jb->lo = per * t < nreads ? per * t : nreads;
+        jb->hi = per * (t + 1) < nreads ? per * (t + 1) : nreads;
+        if (nthreads == 1) bad |= ljob_main(jb) != 0;
+        else pthread_create(&th[t], 0, ljob_main, jb);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; ++t) { void *rv = 0; pthread_join(th[t], &rv); bad |= rv != 0; }
+    free(th); free(jobs);
+    return bad ? -1 : 0;
+}
+
+/* ---- threaded driver of orc_match_insert: out = npairs x 18 ints (insert tuple, Match 1, Match 2;
+ * [1] == -1 of a block: None) */
+typedef struct {
+    const orc_insert_params *p; const char *r1, *r2; const int *l1, *l2; int64_t stride, lo, hi; int *out;
+} ijob_t;
+
+static void *ijob_main(void *arg) {
+    ijob_t *jb = (ijob_t *)arg;
+    for (int64_t r = jb->lo; r < jb->hi; ++r) {
+        int *o = jb->out + 18 * r, has[2];
+        memset(o, 0, sizeof(int) * 18);
+        const int rc = orc_match_insert(jb->p, jb->r1 + r * jb->stride, jb->l1[r], jb->r2 + r * jb->stride, jb->l2[r],
+                                        o, o + 6, o + 12, has);
+        if (rc < 0) return (void *)1;
+        if (rc == 0) o[1] = -1;
+        if (rc == 0 || !has[0]) { memset(o + 6, 0, sizeof(int) * 6); o[7] = -1; }
+        if (rc == 0 || !has[1]) { memset(o + 12, 0, sizeof(int) * 6); o[13] = -1; }
+    }
+    return 0;
+}
+
+int orc_match_insert_many(const orc_insert_params *p, const char *reads1, const int *lens1, const char *reads2,
+                          const int *lens2, int64_t stride, int64_t npairs, int *out, int nthreads) {
+    tables_init();
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    ijob_t *jobs = (ijob_t *)malloc(sizeof(ijob_t) * nthreads);
+    if (!th || !jobs) { free(th); free(jobs); return -1; }
+    const int64_t per = (npairs + nthreads - 1) / nthreads;
+    int bad = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        ijob_t *jb = &jobs[t];
+        jb->p = p; jb->r1 = reads1; jb->r2 = reads2; jb->l1 = lens1; jb->l2 = lens2; jb->stride = stride; jb->out = out;
+        jb->lo = per * t < npairs ? per * t : npairs;
+        jb->hi = per * (t + 1) < npairs ? per * (t + 1) : npairs;
+        if (nthreads == 1) bad |= ijob_main(jb) != 0;
+        else pthread_create(&th[t], 0, ijob_main, jb);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; ++t) { void *rv = 0; pthread_join(th[t], &rv); bad |= rv != 0; }
+    free(th); free(jobs);
+    return bad ? -1 : 0;
 }

@@ -5,6 +5,7 @@ and ``bench.py``'s ``cpu_baseline`` leg; never from ``atropos_amd``.  Parity
 status: pinned against the reference (see align_oracle.c header).
 
 The Python-level pieces restated here (reference file:line):
+  match_to / linked_many   atropos/adapters/__init__.py:338-400, :671-690 (in align_oracle.c)
   rmp()            atropos/util/__init__.py:117-155 (RandomMatchProbability)
   InsertOracle     atropos/align/__init__.py:206-233 (constructor defaults)
 """
@@ -66,6 +67,15 @@ def lib():
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
                                       C.c_void_p, C.c_int]
         L.orc_locate_many.restype = C.c_int
+        L.orc_match_to.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, I6]
+        L.orc_match_to.restype = C.c_int
+        L.orc_linked_many.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int]
+        L.orc_linked_many.restype = C.c_int
+        L.orc_match_insert_many.argtypes = [C.POINTER(_InsertParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int64, C.c_int64, C.c_void_p, C.c_int]
+        L.orc_match_insert_many.restype = C.c_int
         L.orc_acgt_table.argtypes = [C.c_char_p]
         L.orc_iupac_table.argtypes = [C.c_char_p]
         _lib = L
@@ -251,4 +261,73 @@ def locate_many(ref, reads, lens, e, flags, wildcard_ref=False, wildcard_query=F
                                reads.shape[0], out.ctypes.data, nthreads)
     if rc != 0:
         raise MemoryError
+    return out
+
+
+def match_to(seq, flags, read, e, min_overlap=3, indel_cost=1, adapter_wildcards=True, read_wildcards=False):
+    """Adapter(seq, flags, e, min_overlap, read_wildcards, adapter_wildcards, indel_cost=...).match_to(read)
+    for an adapter with indels and no RMP filter -> (astart, astop, rstart, rstop, matches, errors) or
+    None.  The constructor's overrides are applied here: ACGT-only adapters have no wildcards
+    (adapters/__init__.py:268-270), min_overlap is capped at the adapter length (:285)."""
+    s, r = _b(seq), _b(read)
+    aw = bool(adapter_wildcards) and not set(seq) <= set("ACGT")
+    out = (C.c_int * 6)()
+    rc = lib().orc_match_to(s, len(s), flags, r, len(r), e, min(min_overlap, len(s)), indel_cost, int(aw),
+                            int(read_wildcards), out)
+    if rc < 0:
+        raise MemoryError
+    return tuple(out) if rc else None
+
+
+class _LinkedParams(C.Structure):
+    _fields_ = [("nad", C.c_int), ("fronts", C.POINTER(C.c_char_p)), ("flens", C.POINTER(C.c_int)),
+                ("backs", C.POINTER(C.c_char_p)), ("blens", C.POINTER(C.c_int)), ("e", C.c_double),
+                ("min_overlap", C.c_int), ("indel_cost", C.c_int), ("read_wildcards", C.c_int),
+                ("front_wildcards", C.POINTER(C.c_int)), ("back_wildcards", C.POINTER(C.c_int))]
+
+
+def linked_many(fronts, backs, reads, lens, e, min_overlap=3, indel_cost=1, adapter_wildcards=True,
+                read_wildcards=False, nthreads=1):
+    """AdapterCutter._best_match over LinkedAdapter(front, back).match_to for a batch (reads: uint8
+    numpy [n, stride] ASCII, lens int32 [n]).  Returns (which int8 [n, 2] = (first matching adapter
+    or -1, number of matching 5' parts), front int32 [n, 6], back int32 [n, 6]; [:, 1] == -1: None)."""
+    import numpy as np
+    reads = np.ascontiguousarray(reads, dtype=np.uint8)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    n = reads.shape[0]
+    nad = len(fronts)
+    fb, bb = [_b(x) for x in fronts], [_b(x) for x in backs]
+    p = _LinkedParams()
+    p.nad = nad
+    p.fronts = (C.c_char_p * nad)(*fb)
+    p.backs = (C.c_char_p * nad)(*bb)
+    p.flens = (C.c_int * nad)(*[len(x) for x in fb])
+    p.blens = (C.c_int * nad)(*[len(x) for x in bb])
+    p.e, p.min_overlap, p.indel_cost, p.read_wildcards = e, min_overlap, indel_cost, int(read_wildcards)
+    p.front_wildcards = (C.c_int * nad)(*[int(bool(adapter_wildcards) and not set(x) <= set("ACGT")) for x in fronts])
+    p.back_wildcards = (C.c_int * nad)(*[int(bool(adapter_wildcards) and not set(x) <= set("ACGT")) for x in backs])
+    which = np.empty((n, 2), dtype=np.int8)
+    front = np.empty((n, 6), dtype=np.int32)
+    back = np.empty((n, 6), dtype=np.int32)
+    rc = lib().orc_linked_many(C.addressof(p), reads.ctypes.data, lens.ctypes.data, reads.shape[1], n,
+                               which.ctypes.data, front.ctypes.data, back.ctypes.data, nthreads)
+    if rc != 0:
+        raise MemoryError
+    return which, front, back
+
+
+def match_insert_many(orc, reads1, lens1, reads2, lens2, nthreads=1):
+    """InsertOracle.match_insert for a batch of equal-stride uint8 matrices; int32 [n, 3, 6] with
+    [:, t, 1] == -1 for None (t = 0 insert match, 1 / 2 the adapter matches)."""
+    import numpy as np
+    reads1 = np.ascontiguousarray(reads1, dtype=np.uint8)
+    reads2 = np.ascontiguousarray(reads2, dtype=np.uint8)
+    assert reads1.shape == reads2.shape
+    lens1 = np.ascontiguousarray(lens1, dtype=np.int32)
+    lens2 = np.ascontiguousarray(lens2, dtype=np.int32)
+    out = np.empty((reads1.shape[0], 3, 6), dtype=np.int32)
+    rc = lib().orc_match_insert_many(C.byref(orc._p), reads1.ctypes.data, lens1.ctypes.data, reads2.ctypes.data,
+                                     lens2.ctypes.data, reads1.shape[1], reads1.shape[0], out.ctypes.data, nthreads)
+    if rc != 0:
+        raise KeyError("base without complement (or allocation failure)")
     return out

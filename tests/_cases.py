@@ -418,6 +418,125 @@ def check_linked_c4():
     return len(reads)
 
 
+# ---------------------------------------------------------------------------------------------
+# fused linked-adapter pipeline (atr_linked_match_batch) against the oracle
+def oracle_match_to(oracle, seq, flags, read, e, min_overlap, indel_cost, adapter_wildcards, read_wildcards):
+    """Adapter.match_to (reference adapters/__init__.py:338-400) restated on top of the oracle's
+    locate, for adapters WITH indels and no RMP filter: upper-case, literal shortcut unless the
+    adapter has wildcards, alignment, acceptance test.  Returns the 6-tuple or None."""
+    read = read.upper()
+    m = len(seq)
+    if not adapter_wildcards:
+        pos = (0 if read.startswith(seq) else -1) if flags == 8 else read.find(seq)
+        if pos >= 0:
+            return (0, m, pos, pos + m, m, 0)
+    al = oracle.locate(seq, read, e, flags, adapter_wildcards, read_wildcards, min(min_overlap, m), indel_cost)
+    if al is None:
+        return None
+    size = al[1] - al[0]
+    return al if (size >= min(min_overlap, m) and al[5] / size <= e) else None
+
+
+def oracle_linked(oracle, fronts, backs, read, kw):
+    """AdapterCutter._best_match over LinkedAdapter.match_to for one read: (which, count, front, back)."""
+    which, count, fm, bm = -1, 0, None, None
+    for a, (fs, bs) in enumerate(zip(fronts, backs)):
+        aw_f, aw_b = kw["adapter_wildcards"] and not set(fs) <= set("ACGT"), kw["adapter_wildcards"] and not set(bs) <= set("ACGT")
+        f = oracle_match_to(oracle, fs, 8, read, kw["e"], kw["min_overlap"], kw["indel_cost"], aw_f, kw["read_wildcards"])
+        if f is None:
+            continue
+        count += 1
+        if which < 0:
+            which, fm = a, f
+            bm = oracle_match_to(oracle, bs, 14, read[f[3]:], kw["e"], kw["min_overlap"], kw["indel_cost"], aw_b,
+                                 kw["read_wildcards"])
+    return which, count, fm, bm
+
+
+def check_linked_sets_against_oracle(oracle, seed, rounds, reads_per_round=(1, 64, 65, 200)):
+    """Random sets of 1..4 linked adapters (5' parts of 6..26 bases, 3' parts of 8..64: the one-word,
+    NARROW and two-word forms of the pre-pass), error rates, indel costs, wildcard modes, ragged and
+    equal-length batches; reads carry the 5' adapter (exact, mutated, shifted, absent, or TWO
+    adapters' worth) and the matching, a wrong or no 3' adapter.  Every read's (which, count, front,
+    back) through the fused pipeline must equal the reference's rule restated on the oracle."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib
+    from atropos_amd.adapters import LinkedAdapter, LinkedSet, AsciiSource, upper_ascii
+    be = _lib.get_backend()
+    rng = random.Random(seed)
+    total = fused_sets = 0
+    for it in range(rounds):
+        na = rng.randint(1, 4)
+        e = rng.choice([0.05, 0.1, 0.12, 0.2, 0.3])
+        with_n = rng.random() < 0.2                  # every adapter of the set holds an N, or none does -- mostly
+        alpha_f = "ACGTN" if with_n else "ACGT"
+        def force_n(x):
+            if not with_n or "N" in x or rng.random() < 0.1:
+                return x
+            p = rng.randrange(len(x))
+            return x[:p] + "N" + x[p + 1:]
+        kw = dict(e=e, min_overlap=rng.choice([1, 3, 5]), indel_cost=rng.choice([1, 1, 1, 2, 3]),
+                  adapter_wildcards=True, read_wildcards=rng.random() < 0.2)
+        same_len = rng.random() < 0.6
+        top = 26 if rng.random() < 0.15 else min(26, int(31 / (1 + e)), int(7.9 / e))      # mostly inside the fused envelope
+        fl = rng.randint(6, top)
+        fronts = [force_n(rseq(rng, fl if same_len else rng.randint(6, top), alpha_f)) for _ in range(na)]
+        style = rng.choice(["short", "narrow", "wide", "mixed"])
+        def blen():
+            return {"short": rng.randint(8, 32), "narrow": rng.randint(33, 40), "wide": rng.randint(41, 64),
+                    "mixed": rng.randint(8, 64)}[style]
+        backs = [force_n(rseq(rng, blen(), alpha_f)) for _ in range(na)]
+        if kw["read_wildcards"] and any(set(x) <= set("ACGT") for x in fronts + backs):
+            # ACGT-only adapter + read wildcards: literal shortcut on a wildcard compare -> not fused; keep a few
+            if rng.random() < 0.7:
+                kw["read_wildcards"] = False
+        las = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=e, min_overlap=kw["min_overlap"],
+                             indel_cost=kw["indel_cost"], read_wildcards=kw["read_wildcards"]) for f, b in zip(fronts, backs)]
+        lset = LinkedSet(las)
+        fused_sets += int(lset.fused)
+        n = rng.randint(30, 170)
+        fixed = rng.random() < 0.5
+        reads = []
+        for _ in range(rng.choice(reads_per_round)):
+            a = rng.randrange(na)
+            w = rng.random()
+            head = (fronts[a] if w < 0.35 else mutate(rng, fronts[a], rng.choice([0.03, 0.08, 0.15])) if w < 0.7 else
+                    rseq(rng, rng.randint(0, 3)) + fronts[a] if w < 0.75 else
+                    fronts[a] + fronts[(a + 1) % na] if w < 0.8 else "")
+            head = head.replace("N", "A")
+            frag = rseq(rng, rng.randint(0, n), "ACGT" if rng.random() < 0.9 else "ACGTN")
+            b = backs[a if rng.random() < 0.85 else rng.randrange(na)].replace("N", "C")
+            v = rng.random()
+            tail = (b if v < 0.3 else mutate(rng, b, rng.choice([0.03, 0.08, 0.15])) if v < 0.6 else
+                    b[:rng.randint(1, len(b))] if v < 0.8 else "")
+            q = head + frag + tail + (rseq(rng, rng.randint(0, 20)) if rng.random() < 0.5 else "")
+            if fixed:
+                q = (q + rseq(rng, n))[:n]
+            q = q[:rng.choice([n, n, len(head) + rng.randint(0, 3)])] if not fixed and rng.random() < 0.1 else q[:n + 40]
+            if rng.random() < 0.1:
+                q = q.lower()
+            reads.append(q if q else "A")
+        width = max(len(r) for r in reads)
+        mat = np.zeros((len(reads), width), dtype=np.uint8)
+        for i, r in enumerate(reads):
+            mat[i, :len(r)] = np.frombuffer(r.encode(), dtype=np.uint8)
+        a_t = upper_ascii(torch.from_numpy(mat).to(be.device))
+        ragged = not (fixed and all(len(r) == len(reads[0]) for r in reads))
+        l_t = torch.tensor([len(r) for r in reads], dtype=torch.int32, device=be.device) if ragged else None
+        which, count, front, back = lset.match_source(AsciiSource(a_t, l_t))
+        which, count = which.cpu().numpy(), count.cpu().numpy()
+        front, back = front.cpu().numpy(), back.cpu().numpy()
+        for i, q in enumerate(reads):
+            ew, ec, ef, eb = oracle_linked(oracle, fronts, backs, q, kw)
+            gf = None if front[i, 1] < 0 else tuple(int(v) for v in front[i, :6])
+            gb = None if back[i, 1] < 0 else tuple(int(v) for v in back[i, :6])
+            assert (int(which[i]), int(count[i]), gf, gb) == (ew, ec, ef, eb), (
+                fronts, backs, kw, q, lset.fused, (int(which[i]), int(count[i]), gf, gb), (ew, ec, ef, eb))
+            total += 1
+    return total, fused_sets
+
+
 def check_device_resident_adapters():
     """The device-resident twins (match_records, LinkedAdapter.match_records,
     best_adapter_records) against the object-level batch path, which is itself pinned to the

@@ -16,7 +16,7 @@ _CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "e
 _SRCS = _CPPS + [
     os.path.join(_ROOT, "atropos_amd", "csrc", f)
     for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp",
-              "filter_core.hpp", "fastq_core.hpp", "pairs_core.hpp")] + [
+              "filter_core.hpp", "fastq_core.hpp", "pairs_core.hpp", "linked_core.hpp", "linked_host.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -40,8 +40,8 @@ def _check(rc, what):
         raise ValueError("%s: invalid argument" % what)
     if rc == -4:
         raise MemoryError(what)
-    from atropos_amd._lib import AtroposHipError
-    raise AtroposHipError("%s: error %d" % (what, rc))
+    from atropos_amd._lib import AtroposHipError, AtroposUnsupported, ERRORS
+    raise (AtroposUnsupported if rc == -2 else AtroposHipError)("%s: %s" % (what, ERRORS.get(rc, "error %d" % rc)))
 
 
 class EmuBackend(object):
@@ -195,6 +195,30 @@ class EmuBackend(object):
             _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), int(filtered)),
                    "atr_locate_batch")
         return out
+
+    def linked_create(self, specs):
+        from atropos_amd._lib import LinkedAdapterSpec
+        arr = (LinkedAdapterSpec * len(specs))(*specs)
+        h = C.c_void_p()
+        self.lib.emu_linked_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        _check(self.lib.emu_linked_create(C.addressof(arr), len(specs), C.byref(h)), "atr_linked_create")
+        return h
+
+    def linked_destroy(self, h):
+        self.lib.emu_linked_destroy.argtypes = [C.c_void_p]
+        self.lib.emu_linked_destroy.restype = None
+        self.lib.emu_linked_destroy(h)
+
+    def linked_match_batch(self, h, packed, lens, nreads, max_len):
+        which = torch.zeros((nreads, 2), dtype=torch.int8)
+        front = torch.zeros((nreads, 8), dtype=torch.int16)
+        back = torch.zeros((nreads, 8), dtype=torch.int16)
+        if nreads:
+            self.lib.emu_linked_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                                        C.c_void_p, C.c_void_p]
+            _check(self.lib.emu_linked_match_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(which), _ptr(front),
+                                                   _ptr(back)), "atr_linked_match_batch")
+        return which, front, back
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                            query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):

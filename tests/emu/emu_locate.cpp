@@ -12,6 +12,7 @@
 
 #include "aligner_host.hpp"
 #include "filter_core.hpp"
+#include "linked_host.hpp"
 
 using namespace atr;
 
@@ -75,9 +76,19 @@ static uint32_t read_code(const uint32_t *packed, int nchunks, long long r, int 
     return (packed[(((size_t)tile * nchunks + c) * 64 + lane) * 4 + d] >> (4 * b)) & 15u;
 }
 
+// What the LINKED variants of the band / window kernels get on top (locate_fast.hpp, LinkedArgs)
+struct EmuLinked {
+    const uint32_t *front;                                         // 5' records, 4 dwords per read
+    const LinkedPost *post;
+};
+
+// K2..K4 of the filtered pipeline for ONE aligner: `bins` = the FILTER_BINS scatter bins holding the
+// unresolved reads (K2 + K3 as a stable bucket order), K4a / K4 in waves of 64 gathered reads,
+// lock-step like the GPU wave.  la != nullptr: the 3' part of one adapter of a linked set.
 template <int MT, bool NOINDEL>
-void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, long long nreads, int nchunks,
-              int max_len, uint32_t *out) {
+void emu_dp_stage(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, int nchunks, int max_len,
+                  uint32_t *out, const std::vector<uint32_t> &win, const std::vector<std::vector<uint32_t>> &bins,
+                  const EmuLinked *la) {
     const LocateParams &p = a->p;
     const Uniform u = make_uniform(p, MT);
     int16_t s_thr[ATR_MAX_REF_LEN + 2];
@@ -86,26 +97,12 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         if (i <= u.m + 1) s_thr[i] = p.thr[i];
         if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
     }
-    std::vector<uint32_t> win((size_t)nreads);
-    std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
-    for (long long r = 0; r < nreads; ++r) {                       // K1
-        const int n = lens ? lens[r] : max_len;
-        FilterState F;
-        filter_init(F, u, fp.rows);
-        for (int j = 1; j <= n; ++j) {
-            const uint64_t eq = fp.peq[read_code(packed, nchunks, r, j)];
-            if (fp.rows > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
-            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
-            if ((j & 31) == 0 || j == n) filter_fold(F, j);        // as the kernel: once per 32-column chunk
-        }
-        uint32_t rec[4];
-        const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
-        const uint32_t ww = fp.rows > 32 ? filter_decide<true>(F, u, fp, q, nchunks, n, rec) : filter_decide<false>(F, u, fp, q, nchunks, n, rec);
-        win[r] = ww;
-        if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
-        else bins[window_bin(ww, u.m, lens == nullptr)].push_back((uint32_t)r);
-    }
+    auto finish = [&](long long r) {
+        if (!la) return;
+        const LinkedPost &q = *la->post;
+        linked_finish(out + 4 * r, (int)(la->front[4 * r + 1] >> 16), q.m, q.min_overlap, q.pf_thr, q.accept_full != 0,
+                      q.rmp, q.rmp_ld, q.max_rmp);
+    };
     std::vector<uint32_t> order;                                   // K2 + K3
     for (auto &b : bins) order.insert(order.end(), b.begin(), b.end());
     const long long total = (long long)order.size();
@@ -130,6 +127,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
                 band_stage(q, nchunks, window_lo(win[r]), ns, 1);
                 if (and_mode) band_locate<true>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
                 else band_locate<false>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
+                finish(r);
             }
         }
     }
@@ -137,10 +135,11 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
     long long rows_bin0 = 0;                                       // binbase[ROWS_BIN0]
     for (int b = 0; b < ROWS_BIN0; ++b) rows_bin0 += (long long)bins[b].size();
     for (long long base = nband; base < total; base += 64) {       // K4, one wave at a time
-        int jlo = 0x7fffffff, jhi = 0, rows = 0;
+        int jlo = 0x7fffffff, jhi = 0, rows = 0, s_top = 0;
         long long rr[64];
         bool live[64];
         uint32_t wws[64];
+        int s_lane[64];
         for (int lane = 0; lane < 64; ++lane) {
             live[lane] = base + lane < total;
             rr[lane] = live[lane] ? order[base + lane] : 0;
@@ -149,6 +148,8 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
             jlo = std::min(jlo, live[lane] ? lo : 0x7fffffff);
             jhi = std::max(jhi, (live[lane] && hi > lo) ? hi : 0);
             rows = std::max(rows, live[lane] ? window_rows(wws[lane]) : 0);
+            s_lane[lane] = (la && live[lane]) ? (int)(la->front[4 * rr[lane] + 1] >> 16) : 0;
+            s_top = std::max(s_top, s_lane[lane]);
         }
         for (int lane = 0; lane < 64; ++lane) {
             const int n = live[lane] ? (lens ? lens[rr[lane]] : max_len) : 0;
@@ -168,10 +169,40 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
                 int pl = head ? std::min(plimit, u.p0 + (j - jlo) + u.k) : plimit;
                 if (tri) pl = std::min(pl, u.p0 + triangle_rows(rows, max_len, j, u.k));
                 lane_step<MT, NOINDEL, true, true>(L[lane], u, j, nm, s_thr, pl);
+                if (la && j <= s_top && s_lane[lane] == j) lane_restart_window<MT>(L[lane], u, j);
             }
         for (int lane = 0; lane < 64; ++lane)
-            if (live[lane]) lane_result<MT>(L[lane], u, out + 4 * rr[lane]);
+            if (live[lane]) { lane_result<MT>(L[lane], u, out + 4 * rr[lane]); finish(rr[lane]); }
     }
+}
+
+// The filtered pipeline (locate_fast.hpp): K1 per read, then emu_dp_stage.
+template <int MT, bool NOINDEL>
+void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, long long nreads, int nchunks,
+              int max_len, uint32_t *out) {
+    const LocateParams &p = a->p;
+    const Uniform u = make_uniform(p, MT);
+    std::vector<uint32_t> win((size_t)nreads);
+    std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    for (long long r = 0; r < nreads; ++r) {                       // K1
+        const int n = lens ? lens[r] : max_len;
+        FilterState F;
+        filter_init(F, u, fp.rows);
+        for (int j = 1; j <= n; ++j) {
+            const uint64_t eq = fp.peq[read_code(packed, nchunks, r, j)];
+            if (fp.rows > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
+            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
+            if ((j & 31) == 0 || j == n) filter_fold(F, j);        // as the kernel: once per 32-column chunk
+        }
+        uint32_t rec[4];
+        const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
+        const uint32_t ww = fp.rows > 32 ? filter_decide<true>(F, u, fp, q, nchunks, n, rec) : filter_decide<false>(F, u, fp, q, nchunks, n, rec);
+        win[r] = ww;
+        if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
+        else bins[window_bin(ww, u.m, lens == nullptr)].push_back((uint32_t)r);
+    }
+    emu_dp_stage<MT, NOINDEL>(a, packed, lens, nchunks, max_len, out, win, bins, nullptr);
 }
 
 typedef void (*emu_fn)(const atr_aligner *, const uint32_t *, const int32_t *, long long, int, int, uint32_t *);
@@ -246,6 +277,141 @@ int emu_pack_planes(const uint8_t *ascii, int64_t row_stride, const int32_t *len
                 pack_planes_chunk(row, c * 32, n, spread, zero_seen, dst + (((size_t)tile * nchunks + c) * 64 + lane) * 4);
             if (invalid && zero_seen) *invalid += 1;
         }
+    return ATR_OK;
+}
+
+}  // extern "C"
+
+typedef void (*emu_dp_fn)(const atr_aligner *, const uint32_t *, const int32_t *, int, int, uint32_t *,
+                          const std::vector<uint32_t> &, const std::vector<std::vector<uint32_t>> &, const EmuLinked *);
+template <int... I>
+static emu_dp_fn pick_dp(int idx, bool noindel, std::integer_sequence<int, I...>) {
+    emu_dp_fn yes[] = {&emu_dp_stage<(I + 1) * ROW_GRAN, true>...};
+    emu_dp_fn no[] = {&emu_dp_stage<(I + 1) * ROW_GRAN, false>...};
+    return noindel ? yes[idx] : no[idx];
+}
+
+extern "C" {
+int emu_linked_create(const atr_linked_adapter *adapters, int n, atr_linked_set **out) {
+    if (!out) return ATR_ERR_INVALID;
+    *out = nullptr;
+    atr_linked_set *s = new atr_linked_set();
+    const int rc = linked_fill(s, adapters, n);
+    if (rc != ATR_OK) { delete s; return rc; }
+    *out = s;
+    return ATR_OK;
+}
+void emu_linked_destroy(atr_linked_set *s) { delete s; }
+int emu_linked_query_table(const atr_linked_set *s) { return s ? s->table_kind : ATR_ERR_INVALID; }
+}  // extern "C"
+
+// atr_linked_match_batch (linked_kernels.hip), read by read with the kernels' per-lane functions
+template <bool WIDE, bool AND_MODE>
+static void emu_linked_l1(const atr_linked_set *s, const uint32_t *pk, const int32_t *lens, long long nreads, int nchunks,
+                          int max_len, int8_t *which_out, uint32_t *front, uint32_t *back, std::vector<uint32_t> &win,
+                          std::vector<std::vector<std::vector<uint32_t>>> &bins) {
+    const LinkedParams &P = s->p;
+    for (long long r = 0; r < nreads; ++r) {
+        const int n = lens ? lens[r] : max_len;
+        const uint32_t *q = pk + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
+        const uint32_t w0[4] = {q[0], q[1], q[2], q[3]};
+        int which = -1, count = 0;
+        uint32_t frec[4];
+        rec_none(frec);
+        uint32_t dpmask = 0;
+        for (int a = 0; a < P.n; ++a) {
+            const FrontParams &fp = P.f[a];
+            FrontState st;
+            front_init(st, fp.m);
+            for (int j = 1; j <= fp.m + fp.k; ++j) front_step(st, fp.peq[chunk_code(w0, j)], fp.m);
+            const bool exact = fp.accept_full != 0 && front_exact(fp.code, fp.code_mask, w0);
+            if (exact) {
+                ++count;
+                if (which < 0) { which = a; front_exact_record(frec, fp.m); }
+            } else if (st.best <= fp.k) {
+                dpmask |= 1u << a;
+            }
+        }
+        for (int a = 0; a < P.n; ++a) {
+            if (!(dpmask & (1u << a))) continue;
+            const FrontParams &mp = P.f[a], &gp = P.f[P.group_first[mp.group]];
+            const Uniform u = front_uniform(gp.m, gp.k, gp.indel, gp.min_overlap);
+            uint32_t ns[BAND_STREAM], rec[4];
+            band_stage(q, nchunks, -u.k, ns, 1);
+            const uint32_t *rr = mp.rrep;
+            band_locate_prefix_rr<AND_MODE>(u, [rr](int i) { return rr[i - 1]; }, gp.noindel != 0, ns, 1, n, gp.thr, rec);
+            if (front_accept(rec, u.m, u.min_overlap, mp.pf_thr, mp.accept_full != 0, s->rmp.front[a], s->rmp.front_ld[a], s->rmp.front_max[a])) {
+                ++count;
+                if (which < 0 || a < which) { which = a; memcpy(frec, rec, 16); frec[3] = 0; }
+            }
+        }
+        memcpy(front + 4 * r, frec, 16);
+        which_out[2 * r] = (int8_t)which;
+        which_out[2 * r + 1] = (int8_t)count;
+        uint32_t ww = 0, brec[4];
+        rec_none(brec);
+        if (which >= 0) {
+            const BackParams &bp = P.b[which];
+            const int sft = (int)(frec[1] >> 16);
+            Uniform ub = front_uniform(bp.m, bp.k, bp.indel, bp.min_overlap);
+            ub.sq = true; ub.er = true;
+            FilterState F;
+            filter_init(F, ub, bp.rows, WIDE);
+            F.best = FILTER_BEST_NONE_SIGNED;
+            const int z_first = sft >> 3;
+            int jlast = 8 * z_first;
+            for (int z = z_first; 8 * z < n; ++z) {
+                const uint32_t w = read_dword(q, nchunks, z) & start_mask(z, sft);
+                for (int b = 0; b < 8; ++b) {
+                    const int j = 8 * z + b + 1;
+                    if (j > n) break;
+                    const uint32_t code = (w >> (4 * b)) & 15u;
+                    filter_step<WIDE, true>(F, ub, bp.peq[code][0], bp.peq[code][1], (uint32_t)j);
+                    jlast = j;
+                }
+                if ((z & 3) == 3 || 8 * (z + 1) >= n) filter_fold(F, jlast);      // as the kernel: once per 32-column chunk
+            }
+            F.best = filter_unbias_best(F.best, ub.k);
+            LaneFilterParams lf;
+            lf.rows = bp.rows; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
+            ww = filter_decide<WIDE>(F, ub, lf, q, nchunks, n, brec, sft);
+            if (!window_valid(ww))
+                linked_finish(brec, sft, ub.m, ub.min_overlap, bp.pf_thr, bp.accept_full != 0, s->rmp.back[which], s->rmp.back_ld[which],
+                              s->rmp.back_max[which]);
+        }
+        win[r] = ww;
+        if (!window_valid(ww)) memcpy(back + 4 * r, brec, 16);
+        else bins[which][window_bin(ww, P.b[which].m, lens == nullptr)].push_back((uint32_t)r);
+    }
+}
+
+extern "C" {
+int emu_linked_match_batch(const atr_linked_set *s, const uint8_t *packed, const int32_t *lens, int64_t nreads,
+                           int max_len, int8_t *which_out, int16_t *front, int16_t *back) {
+    if (!s || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    if (max_len == 0) return ATR_ERR_UNSUPPORTED;
+    const int nchunks = (max_len + 31) / 32;
+    const uint32_t *pk = (const uint32_t *)packed;
+    std::vector<uint32_t> win((size_t)nreads);
+    std::vector<std::vector<std::vector<uint32_t>>> bins(s->p.n, std::vector<std::vector<uint32_t>>(FILTER_BINS));
+    const bool and_mode = s->p.and_mode != 0;
+    if (s->p.wide) {
+        if (and_mode) emu_linked_l1<true, true>(s, pk, lens, nreads, nchunks, max_len, which_out, (uint32_t *)front, (uint32_t *)back, win, bins);
+        else emu_linked_l1<true, false>(s, pk, lens, nreads, nchunks, max_len, which_out, (uint32_t *)front, (uint32_t *)back, win, bins);
+    } else {
+        if (and_mode) emu_linked_l1<false, true>(s, pk, lens, nreads, nchunks, max_len, which_out, (uint32_t *)front, (uint32_t *)back, win, bins);
+        else emu_linked_l1<false, false>(s, pk, lens, nreads, nchunks, max_len, which_out, (uint32_t *)front, (uint32_t *)back, win, bins);
+    }
+    for (int a = 0; a < s->p.n; ++a) {
+        const atr_aligner *al = &s->back[a];
+        EmuLinked la;
+        la.front = (const uint32_t *)front;
+        la.post = &s->post[a];
+        const int idx = round_up_rows(al->p.m) / ROW_GRAN - 1;
+        pick_dp(idx, al->indel_cost > al->p.k, std::make_integer_sequence<int, FILTER_MAX_M / ROW_GRAN>{})(
+            al, pk, lens, nchunks, max_len, (uint32_t *)back, win, bins[a], &la);
+    }
     return ATR_OK;
 }
 

@@ -57,6 +57,12 @@ def test_adapter_parser_specs(emu_backend):
     assert len(p.parse_multi(back=["ACGT", "GGGG"], front=["TTTT"])) == 3
 
 
+def test_linked_sets_fused(emu_backend, oracle):
+    """The fused linked-adapter pipeline (atr_linked_match_batch) against the oracle."""
+    total, fused = _cases.check_linked_sets_against_oracle(oracle, 21, 120)
+    assert total > 6000 and fused > 70
+
+
 def test_device_resident_adapters(emu_backend):
     assert _cases.check_device_resident_adapters() > 5000
 

@@ -27,6 +27,85 @@ def test_reference_caller_kats(hip_backend):
     _cases.check_caller_kats()
 
 
+def test_linked_sets_fused(hip_backend, oracle):
+    """The fused linked-adapter pipeline (atr_linked_match_batch) on random sets of linked adapters:
+    every (which, count, front, back) against the reference's rule restated on the oracle."""
+    total, fused = _cases.check_linked_sets_against_oracle(oracle, 21, 400, reads_per_round=(1, 64, 65, 200, 700))
+    assert total > 40000 and fused > 250
+
+
+def test_c4_shard_against_oracle(hip_backend, oracle):
+    """BASELINE config C4, one GPU's shard in full (12.5 M x 150 bp, four linked adapters, e = 0.12):
+    a 250 k-read slice bit-exact against the oracle (LinkedAdapter.match_to = PREFIX match_to, then
+    BACK match_to on read[front.rstop:], adapters/__init__.py:671-690), the whole shard against the
+    step-wise device path (one kernel pipeline per adapter part, nothing shared with the fused
+    kernels but the DP cores), and size-independent properties of all 12.5 M record pairs."""
+    import numpy as np
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.adapters import (AsciiSource, LinkedAdapter, LinkedSet, _linked_records_stepwise, upper_ascii)
+    n_total = 12_500_000
+    chunks = [synth.workload("C4", lo, min(2_500_000, n_total - lo), device="cuda") for lo in range(0, n_total, 2_500_000)]
+    w = chunks[0]
+    reads = upper_ascii(torch.cat([c["reads"] for c in chunks]))
+    del chunks
+    las = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=w["max_error_rate"],
+                         min_overlap=w["min_overlap"], indel_cost=w["indel_cost"]) for f, b in zip(w["fronts"], w["backs"])]
+    lset = LinkedSet(las)
+    assert lset.fused
+    src = AsciiSource(reads)
+    which, count, front, back = lset.match_source(src)
+    torch.cuda.synchronize()
+    # (1) slice parity against the oracle
+    lo = 7_654_321
+    k = 250_000
+    sl = reads[lo:lo + k].cpu().numpy()
+    ew, ef, eb = oracle.linked_many(w["fronts"], w["backs"], sl, np.full(k, 150, np.int32), w["max_error_rate"],
+                                    w["min_overlap"], w["indel_cost"], True, False, 8)
+    assert np.array_equal(which[lo:lo + k].cpu().numpy(), ew[:, 0].astype(np.int32))
+    assert np.array_equal(count[lo:lo + k].cpu().numpy(), ew[:, 1].astype(np.int32))
+    assert np.array_equal(front[lo:lo + k, :6].cpu().numpy().astype(np.int32), ef)
+    assert np.array_equal(back[lo:lo + k, :6].cpu().numpy().astype(np.int32), eb)
+    assert (ew[:, 0] >= 0).mean() > 0.7 and (eb[:, 1] >= 0).mean() > 0.3
+    # (2) the whole shard against the step-wise device path
+    w2, c2, f2, b2 = _linked_records_stepwise(las, src)
+    assert torch.equal(which, w2) and torch.equal(count, c2)
+    assert torch.equal(front[:, :6], f2[:, :6]) and torch.equal(back[:, :6], b2[:, :6])
+    # (3) invariants of every record pair
+    fr, bk = front.to(torch.int32), back.to(torch.int32)
+    hasf, hasb = fr[:, 1] >= 0, bk[:, 1] >= 0
+    assert bool((hasf == (which >= 0)).all()) and bool(((count > 0) == (which >= 0)).all())
+    assert bool((hasb <= hasf).all())                                  # no 3' match without a 5' match
+    assert int((count > 1).sum().item()) == 0                          # the four 5' parts are mutually exclusive
+    f = fr[hasf]
+    assert bool((f[:, 0] == 0).all()) and bool((f[:, 2] == 0).all())   # anchored: starts at (0, 0)
+    assert bool((f[:, 1] == 20).all())                                 # no STOP_WITHIN_SEQ1: the whole 5' adapter
+    assert bool(((f[:, 3] >= 18) & (f[:, 3] <= 22)).all())             # at most k = 2 indels
+    assert bool((f[:, 5] <= 2).all()) and bool((f[:, 4] + f[:, 5] >= 20).all())
+    b, s = bk[hasb], fr[hasb][:, 3]
+    mb = torch.tensor([len(x) for x in w["backs"]], device="cuda", dtype=torch.int32)[which[hasb].long()]
+    assert bool((b[:, 0] == 0).all()) and bool(((b[:, 1] > 0) & (b[:, 1] <= mb)).all())
+    assert bool(((b[:, 2] >= 0) & (b[:, 2] <= b[:, 3]) & (b[:, 3] <= 150 - s)).all())   # inside read[front.rstop:]
+    assert bool(((b[:, 1] < mb) <= (b[:, 3] == 150 - s)).all())        # a partial 3' adapter only at the read end
+    assert bool((b[:, 5] <= (b[:, 1].double() * 0.12).floor().to(torch.int32)).all())
+    assert bool((bk[~hasb][:, [0, 2, 3, 4, 5]] == 0).all())
+    # (4) determinism, and independence of the batch split
+    w3, c3, f3, b3 = lset.match_source(src)
+    assert torch.equal(which, w3) and torch.equal(front, f3) and torch.equal(back, b3)
+    part = lset.match_source(AsciiSource(reads[lo:lo + 100_037].contiguous()))
+    assert torch.equal(part[0], which[lo:lo + 100_037]) and torch.equal(part[3], back[lo:lo + 100_037])
+    # (5) ragged lengths: the same reads cut to 60 .. 150 bases, a slice against the oracle
+    g = torch.Generator(device="cuda").manual_seed(11)
+    lens = torch.randint(60, 151, (1_000_000,), generator=g, device="cuda", dtype=torch.int32)
+    sub = reads[:1_000_000].contiguous()
+    rw, rc, rf, rb = lset.match_source(AsciiSource(sub, lens))
+    ew, ef, eb = oracle.linked_many(w["fronts"], w["backs"], sub[:100_000].cpu().numpy(), lens[:100_000].cpu().numpy(),
+                                    w["max_error_rate"], w["min_overlap"], w["indel_cost"], True, False, 8)
+    assert np.array_equal(rw[:100_000].cpu().numpy(), ew[:, 0].astype(np.int32))
+    assert np.array_equal(rf[:100_000, :6].cpu().numpy().astype(np.int32), ef)
+    assert np.array_equal(rb[:100_000, :6].cpu().numpy().astype(np.int32), eb)
+
+
 def test_device_resident_adapters(hip_backend):
     assert _cases.check_device_resident_adapters() > 5000
 

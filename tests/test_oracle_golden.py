@@ -93,3 +93,40 @@ def test_synth_heads(oracle):
         orc = oracle.InsertOracle(w["adapter1"], w["adapter2"], **heads[name]["kw"])
         outs = [_insert_norm(orc.match_insert(a, b)) for a, b in zip(rows(w["reads1"]), rows(w["reads2"]))]
         assert outs == heads[name]["out"]
+
+
+def test_oracle_linked_c4_head(oracle):
+    """oracle.linked_many (Adapter.match_to + LinkedAdapter.match_to restated in C) on the head of
+    the C4 read set against what the reference returned for it (synth_heads.json.gz)."""
+    import numpy as np
+    from atropos_amd import synth
+    heads = load_golden("synth_heads.json.gz")["C4"]
+    w = synth.workload("C4", 0, heads["count"])
+    r = w["reads"].numpy()
+    wh, f, b = oracle.linked_many(w["fronts"], w["backs"], r, np.full(len(r), 150, np.int32), w["max_error_rate"],
+                                  w["min_overlap"], w["indel_cost"], True, False, 2)
+    for i in range(len(r)):
+        exp = heads["out"][i]
+        hits = [a for a in range(4) if exp[a] is not None]
+        assert int(wh[i, 0]) == (hits[0] if hits else -1) and int(wh[i, 1]) == len(hits)
+        if hits:
+            ef, eb = exp[hits[0]]
+            assert list(f[i]) == ef
+            assert (None if b[i, 1] < 0 else list(b[i])) == eb
+
+
+def test_oracle_match_to_golden(oracle):
+    """oracle.match_to against the reference's Adapter.match_to outputs (match_to_fuzz.json.gz), for
+    the cases it restates: adapters with indels, no RMP filter."""
+    cases = load_golden("match_to_fuzz.json.gz") + load_golden("kats.json")["match_to"]
+    n = 0
+    for c in cases:
+        kw = c["kw"]
+        if c.get("use_rmp") or not kw.get("indels", True):
+            continue
+        got = oracle.match_to(c["seq"].upper().replace("U", "T"), c["where"], c["read"], kw.get("max_error_rate", 0.1),
+                              kw.get("min_overlap", 3), kw.get("indel_cost", 1), kw.get("adapter_wildcards", True),
+                              kw.get("read_wildcards", False))
+        assert (None if got is None else list(got)) == c["out"], c
+        n += 1
+    assert n > 1000

@@ -2,14 +2,16 @@
 # Profiling recipe run on the GPU box (via gpurun): kernel trace + stats, then PMC
 # passes in separate runs (rocprofv3 must not combine --pmc with trace domains), then
 # keep only the locate_kernel rows so the merged gpurun_out/ stays small.
-# usage: tools/profile_r.sh <tag>
+# usage: tools/profile_r.sh <tag> [config] [extra bench.py args]
 set -u
 TAG=${1:-r01}
+CONFIG=${2:-C2}
+EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
-BENCH="python bench.py --no-cpu-baseline"
+BENCH="python bench.py --config $CONFIG --no-cpu-baseline --no-secondary $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH --steps 10 --warmup 2 > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum"; do
   N=$(echo $C | cut -d' ' -f1)
@@ -47,7 +49,7 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         for name, cs in acc.items():
             fh.write("%s\n" % name)
             for c, v in cs.items():
-                fh.write("  %s: launches=%d avg=%.1f\n" % (c, len(v), sum(v) / len(v)))
+                fh.write("  %s: launches=%d avg=%.1f sum=%.1f\n" % (c, len(v), sum(v) / len(v), sum(v)))
 PY
 # drop the bulky raw files
 find $OUT -name "*.csv" -size +200k -delete

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Reduce the FETCH_SIZE / WRITE_SIZE sections of a tools/profile_r.sh summary into
-profiles/hbm_traffic.json (the `roofline.traffic` figure of bench.py).
+profiles/traffic_<config>.json (the `roofline.traffic` figure of bench.py).
 
-    python tools/reduce_traffic.py profiles/r18_locate_c2_rocprofv3_summary.txt
+    python tools/reduce_traffic.py profiles/round2_c2_rocprofv3_summary.txt C2 10000000
 
 Counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section):
 FETCH_SIZE reports half of a wide coalesced stream, so the streaming kernels (the pre-pass
@@ -13,7 +13,7 @@ import os
 import re
 import sys
 
-STREAMING = ("filter_kernel", "scan_bins_kernel", "scan_total_kernel", "scatter_kernel")
+STREAMING = ("filter_kernel", "scan_bins_kernel", "scan_total_kernel", "scatter_kernel", "insert_kernel", "correct_kernel")
 
 
 def short(name):
@@ -23,6 +23,11 @@ def short(name):
 
 def main():
     src = sys.argv[1]
+    config = sys.argv[2] if len(sys.argv) > 2 else "C2"
+    units = int(sys.argv[3]) if len(sys.argv) > 3 else 10_000_000
+    # bench.py calls per PMC pass (tools/profile_r.sh: --steps 3 --warmup 1); kernels launched several
+    # times per call (the per-adapter band / window kernels of C4) are summed per call
+    calls = int(sys.argv[4]) if len(sys.argv) > 4 else 4
     per = {}
     counter = None
     kernel = None
@@ -36,9 +41,9 @@ def main():
             continue
         if "atr::" in line and not line.startswith(" "):
             kernel = short(line)
-        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE): launches=\d+ avg=([\d.]+)", line)
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE): launches=(\d+) avg=([\d.]+)", line)
         if m and kernel:
-            per.setdefault(kernel, {})[m.group(1)] = float(m.group(2))
+            per.setdefault(kernel, {})[m.group(1)] = float(m.group(3)) * int(m.group(2)) / calls
     # VALU wave-instructions per launch (SQ_INSTS_VALU pass), for the issue-bound view of the roofline
     valu = {}
     kernel = None
@@ -53,25 +58,24 @@ def main():
             continue
         if "atr::" in line and not line.startswith(" "):
             kernel = short(line)
-        m = re.match(r"\s+SQ_INSTS_VALU: launches=\d+ avg=([\d.]+)", line)
+        m = re.match(r"\s+SQ_INSTS_VALU: launches=(\d+) avg=([\d.]+)", line)
         if m and kernel:
-            valu[kernel] = float(m.group(1))
+            valu[kernel] = float(m.group(2)) * int(m.group(1)) / calls
     total = 0.0
     for k, v in per.items():
         f = 2.0 if any(s in k for s in STREAMING) else 1.0
         total += (f * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
-    reads = 10_000_000
-    out = {"workload": "C2", "reads_per_launch": reads, "hbm_bytes_per_launch": total,
-           "hbm_bytes_per_read": total / reads,
+    out = {"workload": config, "units_per_launch": units, "hbm_bytes_per_launch": total,
+           "hbm_bytes_per_unit": total / units,
            "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % src,
            "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB for the coalesced streaming kernels (gfx950 FETCH_SIZE counts "
                      "half of a wide coalesced stream), raw FETCH_SIZE + WRITE_SIZE for the gathering band / window kernels",
            "per_kernel": per,
            "valu_wave_insts_per_launch": sum(valu.values()), "valu_wave_insts_per_kernel": valu}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "hbm_traffic.json"), "w") as fh:
+    with open(os.path.join(root, "profiles", "traffic_%s.json" % config), "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "hbm_bytes_per_read")}))
+    print(json.dumps({k: out[k] for k in ("hbm_bytes_per_launch", "hbm_bytes_per_unit")}))
 
 
 if __name__ == "__main__":
