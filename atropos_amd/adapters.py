@@ -1,16 +1,18 @@
 # coding: utf-8
-"""Adapters: the boundary objects that call the aligner (reference
-atropos/adapters/__init__.py: ADAPTER_TYPES :41-73, AdapterParser :80-229, Adapter
-:231-505, LinkedMatch/LinkedAdapter :612-745, parse_braces :933-970).
+"""Adapters: the boundary objects that call the aligner.
 
-Same classes, arguments and behaviour; ``match_to`` keeps its per-read form and gains a
-batched twin (``match_to_batch``) that sends the whole batch through the GPU kernels in
-one call and applies the reference's post-filters to the result records.
-ColorspaceAdapter and AdapterCache are out of scope.
+Same public names, constructor arguments, attributes and results as the reference's
+``atropos/adapters/__init__.py`` (ADAPTER_TYPES :41-73, AdapterParser :80-229, Adapter :231-505,
+LinkedMatch / LinkedAdapter :612-745, parse_braces :933-970), so that callers written against it
+keep working -- but organised around BATCHES: an adapter's real entry points are
+``match_to_batch`` (read objects in, Match objects out) and ``match_source`` (device-resident
+reads in, result records out); ``match_to(read)`` is the batch of one.  ColorspaceAdapter and
+AdapterCache are out of scope.
 """
 import itertools
+import operator
 import re
-from collections import defaultdict
+from collections import Counter, defaultdict, namedtuple
 
 import numpy as np
 import torch
@@ -24,49 +26,39 @@ from .util import IUPAC_BASES, GC_BASES, rmp_table
 START_WITHIN_SEQ1, START_WITHIN_SEQ2 = align.START_WITHIN_SEQ1, align.START_WITHIN_SEQ2
 STOP_WITHIN_SEQ1, STOP_WITHIN_SEQ2 = align.STOP_WITHIN_SEQ1, align.STOP_WITHIN_SEQ2
 
+# where an adapter may sit = which ends of the alignment are free (reference :41-73)
+BACK = START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2 | STOP_WITHIN_SEQ1          # 14  regular 3'
+FRONT = START_WITHIN_SEQ2 | STOP_WITHIN_SEQ2 | START_WITHIN_SEQ1        # 11  regular 5'
+PREFIX = STOP_WITHIN_SEQ2                                               # 8   anchored 5'
+SUFFIX = START_WITHIN_SEQ2                                              # 2   anchored 3'
+ANYWHERE = align.SEMIGLOBAL                                             # 15  variable 5'/3'
+LINKED = 'linked'
 
-class AdapterType(object):
-    """Adapter type name, description and alignment flags."""
+_AdapterTypeBase = namedtuple("AdapterType", "name desc flags")
 
-    def __init__(self, name, desc, *flags):
-        self.name = name
-        self.desc = desc
-        self.flags = flags[0]
-        for flag in flags[1:]:
-            self.flags |= flag
+
+class AdapterType(_AdapterTypeBase):
+    """(name, description, alignment flags) of one adapter placement."""
+    __slots__ = ()
 
     def asdict(self):
-        return dict(name=self.name, desc=self.desc, flags=self.flags)
+        return dict(self._asdict())
 
 
-ADAPTER_TYPES = dict(
-    back=AdapterType('back', "regular 3'", START_WITHIN_SEQ2, STOP_WITHIN_SEQ2, STOP_WITHIN_SEQ1),
-    front=AdapterType('front', "regular 5'", START_WITHIN_SEQ2, STOP_WITHIN_SEQ2, START_WITHIN_SEQ1),
-    prefix=AdapterType('prefix', "anchored 5'", STOP_WITHIN_SEQ2),
-    suffix=AdapterType('suffix', "anchored 3'", START_WITHIN_SEQ2),
-    anywhere=AdapterType('anywhere', "variable 5'/3'", align.SEMIGLOBAL),
-    linked=AdapterType('linked', 'linked', 'linked'))
-
-BACK = ADAPTER_TYPES['back'].flags              # 14
-FRONT = ADAPTER_TYPES['front'].flags            # 11
-PREFIX = ADAPTER_TYPES['prefix'].flags          # 8
-SUFFIX = ADAPTER_TYPES['suffix'].flags          # 2
-ANYWHERE = ADAPTER_TYPES['anywhere'].flags      # 15
-LINKED = ADAPTER_TYPES['linked'].flags
+ADAPTER_TYPES = {t.name: t for t in (
+    AdapterType('back', "regular 3'", BACK), AdapterType('front', "regular 5'", FRONT),
+    AdapterType('prefix', "anchored 5'", PREFIX), AdapterType('suffix', "anchored 3'", SUFFIX),
+    AdapterType('anywhere', "variable 5'/3'", ANYWHERE), AdapterType('linked', 'linked', LINKED))}
 
 
 def where_int_to_dict(where):
-    for adapter_type in ADAPTER_TYPES.values():
-        if where == adapter_type.flags:
-            return adapter_type.asdict()
-    raise ValueError("Invalid WHERE value: {}".format(where))
+    found = [t for t in ADAPTER_TYPES.values() if t.flags == where]
+    if not found:
+        raise ValueError("Invalid WHERE value: {}".format(where))
+    return found[0].asdict()
 
 
-ADAPTER_ID_GENERATOR = itertools.count(1)
-
-
-def _generate_adapter_name():
-    return str(next(ADAPTER_ID_GENERATOR))
+_adapter_numbers = itertools.count(1)
 
 
 def parse_braces(sequence):
@@ -91,7 +83,7 @@ def parse_braces(sequence):
         elif isinstance(state, int):
             if token != '}':
                 raise ValueError('"}" expected')
-            result = result[:-1] + result[-1] * state
+            result = result[:-1] + state * result[-1:]
             state = None
         else:
             if token != '{':
@@ -100,15 +92,6 @@ def parse_braces(sequence):
     if isinstance(state, int) or state == '{':
         raise ValueError("Unterminated expression")
     return result
-
-
-def _extract_name_from_spec(spec):
-    fields = spec.split('=', 1)
-    name = None
-    if len(fields) > 1:
-        name, spec = fields
-        name = name.strip()
-    return name, spec.strip()
 
 
 def _seq_of(read):
@@ -158,97 +141,62 @@ class Adapter(object):
     def __init__(self, sequence, where, max_error_rate=0.1, min_overlap=3, read_wildcards=False,
                  adapter_wildcards=True, name=None, indels=True, indel_cost=1, match_probability=None, max_rmp=None,
                  gc_content=0.5, alphabet=None):
-        if len(sequence) == 0:
+        if not sequence:
             raise ValueError("Empty adapter sequence")
+        if where not in (BACK, FRONT, PREFIX, SUFFIX, ANYWHERE):
+            raise ValueError("Invalid WHERE value: {}".format(where))
         sequence = parse_braces(sequence.upper().replace('U', 'T'))
-        seq_set = set(sequence)
-        if seq_set <= set('ACGT'):
-            adapter_wildcards = False
-        if adapter_wildcards and not seq_set <= IUPAC_BASES:
-            raise ValueError("Invalid character(s) in adapter sequence: {}".format(','.join(seq_set - IUPAC_BASES)))
+        letters = set(sequence)
+        # wildcards only make sense when the adapter has some (reference :268-270)
+        adapter_wildcards = bool(adapter_wildcards) and not letters <= set('ACGT')
+        if adapter_wildcards and letters - IUPAC_BASES:
+            raise ValueError("Invalid character(s) in adapter sequence: {}".format(','.join(letters - IUPAC_BASES)))
         if alphabet is not None:
             for character in sequence:
                 if character not in alphabet:
                     raise ValueError("Character {!r} is not in the alphabet".format(character))
-        self.debug = False
-        self.name = _generate_adapter_name() if name is None else name
-        self.sequence = sequence
-        self.where = where
+        self.sequence, self.where = sequence, where
+        self.name = str(next(_adapter_numbers)) if name is None else name
         self.max_error_rate = max_error_rate
-        self.min_overlap = min(min_overlap, len(self.sequence))
-        self.match_probability = match_probability
-        self.max_rmp = max_rmp
-        self.gc_content = gc_content
+        self.min_overlap = min(min_overlap, len(sequence))
+        self.read_wildcards, self.adapter_wildcards = read_wildcards, adapter_wildcards
         self.indels = indels
-        self.adapter_wildcards = adapter_wildcards
-        self.read_wildcards = read_wildcards
-        trimmers = {FRONT: self._trimmed_front, PREFIX: self._trimmed_front, BACK: self._trimmed_back,
-                    SUFFIX: self._trimmed_back, ANYWHERE: self._trimmed_anywhere}
-        self.trimmed = trimmers[where]
-        self._front_flag = None if where == ANYWHERE else where not in (BACK, SUFFIX)
-        # statistics about the removed sequences
-        self.lengths_front = defaultdict(int)
-        self.lengths_back = defaultdict(int)
-        self.errors_front = defaultdict(lambda: defaultdict(int))
-        self.errors_back = defaultdict(lambda: defaultdict(int))
-        self.adjacent_bases = {'A': 0, 'C': 0, 'G': 0, 'T': 0, '': 0}
-        self.aligner = align.Aligner(self.sequence, self.max_error_rate, flags=self.where,
-                                     wildcard_ref=self.adapter_wildcards, wildcard_query=self.read_wildcards)
-        self.aligner.min_overlap = self.min_overlap
-        # when indels are disallowed the aligner simply prices them out (:316-322)
-        self._indel_cost = indel_cost if self.indels else 100000
+        self.match_probability, self.max_rmp, self.gc_content = match_probability, max_rmp, gc_content
+        self.debug = False
+        # which end of the read a match removes: True 5', False 3', None decided per match (ANYWHERE)
+        self._front_flag = {BACK: False, SUFFIX: False, ANYWHERE: None}.get(where, True)
+        # statistics about the removed sequences: length -> count, length -> errors -> count
+        self.lengths_front, self.lengths_back = Counter(), Counter()
+        self.errors_front, self.errors_back = defaultdict(Counter), defaultdict(Counter)
+        self.adjacent_bases = dict.fromkeys(('A', 'C', 'G', 'T', ''), 0)
+        self.aligner = align.Aligner(sequence, max_error_rate, flags=where, wildcard_ref=adapter_wildcards,
+                                     wildcard_query=read_wildcards, min_overlap=self.min_overlap)
+        # an adapter without indels simply prices them out of every alignment (reference :316-322)
+        self._indel_cost = indel_cost if indels else 100000
         self.aligner.indel_cost = self._indel_cost
+        # an anchored adapter without indels is a plain prefix / suffix comparison (reference :370-380)
+        self._plain_compare = not indels and where in (PREFIX, SUFFIX)
         self._exact_aligner = None
         self._rmp_cache = None
         self._rmp_device = None
 
     def __repr__(self):
-        return ('<Adapter(name="{name}", sequence="{sequence}", where={where}, max_error_rate={max_error_rate}, '
-                'min_overlap={min_overlap}, read_wildcards={read_wildcards}, '
-                'adapter_wildcards={adapter_wildcards}, indels={indels})>').format(**vars(self))
+        shown = ("name", "sequence", "where", "max_error_rate", "min_overlap", "read_wildcards", "adapter_wildcards", "indels")
+        return "<Adapter(%s)>" % ", ".join("%s=%r" % (k, getattr(self, k)) for k in shown)
+
+    def __len__(self):
+        return len(self.sequence)
 
     def enable_debug(self):
-        self.debug = True
         self.aligner.enable_debug()
+        self.debug = True
 
     # ------------------------------------------------------------------ matching
-    def _exact_position(self, read_seq):
-        """The exact-match shortcut of match_to (:351-367): first literal occurrence."""
-        if self.where == PREFIX:
-            return 0 if read_seq.startswith(self.sequence) else -1
-        if self.where == SUFFIX:
-            return len(read_seq) - len(self.sequence) if read_seq.endswith(self.sequence) else -1
-        return read_seq.find(self.sequence)
-
-    def _accept(self, astart, astop, matches, errors):
-        """The post-filter of match_to (:386-398); note the DIVISION, not the DP's product."""
-        size = astop - astart
-        return ((size >= self.min_overlap and errors / size <= self.max_error_rate) and
-                (self.max_rmp is None or self.match_probability(matches, size) <= self.max_rmp))
-
     def match_to(self, read):
-        """Attempt to match this adapter to the given read; returns a Match or None if
-        the criteria (minimum overlap, maximum error rate, random-match probability) are
-        not met."""
-        read_seq = read.sequence.upper()
-        # try to find an exact match first unless wildcards are allowed
-        if not self.adapter_wildcards:
-            pos = self._exact_position(read_seq)
-            if pos >= 0:
-                seqlen = len(self.sequence)
-                return Match(0, seqlen, pos, pos + seqlen, seqlen, 0, self._front_flag, self, read)
-        # approximate matching
-        if not self.indels and self.where in (PREFIX, SUFFIX):
-            compare = align.compare_prefixes if self.where == PREFIX else align.compare_suffixes
-            alignment = compare(self.sequence, read_seq, wildcard_ref=self.adapter_wildcards,
-                                wildcard_query=self.read_wildcards)
-        else:
-            alignment = self.aligner.locate(read_seq)
-        if alignment:
-            astart, astop, rstart, rstop, matches, errors = alignment
-            if self._accept(astart, astop, matches, errors):
-                return Match(astart, astop, rstart, rstop, matches, errors, self._front_flag, self, read)
-        return None
+        """Attempt to match this adapter to the given read; returns a Match, or None if the
+        criteria (minimum overlap, maximum error rate, random-match probability) are not met.
+        A batch of one (``match_to_batch``)."""
+        return self.match_to_batch([read])[0]
 
     def _rmp_by_size(self):
         if self._rmp_cache is None:
@@ -260,7 +208,7 @@ class Adapter(object):
         numpy) for already upper-cased reads (list of str or uint8 [n, width] tensor)
         plus, when the literal exact-match shortcut cannot be read off those records, the
         records of the literal search."""
-        if not self.indels and self.where in (PREFIX, SUFFIX):
+        if self._plain_compare:
             rec = align.compare_batch(self.sequence, reads_upper, self.adapter_wildcards, self.read_wildcards,
                                       suffix=(self.where == SUFFIX)).cpu().numpy()
         else:
@@ -299,7 +247,7 @@ class Adapter(object):
             if exact is None:
                 # literal compare mode: an exact full-length occurrence is what the DP returns
                 # for it (most matches, zero errors, leftmost); the shortcut bypasses the filters
-                if not self.indels and self.where in (PREFIX, SUFFIX):
+                if self._plain_compare:
                     full = found & (matches == m) & (errors == 0) & (astop - astart == m)
                 else:
                     full = found & (matches == m) & (errors == 0)
@@ -336,7 +284,7 @@ class Adapter(object):
         upper-case matrix, lens) -- only anchored no-indel adapters need it)."""
         be = _lib.get_backend()
         m = len(self.sequence)
-        if not self.indels and self.where in (PREFIX, SUFFIX):
+        if self._plain_compare:
             ascii_upper, lens = source.ascii()
             rec = align.compare_batch(self.sequence, ascii_upper, self.adapter_wildcards, self.read_wildcards,
                                       suffix=(self.where == SUFFIX), lens=lens)
@@ -362,111 +310,90 @@ class Adapter(object):
         return rec
 
     # ------------------------------------------------------------------ trimming
-    def _trimmed_anywhere(self, match):
-        return self._trimmed_front(match) if match.front else self._trimmed_back(match)
+    def trimmed(self, match):
+        """The read of ``match`` with the adapter (and what lies beyond it) removed; updates the
+        length / error statistics of this adapter."""
+        read, front = match.read, (match.front if self._front_flag is None else self._front_flag)
+        if front:
+            removed = match.rstop
+            self.lengths_front[removed] += 1
+            self.errors_front[removed][match.errors] += 1
+            return read[removed:]
+        removed = len(read) - match.rstart
+        self.lengths_back[removed] += 1
+        self.errors_back[removed][match.errors] += 1
+        before = read.sequence[match.rstart - 1:match.rstart]
+        self.adjacent_bases[before if before in ('A', 'C', 'G', 'T') else ''] += 1
+        return read[:match.rstart]
 
-    def _trimmed_front(self, match):
-        self.lengths_front[match.rstop] += 1
-        self.errors_front[match.rstop][match.errors] += 1
-        return match.read[match.rstop:]
-
-    def _trimmed_back(self, match):
-        self.lengths_back[len(match.read) - match.rstart] += 1
-        self.errors_back[len(match.read) - match.rstart][match.errors] += 1
-        adjacent_base = match.read.sequence[match.rstart - 1:match.rstart]
-        if adjacent_base not in 'ACGT':
-            adjacent_base = ''
-        self.adjacent_bases[adjacent_base] += 1
-        return match.read[:match.rstart]
-
-    def __len__(self):
-        return len(self.sequence)
-
+    # ------------------------------------------------------------------ reporting
     def random_match_probabilities(self):
-        """Probability that the first i bases of this adapter match a random sequence
-        (indels not taken into account), for i = 0..len."""
-        seq = self.sequence[::-1] if self._front_flag else self.sequence
-        base_probs = (self.gc_content / 2.0, (1 - self.gc_content) / 2.0)
-        probabilities = [1.0] + ([0] * len(seq))
-        c_bases = frozenset(GC_BASES if self.adapter_wildcards else 'GC')
-        cur_p = 1.0
-        for idx, base in enumerate(seq, 1):
-            cur_p *= base_probs[0 if base in c_bases else 1]
-            probabilities[idx] = cur_p
-        return probabilities
+        """probabilities[i]: chance that the first i adapter bases (the last i for a 5' adapter)
+        match a random sequence with this GC content, indels not taken into account."""
+        gc, at = self.gc_content / 2.0, (1 - self.gc_content) / 2.0
+        strong = frozenset(GC_BASES if self.adapter_wildcards else 'GC')
+        order = reversed(self.sequence) if self._front_flag else self.sequence
+        return list(itertools.accumulate([1.0] + [gc if base in strong else at for base in order], operator.mul))
 
     def summarize(self):
-        total_front = sum(self.lengths_front.values())
-        total_back = sum(self.lengths_back.values())
-        where = self.where
-        assert (where in (ANYWHERE, LINKED) or (where in (BACK, SUFFIX) and total_front == 0) or
-                (where in (FRONT, PREFIX) and total_back == 0))
-        stats = dict(adapter_class=self.__class__.__name__, total_front=total_front, total_back=total_back,
-                     total=total_front + total_back, match_probabilities=self.random_match_probabilities(),
-                     where=where_int_to_dict(where), sequence=self.sequence, max_error_rate=self.max_error_rate)
-        if where in (ANYWHERE, FRONT, PREFIX):
-            stats["lengths_front"] = dict(self.lengths_front)
-            stats["errors_front"] = {k: dict(v) for k, v in self.errors_front.items()}
-        if where in (ANYWHERE, BACK, SUFFIX):
-            stats["lengths_back"] = dict(self.lengths_back)
-            stats["errors_back"] = {k: dict(v) for k, v in self.errors_back.items()}
+        where, front_side, back_side = self.where, (ANYWHERE, FRONT, PREFIX), (ANYWHERE, BACK, SUFFIX)
+        n_front, n_back = sum(self.lengths_front.values()), sum(self.lengths_back.values())
+        assert (n_front == 0 or where in front_side) and (n_back == 0 or where in back_side)
+        stats = {"adapter_class": type(self).__name__, "where": where_int_to_dict(where), "sequence": self.sequence,
+                 "max_error_rate": self.max_error_rate, "match_probabilities": self.random_match_probabilities(),
+                 "total_front": n_front, "total_back": n_back, "total": n_front + n_back}
+        for side, sides, lengths, errors in (("front", front_side, self.lengths_front, self.errors_front),
+                                            ("back", back_side, self.lengths_back, self.errors_back)):
+            if where in sides:
+                stats["lengths_" + side] = dict(lengths)
+                stats["errors_" + side] = {length: dict(by_errors) for length, by_errors in errors.items()}
         if where in (BACK, SUFFIX):
             stats["adjacent_bases"] = dict(self.adjacent_bases)
         return stats
 
 
 class LinkedMatch(object):
-    """A match of a LinkedAdapter: the front match and (possibly None) the back match."""
+    """Result of ``LinkedAdapter.match_to``: the 5' match and the 3' match (or None) found in
+    what the 5' match left of the read."""
+    __slots__ = ("front_match", "back_match", "adapter")
 
     def __init__(self, front_match, back_match, adapter):
-        self.front_match = front_match
-        self.back_match = back_match
-        self.adapter = adapter
-        assert front_match is not None
+        if front_match is None:
+            raise ValueError("a LinkedMatch needs a 5' match")
+        self.front_match, self.back_match, self.adapter = front_match, back_match, adapter
 
     def get_info_record(self):
-        if self.back_match:
-            return self.back_match.get_info_record()
-        return self.front_match.get_info_record()
+        return (self.back_match or self.front_match).get_info_record()
 
 
 class LinkedAdapter(object):
-    """An adapter with linked front (anchored 5') and back (3') sequences; the back
-    adapter is only searched for when the front adapter was found, in the read with the
-    front match removed."""
+    """``^FRONT...BACK``: an anchored 5' adapter and a regular 3' adapter; the 3' adapter is only
+    looked for in reads that start with the 5' adapter, in ``read[front_match.rstop:]``."""
 
     def __init__(self, front_sequence, back_sequence, front_anchored=True, back_anchored=False, name=None, **kwargs):
-        assert front_anchored and not back_anchored
-        where1 = PREFIX if front_anchored else FRONT
-        where2 = SUFFIX if back_anchored else BACK
-        self.front_anchored = front_anchored
-        self.back_anchored = back_anchored
+        if not front_anchored or back_anchored:
+            raise AssertionError("linked adapters are an anchored 5' part plus a regular 3' part")
+        self.front_anchored, self.back_anchored = front_anchored, back_anchored
         self.where = LINKED
-        self.name = _generate_adapter_name() if name is None else name
-        self.front_adapter = Adapter(front_sequence, where=where1, name=None, **kwargs)
-        self.back_adapter = Adapter(back_sequence, where=where2, name=None, **kwargs)
+        self.name = str(next(_adapter_numbers)) if name is None else name
+        self.front_adapter = Adapter(front_sequence, where=PREFIX, name=None, **kwargs)
+        self.back_adapter = Adapter(back_sequence, where=BACK, name=None, **kwargs)
 
     def enable_debug(self):
-        self.front_adapter.enable_debug()
-        self.back_adapter.enable_debug()
+        for part in (self.front_adapter, self.back_adapter):
+            part.enable_debug()
 
     def match_to(self, read):
-        front_match = self.front_adapter.match_to(read)
-        if front_match is None:
-            return None
-        read = read[front_match.rstop:]
-        back_match = self.back_adapter.match_to(read)
-        return LinkedMatch(front_match, back_match, self)
+        return self.match_to_batch([read])[0]
 
     def match_to_batch(self, reads):
-        """Batched ``match_to``: the front adapter over the whole batch, then the back
-        adapter over the remainders of the reads that had a front match."""
+        """LinkedMatch / None per read: the 5' adapter over the whole batch, then the 3' adapter over
+        the remainders of the reads that had a 5' match."""
         fronts = self.front_adapter.match_to_batch(reads)
-        idx = [i for i, fm in enumerate(fronts) if fm is not None]
-        rest = [reads[i][fronts[i].rstop:] for i in idx]
-        backs = self.back_adapter.match_to_batch(rest) if rest else []
+        claimed = [i for i, fm in enumerate(fronts) if fm is not None]
+        backs = self.back_adapter.match_to_batch([reads[i][fronts[i].rstop:] for i in claimed]) if claimed else []
         out = [None] * len(reads)
-        for i, bm in zip(idx, backs):
+        for i, bm in zip(claimed, backs):
             out[i] = LinkedMatch(fronts[i], bm, self)
         return out
 
@@ -479,22 +406,25 @@ class LinkedAdapter(object):
         return front, back
 
     def trimmed(self, match):
-        front_trimmed = self.front_adapter.trimmed(match.front_match)
-        if match.back_match:
-            return self.back_adapter.trimmed(match.back_match)
-        return front_trimmed
+        rest = self.front_adapter.trimmed(match.front_match)
+        return self.back_adapter.trimmed(match.back_match) if match.back_match else rest
 
     def summarize(self):
-        fa, ba = self.front_adapter, self.back_adapter
-        total_front = sum(fa.lengths_front.values())
-        total_back = sum(ba.lengths_back.values())
-        return dict(total_front=total_front, total_back=total_back, total=total_front + total_back,
-                    where=where_int_to_dict(self.where), front_sequence=fa.sequence, back_sequence=ba.sequence,
-                    front_match_probabilities=fa.random_match_probabilities(),
-                    back_match_probabilities=ba.random_match_probabilities(),
-                    front_max_error_rate=fa.max_error_rate, back_max_error_rate=ba.max_error_rate,
-                    front_lengths_front=dict(fa.lengths_front), front_lengths_back=dict(fa.lengths_back),
-                    back_lengths_front=dict(ba.lengths_front), back_lengths_back=dict(ba.lengths_back))
+        out = {"where": where_int_to_dict(self.where)}
+        for side, part in (("front", self.front_adapter), ("back", self.back_adapter)):
+            out[side + "_sequence"] = part.sequence
+            out[side + "_max_error_rate"] = part.max_error_rate
+            out[side + "_match_probabilities"] = part.random_match_probabilities()
+            out[side + "_lengths_front"] = dict(part.lengths_front)
+            out[side + "_lengths_back"] = dict(part.lengths_back)
+        out["total_front"] = sum(self.front_adapter.lengths_front.values())
+        out["total_back"] = sum(self.back_adapter.lengths_back.values())
+        out["total"] = out["total_front"] + out["total_back"]
+        return out
+
+
+# name=  ^anchored5'  body  anchored3'$ ; the body of a linked adapter is FRONT...BACK
+_SPEC = re.compile(r"^(?:(?P<name>[^=]*)=)?\s*(?P<hat>\^)?(?P<body>.*?)(?P<dollar>\$)?\s*$", re.S)
 
 
 class AdapterParser(object):
@@ -510,68 +440,56 @@ class AdapterParser(object):
     def parse(self, spec, cmdline_type='back'):
         if spec.startswith('file:'):
             raise NotImplementedError("file: adapter specs need the FASTA reader, which is out of scope")
-        yield self.parse_from_spec(spec, cmdline_type)
+        return iter([self.parse_from_spec(spec, cmdline_type)])
 
     def parse_from_spec(self, spec, cmdline_type='back', name=None):
+        """One adapter from its command-line form; cmdline_type: the option it came with
+        ('back' -a, 'front' -g, 'anywhere' -b)."""
         if cmdline_type not in ADAPTER_TYPES:
             raise ValueError('cmdline_type cannot be {0!r}'.format(cmdline_type))
         if spec is None:
             raise ValueError('Either name or spec must be given')
-        orig_spec = spec
-        where = ADAPTER_TYPES[cmdline_type].flags
-        if name is None:
-            name, spec = _extract_name_from_spec(spec)
-        front_anchored = back_anchored = False
-        if spec.startswith('^'):
-            spec = spec[1:]
-            front_anchored = True
-        if spec.endswith('$'):
-            spec = spec[:-1]
-            back_anchored = True
-        sequence1, middle, sequence2 = spec.partition('...')
-        if where == ANYWHERE:
-            if front_anchored or back_anchored:
+        parts = _SPEC.match(spec)
+        if name is None and parts.group("name") is not None:
+            name = parts.group("name").strip()
+        elif name is not None:
+            parts = _SPEC.match("=" + spec)                    # a given name: '=' is not a separator
+        anchor5, anchor3, body = bool(parts.group("hat")), bool(parts.group("dollar")), parts.group("body")
+        make = lambda seq, where: Adapter(sequence=seq, where=where, name=name, **self.constructor_args)
+        if cmdline_type == 'anywhere':
+            if anchor5 or anchor3:
                 raise ValueError("'anywhere' (-b) adapters may not be anchored")
-            if middle == '...':
+            if '...' in body:
                 raise ValueError("'anywhere' (-b) adapters may not be linked")
-            return Adapter(sequence=spec, where=where, name=name, **self.constructor_args)
-        assert where == FRONT or where == BACK
-        if middle == '...':
-            if not sequence1:
-                if where == BACK:           # -a ...ADAPTER
-                    spec = sequence2
-                else:                       # -g ...ADAPTER
-                    raise ValueError('Invalid adapter specification')
-            elif not sequence2:
-                if where == BACK:           # -a ADAPTER...
-                    spec = sequence1
-                    where = FRONT
-                    front_anchored = True
-                else:                       # -g ADAPTER...
-                    spec = sequence1
-            else:
-                if where == BACK:           # the 5' adapter is anchored automatically with -a
-                    front_anchored = True
-                return LinkedAdapter(sequence1, sequence2, name=name, front_anchored=front_anchored,
-                                     back_anchored=back_anchored, **self.constructor_args)
-        if front_anchored and back_anchored:
-            raise ValueError('Trying to use both "^" and "$" in adapter specification {!r}'.format(orig_spec))
-        if front_anchored:
-            if where == BACK:
-                raise ValueError("Cannot anchor the 3' adapter at its 5' end")
-            where = PREFIX
-        elif back_anchored:
-            if where == FRONT:
-                raise ValueError("Cannot anchor 5' adapter at 3' end")
-            where = SUFFIX
-        return Adapter(sequence=spec, where=where, name=name, **self.constructor_args)
+            return make(body, ANYWHERE)
+        three_prime = cmdline_type == 'back'
+        first, dots, second = body.partition('...')
+        if dots:
+            if first and second:
+                # -a FRONT...BACK anchors the 5' part by itself
+                return LinkedAdapter(first, second, name=name, front_anchored=anchor5 or three_prime,
+                                     back_anchored=anchor3, **self.constructor_args)
+            if three_prime and second:          # -a ...ADAPTER: a plain 3' adapter
+                body = second
+            elif three_prime:                   # -a ADAPTER...: an anchored 5' adapter
+                body, three_prime, anchor5 = first, False, True
+            elif first:                         # -g ADAPTER...: a plain 5' adapter
+                body = first
+            else:                               # -g ...ADAPTER
+                raise ValueError('Invalid adapter specification')
+        if anchor5 and anchor3:
+            raise ValueError('Trying to use both "^" and "$" in adapter specification {!r}'.format(spec))
+        if anchor5 and three_prime:
+            raise ValueError("Cannot anchor the 3' adapter at its 5' end")
+        if anchor3 and not three_prime:
+            raise ValueError("Cannot anchor 5' adapter at 3' end")
+        where = (SUFFIX if anchor3 else BACK) if three_prime else (PREFIX if anchor5 else FRONT)
+        return make(body, where)
 
     def parse_multi(self, back=None, anywhere=None, front=None):
-        adapters = []
-        for specs, cmdline_type in ((back, 'back'), (anywhere, 'anywhere'), (front, 'front')):
-            for spec in specs or ():
-                adapters.extend(self.parse(spec, cmdline_type))
-        return adapters
+        """All adapters of a command line, in the order -a, -b, -g."""
+        by_option = (('back', back), ('anywhere', anywhere), ('front', front))
+        return [adapter for option, specs in by_option for spec in (specs or ()) for adapter in self.parse(spec, option)]
 
 
 class LinkedSet(object):

@@ -356,87 +356,68 @@ class MultiAligner(object):
         return self.locate_batch([reference], [query], max_matches)[0]
 
 
-# Common match-result object returned by aligners (reference align/__init__.py:51-175)
+# ---- the match record the boundary objects pass around (reference align/__init__.py:51-175) ----
+
+MatchInfo = namedtuple("MatchInfo", "read_name errors rstart rstop seq_before seq_adapter seq_after adapter_name "
+                                    "qual_before qual_adapter qual_after is_front asize rsize_adapter rsize_total")
+
+_RECORD_FIELDS = ("astart", "astop", "rstart", "rstop", "matches", "errors")
+
 
 class Match(object):
-    """An alignment match.
+    """One adapter match: the six numbers of a result record (interval in the adapter, interval in
+    the read, matching and erroneous positions) plus its context -- ``front`` (does the match
+    remove the read's 5' end?  guessed from ``rstart == 0`` when not given), the ``adapter`` and
+    the ``read`` -- and ``length``, the adapter bases covered.  ``ValueError`` for an empty match or
+    one without a single matching position, as in the reference (:85-88)."""
 
-    Args:
-        astart, astop: match interval within the adapter.
-        rstart, rstop: match interval within the read.
-        matches: number of matching bases.
-        errors: number of mismatching bases (and indels).
-        front: whether the match is to the front of the read (guessed from
-            ``rstart == 0`` when None).
-        adapter, read: the Adapter and the read object.
-    """
-    __slots__ = ['astart', 'astop', 'rstart', 'rstop', 'matches', 'errors', 'front', 'adapter', 'read', 'length']
+    __slots__ = _RECORD_FIELDS + ("front", "adapter", "read", "length")
 
     def __init__(self, astart, astop, rstart, rstop, matches, errors, front=None, adapter=None, read=None):
-        self.astart = astart
-        self.astop = astop
-        self.rstart = rstart
-        self.rstop = rstop
-        self.matches = matches
-        self.errors = errors
-        self.front = self._guess_is_front() if front is None else front
-        self.adapter = adapter
-        self.read = read
-        # Number of aligned characters in the adapter; with indels this may differ from
-        # the number of characters in the read.
-        self.length = self.astop - self.astart
-        if self.length <= 0:
-            raise ValueError('Match length must be >= 0')
-        if self.length - self.errors <= 0:
-            raise ValueError('A Match requires at least one matching position.')
+        covered = astop - astart
+        if covered <= 0:
+            raise ValueError("Match length must be >= 0")
+        if errors >= covered:
+            raise ValueError("A Match requires at least one matching position.")
+        for slot, value in zip(_RECORD_FIELDS, (astart, astop, rstart, rstop, matches, errors)):
+            setattr(self, slot, value)
+        self.length = covered
+        self.front = (rstart == 0) if front is None else front
+        self.adapter, self.read = adapter, read
+
+    def record(self):
+        return tuple(getattr(self, slot) for slot in _RECORD_FIELDS)
 
     def __repr__(self):
-        return 'Match(astart={0}, astop={1}, rstart={2}, rstop={3}, matches={4}, errors={5})'.format(
-            self.astart, self.astop, self.rstart, self.rstop, self.matches, self.errors)
+        return "Match(%s)" % ", ".join("%s=%d" % item for item in zip(_RECORD_FIELDS, self.record()))
 
     def copy(self):
-        return Match(self.astart, self.astop, self.rstart, self.rstop, self.matches, self.errors, self.front,
-                     self.adapter, self.read)
-
-    def _guess_is_front(self):
-        return self.rstart == 0
+        return Match(*self.record(), front=self.front, adapter=self.adapter, read=self.read)
 
     def wildcards(self, wildcard_char='N'):
-        """The read characters that the adapter's wildcard characters matched (not
-        reliable with indels, as the alignment itself is not kept)."""
-        wildcards = [
-            self.read.sequence[self.rstart + i]
-            for i in range(self.length)
-            if (self.adapter.sequence[self.astart + i] == wildcard_char and
-                self.rstart + i < len(self.read.sequence))]
-        return ''.join(wildcards)
+        """The read characters that sit opposite the adapter's ``wildcard_char`` positions (not
+        reliable with indels: the alignment itself is not kept)."""
+        adapter, bases = self.adapter.sequence, self.read.sequence
+        pairs = zip(adapter[self.astart:self.astop], bases[self.rstart:])
+        return "".join(base for letter, base in pairs if letter == wildcard_char)
 
     def rest(self):
-        """The part of the read before the match for a front adapter, after it otherwise."""
-        if self.front:
-            return self.read.sequence[:self.rstart]
-        return self.read.sequence[self.rstop:]
+        """What a front adapter leaves before it, any other adapter after it."""
+        bases = self.read.sequence
+        return bases[:self.rstart] if self.front else bases[self.rstop:]
 
     def get_info_record(self):
-        seq = self.read.sequence
-        qualities = self.read.qualities
-        if qualities is None:
-            qualities = ''
-        rsize = rsize_total = self.rstop - self.rstart
-        if self.front and self.rstart > 0:
-            rsize_total = self.rstop
-        elif not self.front and self.rstop < len(seq):
-            rsize_total = len(seq) - self.rstart
-        return MatchInfo(
-            self.read.name, self.errors, self.rstart, self.rstop, seq[0:self.rstart],
-            seq[self.rstart:self.rstop], seq[self.rstop:], self.adapter.name, qualities[0:self.rstart],
-            qualities[self.rstart:self.rstop], qualities[self.rstop:], self.front, self.astop - self.astart,
-            rsize, rsize_total)
-
-
-MatchInfo = namedtuple("MatchInfo", (
-    "read_name", "errors", "rstart", "rstop", "seq_before", "seq_adapter", "seq_after", "adapter_name",
-    "qual_before", "qual_adapter", "qual_after", "is_front", "asize", "rsize_adapter", "rsize_total"))
+        """The row of the info file for this match (reference :143-170)."""
+        bases, quals = self.read.sequence, self.read.qualities or ""
+        lo, hi = self.rstart, self.rstop
+        removed = hi - lo
+        if self.front:
+            removed = hi if lo > 0 else removed               # everything up to the adapter's end goes
+        elif hi < len(bases):
+            removed = len(bases) - lo                         # everything from the adapter's start goes
+        split = lambda text: (text[:lo], text[lo:hi], text[hi:])
+        return MatchInfo(self.read.name, self.errors, lo, hi, *split(bases), self.adapter.name, *split(quals),
+                         self.front, self.length, hi - lo, removed)
 
 
 class InsertResult(object):
@@ -490,23 +471,19 @@ class InsertAligner(object):
                  min_insert_overlap=1, max_insert_mismatch_frac=0.2, min_adapter_overlap=1,
                  max_adapter_mismatch_frac=0.2, adapter_check_cutoff=9, base_probs=None, adapter_wildcards=True,
                  read_wildcards=False):
-        self._backend = _lib.get_backend()
-        self._handle = None
-        self.adapter1 = adapter1
-        self.adapter1_len = len(adapter1)
-        self.adapter2 = adapter2
-        self.adapter2_len = len(adapter2)
-        self.match_probability = match_probability if match_probability is not None else _default_rmp()
-        self.insert_max_rmp = insert_max_rmp
-        self.adapter_max_rmp = adapter_max_rmp
-        self.min_insert_overlap = min_insert_overlap
-        self.max_insert_mismatch_frac = float(max_insert_mismatch_frac)
-        self.min_adapter_overlap = min_adapter_overlap
-        self.max_adapter_mismatch_frac = float(max_adapter_mismatch_frac)
-        self.adapter_check_cutoff = adapter_check_cutoff
+        self._backend, self._handle = _lib.get_backend(), None
+        self.adapter1, self.adapter2 = adapter1, adapter2
+        self.adapter1_len, self.adapter2_len = len(adapter1), len(adapter2)
+        self.match_probability = _default_rmp() if match_probability is None else match_probability
         self.base_probs = base_probs or dict(match_prob=0.25, mismatch_prob=0.75)
-        self.adapter_wildcards = adapter_wildcards
-        self.read_wildcards = read_wildcards
+        thresholds = dict(insert_max_rmp=insert_max_rmp, adapter_max_rmp=adapter_max_rmp,
+                          min_insert_overlap=min_insert_overlap, min_adapter_overlap=min_adapter_overlap,
+                          max_insert_mismatch_frac=float(max_insert_mismatch_frac),
+                          max_adapter_mismatch_frac=float(max_adapter_mismatch_frac),
+                          adapter_check_cutoff=adapter_check_cutoff, adapter_wildcards=adapter_wildcards,
+                          read_wildcards=read_wildcards)
+        for key, value in thresholds.items():
+            setattr(self, key, value)
         self.aligner = MultiAligner(max_insert_mismatch_frac, START_WITHIN_SEQ1 | STOP_WITHIN_SEQ2, min_insert_overlap)
         self._build()
 
@@ -554,9 +531,10 @@ class InsertAligner(object):
         except Exception:
             pass
 
-    def pack(self, reads, check=False):
+    def pack(self, reads, check=False, max_len=None):
         """Pack one side of the pairs (DNA15 codes as bit planes, the "plane64" layout of
-        atr_pack_planes).  With ``check`` (read 2) every base must be an upper-case IUPAC letter."""
+        atr_pack_planes).  With ``check`` (read 2) every base must be an upper-case IUPAC letter.
+        ``max_len``: layout width (both sides of a batch must be packed with the same one)."""
         if isinstance(reads, ReadBatch):
             if reads.table_kind != _lib.TABLE_DNA15 or reads.layout != "plane64":
                 raise ValueError("the insert aligner needs reads packed by InsertAligner.pack (DNA15 codes, plane64 layout)")
@@ -565,8 +543,11 @@ class InsertAligner(object):
         table = be.translate_table(_lib.TABLE_DNA15)
         if isinstance(reads, (list, tuple)):
             mat, lens = _as_ascii_matrix(reads)
+            if max_len is not None and max_len > mat.shape[1]:
+                mat = np.pad(mat, ((0, 0), (0, max_len - mat.shape[1])))
             ascii_t, lens_t = torch.from_numpy(mat).to(be.device), torch.from_numpy(lens).to(be.device)
-            max_len = int(lens.max()) if len(reads) else 0
+            if max_len is None:
+                max_len = int(lens.max()) if len(reads) else 0
         else:
             ascii_t = reads.to(be.device)
             lens_t, max_len = None, ascii_t.shape[1]
@@ -585,8 +566,12 @@ class InsertAligner(object):
     def match_insert_batch(self, reads1, reads2):
         """Batched ``match_insert``; reads1/reads2: ReadBatch (DNA15), list of str, or
         uint8 [n, width] ASCII tensors of equal-length reads."""
-        b1 = self.pack(reads1)
-        b2 = self.pack(reads2, check=True)
+        width = None
+        if isinstance(reads1, (list, tuple)) and isinstance(reads2, (list, tuple)):
+            # both sides in one layout width, whatever the longest read of each side is
+            width = max([len(r) for r in reads1] + [len(r) for r in reads2] + [0])
+        b1 = self.pack(reads1, max_len=width)
+        b2 = self.pack(reads2, check=True, max_len=width)
         if b1.nreads != b2.nreads:
             raise ValueError("need as many first reads as second reads")
         max_len = max(b1.max_len, b2.max_len)

@@ -36,92 +36,40 @@ COMP_TABLE = _comp_table()
 
 
 class Modifier(object):
-    """Base class of the read modifiers."""
+    """A read modifier: ``modifier(read) -> read``; ``summarize()`` feeds the run summary."""
 
-    @property
-    def name(self):
-        return self.__class__.__name__
+    name = property(lambda self: type(self).__name__)
 
     def summarize(self):
-        return {}
+        return dict()
 
 
 class ReadPairModifier(Modifier):
+    """A modifier of read PAIRS: ``modifier(read1, read2) -> (read1, read2)``."""
+
     def __call__(self, read1, read2):
-        raise NotImplementedError()
+        raise NotImplementedError("%s does not implement __call__" % self.name)
 
 
 class AdapterCutter(Modifier):
-    """Repeatedly find one of multiple adapters in reads; the search is repeated ``times``
-    times.  ``action``: 'trim', 'mask' (replace the adapter by N) or None."""
+    """Find the best-matching of several adapters in each read and remove it, up to ``times`` times
+    (reference commands/trim/modifiers.py:91-195).  ``action``: 'trim', 'mask' (the removed bases
+    become N) or None (only record the match).  The work happens in ``call_batch``: per round ONE GPU
+    call per adapter over all reads that are still being trimmed; ``cutter(read)`` is a batch of one."""
 
     def __init__(self, adapters=None, times=1, action='trim'):
         self.adapters = adapters or []
-        self.times = times
-        self.action = action
+        self.times, self.action = times, action
         self.with_adapters = 0
 
-    def _best_match(self, read):
-        """The adapter whose match has the most matches (first one wins ties)."""
-        best = None
-        for adapter in self.adapters:
-            match = adapter.match_to(read)
-            if match is None:
-                continue
-            if best is None or match.matches > best.matches:
-                best = match
-        return best
-
-    def _finish(self, read, trimmed_read, matches):
-        """Everything __call__ does once the list of consecutive matches is known."""
-        if not matches:
-            trimmed_read.match = None
-            trimmed_read.match_info = None
-            return trimmed_read
-        assert len(trimmed_read) < len(read), "Trimmed read isn't shorter than original"
-        if self.action == 'trim':
-            pass
-        elif self.action == 'mask':
-            masked_sequence = trimmed_read.sequence
-            for match in sorted(matches, reverse=True, key=lambda m: m.astart):
-                nstr = 'N' * (len(match.read.sequence) - len(match.adapter.trimmed(match).sequence))
-                if match.front:
-                    masked_sequence = nstr + masked_sequence
-                else:
-                    masked_sequence += nstr
-            trimmed_read.sequence = masked_sequence
-            trimmed_read.qualities = matches[0].read.qualities
-            assert len(trimmed_read.sequence) == len(read)
-        elif self.action is None:
-            trimmed_read = read
-        trimmed_read.match = matches[-1]
-        trimmed_read.match_info = [match.get_info_record() for match in matches]
-        self.with_adapters += 1
-        return trimmed_read
-
     def __call__(self, read):
-        """Cut the best-matching adapter(s) from one read; returns the modified read."""
-        if len(read) == 0:
-            return read
-        matches = []
-        trimmed_read = read
-        for _ in range(self.times):
-            match = self._best_match(trimmed_read)
-            if match is None:
-                break
-            matches.append(match)
-            trimmed_read = match.adapter.trimmed(match)
-        return self._finish(read, trimmed_read, matches)
+        return self.call_batch([read])[0]
 
     def call_batch(self, reads):
-        """Batched twin of ``__call__``: for each of the ``times`` rounds every adapter is
-        matched against all still-active reads in one GPU call (``match_to_batch``), the
-        best adapter per read is chosen with the reference's rule, and the reads are
-        trimmed on the host."""
         out = list(reads)
-        active = [i for i, r in enumerate(reads) if len(r) > 0]
-        current = {i: reads[i] for i in active}
-        matches = {i: [] for i in active}
+        found = {i: [] for i, read in enumerate(reads) if len(read) > 0}      # read -> its successive matches
+        current = {i: reads[i] for i in found}
+        active = sorted(found)
         for _ in range(self.times):
             if not active:
                 break
@@ -129,27 +77,50 @@ class AdapterCutter(Modifier):
             best = [None] * len(batch)
             for adapter in self.adapters:
                 for k, match in enumerate(adapter.match_to_batch(batch)):
-                    if match is None:
-                        continue
-                    if best[k] is None or match.matches > best[k].matches:
+                    # most matches wins, the earlier adapter on ties (:107-122)
+                    if match is not None and (best[k] is None or match.matches > best[k].matches):
                         best[k] = match
-            still = []
+            again = []
             for k, i in enumerate(active):
-                if best[k] is None:
-                    continue
-                matches[i].append(best[k])
-                current[i] = best[k].adapter.trimmed(best[k])
-                still.append(i)
-            active = still
-        for i in matches:
-            out[i] = self._finish(reads[i], current[i], matches[i])
+                if best[k] is not None:
+                    found[i].append(best[k])
+                    current[i] = best[k].adapter.trimmed(best[k])
+                    again.append(i)
+            active = again                     # a read without a match leaves the rounds (:133-139)
+        for i, matches in found.items():
+            out[i] = self._record(reads[i], current[i], matches)
         return out
 
+    def _record(self, original, trimmed, matches):
+        """Apply ``action`` and attach match / match_info, given the successive matches of one read."""
+        if not matches:
+            trimmed.match = trimmed.match_info = None
+            return trimmed
+        if len(trimmed) >= len(original):
+            raise AssertionError("Trimmed read isn't shorter than original")
+        result = trimmed
+        if self.action == 'mask':
+            # N for every removed base, on the side it was removed from.  The removed length is asked
+            # from the adapter again, which -- as in the reference (:161) -- counts the match a second
+            # time in the adapter's statistics.
+            head = tail = 0
+            for match in sorted(matches, key=lambda m: -m.astart):
+                gone = len(match.read.sequence) - len(match.adapter.trimmed(match).sequence)
+                head, tail = (head + gone, tail) if match.front else (head, tail + gone)
+            result.sequence = 'N' * head + trimmed.sequence + 'N' * tail
+            result.qualities = matches[0].read.qualities
+            if len(result.sequence) != len(original):
+                raise AssertionError("masked read has a different length")
+        elif self.action is None:
+            result = original
+        result.match = matches[-1]
+        result.match_info = [match.get_info_record() for match in matches]
+        self.with_adapters += 1
+        return result
+
     def summarize(self):
-        adapters_summary = OrderedDict()
-        for adapter in self.adapters:
-            adapters_summary[adapter.name] = adapter.summarize()
-        return dict(records_with_adapters=self.with_adapters, adapters=adapters_summary)
+        per_adapter = OrderedDict((adapter.name, adapter.summarize()) for adapter in self.adapters)
+        return {"records_with_adapters": self.with_adapters, "adapters": per_adapter}
 
 
 class ErrorCorrectorMixin(object):
@@ -163,11 +134,9 @@ class ErrorCorrectorMixin(object):
     """
 
     def __init__(self, mismatch_action=None, min_qual_difference=1):
-        self.mismatch_action = mismatch_action
-        self.r1r2_min_qual_difference = min_qual_difference
-        self.r2r1_min_qual_difference = -1 * min_qual_difference
-        self.corrected_pairs = 0
-        self.corrected_bp = [0, 0]
+        self.mismatch_action, self.corrected_pairs, self.corrected_bp = mismatch_action, 0, [0, 0]
+        # quality lead read 1 needs over read 2 (and read 2 over read 1, as a negative number) to win a mismatch
+        self.r1r2_min_qual_difference, self.r2r1_min_qual_difference = min_qual_difference, -min_qual_difference
 
     def correct_errors(self, read1, read2, insert_match, truncate_seqs=False):
         """Correct errors in one pair of overlapping reads (a batch of one on the device)."""
@@ -237,149 +206,122 @@ class ErrorCorrectorMixin(object):
                     read.qualities = quals[k, :ln].tobytes().decode('latin-1')
 
     def summarize(self):
-        return dict(records_corrected=self.corrected_pairs, bp_corrected=self.corrected_bp)
+        return {"records_corrected": self.corrected_pairs, "bp_corrected": self.corrected_bp}
+
+
+def _mirrored(match, read_len):
+    """A lone adapter match of one read carried over to its mate of length ``read_len`` (the
+    adapter is assumed to start at the same position in both reads): None when the mate is too
+    short to reach it; ends at the mate's end when the mate is the shorter read ('matches' and
+    'errors' are then those of the original, as in the reference :421-431)."""
+    if match.rstart > read_len:
+        return None
+    twin = match.copy()
+    overhang = twin.rstop - read_len
+    if overhang < 0:
+        twin.astop += overhang
+        twin.rstop = read_len
+    return twin
 
 
 class InsertAdapterCutter(ReadPairModifier, ErrorCorrectorMixin):
     """AdapterCutter that uses InsertAligner to first try to identify the insert overlap
-    before falling back to semi-global adapter alignment.
+    before falling back to semi-global adapter alignment (reference modifiers.py:359-509).
 
     Args:
         adapter1, adapter2: Adapters.
-        action: 'trim', 'mask', 'lower' or None.
+        action: 'trim', 'mask' or None.
         mismatch_action: see ErrorCorrectorMixin.
         symmetric: assume the adapter appears at the same place in both reads.
         min_insert_overlap: minimum overlap of the reads for an insert match.
         aligner_args: further arguments of InsertAligner.
+
+    ``call_batch`` does the work in stages over all pairs (insert matching, the two adapters'
+    own alignments for the pairs without an insert match, error correction, trimming);
+    ``cutter(read1, read2)`` is a batch of one.
     """
 
     def __init__(self, adapter1, adapter2, action='trim', mismatch_action=None, symmetric=True,
                  min_insert_overlap=1, **aligner_args):
         ErrorCorrectorMixin.__init__(self, mismatch_action)
-        self.adapter1 = adapter1
-        self.adapter2 = adapter2
-        self.aligner = InsertAligner(adapter1.sequence, adapter2.sequence, min_insert_overlap=min_insert_overlap,
-                                     **aligner_args)
-        self.min_insert_len = min_insert_overlap
-        self.action = action
-        self.symmetric = symmetric
+        self.adapter1, self.adapter2 = adapter1, adapter2
+        self.min_insert_len = aligner_args["min_insert_overlap"] = min_insert_overlap
+        self.aligner = InsertAligner(*(a.sequence for a in (adapter1, adapter2)), **aligner_args)
+        self.action, self.symmetric = action, symmetric
         self.with_adapters = [0, 0]
 
-    # -- the decision logic between the alignment stages (modifiers.py:397-446) ----------
-    def _plan(self, read_lengths, match, fallback):
-        """Given the insert match (or None) and, for the fallback, the two adapter matches,
-        return (insert_match_for_correction or None, adapter_match1, adapter_match2)."""
-        insert_match = None
-        correct_errors = False
-        if match:
-            insert_match, adapter_match1, adapter_match2 = match
-            correct_errors = self.mismatch_action is not None and insert_match[5] > 0
+    def _plan(self, lengths, insert_result, fallback):
+        """What to do with one pair: ``(overlap to error-correct or None, match1, match2)``, from the
+        insert aligner's result or -- without one -- the two adapters' own matches (:397-446)."""
+        fix = self.mismatch_action
+        overlap, correct = None, False
+        if insert_result:
+            overlap, match1, match2 = insert_result
+            correct = fix is not None and overlap[5] > 0
         else:
-            adapter_match1, adapter_match2 = fallback
-            # complementary adapter matches: perform error correction
-            if (self.mismatch_action and adapter_match1 and adapter_match2 and
-                    adapter_match1.rstart == adapter_match2.rstart):
-                insert_match = (read_lengths[1] - adapter_match1.rstart, read_lengths[1], 0, adapter_match1.rstart)
-                correct_errors = True
-        # exactly one of the two alignments failed and symmetric: duplicate the good one
-        if self.symmetric and sum(bool(m) for m in (adapter_match1, adapter_match2)) == 1:
-
-            def create_symmetric_match(match, read_len):
-                if match.rstart > read_len:
-                    return None
-                match = match.copy()
-                # unequal read lengths: end the match at the read end ('matches'/'errors'
-                # are then off, as in the reference)
-                if match.rstop < read_len:
-                    match.astop -= (read_len - match.rstop)
-                    match.rstop = read_len
-                return match
-
-            if adapter_match1:
-                adapter_match2 = create_symmetric_match(adapter_match1, read_lengths[1])
+            match1, match2 = fallback
+            # both adapters found at the same position: the reads overlap completely before it
+            if fix and match1 and match2 and match1.rstart == match2.rstart:
+                overlap, correct = self._overlap_before(match1, lengths), True
+        if self.symmetric and (match1 is None) != (match2 is None):
+            if match2 is None:
+                match2 = _mirrored(match1, lengths[1])
             else:
-                adapter_match1 = create_symmetric_match(adapter_match2, read_lengths[0])
-            if self.mismatch_action and not insert_match and adapter_match1 and adapter_match2:
-                insert_match = (read_lengths[1] - adapter_match1.rstart, read_lengths[1], 0, adapter_match1.rstart)
-                correct_errors = True
-        return (insert_match if correct_errors else None), adapter_match1, adapter_match2
+                match1 = _mirrored(match2, lengths[0])
+            if fix and not overlap and match1 and match2:
+                overlap, correct = self._overlap_before(match1, lengths), True
+        return (overlap if correct else None), match1, match2
+
+    @staticmethod
+    def _overlap_before(match1, lengths):
+        """The insert-match coordinates implied by an adapter starting at match1.rstart in both reads."""
+        return (lengths[1] - match1.rstart, lengths[1], 0, match1.rstart)
 
     def __call__(self, read1, read2):
-        read_lengths = [len(r) for r in (read1, read2)]
-        if any(l < self.min_insert_len for l in read_lengths):
-            return (read1, read2)
-        match = self.aligner.match_insert(read1.sequence, read2.sequence)
-        read1.insert_overlap = read2.insert_overlap = (match is not None)
-        fallback = None
-        if not match:
-            fallback = (self.adapter1.match_to(read1), self.adapter2.match_to(read2))
-        to_correct, adapter_match1, adapter_match2 = self._plan(read_lengths, match, fallback)
-        if to_correct is not None:
-            self.correct_errors(read1, read2, to_correct, truncate_seqs=True)
-        return (self.trim(read1, self.adapter1, adapter_match1, 0), self.trim(read2, self.adapter2, adapter_match2, 1))
+        return self.call_batch([read1], [read2])[0]
 
     def call_batch(self, reads1, reads2):
-        """Batched twin of ``__call__``: stage 1 insert matching of all pairs in one GPU
-        call, stage 2 the two adapters' semi-global alignment over the pairs without an
-        insert match, stage 3 error correction of the flagged pairs in one GPU call, then
-        per-read trimming on the host.  Returns the list of (read1, read2) results."""
-        n = len(reads1)
-        out = [None] * n
-        act = [i for i in range(n) if not any(len(r) < self.min_insert_len for r in (reads1[i], reads2[i]))]
-        act_set = set(act)
-        for i in range(n):
-            if i not in act_set:
-                out[i] = (reads1[i], reads2[i])
+        """Returns the list of (read1, read2) results."""
+        out = [(a, b) for a, b in zip(reads1, reads2)]
+        act = [i for i, (a, b) in enumerate(out) if min(len(a), len(b)) >= self.min_insert_len]     # :392-394
         if not act:
             return out
-        width = max(max(len(reads1[i]), len(reads2[i])) for i in act)
-        b1 = self.aligner.pack([reads1[i].sequence for i in act] + ["A" * width])
-        b2 = self.aligner.pack([reads2[i].sequence for i in act] + ["A" * width], check=True)
-        results = self.aligner.match_insert_batch(b1, b2).results()[:-1]
+        results = self.aligner.match_insert_batch([reads1[i].sequence for i in act],
+                                                  [reads2[i].sequence for i in act]).results()
         miss = [k for k, r in enumerate(results) if r is None]
         fb1 = self.adapter1.match_to_batch([reads1[act[k]] for k in miss]) if miss else []
         fb2 = self.adapter2.match_to_batch([reads2[act[k]] for k in miss]) if miss else []
-        fallback = {k: (a, b) for k, a, b in zip(miss, fb1, fb2)}
+        fallback = dict(zip(miss, zip(fb1, fb2)))
         plans = []
         for k, i in enumerate(act):
             reads1[i].insert_overlap = reads2[i].insert_overlap = (results[k] is not None)
             plans.append(self._plan([len(reads1[i]), len(reads2[i])], results[k], fallback.get(k)))
         self.correct_errors_batch([reads1[i] for i in act], [reads2[i] for i in act], [p[0] for p in plans],
                                   truncate_seqs=True)
-        for k, i in enumerate(act):
-            out[i] = (self.trim(reads1[i], self.adapter1, plans[k][1], 0),
-                      self.trim(reads2[i], self.adapter2, plans[k][2], 1))
+        for (_, match1, match2), i in zip(plans, act):
+            out[i] = (self.trim(reads1[i], self.adapter1, match1, 0), self.trim(reads2[i], self.adapter2, match2, 1))
         return out
 
     def trim(self, read, adapter, match, read_idx):
-        """Trim an adapter from a read according to the match."""
-        if not match:
-            read.match = None
-            read.match_info = None
+        """Trim (or mask, or just annotate) one read of a pair according to its match."""
+        if match is None:
+            read.match = read.match_info = None
             return read
-        match.adapter = adapter
-        match.read = read
-        match.front = False
-        if self.action is None or match.rstart >= len(read):
-            trimmed_read = read
-        else:
-            trimmed_read = adapter.trimmed(match)
+        match.adapter, match.read, match.front = adapter, read, False
+        result = read
+        if self.action is not None and match.rstart < len(read):
+            result = adapter.trimmed(match)
             if self.action == 'mask':
-                masked_sequence = trimmed_read.sequence
-                masked_sequence += 'N' * (len(read) - len(trimmed_read))
-                trimmed_read.sequence = masked_sequence
-                trimmed_read.qualities = read.qualities
-        trimmed_read.match = match
-        trimmed_read.match_info = [match.get_info_record()]
+                result.sequence = result.sequence + 'N' * (len(read) - len(result))
+                result.qualities = read.qualities
+        result.match, result.match_info = match, [match.get_info_record()]
         self.with_adapters[read_idx] += 1
-        return trimmed_read
+        return result
 
     def summarize(self):
-        adapters_summary = tuple({adapter.name: adapter.summarize()} for adapter in (self.adapter1, self.adapter2))
-        summary = dict(records_with_adapters=self.with_adapters, adapters=adapters_summary)
-        if self.mismatch_action:
-            summary.update(ErrorCorrectorMixin.summarize(self))
-        return summary
+        parts = (self.adapter1, self.adapter2)
+        summary = {"records_with_adapters": self.with_adapters, "adapters": tuple({a.name: a.summarize()} for a in parts)}
+        return dict(summary, **ErrorCorrectorMixin.summarize(self)) if self.mismatch_action else summary
 
 
 class MergeOverlapping(ReadPairModifier, ErrorCorrectorMixin):
@@ -390,9 +332,9 @@ class MergeOverlapping(ReadPairModifier, ErrorCorrectorMixin):
 
     def __init__(self, min_overlap=0.9, error_rate=0.1, mismatch_action=None):
         ErrorCorrectorMixin.__init__(self, mismatch_action)
-        self.min_overlap = int(min_overlap) if min_overlap > 1 else min_overlap
-        self.error_rate = error_rate
-        self._aligners = {}
+        # above 1: a number of bases; up to 1: a fraction of the shorter read
+        self.min_overlap = min_overlap if min_overlap <= 1 else int(min_overlap)
+        self.error_rate, self._aligners = error_rate, {}
 
     def _aligner(self, flags):
         if flags not in self._aligners:
@@ -402,21 +344,24 @@ class MergeOverlapping(ReadPairModifier, ErrorCorrectorMixin):
     def __call__(self, read1, read2):
         return self.call_batch([read1], [read2])[0]
 
+    def _required_overlap(self, len1, len2):
+        """The overlap in bases a pair of these lengths needs (a fraction <= 1 is relative to the shorter read)."""
+        if self.min_overlap > 1:
+            return self.min_overlap
+        return max(2, round(self.min_overlap * min(len1, len2)))
+
     def call_batch(self, reads1, reads2):
         """Batched twin of ``__call__``: returns the list of (read1, read2-or-None) pairs."""
         out = [(r1, r2) for r1, r2 in zip(reads1, reads2)]
-        plan = {}                                            # flags -> [(index, min_overlap)]
+        plan = {}                                            # flags -> [(index, required overlap, insert matched)]
         for i, (read1, read2) in enumerate(out):
-            len1, len2 = len(read1.sequence), len(read2.sequence)
-            min_overlap = self.min_overlap
-            if min_overlap <= 1:
-                min_overlap = max(2, round(self.min_overlap * min(len1, len2)))
-            if len1 < min_overlap or len2 < min_overlap:
+            need = self._required_overlap(len(read1.sequence), len(read2.sequence))
+            if min(len(read1.sequence), len(read2.sequence)) < need:
                 continue
-            insert_matched = read1.insert_overlap and read2.insert_overlap
+            insert_matched = bool(read1.insert_overlap and read2.insert_overlap)
             # an insert overlap with a 3' overhang was already found: constrain the alignment
             flags = (align.START_WITHIN_SEQ1 | align.STOP_WITHIN_SEQ2) if insert_matched else align.SEMIGLOBAL
-            plan.setdefault(flags, []).append((i, min_overlap, bool(insert_matched)))
+            plan.setdefault(flags, []).append((i, need, insert_matched))
         for flags, todo in plan.items():
             idx = [t[0] for t in todo]
             for i in idx:
@@ -424,36 +369,36 @@ class MergeOverlapping(ReadPairModifier, ErrorCorrectorMixin):
             # reference = reverse_complement(read2) (formed on the device), query = read1
             alignments = self._aligner(flags).locate_batch([out[i][1].sequence for i in idx],
                                                            [out[i][0].sequence for i in idx]).tuples()
-            for (i, min_overlap, insert_matched), alignment in zip(todo, alignments):
-                if alignment:
-                    out[i] = self._merge(out[i][0], out[i][1], alignment, min_overlap, insert_matched)
+            for (i, need, insert_matched), alignment in zip(todo, alignments):
+                if alignment and alignment[4] >= need:
+                    out[i] = self._merge(out[i][0], out[i][1], alignment, insert_matched)
         return out
 
-    def _merge(self, read1, read2, alignment, min_overlap, insert_matched):
-        len1, len2 = len(read1.sequence), len(read2.sequence)
-        read2_rc = reverse_complement(read2.sequence)
-        r2_start, r2_stop, r1_start, r1_stop, matches, errors = alignment
-        if matches < min_overlap:
-            return (read1, read2)
+    def _merge(self, read1, read2, alignment, insert_matched):
+        """Join read 1 and the reverse complement of read 2 along ``alignment`` (read 2 is the
+        reference, read 1 the query); the merged read replaces read 1 (:896-931)."""
+        ref_start, ref_stop, qry_start, qry_stop, _matches, errors = alignment
+        mate = reverse_complement(read2.sequence)            # as it is BEFORE any correction, like the reference (:896)
         # only correct errors if that was not already done by the insert aligner
         if self.mismatch_action and errors > 0 and not insert_matched:
             self.correct_errors(read1, read2, alignment)
-        if r2_start == 0 and r2_stop == len2:
-            pass                                             # r2 is fully contained in r1
-        elif r1_start == 0 and r1_stop == len1:
-            read1.sequence = read2_rc                        # r1 is fully contained in r2
-            read1.qualities = "".join(reversed(read2.qualities))
-        elif r1_start > 0:
-            read1.sequence += read2_rc[r2_stop:]
-            if read1.qualities and read2.qualities:
-                read1.qualities += "".join(reversed(read2.qualities))[r2_stop:]
-        elif r2_start > 0:
-            read1.sequence = read2_rc + read1.sequence[r1_stop:]
-            if read1.qualities and read2.qualities:
-                read1.qualities = "".join(reversed(read2.qualities)) + read1.qualities[r1_stop:]
+        both_quals = bool(read1.qualities and read2.qualities)
+        mate_quals = read2.qualities[::-1] if read2.qualities is not None else None
+        if ref_start == 0 and ref_stop == len(read2.sequence):
+            pass                                                 # read 2 lies inside read 1
+        elif qry_start == 0 and qry_stop == len(read1.sequence):
+            read1.sequence = mate                                # read 1 lies inside read 2
+            read1.qualities = read2.qualities[::-1]              # TypeError without qualities, like the reference
+        elif qry_start > 0:                                      # read 2 continues read 1 to the right
+            read1.sequence = read1.sequence + mate[ref_stop:]
+            if both_quals:
+                read1.qualities = read1.qualities + mate_quals[ref_stop:]
+        elif ref_start > 0:                                      # read 2 starts left of read 1
+            read1.sequence = mate + read1.sequence[qry_stop:]
+            if both_quals:
+                read1.qualities = mate_quals + read1.qualities[qry_stop:]
         else:
             raise ValueError("Invalid alignment while trying to merge read {}: {}".format(
-                read1.name, ",".join(str(i) for i in alignment)))
+                read1.name, ",".join(map(str, alignment))))
         read1.merged = True
         return (read1, None)
-

@@ -1,53 +1,63 @@
-"""The read record the boundary objects operate on: same attributes and slicing
-behaviour as the reference's ``Sequence`` (atropos/io/_seqio.pyx:7-161).  FASTQ/FASTA
-parsing is out of scope; any object with these attributes
-(including the reference's own ``Sequence``) can be handed to the adapters and cutters."""
+"""A minimal read record for the per-read (batch-of-one) entry points and the tests.
+
+The batched pipelines never build one of these (they work on device-resident FASTQ chunks,
+``atropos_amd.fastq``); the boundary objects accept ANY object with ``name``, ``sequence``,
+``qualities`` and slicing -- the reference's own ``Sequence`` (atropos/io/_seqio.pyx:7-161)
+included.  FASTQ/FASTA parsing into such objects is out of scope.
+"""
+# bookkeeping the trimming modifiers attach to a read, with the value a fresh read starts with
+_STATE = (("match", None), ("match_info", None), ("insert_overlap", False), ("merged", False), ("corrected", 0))
 
 
-class Sequence(object):
-    """A FASTQ/FASTA record: name, sequence, qualities (``None`` for FASTA) plus the
-    bookkeeping slots the trimming modifiers fill in (match, match_info, clipped,
-    insert_overlap, merged, corrected)."""
+class Read(object):
+    """name, sequence, qualities (``None`` when there are none) + the modifiers' bookkeeping.
+    ``read[a:b]`` is the same read with sequence and qualities sliced."""
 
-    __slots__ = ("name", "sequence", "qualities", "name2", "original_length", "match", "match_info", "clipped",
-                 "insert_overlap", "merged", "corrected")
+    __slots__ = ("name", "sequence", "qualities", "name2", "original_length", "clipped") + tuple(k for k, _ in _STATE)
 
-    def __init__(self, name, sequence, qualities=None, name2='', original_length=None, match=None, match_info=None,
-                 clipped=None, insert_overlap=False, merged=False, corrected=0):
+    def __init__(self, name, sequence, qualities=None, name2="", original_length=None, clipped=None, **state):
         if qualities is not None and len(qualities) != len(sequence):
-            raise ValueError(
-                "In read named {0!r}: length of quality sequence ({1}) and length of read ({2}) do not "
-                "match".format(name, len(qualities), len(sequence)))
-        self.name = name
-        self.sequence = sequence
-        self.qualities = qualities
-        self.name2 = name2
-        self.original_length = original_length or len(sequence)
-        self.match = match
-        self.match_info = match_info
-        self.clipped = clipped or [0, 0, 0, 0]
-        self.insert_overlap = insert_overlap
-        self.merged = merged
-        self.corrected = corrected
-
-    def __getitem__(self, key):
-        return self.__class__(
-            self.name, self.sequence[key], self.qualities[key] if self.qualities is not None else None, self.name2,
-            self.original_length, self.match, self.match_info, list(self.clipped), self.insert_overlap, self.merged,
-            self.corrected)
+            raise ValueError("read %r: %d bases but %d quality values" % (name, len(sequence), len(qualities)))
+        self.name, self.name2 = name, name2
+        self.sequence, self.qualities = sequence, qualities
+        self.original_length = len(sequence) if not original_length else original_length
+        self.clipped = list(clipped) if clipped else [0, 0, 0, 0]
+        for key, fresh in _STATE:
+            setattr(self, key, state.pop(key, fresh))
+        if state:
+            raise TypeError("unexpected arguments: %s" % ", ".join(sorted(state)))
 
     def __len__(self):
-        return len(self.sequence)
+        bases = self.sequence
+        return len(bases)
+
+    def __getitem__(self, key):
+        part = Read.__new__(type(self))
+        for slot in Read.__slots__:
+            setattr(part, slot, getattr(self, slot))
+        part.clipped = list(self.clipped)
+        part.sequence = self.sequence[key]
+        if self.qualities is not None:
+            part.qualities = self.qualities[key]
+        return part
+
+    def _key(self):
+        return tuple(getattr(self, slot) for slot in ("name", "sequence", "qualities"))
 
     def __eq__(self, other):
-        return (self.name == other.name and self.sequence == other.sequence and self.qualities == other.qualities)
+        return self._key() == Read._key(other)
 
     def __ne__(self, other):
-        return not self.__eq__(other)
+        return not self == other
+
+    __hash__ = None
 
     def __repr__(self):
-        q = '' if self.qualities is None else ', qualities={0!r}'.format(self.qualities)
-        return '<Sequence(name={0!r}, sequence={1!r}{2})>'.format(self.name, self.sequence, q)
+        shown = [repr(self.name), repr(self.sequence)] + ([] if self.qualities is None else [repr(self.qualities)])
+        return "Read(%s)" % ", ".join(shown)
 
     def __reduce__(self):
-        return (Sequence, (self.name, self.sequence, self.qualities, self.name2))
+        return (Read, self._key() + (self.name2,))
+
+
+Sequence = Read          # the reference's name for it

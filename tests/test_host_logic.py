@@ -11,10 +11,12 @@ def test_rmp_matches_reference_values():
         assert repr(RandomMatchProbability()(k, size, p, q)) == rep
         if (p, q) == (0.25, 0.75):
             assert repr(R(k, size)) == rep        # shared cache, as the trim command uses it
-    assert R.factorial(0) == 1 and R.factorial(1) == 1 and R.factorial(3) == 6
-    import math
-    assert R.factorial(150) == math.factorial(150)
-    assert R(3, 5) == 0.103515625
+    assert R(3, 5) == 0.103515625 and R(0, 0) == 1.0 and R(6, 5) == 0.0
+    from atropos_amd.util import rmp_table, tail_row
+    table = rmp_table(R, 40)
+    for k, size, p, q, rep in load_golden("rmp.json"):
+        if (p, q) == (0.25, 0.75) and size <= 40:
+            assert repr(float(table[size, k])) == rep and repr(float(tail_row(size)[k])) == rep
 
 
 def test_reverse_complement():

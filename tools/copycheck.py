@@ -52,13 +52,24 @@ def reference_grams(ref_dir, run):
     return grams
 
 
-def share(path, grams, run):
+def share(path, grams, run, show=False):
     t = tokens_of(path)
     hit = [False] * len(t)
     for i in range(len(t) - run + 1):
         if hash(tuple(t[i:i + run])) in grams:
             for k in range(i, i + run):
                 hit[k] = True
+    if show:
+        i = 0
+        while i < len(t):
+            if hit[i]:
+                j = i
+                while j < len(t) and hit[j]:
+                    j += 1
+                print("    [%d tokens] %s" % (j - i, " ".join(t[i:j])[:300]))
+                i = j
+            else:
+                i += 1
     return (sum(hit) / len(t) if t else 0.0), len(t)
 
 
@@ -66,6 +77,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--run", type=int, default=12)
     ap.add_argument("--ref", default="/root/reference/atropos")
+    ap.add_argument("--show", action="store_true", help="print the matching token runs")
     ap.add_argument("files", nargs="*")
     args = ap.parse_args()
     files = args.files
@@ -75,7 +87,7 @@ def main():
     grams = reference_grams(args.ref, args.run)
     worst = 0.0
     for f in sorted(files):
-        s, n = share(f, grams, args.run)
+        s, n = share(f, grams, args.run, args.show)
         worst = max(worst, s)
         print("%5.1f %%  %6d tokens  %s" % (100 * s, n, os.path.relpath(f, ROOT)))
     print("worst: %.1f %%" % (100 * worst))
