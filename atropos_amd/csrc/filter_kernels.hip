@@ -54,20 +54,26 @@ static const window_group_fn window_groups[4] = {window_group_0, window_group_1,
 // K2a + K2b over wk.nbins bins
 void launch_fast_scan(FastWork wk, hipStream_t st) {
     hipLaunchKernelGGL(scan_bins_kernel, dim3(wk.nbins), dim3(1024), 0, st, wk);
-    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(128), 0, st, wk);
+    hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1024), 0, st, wk);
 }
 
-// K4a (side stream) and K4 (main stream) over the reads `order` lists for one aligner; la != nullptr:
-// the 3' part of one adapter of a linked set (bins la->bin0 ..).  fork: first call of a pipeline
-// (the side stream starts waiting for the main stream's scatter pass); join: last call.
+// K4a and K4 over the reads `order` lists for one aligner; la != nullptr: the 3' part of adapter
+// `idx` of a linked set of `count` adapters (bins la->bin0 ..).  K4a runs on a side stream next to
+// K4 (its waves are latency bound: three dependent gathers per task -- they share the SIMDs with
+// K4's instead of running before them); the K4 launches of the adapters of a linked set are
+// independent of each other (disjoint slots of `order`, disjoint records) and go to one stream each,
+// so that their tails overlap.  idx == 0 forks the side streams off `st` (they wait for the scatter
+// pass), idx == count - 1 joins them again; events only, legal inside a stream capture.
+constexpr int DP_STREAMS = 4;                            // >= LINKED_MAX: band stream + one per further adapter
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, bool fork, bool join, hipStream_t st) {
-    static thread_local SideStream side;
-    if (!side.ready()) return (int)hipErrorInvalidValue;
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st) {
+    static thread_local SideStream side[DP_STREAMS];
+    if (count < 1 || count > DP_STREAMS || idx < 0 || idx >= count) return (int)hipErrorInvalidValue;
     hipError_t e = hipSuccess;
-    if (fork) {
-        e = hipEventRecord(side.fork, st);
-        if (e == hipSuccess) e = hipStreamWaitEvent(side.stream, side.fork, 0);
+    if (idx == 0) {
+        for (int k = 0; k < count; ++k) if (!side[k].ready()) return (int)hipErrorInvalidValue;
+        e = hipEventRecord(side[0].fork, st);
+        for (int k = 0; k < count && e == hipSuccess; ++k) e = hipStreamWaitEvent(side[k].stream, side[0].fork, 0);
         if (e != hipSuccess) return (int)e;
     }
     const dim3 block(256);
@@ -75,22 +81,25 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         const BandParams bp = band_params(a);
         const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 4096));
         if (la) {
-            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
-            else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+            else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
         } else {
             const LinkedArgs none = no_linked_args();
-            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
-            else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, block, 0, side.stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
         }
     }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
-    const int rc = window_groups[idx / 4](idx % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st);
+    const int mt = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    const int rc = window_groups[mt / 4](mt % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la,
+                                                 idx == 0 ? st : side[idx].stream);
     if (rc != 0) return rc;
-    if (join) {
-        e = hipEventRecord(side.join, side.stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, side.join, 0);
+    if (idx == count - 1) {
+        for (int k = 0; k < count && e == hipSuccess; ++k) {
+            e = hipEventRecord(side[k].join, side[k].stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, side[k].join, 0);
+        }
     }
     return (int)e;
 }
@@ -113,7 +122,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
     // joined after K4, so that its waves (latency bound: three dependent gathers per task) share
     // the SIMDs with K4's instead of running before them.
-    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, true, true, st);
+    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, 0, 1, st);
 }
 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,

@@ -9,10 +9,11 @@
 // (:338-400).  Here ONE pass over the packed batch does all of it per read (one read per lane):
 //
 //   front stage   every 5' adapter against the first m + k bases: literal compare (the shortcut),
-//                 then a 32-bit Myers sweep of the anchored unit-cost matrix (row 0 costs j: the
-//                 alignment must start at (0, 0)); only (read, adapter) pairs that have an
-//                 acceptable row-m cell but no literal occurrence run the exact banded DP
-//                 (filter_core.hpp, band_locate_prefix), each lane against its OWN adapter.
+//                 then an exact-piece test (the adapter cut into k + 1 pieces: an alignment with at
+//                 most k errors leaves one of them intact, at most k bases off its place); only
+//                 (read, adapter) pairs that pass it without a literal occurrence run the exact
+//                 banded DP (filter_core.hpp, band_locate_prefix) -- collected over several tiles
+//                 and run densely, each lane against its OWN (read, adapter) task.
 //   back stage    the read keeps the lane; the 3' adapter of the front that matched is swept with
 //                 the bit-parallel pre-pass of filter_core.hpp, match masks and thresholds fetched
 //                 from the lane's own adapter block in LDS.  read[front.rstop:] is not re-packed:
@@ -31,16 +32,19 @@ namespace atr {
 
 constexpr int LINKED_MAX = 4;                       // linked adapters per set
 constexpr int FRONT_MAX_M = 32;                     // 5' part: m + int(e*m) <= 32 -- chunk 0 holds every column it can touch
+constexpr int FRONT_STREAM = 2 + FRONT_MAX_M / 8 + 1;  // stream dwords band_rows reads for m <= 32 (two for the window + one per eight rows)
 
 // One anchored 5' adapter.  Plain data: uploaded once per set, copied to LDS by every workgroup.
+constexpr int FRONT_MAX_PIECES = 8;                 // k + 1 <= 8 (2k + 1 <= BAND_W)
 struct FrontParams {
-    uint32_t peq[16];                               // bit i - 1: row i matches query code c
+    uint32_t pex_code[FRONT_MAX_PIECES], pex_mask[FRONT_MAX_PIECES];   // the k + 1 pieces (<= 8 bases each) as nibbles + masks
+    int32_t pex_off[FRONT_MAX_PIECES];              // adapter offset of each piece
     uint32_t code[4], code_mask[4];                 // the adapter as packed nibbles + the mask of its m nibbles (literal compare)
     uint32_t rrep[FRONT_MAX_M];                     // code of row i in all eight nibbles (banded DP)
     int16_t thr[FRONT_MAX_M + 2];                   // floor(L * e): the DP's candidate test (_align.pyx:447, :468)
     int16_t pf_thr[FRONT_MAX_M + 2];                // largest c with c / L <= e in double DIVISION: match_to's own test (:386-398)
     int32_t m, k, min_overlap, indel;               // indel: effective cost min(indel_cost, k + 1)
-    int32_t noindel, accept_full, group, reserved;  // accept_full: the literal shortcut applies (:351-367)
+    int32_t noindel, accept_full, group, npieces;   // accept_full: the literal shortcut applies (:351-367)
 };
 
 // One regular 3' adapter as the pre-pass sees it (FilterParams with the thresholds in memory).
@@ -123,32 +127,81 @@ ATR_DEV bool front_exact(const uint32_t *code, const uint32_t *code_mask, const 
     return x == 0u;
 }
 
-// Myers / Hyyro sweep of the ANCHORED unit-cost matrix: D[i][0] = i, D[0][j] = j (the horizontal
-// delta entering row 1 is +1 in every column), rows at bits 0 .. m - 1.  Lower bound of the
-// reference's costs for any indel cost, equal to them for indel cost 1.
-struct FrontState {
-    uint32_t pv, mv;
-    int score, best;                                // D[m][j], min over the swept columns
-};
-ATR_DEV void front_init(FrontState &S, int m) {
-    S.pv = m >= 32 ? ~0u : ((1u << m) - 1u);
-    S.mv = 0u;
-    S.score = m; S.best = m;
+// Exact-piece filter (Navarro / Baeza-Yates partitioning): the alignment of an anchored 5' adapter
+// starts at (0, 0) and may hold at most k edit operations (every mismatch, insertion or deletion
+// costs at least 1); cut into k + 1 pieces, one piece is free of them and therefore occurs
+// verbatim in the read, displaced from its adapter offset by the insertions minus the deletions
+// before it -- at most k either way.  Necessary for ANY acceptable alignment, whatever the indel
+// cost; what passes goes to the exact DP.  t = read offset (0-based) of the eight-base window.
+ATR_DEV uint32_t chunk_window(const uint32_t w[4], int t) {                  // t wave-uniform, 0 .. 31
+    const uint32_t sh = 4u * (uint32_t)(t & 7);
+    uint32_t lo, hi;
+    switch (t >> 3) {
+        case 0: lo = w[0]; hi = w[1]; break;
+        case 1: lo = w[1]; hi = w[2]; break;
+        case 2: lo = w[2]; hi = w[3]; break;
+        default: lo = w[3]; hi = 0u; break;
+    }
+#ifdef ATR_HOST_EMU
+    return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#endif
 }
-ATR_DEV void front_step(FrontState &S, uint32_t eq, int m) {
-    const uint32_t xv = eq | S.mv;
-    const uint32_t xh = (((eq & S.pv) + S.pv) ^ S.pv) | eq;
-    uint32_t ph = S.mv | ~(xh | S.pv);
-    uint32_t mh = S.pv & xh;
-    S.score += (int)((ph >> (m - 1)) & 1u) - (int)((mh >> (m - 1)) & 1u);
-    ph = (ph << 1) | 1u;
-    mh <<= 1;
-    S.pv = mh | ~(xv | ph);
-    S.mv = ph & xv;
-    S.best = atr_min(S.best, S.score);
+template <bool AND_MODE>
+ATR_DEV bool front_pex_candidate(const uint32_t *pex_code, const uint32_t *pex_mask, const int32_t *pex_off, int npieces,
+                                 int k, const uint32_t w[4]) {
+    uint32_t best = ~0u;                                                     // 0 <=> some piece occurs
+    for (int p = 0; p < npieces; ++p) {
+        const uint32_t code = pex_code[p], mask = pex_mask[p];
+        const int off = pex_off[p];
+        for (int d = -k; d <= k; ++d) {
+            const int t = off + d;
+            if (t < 0 || t > 31) continue;
+            const uint32_t win = chunk_window(w, t);
+            // literal: every base equal; wildcards: every position shares a bit
+            const uint32_t bad = AND_MODE ? (~nibble_any(win & code)) & (mask & 0x88888888u) : (win ^ code) & mask;
+            best = atr_minu(best, bad);
+        }
+    }
+    return best == 0u;
 }
-// query code of column j (1-based) out of the read's first chunk
-ATR_DEV uint32_t chunk_code(const uint32_t w[4], int j) { return (w[(j - 1) >> 3] >> (4 * ((j - 1) & 7))) & 15u; }
+
+// Result of the 5' stage of one read in one word (anchored: refstart = querystart = 0, refstop = m):
+//   [31:24] adapter index   [23:16] querystop   [15:8] matches   [7:0] errors;  all ones: no match.
+// The smallest word belongs to the first matching adapter.
+constexpr uint32_t FRONT_NONE = ~0u;
+ATR_DEV uint32_t front_word(int a, int querystop, int matches, int errors) {
+    return ((uint32_t)a << 24) | ((uint32_t)querystop << 16) | ((uint32_t)matches << 8) | (uint32_t)errors;
+}
+ATR_DEV uint32_t front_word_of(int a, const uint32_t rec[4]) {
+    return front_word(a, (int)(rec[1] >> 16), (int)(rec[2] & 0xFFFFu), (int)(rec[2] >> 16));
+}
+ATR_DEV void front_word_record(uint32_t word, int m, uint32_t rec[4]) {
+    if (word == FRONT_NONE) { rec_none(rec); return; }
+    rec[0] = (uint32_t)m << 16;
+    rec[1] = ((word >> 16) & 0xFFu) << 16;
+    rec[2] = ((word >> 8) & 0xFFu) | ((word & 0xFFu) << 16);
+    rec[3] = 0u;
+}
+
+// The read's first bases staged for the banded DP (band_stage with dlo = -k, from the first chunk
+// only: m + k <= 32): stream dword z holds bases 1 - k + 8z .. ; ns stride nss, FRONT_STREAM entries.
+ATR_DEV void front_stage(const uint32_t w[4], int k, uint32_t *ns, int nss) {
+    // bases -k+1 .. : an eight-base window that starts k bases before the read
+    const uint32_t ext[6] = {0u, w[0], w[1], w[2], w[3], 0u};
+    const uint32_t sh = 4u * (uint32_t)((8 - k) & 7);
+    const int first = k > 0 ? 0 : 1;                                         // k = 0: the stream starts at base 1
+#pragma unroll
+    for (int z = 0; z < FRONT_STREAM; ++z) {
+        uint32_t v = 0u;
+        if (z + first + 1 < 6) {
+            const uint32_t lo = ext[z + first], hi = ext[z + first + 1];
+            v = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+        }
+        ns[(size_t)z * nss] = v;
+    }
+}
 
 // wave-uniform parameters of a front adapter's DP group
 ATR_DEV Uniform front_uniform(int m, int k, int indel, int min_overlap) {

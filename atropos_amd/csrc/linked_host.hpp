@@ -53,6 +53,7 @@ inline uint64_t linked_peq(const atr_aligner *a, int code, int rows, int W) {
 inline bool linked_front_ok(const atr_aligner *f) {
     const int m = f->p.m, k = f->p.k;
     return f->flags == ATR_STOP_WITHIN_SEQ2 && k >= 0 && k < m && m + k <= FRONT_MAX_M && 2 * k + 1 <= BAND_W &&
+           k + 1 <= FRONT_MAX_PIECES &&
            f->table_kind != ATR_TABLE_CUSTOM;
 }
 inline bool linked_back_ok(const atr_aligner *b) {
@@ -89,13 +90,18 @@ inline int linked_fill(atr_linked_set *s, const atr_linked_adapter *ad, int n) {
         FrontParams &F = P.f[i];
         const int m = f->p.m;
         const bool eqmode = !(f->wildcard_ref || f->wildcard_query);
-        for (int c = 0; c < 16; ++c) {
-            uint32_t mask = 0;
-            for (int r = 0; r < m; ++r) {
-                const int rc = f->codes[r];
-                if (eqmode ? (rc == c) : ((rc & c) != 0)) mask |= 1u << r;
+        (void)eqmode;
+        {   // the k + 1 pieces of the exact-piece filter: nearly equal lengths, the first eight bases of each
+            const int np = f->p.k + 1;
+            F.npieces = np;
+            for (int pc = 0; pc < np; ++pc) {
+                const int lo = (int)((long long)m * pc / np), hi = (int)((long long)m * (pc + 1) / np);
+                F.pex_off[pc] = lo;
+                for (int r = lo; r < hi && r < lo + 8; ++r) {
+                    F.pex_code[pc] |= (uint32_t)(f->codes[r] & 15u) << (4 * (r - lo));
+                    F.pex_mask[pc] |= 15u << (4 * (r - lo));
+                }
             }
-            F.peq[c] = mask;
         }
         for (int r = 0; r < m; ++r) {
             F.code[r >> 3] |= (uint32_t)(f->codes[r] & 15u) << (4 * (r & 7));

@@ -23,7 +23,7 @@ namespace atr {
 
 void launch_fast_scan(FastWork wk, hipStream_t st);
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, bool fork, bool join, hipStream_t st);
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st);
 int hip_fail(hipError_t e, const char *what);
 
 struct LinkedBlob {
@@ -34,6 +34,46 @@ struct LinkedBlob {
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
 
+constexpr int LINKED_ROUND = 8;                      // tiles a wave takes through the 5' stage before their 3' stage
+constexpr int LINKED_TASKS = 512;                    // capacity of a wave's queue of (read, 5' adapter) DP tasks
+static_assert(LINKED_MAX * FILTER_BINS <= 1024, "scan_total_kernel scans at most 1024 bins");
+
+// The wave's queued DP tasks, 64 at a time, every lane against its own (read, adapter): the read's
+// first chunk is gathered again (L2), the banded DP runs once per DP group that has a task in the
+// pass, results are merged into the per-read words (smallest adapter index wins) and counters.
+template <bool RAGGED, bool AND_MODE>
+__device__ __forceinline__ void linked_drain(const LinkedBlob &S, int ngroups, const uint16_t *queue, int ntasks,
+                                             const uint4 *__restrict__ packed, const int32_t *__restrict__ lens,
+                                             long long tile_first, int nchunks, int max_len, uint32_t *s_word,
+                                             uint32_t *s_count, uint32_t *ns, int lane) {
+    for (int base = 0; base < ntasks; base += 64) {                           // wave-uniform
+        const bool valid = base + lane < ntasks;
+        const uint32_t task = valid ? (uint32_t)queue[base + lane] : 0u;      // [14:6] slot * 64 + lane  [1:0] adapter
+        const int a_l = (int)(task & 3u), cell = (int)(task >> 6);
+        const long long tile = tile_first + 4 * (cell >> 6);
+        const long long r = tile * 64 + (cell & 63);
+        const uint4 c0 = valid ? packed[(size_t)tile * nchunks * 64 + (cell & 63)] : make_uint4(0, 0, 0, 0);
+        const uint32_t w0[4] = {c0.x, c0.y, c0.z, c0.w};
+        const int n = valid ? (RAGGED ? lens[r] : max_len) : 0;
+        const FrontParams &mp = S.p.f[a_l];
+        const int grp = valid ? mp.group : -1;
+        for (int g = 0; g < ngroups; ++g) {
+            if (!wave_any(grp == g)) continue;
+            const FrontParams &gp = S.p.f[rfl(S.p.group_first[g])];
+            const Uniform u = front_uniform(rfl(gp.m), rfl(gp.k), rfl(gp.indel), rfl(gp.min_overlap));
+            front_stage(w0, u.k, ns, 64);
+            uint32_t rec[4];
+            const uint32_t *rr = (grp == g ? mp : gp).rrep;
+            band_locate_prefix_rr<AND_MODE>(u, [rr](int i) { return rr[i - 1]; }, rfl(gp.noindel) != 0, ns, 64, n, gp.thr, rec);
+            if (grp == g && front_accept(rec, u.m, u.min_overlap, mp.pf_thr, mp.accept_full != 0, S.rmp.front[a_l],
+                                         S.rmp.front_ld[a_l], S.rmp.front_max[a_l])) {
+                atomicMin(&s_word[cell], front_word_of(a_l, rec));
+                atomicAdd(&s_count[cell >> 2], 1u << (8 * (cell & 3)));
+            }
+        }
+    }
+}
+
 template <bool WIDE, bool RAGGED, bool AND_MODE>
 __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__restrict__ blob,
                                                             const uint4 *__restrict__ packed,
@@ -43,162 +83,148 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
                                                             FastWork wk) {
     __shared__ __attribute__((aligned(16))) LinkedBlob S;
     __shared__ uint32_t s_hist[LINKED_MAX * FILTER_BINS];
-    __shared__ uint32_t s_stream[4][BAND_STREAM][64];              // per wave: the staged read of the 5' banded DP
+    __shared__ uint32_t s_stream[4][FRONT_STREAM][64];             // per wave: the staged reads of the 5' banded DP
+    __shared__ uint32_t s_words[4][LINKED_ROUND * 64];             // per wave and read of the round: front word (linked_core.hpp)
+    __shared__ uint32_t s_counts[4][LINKED_ROUND * 16];            //                                  number of matching 5' parts (a byte each)
+    __shared__ uint16_t s_queue[4][LINKED_TASKS];
     for (int i = threadIdx.x; i < (int)(sizeof(LinkedBlob) / 4); i += 256) ((uint32_t *)&S)[i] = ((const uint32_t *)blob)[i];
     for (int i = threadIdx.x; i < LINKED_MAX * FILTER_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
 
     const int nad = rfl(S.p.n), ngroups = rfl(S.p.ngroups);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *s_word = s_words[wave], *s_count = s_counts[wave];
+    uint16_t *queue = s_queue[wave];
+    uint32_t *ns = &s_stream[wave][0][lane];
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
     block_tiles(ntiles, t0, t1);
-    for (long long tile = t0 + wave; tile < t1; tile += 4) {
-        const long long r = tile * 64 + lane;
-        const bool live = r < nreads;
-        const int n = live ? (RAGGED ? lens[r] : max_len) : 0;
-        const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
-        const uint4 c0v = tp[0];
-        const uint32_t w0[4] = {c0v.x, c0v.y, c0v.z, c0v.w};
-
-        // ---- 5' parts ------------------------------------------------------------------------------
-        int which = -1, count = 0;
-        uint32_t frec[4];
-        rec_none(frec);
-        uint32_t dpmask = 0;
-        for (int a = 0; a < nad; ++a) {                            // wave-uniform
-            const FrontParams &fp = S.p.f[a];
-            const int m = rfl(fp.m), k = rfl(fp.k), mk = m + k;
-            FrontState st;
-            front_init(st, m);
-            int j = 0;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                uint32_t w = w0[d];
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    ++j;
-                    if (j <= mk) {                                 // wave-uniform
-                        front_step(st, fp.peq[w & 15u], m);
-                        w >>= 4;
-                    }
-                }
+    for (long long tile_first = t0 + wave; tile_first < t1; tile_first += 4 * LINKED_ROUND) {
+        const int slots = (int)min((long long)LINKED_ROUND, (t1 - tile_first + 3) / 4);
+        // ---- 5' parts of up to LINKED_ROUND tiles: literal compare, exact-piece test, DP tasks ------------
+        int ntasks = 0;
+        for (int slot = 0; slot < slots; ++slot) {
+            if (ntasks + 64 * nad > LINKED_TASKS) {                          // wave-uniform: room for the next tile?
+                linked_drain<RAGGED, AND_MODE>(S, ngroups, queue, ntasks, packed, lens, tile_first, nchunks, max_len,
+                                               s_word, s_count, ns, lane);
+                ntasks = 0;
             }
-            const bool exact = rfl(fp.accept_full) != 0 && front_exact(fp.code, fp.code_mask, w0);
-            if (live) {
+            const long long tile = tile_first + 4 * slot;
+            const bool live = tile * 64 + lane < nreads;
+            const uint4 c0v = packed[(size_t)tile * nchunks * 64 + lane];
+            const uint32_t w0[4] = {c0v.x, c0v.y, c0v.z, c0v.w};
+            uint32_t word = FRONT_NONE, count = 0u;
+            for (int a = 0; a < nad; ++a) {                                  // wave-uniform
+                const FrontParams &fp = S.p.f[a];
+                const int m = rfl(fp.m), k = rfl(fp.k);
+                const bool exact = rfl(fp.accept_full) != 0 && front_exact(fp.code, fp.code_mask, w0);
                 if (exact) {
                     ++count;
-                    if (which < 0) { which = a; front_exact_record(frec, m); }
-                } else if (st.best <= k) {
-                    dpmask |= 1u << a;
+                    word = min(word, front_word(a, m, m, 0));                // Match(0, m, 0, m, m, 0)
                 }
+                const bool cand = live && !exact &&
+                                  front_pex_candidate<AND_MODE>(fp.pex_code, fp.pex_mask, fp.pex_off, rfl(fp.npieces), k, w0);
+                const unsigned long long votes = __ballot(cand);
+                if (cand) queue[ntasks + __popcll(votes & ((1ull << lane) - 1ull))] = (uint16_t)(((slot * 64 + lane) << 6) | a);
+                ntasks += (int)__popcll(votes);
             }
+            s_word[slot * 64 + lane] = live ? word : FRONT_NONE;
+            // four counters to a dword: gathered with two shuffles, stored by every fourth lane
+            uint32_t packed_counts = live ? count : 0u;
+            packed_counts |= (uint32_t)__shfl_down((int)packed_counts, 1, 64) << 8;
+            packed_counts |= (uint32_t)__shfl_down((int)packed_counts, 2, 64) << 16;
+            if ((lane & 3) == 0) s_count[(slot * 64 + lane) >> 2] = packed_counts;
         }
-        // (read, adapter) pairs with an acceptable cell but no literal occurrence: the exact banded DP,
-        // every lane against its own adapter of the group
-        for (int g = 0; g < ngroups; ++g) {
-            const uint32_t gm = (uint32_t)rfl((int)S.p.group_mask[g]);
-            const FrontParams &gp = S.p.f[rfl(S.p.group_first[g])];
-            const Uniform u = front_uniform(rfl(gp.m), rfl(gp.k), rfl(gp.indel), rfl(gp.min_overlap));
-            const bool noindel = rfl(gp.noindel) != 0;
-            while (wave_any((dpmask & gm) != 0u)) {
-                const uint32_t mine = dpmask & gm;
-                const int a_l = mine ? __ffs((int)mine) - 1 : rfl(S.p.group_first[g]);
-                const FrontParams &mp = S.p.f[a_l];
-                uint32_t *ns = &s_stream[wave][0][lane];
-                band_stage((const uint32_t *)tp, nchunks, -u.k, ns, 64);
-                uint32_t rec[4];
-                const uint32_t *rr = mp.rrep;
-                band_locate_prefix_rr<AND_MODE>(u, [rr](int i) { return rr[i - 1]; }, noindel, ns, 64, n, gp.thr, rec);
-                if (mine) {
-                    dpmask &= ~(1u << a_l);
-                    if (front_accept(rec, u.m, u.min_overlap, mp.pf_thr, mp.accept_full != 0, S.rmp.front[a_l], S.rmp.front_ld[a_l],
-                                     S.rmp.front_max[a_l])) {
-                        ++count;
-                        if (which < 0 || a_l < which) {
-                            which = a_l;
-                            frec[0] = rec[0]; frec[1] = rec[1]; frec[2] = rec[2]; frec[3] = 0u;
-                        }
-                    }
-                }
-            }
-        }
-        if (live) {
-            front_out[r] = make_uint4(frec[0], frec[1], frec[2], frec[3]);
-            which_out[r] = (uint16_t)((uint32_t)(which & 0xFF) | ((uint32_t)count << 8));
-        }
+        linked_drain<RAGGED, AND_MODE>(S, ngroups, queue, ntasks, packed, lens, tile_first, nchunks, max_len, s_word, s_count,
+                                       ns, lane);
 
-        // ---- 3' part of the adapter whose 5' part matched, on read[front.rstop:] ---------------------
-        const bool has = live && which >= 0;
-        uint32_t ww = 0u;
-        uint32_t brec[4];
-        rec_none(brec);
-        int mb = 0;
-        if (wave_any(has)) {
+        // ---- 3' part of the adapter whose 5' part matched, on read[front.rstop:] -----------------------------
+        for (int slot = 0; slot < slots; ++slot) {
+            const long long tile = tile_first + 4 * slot;
+            const long long r = tile * 64 + lane;
+            const bool live = r < nreads;
+            const int n = live ? (RAGGED ? lens[r] : max_len) : 0;
+            const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
+            const uint32_t word = s_word[slot * 64 + lane];
+            const int which = word == FRONT_NONE ? -1 : (int)(word >> 24);
+            const bool has = live && which >= 0;
             const BackParams &bp = S.p.b[which < 0 ? 0 : which];
-            const int s = has ? (int)(frec[1] >> 16) : 0x3fff;             // lanes without a 5' match see no base at all
-            Uniform ub = front_uniform(bp.m, bp.k, bp.indel, bp.min_overlap);
-            ub.sq = true; ub.er = true;                                    // (only m, k, indel, min_overlap, sr are read)
-            mb = ub.m;
-            const int mf = bp.rows;
-            FilterState F;
-            filter_init(F, ub, mf, WIDE);
-            F.best = FILTER_BEST_NONE_SIGNED;
-            const int jhi = RAGGED ? wave_max_i32(has ? n : 0) : max_len;
-            const int jfull = RAGGED ? wave_min_i32(has ? n : 0x7fffffff) : max_len;   // columns every matched lane has
-            const int s_lo = wave_min_i32(has ? s : 0x7fffffff), s_hi = wave_max_i32(has ? s : 0);
-            const int z_first = s_lo >> 3;                                 // first dword holding a live base
-            const char *peq_base = (const char *)bp.peq;
-            if (jhi > 8 * z_first) {
-                const int cfirst = z_first >> 2, c1 = (jhi + 31) >> 5;
-                uint4 nxt = cfirst == 0 ? c0v : tp[(size_t)cfirst * 64];
-                int jlast = 8 * z_first;
-                for (int c = cfirst; c < c1; ++c) {
-                    const uint4 cur = nxt;
-                    if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
+            if (live) {
+                uint32_t frec[4];
+                front_word_record(word, S.p.f[which < 0 ? 0 : which].m, frec);
+                front_out[r] = make_uint4(frec[0], frec[1], frec[2], frec[3]);
+                const uint32_t count = (s_count[(slot * 64 + lane) >> 2] >> (8 * (lane & 3))) & 0xFFu;
+                which_out[r] = (uint16_t)((uint32_t)(which & 0xFF) | (count << 8));
+            }
+            uint32_t ww = 0u;
+            uint32_t brec[4];
+            rec_none(brec);
+            int mb = 0;
+            if (wave_any(has)) {
+                const int s = has ? (int)((word >> 16) & 0xFFu) : 0x3fff;      // lanes without a 5' match see no base at all
+                Uniform ub = front_uniform(bp.m, bp.k, bp.indel, bp.min_overlap);
+                ub.sq = true; ub.er = true;                                    // (only m, k, indel, min_overlap, sr are read)
+                mb = ub.m;
+                const int mf = bp.rows;
+                FilterState F;
+                filter_init(F, ub, mf, WIDE);
+                F.best = FILTER_BEST_NONE_SIGNED;
+                const int jhi = RAGGED ? wave_max_i32(has ? n : 0) : max_len;
+                const int jfull = RAGGED ? wave_min_i32(has ? n : 0x7fffffff) : max_len;   // columns every matched lane has
+                const int s_lo = wave_min_i32(has ? s : 0x7fffffff), s_hi = wave_max_i32(has ? s : 0);
+                const int z_first = s_lo >> 3;                                 // first dword holding a live base
+                const char *peq_base = (const char *)bp.peq;
+                if (jhi > 8 * z_first) {
+                    const int cfirst = z_first >> 2, c1 = (jhi + 31) >> 5;
+                    uint4 nxt = tp[(size_t)cfirst * 64];
+                    int jlast = 8 * z_first;
+                    for (int c = cfirst; c < c1; ++c) {
+                        const uint4 cur = nxt;
+                        if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        const int z = 4 * c + d;
-                        if (z < z_first || 8 * z >= jhi) continue;         // wave-uniform
-                        uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
-                        if (8 * z < s_hi) w &= start_mask(z, s);           // wave-uniform: only the first dwords
-                        // byte offsets of the eight mask entries (8 bytes each): even / odd nibbles pre-scaled
-                        uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
-                        uint2 e[8];
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) {
-                            const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
-                            e[b] = *(const uint2 *)(peq_base + off);
-                        }
-                        const int j0 = 8 * z;
-                        if (j0 + 8 <= jhi && j0 + 8 <= jfull) {                 // wave-uniform
-#pragma unroll
-                            for (int b = 0; b < 8; ++b) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)(j0 + b + 1));
-                        } else {
+                        for (int d = 0; d < 4; ++d) {
+                            const int z = 4 * c + d;
+                            if (z < z_first || 8 * z >= jhi) continue;         // wave-uniform
+                            uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
+                            if (8 * z < s_hi) w &= start_mask(z, s);           // wave-uniform: only the first dwords
+                            // byte offsets of the eight mask entries (8 bytes each): even / odd nibbles pre-scaled
+                            uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
+                            uint2 e[8];
 #pragma unroll
                             for (int b = 0; b < 8; ++b) {
-                                const int j = j0 + b + 1;
-                                if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)j);
+                                const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
+                                e[b] = *(const uint2 *)(peq_base + off);
                             }
+                            const int j0 = 8 * z;
+                            if (j0 + 8 <= jhi && j0 + 8 <= jfull) {             // wave-uniform
+#pragma unroll
+                                for (int b = 0; b < 8; ++b) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)(j0 + b + 1));
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < 8; ++b) {
+                                    const int j = j0 + b + 1;
+                                    if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)j);
+                                }
+                            }
+                            jlast = min(jhi, j0 + 8);
                         }
-                        jlast = min(jhi, j0 + 8);
+                        filter_fold(F, RAGGED ? min(n, jlast) : jlast);        // at most 32 columns since the last fold
                     }
-                    filter_fold(F, RAGGED ? min(n, jlast) : jlast);        // at most 32 columns since the last fold
                 }
+                F.best = filter_unbias_best(F.best, ub.k);
+                LaneFilterParams lf;
+                lf.rows = mf; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
+                ww = filter_decide<WIDE>(F, ub, lf, (const uint32_t *)tp, nchunks, n, brec, s);
+                if (!has) { ww = 0u; rec_none(brec); }
+                else if (!window_valid(ww))
+                    linked_finish(brec, s, ub.m, ub.min_overlap, bp.pf_thr, bp.accept_full != 0, S.rmp.back[which],
+                                  S.rmp.back_ld[which], S.rmp.back_max[which]);
             }
-            F.best = filter_unbias_best(F.best, ub.k);
-            LaneFilterParams lf;
-            lf.rows = mf; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
-            ww = filter_decide<WIDE>(F, ub, lf, (const uint32_t *)tp, nchunks, n, brec, s);
-            if (!has) { ww = 0u; rec_none(brec); }
-            else if (!window_valid(ww))
-                linked_finish(brec, s, ub.m, ub.min_overlap, bp.pf_thr, bp.accept_full != 0, S.rmp.back[which], S.rmp.back_ld[which],
-                              S.rmp.back_max[which]);
-        }
-        if (live) {
-            wk.win[r] = ww;
-            if (!window_valid(ww)) back_out[r] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
-            else atomicAdd(&s_hist[linked_bin(ww, which, mb, !RAGGED)], 1u);
+            if (live) {
+                wk.win[r] = ww;
+                if (!window_valid(ww)) back_out[r] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
+                else atomicAdd(&s_hist[linked_bin(ww, which, mb, !RAGGED)], 1u);
+            }
         }
     }
     __syncthreads();
@@ -306,8 +332,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
         la.bin0 = a * FILTER_BINS;
         la.front = front;
         la.post = s->post[a];
-        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a == 0,
-                                      a == s->p.n - 1, st);
+        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st);
         if (rc != 0) return hip_fail((hipError_t)rc, "linked band / window launch");
     }
     return ATR_OK;

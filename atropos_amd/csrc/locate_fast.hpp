@@ -175,13 +175,21 @@ __global__ __launch_bounds__(1024) void scan_bins_kernel(FastWork wk) {
     if (threadIdx.x == 1023) wk.binbase[blockIdx.x] = s_part[1023];     // bin total (rebased by K2b)
 }
 
-__global__ __launch_bounds__(256) void scan_total_kernel(FastWork wk) {
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int b = 0; b < wk.nbins; ++b) { const uint32_t t = wk.binbase[b]; wk.binbase[b] = run; run += t; }
-        wk.binbase[wk.nbins] = run;
-        wk.total[0] = run;
+// K2b: exclusive scan of the (at most 1024) bin totals, one thread per bin
+__global__ __launch_bounds__(1024) void scan_total_kernel(FastWork wk) {
+    __shared__ uint32_t s_part[1024];
+    const int b = threadIdx.x;
+    const uint32_t mine = b < wk.nbins ? wk.binbase[b] : 0u;
+    s_part[b] = mine;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = b >= off ? s_part[b - off] : 0u;
+        __syncthreads();
+        s_part[b] += add;
+        __syncthreads();
     }
+    if (b < wk.nbins) wk.binbase[b] = s_part[b] - mine;
+    if (b == 1023) { wk.binbase[wk.nbins] = s_part[1023]; wk.total[0] = s_part[1023]; }
 }
 
 __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, int by_rows, FastWork wk) {

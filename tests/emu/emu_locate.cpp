@@ -321,14 +321,11 @@ static void emu_linked_l1(const atr_linked_set *s, const uint32_t *pk, const int
         uint32_t dpmask = 0;
         for (int a = 0; a < P.n; ++a) {
             const FrontParams &fp = P.f[a];
-            FrontState st;
-            front_init(st, fp.m);
-            for (int j = 1; j <= fp.m + fp.k; ++j) front_step(st, fp.peq[chunk_code(w0, j)], fp.m);
             const bool exact = fp.accept_full != 0 && front_exact(fp.code, fp.code_mask, w0);
             if (exact) {
                 ++count;
                 if (which < 0) { which = a; front_exact_record(frec, fp.m); }
-            } else if (st.best <= fp.k) {
+            } else if (front_pex_candidate<AND_MODE>(fp.pex_code, fp.pex_mask, fp.pex_off, fp.npieces, fp.k, w0)) {
                 dpmask |= 1u << a;
             }
         }
@@ -336,8 +333,8 @@ static void emu_linked_l1(const atr_linked_set *s, const uint32_t *pk, const int
             if (!(dpmask & (1u << a))) continue;
             const FrontParams &mp = P.f[a], &gp = P.f[P.group_first[mp.group]];
             const Uniform u = front_uniform(gp.m, gp.k, gp.indel, gp.min_overlap);
-            uint32_t ns[BAND_STREAM], rec[4];
-            band_stage(q, nchunks, -u.k, ns, 1);
+            uint32_t ns[BAND_STREAM] = {0}, rec[4];
+            front_stage(w0, u.k, ns, 1);
             const uint32_t *rr = mp.rrep;
             band_locate_prefix_rr<AND_MODE>(u, [rr](int i) { return rr[i - 1]; }, gp.noindel != 0, ns, 1, n, gp.thr, rec);
             if (front_accept(rec, u.m, u.min_overlap, mp.pf_thr, mp.accept_full != 0, s->rmp.front[a], s->rmp.front_ld[a], s->rmp.front_max[a])) {
