@@ -21,7 +21,7 @@ __device__ __forceinline__ void insert_body(const InsertParams &ip, const uint4 
                                             uint4 *__restrict__ out) {
     constexpr int W = NCH;
     const int lane = threadIdx.x & 63;
-    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long tile = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long ntiles = (npairs + 63) >> 6;
     if (tile >= ntiles) return;
     const long long r = tile * 64 + lane;

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
     __syncthreads();
 
     const int nad = rfl(S.p.n), ngroups = rfl(S.p.ngroups);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler knows
     uint32_t *s_word = s_words[wave], *s_count = s_counts[wave];
     uint16_t *queue = s_queue[wave];
     uint32_t *ns = &s_stream[wave][0][lane];

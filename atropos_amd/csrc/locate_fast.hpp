@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
     if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // readfirstlane: the wave index is uniform, and this is how the compiler gets to know (scalar loop control)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
     block_tiles(ntiles, t0, t1);
@@ -222,7 +223,8 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
     const long long total = (long long)wk.binbase[(LINKED ? la.bin0 : 0) + BAND_BINS];
     const int lane = threadIdx.x & 63;
     const long long nwaves = (total - base + 63) >> 6;
-    for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwaves; wv += (long long)gridDim.x * 4) {
+    for (long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); wv < nwaves;
+         wv += (long long)gridDim.x * 4) {
         const long long slot = base + wv * 64 + lane;
         const bool live = slot < total;
         const long long r = live ? (long long)wk.order[slot] : 0;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         const int s_lane = live ? window_hi(ww) - u.m + u.k - window_lo(ww) : 0;
         const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
         const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
-        uint32_t *ns = &s_stream[threadIdx.x >> 6][0][lane];
+        uint32_t *ns = &s_stream[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][lane];
         band_stage(q, nchunks, window_lo(ww), ns, 64);
         uint32_t rec[4];
         band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
@@ -254,13 +256,13 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
     for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long tile = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (tile * 64 >= nreads) return;
     const long long r = tile * 64 + lane;
     const bool live = r < nreads;
     const int n = live ? (lens ? lens[r] : max_len) : 0;
     const uint32_t *q = (const uint32_t *)(packed + (size_t)tile * nchunks * 64 + lane);
-    uint32_t *ns = &s_stream[threadIdx.x >> 6][0][lane];
+    uint32_t *ns = &s_stream[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][lane];
     band_stage(q, nchunks, -u.k, ns, 64);
     uint32_t rec[4];
     band_locate_prefix<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, s_thr, rec);
@@ -289,7 +291,8 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     const int lane = threadIdx.x & 63;
     const long long nwaves = (total - first + 63) >> 6;
     // persistent grid: each wave takes every (gridDim*4)-th group of 64 slots of `order`
-    for (long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); wv < nwaves; wv += (long long)gridDim.x * 4) {
+    for (long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); wv < nwaves;
+         wv += (long long)gridDim.x * 4) {
         const long long slot = first + wv * 64 + lane;
         const bool live = slot < total;
         const long long r = live ? (long long)wk.order[slot] : 0;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void locate_kernel(const LocateParams p, const
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long tile = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long ntiles = (nreads + 63) >> 6;
     if (tile >= ntiles) return;                              // whole wave
     const long long r = tile * 64 + lane;
