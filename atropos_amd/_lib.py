@@ -7,8 +7,10 @@ there is no CPU fallback.  (The CPU test-suite injects a lock-step emulation of 
 kernel built from the same per-lane source via ``set_backend``; that object lives
 under tests/ and is never imported from here.)
 """
+import contextlib
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -187,6 +189,15 @@ class HipBackend(object):
         self._work = None
 
     # -- helpers ---------------------------------------------------------------
+    @contextlib.contextmanager
+    def worker_context(self):
+        """Device + a stream of its own for a host thread that drives this GPU next to other
+        threads driving theirs; the stream is synchronised on exit."""
+        stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.device(self.device), torch.cuda.stream(stream):
+            yield stream
+            stream.synchronize()
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -492,15 +503,33 @@ class HipBackend(object):
 
 
 _backend = None
+_thread_local = threading.local()
 
 
 def get_backend():
-    """The process-wide backend; created on first use.  Raises (never falls back)
+    """The backend of the calling thread (``thread_backend``: one per GPU in a multi-device
+    process), else the process-wide one, created on first use.  Raises (never falls back)
     when the HIP library or the GPU is missing."""
     global _backend
+    mine = getattr(_thread_local, "backend", None)
+    if mine is not None:
+        return mine
     if _backend is None:
         _backend = HipBackend()
     return _backend
+
+
+@contextlib.contextmanager
+def thread_backend(backend):
+    """Make ``backend`` the backend of the calling thread: objects built inside the block
+    (aligners, adapters) live on its GPU.  Used by the single-process multi-device drivers
+    (atropos_amd.shard), one host thread per device."""
+    prev = getattr(_thread_local, "backend", None)
+    _thread_local.backend = backend
+    try:
+        yield backend
+    finally:
+        _thread_local.backend = prev
 
 
 def set_backend(backend):

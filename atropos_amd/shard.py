@@ -65,6 +65,80 @@ def sharded_locate(aligner, reads, host_group=None):
     return local, gather_records_on_host(local.records, total, host_group)
 
 
+def device_backends(devices=None):
+    """One HipBackend per GPU of this process (all visible ones by default)."""
+    from . import _lib
+    if devices is None:
+        devices = range(torch.cuda.device_count())
+    return [_lib.HipBackend(d) for d in devices]
+
+
+def sharded_run_threads(backends, total, work, out_shape, out_dtype=torch.int16):
+    """Single-process multi-device driver: one host thread and one stream per
+    device, contiguous shards in input order, NO collective -- every device's records are copied
+    into ONE host buffer (page-locked when a GPU is present) at its shard's offset.
+    ``work(lo, hi)`` runs in the device's thread, inside ``_lib.thread_backend(backends[d])``, and
+    returns that shard's record tensor.  Returns (host tensor [total, *out_shape], seconds per device)."""
+    import contextlib
+    import threading
+    import time
+    from . import _lib
+    world = len(backends)
+    out = torch.empty((total,) + tuple(out_shape), dtype=out_dtype)
+    if torch.cuda.is_available():
+        out = out.pin_memory()
+    seconds, errors = [0.0] * world, []
+
+    def run(d):
+        try:
+            be = backends[d]
+            lo, hi = shard_range(total, d, world)
+            t0 = time.perf_counter()
+            ctx = be.worker_context() if hasattr(be, "worker_context") else contextlib.nullcontext()
+            with _lib.thread_backend(be), ctx:
+                if hi > lo:
+                    out[lo:hi].copy_(work(lo, hi), non_blocking=True)
+            seconds[d] = time.perf_counter() - t0
+        except BaseException as err:                      # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append((d, err))
+
+    threads = [threading.Thread(target=run, args=(d,), name="atropos-dev%d" % d) for d in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0][1]
+    return out, seconds
+
+
+def sharded_locate_threads(make_aligner, reads, backends):
+    """``Aligner.locate_batch`` over all GPUs of this process: ``make_aligner()`` builds the aligner
+    (called once per device, in that device's thread), ``reads`` is a host uint8 [n, width] ASCII
+    matrix (or anything ``locate_batch`` takes that can be sliced).  Returns (records int16 [n, 8] on
+    the host, in input order; seconds per device)."""
+    def work(lo, hi):
+        return make_aligner().locate_batch(reads[lo:hi]).records
+    return sharded_run_threads(backends, reads.shape[0], work, (8,))
+
+
+def sharded_linked_threads(make_linked_set, reads, lens, backends):
+    """``LinkedSet.match_source`` over all GPUs of this process; ``reads``: host uint8 [n, width]
+    upper-case ASCII, ``lens`` int32 [n] or None.  Returns (int16 [n, 3, 8] host tensor: row 0 =
+    (which, count, 0, ...), row 1 the 5' record, row 2 the 3' record; seconds per device)."""
+    from .adapters import AsciiSource
+
+    def work(lo, hi):
+        from . import _lib
+        dev = _lib.get_backend().device
+        which, count, front, back = make_linked_set().match_source(
+            AsciiSource(reads[lo:hi].to(dev), None if lens is None else lens[lo:hi].to(dev)))
+        head = torch.zeros_like(front)
+        head[:, 0], head[:, 1] = which.to(torch.int16), count.to(torch.int16)
+        return torch.stack([head, front, back], dim=1)
+    return sharded_run_threads(backends, reads.shape[0], work, (3, 8))
+
+
 # ---------------------------------------------------------------------------------------------
 # sharding a FASTQ file: every rank trims its own byte range of the file, no exchange step
 def fastq_record_start(path, offset, probe=1 << 20):
@@ -100,7 +174,12 @@ def fastq_shard_ranges(path, world):
     import os
     size = os.path.getsize(path)
     cuts = [fastq_record_start(path, size * r // world) for r in range(world)] + [size]
-    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
+    # A probe that finds no record boundary (very long or multi-line records) answers `size`: such a
+    # shard is empty and its bytes belong to the shard before it.  Cuts must never run backwards, or
+    # records would be emitted twice.
+    for r in range(world - 1, -1, -1):
+        cuts[r] = min(cuts[r], cuts[r + 1])
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
 def sharded_trim_file(pipeline, path_in, path_out, rank=None, world=None, chunk_bytes=256 << 20):

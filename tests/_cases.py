@@ -528,6 +528,118 @@ def check_linked_sets_against_oracle(oracle, seed, rounds, reads_per_round=(1, 6
     return total, fused_sets
 
 
+def check_linked_golden():
+    """LinkedSet (the fused pipeline where the set is inside its envelope, the step-wise device path
+    otherwise) and LinkedAdapter.match_to_batch against what the reference returned (linked_fuzz.json.gz)."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib
+    from atropos_amd.adapters import LinkedAdapter, LinkedSet, AsciiSource, upper_ascii
+    from atropos_amd.reads import Sequence
+    be = _lib.get_backend()
+    total = fused = 0
+
+    def f(m):
+        return None if m is None else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+    for c in load_golden("linked_fuzz.json.gz"):
+        las = [LinkedAdapter(fr, bk, front_anchored=True, back_anchored=False, **c["kw"]) for fr, bk in zip(c["fronts"], c["backs"])]
+        lset = LinkedSet(las)
+        fused += int(lset.fused)
+        reads = c["reads"]
+        width = max(len(r) for r in reads)
+        mat = np.zeros((len(reads), width), dtype=np.uint8)
+        for i, r in enumerate(reads):
+            mat[i, :len(r)] = np.frombuffer(r.encode(), dtype=np.uint8)
+        a_t = upper_ascii(torch.from_numpy(mat).to(be.device))
+        l_t = torch.tensor([len(r) for r in reads], dtype=torch.int32, device=be.device)
+        which, count, front, back = lset.match_source(AsciiSource(a_t, l_t))
+        per = [la.match_to_batch([Sequence("r", r) for r in reads]) for la in las]
+        for i, (ew, ec, ef, eb) in enumerate(c["out"]):
+            got = [int(which[i]), int(count[i]), None if front[i, 1] < 0 else [int(v) for v in front[i, :6]],
+                   None if back[i, 1] < 0 else [int(v) for v in back[i, :6]]]
+            assert got == [ew, ec, ef, eb], (c["fronts"], c["backs"], c["kw"], reads[i], lset.fused, got, [ew, ec, ef, eb])
+            hits = [a for a in range(len(las)) if per[a][i] is not None]               # the object path, adapter by adapter
+            assert (hits[0] if hits else -1) == ew and len(hits) == ec
+            if hits:
+                assert [f(per[ew][i].front_match), f(per[ew][i].back_match)] == [ef, eb]
+            total += 1
+    return total, fused
+
+
+def check_info_records():
+    """Match.get_info_record through AdapterCutter (per read and batched) against the reference's
+    MatchInfo rows (info_records.json.gz; cf. the reference's tests/cut/*.info.txt)."""
+    from atropos_amd.adapters import Adapter
+    from atropos_amd.modifiers import AdapterCutter
+    from atropos_amd.reads import Sequence
+    rows = 0
+    for c in load_golden("info_records.json.gz"):
+        def mk():
+            return AdapterCutter([Adapter(sp["seq"], sp["where"], name=sp["name"], **c["kw"]) for sp in c["specs"]],
+                                 times=c["times"], action=c["action"])
+        for batched in (False, True):
+            cutter = mk()
+            reads = [Sequence(name, q, qual) for name, q, qual in c["reads"]]
+            outs = cutter.call_batch(reads) if batched else [cutter(r) for r in reads]
+            got = [None if not r.match_info else [list(info) for info in r.match_info] for r in outs]
+            assert got == c["out"], (c["specs"], c["kw"], c["times"], c["action"], batched)
+        rows += sum(len(o) for o in c["out"] if o)
+    return rows
+
+
+def _c5_states(pairs):
+    def f(m):
+        return None if m is None or not hasattr(m, "astart") else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+    return [[[x.sequence, x.qualities, int(x.corrected), bool(x.insert_overlap), f(x.match)] for x in pair] for pair in pairs]
+
+
+def _digest(state):
+    import hashlib
+    return hashlib.sha256(repr(state).encode()).hexdigest()[:16]
+
+
+def check_c5_head(count=None, text_pipeline=True):
+    """The head of BASELINE config C5 (2 x 250 bp with qualities, read wildcards, liberal error
+    correction) through InsertAdapterCutter.call_batch and -- as FASTQ text -- through the device
+    pipeline (atr_insert_match_batch + atr_insert_plan_batch with in-place correction), against the
+    reference's outputs (c5_head.json.gz: every pair by digest, the first pairs in full)."""
+    from atropos_amd import synth
+    from atropos_amd.adapters import Adapter, BACK
+    from atropos_amd.modifiers import InsertAdapterCutter
+    from atropos_amd.reads import Sequence
+    from atropos_amd.util import RandomMatchProbability
+    g = load_golden("c5_head.json.gz")
+    n = g["count"] if count is None else min(count, g["count"])
+    w = synth.workload("C5", 0, n)
+
+    def rows(t):
+        return [bytes(x.tolist()).decode("ascii") for x in t]
+    r1, q1, r2, q2 = rows(w["reads1"]), rows(w["quals1"]), rows(w["reads2"]), rows(w["quals2"])
+    akw = dict(g["adapter_kw"], match_probability=RandomMatchProbability())
+    cutter = InsertAdapterCutter(Adapter(synth.PE_ADAPTER1, BACK, name="a1", **akw), Adapter(synth.PE_ADAPTER2, BACK, name="a2", **akw),
+                                 action='trim', mismatch_action='liberal', read_wildcards=True)
+    out = cutter.call_batch([Sequence("p", a, b) for a, b in zip(r1, q1)], [Sequence("p", a, b) for a, b in zip(r2, q2)])
+    states = _c5_states(out)
+    for k in range(min(n, len(g["full"]))):
+        assert states[k] == g["full"][k], (k, states[k], g["full"][k])
+    assert [_digest(s) for s in states] == g["digests"][:n]
+    if n == g["count"]:
+        assert list(cutter.with_adapters) == g["with_adapters"] and cutter.corrected_pairs == g["corrected_pairs"]
+        assert list(cutter.corrected_bp) == g["corrected_bp"]
+    if text_pipeline:
+        from atropos_amd.trim import pipeline_from_args
+        fq = lambda seqs, quals: "".join("@p%d\n%s\n+\n%s\n" % (k, s, q) for k, (s, q) in enumerate(zip(seqs, quals))).encode()
+        pipe = pipeline_from_args("-a %s -A %s --aligner insert --correct-mismatches liberal --match-read-wildcards "
+                                  "-e 0.2 -O 1 --indel-cost 3 --adapter-max-rmp 1e-6" % (synth.PE_ADAPTER1, synth.PE_ADAPTER2))
+        o1, o2 = pipe.trim_bytes(fq(r1, q1), fq(r2, q2))
+        rec1, rec2 = o1.decode().split("\n"), o2.decode().split("\n")
+        assert len(rec1) == 4 * n + 1 and len(rec2) == 4 * n + 1
+        for k in range(n):
+            got = [rec1[4 * k + 1], rec1[4 * k + 3], rec2[4 * k + 1], rec2[4 * k + 3]]
+            assert _digest(got) == g["text_digests"][k], (k, got, g["full"][k] if k < len(g["full"]) else None)
+    return n
+
+
 def check_device_resident_adapters():
     """The device-resident twins (match_records, LinkedAdapter.match_records,
     best_adapter_records) against the object-level batch path, which is itself pinned to the

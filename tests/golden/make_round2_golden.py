@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Round-2 golden vectors, generated from the REFERENCE itself (build container only: needs
+/root/reference; the reference package is copied to a scratch directory and its Cython modules are
+built there by tests/golden/make_golden.build_reference -- nothing of it enters this repository).
+
+    python tests/golden/make_round2_golden.py
+
+Fixtures (inputs are generated here; expected values are what the reference returned):
+    linked_fuzz.json.gz    sets of linked adapters (`-a ^FRONT...BACK`): per read what
+                           AdapterCutter._best_match / LinkedAdapter.match_to do -- which adapter, how many
+                           5' parts match (> 1: the reference raises AttributeError), both Match records
+    info_records.json.gz   AdapterCutter runs: the MatchInfo rows (Match.get_info_record) of every read
+    c5_head.json.gz        the first pairs of BASELINE config C5 (2 x 250 bp, qualities) through
+                           InsertAdapterCutter(mismatch_action='liberal', read wildcards): full outputs of
+                           the first pairs, a digest of every pair
+While doing so it pins the oracle's C restatement of Adapter.match_to / LinkedAdapter.match_to
+(oracle.match_to, oracle.linked_many): every case must agree, or the script aborts.
+"""
+import hashlib
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from make_golden import build_reference, dump, match_fields  # noqa: E402
+
+
+def pair_digest(state):
+    text = repr(state).encode()
+    return hashlib.sha256(text).hexdigest()[:16]
+
+
+def main():
+    build_reference("/tmp/atropos_ref_build")
+    import numpy as np
+    from atropos.adapters import Adapter, LinkedAdapter, BACK, FRONT, PREFIX, SUFFIX, ANYWHERE
+    from atropos.commands.trim.modifiers import AdapterCutter, InsertAdapterCutter
+    from atropos.io.seqio import Sequence
+    from atropos.util import RandomMatchProbability
+    from atropos_amd import synth
+    from oracle import oracle as O
+    O.build(force=True)
+    rng = random.Random(20260928)
+
+    def rseq(n, alpha="ACGT"):
+        return "".join(rng.choice(alpha) for _ in range(n))
+
+    def mutate(s, p, alpha="ACGT"):
+        out = []
+        for c in s:
+            r = rng.random()
+            if r < p:
+                out.append(rng.choice(alpha))
+            elif r < p * 1.3:
+                pass
+            elif r < p * 1.6:
+                out.append(c)
+                out.append(rng.choice(alpha))
+            else:
+                out.append(c)
+        return "".join(out)
+
+    # ------------------------------------------------------------------ linked adapter sets
+    def linked_case(n_reads):
+        na = rng.randint(1, 4)
+        e = rng.choice([0.05, 0.1, 0.12, 0.2])
+        kw = dict(max_error_rate=e, min_overlap=rng.choice([1, 3, 5]), indel_cost=rng.choice([1, 1, 2]),
+                  read_wildcards=rng.random() < 0.15)
+        with_n = rng.random() < 0.2
+        alpha = "ACGTN" if with_n else "ACGT"
+        fl = rng.randint(6, 24)
+        fronts = [rseq(fl if rng.random() < 0.6 else rng.randint(6, 24), alpha) for _ in range(na)]
+        backs = [rseq(rng.choice([rng.randint(8, 32), rng.randint(33, 40), rng.randint(41, 64)]), alpha) for _ in range(na)]
+        n = rng.randint(40, 160)
+        reads = []
+        for _ in range(n_reads):
+            a = rng.randrange(na)
+            w = rng.random()
+            head = (fronts[a] if w < 0.35 else mutate(fronts[a], rng.choice([0.03, 0.08, 0.15])) if w < 0.7 else
+                    rseq(rng.randint(0, 3)) + fronts[a] if w < 0.75 else fronts[a] + fronts[(a + 1) % na] if w < 0.8 else "")
+            head = head.replace("N", "A")
+            b = backs[a if rng.random() < 0.85 else rng.randrange(na)].replace("N", "C")
+            v = rng.random()
+            tail = (b if v < 0.3 else mutate(b, rng.choice([0.03, 0.08, 0.15])) if v < 0.6 else
+                    b[:rng.randint(1, len(b))] if v < 0.8 else "")
+            q = (head + rseq(rng.randint(0, n), "ACGT" if rng.random() < 0.9 else "ACGTN") + tail + rseq(rng.randint(0, 12)))[:n + 30]
+            if rng.random() < 0.1:
+                q = q.lower()
+            reads.append(q or "A")
+        return dict(fronts=fronts, backs=backs, kw=kw, reads=reads)
+
+    def run_linked(c):
+        las = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, **c["kw"]) for f, b in zip(c["fronts"], c["backs"])]
+        outs = []
+        for q in c["reads"]:
+            which, count, fm, bm = -1, 0, None, None
+            for a, la in enumerate(las):
+                lm = la.match_to(Sequence(name="r", sequence=q))
+                if lm is None:
+                    continue
+                count += 1
+                if which < 0:
+                    which, fm, bm = a, match_fields(lm.front_match), match_fields(lm.back_match)
+            outs.append([which, count, fm, bm])
+        return outs
+
+    def check_oracle_linked(c, outs):
+        kw = c["kw"]
+        width = max(len(q) for q in c["reads"])
+        mat = np.zeros((len(c["reads"]), width), np.uint8)
+        for i, q in enumerate(c["reads"]):
+            mat[i, :len(q)] = np.frombuffer(q.encode(), np.uint8)
+        lens = np.array([len(q) for q in c["reads"]], np.int32)
+        wh, f, b = O.linked_many(c["fronts"], c["backs"], mat, lens, kw["max_error_rate"], kw["min_overlap"], kw["indel_cost"],
+                                 True, kw["read_wildcards"], 2)
+        for i, (which, count, fm, bm) in enumerate(outs):
+            got = [int(wh[i, 0]), int(wh[i, 1]), None if f[i, 1] < 0 else [int(v) for v in f[i]],
+                   None if b[i, 1] < 0 else [int(v) for v in b[i]]]
+            assert got == [which, count, fm, bm], (c["fronts"], c["backs"], kw, c["reads"][i], got, [which, count, fm, bm])
+
+    cases = []
+    for _ in range(160):
+        c = linked_case(24)
+        c["out"] = run_linked(c)
+        check_oracle_linked(c, c["out"])
+        cases.append(c)
+    dump("linked_fuzz.json.gz", cases)
+    extra = 0
+    for _ in range(1200):                                  # uncommitted: oracle vs reference only
+        c = linked_case(40)
+        check_oracle_linked(c, run_linked(c))
+        extra += len(c["reads"])
+    print("oracle.linked_many == reference on %d committed + %d further reads" % (sum(len(c["reads"]) for c in cases), extra))
+
+    # ------------------------------------------------------------------ info records
+    info_cases = []
+    for _ in range(120):
+        nad = rng.choice([1, 2, 3])
+        specs = []
+        for a in range(nad):
+            specs.append(dict(seq=rseq(rng.randint(6, 34), "ACGT" if rng.random() < 0.8 else "ACGTN"),
+                              where=rng.choice([BACK, BACK, FRONT, PREFIX, SUFFIX, ANYWHERE]), name="ad%d" % a))
+        kw = dict(max_error_rate=rng.choice([0.1, 0.12, 0.2]), min_overlap=rng.choice([1, 3, 5]))
+        times, action = rng.choice([1, 1, 2, 3]), rng.choice(['trim', 'trim', 'mask', None])
+        reads = []
+        for k in range(10):
+            sp = rng.choice(specs)
+            a = mutate(sp["seq"].replace("N", "C"), rng.choice([0, 0, 0.05, 0.1]))
+            body = rseq(rng.randint(20, 90))
+            q = body + a + rseq(rng.randint(0, 12)) if sp["where"] in (BACK, SUFFIX, ANYWHERE) and rng.random() < 0.7 else a + body
+            if rng.random() < 0.3:
+                q += rng.choice(specs)["seq"].replace("N", "G")
+            qual = None if rng.random() < 0.2 else "".join(chr(rng.randint(35, 73)) for _ in q)
+            reads.append(["read%d" % k, q, qual])
+        cutter = AdapterCutter([Adapter(sp["seq"], sp["where"], name=sp["name"], **kw) for sp in specs], times=times, action=action)
+        outs = []
+        for name, q, qual in reads:
+            r = cutter(Sequence(name=name, sequence=q, qualities=qual))
+            outs.append(None if not r.match_info else [list(info) for info in r.match_info])
+        info_cases.append(dict(specs=specs, kw=kw, times=times, action=action, reads=reads, out=outs))
+    dump("info_records.json.gz", info_cases)
+
+    # ------------------------------------------------------------------ C5 head through InsertAdapterCutter
+    count, full = 2048, 96
+    w = synth.workload("C5", 0, count)
+
+    def rows(t):
+        return [bytes(x.tolist()).decode("ascii") for x in t]
+
+    rmp = RandomMatchProbability()
+    akw = dict(max_error_rate=0.2, min_overlap=1, indel_cost=3, match_probability=rmp, max_rmp=1e-6, read_wildcards=True)
+    cutter = InsertAdapterCutter(Adapter(synth.PE_ADAPTER1, BACK, name="a1", **akw), Adapter(synth.PE_ADAPTER2, BACK, name="a2", **akw),
+                                 action='trim', mismatch_action='liberal', read_wildcards=True)
+    states, digests, text_digests = [], [], []
+    for r1, q1, r2, q2 in zip(rows(w["reads1"]), rows(w["quals1"]), rows(w["reads2"]), rows(w["quals2"])):
+        a, b = cutter(Sequence(name="p", sequence=r1, qualities=q1), Sequence(name="p", sequence=r2, qualities=q2))
+        st = [[x.sequence, x.qualities, int(x.corrected), bool(x.insert_overlap),
+               match_fields(x.match) if x.match is not None else None] for x in (a, b)]
+        states.append(st)
+        digests.append(pair_digest(st))
+        text_digests.append(pair_digest([st[0][0], st[0][1], st[1][0], st[1][1]]))      # what the output files hold
+    dump("c5_head.json.gz", dict(count=count, adapter_kw={k: v for k, v in akw.items() if k != "match_probability"},
+                                 full=states[:full], digests=digests, text_digests=text_digests, with_adapters=list(cutter.with_adapters),
+                                 corrected_pairs=cutter.corrected_pairs, corrected_bp=list(cutter.corrected_bp)))
+
+
+if __name__ == "__main__":
+    main()

@@ -120,3 +120,39 @@ def test_fastq_shard_ranges_are_record_aligned(tmp_path):
             shard = text[lo:hi]
             assert shard.count(b"\n") % 4 == 0
             assert not shard or shard.startswith(b"@r")
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_single_process_multi_device(emu_backend, world):
+    """The single-process driver (one host thread + backend per device, one host result buffer at
+    per-device offsets) equals the single-device run -- locate and the fused linked-adapter pipeline."""
+    import numpy as np
+    from atropos_amd import shard, synth
+    from atropos_amd.adapters import AsciiSource, LinkedAdapter, LinkedSet, upper_ascii
+    from atropos_amd.align import Aligner
+    from tests.emu.backend import EmuBackend
+    backends = [EmuBackend() for _ in range(world)]
+    w = synth.workload("C2", 0, 1001)
+    make = lambda: Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    rec, seconds = shard.sharded_locate_threads(make, w["reads"], backends)
+    assert len(seconds) == world and torch.equal(rec, make().locate_batch(w["reads"]).records)
+    w4 = synth.workload("C4", 0, 777)
+    reads = upper_ascii(w4["reads"])
+    mk = lambda: LinkedSet([LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=w4["max_error_rate"],
+                                          min_overlap=w4["min_overlap"], indel_cost=w4["indel_cost"])
+                            for f, b in zip(w4["fronts"], w4["backs"])])
+    got, _ = shard.sharded_linked_threads(mk, reads, None, backends)
+    which, count, front, back = mk().match_source(AsciiSource(reads))
+    assert torch.equal(got[:, 0, 0].to(torch.int32), which) and torch.equal(got[:, 0, 1].to(torch.int32), count)
+    assert torch.equal(got[:, 1], front) and torch.equal(got[:, 2], back)
+
+
+def test_fastq_shard_ranges_monotone(tmp_path):
+    """A probe that finds no record boundary must not make shards overlap (advisor finding)."""
+    from atropos_amd import shard
+    path = tmp_path / "long.fastq"
+    rec = b"@r\n" + b"A" * 3_000_000 + b"\n+\n" + b"I" * 3_000_000 + b"\n"
+    path.write_bytes(rec * 2)
+    ranges = shard.fastq_shard_ranges(str(path), 4)
+    assert ranges[0][0] == 0 and ranges[-1][1] == len(rec) * 2
+    assert all(a <= b for a, b in ranges) and all(ranges[i][1] == ranges[i + 1][0] for i in range(3))

@@ -63,6 +63,19 @@ def test_linked_sets_fused(emu_backend, oracle):
     assert total > 6000 and fused > 70
 
 
+def test_linked_golden(emu_backend):
+    total, fused = _cases.check_linked_golden()
+    assert total == 3840 and fused > 60
+
+
+def test_info_records(emu_backend):
+    assert _cases.check_info_records() > 500
+
+
+def test_c5_head(emu_backend):
+    assert _cases.check_c5_head(count=256) == 256
+
+
 def test_device_resident_adapters(emu_backend):
     assert _cases.check_device_resident_adapters() > 5000
 

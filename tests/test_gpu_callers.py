@@ -106,6 +106,20 @@ def test_c4_shard_against_oracle(hip_backend, oracle):
     assert np.array_equal(rb[:100_000, :6].cpu().numpy().astype(np.int32), eb)
 
 
+def test_linked_golden(hip_backend):
+    total, fused = _cases.check_linked_golden()
+    assert total == 3840 and fused > 60
+
+
+def test_info_records(hip_backend):
+    assert _cases.check_info_records() > 500
+
+
+def test_c5_head(hip_backend):
+    """2048 pairs of C5 with qualities against the reference: object path and device FASTQ pipeline."""
+    assert _cases.check_c5_head() == 2048
+
+
 def test_device_resident_adapters(hip_backend):
     assert _cases.check_device_resident_adapters() > 5000
 

@@ -92,3 +92,60 @@ def test_full_size_insert(hip_backend, oracle, name, count):
                 assert _cases.norm_insert(g) == exp
         del w, b1, b2, rec, r
     assert 0.40 < nfound / count < 0.60
+
+
+def test_c5_correction_at_size(hip_backend, oracle):
+    """BASELINE config C5 at shard-piece size (2 M pairs 2 x 250 bp with qualities, read wildcards):
+    insert match + liberal error correction in place (atr_insert_match_batch + atr_insert_correct_batch).
+    The head against the reference's outputs (c5_head.json.gz), a slice of the insert matches against the
+    oracle, and size-independent properties of all 2 M pairs."""
+    import numpy as np
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.align import InsertAligner
+    from atropos_amd.modifiers import COMP_TABLE
+    from .conftest import load_golden
+    n = 2_000_000
+    w = synth.workload("C5", 0, n, device="cuda")
+    ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
+    s1, s2, q1, q2 = (w[k].clone() for k in ("reads1", "reads2", "quals1", "quals2"))
+    res = ia.match_insert_batch(ia.pack(s1), ia.pack(s2, check=True))
+    rec = res.records
+    changed, newlen = hip_backend.insert_correct_batch(rec, s1, q1, None, s2, q2, None, 2, 1, COMP_TABLE)
+    torch.cuda.synchronize()
+    ins = rec[:, 0].to(torch.int32)
+    found, errs = ins[:, 1] >= 0, ins[:, 5]
+    ch = changed.to(torch.int64)
+    # (1) the head against the reference: the trimmed outputs are prefixes of the corrected reads
+    g = load_golden("c5_head.json.gz")
+    h1, hq1, h2, hq2 = (t[:len(g["full"])].cpu().numpy() for t in (s1, q1, s2, q2))
+    for k, (a, b) in enumerate(g["full"]):
+        for got_s, got_q, exp in ((h1[k], hq1[k], a), (h2[k], hq2[k], b)):
+            assert bytes(got_s[:len(exp[0])]).decode() == exp[0] and bytes(got_q[:len(exp[1])]).decode() == exp[1], k
+        assert int(ch[k, 0]) == a[2] and int(ch[k, 1]) == b[2]
+    # (2) a slice of the insert matches against the oracle
+    lo, k = 1_234_000, 20_000
+    orc = oracle.InsertOracle(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
+    lens = np.full(k, 250, np.int32)
+    exp = oracle.match_insert_many(orc, w["reads1"][lo:lo + k].cpu().numpy(), lens, w["reads2"][lo:lo + k].cpu().numpy(), lens, 8)
+    assert np.array_equal(rec[lo:lo + k, :, :6].cpu().numpy().astype(np.int32), exp)
+    # (3) properties of all pairs
+    assert bool((ch >= 0).all())                                         # no pair failed (KeyError / IndexError / ValueError codes are < 0)
+    untouched = ~(found & (errs > 0))
+    assert bool((ch[untouched] == 0).all())                              # only pairs with an imperfect insert match are corrected
+    assert bool((ch.sum(dim=1) <= errs.to(torch.int64)).all())           # never more changes than mismatches in the overlap
+    same1, same2 = (s1 == w["reads1"]), (s2 == w["reads2"])
+    assert bool((( ~same1).sum(dim=1) == ch[:, 0]).all()) and bool(((~same2).sum(dim=1) == ch[:, 1]).all())
+    cols = torch.arange(250, device="cuda", dtype=torch.int32)[None, :]
+    inside1 = (cols >= ins[:, 2:3]) & (cols < ins[:, 3:4])               # read 1 changes only inside [querystart, querystop)
+    assert bool((same1 | inside1).all())
+    inside2 = (cols >= 250 - ins[:, 1:2]) & (cols < 250 - ins[:, 0:1])   # read 2 only inside [len2 - refstop, len2 - refstart)
+    assert bool((same2 | inside2).all())
+    assert bool(((q1 == w["quals1"]) | ~same1).all()) and bool(((q2 == w["quals2"]) | ~same2).all())   # qualities move with bases
+    assert bool((newlen == 250).all())
+    # (4) correcting the corrected reads again: every overlap now has fewer or as many mismatches, and a second
+    #     pass changes nothing where the first pass resolved every mismatch
+    res2 = ia.match_insert_batch(ia.pack(s1), ia.pack(s2, check=True)).records[:, 0].to(torch.int32)
+    both = found & (res2[:, 1] >= 0) & (res2[:, 0] == ins[:, 0]) & (res2[:, 3] == ins[:, 3])
+    assert bool((res2[both][:, 5] <= errs[both]).all())
+    assert float(both.float().mean().item()) > 0.4

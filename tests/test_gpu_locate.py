@@ -147,3 +147,19 @@ def test_pair_aligner_against_oracle(hip_backend, oracle):
     from atropos_amd.align import PairAligner
     from atropos_amd._lib import AtroposHipError
     assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=78, rounds=120) > 3000
+
+
+def test_single_process_multi_stream(hip_backend):
+    """The single-process multi-device driver on the one GPU there is: three backends on device 0 -- one
+    host thread, stream, scratch and set of aligner handles each -- must reproduce the single-stream
+    records (the per-thread side streams and event pairs of the filtered pipeline included)."""
+    from atropos_amd import _lib, shard, synth
+    from atropos_amd.align import Aligner
+    w = synth.workload("C2", 0, 3_000_001, device="cuda")
+    reads = w["reads"]
+    make = lambda: Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    want = make().locate_batch(reads).records.cpu()
+    backends = [_lib.HipBackend(0) for _ in range(3)]
+    for _ in range(3):
+        got, seconds = shard.sharded_locate_threads(make, reads, backends)
+        assert len(seconds) == 3 and torch.equal(got, want)

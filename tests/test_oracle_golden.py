@@ -130,3 +130,24 @@ def test_oracle_match_to_golden(oracle):
         assert (None if got is None else list(got)) == c["out"], c
         n += 1
     assert n > 1000
+
+
+def test_oracle_linked_fuzz(oracle):
+    """oracle.linked_many against the reference's LinkedAdapter.match_to results (linked_fuzz.json.gz)."""
+    import numpy as np
+    n = 0
+    for c in load_golden("linked_fuzz.json.gz"):
+        kw = c["kw"]
+        width = max(len(q) for q in c["reads"])
+        mat = np.zeros((len(c["reads"]), width), np.uint8)
+        for i, q in enumerate(c["reads"]):
+            mat[i, :len(q)] = np.frombuffer(q.encode(), np.uint8)
+        lens = np.array([len(q) for q in c["reads"]], np.int32)
+        wh, f, b = oracle.linked_many(c["fronts"], c["backs"], mat, lens, kw["max_error_rate"], kw["min_overlap"],
+                                      kw["indel_cost"], True, kw["read_wildcards"], 2)
+        for i, exp in enumerate(c["out"]):
+            got = [int(wh[i, 0]), int(wh[i, 1]), None if f[i, 1] < 0 else [int(v) for v in f[i]],
+                   None if b[i, 1] < 0 else [int(v) for v in b[i]]]
+            assert got == exp, (c["fronts"], c["backs"], kw, c["reads"][i])
+            n += 1
+    assert n == 3840
