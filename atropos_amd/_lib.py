@@ -76,7 +76,7 @@ PROTOTYPES = {
     "atr_correct_errors_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "atr_insert_correct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+    "atr_insert_correct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_insert_aligner_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
@@ -286,9 +286,11 @@ class HipBackend(object):
         return changed, newlen
 
     def insert_correct_batch(self, records, seq1, qual1, lens1, seq2, qual2, lens2, action, min_qual_diff, comp,
-                             changed=None, newlen=None):
+                             changed=None, newlen=None, planes1=None, planes2=None):
         """Error correction of the pairs whose insert match (records of insert_match_batch) has
-        errors, in place on uint8 [n, width] ASCII tensors; returns (changed, newlen) int32 [n, 2]."""
+        errors, in place on uint8 [n, width] ASCII tensors; returns (changed, newlen) int32 [n, 2].
+        planes1 / planes2: the plane64 ReadBatches the records were computed from (optional; the
+        kernel then only visits the positions where the reads disagree)."""
         n = seq1.shape[0]
         changed = self.empty((n, 2), torch.int32) if changed is None else changed
         newlen = self.empty((n, 2), torch.int32) if newlen is None else newlen
@@ -297,7 +299,9 @@ class HipBackend(object):
                 raise ValueError("both reads need the same row stride")
             with torch.cuda.device(self.device):
                 _check(self.lib, self.lib.atr_insert_correct_batch(
-                    _ptr(records), _ptr(seq1), _ptr(qual1), _ptr(lens1), _ptr(seq2), _ptr(qual2), _ptr(lens2),
+                    _ptr(records), None if planes1 is None else _ptr(planes1.packed),
+                    None if planes2 is None else _ptr(planes2.packed), 0 if planes1 is None else planes1.max_len,
+                    _ptr(seq1), _ptr(qual1), _ptr(lens1), _ptr(seq2), _ptr(qual2), _ptr(lens2),
                     seq1.stride(0), n, seq1.shape[1], action, min_qual_diff, comp, _ptr(changed), _ptr(newlen),
                     self._stream()), "atr_insert_correct_batch")
         return changed, newlen

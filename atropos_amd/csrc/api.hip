@@ -23,6 +23,10 @@ int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uin
                    int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st);
+int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,
+                          uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2, long long stride,
+                          long long n, int max_len, int action, int min_qual_diff, const uint8_t *comp, int32_t *changed,
+                          int32_t *newlen, hipStream_t st);
 int launch_postfilter(int16_t *rec, long long n, int m, int min_overlap, double max_error_rate, const double *rmp,
                       int rmp_ld, double max_rmp, int accept_full, hipStream_t st);
 int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
@@ -324,15 +328,25 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "correct_kernel launch");
 }
 
-int atr_insert_correct_batch(const atr_result *d_insert_records, uint8_t *d_seq1, uint8_t *d_qual1,
+int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *d_planes1, const uint8_t *d_planes2,
+                             int planes_max_len, uint8_t *d_seq1, uint8_t *d_qual1,
                              const int32_t *d_lens1, uint8_t *d_seq2, uint8_t *d_qual2, const int32_t *d_lens2,
                              int64_t stride, int64_t n, int max_len, int action, int min_qual_difference,
                              const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream) {
     if (n < 0 || max_len < 0 || action < 0 || action > 2 || !comp) return ATR_ERR_INVALID;
+    if ((d_planes1 == nullptr) != (d_planes2 == nullptr)) return ATR_ERR_INVALID;
     if ((d_qual1 == nullptr) != (d_qual2 == nullptr)) return ATR_ERR_INVALID;
     if (action != ATR_CORRECT_N && !d_qual1) return ATR_ERR_INVALID;      /* modifiers.py:245-248 */
     if (n == 0) return ATR_OK;
     if (!d_insert_records || !d_seq1 || !d_seq2 || !d_changed || !d_newlen) return ATR_ERR_INVALID;
+    if (d_planes1 && planes_max_len > 0 && planes_max_len <= ATR_INSERT_MAX_READ) {
+        // the reads as atr_insert_match_batch saw them: only the positions where they disagree are visited
+        const int rcp = launch_correct_planes((const int16_t *)d_insert_records, (const uint4 *)d_planes1,
+                                              (const uint4 *)d_planes2, (planes_max_len + 31) / 32, d_seq1, d_qual1, d_lens1,
+                                              d_seq2, d_qual2, d_lens2, stride, n, max_len, action, min_qual_difference,
+                                              comp, d_changed, d_newlen, (hipStream_t)stream);
+        return rcp == 0 ? ATR_OK : hip_fail((hipError_t)rcp, "correct_planes_kernel launch");
+    }
     const int rc = launch_correct(d_seq1, d_qual1, d_lens1, d_seq2, d_qual2, d_lens2, stride,
                                   (const int16_t *)d_insert_records, 24, 1, nullptr, n, max_len, action,
                                   min_qual_difference, 1, comp, d_changed, d_newlen, (hipStream_t)stream);

@@ -12,6 +12,8 @@
 
 #include <stdint.h>
 #include "atropos_hip.h"
+#include "locate_core.hpp"      // atr_ctz
+#include "insert_core.hpp"      // atr_bfrev
 
 #ifdef ATR_HOST_EMU
 #ifndef ATR_DEV
@@ -256,6 +258,152 @@ ATR_DEV void correct_errors_one(uint8_t *s1, uint8_t *q1, int len1, uint8_t *s2,
     changed[1] = err ? 0 : c2;
     newlen[0] = (c1 > 0 && !err) ? n1 : len1;      // the truncation quirk (see above)
     newlen[1] = orig_len2;                         // read2 keeps its tail (partial update, :336-339)
+}
+
+// ---- the same correction, guided by the bit planes of the two reads -------------------------------
+// For an insert match of the insert aligner (flags START_WITHIN_SEQ1 | STOP_WITHIN_SEQ2, no indels) the
+// tuple is (L - j, L, 0, j, ...): read1[t] faces the complement of read2[j - 1 - t], t = 0 .. j - 1
+// (correct_errors_one walks exactly these pairs: r1 = [0, j), r2 = [0, j) backwards).  With both reads
+// packed as DNA15 bit planes (plane64, atr_pack_planes) the positions where they DISAGREE come out 32
+// at a time -- complement = plane p <-> 3 - p, and the 32 bases of read 2 that face word w of read 1
+// are the bit-reversed window of read 2 at bit j - 32 (w + 1) -- and only those few positions are
+// visited in the ASCII matrices; everywhere else the reference's loop does nothing.  Equal codes are
+// equal characters here: read 2 holds upper-case IUPAC letters only (atr_insert_match_batch's packing
+// check), and a character of read 1 without a code differs from all of them.
+
+// b2 word source: plane p, word idx of read 2 (0 outside the read)
+template <class W2>
+ATR_DEV uint32_t facing_mismatches(const uint32_t a[4], W2 b2word, int nwords, int j, int w) {
+    // bits of read 2 at [u, u + 32), u = j - 32 (w + 1), reversed: bit b faces read1[32 w + b]
+    const int u = j - 32 * (w + 1);
+    const int q = u >> 5;                                            // floor (arithmetic shift), u may be negative
+    const uint32_t sh = (uint32_t)(u & 31);
+    uint32_t diff = 0u;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t lo = (q >= 0 && q < nwords) ? b2word(3 - p, q) : 0u;
+        const uint32_t hi = (q + 1 >= 0 && q + 1 < nwords) ? b2word(3 - p, q + 1) : 0u;
+        const uint32_t window = sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+        diff |= a[p] ^ atr_bfrev(window);
+    }
+    const int live = j - 32 * w;                                     // positions of this word inside the overlap
+    return live >= 32 ? diff : live <= 0 ? 0u : diff & ((1u << live) - 1u);
+}
+
+// One disagreeing position (i in read 1, jx in read 2): the body of the reference's loop
+// (modifiers.py:272-300).  Returns 0, or the error code (-1: base without complement).
+// known1 / known2: the characters of read1[i] / read2[jx] when the caller already has them (decoded from
+// the bit planes), else 0: read from the matrices.
+ATR_DEV int correct_position(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, int action,
+                             int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend,
+                             uint8_t known1 = 0, uint8_t known2 = 0) {
+    const bool has_quals = q1 != nullptr && q2 != nullptr;
+    const uint8_t base1 = known1 ? known1 : s1[i];
+    const uint8_t base2 = comp[known2 ? known2 : s2[jx]];
+    if (base2 == 0) return -1;
+    if (base1 == base2) return 0;
+    if (action == 0) {                             // 'N'
+        s1[i] = 'N'; s2[jx] = 'N'; ++c1; ++c2;
+    } else if (base1 == 'N') {
+        s1[i] = base2;
+        if (has_quals) q1[i] = q2[jx];
+        ++c1;
+    } else if (base2 == 'N') {
+        const uint8_t cb = comp[base1];
+        if (cb == 0) return -1;
+        s2[jx] = cb;
+        if (has_quals) q2[jx] = q1[i];
+        ++c2;
+    } else if (has_quals) {
+        const int diff = (int)q1[i] - (int)q2[jx];
+        if (diff >= min_qual_diff) {
+            const uint8_t cb = comp[base1];
+            if (cb == 0) return -1;
+            s2[jx] = cb; q2[jx] = q1[i]; ++c2;
+        } else if (diff <= -min_qual_diff) {
+            s1[i] = base2; q1[i] = q2[jx]; ++c1;
+        } else if (action == 2) {
+            ++npend;                               // quals_equal.append(...)
+        }
+    }
+    return 0;
+}
+
+// sum of the first n bytes of a row (rows of the ASCII matrices start at any byte address: four bytes per
+// load through an alignment-1 type, summed with one v_sad_u8 on the device)
+typedef uint32_t __attribute__((aligned(1))) atr_u32_unaligned;
+ATR_DEV long long byte_sum(const uint8_t *row, int n) {
+    uint32_t acc = 0;
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {
+        const uint32_t v = *(const atr_u32_unaligned *)(row + i);
+#ifdef ATR_HOST_EMU
+        acc += (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24);
+#else
+        acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
+#endif
+    }
+    for (; i < n; ++i) acc += row[i];
+    return (long long)acc;
+}
+
+// correct_errors(read1, read2, insert_match, truncate_seqs=True) for a pair with an insert match of
+// j bases; mism[w] = facing_mismatches(...) of word w.  Same outputs as correct_errors_one.
+// code1(i) / code2(jx): the DNA15 codes of read1[i] / read2[jx] out of the planes (0: a character without
+// a code -- it is then read from the matrix), which spares the two scattered byte loads per position.
+ATR_DEV uint8_t dna15_letter(uint32_t code) { return (uint8_t)"\0ACMGRSVTWYHKDBN"[code & 15u]; }
+
+// NW: compile-time bound of the word loops (fully unrolled, so that code1 may index registers by w)
+template <int NW, class C1, class C2>
+ATR_DEV void correct_errors_planes_one(uint8_t *s1, uint8_t *q1, int len1, uint8_t *s2, uint8_t *q2, int len2, int j,
+                                       const uint32_t *mism, int nwords, int action, int min_qual_diff,
+                                       const uint8_t *comp, int32_t *changed, int32_t *newlen, C1 code1, C2 code2) {
+    const int n1 = mc_min(len1, len2);             // both reads are cut to the common length (:250-259)
+    int c1 = 0, c2 = 0, err = 0, npend = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint32_t m = (w < nwords && !err) ? mism[w] : 0u;
+        while (m && !err) {
+            const int b = atr_ctz(m);
+            m &= m - 1u;
+            const int i = 32 * w + b;
+            err = correct_position(s1, q1, s2, q2, i, j - 1 - i, action, min_qual_diff, comp, c1, c2, npend,
+                                   dna15_letter(code1(w, b)), dna15_letter(code2(j - 1 - i)));
+        }
+    }
+    if (!err && npend > 0) {                       // :301-322: equal qualities -- the read with the better overlap wins
+        if (j <= 0) {
+            err = -3;
+        } else {
+            const long long sum1 = byte_sum(q1, j), sum2 = byte_sum(q2, j);
+            const double diff = (double)sum1 / (double)j - (double)sum2 / (double)j;
+            if (diff > 1.0 || diff < -1.0) {
+                for (int w = 0; w < nwords && !err; ++w) {
+                    uint32_t m = mism[w];
+                    while (m && !err) {
+                        const int b = atr_ctz(m);
+                        m &= m - 1u;
+                        const int i = 32 * w + b, jx = j - 1 - i;
+                        const uint8_t base1 = s1[i], base2 = comp[s2[jx]];
+                        if (base1 == base2 || base1 == 'N' || base2 == 'N') continue;
+                        const int qd = (int)q1[i] - (int)q2[jx];
+                        if (qd >= min_qual_diff || qd <= -min_qual_diff) continue;
+                        if (diff > 1.0) {
+                            const uint8_t cb = comp[base1];
+                            if (cb == 0) { err = -1; break; }
+                            s2[jx] = cb; q2[jx] = q1[i]; ++c2;
+                        } else {
+                            s1[i] = base2; q1[i] = q2[jx]; ++c1;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    changed[0] = err ? err : c1;
+    changed[1] = err ? 0 : c2;
+    newlen[0] = (c1 > 0 && !err) ? n1 : len1;      // the truncation quirk of correct_errors_one
+    newlen[1] = len2;
 }
 
 }  // namespace atr

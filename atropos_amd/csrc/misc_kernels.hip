@@ -69,6 +69,83 @@ __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, 
                        changed + 2 * p, newlen + 2 * p);
 }
 
+// Plane-guided correction (misc_core.hpp, correct_errors_planes_one): one pair per lane.  The lane
+// loads the bit planes of both reads (coalesced tile64 chunk loads), parks read 2's in LDS (the 32 bases
+// that face a word of read 1 start at a per-lane bit offset) and only then touches the ASCII
+// matrices, at the few positions where the reads disagree.
+constexpr int PLANES_MAX_WORDS = 8;                  // ATR_INSERT_MAX_READ / 32
+
+__global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__restrict__ records,
+                                                             const uint4 *__restrict__ planes1,
+                                                             const uint4 *__restrict__ planes2, int nchunks,
+                                                             uint8_t *__restrict__ s1, uint8_t *__restrict__ q1,
+                                                             const int32_t *__restrict__ l1, uint8_t *__restrict__ s2,
+                                                             uint8_t *__restrict__ q2, const int32_t *__restrict__ l2,
+                                                             long long stride, long long n, int max_len, int action,
+                                                             int min_qual_diff, const CompTable ct,
+                                                             int32_t *__restrict__ changed, int32_t *__restrict__ newlen) {
+    __shared__ uint8_t s_comp[256];
+    __shared__ uint32_t s_b2[4][4 * PLANES_MAX_WORDS][64];        // per wave: read 2's planes, [plane * W + word][lane]
+    s_comp[threadIdx.x] = ct.c[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    const long long p = tile * 64 + lane;
+    if (tile * 64 >= n) return;
+    const bool live = p < n;
+    const int16_t *rec = records + 24 * (live ? p : 0);
+    const int len1 = live ? (l1 ? l1[p] : max_len) : 0, len2 = live ? (l2 ? l2[p] : max_len) : 0;
+    // a pair is corrected when its insert match exists and has errors (modifiers.py:397-404)
+    const bool todo = live && rec[1] >= 0 && rec[5] > 0;
+    const int j = todo ? (int)rec[3] : 0;                         // the overlap: read1[0:j] faces revcomp(read2[0:j])
+    uint32_t a[PLANES_MAX_WORDS][4];
+    const uint4 *t1 = planes1 + (size_t)tile * nchunks * 64 + lane, *t2 = planes2 + (size_t)tile * nchunks * 64 + lane;
+    uint32_t (*b2)[64] = s_b2[wave];
+#pragma unroll
+    for (int c = 0; c < PLANES_MAX_WORDS; ++c) {
+        if (c < nchunks) {
+            const uint4 v1 = t1[(size_t)c * 64], v2 = t2[(size_t)c * 64];
+            a[c][0] = v1.x; a[c][1] = v1.y; a[c][2] = v1.z; a[c][3] = v1.w;
+            b2[0 * PLANES_MAX_WORDS + c][lane] = v2.x; b2[1 * PLANES_MAX_WORDS + c][lane] = v2.y;
+            b2[2 * PLANES_MAX_WORDS + c][lane] = v2.z; b2[3 * PLANES_MAX_WORDS + c][lane] = v2.w;
+        } else {
+            a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0u;
+        }
+    }
+    uint32_t mism[PLANES_MAX_WORDS];
+    const auto b2word = [b2, lane](int plane, int idx) { return b2[plane * PLANES_MAX_WORDS + idx][lane]; };
+#pragma unroll
+    for (int w = 0; w < PLANES_MAX_WORDS; ++w) mism[w] = (todo && w < nchunks) ? facing_mismatches(a[w], b2word, nchunks, j, w) : 0u;
+    if (!live) return;
+    if (!todo) {
+        changed[2 * p] = changed[2 * p + 1] = 0;
+        newlen[2 * p] = len1; newlen[2 * p + 1] = len2;
+        return;
+    }
+    const auto code1 = [&a](int w, int b) {            // read 1: its planes are still in registers (w is a literal after unrolling)
+        return ((a[w][0] >> b) & 1u) | (((a[w][1] >> b) & 1u) << 1) | (((a[w][2] >> b) & 1u) << 2) | (((a[w][3] >> b) & 1u) << 3);
+    };
+    const auto code2 = [b2, lane](int pos) {           // read 2: by position out of LDS
+        const int w = pos >> 5, b = pos & 31;
+        return ((b2[0 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) | (((b2[1 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) << 1) |
+               (((b2[2 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) << 2) | (((b2[3 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) << 3);
+    };
+    correct_errors_planes_one<PLANES_MAX_WORDS>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
+                                                q2 ? q2 + p * stride : nullptr, len2, j, mism, nchunks, action, min_qual_diff,
+                                                s_comp, changed + 2 * p, newlen + 2 * p, code1, code2);
+}
+
+int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,
+                          uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2, long long stride,
+                          long long n, int max_len, int action, int min_qual_diff, const uint8_t *comp, int32_t *changed,
+                          int32_t *newlen, hipStream_t st) {
+    CompTable ct;
+    memcpy(ct.c, comp, 256);
+    hipLaunchKernelGGL(correct_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, records, planes1, planes2,
+                       nchunks, s1, q1, l1, s2, q2, l2, stride, n, max_len, action, min_qual_diff, ct, changed, newlen);
+    return (int)hipGetLastError();
+}
+
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
                    long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
                    int max_len, int action,

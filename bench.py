@@ -251,7 +251,7 @@ class C5(C3):
         self.k += 1
         self.res = self.ia.match_insert_batch(d["b1"], d["b2"])
         self.be.insert_correct_batch(self.res.records, d["s1"], d["q1"], None, d["s2"], d["q2"], None, 2, 1, self.comp,
-                                     self.changed, self.newlen)
+                                     self.changed, self.newlen, planes1=d["b1"], planes2=d["b2"])
 
     def describe(self):
         d = C3.describe(self)

@@ -287,8 +287,12 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
 /* The correction step of InsertAdapterCutter.__call__ right after the insert match
  * (modifiers.py:397-404): d_insert_records are the 3 records per pair of atr_insert_match_batch;
  * a pair is corrected (correct_errors(read1, read2, insert_match, truncate_seqs=True)) when its
- * insert match exists and has errors > 0.  Other arguments as atr_correct_errors_batch. */
-int atr_insert_correct_batch(const atr_result *d_insert_records, uint8_t *d_seq1, uint8_t *d_qual1,
+ * insert match exists and has errors > 0.  d_planes1 / d_planes2 (may both be NULL): the plane64
+ * buffers the records were computed from (atr_pack_planes, ATR_TABLE_DNA15, layout width
+ * planes_max_len) -- with them the kernel finds the disagreeing positions 32 at a time and touches
+ * the ASCII matrices only there.  Other arguments as atr_correct_errors_batch. */
+int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *d_planes1, const uint8_t *d_planes2,
+                             int planes_max_len, uint8_t *d_seq1, uint8_t *d_qual1,
                              const int32_t *d_lens1, uint8_t *d_seq2, uint8_t *d_qual2, const int32_t *d_lens2,
                              int64_t stride, int64_t n, int max_len, int action, int min_qual_difference,
                              const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream);

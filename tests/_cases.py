@@ -640,6 +640,50 @@ def check_c5_head(count=None, text_pipeline=True):
     return n
 
 
+def check_plane_guided_correction(n=768, seed=5):
+    """atr_insert_correct_batch with the plane buffers (the disagreeing positions found 32 at a time)
+    against the same call without them (the byte walk of correct_errors_one, itself pinned to the
+    reference by the cutter fixtures): all three correction modes, ragged lengths, reads without
+    qualities for 'N'."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib, synth
+    from atropos_amd.align import InsertAligner
+    from atropos_amd.modifiers import COMP_TABLE
+    be = _lib.get_backend()
+    rng = random.Random(seed)
+    w = synth.workload("C5", 12345, n, device=str(be.device))
+    ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
+    done = 0
+    for action, ragged, quals in ((2, False, True), (1, False, True), (0, False, True), (0, False, False), (2, True, True)):
+        s1, s2 = w["reads1"].clone(), w["reads2"].clone()
+        l1 = l2 = None
+        if ragged:
+            l1 = torch.tensor([rng.randint(60, 250) for _ in range(n)], dtype=torch.int32, device=be.device)
+            l2 = torch.tensor([rng.randint(60, 250) for _ in range(n)], dtype=torch.int32, device=be.device)
+            cols = torch.arange(250, device=be.device)[None, :]
+            s1 = torch.where(cols < l1[:, None], s1, torch.zeros_like(s1))
+            s2 = torch.where(cols < l2[:, None], s2, torch.zeros_like(s2))
+        from atropos_amd.batch import ReadBatch
+        table = be.translate_table(_lib.TABLE_DNA15)
+        b1 = ReadBatch(be.pack_reads(s1, l1, 250, table, planes=True), l1, n, 250, _lib.TABLE_DNA15, table, layout="plane64")
+        b2 = ReadBatch(be.pack_reads(s2, l2, 250, table, planes=True), l2, n, 250, _lib.TABLE_DNA15, table, layout="plane64")
+        rec = ia.match_insert_batch(b1, b2).records
+        outs = []
+        for planes in (False, True):
+            a1, a2 = s1.clone(), s2.clone()
+            q1 = w["quals1"].clone() if quals else None
+            q2 = w["quals2"].clone() if quals else None
+            ch, nl = be.insert_correct_batch(rec, a1, q1, l1, a2, q2, l2, action, 1, COMP_TABLE,
+                                             planes1=b1 if planes else None, planes2=b2 if planes else None)
+            outs.append((a1, a2, q1, q2, ch, nl))
+        for x, y in zip(*outs):
+            assert (x is None and y is None) or torch.equal(x, y), (action, ragged, quals)
+        assert ragged or int((outs[0][4] > 0).any(dim=1).sum()) > n // 8
+        done += n
+    return done
+
+
 def check_device_resident_adapters():
     """The device-resident twins (match_records, LinkedAdapter.match_records,
     best_adapter_records) against the object-level batch path, which is itself pinned to the

@@ -154,6 +154,22 @@ class EmuBackend(object):
                                                      _ptr(changed), _ptr(newlen)), "atr_correct_errors_batch")
         return changed, newlen
 
+    def insert_correct_batch(self, records, seq1, qual1, lens1, seq2, qual2, lens2, action, min_qual_diff, comp,
+                             changed=None, newlen=None, planes1=None, planes2=None):
+        n = seq1.shape[0]
+        changed = torch.zeros((n, 2), dtype=torch.int32) if changed is None else changed
+        newlen = torch.zeros((n, 2), dtype=torch.int32) if newlen is None else newlen
+        fn = self.lib.emu_insert_correct_batch
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_void_p,
+                       C.c_void_p]
+        if n:
+            _check(fn(_ptr(records), None if planes1 is None else _ptr(planes1.packed),
+                      None if planes2 is None else _ptr(planes2.packed), 0 if planes1 is None else planes1.max_len,
+                      _ptr(seq1), _ptr(qual1), _ptr(lens1), _ptr(seq2), _ptr(qual2), _ptr(lens2), seq1.stride(0), n,
+                      seq1.shape[1], action, min_qual_diff, comp, _ptr(changed), _ptr(newlen)), "atr_insert_correct_batch")
+        return changed, newlen
+
     def insert_aligner_create(self, cfg):
         h = C.c_void_p()
         _check(self.lib.emu_insert_aligner_create(C.addressof(cfg), C.byref(h)), "atr_insert_aligner_create")

@@ -51,6 +51,50 @@ int emu_adapter_postfilter(int16_t *rec, int64_t n, int m, int min_overlap, doub
     return ATR_OK;
 }
 
+// atr_insert_correct_batch: gated on the insert-match records; with the plane buffers the
+// plane-guided walk of correct_planes_kernel, else the byte walk
+int emu_insert_correct_batch(const int16_t *records, const uint32_t *planes1, const uint32_t *planes2, int planes_max_len,
+                             uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
+                             int64_t stride, int64_t n, int max_len, int action, int min_qual_diff, const uint8_t *comp,
+                             int32_t *changed, int32_t *newlen) {
+    const int nchunks = (planes_max_len + 31) / 32;
+    for (int64_t p = 0; p < n; ++p) {
+        const int len1 = l1 ? l1[p] : max_len, len2 = l2 ? l2[p] : max_len;
+        const int16_t *rec = records + 24 * p;
+        if (rec[1] < 0 || rec[5] <= 0) {
+            changed[2 * p] = changed[2 * p + 1] = 0;
+            newlen[2 * p] = len1; newlen[2 * p + 1] = len2;
+            continue;
+        }
+        if (!planes1) {
+            correct_errors_one(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
+                               q2 ? q2 + p * stride : nullptr, len2, rec, action, min_qual_diff, true, comp, changed + 2 * p,
+                               newlen + 2 * p);
+            continue;
+        }
+        const int64_t tile = p >> 6;
+        const int lane = (int)(p & 63), j = rec[3];
+        auto word = [&](const uint32_t *planes, int plane, int idx) {
+            return planes[(((size_t)tile * nchunks + idx) * 64 + lane) * 4 + plane];
+        };
+        uint32_t mism[8] = {0};
+        for (int w = 0; w < nchunks; ++w) {
+            const uint32_t a[4] = {word(planes1, 0, w), word(planes1, 1, w), word(planes1, 2, w), word(planes1, 3, w)};
+            mism[w] = facing_mismatches(a, [&](int plane, int idx) { return word(planes2, plane, idx); }, nchunks, j, w);
+        }
+        auto code_at = [&](const uint32_t *planes, int pos) {
+            uint32_t c = 0;
+            for (int pl = 0; pl < 4; ++pl) c |= ((word(planes, pl, pos >> 5) >> (pos & 31)) & 1u) << pl;
+            return c;
+        };
+        correct_errors_planes_one<8>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
+                                     q2 ? q2 + p * stride : nullptr, len2, j, mism, nchunks, action, min_qual_diff, comp,
+                                     changed + 2 * p, newlen + 2 * p, [&](int w, int b) { return code_at(planes1, 32 * w + b); },
+                                     [&](int pos) { return code_at(planes2, pos); });
+    }
+    return 0;
+}
+
 int emu_correct_errors_batch(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2,
                              const int32_t *l2, int64_t stride, const int16_t *im, const uint8_t *mask, int64_t n,
                              int max_len, int action, int min_qual_diff, int truncate, const uint8_t comp[256],

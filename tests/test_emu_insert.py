@@ -46,3 +46,7 @@ def test_insert_errors(emu_backend):
         InsertAligner("A" * 65, "ACGT")
     assert ia.match_insert("", "") is None
     assert ia.match_insert("ACGT", "") is None
+
+
+def test_plane_guided_correction(emu_backend):
+    assert _cases.check_plane_guided_correction(n=320) == 5 * 320

@@ -94,6 +94,10 @@ def test_full_size_insert(hip_backend, oracle, name, count):
     assert 0.40 < nfound / count < 0.60
 
 
+def test_plane_guided_correction(hip_backend):
+    assert _cases.check_plane_guided_correction(n=200_000) == 5 * 200_000
+
+
 def test_c5_correction_at_size(hip_backend, oracle):
     """BASELINE config C5 at shard-piece size (2 M pairs 2 x 250 bp with qualities, read wildcards):
     insert match + liberal error correction in place (atr_insert_match_batch + atr_insert_correct_batch).
@@ -109,9 +113,10 @@ def test_c5_correction_at_size(hip_backend, oracle):
     w = synth.workload("C5", 0, n, device="cuda")
     ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
     s1, s2, q1, q2 = (w[k].clone() for k in ("reads1", "reads2", "quals1", "quals2"))
-    res = ia.match_insert_batch(ia.pack(s1), ia.pack(s2, check=True))
+    b1, b2 = ia.pack(s1), ia.pack(s2, check=True)
+    res = ia.match_insert_batch(b1, b2)
     rec = res.records
-    changed, newlen = hip_backend.insert_correct_batch(rec, s1, q1, None, s2, q2, None, 2, 1, COMP_TABLE)
+    changed, newlen = hip_backend.insert_correct_batch(rec, s1, q1, None, s2, q2, None, 2, 1, COMP_TABLE, planes1=b1, planes2=b2)
     torch.cuda.synchronize()
     ins = rec[:, 0].to(torch.int32)
     found, errs = ins[:, 1] >= 0, ins[:, 5]
