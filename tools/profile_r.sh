@@ -25,8 +25,17 @@ def find(pat):
     return glob.glob(os.path.join(out, pat), recursive=True)
 with open(os.path.join(out, "summary.txt"), "w") as fh:
     for f in find("trace/**/*kernel_stats.csv"):
-        fh.write("== kernel_stats (%s)\n" % f)
-        fh.write(open(f).read())
+        fh.write("== kernel_stats (%s): the library's kernels; everything else (torch kernels of the synthetic-data\n"
+                 "   generation and of bench.py's set-up, outside the timed steps) folded into one line\n" % f)
+        rows = list(csv.reader(open(f)))
+        fh.write(",".join(rows[0]) + "\n")
+        other_calls = other_ns = 0
+        for r in rows[1:]:
+            if "atr::" in r[0]:
+                fh.write(",".join('"%s"' % x if i == 0 else x for i, x in enumerate(r)) + "\n")
+            else:
+                other_calls += int(r[1]); other_ns += int(r[2])
+        fh.write('"(other: torch / runtime kernels, set-up only)",%d,%d\n' % (other_calls, other_ns))
     for f in find("trace/**/*kernel_trace.csv"):
         rows = list(csv.DictReader(open(f)))
         durs = collections.defaultdict(list)
