@@ -63,6 +63,7 @@ PROTOTYPES = {
     "atr_packed_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
     "atr_pack_reads": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_planes_count_uncoded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_pack_planes": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_multi_locate_work_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
@@ -228,6 +229,16 @@ class HipBackend(object):
                 _check(self.lib, fn(_ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), _ptr(starts), nreads, max_len, table,
                                     _ptr(packed), _ptr(invalid), self._stream()), "atr_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
+
+    def planes_count_uncoded(self, planes, lens, other_lens, nreads, max_len):
+        """Number of reads of a plane64 buffer with an uncoded base among their first
+        min(lens, other_lens) bases (atr_planes_count_uncoded); either lens may be None (max_len)."""
+        count = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        if nreads and max_len:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_planes_count_uncoded(_ptr(planes), _ptr(lens), _ptr(other_lens), nreads, max_len,
+                                                                   _ptr(count), self._stream()), "atr_planes_count_uncoded")
+        return int(count.item())
 
     def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,
                            max_ref_len, out_stride):

@@ -533,8 +533,9 @@ class InsertAligner(object):
 
     def pack(self, reads, check=False, max_len=None):
         """Pack one side of the pairs (DNA15 codes as bit planes, the "plane64" layout of
-        atr_pack_planes).  With ``check`` (read 2) every base must be an upper-case IUPAC letter.
-        ``max_len``: layout width (both sides of a batch must be packed with the same one)."""
+        atr_pack_planes).  With ``check`` EVERY base must be an upper-case IUPAC letter -- stricter than
+        match_insert, which only complements read 2 up to the length of read 1; ``pack_pair`` applies
+        exactly that rule.  ``max_len``: layout width (both sides of a batch need the same one)."""
         if isinstance(reads, ReadBatch):
             if reads.table_kind != _lib.TABLE_DNA15 or reads.layout != "plane64":
                 raise ValueError("the insert aligner needs reads packed by InsertAligner.pack (DNA15 codes, plane64 layout)")
@@ -563,17 +564,30 @@ class InsertAligner(object):
             packed = be.pack_reads(ascii_t, lens_t, max_len, table, planes=True)
         return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_DNA15, table, layout="plane64")
 
+    def pack_pair(self, reads1, reads2):
+        """Both sides of a batch of pairs, in one layout width, validated the way match_insert does it:
+        read 2 is cut to the length of read 1 before it is reverse-complemented
+        (reference: align/__init__.py:259-267), so only that prefix of read 2 has to consist of
+        upper-case IUPAC letters.  Sides that are already ReadBatches are taken as they are."""
+        width = None
+        if isinstance(reads1, (list, tuple)) and isinstance(reads2, (list, tuple)):
+            # whatever the longest read of each side is
+            width = max([len(r) for r in reads1] + [len(r) for r in reads2] + [0])
+        prepacked = isinstance(reads2, ReadBatch)
+        b1, b2 = self.pack(reads1, max_len=width), self.pack(reads2, max_len=width)
+        if b1.nreads != b2.nreads:
+            raise ValueError("need as many first reads as second reads")
+        if not prepacked and b1.max_len == b2.max_len:
+            bad = self._backend.planes_count_uncoded(b2.packed, b2.lens, b1.lens, b2.nreads, b2.max_len)
+            if bad:
+                raise ValueError("%d second read(s) contain bases without an upper-case IUPAC code where they face "
+                                 "the first read; the device insert aligner cannot reverse-complement them" % bad)
+        return b1, b2
+
     def match_insert_batch(self, reads1, reads2):
         """Batched ``match_insert``; reads1/reads2: ReadBatch (DNA15), list of str, or
         uint8 [n, width] ASCII tensors of equal-length reads."""
-        width = None
-        if isinstance(reads1, (list, tuple)) and isinstance(reads2, (list, tuple)):
-            # both sides in one layout width, whatever the longest read of each side is
-            width = max([len(r) for r in reads1] + [len(r) for r in reads2] + [0])
-        b1 = self.pack(reads1, max_len=width)
-        b2 = self.pack(reads2, check=True, max_len=width)
-        if b1.nreads != b2.nreads:
-            raise ValueError("need as many first reads as second reads")
+        b1, b2 = self.pack_pair(reads1, reads2)
         max_len = max(b1.max_len, b2.max_len)
         if b1.max_len != b2.max_len:
             raise ValueError("both read batches must be packed with the same max_len (got %d and %d)"

@@ -23,6 +23,8 @@ int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uin
                    int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st);
+int launch_planes_uncoded(const uint4 *planes, int nchunks, const int32_t *lens, const int32_t *other, long long n,
+                          int max_len, int32_t *count, hipStream_t st);
 int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,
                           uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2, long long stride,
                           long long n, int max_len, int action, int min_qual_diff, const uint8_t *comp, int32_t *changed,
@@ -86,8 +88,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         const uint8_t *src_al = src - mis;
         const long long rows_here = min<long long>(64, nreads - tile * 64);
         const long long need = mis + rows_here * row_stride;       // bytes of the window that are ours
-        for (long long o = (long long)lane * 16; o < need; o += 64 * 16)
-            *(uint4 *)(stage + o) = *(const uint4 *)(src_al + o);
+        // the caller's matrix is [ascii, buf_end): a 16-byte piece of the aligned window that sticks out of it
+        // (before the first row of the batch, after its last) is copied byte by byte, never read as a whole
+        const uint8_t *buf_end = ascii + nreads * row_stride;
+        for (long long o = (long long)lane * 16; o < need; o += 64 * 16) {
+            const uint8_t *piece = src_al + o;
+            if (piece >= ascii && piece + 16 <= buf_end) {
+                *(uint4 *)(stage + o) = *(const uint4 *)piece;
+            } else {
+                for (int b = 0; b < 16; ++b) stage[o + b] = (piece + b >= ascii && piece + b < buf_end) ? piece[b] : (uint8_t)0;
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         row = stage + mis + (size_t)lane * row_stride + start;     // LDS is visible wave-wide after the stores land
         __builtin_amdgcn_s_waitcnt(0);
@@ -127,8 +138,19 @@ static int pack_launch(const uint8_t *d_ascii, int64_t row_stride, const int32_t
     const int nchunks = (max_len + 31) / 32;
     const long long ntiles = (nreads + 63) / 64;
     const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-    if (row_stride > 0 && row_stride <= PACK_STAGE_MAX) {
-        const size_t per_wave = (((size_t)64 * row_stride + 16) + 15) & ~(size_t)15;
+    const size_t per_wave = (((size_t)64 * (row_stride > 0 ? row_stride : 0) + 16) + 15) & ~(size_t)15;
+    bool staged = row_stride > 0 && row_stride <= PACK_STAGE_MAX;
+    if (staged && 4 * per_wave + 2048 > 64 * 1024) {
+        // more dynamic LDS than a launch gets by default (row_stride 250 .. 256): ask for it once; gfx950 has 160 KB per CU
+        static thread_local size_t granted[2] = {0, 0};
+        if (granted[PLANES ? 1 : 0] < 4 * per_wave) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&pack_kernel<true, PLANES>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * per_wave));
+            if (e == hipSuccess) granted[PLANES ? 1 : 0] = 4 * per_wave;
+            else { (void)hipGetLastError(); staged = false; }      // the plain kernel needs no LDS
+        }
+    }
+    if (staged) {
         hipLaunchKernelGGL((pack_kernel<true, PLANES>), grid, block, 4 * per_wave, (hipStream_t)stream, d_ascii,
                            (long long)row_stride, d_lens, d_starts, (long long)nreads, max_len, nchunks, tab,
                            (uint4 *)d_packed, d_invalid);
@@ -326,6 +348,16 @@ int atr_correct_errors_batch(uint8_t *d_seq1, uint8_t *d_qual1, const int32_t *d
                                   max_len, action, min_qual_difference, truncate_seqs, comp, d_changed, d_newlen,
                                   (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "correct_kernel launch");
+}
+
+int atr_planes_count_uncoded(const uint8_t *d_planes, const int32_t *d_lens, const int32_t *d_other_lens, int64_t nreads,
+                             int max_len, int32_t *d_count, void *stream) {
+    if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (nreads == 0 || max_len == 0) return ATR_OK;
+    if (!d_planes || !d_count) return ATR_ERR_INVALID;
+    const int rc = launch_planes_uncoded((const uint4 *)d_planes, (max_len + 31) / 32, d_lens, d_other_lens, nreads, max_len,
+                                         d_count, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "planes_uncoded_kernel launch");
 }
 
 int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *d_planes1, const uint8_t *d_planes2,

@@ -146,6 +146,40 @@ int launch_correct_planes(const int16_t *records, const uint4 *planes1, const ui
     return (int)hipGetLastError();
 }
 
+// Reads whose first min(len, other_len) bases hold a byte the pack table gave no code (all four
+// plane bits clear): InsertAligner.match_insert only ever looks at that common prefix of read 2.
+__global__ __launch_bounds__(256) void planes_uncoded_kernel(const uint4 *__restrict__ planes, int nchunks,
+                                                             const int32_t *__restrict__ lens,
+                                                             const int32_t *__restrict__ other, long long n, int max_len,
+                                                             int32_t *__restrict__ count) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    const long long p = tile * 64 + lane;
+    if (tile * 64 >= n) return;
+    int len = 0;
+    if (p < n) len = min(lens ? lens[p] : max_len, other ? other[p] : max_len);
+    len = max(0, min(len, max_len));
+    const uint4 *t = planes + (size_t)tile * nchunks * 64 + lane;
+    bool bad = false;
+    for (int c = 0; c < nchunks; ++c) {
+        const int left = len - 32 * c;
+        if (__builtin_amdgcn_readfirstlane(__any(left > 0)) == 0) break;
+        const uint4 v = t[(size_t)c * 64];
+        const uint32_t coded = v.x | v.y | v.z | v.w;
+        const uint32_t want = left >= 32 ? 0xFFFFFFFFu : left > 0 ? (1u << left) - 1u : 0u;
+        bad = bad || (~coded & want) != 0u;
+    }
+    const unsigned long long votes = __ballot(bad);
+    if (lane == 0 && votes) atomicAdd(count, (int)__popcll(votes));
+}
+
+int launch_planes_uncoded(const uint4 *planes, int nchunks, const int32_t *lens, const int32_t *other, long long n,
+                          int max_len, int32_t *count, hipStream_t st) {
+    hipLaunchKernelGGL(planes_uncoded_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, planes, nchunks, lens,
+                       other, n, max_len, count);
+    return (int)hipGetLastError();
+}
+
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
                    long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
                    int max_len, int action,

@@ -302,7 +302,12 @@ class PairedTrimPipeline(object):
                                        % _lib.INSERT_MAX_READ)
         table = be.translate_table(_lib.TABLE_DNA15)
         pb1 = src1.planes(max_len, _lib.TABLE_DNA15, table)
-        pb2 = src2.planes(max_len, _lib.TABLE_DNA15, table, check=True)
+        pb2 = src2.planes(max_len, _lib.TABLE_DNA15, table)
+        # match_insert complements read 2 only as far as read 1 reaches (align/__init__.py:259-267)
+        bad = be.planes_count_uncoded(pb2.packed, pb2.lens, pb1.lens, n, max_len)
+        if bad:
+            raise ValueError("%d second read(s) contain bases without an upper-case IUPAC code where they face the first "
+                             "read; the device insert aligner cannot reverse-complement them" % bad)
         ins = self.insert.match_insert_batch(pb1, pb2).records
         # semi-global fallback (modifiers.py:405-407): only the pairs without an insert match need it
         miss = torch.nonzero(ins[:, 0, 1] < 0).squeeze(1)

@@ -104,6 +104,15 @@ int atr_pack_planes(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d
                    const int32_t *d_starts, int64_t nreads, int max_len, const uint8_t table[256],
                    uint8_t *d_packed, int32_t *d_invalid, void *stream);
 
+/* Counts into *d_count (device int32, zeroed by the caller) the reads of a plane64 buffer whose
+ * first min(d_lens[r], d_other_lens[r]) bases hold an uncoded base (a byte the pack table maps
+ * to 0).  InsertAligner.match_insert reverse-complements only seq2[:min(len(seq1), len(seq2))]
+ * (align/__init__.py:251-259), so that prefix -- not the whole read, which is what d_invalid of
+ * the pack calls covers -- is what must have complements.  Either length array may be NULL
+ * (max_len). */
+int atr_planes_count_uncoded(const uint8_t *d_planes, const int32_t *d_lens, const int32_t *d_other_lens,
+                             int64_t nreads, int max_len, int32_t *d_count, void *stream);
+
 /* ---- Aligner (atropos/align/_align.pyx:121-494) -------------------------- */
 
 /* Aligner.__cinit__(reference, max_error_rate, flags, wildcard_ref,

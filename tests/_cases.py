@@ -997,3 +997,27 @@ def check_fastq_reader_golden():
             got = [list(r) for r in batch.to_records()]
             assert got == case["records"], (k, got[:3], case["records"][:3])
     return len(cases), errors
+
+
+def check_read2_validation(ia):
+    """match_insert reverse-complements read 2 only as far as read 1 reaches (reference
+    align/__init__.py:259-267): letters without a code beyond that point are none of its business,
+    neither per pair nor in a batch (uint8 matrices and the FASTQ pipelines included)."""
+    import pytest
+    r1 = "ACGTTGCAAGGCTA"
+    r2 = "TAGCCTTGCAACGT"
+    want = ia.match_insert(r1, r2)
+    assert ia.match_insert(r1, r2 + "xx..acgt") == ia.match_insert(r1, r2 + "GGTTACGT")
+    got = ia.match_insert_batch([r1, r1, r1[:7]], [r2, r2 + "nn!?", r2[:7] + "acgtacg"]).results()
+    assert got[0] == want and got[1] == ia.match_insert(r1, r2 + "AAAA") and got[2] == ia.match_insert(r1[:7], r2[:7])
+    for at in (0, 5, len(r1) - 1):
+        broken = r2[:at] + "x" + r2[at + 1:] + "ACGT"
+        with pytest.raises(ValueError):
+            ia.match_insert_batch([r1, r1], [r2, broken])
+    # 33 .. 70 bases: the boundary inside and at the end of a 32-base chunk
+    for n1 in (31, 32, 33, 63, 64, 65):
+        a = ("ACGTTGCA" * 10)[:n1]
+        b = ("TGCAACGT" * 10)[:n1]
+        ia.match_insert_batch([a], [b + "?"])
+        with pytest.raises(ValueError):
+            ia.match_insert_batch([a], [b[:-1] + "?"])

@@ -111,6 +111,14 @@ class EmuBackend(object):
                       max_len, table, _ptr(packed), _ptr(invalid)), "emu_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 
+    def planes_count_uncoded(self, planes, lens, other_lens, nreads, max_len):
+        count = torch.zeros((1,), dtype=torch.int32)
+        if nreads and max_len:
+            self.lib.emu_planes_count_uncoded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+            _check(self.lib.emu_planes_count_uncoded(_ptr(planes), _ptr(lens), _ptr(other_lens), nreads, max_len, _ptr(count)),
+                   "emu_planes_count_uncoded")
+        return int(count.item())
+
     def multi_locate_batch(self, refs, ref_lens, queries, query_lens, e, flags, min_overlap, max_matches,
                            max_ref_len, out_stride):
         npairs = refs.shape[0]

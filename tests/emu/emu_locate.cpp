@@ -280,6 +280,25 @@ int emu_pack_planes(const uint8_t *ascii, int64_t row_stride, const int32_t *len
     return ATR_OK;
 }
 
+// atr_planes_count_uncoded
+int emu_planes_count_uncoded(const uint8_t *planes, const int32_t *lens, const int32_t *other, int64_t nreads, int max_len,
+                             int32_t *count) {
+    const int nchunks = (max_len + 31) / 32;
+    const uint32_t *src = (const uint32_t *)planes;
+    for (long long r = 0; r < nreads; ++r) {
+        const int len = std::max(0, std::min(std::min(lens ? lens[r] : max_len, other ? other[r] : max_len), max_len));
+        bool bad = false;
+        for (int c = 0; c < nchunks && 32 * c < len; ++c) {
+            const uint32_t *w = src + (((size_t)(r / 64) * nchunks + c) * 64 + (r % 64)) * 4;
+            const int left = len - 32 * c;
+            const uint32_t want = left >= 32 ? 0xFFFFFFFFu : (1u << left) - 1u;
+            bad = bad || (~(w[0] | w[1] | w[2] | w[3]) & want) != 0u;
+        }
+        if (bad) *count += 1;
+    }
+    return ATR_OK;
+}
+
 }  // extern "C"
 
 typedef void (*emu_dp_fn)(const atr_aligner *, const uint32_t *, const int32_t *, int, int, uint32_t *,

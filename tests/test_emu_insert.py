@@ -46,6 +46,7 @@ def test_insert_errors(emu_backend):
         InsertAligner("A" * 65, "ACGT")
     assert ia.match_insert("", "") is None
     assert ia.match_insert("ACGT", "") is None
+    _cases.check_read2_validation(ia)
 
 
 def test_plane_guided_correction(emu_backend):

@@ -156,3 +156,8 @@ def test_c5_correction_at_size(hip_backend, oracle):
     both = found & (res2[:, 1] >= 0) & (res2[:, 0] == ins[:, 0]) & (res2[:, 3] == ins[:, 3])
     assert bool((res2[both][:, 5] <= errs[both]).all())
     assert float(both.float().mean().item()) > 0.4
+
+
+def test_read2_validation(hip_backend):
+    from atropos_amd.align import InsertAligner
+    _cases.check_read2_validation(InsertAligner("TTAGACATATGG", "CAGTGGAGTATA"))

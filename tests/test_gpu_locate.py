@@ -163,3 +163,36 @@ def test_single_process_multi_stream(hip_backend):
     for _ in range(3):
         got, seconds = shard.sharded_locate_threads(make, reads, backends)
         assert len(seconds) == 3 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("planes", [False, True])
+def test_pack_staged_window_edges(hip_backend, planes):
+    """The LDS-staged pack (row stride <= 256) against the plain one (wide rows) on matrices allocated
+    to the byte: odd strides leave the 16-byte staging window hanging over both ends of the matrix
+    (those pieces are copied byte by byte), strides 250..256 need more than the default 64 KB of LDS."""
+    from atropos_amd import _lib
+    be = hip_backend
+    table = be.translate_table(_lib.TABLE_DNA15)
+    gen = torch.Generator().manual_seed(77)
+    letters = torch.tensor(list(b"ACGTNRYacgtn.-"), dtype=torch.uint8)
+    for width in (1, 15, 16, 17, 63, 100, 101, 249, 250, 251, 255, 256):
+        for nreads in (1, 63, 64, 65, 300):
+            host = letters[torch.randint(0, len(letters), (nreads, width), generator=gen)]
+            lens = torch.randint(0, width + 1, (nreads,), generator=gen, dtype=torch.int32)
+            tight = host.clone().to(be.device)                                 # exactly nreads * width bytes
+            wide = torch.zeros((nreads, 512), dtype=torch.uint8)
+            wide[:, :width] = host
+            wide = wide.to(be.device)
+            dl = lens.to(be.device)
+            a, bad_a = be.pack_reads(tight, dl, width, table, count_invalid=True, planes=planes)
+            b, bad_b = be.pack_reads(wide, dl, width, table, count_invalid=True, planes=planes)
+            torch.cuda.synchronize()
+            assert bad_a == bad_b, (width, nreads)
+            assert torch.equal(a.cpu(), b.cpu()), (width, nreads)
+            # a sub-matrix in the middle of a bigger allocation: the window may touch the neighbours, never use them
+            pool = torch.full((nreads * width + 64,), 0x41, dtype=torch.uint8, device=be.device)
+            inner = pool[29:29 + nreads * width].view(nreads, width)
+            inner.copy_(tight)
+            c = be.pack_reads(inner, dl, width, table, planes=planes)
+            torch.cuda.synchronize()
+            assert torch.equal(a.cpu(), c.cpu()), (width, nreads)
