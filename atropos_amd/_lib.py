@@ -72,6 +72,7 @@ PROTOTYPES = {
                                          C.c_void_p, C.c_int, C.c_void_p]),
     "atr_compare_batch": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_compare_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_adapter_postfilter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                          C.c_double, C.c_int, C.c_void_p]),
     "atr_correct_errors_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -401,6 +402,16 @@ class HipBackend(object):
                                                                  _ptr(front), _ptr(back), _ptr(self._work), self._stream()),
                        "atr_linked_match_batch")
         return which, front, back
+
+    def compare_packed(self, h, packed, lens, nreads, max_len, suffix):
+        """atr_compare_packed: compare_prefixes / compare_suffixes of aligner ``h``'s reference against
+        reads packed for it.  int16 [nreads, 8]."""
+        out = self.empty((nreads, 8), torch.int16)
+        if nreads:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_compare_packed(h, _ptr(packed), _ptr(lens), nreads, max_len, int(suffix),
+                                                             _ptr(out), self._stream()), "atr_compare_packed")
+        return out
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                            query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):

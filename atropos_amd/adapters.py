@@ -116,11 +116,6 @@ class AsciiSource(object):
                                                       _lib.get_backend(), starts=self.starts)
         return self._batches[key]
 
-    def ascii(self):
-        if self.starts is not None:
-            raise NotImplementedError("sliced reads with anchored no-indel adapters")
-        return self.ascii_upper, self.lens
-
     def sliced(self, starts):
         """The source of the reads ``read[start:]``."""
         if self.starts is not None:
@@ -280,14 +275,12 @@ class Adapter(object):
 
     def match_source(self, source):
         """``match_records`` over any read source: an object with ``n``, ``batch(table_kind,
-        table)`` (the reads 4-bit packed with that table) and ``ascii()`` ((uint8 [n, width]
-        upper-case matrix, lens) -- only anchored no-indel adapters need it)."""
+        table)`` (the reads 4-bit packed with that table)."""
         be = _lib.get_backend()
         m = len(self.sequence)
         if self._plain_compare:
-            ascii_upper, lens = source.ascii()
-            rec = align.compare_batch(self.sequence, ascii_upper, self.adapter_wildcards, self.read_wildcards,
-                                      suffix=(self.where == SUFFIX), lens=lens)
+            rec = self.aligner.compare_batch(source.batch(self.aligner.table_kind, self.aligner._table),
+                                             suffix=(self.where == SUFFIX))
         else:
             rec = self.aligner.locate_batch(source.batch(self.aligner.table_kind, self.aligner._table)).records
         rmp_t = None

@@ -177,6 +177,23 @@ class Aligner(object):
         return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len,
                                             filtered))
 
+    def compare_batch(self, reads, suffix=False):
+        """``compare_prefixes(reference, read, wildcard_ref, wildcard_query)`` (``compare_suffixes`` with
+        ``suffix``) for a batch packed for this aligner -- what Adapter.match_to runs instead of
+        ``locate`` for anchored adapters without indels (reference: adapters/__init__.py:370-380,
+        _align.pyx:501-544).  Returns the int16 [n, 8] record tensor on the device."""
+        batch = self.pack(reads)
+        be = self._backend
+        if self._handle is None:                      # empty reference: the empty overlap
+            import torch
+            rec = be.empty((batch.nreads, 8), torch.int16)
+            rec.zero_()
+            if suffix:
+                lens = batch.lens if batch.lens is not None else torch.full((batch.nreads,), batch.max_len)
+                rec[:, 2] = rec[:, 3] = lens.to(rec.device).to(torch.int16)
+            return rec
+        return be.compare_packed(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len, suffix)
+
     def locate(self, query):
         """locate(query) -> (refstart, refstop, querystart, querystop, matches, errors)
 

@@ -23,6 +23,8 @@ int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uin
                    int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st);
+int launch_compare_packed(const LocateParams &lp, const uint32_t *packed, const int32_t *lens, long long n, int max_len,
+                          int suffix, int16_t *out, hipStream_t st);
 int launch_planes_uncoded(const uint4 *planes, int nchunks, const int32_t *lens, const int32_t *other, long long n,
                           int max_len, int32_t *count, hipStream_t st);
 int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,
@@ -321,6 +323,17 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
     const int rc = launch_compare((const uint8_t *)ref, m, d_queries, query_stride, d_lens, n, max_len, wildcard_ref,
                                   wildcard_query, suffix, (int16_t *)d_out, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "compare_kernel launch");
+}
+
+int atr_compare_packed(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads, int max_len,
+                       int suffix, atr_result *d_out, void *stream) {
+    if (!a || nreads < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (max_len > ATR_MAX_READ_LEN) return ATR_ERR_UNSUPPORTED;
+    if (nreads == 0) return ATR_OK;
+    if (!d_out || (!d_packed && max_len > 0)) return ATR_ERR_INVALID;
+    const int rc = launch_compare_packed(a->p, (const uint32_t *)d_packed, d_lens, nreads, max_len, suffix,
+                                         (int16_t *)d_out, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "compare_packed_kernel launch");
 }
 
 int atr_adapter_postfilter(atr_result *d_records, int64_t n, int adapter_len, int min_overlap,

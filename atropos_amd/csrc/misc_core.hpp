@@ -133,6 +133,30 @@ ATR_DEV void compare_one(const uint8_t *ref, int m, const uint8_t *query, int n,
     rec[4] = (int16_t)matches; rec[5] = (int16_t)(len - matches); rec[6] = 0; rec[7] = 0;
 }
 
+// compare_prefixes / compare_suffixes of an aligner's reference against one tile64-packed read
+// (the codes the read was packed with are the aligner's query table, so "does row i match this
+// base" is the aligner's own nmask bit: byte equality or 4-bit AND as its wildcard flags say,
+// _align.pyx:521-539).  words: the read's packed dwords, word w of the read at words[wstride(w)]
+// with wstride(w) = (w >> 2) * 256 + (w & 3) for the lane's slot of a tile (chunk stride 64 uint4).
+template <class WORD>
+ATR_DEV void compare_packed_one(const uint32_t (*nmask)[4], int m, WORD word_at, int n, bool suffix, int16_t *rec) {
+    const int len = mc_min(m, n);
+    // nmask is indexed by register position: reference row i (0-based) owns bit round_up_rows_dev(m) - m + i
+    const int r0 = round_up_rows_dev(m) - m + (suffix ? m - len : 0), q0 = suffix ? n - len : 0;
+    int matches = 0;
+    uint32_t cur = 0;
+    for (int i = 0; i < len; ++i) {
+        const int pos = q0 + i;
+        if (i == 0 || (pos & 7) == 0) cur = word_at(pos >> 3);
+        const uint32_t code = (cur >> (4 * (pos & 7))) & 15u;
+        const int row = r0 + i;
+        matches += 1 - (int)((nmask[code][row >> 5] >> (row & 31)) & 1u);
+    }
+    if (suffix) { rec[0] = (int16_t)(m - len); rec[1] = (int16_t)m; rec[2] = (int16_t)(n - len); rec[3] = (int16_t)n; }
+    else { rec[0] = 0; rec[1] = (int16_t)len; rec[2] = 0; rec[3] = (int16_t)len; }
+    rec[4] = (int16_t)matches; rec[5] = (int16_t)(len - matches); rec[6] = 0; rec[7] = 0;
+}
+
 // Post-filter of Adapter.match_to (atropos/adapters/__init__.py:386-398) on one result
 // record, in place: keep the alignment iff size >= min_overlap and errors/size <=
 // max_error_rate (a DIVISION in double, unlike the DP's product) and, when a table is given,

@@ -39,6 +39,32 @@ __global__ __launch_bounds__(256) void compare_kernel(const CompareRef cr, int m
                 use_tables ? s_tq : nullptr, suffix != 0, out + p * 8);
 }
 
+// compare_packed_one for a batch in tile64 layout: one read per lane, one tile per wave.
+__global__ __launch_bounds__(256) void compare_packed_kernel(const LocateParams lp, const uint32_t *__restrict__ packed,
+                                                             const int32_t *__restrict__ lens, long long n, int max_len,
+                                                             int suffix, int16_t *__restrict__ out) {
+    __shared__ uint32_t s_nmask[16][4];
+    if (threadIdx.x < 64) s_nmask[threadIdx.x >> 2][threadIdx.x & 3] = lp.nmask[threadIdx.x >> 2][threadIdx.x & 3];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long tile = (long long)blockIdx.x * 4 + wave;
+    const long long p = tile * 64 + lane;
+    if (p >= n) return;
+    const int nchunks = (max_len + 31) / 32;
+    const uint32_t *mine = packed + ((size_t)tile * nchunks * 64 + lane) * 4;
+    const int len = max(0, min(lens ? lens[p] : max_len, max_len));
+    int16_t rec[8];
+    compare_packed_one(s_nmask, lp.m, [mine](int w) { return mine[(size_t)(w >> 2) * 256 + (w & 3)]; }, len, suffix != 0, rec);
+    *(uint4 *)(out + 8 * p) = *(const uint4 *)rec;
+}
+
+int launch_compare_packed(const LocateParams &lp, const uint32_t *packed, const int32_t *lens, long long n, int max_len,
+                          int suffix, int16_t *out, hipStream_t st) {
+    hipLaunchKernelGGL(compare_packed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lp, packed, lens, n,
+                       max_len, suffix, out);
+    return (int)hipGetLastError();
+}
+
 struct CompTable { uint8_t c[256]; };
 
 __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, uint8_t *__restrict__ q1,

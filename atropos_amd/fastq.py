@@ -240,9 +240,6 @@ class RecordSource(object):
                                            planes=True)
         return ReadBatch(packed, lens, self.n, max_len, table_kind, table, layout="plane64")
 
-    def ascii(self):
-        raise NotImplementedError("anchored adapters without indels are not supported by the device FASTQ pipeline")
-
 
 # ---------------------------------------------------------------------------------------------
 # file streaming: page-locked staging, threaded reads, read-ahead and write-behind

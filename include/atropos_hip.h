@@ -262,6 +262,16 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
                       const int32_t *d_lens, int64_t n, int max_len, int wildcard_ref, int wildcard_query,
                       int suffix, atr_result *d_out, void *stream);
 
+/* The same comparison for reads that are already packed for an aligner (tile64, the table of
+ * atr_aligner_query_table): `a`'s reference against the first (suffix: last) min(m, len) bases of
+ * every read, matching by the aligner's own rule (byte equality without wildcard flags, 4-bit AND
+ * with them -- _align.pyx:521-539 picks the same tables as Aligner.__cinit__, :243-248).  This is
+ * the branch Adapter.match_to takes for anchored adapters without indels
+ * (adapters/__init__.py:370-380); it lets the device pipelines, whose reads only exist packed
+ * (FASTQ chunks, the remainders a 5' linked part leaves), run it without an ASCII copy. */
+int atr_compare_packed(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
+                       int max_len, int suffix, atr_result *d_out, void *stream);
+
 /* ---- Adapter.match_to post-filter (adapters/__init__.py:386-398) ---------- */
 
 /* Applies, in place on n result records, the acceptance test Adapter.match_to runs on an

@@ -111,6 +111,14 @@ class EmuBackend(object):
                       max_len, table, _ptr(packed), _ptr(invalid)), "emu_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 
+    def compare_packed(self, h, packed, lens, nreads, max_len, suffix):
+        out = torch.zeros((nreads, 8), dtype=torch.int16)
+        if nreads:
+            self.lib.emu_compare_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+            _check(self.lib.emu_compare_packed(h, _ptr(packed), _ptr(lens), nreads, max_len, int(suffix), _ptr(out)),
+                   "emu_compare_packed")
+        return out
+
     def planes_count_uncoded(self, planes, lens, other_lens, nreads, max_len):
         count = torch.zeros((1,), dtype=torch.int32)
         if nreads and max_len:

@@ -44,6 +44,21 @@ int emu_compare_batch(const char *ref, int m, const uint8_t *queries, int64_t q_
     return ATR_OK;
 }
 
+// atr_compare_packed
+int emu_compare_packed(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, int64_t n, int max_len, int suffix,
+                       int16_t *out) {
+    if (!a || n < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (max_len > ATR_MAX_READ_LEN) return ATR_ERR_UNSUPPORTED;
+    const int nchunks = (max_len + 31) / 32;
+    for (int64_t p = 0; p < n; ++p) {
+        const uint32_t *mine = packed + ((size_t)(p / 64) * nchunks * 64 + (p % 64)) * 4;
+        const int len = std::max(0, std::min(lens ? lens[p] : max_len, max_len));
+        compare_packed_one(a->p.nmask, a->p.m, [mine](int w) { return mine[(size_t)(w >> 2) * 256 + (w & 3)]; }, len,
+                           suffix != 0, out + p * 8);
+    }
+    return ATR_OK;
+}
+
 int emu_adapter_postfilter(int16_t *rec, int64_t n, int m, int min_overlap, double max_error_rate,
                            const double *rmp, int rmp_ld, double max_rmp, int accept_full) {
     for (int64_t p = 0; p < n; ++p)

@@ -59,6 +59,46 @@ def synth_fastq(nreads, seed, dos=False, repeat_name=False):
 
 
 TRUSEQ = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCA"
+ANCHOR5, ANCHOR3 = "ACGTACGTTGCA", "GGCATTCAGGAC"
+
+
+def synth_anchor_fastq(nreads, seed):
+    """Reads that start with (a damaged copy of) ANCHOR5 and end with (a damaged copy of) ANCHOR3:
+    substitutions, the odd insertion/deletion, N, truncations -- the input of the anchored
+    adapter cases, without indels (compare_prefixes / compare_suffixes) and with them."""
+    rng = np.random.RandomState(seed)
+
+    def damage(s):
+        out = []
+        for c in s:
+            r = rng.rand()
+            if r < 0.08:
+                out.append("ACGTN"[rng.randint(0, 5)])
+            elif r < 0.10:
+                continue
+            elif r < 0.12:
+                out.append(c + "ACGT"[rng.randint(0, 4)])
+            else:
+                out.append(c)
+        return "".join(out)
+
+    out = []
+    for i in range(nreads):
+        head = damage(ANCHOR5) if rng.rand() < 0.8 else ""
+        tail = damage(ANCHOR3) if rng.rand() < 0.8 else ""
+        if rng.rand() < 0.15:
+            head = head[rng.randint(0, 4):]
+        if rng.rand() < 0.15:
+            tail = tail[:max(0, len(tail) - rng.randint(0, 4))]
+        body = "".join("ACGT"[v] for v in rng.randint(0, 4, size=rng.randint(0, 60)))
+        seq = head + body + tail
+        if rng.rand() < 0.05:
+            seq = seq.lower()
+        if rng.rand() < 0.03:
+            seq = seq[:rng.randint(0, 8)]
+        qual = "".join(chr(int(v) + 33) for v in rng.randint(20, 41, size=len(seq)))
+        out.append("@anchor%d\n%s\n+\n%s\n" % (i, seq, qual))
+    return "".join(out)
 
 # (input name, argument string) -- the reference's own CLI tests (tests/test_atropos.py) that
 # take FASTQ input and stay inside the device pipeline's envelope, plus parameter sweeps on
@@ -105,6 +145,16 @@ CASES = [
     ("synth.fastq", "-a ^ACGTACGT..." + TRUSEQ + " -e 0.15"),
     ("synth.fastq", "-a " + TRUSEQ + "$ -q 12"),
     ("synth.fastq", "-g ^" + "ACGTAC" + " -O 4 -e 0.2"),
+    # anchored adapters, with and without indels (Adapter.match_to's compare_prefixes / compare_suffixes branch)
+    ("anchor.fastq", "-g ^" + ANCHOR5 + " -e 0.2"),
+    ("anchor.fastq", "-g ^" + ANCHOR5 + " -e 0.2 --no-indels"),
+    ("anchor.fastq", "-a " + ANCHOR3 + "$ -e 0.2 --no-indels"),
+    ("anchor.fastq", "-a " + ANCHOR3 + "$ -e 0.1 --no-indels -O 5 --discard-untrimmed"),
+    ("anchor.fastq", "-a ^" + ANCHOR5 + "..." + ANCHOR3 + " -e 0.2 --no-indels"),
+    ("anchor.fastq", "-g ^" + ANCHOR5 + " -a " + ANCHOR3 + "$ -e 0.25 --no-indels --match-read-wildcards -n 2"),
+    ("anchor.fastq", "-g ^ACGTNCGTTGCA -e 0.2 --no-indels -N"),
+    ("anchor.fastq", "-g ^ACGTNCGTTGCA -e 0.2 --no-indels --mask-adapter"),
+    ("synth.fastq", "-a " + TRUSEQ + "$ --no-indels -e 0.15"),
     ("synth_dos.fastq", "-a " + TRUSEQ + " -q 20 -m 20"),
     ("synth_name2.fastq", "-a " + TRUSEQ + " --trim-n"),
     ("nofinalnewline.fastq", "-a TTAGACATATCTCCGTCG"),
@@ -175,6 +225,8 @@ def main():
     sys.path.insert(0, args.scratch)
     from atropos.commands import get_command
     data_dir = os.path.join(args.scratch, "tests", "data")
+    if not os.path.isdir(data_dir):
+        data_dir = "/root/reference/tests/data"                    # the reference's own test inputs (build container)
 
     inputs = {}
     for name in sorted({c[0] for c in CASES}):
@@ -184,6 +236,7 @@ def main():
         elif os.path.exists(path + ".gz"):
             inputs[name] = gzip.open(path + ".gz", "rb").read()
     inputs["synth.fastq"] = synth_fastq(1200, 11).encode()
+    inputs["anchor.fastq"] = synth_anchor_fastq(600, 14).encode()
     inputs["synth_dos.fastq"] = synth_fastq(100, 12, dos=True).encode()
     inputs["synth_name2.fastq"] = synth_fastq(100, 13, repeat_name=True).encode()
     small = inputs["small.fastq"]

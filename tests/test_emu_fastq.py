@@ -17,8 +17,7 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
     import pytest
     from atropos_amd.trim import pipeline_from_args
     pipe = pipeline_from_args("-g ^ACGTACGT --no-indels")                # anchored without indels: compare_prefixes path
-    with pytest.raises(NotImplementedError):
-        pipe.trim_bytes(b"@r\nACGTACGTAA\n+\nIIIIIIIIII\n")
+    assert pipe.trim_bytes(b"@r\nACGTACGTAA\n+\nIIIIIIIIII\n") == b"@r\nAA\n+\nII\n"
     with pytest.raises(NotImplementedError):
         pipeline_from_args("-a AAAA...TTTT -a GGGG")                     # linked + plain adapters mixed
     with pytest.raises(SystemExit):
