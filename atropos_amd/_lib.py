@@ -25,7 +25,7 @@ MAX_REF_LEN = 128
 MAX_READ_LEN = 736
 PAIRS_MAX_LEN = 255
 INSERT_MAX_ADAPTER = 64
-INSERT_MAX_READ = 256
+INSERT_MAX_READ = 320
 
 
 class InsertConfig(C.Structure):
@@ -124,6 +124,9 @@ PROTOTYPES = {
     "atr_read_filter_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_merge_work_bytes": (C.c_size_t, [C.c_int64]),
+    "atr_merge_plan_batch": (C.c_int, [C.c_void_p] * 7 + [C.c_int64] + [C.c_void_p] * 5),
+    "atr_merge_emit_batch": (C.c_int, [C.c_void_p] * 11 + [C.c_int64, C.c_int, C.c_int, C.c_char_p] + [C.c_void_p] * 5),
     "atr_fastq_emit_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_fastq_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -510,6 +513,32 @@ class HipBackend(object):
                 min_insert_len, int(symmetric), trim_action, correct_action, min_qual_difference, comp, _ptr(m1),
                 _ptr(m2), _ptr(corrected), _ptr(err), self._stream()), "atr_insert_plan_batch")
         return m1, m2, corrected, int(err.item())
+
+    def merge_batch(self, align, need, insert_matched, batch1, batch2, begin1, end1, begin2, end2, correct_action=-1,
+                    min_qual_difference=1, comp=None):
+        """MergeOverlapping after the alignments (atr_merge_plan_batch + atr_merge_emit_batch): returns
+        (kind uint8 [n] -- 0: the pair stays a pair --, the FASTQ text of the merged reads in input order,
+        corrected int32 [n, 2], error word).  With a mismatch action the two chunks are corrected in place."""
+        n = begin1.shape[0]
+        kind = self.empty((n,), torch.uint8)
+        offsets = self.empty((n + 1,), torch.int64)
+        corrected = self.empty((n, 2), torch.int32)
+        corrected.zero_()
+        err = self.empty((1,), torch.int64)
+        work = self.empty((max(self.lib.atr_merge_work_bytes(n), 16),), torch.uint8)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_merge_plan_batch(
+                _ptr(align), _ptr(need), _ptr(batch1.records), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), n,
+                _ptr(kind), _ptr(offsets), _ptr(work), _ptr(err), self._stream()), "atr_merge_plan_batch")
+            total = int(offsets[n].item())
+            out = self.empty((max(total, 1),), torch.uint8)
+            if total and int(err.item()) == INT64_MAX:
+                _check(self.lib, self.lib.atr_merge_emit_batch(
+                    _ptr(align), _ptr(kind), _ptr(insert_matched), _ptr(batch1.data), _ptr(batch1.records),
+                    _ptr(batch2.data), _ptr(batch2.records), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), n,
+                    correct_action, min_qual_difference, comp, _ptr(offsets), _ptr(corrected), _ptr(err), _ptr(out),
+                    self._stream()), "atr_merge_emit_batch")
+        return kind, out[:total], corrected, int(err.item())
 
     def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
         """Formatted FASTQ text (uint8 device tensor) of the records with dest == which."""

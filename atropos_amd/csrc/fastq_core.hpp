@@ -298,5 +298,81 @@ ATR_DEV uint32_t fastq_record_bytes(const FastqRecord &rec, int kept) {
     return 1u + rec.name_len + 1u + (uint32_t)kept + 2u + ((rec.flags & 1u) ? rec.name_len : 0u) + 1u + (uint32_t)kept + 1u;
 }
 
+// ---- MergeOverlapping (commands/trim/modifiers.py:864-931) ---------------------------------
+// al = the record of Aligner(reverse_complement(read2), error_rate, flags).locate(read1):
+// (r2_start, r2_stop, r1_start, r1_stop, matches, errors), refstop -1 = None (or a pair that was
+// too short to be aligned at all).  "mate" = reverse_complement(read2) as it was BEFORE any
+// correction (:887); the merged read is one or two segments, each of read 1 or of the mate.
+enum { MERGE_NONE = 0,         // no (sufficient) alignment: the pair stays a pair
+       MERGE_R2_INSIDE = 1,    // read 2 lies inside read 1: read 1 as it is               (:904-906)
+       MERGE_R1_INSIDE = 2,    // read 1 lies inside read 2: the mate                      (:907-910)
+       MERGE_APPEND = 3,       // read1 + mate[r2_stop:]                                   (:911-915)
+       MERGE_PREPEND = 4,      // mate + read1[r1_stop:]                                   (:916-921)
+       MERGE_INVALID = 5 };    // "Invalid alignment while trying to merge read"          (:922-926)
+
+struct MergeShape {
+    int kind;
+    int mate_first;            // the first segment is the mate's (kinds 2 and 4)
+    int from[2], len[2];       // segment s: bases [from, from + len) of its source
+};
+
+ATR_DEV MergeShape merge_shape(const int16_t *al, int len1, int len2, int need) {
+    MergeShape m;
+    m.kind = MERGE_NONE; m.mate_first = 0;
+    m.from[0] = m.from[1] = m.len[0] = m.len[1] = 0;
+    if (al[1] < 0 || (int)al[4] < need) return m;                       // :898-899
+    const int r2_start = al[0], r2_stop = al[1], r1_start = al[2], r1_stop = al[3];
+    if (r2_start == 0 && r2_stop == len2) { m.kind = MERGE_R2_INSIDE; m.len[0] = len1; }
+    else if (r1_start == 0 && r1_stop == len1) { m.kind = MERGE_R1_INSIDE; m.mate_first = 1; m.len[0] = len2; }
+    else if (r1_start > 0) { m.kind = MERGE_APPEND; m.len[0] = len1; m.from[1] = r2_stop; m.len[1] = len2 - r2_stop; }
+    else if (r2_start > 0) { m.kind = MERGE_PREPEND; m.mate_first = 1; m.len[0] = len2; m.from[1] = r1_stop; m.len[1] = len1 - r1_stop; }
+    else m.kind = MERGE_INVALID;
+    if (m.len[1] < 0) m.len[1] = 0;
+    return m;
+}
+
+// The merged record's text, written by `nl` cooperating lanes (lane = 0 .. nl-1; the emulation
+// passes 0, 1).  mate_pass: only the mate's BASES (to be run before the pair is corrected: the
+// reference takes the mate before correct_errors and its qualities after, :887 / :909 / :914 / :919);
+// otherwise everything else -- name, read 1's bases, the '+' line, all qualities.
+ATR_DEV void merge_emit_one(uint8_t *o, const MergeShape &m, const FastqRecord &rec1, const uint8_t *bytes1, int a1,
+                            const FastqRecord &rec2, const uint8_t *bytes2, int a2, int len2, const uint8_t *comp,
+                            bool mate_pass, int lane, int nl) {
+    const uint32_t total = (uint32_t)(m.len[0] + m.len[1]);
+    const uint8_t *s1 = bytes1 + rec1.seq_off + a1, *q1 = bytes1 + rec1.qual_off + a1;
+    const uint8_t *s2 = bytes2 + rec2.seq_off + a2, *q2 = bytes2 + rec2.qual_off + a2;
+    uint8_t *seq = o + 1 + rec1.name_len + 1;
+    uint8_t *plus = seq + total;
+    uint8_t *qual = plus + 2 + ((rec1.flags & 1u) ? rec1.name_len : 0u) + 1;
+    for (int s = 0; s < 2; ++s) {
+        const bool mate = (s == 0) == (m.mate_first != 0);
+        const int base = s == 0 ? 0 : m.len[0];
+        if (mate) {
+            for (int k = lane; k < m.len[s]; k += nl) {
+                const int src = len2 - 1 - (m.from[s] + k);
+                if (mate_pass) seq[base + k] = comp[s2[src]];
+                else qual[base + k] = q2[src];
+            }
+        } else if (!mate_pass) {
+            for (int k = lane; k < m.len[s]; k += nl) {
+                seq[base + k] = s1[m.from[s] + k];
+                qual[base + k] = q1[m.from[s] + k];
+            }
+        }
+    }
+    if (mate_pass) return;
+    for (uint32_t k = (uint32_t)lane; k < rec1.name_len; k += (uint32_t)nl) {
+        o[1 + k] = bytes1[rec1.name_off + k];
+        if (rec1.flags & 1u) plus[2 + k] = bytes1[rec1.name_off + k];
+    }
+    if (lane == 0) {
+        o[0] = '@';
+        o[1 + rec1.name_len] = '\n';
+        plus[0] = '\n'; plus[1] = '+';
+        qual[-1] = '\n';
+        qual[total] = '\n';
+    }
+}
+
 }  // namespace atr
 #endif

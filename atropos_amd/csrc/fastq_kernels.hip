@@ -682,6 +682,82 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
     }
 }
 
+// ------------------------------------------------------------------------- MergeOverlapping
+__global__ __launch_bounds__(256) void merge_plan_kernel(const int16_t *__restrict__ align, const int32_t *__restrict__ need,
+                                                         const FastqRecord *__restrict__ records1,
+                                                         const int32_t *__restrict__ begin1, const int32_t *__restrict__ end1,
+                                                         const int32_t *__restrict__ begin2, const int32_t *__restrict__ end2,
+                                                         long long n, uint8_t *__restrict__ kind, uint32_t *__restrict__ sizes,
+                                                         unsigned long long *__restrict__ error) {
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int len1 = max(0, end1[r] - begin1[r]), len2 = max(0, end2[r] - begin2[r]);
+    const MergeShape m = merge_shape(align + 8 * r, len1, len2, need[r]);
+    kind[r] = (uint8_t)m.kind;
+    uint32_t s = 0;
+    if (m.kind == MERGE_INVALID) atomicMin(error, (unsigned long long)r * 8ull + 4ull);
+    else if (m.kind != MERGE_NONE) s = fastq_record_bytes(records1[r], m.len[0] + m.len[1]);
+    sizes[r] = s;
+}
+
+// One wave writes the merged records of 64 consecutive pairs, one after the other (merge_emit_one).
+__global__ __launch_bounds__(256) void merge_emit_kernel(const int16_t *__restrict__ align, const uint8_t *__restrict__ kind,
+                                                         const uint8_t *__restrict__ bytes1,
+                                                         const FastqRecord *__restrict__ records1,
+                                                         const uint8_t *__restrict__ bytes2,
+                                                         const FastqRecord *__restrict__ records2,
+                                                         const int32_t *__restrict__ begin1, const int32_t *__restrict__ end1,
+                                                         const int32_t *__restrict__ begin2, const int32_t *__restrict__ end2,
+                                                         long long n, const CompTable256 ct, int mate_pass,
+                                                         const long long *__restrict__ offsets, uint8_t *__restrict__ out) {
+    __shared__ uint8_t s_comp[256];
+    s_comp[threadIdx.x] = ct.c[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (r0 >= n) return;
+    const int cnt = (int)min<long long>(64, n - r0);
+    for (int i = 0; i < cnt; ++i) {
+        const long long r = r0 + i;                               // wave-uniform
+        const int k = kind[r];
+        if (k == MERGE_NONE || k == MERGE_INVALID) continue;
+        const int a1 = begin1[r], a2 = begin2[r];
+        const int len1 = max(0, end1[r] - a1), len2 = max(0, end2[r] - a2);
+        const MergeShape m = merge_shape(align + 8 * r, len1, len2, 0);
+        merge_emit_one(out + offsets[r], m, records1[r], bytes1, a1, records2[r], bytes2, a2, len2, s_comp, mate_pass != 0,
+                       lane, 64);
+    }
+}
+
+// ErrorCorrectorMixin.correct_errors(read1, read2, alignment) of the pairs MergeOverlapping corrects
+// (:900-902: a mismatch action is set, the alignment has errors, the insert aligner has not seen the pair).
+__global__ __launch_bounds__(256) void merge_correct_kernel(const int16_t *__restrict__ align, const uint8_t *__restrict__ kind,
+                                                            const uint8_t *__restrict__ insert_matched, uint8_t *bytes1,
+                                                            const FastqRecord *__restrict__ records1, uint8_t *bytes2,
+                                                            const FastqRecord *__restrict__ records2,
+                                                            const int32_t *__restrict__ begin1, const int32_t *__restrict__ end1,
+                                                            const int32_t *__restrict__ begin2, const int32_t *__restrict__ end2,
+                                                            long long n, int action, int min_qual_diff, const CompTable256 ct,
+                                                            int32_t *__restrict__ corrected,
+                                                            unsigned long long *__restrict__ error) {
+    __shared__ uint8_t s_comp[256];
+    s_comp[threadIdx.x] = ct.c[threadIdx.x];
+    __syncthreads();
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    if (corrected) corrected[2 * r] = corrected[2 * r + 1] = 0;
+    const int k = kind[r];
+    if (k == MERGE_NONE || k == MERGE_INVALID || align[8 * r + 5] <= 0 || (insert_matched && insert_matched[r])) return;
+    const FastqRecord r1 = records1[r], r2 = records2[r];
+    const int a1 = begin1[r], a2 = begin2[r];
+    const int len1 = max(0, end1[r] - a1), len2 = max(0, end2[r] - a2);
+    int32_t changed[2], newlen[2];
+    correct_errors_one(bytes1 + r1.seq_off + a1, bytes1 + r1.qual_off + a1, len1, bytes2 + r2.seq_off + a2,
+                       bytes2 + r2.qual_off + a2, len2, align + 8 * r, action, min_qual_diff, false, s_comp, changed, newlen);
+    if (changed[0] < 0) atomicMin(error, (unsigned long long)r * 8ull + (unsigned long long)(-changed[0]));
+    else if (corrected) { corrected[2 * r] = changed[0]; corrected[2 * r + 1] = changed[1]; }
+}
+
 static long long scan_blocks(long long n) { return (n + SCAN_BLOCK - 1) / SCAN_BLOCK; }
 
 // exclusive prefix sums of v[n] -> out[n] (int64); `sums` holds scan_blocks(n) uint64
@@ -923,6 +999,60 @@ int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, co
                        (const FastqRecord *)d_records, d_begin, d_end, d_unmasked_begin, d_unmasked_end, d_dest, dest,
                        (long long)n, (const long long *)d_offsets, d_out);
     return launched("emit_kernel launch");
+}
+
+size_t atr_merge_work_bytes(int64_t n) { return atr_fastq_emit_work_bytes(n); }
+
+int atr_merge_plan_batch(const atr_result *d_align, const int32_t *d_need, const atr_fastq_record *d_records1,
+                         const int32_t *d_begin1, const int32_t *d_end1, const int32_t *d_begin2, const int32_t *d_end2,
+                         int64_t n, uint8_t *d_kind, int64_t *d_offsets, void *d_work, int64_t *d_error, void *stream) {
+    if (n < 0 || !d_offsets || !d_error) return ATR_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, (long long *)d_error, LLONG_MAX);
+    if (n == 0) {
+        hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, st, (long long *)d_offsets, 0ll);
+        return launched("merge plan launch");
+    }
+    if (!d_align || !d_need || !d_records1 || !d_begin1 || !d_end1 || !d_begin2 || !d_end2 || !d_kind || !d_work)
+        return ATR_ERR_INVALID;
+    uint32_t *sizes = (uint32_t *)d_work;
+    unsigned long long *sums = (unsigned long long *)((char *)d_work + align256((size_t)n * 4));
+    hipLaunchKernelGGL(merge_plan_kernel, dim3(grid256(n)), dim3(256), 0, st, (const int16_t *)d_align, d_need,
+                       (const FastqRecord *)d_records1, d_begin1, d_end1, d_begin2, d_end2, (long long)n, d_kind, sizes,
+                       (unsigned long long *)d_error);
+    launch_scan(sizes, n, (long long *)d_offsets, sums, nullptr, st);
+    hipLaunchKernelGGL(emit_total_kernel, dim3(1), dim3(1), 0, st, sizes, (long long *)d_offsets, (long long)n);
+    return launched("merge_plan_kernel launch");
+}
+
+int atr_merge_emit_batch(const atr_result *d_align, const uint8_t *d_kind, const uint8_t *d_insert_matched,
+                         uint8_t *d_bytes1, const atr_fastq_record *d_records1, uint8_t *d_bytes2,
+                         const atr_fastq_record *d_records2, const int32_t *d_begin1, const int32_t *d_end1,
+                         const int32_t *d_begin2, const int32_t *d_end2, int64_t n, int correct_action,
+                         int min_qual_difference, const uint8_t comp[256], const int64_t *d_offsets, int32_t *d_corrected,
+                         int64_t *d_error, uint8_t *d_out, void *stream) {
+    if (n < 0 || correct_action < -1 || correct_action > 2 || !comp) return ATR_ERR_INVALID;
+    if (n == 0) return ATR_OK;
+    if (!d_align || !d_kind || !d_bytes1 || !d_records1 || !d_bytes2 || !d_records2 || !d_begin1 || !d_end1 || !d_begin2 ||
+        !d_end2 || !d_offsets || !d_error || !d_out)
+        return ATR_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    CompTable256 ct;
+    memcpy(ct.c, comp, 256);
+    const unsigned waves = (unsigned)(((n + 63) / 64 + 3) / 4);
+    const FastqRecord *rec1 = (const FastqRecord *)d_records1, *rec2 = (const FastqRecord *)d_records2;
+    // the mate's bases first: the reference reverse-complements read 2 before it corrects the pair (:887)
+    hipLaunchKernelGGL(merge_emit_kernel, dim3(waves), dim3(256), 0, st, (const int16_t *)d_align, d_kind, d_bytes1, rec1,
+                       d_bytes2, rec2, d_begin1, d_end1, d_begin2, d_end2, (long long)n, ct, 1, (const long long *)d_offsets,
+                       d_out);
+    if (correct_action >= 0)
+        hipLaunchKernelGGL(merge_correct_kernel, dim3(grid256(n)), dim3(256), 0, st, (const int16_t *)d_align, d_kind,
+                           d_insert_matched, d_bytes1, rec1, d_bytes2, rec2, d_begin1, d_end1, d_begin2, d_end2, (long long)n,
+                           correct_action, min_qual_difference, ct, d_corrected, (unsigned long long *)d_error);
+    hipLaunchKernelGGL(merge_emit_kernel, dim3(waves), dim3(256), 0, st, (const int16_t *)d_align, d_kind, d_bytes1, rec1,
+                       d_bytes2, rec2, d_begin1, d_end1, d_begin2, d_end2, (long long)n, ct, 0, (const long long *)d_offsets,
+                       d_out);
+    return launched("merge_emit_kernel launch");
 }
 
 }  // extern "C"

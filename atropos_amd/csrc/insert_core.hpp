@@ -89,7 +89,7 @@ static __device__ __forceinline__ uint32_t atr_or_xor(uint32_t x, uint32_t a, ui
 namespace atr {
 
 constexpr int INS_MAX_ADAPTER = 64;                 // adapter length handled by the insert kernel
-constexpr int INS_MAX_LEN = 256;                    // read length handled by the insert kernel
+constexpr int INS_MAX_LEN = 320;                    // read length handled by the insert kernel
 constexpr int INS_MAX_MATCHES = 100;                // MultiAligner.locate(max_matches=100)
 constexpr int INS_CAND = 4;                         // recorded hits per pair in the unordered sweep (more: ordered redo)
 

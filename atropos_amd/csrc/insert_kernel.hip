@@ -74,12 +74,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
 }
 
+// MiSeq-length reads (nine and ten chunks, up to 320 bases): 80 plane dwords per pair live in registers,
+// two waves per SIMD.
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void insert_kernel_long(
+    const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
+    const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
+    uint4 *__restrict__ out) {
+    insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
+}
+
 template <int NCH>
 static int launch_nch(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                       const int32_t *l2, long long npairs, int max_len, uint4 *out, hipStream_t st) {
     const long long ntiles = (npairs + 63) / 64;
-    if (NCH == 4 || NCH == 5)
+    if constexpr (NCH == 4 || NCH == 5)
         hipLaunchKernelGGL((insert_kernel_dense<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
+                           p2, l2, npairs, max_len, out);
+    else if constexpr (NCH > 8)
+        hipLaunchKernelGGL((insert_kernel_long<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
                            p2, l2, npairs, max_len, out);
     else
         hipLaunchKernelGGL((insert_kernel<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
@@ -97,7 +110,9 @@ int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l
         case 5: return launch_nch<5>(a, p1, l1, p2, l2, npairs, max_len, out, st);
         case 6: return launch_nch<6>(a, p1, l1, p2, l2, npairs, max_len, out, st);
         case 7: return launch_nch<7>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        default: return launch_nch<8>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 8: return launch_nch<8>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 9: return launch_nch<9>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        default: return launch_nch<10>(a, p1, l1, p2, l2, npairs, max_len, out, st);
     }
 }
 

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, 
 // loads the bit planes of both reads (coalesced tile64 chunk loads), parks read 2's in LDS (the 32 bases
 // that face a word of read 1 start at a per-lane bit offset) and only then touches the ASCII
 // matrices, at the few positions where the reads disagree.
-constexpr int PLANES_MAX_WORDS = 8;                  // ATR_INSERT_MAX_READ / 32
+constexpr int PLANES_MAX_WORDS = 10;                 // ATR_INSERT_MAX_READ / 32
 
 __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__restrict__ records,
                                                              const uint4 *__restrict__ planes1,

@@ -28,6 +28,7 @@ from . import _lib
 from .adapters import LinkedAdapter
 from .fastq import FastqBatch, RecordSource
 
+DEST_MERGED = 6              # MergedReadFilter (filters.py:109-113): installed first, so a merged pair goes nowhere else
 DEST_NAMES = {_lib.DEST_KEEP: "keep", _lib.DEST_TOO_SHORT: "too_short", _lib.DEST_TOO_LONG: "too_long",
               _lib.DEST_TOO_MANY_N: "too_many_n", _lib.DEST_TRIMMED: "trimmed", _lib.DEST_UNTRIMMED: "untrimmed"}
 
@@ -224,11 +225,20 @@ class TrimPipeline(object):
 class PairedTrimResult(object):
     """Result of the paired-end pipeline: one TrimResult per read, sharing the destination."""
 
-    def __init__(self, res1, res2):
+    def __init__(self, res1, res2, merged=None):
         self.read1, self.read2, self.dest = res1, res2, res1.dest
+        self.merged = merged                     # uint8 device tensor: the FASTQ text of the merged reads, or None
 
     def counts(self):
-        return self.read1.counts()
+        c = torch.bincount(self.dest.to(torch.int64), minlength=7).cpu().tolist()
+        out = {DEST_NAMES[i]: int(c[i]) for i in range(6)}
+        if self.merged is not None:
+            out["merged"] = int(c[DEST_MERGED])
+        return out
+
+    def merged_text(self):
+        """FASTQ text of the merged reads (the --merged-output file), in input order."""
+        return b"" if self.merged is None else bytes(self.merged.cpu().numpy().tobytes())
 
     def text(self, which=_lib.DEST_KEEP):
         return self.read1.text(which), self.read2.text(which)
@@ -241,12 +251,17 @@ class PairedTrimPipeline(object):
     adapter per read (trim/__init__.py:406-456).  ``pair_filter``: 'any' or 'both'.
     ``correct_mismatches`` ('liberal' | 'conservative' | 'N', insert aligner only): error
     correction of the overlaps, written IN PLACE into the two FASTQ chunks in device memory
-    (a batch is consumed by ``run``).  Merging is not part of the device pipeline."""
+    (a batch is consumed by ``run``).  ``merge_overlapping``: MergeOverlapping as the last modifier
+    (commands/trim/modifiers.py:864-931, trim/__init__.py:546-552): pairs whose reads overlap by
+    ``merge_min_overlap`` (a fraction of the shorter read up to 1, else bases) at ``merge_error_rate``
+    become ONE read -- destination ``DEST_MERGED``, text in ``PairedTrimResult.merged`` -- corrected
+    first with ``correct_mismatches`` unless the insert aligner already saw the pair."""
 
     def __init__(self, adapters1=(), adapters2=(), aligner="adapter", times=1, action="trim", cut=(), cut2=(),
                  nextseq_trim=None, quality_cutoff=None, quality_base=33, trim_n=False, minimum_length=None,
                  maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
-                 op_order="CGQAW", insert_args=None, correct_mismatches=None):
+                 op_order="CGQAW", insert_args=None, correct_mismatches=None, merge_overlapping=False,
+                 merge_min_overlap=0.9, merge_error_rate=0.2):
         common = dict(times=times, action=action, nextseq_trim=nextseq_trim, quality_cutoff=quality_cutoff,
                       quality_base=quality_base, trim_n=trim_n, minimum_length=minimum_length,
                       maximum_length=maximum_length, max_n=max_n, discard_trimmed=discard_trimmed,
@@ -259,8 +274,15 @@ class PairedTrimPipeline(object):
         self.min_affected = 2 if pair_filter == "both" else 1            # trim/__init__.py:549
         if correct_mismatches not in (None, "liberal", "conservative", "N"):
             raise ValueError("correct_mismatches must be 'liberal', 'conservative' or 'N'")
-        if correct_mismatches and aligner != "insert":
-            raise NotImplementedError("error correction is part of the insert aligner stage only")
+        if correct_mismatches and aligner != "insert" and not merge_overlapping:
+            raise ValueError("error correction needs the insert aligner or --merge-overlapping")
+        self.merge_overlapping = bool(merge_overlapping)
+        # above 1: a number of bases; up to 1: a fraction of the shorter read (modifiers.py:867)
+        self.merge_min_overlap = merge_min_overlap if merge_min_overlap <= 1 else int(merge_min_overlap)
+        self.merge_error_rate = float(merge_error_rate)
+        self.merged_pairs = 0
+        if self.merge_overlapping and action == "mask":
+            raise NotImplementedError("--merge-overlapping together with --mask-adapter")
         self.correct_mismatches = correct_mismatches
         self.corrected_pairs, self.corrected_bp = 0, [0, 0]               # ErrorCorrectorMixin counters
         self.insert = None
@@ -309,6 +331,7 @@ class PairedTrimPipeline(object):
             raise ValueError("%d second read(s) contain bases without an upper-case IUPAC code where they face the first "
                              "read; the device insert aligner cannot reverse-complement them" % bad)
         ins = self.insert.match_insert_batch(pb1, pb2).records
+        self._insert_matched = (ins[:, 0, 1] >= 0).to(torch.uint8)          # read.insert_overlap, modifiers.py:397
         # semi-global fallback (modifiers.py:405-407): only the pairs without an insert match need it
         miss = torch.nonzero(ins[:, 0, 1] < 0).squeeze(1)
         fb1 = self._fallback(self.p1.adapters[0], b1, st1, miss, n)
@@ -337,6 +360,74 @@ class PairedTrimPipeline(object):
             return (m1, st1[0].clone(), uend1), (m2, st2[0].clone(), uend2)
         return (m1, None, None), (m2, None, None)
 
+    def _merge_stage(self, b1, b2, st1, st2, insert_matched):
+        """MergeOverlapping over the batch: the alignments ``Aligner(reverse_complement(read2), error_rate,
+        flags).locate(read1)`` of the pairs long enough to be tried (atr_locate_pairs_batch, one call per
+        flag set), then the merge itself.  Returns (merged flags uint8 [n], merged FASTQ text)."""
+        from .align import SEMIGLOBAL, START_WITHIN_SEQ1, STOP_WITHIN_SEQ2
+        from .modifiers import COMP_TABLE, _ACTIONS
+        be = b1.backend
+        n = len(b1)
+        dev = st1[0].device
+        len1, len2 = (st1[1] - st1[0]).clamp(min=0), (st2[1] - st2[0]).clamp(min=0)
+        shorter = torch.minimum(len1, len2)
+        if self.merge_min_overlap > 1:
+            need = torch.full_like(shorter, int(self.merge_min_overlap))
+        else:                                                              # max(2, round(frac * shorter)), :870-874
+            need = torch.round(shorter.to(torch.float64) * float(self.merge_min_overlap)).to(torch.int32).clamp(min=2)
+        tried = shorter >= need                                            # :876-877
+        if insert_matched is None:
+            insert_matched = torch.zeros((n,), dtype=torch.uint8, device=dev)
+        align = torch.zeros((n, 8), dtype=torch.int16, device=dev)
+        align[:, 1] = -1
+        table = be.translate_table(_lib.TABLE_DNA15)
+        for flags, group in ((START_WITHIN_SEQ1 | STOP_WITHIN_SEQ2, tried & (insert_matched != 0)),
+                             (SEMIGLOBAL, tried & (insert_matched == 0))):      # :879-886
+            idx = torch.nonzero(group).squeeze(1)
+            if idx.numel() == 0:
+                continue
+            packs = []
+            for b, st in ((b2, st2), (b1, st1)):                            # reference = read 2, query = read 1
+                sub = b if idx.numel() == n else FastqBatch(b.data, b.nbytes, b.records.index_select(0, idx).contiguous(),
+                                                            b.backend)
+                begin, end = (st[0], st[1]) if idx.numel() == n else (st[0].index_select(0, idx).contiguous(),
+                                                                      st[1].index_select(0, idx).contiguous())
+                max_len = int((end - begin).max().clamp_(min=0).item())
+                if max_len > _lib.PAIRS_MAX_LEN:
+                    raise _lib.AtroposHipError("MergeOverlapping: reads longer than %d bases are outside the device "
+                                               "envelope" % _lib.PAIRS_MAX_LEN)
+                packed, lens, bad = be.pack_records(sub.data, sub.records, begin, end, max_len, table, count_invalid=True)
+                if bad:
+                    raise ValueError("%d read(s) contain characters without an upper-case IUPAC code; the device pair "
+                                     "aligner compares 4-bit codes" % bad)
+                packs.append((packed, lens, max_len))
+            (rp, rl, rmax), (qp, ql, qmax) = packs
+            rec = be.locate_pairs_batch(rp, rl, rmax, True, qp, ql, qmax, int(idx.numel()), self.merge_error_rate, flags,
+                                        False, False, 1, 1)
+            if idx.numel() == n:
+                align = rec
+            else:
+                align[idx] = rec
+        correct = _ACTIONS[self.correct_mismatches] if self.correct_mismatches else -1
+        kind, text, corrected, err = be.merge_batch(align.contiguous(), need.to(torch.int32).contiguous(),
+                                                    insert_matched.contiguous(), b1, b2, st1[0], st1[1], st2[0], st2[1],
+                                                    correct, 1, COMP_TABLE)
+        if err != _lib.INT64_MAX:
+            if err % 8 == 4:
+                raise ValueError("Invalid alignment while trying to merge pair %d" % (err // 8))
+            exc = {1: KeyError, 2: IndexError, 3: ValueError}[err % 8]
+            raise exc("error correction of pair %d: %s" % (err // 8, {
+                1: "base without a complement", 2: "overlap outside a read",
+                3: "Cannot determine the mode of an empty sequence"}[err % 8]))
+        merged = kind != 0
+        if correct >= 0:
+            self.corrected_pairs += int((corrected.sum(dim=1) > 0).sum().item())
+            tot = corrected.sum(dim=0).cpu().tolist()
+            self.corrected_bp[0] += int(tot[0])
+            self.corrected_bp[1] += int(tot[1])
+        self.merged_pairs += int(merged.sum().item())
+        return merged, text
+
     def run(self, batch1, batch2):
         if len(batch1) != len(batch2):
             raise ValueError("the two FASTQ batches hold different numbers of records")
@@ -348,10 +439,12 @@ class PairedTrimPipeline(object):
             st.append([torch.zeros((n,), dtype=torch.int32, device=dev), b.seq_lens.clone()])
         extra = [(torch.zeros((n,), dtype=torch.uint8, device=dev), None, None) for _ in range(2)]
         pipes, batches = (self.p1, self.p2), (batch1, batch2)
+        insert_matched = None
         for op in self.op_order:
             if op == "A":
                 if self.aligner == "insert":
                     extra = list(self._insert_stage(batch1, batch2, st[0], st[1]))
+                    insert_matched = self._insert_matched
                 else:
                     for k in range(2):
                         if pipes[k].adapters:
@@ -364,17 +457,26 @@ class PairedTrimPipeline(object):
             matched, ub, ue = extra[k]
             masks.append(pipes[k]._filter_stage(batches[k], st[k][0], st[k][1], ub, ue, matched, masks=True))
         dest = be.pair_filter_batch(masks[0], masks[1], self.min_affected)
+        merged_text = None
+        if self.merge_overlapping:                                  # the last modifier, the first filter
+            merged, merged_text = self._merge_stage(batch1, batch2, st[0], st[1], insert_matched)
+            dest = torch.where(merged, torch.full_like(dest, DEST_MERGED), dest)
         res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
-        return PairedTrimResult(res[0], res[1])
+        return PairedTrimResult(res[0], res[1], merged_text)
 
-    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20):
+    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
-        same number from each file); returns the destination counts."""
+        same number from each file); returns the destination counts.  ``merged_out``: the
+        --merged-output file (without it merged reads are dropped, as by the reference)."""
         from .fastq import ChunkedFastqReader, FastqSink
         be = _lib.get_backend()
         totals = {name: 0 for name in DEST_NAMES.values()}
         readers = [ChunkedFastqReader(p, chunk_bytes, be) for p in (in1, in2)]
         sinks = [FastqSink(p, chunk_bytes + (64 << 20) + 32, be) for p in (out1, out2)]
+        if self.merge_overlapping:
+            totals["merged"] = 0
+            if merged_out is not None:
+                sinks.append(FastqSink(merged_out, 2 * chunk_bytes + (64 << 20) + 32, be))
         try:
             while True:
                 batches = [r.next_batch() for r in readers]
@@ -387,6 +489,8 @@ class PairedTrimPipeline(object):
                 for k, r in enumerate((res.read1, res.read2)):
                     sinks[k].write(be.fastq_emit(r.batch.data, r.batch.records, r.begin, r.end, r.ubegin, r.uend,
                                                  r.dest, _lib.DEST_KEEP))
+                if len(sinks) == 3 and res.merged is not None:
+                    sinks[2].write(res.merged)
                 for name, v in res.counts().items():
                     totals[name] += v
                 if all(done):
@@ -450,8 +554,16 @@ def pipeline_from_args(argv):
     ap.add_argument("--discard-untrimmed", "--trimmed-only", action="store_true", default=False)
     ap.add_argument("--pair-filter", choices=("any", "both"), default=None)
     ap.add_argument("--correct-mismatches", choices=("liberal", "conservative", "N"), default=None)
+    ap.add_argument("-R", "--merge-overlapping", action="store_true", default=False)
+    ap.add_argument("--merge-min-overlap", type=float, default=0.9)
+    ap.add_argument("--merge-error-rate", type=float, default=None)
     o = ap.parse_args(argv)
-    paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert")
+    paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert" or
+                  o.merge_overlapping)
+    if o.merge_min_overlap <= 0:
+        raise ValueError("--merge-min-overlap must be positive")          # positive(float, True), cli.py:206-207
+    if o.merge_overlapping and o.merge_error_rate is None:
+        o.merge_error_rate = o.error_rate or 0.2                          # cli.py:690-691 (before -e gets its default)
     insert_args = None
     if o.aligner == "adapter":                                            # cli.py:659-666
         if o.indels and o.indel_cost is None:
@@ -511,4 +623,5 @@ def pipeline_from_args(argv):
         return TrimPipeline(adapters=adapters, cut=o.cut, **common)
     return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
-                              correct_mismatches=o.correct_mismatches, **common)
+                              correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,
+                              merge_min_overlap=o.merge_min_overlap, merge_error_rate=o.merge_error_rate or 0.2, **common)

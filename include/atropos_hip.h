@@ -203,14 +203,14 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
 /* ---- InsertAligner (atropos/align/__init__.py:178-377) -------------------- */
 
 #define ATR_INSERT_MAX_ADAPTER  64   /* adapter length handled by the insert kernel */
-#define ATR_INSERT_MAX_READ    256   /* read length handled by the insert kernel */
+#define ATR_INSERT_MAX_READ    320   /* read length handled by the insert kernel */
 
 /* InsertAligner.__init__ arguments (align/__init__.py:206-233) plus the host-built
  * tables.  All pointers are HOST pointers; the library copies what it needs.
  *   rmp_insert[size*rmp_ld + matches]  = match_probability(matches, size, **base_probs)  (:359)
  *   rmp_adapter[size*rmp_ld + matches] = match_probability(matches, size)                (:303-304)
  *   max_mismatch_by_alen[a]            = round(a * max_adapter_mismatch_frac)            (:290)
- * computed by the caller with Python's float/bigint/round semantics (rmp_ld >= 257,
+ * computed by the caller with Python's float/bigint/round semantics (rmp_ld >= ATR_INSERT_MAX_READ + 1,
  * n_mismatch >= 65). */
 typedef struct {
     const char *adapter1; int alen1;
@@ -452,6 +452,36 @@ int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, co
                    const int32_t *d_end, const int32_t *d_unmasked_begin, const int32_t *d_unmasked_end,
                    const uint8_t *d_dest, int dest, int64_t n, int record_bytes_hint, int64_t *d_offsets, void *d_work,
                    uint8_t *d_out, void *stream);
+
+/* MergeOverlapping.__call__ after the alignment (commands/trim/modifiers.py:864-931), two calls:
+ *
+ * atr_merge_plan_batch: d_align = one record per pair of Aligner(reverse_complement(read2), error_rate,
+ * flags).locate(read1) on the kept intervals (atr_locate_pairs_batch with revcomp_ref; refstop -1 for pairs
+ * without an alignment and for pairs that were too short to be aligned, :876-877), d_need[p] = the pair's
+ * minimum overlap (:870-874).  d_kind[p] receives 0 (the pair stays a pair) or which of the four shapes
+ * of :904-921 the merged read has; d_offsets[n + 1] the exclusive prefix sums of the merged records'
+ * formatted sizes (FastqFormat.format_entry of read 1 with the merged sequence; d_offsets[n] = total).
+ * *d_error: min over pairs with an "Invalid alignment" (:922-926) of pair * 8 + 4, or INT64_MAX.
+ * d_work: scratch of atr_merge_work_bytes(n) bytes.
+ *
+ * atr_merge_emit_batch: writes the text of the merged records into d_out (d_offsets[n] bytes).
+ * correct_action: -1, or ATR_CORRECT_* = MergeOverlapping's mismatch_action: pairs whose alignment has
+ * errors and for which d_insert_matched[p] == 0 (may be NULL: none matched) are corrected IN PLACE in
+ * the two chunks first (correct_errors(read1, read2, alignment), :900-902) -- except that the mate's
+ * bases are the uncorrected ones, as in the reference, which reverse-complements read 2 before (:887).
+ * d_corrected (may be NULL): 2 x int32 changed-base counts per pair; *d_error (as initialised by the
+ * plan call) additionally receives pair * 8 + {1 KeyError, 2 IndexError, 3 ValueError} of a failing
+ * correction. */
+size_t atr_merge_work_bytes(int64_t n);
+int atr_merge_plan_batch(const atr_result *d_align, const int32_t *d_need, const atr_fastq_record *d_records1,
+                         const int32_t *d_begin1, const int32_t *d_end1, const int32_t *d_begin2, const int32_t *d_end2,
+                         int64_t n, uint8_t *d_kind, int64_t *d_offsets, void *d_work, int64_t *d_error, void *stream);
+int atr_merge_emit_batch(const atr_result *d_align, const uint8_t *d_kind, const uint8_t *d_insert_matched,
+                         uint8_t *d_bytes1, const atr_fastq_record *d_records1, uint8_t *d_bytes2,
+                         const atr_fastq_record *d_records2, const int32_t *d_begin1, const int32_t *d_end1,
+                         const int32_t *d_begin2, const int32_t *d_end2, int64_t n, int correct_action,
+                         int min_qual_difference, const uint8_t comp[256], const int64_t *d_offsets, int32_t *d_corrected,
+                         int64_t *d_error, uint8_t *d_out, void *stream);
 
 #ifdef __cplusplus
 }

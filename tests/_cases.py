@@ -185,7 +185,7 @@ def norm_insert(res):
 
 def check_golden_insert(InsertAligner):
     kats = load_golden("kats.json")["match_insert"]
-    cases = kats + load_golden("insert_fuzz.json.gz")
+    cases = kats + load_golden("insert_fuzz.json.gz") + load_golden("insert_long.json.gz")      # the last: 2 x 257 .. 320 bp
     cache = {}
     for c in cases:
         key = (c["a1"], c["a2"], repr(sorted(c["kw"].items())))
@@ -238,7 +238,7 @@ def check_insert_batches_against_oracle(InsertAligner, oracle, seed, rounds):
             a1 = a1[:20].replace("G", "N", 1)
         ia = InsertAligner(a1, a2, **cfg)
         orc = oracle.InsertOracle(a1, a2, **cfg)
-        n = rng.choice([20, 50, 100, 150, 250])
+        n = rng.choice([20, 50, 100, 150, 250, 257, 290, 300, 320])
         r1s, r2s = [], []
         for _ in range(rng.choice([1, 64, 65, 130])):
             f = rng.randint(0, int(1.6 * n))
@@ -655,25 +655,28 @@ def check_plane_guided_correction(n=768, seed=5):
     w = synth.workload("C5", 12345, n, device=str(be.device))
     ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
     done = 0
-    for action, ragged, quals in ((2, False, True), (1, False, True), (0, False, True), (0, False, False), (2, True, True)):
-        s1, s2 = w["reads1"].clone(), w["reads2"].clone()
+    for action, ragged, quals, width in ((2, False, True, 250), (1, False, True, 250), (0, False, True, 250),
+                                         (0, False, False, 250), (2, True, True, 250), (2, True, True, 310), (1, False, True, 320)):
+        # width > 250: MiSeq-length rows (ten 32-base chunks), the C5 reads with a stretch of themselves appended
+        s1, s2, qa, qb = (torch.cat([t, t[:, 20:20 + width - 250]], dim=1).contiguous()
+                          for t in (w["reads1"], w["reads2"], w["quals1"], w["quals2"]))
         l1 = l2 = None
         if ragged:
-            l1 = torch.tensor([rng.randint(60, 250) for _ in range(n)], dtype=torch.int32, device=be.device)
-            l2 = torch.tensor([rng.randint(60, 250) for _ in range(n)], dtype=torch.int32, device=be.device)
-            cols = torch.arange(250, device=be.device)[None, :]
+            l1 = torch.tensor([rng.randint(60, width) for _ in range(n)], dtype=torch.int32, device=be.device)
+            l2 = torch.tensor([rng.randint(60, width) for _ in range(n)], dtype=torch.int32, device=be.device)
+            cols = torch.arange(width, device=be.device)[None, :]
             s1 = torch.where(cols < l1[:, None], s1, torch.zeros_like(s1))
             s2 = torch.where(cols < l2[:, None], s2, torch.zeros_like(s2))
         from atropos_amd.batch import ReadBatch
         table = be.translate_table(_lib.TABLE_DNA15)
-        b1 = ReadBatch(be.pack_reads(s1, l1, 250, table, planes=True), l1, n, 250, _lib.TABLE_DNA15, table, layout="plane64")
-        b2 = ReadBatch(be.pack_reads(s2, l2, 250, table, planes=True), l2, n, 250, _lib.TABLE_DNA15, table, layout="plane64")
+        b1 = ReadBatch(be.pack_reads(s1, l1, width, table, planes=True), l1, n, width, _lib.TABLE_DNA15, table, layout="plane64")
+        b2 = ReadBatch(be.pack_reads(s2, l2, width, table, planes=True), l2, n, width, _lib.TABLE_DNA15, table, layout="plane64")
         rec = ia.match_insert_batch(b1, b2).records
         outs = []
         for planes in (False, True):
             a1, a2 = s1.clone(), s2.clone()
-            q1 = w["quals1"].clone() if quals else None
-            q2 = w["quals2"].clone() if quals else None
+            q1 = qa.clone() if quals else None
+            q2 = qb.clone() if quals else None
             ch, nl = be.insert_correct_batch(rec, a1, q1, l1, a2, q2, l2, action, 1, COMP_TABLE,
                                              planes1=b1 if planes else None, planes2=b2 if planes else None)
             outs.append((a1, a2, q1, q2, ch, nl))
@@ -943,7 +946,14 @@ def check_trim_golden_paired():
         label = "%s: %s" % (case["input1"], case["args"])
         pipe = pipeline_from_args(case["args"])
         assert isinstance(pipe, PairedTrimPipeline), label
-        outs = pipe.trim_bytes(inputs[case["input1"]], inputs[case["input2"]])
+        from atropos_amd.fastq import FastqBatch
+        b1, _ = FastqBatch.from_bytes(inputs[case["input1"]], final=True)
+        b2, _ = FastqBatch.from_bytes(inputs[case["input2"]], final=True)
+        res = pipe.run(b1, b2)
+        outs = list(res.text())
+        if len(case["outputs"]) == 3:                        # -R: the --merged-output file
+            outs.append(res.merged_text())
+            assert res.counts()["merged"] == outs[2].count(b"\n") // 4 == pipe.merged_pairs, label
         for k, (out, want) in enumerate(zip(outs, case["outputs"])):
             text = base64.b64decode(want["text"])
             head = out[:len(text)] if want["size"] > 20000 else out
@@ -957,6 +967,7 @@ def check_trim_golden_paired():
 def check_paired_file_chunking(tmp_path):
     """PairedTrimPipeline.trim_files in small lock-step chunks == one batch."""
     import base64
+    import hashlib
     from atropos_amd.trim import pipeline_from_args
     doc = load_golden("trim_cases.json.gz")
     d1, d2 = (base64.b64decode(doc["inputs"][k]) for k in ("synth_pe.1.fastq", "synth_pe.2.fastq"))
@@ -969,6 +980,15 @@ def check_paired_file_chunking(tmp_path):
                                                          chunk_bytes=30000)
     assert paths[2].read_bytes() == w1 and paths[3].read_bytes() == w2
     assert sum(counts.values()) == d1.count(b"\n") // 4
+    # with merging: a third file, written chunk by chunk
+    case = [c for c in doc["paired"] if "--merge-min-overlap 20" in c["args"]][0]
+    merged_path = tmp_path / "merged.fastq"
+    mc = pipeline_from_args(case["args"]).trim_files(str(paths[0]), str(paths[1]), str(paths[2]), str(paths[3]),
+                                                     chunk_bytes=30000, merged_out=str(merged_path))
+    texts = [paths[2].read_bytes(), paths[3].read_bytes(), merged_path.read_bytes()]
+    assert [len(t) for t in texts] == [o["size"] for o in case["outputs"]]
+    assert [hashlib.sha256(t).hexdigest() for t in texts] == [o["sha256"] for o in case["outputs"]]
+    assert mc["merged"] == texts[2].count(b"\n") // 4 and sum(mc.values()) == d1.count(b"\n") // 4
     return counts
 
 

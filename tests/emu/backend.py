@@ -329,6 +329,23 @@ class EmuBackend(object):
             _ptr(m1), _ptr(m2), _ptr(corrected), _ptr(err)), "emu_insert_plan_batch")
         return m1, m2, corrected, int(err.item())
 
+    def merge_batch(self, align, need, insert_matched, batch1, batch2, begin1, end1, begin2, end2, correct_action=-1,
+                    min_qual_difference=1, comp=None):
+        n = begin1.shape[0]
+        kind = torch.zeros((n,), dtype=torch.uint8)
+        offsets = torch.zeros((n + 1,), dtype=torch.int64)
+        corrected = torch.zeros((n, 2), dtype=torch.int32)
+        err = torch.zeros((1,), dtype=torch.int64)
+        args = (_ptr(align), _ptr(need), _ptr(insert_matched), _ptr(batch1.data), _ptr(batch1.records), _ptr(batch2.data),
+                _ptr(batch2.records), _ptr(begin1), _ptr(end1), _ptr(begin2), _ptr(end2), C.c_int64(n), correct_action,
+                min_qual_difference, comp, _ptr(kind), _ptr(offsets), _ptr(corrected), _ptr(err))
+        _check(self.lib.emu_merge_batch(*args, None), "emu_merge_batch")
+        total = int(offsets[n])
+        out = torch.zeros((max(total, 1),), dtype=torch.uint8)
+        if total and int(err.item()) == (1 << 63) - 1:
+            _check(self.lib.emu_merge_batch(*args, _ptr(out)), "emu_merge_batch")
+        return kind, out[:total], corrected, int(err.item())
+
     def fastq_emit(self, data, records, begin, end, ubegin, uend, dest, which):
         n = records.shape[0]
         offsets = torch.zeros((n + 1,), dtype=torch.int64)

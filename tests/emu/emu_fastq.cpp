@@ -196,6 +196,50 @@ int emu_insert_plan_batch(const int16_t *ins, const int16_t *fb1, const int16_t 
     return ATR_OK;
 }
 
+// atr_merge_plan_batch + atr_merge_emit_batch in one call: out == NULL sizes the output
+// (offsets[n + 1], kind[n]); with out the text is written (mate bases, correction, the rest).
+int emu_merge_batch(const int16_t *align, const int32_t *need, const uint8_t *insert_matched, uint8_t *bytes1,
+                    const atr_fastq_record *records1, uint8_t *bytes2, const atr_fastq_record *records2,
+                    const int32_t *begin1, const int32_t *end1, const int32_t *begin2, const int32_t *end2, int64_t n,
+                    int correct_action, int min_qual_diff, const uint8_t *comp, uint8_t *kind, int64_t *offsets,
+                    int32_t *corrected, int64_t *error, uint8_t *out) {
+    if (!out) {
+        *error = LLONG_MAX;
+        int64_t at = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            const int len1 = std::max(0, end1[r] - begin1[r]), len2 = std::max(0, end2[r] - begin2[r]);
+            const MergeShape m = merge_shape(align + 8 * r, len1, len2, need[r]);
+            kind[r] = (uint8_t)m.kind;
+            offsets[r] = at;
+            if (m.kind == MERGE_INVALID) *error = std::min<int64_t>(*error, r * 8 + 4);
+            else if (m.kind != MERGE_NONE) at += fastq_record_bytes(*(const FastqRecord *)&records1[r], m.len[0] + m.len[1]);
+        }
+        offsets[n] = at;
+        return ATR_OK;
+    }
+    for (int pass = 0; pass < 3; ++pass)
+        for (int64_t r = 0; r < n; ++r) {
+            if (kind[r] == MERGE_NONE || kind[r] == MERGE_INVALID) continue;
+            const FastqRecord &r1 = *(const FastqRecord *)&records1[r], &r2 = *(const FastqRecord *)&records2[r];
+            const int a1 = begin1[r], a2 = begin2[r];
+            const int len1 = std::max(0, end1[r] - a1), len2 = std::max(0, end2[r] - a2);
+            if (pass == 1) {
+                if (corrected) corrected[2 * r] = corrected[2 * r + 1] = 0;
+                if (correct_action < 0 || align[8 * r + 5] <= 0 || (insert_matched && insert_matched[r])) continue;
+                int32_t changed[2], newlen[2];
+                correct_errors_one(bytes1 + r1.seq_off + a1, bytes1 + r1.qual_off + a1, len1, bytes2 + r2.seq_off + a2,
+                                   bytes2 + r2.qual_off + a2, len2, align + 8 * r, correct_action, min_qual_diff, false, comp,
+                                   changed, newlen);
+                if (changed[0] < 0) *error = std::min<int64_t>(*error, r * 8 - changed[0]);
+                else if (corrected) { corrected[2 * r] = changed[0]; corrected[2 * r + 1] = changed[1]; }
+                continue;
+            }
+            const MergeShape m = merge_shape(align + 8 * r, len1, len2, 0);
+            merge_emit_one(out + offsets[r], m, r1, bytes1, a1, r2, bytes2, a2, len2, comp, pass == 0, 0, 1);
+        }
+    return ATR_OK;
+}
+
 int emu_fastq_emit(const uint8_t *bytes, const atr_fastq_record *records, const int32_t *begin, const int32_t *end,
                    const int32_t *ubegin, const int32_t *uend, const uint8_t *dest, int which, int64_t n,
                    int64_t *offsets, uint8_t *out) {

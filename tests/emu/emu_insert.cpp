@@ -77,7 +77,9 @@ int emu_insert_match_batch(const atr_insert_aligner *a, const uint8_t *p1, const
         case 5: emu_insert_tiles<5>(a, a1, l1, a2, l2, npairs, max_len, o); break;
         case 6: emu_insert_tiles<6>(a, a1, l1, a2, l2, npairs, max_len, o); break;
         case 7: emu_insert_tiles<7>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        default: emu_insert_tiles<8>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 8: emu_insert_tiles<8>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 9: emu_insert_tiles<9>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        default: emu_insert_tiles<10>(a, a1, l1, a2, l2, npairs, max_len, o); break;
     }
     return ATR_OK;
 }

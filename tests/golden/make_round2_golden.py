@@ -10,6 +10,7 @@ Fixtures (inputs are generated here; expected values are what the reference retu
                            AdapterCutter._best_match / LinkedAdapter.match_to do -- which adapter, how many
                            5' parts match (> 1: the reference raises AttributeError), both Match records
     info_records.json.gz   AdapterCutter runs: the MatchInfo rows (Match.get_info_record) of every read
+    insert_long.json.gz    InsertAligner.match_insert on MiSeq-length pairs (2 x 257 .. 320 bp)
     c5_head.json.gz        the first pairs of BASELINE config C5 (2 x 250 bp, qualities) through
                            InsertAdapterCutter(mismatch_action='liberal', read wildcards): full outputs of
                            the first pairs, a digest of every pair
@@ -35,6 +36,7 @@ def pair_digest(state):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None          # e.g. "insert_long": just that fixture
     build_reference("/tmp/atropos_ref_build")
     import numpy as np
     from atropos.adapters import Adapter, LinkedAdapter, BACK, FRONT, PREFIX, SUFFIX, ANYWHERE
@@ -123,14 +125,15 @@ def main():
             assert got == [which, count, fm, bm], (c["fronts"], c["backs"], kw, c["reads"][i], got, [which, count, fm, bm])
 
     cases = []
-    for _ in range(160):
+    for _ in range(160 if only is None else 0):
         c = linked_case(24)
         c["out"] = run_linked(c)
         check_oracle_linked(c, c["out"])
         cases.append(c)
-    dump("linked_fuzz.json.gz", cases)
+    if only is None:
+        dump("linked_fuzz.json.gz", cases)
     extra = 0
-    for _ in range(1200):                                  # uncommitted: oracle vs reference only
+    for _ in range(1200 if only is None else 0):                                  # uncommitted: oracle vs reference only
         c = linked_case(40)
         check_oracle_linked(c, run_linked(c))
         extra += len(c["reads"])
@@ -138,7 +141,7 @@ def main():
 
     # ------------------------------------------------------------------ info records
     info_cases = []
-    for _ in range(120):
+    for _ in range(120 if only is None else 0):
         nad = rng.choice([1, 2, 3])
         specs = []
         for a in range(nad):
@@ -162,7 +165,50 @@ def main():
             r = cutter(Sequence(name=name, sequence=q, qualities=qual))
             outs.append(None if not r.match_info else [list(info) for info in r.match_info])
         info_cases.append(dict(specs=specs, kw=kw, times=times, action=action, reads=reads, out=outs))
-    dump("info_records.json.gz", info_cases)
+    if only is None:
+        dump("info_records.json.gz", info_cases)
+
+    # ------------------------------------------------------------------ match_insert on 2 x 300 bp pairs
+    if only in (None, "insert_long"):
+        from atropos.align import InsertAligner
+        from atropos.util import reverse_complement
+        A1, A2 = synth.PE_ADAPTER1, synth.PE_ADAPTER2
+
+        def noise(s, p):
+            return "".join((rng.choice("ACGTN") if rng.random() < p else c) for c in s)
+
+        long_cases, checked = [], 0
+        cfgs = [dict(), dict(max_insert_mismatch_frac=0.1, max_adapter_mismatch_frac=0.1), dict(read_wildcards=True),
+                dict(adapter_wildcards=False), dict(min_insert_overlap=5, min_adapter_overlap=3),
+                dict(insert_max_rmp=1e-3, adapter_max_rmp=1e-2)]
+        for cfg in cfgs:
+            ref = InsertAligner(A1, A2, **cfg)
+            orc = O.InsertOracle(A1, A2, **cfg)
+            for it in range(160):
+                n = rng.choice([257, 288, 289, 300, 300, 319, 320])
+                f = rng.randint(0, int(1.5 * n))
+                F = rseq(f)
+                r1 = (F + A1 + rseq(n))[:rng.choice([n, n, n - 3, n - 40])]
+                r2 = (reverse_complement(F) + A2 + rseq(n))[:rng.choice([n, n, n - 1, n - 70])]
+                p = rng.choice([0, 0.01, 0.03, 0.1])
+                r1, r2 = noise(r1, p), noise(r2, p)
+                if rng.random() < 0.08:
+                    r1 = rseq(n)
+                if rng.random() < 0.03:
+                    r1, r2 = "A" * len(r1), "T" * len(r2)
+                res = ref.match_insert(r1, r2)
+                out = None if res is None else [list(res[0]), match_fields(res[1]), match_fields(res[2])]
+                mine = orc.match_insert(r1, r2)
+                mine = None if mine is None else [list(mine[0]), None if mine[1] is None else list(mine[1]),
+                                                  None if mine[2] is None else list(mine[2])]
+                assert mine == out, (cfg, r1, r2, mine, out)
+                checked += 1
+                if it < 40:
+                    long_cases.append(dict(a1=A1, a2=A2, r1=r1, r2=r2, kw=cfg, out=out))
+        dump("insert_long.json.gz", long_cases)
+        print("oracle.match_insert == reference on %d pairs of 257 .. 320 bp" % checked)
+    if only is not None:
+        return
 
     # ------------------------------------------------------------------ C5 head through InsertAdapterCutter
     count, full = 2048, 96

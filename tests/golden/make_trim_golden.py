@@ -192,6 +192,15 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 40 -M 140 --trim-n" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -n 2 --discard-trimmed" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --adapter-max-rmp 0.001 --nextseq-trim 20" % (PE1, PE2)),
+    # MergeOverlapping (-R): a third output, the --merged-output file
+    ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -A CAGTGGAGTA -R --merge-min-overlap 0.5"),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s -R" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s -R --merge-min-overlap 0.5 --correct-mismatches liberal" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s -R --merge-min-overlap 30 --merge-error-rate 0.05 -q 20 -m 30" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 20 --merge-error-rate 0.15 --correct-mismatches conservative" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
 ]
 
 
@@ -290,6 +299,9 @@ def main():
             open(paths[1], "wb").write(inputs[n2])
             params = argstr.split() + ["-pe1", paths[0], "-pe2", paths[1], "-o", paths[2], "-p", paths[3], "--quiet",
                                        "--no-default-adapters", "--no-cache-adapters"]
+            if "-R" in argstr.split():
+                paths.append(os.path.join(tmp, "pe_%d_merged.fastq" % idx))
+                params += ["--merged-output", paths[4]]
             retcode, _summary = get_command("trim").execute(params)
             assert retcode == 0, (argstr, retcode)
             case = dict(input1=n1, input2=n2, args=argstr, outputs=[])

@@ -50,4 +50,4 @@ def test_insert_errors(emu_backend):
 
 
 def test_plane_guided_correction(emu_backend):
-    assert _cases.check_plane_guided_correction(n=320) == 5 * 320
+    assert _cases.check_plane_guided_correction(n=320) == 7 * 320

@@ -95,7 +95,7 @@ def test_full_size_insert(hip_backend, oracle, name, count):
 
 
 def test_plane_guided_correction(hip_backend):
-    assert _cases.check_plane_guided_correction(n=200_000) == 5 * 200_000
+    assert _cases.check_plane_guided_correction(n=200_000) == 7 * 200_000
 
 
 def test_c5_correction_at_size(hip_backend, oracle):

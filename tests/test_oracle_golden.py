@@ -61,7 +61,7 @@ def test_prefix_fuzz(oracle):
 
 def test_insert_fuzz(oracle):
     cache = {}
-    for c in load_golden("insert_fuzz.json.gz"):
+    for c in load_golden("insert_fuzz.json.gz") + load_golden("insert_long.json.gz"):
         key = (c["a1"], c["a2"], repr(sorted(c["kw"].items())))
         if key not in cache:
             cache[key] = oracle.InsertOracle(c["a1"], c["a2"], **c["kw"])
