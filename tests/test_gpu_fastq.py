@@ -42,6 +42,7 @@ def _big_fastq(nreads, seed):
     "-a AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC -q 15,20 --trim-n -m 20",
     "-b AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC -n 2 --mask-adapter --max-n 0.2",
     "-a ^ACGT...AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC -e 0.15 -u 2 --discard-untrimmed",
+    "-a AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC$ --no-indels -e 0.2 -g ^ACGTAC -n 2",     # packed compare_prefixes/suffixes
 ])
 def test_large_batch_equals_cpu_twin(hip_backend, args):
     from atropos_amd import _lib
@@ -59,7 +60,69 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
 
 
 def test_paired_pipeline_reference_cli_cases(hip_backend):
-    assert _cases.check_trim_golden_paired() >= 20
+    assert _cases.check_trim_golden_paired() >= 28
+
+
+def test_paired_file_chunking(hip_backend, tmp_path):
+    counts = _cases.check_paired_file_chunking(tmp_path)
+    assert counts["keep"] > 0 and counts["too_short"] > 0
+
+
+def _big_pairs(npairs, seed):
+    """npairs x (2 x 150 bp) C3 pairs with qualities, ragged lengths and N tails."""
+    from atropos_amd import synth
+    w = synth.workload("C3", 3, npairs, device="cpu")
+    rng = np.random.RandomState(seed)
+    texts = []
+    # both reads of a pair cut to the same length: the reference's own correction raises on some
+    # unequal-length pairs ("mode of an empty sequence"), and so does the device path
+    lens = np.where(rng.rand(npairs) < 0.08, rng.randint(25, 151, size=npairs), 150)
+    for reads in (w["reads1"].numpy(), w["reads2"].numpy()):
+        n = reads.shape[1]
+        qual = np.clip(38 - (np.arange(n)[None, :] * rng.uniform(0, 0.3, size=(npairs, 1))).astype(np.int64)
+                       + rng.randint(-3, 4, size=(npairs, n)), 2, 40).astype(np.uint8) + 33
+        parts = []
+        for i in range(npairs):
+            L = int(lens[i])
+            seq = bytes(reads[i, :L])
+            if rng.rand() < 0.1 and L > 8:
+                seq = seq[:L - 4] + b"NNNN"
+            parts.append(b"@p%d/x\n%s\n+\n%s\n" % (i, seq, bytes(qual[i, :L])))
+        texts.append(b"".join(parts))
+    return texts
+
+
+@pytest.mark.parametrize("args", [
+    "--aligner insert -a {a1} -A {a2} -R --merge-min-overlap 0.5 --correct-mismatches liberal",
+    "-a {a1} -A {a2} -R --merge-min-overlap 20 --merge-error-rate 0.15 --correct-mismatches conservative -q 15 -m 20",
+    "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n",
+])
+def test_large_paired_merge_equals_cpu_twin(hip_backend, args):
+    """MergeOverlapping as a device stage at a size where every kernel runs many blocks (the golden cases
+    above pin the same code to the reference's output files)."""
+    from atropos_amd import _lib, synth
+    from atropos_amd.fastq import FastqBatch
+    from atropos_amd.trim import pipeline_from_args
+    from tests.emu.backend import EmuBackend
+    args = args.format(a1=synth.PE_ADAPTER1, a2=synth.PE_ADAPTER2)
+    d1, d2 = _big_pairs(30000, 9)
+
+    def run():
+        pipe = pipeline_from_args(args)
+        b1, _ = FastqBatch.from_bytes(d1, final=True)
+        b2, _ = FastqBatch.from_bytes(d2, final=True)
+        res = pipe.run(b1, b2)
+        return res.text() + (res.merged_text(),), res.counts()
+
+    got, counts = run()
+    prev = _lib.set_backend(EmuBackend())
+    try:
+        want, wcounts = run()
+    finally:
+        _lib.set_backend(prev)
+    assert counts == wcounts and counts["merged"] > 10000
+    for g, w in zip(got, want):
+        assert len(g) == len(w) and g == w, _cases._first_diff(g, w)
 
 
 def test_fastq_reader_fuzz_vs_reference(hip_backend):
