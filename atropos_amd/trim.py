@@ -195,30 +195,40 @@ class TrimPipeline(object):
         batch, _ = FastqBatch.from_bytes(data, final=True)
         return self.run(batch).text(which)
 
-    def trim_file(self, path_in, path_out, chunk_bytes=256 << 20):
+    def trim_file(self, path_in, path_out, chunk_bytes=256 << 20, keep_output=False):
         """Stream a FASTQ file through the GPU in chunks of whole records; returns the
         destination counts.  (Plain files; compressed input is the caller's business.)
         Host side: ``ChunkedFastqReader`` / ``FastqSink`` (page-locked staging buffers, threaded
-        reads, read-ahead and write-behind around the GPU work)."""
-        from .fastq import ChunkedFastqReader, FastqSink
+        reads, read-ahead; device -> host copies on their own stream and write-behind, so the GPU
+        works on chunk i + 1 while chunk i travels back and into the file).  ``keep_output``: overwrite
+        an existing output file in place instead of truncating it first.  The seconds the loop spent
+        waiting per stage are left in ``self.stage_seconds``."""
+        import time
+        from .fastq import ChunkedFastqReader, FastqSink, StageClock
         be = _lib.get_backend()
         totals = {name: 0 for name in DEST_NAMES.values()}
-        reader = ChunkedFastqReader(path_in, chunk_bytes, be)
-        sink = FastqSink(path_out, chunk_bytes + (64 << 20) + 32, be)
+        clock = StageClock()
+        reader = ChunkedFastqReader(path_in, chunk_bytes, be, clock)
+        sink = FastqSink(path_out, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output)
         try:
             while True:
                 batch = reader.next_batch()
                 done = reader.advance()                       # starts reading the next chunk
+                t0 = time.perf_counter()
                 res = self.run(batch)
-                sink.write(be.fastq_emit(batch.data, batch.records, res.begin, res.end, res.ubegin, res.uend,
-                                         res.dest, _lib.DEST_KEEP))
-                for name, v in res.counts().items():
+                text = be.fastq_emit(batch.data, batch.records, res.begin, res.end, res.ubegin, res.uend, res.dest,
+                                     _lib.DEST_KEEP)
+                counts = res.counts()
+                clock.add("trim_and_format", t0)
+                sink.write(text)
+                for name, v in counts.items():
                     totals[name] += v
                 if done:
                     break
         finally:
             reader.close()
             sink.close()
+            self.stage_seconds = dict(clock.seconds)
         return totals
 
 
@@ -464,19 +474,21 @@ class PairedTrimPipeline(object):
         res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
         return PairedTrimResult(res[0], res[1], merged_text)
 
-    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None):
+    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None, keep_output=False):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
         same number from each file); returns the destination counts.  ``merged_out``: the
         --merged-output file (without it merged reads are dropped, as by the reference)."""
-        from .fastq import ChunkedFastqReader, FastqSink
+        import time
+        from .fastq import ChunkedFastqReader, FastqSink, StageClock
         be = _lib.get_backend()
         totals = {name: 0 for name in DEST_NAMES.values()}
-        readers = [ChunkedFastqReader(p, chunk_bytes, be) for p in (in1, in2)]
-        sinks = [FastqSink(p, chunk_bytes + (64 << 20) + 32, be) for p in (out1, out2)]
+        clock = StageClock()
+        readers = [ChunkedFastqReader(p, chunk_bytes, be, clock) for p in (in1, in2)]
+        sinks = [FastqSink(p, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output) for p in (out1, out2)]
         if self.merge_overlapping:
             totals["merged"] = 0
             if merged_out is not None:
-                sinks.append(FastqSink(merged_out, 2 * chunk_bytes + (64 << 20) + 32, be))
+                sinks.append(FastqSink(merged_out, 2 * chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output))
         try:
             while True:
                 batches = [r.next_batch() for r in readers]
@@ -485,13 +497,17 @@ class PairedTrimPipeline(object):
                 done = [readers[k].advance(heads[k][1]) for k in range(2)]
                 if all(r.final for r in readers) and len(batches[0]) != len(batches[1]):
                     raise ValueError("the two input files hold different numbers of records")
+                t0 = time.perf_counter()
                 res = self.run(heads[0][0], heads[1][0])
-                for k, r in enumerate((res.read1, res.read2)):
-                    sinks[k].write(be.fastq_emit(r.batch.data, r.batch.records, r.begin, r.end, r.ubegin, r.uend,
-                                                 r.dest, _lib.DEST_KEEP))
+                texts = [be.fastq_emit(r.batch.data, r.batch.records, r.begin, r.end, r.ubegin, r.uend, r.dest,
+                                       _lib.DEST_KEEP) for r in (res.read1, res.read2)]
+                counts = res.counts()
+                clock.add("trim_and_format", t0)
+                for k in range(2):
+                    sinks[k].write(texts[k])
                 if len(sinks) == 3 and res.merged is not None:
                     sinks[2].write(res.merged)
-                for name, v in res.counts().items():
+                for name, v in counts.items():
                     totals[name] += v
                 if all(done):
                     break
@@ -500,6 +516,7 @@ class PairedTrimPipeline(object):
         finally:
             for obj in readers + sinks:
                 obj.close()
+            self.stage_seconds = dict(clock.seconds)
         return totals
 
     def trim_bytes(self, data1, data2, which=_lib.DEST_KEEP):

@@ -35,16 +35,34 @@ res = {"workload": "host FASTQ bytes -> trimmed host bytes (trim_bytes), %d x 15
 src, dst = "/tmp/atr_e2e_in.fastq", "/tmp/atr_e2e_out.fastq"
 with open(src, "wb") as fh:
     fh.write(host)
-pipe.trim_file(src, dst, chunk_bytes=256 << 20)
-t0 = time.perf_counter()
-for _ in range(steps):
-    counts = pipe.trim_file(src, dst, chunk_bytes=256 << 20)
-ms2 = (time.perf_counter() - t0) / steps * 1e3
-assert open(dst, "rb").read() == out
-res["trim_file"] = {"ms": ms2, "reads_per_s": nreads / ms2 * 1e3, "host_GBps": (nbytes + len(out)) / ms2 / 1e6,
-                    "chunk_bytes": 256 << 20, "counts": counts}
+
+
+def file_to_file(dst, chunk, keep):
+    """steps runs of trim_file; the output file is removed before each run unless keep (then it is
+    overwritten in place: cached pages are reused instead of allocated)."""
+    pipe.trim_file(src, dst, chunk_bytes=chunk, keep_output=keep)
+    total, stages = 0.0, {}
+    for _ in range(steps):
+        if not keep and os.path.exists(dst):
+            os.remove(dst)
+        t0 = time.perf_counter()
+        counts = pipe.trim_file(src, dst, chunk_bytes=chunk, keep_output=keep)
+        total += time.perf_counter() - t0
+        for k, v in pipe.stage_seconds.items():
+            stages[k] = stages.get(k, 0.0) + v
+    ms = total / steps * 1e3
+    assert open(dst, "rb").read() == out
+    os.remove(dst)
+    return {"ms": ms, "reads_per_s": nreads / ms * 1e3, "host_GBps": (nbytes + len(out)) / ms / 1e6, "chunk_bytes": chunk,
+            "counts": counts, "wait_ms_per_run": {k: round(v / steps * 1e3, 2) for k, v in stages.items()}}
+
+
+res["trim_file"] = file_to_file(dst, 256 << 20, False)
+res["trim_file_128M_chunks"] = file_to_file(dst, 128 << 20, False)
+res["trim_file_overwrite"] = file_to_file(dst, 128 << 20, True)
+if os.path.isdir("/dev/shm"):
+    res["trim_file_to_shm"] = file_to_file("/dev/shm/atr_e2e_out.fastq", 128 << 20, False)
 os.remove(src)
-os.remove(dst)
 # paired-end, insert aligner: two files in lock step
 from bench_fastq_pe import device_fastq as device_fastq_pe
 npairs = nreads // 2
@@ -58,14 +76,23 @@ for k, key in enumerate(("reads1", "reads2")):
     sizes += nb
 del w
 pe = pipeline_from_args("--aligner insert -a %s -A %s -q 20 -m 30" % (synth.PE_ADAPTER1, synth.PE_ADAPTER2))
-pe.trim_files(*paths, chunk_bytes=128 << 20)
-t0 = time.perf_counter()
-for _ in range(steps):
-    pe.trim_files(*paths, chunk_bytes=128 << 20)
-ms3 = (time.perf_counter() - t0) / steps * 1e3
-out_bytes = os.path.getsize(paths[2]) + os.path.getsize(paths[3])
-res["trim_files_paired"] = {"npairs": npairs, "ms": ms3, "pairs_per_s": npairs / ms3 * 1e3,
-                            "host_GBps": (sizes + out_bytes) / ms3 / 1e6}
+for label, keep in (("trim_files_paired", False), ("trim_files_paired_overwrite", True)):
+    pe.trim_files(*paths, chunk_bytes=128 << 20, keep_output=keep)
+    total, stages = 0.0, {}
+    for _ in range(steps):
+        if not keep:
+            for p in paths[2:]:
+                os.remove(p)
+        t0 = time.perf_counter()
+        pe.trim_files(*paths, chunk_bytes=128 << 20, keep_output=keep)
+        total += time.perf_counter() - t0
+        for k, v in pe.stage_seconds.items():
+            stages[k] = stages.get(k, 0.0) + v
+    ms3 = total / steps * 1e3
+    out_bytes = os.path.getsize(paths[2]) + os.path.getsize(paths[3])
+    res[label] = {"npairs": npairs, "ms": ms3, "pairs_per_s": npairs / ms3 * 1e3, "reads_per_s": 2 * npairs / ms3 * 1e3,
+                  "host_GBps": (sizes + out_bytes) / ms3 / 1e6,
+                  "wait_ms_per_run": {k: round(v / steps * 1e3, 2) for k, v in stages.items()}}
 for p in paths:
     os.remove(p)
 print(json.dumps(res))

@@ -60,7 +60,7 @@ def timed(fn, steps):
 def main():
     npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    config = sys.argv[3] if len(sys.argv) > 3 else "C3"
+    config = sys.argv[3] if len(sys.argv) > 3 else "C3"        # optional 4th argument "merge"
     be = _lib.get_backend()
     w = synth.workload(config, 0, npairs, device="cuda")
     d1, n1 = device_fastq(w["reads1"], "1")
@@ -73,6 +73,9 @@ def main():
         # pairs (and this pipeline raises the same exception for the same pair).
         args = "--aligner insert -a %s -A %s --correct-mismatches liberal --match-read-wildcards -m 30" % (
             synth.PE_ADAPTER1, synth.PE_ADAPTER2)
+    merge = len(sys.argv) > 4 and sys.argv[4] == "merge"
+    if merge:                                   # MergeOverlapping as the last stage (the merged text counts as output)
+        args += " -R --merge-min-overlap 0.5"
     pipe = pipeline_from_args(args)
     stages = {}
     stages["index_ms"], (b1, b2) = timed(lambda: (FastqBatch.from_device(d1, n1, True, be)[0],
@@ -82,7 +85,7 @@ def main():
         be.fastq_emit(r.batch.data, r.batch.records, r.begin, r.end, None, None, r.dest, _lib.DEST_KEEP)
         for r in (res.read1, res.read2)), steps)
     total_ms = sum(stages.values())
-    out_bytes = int(outs[0].numel() + outs[1].numel())
+    out_bytes = int(outs[0].numel() + outs[1].numel()) + (int(res.merged.numel()) if res.merged is not None else 0)
     print(json.dumps({
         "workload": "%s: 2 FASTQ texts in HBM -> 2 trimmed FASTQ texts in HBM, %d pairs x 2x%d bp, atropos trim %s"
                     % (config, npairs, (n1 // npairs - 18) // 2, args.replace(synth.PE_ADAPTER1, "A1").replace(synth.PE_ADAPTER2, "A2")),
