@@ -23,7 +23,7 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
-PAIRS_MAX_LEN = 255
+PAIRS_MAX_LEN = 320
 INSERT_MAX_ADAPTER = 64
 INSERT_MAX_READ = 320
 

@@ -99,11 +99,11 @@ struct Best {
 // Candidate test of _align.pyx:440-455 / :464-474.  XREP: the payload field holds the
 // diagonal mismatches (see the header); indel = the aligner's effective indel cost, 0 for
 // the no-indel kernels.
-template <bool XREP>
+template <bool XREP, int BIAS = (int)ORG_BIAS>
 ATR_DEV void consider(Best &b, uint32_t w, int ref_stop, int query_stop, int min_overlap,
                       const int16_t *thr, int indel) {
     const int cost = (int)(w >> CSH);
-    const int origin = (int)(w & ORG_MASK) - (int)ORG_BIAS;
+    const int origin = (int)(w & ORG_MASK) - BIAS;
     const int length = ref_stop + atr_min(origin, 0);
     if (length >= min_overlap && cost <= (int)thr[atr_max(length, 0)]) {
         int matches = (int)((w >> MSH) & MAT_MASK);

@@ -11,7 +11,12 @@
 // one ds_read of reference codes, ~6 VALU ops to turn them into eight mismatch bits, and per
 // row ds_read + 6 VALU + ds_write.  The sweep is the full (unbanded) matrix: Ukkonen's band is
 // a CPU shortcut that does not change the result.
-// Limits: m, n <= 255 (8-bit matches field, 10-bit origin field), int(e*m) < 256.
+// Limits: int(e*m) < 256; m, n <= 255 (8-bit matches field) -- or <= 320 when STOP_WITHIN_SEQ2 is set (both
+// flag sets of MergeOverlapping): the payload then counts the diagonal MISMATCHES of the path (XREP, as in
+// locate_core.hpp), which stay below 256 on every cell that can still be accepted (cost <= k < 256; a cell
+// beyond that may wrap its count, but its cost field is exact and only grows along a path, so it never wins
+// against an acceptable cell and is never accepted itself).  The origin field is biased by 384 here (an
+// alignment may start 320 rows into the reference), which leaves 0 .. 639 for starts inside the query.
 //
 // Compiled for gfx950 and, with -DATR_HOST_EMU, for the CPU test emulation.
 #ifndef ATR_PAIRS_CORE_HPP
@@ -23,6 +28,8 @@
 namespace atr {
 
 constexpr int PAIRS_MAX_LEN = ATR_PAIRS_MAX_LEN;
+constexpr int PAIRS_MATCH_COUNT_MAX_LEN = 255;       // longest side the matches payload (no STOP_WITHIN_SEQ2) can count
+constexpr int PAIRS_ORG_BIAS = 384;
 
 struct PairParams {
     int16_t thr[PAIRS_MAX_LEN + 3];       // thr[L] = floor(L * max_error_rate), -1 = accept nothing
@@ -59,7 +66,7 @@ ATR_DEV void stage_reference(uint32_t *refw, int rs, const uint32_t *rp, int m, 
 // col: m + 1 cell words (stride cs); refw: staged reference (stride rs); qp: the lane's
 // packed query.  rec: (refstart, refstop, querystart, querystop, matches, errors) as int16 x 8,
 // refstop = -1 for None.
-template <bool AND_MODE>
+template <bool AND_MODE, bool XREP>
 ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs, int m, const uint32_t *qp, int n,
                              const PairParams &p, const int16_t *thr, uint32_t rec[4]) {
     const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
@@ -72,7 +79,8 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
     const uint32_t klimit = (uint32_t)(k + 1) << CSH;
     const int max_n = sq ? n : atr_min(n, m + k);                      // :314-321
     const int min_n = eq ? 0 : atr_max(0, n - m - k);
-    for (int i = 0; i <= m; ++i) col[(size_t)i * cs] = init_word(i, min_n, sr, sq, indel);   // :333-352
+    for (int i = 0; i <= m; ++i)                                       // :333-352, with this file's origin bias
+        col[(size_t)i * cs] = init_word(i, min_n, sr, sq, indel) + (uint32_t)(PAIRS_ORG_BIAS - (int)ORG_BIAS);
     Best best;
     best.key = COST_FIELD_MAX - (m + n);                               // (matches 0, cost m + n): :358-363
     best.word = (uint32_t)(m + n) << CSH;
@@ -82,8 +90,8 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
         if (((j - 1) & 7) == 0 || j == min_n + 1) qword = qp[(size_t)((j - 1) >> 5) * 256 + (((j - 1) >> 3) & 3)];
         const uint32_t qrep = ((qword >> (4 * ((j - 1) & 7))) & 15u) * 0x11111111u;
         // row 0 (:385-388)
-        const uint32_t row0 = sq ? (ORG_BIAS + (uint32_t)j)
-                                 : (ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
+        const uint32_t row0 = sq ? ((uint32_t)PAIRS_ORG_BIAS + (uint32_t)j)
+                                 : ((uint32_t)PAIRS_ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
         uint32_t old_prev = col[0];                                    // old cell of the row above (diagonal source)
         uint32_t new_prev = row0;                                      // new cell of the row above (insertion source)
         col[0] = row0;
@@ -110,7 +118,7 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const uint32_t bit = (mis >> (4 * b)) & 1u;
-                const uint32_t cd = old_prev + MATCH1 + bit * DIAG_DELTA;               // :394-404
+                const uint32_t cd = XREP ? old_prev + bit * (COST1 + MATCH1) : old_prev + MATCH1 + bit * DIAG_DELTA;               // :394-404
                 const uint32_t cl = oldc[b] + delw, cu = new_prev + insw;               // :405-419
                 nw[b] = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
                 old_prev = oldc[b];
@@ -129,7 +137,7 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
                 const int i = d * 8 + b + 1;
                 const uint32_t old = col[(size_t)i * cs];
                 const uint32_t bit = (mis >> (4 * b)) & 1u;
-                const uint32_t cd = old_prev + MATCH1 + bit * DIAG_DELTA;
+                const uint32_t cd = XREP ? old_prev + bit * (COST1 + MATCH1) : old_prev + MATCH1 + bit * DIAG_DELTA;
                 const uint32_t cl = old + delw, cu = new_prev + insw;
                 const uint32_t nw = atr_minu(atr_minu(cd, cl), cu) & ~PRIO_MASK;
                 col[(size_t)i * cs] = nw;
@@ -138,15 +146,15 @@ ATR_DEV void locate_pair_one(uint32_t *col, int cs, const uint32_t *refw, int rs
             }
         }
         // row-m candidate: looked at only when the band reached row m, i.e. cost <= k (:433-455)
-        if (eq && new_prev < klimit) consider<false>(best, new_prev, m, j, p.min_overlap, thr, indel);
+        if (eq && new_prev < klimit) consider<XREP, PAIRS_ORG_BIAS>(best, new_prev, m, j, p.min_overlap, thr, indel);
     }
     if (max_n == n) {                                                   // :461-474
-        for (int i = er ? 0 : m; i <= m; ++i) consider<false>(best, col[(size_t)i * cs], i, n, p.min_overlap, thr, indel);
+        for (int i = er ? 0 : m; i <= m; ++i) consider<XREP, PAIRS_ORG_BIAS>(best, col[(size_t)i * cs], i, n, p.min_overlap, thr, indel);
     }
     const int cost = (int)(best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
     if (cost != m + n) {                                                // :476-480
-        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        const int origin = (int)(best.word & ORG_MASK) - PAIRS_ORG_BIAS;
         if (origin >= 0) querystart = origin; else refstart = -origin;
         refstop = best.ref_stop; querystop = best.query_stop;
         matches = best.matches; errors = cost;
@@ -236,7 +244,7 @@ ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, int mh
         const int d = min_n - i;
         const int cost = (sr ? (sq ? atr_min(i, min_n) : min_n) : (sq ? i : atr_max(i, min_n))) * indel;
         const int origin = sr ? (sq ? d : atr_min(0, d)) : (sq ? atr_max(0, d) : 0);
-        col[i] = ((uint32_t)atr_min(cost, INIT_COST_CAP) << CSH) | (uint32_t)(origin + (int)ORG_BIAS);
+        col[i] = ((uint32_t)atr_min(cost, INIT_COST_CAP) << CSH) | (uint32_t)(origin + PAIRS_ORG_BIAS);
     }
     Best best;
     best.key = COST_FIELD_MAX - (m + n);
@@ -249,25 +257,25 @@ ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, int mh
         uint32_t nm[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) nm[w] = ~tab[(size_t)(qc * NW + w) * ts];
-        const uint32_t row0 = sq ? (ORG_BIAS + (uint32_t)j)
-                                 : (ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
+        const uint32_t row0 = sq ? ((uint32_t)PAIRS_ORG_BIAS + (uint32_t)j)
+                                 : ((uint32_t)PAIRS_ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
         int mrow = m;
 #ifndef ATR_HOST_EMU
         asm volatile("" : "+v"(mrow));                       // keep the 152 (i == m) lane masks out of the loop preheader
 #endif
         const uint32_t wm = column_step_pairs<MT, XREP>(col, nm, row0, insw, delw, mlo, mhi, mrow);
-        if (eq && wm < klimit) consider<XREP>(best, wm, m, j, p.min_overlap, thr, indel);   // :433-455
+        if (eq && wm < klimit) consider<XREP, PAIRS_ORG_BIAS>(best, wm, m, j, p.min_overlap, thr, indel);   // :433-455
     }
     if (max_n == n) {                                                   // :461-474
         const int first = er ? 0 : m;
 #pragma unroll
         for (int i = 0; i <= MT; ++i)
-            if (i >= first && i <= m) consider<XREP>(best, col[i], i, n, p.min_overlap, thr, indel);
+            if (i >= first && i <= m) consider<XREP, PAIRS_ORG_BIAS>(best, col[i], i, n, p.min_overlap, thr, indel);
     }
     const int cost = (int)(best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
     if (cost != m + n) {                                                // :476-480
-        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        const int origin = (int)(best.word & ORG_MASK) - PAIRS_ORG_BIAS;
         if (origin >= 0) querystart = origin; else refstart = -origin;
         refstop = best.ref_stop; querystop = best.query_stop;
         matches = best.matches; errors = cost;
@@ -284,6 +292,8 @@ inline int pairs_params(double e, int flags, int wildcard_ref, int wildcard_quer
     if (flags < 0 || flags > 15 || min_overlap < 1 || indel_cost < 1) return ATR_ERR_INVALID;
     if (ref_max_len < 0 || query_max_len < 0) return ATR_ERR_INVALID;
     if (ref_max_len > PAIRS_MAX_LEN || query_max_len > PAIRS_MAX_LEN) return ATR_ERR_UNSUPPORTED;
+    if ((ref_max_len > PAIRS_MATCH_COUNT_MAX_LEN || query_max_len > PAIRS_MATCH_COUNT_MAX_LEN) && !(flags & ATR_STOP_WITHIN_SEQ2))
+        return ATR_ERR_UNSUPPORTED;
     const double kd = e * (double)ref_max_len;
     if (!(kd < 256.0) || !(kd > -1.0e9)) return ATR_ERR_UNSUPPORTED;
     // worst computed cost: an initial value (<= (m + k) * indel) plus m insertions; indel is

@@ -1,7 +1,7 @@
 // pairs_kernel.hip -- atr_locate_pairs_batch: Aligner.locate with a per-pair reference
 // (pairs_core.hpp).  One wave = 64 pairs; the wave's DP columns and staged references live in
 // dynamic LDS ((max_m + 1) + ceil(max_m / 8) dwords per lane), so occupancy is LDS-bound:
-// 3 waves per CU at 150 bp, 2 at 250 bp.  VALU-bound like every DP here (no MFMA: the
+// 3 waves per CU at 150 bp, 2 at 250 bp, 1 at 320 bp (92 KB of the CU's 160).  VALU-bound like every DP here (no MFMA: the
 // recurrence is a min-plus chain along the column, not a contraction).
 #include <hip/hip_runtime.h>
 
@@ -12,7 +12,7 @@ namespace atr {
 
 int hip_fail(hipError_t e, const char *what);             // api.hip
 
-template <bool AND_MODE>
+template <bool AND_MODE, bool XREP>
 __global__ __launch_bounds__(64) void pairs_kernel(const PairParams p, const uint32_t *__restrict__ ref_packed,
                                                    const int32_t *__restrict__ ref_lens, int ref_chunks,
                                                    int ref_max_len, int revcomp,
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64) void pairs_kernel(const PairParams p, const uin
     const uint32_t *qp = qry_packed + ((size_t)tile * qry_chunks * 64 + lane) * 4;
     stage_reference(refw, 64, rp, m, revcomp != 0);
     uint32_t rec[4];
-    locate_pair_one<AND_MODE>(col, 64, refw, 64, m, qp, n, p, s_thr, rec);
+    locate_pair_one<AND_MODE, XREP>(col, 64, refw, 64, m, qp, n, p, s_thr, rec);
     out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 
@@ -122,16 +122,18 @@ extern "C" int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t
     }
     const size_t lds = ((size_t)(ref_max_len + 1) + (size_t)(ref_max_len + 7) / 8) * 64 * 4;
     const dim3 grid((unsigned)((npairs + 63) / 64)), block(64);
-#define ATR_LAUNCH_PAIRS(MODE)                                                                                         \
+    const bool xrep = (flags & ATR_STOP_WITHIN_SEQ2) != 0;             // mismatch-counting payload (pairs_core.hpp)
+#define ATR_LAUNCH_PAIRS(MODE, XR)                                                                                     \
     do {                                                                                                               \
-        e = hipFuncSetAttribute((const void *)pairs_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        e = hipFuncSetAttribute((const void *)pairs_kernel<MODE, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e != hipSuccess) return hip_fail(e, "pairs_kernel LDS size");                                              \
-        hipLaunchKernelGGL((pairs_kernel<MODE>), grid, block, lds, (hipStream_t)stream, p,                             \
+        hipLaunchKernelGGL((pairs_kernel<MODE, XR>), grid, block, lds, (hipStream_t)stream, p,                         \
                            (const uint32_t *)d_ref_packed, d_ref_lens, (ref_max_len + 31) / 32, ref_max_len, revcomp_ref, \
                            (const uint32_t *)d_query_packed, d_query_lens, (query_max_len + 31) / 32, query_max_len,   \
                            (long long)npairs, (uint4 *)d_out);                                                         \
     } while (0)
-    if (p.and_mode) ATR_LAUNCH_PAIRS(true); else ATR_LAUNCH_PAIRS(false);
+    if (p.and_mode) { if (xrep) ATR_LAUNCH_PAIRS(true, true); else ATR_LAUNCH_PAIRS(true, false); }
+    else { if (xrep) ATR_LAUNCH_PAIRS(false, true); else ATR_LAUNCH_PAIRS(false, false); }
 #undef ATR_LAUNCH_PAIRS
     e = hipGetLastError();
     return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_kernel launch");

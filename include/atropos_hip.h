@@ -327,8 +327,10 @@ int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *
  * one of the 15 upper-case IUPAC letters), ATR_TABLE_ACGT / ATR_TABLE_IUPAC per wildcard flag
  * otherwise (_align.pyx:243-248, :292-297).  revcomp_ref != 0: the reference of a pair is the
  * reverse complement of the packed sequence (util/__init__.py:479-482).  d_*_lens may be NULL.
- * ATR_ERR_UNSUPPORTED: a side longer than ATR_PAIRS_MAX_LEN or int(e * m) >= 256. */
-#define ATR_PAIRS_MAX_LEN 255
+ * ATR_ERR_UNSUPPORTED: a side longer than ATR_PAIRS_MAX_LEN (longer than 255 when the flags lack
+ * ATR_STOP_WITHIN_SEQ2: only then must the DP cell count matches rather than mismatches) or
+ * int(e * m) >= 256. */
+#define ATR_PAIRS_MAX_LEN 320
 int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
                            const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,
                            int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,

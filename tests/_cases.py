@@ -843,7 +843,7 @@ def check_fastq_chunking(tmp_path):
 
 # ---------------------------------------------------------------------------------------------
 # PairAligner (Aligner.locate with a per-pair reference) against the oracle
-def check_pairs_against_oracle(PairAligner, oracle, unsupported_exc, seed, rounds, max_len=255):
+def check_pairs_against_oracle(PairAligner, oracle, unsupported_exc, seed, rounds, max_len=320):
     """Random settings (all flag sets, indel regimes, wildcard modes, with and without the
     on-device reverse complement); pairs are overlapping fragments with errors, unrelated
     sequences, and ragged / empty ones."""
@@ -857,7 +857,7 @@ def check_pairs_against_oracle(PairAligner, oracle, unsupported_exc, seed, round
         mo = rng.choice([1, 1, 3, 20])
         wr, wq = (rng.random() < 0.2, rng.random() < 0.2)
         rc = rng.random() < 0.5
-        top = rng.choice([12, 40, 100, 150, max_len])
+        top = rng.choice([12, 40, 100, 150, 255, max_len])
         npairs = rng.choice([1, 5, 64, 65, 130])
         refs, qrys = [], []
         for _p in range(npairs):

@@ -176,8 +176,11 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
             continue;
         }
         atr::stage_reference(refw.data(), 1, rp, m, revcomp != 0);
-        if (p.and_mode) atr::locate_pair_one<true>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
-        else atr::locate_pair_one<false>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
+        const bool xr = (flags & ATR_STOP_WITHIN_SEQ2) != 0;
+        if (p.and_mode) { if (xr) atr::locate_pair_one<true, true>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
+                          else atr::locate_pair_one<true, false>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r); }
+        else { if (xr) atr::locate_pair_one<false, true>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r);
+               else atr::locate_pair_one<false, false>(col.data(), 1, refw.data(), 1, m, qp, n, p, p.thr, out + 4 * r); }
     }
     return ATR_OK;
 }

@@ -78,8 +78,10 @@ def main():
                dict(min_overlap=10, error_rate=0.1, mismatch_action="conservative"),
                dict(min_overlap=0.3, error_rate=0.2, mismatch_action="N")]
     cases = []
-    for cfg in configs:
-        for L, count in ((40, 60), (100, 70), (150, 50), (250, 20)):
+    # (the MiSeq-length pairs come last so that the cases before them stay what they were)
+    plan = [(cfg, sizes) for sizes in (((40, 60), (100, 70), (150, 50), (250, 20)), ((300, 14), (308, 8))) for cfg in configs]
+    for cfg, sizes in plan:
+        for L, count in sizes:
             for _ in range(count):
                 r1, q1, r2, q2 = make_pair(rng, L)
                 with_quals = cfg["mismatch_action"] in ("liberal", "conservative") or rng.random() < 0.7

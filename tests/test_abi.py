@@ -76,7 +76,10 @@ def test_argument_validation_without_device():
     assert lib.atr_pack_reads(None, 0, None, None, 1, _lib.MAX_READ_LEN + 1, tab, None, None, None) == INVALID
     assert lib.atr_locate_batch(None, None, None, 1, 100, None, None, None) == INVALID
     assert lib.atr_insert_match_batch(None, None, None, None, None, 1, 100, None, None) == INVALID
-    assert lib.atr_locate_pairs_batch(None, None, 300, 0, None, None, 150, 1, 0.2, 15, 0, 0, 1, 1, None, None) == UNSUPPORTED
+    assert lib.atr_locate_pairs_batch(None, None, 321, 0, None, None, 150, 1, 0.2, 15, 0, 0, 1, 1, None, None) == UNSUPPORTED
+    # above 255 bases the cell counts mismatches, which needs STOP_WITHIN_SEQ2 (flag 8)
+    assert lib.atr_locate_pairs_batch(None, None, 300, 0, None, None, 150, 1, 0.2, 7, 0, 0, 1, 1, None, None) == UNSUPPORTED
+    assert lib.atr_locate_pairs_batch(None, None, 300, 0, None, None, 300, 1, 0.2, 15, 0, 0, 1, 1, None, None) == INVALID
     assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 0.2, 16, 0, 0, 1, 1, None, None) == INVALID
     assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 0.2, 15, 0, 0, 0, 1, None, None) == INVALID
     assert lib.atr_locate_pairs_batch(None, None, 150, 0, None, None, 150, 1, 2.0, 15, 0, 0, 1, 1, None, None) == UNSUPPORTED
