@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, 
 // loads the bit planes of both reads (coalesced tile64 chunk loads), parks read 2's in LDS (the 32 bases
 // that face a word of read 1 start at a per-lane bit offset) and only then touches the ASCII
 // matrices, at the few positions where the reads disagree.
-constexpr int PLANES_MAX_WORDS = 10;                 // ATR_INSERT_MAX_READ / 32
-
+// PW: plane words per read the kernel is built for -- 8 (reads of up to 256 bases: 33 KB of LDS per block, four
+// blocks per CU) or 10 (ATR_INSERT_MAX_READ / 32).
+template <int PW>
 __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__restrict__ records,
                                                              const uint4 *__restrict__ planes1,
                                                              const uint4 *__restrict__ planes2, int nchunks,
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
                                                              int min_qual_diff, const CompTable ct,
                                                              int32_t *__restrict__ changed, int32_t *__restrict__ newlen) {
     __shared__ uint8_t s_comp[256];
-    __shared__ uint32_t s_b2[4][4 * PLANES_MAX_WORDS][64];        // per wave: read 2's planes, [plane * W + word][lane]
+    __shared__ uint32_t s_b2[4][4 * PW][64];        // per wave: read 2's planes, [plane * W + word][lane]
     s_comp[threadIdx.x] = ct.c[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -124,24 +125,24 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     // a pair is corrected when its insert match exists and has errors (modifiers.py:397-404)
     const bool todo = live && rec[1] >= 0 && rec[5] > 0;
     const int j = todo ? (int)rec[3] : 0;                         // the overlap: read1[0:j] faces revcomp(read2[0:j])
-    uint32_t a[PLANES_MAX_WORDS][4];
+    uint32_t a[PW][4];
     const uint4 *t1 = planes1 + (size_t)tile * nchunks * 64 + lane, *t2 = planes2 + (size_t)tile * nchunks * 64 + lane;
     uint32_t (*b2)[64] = s_b2[wave];
 #pragma unroll
-    for (int c = 0; c < PLANES_MAX_WORDS; ++c) {
+    for (int c = 0; c < PW; ++c) {
         if (c < nchunks) {
             const uint4 v1 = t1[(size_t)c * 64], v2 = t2[(size_t)c * 64];
             a[c][0] = v1.x; a[c][1] = v1.y; a[c][2] = v1.z; a[c][3] = v1.w;
-            b2[0 * PLANES_MAX_WORDS + c][lane] = v2.x; b2[1 * PLANES_MAX_WORDS + c][lane] = v2.y;
-            b2[2 * PLANES_MAX_WORDS + c][lane] = v2.z; b2[3 * PLANES_MAX_WORDS + c][lane] = v2.w;
+            b2[0 * PW + c][lane] = v2.x; b2[1 * PW + c][lane] = v2.y;
+            b2[2 * PW + c][lane] = v2.z; b2[3 * PW + c][lane] = v2.w;
         } else {
             a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0u;
         }
     }
-    uint32_t mism[PLANES_MAX_WORDS];
-    const auto b2word = [b2, lane](int plane, int idx) { return b2[plane * PLANES_MAX_WORDS + idx][lane]; };
+    uint32_t mism[PW];
+    const auto b2word = [b2, lane](int plane, int idx) { return b2[plane * PW + idx][lane]; };
 #pragma unroll
-    for (int w = 0; w < PLANES_MAX_WORDS; ++w) mism[w] = (todo && w < nchunks) ? facing_mismatches(a[w], b2word, nchunks, j, w) : 0u;
+    for (int w = 0; w < PW; ++w) mism[w] = (todo && w < nchunks) ? facing_mismatches(a[w], b2word, nchunks, j, w) : 0u;
     if (!live) return;
     if (!todo) {
         changed[2 * p] = changed[2 * p + 1] = 0;
@@ -153,10 +154,10 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     };
     const auto code2 = [b2, lane](int pos) {           // read 2: by position out of LDS
         const int w = pos >> 5, b = pos & 31;
-        return ((b2[0 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) | (((b2[1 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) << 1) |
-               (((b2[2 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) << 2) | (((b2[3 * PLANES_MAX_WORDS + w][lane] >> b) & 1u) << 3);
+        return ((b2[0 * PW + w][lane] >> b) & 1u) | (((b2[1 * PW + w][lane] >> b) & 1u) << 1) |
+               (((b2[2 * PW + w][lane] >> b) & 1u) << 2) | (((b2[3 * PW + w][lane] >> b) & 1u) << 3);
     };
-    correct_errors_planes_one<PLANES_MAX_WORDS>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
+    correct_errors_planes_one<PW>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
                                                 q2 ? q2 + p * stride : nullptr, len2, j, mism, nchunks, action, min_qual_diff,
                                                 s_comp, changed + 2 * p, newlen + 2 * p, code1, code2);
 }
@@ -167,8 +168,14 @@ int launch_correct_planes(const int16_t *records, const uint4 *planes1, const ui
                           int32_t *newlen, hipStream_t st) {
     CompTable ct;
     memcpy(ct.c, comp, 256);
-    hipLaunchKernelGGL(correct_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, records, planes1, planes2,
-                       nchunks, s1, q1, l1, s2, q2, l2, stride, n, max_len, action, min_qual_diff, ct, changed, newlen);
+    if (nchunks <= 8)
+        hipLaunchKernelGGL(correct_planes_kernel<8>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, records, planes1,
+                           planes2, nchunks, s1, q1, l1, s2, q2, l2, stride, n, max_len, action, min_qual_diff, ct, changed,
+                           newlen);
+    else
+        hipLaunchKernelGGL(correct_planes_kernel<10>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, records, planes1,
+                           planes2, nchunks, s1, q1, l1, s2, q2, l2, stride, n, max_len, action, min_qual_diff, ct, changed,
+                           newlen);
     return (int)hipGetLastError();
 }
 

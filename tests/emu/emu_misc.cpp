@@ -92,7 +92,7 @@ int emu_insert_correct_batch(const int16_t *records, const uint32_t *planes1, co
         auto word = [&](const uint32_t *planes, int plane, int idx) {
             return planes[(((size_t)tile * nchunks + idx) * 64 + lane) * 4 + plane];
         };
-        uint32_t mism[8] = {0};
+        uint32_t mism[10] = {0};                                     // ATR_INSERT_MAX_READ / 32 words
         for (int w = 0; w < nchunks; ++w) {
             const uint32_t a[4] = {word(planes1, 0, w), word(planes1, 1, w), word(planes1, 2, w), word(planes1, 3, w)};
             mism[w] = facing_mismatches(a, [&](int plane, int idx) { return word(planes2, plane, idx); }, nchunks, j, w);
@@ -102,7 +102,7 @@ int emu_insert_correct_batch(const int16_t *records, const uint32_t *planes1, co
             for (int pl = 0; pl < 4; ++pl) c |= ((word(planes, pl, pos >> 5) >> (pos & 31)) & 1u) << pl;
             return c;
         };
-        correct_errors_planes_one<8>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
+        correct_errors_planes_one<10>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
                                      q2 ? q2 + p * stride : nullptr, len2, j, mism, nchunks, action, min_qual_diff, comp,
                                      changed + 2 * p, newlen + 2 * p, [&](int w, int b) { return code_at(planes1, 32 * w + b); },
                                      [&](int pos) { return code_at(planes2, pos); });
