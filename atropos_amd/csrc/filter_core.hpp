@@ -117,6 +117,13 @@ ATR_DEV int triangle_rows(int rows, int n, int j, int k) { return rows - (n - j)
 // Every wave of the window DP also skips, in column j, the rows above (j - jlo) + k (jlo = the wave's
 // start column): a path that leaves row 0 at a column c0 >= jlo and reaches (i, j) with a insertions
 // and b deletions has i = (j - c0) - b + a <= (j - jlo) + k.
+// Ragged batches: the same row-count bins serve when the sweep runs in coordinates that count from the read
+// END (window_kernel's tail mode: a lane's column j is its own column j - (max_len - n)), which needs an
+// aligner without START_WITHIN_SEQ1 (a lane that joins the sweep later restarts from the ordinary initial
+// column) -- see ragged_rows_bins().
+ATR_DEV bool ragged_rows_bins(bool start_within_seq1) { return !start_within_seq1; }
+constexpr int TAIL_COLUMNS = 64;                   // columns before the read end a tail-mode wave can sweep
+
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
     if (window_band(w)) return start;

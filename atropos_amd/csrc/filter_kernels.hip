@@ -118,7 +118,9 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
         else        hipLaunchKernelGGL((filter_kernel<false, false>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
     }
     launch_fast_scan(wk, st);
-    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m, ragged ? 0 : 1, wk);
+    // the same bin rule as K1's histogram (filter_kernel): row-count bins also for ragged batches when tail mode applies
+    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m,
+                       (!ragged || !(a->flags & ATR_START_WITHIN_SEQ1)) ? 1 : 0, wk);        // == ragged_rows_bins(u.sr)
     // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
     // joined after K4, so that its waves (latency bound: three dependent gathers per task) share
     // the SIMDs with K4's instead of running before them.

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
             const uint32_t ww = filter_decide<WIDE>(F, u, fp, (const uint32_t *)tp, nchunks, n, rec);
             wk.win[r] = ww;
             if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-            else atomicAdd(&s_hist[window_bin(ww, u.m, !RAGGED)], 1u);
+            else atomicAdd(&s_hist[window_bin(ww, u.m, !RAGGED || ragged_rows_bins(u.sr))], 1u);
         }
     }
     __syncthreads();
@@ -307,8 +307,9 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         // a wave of by-rows bins only; not from a real column 0 of zeros (START_WITHIN_SEQ1), which
         // is no upper bound of the cells to its right
         const bool head = !(u.sr && jlo == 0);
+        // (equal-length batches only: in a ragged one such a wave runs in tail mode below, or without the triangle)
         const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0 &&
-                         head;                          // (wave-uniform by construction; tell the compiler)
+                         head && lens == nullptr;       // (wave-uniform by construction; tell the compiler)
         // linked: the alignment of a lane starts at its own column s (= front.rstop).  The wave's
         // common start column may lie before that -- such a lane is re-initialised when the sweep
         // reaches its s (its own window starts at or after s, so nothing of value was computed).
@@ -316,10 +317,63 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         const int s_top = LINKED ? wave_max_i32(s_lane) : 0;
 
         LaneState<MT> L;
-        lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
-
         // this lane's read inside the tile64 layout (gathered: 16 bytes per lane per chunk)
         const uint4 *tp = packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63);
+
+        // TAIL MODE (ragged batches, waves of the row-count bins): every lane's window ends at its own read
+        // end, so the sweep runs in columns counted from the END -- lane column j stands for the lane's own
+        // column j - shift, shift = max_len - n -- which makes window, row limit and triangle wave-uniform
+        // exactly as in an equal-length batch.  The lane's last TAIL_COLUMNS bases are fetched once, re-aligned
+        // to the read end.  A lane whose read starts inside the swept range (column shift) restarts there from
+        // the initial column, which without START_WITHIN_SEQ1 is the fresh-window column itself.
+        const bool rows_wave = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0;
+        if (!LINKED && lens != nullptr && rows_wave && !u.sr) {
+            const int shift = live ? max_len - n : 0;
+            const int v0 = wave_min_i32(live ? j_lo + shift : 0x7fffffff);
+            if (max_len - v0 <= TAIL_COLUMNS && v0 < max_len) {
+                const int s_top_t = wave_max_i32(shift);
+                lane_init_window<MT, NOINDEL>(L, u, max_len, v0, live ? max_len : 0, live && window_scan(ww), s_init, s_thr);
+                uint32_t tb[TAIL_COLUMNS / 8];                         // bases n - 64 .. n - 1 (0-based), eight per dword
+                {
+                    const int dlo = n - TAIL_COLUMNS;                  // may be negative: those bases read as code 0
+                    const int z0 = dlo >> 3;
+                    const uint32_t sh = 4u * (uint32_t)(dlo & 7);
+                    uint32_t raw[TAIL_COLUMNS / 8 + 1];
+#pragma unroll
+                    for (int t = 0; t <= TAIL_COLUMNS / 8; ++t) raw[t] = live ? read_dword((const uint32_t *)tp, nchunks, z0 + t) : 0u;
+#pragma unroll
+                    for (int t = 0; t < TAIL_COLUMNS / 8; ++t) tb[t] = sh ? ((raw[t] >> sh) | (raw[t + 1] << (32u - sh))) : raw[t];
+                }
+                int j = max_len - TAIL_COLUMNS;                        // column of the base before tb's first
+#pragma unroll 1
+                for (int d = 0; d < TAIL_COLUMNS / 8; ++d) {
+                    uint32_t w = tb[0];
+#pragma unroll
+                    for (int t = 0; t + 1 < TAIL_COLUMNS / 8; ++t) tb[t] = tb[t + 1];
+#pragma unroll 1
+                    for (int b = 0; b < 8; ++b) {
+                        ++j;
+                        const uint32_t q = w & 15u;
+                        w >>= 4;
+                        if (j <= v0) continue;
+                        uint32_t nm[(MT + 31) / 32];
+                        load_mask(nm, s_nm, q);
+                        int pl = min(plimit, u.p0 + (j - v0) + u.k);
+                        pl = min(pl, u.p0 + triangle_rows(rows_w, max_len, j, u.k));
+                        lane_step<MT, NOINDEL, true, true>(L, u, j, nm, s_thr, pl);
+                        if (j <= s_top_t && shift == j) lane_restart_window<MT>(L, u, j);
+                    }
+                }
+                if (live) {
+                    uint32_t rec[4];
+                    lane_result<MT>(L, u, rec);
+                    if ((rec[0] >> 16) != 0xFFFFu) rec[1] -= (uint32_t)shift * 0x00010001u;      // back to the read's own columns
+                    out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+                }
+                continue;
+            }
+        }
+        lane_init_window<MT, NOINDEL>(L, u, n, jlo, j_hi, live && window_scan(ww), s_init, s_thr);
         if (jhi > jlo) {
             const int c0 = jlo >> 5, c1 = (jhi + 31) >> 5;
             uint4 nxt = tp[(size_t)c0 * 64];

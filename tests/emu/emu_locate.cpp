@@ -151,14 +151,47 @@ void emu_dp_stage(const atr_aligner *a, const uint32_t *packed, const int32_t *l
             s_lane[lane] = (la && live[lane]) ? (int)(la->front[4 * rr[lane] + 1] >> 16) : 0;
             s_top = std::max(s_top, s_lane[lane]);
         }
+        const int plimit = u.p0 + rows;
+        if (!la && lens != nullptr && base >= rows_bin0 && !u.sr) {        // tail mode (window_kernel)
+            int v0 = 0x7fffffff, s_top_t = 0, shift[64];
+            for (int lane = 0; lane < 64; ++lane) {
+                shift[lane] = live[lane] ? max_len - lens[rr[lane]] : 0;
+                if (live[lane]) v0 = std::min(v0, window_lo(wws[lane]) + shift[lane]);
+                s_top_t = std::max(s_top_t, shift[lane]);
+            }
+            if (max_len - v0 <= TAIL_COLUMNS && v0 < max_len) {
+                for (int lane = 0; lane < 64; ++lane)
+                    lane_init_window<MT, NOINDEL>(L[lane], u, max_len, v0, live[lane] ? max_len : 0,
+                                                  live[lane] && window_scan(wws[lane]), s_init, s_thr);
+                for (int j = max_len - TAIL_COLUMNS + 1; j <= max_len; ++j) {
+                    if (j <= v0) continue;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int own = j - shift[lane];                   // the lane's own column
+                        const uint32_t q = (live[lane] && own >= 1) ? read_code(packed, nchunks, rr[lane], own) : 0u;
+                        uint32_t nm[(MT + 31) / 32];
+                        for (int w2 = 0; w2 < (MT + 31) / 32; ++w2) nm[w2] = p.nmask[q][w2];
+                        int pl = std::min(plimit, u.p0 + (j - v0) + u.k);
+                        pl = std::min(pl, u.p0 + triangle_rows(rows, max_len, j, u.k));
+                        lane_step<MT, NOINDEL, true, true>(L[lane], u, j, nm, s_thr, pl);
+                        if (j <= s_top_t && shift[lane] == j) lane_restart_window<MT>(L[lane], u, j);
+                    }
+                }
+                for (int lane = 0; lane < 64; ++lane)
+                    if (live[lane]) {
+                        uint32_t *rec = out + 4 * rr[lane];
+                        lane_result<MT>(L[lane], u, rec);
+                        if ((rec[0] >> 16) != 0xFFFFu) rec[1] -= (uint32_t)shift[lane] * 0x00010001u;
+                    }
+                continue;
+            }
+        }
         for (int lane = 0; lane < 64; ++lane) {
             const int n = live[lane] ? (lens ? lens[rr[lane]] : max_len) : 0;
             lane_init_window<MT, NOINDEL>(L[lane], u, n, jlo, live[lane] ? window_hi(wws[lane]) : 0,
                                  live[lane] && window_scan(wws[lane]), s_init, s_thr);
         }
-        const int plimit = u.p0 + rows;
         const bool head = !(u.sr && jlo == 0);
-        const bool tri = base >= rows_bin0 && head;
+        const bool tri = base >= rows_bin0 && head && lens == nullptr;
         if (jhi > jlo)
         for (int j = jlo + 1; j <= jhi; ++j)
             for (int lane = 0; lane < 64; ++lane) {
@@ -200,7 +233,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         const uint32_t ww = fp.rows > 32 ? filter_decide<true>(F, u, fp, q, nchunks, n, rec) : filter_decide<false>(F, u, fp, q, nchunks, n, rec);
         win[r] = ww;
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
-        else bins[window_bin(ww, u.m, lens == nullptr)].push_back((uint32_t)r);
+        else bins[window_bin(ww, u.m, lens == nullptr || ragged_rows_bins(u.sr))].push_back((uint32_t)r);
     }
     emu_dp_stage<MT, NOINDEL>(a, packed, lens, nchunks, max_len, out, win, bins, nullptr);
 }
