@@ -318,34 +318,34 @@ ATR_DEV uint32_t facing_mismatches(const uint32_t a[4], W2 b2word, int nwords, i
 // (modifiers.py:272-300).  Returns 0, or the error code (-1: base without complement).
 // known1 / known2: the characters of read1[i] / read2[jx] when the caller already has them (decoded from
 // the bit planes), else 0: read from the matrices.
-ATR_DEV int correct_position(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, int action,
-                             int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend,
-                             uint8_t known1 = 0, uint8_t known2 = 0) {
+// The decision once the position's bytes are on hand: base1 = read1[i], raw2 = read2[jx] (not yet
+// complemented), qa / qb their qualities (ignored without quality rows).
+ATR_DEV int correct_apply(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, uint8_t base1, uint8_t raw2,
+                          int qa, int qb, int action, int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend) {
     const bool has_quals = q1 != nullptr && q2 != nullptr;
-    const uint8_t base1 = known1 ? known1 : s1[i];
-    const uint8_t base2 = comp[known2 ? known2 : s2[jx]];
+    const uint8_t base2 = comp[raw2];
     if (base2 == 0) return -1;
     if (base1 == base2) return 0;
     if (action == 0) {                             // 'N'
         s1[i] = 'N'; s2[jx] = 'N'; ++c1; ++c2;
     } else if (base1 == 'N') {
         s1[i] = base2;
-        if (has_quals) q1[i] = q2[jx];
+        if (has_quals) q1[i] = (uint8_t)qb;
         ++c1;
     } else if (base2 == 'N') {
         const uint8_t cb = comp[base1];
         if (cb == 0) return -1;
         s2[jx] = cb;
-        if (has_quals) q2[jx] = q1[i];
+        if (has_quals) q2[jx] = (uint8_t)qa;
         ++c2;
     } else if (has_quals) {
-        const int diff = (int)q1[i] - (int)q2[jx];
+        const int diff = qa - qb;
         if (diff >= min_qual_diff) {
             const uint8_t cb = comp[base1];
             if (cb == 0) return -1;
-            s2[jx] = cb; q2[jx] = q1[i]; ++c2;
+            s2[jx] = cb; q2[jx] = (uint8_t)qa; ++c2;
         } else if (diff <= -min_qual_diff) {
-            s1[i] = base2; q1[i] = q2[jx]; ++c1;
+            s1[i] = base2; q1[i] = (uint8_t)qb; ++c1;
         } else if (action == 2) {
             ++npend;                               // quals_equal.append(...)
         }
@@ -353,49 +353,59 @@ ATR_DEV int correct_position(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2,
     return 0;
 }
 
+ATR_DEV int correct_position(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, int action,
+                             int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend,
+                             uint8_t known1 = 0, uint8_t known2 = 0) {
+    const bool has_quals = q1 != nullptr && q2 != nullptr;
+    return correct_apply(s1, q1, s2, q2, i, jx, known1 ? known1 : s1[i], known2 ? known2 : s2[jx], has_quals ? (int)q1[i] : 0,
+                         has_quals ? (int)q2[jx] : 0, action, min_qual_diff, comp, c1, c2, npend);
+}
+
 // sum of the first n bytes of a row (rows of the ASCII matrices start at any byte address: four bytes per
 // load through an alignment-1 type, summed with one v_sad_u8 on the device)
 typedef uint32_t __attribute__((aligned(1))) atr_u32_unaligned;
+struct __attribute__((packed, aligned(1))) atr_u128_unaligned { uint32_t x, y, z, w; };
 ATR_DEV long long byte_sum(const uint8_t *row, int n) {
-    uint32_t acc = 0;
+    // sixteen bytes per load, four loads in flight per round (a lane walks its own row: every round trip counts)
+    uint32_t acc0 = 0, acc1 = 0;
     int i = 0;
+#ifndef ATR_HOST_EMU
+    for (; i + 64 <= n; i += 64) {
+        const atr_u128_unaligned v0 = *(const atr_u128_unaligned *)(row + i), v1 = *(const atr_u128_unaligned *)(row + i + 16);
+        const atr_u128_unaligned v2 = *(const atr_u128_unaligned *)(row + i + 32), v3 = *(const atr_u128_unaligned *)(row + i + 48);
+        acc0 = __builtin_amdgcn_sad_u8(v0.x, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v0.y, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v0.z, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v0.w, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v1.x, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v1.y, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v1.z, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v1.w, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v2.x, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v2.y, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v2.z, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v2.w, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v3.x, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v3.y, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v3.z, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v3.w, 0u, acc1);
+    }
+    for (; i + 16 <= n; i += 16) {
+        const atr_u128_unaligned v = *(const atr_u128_unaligned *)(row + i);
+        acc0 = __builtin_amdgcn_sad_u8(v.x, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v.y, 0u, acc1);
+        acc0 = __builtin_amdgcn_sad_u8(v.z, 0u, acc0); acc1 = __builtin_amdgcn_sad_u8(v.w, 0u, acc1);
+    }
+#endif
     for (; i + 4 <= n; i += 4) {
         const uint32_t v = *(const atr_u32_unaligned *)(row + i);
 #ifdef ATR_HOST_EMU
-        acc += (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24);
+        acc0 += (v & 0xFFu) + ((v >> 8) & 0xFFu) + ((v >> 16) & 0xFFu) + (v >> 24);
 #else
-        acc = __builtin_amdgcn_sad_u8(v, 0u, acc);
+        acc0 = __builtin_amdgcn_sad_u8(v, 0u, acc0);
 #endif
     }
-    for (; i < n; ++i) acc += row[i];
-    return (long long)acc;
+    for (; i < n; ++i) acc0 += row[i];
+    return (long long)acc0 + (long long)acc1;
 }
 
-// correct_errors(read1, read2, insert_match, truncate_seqs=True) for a pair with an insert match of
-// j bases; mism[w] = facing_mismatches(...) of word w.  Same outputs as correct_errors_one.
-// code1(i) / code2(jx): the DNA15 codes of read1[i] / read2[jx] out of the planes (0: a character without
-// a code -- it is then read from the matrix), which spares the two scattered byte loads per position.
-ATR_DEV uint8_t dna15_letter(uint32_t code) { return (uint8_t)"\0ACMGRSVTWYHKDBN"[code & 15u]; }
-
-// NW: compile-time bound of the word loops (fully unrolled, so that code1 may index registers by w)
-template <int NW, class C1, class C2>
-ATR_DEV void correct_errors_planes_one(uint8_t *s1, uint8_t *q1, int len1, uint8_t *s2, uint8_t *q2, int len2, int j,
-                                       const uint32_t *mism, int nwords, int action, int min_qual_diff,
-                                       const uint8_t *comp, int32_t *changed, int32_t *newlen, C1 code1, C2 code2) {
-    const int n1 = mc_min(len1, len2);             // both reads are cut to the common length (:250-259)
-    int c1 = 0, c2 = 0, err = 0, npend = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        uint32_t m = (w < nwords && !err) ? mism[w] : 0u;
-        while (m && !err) {
-            const int b = atr_ctz(m);
-            m &= m - 1u;
-            const int i = 32 * w + b;
-            err = correct_position(s1, q1, s2, q2, i, j - 1 - i, action, min_qual_diff, comp, c1, c2, npend,
-                                   dna15_letter(code1(w, b)), dna15_letter(code2(j - 1 - i)));
-        }
-    }
-    if (!err && npend > 0) {                       // :301-322: equal qualities -- the read with the better overlap wins
+// 'liberal' with positions of equal quality left over (:301-322): the read with the better mean quality over the
+// overlap wins all of them.  mism: the disagreeing positions as facing_mismatches left them (positions settled in
+// the first pass have equal bases by now and are skipped).
+ATR_DEV void correct_ties(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int j, const uint32_t *mism, int nwords,
+                          int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &err) {
+    {
         if (j <= 0) {
             err = -3;
         } else {
@@ -424,6 +434,33 @@ ATR_DEV void correct_errors_planes_one(uint8_t *s1, uint8_t *q1, int len1, uint8
             }
         }
     }
+}
+
+// correct_errors(read1, read2, insert_match, truncate_seqs=True) for a pair with an insert match of
+// j bases; mism[w] = facing_mismatches(...) of word w.  Same outputs as correct_errors_one.
+// code1(i) / code2(jx): the DNA15 codes of read1[i] / read2[jx] out of the planes (0: a character without
+// a code -- it is then read from the matrix), which spares the two scattered byte loads per position.
+ATR_DEV uint8_t dna15_letter(uint32_t code) { return (uint8_t)"\0ACMGRSVTWYHKDBN"[code & 15u]; }
+
+// NW: compile-time bound of the word loops (fully unrolled, so that code1 may index registers by w)
+template <int NW, class C1, class C2>
+ATR_DEV void correct_errors_planes_one(uint8_t *s1, uint8_t *q1, int len1, uint8_t *s2, uint8_t *q2, int len2, int j,
+                                       const uint32_t *mism, int nwords, int action, int min_qual_diff,
+                                       const uint8_t *comp, int32_t *changed, int32_t *newlen, C1 code1, C2 code2) {
+    const int n1 = mc_min(len1, len2);             // both reads are cut to the common length (:250-259)
+    int c1 = 0, c2 = 0, err = 0, npend = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint32_t m = (w < nwords && !err) ? mism[w] : 0u;
+        while (m && !err) {
+            const int b = atr_ctz(m);
+            m &= m - 1u;
+            const int i = 32 * w + b;
+            err = correct_position(s1, q1, s2, q2, i, j - 1 - i, action, min_qual_diff, comp, c1, c2, npend,
+                                   dna15_letter(code1(w, b)), dna15_letter(code2(j - 1 - i)));
+        }
+    }
+    if (!err && npend > 0) correct_ties(s1, q1, s2, q2, j, mism, nwords, min_qual_diff, comp, c1, c2, err);
     changed[0] = err ? err : c1;
     changed[1] = err ? 0 : c2;
     newlen[0] = (c1 > 0 && !err) ? n1 : len1;      // the truncation quirk of correct_errors_one

@@ -99,20 +99,32 @@ __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, 
 // loads the bit planes of both reads (coalesced tile64 chunk loads), parks read 2's in LDS (the 32 bases
 // that face a word of read 1 start at a per-lane bit offset) and only then touches the ASCII
 // matrices, at the few positions where the reads disagree.
-// PW: plane words per read the kernel is built for -- 8 (reads of up to 256 bases: 33 KB of LDS per block, four
-// blocks per CU) or 10 (ATR_INSERT_MAX_READ / 32).
+// PW: plane words per read the kernel is built for -- 8 (reads of up to 256 bases) or 10 (ATR_INSERT_MAX_READ / 32).
+//
+// The disagreeing positions of the wave's 64 pairs become (pair, position) TASKS in a per-wave LDS queue and are
+// worked off 64 at a time, one task per lane: a task is four independent byte loads (both bases, both qualities),
+// the reference's decision (correct_apply) and up to two byte stores -- one memory round trip for 64 positions,
+// where a lane walking its own pair's ~8 positions one after the other paid one round trip EACH.  Positions of a
+// pair touch distinct bytes, so their order does not matter; the per-pair counters are LDS atomics.  Only the
+// 'liberal' pairs with positions of equal quality left (correct_ties) are finished by their own lane afterwards.
+// The queue re-uses the LDS that staged read 2's planes for facing_mismatches.
 template <int PW>
 __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__restrict__ records,
                                                              const uint4 *__restrict__ planes1,
                                                              const uint4 *__restrict__ planes2, int nchunks,
-                                                             uint8_t *__restrict__ s1, uint8_t *__restrict__ q1,
-                                                             const int32_t *__restrict__ l1, uint8_t *__restrict__ s2,
-                                                             uint8_t *__restrict__ q2, const int32_t *__restrict__ l2,
+                                                             uint8_t *s1, uint8_t *q1, const int32_t *__restrict__ l1,
+                                                             uint8_t *s2, uint8_t *q2, const int32_t *__restrict__ l2,
                                                              long long stride, long long n, int max_len, int action,
                                                              int min_qual_diff, const CompTable ct,
                                                              int32_t *__restrict__ changed, int32_t *__restrict__ newlen) {
+    // uint16 tasks that fit the plane staging area; at most 63 left over + 64 x 32 new ones are ever queued
+    static_assert(4 * PW * 64 * 2 >= 64 * 32 + 64, "task queue does not fit the plane staging area");
     __shared__ uint8_t s_comp[256];
-    __shared__ uint32_t s_b2[4][4 * PW][64];        // per wave: read 2's planes, [plane * W + word][lane]
+    __shared__ uint32_t s_b2[4][4 * PW][64];                      // per wave: read 2's planes, [plane * W + word][lane]; then the queue
+    __shared__ uint32_t s_cnt[4][64];                             // per pair: c1 | c2 << 10 | npend << 20
+    __shared__ int32_t s_err[4][64];
+    __shared__ int16_t s_j[4][64];
+    __shared__ uint32_t s_tail[4];
     s_comp[threadIdx.x] = ct.c[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -125,41 +137,94 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     // a pair is corrected when its insert match exists and has errors (modifiers.py:397-404)
     const bool todo = live && rec[1] >= 0 && rec[5] > 0;
     const int j = todo ? (int)rec[3] : 0;                         // the overlap: read1[0:j] faces revcomp(read2[0:j])
-    uint32_t a[PW][4];
-    const uint4 *t1 = planes1 + (size_t)tile * nchunks * 64 + lane, *t2 = planes2 + (size_t)tile * nchunks * 64 + lane;
-    uint32_t (*b2)[64] = s_b2[wave];
-#pragma unroll
-    for (int c = 0; c < PW; ++c) {
-        if (c < nchunks) {
-            const uint4 v1 = t1[(size_t)c * 64], v2 = t2[(size_t)c * 64];
-            a[c][0] = v1.x; a[c][1] = v1.y; a[c][2] = v1.z; a[c][3] = v1.w;
-            b2[0 * PW + c][lane] = v2.x; b2[1 * PW + c][lane] = v2.y;
-            b2[2 * PW + c][lane] = v2.z; b2[3 * PW + c][lane] = v2.w;
-        } else {
-            a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0u;
-        }
-    }
     uint32_t mism[PW];
-    const auto b2word = [b2, lane](int plane, int idx) { return b2[plane * PW + idx][lane]; };
+    {
+        uint32_t a[PW][4];
+        const uint4 *t1 = planes1 + (size_t)tile * nchunks * 64 + lane, *t2 = planes2 + (size_t)tile * nchunks * 64 + lane;
+        uint32_t (*b2)[64] = s_b2[wave];
 #pragma unroll
-    for (int w = 0; w < PW; ++w) mism[w] = (todo && w < nchunks) ? facing_mismatches(a[w], b2word, nchunks, j, w) : 0u;
+        for (int c = 0; c < PW; ++c) {
+            if (c < nchunks) {
+                const uint4 v1 = t1[(size_t)c * 64], v2 = t2[(size_t)c * 64];
+                a[c][0] = v1.x; a[c][1] = v1.y; a[c][2] = v1.z; a[c][3] = v1.w;
+                b2[0 * PW + c][lane] = v2.x; b2[1 * PW + c][lane] = v2.y;
+                b2[2 * PW + c][lane] = v2.z; b2[3 * PW + c][lane] = v2.w;
+            } else {
+                a[c][0] = a[c][1] = a[c][2] = a[c][3] = 0u;
+            }
+        }
+        const auto b2word = [b2, lane](int plane, int idx) { return b2[plane * PW + idx][lane]; };
+#pragma unroll
+        for (int w = 0; w < PW; ++w) mism[w] = (todo && w < nchunks) ? facing_mismatches(a[w], b2word, nchunks, j, w) : 0u;
+    }
+    // ---- the queue (the planes in LDS are not needed any more; one wave, so no block barrier) ----
+    volatile uint16_t *queue = (volatile uint16_t *)&s_b2[wave][0][0];
+    s_cnt[wave][lane] = 0u;
+    s_err[wave][lane] = 0;
+    s_j[wave][lane] = (int16_t)j;
+    if (lane == 0) s_tail[wave] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const bool has_quals = q1 != nullptr && q2 != nullptr;
+    const auto drain = [&](int from, int count) {               // tasks queue[from .. from + count), count <= 64, wave-uniform
+        if (lane < count) {
+            const uint32_t t = queue[from + lane];
+            const int src = (int)(t >> 9), i = (int)(t & 511u);
+            const int jx = (int)s_j[wave][src] - 1 - i;
+            const size_t row = (size_t)(tile * 64 + src) * (size_t)stride;
+            const uint8_t base1 = s1[row + i], raw2 = s2[row + jx];
+            const int qa = has_quals ? (int)q1[row + i] : 0, qb = has_quals ? (int)q2[row + jx] : 0;
+            int c1 = 0, c2 = 0, np = 0;
+            const int e = correct_apply(s1 + row, has_quals ? q1 + row : nullptr, s2 + row, has_quals ? q2 + row : nullptr, i, jx,
+                                        base1, raw2, qa, qb, action, min_qual_diff, s_comp, c1, c2, np);
+            if (e) s_err[wave][src] = e;
+            else if (c1 | c2 | np) atomicAdd(&s_cnt[wave][src], (uint32_t)c1 | ((uint32_t)c2 << 10) | ((uint32_t)np << 20));
+        }
+    };
+    int qsize = 0;                                                // wave-uniform
+#pragma unroll
+    for (int w = 0; w < PW; ++w) {
+        uint32_t m = mism[w];                                     // (0 beyond nchunks)
+        const int cnt = __builtin_popcount(m);
+        if (cnt) {
+            uint32_t at = atomicAdd(&s_tail[wave], (uint32_t)cnt);
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1u;
+                queue[at++] = (uint16_t)((lane << 9) | (32 * w + b));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        qsize = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&s_tail[wave]);
+        while (qsize >= 64) {                                     // full rounds, off the end of the queue
+            qsize -= 64;
+            drain(qsize, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) s_tail[wave] = (uint32_t)qsize;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (qsize > 0) drain(0, qsize);
+    // the lanes' stores, before their pairs' owners (lanes of this same wave: one CU, one L1) read them back --
+    // a device-scope fence would write back the L2 for the sake of other XCDs, once per wave
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
     if (!live) return;
     if (!todo) {
         changed[2 * p] = changed[2 * p + 1] = 0;
         newlen[2 * p] = len1; newlen[2 * p + 1] = len2;
         return;
     }
-    const auto code1 = [&a](int w, int b) {            // read 1: its planes are still in registers (w is a literal after unrolling)
-        return ((a[w][0] >> b) & 1u) | (((a[w][1] >> b) & 1u) << 1) | (((a[w][2] >> b) & 1u) << 2) | (((a[w][3] >> b) & 1u) << 3);
-    };
-    const auto code2 = [b2, lane](int pos) {           // read 2: by position out of LDS
-        const int w = pos >> 5, b = pos & 31;
-        return ((b2[0 * PW + w][lane] >> b) & 1u) | (((b2[1 * PW + w][lane] >> b) & 1u) << 1) |
-               (((b2[2 * PW + w][lane] >> b) & 1u) << 2) | (((b2[3 * PW + w][lane] >> b) & 1u) << 3);
-    };
-    correct_errors_planes_one<PW>(s1 + p * stride, q1 ? q1 + p * stride : nullptr, len1, s2 + p * stride,
-                                                q2 ? q2 + p * stride : nullptr, len2, j, mism, nchunks, action, min_qual_diff,
-                                                s_comp, changed + 2 * p, newlen + 2 * p, code1, code2);
+    const uint32_t packed_counts = *(volatile uint32_t *)&s_cnt[wave][lane];
+    int c1 = (int)(packed_counts & 1023u), c2 = (int)((packed_counts >> 10) & 1023u), err = *(volatile int32_t *)&s_err[wave][lane];
+    const int npend = (int)(packed_counts >> 20);
+    uint8_t *r1 = s1 + p * stride, *r2 = s2 + p * stride;
+    if (!err && npend > 0)
+        correct_ties(r1, has_quals ? q1 + p * stride : nullptr, r2, has_quals ? q2 + p * stride : nullptr, j, mism, nchunks,
+                     min_qual_diff, s_comp, c1, c2, err);
+    changed[2 * p] = err ? err : c1;
+    changed[2 * p + 1] = err ? 0 : c2;
+    newlen[2 * p] = (c1 > 0 && !err) ? min(len1, len2) : len1;   // the truncation quirk of correct_errors_one
+    newlen[2 * p + 1] = len2;
 }
 
 int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,
