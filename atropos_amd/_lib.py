@@ -587,9 +587,13 @@ def thread_backend(backend):
         _thread_local.backend = prev
 
 
-def set_backend(backend):
-    """Install a backend object (used by bench.py to pin a device per rank, and by the
-    CPU test-suite to inject its kernel emulation).  Returns the previous one."""
+def set_backend(backend, _test_double=False):
+    """Install the process-wide backend: a ``HipBackend`` (bench.py pins one device per rank with it)
+    or None (forget the current one).  Returns the previous one.  Anything else is refused -- the
+    product never computes on a stand-in; the CPU test-suite injects its kernel emulation by saying so
+    explicitly (``_test_double=True``, tests/ only)."""
     global _backend
+    if backend is not None and not isinstance(backend, HipBackend) and not _test_double:
+        raise TypeError("set_backend: only a HipBackend can be installed")
     prev, _backend = _backend, backend
     return prev

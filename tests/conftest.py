@@ -41,9 +41,9 @@ def emu_backend():
     package backend for one test; restores the previous backend afterwards."""
     from atropos_amd import _lib
     from tests.emu.backend import EmuBackend
-    prev = _lib.set_backend(EmuBackend())
+    prev = _lib.set_backend(EmuBackend(), _test_double=True)
     yield _lib.get_backend()
-    _lib.set_backend(prev)
+    _lib.set_backend(prev, _test_double=True)
 
 
 @pytest.fixture()
@@ -54,4 +54,4 @@ def hip_backend():
     be = _lib.get_backend()
     assert be.name == "hip"
     yield be
-    _lib.set_backend(prev)
+    _lib.set_backend(prev, _test_double=True)

@@ -28,7 +28,7 @@ def _worker(rank, world, port, total, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _lib.set_backend(EmuBackend())
+    _lib.set_backend(EmuBackend(), _test_double=True)
     w = synth.workload("C2", 0, total)
     al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
     local, gathered = shard.sharded_locate(al, w["reads"])
@@ -75,7 +75,7 @@ def _trim_worker(rank, world, port, path_in, path_out, args):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _lib.set_backend(EmuBackend())
+    _lib.set_backend(EmuBackend(), _test_double=True)
     counts = shard.sharded_trim_file(pipeline_from_args(args), path_in, path_out, chunk_bytes=40000)
     total = torch.tensor([sum(counts.values())], dtype=torch.int64)
     dist.all_reduce(total)                      # host-side sum of the per-rank summaries (multicore.py:389)

@@ -50,11 +50,11 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
     from tests.emu.backend import EmuBackend
     data = _big_fastq(60000, 5)
     got = pipeline_from_args(args).trim_bytes(data)
-    prev = _lib.set_backend(EmuBackend())
+    prev = _lib.set_backend(EmuBackend(), _test_double=True)
     try:
         want = pipeline_from_args(args).trim_bytes(data)
     finally:
-        _lib.set_backend(prev)
+        _lib.set_backend(prev, _test_double=True)
     assert len(got) == len(want) and got == want, _cases._first_diff(got, want)
     assert len(got) > 20000
 
@@ -115,11 +115,11 @@ def test_large_paired_merge_equals_cpu_twin(hip_backend, args):
         return res.text() + (res.merged_text(),), res.counts()
 
     got, counts = run()
-    prev = _lib.set_backend(EmuBackend())
+    prev = _lib.set_backend(EmuBackend(), _test_double=True)
     try:
         want, wcounts = run()
     finally:
-        _lib.set_backend(prev)
+        _lib.set_backend(prev, _test_double=True)
     assert counts == wcounts and counts["merged"] > 10000
     for g, w in zip(got, want):
         assert len(g) == len(w) and g == w, _cases._first_diff(g, w)

@@ -55,4 +55,19 @@ def test_no_gpu_no_fallback():
         with pytest.raises(_lib.AtroposHipError):
             _lib.get_backend()
     finally:
-        _lib.set_backend(prev)
+        _lib.set_backend(prev, _test_double=True)
+
+
+def test_set_backend_refuses_stand_ins():
+    """The product's backend hook takes a HipBackend or None; a test double has to say what it is."""
+    from atropos_amd import _lib
+
+    class Fake(object):
+        name = "fake"
+    prev = _lib.set_backend(None)
+    try:
+        with pytest.raises(TypeError):
+            _lib.set_backend(Fake())
+        assert _lib.set_backend(Fake(), _test_double=True) is None
+    finally:
+        _lib.set_backend(prev, _test_double=True)

@@ -212,7 +212,7 @@ def main():
     from atropos.commands import get_command
     from emu.backend import EmuBackend
     from atropos_amd import _lib
-    _lib.set_backend(EmuBackend())
+    _lib.set_backend(EmuBackend(), _test_double=True)
     from atropos_amd.trim import pipeline_from_args
     rng = random.Random(o.seed)
     bad = skipped = 0
