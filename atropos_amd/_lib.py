@@ -72,6 +72,8 @@ PROTOTYPES = {
                                          C.c_void_p, C.c_int, C.c_void_p]),
     "atr_compare_batch": (C.c_int, [C.c_char_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_locate_debug_bytes": (C.c_size_t, [C.c_void_p, C.c_int]),
+    "atr_locate_debug": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_compare_packed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_adapter_postfilter": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int,
                                          C.c_double, C.c_int, C.c_void_p]),
@@ -405,6 +407,16 @@ class HipBackend(object):
                                                                  _ptr(front), _ptr(back), _ptr(self._work), self._stream()),
                        "atr_linked_match_batch")
         return which, front, back
+
+    def locate_debug(self, h, packed, m, n):
+        """atr_locate_debug: (cost matrix int32 [m + 1, n + 1] on the host, INT32_MIN = not computed; the record)."""
+        work = self.empty((max(self.lib.atr_locate_debug_bytes(h, n), 16),), torch.uint8)
+        out = self.empty((1, 8), torch.int16)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_locate_debug(h, _ptr(packed), n, _ptr(work), _ptr(out), self._stream()),
+                   "atr_locate_debug")
+        cells = (m + 1) * (n + 1)
+        return work[:4 * cells].view(torch.int32).reshape(m + 1, n + 1).cpu(), out.cpu()
 
     def compare_packed(self, h, packed, lens, nreads, max_len, suffix):
         """atr_compare_packed: compare_prefixes / compare_suffixes of aligner ``h``'s reference against

@@ -56,6 +56,7 @@ class Aligner(object):
             raise ValueError('Insertion/deletion cost must be at least 1')    # _align.pyx:229-230
         self._min_overlap = int(min_overlap)
         self._indel_cost = int(indel_cost)
+        self._debug, self._dpmatrix = False, None
         self._set_reference(reference)
 
     # -- construction / destruction -------------------------------------------------
@@ -127,13 +128,15 @@ class Aligner(object):
 
     @property
     def dpmatrix(self):
-        """Always None: the DP matrix is never materialised on the device."""
-        return None
+        """The dynamic programming matrix of the last ``locate`` call as a :class:`DPMatrix`, once
+        ``enable_debug()`` has been called (reference: _align.pyx:250-257)."""
+        return self._dpmatrix
 
     def enable_debug(self):
-        raise NotImplementedError(
-            "the DP-matrix debug dump (reference _align.pyx:259-264) is a CPU-only debugging aid "
-            "and is not provided by the device implementation")
+        """Store the DP matrix while running ``locate`` and make it available as ``.dpmatrix``
+        (reference: _align.pyx:259-264).  A debugging aid: the matrix of one pair comes from a
+        one-lane kernel that walks the reference's own loop (``atr_locate_debug``)."""
+        self._debug = True
 
     # -- packing ----------------------------------------------------------------------
     @property
@@ -202,7 +205,17 @@ class Aligner(object):
         if not isinstance(query, str):
             raise TypeError("query must be str")
         query.encode('ascii')                          # UnicodeEncodeError like the reference (:281)
-        return self.locate_batch([query]).tuples()[0]
+        result = self.locate_batch([query]).tuples()[0]
+        if self._debug and self._handle is not None:
+            batch = self.pack([query])
+            costs, rec = self._backend.locate_debug(self._handle, batch.packed, len(self._ref_bytes), len(query))
+            assert LocateResult(rec).tuples()[0] == result
+            self._dpmatrix = DPMatrix(self.str_reference, query)
+            for i, row in enumerate(costs.tolist()):
+                for j, cost in enumerate(row):
+                    if cost != _DEBUG_NOT_COMPUTED:
+                        self._dpmatrix.set_entry(i, j, cost)
+        return result
 
 
 def locate(reference, query, max_error_rate, flags=SEMIGLOBAL, wildcard_ref=False, wildcard_query=False,
@@ -256,6 +269,28 @@ def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix
         q_t = torch.zeros((q_t.shape[0], 1), dtype=torch.uint8, device=be.device)
         lens = torch.zeros((q_t.shape[0],), dtype=torch.int32, device=be.device) if lens is None else lens
     return be.compare_batch(ref_b, q_t, lens, q_t.shape[1], wildcard_ref, wildcard_query, suffix)
+
+
+_DEBUG_NOT_COMPUTED = -(1 << 31)
+
+
+class DPMatrix(object):
+    """The dynamic programming matrix of one ``Aligner.locate`` call, for debugging: one row per
+    reference position, one column per query position; an entry is None where the aligner never
+    computed a value (reference: class DPMatrix, _align.pyx:88-119)."""
+
+    def __init__(self, reference, query):
+        self.reference, self.query = reference, query
+        self._rows = [[None] * (len(query) + 1) for _ in range(len(reference) + 1)]
+
+    def set_entry(self, i, j, cost):
+        self._rows[i][j] = cost
+
+    def __str__(self):
+        lines = [" " * 5 + " ".join("%2s" % base for base in self.query)]
+        for base, row in zip(" " + self.reference, self._rows):
+            lines.append(base + " " + " ".join("  " if cost is None else "%2d" % cost for cost in row))
+        return "\n".join(lines)
 
 
 class PairAligner(object):

@@ -23,6 +23,8 @@ int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uin
                    int max_len, int action,
                    int min_qual_diff, int truncate, const uint8_t *comp, int32_t *changed, int32_t *newlen,
                    hipStream_t st);
+int launch_locate_debug(const LocateParams &lp, double e, int flags, int min_overlap, int indel, const uint32_t *packed, int n,
+                        void *col, int32_t *matrix, int16_t *rec, hipStream_t st);
 int launch_compare_packed(const LocateParams &lp, const uint32_t *packed, const int32_t *lens, long long n, int max_len,
                           int suffix, int16_t *out, hipStream_t st);
 int launch_planes_uncoded(const uint4 *planes, int nchunks, const int32_t *lens, const int32_t *other, long long n,
@@ -323,6 +325,21 @@ int atr_compare_batch(const char *ref, int m, const uint8_t *d_queries, int64_t 
     const int rc = launch_compare((const uint8_t *)ref, m, d_queries, query_stride, d_lens, n, max_len, wildcard_ref,
                                   wildcard_query, suffix, (int16_t *)d_out, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "compare_kernel launch");
+}
+
+size_t atr_locate_debug_bytes(const atr_aligner *a, int n) {
+    if (!a || n < 0) return 0;
+    return ((size_t)(a->p.m + 1) * (size_t)(n + 1)) * 4 + (size_t)(a->p.m + 1) * 12;
+}
+
+int atr_locate_debug(const atr_aligner *a, const uint8_t *d_packed, int n, void *d_matrix, atr_result *d_out, void *stream) {
+    if (!a || n < 0 || n > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (!d_matrix || !d_out || (n > 0 && !d_packed)) return ATR_ERR_INVALID;
+    int32_t *matrix = (int32_t *)d_matrix;
+    void *col = (void *)(matrix + (size_t)(a->p.m + 1) * (size_t)(n + 1));
+    const int rc = launch_locate_debug(a->p, a->max_error_rate, a->flags, a->min_overlap, a->indel_cost,
+                                       (const uint32_t *)d_packed, n, col, matrix, (int16_t *)d_out, (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_debug_kernel launch");
 }
 
 int atr_compare_packed(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads, int max_len,

@@ -133,6 +133,82 @@ ATR_DEV void compare_one(const uint8_t *ref, int m, const uint8_t *query, int n,
     rec[4] = (int16_t)matches; rec[5] = (int16_t)(len - matches); rec[6] = 0; rec[7] = 0;
 }
 
+// ---- Aligner.enable_debug(): the DP matrix as the reference would print it (_align.pyx:88-119, :354-357,
+// :428-431).  A debugging aid for ONE (reference, query) pair, so this is the reference's own loop with plain
+// integer cells and its Ukkonen cut-off `last` -- the matrix shows exactly the cells that loop computes (an entry
+// it never wrote stays "not computed"), including the stale neighbours a re-entered row is computed from, and the
+// TRUE indel cost (the throughput kernels cap it at k + 1, which changes no result but would change these
+// numbers).  mismatch(i, code): does reference row i (1-based) differ from the query code?
+constexpr int32_t DEBUG_NOT_COMPUTED = INT32_MIN;
+struct DebugCell { int cost, matches, origin; };
+
+template <class MIS, class CODE>
+ATR_DEV void locate_debug_one(int m, int n, double e, int flags, int min_overlap, int indel, MIS mismatch, CODE code_at,
+                              DebugCell *col /* m + 1 */, int32_t *matrix /* (m + 1) x (n + 1), row-major */, int16_t *rec) {
+    const bool sr = (flags & ATR_START_WITHIN_SEQ1) != 0, sq = (flags & ATR_START_WITHIN_SEQ2) != 0;
+    const bool er = (flags & ATR_STOP_WITHIN_SEQ1) != 0, eq = (flags & ATR_STOP_WITHIN_SEQ2) != 0;
+    const int k = (int)(e * m);
+    const int max_n = sq ? n : mc_min(n, m + k), min_n = eq ? 0 : mc_max(0, n - m - k);
+    for (long long t = 0; t < (long long)(m + 1) * (n + 1); ++t) matrix[t] = DEBUG_NOT_COMPUTED;
+    for (int i = 0; i <= m; ++i) {                                       // :333-352
+        DebugCell c;
+        c.matches = 0;
+        if (!sr && !sq) { c.cost = mc_max(i, min_n) * indel; c.origin = 0; }
+        else if (sr && !sq) { c.cost = min_n * indel; c.origin = mc_min(0, min_n - i); }
+        else if (!sr && sq) { c.cost = i * indel; c.origin = mc_max(0, min_n - i); }
+        else { c.cost = mc_min(i, min_n) * indel; c.origin = min_n - i; }
+        col[i] = c;
+        matrix[(long long)i * (n + 1) + min_n] = c.cost;
+    }
+    int b_cost = m + n, b_matches = 0, b_origin = 0, b_ref_stop = m, b_query_stop = n;
+    int last = sr ? m : mc_min(m, k + 1);
+    for (int j = min_n + 1; j <= max_n; ++j) {
+        DebugCell diag = col[0];
+        if (sq) col[0].origin = j; else col[0].cost = j * indel;
+        const uint32_t qc = code_at(j);
+        for (int i = 1; i <= last; ++i) {
+            DebugCell nw;
+            if (!mismatch(i, qc)) {
+                nw.cost = diag.cost; nw.origin = diag.origin; nw.matches = diag.matches + 1;
+            } else {
+                const int sub = diag.cost + 1, del = col[i].cost + indel, ins = col[i - 1].cost + indel;
+                if (sub <= del && sub <= ins) { nw.cost = sub; nw.origin = diag.origin; nw.matches = diag.matches; }
+                else if (ins <= del) { nw.cost = ins; nw.origin = col[i - 1].origin; nw.matches = col[i - 1].matches; }
+                else { nw.cost = del; nw.origin = col[i].origin; nw.matches = col[i].matches; }
+            }
+            diag = col[i];
+            col[i] = nw;
+        }
+        for (int i = 0; i <= last; ++i) matrix[(long long)i * (n + 1) + j] = col[i].cost;       // :428-431
+        while (last >= 0 && col[last].cost > k) --last;
+        if (last < m) {
+            ++last;
+        } else if (eq) {
+            const int length = m + mc_min(col[m].origin, 0), cost = col[m].cost, matches = col[m].matches;
+            if (length >= min_overlap && (double)cost <= (double)length * e &&
+                (matches > b_matches || (matches == b_matches && cost < b_cost))) {
+                b_matches = matches; b_cost = cost; b_origin = col[m].origin; b_ref_stop = m; b_query_stop = j;
+                if (cost == 0 && matches == m) break;
+            }
+        }
+    }
+    if (max_n == n) {
+        for (int i = er ? 0 : m; i <= m; ++i) {
+            const int length = i + mc_min(col[i].origin, 0), cost = col[i].cost, matches = col[i].matches;
+            if (length >= min_overlap && (double)cost <= (double)length * e &&
+                (matches > b_matches || (matches == b_matches && cost < b_cost))) {
+                b_matches = matches; b_cost = cost; b_origin = col[i].origin; b_ref_stop = i; b_query_stop = n;
+            }
+        }
+    }
+    rec[0] = 0; rec[1] = -1; rec[2] = rec[3] = rec[4] = rec[5] = rec[6] = rec[7] = 0;
+    if (b_cost != m + n) {
+        rec[0] = (int16_t)(b_origin >= 0 ? 0 : -b_origin); rec[1] = (int16_t)b_ref_stop;
+        rec[2] = (int16_t)(b_origin >= 0 ? b_origin : 0); rec[3] = (int16_t)b_query_stop;
+        rec[4] = (int16_t)b_matches; rec[5] = (int16_t)b_cost;
+    }
+}
+
 // compare_prefixes / compare_suffixes of an aligner's reference against one tile64-packed read
 // (the codes the read was packed with are the aligner's query table, so "does row i match this
 // base" is the aligner's own nmask bit: byte equality or 4-bit AND as its wildcard flags say,

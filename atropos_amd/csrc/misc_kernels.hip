@@ -65,6 +65,25 @@ int launch_compare_packed(const LocateParams &lp, const uint32_t *packed, const 
     return (int)hipGetLastError();
 }
 
+// Aligner.enable_debug(): one pair, one lane (a debugging aid, not a throughput path)
+__global__ void locate_debug_kernel(const LocateParams lp, double e, int flags, int min_overlap, int indel,
+                                    const uint32_t *__restrict__ packed, int n, DebugCell *col, int32_t *matrix,
+                                    int16_t *rec) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int p0 = round_up_rows_dev(lp.m) - lp.m;
+    locate_debug_one(lp.m, n, e, flags, min_overlap, indel,
+                     [&lp, p0](int i, uint32_t qc) { const int b = p0 + i - 1; return ((lp.nmask[qc][b >> 5] >> (b & 31)) & 1u) != 0u; },
+                     [packed](int j) { return (packed[(size_t)((j - 1) >> 5) * 256 + (((j - 1) >> 3) & 3)] >> (4 * ((j - 1) & 7))) & 15u; },
+                     col, matrix, rec);
+}
+
+int launch_locate_debug(const LocateParams &lp, double e, int flags, int min_overlap, int indel, const uint32_t *packed, int n,
+                        void *col, int32_t *matrix, int16_t *rec, hipStream_t st) {
+    hipLaunchKernelGGL(locate_debug_kernel, dim3(1), dim3(64), 0, st, lp, e, flags, min_overlap, indel, packed, n,
+                       (DebugCell *)col, matrix, rec);
+    return (int)hipGetLastError();
+}
+
 struct CompTable { uint8_t c[256]; };
 
 __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, uint8_t *__restrict__ q1,

@@ -241,6 +241,17 @@ int atr_insert_match_batch(const atr_insert_aligner *a, const uint8_t *d_packed1
 
 /* ---- MultiAligner.locate, compare_prefixes / compare_suffixes (general) --- */
 
+/* Aligner.enable_debug() / .dpmatrix (_align.pyx:88-119, :259-264, :354-357, :428-431): the DP matrix of
+ * ONE locate() call as the reference stores it while debugging -- the costs of exactly the cells its loop
+ * computes (Ukkonen's cut-off included), computed with the aligner's true indel cost.  d_packed: one read
+ * packed for `a` (tile64, the read is lane 0 of tile 0), n its length.  d_matrix: caller scratch of
+ * atr_locate_debug_bytes(a, n) bytes; its first (m + 1) x (n + 1) int32 (row-major, row = reference
+ * position) receive the costs, INT32_MIN = never computed (printed as blanks).  d_out: the result record
+ * of the same call.  A debugging aid: one lane, not a throughput path. */
+size_t atr_locate_debug_bytes(const atr_aligner *a, int n);
+int atr_locate_debug(const atr_aligner *a, const uint8_t *d_packed, int n, void *d_matrix, atr_result *d_out,
+                     void *stream);
+
 /* MultiAligner(max_error_rate, flags, min_overlap).locate(reference, query, max_matches)
  * (_align.pyx:548-787) for npairs independent pairs of raw ASCII strings (row-major,
  * refs at d_refs + p*ref_stride with length d_ref_lens[p], likewise the queries).

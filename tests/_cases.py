@@ -1041,3 +1041,19 @@ def check_read2_validation(ia):
         ia.match_insert_batch([a], [b + "?"])
         with pytest.raises(ValueError):
             ia.match_insert_batch([a], [b[:-1] + "?"])
+
+
+def check_dpmatrix_golden(Aligner):
+    """Aligner.enable_debug(): the printed DP matrix and the result of the same locate() call against what
+    the reference prints (tests/golden/dpmatrix.json.gz: every cell it computed, blanks where it did not)."""
+    done = 0
+    for c in load_golden("dpmatrix.json.gz"):
+        al = Aligner(c["ref"], c["e"], c["flags"], c["wr"], c["wq"], c["mo"])
+        al.indel_cost = c["ic"]
+        assert al.dpmatrix is None
+        al.enable_debug()
+        res = al.locate(c["query"])
+        assert (None if res is None else list(res)) == c["out"], c
+        assert str(al.dpmatrix) == c["matrix"], (c, str(al.dpmatrix))
+        done += 1
+    return done

@@ -111,6 +111,13 @@ class EmuBackend(object):
                       max_len, table, _ptr(packed), _ptr(invalid)), "emu_pack_reads")
         return (packed, int(invalid.item())) if count_invalid else packed
 
+    def locate_debug(self, h, packed, m, n):
+        matrix = torch.zeros((m + 1, n + 1), dtype=torch.int32)
+        out = torch.zeros((1, 8), dtype=torch.int16)
+        self.lib.emu_locate_debug.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        _check(self.lib.emu_locate_debug(h, _ptr(packed), n, _ptr(matrix), _ptr(out)), "emu_locate_debug")
+        return matrix, out
+
     def compare_packed(self, h, packed, lens, nreads, max_len, suffix):
         out = torch.zeros((nreads, 8), dtype=torch.int16)
         if nreads:

@@ -44,6 +44,19 @@ int emu_compare_batch(const char *ref, int m, const uint8_t *queries, int64_t q_
     return ATR_OK;
 }
 
+// atr_locate_debug
+int emu_locate_debug(const atr_aligner *a, const uint32_t *packed, int n, int32_t *matrix, int16_t *rec) {
+    if (!a || n < 0) return ATR_ERR_INVALID;
+    const LocateParams &lp = a->p;
+    const int p0 = round_up_rows(lp.m) - lp.m;
+    std::vector<DebugCell> col((size_t)lp.m + 1);
+    locate_debug_one(lp.m, n, a->max_error_rate, a->flags, a->min_overlap, a->indel_cost,
+                     [&lp, p0](int i, uint32_t qc) { const int b = p0 + i - 1; return ((lp.nmask[qc][b >> 5] >> (b & 31)) & 1u) != 0u; },
+                     [packed](int j) { return (packed[(size_t)((j - 1) >> 5) * 256 + (((j - 1) >> 3) & 3)] >> (4 * ((j - 1) & 7))) & 15u; },
+                     col.data(), matrix, rec);
+    return ATR_OK;
+}
+
 // atr_compare_packed
 int emu_compare_packed(const atr_aligner *a, const uint32_t *packed, const int32_t *lens, int64_t n, int max_len, int suffix,
                        int16_t *out) {

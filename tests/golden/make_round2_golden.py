@@ -10,6 +10,7 @@ Fixtures (inputs are generated here; expected values are what the reference retu
                            AdapterCutter._best_match / LinkedAdapter.match_to do -- which adapter, how many
                            5' parts match (> 1: the reference raises AttributeError), both Match records
     info_records.json.gz   AdapterCutter runs: the MatchInfo rows (Match.get_info_record) of every read
+    dpmatrix.json.gz       str(aligner.dpmatrix) after enable_debug() + locate(), with the result tuple
     insert_long.json.gz    InsertAligner.match_insert on MiSeq-length pairs (2 x 257 .. 320 bp)
     c5_head.json.gz        the first pairs of BASELINE config C5 (2 x 250 bp, qualities) through
                            InsertAdapterCutter(mismatch_action='liberal', read wildcards): full outputs of
@@ -167,6 +168,30 @@ def main():
         info_cases.append(dict(specs=specs, kw=kw, times=times, action=action, reads=reads, out=outs))
     if only is None:
         dump("info_records.json.gz", info_cases)
+
+    # ------------------------------------------------------------------ Aligner.enable_debug() / dpmatrix
+    if only in (None, "dpmatrix"):
+        from atropos.align import Aligner
+        dp_cases = []
+        for it in range(90):
+            m = rng.randint(1, 18)
+            ref = rseq(m, "ACGT" if rng.random() < 0.7 else "ACGTNRY")
+            flags = rng.randint(0, 15) if rng.random() < 0.5 else rng.choice([14, 11, 15, 9, 1, 8])
+            e = rng.choice([0, 0.1, 0.2, 0.25, 0.34, 0.5])
+            wr, wq = rng.random() < 0.25, rng.random() < 0.25
+            mo, ic = rng.choice([1, 1, 3]), rng.choice([1, 1, 1, 2, 3])
+            kind = rng.random()
+            query = (rseq(rng.randint(0, 12)) + mutate(ref.replace("N", "A").replace("R", "G").replace("Y", "C"), 0.15) +
+                     rseq(rng.randint(0, 12))) if kind < 0.6 else rseq(rng.randint(0, 30))
+            if kind > 0.9:
+                query = rseq(rng.randint(0, 5)) + ref[:rng.randint(1, m)]
+            al = Aligner(ref, e, flags, wr, wq, mo)
+            al.indel_cost = ic
+            al.enable_debug()
+            res = al.locate(query)
+            dp_cases.append(dict(ref=ref, query=query, e=e, flags=flags, wr=wr, wq=wq, mo=mo, ic=ic,
+                                 out=None if res is None else list(res), matrix=str(al.dpmatrix)))
+        dump("dpmatrix.json.gz", dp_cases)
 
     # ------------------------------------------------------------------ match_insert on 2 x 300 bp pairs
     if only in (None, "insert_long"):

@@ -95,3 +95,8 @@ def test_pair_aligner_against_oracle(emu_backend, oracle):
     from atropos_amd.align import PairAligner
     from atropos_amd._lib import AtroposHipError
     assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=77, rounds=60) > 1500
+
+
+def test_dpmatrix_debug(emu_backend):
+    from atropos_amd.align import Aligner
+    assert _cases.check_dpmatrix_golden(Aligner) == 90

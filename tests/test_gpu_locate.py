@@ -196,3 +196,8 @@ def test_pack_staged_window_edges(hip_backend, planes):
             c = be.pack_reads(inner, dl, width, table, planes=planes)
             torch.cuda.synchronize()
             assert torch.equal(a.cpu(), c.cpu()), (width, nreads)
+
+
+def test_dpmatrix_debug(hip_backend):
+    from atropos_amd.align import Aligner
+    assert _cases.check_dpmatrix_golden(Aligner) == 90
