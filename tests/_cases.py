@@ -1057,3 +1057,47 @@ def check_dpmatrix_golden(Aligner):
         assert str(al.dpmatrix) == c["matrix"], (c, str(al.dpmatrix))
         done += 1
     return done
+
+
+def check_ragged_tail_mode(Aligner, oracle, seed, nreads=20000, oracle_slice=1500):
+    """Ragged batches at a size where the row-count bins fill whole waves (the window kernel's tail mode:
+    columns counted from the read end): C2-like reads cut to random lengths -- including reads shorter than
+    the adapter and empty ones -- for 3' adapters of several lengths and error rates; the filtered
+    pipeline against the full sweep on every read and against the oracle on a slice."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib, synth
+    from atropos_amd.batch import ReadBatch
+    rng = random.Random(seed)
+    be = _lib.get_backend()
+    w = synth.workload("C2", seed, nreads, device="cpu")
+    ascii_t = w["reads"].to(be.device)
+    total = 0
+    for m, e, ic, flags in ((34, 0.1, 1, 14), (20, 0.15, 1, 14), (12, 0.2, 2, 14), (40, 0.12, 1, 10), (34, 0.1, 1, 15)):
+        ref = w["adapter"][:m] if m <= len(w["adapter"]) else w["adapter"] + rseq(rng, m - len(w["adapter"]))
+        al = Aligner(ref, e, flags, False, False, rng.choice([1, 3]), ic)
+        g = torch.Generator().manual_seed(seed + m)
+        lens = torch.randint(0, 151, (nreads,), generator=g, dtype=torch.int32)
+        lens[torch.rand(nreads, generator=g) < 0.5] = 150                      # half of them full length
+        lens[torch.rand(nreads, generator=g) < 0.1] += 0
+        lens_d = lens.to(be.device)
+        rb = ReadBatch.from_ascii(ascii_t, lens_d, 150, al.table_kind, al._table)
+        got = al.locate_batch(rb).records.cpu()
+        full = al.locate_batch(rb, filtered=False).records.cpu()
+        assert torch.equal(got, full), (m, e, ic, flags, int((got != full).any(dim=1).sum()))
+        reads = w["reads"].numpy()
+        idx = [rng.randrange(nreads) for _ in range(oracle_slice)]
+        tuples = LocateTuples(got)
+        for i in idx:
+            q = bytes(reads[i, :int(lens[i])]).decode("ascii")
+            assert tuples[i] == oracle.locate(ref, q, e, flags, False, False, al.min_overlap, ic), (ref, q, e, flags)
+        total += nreads
+    return total
+
+
+def LocateTuples(records):
+    """int16 [n, 8] records -> list of the reference's 6-tuples / None."""
+    out = []
+    for row in records.tolist():
+        out.append(None if row[1] < 0 else tuple(row[:6]))
+    return out

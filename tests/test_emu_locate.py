@@ -100,3 +100,8 @@ def test_pair_aligner_against_oracle(emu_backend, oracle):
 def test_dpmatrix_debug(emu_backend):
     from atropos_amd.align import Aligner
     assert _cases.check_dpmatrix_golden(Aligner) == 90
+
+
+def test_ragged_tail_mode(emu_backend, oracle):
+    from atropos_amd.align import Aligner
+    assert _cases.check_ragged_tail_mode(Aligner, oracle, 3, nreads=3000, oracle_slice=400) == 15000

@@ -201,3 +201,8 @@ def test_pack_staged_window_edges(hip_backend, planes):
 def test_dpmatrix_debug(hip_backend):
     from atropos_amd.align import Aligner
     assert _cases.check_dpmatrix_golden(Aligner) == 90
+
+
+def test_ragged_tail_mode(hip_backend, oracle):
+    from atropos_amd.align import Aligner
+    assert _cases.check_ragged_tail_mode(Aligner, oracle, 4, nreads=200_000, oracle_slice=3000) == 1_000_000

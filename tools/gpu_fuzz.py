@@ -2,7 +2,8 @@
 """GPU-vs-oracle fuzz campaign (run on the GPU box): every batched kernel path against
 oracle/align_oracle.c on random cases -- the filtered pipeline (all adapter types, the 32-row NARROW
 pre-pass, equal-length batches with partial overlaps), the full sweep over all 16 flag sets, the pair
-aligner, the insert aligner, the fused linked-adapter pipeline and the plane-guided error correction.
+aligner (sides of up to 320 bases), the insert aligner (reads of up to 320 bases), the fused linked-adapter
+pipeline, the plane-guided error correction and ragged batches at wave-filling size (tail-mode window sweep).
 usage: tools/gpu_fuzz.py [first_seed] [seeds]   (the log of the round's last run is kept under profiles/)"""
 import sys, time
 sys.path.insert(0, '.')
@@ -23,5 +24,6 @@ for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
     tot += _cases.check_insert_batches_against_oracle(InsertAligner, oracle, seed + 500, 60)
     tot += _cases.check_linked_sets_against_oracle(oracle, seed + 600, 150, reads_per_round=(1, 64, 65, 200, 700))[0]
     tot += _cases.check_plane_guided_correction(n=20_000, seed=seed + 700)
+    tot += _cases.check_ragged_tail_mode(Aligner, oracle, seed + 800, nreads=40_000, oracle_slice=600)
     print(seed, tot, "%.0f s" % (time.time() - t0), flush=True)
 print("cases", tot)
