@@ -422,9 +422,11 @@ def main():
             "config": desc, "roofline": roof,
             "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         }
-        if args.secondary:
+        # side measurements and the CPU leg belong to the single-GPU line (rank 0 at N = 1): the other ranks of a
+        # multi-GPU run would only wait at the final barrier for them
+        if args.secondary and world == 1:
             line["secondary"] = cfg.secondary(kernel_ms)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cfg.cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
