@@ -24,7 +24,7 @@ TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
 PAIRS_MAX_LEN = 320
-INSERT_MAX_ADAPTER = 64
+INSERT_MAX_ADAPTER = 128
 INSERT_MAX_READ = 320
 
 

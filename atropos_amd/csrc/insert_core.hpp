@@ -88,7 +88,7 @@ static __device__ __forceinline__ uint32_t atr_or_xor(uint32_t x, uint32_t a, ui
 
 namespace atr {
 
-constexpr int INS_MAX_ADAPTER = 64;                 // adapter length handled by the insert kernel
+constexpr int INS_MAX_ADAPTER = 128;                // adapter length handled by the insert kernel (two 64-base halves)
 constexpr int INS_MAX_LEN = 320;                    // read length handled by the insert kernel
 constexpr int INS_MAX_MATCHES = 100;                // MultiAligner.locate(max_matches=100)
 constexpr int INS_CAND = 4;                         // recorded hits per pair in the unordered sweep (more: ordered redo)
@@ -100,19 +100,26 @@ enum { INS_CMP_EQ = 0,        // neither flag: byte equality
        INS_CMP_AND_READ_ACGT = 2 };   // read_wildcards only: read bases that are not A/C/G/T become 0
 
 struct InsertParams {
-    uint32_t a1[4][2], a2[4][2];                    // adapter code PLANES, 64 bases (table chosen by the host per mode)
+    uint32_t a1[4][4], a2[4][4];                    // adapter code PLANES, 128 bases (table chosen by the host per mode)
     int16_t mm_by_alen[INS_MAX_ADAPTER + 1];        // round(alen * max_adapter_mismatch_frac)
     int16_t thr_ins[INS_MAX_LEN + 1];               // floor(j * max_insert_mismatch_frac)
     int16_t k_by_len[INS_MAX_LEN + 1];              // int(max_insert_mismatch_frac * L)
     int32_t thr_hit[INS_MAX_LEN + 1];               // thr_ins[j] for j >= min_insert_overlap, else -1; 32-bit so that the
                                                     // sweep fetches its (wave-uniform) entry with a scalar load
     int alen1, alen2, cmp_mode;
+    int long_adapters;                              // an adapter has more than 64 bases: the overhangs are compared in two halves
+                                                    // (the launcher then picks the kernels built with InsertParamsLong)
+    static constexpr bool kLongAdapters = false;
     int min_insert_overlap, min_adapter_overlap, adapter_check_cutoff;
     int min_hit_j;                                  // smallest j whose PERFECT overlap passes insert_max_rmp (host)
     int rmp_ld;
     double insert_max_rmp, adapter_max_rmp;
     const double *rmp_insert, *rmp_adapter;         // device pointers, [size][matches], ld = rmp_ld
 };
+
+// Same bytes; the type tells the compare code at compile time to look at the second 64 adapter bases too (the
+// extra path costs the common kernels registers they do not have: C3 1.04 -> 1.27 ms when it was a run-time test).
+struct InsertParamsLong : InsertParams { static constexpr bool kLongAdapters = true; };
 
 ATR_DEV uint32_t low_mask(int nb) {                 // nb low bits set, nb in (-inf, 32]
     return nb >= 32 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
@@ -138,8 +145,8 @@ struct PairState {
 };
 
 // b1, b2: the plane64 chunks of the two reads (word p of chunk c at [4*c + p]).
-template <int W>
-ATR_DEV void pair_init(PairState<W> &P, const InsertParams &ip, int len1, int len2, const uint32_t *b1, const uint32_t *b2) {
+template <int W, class IP>
+ATR_DEV void pair_init(PairState<W> &P, const IP &ip, int len1, int len2, const uint32_t *b1, const uint32_t *b2) {
     P.len1 = len1; P.len2 = len2;
     P.L = atr_imin(len1, len2);                                       // align/__init__.py:259-265
     P.k = ip.k_by_len[atr_imin(P.L, INS_MAX_LEN)];
@@ -161,15 +168,18 @@ ATR_DEV void pair_reset(PairState<W> &P) {
     for (int c = 0; c < INS_CAND; ++c) P.cand[c] = 0u;
 }
 
-// Mismatches of 64 bases of read overhang (planes ov[p][0..1]) against an adapter.
-ATR_DEV int overhang_mismatches(const uint32_t (&ov)[4][2], const uint32_t (&ad)[4][2], int alen, int mode) {
+// Mismatches of 64 bases of read overhang (planes ov[p][0..1]) against the bases 64 * half .. of an adapter
+// (alen = the adapter bases compared in all; the second half only exists for adapters of more than 64 bases).
+ATR_DEV int overhang_mismatches(const uint32_t (&ov)[4][2], const uint32_t (&adp)[4][4], int alen, int mode, int half = 0) {
     int mism = 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         uint32_t x0 = ov[0][t], x1 = ov[1][t], x2 = ov[2][t], x3 = ov[3][t];
+        const uint32_t ad[4][1] = {{half ? adp[0][2 + t] : adp[0][t]}, {half ? adp[1][2 + t] : adp[1][t]},
+                                   {half ? adp[2][2 + t] : adp[2][t]}, {half ? adp[3][2 + t] : adp[3][t]}};
         uint32_t bad;
         if (mode == INS_CMP_EQ) {
-            bad = (x0 ^ ad[0][t]) | (x1 ^ ad[1][t]) | (x2 ^ ad[2][t]) | (x3 ^ ad[3][t]);
+            bad = (x0 ^ ad[0][0]) | (x1 ^ ad[1][0]) | (x2 ^ ad[2][0]) | (x3 ^ ad[3][0]);
         } else {
             if (mode == INS_CMP_AND_READ_ACGT) {
                 // keep only A/C/G/T codes (exactly one plane bit), zero everything else: the
@@ -177,9 +187,9 @@ ATR_DEV int overhang_mismatches(const uint32_t (&ov)[4][2], const uint32_t (&ad)
                 const uint32_t one = ((x0 ^ x1) ^ (x2 ^ x3)) & ~((x0 & x1) | (x2 & x3));
                 x0 &= one; x1 &= one; x2 &= one; x3 &= one;
             }
-            bad = ~((x0 & ad[0][t]) | (x1 & ad[1][t]) | (x2 & ad[2][t]) | (x3 & ad[3][t]));
+            bad = ~((x0 & ad[0][0]) | (x1 & ad[1][0]) | (x2 & ad[2][0]) | (x3 & ad[3][0]));
         }
-        mism += atr_popc(bad & low_mask(alen - 32 * t));
+        mism += atr_popc(bad & low_mask(alen - 64 * half - 32 * t));
     }
     return mism;
 }
@@ -199,8 +209,8 @@ ATR_DEV void planes_from(const uint32_t (&v)[4][W], int sh, uint32_t (&ov)[4][2]
 // Everything that happens to a hit of MultiAligner.locate (overlap j, `cost` mismatches):
 // insert RMP filter and InsertAligner._match.  WI = j >> 5 as a compile-time constant.
 // Returns whether the hit survives; prob, e1, e2 describe it.
-template <int W, int WI>
-ATR_DEV bool evaluate_hit(const PairState<W> &P, const InsertParams &ip, int j, int cost, double &prob, int &e1, int &e2) {
+template <int W, int WI, class IP>
+ATR_DEV bool evaluate_hit(const PairState<W> &P, const IP &ip, int j, int cost, double &prob, int &e1, int &e2) {
     const int matches = j - cost;
     prob = ip.rmp_insert[(size_t)j * ip.rmp_ld + matches];            // align/__init__.py:359
     e1 = e2 = -1;
@@ -211,6 +221,10 @@ ATR_DEV bool evaluate_hit(const PairState<W> &P, const InsertParams &ip, int j, 
         uint32_t ov[4][2];
         planes_from<W, WI>(P.a, j & 31, ov);
         e1 = overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode);
+        if (IP::kLongAdapters) {                                      // compile time: adapters of more than 64 bases
+            planes_from<W, WI + 2>(P.a, j & 31, ov);
+            e1 += overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode, 1);
+        }
         // read 2 in natural order: plane p word w = bitrev(R[3-p][W-1-w])
         uint32_t b2[4][W];
 #pragma unroll
@@ -219,6 +233,10 @@ ATR_DEV bool evaluate_hit(const PairState<W> &P, const InsertParams &ip, int j, 
             for (int w = 0; w < W; ++w) b2[p][w] = atr_bfrev(P.r[3 - p][W - 1 - w]);
         planes_from<W, WI>(b2, j & 31, ov);
         e2 = overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode);
+        if (IP::kLongAdapters) {
+            planes_from<W, WI + 2>(b2, j & 31, ov);
+            e2 += overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode, 1);
+        }
         if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return false;   // :297-300
         if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                               // :302-306
             const double p1 = ip.rmp_adapter[(size_t)al1 * ip.rmp_ld + (al1 - e1)];
@@ -231,8 +249,8 @@ ATR_DEV bool evaluate_hit(const PairState<W> &P, const InsertParams &ip, int j, 
 
 // Overlap length j = 32*(W - Q) - s with `cost` mismatches, for one lane, in the reference's
 // order (increasing j).
-template <int W, int Q>
-ATR_DEV void pair_hit_ordered(PairState<W> &P, const InsertParams &ip, int s, int j, int cost) {
+template <int W, int Q, class IP>
+ATR_DEV void pair_hit_ordered(PairState<W> &P, const IP &ip, int s, int j, int cost) {
     if (j > P.L || P.nhits >= INS_MAX_MATCHES) return;
     // the hit test of MultiAligner.locate (_align.pyx:713-745)
     if (cost > P.k || j < ip.min_insert_overlap || cost > (int)ip.thr_ins[j]) return;
@@ -250,8 +268,8 @@ ATR_DEV void pair_hit_ordered(PairState<W> &P, const InsertParams &ip, int s, in
 
 // The same hit in the unordered sweep: count it; if its overlap is long enough to pass the
 // insert RMP filter at all, remember it for the evaluation pass.
-template <int W>
-ATR_DEV void pair_hit_record(PairState<W> &P, const InsertParams &ip, int j, int cost, int limit) {
+template <int W, class IP>
+ATR_DEV void pair_hit_record(PairState<W> &P, const IP &ip, int j, int cost, int limit) {
     if (j > P.L || cost > limit) return;                // the common exit; limit = ip.thr_hit[j], in an SGPR
     if (cost > P.k) return;
     P.nhits += 1;
@@ -280,8 +298,8 @@ ATR_DEV void planes_from_memory(const uint32_t *g, int cstride, int nchunks, int
 }
 
 // Evaluation of one recorded hit (insert RMP filter + InsertAligner._match) with a per-lane j.
-template <int W>
-ATR_DEV bool evaluate_candidate(const PairState<W> &P, const InsertParams &ip, int j, int cost, const uint32_t *g1,
+template <int W, class IP>
+ATR_DEV bool evaluate_candidate(const PairState<W> &P, const IP &ip, int j, int cost, const uint32_t *g1,
                                 const uint32_t *g2, int cstride, double &prob, int &e1, int &e2) {
     prob = ip.rmp_insert[(size_t)j * ip.rmp_ld + (j - cost)];         // align/__init__.py:359
     e1 = e2 = -1;
@@ -294,6 +312,12 @@ ATR_DEV bool evaluate_candidate(const PairState<W> &P, const InsertParams &ip, i
         e1 = overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode);
         planes_from_memory(g2, cstride, W, j, ov);
         e2 = overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode);
+        if (IP::kLongAdapters) {                                      // compile time: adapters of more than 64 bases
+            planes_from_memory(g1, cstride, W, j + 64, ov);
+            e1 += overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode, 1);
+            planes_from_memory(g2, cstride, W, j + 64, ov);
+            e2 += overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode, 1);
+        }
         if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return false;   // :297-300
         if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                               // :302-306
             const double p1 = ip.rmp_adapter[(size_t)al1 * ip.rmp_ld + (al1 - e1)];
@@ -351,7 +375,8 @@ ATR_DEV int overlap_cost_limited(const PairState<W> &P, const uint32_t (&rs)[4][
 template <int W, int Q, bool ORDERED>
 struct WordShift {
     // unordered sweep: one bit shift s, all word shifts
-    static ATR_DEV_MEMBER void all(PairState<W> &P, const InsertParams &ip, int s, const uint32_t (&rs)[4][W],
+    template <class IP>
+    static ATR_DEV_MEMBER void all(PairState<W> &P, const IP &ip, int s, const uint32_t (&rs)[4][W],
                                    uint32_t topmask, int jmax) {
         const int j = 32 * (W - Q) - s;
         if (j >= 1 && j <= jmax) {
@@ -361,7 +386,8 @@ struct WordShift {
         WordShift<W, Q + 1, ORDERED>::all(P, ip, s, rs, topmask, jmax);
     }
     // ordered sweep: word shifts from W-1 down (j ascending), all bit shifts from 31 down inside
-    static ATR_DEV_MEMBER void descending(PairState<W> &P, const InsertParams &ip, int jmax) {
+    template <class IP>
+    static ATR_DEV_MEMBER void descending(PairState<W> &P, const IP &ip, int jmax) {
         if (32 * (W - Q) - 31 <= jmax) {                              // wave-uniform
 #ifndef ATR_HOST_EMU
 #pragma unroll 1
@@ -391,8 +417,8 @@ struct WordShift<W, W, ORDERED> {
 
 // The unordered sweep of one lane; jmax = the wave-uniform upper bound of the overlap length.
 // g1, g2: the lane's plane64 chunks in memory (chunk stride cstride dwords), for the evaluation pass.
-template <int W>
-ATR_DEV void sweep_unordered(PairState<W> &P, const InsertParams &ip, int jmax, const uint32_t *g1, const uint32_t *g2,
+template <int W, class IP>
+ATR_DEV void sweep_unordered(PairState<W> &P, const IP &ip, int jmax, const uint32_t *g1, const uint32_t *g2,
                              int cstride) {
     pair_reset<W>(P);
 #ifndef ATR_HOST_EMU
@@ -436,16 +462,16 @@ ATR_DEV bool unordered_is_exact(const PairState<W> &P) { return P.nhits <= INS_M
 
 // The reference's own order (increasing j, at most 100 hits): only for the rare pairs whose
 // unordered sweep does not stand (low-complexity reads).
-template <int W>
-ATR_DEV void sweep_ordered(PairState<W> &P, const InsertParams &ip, int jmax) {
+template <int W, class IP>
+ATR_DEV void sweep_ordered(PairState<W> &P, const IP &ip, int jmax) {
     pair_reset<W>(P);
     WordShift<W, W - 1, true>::descending(P, ip, jmax);
 }
 
 // Three 16-byte records per pair: the insert match, Match 1, Match 2
 // (refstop / astop == -1: absent).
-template <int W>
-ATR_DEV void pair_result(const PairState<W> &P, const InsertParams &ip, uint32_t rec[12]) {
+template <int W, class IP>
+ATR_DEV void pair_result(const PairState<W> &P, const IP &ip, uint32_t rec[12]) {
     int v[18];
 #pragma unroll
     for (int i = 0; i < 18; ++i) v[i] = 0;

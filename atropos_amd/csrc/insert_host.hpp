@@ -31,6 +31,7 @@ inline int insert_fill(atr_insert_aligner *h, const atr_insert_config *c) {
     InsertParams &p = h->p;
     memset(&p, 0, sizeof(p));
     p.alen1 = c->alen1; p.alen2 = c->alen2;
+    p.long_adapters = (c->alen1 > 64 || c->alen2 > 64) ? 1 : 0;
     // compare_prefixes(read_overhang, adapter, wildcard_ref=adapter_wildcards,
     // wildcard_query=read_wildcards) (align/__init__.py:285-288, _align.pyx:521-530):
     // the READ is the "ref" side: IUPAC table if adapter_wildcards, else ACGT table if

@@ -14,8 +14,8 @@ static __device__ __forceinline__ int wave_max_i32_ins(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int NCH>
-__device__ __forceinline__ void insert_body(const InsertParams &ip, const uint4 *__restrict__ packed1,
+template <int NCH, class IP>
+__device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restrict__ packed1,
                                             const int32_t *__restrict__ lens1, const uint4 *__restrict__ packed2,
                                             const int32_t *__restrict__ lens2, long long npairs, int max_len,
                                             uint4 *__restrict__ out) {
@@ -75,24 +75,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 // MiSeq-length reads (nine and ten chunks, up to 320 bases): 80 plane dwords per pair live in registers,
-// two waves per SIMD.
-template <int NCH>
+// two waves per SIMD.  The same register budget serves every read length when an ADAPTER has more than 64
+// bases (LONGAD: the overhangs are compared in two halves, insert_core.hpp InsertParamsLong).
+template <int NCH, bool LONGAD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void insert_kernel_long(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
     const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
     uint4 *__restrict__ out) {
-    insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
+    if (LONGAD) insert_body<NCH>(static_cast<const InsertParamsLong &>(ip), packed1, lens1, packed2, lens2, npairs, max_len, out);
+    else insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
 }
 
 template <int NCH>
 static int launch_nch(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                       const int32_t *l2, long long npairs, int max_len, uint4 *out, hipStream_t st) {
     const long long ntiles = (npairs + 63) / 64;
+    if (a->p.long_adapters) {
+        hipLaunchKernelGGL((insert_kernel_long<NCH, true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
+                           p2, l2, npairs, max_len, out);
+        return (int)hipGetLastError();
+    }
     if constexpr (NCH == 4 || NCH == 5)
         hipLaunchKernelGGL((insert_kernel_dense<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
                            p2, l2, npairs, max_len, out);
     else if constexpr (NCH > 8)
-        hipLaunchKernelGGL((insert_kernel_long<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
+        hipLaunchKernelGGL((insert_kernel_long<NCH, false>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
                            p2, l2, npairs, max_len, out);
     else
         hipLaunchKernelGGL((insert_kernel<NCH>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,

@@ -202,7 +202,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
 
 /* ---- InsertAligner (atropos/align/__init__.py:178-377) -------------------- */
 
-#define ATR_INSERT_MAX_ADAPTER  64   /* adapter length handled by the insert kernel */
+#define ATR_INSERT_MAX_ADAPTER 128   /* adapter length handled by the insert kernel */
 #define ATR_INSERT_MAX_READ    320   /* read length handled by the insert kernel */
 
 /* InsertAligner.__init__ arguments (align/__init__.py:206-233) plus the host-built
@@ -211,7 +211,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
  *   rmp_adapter[size*rmp_ld + matches] = match_probability(matches, size)                (:303-304)
  *   max_mismatch_by_alen[a]            = round(a * max_adapter_mismatch_frac)            (:290)
  * computed by the caller with Python's float/bigint/round semantics (rmp_ld >= ATR_INSERT_MAX_READ + 1,
- * n_mismatch >= 65). */
+ * n_mismatch >= ATR_INSERT_MAX_ADAPTER + 1). */
 typedef struct {
     const char *adapter1; int alen1;
     const char *adapter2; int alen2;

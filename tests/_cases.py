@@ -236,6 +236,9 @@ def check_insert_batches_against_oracle(InsertAligner, oracle, seed, rounds):
         a1, a2 = synth.PE_ADAPTER1, synth.PE_ADAPTER2
         if it % 2 and cfg.get("adapter_wildcards", True):
             a1 = a1[:20].replace("G", "N", 1)
+        if it % 5 == 3:                        # adapters of more than 64 bases (indexed TruSeq adapters are 66): two halves
+            a1, a2 = a1 + rseq(rng, rng.choice([2, 13, 64 - 0])), a2 + rseq(rng, rng.choice([1, 30, 60]))
+            a1, a2 = a1[:128], a2[:128]
         ia = InsertAligner(a1, a2, **cfg)
         orc = oracle.InsertOracle(a1, a2, **cfg)
         n = rng.choice([20, 50, 100, 150, 250, 257, 290, 300, 320])

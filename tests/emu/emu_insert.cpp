@@ -14,9 +14,9 @@ using namespace atr;
 
 namespace {
 
-template <int NCH>
-void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int32_t *l1, const uint32_t *p2,
-                      const int32_t *l2, long long npairs, int max_len, uint32_t *out) {
+template <int NCH, class IP>
+void emu_insert_tiles_ip(const IP &ip, const uint32_t *p1, const int32_t *l1, const uint32_t *p2,
+                         const int32_t *l2, long long npairs, int max_len, uint32_t *out) {
     constexpr int W = NCH;
     const long long ntiles = (npairs + 63) / 64;
     for (long long tile = 0; tile < ntiles; ++tile) {
@@ -35,13 +35,21 @@ void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int
                     b2[4 * c + d] = p2[(((size_t)tile * NCH + c) * 64 + lane) * 4 + d];
                 }
             PairState<W> P;
-            pair_init<W>(P, a->p, l1 ? l1[r] : max_len, l2 ? l2[r] : max_len, b1, b2);
-            sweep_unordered<W>(P, a->p, jmax, p1 + (((size_t)tile * NCH) * 64 + lane) * 4,
+            pair_init<W>(P, ip, l1 ? l1[r] : max_len, l2 ? l2[r] : max_len, b1, b2);
+            sweep_unordered<W>(P, ip, jmax, p1 + (((size_t)tile * NCH) * 64 + lane) * 4,
                                p2 + (((size_t)tile * NCH) * 64 + lane) * 4, 64 * 4);
-            if (!unordered_is_exact<W>(P)) sweep_ordered<W>(P, a->p, jmax);
-            pair_result<W>(P, a->p, out + 12 * r);
+            if (!unordered_is_exact<W>(P)) sweep_ordered<W>(P, ip, jmax);
+            pair_result<W>(P, ip, out + 12 * r);
         }
     }
+}
+
+// as the launcher: adapters of more than 64 bases take the code built with InsertParamsLong
+template <int NCH>
+void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int32_t *l1, const uint32_t *p2,
+                      const int32_t *l2, long long npairs, int max_len, uint32_t *out) {
+    if (a->p.long_adapters) emu_insert_tiles_ip<NCH>(static_cast<const InsertParamsLong &>(a->p), p1, l1, p2, l2, npairs, max_len, out);
+    else emu_insert_tiles_ip<NCH>(a->p, p1, l1, p2, l2, npairs, max_len, out);
 }
 
 }  // namespace

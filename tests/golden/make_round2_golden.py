@@ -230,8 +230,33 @@ def main():
                 checked += 1
                 if it < 40:
                     long_cases.append(dict(a1=A1, a2=A2, r1=r1, r2=r2, kw=cfg, out=out))
+        # adapters of more than 64 bases (an indexed TruSeq adapter has 66): overhangs compared beyond base 64
+        B1 = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC" + "ATCACGAT" + "ATCTCGTATGCCGTCTTCTGCTTG"
+        B2 = A2 + rseq(42)
+        assert len(B1) == 66 and len(B2) == 100
+        for cfg in cfgs[:4]:
+            ref = InsertAligner(B1, B2, **cfg)
+            orc = O.InsertOracle(B1, B2, **cfg)
+            for it in range(120):
+                n = rng.choice([100, 150, 150, 250, 300])
+                f = rng.randint(0, n)                       # overhangs of up to n bases
+                F = rseq(f)
+                t1, t2 = mutate(B1, rng.choice([0, 0.03, 0.1])), mutate(B2, rng.choice([0, 0.03, 0.1]))
+                r1 = (F + t1 + rseq(n))[:n]
+                r2 = (reverse_complement(F) + t2 + rseq(n))[:rng.choice([n, n, n - 2])]
+                p = rng.choice([0, 0.01, 0.03])
+                r1, r2 = noise(r1, p), noise(r2, p)
+                res = ref.match_insert(r1, r2)
+                out = None if res is None else [list(res[0]), match_fields(res[1]), match_fields(res[2])]
+                mine = orc.match_insert(r1, r2)
+                mine = None if mine is None else [list(mine[0]), None if mine[1] is None else list(mine[1]),
+                                                  None if mine[2] is None else list(mine[2])]
+                assert mine == out, (cfg, r1, r2, mine, out)
+                checked += 1
+                if it < 30:
+                    long_cases.append(dict(a1=B1, a2=B2, r1=r1, r2=r2, kw=cfg, out=out))
         dump("insert_long.json.gz", long_cases)
-        print("oracle.match_insert == reference on %d pairs of 257 .. 320 bp" % checked)
+        print("oracle.match_insert == reference on %d pairs (257 .. 320 bp reads; adapters of 66 / 100 bases)" % checked)
     if only is not None:
         return
 

@@ -43,7 +43,7 @@ def test_insert_errors(emu_backend):
     with pytest.raises(ValueError):
         ia.match_insert_batch(["ACGT"], ["ACXT"])
     with pytest.raises(_lib.AtroposHipError):
-        InsertAligner("A" * 65, "ACGT")
+        InsertAligner("A" * 129, "ACGT")
     assert ia.match_insert("", "") is None
     assert ia.match_insert("ACGT", "") is None
     _cases.check_read2_validation(ia)
