@@ -75,6 +75,23 @@ for threads in (1, 2, 4, 8, 16):
     res["pwrite_overwrite_GBps_%d" % threads] = round(timed(wr), 2)
     res["pwrite_fresh_GBps_%d" % threads] = round(timed(wr_fresh, 2), 2)
     pool.shutdown()
+# O_DIRECT: page-cache bypass (the staging buffers are page aligned); unsupported on some file systems
+for threads in (1, 4):
+    try:
+        p2 = path + ".direct"
+        f2 = os.open(p2, os.O_RDWR | os.O_CREAT | os.O_TRUNC | os.O_DIRECT)
+        pool = ThreadPoolExecutor(threads)
+        step = ((n + threads - 1) // threads + 4095) & ~4095
+
+        def wr_direct():
+            jobs = [pool.submit(os.pwrite, f2, view[t * step:min(n, (t + 1) * step)], t * step) for t in range(threads)]
+            assert sum(j.result() for j in jobs) == n
+        res["pwrite_O_DIRECT_GBps_%d" % threads] = round(timed(wr_direct, 2), 2)
+        pool.shutdown()
+        os.close(f2)
+        os.remove(p2)
+    except OSError as err:
+        res["pwrite_O_DIRECT_%d" % threads] = "unsupported: %s" % err
 if torch.cuda.is_available():
     dev = torch.empty((n,), dtype=torch.uint8, device="cuda")
 
