@@ -379,32 +379,66 @@ class FastqSink(object):
     device -> host copy runs on its own stream behind an event (the caller's stream goes on with the
     next chunk) and a writer thread puts the buffer into the file once the copy has landed -- in
     order, one ``pwrite`` at a time (writes to one file are serialised by the kernel anyway).
-    ``keep``: do not truncate an existing file first (overwriting cached pages is about twice as
-    fast as allocating new ones); the file is cut to the written length at the end."""
 
-    def __init__(self, path, capacity, backend=None, clock=None, keep=False):
+    Every ``pwrite`` covers whole 4 KiB blocks of a block-aligned staging buffer at a block-aligned
+    offset; the odd bytes at the end of a chunk are carried to the front of the next buffer (the next
+    device -> host copy lands right behind them) and the last few go out in ``close``.  That makes
+    ``direct=True`` (O_DIRECT, page-cache bypass) possible where the file system allows it -- off by
+    default: a lone 1 GB ``pwrite`` into a new file runs at 14 GB/s that way against 6-7 GB/s through the
+    page cache on the measured host, but inside the pipeline the synchronous direct writes were no faster
+    than the buffered ones (110 vs 100 ms per 4 M reads) and slower than overwriting in place.
+    ``keep``: do not truncate an existing file first (overwriting cached pages is about twice as fast as
+    allocating new ones); the file is cut to the written length at the end."""
+
+    BLOCK = 4096
+
+    def __init__(self, path, capacity, backend=None, clock=None, keep=False, direct=False):
         import os
         from concurrent.futures import ThreadPoolExecutor
         be = backend or _lib.get_backend()
         self.clock = clock or StageClock()
         self.gpu = getattr(be, "name", "") == "hip"
-        self.buf = [_staging(capacity, self.gpu) for _ in range(3)]
-        self.fd = os.open(path, os.O_WRONLY | os.O_CREAT | (0 if keep else os.O_TRUNC), 0o644)
-        self.offset = 0
+        self.path = path
+        self.buf = [_staging(capacity + self.BLOCK, self.gpu) for _ in range(3)]
+        flags = os.O_WRONLY | os.O_CREAT | (0 if keep else os.O_TRUNC)
+        self.direct = False
+        self.fd = -1
+        if direct and hasattr(os, "O_DIRECT") and all(t.data_ptr() % self.BLOCK == 0 for t in self.buf):
+            try:
+                self.fd = os.open(path, flags | os.O_DIRECT, 0o644)
+                self.direct = True
+            except OSError:
+                self.fd = -1
+        if self.fd < 0:
+            self.fd = os.open(path, flags, 0o644)
+        self.offset = 0                                       # bytes handed to pwrite so far (a multiple of BLOCK)
+        self.rem = 0                                          # carried bytes at the front of the next buffer
         self.pool = ThreadPoolExecutor(1)
         self.pending = [None, None, None]
         self.k = 0
         self.copy_stream = torch.cuda.Stream(device=be.device) if self.gpu else None
 
-    def _put(self, host, n, offset, done, text):
+    def _put(self, k, rem, n, offset, done, text):
         import os
         if done is not None:
             done.synchronize()                                # the device -> host copy has landed
         del text
+        host = self.buf[k]
+        total = rem + n
+        whole = total - total % self.BLOCK
         view = memoryview(host.numpy())
         at = 0
-        while at < n:
-            at += os.pwrite(self.fd, view[at:n], offset + at)
+        while at < whole:
+            try:
+                at += os.pwrite(self.fd, view[at:whole], offset + at)
+            except OSError:
+                if not self.direct:
+                    raise
+                os.close(self.fd)                             # the file system refused the direct write: go on buffered
+                self.fd = os.open(self.path, os.O_WRONLY)
+                self.direct = False
+        if total > whole:                                     # the odd bytes travel to the front of the next buffer
+            self.buf[(k + 1) % 3][:total - whole].copy_(host[whole:total])
 
     def write(self, text):
         import time
@@ -413,8 +447,9 @@ class FastqSink(object):
         if self.pending[self.k] is not None:
             self.pending[self.k].result()                     # this buffer is free again after its write
         self.clock.add("wait_file_write", t0)
-        if n > self.buf[self.k].numel():
-            self.buf[self.k] = _staging(n, self.gpu)
+        rem = self.rem
+        if rem + n > self.buf[self.k].numel():
+            raise ValueError("FastqSink: a chunk of %d bytes does not fit the staging buffers" % n)
         host = self.buf[self.k]
         done = None
         if self.gpu and n:
@@ -422,14 +457,16 @@ class FastqSink(object):
             ready.record()                                    # the text is complete on the caller's stream here
             with torch.cuda.stream(self.copy_stream):
                 self.copy_stream.wait_event(ready)
-                host[:n].copy_(text, non_blocking=True)
+                host[rem:rem + n].copy_(text, non_blocking=True)
                 done = torch.cuda.Event()
                 done.record()
             text.record_stream(self.copy_stream)
         elif n:
-            host[:n].copy_(text)
-        self.pending[self.k] = self.pool.submit(self._put, host, n, self.offset, done, text)
-        self.offset += n
+            host[rem:rem + n].copy_(text)
+        self.pending[self.k] = self.pool.submit(self._put, self.k, rem, n, self.offset, done, text)
+        total = rem + n
+        self.offset += total - total % self.BLOCK
+        self.rem = total % self.BLOCK
         self.k = (self.k + 1) % 3
 
     def close(self):
@@ -440,11 +477,18 @@ class FastqSink(object):
             for job in self.pending:
                 if job is not None:
                     job.result()
+            if self.rem:                                      # the last odd bytes: an ordinary write
+                tail = bytes(self.buf[self.k][:self.rem].numpy().tobytes())
+                fd = os.open(self.path, os.O_WRONLY) if self.direct else self.fd
+                try:
+                    os.pwrite(fd, tail, self.offset)
+                finally:
+                    if self.direct:
+                        os.close(fd)
         finally:
             self.clock.add("wait_file_write", t0)
             self.pool.shutdown()
-            os.ftruncate(self.fd, self.offset)
+            os.ftruncate(self.fd, self.offset + self.rem)
             os.close(self.fd)
             _release(self.buf)
             self.buf = []
-

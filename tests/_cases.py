@@ -841,6 +841,21 @@ def check_fastq_chunking(tmp_path):
     counts = pipe.trim_file(str(src), str(dst), chunk_bytes=50000)
     assert dst.read_bytes() == whole
     assert sum(counts.values()) == data.count(b"\n") // 4
+    # the sink on its own: odd chunk sizes around the 4 KiB block, buffered and (where the file system and the
+    # staging buffers allow it) O_DIRECT
+    import torch
+    from atropos_amd import _lib
+    from atropos_amd.fastq import FastqSink
+    be = _lib.get_backend()
+    gen = torch.Generator().manual_seed(3)
+    pieces = [torch.randint(0, 255, (sz,), dtype=torch.uint8, generator=gen) for sz in (1, 4095, 4096, 4097, 123457, 0, 8191, 70000)]
+    for direct in (False, True):
+        out = tmp_path / ("sink_%d.bin" % direct)
+        sink = FastqSink(str(out), 200000, be, direct=direct)
+        for piece in pieces:
+            sink.write(piece.to(be.device))
+        sink.close()
+        assert out.read_bytes() == b"".join(bytes(p.numpy().tobytes()) for p in pieces), direct
     return counts
 
 
