@@ -68,6 +68,8 @@ def check_batches_against_oracle(Aligner, oracle, unsupported_exc, seed, rounds,
         ref = rseq(rng, m, "ACGT" if rng.random() < 0.7 else "ACGTNRY")
         flags = rng.randint(0, 15) if rng.random() < 0.5 else rng.choice([14, 11, 8, 2, 15, 9])
         e = rng.choice([0, 0.05, 0.1, 0.12, 0.2, 0.3, 0.5])
+        if rng.random() < 0.08:
+            e = rng.choice([1.0, 1.5])             # k = int(e * m) >= m: every row is "within k" (round-1 advisor finding)
         ic = rng.choice([1, 1, 2, 3, 100000])
         mo = rng.choice([1, 3, 5])
         wr, wq = rng.random() < 0.3, rng.random() < 0.3
