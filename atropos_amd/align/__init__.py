@@ -271,6 +271,22 @@ def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix
     return be.compare_batch(ref_b, q_t, lens, q_t.shape[1], wildcard_ref, wildcard_query, suffix)
 
 
+def case_sensitive_pair_table(dna15):
+    """Translate table for the LITERAL pair compare of reads with soft-masked (lower-case) bases: the
+    aligner MergeOverlapping builds compares characters, so ``a`` differs from ``A`` and equals ``a``
+    (reference: _align.pyx:390-391), and its reverse complement keeps the case
+    (util/__init__.py:67-88).  The 4-bit codes only have to be distinct per character and closed under
+    the device's complement (nibble bit-reversal): upper-case A C G T N W B D H V keep their DNA15
+    codes, a / t take 3 / 12, c / g take 5 / 10, n takes 6 -- the codes of M K R Y S, which this table
+    therefore cannot hold (0: no code)."""
+    table = bytearray(dna15)
+    for ch in b"MKRYS":
+        table[ch] = 0
+    for ch, code in zip(b"atcgn", (3, 12, 5, 10, 6)):
+        table[ch] = code
+    return bytes(table)
+
+
 _DEBUG_NOT_COMPUTED = -(1 << 31)
 
 
@@ -318,7 +334,7 @@ class PairAligner(object):
         return (_lib.TABLE_IUPAC if self.wildcard_ref else _lib.TABLE_ACGT,
                 _lib.TABLE_IUPAC if self.wildcard_query else _lib.TABLE_ACGT)
 
-    def _pack(self, seqs, kind, be, literal):
+    def _pack(self, seqs, kind, be, literal, case_table=None, may_retry=False):
         if isinstance(seqs, ReadBatch):
             if seqs.table_kind != kind:
                 raise ValueError("batch packed with table %d, this side needs %d" % (seqs.table_kind, kind))
@@ -336,10 +352,14 @@ class PairAligner(object):
                                        % _lib.PAIRS_MAX_LEN)
         if literal or self.revcomp_ref:
             # the literal compare works on 4-bit codes: every base needs one (and a complement)
+            if case_table is not None:
+                table = case_table
             packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True)
+            if bad and case_table is None and literal and may_retry:
+                return None                               # the caller packs both sides again, case-sensitively
             if bad and (literal or kind == _lib.TABLE_DNA15):
-                raise ValueError("%d sequence(s) contain characters without an upper-case IUPAC code; the device "
-                                 "pair aligner compares 4-bit codes" % bad)
+                raise ValueError("%d sequence(s) contain characters the device pair aligner has no 4-bit code for "
+                                 "(upper-case IUPAC letters, or A C G T N W B D H V in either case)" % bad)
         else:
             packed = be.pack_reads(ascii_t, lens_t, max_len, table)
         return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, kind, table)
@@ -350,8 +370,15 @@ class PairAligner(object):
         be = _lib.get_backend()
         rk, qk = self._table_kinds()
         literal = not (self.wildcard_ref or self.wildcard_query)
-        rb = self._pack(references, rk, be, literal)
-        qb = self._pack(queries, qk, be, literal)
+        raw = not isinstance(references, ReadBatch) and not isinstance(queries, ReadBatch)
+        rb = self._pack(references, rk, be, literal, may_retry=raw)
+        qb = self._pack(queries, qk, be, literal, may_retry=raw) if rb is not None else None
+        if rb is None or qb is None:
+            # soft-masked reads in the literal compare: BOTH sides with the table that tells the cases apart (the
+            # two tables share codes, so one side alone must never switch)
+            both = case_sensitive_pair_table(be.translate_table(_lib.TABLE_DNA15))
+            rb = self._pack(references, rk, be, literal, case_table=both)
+            qb = self._pack(queries, qk, be, literal, case_table=both)
         if rb.nreads != qb.nreads:
             raise ValueError("need as many references as queries")
         rec = be.locate_pairs_batch(rb.packed, rb.lens, rb.max_len, self.revcomp_ref, qb.packed, qb.lens, qb.max_len,

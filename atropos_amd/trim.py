@@ -390,13 +390,15 @@ class PairedTrimPipeline(object):
             insert_matched = torch.zeros((n,), dtype=torch.uint8, device=dev)
         align = torch.zeros((n, 8), dtype=torch.int16, device=dev)
         align[:, 1] = -1
-        table = be.translate_table(_lib.TABLE_DNA15)
+        from .align import case_sensitive_pair_table
+        tables = [be.translate_table(_lib.TABLE_DNA15)]
+        tables.append(case_sensitive_pair_table(tables[0]))     # soft-masked reads: second try, both reads with it
         for flags, group in ((START_WITHIN_SEQ1 | STOP_WITHIN_SEQ2, tried & (insert_matched != 0)),
                              (SEMIGLOBAL, tried & (insert_matched == 0))):      # :879-886
             idx = torch.nonzero(group).squeeze(1)
             if idx.numel() == 0:
                 continue
-            packs = []
+            sides = []
             for b, st in ((b2, st2), (b1, st1)):                            # reference = read 2, query = read 1
                 sub = b if idx.numel() == n else FastqBatch(b.data, b.nbytes, b.records.index_select(0, idx).contiguous(),
                                                             b.backend)
@@ -406,11 +408,20 @@ class PairedTrimPipeline(object):
                 if max_len > _lib.PAIRS_MAX_LEN:
                     raise _lib.AtroposHipError("MergeOverlapping: reads longer than %d bases are outside the device "
                                                "envelope" % _lib.PAIRS_MAX_LEN)
-                packed, lens, bad = be.pack_records(sub.data, sub.records, begin, end, max_len, table, count_invalid=True)
-                if bad:
-                    raise ValueError("%d read(s) contain characters without an upper-case IUPAC code; the device pair "
-                                     "aligner compares 4-bit codes" % bad)
-                packs.append((packed, lens, max_len))
+                sides.append((sub, begin, end, max_len))
+            for table in tables:
+                # the aligner compares characters (_align.pyx:390-391): upper-case IUPAC codes first; if a read is
+                # soft-masked, both reads again with the table that tells the cases apart
+                packs, bad = [], 0
+                for sub, begin, end, max_len in sides:
+                    packed, lens, nbad = be.pack_records(sub.data, sub.records, begin, end, max_len, table, count_invalid=True)
+                    packs.append((packed, lens, max_len))
+                    bad += nbad
+                if not bad:
+                    break
+            if bad:
+                raise ValueError("%d read(s) contain characters the device pair aligner has no 4-bit code for (upper-case "
+                                 "IUPAC letters, or A C G T N W B D H V in either case)" % bad)
             (rp, rl, rmax), (qp, ql, qmax) = packs
             rec = be.locate_pairs_batch(rp, rl, rmax, True, qp, ql, qmax, int(idx.numel()), self.merge_error_rate, flags,
                                         False, False, 1, 1)

@@ -201,6 +201,9 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
+    # soft-masked reads: the merge aligner compares characters, a != A
+    ("soft_pe.1.fastq", "soft_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.4 --correct-mismatches liberal" % (PE1, PE2)),
+    ("soft_pe.1.fastq", "soft_pe.2.fastq", "-R --merge-min-overlap 15 --merge-error-rate 0.1 -u 1 -U 1"),
 ]
 
 
@@ -291,6 +294,23 @@ def main():
     for name in ("paired.1.fastq", "paired.2.fastq"):
         inputs[name] = open(os.path.join(data_dir, name), "rb").read()
     inputs["synth_pe.1.fastq"], inputs["synth_pe.2.fastq"] = synth_pairs(500, 21)
+    soft = []
+    rng = np.random.RandomState(22)
+    for text in synth_pairs(300, 23):
+        lines = text.decode().split("\n")
+        soft.append(lines)
+    for r in range(300):                               # lower-case stretches: one mate, both mates, whole reads
+        kind = rng.rand()
+        for k, lines in enumerate(soft):
+            seq = lines[4 * r + 1]
+            if kind < 0.15 or (kind < 0.3 and k == 0):
+                a = rng.randint(0, max(1, len(seq)))
+                b = rng.randint(a, len(seq) + 1)
+                seq = seq[:a] + seq[a:b].lower() + seq[b:]
+            elif kind < 0.36:
+                seq = seq.lower()
+            lines[4 * r + 1] = seq
+    inputs["soft_pe.1.fastq"], inputs["soft_pe.2.fastq"] = ("\n".join(lines).encode() for lines in soft)
     paired = []
     with tempfile.TemporaryDirectory() as tmp:
         for idx, (n1, n2, argstr) in enumerate(PAIRED_CASES):
