@@ -79,11 +79,22 @@ def main():
                dict(min_overlap=0.3, error_rate=0.2, mismatch_action="N")]
     cases = []
     # (the MiSeq-length pairs come last so that the cases before them stay what they were)
-    plan = [(cfg, sizes) for sizes in (((40, 60), (100, 70), (150, 50), (250, 20)), ((300, 14), (308, 8))) for cfg in configs]
-    for cfg, sizes in plan:
+    plan = [(cfg, sizes, False) for sizes in (((40, 60), (100, 70), (150, 50), (250, 20)), ((300, 14), (308, 8))) for cfg in configs]
+    plan += [(cfg, ((60, 10), (150, 6)), True) for cfg in configs]          # soft-masked reads: the aligner compares characters
+    for cfg, sizes, soft in plan:
         for L, count in sizes:
             for _ in range(count):
                 r1, q1, r2, q2 = make_pair(rng, L)
+                if soft:
+                    kind = rng.random()
+                    if kind < 0.4 and r1:
+                        a = rng.randrange(len(r1)); b = rng.randint(a, len(r1))
+                        r1 = r1[:a] + r1[a:b].lower() + r1[b:]
+                    if 0.2 < kind < 0.7 and r2:
+                        a = rng.randrange(len(r2)); b = rng.randint(a, len(r2))
+                        r2 = r2[:a] + r2[a:b].lower() + r2[b:]
+                    if kind > 0.85:
+                        r1, r2 = r1.lower(), r2.lower()
                 with_quals = cfg["mismatch_action"] in ("liberal", "conservative") or rng.random() < 0.7
                 insert = rng.random() < 0.15
                 a = Sequence("p/1", r1, q1 if with_quals else None)

@@ -81,5 +81,5 @@ def test_device_resident_adapters(emu_backend):
 
 
 def test_merge_overlapping(emu_backend):
-    assert _cases.check_merge_golden(batch=True) == 1110
-    assert _cases.check_merge_golden(batch=False) == 1110
+    assert _cases.check_merge_golden(batch=True) == 1190
+    assert _cases.check_merge_golden(batch=False) == 1190

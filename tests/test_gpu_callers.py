@@ -125,4 +125,4 @@ def test_device_resident_adapters(hip_backend):
 
 
 def test_merge_overlapping(hip_backend):
-    assert _cases.check_merge_golden(batch=True) == 1110
+    assert _cases.check_merge_golden(batch=True) == 1190
