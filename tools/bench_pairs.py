@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of atr_locate_pairs_batch (the per-pair aligner behind MergeOverlapping) on
 workload C3's read pairs: reference = reverse complement of read 2 (formed on the device),
-query = read 1, flags SEMIGLOBAL, e = 0.2.  usage: tools/bench_pairs.py [npairs] [steps]"""
+query = read 1, flags SEMIGLOBAL, e = 0.2.  usage: tools/bench_pairs.py [npairs] [steps] [C3|C5]"""
 import json
 import os
 import sys
@@ -15,7 +15,8 @@ from atropos_amd.align import PairAligner              # noqa: E402
 
 npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-w = synth.workload("C3", 0, npairs, device="cuda")
+config = sys.argv[3] if len(sys.argv) > 3 else "C3"          # C3: 2 x 150 bp, C5: 2 x 250 bp
+w = synth.workload(config, 0, npairs, device="cuda")
 pa = PairAligner(0.2, 15, revcomp_ref=True)
 be = _lib.get_backend()
 rb = pa._pack(w["reads2"], _lib.TABLE_DNA15, be, True)
@@ -29,6 +30,6 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / steps * 1e3
 found = float(res.found().float().mean().item())
 n = w["reads1"].shape[1]
-print(json.dumps({"workload": "C3 pairs, Aligner(rc(read2), 0.2, SEMIGLOBAL).locate(read1), %d x 2x%d bp" % (npairs, n),
+print(json.dumps({"workload": config + " pairs, Aligner(rc(read2), 0.2, SEMIGLOBAL).locate(read1), %d x 2x%d bp" % (npairs, n),
                   "npairs": npairs, "ms_per_step": ms, "pairs_per_s": npairs / ms * 1e3, "found_fraction": found,
                   "cell_updates_per_s": npairs * n * n / ms * 1e3}))

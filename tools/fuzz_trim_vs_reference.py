@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--paired", action="store_true")
     ap.add_argument("--insert", action="store_true", help="paired-end with the insert aligner (+ error correction)")
+    ap.add_argument("--long", action="store_true", help="reads of 150 .. 300 bases (MiSeq lengths)")
     ap.add_argument("--merge", action="store_true", help="paired-end modes: add --merge-overlapping options (third output file)")
     ap.add_argument("--scratch", default="/tmp/oracle_ref")
     o = ap.parse_args()
@@ -220,7 +221,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         o.paired = o.paired or o.insert
         for case in range(o.cases):
-            L = rng.choice([30, 60, 100, 150])
+            L = rng.choice([30, 60, 100, 150] if not o.long else [150, 250, 300])
             n = rng.choice([1, 20, 70, 130])
             if o.insert:
                 a1, a2, args = insert_args(rng)
