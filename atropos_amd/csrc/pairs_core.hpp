@@ -286,6 +286,119 @@ ATR_DEV void locate_pair_reg(const uint32_t *tab, int ts, int m, int mlo, int mh
     rec[3] = 0;
 }
 
+// ---- register strips (references of more than PAIRS_REG_MAX rows) ----------------------------
+// The matrix is swept in horizontal strips of PAIRS_STRIP_ROWS rows, each with the register column of the
+// variant above: strip s holds rows R + 1 .. R + 128 (R = 128 s), its "row 0" is row R -- the free / costly
+// top row for s = 0, else the bottom row the strip before left behind in `bnd` (one word per column, read at
+// column j before this strip's own bottom cell of column j overwrites it).  A lane's row m is picked up in
+// the strip that holds it; strips above a lane's m sweep don't-care rows, strips the whole wave is done with
+// are skipped.  Candidate order is the reference's: the in-loop row-m cells of all columns come before the
+// last-column cells (_align.pyx:433-474), so the two groups keep separate trackers and a last-column cell
+// only wins when it is strictly better.
+constexpr int PAIRS_STRIP_ROWS = 128;
+constexpr int PAIRS_MAX_STRIPS = (ATR_PAIRS_MAX_LEN + PAIRS_STRIP_ROWS - 1) / PAIRS_STRIP_ROWS;
+
+// match masks of rows r0 + 1 .. r0 + MT (bit i: row r0 + 1 + i)
+template <int MT, bool AND_MODE>
+ATR_DEV void build_match_masks_rows(uint32_t *tab, int ts, const uint32_t *rp, int m, bool revcomp, int r0) {
+    constexpr int NW = (MT + 31) / 32;
+    for (int t = 0; t < 16 * NW; ++t) tab[(size_t)t * ts] = 0u;
+    for (int i = r0; i < m && i < r0 + MT; ++i) {
+        uint32_t c = packed_code(rp, revcomp ? m - 1 - i : i);
+        if (revcomp) c = bitrev4(c);
+        const int b = i - r0;
+        const uint32_t bit = 1u << (b & 31);
+        if (AND_MODE) {
+            for (uint32_t q = 1; q < 16; ++q)
+                if (q & c) tab[(size_t)(q * NW + (b >> 5)) * ts] |= bit;
+        } else {
+            tab[(size_t)(c * NW + (b >> 5)) * ts] |= bit;
+        }
+    }
+}
+
+// mlo_s / mhi_s: per strip, the smallest / largest LOCAL row (m - R) over the wave's lanes whose m lies in that
+// strip (mlo > mhi: none); mtop: the wave's largest m.  bnd: n + 1 words per lane, stride bs.
+template <bool AND_MODE, bool XREP>
+ATR_DEV void locate_pair_strips(uint32_t *tab, int ts, uint32_t *bnd, int bs, const uint32_t *rp, bool revcomp, int m,
+                                const int *mlo_s, const int *mhi_s, int mtop, const uint32_t *qp, int n,
+                                const PairParams &p, const int16_t *thr, uint32_t rec[4]) {
+    constexpr int MT = PAIRS_STRIP_ROWS, NW = MT / 32;
+    const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
+    const bool er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0, eq = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;
+    int k = (int)(p.e * m);
+    if (k < 0) k = -1;
+    int indel = p.indel_cost > k ? k + 1 : p.indel_cost;
+    if (indel < 1) indel = 1;
+    const uint32_t insw = (uint32_t)indel * COST1 + PRIO_INS, delw = (uint32_t)indel * COST1 + PRIO_DEL;
+    const uint32_t klimit = (uint32_t)(k + 1) << CSH;
+    const int max_n = sq ? n : atr_min(n, m + k);
+    const int min_n = eq ? 0 : atr_max(0, n - m - k);
+    Best loop_best, last_best;
+    loop_best.key = last_best.key = COST_FIELD_MAX - (m + n);
+    loop_best.word = last_best.word = (uint32_t)(m + n) << CSH;
+    loop_best.ref_stop = last_best.ref_stop = m;
+    loop_best.query_stop = last_best.query_stop = n;
+    loop_best.matches = last_best.matches = 0;
+    for (int s = 0; s * MT < mtop; ++s) {                                  // wave-uniform
+        const int R = s * MT;
+        const bool more = (s + 1) * MT < mtop;                             // another strip follows: leave the bottom row behind
+        const int mloc = m - R;                                            // this lane's row m in strip rows (in 1 .. MT: here)
+        const bool here = mloc >= 1 && mloc <= MT;
+        build_match_masks_rows<MT, AND_MODE>(tab, ts, rp, m, revcomp, R);
+        uint32_t col[MT + 1];
+#pragma unroll
+        for (int i = 0; i <= MT; ++i) {
+            const int row = R + i, d = min_n - row;                        // init_word(row, min_n, sr, sq, indel), :333-352
+            const int cost = (sr ? (sq ? atr_min(row, min_n) : min_n) : (sq ? row : atr_max(row, min_n))) * indel;
+            const int origin = sr ? (sq ? d : atr_min(0, d)) : (sq ? atr_max(0, d) : 0);
+            col[i] = ((uint32_t)atr_min(cost, INIT_COST_CAP) << CSH) | (uint32_t)(origin + PAIRS_ORG_BIAS);
+        }
+        if (more) bnd[(size_t)min_n * bs] = col[MT];
+        uint32_t qword = 0;
+        for (int j = min_n + 1; j <= max_n; ++j) {
+            if (((j - 1) & 7) == 0 || j == min_n + 1) qword = qp[(size_t)((j - 1) >> 5) * 256 + (((j - 1) >> 3) & 3)];
+            const uint32_t qc = (qword >> (4 * ((j - 1) & 7))) & 15u;
+            uint32_t nm[NW];
+#pragma unroll
+            for (int w = 0; w < NW; ++w) nm[w] = ~tab[(size_t)(qc * NW + w) * ts];
+            uint32_t row0;
+            if (s == 0) row0 = sq ? ((uint32_t)PAIRS_ORG_BIAS + (uint32_t)j)
+                                  : ((uint32_t)PAIRS_ORG_BIAS | ((uint32_t)atr_min(j * indel, INIT_COST_CAP) << CSH));
+            else row0 = bnd[(size_t)j * bs];                               // row R of this column, from the strip above
+            int mrow = here ? mloc : 0;
+#ifndef ATR_HOST_EMU
+            asm volatile("" : "+v"(mrow));
+#endif
+            const uint32_t wm = column_step_pairs<MT, XREP>(col, nm, row0, insw, delw, mlo_s[s], mhi_s[s], mrow);
+            if (more) bnd[(size_t)j * bs] = col[MT];
+            if (eq && here && wm < klimit) consider<XREP, PAIRS_ORG_BIAS>(loop_best, wm, m, j, p.min_overlap, thr, indel);
+        }
+        if (max_n == n) {                                                   // :461-474, rows of this strip in increasing order
+            const int first = er ? 0 : m;
+#pragma unroll
+            for (int i = 0; i <= MT; ++i) {
+                const int row = R + i;
+                if ((i > 0 || s == 0) && row >= first && row <= m)
+                    consider<XREP, PAIRS_ORG_BIAS>(last_best, col[i], row, n, p.min_overlap, thr, indel);
+            }
+        }
+    }
+    const Best &best = last_best.key > loop_best.key ? last_best : loop_best;
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != m + n) {
+        const int origin = (int)(best.word & ORG_MASK) - PAIRS_ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
 // Host side: thresholds and envelope check shared by the library and the emulation.
 inline int pairs_params(double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
                         int ref_max_len, int query_max_len, PairParams &p) {

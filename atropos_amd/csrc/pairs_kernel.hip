@@ -4,6 +4,7 @@
 // 3 waves per CU at 150 bp, 2 at 250 bp, 1 at 320 bp (92 KB of the CU's 160).  VALU-bound like every DP here (no MFMA: the
 // recurrence is a min-plus chain along the column, not a contraction).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include "atropos_hip.h"
 #include "pairs_core.hpp"
@@ -74,6 +75,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void p
     if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
 }
 
+// Register strips (pairs_core.hpp, locate_pair_strips): references of more than PAIRS_REG_MAX rows.  A persistent
+// grid; every wave owns one slot of the boundary buffer ((query_max_len + 1) x 64 words: the bottom row a strip
+// leaves to the next one).
+template <bool AND_MODE, bool XREP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void pairs_strip_kernel(
+    const PairParams p, const uint32_t *__restrict__ ref_packed, const int32_t *__restrict__ ref_lens, int ref_chunks,
+    int ref_max_len, int revcomp, const uint32_t *__restrict__ qry_packed, const int32_t *__restrict__ qry_lens,
+    int qry_chunks, int qry_max_len, long long npairs, uint32_t *__restrict__ boundary, uint4 *__restrict__ out) {
+    constexpr int NW = PAIRS_STRIP_ROWS / 32;
+    __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pairs[];
+    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 3; i += 256) s_thr[i] = p.thr[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *tab = s_pairs + (size_t)wave * 16 * NW * 64 + lane;     // [code][word][lane]
+    uint32_t *bnd = boundary + ((size_t)blockIdx.x * 4 + wave) * (size_t)(qry_max_len + 1) * 64 + lane;
+    const long long ntiles = (npairs + 63) >> 6;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long r = tile * 64 + lane;
+        const bool live = r < npairs;
+        const int m = live ? min(ref_lens ? ref_lens[r] : ref_max_len, ref_max_len) : 0;
+        const int n = live ? min(qry_lens ? qry_lens[r] : qry_max_len, qry_max_len) : 0;
+        const uint32_t *rp = ref_packed + ((size_t)tile * ref_chunks * 64 + lane) * 4;
+        const uint32_t *qp = qry_packed + ((size_t)tile * qry_chunks * 64 + lane) * 4;
+        int mtop = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mtop = max(mtop, __shfl_xor(mtop, o, 64));
+        mtop = __builtin_amdgcn_readfirstlane(mtop);
+        int mlo_s[PAIRS_MAX_STRIPS], mhi_s[PAIRS_MAX_STRIPS];
+#pragma unroll
+        for (int s = 0; s < PAIRS_MAX_STRIPS; ++s) {
+            const int loc = m - s * PAIRS_STRIP_ROWS;
+            const bool here = live && loc >= 1 && loc <= PAIRS_STRIP_ROWS;
+            int lo = here ? loc : 0x7fffffff, hi = here ? loc : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+            mlo_s[s] = __builtin_amdgcn_readfirstlane(lo);
+            mhi_s[s] = __builtin_amdgcn_readfirstlane(hi);
+        }
+        uint32_t rec[4];
+        locate_pair_strips<AND_MODE, XREP>(tab, 64, bnd, 64, rp, revcomp != 0, m, mlo_s, mhi_s, mtop, qp, n, p, s_thr, rec);
+        if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+}
+
+static hipError_t launch_pairs_strips(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
+                                      const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out,
+                                      hipStream_t st) {
+    constexpr int NW = PAIRS_STRIP_ROWS / 32;
+    const size_t lds = (size_t)4 * 16 * NW * 64 * 4;
+    const long long ntiles = (npairs + 63) / 64;
+    const unsigned blocks = (unsigned)std::min<long long>((ntiles + 3) / 4, 512);      // two blocks per CU are resident
+    const size_t bytes = (size_t)blocks * 4 * (size_t)(qmax + 1) * 64 * 4;
+    uint32_t *boundary = nullptr;
+    hipError_t e = hipMallocAsync((void **)&boundary, bytes, st);                       // stream-ordered: one buffer per call
+    if (e != hipSuccess) return e;
+    const bool xrep = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0;
+#define ATR_LAUNCH_STRIPS(AND, XR)                                                                                     \
+    do {                                                                                                               \
+        e = hipFuncSetAttribute((const void *)pairs_strip_kernel<AND, XR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess)                                                                                           \
+            hipLaunchKernelGGL((pairs_strip_kernel<AND, XR>), dim3(blocks), dim3(256), lds, st, p, rp, rl, (rmax + 31) / 32, rmax, \
+                               revcomp, qp, ql, (qmax + 31) / 32, qmax, npairs, boundary, out);                         \
+    } while (0)
+    if (p.and_mode) { if (xrep) ATR_LAUNCH_STRIPS(true, true); else ATR_LAUNCH_STRIPS(true, false); }
+    else { if (xrep) ATR_LAUNCH_STRIPS(false, true); else ATR_LAUNCH_STRIPS(false, false); }
+#undef ATR_LAUNCH_STRIPS
+    const hipError_t launched = e == hipSuccess ? hipGetLastError() : e;
+    const hipError_t freed = hipFreeAsync(boundary, st);
+    return launched != hipSuccess ? launched : freed;
+}
+
 template <int MT>
 static hipError_t launch_pairs_reg(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
                                    const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out,
@@ -119,6 +192,15 @@ extern "C" int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t
         else if (ref_max_len <= 104) e = launch_pairs_reg<104>(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len, npairs, (uint4 *)d_out, (hipStream_t)stream);
         else e = launch_pairs_reg<152>(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len, npairs, (uint4 *)d_out, (hipStream_t)stream);
         return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_reg_kernel launch");
+    }
+    {   // more than PAIRS_REG_MAX rows: the register column in strips of 128 rows; the LDS-column kernel below
+        // remains for a runtime without stream-ordered allocation
+        e = launch_pairs_strips(p, (const uint32_t *)d_ref_packed, d_ref_lens, ref_max_len, revcomp_ref,
+                                (const uint32_t *)d_query_packed, d_query_lens, query_max_len, npairs, (uint4 *)d_out,
+                                (hipStream_t)stream);
+        if (e == hipSuccess) return ATR_OK;
+        (void)hipGetLastError();
+        if (e != hipErrorNotSupported && e != hipErrorOutOfMemory) return hip_fail(e, "pairs_strip_kernel launch");
     }
     const size_t lds = ((size_t)(ref_max_len + 1) + (size_t)(ref_max_len + 7) / 8) * 64 * 4;
     const dim3 grid((unsigned)((npairs + 63) / 64)), block(64);

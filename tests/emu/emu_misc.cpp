@@ -145,6 +145,9 @@ int emu_correct_errors_batch(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_
 }
 
 // atr_locate_pairs_batch: one pair after the other, column and staged reference in plain arrays
+// test hook: also exercise the LDS-column variant (the library's fallback when stream-ordered allocation is missing)
+int emu_pairs_use_lds_column = 0;
+
 int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
                            const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
                            double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
@@ -187,6 +190,26 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
             else ATR_EMU_REG(152);
 #undef ATR_EMU_REG
             continue;
+        }
+        {   // as the library: register strips (the LDS-column kernel is only its fallback)
+            int mtop = 0, mlo_s[atr::PAIRS_MAX_STRIPS], mhi_s[atr::PAIRS_MAX_STRIPS];
+            for (int s = 0; s < atr::PAIRS_MAX_STRIPS; ++s) { mlo_s[s] = 0x7fffffff; mhi_s[s] = 0; }
+            for (int64_t t = tile * 64; t < std::min<int64_t>(npairs, tile * 64 + 64); ++t) {
+                const int mt = std::min(ref_lens ? ref_lens[t] : ref_max_len, ref_max_len);
+                mtop = std::max(mtop, mt);
+                for (int s = 0; s < atr::PAIRS_MAX_STRIPS; ++s) {
+                    const int loc = mt - s * atr::PAIRS_STRIP_ROWS;
+                    if (loc >= 1 && loc <= atr::PAIRS_STRIP_ROWS) { mlo_s[s] = std::min(mlo_s[s], loc); mhi_s[s] = std::max(mhi_s[s], loc); }
+                }
+            }
+            uint32_t tabs[16 * (atr::PAIRS_STRIP_ROWS / 32)];
+            std::vector<uint32_t> bnd((size_t)qry_max_len + 1);
+            const bool xs = (flags & ATR_STOP_WITHIN_SEQ2) != 0;
+            if (p.and_mode) { if (xs) atr::locate_pair_strips<true, true>(tabs, 1, bnd.data(), 1, rp, revcomp != 0, m, mlo_s, mhi_s, mtop, qp, n, p, p.thr, out + 4 * r);
+                              else atr::locate_pair_strips<true, false>(tabs, 1, bnd.data(), 1, rp, revcomp != 0, m, mlo_s, mhi_s, mtop, qp, n, p, p.thr, out + 4 * r); }
+            else { if (xs) atr::locate_pair_strips<false, true>(tabs, 1, bnd.data(), 1, rp, revcomp != 0, m, mlo_s, mhi_s, mtop, qp, n, p, p.thr, out + 4 * r);
+                   else atr::locate_pair_strips<false, false>(tabs, 1, bnd.data(), 1, rp, revcomp != 0, m, mlo_s, mhi_s, mtop, qp, n, p, p.thr, out + 4 * r); }
+            if (!emu_pairs_use_lds_column) continue;
         }
         atr::stage_reference(refw.data(), 1, rp, m, revcomp != 0);
         const bool xr = (flags & ATR_STOP_WITHIN_SEQ2) != 0;

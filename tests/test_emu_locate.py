@@ -105,3 +105,17 @@ def test_dpmatrix_debug(emu_backend):
 def test_ragged_tail_mode(emu_backend, oracle):
     from atropos_amd.align import Aligner
     assert _cases.check_ragged_tail_mode(Aligner, oracle, 3, nreads=3000, oracle_slice=400) == 15000
+
+
+def test_pair_aligner_lds_column_fallback(emu_backend, oracle):
+    """The LDS-column pair kernel only runs where stream-ordered allocation is missing; keep its per-lane code
+    (locate_pair_one) under test as well."""
+    import ctypes as C
+    from atropos_amd._lib import AtroposHipError
+    from atropos_amd.align import PairAligner
+    flag = C.c_int.in_dll(emu_backend.lib, "emu_pairs_use_lds_column")
+    flag.value = 1
+    try:
+        assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=79, rounds=25) > 500
+    finally:
+        flag.value = 0
