@@ -308,7 +308,14 @@ class ChunkedFastqReader(object):
         n0 = len(carry)
         if n0:
             view[:n0] = carry
-        want = min(self.chunk_bytes, self.size - self.pos)
+        # a chunk is carry + new bytes ~ chunk_bytes in all: in a paired run the file with the smaller records
+        # carries its surplus records over every time, and reading a full chunk on top of it would let that
+        # surplus grow without bound (1 % of a chunk per step for records 1 % apart)
+        room = self.buf[k].numel() - 32 - n0
+        want = max(self.chunk_bytes - n0, min(self.chunk_bytes // 4, room))
+        if want <= 0:
+            raise ValueError("FASTQ record of more than %d bytes" % self.buf[k].numel())
+        want = min(want, room, self.size - self.pos)
         step = ((want + IO_THREADS - 1) // IO_THREADS + 4095) & ~4095
         jobs = []
         for t in range(IO_THREADS):

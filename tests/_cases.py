@@ -1000,6 +1000,18 @@ def check_paired_file_chunking(tmp_path):
                                                          chunk_bytes=30000)
     assert paths[2].read_bytes() == w1 and paths[3].read_bytes() == w2
     assert sum(counts.values()) == d1.count(b"\n") // 4
+    # records of different sizes in the two files (longer descriptions in file 2): the file with the smaller
+    # records carries surplus records from chunk to chunk; that surplus must stay bounded
+    lines2 = d2.split(b"\n")
+    for i in range(0, len(lines2) - 1, 4):
+        lines2[i] += b" a much longer description than its mate has, to make the records unequal"
+    d2_long = b"\n".join(lines2)
+    want1, want2 = pipeline_from_args(case["args"]).trim_bytes(d1, d2_long)
+    paths[1].write_bytes(d2_long)
+    pipe = pipeline_from_args(case["args"])
+    pipe.trim_files(str(paths[0]), str(paths[1]), str(paths[2]), str(paths[3]), chunk_bytes=12000)
+    assert paths[2].read_bytes() == want1 and paths[3].read_bytes() == want2
+    paths[1].write_bytes(d2)
     # with merging: a third file, written chunk by chunk
     case = [c for c in doc["paired"] if "--merge-min-overlap 20" in c["args"]][0]
     merged_path = tmp_path / "merged.fastq"
