@@ -87,6 +87,9 @@ PROTOTYPES = {
     "atr_insert_aligner_destroy": (None, [C.c_void_p]),
     "atr_insert_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                          C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_insert_match_batch_coded": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_case_sensitive_table": (C.c_int, [C.c_char_p]),
     "atr_aligner_create": (C.c_int, [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.POINTER(C.c_void_p)]),
     "atr_aligner_destroy": (None, [C.c_void_p]),
@@ -333,14 +336,20 @@ class HipBackend(object):
     def insert_aligner_destroy(self, h):
         self.lib.atr_insert_aligner_destroy(h)
 
-    def insert_match_batch(self, h, packed1, lens1, packed2, lens2, npairs, max_len):
+    def insert_match_batch(self, h, packed1, lens1, packed2, lens2, npairs, max_len, cased=False):
+        """cased: both reads are packed with ``case_sensitive_table()`` (soft-masked reads)."""
         out = self.empty((npairs, 3, 8), torch.int16)
         if npairs:
             with torch.cuda.device(self.device):
-                _check(self.lib, self.lib.atr_insert_match_batch(h, _ptr(packed1), _ptr(lens1), _ptr(packed2),
-                                                                 _ptr(lens2), npairs, max_len, _ptr(out),
-                                                                 self._stream()), "atr_insert_match_batch")
+                _check(self.lib, self.lib.atr_insert_match_batch_coded(
+                    h, _ptr(packed1), _ptr(lens1), _ptr(packed2), _ptr(lens2), npairs, max_len, 1 if cased else 0, _ptr(out),
+                    self._stream()), "atr_insert_match_batch_coded")
         return out
+
+    def case_sensitive_table(self):
+        buf = C.create_string_buffer(256)
+        _check(self.lib, self.lib.atr_case_sensitive_table(buf), "atr_case_sensitive_table")
+        return buf.raw
 
     def aligner_create(self, ref, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
         h = C.c_void_p()

@@ -610,17 +610,19 @@ class InsertAligner(object):
         except Exception:
             pass
 
-    def pack(self, reads, check=False, max_len=None):
+    def pack(self, reads, check=False, max_len=None, cased=False):
         """Pack one side of the pairs (DNA15 codes as bit planes, the "plane64" layout of
         atr_pack_planes).  With ``check`` EVERY base must be an upper-case IUPAC letter -- stricter than
         match_insert, which only complements read 2 up to the length of read 1; ``pack_pair`` applies
-        exactly that rule.  ``max_len``: layout width (both sides of a batch need the same one)."""
+        exactly that rule (and handles soft-masked reads).  ``max_len``: layout width (both sides of a
+        batch need the same one).  ``cased``: the case-sensitive table of soft-masked batches
+        (``atr_insert_match_batch_coded``; both sides must use it)."""
         if isinstance(reads, ReadBatch):
-            if reads.table_kind != _lib.TABLE_DNA15 or reads.layout != "plane64":
+            if reads.table_kind not in (_lib.TABLE_DNA15, _lib.TABLE_CUSTOM) or reads.layout != "plane64":
                 raise ValueError("the insert aligner needs reads packed by InsertAligner.pack (DNA15 codes, plane64 layout)")
             return reads
         be = self._backend
-        table = be.translate_table(_lib.TABLE_DNA15)
+        table = be.case_sensitive_table() if cased else be.translate_table(_lib.TABLE_DNA15)
         if isinstance(reads, (list, tuple)):
             mat, lens = _as_ascii_matrix(reads)
             if max_len is not None and max_len > mat.shape[1]:
@@ -639,9 +641,14 @@ class InsertAligner(object):
             if bad:
                 raise ValueError("%d read(s) contain bases without an upper-case IUPAC code; the device insert "
                                  "aligner cannot reverse-complement them" % bad)
-        else:
-            packed = be.pack_reads(ascii_t, lens_t, max_len, table, planes=True)
-        return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_DNA15, table, layout="plane64")
+            batch = ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_DNA15, table, layout="plane64")
+            batch.uncoded_reads = 0
+            return batch
+        packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True, planes=True)
+        batch = ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, _lib.TABLE_CUSTOM if cased else _lib.TABLE_DNA15, table,
+                          layout="plane64")
+        batch.uncoded_reads = bad              # reads with a character the table has no code for (anywhere in the read)
+        return batch
 
     def pack_pair(self, reads1, reads2):
         """Both sides of a batch of pairs, in one layout width, validated the way match_insert does it:
@@ -654,8 +661,15 @@ class InsertAligner(object):
             width = max([len(r) for r in reads1] + [len(r) for r in reads2] + [0])
         prepacked = isinstance(reads2, ReadBatch)
         b1, b2 = self.pack(reads1, max_len=width), self.pack(reads2, max_len=width)
+        if (getattr(b1, "uncoded_reads", 0) or getattr(b2, "uncoded_reads", 0)) and not (
+                prepacked or isinstance(reads1, ReadBatch)):
+            # soft-masked reads (or characters without any code): match_insert tells the cases apart in the insert
+            # compare and folds them in the adapter compares -- both sides again, with the case-sensitive codes
+            b1, b2 = self.pack(reads1, max_len=width, cased=True), self.pack(reads2, max_len=width, cased=True)
         if b1.nreads != b2.nreads:
             raise ValueError("need as many first reads as second reads")
+        if (b1.table_kind == _lib.TABLE_CUSTOM) != (b2.table_kind == _lib.TABLE_CUSTOM):
+            raise ValueError("both sides of a soft-masked batch must be packed with the case-sensitive table")
         if not prepacked and b1.max_len == b2.max_len:
             bad = self._backend.planes_count_uncoded(b2.packed, b2.lens, b1.lens, b2.nreads, b2.max_len)
             if bad:
@@ -671,7 +685,8 @@ class InsertAligner(object):
         if b1.max_len != b2.max_len:
             raise ValueError("both read batches must be packed with the same max_len (got %d and %d)"
                              % (b1.max_len, b2.max_len))
-        rec = self._backend.insert_match_batch(self._handle, b1.packed, b1.lens, b2.packed, b2.lens, b1.nreads, max_len)
+        rec = self._backend.insert_match_batch(self._handle, b1.packed, b1.lens, b2.packed, b2.lens, b1.nreads, max_len,
+                                               cased=b1.table_kind == _lib.TABLE_CUSTOM)
         return InsertResult(rec)
 
     def match_insert(self, seq1, seq2):
@@ -684,24 +699,7 @@ class InsertAligner(object):
         seq1.encode('ascii')
         for base in reversed(seq2[:n]):           # reverse_complement(seq2): KeyError on unknown bases
             BASE_COMPLEMENTS[base]
-        if seq2[:n] != seq2[:n].upper():
-            raise ValueError("lower-case bases in read 2 are not supported by the device insert aligner")
-        if max(len(seq1), len(seq2)) > _lib.INSERT_MAX_READ:
-            raise _lib.AtroposHipError("InsertAligner: reads longer than %d bases are outside the device envelope"
-                                       % _lib.INSERT_MAX_READ)
-        be = self._backend
-        table = be.translate_table(_lib.TABLE_DNA15)
-        width = max(len(seq1), len(seq2), 1)
-        mat = np.zeros((2, width), dtype=np.uint8)
-        mat[0, :len(seq1)] = np.frombuffer(seq1.encode('ascii'), dtype=np.uint8)
-        mat[1, :len(seq2)] = np.frombuffer(seq2.encode('ascii'), dtype=np.uint8)
-        t = torch.from_numpy(mat).to(be.device)
-        l1 = torch.tensor([len(seq1)], dtype=torch.int32, device=be.device)
-        l2 = torch.tensor([len(seq2)], dtype=torch.int32, device=be.device)
-        p1 = be.pack_reads(t[0:1], l1, width, table, planes=True)
-        p2 = be.pack_reads(t[1:2], l2, width, table, planes=True)
-        rec = be.insert_match_batch(self._handle, p1, l1, p2, l2, 1, width)
-        return InsertResult(rec).results()[0]
+        return self.match_insert_batch([seq1], [seq2]).results()[0]
 
 
 _DEFAULT_RMP = None

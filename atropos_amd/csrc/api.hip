@@ -16,7 +16,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                        int max_len, uint4 *out, hipStream_t st);
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
-                  const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st);
+                  const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, int cased, hipStream_t st);
 
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
                    long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
@@ -192,6 +192,12 @@ int atr_translate_table(int kind, uint8_t table[256]) {
     }
 }
 
+int atr_case_sensitive_table(uint8_t table[256]) {
+    if (!table) return ATR_ERR_INVALID;
+    case_sensitive_table(tables().dna15, table);
+    return ATR_OK;
+}
+
 size_t atr_packed_bytes(int64_t nreads, int max_len) { return packed_bytes(nreads, max_len); }
 
 int atr_pack_reads(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, const int32_t *d_starts,
@@ -284,13 +290,23 @@ void atr_insert_aligner_destroy(atr_insert_aligner *a) {
 int atr_insert_match_batch(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
                            const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
                            atr_result *d_out, void *stream) {
+    return atr_insert_match_batch_coded(a, d_packed1, d_lens1, d_packed2, d_lens2, npairs, max_len, ATR_READ_CODES_DNA15,
+                                        d_out, stream);
+}
+
+int atr_insert_match_batch_coded(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
+                                 const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
+                                 int read_codes, atr_result *d_out, void *stream) {
     if (!a || npairs < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (read_codes != ATR_READ_CODES_DNA15 && read_codes != ATR_READ_CODES_CASED) return ATR_ERR_INVALID;
+    if (read_codes == ATR_READ_CODES_CASED && !a->cased_ok) return ATR_ERR_UNSUPPORTED;
     if (max_len > ATR_INSERT_MAX_READ) return ATR_ERR_UNSUPPORTED;
     if (npairs == 0) return ATR_OK;
     if (!d_out || (max_len > 0 && (!d_packed1 || !d_packed2))) return ATR_ERR_INVALID;
     const int nchunks = (max_len + 31) / 32;
     const int rc = launch_insert(a, (const uint4 *)d_packed1, d_lens1, (const uint4 *)d_packed2, d_lens2,
-                                 npairs, nchunks, max_len, (uint4 *)d_out, (hipStream_t)stream);
+                                 npairs, nchunks, max_len, (uint4 *)d_out, read_codes == ATR_READ_CODES_CASED ? 1 : 0,
+                                 (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "insert_kernel launch");
 }
 

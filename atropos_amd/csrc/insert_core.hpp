@@ -110,6 +110,7 @@ struct InsertParams {
     int long_adapters;                              // an adapter has more than 64 bases: the overhangs are compared in two halves
                                                     // (the launcher then picks the kernels built with InsertParamsLong)
     static constexpr bool kLongAdapters = false;
+    static constexpr bool kCasedReads = false;
     int min_insert_overlap, min_adapter_overlap, adapter_check_cutoff;
     int min_hit_j;                                  // smallest j whose PERFECT overlap passes insert_max_rmp (host)
     int rmp_ld;
@@ -120,6 +121,12 @@ struct InsertParams {
 // Same bytes; the type tells the compare code at compile time to look at the second 64 adapter bases too (the
 // extra path costs the common kernels registers they do not have: C3 1.04 -> 1.27 ms when it was a run-time test).
 struct InsertParamsLong : InsertParams { static constexpr bool kLongAdapters = true; };
+// Soft-masked reads: both reads are packed with the CASE-SENSITIVE table (lower-case a/t, c/g, n on the codes 3/12,
+// 5/10, 6 -- closed under the complement, distinct from their upper-case letters, as the insert compare needs:
+// MultiAligner compares characters, _align.pyx:690), and the adapter compares that translate the read
+// (compare_prefixes with a wildcard flag folds the case, _align.pyx:31-86) fold those codes back first.
+struct InsertParamsCased : InsertParams { static constexpr bool kCasedReads = true; };
+struct InsertParamsLongCased : InsertParams { static constexpr bool kLongAdapters = true; static constexpr bool kCasedReads = true; };
 
 ATR_DEV uint32_t low_mask(int nb) {                 // nb low bits set, nb in (-inf, 32]
     return nb >= 32 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << nb) - 1u));
@@ -168,13 +175,27 @@ ATR_DEV void pair_reset(PairState<W> &P) {
     for (int c = 0; c < INS_CAND; ++c) P.cand[c] = 0u;
 }
 
+// Case-sensitive read codes -> the codes of their upper-case letters (3 -> 1, 12 -> 8, 5 -> 2, 10 -> 4, 6 -> 15),
+// 32 bases per word on the four planes.
+ATR_DEV void fold_case_planes(uint32_t &b0, uint32_t &b1, uint32_t &b2, uint32_t &b3) {
+    const uint32_t la = ~b3 & ~b2 & b1 & b0, lt = b3 & b2 & ~b1 & ~b0, lc = ~b3 & b2 & ~b1 & b0;
+    const uint32_t lg = b3 & ~b2 & b1 & ~b0, ln = ~b3 & b2 & b1 & ~b0;
+    const uint32_t o0 = (b0 & ~lc) | ln;
+    const uint32_t o1 = (b1 & ~la & ~lg) | lc | ln;
+    const uint32_t o2 = (b2 & ~lt & ~lc) | lg | ln;
+    const uint32_t o3 = (b3 & ~lg) | ln;
+    b0 = o0; b1 = o1; b2 = o2; b3 = o3;
+}
+
 // Mismatches of 64 bases of read overhang (planes ov[p][0..1]) against the bases 64 * half .. of an adapter
 // (alen = the adapter bases compared in all; the second half only exists for adapters of more than 64 bases).
+template <bool CASED = false>
 ATR_DEV int overhang_mismatches(const uint32_t (&ov)[4][2], const uint32_t (&adp)[4][4], int alen, int mode, int half = 0) {
     int mism = 0;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         uint32_t x0 = ov[0][t], x1 = ov[1][t], x2 = ov[2][t], x3 = ov[3][t];
+        if (CASED && mode != INS_CMP_EQ) fold_case_planes(x0, x1, x2, x3);        // the translate tables fold the case
         const uint32_t ad[4][1] = {{half ? adp[0][2 + t] : adp[0][t]}, {half ? adp[1][2 + t] : adp[1][t]},
                                    {half ? adp[2][2 + t] : adp[2][t]}, {half ? adp[3][2 + t] : adp[3][t]}};
         uint32_t bad;
@@ -220,10 +241,10 @@ ATR_DEV bool evaluate_hit(const PairState<W> &P, const IP &ip, int j, int cost, 
         const int al1 = atr_imin(offset, ip.alen1), al2 = atr_imin(offset, ip.alen2);
         uint32_t ov[4][2];
         planes_from<W, WI>(P.a, j & 31, ov);
-        e1 = overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode);
+        e1 = overhang_mismatches<IP::kCasedReads>(ov, ip.a1, al1, ip.cmp_mode);
         if (IP::kLongAdapters) {                                      // compile time: adapters of more than 64 bases
             planes_from<W, WI + 2>(P.a, j & 31, ov);
-            e1 += overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode, 1);
+            e1 += overhang_mismatches<IP::kCasedReads>(ov, ip.a1, al1, ip.cmp_mode, 1);
         }
         // read 2 in natural order: plane p word w = bitrev(R[3-p][W-1-w])
         uint32_t b2[4][W];
@@ -232,10 +253,10 @@ ATR_DEV bool evaluate_hit(const PairState<W> &P, const IP &ip, int j, int cost, 
 #pragma unroll
             for (int w = 0; w < W; ++w) b2[p][w] = atr_bfrev(P.r[3 - p][W - 1 - w]);
         planes_from<W, WI>(b2, j & 31, ov);
-        e2 = overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode);
+        e2 = overhang_mismatches<IP::kCasedReads>(ov, ip.a2, al2, ip.cmp_mode);
         if (IP::kLongAdapters) {
             planes_from<W, WI + 2>(b2, j & 31, ov);
-            e2 += overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode, 1);
+            e2 += overhang_mismatches<IP::kCasedReads>(ov, ip.a2, al2, ip.cmp_mode, 1);
         }
         if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return false;   // :297-300
         if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                               // :302-306
@@ -309,14 +330,14 @@ ATR_DEV bool evaluate_candidate(const PairState<W> &P, const IP &ip, int j, int 
         const int al1 = atr_imin(offset, ip.alen1), al2 = atr_imin(offset, ip.alen2);
         uint32_t ov[4][2];
         planes_from_memory(g1, cstride, W, j, ov);
-        e1 = overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode);
+        e1 = overhang_mismatches<IP::kCasedReads>(ov, ip.a1, al1, ip.cmp_mode);
         planes_from_memory(g2, cstride, W, j, ov);
-        e2 = overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode);
+        e2 = overhang_mismatches<IP::kCasedReads>(ov, ip.a2, al2, ip.cmp_mode);
         if (IP::kLongAdapters) {                                      // compile time: adapters of more than 64 bases
             planes_from_memory(g1, cstride, W, j + 64, ov);
-            e1 += overhang_mismatches(ov, ip.a1, al1, ip.cmp_mode, 1);
+            e1 += overhang_mismatches<IP::kCasedReads>(ov, ip.a1, al1, ip.cmp_mode, 1);
             planes_from_memory(g2, cstride, W, j + 64, ov);
-            e2 += overhang_mismatches(ov, ip.a2, al2, ip.cmp_mode, 1);
+            e2 += overhang_mismatches<IP::kCasedReads>(ov, ip.a2, al2, ip.cmp_mode, 1);
         }
         if (e1 > (int)ip.mm_by_alen[al1] && e2 > (int)ip.mm_by_alen[al2]) return false;   // :297-300
         if (atr_imin(al1, al2) > ip.adapter_check_cutoff) {                               // :302-306

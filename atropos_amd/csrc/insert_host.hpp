@@ -17,7 +17,15 @@ struct atr_insert_aligner {
     atr::InsertParams p;                 // rmp pointers are filled by the owner (device or host copies)
     std::vector<double> rmp_insert, rmp_adapter;   // host copies, [ld][ld]
     void *d_tables;                      // device allocation holding both tables (HIP build only)
+    int cased_ok;                        // the adapters allow case-sensitive read codes (atr_insert_match_batch_coded)
 };
+
+// the case-sensitive read table (see atr_insert_match_batch_coded): DNA15 without M K R Y S, plus a/t, c/g, n
+inline void case_sensitive_table(const uint8_t dna15[256], uint8_t out[256]) {
+    memcpy(out, dna15, 256);
+    for (const char *ch = "MKRYS"; *ch; ++ch) out[(unsigned char)*ch] = 0;
+    out['a'] = 3; out['t'] = 12; out['c'] = 5; out['g'] = 10; out['n'] = 6;
+}
 
 namespace atr {
 
@@ -32,6 +40,15 @@ inline int insert_fill(atr_insert_aligner *h, const atr_insert_config *c) {
     memset(&p, 0, sizeof(p));
     p.alen1 = c->alen1; p.alen2 = c->alen2;
     p.long_adapters = (c->alen1 > 64 || c->alen2 > 64) ? 1 : 0;
+    // case-sensitive read codes: in the literal compare mode an adapter letter on one of the lower-case codes (M K R Y S)
+    // or a lower-case adapter letter could not be told from a soft-masked read base
+    h->cased_ok = 1;
+    if (!c->adapter_wildcards && !c->read_wildcards)
+        for (int side = 0; side < 2; ++side) {
+            const char *ad = side ? c->adapter2 : c->adapter1;
+            for (int i = 0; i < (side ? c->alen2 : c->alen1); ++i)
+                if (strchr("MKRYS", ad[i]) || (ad[i] >= 'a' && ad[i] <= 'z')) h->cased_ok = 0;
+        }
     // compare_prefixes(read_overhang, adapter, wildcard_ref=adapter_wildcards,
     // wildcard_query=read_wildcards) (align/__init__.py:285-288, _align.pyx:521-530):
     // the READ is the "ref" side: IUPAC table if adapter_wildcards, else ACGT table if

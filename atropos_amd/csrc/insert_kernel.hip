@@ -77,19 +77,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // MiSeq-length reads (nine and ten chunks, up to 320 bases): 80 plane dwords per pair live in registers,
 // two waves per SIMD.  The same register budget serves every read length when an ADAPTER has more than 64
 // bases (LONGAD: the overhangs are compared in two halves, insert_core.hpp InsertParamsLong).
-template <int NCH, bool LONGAD>
+template <int NCH, bool LONGAD, bool CASED = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void insert_kernel_long(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
     const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
     uint4 *__restrict__ out) {
-    if (LONGAD) insert_body<NCH>(static_cast<const InsertParamsLong &>(ip), packed1, lens1, packed2, lens2, npairs, max_len, out);
+    if (LONGAD && CASED) insert_body<NCH>(static_cast<const InsertParamsLongCased &>(ip), packed1, lens1, packed2, lens2, npairs, max_len, out);
+    else if (CASED) insert_body<NCH>(static_cast<const InsertParamsCased &>(ip), packed1, lens1, packed2, lens2, npairs, max_len, out);
+    else if (LONGAD) insert_body<NCH>(static_cast<const InsertParamsLong &>(ip), packed1, lens1, packed2, lens2, npairs, max_len, out);
     else insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
 }
 
 template <int NCH>
 static int launch_nch(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
-                      const int32_t *l2, long long npairs, int max_len, uint4 *out, hipStream_t st) {
+                      const int32_t *l2, long long npairs, int max_len, uint4 *out, int cased, hipStream_t st) {
     const long long ntiles = (npairs + 63) / 64;
+    if (cased) {                                          // soft-masked reads: kernels of their own, as for long adapters
+        if (a->p.long_adapters)
+            hipLaunchKernelGGL((insert_kernel_long<NCH, true, true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p,
+                               p1, l1, p2, l2, npairs, max_len, out);
+        else
+            hipLaunchKernelGGL((insert_kernel_long<NCH, false, true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p,
+                               p1, l1, p2, l2, npairs, max_len, out);
+        return (int)hipGetLastError();
+    }
     if (a->p.long_adapters) {
         hipLaunchKernelGGL((insert_kernel_long<NCH, true>), dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, a->p, p1, l1,
                            p2, l2, npairs, max_len, out);
@@ -108,18 +119,18 @@ static int launch_nch(const atr_insert_aligner *a, const uint4 *p1, const int32_
 }
 
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
-                  const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, hipStream_t st) {
+                  const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, int cased, hipStream_t st) {
     switch (nchunks) {
-        case 0: case 1: return launch_nch<1>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 2: return launch_nch<2>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 3: return launch_nch<3>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 4: return launch_nch<4>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 5: return launch_nch<5>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 6: return launch_nch<6>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 7: return launch_nch<7>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 8: return launch_nch<8>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        case 9: return launch_nch<9>(a, p1, l1, p2, l2, npairs, max_len, out, st);
-        default: return launch_nch<10>(a, p1, l1, p2, l2, npairs, max_len, out, st);
+        case 0: case 1: return launch_nch<1>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 2: return launch_nch<2>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 3: return launch_nch<3>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 4: return launch_nch<4>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 5: return launch_nch<5>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 6: return launch_nch<6>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 7: return launch_nch<7>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 8: return launch_nch<8>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        case 9: return launch_nch<9>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
+        default: return launch_nch<10>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
     }
 }
 

@@ -516,7 +516,9 @@ ATR_DEV void correct_ties(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, in
 // j bases; mism[w] = facing_mismatches(...) of word w.  Same outputs as correct_errors_one.
 // code1(i) / code2(jx): the DNA15 codes of read1[i] / read2[jx] out of the planes (0: a character without
 // a code -- it is then read from the matrix), which spares the two scattered byte loads per position.
-ATR_DEV uint8_t dna15_letter(uint32_t code) { return (uint8_t)"\0ACMGRSVTWYHKDBN"[code & 15u]; }
+// (codes 3, 5, 6, 10, 12 are M R S Y K in the DNA15 table and the lower-case a c n g t of the case-sensitive one:
+// those are left to the matrix)
+ATR_DEV uint8_t dna15_letter(uint32_t code) { return (uint8_t)"\0AC\0G\0\0VTW\0H\0DBN"[code & 15u]; }
 
 // NW: compile-time bound of the word loops (fully unrolled, so that code1 may index registers by w)
 template <int NW, class C1, class C2>

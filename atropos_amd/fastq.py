@@ -224,11 +224,18 @@ class RecordSource(object):
         begin = self.begin + starts.to(self.begin.dtype)
         return RecordSource(self.fq, begin, torch.maximum(self.end, begin))
 
-    def planes(self, max_len, table_kind, table, check=False):
+    def planes(self, max_len, table_kind, table, check=False, count=False):
         """plane64 pack (insert aligner) of the kept intervals with a given max_len; no case
-        folding (InsertAligner compares the reads as they are).  check: every base must have a code."""
+        folding (InsertAligner compares the reads as they are).  check: every base must have a code;
+        count: leave the number of reads with an uncoded character in ``.uncoded_reads``."""
         from .batch import ReadBatch
         be = self.fq.backend
+        if count:
+            packed, lens, bad = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(table),
+                                                count_invalid=True, planes=True)
+            batch = ReadBatch(packed, lens, self.n, max_len, table_kind, table, layout="plane64")
+            batch.uncoded_reads = bad
+            return batch
         if check:
             packed, lens, bad = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(table),
                                                 count_invalid=True, planes=True)

@@ -333,8 +333,14 @@ class PairedTrimPipeline(object):
             raise _lib.AtroposHipError("InsertAligner: reads longer than %d bases are outside the device envelope"
                                        % _lib.INSERT_MAX_READ)
         table = be.translate_table(_lib.TABLE_DNA15)
-        pb1 = src1.planes(max_len, _lib.TABLE_DNA15, table)
-        pb2 = src2.planes(max_len, _lib.TABLE_DNA15, table)
+        pb1 = src1.planes(max_len, _lib.TABLE_DNA15, table, count=True)
+        pb2 = src2.planes(max_len, _lib.TABLE_DNA15, table, count=True)
+        if pb1.uncoded_reads or pb2.uncoded_reads:
+            # soft-masked reads: match_insert tells the cases apart in the insert compare and folds them in the adapter
+            # compares (atr_insert_match_batch_coded) -- both reads again, with the case-sensitive codes
+            table = be.case_sensitive_table()
+            pb1 = src1.planes(max_len, _lib.TABLE_CUSTOM, table)
+            pb2 = src2.planes(max_len, _lib.TABLE_CUSTOM, table)
         # match_insert complements read 2 only as far as read 1 reaches (align/__init__.py:259-267)
         bad = be.planes_count_uncoded(pb2.packed, pb2.lens, pb1.lens, n, max_len)
         if bad:

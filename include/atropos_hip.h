@@ -239,6 +239,20 @@ int atr_insert_match_batch(const atr_insert_aligner *a, const uint8_t *d_packed1
                            const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
                            atr_result *d_out, void *stream);
 
+/* The same for SOFT-MASKED reads.  match_insert compares the two reads character by character (lower case is not
+ * upper case, _align.pyx:690; reverse_complement keeps the case, util/__init__.py:67-88) but folds the case of
+ * the overhangs where compare_prefixes translates them (a wildcard flag set, _align.pyx:521-530).  With
+ * ATR_READ_CODES_CASED both reads are packed with atr_case_sensitive_table(): upper-case A C G T N W B D H V keep
+ * their DNA15 codes, lower-case a/t, c/g, n take the codes 3/12, 5/10, 6 (closed under the device's complement);
+ * M K R Y S have no code in that table.  ATR_ERR_UNSUPPORTED: without wildcard flags an adapter that holds one of
+ * M K R Y S or a lower-case letter cannot be told from a soft-masked read base. */
+#define ATR_READ_CODES_DNA15 0
+#define ATR_READ_CODES_CASED 1
+int atr_case_sensitive_table(uint8_t table[256]);
+int atr_insert_match_batch_coded(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
+                                 const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
+                                 int read_codes, atr_result *d_out, void *stream);
+
 /* ---- MultiAligner.locate, compare_prefixes / compare_suffixes (general) --- */
 
 /* Aligner.enable_debug() / .dpmatrix (_align.pyx:88-119, :259-264, :354-357, :428-431): the DP matrix of

@@ -77,7 +77,7 @@ class EmuBackend(object):
         L.emu_insert_aligner_destroy.argtypes = [C.c_void_p]
         L.emu_insert_aligner_destroy.restype = None
         L.emu_insert_match_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
-                                             C.c_int, C.c_void_p]
+                                             C.c_int, C.c_int, C.c_void_p]
         L.emu_locate_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         self.device = torch.device("cpu")
         from atropos_amd import _lib
@@ -201,12 +201,17 @@ class EmuBackend(object):
     def insert_aligner_destroy(self, h):
         self.lib.emu_insert_aligner_destroy(h)
 
-    def insert_match_batch(self, h, packed1, lens1, packed2, lens2, npairs, max_len):
+    def insert_match_batch(self, h, packed1, lens1, packed2, lens2, npairs, max_len, cased=False):
         out = torch.zeros((npairs, 3, 8), dtype=torch.int16)
         if npairs:
             _check(self.lib.emu_insert_match_batch(h, _ptr(packed1), _ptr(lens1), _ptr(packed2), _ptr(lens2), npairs,
-                                                   max_len, _ptr(out)), "atr_insert_match_batch")
+                                                   max_len, int(cased), _ptr(out)), "atr_insert_match_batch")
         return out
+
+    def case_sensitive_table(self):
+        buf = C.create_string_buffer(256)
+        _check(self.lib.emu_case_sensitive_table(buf), "emu_case_sensitive_table")
+        return buf.raw
 
     def aligner_create(self, ref, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
         h = C.c_void_p()

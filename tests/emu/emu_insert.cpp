@@ -47,8 +47,10 @@ void emu_insert_tiles_ip(const IP &ip, const uint32_t *p1, const int32_t *l1, co
 // as the launcher: adapters of more than 64 bases take the code built with InsertParamsLong
 template <int NCH>
 void emu_insert_tiles(const atr_insert_aligner *a, const uint32_t *p1, const int32_t *l1, const uint32_t *p2,
-                      const int32_t *l2, long long npairs, int max_len, uint32_t *out) {
-    if (a->p.long_adapters) emu_insert_tiles_ip<NCH>(static_cast<const InsertParamsLong &>(a->p), p1, l1, p2, l2, npairs, max_len, out);
+                      const int32_t *l2, long long npairs, int max_len, uint32_t *out, int cased) {
+    if (cased && a->p.long_adapters) emu_insert_tiles_ip<NCH>(static_cast<const InsertParamsLongCased &>(a->p), p1, l1, p2, l2, npairs, max_len, out);
+    else if (cased) emu_insert_tiles_ip<NCH>(static_cast<const InsertParamsCased &>(a->p), p1, l1, p2, l2, npairs, max_len, out);
+    else if (a->p.long_adapters) emu_insert_tiles_ip<NCH>(static_cast<const InsertParamsLong &>(a->p), p1, l1, p2, l2, npairs, max_len, out);
     else emu_insert_tiles_ip<NCH>(a->p, p1, l1, p2, l2, npairs, max_len, out);
 }
 
@@ -70,24 +72,30 @@ int emu_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner *
 
 void emu_insert_aligner_destroy(atr_insert_aligner *a) { delete a; }
 
+int emu_case_sensitive_table(uint8_t table[256]) {
+    case_sensitive_table(tables().dna15, table);
+    return ATR_OK;
+}
+
 int emu_insert_match_batch(const atr_insert_aligner *a, const uint8_t *p1, const int32_t *l1, const uint8_t *p2,
-                           const int32_t *l2, int64_t npairs, int max_len, int16_t *out) {
+                           const int32_t *l2, int64_t npairs, int max_len, int cased, int16_t *out) {
     if (!a || npairs < 0 || max_len < 0) return ATR_ERR_INVALID;
+    if (cased && !a->cased_ok) return ATR_ERR_UNSUPPORTED;
     if (max_len > ATR_INSERT_MAX_READ) return ATR_ERR_UNSUPPORTED;
     if (npairs == 0) return ATR_OK;
     const uint32_t *a1 = (const uint32_t *)p1, *a2 = (const uint32_t *)p2;
     uint32_t *o = (uint32_t *)out;
     switch ((max_len + 31) / 32) {
-        case 0: case 1: emu_insert_tiles<1>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 2: emu_insert_tiles<2>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 3: emu_insert_tiles<3>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 4: emu_insert_tiles<4>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 5: emu_insert_tiles<5>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 6: emu_insert_tiles<6>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 7: emu_insert_tiles<7>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 8: emu_insert_tiles<8>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        case 9: emu_insert_tiles<9>(a, a1, l1, a2, l2, npairs, max_len, o); break;
-        default: emu_insert_tiles<10>(a, a1, l1, a2, l2, npairs, max_len, o); break;
+        case 0: case 1: emu_insert_tiles<1>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 2: emu_insert_tiles<2>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 3: emu_insert_tiles<3>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 4: emu_insert_tiles<4>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 5: emu_insert_tiles<5>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 6: emu_insert_tiles<6>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 7: emu_insert_tiles<7>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 8: emu_insert_tiles<8>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        case 9: emu_insert_tiles<9>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
+        default: emu_insert_tiles<10>(a, a1, l1, a2, l2, npairs, max_len, o, cased); break;
     }
     return ATR_OK;
 }

@@ -255,8 +255,46 @@ def main():
                 checked += 1
                 if it < 30:
                     long_cases.append(dict(a1=B1, a2=B2, r1=r1, r2=r2, kw=cfg, out=out))
+        # soft-masked reads: the insert compare tells the cases apart, the adapter compares fold them when a
+        # wildcard flag is set (compare_prefixes translates), and compare literally when none is
+        def soften(s):
+            kind = rng.random()
+            if kind < 0.3 or not s:
+                return s
+            if kind < 0.4:
+                return s.lower()
+            a = rng.randrange(len(s)); b = rng.randint(a, len(s))
+            return s[:a] + s[a:b].lower() + s[b:]
+        soft_cfgs = [dict(), dict(read_wildcards=True), dict(adapter_wildcards=False),
+                     dict(adapter_wildcards=False, read_wildcards=True), dict(max_insert_mismatch_frac=0.3, min_adapter_overlap=3)]
+        for cfg in soft_cfgs:
+            ref = InsertAligner(A1, A2, **cfg)
+            orc = O.InsertOracle(A1, A2, **cfg)
+            for it in range(150):
+                n = rng.choice([40, 75, 100, 150])
+                f = rng.randint(0, int(1.3 * n))
+                F = rseq(f)
+                r1 = (F + A1 + rseq(n))[:n]
+                r2 = (reverse_complement(F) + A2 + rseq(n))[:rng.choice([n, n, n - 4])]
+                p = rng.choice([0, 0.01, 0.05])
+                r1, r2 = noise(r1, p), noise(r2, p)
+                if rng.random() < 0.5:                     # the same stretch of the insert lower-case in both reads
+                    a = rng.randint(0, max(0, min(f, n) - 1)); b = rng.randint(a, min(f, n))
+                    r1 = r1[:a] + r1[a:b].lower() + r1[b:]
+                    lo, hi = max(0, f - b), max(0, f - a)
+                    r2 = r2[:lo] + r2[lo:hi].lower() + r2[hi:]
+                r1, r2 = soften(r1), soften(r2)
+                res = ref.match_insert(r1, r2)
+                out = None if res is None else [list(res[0]), match_fields(res[1]), match_fields(res[2])]
+                mine = orc.match_insert(r1, r2)
+                mine = None if mine is None else [list(mine[0]), None if mine[1] is None else list(mine[1]),
+                                                  None if mine[2] is None else list(mine[2])]
+                assert mine == out, (cfg, r1, r2, mine, out)
+                checked += 1
+                if it < 40:
+                    long_cases.append(dict(a1=A1, a2=A2, r1=r1, r2=r2, kw=cfg, out=out))
         dump("insert_long.json.gz", long_cases)
-        print("oracle.match_insert == reference on %d pairs (257 .. 320 bp reads; adapters of 66 / 100 bases)" % checked)
+        print("oracle.match_insert == reference on %d pairs (257 .. 320 bp reads; adapters of 66 / 100 bases; soft-masked reads)" % checked)
     if only is not None:
         return
 

@@ -204,6 +204,10 @@ PAIRED_CASES = [
     # soft-masked reads: the merge aligner compares characters, a != A
     ("soft_pe.1.fastq", "soft_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.4 --correct-mismatches liberal" % (PE1, PE2)),
     ("soft_pe.1.fastq", "soft_pe.2.fastq", "-R --merge-min-overlap 15 --merge-error-rate 0.1 -u 1 -U 1"),
+    # ... and the insert aligner on them: characters in the insert compare, case folded in the adapter compares
+    ("soft_pe.1.fastq", "soft_pe.2.fastq", "--aligner insert -a %s -A %s" % (PE1, PE2)),
+    ("soft_pe.1.fastq", "soft_pe.2.fastq", "--aligner insert -a %s -A %s --correct-mismatches liberal -R --merge-min-overlap 0.5" % (PE1, PE2)),
+    ("soft_pe.1.fastq", "soft_pe.2.fastq", "--aligner insert -a %s -A %s -N --correct-mismatches N -m 20" % (PE1, PE2)),
 ]
 
 
