@@ -76,6 +76,15 @@ def make_pairs(rng, n, a1, a2, L):
         if rng.random() < 0.08 and r1:
             k = rng.randrange(len(r1))
             r1 = r1[:k] + "N" + r1[k + 1:]
+        soft = rng.random()
+        if soft < 0.06:                                       # soft-masked: a stretch of one read, or both reads whole
+            a = rng.randrange(len(r1) + 1)
+            r1 = r1[:a] + r1[a:].lower()
+        elif soft < 0.1:
+            r1, r2 = r1.lower(), r2.lower()
+        elif soft < 0.14 and r2:
+            a = rng.randrange(len(r2))
+            r2 = r2[:a] + r2[a:a + 12].lower() + r2[a + 12:]
         for r, out, tag in ((r1, out1, 1), (r2, out2, 2)):
             q = "".join(chr(33 + rng.randint(2, 40)) for _ in r)
             out.append("@p%d/%d\n%s\n+\n%s\n" % (i, tag, r, q))
