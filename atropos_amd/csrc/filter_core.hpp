@@ -224,8 +224,10 @@ ATR_DEV void filter_push_hit(uint32_t &hits, int score) {
 // SIGNED_KEY (linked-adapter pipeline: k differs from lane to lane, so the bias (k + 1) << 10 cannot
 // ride in the wave-uniform tag): the tracker keeps min over the columns of (score << 10) + tag as a
 // SIGNED number and the bias is added once after the sweep (filter_unbias_best).
-template <bool WIDE, bool SIGNED_KEY = false>
-ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
+// filter_step_key: the column update without the tracker; returns the column's key (score << 10) + tag, so that
+// a caller sweeping two columns can fold both keys into the tracker with ONE v_min3_u32.
+template <bool WIDE>
+ATR_DEV uint32_t filter_step_key(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
     const uint32_t xvl = eql | F.mvl;
     const uint32_t tl = eql & F.pvl;
     const uint32_t sl = tl + F.pvl;
@@ -257,6 +259,11 @@ ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_
     uint32_t key;
     asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(key) : "v"(F.score), "s"(tag));
 #endif
+    return key;
+}
+template <bool WIDE, bool SIGNED_KEY = false>
+ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
+    const uint32_t key = filter_step_key<WIDE>(F, u, eql, eqh, tag);
     if (SIGNED_KEY) F.best = (uint32_t)atr_min((int)F.best, (int)key);
     else F.best = atr_minu(F.best, key);
 }
@@ -309,10 +316,13 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &
             if (d <= fp.thr_row[i]) largest = i;
         }
     }
-    {   // its cost: the vertical deltas of rows 1 .. largest
+    if (WIDE) {   // its cost: the vertical deltas of rows 1 .. largest
         const uint64_t rows = (largest >= 64 ? ~0ull : ((1ull << largest) - 1ull)) << off;
         const uint64_t pv = ((uint64_t)F.pvh << 32) | F.pvl, mv = ((uint64_t)F.mvh << 32) | F.mvl;
         cost_of_largest = atr_popc64(pv & rows) - atr_popc64(mv & rows);
+    } else {      // one word: no 64-bit view of (mvl, mvh) -- it made hipcc keep the pair together in the sweep (a v_mov_b64 per column)
+        const uint32_t rows = (largest >= 32 ? ~0u : ((1u << largest) - 1u)) << off;
+        cost_of_largest = atr_popc64((uint64_t)(F.pvl & rows)) - atr_popc64((uint64_t)(F.mvl & rows));
     }
     for (int i = mf + 1; i <= u.m; ++i)
         if (d - (i - mf) <= fp.thr_row[i]) { largest = i; exact = false; }
@@ -420,15 +430,19 @@ ATR_DEV uint32_t read_dword(const uint32_t *q, int nchunks, int z8) {          /
     return q[(size_t)(z8 >> 2) * 256 + (z8 & 3)];
 }
 
-ATR_DEV void band_stage(const uint32_t *q, int nchunks, int dlo, uint32_t *ns, int nss) {
+// The row loop of an m-row adapter looks at the stream dwords 0 .. 2 + m / 8 only (band_stream_dwords(m)
+// of them): the gathers beyond are skipped (wave-uniform), which for a 34-row adapter is five of thirteen
+// loads and, most of the time, one 64-byte line of the read.
+ATR_DEV int band_stream_dwords(int m) { return atr_min(BAND_STREAM, 3 + (m >> 3)); }
+ATR_DEV void band_stage(const uint32_t *q, int nchunks, int dlo, uint32_t *ns, int nss, int ndw = BAND_STREAM) {
     const int z0 = dlo >> 3;                          // dlo + 1 is base (dlo & 7) of dword z0 (0-based base index dlo)
     const uint32_t sh = 4u * (uint32_t)(dlo & 7);
     uint32_t raw[BAND_STREAM + 1];
 #pragma unroll
-    for (int k = 0; k <= BAND_STREAM; ++k) raw[k] = read_dword(q, nchunks, z0 + k);
+    for (int k = 0; k <= BAND_STREAM; ++k) raw[k] = k <= ndw ? read_dword(q, nchunks, z0 + k) : 0u;
 #pragma unroll
     for (int k = 0; k < BAND_STREAM; ++k)
-        ns[(size_t)k * nss] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
+        if (k < ndw) ns[(size_t)k * nss] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
 }
 
 // bit 3 of every nibble = "the nibble is not zero": v | v << 1, then | << 2 (bits that cross into

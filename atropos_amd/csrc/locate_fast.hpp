@@ -129,11 +129,24 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
 #pragma unroll
                         for (int b = 0; b < 8; ++b) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + b + 1));
                         j += 8;
-                    } else {
+                    } else if (RAGGED) {
 #pragma unroll
                         for (int b = 0; b < 8; ++b) {
                             ++j;
-                            if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j));
+                            if (j <= jhi && j <= n) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j));
+                        }
+                    } else {
+                        // two columns per wave-uniform test, their keys folded into the tracker by one v_min3_u32
+#pragma unroll
+                        for (int b = 0; b < 8; b += 2) {
+                            if (j + 2 <= jhi) {
+                                const uint32_t k1 = filter_step_key<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + 1));
+                                const uint32_t k2 = filter_step_key<WIDE>(F, u, e[b + 1].x, e[b + 1].y, filter_column_tag(u, fp.rows, j + 2));
+                                F.best = atr_minu(atr_minu(F.best, k1), k2);
+                            } else if (j + 1 <= jhi) {
+                                filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + 1));
+                            }
+                            j += 2;
                         }
                     }
                     if (j >= jhi) break;                     // wave-uniform
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
         const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
         uint32_t *ns = &s_stream[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][lane];
-        band_stage(q, nchunks, window_lo(ww), ns, 64);
+        band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
         uint32_t rec[4];
         band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
         if (LINKED && live)
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
     const int n = live ? (lens ? lens[r] : max_len) : 0;
     const uint32_t *q = (const uint32_t *)(packed + (size_t)tile * nchunks * 64 + lane);
     uint32_t *ns = &s_stream[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][lane];
-    band_stage(q, nchunks, -u.k, ns, 64);
+    band_stage(q, nchunks, -u.k, ns, 64, band_stream_dwords(u.m));
     uint32_t rec[4];
     band_locate_prefix<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, s_thr, rec);
     if (live) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);

@@ -258,6 +258,15 @@ def check_insert_batches_against_oracle(InsertAligner, oracle, seed, rounds):
             if rng.random() < 0.05:
                 r1 = "A" * len(r1)
                 r2 = "T" * len(r2)          # low complexity: many hits
+            soft = rng.random()              # soft-masked reads: characters compare as they are (_align.pyx:690)
+            if soft < 0.04 and r1:
+                at = rng.randrange(len(r1))
+                r1 = r1[:at] + r1[at:].lower()
+            elif soft < 0.07:
+                r1, r2 = r1.lower(), r2.lower()
+            elif soft < 0.1 and r2:
+                at = rng.randrange(len(r2))
+                r2 = r2[:at] + r2[at:at + 9].lower() + r2[at + 9:]
             r1s.append(r1)
             r2s.append(r2)
         got = ia.match_insert_batch(r1s, r2s).results()

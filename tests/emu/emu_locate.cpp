@@ -124,7 +124,7 @@ void emu_dp_stage(const atr_aligner *a, const uint32_t *packed, const int32_t *l
                 const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
                 const int n = lens ? lens[r] : max_len;
                 uint32_t ns[BAND_STREAM];
-                band_stage(q, nchunks, window_lo(win[r]), ns, 1);
+                band_stage(q, nchunks, window_lo(win[r]), ns, 1, band_stream_dwords(u.m));
                 if (and_mode) band_locate<true>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
                 else band_locate<false>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
                 finish(r);
@@ -481,7 +481,7 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
         for (long long r = 0; r < nreads; ++r) {
             const uint32_t *q = pk + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
             uint32_t ns[BAND_STREAM];
-            band_stage(q, nchunks, -u.k, ns, 1);
+            band_stage(q, nchunks, -u.k, ns, 1, band_stream_dwords(u.m));
             const int n = lens ? lens[r] : max_len;
             if (!eqmode) band_locate_prefix<true>(u, codes, noindel, ns, 1, n, p.thr, (uint32_t *)out + 4 * r);
             else band_locate_prefix<false>(u, codes, noindel, ns, 1, n, p.thr, (uint32_t *)out + 4 * r);
