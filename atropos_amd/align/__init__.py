@@ -71,9 +71,51 @@ class Aligner(object):
             self._table_kind, self._table = _lib.TABLE_DNA15, None
             return
         be = self._backend
+        self._long = len(ref_bytes) > _lib.MAX_REF_LEN
+        if self._long:
+            # A reference of 129 .. 320 bases has no aligner handle (the column kernels hold the rows in
+            # registers): locate_batch runs the per-pair aligner with this reference on every pair
+            # (PairAligner, register strips of 128 rows) -- the same Aligner.locate, batch-of-n.
+            if len(ref_bytes) > _lib.PAIRS_MAX_LEN:
+                raise _lib.AtroposHipError("Aligner: references longer than %d bases are outside the device envelope"
+                                           % _lib.PAIRS_MAX_LEN)
+            self._table_kind, self._table = self._pair_aligner()._table_kinds()[1], None
+            return
         self._handle = be.aligner_create(ref_bytes, self.max_error_rate, self.flags, self.wildcard_ref,
                                          self.wildcard_query, self._min_overlap, self._indel_cost)
         self._table_kind, self._table = be.aligner_query_table(self._handle)
+
+    def _pair_aligner(self):
+        return PairAligner(self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query,
+                           self._min_overlap, self._indel_cost)
+
+    LONG_CHUNK = 1 << 20                              # reads per PairAligner call of a long reference
+
+    def _locate_long(self, reads):
+        """locate_batch for a reference of more than MAX_REF_LEN bases: the reference is laid out once per
+        read of a chunk and the chunk goes through the per-pair aligner."""
+        be = self._backend
+        pa = self._pair_aligner()
+        if isinstance(reads, ReadBatch):
+            raise _lib.AtroposUnsupported("a reference of more than %d bases takes the reads as strings or as an "
+                                          "ASCII matrix, not as a packed batch (the device-resident pipelines "
+                                          "stop at %d-base adapters)" % (_lib.MAX_REF_LEN, _lib.MAX_REF_LEN))
+        ref_row = torch.frombuffer(bytearray(self._ref_bytes), dtype=torch.uint8).to(be.device)
+        if isinstance(reads, (list, tuple)):
+            n = len(reads)
+            chunks = ((reads[i:i + self.LONG_CHUNK]) for i in range(0, n, self.LONG_CHUNK))
+        else:
+            n = reads.shape[0]
+            chunks = ((reads[i:i + self.LONG_CHUNK]) for i in range(0, n, self.LONG_CHUNK))
+        recs = []
+        for chunk in chunks:
+            count = len(chunk) if isinstance(chunk, (list, tuple)) else chunk.shape[0]
+            refs = ref_row[None, :].expand(count, -1).contiguous()
+            recs.append(pa.locate_batch(refs, chunk).records)
+        if not recs:
+            rec = be.empty((0, 8), torch.int16)
+            return LocateResult(rec)
+        return LocateResult(recs[0] if len(recs) == 1 else torch.cat(recs, 0))
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
@@ -169,10 +211,11 @@ class Aligner(object):
         """Batched ``locate``: one result record per read (see LocateResult).  ``filtered``
         lets the library use its filtered pipeline (bit-parallel pre-pass + windowed DP)
         where it applies; the records are identical either way."""
+        if getattr(self, "_long", False):
+            return self._locate_long(reads)
         batch = self.pack(reads)
         be = self._backend
         if self._handle is None:                      # empty reference: nothing ever matches
-            import torch
             rec = be.empty((batch.nreads, 8), torch.int16)
             rec.zero_()
             rec[:, 1] = -1
@@ -185,10 +228,12 @@ class Aligner(object):
         ``suffix``) for a batch packed for this aligner -- what Adapter.match_to runs instead of
         ``locate`` for anchored adapters without indels (reference: adapters/__init__.py:370-380,
         _align.pyx:501-544).  Returns the int16 [n, 8] record tensor on the device."""
+        if getattr(self, "_long", False):
+            raise _lib.AtroposHipError("compare_batch: references longer than %d bases go through "
+                                       "align.compare_batch(ref, queries, ...)" % _lib.MAX_REF_LEN)
         batch = self.pack(reads)
         be = self._backend
         if self._handle is None:                      # empty reference: the empty overlap
-            import torch
             rec = be.empty((batch.nreads, 8), torch.int16)
             rec.zero_()
             if suffix:

@@ -54,7 +54,8 @@ extern "C" {
 #define ATR_SEMIGLOBAL        15
 
 /* envelope of the device kernels */
-#define ATR_MAX_REF_LEN      128   /* adapter / reference length m */
+#define ATR_MAX_REF_LEN      128   /* adapter / reference length m of an aligner handle (longer references, up to
+                                    * ATR_PAIRS_MAX_LEN: atr_locate_pairs_batch with the same reference on every pair) */
 #define ATR_MAX_READ_LEN     736   /* read length n (23 chunks) */
 
 /* which 256-entry translate table the packed reads must have been built with */

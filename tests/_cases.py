@@ -1100,6 +1100,51 @@ def check_dpmatrix_golden(Aligner):
     return done
 
 
+def check_long_reference(Aligner, oracle, AtroposHipError, batch_rounds=6):
+    """Aligner with a reference of 129 .. 320 bases (no aligner handle: every read goes through the per-pair
+    aligner with the same reference): the reference's own results (tests/golden/long_reference.json.gz),
+    then batches of reads against the oracle."""
+    done = 0
+    for c in load_golden("long_reference.json.gz"):
+        al = Aligner(c["ref"], c["e"], c["flags"], c["wr"], c["wq"], c["mo"])
+        al.indel_cost = c["ic"]
+        assert oracle.locate(c["ref"], c["query"], c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"]) == \
+            (None if c["out"] is None else tuple(c["out"])), c
+        if len(c["query"]) > 320 or (max(len(c["ref"]), len(c["query"])) > 255 and not c["flags"] & 8):
+            try:                                            # outside the envelope of the per-pair aligner: a loud refusal
+                al.locate(c["query"])
+                raise AssertionError("expected a refusal: %r" % (c,))
+            except AtroposHipError:
+                continue
+        res = al.locate(c["query"])
+        assert (None if res is None else list(res)) == c["out"], (c, res)
+        done += 1
+    rng = random.Random(4242)
+    for it in range(batch_rounds):
+        m = rng.choice([129, 200, 256, 320])
+        ref = rseq(rng, m)
+        flags = rng.choice([14, 11, 15, 9])
+        e, mo = rng.choice([0.05, 0.1]), rng.choice([1, 5])
+        al = Aligner(ref, e, flags, False, False, mo)
+        al.LONG_CHUNK = 50                                     # several chunks per call
+        reads = []
+        for _ in range(rng.choice([1, 64, 130])):
+            n = rng.randint(0, 300)
+            keep = rng.randint(0, min(m, n))
+            reads.append(rng.choice([(rseq(rng, n) + ref[:keep])[-n:] if n else "", (ref[m - keep:] + rseq(rng, n))[:n],
+                                     rseq(rng, n)]))
+        got = al.locate_batch(reads).tuples()
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, e, flags, False, False, mo, 1), (ref, q, e, flags, mo, g)
+            done += 1
+    try:
+        Aligner("A" * 321, 0.1)
+        raise AssertionError("a 321-base reference should be outside the envelope")
+    except AtroposHipError:
+        pass
+    return done
+
+
 def check_ragged_tail_mode(Aligner, oracle, seed, nreads=20000, oracle_slice=1500):
     """Ragged batches at a size where the row-count bins fill whole waves (the window kernel's tail mode:
     columns counted from the read end): C2-like reads cut to random lengths -- including reads shorter than

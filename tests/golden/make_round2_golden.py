@@ -12,6 +12,7 @@ Fixtures (inputs are generated here; expected values are what the reference retu
     info_records.json.gz   AdapterCutter runs: the MatchInfo rows (Match.get_info_record) of every read
     dpmatrix.json.gz       str(aligner.dpmatrix) after enable_debug() + locate(), with the result tuple
     insert_long.json.gz    InsertAligner.match_insert on MiSeq-length pairs (2 x 257 .. 320 bp)
+    long_reference.json.gz Aligner.locate with references of 129 .. 320 bases (all adapter flag sets)
     c5_head.json.gz        the first pairs of BASELINE config C5 (2 x 250 bp, qualities) through
                            InsertAdapterCutter(mismatch_action='liberal', read wildcards): full outputs of
                            the first pairs, a digest of every pair
@@ -295,6 +296,41 @@ def main():
                     long_cases.append(dict(a1=A1, a2=A2, r1=r1, r2=r2, kw=cfg, out=out))
         dump("insert_long.json.gz", long_cases)
         print("oracle.match_insert == reference on %d pairs (257 .. 320 bp reads; adapters of 66 / 100 bases; soft-masked reads)" % checked)
+    # ------------------------------------------------------------------ Aligner with a reference of 129 .. 320 bases
+    if only in (None, "long_reference"):
+        from atropos.align import Aligner
+        lr_cases = []
+        for it in range(220):
+            m = rng.choice([129, 130, 150, 160, 200, 255, 256, 257, 300, 320]) if it % 3 else rng.randint(129, 320)
+            alpha = "ACGT" if rng.random() < 0.7 else "ACGTN"
+            ref = rseq(m, alpha)
+            flags = rng.choice([14, 11, 15, 8, 2, 9, 15, 14])
+            e = rng.choice([0, 0.02, 0.05, 0.1, 0.2])
+            wr, wq = rng.random() < 0.3, rng.random() < 0.3
+            if m > 255 and not flags & 8:
+                flags |= 8                                   # the device envelope above 255 rows: STOP_WITHIN_SEQ2
+            mo, ic = rng.choice([1, 1, 3, 20]), rng.choice([1, 1, 1, 2])
+            n = rng.choice([0, 30, 100, 150, 250, 300, 320])
+            kind = rng.random()
+            core = ref.replace("N", "A")
+            if kind < 0.35:                                  # the reference's head at the read end (3' adapter)
+                keep = rng.randint(1, min(m, n)) if n else 0
+                query = (rseq(n) + mutate(core[:keep], 0.03))[-n:] if n else ""
+            elif kind < 0.6:                                 # its tail at the read start (5' adapter)
+                keep = rng.randint(1, min(m, n)) if n else 0
+                query = (mutate(core[m - keep:], 0.03) + rseq(n))[:n]
+            elif kind < 0.8:                                 # the read inside the reference
+                at = rng.randint(0, max(0, m - n))
+                query = mutate(core[at:at + n], 0.04)
+            else:
+                query = rseq(n, "ACGTN" if wq else "ACGT")
+            al = Aligner(ref, e, flags, wr, wq, mo)
+            al.indel_cost = ic
+            res = al.locate(query)
+            lr_cases.append(dict(ref=ref, query=query, e=e, flags=flags, wr=wr, wq=wq, mo=mo, ic=ic,
+                                 out=None if res is None else list(res)))
+        dump("long_reference.json.gz", lr_cases)
+        print("long_reference: %d cases, %d with a match" % (len(lr_cases), sum(c["out"] is not None for c in lr_cases)))
     if only is not None:
         return
 

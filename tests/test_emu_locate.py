@@ -119,3 +119,11 @@ def test_pair_aligner_lds_column_fallback(emu_backend, oracle):
         assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=79, rounds=25) > 500
     finally:
         flag.value = 0
+
+
+def test_long_reference(emu_backend):
+    """References of 129 .. 320 bases: Aligner.locate through the per-pair aligner."""
+    from atropos_amd.align import Aligner
+    from atropos_amd._lib import AtroposHipError
+    from oracle import oracle
+    assert _cases.check_long_reference(Aligner, oracle, AtroposHipError) > 400

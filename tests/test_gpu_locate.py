@@ -206,3 +206,11 @@ def test_dpmatrix_debug(hip_backend):
 def test_ragged_tail_mode(hip_backend, oracle):
     from atropos_amd.align import Aligner
     assert _cases.check_ragged_tail_mode(Aligner, oracle, 4, nreads=200_000, oracle_slice=3000) == 1_000_000
+
+
+def test_long_reference(hip_backend):
+    """References of 129 .. 320 bases: Aligner.locate through the per-pair aligner (register strips)."""
+    from atropos_amd.align import Aligner
+    from atropos_amd._lib import AtroposHipError
+    from oracle import oracle
+    assert _cases.check_long_reference(Aligner, oracle, AtroposHipError, batch_rounds=12) > 400
