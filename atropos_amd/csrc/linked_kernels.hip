@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
         const uint32_t ww = wk.win[r];
         if (window_valid(ww)) {
             const int which = (int)(which_out[r] & 0xFFu);
-            wk.order[atomicAdd(&s_cur[linked_bin(ww, which, ms.m[which], by_rows != 0)], 1u)] = (uint32_t)r;
+            wk.order[atomicAdd(&s_cur[linked_bin(ww, which, ms.m[which], by_rows != 0)], 1u)] = make_uint2((uint32_t)r, ww);
         }
     }
 }

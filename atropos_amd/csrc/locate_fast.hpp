@@ -6,9 +6,9 @@
 //                       overlap at the read end) and a window word for the rest; per-block
 //                       histogram of the scatter bins.
 //   K2  scan kernels    exclusive scan of the (bin, block) histogram -> scatter offsets.
-//   K3  scatter_kernel  read indices of the unresolved reads, ordered by bin (filter_core.hpp,
-//                       window_bin), so that the 64 lanes of a K4 wave sweep nearly the same
-//                       cells.
+//   K3  scatter_kernel  (read index, window word) of the unresolved reads, ordered by bin
+//                       (filter_core.hpp, window_bin), so that the 64 lanes of a K4 wave sweep nearly
+//                       the same cells and fetch their task with one coalesced load.
 //   K4a band_kernel     reads whose candidates all sit on <= 16 neighbouring diagonals: row-major
 //                       banded DP (filter_core.hpp, band_locate).
 //   K4  window_kernel   everything else: the packed-word DP (locate_core.hpp, window mode) over
@@ -32,7 +32,8 @@ constexpr int FAST_BLOCKS = 8192;                   // grid of K1 / K3: four rou
 
 struct FastWork {                                    // carve-up of the caller's workspace
     uint32_t *win;                                   // [nreads]
-    uint32_t *order;                                 // [nreads]
+    uint2 *order;                                    // [nreads] (read, its window word): the DP kernels read both with ONE
+                                                     // coalesced load instead of gathering win[read] (a 64-byte line per read)
     uint32_t *counts;                                // [nbins][FAST_BLOCKS] -> in-bin offsets after K2a
     uint32_t *binbase;                               // [nbins + 1] first slot of each bin after K2b; [nbins] = total
     uint32_t *total;                                 // [1] number of unresolved reads
@@ -40,14 +41,14 @@ struct FastWork {                                    // carve-up of the caller's
 };
 
 inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
-    return (size_t)nreads * 8 + (size_t)FAST_BLOCKS * nbins * 4 + (size_t)(nbins + 1) * 4 + 256;
+    return (size_t)nreads * 12 + (size_t)FAST_BLOCKS * nbins * 4 + (size_t)(nbins + 1) * 4 + 256 + 8;
 }
 
 inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS) {
     FastWork w;
     w.win = (uint32_t *)work;
-    w.order = w.win + nreads;
-    w.counts = w.order + nreads;
+    w.order = (uint2 *)(w.win + ((nreads + 1) & ~1ll));              // 8-byte aligned
+    w.counts = (uint32_t *)(w.order + nreads);
     w.binbase = w.counts + (size_t)FAST_BLOCKS * nbins;
     w.total = w.binbase + nbins + 1;
     w.nbins = nbins;
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, i
     block_tiles(ntiles, t0, t1);
     for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
         const uint32_t ww = wk.win[r];
-        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m, by_rows != 0)], 1u)] = (uint32_t)r;
+        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m, by_rows != 0)], 1u)] = make_uint2((uint32_t)r, ww);
     }
 }
 // K4a: the banded DP over the band reads = the slots [0, binbase[BAND_BINS]) of `order`
@@ -241,8 +242,9 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
          wv += (long long)gridDim.x * 4) {
         const long long slot = base + wv * 64 + lane;
         const bool live = slot < total;
-        const long long r = live ? (long long)wk.order[slot] : 0;
-        const uint32_t ww = live ? wk.win[r] : 0u;
+        const uint2 task = live ? wk.order[slot] : make_uint2(0u, 0u);
+        const long long r = (long long)task.x;
+        const uint32_t ww = task.y;
         const int n = live ? (lens ? lens[r] : max_len) : 0;
         const int s_lane = live ? window_hi(ww) - u.m + u.k - window_lo(ww) : 0;
         const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
@@ -309,8 +311,9 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
          wv += (long long)gridDim.x * 4) {
         const long long slot = first + wv * 64 + lane;
         const bool live = slot < total;
-        const long long r = live ? (long long)wk.order[slot] : 0;
-        const uint32_t ww = live ? wk.win[r] : 0u;
+        const uint2 task = live ? wk.order[slot] : make_uint2(0u, 0u);
+        const long long r = (long long)task.x;
+        const uint32_t ww = task.y;
         const int n = live ? (lens ? lens[r] : max_len) : 0;
         const int j_lo = window_lo(ww), j_hi = live ? window_hi(ww) : 0;
         const bool has_window = live && j_hi > j_lo;
