@@ -53,7 +53,7 @@ static const window_group_fn window_groups[4] = {window_group_0, window_group_1,
 
 // K2a + K2b over wk.nbins bins
 void launch_fast_scan(FastWork wk, hipStream_t st) {
-    hipLaunchKernelGGL(scan_bins_kernel, dim3(wk.nbins), dim3(1024), 0, st, wk);
+    hipLaunchKernelGGL(scan_bins_kernel, dim3(SCAN_CHUNKS, wk.nbins / 256), dim3(256), 0, st, wk);
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1024), 0, st, wk);
 }
 

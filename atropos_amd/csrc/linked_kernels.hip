@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
     }
     __syncthreads();
     const int nbins = nad * FILTER_BINS;
-    for (int b = threadIdx.x; b < nbins; b += 256) wk.counts[(size_t)b * FAST_BLOCKS + blockIdx.x] = s_hist[b];
+    for (int b = threadIdx.x; b < nbins; b += 256) wk.counts[(size_t)blockIdx.x * nbins + b] = s_hist[b];
 }
 
 struct LinkedLens { int m[LINKED_MAX]; };
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
                                                              const uint16_t *__restrict__ which_out, FastWork wk) {
     __shared__ uint32_t s_cur[LINKED_MAX * FILTER_BINS];
     for (int b = threadIdx.x; b < wk.nbins; b += 256)
-        s_cur[b] = wk.binbase[b] + wk.counts[(size_t)b * FAST_BLOCKS + blockIdx.x];
+        s_cur[b] = fast_slot0(wk, b);
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;

@@ -31,25 +31,29 @@ constexpr int FAST_BLOCKS = 8192;                   // grid of K1 / K3: four rou
                                                     // block per CU slot balances the chip (K1 0.74 -> 0.65 ms)
 
 struct FastWork {                                    // carve-up of the caller's workspace
-    uint32_t *win;                                   // [nreads]
+    uint32_t *win;                                   // [nreads] window words (single aligner: per tile, the unresolved reads' words first)
+    uint64_t *mask;                                  // [ntiles] single aligner: the tile's unresolved lanes
     uint2 *order;                                    // [nreads] (read, its window word): the DP kernels read both with ONE
                                                      // coalesced load instead of gathering win[read] (a 64-byte line per read)
-    uint32_t *counts;                                // [nbins][FAST_BLOCKS] -> in-bin offsets after K2a
+    uint32_t *counts;                                // [FAST_BLOCKS][nbins] -> in-bin offsets after K2a
+    uint32_t *chunks;                                // [SCAN_CHUNKS][nbins] chunk totals -> chunk offsets inside the bin (K2b)
     uint32_t *binbase;                               // [nbins + 1] first slot of each bin after K2b; [nbins] = total
     uint32_t *total;                                 // [1] number of unresolved reads
     int nbins;                                       // FILTER_BINS, or FILTER_BINS per adapter of a linked set
 };
 
 inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
-    return (size_t)nreads * 12 + (size_t)FAST_BLOCKS * nbins * 4 + (size_t)(nbins + 1) * 4 + 256 + 8;
+    return (size_t)nreads * 12 + (size_t)((nreads + 63) / 64) * 8 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * nbins * 4 + (size_t)(nbins + 1) * 4 + 256 + 16;
 }
 
 inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS) {
     FastWork w;
     w.win = (uint32_t *)work;
     w.order = (uint2 *)(w.win + ((nreads + 1) & ~1ll));              // 8-byte aligned
-    w.counts = (uint32_t *)(w.order + nreads);
-    w.binbase = w.counts + (size_t)FAST_BLOCKS * nbins;
+    w.mask = (uint64_t *)(w.order + nreads);
+    w.counts = (uint32_t *)(((uintptr_t)(w.mask + (nreads + 63) / 64) + 15) & ~(uintptr_t)15);    // K2a reads 16-byte segments
+    w.chunks = w.counts + (size_t)FAST_BLOCKS * nbins;
+    w.binbase = w.chunks + (size_t)(FAST_BLOCKS / 64) * nbins;          // SCAN_CHUNKS rows
     w.total = w.binbase + nbins + 1;
     w.nbins = nbins;
     return w;
@@ -69,6 +73,13 @@ __device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, lon
     const long long per = (ntiles + FAST_BLOCKS - 1) / FAST_BLOCKS;
     t0 = min(ntiles, per * (long long)blockIdx.x);
     t1 = min(ntiles, t0 + per);
+}
+
+constexpr int SCAN_CHUNK = 64, SCAN_CHUNKS = FAST_BLOCKS / SCAN_CHUNK;       // two-level scan of the histogram (K2a / K2b)
+// first slot of (bin, block) in `order`, for the scatter kernels
+__device__ __forceinline__ uint32_t fast_slot0(const FastWork &wk, int bin) {
+    return wk.binbase[bin] + wk.chunks[(size_t)(blockIdx.x / SCAN_CHUNK) * wk.nbins + bin] +
+           wk.counts[(size_t)blockIdx.x * wk.nbins + bin];
 }
 
 #ifdef ATR_DEFINE_FILTER_KERNELS   // K1..K3 are defined once, in filter_kernels.hip
@@ -155,50 +166,63 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                 filter_fold(F, RAGGED ? min(n, min(j, jhi)) : min(j, jhi));   // at most 32 columns since the last fold
             }
         }
+        uint32_t ww_lane = 0u;
         if (live) {
             uint32_t rec[4];
             const uint32_t ww = filter_decide<WIDE>(F, u, fp, (const uint32_t *)tp, nchunks, n, rec);
-            wk.win[r] = ww;
+            ww_lane = ww;
             if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
             else atomicAdd(&s_hist[window_bin(ww, u.m, !RAGGED || ragged_rows_bins(u.sr))], 1u);
         }
+        // Window words of the unresolved reads only, compacted to the front of the tile's 64 slots of `win`, plus the
+        // tile's 64-bit mask of unresolved lanes: one line written (and read back by K3) per tile instead of four.
+        const uint64_t um = __ballot(window_valid(ww_lane));
+        if (lane == 0) wk.mask[tile] = um;
+        if (window_valid(ww_lane)) wk.win[tile * 64 + __popcll(um & ((1ull << lane) - 1ull))] = ww_lane;
     }
     __syncthreads();
-    // counts are stored bin-major ([bin][block]) so that K2 scans contiguous runs
-    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)threadIdx.x * FAST_BLOCKS + blockIdx.x] = s_hist[threadIdx.x];
+    // counts are stored block-major ([block][bin]): one coalesced run per block here and in K3
+    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] = s_hist[threadIdx.x];
 }
 
-// K2a: one block per bin: exclusive scan of that bin's FAST_BLOCKS per-block counts (in
-// place) and the bin's total.  K2b: exclusive scan of the bin totals -> bin bases.
-__global__ __launch_bounds__(1024) void scan_bins_kernel(FastWork wk) {
-    __shared__ uint32_t s_part[1024];
-    constexpr int PER = FAST_BLOCKS / 1024;
-    uint32_t *row = wk.counts + (size_t)blockIdx.x * FAST_BLOCKS;
-    uint32_t v[PER], sum = 0;
+// K2a / K2b: exclusive scan over the FAST_BLOCKS blocks of every bin's per-block count, in two levels.
+// The counts are stored block-major ([block][bin]: K1 writes and K3 reads its row as one coalesced run -- the
+// bin-major layout of round 1 cost a 4-byte store into a line of its own per (bin, block), 60 MB of counted
+// writes per call).  K2a: one thread per bin and chunk of SCAN_CHUNK blocks walks its column (coalesced rows,
+// loads issued sixteen at a time), leaves the offsets inside the chunk in place and the chunk's total in
+// `chunks`.  K2b: one thread per bin scans the SCAN_CHUNKS chunk totals (in place: chunk offsets inside the bin),
+// then the bin totals are scanned across the block -> bin bases.  K3 adds the three levels up.
+__global__ __launch_bounds__(256) void scan_bins_kernel(FastWork wk) {
+    const int bin = blockIdx.y * 256 + threadIdx.x;
+    uint32_t *col = wk.counts + (size_t)blockIdx.x * SCAN_CHUNK * wk.nbins + bin;
+    uint32_t run = 0;
+    for (int b0 = 0; b0 < SCAN_CHUNK; b0 += 16) {
+        uint32_t v[16];
 #pragma unroll
-    for (int t = 0; t < PER; ++t) { v[t] = row[threadIdx.x * PER + t]; sum += v[t]; }
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
-        const uint32_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_part[threadIdx.x] += add;
-        __syncthreads();
+        for (int i = 0; i < 16; ++i) v[i] = col[(size_t)(b0 + i) * wk.nbins];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { col[(size_t)(b0 + i) * wk.nbins] = run; run += v[i]; }
     }
-    uint32_t run = s_part[threadIdx.x] - sum;
-#pragma unroll
-    for (int t = 0; t < PER; ++t) { row[threadIdx.x * PER + t] = run; run += v[t]; }
-    if (threadIdx.x == 1023) wk.binbase[blockIdx.x] = s_part[1023];     // bin total (rebased by K2b)
+    wk.chunks[(size_t)blockIdx.x * wk.nbins + bin] = run;
 }
 
-// K2b: exclusive scan of the (at most 1024) bin totals, one thread per bin
 __global__ __launch_bounds__(1024) void scan_total_kernel(FastWork wk) {
     __shared__ uint32_t s_part[1024];
     const int b = threadIdx.x;
-    const uint32_t mine = b < wk.nbins ? wk.binbase[b] : 0u;
+    uint32_t mine = 0u;
+    if (b < wk.nbins) {
+        uint32_t *col = wk.chunks + b;
+        for (int c0 = 0; c0 < SCAN_CHUNKS; c0 += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = col[(size_t)(c0 + i) * wk.nbins];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { col[(size_t)(c0 + i) * wk.nbins] = mine; mine += v[i]; }
+        }
+    }
     s_part[b] = mine;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan of the bin totals
         const uint32_t add = b >= off ? s_part[b - off] : 0u;
         __syncthreads();
         s_part[b] += add;
@@ -211,14 +235,18 @@ __global__ __launch_bounds__(1024) void scan_total_kernel(FastWork wk) {
 __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, int by_rows, FastWork wk) {
     __shared__ uint32_t s_cur[FILTER_BINS];
     if (threadIdx.x < FILTER_BINS)
-        s_cur[threadIdx.x] = wk.binbase[threadIdx.x] + wk.counts[(size_t)threadIdx.x * FAST_BLOCKS + blockIdx.x];
+        s_cur[threadIdx.x] = fast_slot0(wk, threadIdx.x);
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
     block_tiles(ntiles, t0, t1);
-    for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
-        const uint32_t ww = wk.win[r];
-        if (window_valid(ww)) wk.order[atomicAdd(&s_cur[window_bin(ww, m, by_rows != 0)], 1u)] = make_uint2((uint32_t)r, ww);
+    for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {       // a wave: one tile per round
+        const uint64_t um = wk.mask[r >> 6];
+        const int lane = (int)(r & 63);
+        if ((um >> lane) & 1ull) {
+            const uint32_t ww = wk.win[(r & ~63ll) + __popcll(um & ((1ull << lane) - 1ull))];
+            wk.order[atomicAdd(&s_cur[window_bin(ww, m, by_rows != 0)], 1u)] = make_uint2((uint32_t)r, ww);
+        }
     }
 }
 // K4a: the banded DP over the band reads = the slots [0, binbase[BAND_BINS]) of `order`
