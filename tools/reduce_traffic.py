@@ -5,15 +5,17 @@ profiles/traffic_<config>.json (the `roofline.traffic` figure of bench.py).
     python tools/reduce_traffic.py profiles/round2_c2_rocprofv3_summary.txt C2 10000000
 
 Counter unit: KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section):
-FETCH_SIZE reports half of a wide coalesced stream, so the streaming kernels (the pre-pass
-and the scan / scatter passes) count 2 x FETCH_SIZE; the band / window kernels gather 16-byte
-pieces per lane and count the raw value."""
+FETCH_SIZE reports half of a wide coalesced stream of 16 bytes per lane, so the kernels that stream
+the packed batch that way (the pre-passes, the insert sweep) count 2 x FETCH_SIZE; every other
+kernel counts the raw value -- calibrated as the guide asks on known byte counts: scatter_kernel
+read 40.0 MB of window words + 8.4 MB of histogram with 4-byte loads and FETCH_SIZE said 52.3 MB;
+pack_kernel wrote 800 MB and WRITE_SIZE said 800 MB."""
 import json
 import os
 import re
 import sys
 
-STREAMING = ("filter_kernel", "scan_bins_kernel", "scan_total_kernel", "scatter_kernel", "insert_kernel", "correct_kernel")
+STREAMING = ("filter_kernel", "insert_kernel")        # 16-byte-per-lane coalesced streams of the packed batch
 
 
 def short(name):
@@ -68,8 +70,9 @@ def main():
     out = {"workload": config, "units_per_launch": units, "hbm_bytes_per_launch": total,
            "hbm_bytes_per_unit": total / units,
            "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % src,
-           "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB for the coalesced streaming kernels (gfx950 FETCH_SIZE counts "
-                     "half of a wide coalesced stream), raw FETCH_SIZE + WRITE_SIZE for the gathering band / window kernels",
+           "method": "(2*FETCH_SIZE + WRITE_SIZE) KiB for the kernels that stream the packed batch with 16-byte loads per lane "
+                     "(gfx950 FETCH_SIZE counts half of such a stream), raw FETCH_SIZE + WRITE_SIZE for all others (calibrated: "
+                     "scatter_kernel 48.4 MB of 4-byte loads read as 52.3 MB)",
            "per_kernel": per,
            "valu_wave_insts_per_launch": sum(valu.values()), "valu_wave_insts_per_kernel": valu}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
