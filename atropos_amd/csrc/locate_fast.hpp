@@ -53,7 +53,7 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.mask = (uint64_t *)(w.order + nreads);
     w.counts = (uint32_t *)(((uintptr_t)(w.mask + (nreads + 63) / 64) + 15) & ~(uintptr_t)15);    // K2a reads 16-byte segments
     w.chunks = w.counts + (size_t)FAST_BLOCKS * nbins;
-    w.binbase = w.chunks + (size_t)(FAST_BLOCKS / 64) * nbins;          // SCAN_CHUNKS rows
+    w.binbase = w.chunks + (size_t)(FAST_BLOCKS / 64) * nbins;          // SCAN_CHUNKS rows (SCAN_CHUNK = 64, below)
     w.total = w.binbase + nbins + 1;
     w.nbins = nbins;
     return w;
@@ -76,6 +76,7 @@ __device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, lon
 }
 
 constexpr int SCAN_CHUNK = 64, SCAN_CHUNKS = FAST_BLOCKS / SCAN_CHUNK;       // two-level scan of the histogram (K2a / K2b)
+static_assert(FAST_BLOCKS % SCAN_CHUNK == 0 && SCAN_CHUNKS % 16 == 0 && SCAN_CHUNK % 16 == 0, "scan kernels walk 16 rows at a time");
 // first slot of (bin, block) in `order`, for the scatter kernels
 __device__ __forceinline__ uint32_t fast_slot0(const FastWork &wk, int bin) {
     return wk.binbase[bin] + wk.chunks[(size_t)(blockIdx.x / SCAN_CHUNK) * wk.nbins + bin] +
