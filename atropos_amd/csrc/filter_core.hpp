@@ -292,9 +292,16 @@ ATR_DEV void filter_fold(FilterState &F, int j) {
 // when that row lies beyond the swept rows and was only kept by its lower bound (NARROW mode).
 // P: FilterParams (wave-uniform kernel argument) or LaneFilterParams (linked_core.hpp: per lane,
 // thresholds behind a pointer into LDS).
+// NARROW mode, rows beyond the swept ones (i > mf): a candidate (i, n) of cost c <= thr_row[i] <= k leaves row mf
+// for the last time in a cell (mf, j') of cost <= c -- a hit of the mf-row matrix -- with n - j' <= (i - mf) + k.
+//   tail_rule 1: no hit in the columns n - T - k .. n  ->  no such row qualifies;
+//   tail_rule 2: the only hit is column n itself  ->  the path ends with i - mf insertions below (mf, n), so
+//                D'[mf][n] + (i - mf) <= thr_row[i] is necessary;
+//   tail_rule 0: anything else -- the lower bound D'[mf][n] - (i - mf) (a vertical delta is >= -1).
+// d_mf: D'[mf][n], for the caller's row-m test under rule 2.
 template <bool WIDE, class P>
 ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &fp, int &cost_of_largest,
-                               bool &exact) {
+                               bool &exact, int tail_rule, int &d_mf) {
     const int mf = fp.rows;
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
     exact = true;
@@ -324,8 +331,10 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &
         const uint32_t rows = (largest >= 32 ? ~0u : ((1u << largest) - 1u)) << off;
         cost_of_largest = atr_popc64((uint64_t)(F.pvl & rows)) - atr_popc64((uint64_t)(F.mvl & rows));
     }
-    for (int i = mf + 1; i <= u.m; ++i)
-        if (d - (i - mf) <= fp.thr_row[i]) { largest = i; exact = false; }
+    d_mf = d;
+    if (tail_rule != 1)
+        for (int i = mf + 1; i <= u.m; ++i)
+            if ((tail_rule == 2 ? d + (i - mf) : d - (i - mf)) <= fp.thr_row[i]) { largest = i; exact = false; }
     return largest;
 }
 
@@ -364,11 +373,14 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
             return 0;
         }
     }
-    int cost_l = 0;
+    int cost_l = 0, d_mf = 0;
     bool exact_l = true;
-    const int row_l = filter_last_column<WIDE>(F, u, fp, cost_l, exact_l);
+    // NARROW mode: which hits of the mf-row matrix can a path to a longer row (or to row m) still use?
+    const int tail_rule = T == 0 ? 0 : (F.j_first == 0 || F.j_last < n - T - u.k) ? 1 : F.j_first == n ? 2 : 0;
+    const int row_l = filter_last_column<WIDE>(F, u, fp, cost_l, exact_l, tail_rule, d_mf);
     const bool lastcol = row_l != 0;
-    const bool rowm = F.j_first != 0 && u.m >= u.min_overlap;
+    // rule 2: a row-m candidate would have to come down from (mf, n) by T insertions
+    const bool rowm = F.j_first != 0 && u.m >= u.min_overlap && !(tail_rule == 2 && d_mf + T > u.k);
     if (!lastcol && !rowm) return 0;
     if (!rowm && !u.sr && exact_l && cost_l == 0) {
         // The only acceptable cells sit in the last column, and the longest of them is a
