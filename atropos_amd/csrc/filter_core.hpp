@@ -124,9 +124,13 @@ ATR_DEV int triangle_rows(int rows, int n, int j, int k) { return rows - (n - j)
 ATR_DEV bool ragged_rows_bins(bool start_within_seq1) { return !start_within_seq1; }
 constexpr int TAIL_COLUMNS = 64;                   // columns before the read end a tail-mode wave can sweep
 
+// Band reads (band_kernel): [0, 32) by window start / 32 -- a band read stages its own 16 diagonals, so its wave
+// mates only matter for locality -- and [32, 96) the LAST-COLUMN band reads (band_locate_last) by row count,
+// which makes their waves uniform in the number of rows swept.
+constexpr int LAST_BIN0 = 32;
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
-    if (window_band(w)) return start;
+    if (window_band(w)) return window_scan(w) ? LAST_BIN0 + atr_min(rows, 63) : (start >> 2);
     if (rows >= m || !by_rows) return 96 + start;
     return ROWS_BIN0 + atr_min(rows, 63);
 }
@@ -392,6 +396,17 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
         rec[2] = (uint32_t)row_l;
         return 0;
     }
+    if (!rowm && !u.sr && exact_l && u.indel == 1) {
+        // LAST-COLUMN BAND.  Only last-column cells can be accepted, (row_l, n) is one of them (its cost is exact)
+        // and holds at least row_l - cost_l matches, so no row below row_l - cost_l can win (a row holds at most
+        // as many matches as it has bases, and the reference keeps the cell with MORE matches, :468).  The rows
+        // row_l - cost_l .. row_l cost at most k each, so their tracebacks stay on the diagonals
+        // n - row_l - k .. n - row_l + cost_l + k: a banded row-major DP over cost_l + 2k + 1 diagonals and
+        // row_l rows (band_locate_last) instead of the column sweep over the window.  Word: j_lo = first
+        // diagonal, j_hi field = cost_l, rows = row_l, band + scan bits.
+        const int dlo = n - row_l - u.k;
+        if (dlo >= s && cost_l + 2 * u.k <= BAND_W - 1) return window_word(dlo, cost_l, true, row_l, true);
+    }
     // Window start: a cell (i, j) of cost c is reached from row 0 at a column >= j - i - (number
     // of deletions on its path), and that number is at most c (unit indel cost: c is the
     // exact D) or k.  Row-m candidates: the first one bounds them all (j - D[m][j] never
@@ -542,6 +557,87 @@ ATR_DEV void band_locate(const Uniform &u, const uint32_t *rreps, bool noindel, 
         const int j = dlo + u.m + c;
         if (c <= smax && band[c] < u.klimit && j <= n) consider<true>(best, band[c], u.m, j, u.min_overlap, thr, cindel);
     }
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != u.m + n) {
+        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
+
+// ---- last-column band reads (filter_decide, LAST-COLUMN BAND) --------------------------------------
+// The same row-major sweep over ND diagonals from diagonal dlo = n - row_l - k on, rows 1 .. rows_max (the
+// wave's largest row_l); cell (i, n) sits on band index row_l + k - i when row i is done, and the rows
+// row_l - cost_l .. row_l go through the candidate test in the reference's order (ascending rows, :464-474).
+// Columns beyond n hold garbage (bases read as code 0) that never feeds a column <= n.
+// cap_lo: the wave's smallest row_l - cost_l (no lane looks at an earlier row).
+template <bool AND_MODE, int ND>
+ATR_DEV void band_rows_last(const Uniform &u, const uint32_t *rreps, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W],
+                            int rows_max, int cap_lo, bool active, int row_l, int cost_l, int n, const int16_t *thr,
+                            int cindel, Best &best) {
+    const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
+    uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
+    uint32_t feed = ns[(size_t)2 * nss];
+    for (int i = 1; i <= rows_max; ++i) {
+        const uint32_t rrep = rreps[i - 1];
+        uint32_t m0 = nibble_any(AND_MODE ? (qw0 & rrep) : (qw0 ^ rrep));
+        uint32_t m1 = ND > 8 ? nibble_any(AND_MODE ? (qw1 & rrep) : (qw1 ^ rrep)) : 0u;
+        if (AND_MODE) { m0 = ~m0; m1 = ~m1; }
+        uint32_t left = inf;
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+            const uint32_t bit = atr_bfe1(c < 8 ? m0 : m1, 4 * (c & 7) + 3);
+            const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, band[c]);
+            const uint32_t up = c + 1 < ND ? band[c + 1 < ND ? c + 1 : 0] : inf;
+            const uint32_t nw = atr_minu(atr_minu(cd, left + u.delw), up + u.insw) & ~PRIO_MASK;
+            band[c] = nw;
+            left = nw;
+        }
+        if (i >= cap_lo) {                            // wave-uniform: some lane's rows of interest have begun
+            const int at = row_l + u.k - i;           // this lane's band index of cell (i, n)
+            if (active && i <= row_l && i >= row_l - cost_l && (u.er || i == u.m)) {
+                uint32_t cell = band[0];
+#pragma unroll
+                for (int c = 1; c < ND; ++c) cell = at == c ? band[c] : cell;
+                if (cell < u.klimit) consider<true>(best, cell, i, n, u.min_overlap, thr, cindel);
+            }
+        }
+        qw0 = (qw0 >> 4) | (qw1 << 28);
+        qw1 = (qw1 >> 4) | (feed << 28);
+        feed >>= 4;
+        if ((i & 7) == 0) {
+            const int k = 2 + (i >> 3);
+            feed = k < BAND_STREAM ? ns[(size_t)k * nss] : 0u;
+        }
+    }
+}
+
+// active: this lane holds a last-column band read (other lanes of the wave run along and are ignored).
+template <bool AND_MODE>
+ATR_DEV void band_locate_last(const Uniform &u, const uint32_t *rreps, bool noindel, const uint32_t *ns, int nss, int n,
+                              uint32_t ww, bool active, int smax, int rows_max, int cap_lo, const int16_t *thr,
+                              uint32_t rec[4]) {
+    const int dlo = window_lo(ww), row_l = window_rows(ww), cost_l = window_hi(ww);
+    uint32_t band[BAND_W];
+#pragma unroll
+    for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
+    Best best;
+    best.key = COST_FIELD_MAX - (u.m + n);
+    best.word = (uint32_t)(u.m + n) << CSH;
+    best.ref_stop = u.m; best.query_stop = n; best.matches = 0;
+    const int cindel = noindel ? 0 : u.indel;
+    if (smax < 8) band_rows_last<AND_MODE, 8>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
+    else if (smax < 10) band_rows_last<AND_MODE, 10>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
+    else if (smax < 12) band_rows_last<AND_MODE, 12>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
+    else if (smax < 14) band_rows_last<AND_MODE, 14>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
+    else band_rows_last<AND_MODE, 16>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
     const int cost = (int)(best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
     if (cost != u.m + n) {

@@ -113,19 +113,29 @@ void emu_dp_stage(const atr_aligner *a, const uint32_t *packed, const int32_t *l
         for (int i = 0; i < u.m && i < FILTER_MAX_M; ++i) codes[i] = (uint32_t)(a->codes[i] & 15u) * 0x11111111u;
         const bool and_mode = a->wildcard_ref || a->wildcard_query, noindel = a->indel_cost > p.k;
         for (long long base = 0; base < nband; base += 64) {
-            int smax = 0;
+            int smax = 0, smax_l = 0, rows_max = 0, cap_lo = 0x7fffffff;        // the wave-level values of band_kernel
             for (int lane = 0; lane < 64 && base + lane < nband; ++lane) {
                 const uint32_t ww = win[order[base + lane]];
-                smax = std::max(smax, window_hi(ww) - u.m + u.k - window_lo(ww));
+                if (window_scan(ww)) {
+                    smax_l = std::max(smax_l, window_hi(ww) + 2 * u.k);
+                    rows_max = std::max(rows_max, window_rows(ww));
+                    cap_lo = std::min(cap_lo, window_rows(ww) - window_hi(ww));
+                } else {
+                    smax = std::max(smax, window_hi(ww) - u.m + u.k - window_lo(ww));
+                }
             }
             smax = std::min(smax, BAND_W - 1);
+            smax_l = std::min(smax_l, BAND_W - 1);
             for (int lane = 0; lane < 64 && base + lane < nband; ++lane) {
                 const long long r = order[base + lane];
                 const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
                 const int n = lens ? lens[r] : max_len;
                 uint32_t ns[BAND_STREAM];
                 band_stage(q, nchunks, window_lo(win[r]), ns, 1, band_stream_dwords(u.m));
-                if (and_mode) band_locate<true>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
+                if (window_scan(win[r])) {
+                    if (and_mode) band_locate_last<true>(u, codes, noindel, ns, 1, n, win[r], true, smax_l, rows_max, cap_lo, s_thr, out + 4 * r);
+                    else band_locate_last<false>(u, codes, noindel, ns, 1, n, win[r], true, smax_l, rows_max, cap_lo, s_thr, out + 4 * r);
+                } else if (and_mode) band_locate<true>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
                 else band_locate<false>(u, codes, noindel, ns, 1, n, win[r], smax, s_thr, out + 4 * r);
                 finish(r);
             }
