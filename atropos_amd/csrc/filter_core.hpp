@@ -99,6 +99,15 @@ ATR_DEV int window_lo(uint32_t w) { return (int)(w & 0x3FFu); }
 ATR_DEV int window_hi(uint32_t w) { return (int)((w >> 10) & 0x3FFu); }
 ATR_DEV bool window_scan(uint32_t w) { return ((w >> 20) & 1u) != 0; }
 ATR_DEV bool window_valid(uint32_t w) { return (w >> 31) != 0; }
+// Last-column band reads (band + scan bits; filter_decide): [9:0] first diagonal, rows field = the highest row
+// looked at in the last column, the j_hi field holds (highest - lowest such row) in its low six bits and the
+// number of diagonals - 1 above them, bit 29: row-m candidates inside the band as well.
+ATR_DEV uint32_t last_band_word(int dlo, int top, int span, int width, bool rowm) {
+    return window_word(dlo, span | (width << 6), true, top, true) | (rowm ? (1u << 29) : 0u);
+}
+ATR_DEV int last_band_span(uint32_t w) { return window_hi(w) & 63; }
+ATR_DEV int last_band_width(uint32_t w) { return window_hi(w) >> 6; }
+ATR_DEV bool last_band_rowm(uint32_t w) { return ((w >> 29) & 1u) != 0; }
 // Scatter bin, chosen so that the 64 reads of a wave sweep nearly the same cells.
 //   [0, 96)    band reads (band_locate below), by window start / 8;
 //   [96, 192)  reads that need every row of the column sweep, by window start / 8 -- and, in
@@ -305,7 +314,7 @@ ATR_DEV void filter_fold(FilterState &F, int j) {
 // d_mf: D'[mf][n], for the caller's row-m test under rule 2.
 template <bool WIDE, class P>
 ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &fp, int &cost_of_largest,
-                               bool &exact, int tail_rule, int &d_mf) {
+                               bool &exact, int tail_rule, int &d_mf, int &row_exact) {
     const int mf = fp.rows;
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
     exact = true;
@@ -336,6 +345,7 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &
         cost_of_largest = atr_popc64((uint64_t)(F.pvl & rows)) - atr_popc64((uint64_t)(F.mvl & rows));
     }
     d_mf = d;
+    row_exact = largest;                            // the largest qualifying row among the swept ones; cost_of_largest is its cost
     if (tail_rule != 1)
         for (int i = mf + 1; i <= u.m; ++i)
             if ((tail_rule == 2 ? d + (i - mf) : d - (i - mf)) <= fp.thr_row[i]) { largest = i; exact = false; }
@@ -377,11 +387,11 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
             return 0;
         }
     }
-    int cost_l = 0, d_mf = 0;
+    int cost_l = 0, d_mf = 0, row_e = 0;
     bool exact_l = true;
     // NARROW mode: which hits of the mf-row matrix can a path to a longer row (or to row m) still use?
     const int tail_rule = T == 0 ? 0 : (F.j_first == 0 || F.j_last < n - T - u.k) ? 1 : F.j_first == n ? 2 : 0;
-    const int row_l = filter_last_column<WIDE>(F, u, fp, cost_l, exact_l, tail_rule, d_mf);
+    const int row_l = filter_last_column<WIDE>(F, u, fp, cost_l, exact_l, tail_rule, d_mf, row_e);
     const bool lastcol = row_l != 0;
     // rule 2: a row-m candidate would have to come down from (mf, n) by T insertions
     const bool rowm = F.j_first != 0 && u.m >= u.min_overlap && !(tail_rule == 2 && d_mf + T > u.k);
@@ -405,7 +415,16 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
         // row_l rows (band_locate_last) instead of the column sweep over the window.  Word: j_lo = first
         // diagonal, j_hi field = cost_l, rows = row_l, band + scan bits.
         const int dlo = n - row_l - u.k;
-        if (dlo >= s && cost_l + 2 * u.k <= BAND_W - 1) return window_word(dlo, cost_l, true, row_l, true);
+        if (dlo >= s && cost_l + 2 * u.k <= BAND_W - 1) return last_band_word(dlo, row_l, atr_min(cost_l, row_l - 1), cost_l + 2 * u.k, false);
+    }
+    if (rowm && lastcol && !u.sr && u.indel == 1 && row_e != 0) {
+        // The same with row-m candidates besides (an adapter that ends at or near the read end).  (row_e, n), the
+        // largest last-column candidate among the swept rows, is exact and holds >= row_e - cost matches, so the
+        // last-column rows that can win are r0 = row_e - cost .. top (top = m when a longer row was only kept by a
+        // bound); the row-m candidates keep to the diagonals j_first - mf - k .. j_last - mf + k as for a band read.
+        const int top = exact_l ? row_l : u.m, r0 = atr_max(1, row_e - cost_l);
+        const int dlo = atr_min(F.j_first - mf - u.k, n - top - u.k), dhi = atr_max(F.j_last - mf + u.k, n - r0 + u.k);
+        if (dlo >= s && dhi - dlo <= BAND_W - 1) return last_band_word(dlo, top, top - r0, dhi - dlo, true);
     }
     // Window start: a cell (i, j) of cost c is reached from row 0 at a column >= j - i - (number
     // of deletions on its path), and that number is at most c (unit indel cost: c is the
@@ -580,7 +599,7 @@ ATR_DEV void band_locate(const Uniform &u, const uint32_t *rreps, bool noindel, 
 // cap_lo: the wave's smallest row_l - cost_l (no lane looks at an earlier row).
 template <bool AND_MODE, int ND>
 ATR_DEV void band_rows_last(const Uniform &u, const uint32_t *rreps, const uint32_t *ns, int nss, uint32_t (&band)[BAND_W],
-                            int rows_max, int cap_lo, bool active, int row_l, int cost_l, int n, const int16_t *thr,
+                            int rows_max, int cap_lo, bool active, int top, int r0, int at0, int n, const int16_t *thr,
                             int cindel, Best &best) {
     const uint32_t inf = ((uint32_t)INIT_COST_CAP << CSH) | ORG_BIAS;
     uint32_t qw0 = ns[0], qw1 = ns[(size_t)nss];
@@ -601,8 +620,8 @@ ATR_DEV void band_rows_last(const Uniform &u, const uint32_t *rreps, const uint3
             left = nw;
         }
         if (i >= cap_lo) {                            // wave-uniform: some lane's rows of interest have begun
-            const int at = row_l + u.k - i;           // this lane's band index of cell (i, n)
-            if (active && i <= row_l && i >= row_l - cost_l && (u.er || i == u.m)) {
+            const int at = at0 - i;                   // this lane's band index of cell (i, n): n - dlo - i
+            if (active && i <= top && i >= r0 && (u.er || i == u.m)) {
                 uint32_t cell = band[0];
 #pragma unroll
                 for (int c = 1; c < ND; ++c) cell = at == c ? band[c] : cell;
@@ -620,24 +639,37 @@ ATR_DEV void band_rows_last(const Uniform &u, const uint32_t *rreps, const uint3
 }
 
 // active: this lane holds a last-column band read (other lanes of the wave run along and are ignored).
+// rows_max: the wave's highest row to sweep (m as soon as a lane has row-m candidates too).
 template <bool AND_MODE>
 ATR_DEV void band_locate_last(const Uniform &u, const uint32_t *rreps, bool noindel, const uint32_t *ns, int nss, int n,
                               uint32_t ww, bool active, int smax, int rows_max, int cap_lo, const int16_t *thr,
                               uint32_t rec[4]) {
-    const int dlo = window_lo(ww), row_l = window_rows(ww), cost_l = window_hi(ww);
+    const int dlo = window_lo(ww), top = window_rows(ww), r0 = top - last_band_span(ww), at0 = n - dlo;
     uint32_t band[BAND_W];
 #pragma unroll
     for (int c = 0; c < BAND_W; ++c) band[c] = ORG_BIAS + (uint32_t)(dlo + c);     // row 0: cost 0, origin j (:385-388)
-    Best best;
+    Best best, bm;                                   // last-column candidates / row-m candidates
     best.key = COST_FIELD_MAX - (u.m + n);
     best.word = (uint32_t)(u.m + n) << CSH;
     best.ref_stop = u.m; best.query_stop = n; best.matches = 0;
+    bm = best;
     const int cindel = noindel ? 0 : u.indel;
-    if (smax < 8) band_rows_last<AND_MODE, 8>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
-    else if (smax < 10) band_rows_last<AND_MODE, 10>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
-    else if (smax < 12) band_rows_last<AND_MODE, 12>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
-    else if (smax < 14) band_rows_last<AND_MODE, 14>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
-    else band_rows_last<AND_MODE, 16>(u, rreps, ns, nss, band, rows_max, cap_lo, active, row_l, cost_l, n, thr, cindel, best);
+    if (smax < 8) band_rows_last<AND_MODE, 8>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    else if (smax < 10) band_rows_last<AND_MODE, 10>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    else if (smax < 12) band_rows_last<AND_MODE, 12>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    else if (smax < 14) band_rows_last<AND_MODE, 14>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    else band_rows_last<AND_MODE, 16>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    if (last_band_rowm(ww) && rows_max == u.m) {
+        // the row-m cells of the band, in column order (:433-455) -- the reference sees them BEFORE the last
+        // column, so on equal (matches, cost) they keep the place
+        const int width = last_band_width(ww);
+#pragma unroll
+        for (int c = 0; c < BAND_W; ++c) {
+            const int j = dlo + u.m + c;
+            if (c <= width && band[c] < u.klimit && j <= n) consider<true>(bm, band[c], u.m, j, u.min_overlap, thr, cindel);
+        }
+        if (bm.key >= best.key) best = bm;
+    }
     const int cost = (int)(best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
     if (cost != u.m + n) {

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         const uint32_t ww = task.y;
         const int n = live ? (lens ? lens[r] : max_len) : 0;
         // two kinds of band reads (filter_core.hpp): row-m candidates on <= 16 diagonals, and last-column candidates
-        // (scan bit); their bins are disjoint, so only a wave that straddles the boundary runs both sweeps
+        // (scan bit; possibly with row-m candidates besides); their bins are disjoint, so only a wave that straddles
+        // the boundary runs both sweeps
         const bool last = live && window_scan(ww);
         const bool any_last = wave_max_i32(last ? 1 : 0) != 0, any_rowm = wave_max_i32(live && !last ? 1 : 0) != 0;
         const int s_lane = (live && !last) ? window_hi(ww) - u.m + u.k - window_lo(ww) : 0;
@@ -287,9 +288,9 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         uint32_t rec[4] = {0xFFFF0000u, 0u, 0u, 0u};
         if (any_rowm) band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
         if (any_last) {
-            const int smax_l = min(BAND_W - 1, wave_max_i32(last ? window_hi(ww) + 2 * u.k : 0));
-            const int rows_max = wave_max_i32(last ? window_rows(ww) : 0);
-            const int cap_lo = wave_min_i32(last ? window_rows(ww) - window_hi(ww) : 0x7fffffff);
+            const int smax_l = min(BAND_W - 1, wave_max_i32(last ? last_band_width(ww) : 0));
+            const int rows_max = wave_max_i32(last ? (last_band_rowm(ww) ? u.m : window_rows(ww)) : 0);
+            const int cap_lo = wave_min_i32(last ? window_rows(ww) - last_band_span(ww) : 0x7fffffff);
             uint32_t rec_l[4];
             band_locate_last<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, last, smax_l, rows_max, cap_lo, s_thr, rec_l);
             if (last) { rec[0] = rec_l[0]; rec[1] = rec_l[1]; rec[2] = rec_l[2]; rec[3] = rec_l[3]; }

@@ -117,9 +117,9 @@ void emu_dp_stage(const atr_aligner *a, const uint32_t *packed, const int32_t *l
             for (int lane = 0; lane < 64 && base + lane < nband; ++lane) {
                 const uint32_t ww = win[order[base + lane]];
                 if (window_scan(ww)) {
-                    smax_l = std::max(smax_l, window_hi(ww) + 2 * u.k);
-                    rows_max = std::max(rows_max, window_rows(ww));
-                    cap_lo = std::min(cap_lo, window_rows(ww) - window_hi(ww));
+                    smax_l = std::max(smax_l, last_band_width(ww));
+                    rows_max = std::max(rows_max, last_band_rowm(ww) ? u.m : window_rows(ww));
+                    cap_lo = std::min(cap_lo, window_rows(ww) - last_band_span(ww));
                 } else {
                     smax = std::max(smax, window_hi(ww) - u.m + u.k - window_lo(ww));
                 }
