@@ -139,7 +139,8 @@ constexpr int TAIL_COLUMNS = 64;                   // columns before the read en
 constexpr int LAST_BIN0 = 32;
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
-    if (window_band(w)) return window_scan(w) ? LAST_BIN0 + atr_min(rows, 63) : (start >> 2);
+    // (most rows first: the persistent grid of band_kernel then ends on its cheapest tasks)
+    if (window_band(w)) return window_scan(w) ? LAST_BIN0 + 63 - atr_min(rows, 63) : (start >> 2);
     if (rows >= m || !by_rows) return 96 + start;
     return ROWS_BIN0 + atr_min(rows, 63);
 }
@@ -410,12 +411,13 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
         // LAST-COLUMN BAND.  Only last-column cells can be accepted, (row_l, n) is one of them (its cost is exact)
         // and holds at least row_l - cost_l matches, so no row below row_l - cost_l can win (a row holds at most
         // as many matches as it has bases, and the reference keeps the cell with MORE matches, :468).  The rows
-        // row_l - cost_l .. row_l cost at most k each, so their tracebacks stay on the diagonals
-        // n - row_l - k .. n - row_l + cost_l + k: a banded row-major DP over cost_l + 2k + 1 diagonals and
+        // row_l - cost_l .. row_l cost at most kk <= k each, so their tracebacks stay on the diagonals
+        // n - row_l - kk .. n - row_l + cost_l + kk: a banded row-major DP over cost_l + 2 kk + 1 diagonals and
         // row_l rows (band_locate_last) instead of the column sweep over the window.  Word: j_lo = first
         // diagonal, j_hi field = cost_l, rows = row_l, band + scan bits.
-        const int dlo = n - row_l - u.k;
-        if (dlo >= s && cost_l + 2 * u.k <= BAND_W - 1) return last_band_word(dlo, row_l, atr_min(cost_l, row_l - 1), cost_l + 2 * u.k, false);
+        // (every row i <= row_l is accepted with cost <= thr_row[i] <= thr_row[row_l] only: kk, not k, bounds the indels)
+        const int kk = atr_min(u.k, (int)fp.thr_row[row_l]), dlo = n - row_l - kk;
+        if (dlo >= s && cost_l + 2 * kk <= BAND_W - 1) return last_band_word(dlo, row_l, atr_min(cost_l, row_l - 1), cost_l + 2 * kk, false);
     }
     if (rowm && lastcol && !u.sr && u.indel == 1 && row_e != 0) {
         // The same with row-m candidates besides (an adapter that ends at or near the read end).  (row_e, n), the
