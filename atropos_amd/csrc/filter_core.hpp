@@ -109,11 +109,13 @@ ATR_DEV int last_band_span(uint32_t w) { return window_hi(w) & 63; }
 ATR_DEV int last_band_width(uint32_t w) { return window_hi(w) >> 6; }
 ATR_DEV bool last_band_rowm(uint32_t w) { return ((w >> 29) & 1u) != 0; }
 // Scatter bin, chosen so that the 64 reads of a wave sweep nearly the same cells.
-//   [0, 96)    band reads (band_locate below), by window start / 8;
+//   [0, 32)    band reads (band_locate below: row-m candidates on <= 16 diagonals), by window start / 32;
+//   [32, 96)   last-column band reads (band_locate_last), by row count, most rows first;
 //   [96, 192)  reads that need every row of the column sweep, by window start / 8 -- and, in
 //              ragged batches, the row-limited ones too;
-//   [192, 256) equal-length batches (by_rows): the row-limited partial overlaps at the read end
-//              (window = [n - rows - errors, n]) by row count, which makes a wave uniform in
+//   [192, 256) equal-length batches (by_rows): the row-limited partial overlaps at the read end that the
+//              last-column band does not take (indel cost > 1, START_WITHIN_SEQ1, a band of more than 16
+//              diagonals; window = [n - rows - errors, n]) by row count, which makes a wave uniform in
 //              rows AND window.
 constexpr int BAND_BINS = 96, ROWS_BIN0 = 192;
 // A wave made of [192, 256) reads only (equal read length n, last-column candidates only, at

@@ -9,8 +9,9 @@
 //   K3  scatter_kernel  (read index, window word) of the unresolved reads, ordered by bin
 //                       (filter_core.hpp, window_bin), so that the 64 lanes of a K4 wave sweep nearly
 //                       the same cells and fetch their task with one coalesced load.
-//   K4a band_kernel     reads whose candidates all sit on <= 16 neighbouring diagonals: row-major
-//                       banded DP (filter_core.hpp, band_locate).
+//   K4a band_kernel     reads whose candidates all sit on <= 16 neighbouring diagonals -- row-m cells of an
+//                       adapter inside the read, or last-column cells of a partial adapter at the read end:
+//                       row-major banded DP (filter_core.hpp, band_locate / band_locate_last).
 //   K4  window_kernel   everything else: the packed-word DP (locate_core.hpp, window mode) over
 //                       each read's window only; reads are gathered by index (16-byte chunk
 //                       loads).
