@@ -65,6 +65,7 @@ class Aligner(object):
         self._release()
         self.str_reference = reference
         self._ref_bytes = ref_bytes
+        self._long = False
         if len(ref_bytes) == 0:
             # An empty reference can never produce a non-empty alignment (the reference
             # implementation returns None for every query); no device state is needed.

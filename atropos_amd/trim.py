@@ -367,8 +367,13 @@ class PairedTrimPipeline(object):
             raise exc("error correction of pair %d: %s" % (err // 8, {
                 1: "base without a complement", 2: "overlap outside a read",
                 3: "Cannot determine the mode of an empty sequence"}[err % 8]))
+        self._already_corrected = None
         if correct >= 0:
-            self.corrected_pairs += int((corrected.sum(dim=1) > 0).sum().item())
+            # read.corrected of both reads: a later correct_errors call (MergeOverlapping) returns at once for
+            # these pairs (modifiers.py:232-233) -- also for the ones corrected from complementary fallback
+            # matches, which have no insert match
+            self._already_corrected = (corrected.sum(dim=1) > 0).to(torch.uint8)
+            self.corrected_pairs += int(self._already_corrected.sum().item())
             tot = corrected.sum(dim=0).cpu().tolist()
             self.corrected_bp[0] += int(tot[0])
             self.corrected_bp[1] += int(tot[1])
@@ -376,7 +381,7 @@ class PairedTrimPipeline(object):
             return (m1, st1[0].clone(), uend1), (m2, st2[0].clone(), uend2)
         return (m1, None, None), (m2, None, None)
 
-    def _merge_stage(self, b1, b2, st1, st2, insert_matched):
+    def _merge_stage(self, b1, b2, st1, st2, insert_matched, already_corrected=None):
         """MergeOverlapping over the batch: the alignments ``Aligner(reverse_complement(read2), error_rate,
         flags).locate(read1)`` of the pairs long enough to be tried (atr_locate_pairs_batch, one call per
         flag set), then the merge itself.  Returns (merged flags uint8 [n], merged FASTQ text)."""
@@ -436,8 +441,11 @@ class PairedTrimPipeline(object):
             else:
                 align[idx] = rec
         correct = _ACTIONS[self.correct_mismatches] if self.correct_mismatches else -1
+        # pairs the merge must not correct: bit 0 the insert aligner saw them (modifiers.py:900), bit 1 a read of
+        # the pair was corrected before (correct_errors' own guard, :232-233)
+        no_correct = insert_matched if already_corrected is None else insert_matched | (already_corrected << 1)
         kind, text, corrected, err = be.merge_batch(align.contiguous(), need.to(torch.int32).contiguous(),
-                                                    insert_matched.contiguous(), b1, b2, st1[0], st1[1], st2[0], st2[1],
+                                                    no_correct.contiguous(), b1, b2, st1[0], st1[1], st2[0], st2[1],
                                                     correct, 1, COMP_TABLE)
         if err != _lib.INT64_MAX:
             if err % 8 == 4:
@@ -466,12 +474,12 @@ class PairedTrimPipeline(object):
             st.append([torch.zeros((n,), dtype=torch.int32, device=dev), b.seq_lens.clone()])
         extra = [(torch.zeros((n,), dtype=torch.uint8, device=dev), None, None) for _ in range(2)]
         pipes, batches = (self.p1, self.p2), (batch1, batch2)
-        insert_matched = None
+        insert_matched = already_corrected = None
         for op in self.op_order:
             if op == "A":
                 if self.aligner == "insert":
                     extra = list(self._insert_stage(batch1, batch2, st[0], st[1]))
-                    insert_matched = self._insert_matched
+                    insert_matched, already_corrected = self._insert_matched, self._already_corrected
                 else:
                     for k in range(2):
                         if pipes[k].adapters:
@@ -486,7 +494,7 @@ class PairedTrimPipeline(object):
         dest = be.pair_filter_batch(masks[0], masks[1], self.min_affected)
         merged_text = None
         if self.merge_overlapping:                                  # the last modifier, the first filter
-            merged, merged_text = self._merge_stage(batch1, batch2, st[0], st[1], insert_matched)
+            merged, merged_text = self._merge_stage(batch1, batch2, st[0], st[1], insert_matched, already_corrected)
             dest = torch.where(merged, torch.full_like(dest, DEST_MERGED), dest)
         res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
         return PairedTrimResult(res[0], res[1], merged_text)
@@ -505,7 +513,8 @@ class PairedTrimPipeline(object):
         if self.merge_overlapping:
             totals["merged"] = 0
             if merged_out is not None:
-                sinks.append(FastqSink(merged_out, 2 * chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output))
+                # a merged record is at most its two input records, and each input chunk may carry up to 64 MB over
+                sinks.append(FastqSink(merged_out, 2 * (chunk_bytes + (64 << 20)) + 32, be, clock, keep=keep_output))
         try:
             while True:
                 batches = [r.next_batch() for r in readers]
@@ -658,4 +667,5 @@ def pipeline_from_args(argv):
     return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,
-                              merge_min_overlap=o.merge_min_overlap, merge_error_rate=o.merge_error_rate or 0.2, **common)
+                              merge_min_overlap=o.merge_min_overlap,
+                              merge_error_rate=0.2 if o.merge_error_rate is None else o.merge_error_rate, **common)

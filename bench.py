@@ -239,7 +239,7 @@ class C5(C3):
             w = synth.workload("C5", (rank * self.nbatches + b) * self.n, self.n, device=dev)
             if self.sample is None and rank == 0:
                 k = 100_000
-                self.sample = (w["reads1"][:k].cpu().numpy(), w["reads2"][:k].cpu().numpy())
+                self.sample = tuple(w[key][:k].cpu().numpy() for key in ("reads1", "reads2", "quals1", "quals2"))
             self.batches.append(dict(b1=self.ia.pack(w["reads1"]), b2=self.ia.pack(w["reads2"], check=True),
                                      s1=w["reads1"], s2=w["reads2"], q1=w["quals1"], q2=w["quals2"]))
         self.changed = self.be.empty((self.n, 2), torch.int32)
@@ -262,7 +262,22 @@ class C5(C3):
         return d
 
     def kernel(self):
-        return "insert_kernel + correct_kernel (atr_insert_match_batch + atr_insert_correct_batch)"
+        return "insert_kernel + correct_planes_kernel (atr_insert_match_batch + atr_insert_correct_batch)"
+
+    def cpu_baseline(self):
+        """match_insert AND the liberal correction of the overlap, as the timed GPU step does."""
+        from oracle import oracle as O
+        cores = usable_cores()
+        orc = O.InsertOracle(self.ia.adapter1, self.ia.adapter2, **self.kw)
+        r1, r2, q1, q2 = self.sample
+        lens = np.full(len(r1), r1.shape[1], np.int32)
+
+        def fn():
+            a1, a2, b1, b2 = r1.copy(), r2.copy(), q1.copy(), q2.copy()      # the correction is in place
+            rec = O.match_insert_many(orc, a1, lens, a2, lens, cores)
+            O.insert_correct_many(rec, a1, b1, lens, a2, b2, lens, "liberal", 1, cores)
+        return timed_cpu(fn, 2 * len(r1), "first %d pairs of the same C5 batch (match_insert + correct_errors, incl. "
+                                          "a copy of the four matrices per pass)" % len(r1), cores)
 
 
 class C4(object):
@@ -329,38 +344,13 @@ class C4(object):
 CONFIGS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--reads", type=int, default=None, help="reads (C2, C4) or pairs (C3, C5) per GPU and step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
-                    help="skip the pack-inclusive / ragged-batch side measurements (C2)")
-    ap.add_argument("--full-sweep", action="store_true",
-                    help="C2: time the unfiltered full-column DP kernel instead of the filtered pipeline")
-    args = ap.parse_args()
-    cfg_cls = CONFIGS[args.config]
-    if args.reads is None:
-        args.reads = cfg_cls.default_units
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from atropos_amd import _lib
-    _lib.set_backend(_lib.HipBackend(local_rank))
-    cfg = cfg_cls(args, rank, "cuda:%d" % local_rank)
+def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
+    """Build one config's workload, run warmup + EXACTLY args.steps timed steps (barrier + synchronize on both
+    sides, HIP events on the launch stream around every step, max over ranks) and return its result dict
+    (rank 0; None elsewhere).  headline: the config whose figures are the top-level fields of the line."""
+    cargs = argparse.Namespace(**vars(args))
+    cargs.reads = args.reads if (headline and args.reads is not None) else cfg_cls.default_units
+    cfg = cfg_cls(cargs, rank, "cuda:%d" % local_rank)
     torch.cuda.synchronize()
 
     def barrier():
@@ -371,8 +361,6 @@ def main():
 
     for s in range(args.warmup):
         cfg.step(s)
-    # timed region: EXACTLY `steps` passes, bracketed by barrier + synchronize; the HIP events
-    # sit on the stream the kernels are launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -390,44 +378,100 @@ def main():
         dist.all_reduce(tall, op=dist.ReduceOp.SUM)
     per_rank = [float(x) for x in tall.tolist()]
     dt_max = max(per_rank)
+    if rank != 0:
+        return None
 
+    units = cargs.reads * cfg.unit_reads                         # reads per step and GPU
+    achieved = cfg.algo_bytes * cargs.reads / (kernel_ms * 1e-3) / 1e9
+    prof = profile_counters(cfg.name) if not args.full_sweep else None
+    desc = cfg.describe()
+    desc["parallelism"] = "shard%d" % world
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS,
+            "frac_of_measured": achieved / HBM_MEASURED_GBS,
+            "traffic": None, "kernel": cfg.kernel(), "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_unit": cfg.algo_bytes, "note": cfg.note(kernel_ms)}
+    if prof:
+        scale = cargs.reads / prof["units_per_launch"]
+        roof["traffic"] = prof["hbm_bytes_per_launch"] * scale
+        roof["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 PMC passes of an earlier run, not this run)" % cfg.name
+        if prof.get("valu_wave_insts_per_launch"):
+            lane_ops = prof["valu_wave_insts_per_launch"] * scale * 64 / (kernel_ms * 1e-3) / 1e12
+            roof["valu"] = {"wave_insts_per_launch": prof["valu_wave_insts_per_launch"] * scale,
+                            "source": roof["traffic_source"], "achieved": lane_ops, "unit": "T lane-ops/s",
+                            "peak": VALU_NOMINAL_T, "frac": lane_ops / VALU_NOMINAL_T,
+                            "mixed_stream_model": VALU_MIXED_MODEL_T,
+                            "frac_of_mixed_stream_model": lane_ops / VALU_MIXED_MODEL_T,
+                            "model_note": "39.3 T = every VALU op of a mixed integer stream at 4 issue cycles; a "
+                                          "model of this instruction mix, not a hardware ceiling"}
+    out = {
+        "metric": cfg.metric, "value": units * world * args.steps / dt_max, "unit": "reads/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
+        "config": desc, "roofline": roof,
+        "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+    }
+    # side measurements and the CPU leg belong to the single-GPU line (rank 0 at N = 1): the other ranks of a
+    # multi-GPU run would only wait at the next barrier for them
+    if args.secondary and world == 1:
+        out["secondary"] = cfg.secondary(kernel_ms)
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cfg.cpu_baseline()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="time this BASELINE config only; default: C2 is the headline (top-level fields) and C3, C4, "
+                         "C5 follow in the same process under \"configs\"")
+    ap.add_argument("--reads", type=int, default=None, help="reads (C2, C4) or pairs (C3, C5) per GPU and step of the "
+                                                            "headline config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the pack-inclusive / ragged-batch / small-batch side measurements")
+    ap.add_argument("--no-other-configs", dest="others", action="store_false",
+                    help="default run: C2 only, without the C3 / C4 / C5 entries")
+    ap.add_argument("--full-sweep", action="store_true",
+                    help="C2: time the unfiltered full-column DP kernel instead of the filtered pipeline")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from atropos_amd import _lib
+    _lib.set_backend(_lib.HipBackend(local_rank))
+    head = args.config or "C2"
+    line = measure(CONFIGS[head], args, rank, world, local_rank, dist, True)
+    if args.config is None and args.others and not args.full_sweep:
+        # the other BASELINE configs on the same clock: same steps / warmup, one after the other, each with its
+        # own roofline and (N = 1) cpu_baseline.  A failure there must not cost the headline its line.
+        others = {}
+        for name in ("C3", "C4", "C5"):
+            torch.cuda.empty_cache()
+            try:
+                res = measure(CONFIGS[name], args, rank, world, local_rank, dist, False)
+            except Exception as exc:                              # noqa: BLE001 -- reported in the line
+                if dist is not None:
+                    raise                                         # the ranks would lose step with each other
+                res = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            if rank == 0:
+                others[name] = res
+        if rank == 0:
+            line["configs"] = others
     if rank == 0:
-        units = args.reads * cfg.unit_reads                         # reads per step and GPU
-        achieved = cfg.algo_bytes * args.reads / (kernel_ms * 1e-3) / 1e9
-        prof = profile_counters(cfg.name) if not args.full_sweep else None
-        desc = cfg.describe()
-        desc["parallelism"] = "shard%d" % world
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS,
-                "frac_of_measured": achieved / HBM_MEASURED_GBS,
-                "traffic": None, "kernel": cfg.kernel(), "kernel_ms": kernel_ms,
-                "algorithmic_bytes_per_unit": cfg.algo_bytes, "note": cfg.note(kernel_ms)}
-        if prof:
-            scale = args.reads / prof["units_per_launch"]
-            roof["traffic"] = prof["hbm_bytes_per_launch"] * scale
-            roof["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 PMC passes of an earlier run, not this run)" % cfg.name
-            if prof.get("valu_wave_insts_per_launch"):
-                lane_ops = prof["valu_wave_insts_per_launch"] * scale * 64 / (kernel_ms * 1e-3) / 1e12
-                roof["valu"] = {"wave_insts_per_launch": prof["valu_wave_insts_per_launch"] * scale,
-                                "source": roof["traffic_source"], "achieved": lane_ops, "unit": "T lane-ops/s",
-                                "peak": VALU_NOMINAL_T, "frac": lane_ops / VALU_NOMINAL_T,
-                                "mixed_stream_model": VALU_MIXED_MODEL_T,
-                                "frac_of_mixed_stream_model": lane_ops / VALU_MIXED_MODEL_T,
-                                "model_note": "39.3 T = every VALU op of a mixed integer stream at 4 issue cycles; a "
-                                              "model of this instruction mix, not a hardware ceiling"}
-        line = {
-            "metric": cfg.metric, "value": units * world * args.steps / dt_max, "unit": "reads/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
-            "config": desc, "roofline": roof,
-            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
-        }
-        # side measurements and the CPU leg belong to the single-GPU line (rank 0 at N = 1): the other ranks of a
-        # multi-GPU run would only wait at the final barrier for them
-        if args.secondary and world == 1:
-            line["secondary"] = cfg.secondary(kernel_ms)
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cfg.cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -494,7 +494,8 @@ int atr_fastq_emit(const uint8_t *d_bytes, const atr_fastq_record *d_records, co
  *
  * atr_merge_emit_batch: writes the text of the merged records into d_out (d_offsets[n] bytes).
  * correct_action: -1, or ATR_CORRECT_* = MergeOverlapping's mismatch_action: pairs whose alignment has
- * errors and for which d_insert_matched[p] == 0 (may be NULL: none matched) are corrected IN PLACE in
+ * errors and for which d_insert_matched[p] == 0 (may be NULL: none matched; callers also set a non-zero
+ * byte for pairs with read.corrected > 0, which correct_errors leaves alone, :232-233) are corrected IN PLACE in
  * the two chunks first (correct_errors(read1, read2, alignment), :900-902) -- except that the mate's
  * bases are the uncorrected ones, as in the reference, which reverse-complements read 2 before (:887).
  * d_corrected (may be NULL): 2 x int32 changed-base counts per pair; *d_error (as initialised by the

@@ -23,6 +23,9 @@
  *   orc_match_to                      atropos/adapters/__init__.py:338-400 (adapters with indels, no RMP filter)
  *   orc_linked                        atropos/adapters/__init__.py:671-690 under
  *                                     atropos/commands/trim/modifiers.py:107-122 (which adapter, both matches)
+ *   orc_correct_errors                atropos/commands/trim/modifiers.py:219-350 (ErrorCorrectorMixin.correct_errors)
+ *   orc_insert_correct_many           atropos/commands/trim/modifiers.py:397-404, :448-449 (the correction step of
+ *                                     InsertAdapterCutter.__call__ right after an insert match with errors)
  *   orc_locate_many / orc_linked_many / orc_match_insert_many (threaded drivers) -- harness only, no reference twin
  *
  * The DP keeps the reference's exact evaluation order: one column of
@@ -633,6 +636,179 @@ int orc_match_insert_many(const orc_insert_params *p, const char *reads1, const 
         jb->hi = per * (t + 1) < npairs ? per * (t + 1) : npairs;
         if (nthreads == 1) bad |= ijob_main(jb) != 0;
         else pthread_create(&th[t], 0, ijob_main, jb);
+    }
+    if (nthreads > 1) for (int t = 0; t < nthreads; ++t) { void *rv = 0; pthread_join(th[t], &rv); bad |= rv != 0; }
+    free(th); free(jobs);
+    return bad ? -1 : 0;
+}
+
+/* ---- ErrorCorrectorMixin.correct_errors (commands/trim/modifiers.py:219-350) ----------------
+ * In place on seq1/qual1 (len1 bytes) and seq2/qual2 (len2 bytes); qual1/qual2 may both be NULL
+ * (`has_quals` false, :239).  im = insert_match[0..3].  action: 0 'N', 1 'conservative', 2 'liberal'.
+ * changed[2] = (r1_changed, r2_changed); newlen[2] = len(read.sequence) afterwards (update_read
+ * replaces a changed read 1 by the TRUNCATED list when truncate_seqs cut it, :329-334: `partial`
+ * compares against the un-updated len1).  Python's list semantics are kept: a negative index wraps
+ * once, anything else out of range is an IndexError, slices clamp.
+ * Returns 0, or -1 KeyError (a base without complement, :273, :286, :293), -2 IndexError (:272-273),
+ * -3 ValueError (:245-248 quality-based action without qualities; util mean() of an empty slice,
+ * :303-304); on an error nothing is written (the reference only assigns read.sequence at the end). */
+static int py_index(int i, int n) {            /* list[i]: resolved position or -1 (IndexError) */
+    if (i < 0) i += n;
+    return (i < 0 || i >= n) ? -1 : i;
+}
+
+static void py_slice(int a, int b, int n, int *lo, int *hi) {   /* list[a:b] on a list of n items */
+    if (a < 0) { a += n; if (a < 0) a = 0; } else if (a > n) a = n;
+    if (b < 0) { b += n; if (b < 0) b = 0; } else if (b > n) b = n;
+    *lo = a; *hi = b > a ? b : a;
+}
+
+static unsigned char g_comp[256];
+static int g_comp_ready;
+static void comp_init(void) {                  /* BASE_COMPLEMENTS, util/__init__.py:67-88 */
+    if (g_comp_ready) return;
+    memset(g_comp, 0, 256);
+    const char *a = "ACRSWKBDN", *b = "TGYSWMVHN";
+    for (int i = 0; a[i]; ++i) {
+        g_comp[(unsigned char)a[i]] = (unsigned char)b[i]; g_comp[(unsigned char)b[i]] = (unsigned char)a[i];
+        g_comp[(unsigned char)(a[i] | 0x20)] = (unsigned char)(b[i] | 0x20);
+        g_comp[(unsigned char)(b[i] | 0x20)] = (unsigned char)(a[i] | 0x20);
+    }
+    g_comp_ready = 1;
+}
+
+int orc_correct_errors(char *seq1, char *qual1, int len1, char *seq2, char *qual2, int len2, const int im[4],
+                       int action, int min_qual_difference, int truncate_seqs, int changed[2], int newlen[2]) {
+    comp_init();
+    changed[0] = changed[1] = 0;
+    newlen[0] = len1; newlen[1] = len2;
+    const int has_quals = qual1 && qual2 && len1 > 0 && len2 > 0;                 /* :239 (empty str is falsy) */
+    if (!has_quals && action != 0) return -3;                                      /* :244-248 */
+    int n1 = len1, n2 = len2, l2 = len2;       /* list lengths; l2 = the reference's `len2` variable */
+    if (truncate_seqs) {                                                           /* :250-259 */
+        if (len1 > len2) n1 = len2;
+        else if (len2 > len1) { n2 = len1; l2 = len1; }
+    }
+    unsigned char *s1 = (unsigned char *)malloc((size_t)(2 * n1 + 2 * n2 + 4));
+    int *defer = (int *)malloc(sizeof(int) * 2 * (size_t)(n1 + 1));
+    if (!s1 || !defer) { free(s1); free(defer); return -4; }
+    unsigned char *q1 = s1 + n1, *s2 = q1 + n1, *q2 = s2 + n2;
+    memcpy(s1, seq1, n1); memcpy(s2, seq2, n2);
+    if (has_quals) { memcpy(q1, qual1, n1); memcpy(q2, qual2, n2); }
+    const int r1_start = im[2], r1_end = im[3];                                    /* :261-266 */
+    const int r2_start = l2 - im[1], r2_end = l2 - im[0];
+    int c1 = 0, c2 = 0, ndefer = 0, rc = 0;
+    const int cnt1 = r1_end > r1_start ? r1_end - r1_start : 0, cnt2 = r2_end > r2_start ? r2_end - r2_start : 0;
+    const int cnt = cnt1 < cnt2 ? cnt1 : cnt2;                                     /* zip of the two ranges, :269-270 */
+    for (int t = 0; t < cnt && !rc; ++t) {
+        const int i = py_index(r1_start + t, n1);
+        if (i < 0) { rc = -2; break; }
+        const int j = py_index(r2_end - 1 - t, n2);
+        if (j < 0) { rc = -2; break; }
+        const unsigned char base1 = s1[i], base2 = g_comp[s2[j]];
+        if (!base2) { rc = -1; break; }
+        if (base1 == base2) continue;
+        if (action == 0) {                                                         /* :275-279 */
+            s1[i] = 'N'; s2[j] = 'N'; ++c1; ++c2;
+        } else if (base1 == 'N') {                                                 /* :280-284 */
+            s1[i] = base2; if (has_quals) q1[i] = q2[j]; ++c1;
+        } else if (base2 == 'N') {                                                 /* :285-289 */
+            if (!g_comp[base1]) { rc = -1; break; }
+            s2[j] = g_comp[base1]; if (has_quals) q2[j] = q1[i]; ++c2;
+        } else if (has_quals) {                                                    /* :290-301 */
+            const int diff = (int)q1[i] - (int)q2[j];
+            if (diff >= min_qual_difference) {
+                if (!g_comp[base1]) { rc = -1; break; }
+                s2[j] = g_comp[base1]; q2[j] = q1[i]; ++c2;
+            } else if (diff <= -min_qual_difference) {
+                s1[i] = base2; q1[i] = q2[j]; ++c1;
+            } else if (action == 2) {
+                defer[2 * ndefer] = i; defer[2 * ndefer + 1] = j; ++ndefer;
+                /* base1 / base2 of the tuple are the values read here; positions are distinct unless an
+                 * index wrapped, and then the reference uses the remembered bases too: keep them */
+                defer[2 * ndefer - 2] |= (int)base1 << 16; defer[2 * ndefer - 1] |= (int)base2 << 16;
+            }
+        }
+    }
+    if (!rc && ndefer) {                                                           /* :303-322 */
+        int lo, hi;
+        long sum1 = 0, sum2 = 0;
+        py_slice(r1_start, r1_end, n1, &lo, &hi);
+        const int k1 = hi - lo;
+        for (int x = lo; x < hi; ++x) sum1 += q1[x];
+        py_slice(r2_start, r2_end, n2, &lo, &hi);
+        const int k2 = hi - lo;
+        for (int x = lo; x < hi; ++x) sum2 += q2[x];
+        if (k1 == 0 || k2 == 0) rc = -3;
+        else {
+            const double d = (double)sum1 / (double)k1 - (double)sum2 / (double)k2;
+            if (d > 1) {
+                for (int t = 0; t < ndefer && !rc; ++t) {
+                    const int i = defer[2 * t] & 0xFFFF, j = defer[2 * t + 1] & 0xFFFF;
+                    const unsigned char base1 = (unsigned char)(defer[2 * t] >> 16);
+                    if (!g_comp[base1]) { rc = -1; break; }
+                    s2[j] = g_comp[base1]; q2[j] = q1[i]; ++c2;
+                }
+            } else if (d < -1) {
+                for (int t = 0; t < ndefer; ++t) {
+                    const int i = defer[2 * t] & 0xFFFF, j = defer[2 * t + 1] & 0xFFFF;
+                    s1[i] = (unsigned char)(defer[2 * t + 1] >> 16); q1[i] = q2[j]; ++c1;
+                }
+            }
+        }
+    }
+    if (!rc) {                                                                     /* :324-350 */
+        if (c1) { memcpy(seq1, s1, n1); if (has_quals) memcpy(qual1, q1, n1); newlen[0] = n1; }
+        if (c2) { memcpy(seq2, s2, n2); if (has_quals) memcpy(qual2, q2, n2); }
+        changed[0] = c1; changed[1] = c2;
+    }
+    free(s1); free(defer);
+    return rc;
+}
+
+/* ---- threaded driver: InsertAdapterCutter's correction step over a batch (modifiers.py:397-404, :448-449):
+ * pairs whose insert match (records: npairs x 18 ints as written by orc_match_insert_many) exists and has
+ * errors > 0 get correct_errors(read1, read2, insert_match, truncate_seqs=True), in place on the four
+ * equal-stride matrices.  changed / newlen: npairs x 2 ints (changed[0] = -1 / -2 / -3: the exception). */
+typedef struct {
+    const int *rec; char *s1, *q1, *s2, *q2; const int *l1, *l2; int64_t stride, lo, hi;
+    int action, mqd; int *changed, *newlen;
+} cjob_t;
+
+static void *cjob_main(void *arg) {
+    cjob_t *jb = (cjob_t *)arg;
+    for (int64_t r = jb->lo; r < jb->hi; ++r) {
+        const int *im = jb->rec + 18 * r;
+        int *ch = jb->changed + 2 * r, *nl = jb->newlen + 2 * r;
+        ch[0] = ch[1] = 0; nl[0] = jb->l1[r]; nl[1] = jb->l2[r];
+        if (im[1] < 0 || im[5] <= 0) continue;
+        const int rc = orc_correct_errors(jb->s1 + r * jb->stride, jb->q1 ? jb->q1 + r * jb->stride : 0, jb->l1[r],
+                                          jb->s2 + r * jb->stride, jb->q2 ? jb->q2 + r * jb->stride : 0, jb->l2[r],
+                                          im, jb->action, jb->mqd, 1, ch, nl);
+        if (rc == -4) return (void *)1;
+        if (rc < 0) { ch[0] = rc; ch[1] = 0; }
+    }
+    return 0;
+}
+
+int orc_insert_correct_many(const int *records, char *seq1, char *qual1, const int *lens1, char *seq2, char *qual2,
+                            const int *lens2, int64_t stride, int64_t npairs, int action, int min_qual_difference,
+                            int *changed, int *newlen, int nthreads) {
+    comp_init();
+    if (nthreads < 1) nthreads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    cjob_t *jobs = (cjob_t *)malloc(sizeof(cjob_t) * nthreads);
+    if (!th || !jobs) { free(th); free(jobs); return -1; }
+    const int64_t per = (npairs + nthreads - 1) / nthreads;
+    int bad = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        cjob_t *jb = &jobs[t];
+        jb->rec = records; jb->s1 = seq1; jb->q1 = qual1; jb->s2 = seq2; jb->q2 = qual2; jb->l1 = lens1; jb->l2 = lens2;
+        jb->stride = stride; jb->action = action; jb->mqd = min_qual_difference; jb->changed = changed; jb->newlen = newlen;
+        jb->lo = per * t < npairs ? per * t : npairs;
+        jb->hi = per * (t + 1) < npairs ? per * (t + 1) : npairs;
+        if (nthreads == 1) bad |= cjob_main(jb) != 0;
+        else pthread_create(&th[t], 0, cjob_main, jb);
     }
     if (nthreads > 1) for (int t = 0; t < nthreads; ++t) { void *rv = 0; pthread_join(th[t], &rv); bad |= rv != 0; }
     free(th); free(jobs);

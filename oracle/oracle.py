@@ -8,6 +8,7 @@ The Python-level pieces restated here (reference file:line):
   match_to / linked_many   atropos/adapters/__init__.py:338-400, :671-690 (in align_oracle.c)
   rmp()            atropos/util/__init__.py:117-155 (RandomMatchProbability)
   InsertOracle     atropos/align/__init__.py:206-233 (constructor defaults)
+  correct_errors / insert_correct_many   atropos/commands/trim/modifiers.py:219-350, :397-404 (in align_oracle.c)
 """
 import ctypes as C
 import os
@@ -76,6 +77,12 @@ def lib():
         L.orc_match_insert_many.argtypes = [C.POINTER(_InsertParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                             C.c_int64, C.c_int64, C.c_void_p, C.c_int]
         L.orc_match_insert_many.restype = C.c_int
+        L.orc_correct_errors.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, I6, C.c_int,
+                                         C.c_int, C.c_int, I6, I6]
+        L.orc_correct_errors.restype = C.c_int
+        L.orc_insert_correct_many.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p,
+                                                                 C.c_void_p, C.c_int]
+        L.orc_insert_correct_many.restype = C.c_int
         L.orc_acgt_table.argtypes = [C.c_char_p]
         L.orc_iupac_table.argtypes = [C.c_char_p]
         _lib = L
@@ -331,3 +338,57 @@ def match_insert_many(orc, reads1, lens1, reads2, lens2, nthreads=1):
     if rc != 0:
         raise KeyError("base without complement (or allocation failure)")
     return out
+
+
+CORRECT_ACTIONS = {"N": 0, "conservative": 1, "liberal": 2}
+_CORRECT_ERRORS = {-1: KeyError, -2: IndexError, -3: ValueError, -4: MemoryError}
+
+
+def correct_errors(seq1, qual1, seq2, qual2, insert_match, mismatch_action, min_qual_difference=1,
+                   truncate_seqs=False):
+    """ErrorCorrectorMixin(mismatch_action, min_qual_difference).correct_errors(read1, read2, insert_match,
+    truncate_seqs) on fresh reads (corrected == 0).  Returns (sequence1, qualities1, sequence2, qualities2,
+    (changed1, changed2)) as the reads hold them afterwards; raises what the reference raises."""
+    s1, s2 = C.create_string_buffer(_b(seq1), len(seq1) + 1), C.create_string_buffer(_b(seq2), len(seq2) + 1)
+    q1 = C.create_string_buffer(_b(qual1), len(qual1) + 1) if qual1 else None
+    q2 = C.create_string_buffer(_b(qual2), len(qual2) + 1) if qual2 else None
+    if q1 is None or q2 is None:
+        qa = qb = None
+    else:
+        qa, qb = q1, q2
+    im = (C.c_int * 6)(*[int(x) for x in insert_match[:4]], 0, 0)
+    changed, newlen = (C.c_int * 6)(), (C.c_int * 6)()
+    rc = lib().orc_correct_errors(s1, qa, len(seq1), s2, qb, len(seq2), im, CORRECT_ACTIONS[mismatch_action],
+                                  min_qual_difference, int(truncate_seqs), changed, newlen)
+    if rc < 0:
+        raise _CORRECT_ERRORS[rc]("correct_errors")
+    o1 = s1.raw[:newlen[0]].decode("ascii")
+    o2 = s2.raw[:newlen[1]].decode("ascii")
+    # qualities are only rewritten when the reference has them (has_quals) and the read changed
+    oq1 = q1.raw[:newlen[0] if (qa is not None and changed[0]) else len(qual1)].decode("ascii") if q1 is not None else qual1
+    oq2 = q2.raw[:len(qual2)].decode("ascii") if q2 is not None else qual2
+    return o1, oq1, o2, oq2, (changed[0], changed[1])
+
+
+def insert_correct_many(records, seq1, qual1, lens1, seq2, qual2, lens2, mismatch_action, min_qual_difference=1,
+                        nthreads=1):
+    """The correction step of InsertAdapterCutter.__call__ over a batch, IN PLACE on the four uint8
+    numpy matrices (same shape, C-contiguous): pairs whose insert match (records int32 [n, 3, 6] of
+    match_insert_many) has errors > 0 are corrected with truncate_seqs=True.  Returns (changed int32
+    [n, 2], newlen int32 [n, 2]); changed[:, 0] in (-1, -2, -3): KeyError / IndexError / ValueError."""
+    import numpy as np
+    n = seq1.shape[0]
+    for a in (seq1, seq2, qual1, qual2):
+        assert a is None or (a.dtype == np.uint8 and a.flags.c_contiguous and a.shape == seq1.shape)
+    records = np.ascontiguousarray(records, dtype=np.int32)
+    lens1 = np.ascontiguousarray(lens1, dtype=np.int32)
+    lens2 = np.ascontiguousarray(lens2, dtype=np.int32)
+    changed = np.zeros((n, 2), dtype=np.int32)
+    newlen = np.zeros((n, 2), dtype=np.int32)
+    rc = lib().orc_insert_correct_many(records.ctypes.data, seq1.ctypes.data, None if qual1 is None else qual1.ctypes.data,
+                                       lens1.ctypes.data, seq2.ctypes.data, None if qual2 is None else qual2.ctypes.data,
+                                       lens2.ctypes.data, seq1.shape[1], n, CORRECT_ACTIONS[mismatch_action],
+                                       min_qual_difference, changed.ctypes.data, newlen.ctypes.data, nthreads)
+    if rc != 0:
+        raise MemoryError
+    return changed, newlen

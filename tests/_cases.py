@@ -1187,3 +1187,65 @@ def LocateTuples(records):
     for row in records.tolist():
         out.append(None if row[1] < 0 else tuple(row[:6]))
     return out
+
+
+def check_correct_errors_fixture():
+    """atr_correct_errors_batch (the device twin of ErrorCorrectorMixin.correct_errors, byte walk) against
+    correct_errors_fuzz.json.gz: 4 000 reference cases -- three actions, min_qual_difference, truncate_seqs,
+    unequal lengths, index wrap-around and the three exceptions.  Cases are grouped by the per-call
+    arguments (action, min_qual_difference, truncate_seqs, qualities present)."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib
+    from atropos_amd.modifiers import COMP_TABLE
+    be = _lib.get_backend()
+    cases = load_golden("correct_errors_fuzz.json.gz")
+    assert len(cases) == 4000
+    groups = {}
+    for c in cases:
+        has_q = bool(c["qual1"]) and bool(c["qual2"])
+        groups.setdefault((c["action"], c["mqd"], c["truncate"], has_q), []).append(c)
+    codes = {"KeyError": -1, "IndexError": -2, "ValueError": -3}
+    actions = {"N": 0, "conservative": 1, "liberal": 2}
+    done = 0
+    for (action, mqd, truncate, has_q), group in sorted(groups.items(), key=repr):
+        if not has_q and action != "N":
+            # the reference raises ValueError before it looks at the reads (:244-248); the host wrappers raise too
+            assert all(c["out"] == {"error": "ValueError"} for c in group)
+            done += len(group)
+            continue
+        n = len(group)
+        width = max(max(len(c["seq1"]), len(c["seq2"])) for c in group)
+
+        def mat(key):
+            m = np.zeros((n, width), dtype=np.uint8)
+            for r, c in enumerate(group):
+                b = c[key].encode("latin-1")
+                m[r, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+            return torch.from_numpy(m).to(be.device)
+
+        s1, s2 = mat("seq1"), mat("seq2")
+        q1, q2 = (mat("qual1"), mat("qual2")) if has_q else (None, None)
+        l1 = torch.tensor([len(c["seq1"]) for c in group], dtype=torch.int32, device=be.device)
+        l2 = torch.tensor([len(c["seq2"]) for c in group], dtype=torch.int32, device=be.device)
+        im = torch.tensor([c["im"] for c in group], dtype=torch.int16, device=be.device)
+        changed, newlen = be.correct_errors_batch(s1, q1, l1, s2, q2, l2, im, None, actions[action], mqd, truncate, COMP_TABLE)
+        changed, newlen = changed.cpu().numpy(), newlen.cpu().numpy()
+        hs1, hs2 = s1.cpu().numpy(), s2.cpu().numpy()
+        hq1, hq2 = (q1.cpu().numpy(), q2.cpu().numpy()) if has_q else (None, None)
+        for r, c in enumerate(group):
+            exp = c["out"]
+            if "error" in exp:
+                # the exception ends the reference's run; the callers of the batch raise it too (trim.py), so
+                # what the in-place kernel had already rewritten of such a pair is never looked at
+                assert changed[r, 0] == codes[exp["error"]], (c, changed[r])
+                continue
+            assert list(changed[r]) == exp["corrected"], (c, changed[r])
+            assert newlen[r, 0] == len(exp["seq1"]) and newlen[r, 1] == len(exp["seq2"]), (c, newlen[r])
+            assert bytes(hs1[r, :newlen[r, 0]]).decode("latin-1") == exp["seq1"], c
+            assert bytes(hs2[r, :newlen[r, 1]]).decode("latin-1") == exp["seq2"], c
+            if has_q:
+                assert bytes(hq1[r, :len(exp["qual1"])]).decode("latin-1") == exp["qual1"], c
+                assert bytes(hq2[r, :len(exp["qual2"])]).decode("latin-1") == exp["qual2"], c
+        done += n
+    return done

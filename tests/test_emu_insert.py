@@ -50,3 +50,7 @@ def test_insert_errors(emu_backend):
 
 def test_plane_guided_correction(emu_backend):
     assert _cases.check_plane_guided_correction(n=320) == 7 * 320
+
+
+def test_correct_errors_fixture(emu_backend):
+    assert _cases.check_correct_errors_fixture() == 4000

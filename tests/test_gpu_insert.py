@@ -98,6 +98,10 @@ def test_plane_guided_correction(hip_backend):
     assert _cases.check_plane_guided_correction(n=200_000) == 7 * 200_000
 
 
+def test_correct_errors_fixture(hip_backend):
+    assert _cases.check_correct_errors_fixture() == 4000
+
+
 def test_c5_correction_at_size(hip_backend, oracle):
     """BASELINE config C5 at shard-piece size (2 M pairs 2 x 250 bp with qualities, read wildcards):
     insert match + liberal error correction in place (atr_insert_match_batch + atr_insert_correct_batch).
@@ -136,6 +140,16 @@ def test_c5_correction_at_size(hip_backend, oracle):
     lens = np.full(k, 250, np.int32)
     exp = oracle.match_insert_many(orc, w["reads1"][lo:lo + k].cpu().numpy(), lens, w["reads2"][lo:lo + k].cpu().numpy(), lens, 8)
     assert np.array_equal(rec[lo:lo + k, :, :6].cpu().numpy().astype(np.int32), exp)
+    # (2b) the corrected bases AND qualities of two slices against the checker's correct_errors (pinned to the
+    #      reference by correct_errors_fuzz.json.gz): 40 k pairs, byte for byte, plus the per-read counts
+    for lo2 in (lo, 0):
+        e1, e2, eq1, eq2 = (np.ascontiguousarray(w[key][lo2:lo2 + k].cpu().numpy()) for key in ("reads1", "reads2", "quals1", "quals2"))
+        exp_rec = exp if lo2 == lo else oracle.match_insert_many(orc, e1, lens, e2, lens, 8)
+        ech, enl = oracle.insert_correct_many(exp_rec, e1, eq1, lens, e2, eq2, lens, "liberal", 1, 8)
+        assert int((ech.sum(axis=1) > 0).sum()) > k // 8
+        for got_t, exp_m in ((s1, e1), (s2, e2), (q1, eq1), (q2, eq2)):
+            assert np.array_equal(got_t[lo2:lo2 + k].cpu().numpy(), exp_m)
+        assert np.array_equal(changed[lo2:lo2 + k].cpu().numpy(), ech) and np.array_equal(newlen[lo2:lo2 + k].cpu().numpy(), enl)
     # (3) properties of all pairs
     assert bool((ch >= 0).all())                                         # no pair failed (KeyError / IndexError / ValueError codes are < 0)
     untouched = ~(found & (errs > 0))

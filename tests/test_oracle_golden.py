@@ -151,3 +151,21 @@ def test_oracle_linked_fuzz(oracle):
             assert got == exp, (c["fronts"], c["backs"], kw, c["reads"][i])
             n += 1
     assert n == 3840
+
+
+def test_correct_errors_fuzz(oracle):
+    """oracle.correct_errors (orc_correct_errors) against 4 000 reference runs of
+    ErrorCorrectorMixin.correct_errors (tests/golden/make_round3_golden.py)."""
+    cases = load_golden("correct_errors_fuzz.json.gz")
+    assert len(cases) == 4000
+    seen = set()
+    for c in cases:
+        try:
+            s1, q1, s2, q2, ch = oracle.correct_errors(c["seq1"], c["qual1"], c["seq2"], c["qual2"], c["im"], c["action"],
+                                                       c["mqd"], c["truncate"])
+            got = dict(seq1=s1, qual1=q1, seq2=s2, qual2=q2, corrected=list(ch), pairs=int(ch[0] > 0 or ch[1] > 0), bp=list(ch))
+        except (KeyError, IndexError, ValueError) as exc:
+            got = dict(error=type(exc).__name__)
+        assert got == c["out"], c
+        seen.add(got.get("error", "ok"))
+    assert seen == {"ok", "KeyError", "IndexError", "ValueError"}
