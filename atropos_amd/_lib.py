@@ -108,6 +108,12 @@ PROTOTYPES = {
     "atr_locate_pairs_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p]),
+    "atr_locate_pairs_need_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "atr_locate_pairs_full_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p]),
     "atr_fastq_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_fastq_count_lines": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_fastq_index": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -438,14 +444,28 @@ class HipBackend(object):
         return out
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
-                           query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
-        """Aligner.locate with a per-pair reference; both sides tile64-packed.  int16 [npairs, 8]."""
+                           query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost,
+                           need=None):
+        """Aligner.locate with a per-pair reference; both sides tile64-packed.  int16 [npairs, 8].
+        need: int32 [npairs] or None -- alignments with fewer matches may come back as None
+        (atr_locate_pairs_need_batch)."""
         out = self.empty((npairs, 8), torch.int16)
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.atr_locate_pairs_batch(
+            _check(self.lib, self.lib.atr_locate_pairs_need_batch(
                 _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
                 query_max_len, npairs, e, flags, int(wildcard_ref), int(wildcard_query), min_overlap, indel_cost,
-                _ptr(out), self._stream()), "atr_locate_pairs_batch")
+                _ptr(need), _ptr(out), self._stream()), "atr_locate_pairs_need_batch")
+        return out
+
+    def locate_pairs_full_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                                query_max_len, npairs, e, flags, min_overlap, indel_cost):
+        """The same records by the full-matrix sweep alone (atr_locate_pairs_full_batch)."""
+        out = self.empty((npairs, 8), torch.int16)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_locate_pairs_full_batch(
+                _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
+                query_max_len, npairs, e, flags, 0, 0, min_overlap, indel_cost, _ptr(out), self._stream()),
+                "atr_locate_pairs_full_batch")
         return out
 
     # -- device-resident FASTQ batch --------------------------------------------

@@ -362,6 +362,25 @@ int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_len
                            int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
                            int min_overlap, int indel_cost, atr_result *d_out, void *stream);
 
+/* The same with a per-pair lower bound on the alignment's matches (d_need, device, may be NULL = 1 everywhere):
+ * MergeOverlapping only looks at an alignment when `matches >= min_overlap` (modifiers.py:896-897, min_overlap
+ * from :870-874), so a pair whose reference alignment has fewer matches than d_need[p] may be reported as
+ * refstop -1 instead -- which lets the library stop after its cost pass for pairs that cannot overlap that far.
+ * Pairs whose alignment has at least d_need[p] matches get the reference's record, bit for bit.
+ * With STOP_WITHIN_SEQ2, indel cost 1 and no wildcard flag (both flag sets of MergeOverlapping) the batch runs
+ * through: exact costs of all candidate cells by Myers' bit-vector recurrence, the candidates that can still be
+ * the reference's choice, and the packed-word DP on the band of diagonals that holds all their optimal paths;
+ * other settings -- and pairs outside that pipeline's envelope -- sweep the whole matrix. */
+int atr_locate_pairs_need_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
+                                const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,
+                                int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
+                                int min_overlap, int indel_cost, const int32_t *d_need, atr_result *d_out, void *stream);
+/* atr_locate_pairs_batch by the full-matrix sweep alone (same records; the checker of the pipeline above). */
+int atr_locate_pairs_full_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
+                                const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,
+                                int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
+                                int min_overlap, int indel_cost, atr_result *d_out, void *stream);
+
 /* ---- device-resident FASTQ batch (io/_seqio.pyx:163-245, io/seqio.py:686-700) ---- */
 
 /* One chunk of FASTQ text (whole records, < 4 GiB, 16-byte aligned, ending in a line end) is

@@ -1249,3 +1249,51 @@ def check_correct_errors_fixture():
                 assert bytes(hq2[r, :len(exp["qual2"])]).decode("latin-1") == exp["qual2"], c
         done += n
     return done
+
+
+# ---------------------------------------------------------------------------------------------
+# The fast pair pipeline (pairs_fast_core.hpp: bit-vector costs, threat analysis, banded payload) against the oracle
+def check_pairs_fast(PairAligner, oracle, seed, rounds, top=150, npairs=96, adversarial=True):
+    """Settings the fast pipeline takes (STOP_WITHIN_SEQ2, indel cost 1, literal compare): overlapping read
+    pairs cut from one fragment (both overlap directions, substitutions and indels), unrelated pairs, and --
+    adversarial -- low-complexity / tandem-repeat fragments, where many diagonals tie and the banded pass must
+    either certify its payload or hand the pair to the full sweep."""
+    from atropos_amd.util import reverse_complement
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        flags = rng.choice([15, 9, 15, 9, 8, 10, 12, 11, 13, 14])
+        e = rng.choice([0.05, 0.1, 0.2, 0.2, 0.2, 0.3])
+        mo = rng.choice([1, 1, 1, 3, 20])
+        rc = rng.random() < 0.7
+        ragged = rng.random() < 0.4
+        refs, qrys = [], []
+        for _p in range(npairs):
+            m = rng.randint(max(1, top // 3), top) if ragged else top
+            n = rng.randint(max(1, top // 3), top) if ragged else top
+            kind = rng.random()
+            if adversarial and kind < 0.25:
+                unit = rseq(rng, rng.choice([1, 2, 3, 5, 7, 11]), "ACGT")
+                frag = (unit * (2 * (m + n) // len(unit) + 2))[:2 * (m + n)]
+                frag = mutate(rng, frag, rng.choice([0, 0.01, 0.05]), "ACGT")
+            else:
+                frag = rseq(rng, 2 * (m + n), "ACGT" if rng.random() < 0.85 else "ACGTN")
+            if kind < 0.85:
+                # read 1 = frag[a : a + n], the reference = frag[b : b + m]: any relative offset
+                a = rng.randint(0, m + n - 1)
+                b = rng.randint(max(0, a - m + 1), a + n - 1) if rng.random() < 0.85 else rng.randint(0, m + n - 1)
+                p_err = rng.choice([0, 0.01, 0.02, 0.05, 0.1])
+                qry = mutate(rng, frag[a:a + n], p_err, "ACGT")[:n]
+                ref = mutate(rng, frag[b:b + m], p_err / 2, "ACGT")[:m]
+            else:
+                ref, qry = rseq(rng, m, "ACGT"), rseq(rng, n, "ACGT")
+            refs.append(ref or "A")
+            qrys.append(qry or "C")
+        given = [reverse_complement(r) for r in refs] if rc else refs
+        pa = PairAligner(e, flags, False, False, mo, 1, revcomp_ref=rc)
+        got = pa.locate_batch(given, qrys).tuples()
+        for ref, qry, g in zip(refs, qrys, got):
+            exp = oracle.locate(ref, qry, e, flags, False, False, mo, 1)
+            assert g == exp, (ref, qry, e, flags, mo, rc, g, exp)
+            total += 1
+    return total

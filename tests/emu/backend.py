@@ -16,7 +16,7 @@ _CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "e
 _SRCS = _CPPS + [
     os.path.join(_ROOT, "atropos_amd", "csrc", f)
     for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp",
-              "filter_core.hpp", "fastq_core.hpp", "pairs_core.hpp", "linked_core.hpp", "linked_host.hpp")] + [
+              "filter_core.hpp", "fastq_core.hpp", "pairs_core.hpp", "pairs_fast_core.hpp", "linked_core.hpp", "linked_host.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -265,13 +265,24 @@ class EmuBackend(object):
         return which, front, back
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
-                           query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+                           query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost,
+                           need=None):
         out = torch.zeros((npairs, 8), dtype=torch.int16)
-        _check(self.lib.emu_locate_pairs_batch(
+        _check(self.lib.emu_locate_pairs_need_batch(
             _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
             query_max_len, C.c_int64(npairs), C.c_double(e), flags, int(wildcard_ref), int(wildcard_query), min_overlap,
-            indel_cost, _ptr(out)), "emu_locate_pairs_batch")
+            indel_cost, _ptr(need), _ptr(out)), "emu_locate_pairs_need_batch")
         return out
+
+    def locate_pairs_full_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                                query_max_len, npairs, e, flags, min_overlap, indel_cost):
+        fast = C.c_int.in_dll(self.lib, "emu_pairs_fast")
+        prev, fast.value = fast.value, 0
+        try:
+            return self.locate_pairs_batch(ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                                           query_max_len, npairs, e, flags, False, False, min_overlap, indel_cost)
+        finally:
+            fast.value = prev
 
     # -- device-resident FASTQ batch (CPU twin) ----------------------------------
     def fastq_index(self, data, nbytes):

@@ -3,11 +3,13 @@
 #include <cstdint>
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
 #include <vector>
 
 #include "aligner_host.hpp"
 #include "misc_core.hpp"
 #include "pairs_core.hpp"
+#include "pairs_fast_core.hpp"
 
 using namespace atr;
 
@@ -148,10 +150,100 @@ int emu_correct_errors_batch(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_
 // test hook: also exercise the LDS-column variant (the library's fallback when stream-ordered allocation is missing)
 int emu_pairs_use_lds_column = 0;
 
+// test hooks of the fast pipeline (pairs_fast_core.hpp): 0 = off (every pair takes the full sweep), 1 = on;
+// widen: run the banded pass with the widest class / extra rows, as a lane does whose wave mates need more
+int emu_pairs_fast = 1, emu_pairs_fast_widen = 0, emu_pairs_fast_debug = 0;
+long long emu_pairs_fast_stats[4];                                 // none / band ok / full sweep / certificate failed
+
+}  // extern "C"
+
+// One pair through the fast pipeline; returns false when the pair needs the full sweep.
+template <int NW>
+static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp, int rndw, int m, bool revcomp,
+                              const uint32_t *qp, int qndw, int n, int need, uint32_t pair, uint32_t *rec) {
+    using namespace atr;
+    const PairParams &p = fp.pp;
+    const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
+    if (m < 1 || n < 1 || (int)p.thr[m] > PF_MAX_K) { ++emu_pairs_fast_stats[2]; return false; }
+    uint32_t tab[PF_TAB_ROWS * NW];
+    bool known = pf_build_masks<NW>(tab, 1, rp, rndw, m, revcomp, sq);
+    const int k = (int)p.thr[m];
+    const int n_sweep = sq ? n : std::min(n, m + k);                   // _align.pyx:314-321
+    const bool scan_last = n_sweep == n;
+    std::vector<uint8_t> crow((size_t)n + 2, 255);
+    PfMyers<NW> S;
+    pf_myers_init<NW>(S, m, sr);
+    uint32_t pvn[NW], mvn[NW];
+    for (int j = 1; j <= n_sweep; ++j) {
+        const uint32_t code = packed_code(qp, j - 1);
+        known = known && pf_codes_known(code);
+        const int row = pf_code_row(code);
+        uint32_t eq[NW];
+        for (int w = 0; w < NW; ++w) eq[w] = tab[row * NW + w];
+        pf_myers_step<NW>(S, eq, sq ? 0u : 1u);
+        crow[j] = (uint8_t)std::min(S.score, 255);
+    }
+    for (int j = n_sweep + 1; j <= n; ++j) known = known && pf_codes_known(packed_code(qp, j - 1));
+    for (int w = 0; w < NW; ++w) { pvn[w] = S.pv[w]; mvn[w] = S.mv[w]; }
+    if (!known) { ++emu_pairs_fast_stats[2]; return false; }
+    PfDecision D;
+    pf_analyse<NW>(crow.data(), 1, pvn, mvn, m, n, n_sweep, scan_last, fp, p.thr, fp.g_ap, fp.g_as, need, pair, D);
+    if (emu_pairs_fast_debug && D.kind == 2) fprintf(stderr, "pair %u wide: lo %d hi %d mlb %d rl %d\n", pair, D.task.d_lo, D.task.row_first, D.task.mlb, D.task.row_last);
+    if (emu_pairs_fast_debug)
+        fprintf(stderr, "pair %u m %d n %d kind %d cls %d d_lo %d rf %d rl %d mlb %d cand_first %d\n", pair, m, n,
+                D.kind, D.cls, D.kind == 1 ? D.task.d_lo : 0, D.kind == 1 ? D.task.row_first : 0, D.kind == 1 ? D.task.row_last : 0,
+                D.kind == 1 ? D.task.mlb : 0, D.kind == 1 ? D.task.cand_first : 0);
+    if (D.kind == 0) {
+        rec[0] = 0xFFFF0000u; rec[1] = rec[2] = rec[3] = 0u;
+        ++emu_pairs_fast_stats[0];
+        return true;
+    }
+    if (D.kind == 2) { ++emu_pairs_fast_stats[2]; return false; }
+    PfBandLane L;
+    L.d_lo = D.task.d_lo; L.row_first = D.task.row_first; L.row_last = D.task.row_last; L.m = m; L.n = n; L.n_sweep = n_sweep;
+    L.cand_first = D.task.cand_first; L.mlb = D.task.mlb;
+    L.scan_last = scan_last; L.live = true;
+    const int cls = emu_pairs_fast_widen ? PF_CLASSES - 1 : D.cls;
+    const int wb = pf_class_width(cls);
+    int nrows = std::max(0, (int)L.row_last - (int)L.row_first + 1);
+    if (emu_pairs_fast_widen) nrows += 9;
+    const int ninj = std::min(nrows, std::max(0, -L.d_lo - L.row_first + 1) + (emu_pairs_fast_widen ? 3 : 0));
+    const int nrd = pf_ref_stream_dwords(nrows), nqd = pf_query_stream_dwords(nrows, wb);
+    std::vector<uint32_t> rs((size_t)nrd + 1), qs((size_t)nqd + 1);
+    pf_stage_streams(rs.data(), 1, nrd, qs.data(), 1, nqd, rp, rndw, m, revcomp, qp, qndw, L.row_first, L.d_lo);
+    switch (cls) {
+        case 0: pf_band_sweep<16>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 1: pf_band_sweep<32>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 2: pf_band_sweep<48>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 3: pf_band_sweep<64>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 4: pf_band_sweep<80>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 5: pf_band_sweep<96>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 6: pf_band_sweep<112>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        default: pf_band_sweep<128>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+    }
+    ++emu_pairs_fast_stats[1];
+    return true;
+}
+
+extern "C" {
+
+int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
+                                const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
+                                double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                                const int32_t *need, uint32_t *out);
+
 int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
                            const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
                            double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
                            uint32_t *out) {
+    return emu_locate_pairs_need_batch(ref_packed, ref_lens, ref_max_len, revcomp, qry_packed, qry_lens, qry_max_len, npairs, e,
+                                       flags, wildcard_ref, wildcard_query, min_overlap, indel_cost, nullptr, out);
+}
+
+int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
+                                const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
+                                double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                                const int32_t *need, uint32_t *out) {
     if (npairs < 0) return ATR_ERR_INVALID;
     atr::PairParams p;
     const int rc = atr::pairs_params(e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost, ref_max_len,
@@ -159,6 +251,10 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
     if (rc != ATR_OK) return rc;
     const int rch = (ref_max_len + 31) / 32, qch = (qry_max_len + 31) / 32;
     std::vector<uint32_t> col((size_t)ref_max_len + 1), refw((size_t)(ref_max_len + 7) / 8 + 1);
+    const bool fast = emu_pairs_fast && atr::pairs_fast_applies(e, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len,
+                                                                qry_max_len);
+    static atr::PairFastParams fp;
+    if (fast) { fp.pp = p; atr::pairs_fast_tables(e, fp); }
     for (int64_t r = 0; r < npairs; ++r) {
         const int64_t tile = r >> 6;
         const int lane = (int)(r & 63);
@@ -167,6 +263,14 @@ int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, 
         if (n > qry_max_len) n = qry_max_len;
         const uint32_t *rp = ref_packed + ((size_t)tile * rch * 64 + lane) * 4;
         const uint32_t *qp = qry_packed + ((size_t)tile * qch * 64 + lane) * 4;
+        if (fast) {                                                  // as the library: costs, threats, banded payload
+            const int nd = need ? need[r] : 1;
+            bool done;
+            if (ref_max_len <= 160) done = emu_pair_fast_one<5>(fp, rp, rch * 4, m, revcomp != 0, qp, qch * 4, n, nd, (uint32_t)r, out + 4 * r);
+            else if (ref_max_len <= 256) done = emu_pair_fast_one<8>(fp, rp, rch * 4, m, revcomp != 0, qp, qch * 4, n, nd, (uint32_t)r, out + 4 * r);
+            else done = emu_pair_fast_one<10>(fp, rp, rch * 4, m, revcomp != 0, qp, qch * 4, n, nd, (uint32_t)r, out + 4 * r);
+            if (done) continue;
+        }
         if (ref_max_len <= atr::PAIRS_REG_MAX) {                     // as the library: register-column variant
             // the wave's smallest m (select range of the row-m pick-up)
             int mlo = 0x7fffffff, mhi = 0;

@@ -149,6 +149,45 @@ def test_pair_aligner_against_oracle(hip_backend, oracle):
     assert _cases.check_pairs_against_oracle(PairAligner, oracle, AtroposHipError, seed=78, rounds=120) > 3000
 
 
+def test_pairs_fast_pipeline_vs_oracle(hip_backend, oracle):
+    """The fast pair pipeline (bit-vector costs, threat analysis, banded payload; pairs_fast_core.hpp) on the
+    settings it takes: overlapping pairs in both directions, unrelated pairs, tandem repeats; 150- and 320-base
+    envelopes (three mask-word counts, all band classes)."""
+    from atropos_amd.align import PairAligner
+    assert _cases.check_pairs_fast(PairAligner, oracle, seed=5, rounds=60, top=150) == 60 * 96
+    assert _cases.check_pairs_fast(PairAligner, oracle, seed=6, rounds=30, top=250, npairs=130) == 30 * 130
+    assert _cases.check_pairs_fast(PairAligner, oracle, seed=7, rounds=20, top=320, npairs=70) == 20 * 70
+    assert _cases.check_pairs_fast(PairAligner, oracle, seed=8, rounds=40, top=40, npairs=200) == 40 * 200
+
+
+def test_pairs_fast_at_size(hip_backend, oracle):
+    """2 M C3 pairs and 500 k C5 pairs through atr_locate_pairs_batch (MergeOverlapping's two flag sets): slices
+    against the oracle, and every pair against the full sweep of pairs_core.hpp (atr_locate_pairs_full_batch)."""
+    import numpy as np
+    import torch
+    from atropos_amd import _lib, synth
+    from atropos_amd.align import PairAligner
+    from atropos_amd.util import reverse_complement
+    for config, n, k in (("C3", 2_000_000, 6000), ("C5", 500_000, 3000)):
+        w = synth.workload(config, 11, n, device="cuda")
+        for flags in (15, 9):
+            pa = PairAligner(0.2, flags, revcomp_ref=True)
+            be = _lib.get_backend()
+            rb = pa._pack(w["reads2"], _lib.TABLE_DNA15, be, True)
+            qb = pa._pack(w["reads1"], _lib.TABLE_DNA15, be, True)
+            got = pa.locate_batch(rb, qb).records
+            lo = 123_456
+            r1 = w["reads1"][lo:lo + k].cpu().numpy()
+            r2 = w["reads2"][lo:lo + k].cpu().numpy()
+            sub = got[lo:lo + k, :6].cpu().numpy().astype(np.int32)
+            for i in range(k):
+                exp = oracle.locate(reverse_complement(bytes(r2[i]).decode()), bytes(r1[i]).decode(), 0.2, flags, False, False, 1, 1)
+                g = None if sub[i, 1] < 0 else tuple(int(v) for v in sub[i])
+                assert g == exp, (config, flags, lo + i, g, exp)
+            full = be.locate_pairs_full_batch(rb.packed, rb.lens, rb.max_len, True, qb.packed, qb.lens, qb.max_len, n, 0.2, flags, 1, 1)
+            assert torch.equal(got, full), (config, flags)
+
+
 def test_single_process_multi_stream(hip_backend):
     """The single-process multi-device driver on the one GPU there is: three backends on device 0 -- one
     host thread, stream, scratch and set of aligner handles each -- must reproduce the single-stream
