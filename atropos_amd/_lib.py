@@ -15,7 +15,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libatropos_hip.so")
+LIB_PATH = os.environ.get("ATROPOS_HIP_LIB") or os.path.join(_HERE, "libatropos_hip.so")   # (override: kernel experiments)
 
 ATR_OK = 0
 ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "HIP runtime error",

@@ -410,9 +410,12 @@ class PairAligner(object):
             packed = be.pack_reads(ascii_t, lens_t, max_len, table)
         return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, kind, table)
 
-    def locate_batch(self, references, queries):
+    def locate_batch(self, references, queries, need=None):
         """references/queries: lists of str, uint8 [n, width] ASCII tensors, or ReadBatches
-        packed with the right tables.  Returns a LocateResult (int16 [n, 8] records)."""
+        packed with the right tables.  Returns a LocateResult (int16 [n, 8] records).
+        need: per pair (list or int32 tensor), the number of matches below which the caller ignores the
+        alignment (MergeOverlapping's ``matches >= min_overlap``, modifiers.py:896-897): such pairs may come
+        back as None, which lets the library stop after its cost pass for pairs that cannot overlap that far."""
         be = _lib.get_backend()
         rk, qk = self._table_kinds()
         literal = not (self.wildcard_ref or self.wildcard_query)
@@ -427,9 +430,15 @@ class PairAligner(object):
             qb = self._pack(queries, qk, be, literal, case_table=both)
         if rb.nreads != qb.nreads:
             raise ValueError("need as many references as queries")
+        if need is not None and not torch.is_tensor(need):
+            need = torch.tensor(list(need), dtype=torch.int32)
+        if need is not None:
+            need = need.to(device=rb.packed.device, dtype=torch.int32).contiguous()
+            if need.numel() != rb.nreads:
+                raise ValueError("need: one entry per pair")
         rec = be.locate_pairs_batch(rb.packed, rb.lens, rb.max_len, self.revcomp_ref, qb.packed, qb.lens, qb.max_len,
                                     rb.nreads, self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query,
-                                    self.min_overlap, self.indel_cost)
+                                    self.min_overlap, self.indel_cost, need=need)
         return LocateResult(rec)
 
     def locate(self, reference, query):

@@ -41,27 +41,39 @@ struct PairsFastArgs {
     uint4 *out;
 };
 
+// tiles [t0, t1) of a block of P1 / P3: contiguous ranges of a whole number of wave rounds (a short batch then keeps
+// all waves of its blocks busy instead of one wave in each of FAST_BLOCKS blocks); the blocks behind the last tile
+// write empty histogram rows
+__device__ __forceinline__ void pairs_block_tiles(long long ntiles, int nwaves, long long &t0, long long &t1) {
+    long long per = (ntiles + FAST_BLOCKS - 1) / FAST_BLOCKS;
+    per = (per + nwaves - 1) / nwaves * nwaves;
+    t0 = min(ntiles, per * (long long)blockIdx.x);
+    t1 = min(ntiles, t0 + per);
+}
+
 // ---- P1 ------------------------------------------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFastWork wk) {
     __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3], s_gap[PAIRS_MAX_LEN + 2], s_gas[PAIRS_MAX_LEN + 2];
     __shared__ uint32_t s_hist[PF_BINS];
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 3; i += 256) s_thr[i] = fp.pp.thr[i];
-    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 2; i += 256) { s_gap[i] = fp.g_ap[i]; s_gas[i] = fp.g_as[i]; }
-    if (threadIdx.x < PF_BINS) s_hist[threadIdx.x] = 0u;
+    const int nthreads = (int)blockDim.x, nwaves = nthreads >> 6;     // 4 waves, fewer when the LDS of long reads demands it
+    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 3; i += nthreads) s_thr[i] = fp.pp.thr[i];
+    for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 2; i += nthreads) { s_gap[i] = fp.g_ap[i]; s_gas[i] = fp.g_as[i]; }
+    for (int i = threadIdx.x; i < PF_BINS; i += nthreads) s_hist[i] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool sr = (fp.pp.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (fp.pp.flags & ATR_START_WITHIN_SEQ2) != 0;
-    // per wave: PF_TAB_ROWS x NW mask words and (qry_max_len + 1) cost bytes per lane
-    const int crow_words = ((a.qry_max_len + 1) * 64 + 3) / 4;
-    uint32_t *tab = s_dyn + (size_t)wave * (PF_TAB_ROWS * NW * 64 + crow_words) + lane;
-    uint8_t *crow = (uint8_t *)(s_dyn + (size_t)wave * (PF_TAB_ROWS * NW * 64 + crow_words) + PF_TAB_ROWS * NW * 64) + lane;
+    // per wave: PF_TAB_ROWS x NW mask words and PF_LIST_CAP 16-bit candidate entries per lane
+    constexpr int WAVE_WORDS = PF_TAB_ROWS * NW * 64 + PF_LIST_CAP * 32;
+    uint32_t *tab = s_dyn + (size_t)wave * WAVE_WORDS + lane;
+    uint16_t *list = (uint16_t *)(s_dyn + (size_t)wave * WAVE_WORDS + PF_TAB_ROWS * NW * 64) + lane;
     const long long ntiles = (a.npairs + 63) >> 6;
     long long t0, t1;
-    block_tiles(ntiles, t0, t1);
+    pairs_block_tiles(ntiles, nwaves, t0, t1);
     const int rndw = a.ref_chunks * 4, qndw = a.qry_chunks * 4;
-    for (long long tile = t0 + wave; tile < t1; tile += 4) {
+    const bool er = (fp.pp.flags & ATR_STOP_WITHIN_SEQ1) != 0;
+    for (long long tile = t0 + wave; tile < t1; tile += nwaves) {
         const long long r = tile * 64 + lane;
         const bool live = r < a.npairs;
         const int m = live ? min(a.ref_lens ? a.ref_lens[r] : a.ref_max_len, a.ref_max_len) : 0;
@@ -75,9 +87,17 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
         PfMyers<NW> S;
         pf_myers_init<NW>(S, m, sr);
         const uint32_t hin = sq ? 0u : 1u;
+        int cnt = 0;
         if (jhi > 0) {
             const int c1 = (jhi + 31) >> 5;
             uint4 nxt = qt[0];
+            // the match masks of a column are fetched from LDS one column ahead of the (serially dependent) update
+            uint32_t eqn[NW];
+            {
+                const uint32_t row0 = min(pf_code_rows8(nxt.x) & 7u, (uint32_t)(PF_TAB_ROWS - 1));
+#pragma unroll
+                for (int x = 0; x < NW; ++x) eqn[x] = tab[(size_t)(row0 * NW + x) * 64];
+            }
             for (int c = 0; c < c1; ++c) {
                 const uint4 cur = nxt;
                 if (c + 1 < c1) nxt = qt[(size_t)(c + 1) * 64];
@@ -85,20 +105,24 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
 #pragma unroll 1
                 for (int d = 0; d < 4; ++d) {
                     const uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
+                    const uint32_t wn = d == 0 ? cur.y : d == 1 ? cur.z : d == 2 ? cur.w : nxt.x;     // the dword after
                     known = known && pf_codes_known(w);
-                    uint32_t rows = pf_code_rows8(w);                 // table row of each of the eight bases
+                    // table rows of the bases of columns j + 2 .. j + 9 (the prefetch runs one column ahead)
+                    uint32_t rows = (pf_code_rows8(w) >> 4) | (pf_code_rows8(wn) << 28);
 #pragma unroll 1
                     for (int b = 0; b < 8; ++b) {
                         ++j;
-                        const uint32_t row = rows & 7u;
-                        rows >>= 4;
                         if (j > jhi) break;                           // wave-uniform
                         uint32_t eq[NW];
 #pragma unroll
-                        for (int x = 0; x < NW; ++x) eq[x] = tab[(size_t)(row * NW + x) * 64];
+                        for (int x = 0; x < NW; ++x) eq[x] = eqn[x];
+                        const uint32_t row = min(rows & 7u, (uint32_t)(PF_TAB_ROWS - 1));
+                        rows >>= 4;
+#pragma unroll
+                        for (int x = 0; x < NW; ++x) eqn[x] = tab[(size_t)(row * NW + x) * 64];
                         if (j <= n_sweep) {
                             pf_myers_step<NW>(S, eq, hin);
-                            crow[(size_t)j * 64] = (uint8_t)min(S.score, 255);
+                            pf_collect_rowm(list, 64, cnt, j, S.score, min(k, (int)fp.g_ap[j]));
                         }
                     }
                     if (j >= jhi) break;
@@ -106,12 +130,20 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
             }
         }
         // the bases behind n_sweep (only without START_WITHIN_SEQ2) are never compared; they need no code check
+        const int cnt_row = cnt;
+        const bool scan_last = n_sweep == n;
+        if (live && scan_last && m >= 1 && n >= 1)
+            pf_collect_lastcol<NW>(list, 64, cnt, S.pv, S.mv, m, n, sq, er, s_thr, (int)s_gap[n]);
         PfDecision D;
         D.kind = 2; D.cls = 0;
-        if (live && known && m >= 1 && n >= 1 && k <= PF_MAX_K) {
-            pf_analyse<NW>(crow, 64, S.pv, S.mv, m, n, n_sweep, n_sweep == n, fp, s_thr, s_gap, s_gas,
-                           a.need ? a.need[r] : 1, (uint32_t)r, D);
-        }
+        const bool ok = live && known && m >= 1 && n >= 1 && k <= PF_MAX_K && cnt <= PF_LIST_CAP;
+        const int nmax = wave_max_i32(ok ? cnt : 0);
+#ifdef PF_EXPERIMENT_NO_ANALYSIS
+        if (live) D.kind = 0;
+#else
+        pf_analyse(list, 64, cnt_row, ok ? cnt : 0, nmax, m, n, fp, s_thr, s_gap, s_gas, a.need && live ? a.need[r] : 1, (uint32_t)r, D);
+        if (!ok) D.kind = 2;
+#endif
         if (live) {
             if (D.kind == 0) {
                 a.out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);
@@ -131,17 +163,17 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
         }
     }
     __syncthreads();
-    if (threadIdx.x < PF_BINS) wk.fw.counts[(size_t)blockIdx.x * PF_BINS + threadIdx.x] = s_hist[threadIdx.x];
+    for (int i = threadIdx.x; i < PF_BINS; i += nthreads) wk.fw.counts[(size_t)blockIdx.x * PF_BINS + i] = s_hist[i];
 }
 
 // ---- P3 ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pairs_scatter_kernel(long long npairs, PairsFastWork wk) {
+__global__ __launch_bounds__(256) void pairs_scatter_kernel(long long npairs, int p1_waves, PairsFastWork wk) {
     __shared__ uint32_t s_cur[PF_BINS];
     if (threadIdx.x < PF_BINS) s_cur[threadIdx.x] = fast_slot0(wk.fw, threadIdx.x);
     __syncthreads();
     const long long ntiles = (npairs + 63) >> 6;
     long long t0, t1;
-    block_tiles(ntiles, t0, t1);
+    pairs_block_tiles(ntiles, p1_waves, t0, t1);                 // the tiles whose bins P1's block of the same index counted
     const long long rend = min(npairs, t1 * 64);
     for (long long r = t0 * 64 + threadIdx.x; r < rend; r += 256) {
         const uint32_t bin = wk.bins[r];
@@ -152,7 +184,7 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(long long npairs, Pa
 // ---- P4 ------------------------------------------------------------------------------------------------
 // Two waves per block; a wave's LDS: ref stream (nrd dwords) + query stream (nqd dwords) per lane.
 template <int WB>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WB <= 32 ? 4 : WB <= 64 ? 3 : WB <= 96 ? 2 : 1)))
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WB <= 32 ? 5 : WB <= 64 ? 4 : WB <= 96 ? 3 : 2)))
 void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFastWork wk,
                                                          int cls, int nrd_max, int nqd_max) {
     __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3], s_gap[PAIRS_MAX_LEN + 2];
@@ -183,13 +215,12 @@ void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFast
         L.n_sweep = sq ? L.n : min(L.n, L.m + k);
         L.scan_last = L.n_sweep == L.n;
         const int nrows = wave_max_i32(live ? L.row_last - L.row_first + 1 : 0);
-        const int ninj = min(nrows, wave_max_i32(live ? -L.d_lo - L.row_first + 1 : 0));
         const uint32_t *rp = a.ref_packed + ((size_t)(r >> 6) * a.ref_chunks * 64 + (r & 63)) * 4;
         const uint32_t *qp = a.qry_packed + ((size_t)(r >> 6) * a.qry_chunks * 64 + (r & 63)) * 4;
         const int nrd = min(nrd_max, pf_ref_stream_dwords(nrows)), nqd = min(nqd_max, pf_query_stream_dwords(nrows, WB));
         pf_stage_streams(rs, 64, nrd, qs, 64, nqd, rp, rndw, L.m, a.revcomp != 0, qp, qndw, L.row_first, L.d_lo);
         uint32_t rec[4];
-        pf_band_sweep<WB>(L, nrows, ninj, rs, 64, qs, 64, fp.pp, s_thr, s_gap, rec);
+        pf_band_sweep<WB>(L, nrows, rs, 64, qs, 64, fp.pp, s_thr, s_gap, rec);
         if (live) a.out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     }
 }
@@ -231,13 +262,17 @@ static hipError_t launch_band(const PairFastParams &fp, const PairsFastArgs &a, 
     return hipGetLastError();
 }
 
+// waves per block of P1: four, two for the long reads (whose LDS would leave one block per CU)
+static int myers_waves(int nw) { return nw <= 5 ? 4 : 2; }
+
 template <int NW>
 static hipError_t launch_myers(const PairFastParams &fp, const PairsFastArgs &a, const PairsFastWork &wk, hipStream_t st) {
-    const size_t per_wave = (size_t)PF_TAB_ROWS * NW * 64 * 4 + (size_t)(((a.qry_max_len + 1) * 64 + 3) / 4) * 4;
-    const size_t lds = 4 * per_wave;
+    const size_t per_wave = ((size_t)PF_TAB_ROWS * NW * 64 + (size_t)PF_LIST_CAP * 32) * 4;
+    const int waves = myers_waves(NW);
+    const size_t lds = (size_t)waves * per_wave;
     hipError_t e = hipFuncSetAttribute((const void *)pairs_myers_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pairs_myers_kernel<NW>), dim3(FAST_BLOCKS), dim3(256), lds, st, fp, a, wk);
+    hipLaunchKernelGGL((pairs_myers_kernel<NW>), dim3(FAST_BLOCKS), dim3(64 * waves), lds, st, fp, a, wk);
     return hipGetLastError();
 }
 
@@ -263,7 +298,8 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
     if (e == hipSuccess) {
         hipLaunchKernelGGL(scan_bins_kernel, dim3(SCAN_CHUNKS, PF_BINS / 256), dim3(256), 0, st, wk.fw);
         hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1024), 0, st, wk.fw);
-        hipLaunchKernelGGL(pairs_scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, npairs, wk);
+        hipLaunchKernelGGL(pairs_scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, npairs,
+                           myers_waves(rmax <= 160 ? 5 : rmax <= 256 ? 8 : 10), wk);
         e = hipGetLastError();
     }
     // one launch per band class (which classes hold tasks is only known on the device; an empty class returns at once)

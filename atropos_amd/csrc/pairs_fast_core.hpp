@@ -49,7 +49,7 @@ constexpr int PF_ROW_BIN_SHIFT = 12;
 constexpr int PF_FALLBACK_BIN = PF_CLASSES * PF_ROW_BINS;        // pairs for the full sweep
 constexpr int PF_BINS = 256;                        // histogram width (a multiple of 256 for the scan kernels)
 constexpr int PF_MAX_K = 126;                       // costs live in 7 bits of the row-m byte
-constexpr int PF_TAB_ROWS = 8;                      // match masks by pf_code_row: A C G T at 0 .. 3, N at 6 (the rest stay empty)
+constexpr int PF_TAB_ROWS = 5;                      // match masks by pf_code_row: A C G T N
 ATR_DEV int pf_class_width(int cls) { return 16 * (cls + 1); }
 
 struct PairFastParams {
@@ -123,9 +123,14 @@ ATR_DEV void pf_myers_step(PfMyers<NW> &S, const uint32_t (&eq)[NW], uint32_t hi
     }
 }
 
-// table row of a 4-bit DNA15 code: A C G T -> 0 .. 3, N -> 6, eight codes at a time (one per nibble).  Other
-// codes land on some row too; pf_codes_known tells, and such a pair takes the full sweep.
-ATR_DEV uint32_t pf_code_rows8(uint32_t codes) { return ((codes >> 1) & 0x77777777u) - ((codes >> 3) & 0x11111111u); }
+// table row of a 4-bit DNA15 code: A C G T N -> 0 .. 4, eight codes at a time (one per nibble): code / 2 for the
+// one-bit codes 1 2 4, minus one for T (8 -> 3), minus three for N (15 -> 7 -> 4).  Other codes land on some row
+// too (possibly beyond the table); pf_codes_known tells, and such a pair takes the full sweep.
+ATR_DEV uint32_t pf_code_rows8(uint32_t codes) {
+    const uint32_t hi = (codes >> 3) & 0x11111111u;                        // T or N
+    const uint32_t nn = hi & (codes >> 2);                                 // N (bits 3 and 2)
+    return (((codes >> 1) & 0x77777777u) - hi - (nn << 1)) & 0x77777777u;
+}
 ATR_DEV int pf_code_row(uint32_t code) { return (int)(pf_code_rows8(code) & 7u); }
 // are all eight nibbles one of 0 (beyond the read), A C G T (one bit) or N (four bits)?
 ATR_DEV bool pf_codes_known(uint32_t codes) {
@@ -194,8 +199,7 @@ ATR_DEV bool pf_build_masks(uint32_t *tab, int ts, const uint32_t *rp, int ndw, 
         tab[(size_t)(1 * NW + w) * ts] = (pl[1] & ~(pl[0] | pl[2] | pl[3])) | pad;       // C = 2
         tab[(size_t)(2 * NW + w) * ts] = (pl[2] & ~(pl[0] | pl[1] | pl[3])) | pad;       // G = 4
         tab[(size_t)(3 * NW + w) * ts] = (pl[3] & ~(pl[0] | pl[1] | pl[2])) | pad;       // T = 8
-        tab[(size_t)(6 * NW + w) * ts] = all | pad;                                      // N = 15 equals N only (:390-391)
-        tab[(size_t)(4 * NW + w) * ts] = 0u; tab[(size_t)(5 * NW + w) * ts] = 0u; tab[(size_t)(7 * NW + w) * ts] = 0u;
+        tab[(size_t)(4 * NW + w) * ts] = all | pad;                                      // N = 15 equals N only (:390-391)
     }
     return known;
 }
@@ -247,59 +251,72 @@ ATR_DEV void pf_pass2(PfScan &S, int ie, int je, int c, int thr_rows, int gap, i
     }
 }
 
-// crow[j * cs] = min(D[m][j], 255) for j = 1 .. n_sweep; pv / mv = the vertical deltas of column n (only read
-// when scan_last).  need: the caller only cares about alignments with at least this many matches (>= 1).
-template <int NW>
-ATR_DEV void pf_analyse(const uint8_t *crow, int cs, const uint32_t (&pv)[NW], const uint32_t (&mv)[NW], int m, int n,
-                        int n_sweep, bool scan_last, const PairFastParams &fp, const int16_t *thr, const int16_t *g_ap,
-                        const int16_t *g_as, int need, uint32_t pair, PfDecision &D) {
-    const PairParams &p = fp.pp;
-    const bool sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0, er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0;
-    const int p0 = 32 * NW - m, k = (int)thr[m], mo = p.min_overlap;
-    PfScan S;
-    S.mlb = atr_max(need, 1) - 1; S.dbest = 0;
-    S.lo = 0x7fff; S.hi = -0x7fff; S.rl = 0; S.cand_first = 0; S.have = false;
-    // pass 1
-    for (int j = 1; j <= n_sweep; ++j) {
-        const int c = (int)crow[(size_t)j * cs];
-        if (c <= k) pf_pass1(S, m, j, c, k, (int)g_as[j], mo);
+// The candidates that pass the accept-possible test are collected while the costs are computed -- a list of
+// 16-bit entries (cost << 9 | position) per lane, the row-m cells (position = column) first, then the last-column
+// cells (position = row) -- so that the two passes of the analysis only walk the few cells that matter.
+constexpr int PF_LIST_CAP = 96;                     // entries per lane; a pair with more takes the full sweep
+
+ATR_DEV uint32_t pf_entry(int pos, int cost) { return (uint32_t)pos | ((uint32_t)cost << 9); }
+
+// row m, column j (during the sweep): accept-possible  <=>  c <= thr[m] and c <= g_ap[j]
+ATR_DEV void pf_collect_rowm(uint16_t *list, int ls, int &cnt, int j, int score, int lim) {
+    if (score <= lim) {
+        if (cnt < PF_LIST_CAP) list[(size_t)cnt * ls] = (uint16_t)pf_entry(j, score);
+        ++cnt;
     }
-    if (scan_last) {
-        // D[i][n] = D[0][n] + the vertical deltas up to row i; the pads below row 1 carry none.  The word index is
-        // static (pv / mv live in registers), the row of a bit depends on the lane's p0.
-        int d = sq ? 0 : n;
-        const int gas = (int)g_as[n];
+}
+
+// last column: D[i][n] = D[0][n] + the vertical deltas up to row i (the pads below row 1 carry none).  The word index
+// is static (pv / mv live in registers), the row of a bit depends on the lane's p0.
+template <int NW>
+ATR_DEV void pf_collect_lastcol(uint16_t *list, int ls, int &cnt, const uint32_t (&pv)[NW], const uint32_t (&mv)[NW], int m,
+                                int n, bool sq, bool er, const int16_t *thr, int gap_n) {
+    const int p0 = 32 * NW - m;
+    int d = sq ? 0 : n;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            uint32_t pw = pv[w], mw = mv[w];
+    for (int w = 0; w < NW; ++w) {
+        uint32_t pw = pv[w], mw = mv[w];
 #pragma unroll 1
-            for (int b = 0; b < 32; ++b) {
-                const int i = 32 * w + b - p0 + 1;
-                d += (int)(pw & 1u) - (int)(mw & 1u);
-                pw >>= 1; mw >>= 1;
-                if (i >= 1 && (er || i == m)) pf_pass1(S, i, n, d, (int)thr[i], gas, mo);
+        for (int b = 0; b < 32; ++b) {
+            const int i = 32 * w + b - p0 + 1;
+            d += (int)(pw & 1u) - (int)(mw & 1u);
+            pw >>= 1; mw >>= 1;
+            if (i >= 1 && (er || i == m) && d <= gap_n && d <= (int)thr[i]) {
+                if (cnt < PF_LIST_CAP) list[(size_t)cnt * ls] = (uint16_t)pf_entry(i, d);
+                ++cnt;
             }
         }
     }
-    S.mlb = atr_max(S.mlb, atr_max(need, 1));
-    // pass 2
-    for (int j = 1; j <= n_sweep; ++j) {
-        const int c = (int)crow[(size_t)j * cs];
-        if (c <= k) pf_pass2(S, m, j, c, k, (int)g_ap[j], mo, false);
+}
+
+// list[0 .. cnt_row): row-m entries, list[cnt_row .. cnt): last-column entries (cnt <= PF_LIST_CAP).
+// need: the caller only cares about alignments with at least this many matches (>= 1).
+ATR_DEV void pf_analyse(const uint16_t *list, int ls, int cnt_row, int cnt, int nmax, int m, int n, const PairFastParams &fp,
+                        const int16_t *thr, const int16_t *g_ap, const int16_t *g_as, int need, uint32_t pair, PfDecision &D) {
+    const PairParams &p = fp.pp;
+    const int k = (int)thr[m], mo = p.min_overlap;
+    PfScan S;
+    S.mlb = atr_max(need, 1) - 1; S.dbest = 0;
+    S.lo = 0x7fff; S.hi = -0x7fff; S.rl = 0; S.cand_first = 0; S.have = false;
+    // pass 1: the lower bound of the winner's matches (nmax: the wave's largest cnt)
+    for (int e = 0; e < nmax; ++e) {
+        if (e < cnt) {
+            const uint32_t v = list[(size_t)e * ls];
+            const int pos = (int)(v & 511u), c = (int)(v >> 9);
+            const bool lastcol = e >= cnt_row;
+            const int ie = lastcol ? pos : m, je = lastcol ? n : pos;
+            pf_pass1(S, ie, je, c, lastcol ? (int)thr[ie] : k, (int)g_as[je], mo);
+        }
     }
-    if (scan_last) {
-        int d = sq ? 0 : n;
-        const int gap = (int)g_ap[n];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            uint32_t pw = pv[w], mw = mv[w];
-#pragma unroll 1
-            for (int b = 0; b < 32; ++b) {
-                const int i = 32 * w + b - p0 + 1;
-                d += (int)(pw & 1u) - (int)(mw & 1u);
-                pw >>= 1; mw >>= 1;
-                if (i >= 1 && (er || i == m)) pf_pass2(S, i, n, d, (int)thr[i], gap, mo, true);
-            }
+    S.mlb = atr_max(S.mlb, atr_max(need, 1));
+    // pass 2: the threats (every entry is accept-possible already)
+    for (int e = 0; e < nmax; ++e) {
+        if (e < cnt) {
+            const uint32_t v = list[(size_t)e * ls];
+            const int pos = (int)(v & 511u), c = (int)(v >> 9);
+            const bool lastcol = e >= cnt_row;
+            const int ie = lastcol ? pos : m, je = lastcol ? n : pos;
+            pf_pass2(S, ie, je, c, lastcol ? (int)thr[ie] : k, (int)g_ap[je], mo, lastcol);
         }
     }
     D.cls = 0;
@@ -378,29 +395,39 @@ struct PfBandLane {
     bool scan_last, live;
 };
 
-// The row-major sweep of one lane over `nrows` rows from its own row_first on (the wave's trip count; rows
-// beyond a lane's row_last or m compute cells nobody looks at).  rs / qs: the lane's reference codes and
-// query bases as streams of eight 4-bit codes per dword: nibble t of rs = the code of row row_first + t,
-// nibble s of qs = the base of column row_first + d_lo + s (0 outside the read).
-// ninj (wave-uniform): the leading rows in which some lane's band still touches column 0.
+// The row-major sweep of one lane over its rows row_first .. row_last (`nrows` = the wave's trip count; a lane
+// that has done its own rows keeps its last row).  rs / qs: the lane's reference codes and query bases as
+// streams of eight 4-bit codes per dword: nibble t of rs = the code of row row_first + t, nibble s of qs = the
+// base of column row_first + d_lo + s, 0 outside the read.
+// Column 0 without special cases: code 0 (the columns j <= 0 and those behind the read) matches every row, and
+// the band starts from VIRTUAL cells left of the matrix -- with START_WITHIN_SEQ1 cost 0 and origin j - i (the
+// diagonal through them reaches column 0 in the cell (i - j, 0) = cost 0, origin -(i - j): _align.pyx:343-346,
+// :349-352), else unreachable, so that column 0 holds the i insertions from (0, 0) (:336-342, :347-348).
 template <int WB>
-ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, int ninj, const uint32_t *rs, int rss, const uint32_t *qs, int qss,
+ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, const uint32_t *rs, int rss, const uint32_t *qs, int qss,
                            const PairParams &p, const int16_t *thr, const int16_t *g_ap, uint32_t rec[4]) {
     constexpr int NQ = WB / 8;
     const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
     const uint32_t insw = COST1 + PRIO_INS, delw = COST1 + PRIO_DEL;
     const int m = L.m, n = L.n;
     uint32_t cell[WB];
-    // the row before the first: row 0 (cost 0 or j, origin j; :385-388) when the sweep starts at row 1, else
-    // nothing of the band exists yet
+    {   // the row before the first (row i0 = row_first - 1)
+        const int i0 = L.row_first - 1;
 #pragma unroll
-    for (int c = 0; c < WB; ++c) {
-        const int j = L.d_lo + c;
-        uint32_t w = PF_INF;
-        if (L.row_first == 1 && j >= 0)
-            w = sq ? ((uint32_t)PAIRS_ORG_BIAS + (uint32_t)j)
-                   : ((uint32_t)PAIRS_ORG_BIAS | ((uint32_t)atr_min(j, INIT_COST_CAP) << CSH));
-        cell[c] = w;
+        for (int c = 0; c < WB; ++c) {
+            const int j = i0 + L.d_lo + c;
+            uint32_t w = PF_INF;
+            if (j > 0) {
+                if (i0 == 0)                          // row 0: cost 0 or j, origin j (:385-388)
+                    w = sq ? ((uint32_t)PAIRS_ORG_BIAS + (uint32_t)j)
+                           : ((uint32_t)PAIRS_ORG_BIAS | ((uint32_t)atr_min(j, INIT_COST_CAP) << CSH));
+            } else if (sr) {
+                if (j - i0 >= -m) w = (uint32_t)(PAIRS_ORG_BIAS + j - i0);       // cost 0, origin j - i0
+            } else if (j == 0) {
+                w = (uint32_t)PAIRS_ORG_BIAS | ((uint32_t)atr_min(i0, INIT_COST_CAP) << CSH);   // (i0, 0): i0 insertions
+            }
+            cell[c] = w;
+        }
     }
     Best bl, bm;                                     // last-column candidates / row-m candidates
     bl.key = COST_FIELD_MAX - (m + n);
@@ -409,39 +436,23 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, int ninj, const uint3
     bm = bl;
     const bool er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0;
     const int gap_n = (int)g_ap[n];
+    const int own_rows = L.live ? L.row_last - L.row_first + 1 : 0;
     uint32_t qw[NQ + 1];
 #pragma unroll
     for (int t = 0; t <= NQ; ++t) qw[t] = qs[(size_t)t * qss];
     uint32_t rw = rs[0];
 #pragma unroll 1
     for (int t = 0; t < nrows; ++t) {
-        const int i = L.row_first + t;
-        const uint32_t code = rw & 15u;
-        uint32_t rrep = code | (code << 4);
-        rrep |= rrep << 8;
-        rrep |= rrep << 16;
-        uint32_t mis[NQ];
+        if (t < own_rows) {
+            const int i = L.row_first + t;
+            const uint32_t code = rw & 15u;
+            uint32_t rrep = code | (code << 4);
+            rrep |= rrep << 8;
+            rrep |= rrep << 16;
+            uint32_t mis[NQ];
 #pragma unroll
-        for (int g = 0; g < NQ; ++g) mis[g] = pf_nibble_any(qw[g] ^ rrep);          // nibble != 0, at bit 3
-        uint32_t left = PF_INF;
-        if (t < ninj) {                              // wave-uniform
-            // column 0 of this row sits at band index c0 (cost 0 / origin -i with START_WITHIN_SEQ1, else cost i:
-            // :333-352); the cells left of it do not exist
-            const int c0 = -L.d_lo - i;
-            const uint32_t col0 = init_word(i, 0, sr, sq, 1) + (uint32_t)(PAIRS_ORG_BIAS - (int)ORG_BIAS);
-#pragma unroll
-            for (int c = 0; c < WB; ++c) {
-                const uint32_t bit = atr_bfe1(mis[c >> 3], 4 * (c & 7) + 3);
-                const uint32_t cd = atr_mad24(bit, COST1 + MATCH1, cell[c]);
-                uint32_t up = c + 1 < WB ? cell[c + 1 < WB ? c + 1 : 0] : PF_INF;
-                pf_opaque(up);                       // (else `up + insw` of all cells is hoisted above both row variants)
-                uint32_t nw = atr_minu(atr_minu(cd, left + delw), up + insw) & ~PRIO_MASK;
-                if (c <= c0) nw = c == c0 ? col0 : PF_INF;
-                cell[c] = nw;
-                left = nw;
-                if ((c & 7) == 7) pf_sched_fence();
-            }
-        } else {
+            for (int g = 0; g < NQ; ++g) mis[g] = pf_nibble_any(qw[g] ^ rrep) & pf_nibble_any(qw[g]);   // differs, and is a base
+            uint32_t left = PF_INF;
 #pragma unroll
             for (int c = 0; c < WB; ++c) {
                 const uint32_t bit = atr_bfe1(mis[c >> 3], 4 * (c & 7) + 3);
@@ -452,31 +463,17 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, int ninj, const uint3
                 left = nw;
                 if ((c & 7) == 7) pf_sched_fence();
             }
-        }
-        // last-column candidate of this row (:461-474, rows in increasing order): only the threats -- their
-        // payload is the reference's; any other cell fails the threat test with its own (never too low) cost
-#ifndef PF_NO_LASTCOL
-        if (L.live && L.scan_last && L.cand_first != 0 && i >= L.cand_first && i <= L.row_last && (er || i == m)) {
-            const int cn = n - L.d_lo - i;
-            if (cn >= 0 && cn < WB) {
-                const uint32_t w = pf_pick<WB>(cell, cn);
-                if (pf_is_threat(i, n, (int)(w >> CSH), (int)thr[i], gap_n, p.min_overlap, L.mlb))
-                    consider<true, PAIRS_ORG_BIAS>(bl, w, i, n, p.min_overlap, thr, 1);
+            // last-column candidate of this row (:461-474, rows in increasing order): only the threats -- their
+            // payload is the reference's; any other cell fails the threat test with its own (never too low) cost
+            if (L.scan_last && L.cand_first != 0 && i >= L.cand_first && (er || i == m)) {
+                const int cn = n - L.d_lo - i;
+                if (cn >= 0 && cn < WB) {
+                    const uint32_t w = pf_pick<WB>(cell, cn);
+                    if (pf_is_threat(i, n, (int)(w >> CSH), (int)thr[i], gap_n, p.min_overlap, L.mlb))
+                        consider<true, PAIRS_ORG_BIAS>(bl, w, i, n, p.min_overlap, thr, 1);
+                }
             }
         }
-#endif
-#ifndef PF_NO_ROWM
-        // row m: its cells in column order (:433-455)
-        if (L.live && i == m) {
-            const int km = (int)thr[m];
-#pragma unroll
-            for (int c = 0; c < WB; ++c) {
-                const int j = m + L.d_lo + c;
-                if (j >= 1 && j <= L.n_sweep && pf_is_threat(m, j, (int)(cell[c] >> CSH), km, (int)g_ap[j], p.min_overlap, L.mlb))
-                    consider<true, PAIRS_ORG_BIAS>(bm, cell[c], m, j, p.min_overlap, thr, 1);
-            }
-        }
-#endif
         // next row: slide the window by one base, next reference code
 #pragma unroll
         for (int g = 0; g < NQ; ++g) qw[g] = (qw[g] >> 4) | (qw[g + 1] << 28);
@@ -485,6 +482,16 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, int ninj, const uint3
         if ((t & 7) == 7) {
             qw[NQ] = qs[(size_t)(NQ + 1 + (t >> 3)) * qss];
             rw = rs[(size_t)(1 + (t >> 3)) * rss];
+        }
+    }
+    // row m (the last row of the lanes that have row-m threats): its cells in column order (:433-455)
+    if (L.live && L.row_last == m) {
+        const int km = (int)thr[m];
+#pragma unroll
+        for (int c = 0; c < WB; ++c) {
+            const int j = m + L.d_lo + c;
+            if (j >= 1 && j <= L.n_sweep && pf_is_threat(m, j, (int)(cell[c] >> CSH), km, (int)g_ap[j], p.min_overlap, L.mlb))
+                consider<true, PAIRS_ORG_BIAS>(bm, cell[c], m, j, p.min_overlap, thr, 1);
         }
     }
     if (bm.key >= bl.key) bl = bm;                   // the reference sees the row-m cells first: they keep ties

@@ -252,7 +252,11 @@ extern "C" int atr_locate_pairs_need_batch(const uint8_t *d_ref_packed, const in
     if (npairs == 0) return ATR_OK;
     if (!d_out || (ref_max_len > 0 && !d_ref_packed) || (query_max_len > 0 && !d_query_packed)) return ATR_ERR_INVALID;
     const uint32_t *rp = (const uint32_t *)d_ref_packed, *qp = (const uint32_t *)d_query_packed;
-    if (pairs_fast_applies(max_error_rate, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, query_max_len) &&
+    // Reads of more than 160 bases without a caller's bound on the matches: their bands (2 k + 1 diagonals on either
+    // side of the overlap's end, k = 50 at 250 bases) cost as much as the whole matrix -- measured 66 M pairs/s
+    // against 76 M on 2 x 250 bp -- so they keep the full sweep; with d_need most pairs end after the cost pass.
+    const bool worth = ref_max_len <= 160 || d_need != nullptr;
+    if (worth && pairs_fast_applies(max_error_rate, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, query_max_len) &&
         npairs < (1ll << 32)) {
         // costs by bit-vector, threats, banded payload (pairs_fast_core.hpp); pairs outside its envelope take the
         // full sweep inside the same call

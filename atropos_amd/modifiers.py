@@ -367,8 +367,10 @@ class MergeOverlapping(ReadPairModifier, ErrorCorrectorMixin):
             for i in idx:
                 reverse_complement(out[i][1].sequence)       # KeyError on a base without complement, as the reference
             # reference = reverse_complement(read2) (formed on the device), query = read1
+            # (need: an alignment with fewer matches is not looked at below -- the library may then report None)
             alignments = self._aligner(flags).locate_batch([out[i][1].sequence for i in idx],
-                                                           [out[i][0].sequence for i in idx]).tuples()
+                                                           [out[i][0].sequence for i in idx],
+                                                           need=[t[1] for t in todo]).tuples()
             for (i, need, insert_matched), alignment in zip(todo, alignments):
                 if alignment and alignment[4] >= need:
                     out[i] = self._merge(out[i][0], out[i][1], alignment, insert_matched)

@@ -434,8 +434,10 @@ class PairedTrimPipeline(object):
                 raise ValueError("%d read(s) contain characters the device pair aligner has no 4-bit code for (upper-case "
                                  "IUPAC letters, or A C G T N W B D H V in either case)" % bad)
             (rp, rl, rmax), (qp, ql, qmax) = packs
+            # the merge below only looks at alignments with matches >= need (modifiers.py:896-897)
+            need_g = need.to(torch.int32) if idx.numel() == n else need.to(torch.int32).index_select(0, idx)
             rec = be.locate_pairs_batch(rp, rl, rmax, True, qp, ql, qmax, int(idx.numel()), self.merge_error_rate, flags,
-                                        False, False, 1, 1)
+                                        False, False, 1, 1, need=need_g.contiguous())
             if idx.numel() == n:
                 align = rec
             else:

@@ -1291,9 +1291,16 @@ def check_pairs_fast(PairAligner, oracle, seed, rounds, top=150, npairs=96, adve
             qrys.append(qry or "C")
         given = [reverse_complement(r) for r in refs] if rc else refs
         pa = PairAligner(e, flags, False, False, mo, 1, revcomp_ref=rc)
-        got = pa.locate_batch(given, qrys).tuples()
-        for ref, qry, g in zip(refs, qrys, got):
+        # need = 1: every alignment matters (and reads of more than 160 bases take the fast pipeline as well)
+        got = pa.locate_batch(given, qrys, need=[1] * len(refs)).tuples()
+        nd = rng.choice([2, 10, top // 3, top // 2])
+        part = pa.locate_batch(given, qrys, need=[nd] * len(refs)).tuples()
+        for ref, qry, g, h in zip(refs, qrys, got, part):
             exp = oracle.locate(ref, qry, e, flags, False, False, mo, 1)
             assert g == exp, (ref, qry, e, flags, mo, rc, g, exp)
+            if exp is not None and exp[4] >= nd:
+                assert h == exp, (ref, qry, e, flags, mo, rc, nd, h, exp)       # an alignment that reaches the bound is exact
+            else:
+                assert h is None or h[4] < nd, (nd, h, exp)
             total += 1
     return total

@@ -170,24 +170,26 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
     const int k = (int)p.thr[m];
     const int n_sweep = sq ? n : std::min(n, m + k);                   // _align.pyx:314-321
     const bool scan_last = n_sweep == n;
-    std::vector<uint8_t> crow((size_t)n + 2, 255);
+    std::vector<uint16_t> list(PF_LIST_CAP);
+    int cnt = 0;
     PfMyers<NW> S;
     pf_myers_init<NW>(S, m, sr);
-    uint32_t pvn[NW], mvn[NW];
     for (int j = 1; j <= n_sweep; ++j) {
         const uint32_t code = packed_code(qp, j - 1);
         known = known && pf_codes_known(code);
-        const int row = pf_code_row(code);
+        const int row = std::min(pf_code_row(code), PF_TAB_ROWS - 1);      // (an unknown code: the pair falls back anyway)
         uint32_t eq[NW];
         for (int w = 0; w < NW; ++w) eq[w] = tab[row * NW + w];
         pf_myers_step<NW>(S, eq, sq ? 0u : 1u);
-        crow[j] = (uint8_t)std::min(S.score, 255);
+        pf_collect_rowm(list.data(), 1, cnt, j, S.score, std::min(k, (int)fp.g_ap[j]));
     }
     for (int j = n_sweep + 1; j <= n; ++j) known = known && pf_codes_known(packed_code(qp, j - 1));
-    for (int w = 0; w < NW; ++w) { pvn[w] = S.pv[w]; mvn[w] = S.mv[w]; }
-    if (!known) { ++emu_pairs_fast_stats[2]; return false; }
+    const int cnt_row = cnt;
+    if (scan_last)
+        pf_collect_lastcol<NW>(list.data(), 1, cnt, S.pv, S.mv, m, n, sq, (p.flags & ATR_STOP_WITHIN_SEQ1) != 0, p.thr, (int)fp.g_ap[n]);
+    if (!known || cnt > PF_LIST_CAP) { ++emu_pairs_fast_stats[2]; return false; }
     PfDecision D;
-    pf_analyse<NW>(crow.data(), 1, pvn, mvn, m, n, n_sweep, scan_last, fp, p.thr, fp.g_ap, fp.g_as, need, pair, D);
+    pf_analyse(list.data(), 1, cnt_row, cnt, cnt + (emu_pairs_fast_widen ? 5 : 0), m, n, fp, p.thr, fp.g_ap, fp.g_as, need, pair, D);
     if (emu_pairs_fast_debug && D.kind == 2) fprintf(stderr, "pair %u wide: lo %d hi %d mlb %d rl %d\n", pair, D.task.d_lo, D.task.row_first, D.task.mlb, D.task.row_last);
     if (emu_pairs_fast_debug)
         fprintf(stderr, "pair %u m %d n %d kind %d cls %d d_lo %d rf %d rl %d mlb %d cand_first %d\n", pair, m, n,
@@ -207,19 +209,18 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
     const int wb = pf_class_width(cls);
     int nrows = std::max(0, (int)L.row_last - (int)L.row_first + 1);
     if (emu_pairs_fast_widen) nrows += 9;
-    const int ninj = std::min(nrows, std::max(0, -L.d_lo - L.row_first + 1) + (emu_pairs_fast_widen ? 3 : 0));
     const int nrd = pf_ref_stream_dwords(nrows), nqd = pf_query_stream_dwords(nrows, wb);
     std::vector<uint32_t> rs((size_t)nrd + 1), qs((size_t)nqd + 1);
     pf_stage_streams(rs.data(), 1, nrd, qs.data(), 1, nqd, rp, rndw, m, revcomp, qp, qndw, L.row_first, L.d_lo);
     switch (cls) {
-        case 0: pf_band_sweep<16>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 1: pf_band_sweep<32>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 2: pf_band_sweep<48>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 3: pf_band_sweep<64>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 4: pf_band_sweep<80>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 5: pf_band_sweep<96>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 6: pf_band_sweep<112>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        default: pf_band_sweep<128>(L, nrows, ninj, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 0: pf_band_sweep<16>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 1: pf_band_sweep<32>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 2: pf_band_sweep<48>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 3: pf_band_sweep<64>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 4: pf_band_sweep<80>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 5: pf_band_sweep<96>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 6: pf_band_sweep<112>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        default: pf_band_sweep<128>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
     }
     ++emu_pairs_fast_stats[1];
     return true;

@@ -127,3 +127,23 @@ def test_long_reference(emu_backend):
     from atropos_amd._lib import AtroposHipError
     from oracle import oracle
     assert _cases.check_long_reference(Aligner, oracle, AtroposHipError) > 400
+
+
+def test_pairs_fast_pipeline(emu_backend, oracle):
+    """pairs_fast_core.hpp (bit-vector costs, threat analysis, banded payload DP) through the CPU twin: the settings
+    the fast pipeline takes, with and without a bound on the matches, three mask-word counts, and -- widen -- the
+    banded pass run wider and longer than a pair needs, as in a wave whose other lanes need more."""
+    import ctypes as C
+    from atropos_amd.align import PairAligner
+    stats = (C.c_longlong * 4).in_dll(emu_backend.lib, "emu_pairs_fast_stats")
+    widen = C.c_int.in_dll(emu_backend.lib, "emu_pairs_fast_widen")
+    for i in range(4):
+        stats[i] = 0
+    try:
+        for w, (seed, rounds, top, npairs) in enumerate(((5, 25, 150, 64), (6, 8, 250, 48), (7, 6, 320, 40), (8, 30, 40, 96))):
+            widen.value = w % 2
+            assert _cases.check_pairs_fast(PairAligner, oracle, seed, rounds, top=top, npairs=npairs) == rounds * npairs
+    finally:
+        widen.value = 0
+    none, band, full, _ = list(stats)
+    assert band > 2000 and none > 1000 and full < band          # the banded pass is what most pairs with an alignment take

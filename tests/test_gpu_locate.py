@@ -175,7 +175,8 @@ def test_pairs_fast_at_size(hip_backend, oracle):
             be = _lib.get_backend()
             rb = pa._pack(w["reads2"], _lib.TABLE_DNA15, be, True)
             qb = pa._pack(w["reads1"], _lib.TABLE_DNA15, be, True)
-            got = pa.locate_batch(rb, qb).records
+            # need = 1 everywhere: every alignment matters, and the long reads take the fast pipeline too
+            got = pa.locate_batch(rb, qb, need=torch.ones((n,), dtype=torch.int32, device="cuda")).records
             lo = 123_456
             r1 = w["reads1"][lo:lo + k].cpu().numpy()
             r2 = w["reads2"][lo:lo + k].cpu().numpy()
@@ -186,6 +187,13 @@ def test_pairs_fast_at_size(hip_backend, oracle):
                 assert g == exp, (config, flags, lo + i, g, exp)
             full = be.locate_pairs_full_batch(rb.packed, rb.lens, rb.max_len, True, qb.packed, qb.lens, qb.max_len, n, 0.2, flags, 1, 1)
             assert torch.equal(got, full), (config, flags)
+            # with a bound on the matches: the pairs that reach it keep their record, the others may turn into None
+            need = torch.full((n,), 100 if config == "C3" else 180, dtype=torch.int32, device="cuda")
+            part = pa.locate_batch(rb, qb, need=need).records
+            reach = (full[:, 1] >= 0) & (full[:, 4] >= need.to(torch.int16))
+            assert torch.equal(part[reach], full[reach]) and int(reach.sum()) > n // 10
+            rest = part[~reach]
+            assert bool(((rest[:, 1] < 0) | (rest[:, 4] < need[~reach].to(torch.int16))).all())
 
 
 def test_single_process_multi_stream(hip_backend):
