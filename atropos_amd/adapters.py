@@ -420,19 +420,47 @@ class LinkedAdapter(object):
 _SPEC = re.compile(r"^(?:(?P<name>[^=]*)=)?\s*(?P<hat>\^)?(?P<body>.*?)(?P<dollar>\$)?\s*$", re.S)
 
 
+def fasta_records(path):
+    """(header, sequence) of every record of a FASTA file as the adapter parser needs them: lines are
+    stripped (DOS line ends too), blank lines and ``#`` comment lines skipped, wrapped sequences joined; text
+    before the first ``>`` is an error (reference: FastaReader.__iter__, io/seqio.py:251-280).  Plain or
+    gzip-compressed text."""
+    import gzip
+    opener = gzip.open if str(path).endswith(".gz") else open
+    header, parts = None, []
+    with opener(path, "rt") as handle:
+        for number, raw in enumerate(handle, 1):
+            line = raw.strip()
+            if not line or (line[0] == '#'):
+                continue
+            if line[0] == '>':
+                if header is not None:
+                    yield header, "".join(parts)
+                header, parts = line[1:], []
+            elif header is None:
+                from .fastq import FormatError
+                shown = line if len(line) <= 100 else line[:97] + "..."       # util.truncate_string
+                raise FormatError("At line {0}: Expected '>' at beginning of FASTA record, but got {1!r}.".format(number, shown))
+            else:
+                parts.append(line)
+    if header is not None:
+        yield header, "".join(parts)
+
+
 class AdapterParser(object):
     """Factory for Adapter objects that all share the same parameters (error rate, indels
     ...); ``**kwargs`` go to the Adapter constructors.  Supports the command-line
     notation: ``name=SEQ``, ``^SEQ`` (anchored 5'), ``SEQ$`` (anchored 3'),
-    ``SEQ1...SEQ2`` (linked).  (``file:`` specs, colorspace and the adapter cache are out
-    of scope.)"""
+    ``SEQ1...SEQ2`` (linked), and ``file:PATH`` -- one adapter per record of a FASTA file, named by the
+    first word of its header.  (Colorspace and the adapter cache are out of scope.)"""
 
     def __init__(self, **kwargs):
         self.constructor_args = kwargs
 
     def parse(self, spec, cmdline_type='back'):
-        if spec.startswith('file:'):
-            raise NotImplementedError("file: adapter specs need the FASTA reader, which is out of scope")
+        if spec.startswith('file:'):                  # adapters/__init__.py:113-119
+            return (self.parse_from_spec(sequence, cmdline_type, header.split(None, 1)[0])
+                    for header, sequence in fasta_records(spec[5:]))
         return iter([self.parse_from_spec(spec, cmdline_type)])
 
     def parse_from_spec(self, spec, cmdline_type='back', name=None):

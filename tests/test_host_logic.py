@@ -71,3 +71,37 @@ def test_set_backend_refuses_stand_ins():
         assert _lib.set_backend(Fake(), _test_double=True) is None
     finally:
         _lib.set_backend(prev, _test_double=True)
+
+
+def test_file_adapter_specs(tmp_path, emu_backend):
+    """`file:PATH` adapter specs (adapters/__init__.py:113-119 over FastaReader, io/seqio.py:251-280): one adapter per
+    FASTA record, named by the first word of the header; wrapped sequences, comments, blank and DOS lines."""
+    import gzip
+    from atropos_amd.adapters import AdapterParser, fasta_records, BACK, PREFIX
+    from atropos_amd.fastq import FormatError
+    text = ">first adapter one\r\nAGATCGGAAG\nAGCACACG\n\n# a comment\n>second\nTTAGACATAT\n>empty\n>anch\n^ACGTACGT\n"
+    path = tmp_path / "adapters.fa"
+    path.write_text(text)
+    assert list(fasta_records(str(path))) == [("first adapter one", "AGATCGGAAGAGCACACG"), ("second", "TTAGACATAT"),
+                                             ("empty", ""), ("anch", "^ACGTACGT")]
+    with gzip.open(str(path) + ".gz", "wt") as fh:
+        fh.write(text)
+    assert list(fasta_records(str(path) + ".gz")) == list(fasta_records(str(path)))
+    good = tmp_path / "good.fa"
+    good.write_text(">first adapter one\nAGATCGGAAG\nAGCACACG\n>anch\n^ACGTACGT\n")
+    ads = list(AdapterParser(max_error_rate=0.1).parse("file:" + str(good), "front"))
+    assert [(a.name, a.sequence, a.where) for a in ads[1:]] == [("anch", "ACGTACGT", PREFIX)]
+    assert ads[0].name == "first" and ads[0].sequence == "AGATCGGAAGAGCACACG"
+    back = tmp_path / "back.fa"
+    back.write_text(">a1\nAGATCGGAAG\n>a2 second\nTTAGACATAT$\n")
+    ads = AdapterParser(max_error_rate=0.1).parse_multi(["file:" + str(back), "GGGG"], [], [])
+    assert [(a.name, a.sequence) for a in ads[:2]] == [("a1", "AGATCGGAAG"), ("a2", "TTAGACATAT")] and len(ads) == 3
+    assert ads[0].where == BACK and ads[1].where != BACK
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>x\nACGT\n")
+    try:
+        list(fasta_records(str(bad)))
+    except FormatError as exc:
+        assert str(exc) == "At line 1: Expected '>' at beginning of FASTA record, but got 'ACGT'."
+    else:
+        raise AssertionError("no FormatError")
