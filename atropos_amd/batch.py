@@ -13,13 +13,22 @@ from . import _lib
 
 def _as_ascii_matrix(reads):
     """list of str/bytes -> (uint8 ndarray [n, max_len], int32 lens)."""
-    rows = [r.encode("ascii") if isinstance(r, str) else bytes(r) for r in reads]
-    lens = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
-    max_len = int(lens.max()) if len(rows) else 0
-    mat = np.zeros((len(rows), max(max_len, 1)), dtype=np.uint8)
-    for i, r in enumerate(rows):
-        if r:
-            mat[i, :len(r)] = np.frombuffer(r, dtype=np.uint8)
+    n = len(reads)
+    if n and all(isinstance(r, str) for r in reads):
+        flat = "".join(reads).encode("ascii")             # one pass in C (UnicodeEncodeError as the per-read encode)
+        lens = np.fromiter(map(len, reads), dtype=np.int32, count=n)
+    else:
+        rows = [r.encode("ascii") if isinstance(r, str) else bytes(r) for r in reads]
+        flat = b"".join(rows)
+        lens = np.fromiter(map(len, rows), dtype=np.int32, count=n)
+    max_len = int(lens.max()) if n else 0
+    width = max(max_len, 1)
+    data = np.frombuffer(flat, dtype=np.uint8)
+    if n and int(lens.min()) == max_len and max_len > 0:  # equal lengths: the text IS the matrix
+        return data.reshape(n, max_len).copy(), lens
+    mat = np.zeros((n, width), dtype=np.uint8)
+    if data.size:
+        mat[np.arange(width, dtype=np.int32)[None, :] < lens[:, None]] = data      # row-major fill of the ragged rows
     return mat, lens
 
 
@@ -91,6 +100,8 @@ class ReadBatch(object):
             if table is None:
                 table = be.translate_table(table_kind)
             return cls(be.empty((16,), torch.uint8), None, 0, 0, table_kind, table)
+        if int(lens.min()) == mat.shape[1]:               # equal lengths: no length array (the kernels' uniform path)
+            lens = None
         return cls.from_ascii(mat, lens, None, table_kind, table, backend)
 
 
@@ -113,5 +124,5 @@ class LocateResult(object):
 
     def tuples(self):
         """List of 6-tuples / None, exactly what per-read ``locate`` calls return."""
-        arr = self.numpy()
-        return [None if row[1] < 0 else tuple(int(v) for v in row[:6]) for row in arr]
+        rows = self.numpy()[:, :6].tolist()               # one conversion in C instead of six int() calls per read
+        return [None if row[1] < 0 else tuple(row) for row in rows]

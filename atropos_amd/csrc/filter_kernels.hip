@@ -4,6 +4,8 @@
 
 namespace atr {
 
+constexpr long long FAST_SERIAL_READS = 65536;       // "short batch": no side stream, a wave per few tasks
+
 window_launcher window_group_0(int), window_group_1(int), window_group_2(int), window_group_3(int);
 
 static BandParams band_params(const atr_aligner *a) {
@@ -53,7 +55,7 @@ static const window_group_fn window_groups[4] = {window_group_0, window_group_1,
 
 // K2a + K2b over wk.nbins bins
 void launch_fast_scan(FastWork wk, hipStream_t st) {
-    hipLaunchKernelGGL(scan_bins_kernel, dim3(SCAN_CHUNKS, wk.nbins / 256), dim3(256), 0, st, wk);
+    hipLaunchKernelGGL(scan_bins_kernel, dim3((wk.nused + SCAN_CHUNK - 1) / SCAN_CHUNK, wk.nbins / 256), dim3(256), 0, st, wk);
     hipLaunchKernelGGL(scan_total_kernel, dim3(1), dim3(1024), 0, st, wk);
 }
 
@@ -70,6 +72,25 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
     static thread_local SideStream side[DP_STREAMS];
     if (count < 1 || count > DP_STREAMS || idx < 0 || idx >= count) return (int)hipErrorInvalidValue;
     hipError_t e = hipSuccess;
+    // a short batch (the <= 1000 reads the unchanged trim command hands over per call) leaves most of the chip
+    // idle anyway: the fork / join events would cost more than the overlap gives, both DP kernels go to `st`
+    const bool serial = count == 1 && nreads <= FAST_SERIAL_READS;
+    if (serial) {
+        const BandParams bp = band_params(a);
+        const dim3 bgrid((unsigned)std::max<long long>(1, std::min<long long>((nreads + 3) / 4, 4096)));
+        const LinkedArgs none = la ? *la : no_linked_args();
+        if (la) {
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+        } else {
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+        }
+        e = hipGetLastError();
+        if (e != hipSuccess) return (int)e;
+        const int mts = round_up_rows(a->p.m) / ROW_GRAN - 1;
+        return window_groups[mts / 4](mts % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st);
+    }
     if (idx == 0) {
         for (int k = 0; k < count; ++k) if (!side[k].ready()) return (int)hipErrorInvalidValue;
         e = hipEventRecord(side[0].fork, st);
@@ -107,9 +128,11 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st) {
     FastWork wk = fast_carve(work, nreads);
+    wk.nused = fast_blocks_for((nreads + 63) / 64);
+    wk.lpw = nreads <= 8192 ? 0 : 64;
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
     const bool wide = fp.rows > 32, ragged = lens != nullptr;
-    const dim3 grid(FAST_BLOCKS), block(256);
+    const dim3 grid(wk.nused), block(256);
     if (wide) {
         if (ragged) hipLaunchKernelGGL((filter_kernel<true, true>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
         else        hipLaunchKernelGGL((filter_kernel<true, false>), grid, block, 0, st, a->p, fp, packed, lens, nreads, nchunks, max_len, out, wk);
@@ -119,7 +142,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     }
     launch_fast_scan(wk, st);
     // the same bin rule as K1's histogram (filter_kernel): row-count bins also for ragged batches when tail mode applies
-    hipLaunchKernelGGL(scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, nreads, a->p.m,
+    hipLaunchKernelGGL(scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m,
                        (!ragged || !(a->flags & ATR_START_WITHIN_SEQ1)) ? 1 : 0, wk);        // == ragged_rows_bins(u.sr)
     // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
     // joined after K4, so that its waves (latency bound: three dependent gathers per task) share

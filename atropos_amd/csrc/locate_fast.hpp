@@ -41,6 +41,10 @@ struct FastWork {                                    // carve-up of the caller's
     uint32_t *binbase;                               // [nbins + 1] first slot of each bin after K2b; [nbins] = total
     uint32_t *total;                                 // [1] number of unresolved reads
     int nbins;                                       // FILTER_BINS, or FILTER_BINS per adapter of a linked set
+    int nused;                                       // blocks K1 / K3 are launched with (FAST_BLOCKS; fewer for a short batch:
+                                                     // the scans then only walk the histogram rows that exist)
+    int lpw;                                         // tasks a wave of the DP kernels takes: 64, or 0 = as few as the grid
+                                                     // allows (short batches, dp_lanes_per_wave)
 };
 
 inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
@@ -57,6 +61,8 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.binbase = w.chunks + (size_t)(FAST_BLOCKS / 64) * nbins;          // SCAN_CHUNKS rows (SCAN_CHUNK = 64, below)
     w.total = w.binbase + nbins + 1;
     w.nbins = nbins;
+    w.nused = FAST_BLOCKS;
+    w.lpw = 64;
     return w;
 }
 
@@ -69,9 +75,26 @@ struct LinkedArgs {
     LinkedPost post;
 };
 
-// tiles [t0, t1) owned by a block of the persistent grid
-__device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, long long &t1) {
-    const long long per = (ntiles + FAST_BLOCKS - 1) / FAST_BLOCKS;
+// blocks a batch of ntiles tiles keeps busy with four waves each (K1 / K3 of a short batch are launched with these)
+inline int fast_blocks_for(long long ntiles) {
+    return (int)std::max<long long>(1, std::min<long long>(FAST_BLOCKS, (ntiles + 3) / 4));
+}
+
+// Tasks per wave of a DP kernel (K4a / K4) for a SHORT batch: the smallest power of two that still gives every
+// wave of the grid work.  A wave sweeps the union of its tasks' windows, one task per lane: a short batch leaves
+// most SIMDs idle, so fewer lanes per wave mean shorter sweeps on more SIMDs (1000 reads: 101 -> 89 us per call).
+// Not for long batches -- there the chip is VALU-bound and more, emptier waves only add instructions (tried on
+// C2's 48 k window reads: 0.92 -> 1.06 ms).
+__device__ __forceinline__ int dp_lanes_per_wave(long long tasks, long long grid_waves, int fixed) {
+    if (fixed) return fixed;
+    int lpw = 1;
+    while (lpw < 64 && (long long)lpw * grid_waves < tasks) lpw <<= 1;
+    return lpw;
+}
+
+// tiles [t0, t1) owned by a block of the persistent grid of `nblocks` blocks
+__device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, long long &t1, int nblocks = FAST_BLOCKS) {
+    const long long per = (ntiles + nblocks - 1) / nblocks;
     t0 = min(ntiles, per * (long long)blockIdx.x);
     t1 = min(ntiles, t0 + per);
 }
@@ -103,7 +126,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
-    block_tiles(ntiles, t0, t1);
+    block_tiles(ntiles, t0, t1, wk.nused);
     for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
         const bool live = r < nreads;
@@ -197,13 +220,14 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
 __global__ __launch_bounds__(256) void scan_bins_kernel(FastWork wk) {
     const int bin = blockIdx.y * 256 + threadIdx.x;
     uint32_t *col = wk.counts + (size_t)blockIdx.x * SCAN_CHUNK * wk.nbins + bin;
+    const int rows = min(SCAN_CHUNK, wk.nused - (int)blockIdx.x * SCAN_CHUNK);      // histogram rows of this chunk that exist
     uint32_t run = 0;
-    for (int b0 = 0; b0 < SCAN_CHUNK; b0 += 16) {
+    for (int b0 = 0; b0 < rows; b0 += 16) {
         uint32_t v[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = col[(size_t)(b0 + i) * wk.nbins];
+        for (int i = 0; i < 16; ++i) v[i] = b0 + i < rows ? col[(size_t)(b0 + i) * wk.nbins] : 0u;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { col[(size_t)(b0 + i) * wk.nbins] = run; run += v[i]; }
+        for (int i = 0; i < 16; ++i) { if (b0 + i < rows) col[(size_t)(b0 + i) * wk.nbins] = run; run += v[i]; }
     }
     wk.chunks[(size_t)blockIdx.x * wk.nbins + bin] = run;
 }
@@ -214,12 +238,13 @@ __global__ __launch_bounds__(1024) void scan_total_kernel(FastWork wk) {
     uint32_t mine = 0u;
     if (b < wk.nbins) {
         uint32_t *col = wk.chunks + b;
-        for (int c0 = 0; c0 < SCAN_CHUNKS; c0 += 16) {
+        const int chunks = (wk.nused + SCAN_CHUNK - 1) / SCAN_CHUNK;          // chunk totals K2a wrote
+        for (int c0 = 0; c0 < chunks; c0 += 16) {
             uint32_t v[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = col[(size_t)(c0 + i) * wk.nbins];
+            for (int i = 0; i < 16; ++i) v[i] = c0 + i < chunks ? col[(size_t)(c0 + i) * wk.nbins] : 0u;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { col[(size_t)(c0 + i) * wk.nbins] = mine; mine += v[i]; }
+            for (int i = 0; i < 16; ++i) { if (c0 + i < chunks) col[(size_t)(c0 + i) * wk.nbins] = mine; mine += v[i]; }
         }
     }
     s_part[b] = mine;
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, i
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
-    block_tiles(ntiles, t0, t1);
+    block_tiles(ntiles, t0, t1, wk.nused);
     // a wave takes one tile per round; the loads of SCATTER_ROUNDS rounds are issued together (the block is a chain of
     // dependent round trips otherwise: mask -> word -> LDS cursor -> store, 34 us for 30 MB of traffic)
     constexpr int SCATTER_ROUNDS = 4;
@@ -284,11 +309,12 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
     const long long base = LINKED ? (long long)wk.binbase[la.bin0] : 0;
     const long long total = (long long)wk.binbase[(LINKED ? la.bin0 : 0) + BAND_BINS];
     const int lane = threadIdx.x & 63;
-    const long long nwaves = (total - base + 63) >> 6;
+    const int lpw = dp_lanes_per_wave(total - base, (long long)gridDim.x * 4, wk.lpw);
+    const long long nwaves = (total - base + lpw - 1) / lpw;
     for (long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); wv < nwaves;
          wv += (long long)gridDim.x * 4) {
-        const long long slot = base + wv * 64 + lane;
-        const bool live = slot < total;
+        const long long slot = base + wv * lpw + lane;
+        const bool live = lane < lpw && slot < total;
         const uint2 task = live ? wk.order[slot] : make_uint2(0u, 0u);
         const long long r = (long long)task.x;
         const uint32_t ww = task.y;
@@ -365,12 +391,13 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     const int bin0 = LINKED ? la.bin0 : 0;
     const long long first = (long long)wk.binbase[bin0 + BAND_BINS], total = (long long)wk.binbase[bin0 + FILTER_BINS];
     const int lane = threadIdx.x & 63;
-    const long long nwaves = (total - first + 63) >> 6;
-    // persistent grid: each wave takes every (gridDim*4)-th group of 64 slots of `order`
+    const int lpw = dp_lanes_per_wave(total - first, (long long)gridDim.x * 4, wk.lpw);
+    const long long nwaves = (total - first + lpw - 1) / lpw;
+    // persistent grid: each wave takes every (gridDim*4)-th group of lpw slots of `order`
     for (long long wv = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); wv < nwaves;
          wv += (long long)gridDim.x * 4) {
-        const long long slot = first + wv * 64 + lane;
-        const bool live = slot < total;
+        const long long slot = first + wv * lpw + lane;
+        const bool live = lane < lpw && slot < total;
         const uint2 task = live ? wk.order[slot] : make_uint2(0u, 0u);
         const long long r = (long long)task.x;
         const uint32_t ww = task.y;
@@ -385,7 +412,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         // is no upper bound of the cells to its right
         const bool head = !(u.sr && jlo == 0);
         // (equal-length batches only: in a ragged one such a wave runs in tail mode below, or without the triangle)
-        const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0 &&
+        const bool tri = __builtin_amdgcn_readfirstlane((int)(first + wv * lpw >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0 &&
                          head && lens == nullptr;       // (wave-uniform by construction; tell the compiler)
         // linked: the alignment of a lane starts at its own column s (= front.rstop).  The wave's
         // common start column may lie before that -- such a lane is re-initialised when the sweep
@@ -403,7 +430,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         // exactly as in an equal-length batch.  The lane's last TAIL_COLUMNS bases are fetched once, re-aligned
         // to the read end.  A lane whose read starts inside the swept range (column shift) restarts there from
         // the initial column, which without START_WITHIN_SEQ1 is the fresh-window column itself.
-        const bool rows_wave = __builtin_amdgcn_readfirstlane((int)(first + wv * 64 >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0;
+        const bool rows_wave = __builtin_amdgcn_readfirstlane((int)(first + wv * lpw >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0;
         if (!LINKED && lens != nullptr && rows_wave && !u.sr) {
             const int shift = live ? max_len - n : 0;
             const int v0 = wave_min_i32(live ? j_lo + shift : 0x7fffffff);
@@ -499,7 +526,8 @@ template <int MT>
 int launch_window_mt(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                      int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, hipStream_t st) {
     const bool noindel = a->indel_cost > a->p.k;
-    const dim3 grid((unsigned)std::min<long long>((nreads + 255) / 256, 4096)), block(256);
+    // (one block of four waves per 4 reads at the low end: a short batch gets a wave per task)
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((nreads + 3) / 4, 4096))), block(256);
     if (la) {
         if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
         else         hipLaunchKernelGGL((window_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);

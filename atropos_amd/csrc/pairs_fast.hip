@@ -240,6 +240,7 @@ static PairsFastWork pairs_fast_carve(void *work, long long npairs) {
     w.fw.binbase = w.fw.chunks + (size_t)(FAST_BLOCKS / 64) * PF_BINS;
     w.fw.total = w.fw.binbase + PF_BINS + 1;
     w.fw.nbins = PF_BINS;
+    w.fw.nused = FAST_BLOCKS;
     w.bins = (uint8_t *)(w.fw.total + 4);
     return w;
 }

@@ -147,6 +147,14 @@ class C2(object):
             ms = run(lambda: self.al.locate_batch(rb, self.filtered))
             out["ragged_batch_reads_per_s"] = self.n / (ms * 1e-3)
         out["pcie_inclusive_bound_reads_per_s"] = PCIE_GBS * 1e9 / (150 + 16)    # ASCII in + record out over PCIe Gen5 x16
+        # the small-batch regime of the drop-in path (tools/bench_small.py): the unchanged trim command hands over
+        # <= 1000 reads per call (/root/reference/atropos/commands/base.py:179), the per-read API a batch of one
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_small
+            out["small_batches"] = bench_small.measure()
+        except Exception as exc:                                              # noqa: BLE001 -- a side figure
+            out["small_batches"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         return out
 
 

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""The small-batch regime of the drop-in path: reads/s of C2's aligner against the batch size (1, 1 000 -- what
+the unchanged trim command hands over per call, /root/reference/atropos/commands/base.py:179 -- 64 k, 1 M), for
+  packed   : atr_locate_batch on a resident tile64 batch (records stay on the device),
+  ascii    : pack + locate from an ASCII matrix resident on the device,
+  strings  : Python strings in, result tuples out (host -> device -> host), i.e. Aligner.locate_batch(list),
+and the per-read API: Aligner.locate(str) -> tuple, one GPU batch of one per call.
+usage: tools/bench_small.py [json-out]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from atropos_amd import synth                          # noqa: E402
+from atropos_amd.align import Aligner                  # noqa: E402
+
+
+def timed(fn, min_reps=5, target_s=0.5):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    one = time.perf_counter() - t0
+    reps = int(max(min_reps, min(2000, target_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def measure(sizes=(1, 1000, 65536, 1_000_000)):
+    w = synth.workload("C2", 0, max(sizes), device="cuda")
+    al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    host = w["reads"].cpu().numpy()
+    out = {"batch_sizes": list(sizes), "packed_us": [], "ascii_us": [], "strings_us": []}
+    for n in sizes:
+        a = w["reads"][:n].contiguous()
+        batch = al.pack(a)
+        out["packed_us"].append(timed(lambda: al.locate_batch(batch)) * 1e6)
+        out["ascii_us"].append(timed(lambda: al.locate_batch(al.pack(a))) * 1e6)
+        if n <= 65536:
+            strings = [bytes(r).decode() for r in host[:n]]
+            out["strings_us"].append(timed(lambda: al.locate_batch(strings).tuples(), min_reps=3) * 1e6)
+        else:
+            out["strings_us"].append(None)
+    for key in ("packed", "ascii", "strings"):
+        out[key + "_reads_per_s"] = [None if t is None else n / (t * 1e-6) for n, t in zip(sizes, out[key + "_us"])]
+    one = bytes(host[0]).decode()
+    t = timed(lambda: al.locate(one), min_reps=50)
+    out["per_read_locate_us"] = t * 1e6
+    out["per_read_locate_reads_per_s"] = 1.0 / t
+    return out
+
+
+if __name__ == "__main__":
+    res = measure()
+    text = json.dumps(res)
+    print(text)
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as fh:
+            fh.write(text + "\n")
