@@ -147,9 +147,15 @@ struct PairState {
     bool has_best;
     // unordered sweep: hits that can pass the insert RMP filter are only recorded during the
     // sweep (j << 16 | cost) and evaluated afterwards, all lanes together
-    uint32_t cand[INS_CAND];
+    // (four scalars, not an array: `if (ncand == c) cand[c] = v` over an array is rewritten by the compiler into
+    // cand[ncand] = v, a dynamically indexed store that moves the WHOLE PairState into scratch memory -- 176 bytes
+    // written per pair before the sweep starts, the "spill" traffic the round-2 counters showed)
+    uint32_t cand0, cand1, cand2, cand3;
     int ncand;
 };
+static_assert(INS_CAND == 4, "PairState holds four recorded hits");
+template <int W>
+ATR_DEV uint32_t cand_get(const PairState<W> &P, int c) { return c == 0 ? P.cand0 : c == 1 ? P.cand1 : c == 2 ? P.cand2 : P.cand3; }
 
 // b1, b2: the plane64 chunks of the two reads (word p of chunk c at [4*c + p]).
 template <int W, class IP>
@@ -171,8 +177,7 @@ ATR_DEV void pair_reset(PairState<W> &P) {
     P.nhits = 0; P.has_best = false; P.best_prob = 0.0;
     P.best_j = P.best_cost = 0; P.best_e1 = P.best_e2 = -1;
     P.ncand = 0;
-#pragma unroll
-    for (int c = 0; c < INS_CAND; ++c) P.cand[c] = 0u;
+    P.cand0 = P.cand1 = P.cand2 = P.cand3 = 0u;
 }
 
 // Case-sensitive read codes -> the codes of their upper-case letters (3 -> 1, 12 -> 8, 5 -> 2, 10 -> 4, 6 -> 15),
@@ -298,9 +303,11 @@ ATR_DEV void pair_hit_record(PairState<W> &P, const IP &ip, int j, int cost, int
     // slot ncand, written in place under the lane mask (a rotation of the slots would cost register
     // copies on every offset, hit or not); the evaluation pass does not depend on the slot order
     const uint32_t v = ((uint32_t)j << 16) | (uint32_t)cost;
-#pragma unroll
-    for (int c = 0; c < INS_CAND; ++c)
-        if (P.ncand == c) P.cand[c] = v;
+    const int at = P.ncand;
+    P.cand0 = at == 0 ? v : P.cand0;
+    P.cand1 = at == 1 ? v : P.cand1;
+    P.cand2 = at == 2 ? v : P.cand2;
+    P.cand3 = at == 3 ? v : P.cand3;
     P.ncand += 1;
 }
 
@@ -463,7 +470,144 @@ ATR_DEV void sweep_unordered(PairState<W> &P, const IP &ip, int jmax, const uint
     bool exact = false;
     for (int c = 0; c < INS_CAND; ++c) {
         if (c >= P.ncand) continue;
-        const int j = (int)(P.cand[c] >> 16), cost = (int)(P.cand[c] & 0xFFFFu);
+        const uint32_t cv = cand_get<W>(P, c);
+        const int j = (int)(cv >> 16), cost = (int)(cv & 0xFFFFu);
+        double prob;
+        int e1, e2;
+        const bool ok = evaluate_candidate<W>(P, ip, j, cost, g1, g2, cstride, prob, e1, e2);
+        const bool full = (cost == 0 && j == P.L);
+        if (exact && !full) continue;
+        if (full) { exact = true; P.has_best = false; }
+        if (!ok) continue;
+        if (!full && P.has_best && !(prob < P.best_prob || (prob == P.best_prob && j < P.best_j))) continue;
+        P.has_best = true; P.best_prob = prob; P.best_j = j; P.best_cost = cost; P.best_e1 = e1; P.best_e2 = e2;
+    }
+}
+
+// ---- probed sweep: the unordered sweep in two passes ------------------------------------------------------
+// The unordered sweep above compares all four planes of every (bit shift, word shift) step as soon as ONE lane of
+// the wave is still below its limit after two words -- and with 64 pairs per wave some lane's true overlap sits in
+// 40 % of the steps.  Here pass 1 only computes a LOWER BOUND of every overlap's cost -- the positions where planes
+// 0 and 1 differ (two ops per 32 bases instead of four; 5/8 of random bases differ there, 3/4 in all four planes)
+// over the first two to four words (ins_probe_words) -- and notes the overlap lengths the bound cannot reject in a per-lane list
+// in LDS; pass 2 computes the exact cost of the listed lengths, each lane its own (the planes of read 2 sit in
+// LDS, indexed per lane), and hands them to the same pair_hit_record.  A true hit always passes the bound, so the
+// hits -- and with them everything after -- are those of the unordered sweep.  Overlaps of at most 32 bases (one
+// word) are costed exactly in pass 1: the many chance hits of a few bases need no second look.
+// rl: the lane's R planes in LDS, rl[(p * (W + 1) + w) * rls], word W = 0; cl: its candidate list, cl[c * cls].
+// Words the bound looks at, by the words of the overlap: 32 random bases differ in planes 0 / 1 at 20 +- 2.7
+// positions, the limit of an overlap of n words is 6.4 n (frac 0.2): the bound must clear it by a few sigma, or
+// every long overlap lands in the list (2 words at 2 x 250 bp: list overflow, ordered redo, 0.41 -> 1.5 ms).
+constexpr int ins_probe_words(int nw) { return nw <= 3 ? 2 : nw <= 6 ? 3 : 4; }
+constexpr int INS_LIST_CAP = 16;                    // listed overlap lengths per lane; more: ordered redo
+
+template <int W>
+ATR_DEV void planes_to_lds(const PairState<W> &P, uint32_t *rl, int rls) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int w = 0; w < W; ++w) rl[(size_t)(p * (W + 1) + w) * rls] = P.r[p][w];
+        rl[(size_t)(p * (W + 1) + W) * rls] = 0u;
+    }
+}
+template <int W>
+ATR_DEV void planes_from_lds(PairState<W> &P, const uint32_t *rl, int rls) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int w = 0; w < W; ++w) P.r[p][w] = rl[(size_t)(p * (W + 1) + w) * rls];
+}
+
+template <int W, int Q>
+struct ProbeShift {
+    template <class IP>
+    static ATR_DEV_MEMBER void all(PairState<W> &P, const IP &ip, int s, const uint32_t (&rs0)[W], const uint32_t (&rs1)[W],
+                                   uint32_t rt2, uint32_t rt3, uint32_t topmask, int jmax, uint16_t *cl, int cls, int &nlist) {
+        const int j = 32 * (W - Q) - s;
+        if (j >= 1 && j <= jmax) {                                        // wave-uniform
+            const int limit = ip.thr_hit[atr_imin(j, INS_MAX_LEN)];       // wave-uniform: a scalar load
+            if constexpr (Q == W - 1) {
+                // one word: the exact cost, as the unordered sweep
+                uint32_t m = P.a[0][0] ^ rs0[W - 1];
+                m = atr_or_xor(m, P.a[1][0], rs1[W - 1]);
+                m = atr_or_xor(m, P.a[2][0], rt2);
+                m = atr_or_xor(m, P.a[3][0], rt3);
+                pair_hit_record<W>(P, ip, j, atr_popc(m & topmask), limit);
+            } else {
+                int lb = 0;
+#pragma unroll
+                for (int w = 0; w + Q < W && w < ins_probe_words(W - Q); ++w) {
+                    uint32_t m = atr_or_xor(P.a[0][w] ^ rs0[w + Q], P.a[1][w], rs1[w + Q]);
+                    if (w + Q == W - 1) m &= topmask;
+                    lb += atr_popc(m);
+                }
+                if (lb <= limit && j <= P.L) {
+                    if (nlist < INS_LIST_CAP) cl[(size_t)nlist * cls] = (uint16_t)j;
+                    nlist += 1;
+                }
+            }
+        }
+        if constexpr (Q + 1 < W) ProbeShift<W, Q + 1>::all(P, ip, s, rs0, rs1, rt2, rt3, topmask, jmax, cl, cls, nlist);
+    }
+};
+
+// exact cost of overlap j for one lane, read 2's planes from LDS (per-lane word shift)
+template <int W>
+ATR_DEV int overlap_cost_lds(const PairState<W> &P, const uint32_t *rl, int rls, int j) {
+    const int sh = 32 * W - j, q = sh >> 5, s = sh & 31;
+    const uint32_t topmask = 0xFFFFFFFFu >> s;
+    int cost = 0;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        if (w + q < W) {
+            uint32_t m = 0u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t lo = rl[(size_t)(p * (W + 1) + w + q) * rls], hi = rl[(size_t)(p * (W + 1) + w + q + 1) * rls];
+                m = atr_or_xor(m, P.a[p][w], atr_funnel(hi, lo, s));
+            }
+            if (w + q == W - 1) m &= topmask;
+            cost += atr_popc(m);
+        }
+    }
+    return cost;
+}
+
+// nmax_of(n): the wave's largest n (the kernel: a cross-lane maximum; the emulation: n itself)
+template <int W, class IP, class NMAX>
+ATR_DEV void sweep_probed(PairState<W> &P, const IP &ip, int jmax, const uint32_t *g1, const uint32_t *g2, int cstride,
+                          const uint32_t *rl, int rls, uint16_t *cl, int cls, const int32_t *thr_hit, NMAX nmax_of) {
+    pair_reset<W>(P);
+    int nlist = 0;
+#ifndef ATR_HOST_EMU
+#pragma unroll 1
+#endif
+    for (int s = 0; s < 32; ++s) {
+        if (32 * W - s < 1) break;
+        uint32_t rs0[W], rs1[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+            rs0[w] = atr_funnel((w + 1 < W) ? P.r[0][(w + 1 < W) ? w + 1 : 0] : 0u, P.r[0][w], s);
+            rs1[w] = atr_funnel((w + 1 < W) ? P.r[1][(w + 1 < W) ? w + 1 : 0] : 0u, P.r[1][w], s);
+        }
+        const uint32_t rt2 = P.r[2][W - 1] >> s, rt3 = P.r[3][W - 1] >> s;
+        ProbeShift<W, 0>::all(P, ip, s, rs0, rs1, rt2, rt3, 0xFFFFFFFFu >> s, jmax, cl, cls, nlist);
+    }
+    // pass 2: the exact cost of the listed overlap lengths
+    const int nmax = nmax_of(atr_imin(nlist, INS_LIST_CAP));
+    for (int c = 0; c < nmax; ++c) {
+        if (c < nlist && c < INS_LIST_CAP) {
+            const int j = (int)cl[(size_t)c * cls];
+            pair_hit_record<W>(P, ip, j, overlap_cost_lds<W>(P, rl, rls, j), thr_hit[atr_imin(j, INS_MAX_LEN)]);
+        }
+    }
+    if (nlist > INS_LIST_CAP) P.ncand = INS_CAND + 1;                     // list overflow: the ordered sweep decides
+    // evaluation pass, as in sweep_unordered
+    bool exact = false;
+    for (int c = 0; c < INS_CAND; ++c) {
+        if (c >= P.ncand) continue;
+        const uint32_t cv = cand_get<W>(P, c);
+        const int j = (int)(cv >> 16), cost = (int)(cv & 0xFFFFu);
         double prob;
         int e1, e2;
         const bool ok = evaluate_candidate<W>(P, ip, j, cost, g1, g2, cstride, prob, e1, e2);

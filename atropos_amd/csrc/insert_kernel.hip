@@ -22,16 +22,16 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     constexpr int W = NCH;
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const long long ntiles = (npairs + 63) >> 6;
-    if (tile >= ntiles) return;
     const long long r = tile * 64 + lane;
-    const bool live = r < npairs;
+    const bool live = r < npairs;                    // (a wave behind the last tile runs along on empty pairs: the block meets at a barrier)
     const int len1 = live ? (lens1 ? lens1[r] : max_len) : 0;
     const int len2 = live ? (lens2 ? lens2[r] : max_len) : 0;
 
     uint32_t b1[4 * W], b2[4 * W];
-    const uint4 *t1 = packed1 + (size_t)tile * NCH * 64 + lane;
-    const uint4 *t2 = packed2 + (size_t)tile * NCH * 64 + lane;
+    const long long ntiles = (npairs + 63) >> 6;
+    const long long tile_ld = min(tile, ntiles - 1);                  // (an idle wave reads the last tile)
+    const uint4 *t1 = packed1 + (size_t)tile_ld * NCH * 64 + lane;
+    const uint4 *t2 = packed2 + (size_t)tile_ld * NCH * 64 + lane;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const uint4 a = t1[(size_t)c * 64], b = t2[(size_t)c * 64];
@@ -41,10 +41,25 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     PairState<W> P;
     pair_init<W>(P, ip, len1, len2, b1, b2);
     const int jmax = wave_max_i32_ins(P.L);
-    sweep_unordered<W>(P, ip, jmax, (const uint32_t *)t1, (const uint32_t *)t2, 64 * 4);
+    // read 2's planes per lane in LDS ([plane][word][lane]: a lane's words sit in its own bank), its list of
+    // overlap lengths to cost exactly, and the per-length hit thresholds (pass 2 indexes them per lane)
+    __shared__ uint32_t s_rl[4][4 * (W + 1) * 64];
+    __shared__ uint16_t s_cl[4][INS_LIST_CAP * 64];
+    __shared__ int32_t s_thr_hit[INS_MAX_LEN + 1];
+    for (int i = threadIdx.x; i <= INS_MAX_LEN; i += 256) s_thr_hit[i] = ip.thr_hit[i];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *rl = &s_rl[wv][lane];
+    uint16_t *cl = &s_cl[wv][lane];
+    planes_to_lds<W>(P, rl, 64);
+    __syncthreads();
+    sweep_probed<W>(P, ip, jmax, (const uint32_t *)t1, (const uint32_t *)t2, 64 * 4, rl, 64, cl, 64, s_thr_hit,
+                    [](int n) { return wave_max_i32_ins(n); });
     // "stop after 100 hits" depends on the order of the hits: redo such (low-complexity) pairs
     // in the reference's order; the other lanes of the wave get the same result again
-    if (__any(!unordered_is_exact<W>(P))) sweep_ordered<W>(P, ip, jmax);
+    if (__any(!unordered_is_exact<W>(P))) {
+        planes_from_lds<W>(P, rl, 64);
+        sweep_ordered<W>(P, ip, jmax);
+    }
     if (live) {
         uint32_t rec[12];
         pair_result<W>(P, ip, rec);
@@ -59,7 +74,7 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
 // with a few spilled dwords (96 VGPRs; C3 1.25 -> 1.08 ms); longer reads would spill their planes there
 // (C5: 1.0 -> 2.4 ms) and are compiled for four waves (128 VGPRs, C5 -7 %).
 template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void insert_kernel_dense(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void insert_kernel_dense(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
     const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
     uint4 *__restrict__ out) {

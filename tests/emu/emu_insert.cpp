@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "insert_host.hpp"
@@ -36,10 +37,21 @@ void emu_insert_tiles_ip(const IP &ip, const uint32_t *p1, const int32_t *l1, co
                 }
             PairState<W> P;
             pair_init<W>(P, ip, l1 ? l1[r] : max_len, l2 ? l2[r] : max_len, b1, b2);
-            sweep_unordered<W>(P, ip, jmax, p1 + (((size_t)tile * NCH) * 64 + lane) * 4,
-                               p2 + (((size_t)tile * NCH) * 64 + lane) * 4, 64 * 4);
+            const uint32_t *g1 = p1 + (((size_t)tile * NCH) * 64 + lane) * 4, *g2 = p2 + (((size_t)tile * NCH) * 64 + lane) * 4;
+            uint32_t rec_probed[12];
+            {   // as the kernel: the probed two-pass sweep (read 2's planes and the list of overlap lengths in "LDS")
+                uint32_t rl[4 * (W + 1)];
+                uint16_t cl[INS_LIST_CAP];
+                planes_to_lds<W>(P, rl, 1);
+                sweep_probed<W>(P, ip, jmax, g1, g2, 64 * 4, rl, 1, cl, 1, ip.thr_hit, [](int n) { return n; });
+                if (!unordered_is_exact<W>(P)) { planes_from_lds<W>(P, rl, 1); sweep_ordered<W>(P, ip, jmax); }
+                pair_result<W>(P, ip, rec_probed);
+            }
+            // and the one-pass unordered sweep it replaced: the same records, or the emulation aborts
+            sweep_unordered<W>(P, ip, jmax, g1, g2, 64 * 4);
             if (!unordered_is_exact<W>(P)) sweep_ordered<W>(P, ip, jmax);
             pair_result<W>(P, ip, out + 12 * r);
+            if (memcmp(rec_probed, out + 12 * r, sizeof(rec_probed)) != 0) abort();
         }
     }
 }
