@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 20 --warmup 3                 # C2, the headline (BASELINE.json configs[1])
     python bench.py --config C3|C4|C5 ...                          # the other BASELINE configs, one GPU shard each
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --single-process                      # the same shards from one process (threads + streams)
 
 A step is one pass of the hot path over one batch of packed reads resident in HBM; with N GPUs
 every rank owns its own shard (weak scaling, no data-path collective: reads are independent,
@@ -42,6 +43,59 @@ def profile_counters(config):
         return None
     with open(path) as fh:
         return json.load(fh)
+
+
+STREAMING_KERNELS = ("filter_kernel", "insert_kernel")   # stream the packed batch with 16 bytes per lane (see live_counters)
+
+
+def live_counters(config, reads, want_valu):
+    """HBM traffic (and VALU wave-instructions) of one step of `config`, MEASURED by this invocation: bench.py runs
+    itself under `rocprofv3 --pmc <counter>` -- one pass per counter, no trace domains, as MI355X_MICROARCH.md's
+    HBM section prescribes -- for three short calls and reduces the per-kernel CSV:  bytes = 2 x FETCH_SIZE +
+    WRITE_SIZE (KiB) for the kernels that stream the packed batch with 16-byte loads per lane (gfx950 FETCH_SIZE
+    counts half of such a stream), raw FETCH_SIZE + WRITE_SIZE for the others; the pack kernels of the set-up are
+    left out.  Returns None when rocprofv3 is not there or a pass fails (the line then falls back to the committed
+    profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    calls = 3
+    totals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE") + (("SQ_INSTS_VALU",) if want_valu else ()):
+            out = tempfile.mkdtemp(prefix="atr_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--config", config, "--reads", str(reads), "--steps", str(calls - 1), "--warmup", "1",
+                   "--no-cpu-baseline", "--no-secondary", "--no-live-counters"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(cmd, cwd="/tmp", env=env, timeout=300, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            per = {}
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as fh:
+                    for row in csv.DictReader(fh):
+                        name = row["Kernel_Name"]
+                        if "atr::" in name and "pack" not in name and row["Counter_Name"] == counter:
+                            per[name] = per.get(name, 0.0) + float(row["Counter_Value"])
+            shutil.rmtree(out, ignore_errors=True)
+            if not per:
+                return None
+            totals[counter] = per
+    except Exception:                                             # noqa: BLE001 -- rocprofv3 missing / failed: fall back
+        return None
+    hbm = 0.0
+    for name, v in totals["FETCH_SIZE"].items():
+        hbm += (2.0 if any(k in name for k in STREAMING_KERNELS) else 1.0) * v * 1024.0
+    hbm += sum(totals["WRITE_SIZE"].values()) * 1024.0
+    res = {"hbm_bytes_per_launch": hbm / calls, "units_per_launch": reads,
+           "source": "this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %d calls each (2 x FETCH_SIZE for "
+                     "the 16-byte-per-lane streaming kernels, gfx950)" % calls}
+    if want_valu:
+        res["valu_wave_insts_per_launch"] = sum(totals["SQ_INSTS_VALU"].values()) / calls
+    return res
 
 
 def usable_cores():
@@ -393,16 +447,31 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
     achieved = cfg.algo_bytes * cargs.reads / (kernel_ms * 1e-3) / 1e9
     prof = profile_counters(cfg.name) if not args.full_sweep else None
     desc = cfg.describe()
+    live = None
+    if args.live_counters and world == 1 and not args.full_sweep:
+        live = live_counters(cfg.name, cargs.reads, headline)        # (child processes on the same GPU)
     desc["parallelism"] = "shard%d" % world
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS,
             "frac_of_measured": achieved / HBM_MEASURED_GBS,
             "traffic": None, "kernel": cfg.kernel(), "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_unit": cfg.algo_bytes, "note": cfg.note(kernel_ms)}
+    if live:
+        roof["traffic"] = live["hbm_bytes_per_launch"]
+        roof["traffic_source"] = live["source"]
+        roof["traffic_over_algorithmic"] = live["hbm_bytes_per_launch"] / (cfg.algo_bytes * cargs.reads)
+        if prof is None:
+            prof = {}
+        prof = dict(prof, units_per_launch=cargs.reads)
+        if live.get("valu_wave_insts_per_launch"):
+            prof["valu_wave_insts_per_launch"] = live["valu_wave_insts_per_launch"]
+        else:
+            prof.pop("valu_wave_insts_per_launch", None)
     if prof:
         scale = cargs.reads / prof["units_per_launch"]
-        roof["traffic"] = prof["hbm_bytes_per_launch"] * scale
-        roof["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 PMC passes of an earlier run, not this run)" % cfg.name
+        if not live:
+            roof["traffic"] = prof["hbm_bytes_per_launch"] * scale
+            roof["traffic_source"] = "profiles/traffic_%s.json (rocprofv3 PMC passes of an earlier run, not this run)" % cfg.name
         if prof.get("valu_wave_insts_per_launch"):
             lane_ops = prof["valu_wave_insts_per_launch"] * scale * 64 / (kernel_ms * 1e-3) / 1e12
             roof["valu"] = {"wave_insts_per_launch": prof["valu_wave_insts_per_launch"] * scale,
@@ -428,6 +497,70 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
     return out
 
 
+def measure_threads(cfg_cls, args, devices):
+    """--single-process: ONE process, one host thread + HipBackend + stream per GPU (atropos_amd.shard's
+    single-process driver: no torchrun, no process group, no NCCL -- the path shards without any exchange, so a
+    thread barrier is all the synchronisation the contract needs).  Every thread builds its own shard of the
+    workload on its device, runs the warmup, meets the others at a barrier, times EXACTLY args.steps steps and
+    synchronises its stream; the job's time is first start to last finish."""
+    import threading
+    from atropos_amd import _lib
+    world = len(devices)
+    cargs = argparse.Namespace(**vars(args))
+    cargs.reads = args.reads if args.reads is not None else cfg_cls.default_units
+    start = threading.Barrier(world)
+    t_begin, t_end, kernel_ms, errors, cfgs = [0.0] * world, [0.0] * world, [0.0] * world, [], [None] * world
+
+    def run(rank):
+        try:
+            dev = devices[rank]
+            be = _lib.HipBackend(dev)
+            with _lib.thread_backend(be), be.worker_context() as stream:
+                cfg = cfgs[rank] = cfg_cls(cargs, rank, "cuda:%d" % dev)
+                for s in range(args.warmup):
+                    cfg.step(s)
+                stream.synchronize()
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                start.wait()
+                t_begin[rank] = time.perf_counter()
+                for s in range(args.steps):
+                    ev[s][0].record()
+                    cfg.step(args.warmup + s)
+                    ev[s][1].record()
+                stream.synchronize()
+                t_end[rank] = time.perf_counter()
+                kernel_ms[rank] = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        except BaseException as err:                      # noqa: BLE001 -- re-raised below
+            errors.append(err)
+            start.abort()
+
+    threads = [threading.Thread(target=run, args=(r,), name="bench-dev%d" % r) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    dt = max(t_end) - min(t_begin)
+    cfg = cfgs[0]
+    units = cargs.reads * cfg.unit_reads
+    kms = float(np.mean(kernel_ms))
+    achieved = cfg.algo_bytes * cargs.reads / (kms * 1e-3) / 1e9
+    with _lib.thread_backend(_lib.HipBackend(devices[0])):
+        desc = cfg.describe()
+    desc["parallelism"] = "shard%d" % world
+    return {
+        "metric": cfg.metric, "value": units * world * args.steps / dt, "unit": "reads/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
+        "config": desc, "launcher": "single process, one host thread + stream per GPU (no process group)",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": cfg.kernel(), "kernel_ms": kms, "algorithmic_bytes_per_unit": cfg.algo_bytes,
+                     "note": "per GPU; " + cfg.note(kms)},
+        "per_rank_ms_per_step": [(e - b) / args.steps * 1e3 for b, e in zip(t_begin, t_end)],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -441,12 +574,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", dest="secondary", action="store_false",
                     help="skip the pack-inclusive / ragged-batch / small-batch side measurements")
+    ap.add_argument("--no-live-counters", dest="live_counters", action="store_false",
+                    help="take roofline.traffic from the committed profile instead of measuring it with rocprofv3 PMC passes "
+                         "of this invocation")
     ap.add_argument("--no-other-configs", dest="others", action="store_false",
                     help="default run: C2 only, without the C3 / C4 / C5 entries")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N from ONE process: a host thread, backend and stream per GPU (no torchrun / NCCL); times "
+                         "the headline config only")
+    ap.add_argument("--devices", default=None, help="--single-process: comma-separated device ordinals (default 0 .. N-1)")
     ap.add_argument("--full-sweep", action="store_true",
                     help="C2: time the unfiltered full-column DP kernel instead of the filtered pipeline")
     args = ap.parse_args()
 
+    if args.single_process:
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        if len(devices) != args.gpus:
+            raise SystemExit("--devices must name --gpus devices")
+        print(json.dumps(measure_threads(CONFIGS[args.config or "C2"], args, devices)), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
