@@ -23,6 +23,8 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
+WAVE_MAX_READS = 16384                   # atr_locate_batch: short batches take the wavefront-per-read kernel
+LOCATE_PATHS = {"auto": 0, "full": 1, "filtered": 2, "wave": 3}   # ATR_LOCATE_* of include/atropos_hip.h
 PAIRS_MAX_LEN = 320
 INSERT_MAX_ADAPTER = 128
 INSERT_MAX_READ = 320
@@ -99,6 +101,8 @@ PROTOTYPES = {
     "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p]),
     "atr_linked_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "atr_linked_destroy": (None, [C.c_void_p]),
     "atr_linked_query_table": (C.c_int, [C.c_void_p]),
@@ -378,21 +382,33 @@ class HipBackend(object):
         kind = _check(self.lib, self.lib.atr_aligner_query_table(h, buf), "atr_aligner_query_table")
         return kind, buf.raw
 
-    def locate_batch(self, h, packed, lens, nreads, max_len, filtered=True):
-        """filtered: give the library its scratch so that it may run the filtered pipeline
-        (bit-parallel pre-pass + windowed DP); the records are identical either way."""
+    def locate_batch(self, h, packed, lens, nreads, max_len, filtered=True, path=None):
+        """path: one of LOCATE_PATHS ("auto": the fastest applicable kernels -- a wavefront per read for short
+        batches, the filtered pipeline (bit-parallel pre-pass + windowed DP) for long ones; "full", "filtered",
+        "wave": that kernel family); the records are identical on every path.  ``filtered=False`` is "full"."""
+        if path is None:
+            path = "auto" if filtered else "full"
+        code = LOCATE_PATHS[path]
         out = self.empty((nreads, 8), torch.int16)
         if nreads:
             work = None
-            if filtered:
+            if code in (0, 2) and (code == 2 or nreads > WAVE_MAX_READS):
                 need = self.lib.atr_locate_work_bytes(nreads)
                 if self._work is None or self._work.numel() < need:
                     self._work = self.empty((need,), torch.uint8)
                 work = self._work
+            elif code == 0:
+                work = self._work if self._work is not None else self._small_work()
             with torch.cuda.device(self.device):
-                _check(self.lib, self.lib.atr_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
-                                                           _ptr(work), self._stream()), "atr_locate_batch")
+                _check(self.lib, self.lib.atr_locate_batch_path(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
+                                                                _ptr(work), code, self._stream()), "atr_locate_batch")
         return out
+
+    def _small_work(self):
+        """Scratch for the short batches that do not take the wave kernel (references of more than 64 bases never
+        use it, anchored prefixes only need it to be there)."""
+        self._work = self.empty((self.lib.atr_locate_work_bytes(WAVE_MAX_READS),), torch.uint8)
+        return self._work
 
     # -- linked adapters (one fused pipeline for the whole set) ---------------------
     def linked_create(self, specs):

@@ -208,10 +208,12 @@ class Aligner(object):
                              "(use aligner.pack(reads))" % (batch.table_kind, self._table_kind))
 
     # -- alignment ----------------------------------------------------------------------
-    def locate_batch(self, reads, filtered=True):
-        """Batched ``locate``: one result record per read (see LocateResult).  ``filtered``
-        lets the library use its filtered pipeline (bit-parallel pre-pass + windowed DP)
-        where it applies; the records are identical either way."""
+    def locate_batch(self, reads, filtered=True, path=None):
+        """Batched ``locate``: one result record per read (see LocateResult).  The library picks
+        its kernels by batch size (a wavefront per read for short batches, the filtered pipeline --
+        bit-parallel pre-pass + windowed DP -- for long ones); ``path`` ("full", "filtered", "wave",
+        ``_lib.LOCATE_PATHS``) names one, ``filtered=False`` is "full"; the records are identical
+        on every path."""
         if getattr(self, "_long", False):
             return self._locate_long(reads)
         batch = self.pack(reads)
@@ -222,7 +224,7 @@ class Aligner(object):
             rec[:, 1] = -1
             return LocateResult(rec)
         return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len,
-                                            filtered))
+                                            filtered, path))
 
     def compare_batch(self, reads, suffix=False):
         """``compare_prefixes(reference, read, wildcard_ref, wildcard_query)`` (``compare_suffixes`` with

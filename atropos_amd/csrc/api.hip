@@ -8,6 +8,7 @@
 #include "locate_kernel.hpp"
 #include "insert_host.hpp"
 #include "locate_fast.hpp"
+#include "wave_core.hpp"
 
 namespace atr {
 
@@ -17,6 +18,8 @@ int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t 
                        int max_len, uint4 *out, hipStream_t st);
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                   const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, int cased, hipStream_t st);
+int launch_locate_wave(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                       int max_len, uint4 *out, hipStream_t st);
 
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
                    long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
@@ -234,10 +237,25 @@ size_t atr_locate_work_bytes(int64_t nreads) { return nreads < 0 ? 0 : fast_work
 
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
                      int max_len, atr_result *d_out, void *d_work, void *stream) {
+    return atr_locate_batch_path(a, d_packed, d_lens, nreads, max_len, d_out, d_work, ATR_LOCATE_AUTO, stream);
+}
+
+int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
+                          int max_len, atr_result *d_out, void *d_work, int path, void *stream) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (path < ATR_LOCATE_AUTO || path > ATR_LOCATE_WAVE) return ATR_ERR_INVALID;
+    if (path == ATR_LOCATE_WAVE && a->p.m > WAVE_MAX_M) return ATR_ERR_UNSUPPORTED;
     if (nreads == 0) return ATR_OK;
     if (!d_out || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
-    if (d_work && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k)) {
+    if (path == ATR_LOCATE_FULL) d_work = nullptr;
+    const bool band = d_work && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k);
+    if (path == ATR_LOCATE_WAVE || (path == ATR_LOCATE_AUTO && !band && wave_applies(a->p.m, nreads))) {
+        // short batch: a wavefront per read (wave_core.hpp)
+        const int rc = launch_locate_wave(a, (const uint4 *)d_packed, d_lens, nreads, (max_len + 31) / 32, max_len,
+                                          (uint4 *)d_out, (hipStream_t)stream);
+        return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_wave_kernel launch");
+    }
+    if (band) {
         // anchored 5' adapter: banded DP over the 2k + 1 diagonals around the main one
         const int rc = launch_prefix_band(a, (const uint4 *)d_packed, d_lens, nreads, (max_len + 31) / 32, max_len,
                                           (uint4 *)d_out, (hipStream_t)stream);

@@ -1,0 +1,117 @@
+// wave_core.hpp -- Aligner.locate for SHORT batches: one read per WAVEFRONT, one DP row per lane.
+// (reference: atropos/align/_align.pyx:266-491; the cell word, the candidate test and the
+// initial column are those of locate_core.hpp.)
+//
+// The kernels of locate_kernel.hpp / filter_core.hpp give every read one lane: a column of m rows is
+// a chain of 3 m dependent VALU ops, so a call over a few hundred reads -- the 1000-read batches of the
+// unchanged trim command (commands/base.py:179), the per-read API -- runs at the latency of ONE lane
+// (a 150-base read against a 33-row adapter: ~40 k dependent ops) while 63 lanes of the wave and most of
+// the chip idle.  Here lane l owns row l + 1 and the wave sweeps ANTI-DIAGONALS: in step t lane l
+// computes cell (l + 1, j) with j = min_n + t - l, from
+//     left  (l + 1, j - 1)  its own cell of step t - 1,
+//     up    (l,     j)      lane l - 1's cell of step t - 1  (one DPP wave_shr:1; lane 0 takes row 0),
+//     diag  (l,     j - 1)  the `up` of step t - 1,
+// i.e. n + m steps of ~13 VALU ops instead of n * m * 7.  A lane is active while 1 <= j - min_n <= span and
+// keeps its last cell afterwards, so at the end lane l holds (l + 1, max_n): the last column.  Row-m
+// candidates are taken by lane m - 1 in column order, the last column by a wave reduction that prefers the
+// smallest row among equal keys (the reference scans it in ascending rows and keeps the first on ties).
+// The query codes sit in LDS, one dword per column (a byte would cost a zero-extension per use); every lane fetches the code of its own column two steps
+// ahead.
+#ifndef ATR_WAVE_CORE_HPP
+#define ATR_WAVE_CORE_HPP
+
+#include "locate_core.hpp"
+
+namespace atr {
+
+constexpr int WAVE_MAX_M = 64;                 // rows 1 .. 64 on the 64 lanes (row 0 is injected)
+constexpr long long WAVE_MAX_READS = 16384;    // beyond: the lane-per-read kernels (the chip is full, fewer instructions win)
+constexpr int WAVE_CODE_PAD = 64;              // LDS entries in front of the codes, twice as many behind (inactive lanes read there)
+
+// bit (i & 31) of w
+#ifdef ATR_HOST_EMU
+static inline uint32_t atr_bfe1v(uint32_t w, uint32_t i) { return (w >> (i & 31u)) & 1u; }
+#else
+static __device__ __forceinline__ uint32_t atr_bfe1v(uint32_t w, uint32_t i) {
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(w), "v"(i));
+    return r;
+}
+#endif
+
+// bit c of the result: the reference row owned by `lane` does NOT match query code c
+ATR_DEV uint32_t wave_rowmask(const LocateParams &p, int p0, int lane) {
+    const int pos = p0 + lane, w = pos >> 5, b = pos & 31;
+    // (masks, not a select chain over the three words: the compiler turns that into p.nmask[c][w], a run-time index
+    //  that moves the whole parameter block to scratch memory)
+    const uint32_t s0 = w == 0 ? ~0u : 0u, s1 = w == 1 ? ~0u : 0u, s2 = w == 2 ? ~0u : 0u;
+    uint32_t mask = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const uint32_t word = (p.nmask[c][0] & s0) | (p.nmask[c][1] & s1) | (p.nmask[c][2] & s2);
+        mask |= ((word >> b) & 1u) << c;
+    }
+    return mask;
+}
+
+// row 0 of column j (_align.pyx:385-388)
+ATR_DEV uint32_t wave_row0(const Uniform &u, int j) {
+    return u.sq ? (ORG_BIAS + (uint32_t)j) : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
+}
+
+// one cell: the three-way choice of locate_core.hpp's column_step
+template <bool XREP>
+ATR_DEV uint32_t wave_cell(uint32_t diag, uint32_t left, uint32_t up, uint32_t rowmask, uint32_t q, uint32_t insw,
+                           uint32_t delw) {
+    const uint32_t bit = atr_bfe1v(rowmask, q);
+    const uint32_t cd = XREP ? atr_mad24(bit, COST1 + MATCH1, diag) : atr_mad24(bit, DIAG_DELTA, diag + MATCH1);
+    return atr_minu(atr_minu(cd, left + delw), up + insw) & ~PRIO_MASK;
+}
+
+// the column window of a read of n bases (_align.pyx:314-321)
+struct WaveWindow { int min_n, max_n, span; bool scan; };
+template <bool XREP>
+ATR_DEV WaveWindow wave_window(const Uniform &u, int n) {
+    WaveWindow w;
+    w.max_n = u.sq ? n : atr_min(n, u.m + u.k);
+    w.min_n = XREP ? 0 : atr_max(0, n - u.m - u.k);
+    w.span = atr_max(0, w.max_n - w.min_n);
+    w.scan = w.max_n == n && (w.span > 0 || n == 0);          // :461; an empty read scans its initial column
+    return w;
+}
+
+// key of a last-column cell for the wave reduction: (key of consider(), smallest row first); -1 = no candidate
+template <bool XREP>
+ATR_DEV int wave_last_key(uint32_t cell, int row, int lane, bool wanted, const Uniform &u, int n, const int16_t *thr,
+                          Best &b) {
+    b.key = -1; b.word = 0; b.ref_stop = 0; b.query_stop = 0; b.matches = 0;
+    if (wanted && cell < u.klimit) consider<XREP>(b, cell, row, n, u.min_overlap, thr, u.indel);
+    return b.key < 0 ? -1 : (b.key << 6) | (63 - lane);
+}
+
+ATR_DEV void wave_best_init(Best &b, const Uniform &u, int n) {
+    b.key = COST_FIELD_MAX - (u.m + n);                      // (matches 0, cost m + n): :358-363
+    b.word = (uint32_t)(u.m + n) << CSH;
+    b.ref_stop = u.m; b.query_stop = n; b.matches = 0;
+}
+
+// the result record of locate_core.hpp's lane_result from a Best
+ATR_DEV void wave_result(const Best &best, const Uniform &u, int n, uint32_t rec[4]) {
+    const int cost = (int)(best.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != u.m + n) {
+        const int origin = (int)(best.word & ORG_MASK) - (int)ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = best.ref_stop; querystop = best.query_stop;
+        matches = best.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
+inline bool wave_applies(int m, long long nreads) { return m >= 1 && m <= WAVE_MAX_M && nreads <= WAVE_MAX_READS; }
+
+}  // namespace atr
+#endif

@@ -79,9 +79,12 @@ def check_batches_against_oracle(Aligner, oracle, unsupported_exc, seed, rounds,
             continue
         fixed = rng.randint(0, 200) if rng.random() < 0.3 else None
         reads = planted_reads(rng, ref, rng.choice([1, 63, 64, 65, 130, 200]), 200, fixed)
-        got = al.locate_batch(reads).tuples()                       # filtered pipeline where it applies
-        plain = al.locate_batch(reads, filtered=False).tuples()      # full sweep
+        got = al.locate_batch(reads, path="filtered").tuples()      # filtered pipeline where it applies
+        plain = al.locate_batch(reads, path="full").tuples()         # full sweep
         assert len(got) == len(reads) and plain == got
+        assert al.locate_batch(reads).tuples() == got                # what a caller gets: short batch -> a wave per read
+        if m <= 64:
+            assert al.locate_batch(reads, path="wave").tuples() == got
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1
@@ -120,14 +123,15 @@ def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, m_ra
                 reads.append(rseq(rng, rng.randint(0, 40)) + ref[:cut])
             reads += [rseq(rng, 20) + bad + rseq(rng, 9) + ref + rseq(rng, 5), rseq(rng, 7) + bad,
                       bad + ref[:33], rseq(rng, 3) + mutate(rng, ref[:32], 0.05) + ref[32:] + rseq(rng, 11)]
-        got = al.locate_batch(reads).tuples()
-        assert got == al.locate_batch(reads, filtered=False).tuples()
+        got = al.locate_batch(reads, path="filtered").tuples()
+        assert got == al.locate_batch(reads, path="full").tuples()
+        assert got == al.locate_batch(reads, path="wave").tuples() and got == al.locate_batch(reads).tuples()
         if fixed and all(len(r) == fixed for r in reads):
             # the same reads as an equal-length batch (no lens array): the pre-pass then bins the
             # partial overlaps by row count and the window DP sweeps a triangle only
             import numpy as np
             mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(len(reads), fixed).copy()
-            assert al.locate_batch(al.pack(mat)).tuples() == got
+            assert al.locate_batch(al.pack(mat), path="filtered").tuples() == got
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1
@@ -167,8 +171,9 @@ def check_uniform_partial_overlaps(Aligner, oracle, unsupported_exc, seed, round
                 q = rseq(rng, n, "ACGTN")
             reads.append(q)
         mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(count, n).copy()
-        got = al.locate_batch(al.pack(mat)).tuples()
-        assert got == al.locate_batch(al.pack(mat), filtered=False).tuples()
+        got = al.locate_batch(al.pack(mat), path="filtered").tuples()
+        assert got == al.locate_batch(al.pack(mat), path="full").tuples()
+        assert got == al.locate_batch(al.pack(mat), path="wave").tuples()
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1

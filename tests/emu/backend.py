@@ -233,10 +233,13 @@ class EmuBackend(object):
         kind = _check(self.lib.emu_aligner_query_table(h, buf), "atr_aligner_query_table")
         return kind, buf.raw
 
-    def locate_batch(self, h, packed, lens, nreads, max_len, filtered=True):
+    def locate_batch(self, h, packed, lens, nreads, max_len, filtered=True, path=None):
+        from atropos_amd._lib import LOCATE_PATHS
+        if path is None:
+            path = "auto" if filtered else "full"
         out = torch.zeros((nreads, 8), dtype=torch.int16)
         if nreads:
-            _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), int(filtered)),
+            _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), LOCATE_PATHS[path]),
                    "atr_locate_batch")
         return out
 

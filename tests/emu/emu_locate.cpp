@@ -13,6 +13,7 @@
 #include "aligner_host.hpp"
 #include "filter_core.hpp"
 #include "linked_host.hpp"
+#include "wave_core.hpp"
 
 using namespace atr;
 
@@ -474,10 +475,85 @@ int emu_linked_match_batch(const atr_linked_set *s, const uint8_t *packed, const
     return ATR_OK;
 }
 
+}  // extern "C"
+
+// locate_wave_kernel (wave_kernel.hip) for one read: the 64 lanes in lock step, the cross-lane moves spelled out
+template <bool XREP>
+static void emu_wave_read(const atr_aligner *a, const uint32_t *pk, int nchunks, long long r, int n, uint32_t *rec) {
+    const LocateParams &p = a->p;
+    const Uniform u = make_uniform(p, round_up_rows(p.m));
+    const WaveWindow win = wave_window<XREP>(u, n);
+    std::vector<uint32_t> s_code(WAVE_CODE_PAD + (ATR_MAX_READ_LEN + 31) / 32 * 32 + 2 * WAVE_CODE_PAD, 0xEEEEEEEEu);   // pads: junk on purpose
+    for (int c = 0; c < (n + 31) / 32; ++c)
+        for (int b = 0; b < 32; ++b) {
+            const uint32_t w = pk[(((size_t)(r >> 6) * nchunks + c) * 64 + (r & 63)) * 4 + (b >> 3)];
+            s_code[WAVE_CODE_PAD + 32 * c + b] = (w >> (4 * (b & 7))) & 15u;
+        }
+    uint32_t cur[64], diag[64], rowmask[64], up[64], nw[64];
+    int c[64];
+    Best best[64];
+    for (int l = 0; l < 64; ++l) {
+        rowmask[l] = wave_rowmask(p, u.p0, l);
+        cur[l] = init_word(l + 1, win.min_n, u.sr, u.sq, u.indel);
+        c[l] = -l - 1;
+        wave_best_init(best[l], u, n);
+    }
+    for (int l = 0; l < 64; ++l) diag[l] = l ? cur[l - 1] : wave_row0(u, win.min_n);
+    const uint32_t *code = s_code.data() + WAVE_CODE_PAD + win.min_n;
+    const int steps = win.span > 0 ? win.span + u.m - 1 : 0;
+    for (int t = 1; t <= steps; ++t) {
+        for (int l = 0; l < 64; ++l) up[l] = l ? cur[l - 1] : wave_row0(u, win.min_n + t);
+        for (int l = 0; l < 64; ++l) {
+            ++c[l];
+            nw[l] = wave_cell<XREP>(diag[l], cur[l], up[l], rowmask[l], code[c[l]], u.insw, u.delw);
+            const bool active = (unsigned)c[l] < (unsigned)win.span;
+            diag[l] = up[l];
+            if (XREP && l == u.m - 1 && active && nw[l] < u.klimit)
+                consider<XREP>(best[l], nw[l], u.m, win.min_n + c[l] + 1, u.min_overlap, p.thr, u.indel);
+            if (active) cur[l] = nw[l];
+        }
+    }
+    Best fin = best[u.m - 1];
+    if (win.scan) {
+        const int first_row = u.er ? 0 : u.m;
+        if (first_row == 0) {
+            const uint32_t w0 = wave_row0(u, win.max_n);
+            if (w0 < u.klimit) consider<XREP>(fin, w0, 0, n, u.min_overlap, p.thr, u.indel);
+        }
+        Best mine[64];
+        int top = -1;
+        for (int l = 0; l < 64; ++l)
+            top = std::max(top, wave_last_key<XREP>(cur[l], l + 1, l, l + 1 >= first_row && l < u.m, u, n, p.thr, mine[l]));
+        if (top >= 0 && (top >> 6) > fin.key) {
+            const int src = 63 - (top & 63);
+            fin.key = top >> 6; fin.word = mine[src].word; fin.ref_stop = src + 1; fin.query_stop = n;
+            fin.matches = mine[src].matches;
+        }
+    }
+    wave_result(fin, u, n, rec);
+}
+
+extern "C" {
+
 int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t *lens, int64_t nreads,
-                     int max_len, int16_t *out, int filtered) {
+                     int max_len, int16_t *out, int path) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (path < ATR_LOCATE_AUTO || path > ATR_LOCATE_WAVE) return ATR_ERR_INVALID;
+    if (path == ATR_LOCATE_WAVE && a->p.m > WAVE_MAX_M) return ATR_ERR_UNSUPPORTED;
     if (nreads == 0) return ATR_OK;
+    const int filtered = path != ATR_LOCATE_FULL;
+    {   // as atr_locate_batch_path
+        const bool band = filtered && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k);
+        if (path == ATR_LOCATE_WAVE || (path == ATR_LOCATE_AUTO && !band && wave_applies(a->p.m, nreads))) {
+            const int nchunks = (max_len + 31) / 32;
+            for (long long r = 0; r < nreads; ++r) {
+                const int n = lens ? lens[r] : max_len;
+                if (a->flags & ATR_STOP_WITHIN_SEQ2) emu_wave_read<true>(a, (const uint32_t *)packed, nchunks, r, n, (uint32_t *)out + 4 * r);
+                else emu_wave_read<false>(a, (const uint32_t *)packed, nchunks, r, n, (uint32_t *)out + 4 * r);
+            }
+            return ATR_OK;
+        }
+    }
     const bool eqmode = !(a->wildcard_ref || a->wildcard_query);
     const bool noindel = a->indel_cost > a->p.k;
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;

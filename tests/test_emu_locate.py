@@ -49,8 +49,8 @@ def test_synthetic_heads(emu_backend):
     for name in ("C1", "C2"):
         w = synth.workload(name, 0, heads[name]["count"])
         al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
-        assert al.locate_batch(w["reads"]).tuples() == [tup(x) for x in heads[name]["out"]]
-        assert al.locate_batch(w["reads"], filtered=False).tuples() == [tup(x) for x in heads[name]["out"]]
+        for path in ("auto", "filtered", "full", "wave"):
+            assert al.locate_batch(w["reads"], path=path).tuples() == [tup(x) for x in heads[name]["out"]], path
 
 
 def test_api_surface(emu_backend, oracle):

@@ -65,8 +65,10 @@ def test_every_column_size(hip_backend, oracle):
             e = 0.1 if m >= 10 else 0.34
             al = Aligner(ref, e, 14, wr, False, 3, ic)
             reads = _cases.planted_reads(rng, ref, 96, 220)
-            got = al.locate_batch(reads).tuples()
-            assert got == al.locate_batch(reads, filtered=False).tuples()
+            got = al.locate_batch(reads, path="filtered").tuples()
+            assert got == al.locate_batch(reads, path="full").tuples() and got == al.locate_batch(reads).tuples()
+            if m <= 64:
+                assert got == al.locate_batch(reads, path="wave").tuples()
             for q, g in zip(reads, got):
                 assert g == oracle.locate(ref, q, e, 14, wr, False, 3, ic), (m, ic, wr, q)
 
@@ -78,7 +80,8 @@ def test_synthetic_heads(hip_backend):
     for name in ("C1", "C2"):
         w = synth.workload(name, 0, heads[name]["count"], device="cuda")
         al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
-        assert al.locate_batch(w["reads"]).tuples() == [tup(x) for x in heads[name]["out"]]
+        for path in ("auto", "filtered", "full", "wave"):
+            assert al.locate_batch(w["reads"], path=path).tuples() == [tup(x) for x in heads[name]["out"]], path
 
 
 def test_c1_full_against_oracle(hip_backend, oracle):

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-call time of atr_locate_batch_path on short batches of C2 reads: wave / filtered / full kernels, and parity
+between them.  usage: tools/micro/wave_paths.py"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from atropos_amd import synth                          # noqa: E402
+from atropos_amd.align import Aligner                  # noqa: E402
+
+
+def timed(fn, reps=200):
+    fn(); fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+w = synth.workload("C2", 0, 65536, device="cuda")
+al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+for n in (1, 64, 256, 1000, 2048, 4096, 8192, 16384, 65536):
+    batch = al.pack(w["reads"][:n].contiguous())
+    ref = al.locate_batch(batch, path="full").records
+    row = {"n": n}
+    for path in ("wave", "filtered", "full"):
+        if path == "full" and n > 4096:
+            continue
+        assert torch.equal(al.locate_batch(batch, path=path).records, ref), (n, path)
+        row[path + "_us"] = round(timed(lambda: al.locate_batch(batch, path=path), 200 if n <= 4096 else 50), 1)
+    print(json.dumps(row), flush=True)
