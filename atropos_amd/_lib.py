@@ -23,7 +23,7 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
-WAVE_MAX_READS = 16384                   # atr_locate_batch: short batches take the wavefront-per-read kernel
+WAVE_MAX_READS = 32768                   # atr_locate_batch: short batches take the wavefront-per-read kernel
 LOCATE_PATHS = {"auto": 0, "full": 1, "filtered": 2, "wave": 3}   # ATR_LOCATE_* of include/atropos_hip.h
 PAIRS_MAX_LEN = 320
 INSERT_MAX_ADAPTER = 128

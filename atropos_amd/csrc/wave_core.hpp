@@ -6,17 +6,22 @@
 // a chain of 3 m dependent VALU ops, so a call over a few hundred reads -- the 1000-read batches of the
 // unchanged trim command (commands/base.py:179), the per-read API -- runs at the latency of ONE lane
 // (a 150-base read against a 33-row adapter: ~40 k dependent ops) while 63 lanes of the wave and most of
-// the chip idle.  Here lane l owns row l + 1 and the wave sweeps ANTI-DIAGONALS: in step t lane l
-// computes cell (l + 1, j) with j = min_n + t - l, from
-//     left  (l + 1, j - 1)  its own cell of step t - 1,
-//     up    (l,     j)      lane l - 1's cell of step t - 1  (one DPP wave_shr:1; lane 0 takes row 0),
-//     diag  (l,     j - 1)  the `up` of step t - 1,
-// i.e. n + m steps of ~13 VALU ops instead of n * m * 7.  A lane is active while 1 <= j - min_n <= span and
-// keeps its last cell afterwards, so at the end lane l holds (l + 1, max_n): the last column.  Row-m
-// candidates are taken by lane m - 1 in column order, the last column by a wave reduction that prefers the
-// smallest row among equal keys (the reference scans it in ascending rows and keeps the first on ties).
-// The query codes sit in LDS, one dword per column (a byte would cost a zero-extension per use); every lane fetches the code of its own column two steps
-// ahead.
+// the chip idle.  Here lane l owns ROW l (lane 0: row 0) and the wave sweeps ANTI-DIAGONALS: in step t
+// lane l computes cell (l, j) with j = min_n + t - l, from
+//     left  (l,     j - 1)  its own cell of step t - 1,
+//     up    (l - 1, j)      lane l - 1's cell of step t - 1  (one DPP wave_shr:1),
+//     diag  (l - 1, j - 1)  the `up` of step t - 1,
+// i.e. n + m steps of 7 - 12 VALU ops instead of n * m * 7.  Lane 0 has no lane below it: the DPP move leaves
+// its destination alone there, and that register holds WAVE_HUGE from the start, so lane 0 always takes the
+// `left` candidate, with its own increment instead of the deletion cost: row 0 of the reference
+// (:385-388: origin j, or cost j * indel).  A lane is active while 1 <= j - min_n <= span and keeps its
+// last cell afterwards, so at the end lane l holds (l, max_n): the last column.  Row-m candidates are taken
+// by lane m in column order, the last column by a wave reduction that prefers the smallest row among equal
+// keys (the reference scans it in ascending rows and keeps the first on ties).  A single wave issues one
+// instruction every few cycles whatever its kind, so the sweep is split: the steps in which every row is
+// active (m < t <= span) run without the per-lane activity test, four per trip, with one look at lane m's
+// four cells per trip.  The query codes sit in LDS, one dword per column (a byte would cost a
+// zero-extension per use); every lane fetches the codes of its next four columns one trip ahead.
 #ifndef ATR_WAVE_CORE_HPP
 #define ATR_WAVE_CORE_HPP
 
@@ -24,11 +29,11 @@
 
 namespace atr {
 
-constexpr int WAVE_MAX_M = 64;                 // rows 1 .. 64 on the 64 lanes (row 0 is injected)
-constexpr long long WAVE_MAX_READS = 16384;    // beyond: the lane-per-read kernels (the chip is full, fewer instructions win)
+constexpr int WAVE_MAX_M = 63;                 // rows 0 .. 63 on the 64 lanes
+constexpr long long WAVE_MAX_READS = 32768;    // beyond: the lane-per-read kernels (the chip is full, fewer instructions win)
 constexpr int WAVE_CODE_PAD = 64;              // LDS entries in front of the codes, twice as many behind (inactive lanes read there)
+constexpr uint32_t WAVE_HUGE = 0xBFF00000u;    // "no such cell": cost 3071, beyond every real cell, no overflow after + indel
 
-// bit (i & 31) of w
 #ifdef ATR_HOST_EMU
 static inline uint32_t atr_bfe1v(uint32_t w, uint32_t i) { return (w >> (i & 31u)) & 1u; }
 #else
@@ -39,9 +44,9 @@ static __device__ __forceinline__ uint32_t atr_bfe1v(uint32_t w, uint32_t i) {
 }
 #endif
 
-// bit c of the result: the reference row owned by `lane` does NOT match query code c
-ATR_DEV uint32_t wave_rowmask(const LocateParams &p, int p0, int lane) {
-    const int pos = p0 + lane, w = pos >> 5, b = pos & 31;
+// bit c of the result: reference row `row` (1-based) does NOT match query code c
+ATR_DEV uint32_t wave_rowmask(const LocateParams &p, int p0, int row) {
+    const int pos = p0 + row - 1, w = pos >> 5, b = pos & 31;
     // (masks, not a select chain over the three words: the compiler turns that into p.nmask[c][w], a run-time index
     //  that moves the whole parameter block to scratch memory)
     const uint32_t s0 = w == 0 ? ~0u : 0u, s1 = w == 1 ? ~0u : 0u, s2 = w == 2 ? ~0u : 0u;
@@ -58,14 +63,22 @@ ATR_DEV uint32_t wave_rowmask(const LocateParams &p, int p0, int lane) {
 ATR_DEV uint32_t wave_row0(const Uniform &u, int j) {
     return u.sq ? (ORG_BIAS + (uint32_t)j) : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
 }
+// what a step adds to the `left` candidate of lane l: the deletion word, or row 0's increment per column
+ATR_DEV uint32_t wave_left_step(const Uniform &u, int lane) {
+    return lane > 0 ? u.delw : u.sq ? 1u : (uint32_t)u.indel << CSH;
+}
+constexpr uint32_t WAVE_ROW0_CAP = ORG_BIAS | ((uint32_t)INIT_COST_CAP << CSH);     // row 0 without START_WITHIN_SEQ2, saturated
 
-// one cell: the three-way choice of locate_core.hpp's column_step
-template <bool XREP>
+// one cell: the three-way choice of locate_core.hpp's column_step.  SQ == false: row 0's cost is capped as in
+// wave_row0 (as a minimum over the whole wave: a cell of cost >= 2047 never decides anything).
+template <bool XREP, bool SQ>
 ATR_DEV uint32_t wave_cell(uint32_t diag, uint32_t left, uint32_t up, uint32_t rowmask, uint32_t q, uint32_t insw,
-                           uint32_t delw) {
+                           uint32_t left_step) {
     const uint32_t bit = atr_bfe1v(rowmask, q);
     const uint32_t cd = XREP ? atr_mad24(bit, COST1 + MATCH1, diag) : atr_mad24(bit, DIAG_DELTA, diag + MATCH1);
-    return atr_minu(atr_minu(cd, left + delw), up + insw) & ~PRIO_MASK;
+    uint32_t nw = atr_minu(atr_minu(cd, left + left_step), up + insw) & ~PRIO_MASK;
+    if (!SQ) nw = atr_minu(nw, WAVE_ROW0_CAP);
+    return nw;
 }
 
 // the column window of a read of n bases (_align.pyx:314-321)

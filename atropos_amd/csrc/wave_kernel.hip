@@ -1,14 +1,15 @@
 // wave_kernel.hip -- locate_wave_kernel: one read per wavefront, anti-diagonal sweep (wave_core.hpp).
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <type_traits>
 #include "aligner_host.hpp"
 #include "wave_core.hpp"
 
 namespace atr {
 
-// value of lane - 1; lane 0 takes `first` (v_mov_b32_dpp wave_shr:1, bound_ctrl off: lane 0 keeps `old`)
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t first) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false);
+// value of lane - 1; lane 0 keeps what `keep` holds there (v_mov_b32_dpp wave_shr:1, bound_ctrl off)
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v, uint32_t keep) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x138, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ int wave_max_key(int v) {
@@ -17,7 +18,7 @@ __device__ __forceinline__ int wave_max_key(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <bool XREP>
+template <bool XREP, bool SQ>
 __global__ __launch_bounds__(64) void locate_wave_kernel(const LocateParams p, const uint4 *__restrict__ packed,
                                                          const int32_t *__restrict__ lens, long long nreads, int nchunks,
                                                          int max_len, uint4 *__restrict__ out) {
@@ -46,76 +47,92 @@ __global__ __launch_bounds__(64) void locate_wave_kernel(const LocateParams p, c
             dst[2 * d + 1] = make_uint4((w[d] >> 16) & 15u, (w[d] >> 20) & 15u, (w[d] >> 24) & 15u, w[d] >> 28);
         }
     }
-    const uint32_t rowmask = wave_rowmask(p, u.p0, lane);
+    const uint32_t rowmask = lane > 0 ? wave_rowmask(p, u.p0, lane) : 0u;
+    const uint32_t left_step = wave_left_step(u, lane);
     __syncthreads();
 
-    // cells of the initial column (min_n), the diagonal input of the first step
-    uint32_t cur = init_word(lane + 1, win.min_n, u.sr, u.sq, u.indel);
-    // row 0 by column (wave_row0), incrementally: origin + 1 per column with START_WITHIN_SEQ2, else cost + indel, saturated
-    const uint32_t r0_inc = u.sq ? 1u : (uint32_t)u.indel << CSH;
-    const uint32_t r0_cap = u.sq ? 0xFFFFFFFFu : (ORG_BIAS | ((uint32_t)INIT_COST_CAP << CSH));
-    uint32_t r0 = wave_row0(u, win.min_n);
-    uint32_t diag = wave_shr1(cur, r0);
+    // cells of the initial column (min_n); lane 0: row 0.  `up` lives in two registers used in turn, so that the
+    // one a DPP move writes is the one whose lane 0 still holds WAVE_HUGE.
+    uint32_t cur = init_word(lane, win.min_n, u.sr, u.sq, u.indel);
+    uint32_t upa = wave_shr1(cur, WAVE_HUGE), upb = WAVE_HUGE;       // upa: the diagonal input of step 1
     int a = win.min_n - lane - 1;                                    // 0-based query position of this lane's column, before step 1
     const uint32_t *code = s_code + WAVE_CODE_PAD;
     Best best;
     wave_best_init(best, u, n);
-    const bool rowm = lane == u.m - 1;
-    const int steps = win.span > 0 ? win.span + u.m - 1 : 0;
-    // Four steps per trip: the codes of a group are fetched from LDS while the group before it runs, and the row-m
-    // cells of a group are looked at together (one branch per group; only lane m - 1 ever takes it).  Steps beyond
-    // `steps` change nothing: no lane is active there.
-    uint32_t q[4], qn[4];
+    const bool rowm = lane == u.m;
+    const int steps = win.span > 0 ? win.span + u.m : 0;
+    // One trip = eight steps.  The codes of steps 4 - 7 are fetched from LDS at the top of the trip (steps 0 - 3 hide
+    // the latency), those of the next trip's steps 0 - 3 after step 3 (hidden by steps 4 - 7).
+    // GUARDED: with the per-lane activity test (the ramps: some rows have not started yet or are done).
+    uint32_t q[8];
 #pragma unroll
     for (int s = 0; s < 4; ++s) q[s] = code[a + 1 + s];
-    for (int t = 0; t < steps; t += 4) {
+    auto trip = [&](auto guarded_tag) {
+        constexpr bool GUARDED = decltype(guarded_tag)::value;
+        const int a0 = a;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qn[s] = code[a + 5 + s];
-        __builtin_amdgcn_sched_barrier(0);                           // (the loads stay up here: a group of steps hides them)
-        uint32_t cell[4];
-        bool hit[4];
+        for (int s = 4; s < 8; ++s) q[s] = code[a0 + 1 + s];
+        __builtin_amdgcn_sched_barrier(0);                           // (the loads stay where they are written)
+        uint32_t cell[8];
+        bool hit[8];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            ++a;
-            r0 = min(r0 + r0_inc, r0_cap);
-            const uint32_t up = wave_shr1(cur, r0);
-            const uint32_t nw = wave_cell<XREP>(diag, cur, up, rowmask, q[s], u.insw, u.delw);
-            const bool active = (unsigned)(a - win.min_n) < (unsigned)win.span;
-            diag = up;
+        for (int s = 0; s < 8; ++s) {
+            uint32_t &up = (s & 1) ? upa : upb, &diag = (s & 1) ? upb : upa;
+            up = wave_shr1(cur, up);
+            const uint32_t nw = wave_cell<XREP, SQ>(diag, cur, up, rowmask, q[s], u.insw, left_step);
             cell[s] = nw;
-            hit[s] = XREP && rowm && active && nw < u.klimit;        // row-m candidate (:433-455)
-            cur = active ? nw : cur;
-        }
-        if (XREP && (hit[0] | hit[1] | hit[2] | hit[3])) {
+            if (GUARDED) {
+                ++a;
+                const bool active = (unsigned)(a - win.min_n) < (unsigned)win.span;
+                hit[s] = XREP && rowm && active && nw < u.klimit;    // row-m candidate (:433-455)
+                cur = active ? nw : cur;
+            } else {
+                cur = nw;
+            }
+            if (s == 3) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                if (hit[s]) consider<XREP>(best, cell[s], u.m, a - 2 + s, u.min_overlap, s_thr, u.indel);
+                for (int k = 0; k < 4; ++k) q[k] = code[a0 + 9 + k];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        if (GUARDED) {
+            if (XREP && (hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7])) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) q[s] = qn[s];
-    }
+                for (int s = 0; s < 8; ++s)
+                    if (hit[s]) consider<XREP>(best, cell[s], u.m, a0 + 2 + s, u.min_overlap, s_thr, u.indel);
+            }
+        } else {
+            a += 8;
+            const uint32_t least = min(min(min(cell[0], cell[1]), min(cell[2], cell[3])), min(min(cell[4], cell[5]), min(cell[6], cell[7])));
+            if (XREP && rowm && least < u.klimit) {                  // lane m only, and rarely
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (cell[s] < u.klimit) consider<XREP>(best, cell[s], u.m, a0 + 2 + s, u.min_overlap, s_thr, u.indel);
+            }
+        }
+    };
+    int t = 1;                                                       // first step of the next trip
+    for (; t <= steps && t <= u.m; t += 8) trip(std::true_type{});  // ramp up: rows start one by one
+    for (; t + 7 <= win.span; t += 8) trip(std::false_type{});      // m < t .. t + 7 <= span: every row 0 .. m is active
+    for (; t <= steps; t += 8) trip(std::true_type{});              // ramp down (steps beyond `steps`: no lane is active)
 
-    // the candidates in the reference's order: row m by column (lane m - 1), then the last column by row
+    // the candidates in the reference's order: row m by column (lane m), then the last column by row
     Best fin;
-    fin.key = __builtin_amdgcn_readlane(best.key, u.m - 1);
-    fin.word = (uint32_t)__builtin_amdgcn_readlane((int)best.word, u.m - 1);
-    fin.ref_stop = __builtin_amdgcn_readlane(best.ref_stop, u.m - 1);
-    fin.query_stop = __builtin_amdgcn_readlane(best.query_stop, u.m - 1);
-    fin.matches = __builtin_amdgcn_readlane(best.matches, u.m - 1);
+    fin.key = __builtin_amdgcn_readlane(best.key, u.m);
+    fin.word = (uint32_t)__builtin_amdgcn_readlane((int)best.word, u.m);
+    fin.ref_stop = __builtin_amdgcn_readlane(best.ref_stop, u.m);
+    fin.query_stop = __builtin_amdgcn_readlane(best.query_stop, u.m);
+    fin.matches = __builtin_amdgcn_readlane(best.matches, u.m);
     if (win.scan) {
-        const int first_row = u.er ? 0 : u.m;
-        if (first_row == 0) {
-            const uint32_t w0 = wave_row0(u, win.max_n);
-            if (w0 < u.klimit) consider<XREP>(fin, w0, 0, n, u.min_overlap, s_thr, u.indel);
-        }
         Best mine;
-        const int key = wave_last_key<XREP>(cur, lane + 1, lane, lane + 1 >= first_row && lane < u.m, u, n, s_thr, mine);
+        const int key = wave_last_key<XREP>(cur, lane, lane, lane >= (u.er ? 0 : u.m) && lane <= u.m, u, n, s_thr, mine);
         const int top = wave_max_key(key);
         if (top >= 0 && (top >> 6) > fin.key) {
             const int src = 63 - (top & 63);
             fin.key = top >> 6;
             fin.word = (uint32_t)__builtin_amdgcn_readlane((int)mine.word, src);
-            fin.ref_stop = src + 1;
+            fin.ref_stop = src;
             fin.query_stop = n;
             fin.matches = __builtin_amdgcn_readlane(mine.matches, src);
         }
@@ -130,10 +147,11 @@ __global__ __launch_bounds__(64) void locate_wave_kernel(const LocateParams p, c
 int launch_locate_wave(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                        int max_len, uint4 *out, hipStream_t st) {
     const dim3 grid((unsigned)nreads), block(64);
-    if (a->flags & ATR_STOP_WITHIN_SEQ2)
-        hipLaunchKernelGGL(locate_wave_kernel<true>, grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
-    else
-        hipLaunchKernelGGL(locate_wave_kernel<false>, grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    const bool xrep = (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (a->flags & ATR_START_WITHIN_SEQ2) != 0;
+    if (xrep && sq)  hipLaunchKernelGGL((locate_wave_kernel<true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (xrep && !sq) hipLaunchKernelGGL((locate_wave_kernel<true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (!xrep && sq) hipLaunchKernelGGL((locate_wave_kernel<false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (!xrep && !sq) hipLaunchKernelGGL((locate_wave_kernel<false, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
     return (int)hipGetLastError();
 }
 

@@ -478,9 +478,9 @@ int emu_linked_match_batch(const atr_linked_set *s, const uint8_t *packed, const
 }  // extern "C"
 
 // locate_wave_kernel (wave_kernel.hip) for one read: the 64 lanes in lock step, the cross-lane moves spelled out
-template <bool XREP>
-static void emu_wave_read(const atr_aligner *a, const uint32_t *pk, int nchunks, long long r, int n, uint32_t *rec) {
-    const LocateParams &p = a->p;
+template <bool XREP, bool SQ>
+static void emu_wave_read(const atr_aligner *a_, const uint32_t *pk, int nchunks, long long r, int n, uint32_t *rec) {
+    const LocateParams &p = a_->p;
     const Uniform u = make_uniform(p, round_up_rows(p.m));
     const WaveWindow win = wave_window<XREP>(u, n);
     std::vector<uint32_t> s_code(WAVE_CODE_PAD + (ATR_MAX_READ_LEN + 31) / 32 * 32 + 2 * WAVE_CODE_PAD, 0xEEEEEEEEu);   // pads: junk on purpose
@@ -489,44 +489,69 @@ static void emu_wave_read(const atr_aligner *a, const uint32_t *pk, int nchunks,
             const uint32_t w = pk[(((size_t)(r >> 6) * nchunks + c) * 64 + (r & 63)) * 4 + (b >> 3)];
             s_code[WAVE_CODE_PAD + 32 * c + b] = (w >> (4 * (b & 7))) & 15u;
         }
-    uint32_t cur[64], diag[64], rowmask[64], up[64], nw[64];
-    int c[64];
+    uint32_t cur[64], upa[64], upb[64], rowmask[64], left_step[64];
+    int a[64];
     Best best[64];
     for (int l = 0; l < 64; ++l) {
-        rowmask[l] = wave_rowmask(p, u.p0, l);
-        cur[l] = init_word(l + 1, win.min_n, u.sr, u.sq, u.indel);
-        c[l] = -l - 1;
+        rowmask[l] = l > 0 ? wave_rowmask(p, u.p0, l) : 0u;
+        left_step[l] = wave_left_step(u, l);
+        cur[l] = init_word(l, win.min_n, u.sr, u.sq, u.indel);
+        a[l] = win.min_n - l - 1;
         wave_best_init(best[l], u, n);
+        upb[l] = WAVE_HUGE;
     }
-    for (int l = 0; l < 64; ++l) diag[l] = l ? cur[l - 1] : wave_row0(u, win.min_n);
-    const uint32_t *code = s_code.data() + WAVE_CODE_PAD + win.min_n;
-    const int steps = win.span > 0 ? win.span + u.m - 1 : 0;
-    for (int t = 1; t <= steps; ++t) {
-        for (int l = 0; l < 64; ++l) up[l] = l ? cur[l - 1] : wave_row0(u, win.min_n + t);
+    auto shr1 = [](const uint32_t *v, uint32_t *keep) {            // keep[l] = v[l - 1], lane 0 untouched
+        uint32_t tmp[64];
+        for (int l = 1; l < 64; ++l) tmp[l] = v[l - 1];
+        for (int l = 1; l < 64; ++l) keep[l] = tmp[l];
+    };
+    for (int l = 0; l < 64; ++l) upa[l] = WAVE_HUGE;
+    shr1(cur, upa);
+    const uint32_t *code = s_code.data() + WAVE_CODE_PAD;
+    const int steps = win.span > 0 ? win.span + u.m : 0;
+    auto trip = [&](bool guarded) {                                   // eight steps (wave_kernel.hip)
+        uint32_t cell[8][64];
+        bool hit[8][64];
+        int a0[64];
+        for (int l = 0; l < 64; ++l) a0[l] = a[l];
+        for (int s = 0; s < 8; ++s) {
+            uint32_t *up = (s & 1) ? upa : upb, *diag = (s & 1) ? upb : upa;
+            shr1(cur, up);
+            for (int l = 0; l < 64; ++l) {
+                const uint32_t nw = wave_cell<XREP, SQ>(diag[l], cur[l], up[l], rowmask[l], code[a0[l] + 1 + s], u.insw, left_step[l]);
+                cell[s][l] = nw;
+                if (guarded) {
+                    ++a[l];
+                    const bool active = (unsigned)(a[l] - win.min_n) < (unsigned)win.span;
+                    hit[s][l] = XREP && l == u.m && active && nw < u.klimit;
+                    if (active) cur[l] = nw;
+                } else {
+                    cur[l] = nw;
+                }
+            }
+        }
         for (int l = 0; l < 64; ++l) {
-            ++c[l];
-            nw[l] = wave_cell<XREP>(diag[l], cur[l], up[l], rowmask[l], code[c[l]], u.insw, u.delw);
-            const bool active = (unsigned)c[l] < (unsigned)win.span;
-            diag[l] = up[l];
-            if (XREP && l == u.m - 1 && active && nw[l] < u.klimit)
-                consider<XREP>(best[l], nw[l], u.m, win.min_n + c[l] + 1, u.min_overlap, p.thr, u.indel);
-            if (active) cur[l] = nw[l];
+            if (!guarded) {
+                a[l] += 8;
+                for (int s = 0; s < 8; ++s) hit[s][l] = XREP && l == u.m && cell[s][l] < u.klimit;
+            }
+            for (int s = 0; s < 8; ++s)
+                if (hit[s][l]) consider<XREP>(best[l], cell[s][l], u.m, a0[l] + 2 + s, u.min_overlap, p.thr, u.indel);
         }
-    }
-    Best fin = best[u.m - 1];
+    };
+    int t = 1;
+    for (; t <= steps && t <= u.m; t += 8) trip(true);
+    for (; t + 7 <= win.span; t += 8) trip(false);
+    for (; t <= steps; t += 8) trip(true);
+    Best fin = best[u.m];
     if (win.scan) {
-        const int first_row = u.er ? 0 : u.m;
-        if (first_row == 0) {
-            const uint32_t w0 = wave_row0(u, win.max_n);
-            if (w0 < u.klimit) consider<XREP>(fin, w0, 0, n, u.min_overlap, p.thr, u.indel);
-        }
         Best mine[64];
         int top = -1;
         for (int l = 0; l < 64; ++l)
-            top = std::max(top, wave_last_key<XREP>(cur[l], l + 1, l, l + 1 >= first_row && l < u.m, u, n, p.thr, mine[l]));
+            top = std::max(top, wave_last_key<XREP>(cur[l], l, l, l >= (u.er ? 0 : u.m) && l <= u.m, u, n, p.thr, mine[l]));
         if (top >= 0 && (top >> 6) > fin.key) {
             const int src = 63 - (top & 63);
-            fin.key = top >> 6; fin.word = mine[src].word; fin.ref_stop = src + 1; fin.query_stop = n;
+            fin.key = top >> 6; fin.word = mine[src].word; fin.ref_stop = src; fin.query_stop = n;
             fin.matches = mine[src].matches;
         }
     }
@@ -548,8 +573,12 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
             const int nchunks = (max_len + 31) / 32;
             for (long long r = 0; r < nreads; ++r) {
                 const int n = lens ? lens[r] : max_len;
-                if (a->flags & ATR_STOP_WITHIN_SEQ2) emu_wave_read<true>(a, (const uint32_t *)packed, nchunks, r, n, (uint32_t *)out + 4 * r);
-                else emu_wave_read<false>(a, (const uint32_t *)packed, nchunks, r, n, (uint32_t *)out + 4 * r);
+                const bool xrep = (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (a->flags & ATR_START_WITHIN_SEQ2) != 0;
+                uint32_t *rec = (uint32_t *)out + 4 * r;
+                if (xrep && sq) emu_wave_read<true, true>(a, (const uint32_t *)packed, nchunks, r, n, rec);
+                if (xrep && !sq) emu_wave_read<true, false>(a, (const uint32_t *)packed, nchunks, r, n, rec);
+                if (!xrep && sq) emu_wave_read<false, true>(a, (const uint32_t *)packed, nchunks, r, n, rec);
+                if (!xrep && !sq) emu_wave_read<false, false>(a, (const uint32_t *)packed, nchunks, r, n, rec);
             }
             return ATR_OK;
         }

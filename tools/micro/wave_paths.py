@@ -25,7 +25,7 @@ def timed(fn, reps=200):
 
 w = synth.workload("C2", 0, 65536, device="cuda")
 al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
-for n in (1, 64, 256, 1000, 2048, 4096, 8192, 16384, 65536):
+for n in (1, 64, 256, 1000, 4096, 16384, 32768, 65536):
     batch = al.pack(w["reads"][:n].contiguous())
     ref = al.locate_batch(batch, path="full").records
     row = {"n": n}
