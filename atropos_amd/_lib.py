@@ -25,6 +25,7 @@ MAX_REF_LEN = 128
 MAX_READ_LEN = 736
 WAVE_MAX_READS = 32768                   # atr_locate_batch: short batches take the wavefront-per-read kernel
 LOCATE_PATHS = {"auto": 0, "full": 1, "filtered": 2, "wave": 3}   # ATR_LOCATE_* of include/atropos_hip.h
+PAIRS_PATHS = {"auto": 0, "full": 1, "fast": 2, "wave": 3}        # ATR_PAIRS_*
 PAIRS_MAX_LEN = 320
 INSERT_MAX_ADAPTER = 128
 INSERT_MAX_READ = 320
@@ -115,6 +116,9 @@ PROTOTYPES = {
     "atr_locate_pairs_need_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p, C.c_void_p]),
+    "atr_locate_pairs_path_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_pairs_full_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p]),
@@ -461,16 +465,17 @@ class HipBackend(object):
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                            query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost,
-                           need=None):
+                           need=None, path="auto"):
         """Aligner.locate with a per-pair reference; both sides tile64-packed.  int16 [npairs, 8].
         need: int32 [npairs] or None -- alignments with fewer matches may come back as None
-        (atr_locate_pairs_need_batch)."""
+        (atr_locate_pairs_need_batch).  path: PAIRS_PATHS ("auto": a wavefront per pair for short batches, the
+        cost / threat / band pipeline or the full sweep for long ones; "full", "fast", "wave": that family)."""
         out = self.empty((npairs, 8), torch.int16)
         with torch.cuda.device(self.device):
-            _check(self.lib, self.lib.atr_locate_pairs_need_batch(
+            _check(self.lib, self.lib.atr_locate_pairs_path_batch(
                 _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
                 query_max_len, npairs, e, flags, int(wildcard_ref), int(wildcard_query), min_overlap, indel_cost,
-                _ptr(need), _ptr(out), self._stream()), "atr_locate_pairs_need_batch")
+                _ptr(need), PAIRS_PATHS[path], _ptr(out), self._stream()), "atr_locate_pairs_path_batch")
         return out
 
     def locate_pairs_full_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,

@@ -412,9 +412,11 @@ class PairAligner(object):
             packed = be.pack_reads(ascii_t, lens_t, max_len, table)
         return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, kind, table)
 
-    def locate_batch(self, references, queries, need=None):
+    def locate_batch(self, references, queries, need=None, path="auto"):
         """references/queries: lists of str, uint8 [n, width] ASCII tensors, or ReadBatches
         packed with the right tables.  Returns a LocateResult (int16 [n, 8] records).
+        path: the kernel family (``_lib.PAIRS_PATHS``; "auto" picks by batch size: a wavefront per pair for short
+        batches, the cost / threat / band pipeline or the full sweep for long ones).
         need: per pair (list or int32 tensor), the number of matches below which the caller ignores the
         alignment (MergeOverlapping's ``matches >= min_overlap``, modifiers.py:896-897): such pairs may come
         back as None, which lets the library stop after its cost pass for pairs that cannot overlap that far."""
@@ -440,7 +442,7 @@ class PairAligner(object):
                 raise ValueError("need: one entry per pair")
         rec = be.locate_pairs_batch(rb.packed, rb.lens, rb.max_len, self.revcomp_ref, qb.packed, qb.lens, qb.max_len,
                                     rb.nreads, self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query,
-                                    self.min_overlap, self.indel_cost, need=need)
+                                    self.min_overlap, self.indel_cost, need=need, path=path)
         return LocateResult(rec)
 
     def locate(self, reference, query):

@@ -42,6 +42,7 @@
 
 namespace atr {
 
+constexpr long long PAIRS_FAST_MIN_PAIRS = 262144;      // below: the full sweep (the pipeline's fixed cost, pairs_kernel.hip)
 constexpr int PF_CLASSES = 8;                       // band widths 16, 32, .. 128 cells
 constexpr int PF_MAX_W = 16 * PF_CLASSES;
 constexpr int PF_ROW_BINS = 28;                     // (rows swept) / 12, clamped

@@ -9,6 +9,7 @@
 #include "atropos_hip.h"
 #include "pairs_core.hpp"
 #include "pairs_fast_core.hpp"
+#include "wave_core.hpp"
 
 namespace atr {
 
@@ -228,6 +229,9 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
                              const uint32_t *qp, const int32_t *ql, int qmax, const int32_t *need, long long npairs,
                              uint4 *out, hipStream_t st);
 
+hipError_t launch_pairs_wave(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
+                             const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out, hipStream_t st);
+
 hipError_t launch_pairs_full_indexed(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
                                      const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out,
                                      const uint4 *order, const uint32_t *range, hipStream_t st) {
@@ -244,7 +248,17 @@ extern "C" int atr_locate_pairs_need_batch(const uint8_t *d_ref_packed, const in
                                            int query_max_len, int64_t npairs, double max_error_rate, int flags,
                                            int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
                                            const int32_t *d_need, atr_result *d_out, void *stream) {
-    if (npairs < 0) return ATR_ERR_INVALID;
+    return atr_locate_pairs_path_batch(d_ref_packed, d_ref_lens, ref_max_len, revcomp_ref, d_query_packed, d_query_lens,
+                                       query_max_len, npairs, max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap,
+                                       indel_cost, d_need, ATR_PAIRS_AUTO, d_out, stream);
+}
+
+extern "C" int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len,
+                                           int revcomp_ref, const uint8_t *d_query_packed, const int32_t *d_query_lens,
+                                           int query_max_len, int64_t npairs, double max_error_rate, int flags,
+                                           int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                                           const int32_t *d_need, int path, atr_result *d_out, void *stream) {
+    if (npairs < 0 || path < ATR_PAIRS_AUTO || path > ATR_PAIRS_WAVE) return ATR_ERR_INVALID;
     PairParams p;
     const int rc = pairs_params(max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost, ref_max_len,
                                 query_max_len, p);
@@ -255,8 +269,17 @@ extern "C" int atr_locate_pairs_need_batch(const uint8_t *d_ref_packed, const in
     // Reads of more than 160 bases without a caller's bound on the matches: their bands (2 k + 1 diagonals on either
     // side of the overlap's end, k = 50 at 250 bases) cost as much as the whole matrix -- measured 66 M pairs/s
     // against 76 M on 2 x 250 bp -- so they keep the full sweep; with d_need most pairs end after the cost pass.
-    const bool worth = ref_max_len <= 160 || d_need != nullptr;
-    if (worth && pairs_fast_applies(max_error_rate, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, query_max_len) &&
+    if (path == ATR_PAIRS_WAVE && !wave_pairs_applies(ref_max_len, 0)) return ATR_ERR_UNSUPPORTED;
+    if (path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && wave_pairs_applies(ref_max_len, (long long)npairs) && ref_max_len > 0)) {
+        // short batch: a wavefront per pair (pairs_wave.hip); a lane per pair is one chain of m x n dependent cells
+        const hipError_t e = launch_pairs_wave(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len,
+                                               (long long)npairs, (uint4 *)d_out, (hipStream_t)stream);
+        return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_wave_kernel launch");
+    }
+    // ... and a batch below a quarter of a million pairs: the pipeline's dozen launches cost 1.2 ms (2 x 150 bp) whatever
+    // the batch holds, the full sweep 0.36 ms up to 64 k pairs (tools/micro/small_pairs.py)
+    const bool worth = path == ATR_PAIRS_FAST || ((ref_max_len <= 160 || d_need != nullptr) && npairs >= PAIRS_FAST_MIN_PAIRS);
+    if (path != ATR_PAIRS_FULL && worth && pairs_fast_applies(max_error_rate, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, query_max_len) &&
         npairs < (1ll << 32)) {
         // costs by bit-vector, threats, banded payload (pairs_fast_core.hpp); pairs outside its envelope take the
         // full sweep inside the same call

@@ -126,5 +126,53 @@ ATR_DEV void wave_result(const Best &best, const Uniform &u, int n, uint32_t rec
 
 inline bool wave_applies(int m, long long nreads) { return m >= 1 && m <= WAVE_MAX_M && nreads <= WAVE_MAX_READS; }
 
+// ---- R rows per lane (the per-pair aligner: references of up to 64 R - 1 bases) -------------------------------
+// Lane l owns R consecutive rows and sweeps them top-down inside a step (the column_step of locate_core.hpp on R
+// cells); its top row takes `up` / `diag` from lane l - 1's BOTTOM row through the DPP move.  Rows are
+// BOTTOM-ALIGNED: row m is the bottom row of lane L - 1 (L = lanes in use), so its cell is found without a
+// per-pair select; the `off` = L R - 1 - m slots above row 0 in lane 0 are padding that stays at WAVE_HUGE
+// (left step 0), which makes row 0 -- wherever it sits in lane 0 -- take its `left` candidate as in the
+// one-row kernel.
+constexpr int WAVE_PAIR_ROWS_MAX = 5;          // 64 * 5 - 1 = 319 rows
+constexpr long long WAVE_MAX_PAIRS = 32768;
+inline int wave_pair_rows(int m) { return (m + 1 + 63) / 64; }                 // rows per lane for a reference of m bases
+inline bool wave_pairs_applies(int ref_max_len, long long npairs) {
+    return ref_max_len >= 1 && ref_max_len <= 64 * WAVE_PAIR_ROWS_MAX - 1 && npairs <= WAVE_MAX_PAIRS;
+}
+
+template <int R>
+struct WaveRows {
+    uint32_t col[R];           // the lane's cells of its current column
+    uint32_t rowmask[R];       // bit c: the row does NOT match query code c
+    uint32_t lstep[R];         // what a step adds to the `left` candidate: deletion word / row 0's increment / 0 (padding)
+};
+
+// the new cells of a lane for the next column (not stored); CAPW: see wave_cell
+template <bool XREP, bool SQ, int R, uint32_t CAPW>
+ATR_DEV void wave_rows_step(const WaveRows<R> &W, uint32_t diag_in, uint32_t up_in, uint32_t q, uint32_t insw, uint32_t (&out)[R]) {
+    uint32_t prev_old = diag_in, prev_new = up_in;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t bit = atr_bfe1v(W.rowmask[r], q);
+        const uint32_t cd = XREP ? atr_mad24(bit, COST1 + MATCH1, prev_old) : atr_mad24(bit, DIAG_DELTA, prev_old + MATCH1);
+        uint32_t nw = atr_minu(atr_minu(cd, W.col[r] + W.lstep[r]), prev_new + insw) & ~PRIO_MASK;
+        if (!SQ) nw = atr_minu(nw, CAPW);
+        prev_old = W.col[r];
+        prev_new = nw;
+        out[r] = nw;
+    }
+}
+
+// geometry of one pair on the wave: rows per lane R, lanes in use, padding slots above row 0
+struct WaveGeom { int lanes, off; };
+ATR_DEV WaveGeom wave_geom(int m, int R) {
+    WaveGeom g;
+    g.lanes = (m + 1 + R - 1) / R;
+    g.off = g.lanes * R - 1 - m;
+    return g;
+}
+// global row of slot rr of `lane` (negative: padding)
+ATR_DEV int wave_slot_row(const WaveGeom &g, int R, int lane, int rr) { return lane * R + rr - g.off; }
+
 }  // namespace atr
 #endif

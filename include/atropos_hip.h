@@ -388,6 +388,19 @@ int atr_locate_pairs_need_batch(const uint8_t *d_ref_packed, const int32_t *d_re
                                 const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,
                                 int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
                                 int min_overlap, int indel_cost, const int32_t *d_need, atr_result *d_out, void *stream);
+
+/* The same with the kernel family named (identical records up to the `need` rule; cross-checks, tuning).  Short
+ * batches -- the 1000 pairs MergeOverlapping sees per call of the reference's trim command -- take ATR_PAIRS_WAVE:
+ * one pair per wavefront, 64 lanes x up to 5 rows each (references of up to 319 bases), anti-diagonal sweep. */
+#define ATR_PAIRS_AUTO  0   /* WAVE for at most 32768 pairs where it applies, else FAST where it pays, else FULL */
+#define ATR_PAIRS_FULL  1   /* full-matrix sweep, one pair per lane (atr_locate_pairs_full_batch) */
+#define ATR_PAIRS_FAST  2   /* costs by bit-vector, threats, banded payload; FULL for what is outside its envelope */
+#define ATR_PAIRS_WAVE  3   /* one pair per wavefront; ATR_ERR_UNSUPPORTED for references of more than 319 bases */
+int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len,
+                                int revcomp_ref, const uint8_t *d_query_packed, const int32_t *d_query_lens,
+                                int query_max_len, int64_t npairs, double max_error_rate, int flags,
+                                int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                                const int32_t *d_need, int path, atr_result *d_out, void *stream);
 /* atr_locate_pairs_batch by the full-matrix sweep alone (same records; the checker of the pipeline above). */
 int atr_locate_pairs_full_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
                                 const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,

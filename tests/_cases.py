@@ -914,9 +914,11 @@ def check_pairs_against_oracle(PairAligner, oracle, unsupported_exc, seed, round
         given = [reverse_complement(r) for r in refs] if rc else refs     # what the device is handed
         try:
             pa = PairAligner(e, flags, wr, wq, mo, ic, revcomp_ref=rc)
-            got = pa.locate_batch(given, qrys).tuples()
+            got = pa.locate_batch(given, qrys).tuples()               # short batch: a wavefront per pair (<= 319 rows)
         except unsupported_exc:
             continue
+        for path in ("full", "fast") + (("wave",) if top <= 319 else ()):
+            assert pa.locate_batch(given, qrys, path=path).tuples() == got, (path, e, flags, wr, wq, mo, ic, rc, top)
         for ref, qry, g in zip(refs, qrys, got):
             assert g == oracle.locate(ref, qry, e, flags, wr, wq, mo, ic), (ref, qry, e, flags, wr, wq, mo, ic, rc, g)
             total += 1
@@ -1300,9 +1302,11 @@ def check_pairs_fast(PairAligner, oracle, seed, rounds, top=150, npairs=96, adve
         given = [reverse_complement(r) for r in refs] if rc else refs
         pa = PairAligner(e, flags, False, False, mo, 1, revcomp_ref=rc)
         # need = 1: every alignment matters (and reads of more than 160 bases take the fast pipeline as well)
-        got = pa.locate_batch(given, qrys, need=[1] * len(refs)).tuples()
+        got = pa.locate_batch(given, qrys, need=[1] * len(refs), path="fast").tuples()
         nd = rng.choice([2, 10, top // 3, top // 2])
-        part = pa.locate_batch(given, qrys, need=[nd] * len(refs)).tuples()
+        part = pa.locate_batch(given, qrys, need=[nd] * len(refs), path="fast").tuples()
+        if top <= 319:
+            assert pa.locate_batch(given, qrys, path="wave").tuples() == got
         for ref, qry, g, h in zip(refs, qrys, got, part):
             exp = oracle.locate(ref, qry, e, flags, False, False, mo, 1)
             assert g == exp, (ref, qry, e, flags, mo, rc, g, exp)

@@ -269,8 +269,10 @@ class EmuBackend(object):
 
     def locate_pairs_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                            query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost,
-                           need=None):
+                           need=None, path="auto"):
+        from atropos_amd._lib import PAIRS_PATHS
         out = torch.zeros((npairs, 8), dtype=torch.int16)
+        C.c_int.in_dll(self.lib, "emu_pairs_path").value = PAIRS_PATHS[path]
         _check(self.lib.emu_locate_pairs_need_batch(
             _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
             query_max_len, C.c_int64(npairs), C.c_double(e), flags, int(wildcard_ref), int(wildcard_query), min_overlap,
@@ -279,13 +281,8 @@ class EmuBackend(object):
 
     def locate_pairs_full_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                                 query_max_len, npairs, e, flags, min_overlap, indel_cost):
-        fast = C.c_int.in_dll(self.lib, "emu_pairs_fast")
-        prev, fast.value = fast.value, 0
-        try:
-            return self.locate_pairs_batch(ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
-                                           query_max_len, npairs, e, flags, False, False, min_overlap, indel_cost)
-        finally:
-            fast.value = prev
+        return self.locate_pairs_batch(ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                                       query_max_len, npairs, e, flags, False, False, min_overlap, indel_cost, path="full")
 
     # -- device-resident FASTQ batch (CPU twin) ----------------------------------
     def fastq_index(self, data, nbytes):

@@ -10,6 +10,7 @@
 #include "misc_core.hpp"
 #include "pairs_core.hpp"
 #include "pairs_fast_core.hpp"
+#include "wave_core.hpp"
 
 using namespace atr;
 
@@ -226,7 +227,141 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
     return true;
 }
 
+// pairs_wave_kernel (pairs_wave.hip) for one pair: the 64 lanes in lock step, the cross-lane move spelled out
+template <bool XREP, bool SQ, int R, bool AND_MODE>
+static void emu_pair_wave_one(const atr::PairParams &p, const uint32_t *rp, int m, bool revcomp, const uint32_t *qp, int n,
+                              uint32_t *rec) {
+    using namespace atr;
+    constexpr int PAD = 64;
+    constexpr uint32_t CAPW = (uint32_t)PAIRS_ORG_BIAS | ((uint32_t)INIT_COST_CAP << CSH);
+    const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0;
+    int k = (int)(p.e * m);
+    if (k < 0) k = -1;
+    int indel = p.indel_cost > k ? k + 1 : p.indel_cost;
+    if (indel < 1) indel = 1;
+    const uint32_t insw = (uint32_t)indel * COST1 + PRIO_INS, delw = (uint32_t)indel * COST1 + PRIO_DEL;
+    const uint32_t klimit = (uint32_t)(k + 1) << CSH;
+    const int max_n = SQ ? n : std::min(n, m + k), min_n = XREP ? 0 : std::max(0, n - m - k);
+    const int span = std::max(0, max_n - min_n);
+    const bool scan = max_n == n;
+    std::vector<uint32_t> s_code(PAD + (PAIRS_MAX_LEN + 31) / 32 * 32 + 2 * PAD, 0xEEEEEEEEu), s_ref(PAIRS_MAX_LEN + 64, 0u);
+    for (int j = 0; j < n; ++j) s_code[PAD + j] = packed_code(qp, j);
+    for (int i = 0; i < m; ++i) {
+        const uint32_t c = packed_code(rp, i);
+        if (revcomp) s_ref[m - 1 - i] = bitrev4(c); else s_ref[i] = c;
+    }
+    const WaveGeom g = wave_geom(m, R);
+    WaveRows<R> W[64];
+    uint32_t upa[64], upb[64];
+    int a[64];
+    Best best[64];
+    for (int l = 0; l < 64; ++l) {
+        for (int rr = 0; rr < R; ++rr) {
+            const int row = wave_slot_row(g, R, l, rr);
+            uint32_t mask = 0u;
+            if (row >= 1 && row <= m) {
+                const uint32_t c = s_ref[row - 1];
+                if (AND_MODE) { for (uint32_t q = 0; q < 16; ++q) mask |= ((c & q) == 0u ? 1u : 0u) << q; }
+                else mask = ~(1u << c) & 0xFFFFu;
+            }
+            W[l].rowmask[rr] = mask;
+            W[l].lstep[rr] = row < 0 ? 0u : row == 0 ? (SQ ? 1u : (uint32_t)indel << CSH) : delw;
+            W[l].col[rr] = row < 0 ? WAVE_HUGE : init_word(row, min_n, sr, SQ, indel) + (uint32_t)(PAIRS_ORG_BIAS - (int)ORG_BIAS);
+        }
+        a[l] = min_n - l - 1;
+        best[l].key = COST_FIELD_MAX - (m + n); best[l].word = (uint32_t)(m + n) << CSH;
+        best[l].ref_stop = m; best[l].query_stop = n; best[l].matches = 0;
+        upa[l] = upb[l] = WAVE_HUGE;
+    }
+    auto shr1 = [&](uint32_t *keep) {                               // keep[l] = bottom cell of lane l - 1; lane 0 untouched
+        uint32_t tmp[64];
+        for (int l = 1; l < 64; ++l) tmp[l] = W[l - 1].col[R - 1];
+        for (int l = 1; l < 64; ++l) keep[l] = tmp[l];
+    };
+    shr1(upa);
+    const uint32_t *code = s_code.data() + PAD;
+    const int steps = span > 0 ? span + g.lanes - 1 : 0;
+    auto trip = [&](bool guarded) {
+        uint32_t bottom[4][64];
+        bool hit[4][64];
+        int a0[64];
+        for (int l = 0; l < 64; ++l) a0[l] = a[l];
+        for (int s = 0; s < 4; ++s) {
+            uint32_t *up = (s & 1) ? upa : upb, *diag = (s & 1) ? upb : upa;
+            shr1(up);
+            for (int l = 0; l < 64; ++l) {
+                uint32_t nw[R];
+                wave_rows_step<XREP, SQ, R, CAPW>(W[l], diag[l], up[l], code[a0[l] + 1 + s], insw, nw);
+                bottom[s][l] = nw[R - 1];
+                if (guarded) {
+                    ++a[l];
+                    const bool active = (unsigned)(a[l] - min_n) < (unsigned)span;
+                    hit[s][l] = XREP && l == g.lanes - 1 && active && nw[R - 1] < klimit;
+                    if (active) for (int rr = 0; rr < R; ++rr) W[l].col[rr] = nw[rr];
+                } else {
+                    for (int rr = 0; rr < R; ++rr) W[l].col[rr] = nw[rr];
+                }
+            }
+        }
+        for (int l = 0; l < 64; ++l) {
+            if (!guarded) {
+                a[l] += 4;
+                for (int s = 0; s < 4; ++s) hit[s][l] = XREP && l == g.lanes - 1 && bottom[s][l] < klimit;
+            }
+            for (int s = 0; s < 4; ++s)
+                if (hit[s][l]) consider<XREP, PAIRS_ORG_BIAS>(best[l], bottom[s][l], m, a0[l] + 2 + s, p.min_overlap, p.thr, indel);
+        }
+    };
+    int t = 1;
+    for (; t <= steps && t <= g.lanes - 1; t += 4) trip(true);
+    for (; t + 3 <= span; t += 4) trip(false);
+    for (; t <= steps; t += 4) trip(true);
+    Best fin = best[g.lanes - 1];
+    if (scan) {
+        const int first_row = er ? 0 : m;
+        Best mine[64];
+        int top = -1;
+        for (int l = 0; l < 64; ++l) {
+            mine[l].key = -1; mine[l].word = 0; mine[l].ref_stop = 0; mine[l].query_stop = n; mine[l].matches = 0;
+            for (int rr = 0; rr < R; ++rr) {
+                const int row = wave_slot_row(g, R, l, rr);
+                if (row >= first_row && row <= m) consider<XREP, PAIRS_ORG_BIAS>(mine[l], W[l].col[rr], row, n, p.min_overlap, p.thr, indel);
+            }
+            top = std::max(top, mine[l].key < 0 ? -1 : (mine[l].key << 6) | (63 - l));
+        }
+        if (top >= 0 && (top >> 6) > fin.key) {
+            const int src = 63 - (top & 63);
+            fin.key = top >> 6; fin.word = mine[src].word; fin.ref_stop = mine[src].ref_stop; fin.query_stop = n;
+            fin.matches = mine[src].matches;
+        }
+    }
+    const int cost = (int)(fin.word >> CSH);
+    int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
+    if (cost != m + n) {
+        const int origin = (int)(fin.word & ORG_MASK) - PAIRS_ORG_BIAS;
+        if (origin >= 0) querystart = origin; else refstart = -origin;
+        refstop = fin.ref_stop; querystop = fin.query_stop; matches = fin.matches; errors = cost;
+    }
+    rec[0] = (uint32_t)(refstart & 0xFFFF) | ((uint32_t)(refstop & 0xFFFF) << 16);
+    rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
+    rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
+    rec[3] = 0;
+}
+
+template <int R>
+static void emu_pair_wave_r(const atr::PairParams &p, const uint32_t *rp, int m, bool revcomp, const uint32_t *qp, int n, uint32_t *rec) {
+    const bool xrep = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0, am = p.and_mode != 0;
+#define ATR_EMU_PW(X, S, A) emu_pair_wave_one<X, S, R, A>(p, rp, m, revcomp, qp, n, rec)
+    if (xrep && sq) { if (am) ATR_EMU_PW(true, true, true); else ATR_EMU_PW(true, true, false); }
+    else if (xrep) { if (am) ATR_EMU_PW(true, false, true); else ATR_EMU_PW(true, false, false); }
+    else if (sq) { if (am) ATR_EMU_PW(false, true, true); else ATR_EMU_PW(false, true, false); }
+    else { if (am) ATR_EMU_PW(false, false, true); else ATR_EMU_PW(false, false, false); }
+#undef ATR_EMU_PW
+}
+
 extern "C" {
+
+int emu_pairs_path = 0;          // ATR_PAIRS_* of the next emu_locate_pairs_*_batch call (set by tests/emu/backend.py)
 
 int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
                                 const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
@@ -252,8 +387,13 @@ int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_l
     if (rc != ATR_OK) return rc;
     const int rch = (ref_max_len + 31) / 32, qch = (qry_max_len + 31) / 32;
     std::vector<uint32_t> col((size_t)ref_max_len + 1), refw((size_t)(ref_max_len + 7) / 8 + 1);
-    const bool fast = emu_pairs_fast && atr::pairs_fast_applies(e, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len,
-                                                                qry_max_len);
+    const int path = emu_pairs_path;
+    if (path < ATR_PAIRS_AUTO || path > ATR_PAIRS_WAVE) return ATR_ERR_INVALID;
+    if (path == ATR_PAIRS_WAVE && !atr::wave_pairs_applies(ref_max_len, 0)) return ATR_ERR_UNSUPPORTED;
+    const bool wave = path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && atr::wave_pairs_applies(ref_max_len, npairs) && ref_max_len > 0);
+    const bool worth = path == ATR_PAIRS_FAST || ((ref_max_len <= 160 || need != nullptr) && npairs >= atr::PAIRS_FAST_MIN_PAIRS);   // as the library
+    const bool fast = !wave && path != ATR_PAIRS_FULL && (path == ATR_PAIRS_FAST || emu_pairs_fast) && worth &&
+                      atr::pairs_fast_applies(e, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, qry_max_len);
     static atr::PairFastParams fp;
     if (fast) { fp.pp = p; atr::pairs_fast_tables(e, fp); }
     for (int64_t r = 0; r < npairs; ++r) {
@@ -264,6 +404,16 @@ int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_l
         if (n > qry_max_len) n = qry_max_len;
         const uint32_t *rp = ref_packed + ((size_t)tile * rch * 64 + lane) * 4;
         const uint32_t *qp = qry_packed + ((size_t)tile * qch * 64 + lane) * 4;
+        if (wave) {                                                  // as the library: a wavefront per pair
+            switch (atr::wave_pair_rows(ref_max_len)) {
+                case 1: emu_pair_wave_r<1>(p, rp, m, revcomp != 0, qp, n, out + 4 * r); break;
+                case 2: emu_pair_wave_r<2>(p, rp, m, revcomp != 0, qp, n, out + 4 * r); break;
+                case 3: emu_pair_wave_r<3>(p, rp, m, revcomp != 0, qp, n, out + 4 * r); break;
+                case 4: emu_pair_wave_r<4>(p, rp, m, revcomp != 0, qp, n, out + 4 * r); break;
+                default: emu_pair_wave_r<5>(p, rp, m, revcomp != 0, qp, n, out + 4 * r); break;
+            }
+            continue;
+        }
         if (fast) {                                                  // as the library: costs, threats, banded payload
             const int nd = need ? need[r] : 1;
             bool done;
