@@ -11,7 +11,8 @@
 //     left  (l,     j - 1)  its own cell of step t - 1,
 //     up    (l - 1, j)      lane l - 1's cell of step t - 1  (one DPP wave_shr:1),
 //     diag  (l - 1, j - 1)  the `up` of step t - 1,
-// i.e. n + m steps of 7 - 12 VALU ops instead of n * m * 7.  Lane 0 has no lane below it: the DPP move leaves
+// i.e. n + m steps of 7 - 12 VALU ops instead of n * m * 7 (references of 64 bases and more: two or three rows per
+// lane, see WaveRows below).  Lane 0 has no lane below it: the DPP move leaves
 // its destination alone there, and that register holds WAVE_HUGE from the start, so lane 0 always takes the
 // `left` candidate, with its own increment instead of the deletion cost: row 0 of the reference
 // (:385-388: origin j, or cost j * indel).  A lane is active while 1 <= j - min_n <= span and keeps its
@@ -29,7 +30,7 @@
 
 namespace atr {
 
-constexpr int WAVE_MAX_M = 63;                 // rows 0 .. 63 on the 64 lanes
+constexpr int WAVE_MAX_M = ATR_MAX_REF_LEN;    // rows 0 .. m on the 64 lanes, up to three per lane
 constexpr long long WAVE_MAX_READS = 32768;    // beyond: the lane-per-read kernels (the chip is full, fewer instructions win)
 constexpr int WAVE_CODE_PAD = 64;              // LDS entries in front of the codes, twice as many behind (inactive lanes read there)
 constexpr uint32_t WAVE_HUGE = 0xBFF00000u;    // "no such cell": cost 3071, beyond every real cell, no overflow after + indel
@@ -47,13 +48,13 @@ static __device__ __forceinline__ uint32_t atr_bfe1v(uint32_t w, uint32_t i) {
 // bit c of the result: reference row `row` (1-based) does NOT match query code c
 ATR_DEV uint32_t wave_rowmask(const LocateParams &p, int p0, int row) {
     const int pos = p0 + row - 1, w = pos >> 5, b = pos & 31;
-    // (masks, not a select chain over the three words: the compiler turns that into p.nmask[c][w], a run-time index
+    // (masks, not a select chain over the four words: the compiler turns that into p.nmask[c][w], a run-time index
     //  that moves the whole parameter block to scratch memory)
-    const uint32_t s0 = w == 0 ? ~0u : 0u, s1 = w == 1 ? ~0u : 0u, s2 = w == 2 ? ~0u : 0u;
+    const uint32_t s0 = w == 0 ? ~0u : 0u, s1 = w == 1 ? ~0u : 0u, s2 = w == 2 ? ~0u : 0u, s3 = w == 3 ? ~0u : 0u;
     uint32_t mask = 0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const uint32_t word = (p.nmask[c][0] & s0) | (p.nmask[c][1] & s1) | (p.nmask[c][2] & s2);
+        const uint32_t word = (p.nmask[c][0] & s0) | (p.nmask[c][1] & s1) | (p.nmask[c][2] & s2) | (p.nmask[c][3] & s3);
         mask |= ((word >> b) & 1u) << c;
     }
     return mask;
@@ -91,15 +92,6 @@ ATR_DEV WaveWindow wave_window(const Uniform &u, int n) {
     w.span = atr_max(0, w.max_n - w.min_n);
     w.scan = w.max_n == n && (w.span > 0 || n == 0);          // :461; an empty read scans its initial column
     return w;
-}
-
-// key of a last-column cell for the wave reduction: (key of consider(), smallest row first); -1 = no candidate
-template <bool XREP>
-ATR_DEV int wave_last_key(uint32_t cell, int row, int lane, bool wanted, const Uniform &u, int n, const int16_t *thr,
-                          Best &b) {
-    b.key = -1; b.word = 0; b.ref_stop = 0; b.query_stop = 0; b.matches = 0;
-    if (wanted && cell < u.klimit) consider<XREP>(b, cell, row, n, u.min_overlap, thr, u.indel);
-    return b.key < 0 ? -1 : (b.key << 6) | (63 - lane);
 }
 
 ATR_DEV void wave_best_init(Best &b, const Uniform &u, int n) {

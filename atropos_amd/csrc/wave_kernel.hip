@@ -18,7 +18,7 @@ __device__ __forceinline__ int wave_max_key(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <bool XREP, bool SQ>
+template <bool XREP, bool SQ, int R>
 __global__ __launch_bounds__(64) void locate_wave_kernel(const LocateParams p, const uint4 *__restrict__ packed,
                                                          const int32_t *__restrict__ lens, long long nreads, int nchunks,
                                                          int max_len, uint4 *__restrict__ out) {
@@ -47,92 +47,115 @@ __global__ __launch_bounds__(64) void locate_wave_kernel(const LocateParams p, c
             dst[2 * d + 1] = make_uint4((w[d] >> 16) & 15u, (w[d] >> 20) & 15u, (w[d] >> 24) & 15u, w[d] >> 28);
         }
     }
-    const uint32_t rowmask = lane > 0 ? wave_rowmask(p, u.p0, lane) : 0u;
-    const uint32_t left_step = wave_left_step(u, lane);
+    // R rows per lane, bottom-aligned: row m is the bottom slot of lane g.lanes - 1, the slots above row 0 are padding
+    const WaveGeom g = wave_geom(u.m, R);
+    WaveRows<R> W;
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {
+        const int row = wave_slot_row(g, R, lane, rr);
+        W.rowmask[rr] = (row >= 1 && row <= u.m) ? wave_rowmask(p, u.p0, row) : 0u;
+        W.lstep[rr] = row < 0 ? 0u : row == 0 ? (SQ ? 1u : (uint32_t)u.indel << CSH) : u.delw;
+        W.col[rr] = row < 0 ? WAVE_HUGE : init_word(row, win.min_n, u.sr, SQ, u.indel);   // cells of the initial column (min_n)
+    }
     __syncthreads();
 
-    // cells of the initial column (min_n); lane 0: row 0.  `up` lives in two registers used in turn, so that the
-    // one a DPP move writes is the one whose lane 0 still holds WAVE_HUGE.
-    uint32_t cur = init_word(lane, win.min_n, u.sr, u.sq, u.indel);
-    uint32_t upa = wave_shr1(cur, WAVE_HUGE), upb = WAVE_HUGE;       // upa: the diagonal input of step 1
+    // `up` lives in two registers used in turn, so that the one a DPP move writes is the one whose lane 0 still
+    // holds WAVE_HUGE.
+    uint32_t upa = wave_shr1(W.col[R - 1], WAVE_HUGE), upb = WAVE_HUGE;   // upa: the diagonal input of step 1
     int a = win.min_n - lane - 1;                                    // 0-based query position of this lane's column, before step 1
     const uint32_t *code = s_code + WAVE_CODE_PAD;
     Best best;
     wave_best_init(best, u, n);
-    const bool rowm = lane == u.m;
-    const int steps = win.span > 0 ? win.span + u.m : 0;
-    // One trip = eight steps.  The codes of steps 4 - 7 are fetched from LDS at the top of the trip (steps 0 - 3 hide
-    // the latency), those of the next trip's steps 0 - 3 after step 3 (hidden by steps 4 - 7).
+    const bool rowm = lane == g.lanes - 1;
+    const int steps = win.span > 0 ? win.span + g.lanes - 1 : 0;
+    // One trip = TRIP steps (eight of one row, four of more).  The codes of a trip's second half are fetched from LDS at
+    // its top (the first half hides the latency), those of the next trip's first half after this one's.
     // GUARDED: with the per-lane activity test (the ramps: some rows have not started yet or are done).
-    uint32_t q[8];
+    constexpr int TRIP = R == 1 ? 8 : 4, HALF = TRIP / 2;
+    uint32_t q[TRIP];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) q[s] = code[a + 1 + s];
+    for (int s = 0; s < HALF; ++s) q[s] = code[a + 1 + s];
     auto trip = [&](auto guarded_tag) {
         constexpr bool GUARDED = decltype(guarded_tag)::value;
         const int a0 = a;
 #pragma unroll
-        for (int s = 4; s < 8; ++s) q[s] = code[a0 + 1 + s];
+        for (int s = HALF; s < TRIP; ++s) q[s] = code[a0 + 1 + s];
         __builtin_amdgcn_sched_barrier(0);                           // (the loads stay where they are written)
-        uint32_t cell[8];
-        bool hit[8];
+        uint32_t bottom[TRIP];
+        bool hit[TRIP];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < TRIP; ++s) {
             uint32_t &up = (s & 1) ? upa : upb, &diag = (s & 1) ? upb : upa;
-            up = wave_shr1(cur, up);
-            const uint32_t nw = wave_cell<XREP, SQ>(diag, cur, up, rowmask, q[s], u.insw, left_step);
-            cell[s] = nw;
+            up = wave_shr1(W.col[R - 1], up);
+            uint32_t nw[R];
+            wave_rows_step<XREP, SQ, R, WAVE_ROW0_CAP>(W, diag, up, q[s], u.insw, nw);
+            bottom[s] = nw[R - 1];
             if (GUARDED) {
                 ++a;
                 const bool active = (unsigned)(a - win.min_n) < (unsigned)win.span;
-                hit[s] = XREP && rowm && active && nw < u.klimit;    // row-m candidate (:433-455)
-                cur = active ? nw : cur;
+                hit[s] = XREP && rowm && active && nw[R - 1] < u.klimit;    // row-m candidate (:433-455)
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) W.col[rr] = active ? nw[rr] : W.col[rr];
             } else {
-                cur = nw;
+#pragma unroll
+                for (int rr = 0; rr < R; ++rr) W.col[rr] = nw[rr];
             }
-            if (s == 3) {
+            if (s == HALF - 1) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) q[k] = code[a0 + 9 + k];
+                for (int k = 0; k < HALF; ++k) q[k] = code[a0 + TRIP + 1 + k];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (GUARDED) {
-            if (XREP && (hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7])) {
+            bool any = false;
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    if (hit[s]) consider<XREP>(best, cell[s], u.m, a0 + 2 + s, u.min_overlap, s_thr, u.indel);
+            for (int s = 0; s < TRIP; ++s) any = any | hit[s];
+            if (XREP && any) {
+#pragma unroll
+                for (int s = 0; s < TRIP; ++s)
+                    if (hit[s]) consider<XREP>(best, bottom[s], u.m, a0 + 2 + s, u.min_overlap, s_thr, u.indel);
             }
         } else {
-            a += 8;
-            const uint32_t least = min(min(min(cell[0], cell[1]), min(cell[2], cell[3])), min(min(cell[4], cell[5]), min(cell[6], cell[7])));
-            if (XREP && rowm && least < u.klimit) {                  // lane m only, and rarely
+            a += TRIP;
+            uint32_t least = bottom[0];
 #pragma unroll
-                for (int s = 0; s < 8; ++s)
-                    if (cell[s] < u.klimit) consider<XREP>(best, cell[s], u.m, a0 + 2 + s, u.min_overlap, s_thr, u.indel);
+            for (int s = 1; s < TRIP; ++s) least = min(least, bottom[s]);
+            if (XREP && rowm && least < u.klimit) {                  // lane L - 1 only, and rarely
+#pragma unroll
+                for (int s = 0; s < TRIP; ++s)
+                    if (bottom[s] < u.klimit) consider<XREP>(best, bottom[s], u.m, a0 + 2 + s, u.min_overlap, s_thr, u.indel);
             }
         }
     };
     int t = 1;                                                       // first step of the next trip
-    for (; t <= steps && t <= u.m; t += 8) trip(std::true_type{});  // ramp up: rows start one by one
-    for (; t + 7 <= win.span; t += 8) trip(std::false_type{});      // m < t .. t + 7 <= span: every row 0 .. m is active
-    for (; t <= steps; t += 8) trip(std::true_type{});              // ramp down (steps beyond `steps`: no lane is active)
+    for (; t <= steps && t <= g.lanes - 1; t += TRIP) trip(std::true_type{});    // ramp up: lanes start one by one
+    for (; t + TRIP - 1 <= win.span; t += TRIP) trip(std::false_type{});         // every lane in use is active
+    for (; t <= steps; t += TRIP) trip(std::true_type{});                         // ramp down (beyond `steps`: no lane is active)
 
-    // the candidates in the reference's order: row m by column (lane m), then the last column by row
+    // the candidates in the reference's order: row m by column (lane L - 1), then the last column by row
     Best fin;
-    fin.key = __builtin_amdgcn_readlane(best.key, u.m);
-    fin.word = (uint32_t)__builtin_amdgcn_readlane((int)best.word, u.m);
-    fin.ref_stop = __builtin_amdgcn_readlane(best.ref_stop, u.m);
-    fin.query_stop = __builtin_amdgcn_readlane(best.query_stop, u.m);
-    fin.matches = __builtin_amdgcn_readlane(best.matches, u.m);
+    fin.key = __builtin_amdgcn_readlane(best.key, g.lanes - 1);
+    fin.word = (uint32_t)__builtin_amdgcn_readlane((int)best.word, g.lanes - 1);
+    fin.ref_stop = __builtin_amdgcn_readlane(best.ref_stop, g.lanes - 1);
+    fin.query_stop = __builtin_amdgcn_readlane(best.query_stop, g.lanes - 1);
+    fin.matches = __builtin_amdgcn_readlane(best.matches, g.lanes - 1);
     if (win.scan) {
+        const int first_row = u.er ? 0 : u.m;
         Best mine;
-        const int key = wave_last_key<XREP>(cur, lane, lane, lane >= (u.er ? 0 : u.m) && lane <= u.m, u, n, s_thr, mine);
-        const int top = wave_max_key(key);
+        mine.key = -1; mine.word = 0; mine.ref_stop = 0; mine.query_stop = n; mine.matches = 0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) {                              // ascending rows: the first of equal keys stays
+            const int row = wave_slot_row(g, R, lane, rr);
+            if (row >= first_row && row <= u.m && W.col[rr] < u.klimit)
+                consider<XREP>(mine, W.col[rr], row, n, u.min_overlap, s_thr, u.indel);
+        }
+        const int top = wave_max_key(mine.key < 0 ? -1 : (mine.key << 6) | (63 - lane));
         if (top >= 0 && (top >> 6) > fin.key) {
             const int src = 63 - (top & 63);
             fin.key = top >> 6;
             fin.word = (uint32_t)__builtin_amdgcn_readlane((int)mine.word, src);
-            fin.ref_stop = src;
+            fin.ref_stop = __builtin_amdgcn_readlane(mine.ref_stop, src);
             fin.query_stop = n;
             fin.matches = __builtin_amdgcn_readlane(mine.matches, src);
         }
@@ -144,14 +167,24 @@ __global__ __launch_bounds__(64) void locate_wave_kernel(const LocateParams p, c
     }
 }
 
-int launch_locate_wave(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                       int max_len, uint4 *out, hipStream_t st) {
+template <int R>
+static void launch_wave_r(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                          int max_len, uint4 *out, hipStream_t st) {
     const dim3 grid((unsigned)nreads), block(64);
     const bool xrep = (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (a->flags & ATR_START_WITHIN_SEQ2) != 0;
-    if (xrep && sq)  hipLaunchKernelGGL((locate_wave_kernel<true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
-    if (xrep && !sq) hipLaunchKernelGGL((locate_wave_kernel<true, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
-    if (!xrep && sq) hipLaunchKernelGGL((locate_wave_kernel<false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
-    if (!xrep && !sq) hipLaunchKernelGGL((locate_wave_kernel<false, false>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (xrep && sq)  hipLaunchKernelGGL((locate_wave_kernel<true, true, R>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (xrep && !sq) hipLaunchKernelGGL((locate_wave_kernel<true, false, R>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (!xrep && sq) hipLaunchKernelGGL((locate_wave_kernel<false, true, R>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+    if (!xrep && !sq) hipLaunchKernelGGL((locate_wave_kernel<false, false, R>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out);
+}
+
+int launch_locate_wave(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                       int max_len, uint4 *out, hipStream_t st) {
+    switch (wave_pair_rows(a->p.m)) {                               // rows per lane: 1 up to 63 bases, 2 up to 127, 3 for 128
+        case 1: launch_wave_r<1>(a, packed, lens, nreads, nchunks, max_len, out, st); break;
+        case 2: launch_wave_r<2>(a, packed, lens, nreads, nchunks, max_len, out, st); break;
+        default: launch_wave_r<3>(a, packed, lens, nreads, nchunks, max_len, out, st); break;
+    }
     return (int)hipGetLastError();
 }
 

@@ -154,12 +154,12 @@ int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_
  * Short batches -- the 1000 reads the reference's trim command hands over per call
  * (commands/base.py:179), the per-read API -- are bound by the latency of one wavefront, not by
  * throughput: ATR_LOCATE_WAVE gives every read a WAVEFRONT (one DP row per lane, anti-diagonal
- * sweep: n + m steps instead of n * m cells per lane; references of up to 63 bases, no scratch). */
+ * sweep: n + m steps instead of n * m cells per lane; up to three rows per lane for long references, no scratch). */
 #define ATR_LOCATE_AUTO      0   /* what atr_locate_batch does: WAVE for batches of at most 32768 reads where it
                                     applies, else the anchored-prefix band / FILTERED with d_work, else FULL */
 #define ATR_LOCATE_FULL      1   /* full-matrix sweep, one read per lane */
 #define ATR_LOCATE_FILTERED  2   /* bit-vector pre-pass + window / band DP (needs d_work); FULL where it does not apply */
-#define ATR_LOCATE_WAVE      3   /* one read per wavefront; ATR_ERR_UNSUPPORTED for references of more than 63 bases */
+#define ATR_LOCATE_WAVE      3   /* one read per wavefront */
 int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                           int64_t nreads, int max_len, atr_result *d_out, void *d_work, int path, void *stream);
 

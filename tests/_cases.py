@@ -83,8 +83,7 @@ def check_batches_against_oracle(Aligner, oracle, unsupported_exc, seed, rounds,
         plain = al.locate_batch(reads, path="full").tuples()         # full sweep
         assert len(got) == len(reads) and plain == got
         assert al.locate_batch(reads).tuples() == got                # what a caller gets: short batch -> a wave per read
-        if m <= 63:
-            assert al.locate_batch(reads, path="wave").tuples() == got
+        assert al.locate_batch(reads, path="wave").tuples() == got
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1
@@ -125,9 +124,7 @@ def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, m_ra
                       bad + ref[:33], rseq(rng, 3) + mutate(rng, ref[:32], 0.05) + ref[32:] + rseq(rng, 11)]
         got = al.locate_batch(reads, path="filtered").tuples()
         assert got == al.locate_batch(reads, path="full").tuples()
-        assert got == al.locate_batch(reads).tuples()
-        if m <= 63:
-            assert got == al.locate_batch(reads, path="wave").tuples()
+        assert got == al.locate_batch(reads).tuples() and got == al.locate_batch(reads, path="wave").tuples()
         if fixed and all(len(r) == fixed for r in reads):
             # the same reads as an equal-length batch (no lens array): the pre-pass then bins the
             # partial overlaps by row count and the window DP sweeps a triangle only
@@ -175,8 +172,7 @@ def check_uniform_partial_overlaps(Aligner, oracle, unsupported_exc, seed, round
         mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(count, n).copy()
         got = al.locate_batch(al.pack(mat), path="filtered").tuples()
         assert got == al.locate_batch(al.pack(mat), path="full").tuples()
-        if m <= 63:
-            assert got == al.locate_batch(al.pack(mat), path="wave").tuples()
+        assert got == al.locate_batch(al.pack(mat), path="wave").tuples()
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
             total += 1

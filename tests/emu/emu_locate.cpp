@@ -477,8 +477,8 @@ int emu_linked_match_batch(const atr_linked_set *s, const uint8_t *packed, const
 
 }  // extern "C"
 
-// locate_wave_kernel (wave_kernel.hip) for one read: the 64 lanes in lock step, the cross-lane moves spelled out
-template <bool XREP, bool SQ>
+// locate_wave_kernel (wave_kernel.hip) for one read: the 64 lanes in lock step, the cross-lane move spelled out
+template <bool XREP, bool SQ, int R>
 static void emu_wave_read(const atr_aligner *a_, const uint32_t *pk, int nchunks, long long r, int n, uint32_t *rec) {
     const LocateParams &p = a_->p;
     const Uniform u = make_uniform(p, round_up_rows(p.m));
@@ -489,73 +489,96 @@ static void emu_wave_read(const atr_aligner *a_, const uint32_t *pk, int nchunks
             const uint32_t w = pk[(((size_t)(r >> 6) * nchunks + c) * 64 + (r & 63)) * 4 + (b >> 3)];
             s_code[WAVE_CODE_PAD + 32 * c + b] = (w >> (4 * (b & 7))) & 15u;
         }
-    uint32_t cur[64], upa[64], upb[64], rowmask[64], left_step[64];
+    const WaveGeom g = wave_geom(u.m, R);
+    WaveRows<R> W[64];
+    uint32_t upa[64], upb[64];
     int a[64];
     Best best[64];
     for (int l = 0; l < 64; ++l) {
-        rowmask[l] = l > 0 ? wave_rowmask(p, u.p0, l) : 0u;
-        left_step[l] = wave_left_step(u, l);
-        cur[l] = init_word(l, win.min_n, u.sr, u.sq, u.indel);
+        for (int rr = 0; rr < R; ++rr) {
+            const int row = wave_slot_row(g, R, l, rr);
+            W[l].rowmask[rr] = (row >= 1 && row <= u.m) ? wave_rowmask(p, u.p0, row) : 0u;
+            W[l].lstep[rr] = row < 0 ? 0u : row == 0 ? (SQ ? 1u : (uint32_t)u.indel << CSH) : u.delw;
+            W[l].col[rr] = row < 0 ? WAVE_HUGE : init_word(row, win.min_n, u.sr, SQ, u.indel);
+        }
         a[l] = win.min_n - l - 1;
         wave_best_init(best[l], u, n);
-        upb[l] = WAVE_HUGE;
+        upa[l] = upb[l] = WAVE_HUGE;
     }
-    auto shr1 = [](const uint32_t *v, uint32_t *keep) {            // keep[l] = v[l - 1], lane 0 untouched
+    auto shr1 = [&](uint32_t *keep) {                               // keep[l] = bottom cell of lane l - 1; lane 0 untouched
         uint32_t tmp[64];
-        for (int l = 1; l < 64; ++l) tmp[l] = v[l - 1];
+        for (int l = 1; l < 64; ++l) tmp[l] = W[l - 1].col[R - 1];
         for (int l = 1; l < 64; ++l) keep[l] = tmp[l];
     };
-    for (int l = 0; l < 64; ++l) upa[l] = WAVE_HUGE;
-    shr1(cur, upa);
+    shr1(upa);
     const uint32_t *code = s_code.data() + WAVE_CODE_PAD;
-    const int steps = win.span > 0 ? win.span + u.m : 0;
-    auto trip = [&](bool guarded) {                                   // eight steps (wave_kernel.hip)
-        uint32_t cell[8][64];
-        bool hit[8][64];
+    const int steps = win.span > 0 ? win.span + g.lanes - 1 : 0;
+    constexpr int TRIP = R == 1 ? 8 : 4;
+    auto trip = [&](bool guarded) {
+        uint32_t bottom[TRIP][64];
+        bool hit[TRIP][64];
         int a0[64];
         for (int l = 0; l < 64; ++l) a0[l] = a[l];
-        for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < TRIP; ++s) {
             uint32_t *up = (s & 1) ? upa : upb, *diag = (s & 1) ? upb : upa;
-            shr1(cur, up);
+            shr1(up);
             for (int l = 0; l < 64; ++l) {
-                const uint32_t nw = wave_cell<XREP, SQ>(diag[l], cur[l], up[l], rowmask[l], code[a0[l] + 1 + s], u.insw, left_step[l]);
-                cell[s][l] = nw;
+                uint32_t nw[R];
+                wave_rows_step<XREP, SQ, R, WAVE_ROW0_CAP>(W[l], diag[l], up[l], code[a0[l] + 1 + s], u.insw, nw);
+                bottom[s][l] = nw[R - 1];
                 if (guarded) {
                     ++a[l];
                     const bool active = (unsigned)(a[l] - win.min_n) < (unsigned)win.span;
-                    hit[s][l] = XREP && l == u.m && active && nw < u.klimit;
-                    if (active) cur[l] = nw;
+                    hit[s][l] = XREP && l == g.lanes - 1 && active && nw[R - 1] < u.klimit;
+                    if (active) for (int rr = 0; rr < R; ++rr) W[l].col[rr] = nw[rr];
                 } else {
-                    cur[l] = nw;
+                    for (int rr = 0; rr < R; ++rr) W[l].col[rr] = nw[rr];
                 }
             }
         }
         for (int l = 0; l < 64; ++l) {
             if (!guarded) {
-                a[l] += 8;
-                for (int s = 0; s < 8; ++s) hit[s][l] = XREP && l == u.m && cell[s][l] < u.klimit;
+                a[l] += TRIP;
+                for (int s = 0; s < TRIP; ++s) hit[s][l] = XREP && l == g.lanes - 1 && bottom[s][l] < u.klimit;
             }
-            for (int s = 0; s < 8; ++s)
-                if (hit[s][l]) consider<XREP>(best[l], cell[s][l], u.m, a0[l] + 2 + s, u.min_overlap, p.thr, u.indel);
+            for (int s = 0; s < TRIP; ++s)
+                if (hit[s][l]) consider<XREP>(best[l], bottom[s][l], u.m, a0[l] + 2 + s, u.min_overlap, p.thr, u.indel);
         }
     };
     int t = 1;
-    for (; t <= steps && t <= u.m; t += 8) trip(true);
-    for (; t + 7 <= win.span; t += 8) trip(false);
-    for (; t <= steps; t += 8) trip(true);
-    Best fin = best[u.m];
+    for (; t <= steps && t <= g.lanes - 1; t += TRIP) trip(true);
+    for (; t + TRIP - 1 <= win.span; t += TRIP) trip(false);
+    for (; t <= steps; t += TRIP) trip(true);
+    Best fin = best[g.lanes - 1];
     if (win.scan) {
+        const int first_row = u.er ? 0 : u.m;
         Best mine[64];
         int top = -1;
-        for (int l = 0; l < 64; ++l)
-            top = std::max(top, wave_last_key<XREP>(cur[l], l, l, l >= (u.er ? 0 : u.m) && l <= u.m, u, n, p.thr, mine[l]));
+        for (int l = 0; l < 64; ++l) {
+            mine[l].key = -1; mine[l].word = 0; mine[l].ref_stop = 0; mine[l].query_stop = n; mine[l].matches = 0;
+            for (int rr = 0; rr < R; ++rr) {
+                const int row = wave_slot_row(g, R, l, rr);
+                if (row >= first_row && row <= u.m && W[l].col[rr] < u.klimit)
+                    consider<XREP>(mine[l], W[l].col[rr], row, n, u.min_overlap, p.thr, u.indel);
+            }
+            top = std::max(top, mine[l].key < 0 ? -1 : (mine[l].key << 6) | (63 - l));
+        }
         if (top >= 0 && (top >> 6) > fin.key) {
             const int src = 63 - (top & 63);
-            fin.key = top >> 6; fin.word = mine[src].word; fin.ref_stop = src; fin.query_stop = n;
+            fin.key = top >> 6; fin.word = mine[src].word; fin.ref_stop = mine[src].ref_stop; fin.query_stop = n;
             fin.matches = mine[src].matches;
         }
     }
     wave_result(fin, u, n, rec);
+}
+
+template <int R>
+static void emu_wave_read_r(const atr_aligner *a, const uint32_t *pk, int nchunks, long long r, int n, uint32_t *rec) {
+    const bool xrep = (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (a->flags & ATR_START_WITHIN_SEQ2) != 0;
+    if (xrep && sq) emu_wave_read<true, true, R>(a, pk, nchunks, r, n, rec);
+    if (xrep && !sq) emu_wave_read<true, false, R>(a, pk, nchunks, r, n, rec);
+    if (!xrep && sq) emu_wave_read<false, true, R>(a, pk, nchunks, r, n, rec);
+    if (!xrep && !sq) emu_wave_read<false, false, R>(a, pk, nchunks, r, n, rec);
 }
 
 extern "C" {
@@ -573,12 +596,12 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
             const int nchunks = (max_len + 31) / 32;
             for (long long r = 0; r < nreads; ++r) {
                 const int n = lens ? lens[r] : max_len;
-                const bool xrep = (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (a->flags & ATR_START_WITHIN_SEQ2) != 0;
                 uint32_t *rec = (uint32_t *)out + 4 * r;
-                if (xrep && sq) emu_wave_read<true, true>(a, (const uint32_t *)packed, nchunks, r, n, rec);
-                if (xrep && !sq) emu_wave_read<true, false>(a, (const uint32_t *)packed, nchunks, r, n, rec);
-                if (!xrep && sq) emu_wave_read<false, true>(a, (const uint32_t *)packed, nchunks, r, n, rec);
-                if (!xrep && !sq) emu_wave_read<false, false>(a, (const uint32_t *)packed, nchunks, r, n, rec);
+                switch (wave_pair_rows(a->p.m)) {
+                    case 1: emu_wave_read_r<1>(a, (const uint32_t *)packed, nchunks, r, n, rec); break;
+                    case 2: emu_wave_read_r<2>(a, (const uint32_t *)packed, nchunks, r, n, rec); break;
+                    default: emu_wave_read_r<3>(a, (const uint32_t *)packed, nchunks, r, n, rec); break;
+                }
             }
             return ATR_OK;
         }

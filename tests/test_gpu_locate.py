@@ -67,8 +67,7 @@ def test_every_column_size(hip_backend, oracle):
             reads = _cases.planted_reads(rng, ref, 96, 220)
             got = al.locate_batch(reads, path="filtered").tuples()
             assert got == al.locate_batch(reads, path="full").tuples() and got == al.locate_batch(reads).tuples()
-            if m <= 63:
-                assert got == al.locate_batch(reads, path="wave").tuples()
+            assert got == al.locate_batch(reads, path="wave").tuples()
             for q, g in zip(reads, got):
                 assert g == oracle.locate(ref, q, e, 14, wr, False, 3, ic), (m, ic, wr, q)
 
