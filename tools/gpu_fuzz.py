@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """GPU-vs-oracle fuzz campaign (run on the GPU box): every batched kernel path against
 oracle/align_oracle.c on random cases -- the filtered pipeline (all adapter types, the 32-row NARROW
-pre-pass, equal-length batches with partial overlaps), the full sweep over all 16 flag sets, the pair
-aligner (sides of up to 320 bases), the insert aligner (reads of up to 320 bases), the fused linked-adapter
+pre-pass, equal-length batches with partial overlaps), the full sweep over all 16 flag sets and the wavefront-per-read
+kernel (every batch goes through all three families and the automatic choice), the pair aligner (sides of up to 320
+bases: full sweep, cost / threat / band pipeline with and without `need`, wavefront per pair), the insert aligner
+(reads of up to 320 bases, probed sweep), the fused linked-adapter
 pipeline, the plane-guided error correction and ragged batches at wave-filling size (tail-mode window sweep).
 usage: tools/gpu_fuzz.py [first_seed] [seeds]   (the log of the round's last run is kept under profiles/)"""
 import sys, time
@@ -14,6 +16,12 @@ from oracle import oracle
 from tests import _cases
 t0 = time.time()
 tot = 0
+
+
+def rng_top(seed):
+    return (150, 100, 250, 300, 64)[seed % 5]     # read lengths of the pair-pipeline rounds (Myers words 5 / 8 / 10)
+
+
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4)):
     tot += _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, seed, 500)
@@ -21,6 +29,7 @@ for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
     tot += _cases.check_uniform_partial_overlaps(Aligner, oracle, _lib.AtroposHipError, seed + 200, 150)
     tot += _cases.check_batches_against_oracle(Aligner, oracle, _lib.AtroposHipError, seed + 300, 300)
     tot += _cases.check_pairs_against_oracle(PairAligner, oracle, _lib.AtroposHipError, seed + 400, 150)
+    tot += _cases.check_pairs_fast(PairAligner, oracle, seed + 450, 12, top=rng_top(seed), npairs=96)
     tot += _cases.check_insert_batches_against_oracle(InsertAligner, oracle, seed + 500, 60)
     tot += _cases.check_linked_sets_against_oracle(oracle, seed + 600, 150, reads_per_round=(1, 64, 65, 200, 700))[0]
     tot += _cases.check_plane_guided_correction(n=20_000, seed=seed + 700)
