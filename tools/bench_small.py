@@ -4,7 +4,8 @@ the unchanged trim command hands over per call, /root/reference/atropos/commands
   packed   : atr_locate_batch on a resident tile64 batch (records stay on the device),
   ascii    : pack + locate from an ASCII matrix resident on the device,
   strings  : Python strings in, result tuples out (host -> device -> host), i.e. Aligner.locate_batch(list),
-and the per-read API: Aligner.locate(str) -> tuple, one GPU batch of one per call.
+the per-read API: Aligner.locate(str) -> tuple, one GPU batch of one per call; and the pair-wise entry points
+(insert aligner, MergeOverlapping's per-pair aligner) on 1 000 pairs.
 usage: tools/bench_small.py [json-out]"""
 import json
 import os
@@ -54,7 +55,25 @@ def measure(sizes=(1, 1000, 65536, 1_000_000)):
     t = timed(lambda: al.locate(one), min_reps=50)
     out["per_read_locate_us"] = t * 1e6
     out["per_read_locate_reads_per_s"] = 1.0 / t
+    out["pairs_1000"] = measure_pairs()
     return out
+
+
+def measure_pairs(n=1000):
+    """The pair-wise entry points on the 1 000 pairs the reference's trim command hands over per call (C3 pairs, batches
+    resident): InsertAligner.match_insert_batch and PairAligner.locate_batch (MergeOverlapping's aligner)."""
+    from atropos_amd import _lib
+    from atropos_amd.align import InsertAligner, PairAligner
+    w = synth.workload("C3", 0, n, device="cuda")
+    ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2)
+    pa = PairAligner(0.2, 15, revcomp_ref=True)
+    be = _lib.get_backend()
+    b1, b2 = ia.pack(w["reads1"]), ia.pack(w["reads2"], check=True)
+    rb, qb = pa._pack(w["reads2"], _lib.TABLE_DNA15, be, True), pa._pack(w["reads1"], _lib.TABLE_DNA15, be, True)
+    return {"pairs": n, "read_len": int(w["reads1"].shape[1]),
+            "insert_match_us": timed(lambda: ia.match_insert_batch(b1, b2)) * 1e6,
+            "pair_locate_us": timed(lambda: pa.locate_batch(rb, qb)) * 1e6,
+            "pair_locate_full_sweep_us": timed(lambda: pa.locate_batch(rb, qb, path="full"), min_reps=3) * 1e6}
 
 
 if __name__ == "__main__":
