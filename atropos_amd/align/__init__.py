@@ -112,7 +112,7 @@ class Aligner(object):
         for chunk in chunks:
             count = len(chunk) if isinstance(chunk, (list, tuple)) else chunk.shape[0]
             refs = ref_row[None, :].expand(count, -1).contiguous()
-            recs.append(pa.locate_batch(refs, chunk).records)
+            recs.append(pa.locate_batch(refs, chunk, unknown_queries_ok=True).records)
         if not recs:
             rec = be.empty((0, 8), torch.int16)
             return LocateResult(rec)
@@ -382,7 +382,7 @@ class PairAligner(object):
         return (_lib.TABLE_IUPAC if self.wildcard_ref else _lib.TABLE_ACGT,
                 _lib.TABLE_IUPAC if self.wildcard_query else _lib.TABLE_ACGT)
 
-    def _pack(self, seqs, kind, be, literal, case_table=None, may_retry=False):
+    def _pack(self, seqs, kind, be, literal, case_table=None, may_retry=False, unknown_ok=False):
         if isinstance(seqs, ReadBatch):
             if seqs.table_kind != kind:
                 raise ValueError("batch packed with table %d, this side needs %d" % (seqs.table_kind, kind))
@@ -405,18 +405,21 @@ class PairAligner(object):
             packed, bad = be.pack_reads(ascii_t, lens_t, max_len, table, count_invalid=True)
             if bad and case_table is None and literal and may_retry:
                 return None                               # the caller packs both sides again, case-sensitively
-            if bad and (literal or kind == _lib.TABLE_DNA15):
+            if bad and (literal or kind == _lib.TABLE_DNA15) and not (unknown_ok and literal and not self.revcomp_ref):
                 raise ValueError("%d sequence(s) contain characters the device pair aligner has no 4-bit code for "
                                  "(upper-case IUPAC letters, or A C G T N W B D H V in either case)" % bad)
         else:
             packed = be.pack_reads(ascii_t, lens_t, max_len, table)
         return ReadBatch(packed, lens_t, ascii_t.shape[0], max_len, kind, table)
 
-    def locate_batch(self, references, queries, need=None, path="auto"):
+    def locate_batch(self, references, queries, need=None, path="auto", unknown_queries_ok=False):
         """references/queries: lists of str, uint8 [n, width] ASCII tensors, or ReadBatches
         packed with the right tables.  Returns a LocateResult (int16 [n, 8] records).
         path: the kernel family (``_lib.PAIRS_PATHS``; "auto" picks by batch size: a wavefront per pair for short
         batches, the cost / threat / band pipeline or the full sweep for long ones).
+        unknown_queries_ok: a query character without a 4-bit code (anything but IUPAC letters) takes code 0 and
+        matches nothing instead of raising -- exact for the literal compare as long as the references hold coded
+        characters only (they are still checked): what ``Aligner.locate`` does with such reads.
         need: per pair (list or int32 tensor), the number of matches below which the caller ignores the
         alignment (MergeOverlapping's ``matches >= min_overlap``, modifiers.py:896-897): such pairs may come
         back as None, which lets the library stop after its cost pass for pairs that cannot overlap that far."""
@@ -431,7 +434,7 @@ class PairAligner(object):
             # two tables share codes, so one side alone must never switch)
             both = case_sensitive_pair_table(be.translate_table(_lib.TABLE_DNA15))
             rb = self._pack(references, rk, be, literal, case_table=both)
-            qb = self._pack(queries, qk, be, literal, case_table=both)
+            qb = self._pack(queries, qk, be, literal, case_table=both, unknown_ok=unknown_queries_ok)
         if rb.nreads != qb.nreads:
             raise ValueError("need as many references as queries")
         if need is not None and not torch.is_tensor(need):

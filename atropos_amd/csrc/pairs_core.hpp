@@ -409,13 +409,11 @@ inline int pairs_params(double e, int flags, int wildcard_ref, int wildcard_quer
         return ATR_ERR_UNSUPPORTED;
     const double kd = e * (double)ref_max_len;
     if (!(kd < 256.0) || !(kd > -1.0e9)) return ATR_ERR_UNSUPPORTED;
-    // worst computed cost: an initial value (<= (m + k) * indel) plus m insertions; indel is
-    // capped at k + 1 inside the kernel
-    {
-        const int k = (int)kd < 0 ? 0 : (int)kd;
-        const long long ind = indel_cost > k ? k + 1 : indel_cost;
-        if ((long long)(ref_max_len + k + ref_max_len + 1) * ind > INIT_COST_CAP) return ATR_ERR_UNSUPPORTED;
-    }
+    // The cost field never overflows: initial cells and row 0 are saturated at INIT_COST_CAP (always > k, so a
+    // saturated cell and everything derived from it stays out of every candidate test), a cell is at most its
+    // diagonal neighbour + 1, and a candidate word formed on the way adds one indel (capped at k + 1 <= 256 inside
+    // the kernels): INIT_COST_CAP + min(m, n) + 257 < 4096 for every supported length.
+    static_assert(INIT_COST_CAP + PAIRS_MAX_LEN + 257 < COST_FIELD_MAX, "cost field of the pair kernels");
     for (int L = 0; L < PAIRS_MAX_LEN + 3; ++L) {
         double t = std::floor((double)L * e);                           // cost <= L*e  <=>  cost <= floor(L*e)
         if (t > COST_FIELD_MAX) t = COST_FIELD_MAX;

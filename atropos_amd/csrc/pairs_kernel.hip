@@ -270,7 +270,7 @@ extern "C" int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const in
     // side of the overlap's end, k = 50 at 250 bases) cost as much as the whole matrix -- measured 66 M pairs/s
     // against 76 M on 2 x 250 bp -- so they keep the full sweep; with d_need most pairs end after the cost pass.
     if (path == ATR_PAIRS_WAVE && !wave_pairs_applies(ref_max_len, 0)) return ATR_ERR_UNSUPPORTED;
-    if (path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && wave_pairs_applies(ref_max_len, (long long)npairs) && ref_max_len > 0)) {
+    if (path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && wave_pairs_applies(ref_max_len, (long long)npairs))) {
         // short batch: a wavefront per pair (pairs_wave.hip); a lane per pair is one chain of m x n dependent cells
         const hipError_t e = launch_pairs_wave(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len,
                                                (long long)npairs, (uint4 *)d_out, (hipStream_t)stream);

@@ -129,7 +129,7 @@ constexpr int WAVE_PAIR_ROWS_MAX = 5;          // 64 * 5 - 1 = 319 rows
 constexpr long long WAVE_MAX_PAIRS = 32768;
 inline int wave_pair_rows(int m) { return (m + 1 + 63) / 64; }                 // rows per lane for a reference of m bases
 inline bool wave_pairs_applies(int ref_max_len, long long npairs) {
-    return ref_max_len >= 1 && ref_max_len <= 64 * WAVE_PAIR_ROWS_MAX - 1 && npairs <= WAVE_MAX_PAIRS;
+    return ref_max_len >= 0 && ref_max_len <= 64 * WAVE_PAIR_ROWS_MAX - 1 && npairs <= WAVE_MAX_PAIRS;
 }
 
 template <int R>

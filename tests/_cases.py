@@ -1312,3 +1312,39 @@ def check_pairs_fast(PairAligner, oracle, seed, rounds, top=150, npairs=96, adve
                 assert h is None or h[4] < nd, (nd, h, exp)
             total += 1
     return total
+
+
+def check_long_reference_envelope(Aligner, PairAligner, oracle):
+    """What the round-2 advisor found narrower on the long-reference path (129 .. 320 bases, per-pair aligner) than on
+    aligner handles: adapters without indels (indel cost 100000) and reads with characters outside the IUPAC
+    alphabet, which match nothing instead of raising; large indel costs on long pairs through every kernel family."""
+    rng = random.Random(3)
+    total = 0
+    ref = rseq(rng, 150)
+    for flags, ic in ((14, 1), (14, 100000), (11, 100000), (15, 2)):
+        al = Aligner(ref, 0.1, flags, False, False, 3, ic)
+        reads = [rseq(rng, 40) + ref[:rng.randint(5, 150)] for _ in range(20)]
+        reads[3] = reads[3][:10] + "." + reads[3][11:]
+        reads[7] = "#" + reads[7] + ".."
+        reads[9] = reads[9].lower()
+        got = al.locate_batch(reads).tuples()
+        assert got == [oracle.locate(ref, q, 0.1, flags, False, False, 3, ic) for q in reads], (flags, ic)
+        total += len(reads)
+    for rnd in range(12):
+        flags = rng.choice([15, 9, 14, 11, 8, 2, 0, 10])
+        e, ic = rng.choice([0.1, 0.2, 0.3]), rng.choice([100000, 50, 7, 3])
+        top = rng.choice([40, 150, 255, 320])
+        if top > 255 and not (flags & 8):
+            top = 255
+        refs, qs = [], []
+        for _ in range(16):
+            m, n = rng.randint(0, top), rng.randint(0, top)
+            frag = rseq(rng, m + n + 1)
+            refs.append(frag[:m])
+            qs.append(mutate(rng, frag[rng.randint(0, m):][:n], rng.choice([0, 0.05, 0.15]))[:n] if rng.random() < 0.7 else rseq(rng, n))
+        pa = PairAligner(e, flags, False, False, rng.choice([1, 3]), ic)
+        exp = [oracle.locate(r, q, e, flags, False, False, pa.min_overlap, ic) for r, q in zip(refs, qs)]
+        for path in ("auto", "full", "fast") + (("wave",) if top <= 319 else ()):
+            assert pa.locate_batch(refs, qs, path=path).tuples() == exp, (path, e, flags, ic, top)
+        total += len(refs)
+    return total

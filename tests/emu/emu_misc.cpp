@@ -390,7 +390,7 @@ int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_l
     const int path = emu_pairs_path;
     if (path < ATR_PAIRS_AUTO || path > ATR_PAIRS_WAVE) return ATR_ERR_INVALID;
     if (path == ATR_PAIRS_WAVE && !atr::wave_pairs_applies(ref_max_len, 0)) return ATR_ERR_UNSUPPORTED;
-    const bool wave = path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && atr::wave_pairs_applies(ref_max_len, npairs) && ref_max_len > 0);
+    const bool wave = path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && atr::wave_pairs_applies(ref_max_len, npairs));
     const bool worth = path == ATR_PAIRS_FAST || ((ref_max_len <= 160 || need != nullptr) && npairs >= atr::PAIRS_FAST_MIN_PAIRS);   // as the library
     const bool fast = !wave && path != ATR_PAIRS_FULL && (path == ATR_PAIRS_FAST || emu_pairs_fast) && worth &&
                       atr::pairs_fast_applies(e, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, qry_max_len);

@@ -147,3 +147,8 @@ def test_pairs_fast_pipeline(emu_backend, oracle):
         widen.value = 0
     none, band, full, _ = list(stats)
     assert band > 2000 and none > 1000 and full < band          # the banded pass is what most pairs with an alignment take
+
+
+def test_long_reference_envelope(emu_backend, oracle):
+    from atropos_amd.align import Aligner, PairAligner
+    assert _cases.check_long_reference_envelope(Aligner, PairAligner, oracle) > 250

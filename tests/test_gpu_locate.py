@@ -263,3 +263,8 @@ def test_long_reference(hip_backend):
     from atropos_amd._lib import AtroposHipError
     from oracle import oracle
     assert _cases.check_long_reference(Aligner, oracle, AtroposHipError, batch_rounds=12) > 400
+
+
+def test_long_reference_envelope(hip_backend, oracle):
+    from atropos_amd.align import Aligner, PairAligner
+    assert _cases.check_long_reference_envelope(Aligner, PairAligner, oracle) > 250
