@@ -195,21 +195,24 @@ class TrimPipeline(object):
         batch, _ = FastqBatch.from_bytes(data, final=True)
         return self.run(batch).text(which)
 
-    def trim_file(self, path_in, path_out, chunk_bytes=256 << 20, keep_output=False):
+    def trim_file(self, path_in, path_out, chunk_bytes=256 << 20, keep_output=False, output_parts=1):
         """Stream a FASTQ file through the GPU in chunks of whole records; returns the
         destination counts.  (Plain files; compressed input is the caller's business.)
         Host side: ``ChunkedFastqReader`` / ``FastqSink`` (page-locked staging buffers, threaded
         reads, read-ahead; device -> host copies on their own stream and write-behind, so the GPU
         works on chunk i + 1 while chunk i travels back and into the file).  ``keep_output``: overwrite
-        an existing output file in place instead of truncating it first.  The seconds the loop spent
-        waiting per stage are left in ``self.stage_seconds``."""
+        an existing output file in place instead of truncating it first.  ``output_parts`` > 1: the output
+        as that many part files ``<path_out>.part<i>`` with a writer each (``fastq.PartSink``: chunk k goes to
+        part k mod N; what the reference's ``--no-writer-process`` does with its worker processes) -- for hosts
+        that serialise the writers of one file.  The seconds the loop spent waiting per stage are left in
+        ``self.stage_seconds``."""
         import time
-        from .fastq import ChunkedFastqReader, FastqSink, StageClock
+        from .fastq import ChunkedFastqReader, StageClock, make_sink
         be = _lib.get_backend()
         totals = {name: 0 for name in DEST_NAMES.values()}
         clock = StageClock()
         reader = ChunkedFastqReader(path_in, chunk_bytes, be, clock)
-        sink = FastqSink(path_out, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output)
+        sink = make_sink(path_out, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output)
         try:
             while True:
                 batch = reader.next_batch()
@@ -501,22 +504,24 @@ class PairedTrimPipeline(object):
         res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
         return PairedTrimResult(res[0], res[1], merged_text)
 
-    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None, keep_output=False):
+    def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None, keep_output=False, output_parts=1):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
         same number from each file); returns the destination counts.  ``merged_out``: the
-        --merged-output file (without it merged reads are dropped, as by the reference)."""
+        --merged-output file (without it merged reads are dropped, as by the reference).
+        ``output_parts`` > 1: every output as that many part files (``TrimPipeline.trim_file``); part i of
+        ``out1`` and part i of ``out2`` hold the same pairs in the same order."""
         import time
-        from .fastq import ChunkedFastqReader, FastqSink, StageClock
+        from .fastq import ChunkedFastqReader, StageClock, make_sink
         be = _lib.get_backend()
         totals = {name: 0 for name in DEST_NAMES.values()}
         clock = StageClock()
         readers = [ChunkedFastqReader(p, chunk_bytes, be, clock) for p in (in1, in2)]
-        sinks = [FastqSink(p, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output) for p in (out1, out2)]
+        sinks = [make_sink(p, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output) for p in (out1, out2)]
         if self.merge_overlapping:
             totals["merged"] = 0
             if merged_out is not None:
                 # a merged record is at most its two input records, and each input chunk may carry up to 64 MB over
-                sinks.append(FastqSink(merged_out, 2 * (chunk_bytes + (64 << 20)) + 32, be, clock, keep=keep_output))
+                sinks.append(make_sink(merged_out, output_parts, 2 * (chunk_bytes + (64 << 20)) + 32, be, clock, keep=keep_output))
         try:
             while True:
                 batches = [r.next_batch() for r in readers]
@@ -533,8 +538,8 @@ class PairedTrimPipeline(object):
                 clock.add("trim_and_format", t0)
                 for k in range(2):
                     sinks[k].write(texts[k])
-                if len(sinks) == 3 and res.merged is not None:
-                    sinks[2].write(res.merged)
+                if len(sinks) == 3:
+                    sinks[2].write(res.merged if res.merged is not None else texts[0][:0])
                 for name, v in counts.items():
                     totals[name] += v
                 if all(done):

@@ -856,6 +856,28 @@ def check_fastq_chunking(tmp_path):
     counts = pipe.trim_file(str(src), str(dst), chunk_bytes=50000)
     assert dst.read_bytes() == whole
     assert sum(counts.values()) == data.count(b"\n") // 4
+    # the output as three part files with a writer each: chunk k in part k mod 3, in order inside a part -- the records
+    # of all parts are those of the single file
+    counts3 = pipe.trim_file(str(src), str(dst), chunk_bytes=50000, output_parts=3)
+    parts = [(tmp_path / ("out.fastq.part%d" % i)).read_bytes() for i in range(3)]
+    assert counts3 == counts and all(parts) and sum(len(p) for p in parts) == len(whole)
+
+    def records(text):
+        lines = text.split(b"\n")
+        return [b"\n".join(lines[i:i + 4]) for i in range(0, len(lines) - 1, 4)]
+    assert sorted(r for p in parts for r in records(p)) == sorted(records(whole))
+    k, rebuilt, at = 0, [], [0, 0, 0]               # chunk k is the next run of part k % 3: walk the single file
+    whole_records = records(whole)
+    part_records = [records(p) for p in parts]
+    pos = 0
+    while pos < len(whole_records):
+        i = k % 3
+        n = 0
+        while at[i] + n < len(part_records[i]) and pos + n < len(whole_records) and part_records[i][at[i] + n] == whole_records[pos + n]:
+            n += 1
+        assert n > 0, (k, pos)
+        at[i] += n; pos += n; k += 1
+    assert at == [len(p) for p in part_records]
     # the sink on its own: odd chunk sizes around the 4 KiB block, buffered and (where the file system and the
     # staging buffers allow it) O_DIRECT
     import torch
@@ -1036,6 +1058,17 @@ def check_paired_file_chunking(tmp_path):
     assert [len(t) for t in texts] == [o["size"] for o in case["outputs"]]
     assert [hashlib.sha256(t).hexdigest() for t in texts] == [o["sha256"] for o in case["outputs"]]
     assert mc["merged"] == texts[2].count(b"\n") // 4 and sum(mc.values()) == d1.count(b"\n") // 4
+    # two part files per output: part i of both reads holds the same pairs, all parts together the single-file records
+    mc2 = pipeline_from_args(case["args"]).trim_files(str(paths[0]), str(paths[1]), str(paths[2]), str(paths[3]),
+                                                      chunk_bytes=30000, merged_out=str(merged_path), output_parts=2)
+    assert mc2 == mc
+    for whole_text, base in zip(texts, (paths[2], paths[3], merged_path)):
+        parts = [(tmp_path / (base.name + ".part%d" % i)).read_bytes() for i in range(2)]
+        assert sorted(b"".join(parts).split(b"\n")) == sorted(whole_text.split(b"\n"))
+    names = [[ln.split()[0] for ln in (tmp_path / (b.name + ".part%d" % i)).read_bytes().split(b"\n")[0::4] if ln]
+             for b in (paths[2], paths[3]) for i in range(2)]
+    assert [n.rstrip(b"12").rstrip(b"/") for n in names[0]] == [n.rstrip(b"12").rstrip(b"/") for n in names[2]]
+    assert [n.rstrip(b"12").rstrip(b"/") for n in names[1]] == [n.rstrip(b"12").rstrip(b"/") for n in names[3]]
     return counts
 
 
