@@ -85,7 +85,7 @@ def _trim_worker(rank, world, port, path_in, path_out, args):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_trim_file_matches_single_process(tmp_path, emu_backend, world):
     """Each rank trims its own byte range of the FASTQ file; the parts in rank order are the
     single-process output (no data-path collective)."""
