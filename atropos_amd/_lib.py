@@ -12,6 +12,7 @@ import ctypes as C
 import os
 import threading
 
+import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -407,6 +408,37 @@ class HipBackend(object):
                 _check(self.lib, self.lib.atr_locate_batch_path(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
                                                                 _ptr(work), code, self._stream()), "atr_locate_batch")
         return out
+
+    def locate_one(self, h, table, query):
+        """``Aligner.locate`` of ONE read (bytes) -- what the module swap of INTEGRATION.md section 1 calls per
+        read: pack + locate on buffers kept for the life of the backend (page-locked staging both ways), no
+        allocation, one synchronisation.  Returns the six numbers or None."""
+        n = len(query)
+        one = getattr(self, "_one", None)
+        if one is None or one["cap"] < n:
+            cap = max(1024, (n + 255) // 256 * 256)
+            one = self._one = {
+                "cap": cap,
+                "host_in": torch.empty((1, cap), dtype=torch.uint8).pin_memory(),
+                "dev_in": self.empty((1, cap), torch.uint8),
+                "packed": self.empty((max(self.packed_bytes(1, cap), 16),), torch.uint8),
+                "out": self.empty((1, 8), torch.int16),
+                "host_out": torch.empty((1, 8), dtype=torch.int16).pin_memory()}
+            one["np_in"] = one["host_in"].numpy()
+            one["np_out"] = one["host_out"].numpy()
+        with torch.cuda.device(self.device):
+            stream = self._stream()
+            if n:
+                one["np_in"][0, :n] = np.frombuffer(query, dtype=np.uint8)
+                one["dev_in"][:, :n].copy_(one["host_in"][:, :n], non_blocking=True)
+                _check(self.lib, self.lib.atr_pack_reads(_ptr(one["dev_in"]), one["cap"], None, None, 1, n, table,
+                                                         _ptr(one["packed"]), None, stream), "atr_pack_reads")
+            _check(self.lib, self.lib.atr_locate_batch_path(h, _ptr(one["packed"]), None, 1, n, _ptr(one["out"]), None, 0,
+                                                            stream), "atr_locate_batch")
+            one["host_out"].copy_(one["out"], non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        row = one["np_out"][0, :6].tolist()
+        return None if row[1] < 0 else tuple(row)
 
     def _small_work(self):
         """Scratch for the short batches that do not take the wave kernel (references of more than 64 bases never

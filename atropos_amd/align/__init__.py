@@ -252,8 +252,14 @@ class Aligner(object):
         (reference: Aligner.locate, _align.pyx:266-491)."""
         if not isinstance(query, str):
             raise TypeError("query must be str")
-        query.encode('ascii')                          # UnicodeEncodeError like the reference (:281)
-        result = self.locate_batch([query]).tuples()[0]
+        qbytes = query.encode('ascii')                 # UnicodeEncodeError like the reference (:281)
+        be = self._backend
+        if self._handle is not None and hasattr(be, "locate_one") and len(qbytes) <= _lib.MAX_READ_LEN:
+            # the per-read API as the module swap uses it: cached buffers, no allocation (HipBackend.locate_one)
+            table = self._table if self._table is not None else be.translate_table(self._table_kind)
+            result = be.locate_one(self._handle, table, qbytes)
+        else:
+            result = self.locate_batch([query]).tuples()[0]
         if self._debug and self._handle is not None:
             batch = self.pack([query])
             costs, rec = self._backend.locate_debug(self._handle, batch.packed, len(self._ref_bytes), len(query))

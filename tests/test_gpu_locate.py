@@ -268,3 +268,25 @@ def test_long_reference(hip_backend):
 def test_long_reference_envelope(hip_backend, oracle):
     from atropos_amd.align import Aligner, PairAligner
     assert _cases.check_long_reference_envelope(Aligner, PairAligner, oracle) > 250
+
+
+def test_per_read_api(hip_backend, oracle):
+    """Aligner.locate(str) (HipBackend.locate_one: cached buffers) == the oracle, for aligners used in turn, empty and
+    maximum-length queries, references beyond an aligner handle (those keep the batch path)."""
+    import random
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    rng = random.Random(11)
+    aligners = []
+    for m, flags, e, wr, wq, ic in ((33, 14, 0.1, False, False, 1), (20, 11, 0.2, True, False, 2), (64, 15, 0.1, False, True, 1),
+                                    (100, 10, 0.12, False, False, 100000), (5, 8, 0.3, False, False, 1), (150, 14, 0.1, False, False, 1)):
+        ref = _cases.rseq(rng, m, "ACGTN" if wr else "ACGT")
+        aligners.append((Aligner(ref, e, flags, wr, wq, 3, ic), ref, (e, flags, wr, wq, 3, ic)))
+    total = 0
+    for rnd in range(300):
+        al, ref, args = aligners[rnd % len(aligners)]
+        n = rng.choice([0, 1, 30, 150, 151, 300, _lib.MAX_READ_LEN if len(ref) <= 128 else 320])
+        q = (_cases.rseq(rng, rng.randint(0, n)) + _cases.mutate(rng, ref, 0.05))[:n] if rng.random() < 0.7 else _cases.rseq(rng, n, "ACGTN")
+        assert al.locate(q) == oracle.locate(ref, q, *args), (ref, q, args)
+        total += 1
+    assert total == 300
