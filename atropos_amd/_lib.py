@@ -103,6 +103,8 @@ PROTOTYPES = {
     "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "atr_locate_ascii_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_locate_one": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]),
     "atr_linked_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -411,34 +413,25 @@ class HipBackend(object):
 
     def locate_one(self, h, table, query):
         """``Aligner.locate`` of ONE read (bytes) -- what the module swap of INTEGRATION.md section 1 calls per
-        read: pack + locate on buffers kept for the life of the backend (page-locked staging both ways), no
-        allocation, one synchronisation.  Returns the six numbers or None."""
-        n = len(query)
-        one = getattr(self, "_one", None)
-        if one is None or one["cap"] < n:
-            cap = max(1024, (n + 255) // 256 * 256)
-            one = self._one = {
-                "cap": cap,
-                "host_in": torch.empty((1, cap), dtype=torch.uint8).pin_memory(),
-                "dev_in": self.empty((1, cap), torch.uint8),
-                "packed": self.empty((max(self.packed_bytes(1, cap), 16),), torch.uint8),
-                "out": self.empty((1, 8), torch.int16),
-                "host_out": torch.empty((1, 8), dtype=torch.int16).pin_memory()}
-            one["np_in"] = one["host_in"].numpy()
-            one["np_out"] = one["host_out"].numpy()
+        read: atr_locate_one (the kernel reads the read from a page-locked staging buffer and writes the record
+        into one; one launch, one synchronisation, no allocation).  Returns the six numbers or None."""
+        rec = self._one_rec if hasattr(self, "_one_rec") else None
+        if rec is None:
+            rec = self._one_rec = (C.c_int16 * 8)()
         with torch.cuda.device(self.device):
-            stream = self._stream()
-            if n:
-                one["np_in"][0, :n] = np.frombuffer(query, dtype=np.uint8)
-                one["dev_in"][:, :n].copy_(one["host_in"][:, :n], non_blocking=True)
-                _check(self.lib, self.lib.atr_pack_reads(_ptr(one["dev_in"]), one["cap"], None, None, 1, n, table,
-                                                         _ptr(one["packed"]), None, stream), "atr_pack_reads")
-            _check(self.lib, self.lib.atr_locate_batch_path(h, _ptr(one["packed"]), None, 1, n, _ptr(one["out"]), None, 0,
-                                                            stream), "atr_locate_batch")
-            one["host_out"].copy_(one["out"], non_blocking=True)
-            torch.cuda.current_stream(self.device).synchronize()
-        row = one["np_out"][0, :6].tolist()
-        return None if row[1] < 0 else tuple(row)
+            _check(self.lib, self.lib.atr_locate_one(h, query, len(query), C.addressof(rec), self._stream()), "atr_locate_one")
+        return None if rec[1] < 0 else (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
+
+    def locate_ascii_batch(self, h, ascii_2d, lens, max_len):
+        """atr_locate_ascii_batch: a short batch of ASCII rows (uint8 [n, width] on the device, row stride a multiple of
+        four) through the wavefront-per-read kernel without packing; int16 [n, 8] records."""
+        n = ascii_2d.shape[0]
+        out = self.empty((n, 8), torch.int16)
+        if n:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_locate_ascii_batch(h, _ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), n, max_len,
+                                                                 _ptr(out), self._stream()), "atr_locate_ascii_batch")
+        return out
 
     def _small_work(self):
         """Scratch for the short batches that do not take the wave kernel (references of more than 64 bases never

@@ -216,8 +216,20 @@ class Aligner(object):
         on every path."""
         if getattr(self, "_long", False):
             return self._locate_long(reads)
-        batch = self.pack(reads)
         be = self._backend
+        if (self._handle is not None and path in (None, "auto", "wave") and filtered and isinstance(reads, (list, tuple))
+                and 0 < len(reads) <= _lib.WAVE_MAX_READS and hasattr(be, "locate_ascii_batch")):
+            # a short list of strings: the rows go to the device as they are and the wavefront-per-read kernel
+            # translates them itself (no pack kernel in between)
+            mat, lens = _as_ascii_matrix(reads)
+            width = (mat.shape[1] + 3) // 4 * 4
+            if width <= _lib.MAX_READ_LEN + 3 and int(lens.max()) <= _lib.MAX_READ_LEN:
+                if width != mat.shape[1]:
+                    mat = np.pad(mat, ((0, 0), (0, width - mat.shape[1])))
+                lens_t = None if int(lens.min()) == int(lens.max()) else torch.from_numpy(lens).to(be.device)
+                return LocateResult(be.locate_ascii_batch(self._handle, torch.from_numpy(mat).to(be.device), lens_t,
+                                                          int(lens.max())))
+        batch = self.pack(reads)
         if self._handle is None:                      # empty reference: nothing ever matches
             rec = be.empty((batch.nreads, 8), torch.int16)
             rec.zero_()

@@ -18,8 +18,8 @@ int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t 
                        int max_len, uint4 *out, hipStream_t st);
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
                   const int32_t *l2, long long npairs, int nchunks, int max_len, uint4 *out, int cased, hipStream_t st);
-int launch_locate_wave(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                       int max_len, uint4 *out, hipStream_t st);
+int launch_locate_wave(const atr_aligner *a, const uint4 *packed, const uint8_t *ascii, long long stride, const int32_t *lens,
+                       long long nreads, int nchunks, int max_len, uint4 *out, hipStream_t st);
 
 int launch_correct(uint8_t *s1, uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2,
                    long long stride, const int16_t *im, int im_stride, int gate_records, const uint8_t *mask, long long n,
@@ -251,7 +251,8 @@ int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const i
     const bool band = d_work && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k);
     if (path == ATR_LOCATE_WAVE || (path == ATR_LOCATE_AUTO && !band && wave_applies(a->p.m, nreads))) {
         // short batch: a wavefront per read (wave_core.hpp)
-        const int rc = launch_locate_wave(a, (const uint4 *)d_packed, d_lens, nreads, (max_len + 31) / 32, max_len,
+        if (max_len == 0) d_packed = (const uint8_t *)d_out;          // (nothing is read; non-null = "packed input")
+        const int rc = launch_locate_wave(a, (const uint4 *)d_packed, nullptr, 0, d_lens, nreads, (max_len + 31) / 32, max_len,
                                           (uint4 *)d_out, (hipStream_t)stream);
         return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_wave_kernel launch");
     }
@@ -276,6 +277,55 @@ int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const i
     const int rc = fn(a, (const uint4 *)d_packed, d_lens, nreads, nchunks, max_len, (uint4 *)d_out,
                       (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_kernel launch");
+}
+
+int atr_locate_ascii_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
+                           int64_t nreads, int max_len, atr_result *d_out, void *stream) {
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || row_stride < max_len) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    if (!d_out || !d_ascii) return ATR_ERR_INVALID;
+    if (nreads > WAVE_MAX_READS || (row_stride & 3) || ((uintptr_t)d_ascii & 3)) return ATR_ERR_UNSUPPORTED;
+    const int rc = launch_locate_wave(a, nullptr, d_ascii, row_stride, d_lens, nreads, 0, max_len, (uint4 *)d_out,
+                                      (hipStream_t)stream);
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_wave_kernel launch");
+}
+
+// Page-locked, device-visible staging of atr_locate_one: one read in, one record out; per host thread, kept for its life.
+struct OneShot {
+    uint8_t *in = nullptr;              // ATR_MAX_READ_LEN bytes, rounded up
+    atr_result *out = nullptr;
+    int device = -1;
+    bool ready() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (in && dev == device) return true;
+        if (in) { (void)hipHostFree(in); in = nullptr; out = nullptr; }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 1024 + 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false;
+        in = (uint8_t *)p;
+        out = (atr_result *)(in + 1024);
+        device = dev;
+        return true;
+    }
+};
+
+int atr_locate_one(const atr_aligner *a, const char *query, int n, atr_result *out, void *stream) {
+    if (!a || n < 0 || (n > 0 && !query) || !out) return ATR_ERR_INVALID;
+    if (n > ATR_MAX_READ_LEN) return ATR_ERR_UNSUPPORTED;
+    static_assert(ATR_MAX_READ_LEN <= 1024, "staging buffer of atr_locate_one");
+    static thread_local OneShot shot;
+    if (!shot.ready()) return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(atr_locate_one staging)");
+    memcpy(shot.in, query, (size_t)n);
+    void *din = nullptr, *dout = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&din, shot.in, 0);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&dout, shot.out, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer");
+    const int rc = launch_locate_wave(a, nullptr, (const uint8_t *)din, 1024, nullptr, 1, 0, n, (uint4 *)dout, (hipStream_t)stream);
+    if (rc != 0) return hip_fail((hipError_t)rc, "locate_wave_kernel launch");
+    e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    *out = *shot.out;
+    return ATR_OK;
 }
 
 int atr_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner **out) {

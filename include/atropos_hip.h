@@ -163,6 +163,19 @@ int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_
 int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                           int64_t nreads, int max_len, atr_result *d_out, void *d_work, int path, void *stream);
 
+/* Short batches straight from ASCII (no atr_pack_reads in between): row r of d_ascii (row_stride bytes apart; base
+ * address and stride multiples of four) holds read r, translated inside the wavefront-per-read kernel with the aligner's
+ * own query table (_align.pyx:243-248, :292-297).  At most 32768 reads per call (ATR_ERR_UNSUPPORTED beyond: pack the
+ * batch and call atr_locate_batch). */
+int atr_locate_ascii_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
+                           int64_t nreads, int max_len, atr_result *d_out, void *stream);
+
+/* Aligner.locate(query) for ONE read in HOST memory, synchronously: what the module swap of INTEGRATION.md section 1
+ * calls per read.  The read goes through a page-locked staging buffer of the calling thread that the kernel reads
+ * directly, the record comes back the same way; one launch, one stream synchronisation, no allocation.
+ * query: n ASCII bytes (not translated, not terminated); *out: the record (refstop = -1 for None). */
+int atr_locate_one(const atr_aligner *a, const char *query, int n, atr_result *out, void *stream);
+
 /* ---- linked adapters: LinkedAdapter.match_to under AdapterCutter._best_match ------------
  * (atropos/adapters/__init__.py:648-690, atropos/commands/trim/modifiers.py:107-122) --------- */
 
