@@ -118,6 +118,97 @@ ATR_DEV int multi_locate_one(const uint8_t *ref, int m, const uint8_t *query, in
 #undef ORIG
 }
 
+// ---- the same result without a DP: MultiAligner allows no indels, so a cell only depends on its diagonal ----------
+// Every cell the reference can accept lies on a diagonal whose first cell -- in row 0 or in the initial column -- has
+// cost 0 (the others start with an overhang cost of 100000 per position and never get below it), and its cost is the
+// number of mismatches between that first cell and itself: one Hamming distance per candidate.  Ukkonen's `last`
+// only ever hides cells of cost > k, which no test accepts (cost <= length * e implies cost <= k), and the stale
+// values it leaves behind in the last column are init values or costs > k.  What remains of the DP is its ORDER:
+// row-m cells by column (break at a perfect full-length hit, cut at max_matches), then -- unless the loop broke --
+// the last column by row (the for ... else of :746-763), and "only the exact hit" at the end (:767-768).
+// The kernel evaluates 64 candidates at a time, one per lane; this file holds what a lane does.
+struct MultiSetup {
+    bool sr, sq, er, eq;
+    int m, n, k, min_n, max_n, min_overlap;
+    double e;
+};
+ATR_DEV MultiSetup multi_setup(int m, int n, double e, int flags, int min_overlap) {
+    MultiSetup S;
+    S.sr = (flags & ATR_START_WITHIN_SEQ1) != 0; S.sq = (flags & ATR_START_WITHIN_SEQ2) != 0;
+    S.er = (flags & ATR_STOP_WITHIN_SEQ1) != 0;  S.eq = (flags & ATR_STOP_WITHIN_SEQ2) != 0;
+    S.m = m; S.n = n; S.e = e; S.min_overlap = min_overlap;
+    S.k = (int)(e * m);                                                // :634
+    S.max_n = S.sq ? n : mc_min(n, m + S.k);
+    S.min_n = S.eq ? 0 : mc_max(0, n - m - S.k);
+    return S;
+}
+
+// First cell (i0, j0) of the diagonal through (ie, je) and its origin; false when that cell carries an overhang cost.
+ATR_DEV bool multi_diag_start(const MultiSetup &S, int ie, int je, int &i0, int &j0, int &origin) {
+    const int d = je - ie;
+    if (d > S.min_n) {                                                 // row 0, column d (:672-676)
+        if (!S.sq) return false;                                       // cost d * overhang
+        i0 = 0; j0 = d; origin = d;
+        return true;
+    }
+    i0 = S.min_n - d; j0 = S.min_n;                                    // the initial column (:646-665)
+    if (!S.sr && !S.sq) { origin = 0; return i0 == 0 && S.min_n == 0; }
+    if (S.sr && !S.sq)  { origin = mc_min(0, S.min_n - i0); return S.min_n == 0; }
+    if (!S.sr && S.sq)  { origin = mc_max(0, S.min_n - i0); return i0 == 0; }
+    origin = S.min_n - i0;
+    return i0 == 0 || S.min_n == 0;
+}
+
+// The candidate test of :717-745 / :750-763 for the cell (ie, je); rec: its record when accepted.
+// perfect: a full-length hit without errors (the reference breaks out of its loop there).
+ATR_DEV bool multi_candidate(const MultiSetup &S, const uint8_t *ref, const uint8_t *query, int ie, int je, int16_t rec[8],
+                             bool &perfect) {
+    perfect = false;
+    int i0, j0, origin;
+    if (!multi_diag_start(S, ie, je, i0, j0, origin) || i0 > ie) return false;
+    const int len = ie - i0;
+    int mism = 0;
+    for (int t = 0; t < len; ++t) mism += (ref[i0 + t] != query[j0 + t]) ? 1 : 0;
+    const int length = ie + mc_min(origin, 0);
+    if (!(length >= S.min_overlap && (double)mism <= length * S.e)) return false;
+    put_record(rec, origin, ie, je, len - mism, mism);
+    perfect = mism == 0 && len == S.m;
+    return true;
+}
+
+// The whole call, candidate by candidate in the reference's order (the CPU twin of multi_wave_kernel; the kernel does
+// the same with 64 candidates per step and ballots).
+ATR_DEV int multi_locate_diag(const uint8_t *ref, int m, const uint8_t *query, int n, double e, int flags, int min_overlap,
+                              int max_matches, int16_t *out, int cap) {
+    const MultiSetup S = multi_setup(m, n, e, flags, min_overlap);
+    int nh = 0, exact = -1;
+    bool broke = false;
+    int16_t rec[8];
+    bool perfect;
+    if (S.eq) {
+        for (int j = S.min_n + 1; j <= S.max_n && !broke; ++j) {
+            if (!multi_candidate(S, ref, query, m, j, rec, perfect)) continue;
+            const int slot = nh < cap ? nh : (perfect && cap > 0 ? cap - 1 : -1);
+            if (slot >= 0) for (int t = 0; t < 8; ++t) out[8 * slot + t] = rec[t];
+            if (perfect) { exact = nh; ++nh; broke = true; }
+            else if (++nh >= max_matches) broke = true;
+        }
+    }
+    if (!broke && S.max_n == n) {
+        for (int i = S.er ? 0 : m; i <= m; ++i) {
+            if (!multi_candidate(S, ref, query, i, n, rec, perfect)) continue;
+            if (nh < cap) for (int t = 0; t < 8; ++t) out[8 * nh + t] = rec[t];
+            ++nh;
+        }
+    }
+    if (exact >= 0) {
+        if (exact != 0 && exact < cap) for (int t = 0; t < 8; ++t) out[t] = out[8 * exact + t];
+        else if (exact != 0 && cap > 0) for (int t = 0; t < 8; ++t) out[t] = out[8 * (cap - 1) + t];
+        return 1;
+    }
+    return nh;
+}
+
 // compare_prefixes / compare_suffixes of one uniform reference against one query.
 // tr / tq: translate tables or NULL for byte equality (both NULL together).
 ATR_DEV void compare_one(const uint8_t *ref, int m, const uint8_t *query, int n, const uint8_t *tr,

@@ -26,10 +26,22 @@ int emu_multi_locate_batch(const uint8_t *refs, int64_t ref_stride, const int32_
                            int32_t *counts, int out_stride) {
     if (npairs < 0 || flags < 0 || flags > 15 || max_matches < 1 || out_stride < 1) return ATR_ERR_INVALID;
     (void)max_ref_len;
-    for (int64_t p = 0; p < npairs; ++p)
-        counts[p] = multi_locate_one(refs + p * ref_stride, ref_lens[p], queries + p * q_stride, q_lens[p], e, flags,
-                                     min_overlap, max_matches, (int *)work + p, npairs,
-                                     out + (size_t)p * out_stride * 8, out_stride);
+    std::vector<int16_t> dp((size_t)out_stride * 8);
+    for (int64_t p = 0; p < npairs; ++p) {
+        int16_t *rec = out + (size_t)p * out_stride * 8;
+        // what multi_wave_kernel computes (one Hamming distance per candidate) ...
+        counts[p] = multi_locate_diag(refs + p * ref_stride, ref_lens[p], queries + p * q_stride, q_lens[p], e, flags,
+                                      min_overlap, max_matches, rec, out_stride);
+        // ... against the reference's own column-by-column DP, kept as the cross-check
+        const int c2 = multi_locate_one(refs + p * ref_stride, ref_lens[p], queries + p * q_stride, q_lens[p], e, flags,
+                                        min_overlap, max_matches, (int *)work + p, npairs, dp.data(), out_stride);
+        const int stored = std::min((int)counts[p], out_stride);
+        if (c2 != counts[p] || memcmp(dp.data(), rec, (size_t)stored * 16) != 0) {
+            fprintf(stderr, "emu_multi_locate_batch: the diagonal form disagrees with the DP (pair %lld: %d vs %d hits)\n",
+                    (long long)p, (int)counts[p], c2);
+            abort();
+        }
+    }
     return ATR_OK;
 }
 
