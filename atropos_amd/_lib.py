@@ -105,6 +105,9 @@ PROTOTYPES = {
                                    C.c_void_p, C.c_void_p]),
     "atr_locate_ascii_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_one": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_multi_locate_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_compare_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]),
     "atr_linked_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -421,6 +424,30 @@ class HipBackend(object):
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_locate_one(h, query, len(query), C.addressof(rec), self._stream()), "atr_locate_one")
         return None if rec[1] < 0 else (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
+
+    def multi_locate_one(self, ref, query, e, flags, min_overlap, max_matches):
+        """``MultiAligner.locate`` of ONE pair of byte strings (atr_multi_locate_one); list of 6-tuples or None."""
+        cap = max_matches + len(ref) + 2              # the last-column scan appends past max_matches (_align.pyx:750-763)
+        buf = getattr(self, "_multi_buf", None)
+        if buf is None or len(buf) < cap * 8:
+            buf = self._multi_buf = (C.c_int16 * (cap * 8))()
+            self._multi_cnt = C.c_int32()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_multi_locate_one(ref, len(ref), query, len(query), e, flags, min_overlap, max_matches,
+                                                           C.addressof(buf), cap, C.addressof(self._multi_cnt), self._stream()),
+                   "atr_multi_locate_one")
+        c = self._multi_cnt.value
+        return None if c == 0 else [tuple(buf[8 * t:8 * t + 6]) for t in range(c)]
+
+    def compare_one(self, ref, query, wildcard_ref, wildcard_query, suffix):
+        """compare_prefixes / compare_suffixes of one pair of byte strings (atr_compare_one); the 6-tuple."""
+        rec = getattr(self, "_cmp_rec", None)
+        if rec is None:
+            rec = self._cmp_rec = (C.c_int16 * 8)()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_compare_one(ref, len(ref), query, len(query), int(wildcard_ref), int(wildcard_query),
+                                                      int(suffix), C.addressof(rec), self._stream()), "atr_compare_one")
+        return (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
 
     def locate_ascii_batch(self, h, ascii_2d, lens, max_len):
         """atr_locate_ascii_batch: a short batch of ASCII rows (uint8 [n, width] on the device, row stride a multiple of

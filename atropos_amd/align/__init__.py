@@ -312,6 +312,9 @@ def compare_suffixes(suffix_ref, suffix_query, wildcard_ref=False, wildcard_quer
 
 
 def _compare(ref, query, wildcard_ref, wildcard_query, suffix):
+    be = _lib.get_backend()
+    if hasattr(be, "compare_one") and len(ref) <= 1024:
+        return be.compare_one(ref.encode('ascii'), query.encode('ascii'), wildcard_ref, wildcard_query, suffix)
     rec = compare_batch(ref, [query], wildcard_ref, wildcard_query, suffix).cpu().numpy()[0]
     return tuple(int(v) for v in rec[:6])
 
@@ -512,6 +515,10 @@ class MultiAligner(object):
     def locate(self, reference, query, max_matches=100):
         """locate(reference, query) -> list of (refstart, refstop, querystart, querystop,
         matches, errors), or None."""
+        be = _lib.get_backend()
+        if hasattr(be, "multi_locate_one") and len(reference) <= 20000 and len(query) <= 32000:
+            return be.multi_locate_one(reference.encode('ascii'), query.encode('ascii'), self.max_error_rate, self.flags,
+                                       self._min_overlap, max_matches)
         return self.locate_batch([reference], [query], max_matches)[0]
 
 

@@ -290,41 +290,85 @@ int atr_locate_ascii_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_wave_kernel launch");
 }
 
-// Page-locked, device-visible staging of atr_locate_one: one read in, one record out; per host thread, kept for its life.
+// Page-locked, device-visible staging of the one-object calls (atr_locate_one, atr_multi_locate_one, atr_compare_one):
+// the object goes in, the records come out; per host thread, kept for its life, grown on demand.
 struct OneShot {
-    uint8_t *in = nullptr;              // ATR_MAX_READ_LEN bytes, rounded up
-    atr_result *out = nullptr;
+    uint8_t *base = nullptr, *dev = nullptr;
+    size_t cap = 0;
     int device = -1;
-    bool ready() {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (in && dev == device) return true;
-        if (in) { (void)hipHostFree(in); in = nullptr; out = nullptr; }
-        void *p = nullptr;
-        if (hipHostMalloc(&p, 1024 + 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false;
-        in = (uint8_t *)p;
-        out = (atr_result *)(in + 1024);
-        device = dev;
+    bool ready(size_t bytes) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return false;
+        if (base && cur == device && bytes <= cap) return true;
+        if (base) { (void)hipHostFree(base); base = nullptr; cap = 0; }
+        const size_t want = bytes < 4096 ? 4096 : (bytes + 4095) / 4096 * 4096;
+        void *p = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { (void)hipHostFree(p); return false; }
+        base = (uint8_t *)p; dev = (uint8_t *)dp; cap = want; device = cur;
         return true;
     }
 };
+static OneShot &one_shot() {
+    static thread_local OneShot shot;
+    return shot;
+}
 
 int atr_locate_one(const atr_aligner *a, const char *query, int n, atr_result *out, void *stream) {
     if (!a || n < 0 || (n > 0 && !query) || !out) return ATR_ERR_INVALID;
     if (n > ATR_MAX_READ_LEN) return ATR_ERR_UNSUPPORTED;
-    static_assert(ATR_MAX_READ_LEN <= 1024, "staging buffer of atr_locate_one");
-    static thread_local OneShot shot;
-    if (!shot.ready()) return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(atr_locate_one staging)");
-    memcpy(shot.in, query, (size_t)n);
-    void *din = nullptr, *dout = nullptr;
-    hipError_t e = hipHostGetDevicePointer(&din, shot.in, 0);
-    if (e == hipSuccess) e = hipHostGetDevicePointer(&dout, shot.out, 0);
-    if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer");
-    const int rc = launch_locate_wave(a, nullptr, (const uint8_t *)din, 1024, nullptr, 1, 0, n, (uint4 *)dout, (hipStream_t)stream);
+    static_assert(ATR_MAX_READ_LEN <= 1024, "staging layout of atr_locate_one");
+    OneShot &shot = one_shot();
+    if (!shot.ready(1024 + 64)) return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(one-object staging)");
+    memcpy(shot.base, query, (size_t)n);
+    const int rc = launch_locate_wave(a, nullptr, shot.dev, 1024, nullptr, 1, 0, n, (uint4 *)(shot.dev + 1024), (hipStream_t)stream);
     if (rc != 0) return hip_fail((hipError_t)rc, "locate_wave_kernel launch");
-    e = hipStreamSynchronize((hipStream_t)stream);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
-    *out = *shot.out;
+    *out = *(const atr_result *)(shot.base + 1024);
+    return ATR_OK;
+}
+
+int atr_multi_locate_one(const char *ref, int m, const char *query, int n, double max_error_rate, int flags, int min_overlap,
+                         int max_matches, atr_result *out, int cap, int32_t *count, void *stream) {
+    if (m < 0 || n < 0 || (m > 0 && !ref) || (n > 0 && !query) || flags < 0 || flags > 15 || max_matches < 1 || cap < 1 || !out ||
+        !count)
+        return ATR_ERR_INVALID;
+    if (m > 20000 || n > 32000) return ATR_ERR_UNSUPPORTED;           // int16 coordinates
+    // layout: [lens: 2 x int32][count: int32, pad][records: cap x 16][reference][query]
+    const size_t rec_off = 16, ref_off = rec_off + (size_t)cap * 16, qry_off = ref_off + (((size_t)m + 15) & ~(size_t)15);
+    OneShot &shot = one_shot();
+    if (!shot.ready(qry_off + (size_t)n + 16)) return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(one-object staging)");
+    int32_t *head = (int32_t *)shot.base;
+    head[0] = m; head[1] = n; head[2] = 0;
+    memcpy(shot.base + ref_off, ref, (size_t)m);
+    memcpy(shot.base + qry_off, query, (size_t)n);
+    const int rc = launch_multi(shot.dev + ref_off, 0, (const int32_t *)shot.dev, shot.dev + qry_off, 0,
+                                (const int32_t *)shot.dev + 1, 1, max_error_rate, flags, min_overlap, max_matches, nullptr,
+                                (int16_t *)(shot.dev + rec_off), (int32_t *)shot.dev + 2, cap, (hipStream_t)stream);
+    if (rc != 0) return hip_fail((hipError_t)rc, "multi_wave_kernel launch");
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    *count = head[2];
+    const int stored = head[2] < cap ? head[2] : cap;
+    memcpy(out, shot.base + rec_off, (size_t)(stored > 0 ? stored : 0) * 16);
+    return ATR_OK;
+}
+
+int atr_compare_one(const char *ref, int m, const char *query, int n, int wildcard_ref, int wildcard_query, int suffix,
+                    atr_result *out, void *stream) {
+    if (m < 0 || n < 0 || (m > 0 && !ref) || (n > 0 && !query) || !out) return ATR_ERR_INVALID;
+    if (m > 1024 || n > 32000) return ATR_ERR_UNSUPPORTED;
+    OneShot &shot = one_shot();
+    if (!shot.ready(32 + (size_t)n + 16)) return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(one-object staging)");
+    *(int32_t *)(shot.base + 16) = n;
+    memcpy(shot.base + 32, query, (size_t)n);
+    const int rc = launch_compare((const uint8_t *)(m ? ref : ""), m, shot.dev + 32, 0, (const int32_t *)(shot.dev + 16), 1, n,
+                                  wildcard_ref, wildcard_query, suffix, (int16_t *)shot.dev, (hipStream_t)stream);
+    if (rc != 0) return hip_fail((hipError_t)rc, "compare_kernel launch");
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    *out = *(const atr_result *)shot.base;
     return ATR_OK;
 }
 

@@ -1,25 +1,95 @@
-// misc_kernels.hip -- gfx950 kernels around misc_core.hpp (general MultiAligner.locate,
-// compare_prefixes/compare_suffixes), one pair per thread.
+// misc_kernels.hip -- gfx950 kernels around misc_core.hpp (general MultiAligner.locate: one pair per wavefront;
+// compare_prefixes/compare_suffixes: one pair per thread).
 #include <hip/hip_runtime.h>
 #include "aligner_host.hpp"
 #include "misc_core.hpp"
 
 namespace atr {
 
-__global__ __launch_bounds__(256) void multi_locate_kernel(const uint8_t *__restrict__ refs, long long ref_stride,
-                                                           const int32_t *__restrict__ ref_lens,
-                                                           const uint8_t *__restrict__ queries, long long q_stride,
-                                                           const int32_t *__restrict__ q_lens, long long npairs,
-                                                           double e, int flags, int min_overlap, int max_matches,
-                                                           int *__restrict__ work, int16_t *__restrict__ out,
-                                                           int32_t *__restrict__ counts, int out_stride) {
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npairs) return;
-    // column scratch is interleaved across pairs (element i of pair p at work[i*npairs + p]):
-    // the threads of a wave touch consecutive words
-    counts[p] = multi_locate_one(refs + p * ref_stride, ref_lens[p], queries + p * q_stride, q_lens[p], e, flags,
-                                 min_overlap, max_matches, work + p, npairs, out + (size_t)p * out_stride * 8,
-                                 out_stride);
+// MultiAligner.locate, one pair per WAVEFRONT: 64 candidates at a time, one Hamming distance per lane (misc_core.hpp,
+// multi_locate_diag is the same thing candidate by candidate), the reference's order restored with ballots.  The
+// lane-per-pair kernel above runs the column DP as one chain of m * n dependent byte operations: 2.6 ms for ONE pair
+// of 150-base reads, which is what the module swap of INTEGRATION.md section 1 pays per read pair with the insert
+// aligner.  Pairs of up to MULTI_LDS bytes a side are staged in LDS.
+constexpr int MULTI_LDS = 4096;
+
+__global__ __launch_bounds__(64) void multi_wave_kernel(const uint8_t *__restrict__ refs, long long ref_stride,
+                                                        const int32_t *__restrict__ ref_lens,
+                                                        const uint8_t *__restrict__ queries, long long q_stride,
+                                                        const int32_t *__restrict__ q_lens, long long npairs, double e,
+                                                        int flags, int min_overlap, int max_matches,
+                                                        int16_t *__restrict__ out, int32_t *__restrict__ counts, int cap) {
+    __shared__ uint8_t s_ref[MULTI_LDS], s_qry[MULTI_LDS];
+    const int lane = threadIdx.x;
+    const long long p = blockIdx.x;
+    const int m = __builtin_amdgcn_readfirstlane(ref_lens[p]), n = __builtin_amdgcn_readfirstlane(q_lens[p]);
+    const uint8_t *R = refs + p * ref_stride, *Q = queries + p * q_stride;
+    if (m <= MULTI_LDS && n <= MULTI_LDS) {
+        for (int i = lane; i < m; i += 64) s_ref[i] = R[i];
+        for (int i = lane; i < n; i += 64) s_qry[i] = Q[i];
+        __syncthreads();
+        R = s_ref; Q = s_qry;
+    }
+    const MultiSetup S = multi_setup(m, n, e, flags, min_overlap);
+    int16_t *o = out + (size_t)p * cap * 8;
+    int nh = 0, exact = -1, exact_lane = -1;
+    bool broke = false;
+    int16_t rec[8], exact_rec[8];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (S.eq) {
+        for (int j0 = S.min_n + 1; j0 <= S.max_n && !broke; j0 += 64) {     // row m, by column (:667-745)
+            const int j = j0 + lane;
+            bool perfect = false;
+            const bool acc = j <= S.max_n && multi_candidate(S, R, Q, m, j, rec, perfect);
+            const unsigned long long A = __ballot(acc), X = __ballot(acc && perfect);
+            if (A == 0ull) continue;
+            // where the reference's loop ends inside this chunk: at the first perfect hit, or at the hit that fills max_matches
+            unsigned long long t = A;
+            for (int c = 1; c < max_matches - nh && t; ++c) t &= t - 1ull;
+            const int cut = t ? (int)__builtin_ctzll(t) : 64, ex = X ? (int)__builtin_ctzll(X) : 64;
+            const int brk = ex <= cut ? ex : cut;
+            const int slot = nh + (int)__popcll(A & below);
+            if (acc && lane <= brk) {
+                const bool is_exact = lane == ex && lane == brk;
+                const int at = slot < cap ? slot : (is_exact && cap > 0 ? cap - 1 : -1);
+                if (at >= 0)
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) o[8 * at + w] = rec[w];
+                if (is_exact)
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) exact_rec[w] = rec[w];
+            }
+            if (brk < 64) {
+                const int taken = (int)__popcll(A & ((2ull << brk) - 1ull));
+                if (brk == ex) { exact = nh + taken - 1; exact_lane = brk; }
+                nh += taken;
+                broke = true;
+            } else {
+                nh += (int)__popcll(A);
+            }
+        }
+    }
+    if (!broke && S.max_n == n) {                                            // the last column, by row (:746-763)
+        for (int i0 = S.er ? 0 : m; i0 <= m; i0 += 64) {
+            const int i = i0 + lane;
+            bool perfect = false;
+            const bool acc = i <= m && multi_candidate(S, R, Q, i, n, rec, perfect);
+            const unsigned long long A = __ballot(acc);
+            const int slot = nh + (int)__popcll(A & below);
+            if (acc && slot < cap)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) o[8 * slot + w] = rec[w];
+            nh += (int)__popcll(A);
+        }
+    }
+    if (exact >= 0) {                                                        // only the exact hit (:767-768)
+        __syncthreads();                                                     // (the stores above have landed)
+        if (exact != 0 && cap > 0 && lane == exact_lane)
+#pragma unroll
+            for (int w = 0; w < 8; ++w) o[w] = exact_rec[w];
+        nh = 1;
+    }
+    if (lane == 0) counts[p] = nh;
 }
 
 struct CompareRef { uint8_t r[1024]; uint8_t tr[256]; uint8_t tq[256]; };
@@ -332,9 +402,9 @@ int launch_postfilter(int16_t *rec, long long n, int m, int min_overlap, double 
 int launch_multi(const uint8_t *refs, long long ref_stride, const int32_t *ref_lens, const uint8_t *queries,
                  long long q_stride, const int32_t *q_lens, long long npairs, double e, int flags, int min_overlap,
                  int max_matches, int *work, int16_t *out, int32_t *counts, int out_stride, hipStream_t st) {
-    hipLaunchKernelGGL(multi_locate_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, refs, ref_stride,
-                       ref_lens, queries, q_stride, q_lens, npairs, e, flags, min_overlap, max_matches, work, out,
-                       counts, out_stride);
+    (void)work;                                                       // (scratch of the lane-per-pair DP kernel, kept in the ABI)
+    hipLaunchKernelGGL(multi_wave_kernel, dim3((unsigned)npairs), dim3(64), 0, st, refs, ref_stride, ref_lens, queries, q_stride,
+                       q_lens, npairs, e, flags, min_overlap, max_matches, out, counts, out_stride);
     return (int)hipGetLastError();
 }
 

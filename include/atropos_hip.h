@@ -176,6 +176,16 @@ int atr_locate_ascii_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t
  * query: n ASCII bytes (not translated, not terminated); *out: the record (refstop = -1 for None). */
 int atr_locate_one(const atr_aligner *a, const char *query, int n, atr_result *out, void *stream);
 
+/* The same for the other two functions the module swap calls once per read pair with the insert aligner
+ * (align/__init__.py:250-377): MultiAligner(max_error_rate, flags, min_overlap).locate(ref, query, max_matches)
+ * (_align.pyx:593-783; out: up to cap records, *count: the number of hits the reference returns, 0 = None) and
+ * compare_prefixes / compare_suffixes(ref, query, wildcard_ref, wildcard_query) (_align.pyx:501-544,
+ * align/__init__.py:28-44).  Host strings in, host records out, one launch and one synchronisation each. */
+int atr_multi_locate_one(const char *ref, int m, const char *query, int n, double max_error_rate, int flags, int min_overlap,
+                         int max_matches, atr_result *out, int cap, int32_t *count, void *stream);
+int atr_compare_one(const char *ref, int m, const char *query, int n, int wildcard_ref, int wildcard_query, int suffix,
+                    atr_result *out, void *stream);
+
 /* ---- linked adapters: LinkedAdapter.match_to under AdapterCutter._best_match ------------
  * (atropos/adapters/__init__.py:648-690, atropos/commands/trim/modifiers.py:107-122) --------- */
 

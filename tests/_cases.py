@@ -1381,3 +1381,36 @@ def check_long_reference_envelope(Aligner, PairAligner, oracle):
             assert pa.locate_batch(refs, qs, path=path).tuples() == exp, (path, e, flags, ic, top)
         total += len(refs)
     return total
+
+
+def check_multi_against_oracle(MultiAligner, oracle, seed, rounds, npairs=40, top=60):
+    """MultiAligner.locate (no indels; up to max_matches hits) against the oracle: all 16 flag sets, error rates up to
+    1, small alphabets (many hits: the max_matches cut and the perfect-hit break), unequal and empty sides."""
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        flags = rng.randint(0, 15) if rng.random() < 0.7 else 9
+        e = rng.choice([0, 0.05, 0.1, 0.2, 0.3, 0.5, 1.0])
+        mo, mm = rng.choice([1, 1, 3, 10]), rng.choice([1, 2, 5, 100])
+        ma = MultiAligner(e, flags, mo)
+        refs, qs = [], []
+        for _p in range(npairs):
+            m, n = rng.randint(0, top), rng.randint(0, top)
+            alpha = rng.choice(["ACGT", "AC", "A", "ACGTN"])
+            frag = rseq(rng, m + n + 2, alpha)
+            kind = rng.random()
+            if kind < 0.5:
+                off = rng.randint(0, m)
+                refs.append(frag[:m])
+                qs.append(mutate(rng, frag[off:off + n], rng.choice([0, 0.05, 0.2]), alpha)[:n])
+            elif kind < 0.7:
+                refs.append(frag[:m])
+                qs.append(frag[:m][:n] if rng.random() < 0.5 else frag[:m] * 2)
+            else:
+                refs.append(rseq(rng, m, alpha))
+                qs.append(rseq(rng, n, alpha))
+        got = ma.locate_batch(refs, qs, mm)
+        for r, q, g in zip(refs, qs, got):
+            assert g == oracle.multi_locate(r, q, e, flags, mo, mm), (r, q, e, flags, mo, mm, g)
+            total += 1
+    return total

@@ -54,3 +54,8 @@ def test_plane_guided_correction(emu_backend):
 
 def test_correct_errors_fixture(emu_backend):
     assert _cases.check_correct_errors_fixture() == 4000
+
+
+def test_multi_aligner_against_oracle(emu_backend, oracle):
+    from atropos_amd.align import MultiAligner
+    assert _cases.check_multi_against_oracle(MultiAligner, oracle, 21, 60) == 2400

@@ -175,3 +175,11 @@ def test_c5_correction_at_size(hip_backend, oracle):
 def test_read2_validation(hip_backend):
     from atropos_amd.align import InsertAligner
     _cases.check_read2_validation(InsertAligner("TTAGACATATGG", "CAGTGGAGTATA"))
+
+
+def test_multi_aligner_against_oracle(hip_backend, oracle):
+    """multi_wave_kernel (a wavefront per pair, one Hamming distance per candidate) against the oracle, short and
+    MiSeq-length sides."""
+    from atropos_amd.align import MultiAligner
+    assert _cases.check_multi_against_oracle(MultiAligner, oracle, 21, 60) == 2400
+    assert _cases.check_multi_against_oracle(MultiAligner, oracle, 22, 12, npairs=30, top=320) == 360
