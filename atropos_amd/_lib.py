@@ -125,6 +125,8 @@ PROTOTYPES = {
     "atr_locate_pairs_path_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_locate_pair_one": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_pairs_full_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_void_p]),
@@ -448,6 +450,19 @@ class HipBackend(object):
             _check(self.lib, self.lib.atr_compare_one(ref, len(ref), query, len(query), int(wildcard_ref), int(wildcard_query),
                                                       int(suffix), C.addressof(rec), self._stream()), "atr_compare_one")
         return (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
+
+    def locate_pair_one(self, ref_codes, revcomp_ref, query_codes, e, flags, wildcard_ref, wildcard_query, min_overlap,
+                        indel_cost):
+        """``Aligner(ref, ...).locate(query)`` for ONE pair of translated byte strings (atr_locate_pair_one)."""
+        rec = getattr(self, "_pair_rec", None)
+        if rec is None:
+            rec = self._pair_rec = (C.c_int16 * 8)()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_locate_pair_one(ref_codes, len(ref_codes), int(revcomp_ref), query_codes,
+                                                          len(query_codes), e, flags, int(wildcard_ref), int(wildcard_query),
+                                                          min_overlap, indel_cost, C.addressof(rec), self._stream()),
+                   "atr_locate_pair_one")
+        return None if rec[1] < 0 else (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
 
     def locate_ascii_batch(self, h, ascii_2d, lens, max_len):
         """atr_locate_ascii_batch: a short batch of ASCII rows (uint8 [n, width] on the device, row stride a multiple of

@@ -266,7 +266,9 @@ class Aligner(object):
             raise TypeError("query must be str")
         qbytes = query.encode('ascii')                 # UnicodeEncodeError like the reference (:281)
         be = self._backend
-        if self._handle is not None and hasattr(be, "locate_one") and len(qbytes) <= _lib.MAX_READ_LEN:
+        if getattr(self, "_long", False) and not self._debug:
+            result = self._pair_aligner().locate(self.str_reference, query, unknown_queries_ok=True)
+        elif self._handle is not None and hasattr(be, "locate_one") and len(qbytes) <= _lib.MAX_READ_LEN:
             # the per-read API as the module swap uses it: cached buffers, no allocation (HipBackend.locate_one)
             table = self._table if self._table is not None else be.translate_table(self._table_kind)
             result = be.locate_one(self._handle, table, qbytes)
@@ -469,8 +471,21 @@ class PairAligner(object):
                                     self.min_overlap, self.indel_cost, need=need, path=path)
         return LocateResult(rec)
 
-    def locate(self, reference, query):
-        return self.locate_batch([reference], [query]).tuples()[0]
+    def locate(self, reference, query, unknown_queries_ok=False):
+        be = _lib.get_backend()
+        if hasattr(be, "locate_pair_one") and len(reference) <= 319 and len(query) <= _lib.PAIRS_MAX_LEN:
+            # one pair: translate here (bytes.translate, as the reference does per read), one library call
+            rk, qk = self._table_kinds()
+            literal = not (self.wildcard_ref or self.wildcard_query)
+            rc = reference.encode('ascii').translate(be.translate_table(rk))
+            qc = query.encode('ascii').translate(be.translate_table(qk))
+            checked = literal or self.revcomp_ref
+            clean = not checked or (b"\0" not in rc and (b"\0" not in qc or (unknown_queries_ok and literal and not self.revcomp_ref)))
+            if clean and (self.flags & STOP_WITHIN_SEQ2 or max(len(rc), len(qc)) <= 255):
+                return be.locate_pair_one(rc, self.revcomp_ref, qc, self.max_error_rate, self.flags, self.wildcard_ref,
+                                          self.wildcard_query, self.min_overlap, self.indel_cost)
+            # (soft-masked or uncoded characters: the batch path sorts those out)
+        return self.locate_batch([reference], [query], unknown_queries_ok=unknown_queries_ok).tuples()[0]
 
 
 class MultiAligner(object):

@@ -5,6 +5,7 @@
 // recurrence is a min-plus chain along the column, not a contraction).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstring>
 
 #include "atropos_hip.h"
 #include "pairs_core.hpp"
@@ -230,7 +231,8 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
                              uint4 *out, hipStream_t st);
 
 hipError_t launch_pairs_wave(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
-                             const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out, hipStream_t st);
+                             const uint32_t *qp, const int32_t *ql, int qmax, const uint8_t *ref_codes, const uint8_t *qry_codes,
+                             long long npairs, uint4 *out, hipStream_t st);
 
 hipError_t launch_pairs_full_indexed(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
                                      const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out,
@@ -273,7 +275,7 @@ extern "C" int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const in
     if (path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && wave_pairs_applies(ref_max_len, (long long)npairs))) {
         // short batch: a wavefront per pair (pairs_wave.hip); a lane per pair is one chain of m x n dependent cells
         const hipError_t e = launch_pairs_wave(p, rp, d_ref_lens, ref_max_len, revcomp_ref, qp, d_query_lens, query_max_len,
-                                               (long long)npairs, (uint4 *)d_out, (hipStream_t)stream);
+                                               nullptr, nullptr, (long long)npairs, (uint4 *)d_out, (hipStream_t)stream);
         return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_wave_kernel launch");
     }
     // ... and a batch below a quarter of a million pairs: the pipeline's dozen launches cost 1.2 ms (2 x 150 bp) whatever
@@ -320,4 +322,47 @@ extern "C" int atr_locate_pairs_full_batch(const uint8_t *d_ref_packed, const in
     return pairs_full(p, (const uint32_t *)d_ref_packed, d_ref_lens, ref_max_len, revcomp_ref, (const uint32_t *)d_query_packed,
                       d_query_lens, query_max_len, (long long)npairs, (uint4 *)d_out, (hipStream_t)stream,
                       PairIndex{nullptr, nullptr});
+}
+
+// Aligner(reference, ...).locate(query) for ONE pair in host memory, synchronously (what MergeOverlapping does per read
+// pair through the module swap when the reads are longer than an aligner handle's 128 bases): ref_codes / query_codes
+// are the strings translated to 4-bit codes, one per byte, with the tables of atr_locate_pairs_batch.
+namespace {
+struct PairShot {
+    uint8_t *base = nullptr, *dev = nullptr;
+    int device = -1;
+    bool ready() {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return false;
+        if (base && cur == device) return true;
+        if (base) { (void)hipHostFree(base); base = nullptr; }
+        void *p = nullptr, *dp = nullptr;
+        if (hipHostMalloc(&p, 1024, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) return false;
+        if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) { (void)hipHostFree(p); return false; }
+        base = (uint8_t *)p; dev = (uint8_t *)dp; device = cur;
+        return true;
+    }
+};
+}  // namespace
+
+extern "C" int atr_locate_pair_one(const uint8_t *ref_codes, int m, int revcomp_ref, const uint8_t *query_codes, int n,
+                                   double max_error_rate, int flags, int wildcard_ref, int wildcard_query, int min_overlap,
+                                   int indel_cost, atr_result *out, void *stream) {
+    if (m < 0 || n < 0 || (m > 0 && !ref_codes) || (n > 0 && !query_codes) || !out) return ATR_ERR_INVALID;
+    PairParams p;
+    const int rc = pairs_params(max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost, m, n, p);
+    if (rc != ATR_OK) return rc;
+    if (!wave_pairs_applies(m, 1)) return ATR_ERR_UNSUPPORTED;
+    static_assert(2 * 320 + 64 <= 1024 && ATR_PAIRS_MAX_LEN <= 320, "staging layout of atr_locate_pair_one");
+    static thread_local PairShot shot;
+    if (!shot.ready()) return hip_fail(hipErrorOutOfMemory, "hipHostMalloc(pair staging)");
+    std::memcpy(shot.base + 64, ref_codes, (size_t)m);                      // [record: 16 B, pad][reference: 320][query: 320]
+    std::memcpy(shot.base + 64 + 320, query_codes, (size_t)n);
+    const hipError_t e = launch_pairs_wave(p, nullptr, nullptr, m, revcomp_ref, nullptr, nullptr, n, shot.dev + 64, shot.dev + 64 + 320,
+                                           1, (uint4 *)shot.dev, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "pairs_wave_kernel launch");
+    const hipError_t s = hipStreamSynchronize((hipStream_t)stream);
+    if (s != hipSuccess) return hip_fail(s, "hipStreamSynchronize");
+    *out = *(const atr_result *)shot.base;
+    return ATR_OK;
 }

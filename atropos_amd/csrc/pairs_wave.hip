@@ -38,6 +38,7 @@ __global__ __launch_bounds__(64) void pairs_wave_kernel(const PairParams p, cons
                                                         const int32_t *__restrict__ ref_lens, int ref_chunks, int ref_max_len,
                                                         int revcomp, const uint4 *__restrict__ qry_packed,
                                                         const int32_t *__restrict__ qry_lens, int qry_chunks, int qry_max_len,
+                                                        const uint8_t *__restrict__ ref_codes, const uint8_t *__restrict__ qry_codes,
                                                         long long npairs, uint4 *__restrict__ out) {
     __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3];
     __shared__ __attribute__((aligned(16))) uint32_t s_code[PW_PAD + (PAIRS_MAX_LEN + 31) / 32 * 32 + 2 * PW_PAD];
@@ -63,6 +64,16 @@ __global__ __launch_bounds__(64) void pairs_wave_kernel(const PairParams p, cons
         const int16_t *kthr = (const int16_t *)((const char *)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PairParams, thr));
         for (int i = lane; i < PAIRS_MAX_LEN + 3; i += 64) s_thr[i] = kthr[i];
     }
+    if (ref_codes) {
+        // one 4-bit code per byte, row r of each matrix (row stride = the layout width): atr_locate_pair_one hands the
+        // translated strings over in page-locked host memory
+        const uint8_t *rr = ref_codes + (size_t)r * ref_max_len, *qq = qry_codes + (size_t)r * qry_max_len;
+        for (int i = lane; i < n; i += 64) s_code[PW_PAD + i] = qq[i] & 15u;
+        for (int i = lane; i < m; i += 64) {
+            const uint32_t c = rr[i] & 15u;
+            if (revcomp) s_ref[m - 1 - i] = bitrev4(c); else s_ref[i] = c;
+        }
+    } else {
     if (lane < (n + 31) / 32) {
         uint32_t c[32];
         pw_unpack(qry_packed[((size_t)(r >> 6) * qry_chunks + lane) * 64 + (size_t)(r & 63)], c);
@@ -81,6 +92,7 @@ __global__ __launch_bounds__(64) void pairs_wave_kernel(const PairParams p, cons
                 else s_ref[i] = c[b];
             }
         }
+    }
     }
     __syncthreads();
 
@@ -210,10 +222,11 @@ __global__ __launch_bounds__(64) void pairs_wave_kernel(const PairParams p, cons
 
 template <int R>
 static void launch_pw_r(const PairParams &p, const uint4 *rp, const int32_t *rl, int rch, int rmax, int revcomp, const uint4 *qp,
-                        const int32_t *ql, int qch, int qmax, long long npairs, uint4 *out, hipStream_t st) {
+                        const int32_t *ql, int qch, int qmax, const uint8_t *rc, const uint8_t *qc, long long npairs, uint4 *out,
+                        hipStream_t st) {
     const dim3 grid((unsigned)npairs), block(64);
     const bool xrep = (p.flags & ATR_STOP_WITHIN_SEQ2) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0, am = p.and_mode != 0;
-#define ATR_PW_LAUNCH(X, S, A) hipLaunchKernelGGL((pairs_wave_kernel<X, S, R, A>), grid, block, 0, st, p, rp, rl, rch, rmax, revcomp, qp, ql, qch, qmax, npairs, out)
+#define ATR_PW_LAUNCH(X, S, A) hipLaunchKernelGGL((pairs_wave_kernel<X, S, R, A>), grid, block, 0, st, p, rp, rl, rch, rmax, revcomp, qp, ql, qch, qmax, rc, qc, npairs, out)
     if (xrep && sq) { if (am) ATR_PW_LAUNCH(true, true, true); else ATR_PW_LAUNCH(true, true, false); }
     else if (xrep) { if (am) ATR_PW_LAUNCH(true, false, true); else ATR_PW_LAUNCH(true, false, false); }
     else if (sq) { if (am) ATR_PW_LAUNCH(false, true, true); else ATR_PW_LAUNCH(false, true, false); }
@@ -221,18 +234,22 @@ static void launch_pw_r(const PairParams &p, const uint4 *rp, const int32_t *rl,
 #undef ATR_PW_LAUNCH
 }
 
-// every pair of the batch on a wavefront of its own; R from the longest reference
+// every pair of the batch on a wavefront of its own; R from the longest reference.  rp == nullptr: the sides as code
+// bytes (ref_codes / qry_codes, rows of rmax / qmax bytes).
 hipError_t launch_pairs_wave(const PairParams &p, const uint32_t *rp, const int32_t *rl, int rmax, int revcomp,
-                             const uint32_t *qp, const int32_t *ql, int qmax, long long npairs, uint4 *out, hipStream_t st) {
+                             const uint32_t *qp, const int32_t *ql, int qmax, const uint8_t *ref_codes, const uint8_t *qry_codes,
+                             long long npairs, uint4 *out, hipStream_t st) {
     const int rch = (rmax + 31) / 32, qch = (qmax + 31) / 32;
+#define ATR_PW_R(R) launch_pw_r<R>(p, (const uint4 *)rp, rl, rch, rmax, revcomp, (const uint4 *)qp, ql, qch, qmax, ref_codes, qry_codes, npairs, out, st)
     switch (wave_pair_rows(rmax)) {
-        case 1: launch_pw_r<1>(p, (const uint4 *)rp, rl, rch, rmax, revcomp, (const uint4 *)qp, ql, qch, qmax, npairs, out, st); break;
-        case 2: launch_pw_r<2>(p, (const uint4 *)rp, rl, rch, rmax, revcomp, (const uint4 *)qp, ql, qch, qmax, npairs, out, st); break;
-        case 3: launch_pw_r<3>(p, (const uint4 *)rp, rl, rch, rmax, revcomp, (const uint4 *)qp, ql, qch, qmax, npairs, out, st); break;
-        case 4: launch_pw_r<4>(p, (const uint4 *)rp, rl, rch, rmax, revcomp, (const uint4 *)qp, ql, qch, qmax, npairs, out, st); break;
-        case 5: launch_pw_r<5>(p, (const uint4 *)rp, rl, rch, rmax, revcomp, (const uint4 *)qp, ql, qch, qmax, npairs, out, st); break;
+        case 1: ATR_PW_R(1); break;
+        case 2: ATR_PW_R(2); break;
+        case 3: ATR_PW_R(3); break;
+        case 4: ATR_PW_R(4); break;
+        case 5: ATR_PW_R(5); break;
         default: return hipErrorNotSupported;
     }
+#undef ATR_PW_R
     return hipGetLastError();
 }
 

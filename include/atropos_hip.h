@@ -424,6 +424,14 @@ int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const int32_t *d_re
                                 int query_max_len, int64_t npairs, double max_error_rate, int flags,
                                 int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
                                 const int32_t *d_need, int path, atr_result *d_out, void *stream);
+
+/* The same for ONE pair in host memory, synchronously -- what MergeOverlapping does per read pair through the module swap
+ * (a new Aligner per pair, commands/trim/modifiers.py:889-894) when the reads are longer than an aligner handle's 128
+ * bases.  ref_codes / query_codes: the two strings translated to 4-bit codes, one per byte, with the tables named
+ * above (what atr_pack_reads would pack); references of up to 319 codes. */
+int atr_locate_pair_one(const uint8_t *ref_codes, int m, int revcomp_ref, const uint8_t *query_codes, int n,
+                        double max_error_rate, int flags, int wildcard_ref, int wildcard_query, int min_overlap,
+                        int indel_cost, atr_result *out, void *stream);
 /* atr_locate_pairs_batch by the full-matrix sweep alone (same records; the checker of the pipeline above). */
 int atr_locate_pairs_full_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
                                 const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,

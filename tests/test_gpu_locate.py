@@ -290,3 +290,16 @@ def test_per_read_api(hip_backend, oracle):
         assert al.locate(q) == oracle.locate(ref, q, *args), (ref, q, args)
         total += 1
     assert total == 300
+    # the per-pair form (what MergeOverlapping calls through the module swap): atr_locate_pair_one
+    from atropos_amd.align import PairAligner
+    from atropos_amd.util import reverse_complement
+    for rnd in range(200):
+        flags = rng.choice([15, 9, 14, 11, 0, 3])
+        e, ic, rc = rng.choice([0.1, 0.2]), rng.choice([1, 2, 100000]), rng.random() < 0.5
+        wr, wq = (rng.random() < 0.2, rng.random() < 0.2) if not rc else (False, False)
+        top = rng.choice([30, 150, 255, 319 if flags & 8 else 255])
+        m, n = rng.randint(0, top), rng.randint(0, top)
+        frag = _cases.rseq(rng, m + n + 1)
+        ref, q = frag[:m], _cases.mutate(rng, frag[rng.randint(0, m):][:n], 0.05)[:n]
+        pa = PairAligner(e, flags, wr, wq, 3, ic, revcomp_ref=rc)
+        assert pa.locate(reverse_complement(ref) if rc else ref, q) == oracle.locate(ref, q, e, flags, wr, wq, 3, ic), (ref, q, flags, e, ic, rc)

@@ -34,12 +34,14 @@ al = Aligner(synth.TRUSEQ_34, 0.1, 14, False, False, 3, 1)
 ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2)
 pa = PairAligner(0.2, 15, revcomp_ref=True)
 ad = Adapter(synth.TRUSEQ_34, BACK, 0.1, 3)
+rc2 = reverse_complement(r2[2])
 out = {"Aligner.locate": timed(lambda: al.locate(c2[3])),
        "compare_prefixes": timed(lambda: compare_prefixes(synth.TRUSEQ_34, c2[5])),
        "InsertAligner.match_insert": timed(lambda: ia.match_insert(r1[2], r2[2])),
        "PairAligner.locate": timed(lambda: pa.locate(r2[4], r1[4])),
        "Adapter.match_to": timed(lambda: ad.match_to(c2[7]))}
+out["Aligner(150-base ref).locate, built per call (MergeOverlapping)"] = timed(lambda: Aligner(rc2, 0.2, 15).locate(r1[2]), 100)
+out["Aligner(34-base ref) built per call + locate"] = timed(lambda: Aligner(synth.TRUSEQ_34, 0.1, 14).locate(c2[3]), 100)
 ma = MultiAligner(0.2, 9, 1)
-rc2 = reverse_complement(r2[2])
 out["MultiAligner.locate (2 x 150 bp, flags 9)"] = timed(lambda: ma.locate(rc2, r1[2]), 50)
 print(json.dumps(out))
