@@ -4,14 +4,14 @@ oracle/align_oracle.c on random cases -- the filtered pipeline (all adapter type
 pre-pass, equal-length batches with partial overlaps), the full sweep over all 16 flag sets and the wavefront-per-read
 kernel (every batch goes through all three families and the automatic choice), the pair aligner (sides of up to 320
 bases: full sweep, cost / threat / band pipeline with and without `need`, wavefront per pair), the insert aligner
-(reads of up to 320 bases, probed sweep), the fused linked-adapter
+(reads of up to 320 bases, probed sweep), MultiAligner (a wavefront per pair), the fused linked-adapter
 pipeline, the plane-guided error correction and ragged batches at wave-filling size (tail-mode window sweep).
 usage: tools/gpu_fuzz.py [first_seed] [seeds]   (the log of the round's last run is kept under profiles/)"""
 import sys, time
 sys.path.insert(0, '.')
 from atropos_amd import _lib
 _lib.set_backend(_lib.HipBackend(0))
-from atropos_amd.align import Aligner, PairAligner, InsertAligner
+from atropos_amd.align import Aligner, PairAligner, InsertAligner, MultiAligner
 from oracle import oracle
 from tests import _cases
 t0 = time.time()
@@ -31,6 +31,7 @@ for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
     tot += _cases.check_pairs_against_oracle(PairAligner, oracle, _lib.AtroposHipError, seed + 400, 150)
     tot += _cases.check_pairs_fast(PairAligner, oracle, seed + 450, 12, top=rng_top(seed), npairs=96)
     tot += _cases.check_insert_batches_against_oracle(InsertAligner, oracle, seed + 500, 60)
+    tot += _cases.check_multi_against_oracle(MultiAligner, oracle, seed + 550, 40)
     tot += _cases.check_linked_sets_against_oracle(oracle, seed + 600, 150, reads_per_round=(1, 64, 65, 200, 700))[0]
     tot += _cases.check_plane_guided_correction(n=20_000, seed=seed + 700)
     tot += _cases.check_ragged_tail_mode(Aligner, oracle, seed + 800, nreads=40_000, oracle_slice=600)
