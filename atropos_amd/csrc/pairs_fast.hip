@@ -198,7 +198,7 @@ void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFast
     const long long first = (long long)wk.fw.binbase[cls * PF_ROW_BINS], total = (long long)wk.fw.binbase[(cls + 1) * PF_ROW_BINS];
     const long long nwaves = (total - first + 63) >> 6;
     const bool sq = (fp.pp.flags & ATR_START_WITHIN_SEQ2) != 0;
-    const int rndw = a.ref_chunks * 4;
+    const int rndw = a.ref_chunks * 4, qndw = a.qry_chunks * 4;
     for (long long wv = (long long)blockIdx.x * 2 + wave; wv < nwaves; wv += (long long)gridDim.x * 2) {
         const long long slot = first + wv * 64 + lane;
         const bool live = slot < total;
