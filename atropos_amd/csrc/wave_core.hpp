@@ -20,9 +20,9 @@
 // by lane m in column order, the last column by a wave reduction that prefers the smallest row among equal
 // keys (the reference scans it in ascending rows and keeps the first on ties).  A single wave issues one
 // instruction every few cycles whatever its kind, so the sweep is split: the steps in which every row is
-// active (m < t <= span) run without the per-lane activity test, four per trip, with one look at lane m's
-// four cells per trip.  The query codes sit in LDS, one dword per column (a byte would cost a
-// zero-extension per use); every lane fetches the codes of its next four columns one trip ahead.
+// active (m < t <= span) run without the per-lane activity test, eight per trip (four with more than one row per
+// lane), with one look at lane m's cells per trip.  The query codes sit in LDS, one dword per column (a byte would
+// cost a zero-extension per use); every lane fetches the codes of its next columns half a trip ahead.
 #ifndef ATR_WAVE_CORE_HPP
 #define ATR_WAVE_CORE_HPP
 
