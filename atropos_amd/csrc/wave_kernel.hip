@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void locate_wave_kernel(const WaveParams wp, co
     const int lane = threadIdx.x;
     const long long r = blockIdx.x;
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
-    const int n = __builtin_amdgcn_readfirstlane(lens ? lens[r] : max_len);
+    const int n = __builtin_amdgcn_readfirstlane(lens ? min(max(lens[r], 0), max_len) : max_len);    // (never beyond the layout)
     const WaveWindow win = wave_window<XREP>(u, n);
 
     // thresholds and the read's codes (one dword per column) into LDS
