@@ -5,6 +5,7 @@
 namespace atr {
 
 constexpr long long FAST_SERIAL_READS = 65536;       // "short batch": no side stream, a wave per few tasks
+constexpr long long FAST_SERIAL_READS_LINKED = 64;   // the same for the adapters of a linked set (their launches would overlap)
 
 window_launcher window_group_0(int), window_group_1(int), window_group_2(int), window_group_3(int);
 
@@ -74,7 +75,7 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
     hipError_t e = hipSuccess;
     // a short batch (the <= 1000 reads the unchanged trim command hands over per call) leaves most of the chip
     // idle anyway: the fork / join events would cost more than the overlap gives, both DP kernels go to `st`
-    const bool serial = count == 1 && nreads <= FAST_SERIAL_READS;
+    const bool serial = nreads <= (count == 1 ? FAST_SERIAL_READS : FAST_SERIAL_READS_LINKED);
     if (serial) {
         const BandParams bp = band_params(a);
         const dim3 bgrid((unsigned)std::max<long long>(1, std::min<long long>((nreads + 3) / 4, 4096)));

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
     uint32_t *ns = &s_stream[wave][0][lane];
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
-    block_tiles(ntiles, t0, t1);
+    block_tiles(ntiles, t0, t1, wk.nused);
     for (long long tile_first = t0 + wave; tile_first < t1; tile_first += 4 * LINKED_ROUND) {
         const int slots = (int)min((long long)LINKED_ROUND, (t1 - tile_first + 3) / 4);
         // ---- 5' parts of up to LINKED_ROUND tiles: literal compare, exact-piece test, DP tasks ------------
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
-    block_tiles(ntiles, t0, t1);
+    block_tiles(ntiles, t0, t1, wk.nused);
     for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
         const uint32_t ww = wk.win[r];
         if (window_valid(ww)) {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
 template <bool WIDE, bool RAGGED>
 static void launch_l1(bool and_mode, const LinkedBlob *blob, const uint4 *packed, const int32_t *lens, long long nreads,
                       int nchunks, int max_len, uint16_t *which, uint4 *front, uint4 *back, FastWork wk, hipStream_t st) {
-    const dim3 grid(FAST_BLOCKS), block(256);
+    const dim3 grid(wk.nused), block(256);
     if (and_mode) hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, true>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk);
     else          hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, false>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk);
 }
@@ -306,6 +306,8 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     hipStream_t st = (hipStream_t)stream;
     const int nchunks = (max_len + 31) / 32;
     FastWork wk = fast_carve(d_work, nreads, s->p.n * FILTER_BINS);
+    wk.nused = fast_blocks_for((nreads + 63) / 64);                // a short batch: only the blocks it fills (and their histogram rows)
+    wk.lpw = nreads <= 8192 ? 0 : 64;
     const LinkedBlob *blob = (const LinkedBlob *)s->d_params;
     const bool ragged = d_lens != nullptr, and_mode = s->p.and_mode != 0;
     uint16_t *which = (uint16_t *)d_which;
@@ -323,7 +325,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     launch_fast_scan(wk, st);
     LinkedLens ms;
     for (int a = 0; a < LINKED_MAX; ++a) ms.m[a] = a < s->p.n ? s->p.b[a].m : 0;
-    hipLaunchKernelGGL(linked_scatter_kernel, dim3(FAST_BLOCKS), dim3(256), 0, st, (long long)nreads, ms, ragged ? 0 : 1,
+    hipLaunchKernelGGL(linked_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, (long long)nreads, ms, ragged ? 0 : 1,
                        (const uint16_t *)which, wk);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "linked scatter launch");
