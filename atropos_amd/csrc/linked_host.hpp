@@ -17,6 +17,7 @@ struct atr_linked_set {
     atr_aligner back[atr::LINKED_MAX];            // copies of the 3' aligners
     int table_kind;
     void *d_params;                               // device copy of {p, rmp} (HIP build only)
+    void *d_wave;                                 // device copy of the 3' aligners' LocateParams + LinkedPost (linked_wave_kernel)
 };
 
 namespace atr {

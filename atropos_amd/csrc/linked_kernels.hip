@@ -18,6 +18,7 @@
 #include "atropos_hip.h"
 #include "linked_host.hpp"
 #include "locate_fast.hpp"
+#include "wave_sweep.hpp"
 
 namespace atr {
 
@@ -232,6 +233,57 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
     for (int b = threadIdx.x; b < nbins; b += 256) wk.counts[(size_t)blockIdx.x * nbins + b] = s_hist[b];
 }
 
+// Short batches: the 3' part of every read the pre-pass left open on a wavefront of its own (wave_sweep.hpp) -- the
+// aligner of the read's own adapter on read[front.rstop:], exactly the reference's second match_to -- instead of
+// counting sort + four band and four window launches whose single lanes run for 17 - 34 us each.
+struct LinkedWaveBlob {
+    LocateParams p[LINKED_MAX];
+    LinkedPost post[LINKED_MAX];
+};
+constexpr long long LINKED_WAVE_MAX_READS = 262144;
+
+template <int R>
+__global__ __launch_bounds__(64) void linked_wave_kernel(const LinkedWaveBlob *__restrict__ blob, const uint4 *__restrict__ packed,
+                                                         const int32_t *__restrict__ lens, long long nreads, int nchunks,
+                                                         int max_len, const uint16_t *__restrict__ which_out,
+                                                         const uint4 *__restrict__ front, uint4 *__restrict__ back_out,
+                                                         const uint32_t *__restrict__ win) {
+    __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
+    __shared__ __attribute__((aligned(16))) uint32_t s_code[WAVE_CODE_PAD + (ATR_MAX_READ_LEN + 31) / 32 * 32 + 2 * WAVE_CODE_PAD];
+    const int lane = threadIdx.x;
+    const long long r = blockIdx.x;
+    if (!window_valid(win[r])) return;                               // resolved by the pre-pass (whole wave)
+    const int which = __builtin_amdgcn_readfirstlane((int)(which_out[r] & 0xFFu));
+    const int s = __builtin_amdgcn_readfirstlane((int)(front[r].y >> 16));
+    const int n = __builtin_amdgcn_readfirstlane(lens ? min(max(lens[r], 0), max_len) : max_len);
+    const LocateParams &p = blob->p[which];
+    const LinkedPost &post = blob->post[which];
+    for (int i = lane; i <= p.m + 1; i += 64) s_thr[i] = p.thr[i];
+    if (lane < (n + 31) / 32) {
+        const uint4 v = packed[((size_t)(r >> 6) * nchunks + lane) * 64 + (size_t)(r & 63)];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint4 *dst = (uint4 *)(s_code + WAVE_CODE_PAD + 32 * lane);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            dst[2 * d] = make_uint4(w[d] & 15u, (w[d] >> 4) & 15u, (w[d] >> 8) & 15u, (w[d] >> 12) & 15u);
+            dst[2 * d + 1] = make_uint4((w[d] >> 16) & 15u, (w[d] >> 20) & 15u, (w[d] >> 24) & 15u, w[d] >> 28);
+        }
+    }
+    uint32_t rec[4];
+    wave_locate<true, true, R>(p, s_thr, s_code + WAVE_CODE_PAD + s, max(0, n - s), lane, rec);     // regular 3' adapters: flags 14
+    if (lane == 0) {
+        if (rec_found(rec)) {                                        // Adapter.match_to's own test (adapters/__init__.py:386-398)
+            const int refstart = (int)(rec[0] & 0xFFFFu), refstop = (int)(rec[0] >> 16);
+            if (!linked_accept(refstop - refstart, (int)(rec[2] & 0xFFFFu), (int)(rec[2] >> 16), post.m, post.min_overlap,
+                               post.pf_thr, post.accept_full != 0, post.rmp, post.rmp_ld, post.max_rmp))
+                rec_none(rec);
+        } else {
+            rec_none(rec);
+        }
+        back_out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    }
+}
+
 struct LinkedLens { int m[LINKED_MAX]; };
 
 __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, const LinkedLens ms, int by_rows,
@@ -280,12 +332,30 @@ int atr_linked_create(const atr_linked_adapter *adapters, int n_adapters, atr_li
     if (e != hipSuccess) { delete s; return e == hipErrorOutOfMemory ? ATR_ERR_NOMEM : hip_fail(e, "hipMalloc(linked set)"); }
     e = hipMemcpy(s->d_params, &blob, sizeof(LinkedBlob), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(s->d_params); delete s; return hip_fail(e, "hipMemcpy(linked set)"); }
+    {   // the 3' aligners as the wavefront-per-read kernel wants them
+        LinkedWaveBlob *hb = new (std::nothrow) LinkedWaveBlob();
+        s->d_wave = nullptr;
+        if (hb) {
+            for (int a = 0; a < LINKED_MAX; ++a) { hb->p[a] = s->back[a < s->p.n ? a : 0].p; hb->post[a] = s->post[a < s->p.n ? a : 0]; }
+            if (hipMalloc(&s->d_wave, sizeof(LinkedWaveBlob)) == hipSuccess) {
+                if (hipMemcpy(s->d_wave, hb, sizeof(LinkedWaveBlob), hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipFree(s->d_wave);
+                    s->d_wave = nullptr;
+                }
+            } else {
+                s->d_wave = nullptr;
+                (void)hipGetLastError();
+            }
+            delete hb;
+        }
+    }
     *out = s;
     return ATR_OK;
 }
 
 void atr_linked_destroy(atr_linked_set *s) {
     if (!s) return;
+    if (s->d_wave) (void)hipFree(s->d_wave);
     if (s->d_params) (void)hipFree(s->d_params);
     delete s;
 }
@@ -322,6 +392,25 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "linked_filter_kernel launch");
+    {   // short batch: the open 3' parts on a wavefront each, no sort, no band / window launches
+        bool regular = s->d_wave != nullptr && nreads <= LINKED_WAVE_MAX_READS;
+        int mmax = 0;
+        for (int a = 0; a < s->p.n; ++a) {
+            regular = regular && s->back[a].flags == (ATR_START_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ1);
+            mmax = std::max(mmax, s->back[a].p.m);
+        }
+        if (regular) {
+            const LinkedWaveBlob *wb = (const LinkedWaveBlob *)s->d_wave;
+            const dim3 grid((unsigned)nreads), block(64);
+            switch (wave_pair_rows(mmax)) {
+                case 1: hipLaunchKernelGGL(linked_wave_kernel<1>, grid, block, 0, st, wb, packed, d_lens, (long long)nreads, nchunks, max_len, (const uint16_t *)which, (const uint4 *)front, back, (const uint32_t *)wk.win); break;
+                case 2: hipLaunchKernelGGL(linked_wave_kernel<2>, grid, block, 0, st, wb, packed, d_lens, (long long)nreads, nchunks, max_len, (const uint16_t *)which, (const uint4 *)front, back, (const uint32_t *)wk.win); break;
+                default: hipLaunchKernelGGL(linked_wave_kernel<3>, grid, block, 0, st, wb, packed, d_lens, (long long)nreads, nchunks, max_len, (const uint16_t *)which, (const uint4 *)front, back, (const uint32_t *)wk.win); break;
+            }
+            e = hipGetLastError();
+            return e == hipSuccess ? ATR_OK : hip_fail(e, "linked_wave_kernel launch");
+        }
+    }
     launch_fast_scan(wk, st);
     LinkedLens ms;
     for (int a = 0; a < LINKED_MAX; ++a) ms.m[a] = a < s->p.n ? s->p.b[a].m : 0;
