@@ -18,6 +18,7 @@
 
 #include "atropos_hip.h"
 #include "locate_fast.hpp"
+#include "side_stream.hpp"
 #include "pairs_fast_core.hpp"
 
 namespace atr {
@@ -303,15 +304,31 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
                            myers_waves(rmax <= 160 ? 5 : rmax <= 256 ? 8 : 10), wk);
         e = hipGetLastError();
     }
-    // one launch per band class (which classes hold tasks is only known on the device; an empty class returns at once)
-    if (e == hipSuccess) e = launch_band<16>(fp, a, wk, 0, st);
-    if (e == hipSuccess) e = launch_band<32>(fp, a, wk, 1, st);
-    if (e == hipSuccess) e = launch_band<48>(fp, a, wk, 2, st);
-    if (e == hipSuccess) e = launch_band<64>(fp, a, wk, 3, st);
-    if (e == hipSuccess) e = launch_band<80>(fp, a, wk, 4, st);
-    if (e == hipSuccess) e = launch_band<96>(fp, a, wk, 5, st);
-    if (e == hipSuccess) e = launch_band<112>(fp, a, wk, 6, st);
-    if (e == hipSuccess) e = launch_band<128>(fp, a, wk, 7, st);
+    // One launch per band class (which classes hold tasks is only known on the device; an empty class returns at once),
+    // each on a stream of its own forked off `st` behind the scatter pass and joined again before the workspace goes:
+    // the classes work on disjoint tasks, and a class with few tasks is a handful of waves whose single lanes run
+    // for 0.1 - 0.3 ms -- back to back that was 1.2 ms of latency per call whatever the batch held.
+    static thread_local SideStream side[PF_CLASSES];
+    bool forked = false;
+    if (e == hipSuccess) {
+        forked = true;
+        for (int c = 0; c < PF_CLASSES && forked; ++c) forked = side[c].ready();
+        if (forked) {
+            e = hipEventRecord(side[0].fork, st);
+            for (int c = 0; c < PF_CLASSES && e == hipSuccess; ++c) e = hipStreamWaitEvent(side[c].stream, side[0].fork, 0);
+        }
+    }
+#define ATR_PF_BAND(WB, C) if (e == hipSuccess) e = launch_band<WB>(fp, a, wk, C, forked ? side[C].stream : st)
+    ATR_PF_BAND(16, 0); ATR_PF_BAND(32, 1); ATR_PF_BAND(48, 2); ATR_PF_BAND(64, 3);
+    ATR_PF_BAND(80, 4); ATR_PF_BAND(96, 5); ATR_PF_BAND(112, 6); ATR_PF_BAND(128, 7);
+#undef ATR_PF_BAND
+    if (forked) {                                                    // join whatever was launched (also after an error)
+        for (int c = 0; c < PF_CLASSES; ++c) {
+            hipError_t j = hipEventRecord(side[c].join, side[c].stream);
+            if (j == hipSuccess) j = hipStreamWaitEvent(st, side[c].join, 0);
+            if (e == hipSuccess) e = j;
+        }
+    }
     if (e == hipSuccess)
         e = launch_pairs_full_indexed(p, rp, rl, rmax, revcomp, qp, ql, qmax, npairs, out, wk.order, wk.fw.binbase + PF_FALLBACK_BIN, st);
     const hipError_t freed = hipFreeAsync(work, st);
