@@ -268,9 +268,6 @@ extern "C" int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const in
     if (npairs == 0) return ATR_OK;
     if (!d_out || (ref_max_len > 0 && !d_ref_packed) || (query_max_len > 0 && !d_query_packed)) return ATR_ERR_INVALID;
     const uint32_t *rp = (const uint32_t *)d_ref_packed, *qp = (const uint32_t *)d_query_packed;
-    // Reads of more than 160 bases without a caller's bound on the matches: their bands (2 k + 1 diagonals on either
-    // side of the overlap's end, k = 50 at 250 bases) cost as much as the whole matrix -- measured 66 M pairs/s
-    // against 76 M on 2 x 250 bp -- so they keep the full sweep; with d_need most pairs end after the cost pass.
     if (path == ATR_PAIRS_WAVE && !wave_pairs_applies(ref_max_len, 0)) return ATR_ERR_UNSUPPORTED;
     if (path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && wave_pairs_applies(ref_max_len, (long long)npairs))) {
         // short batch: a wavefront per pair (pairs_wave.hip); a lane per pair is one chain of m x n dependent cells
@@ -278,9 +275,13 @@ extern "C" int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const in
                                                nullptr, nullptr, (long long)npairs, (uint4 *)d_out, (hipStream_t)stream);
         return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_wave_kernel launch");
     }
-    // ... and a batch below a quarter of a million pairs: the pipeline's dozen launches cost 1.2 ms (2 x 150 bp) whatever
-    // the batch holds, the full sweep 0.36 ms up to 64 k pairs (tools/micro/small_pairs.py)
-    const bool worth = path == ATR_PAIRS_FAST || ((ref_max_len <= 160 || d_need != nullptr) && npairs >= PAIRS_FAST_MIN_PAIRS);
+    // The cost / threat / band pipeline from a quarter of a million pairs on: its launches cost 0.65 ms (2 x 150 bp; the
+    // latency of single lanes) whatever the batch holds, the full sweep 5.5 ns per pair with a floor of 0.36 ms
+    // (tools/micro/small_pairs.py, pairs_fixed_cost.py).  Reads of more than 160 bases have bands almost as wide as the
+    // matrix (2 k + 1 diagonals on either side of the overlap's end, k = 50 at 250 bases): 82 M against 75 M pairs/s on
+    // 500 k pairs 2 x 250 bp, so they need more pairs to pay -- unless d_need ends most pairs after the cost pass.
+    const long long fast_min = (ref_max_len <= 160 || d_need != nullptr) ? PAIRS_FAST_MIN_PAIRS : 3 * PAIRS_FAST_MIN_PAIRS / 2;
+    const bool worth = path == ATR_PAIRS_FAST || npairs >= fast_min;
     if (path != ATR_PAIRS_FULL && worth && pairs_fast_applies(max_error_rate, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, query_max_len) &&
         npairs < (1ll << 32)) {
         // costs by bit-vector, threats, banded payload (pairs_fast_core.hpp); pairs outside its envelope take the

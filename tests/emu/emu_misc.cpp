@@ -403,7 +403,8 @@ int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_l
     if (path < ATR_PAIRS_AUTO || path > ATR_PAIRS_WAVE) return ATR_ERR_INVALID;
     if (path == ATR_PAIRS_WAVE && !atr::wave_pairs_applies(ref_max_len, 0)) return ATR_ERR_UNSUPPORTED;
     const bool wave = path == ATR_PAIRS_WAVE || (path == ATR_PAIRS_AUTO && atr::wave_pairs_applies(ref_max_len, npairs));
-    const bool worth = path == ATR_PAIRS_FAST || ((ref_max_len <= 160 || need != nullptr) && npairs >= atr::PAIRS_FAST_MIN_PAIRS);   // as the library
+    const long long fast_min = (ref_max_len <= 160 || need != nullptr) ? atr::PAIRS_FAST_MIN_PAIRS : 3 * atr::PAIRS_FAST_MIN_PAIRS / 2;
+    const bool worth = path == ATR_PAIRS_FAST || npairs >= fast_min;                           // as the library
     const bool fast = !wave && path != ATR_PAIRS_FULL && (path == ATR_PAIRS_FAST || emu_pairs_fast) && worth &&
                       atr::pairs_fast_applies(e, flags, wildcard_ref, wildcard_query, indel_cost, ref_max_len, qry_max_len);
     static atr::PairFastParams fp;
