@@ -190,8 +190,23 @@ class Adapter(object):
     def match_to(self, read):
         """Attempt to match this adapter to the given read; returns a Match, or None if the
         criteria (minimum overlap, maximum error rate, random-match probability) are not met.
-        A batch of one (``match_to_batch``)."""
-        return self.match_to_batch([read])[0]
+        The rules of ``match_to_batch`` on one alignment (``Aligner.locate``: one library call); the rarer modes -- plain
+        prefix / suffix compare, read wildcards with a literal adapter -- are a batch of one."""
+        if self._plain_compare or (not self.adapter_wildcards and self.read_wildcards):
+            return self.match_to_batch([read])[0]
+        hit = self.aligner.locate(_seq_of(read).upper())
+        if hit is None:
+            return None
+        astart, astop, rstart, rstop, matches, errors = hit
+        m, size = len(self.sequence), astop - astart
+        ok = size >= self.min_overlap and size > 0 and errors / size <= self.max_error_rate       # :386-398
+        if ok and self.max_rmp is not None:
+            ok = bool(self._rmp_by_size()[min(max(size, 0), m), min(max(matches, 0), m)] <= self.max_rmp)
+        if not ok and not self.adapter_wildcards and matches == m and errors == 0:
+            ok = True                                 # the literal shortcut: a full-length exact occurrence bypasses the filters (:351-367)
+        if not ok:
+            return None
+        return Match(astart, astop, rstart, rstop, matches, errors, self._front_flag, self, None if isinstance(read, str) else read)
 
     def _rmp_by_size(self):
         if self._rmp_cache is None:
