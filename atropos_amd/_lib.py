@@ -105,6 +105,7 @@ PROTOTYPES = {
                                    C.c_void_p, C.c_void_p]),
     "atr_locate_ascii_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_one": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_insert_match_one": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_multi_locate_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_compare_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -463,6 +464,17 @@ class HipBackend(object):
                                                           min_overlap, indel_cost, C.addressof(rec), self._stream()),
                    "atr_locate_pair_one")
         return None if rec[1] < 0 else (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
+
+    def insert_match_one(self, h, seq1, seq2):
+        """``InsertAligner.match_insert`` of ONE pair of byte strings (upper-case IUPAC letters only: the caller checks);
+        the three records as a flat list of 24 int16 values (atr_insert_match_one)."""
+        rec = getattr(self, "_ins_rec", None)
+        if rec is None:
+            rec = self._ins_rec = (C.c_int16 * 24)()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_insert_match_one(h, seq1, len(seq1), seq2, len(seq2), C.addressof(rec), self._stream()),
+                   "atr_insert_match_one")
+        return rec
 
     def locate_ascii_batch(self, h, ascii_2d, lens, max_len):
         """atr_locate_ascii_batch: a short batch of ASCII rows (uint8 [n, width] on the device, row stride a multiple of

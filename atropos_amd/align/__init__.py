@@ -801,6 +801,17 @@ class InsertAligner(object):
         seq1.encode('ascii')
         for base in reversed(seq2[:n]):           # reverse_complement(seq2): KeyError on unknown bases
             BASE_COMPLEMENTS[base]
+        be = self._backend
+        if hasattr(be, "insert_match_one") and max(len(seq1), len(seq2)) <= _lib.INSERT_MAX_READ:
+            table = be.translate_table(_lib.TABLE_DNA15)
+            b1, b2 = seq1.encode('ascii'), seq2.encode('ascii')
+            if b"\0" not in b1.translate(table) and b"\0" not in b2.translate(table):      # upper-case IUPAC letters only
+                rec = be.insert_match_one(self._handle, b1, b2)
+                if rec[1] < 0:
+                    return None
+                ms = [None if rec[8 * t + 1] < 0 else Match(*rec[8 * t:8 * t + 6]) for t in (1, 2)]
+                return (tuple(rec[0:6]), ms[0], ms[1])
+            # (soft-masked reads and uncoded characters: the batch path sorts those out)
         return self.match_insert_batch([seq1], [seq2]).results()[0]
 
 

@@ -372,6 +372,57 @@ int atr_compare_one(const char *ref, int m, const char *query, int n, int wildca
     return ATR_OK;
 }
 
+// InsertAligner.match_insert(seq1, seq2) for ONE pair in host memory (align/__init__.py:250-377): both reads -- upper-case
+// IUPAC letters only, the caller checks -- go through the staging buffer, are packed to bit planes and matched; three
+// launches, one synchronisation.  out: the three records of atr_insert_match_batch.
+struct InsertShot {
+    uint8_t *packed = nullptr;                // two plane64 batches of one pair (device memory)
+    size_t half = 0;
+    int device = -1;
+    bool ready() {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) return false;
+        if (packed && cur == device) return true;
+        if (packed) { (void)hipFree(packed); packed = nullptr; }
+        half = atr_packed_bytes(1, ATR_INSERT_MAX_READ);
+        if (hipMalloc((void **)&packed, 2 * half) != hipSuccess) { packed = nullptr; return false; }
+        device = cur;
+        return true;
+    }
+};
+
+int atr_insert_match_one(const atr_insert_aligner *a, const char *seq1, int n1, const char *seq2, int n2, atr_result *out,
+                         void *stream) {
+    if (!a || n1 < 0 || n2 < 0 || (n1 > 0 && !seq1) || (n2 > 0 && !seq2) || !out) return ATR_ERR_INVALID;
+    if (n1 > ATR_INSERT_MAX_READ || n2 > ATR_INSERT_MAX_READ) return ATR_ERR_UNSUPPORTED;
+    static_assert(ATR_INSERT_MAX_READ <= 512, "staging layout of atr_insert_match_one");
+    OneShot &shot = one_shot();
+    static thread_local InsertShot dev;
+    if (!shot.ready(64 + 2 * 512) || !dev.ready()) return hip_fail(hipErrorOutOfMemory, "staging of atr_insert_match_one");
+    // layout: [records: 48 B][lens: 2 x int32, pad to 64][read 1: 512][read 2: 512]
+    int32_t *lens = (int32_t *)(shot.base + 48);
+    lens[0] = n1; lens[1] = n2;
+    memcpy(shot.base + 64, seq1, (size_t)n1);
+    memcpy(shot.base + 64 + 512, seq2, (size_t)n2);
+    const int max_len = n1 > n2 ? n1 : n2;
+    const Tables &T = tables();
+    int rc = ATR_OK;
+    if (max_len > 0) {
+        rc = pack_launch<true>(shot.dev + 64, 512, (const int32_t *)(shot.dev + 48), nullptr, 1, max_len, T.dna15, dev.packed, nullptr, stream);
+        if (rc == ATR_OK)
+            rc = pack_launch<true>(shot.dev + 64 + 512, 512, (const int32_t *)(shot.dev + 52), nullptr, 1, max_len, T.dna15, dev.packed + dev.half,
+                                   nullptr, stream);
+        if (rc != ATR_OK) return rc;
+    }
+    rc = atr_insert_match_batch(a, dev.packed, (const int32_t *)(shot.dev + 48), dev.packed + dev.half, (const int32_t *)(shot.dev + 52), 1,
+                                max_len, (atr_result *)shot.dev, stream);
+    if (rc != ATR_OK) return rc;
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+    memcpy(out, shot.base, 48);
+    return ATR_OK;
+}
+
 int atr_insert_aligner_create(const atr_insert_config *cfg, atr_insert_aligner **out) {
     if (!out) return ATR_ERR_INVALID;
     *out = nullptr;

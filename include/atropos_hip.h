@@ -290,6 +290,12 @@ int atr_insert_match_batch_coded(const atr_insert_aligner *a, const uint8_t *d_p
                                  const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
                                  int read_codes, atr_result *d_out, void *stream);
 
+/* InsertAligner.match_insert(seq1, seq2) for ONE pair of reads in host memory, synchronously (the per-pair call of
+ * InsertAdapterCutter.__call__, commands/trim/modifiers.py:381-390): n1 / n2 upper-case IUPAC letters each (the caller
+ * checks; soft-masked reads take atr_insert_match_batch_coded).  out: the three records of atr_insert_match_batch. */
+int atr_insert_match_one(const atr_insert_aligner *a, const char *seq1, int n1, const char *seq2, int n2, atr_result *out,
+                         void *stream);
+
 /* ---- MultiAligner.locate, compare_prefixes / compare_suffixes (general) --- */
 
 /* Aligner.enable_debug() / .dpmatrix (_align.pyx:88-119, :259-264, :354-357, :428-431): the DP matrix of
