@@ -31,7 +31,7 @@ struct PairsFastWork {
     FastWork fw;                                    // counts / chunks / binbase (nbins = PF_BINS); win, mask, order unused
     uint4 *tasks;                                   // [npairs] PairTask per pair (P1)
     uint4 *order;                                   // [npairs] tasks by bin (P3)
-    uint16_t *bins;                                 // [npairs] scatter bin, 0xFFFF: resolved in P1
+    uint8_t *bins;                                  // [npairs] scatter bin, 0xFF: resolved in P1
 };
 
 struct PairsFastArgs {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
         if (live) {
             if (D.kind == 0) {
                 a.out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);
-                wk.bins[r] = 0xFFFFu;
+                wk.bins[r] = 0xFFu;
             } else {
                 const int bin = pf_task_bin(D);
                 if (D.kind != 1) {
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
                 wk.tasks[r] = make_uint4(D.task.pair, (uint32_t)(uint16_t)D.task.d_lo | ((uint32_t)(uint16_t)D.task.row_first << 16),
                                          (uint32_t)(uint16_t)D.task.row_last | ((uint32_t)(uint16_t)D.task.mlb << 16),
                                          (uint32_t)(uint16_t)D.task.cand_first);
-                wk.bins[r] = (uint16_t)bin;
+                wk.bins[r] = (uint8_t)bin;
                 atomicAdd(&s_hist[bin], 1u);
             }
         }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
 // ---- P3 ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pairs_scatter_kernel(long long npairs, int p1_waves, PairsFastWork wk) {
     __shared__ uint32_t s_cur[PF_BINS];
-    for (int b = threadIdx.x; b < PF_BINS; b += 256) s_cur[b] = fast_slot0(wk.fw, b);
+    if (threadIdx.x < PF_BINS) s_cur[threadIdx.x] = fast_slot0(wk.fw, threadIdx.x);
     __syncthreads();
     const long long ntiles = (npairs + 63) >> 6;
     long long t0, t1;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(long long npairs, in
     const long long rend = min(npairs, t1 * 64);
     for (long long r = t0 * 64 + threadIdx.x; r < rend; r += 256) {
         const uint32_t bin = wk.bins[r];
-        if (bin != 0xFFFFu) wk.order[atomicAdd(&s_cur[bin], 1u)] = wk.tasks[r];
+        if (bin != 0xFFu) wk.order[atomicAdd(&s_cur[bin], 1u)] = wk.tasks[r];
     }
 }
 
@@ -227,7 +227,7 @@ void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFast
 }
 
 size_t pairs_fast_work_bytes(long long npairs) {
-    return (size_t)npairs * 34 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * PF_BINS * 4 + (size_t)(PF_BINS + 1) * 4 + 1024;
+    return (size_t)npairs * 33 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * PF_BINS * 4 + (size_t)(PF_BINS + 1) * 4 + 1024;
 }
 
 static PairsFastWork pairs_fast_carve(void *work, long long npairs) {
@@ -242,7 +242,7 @@ static PairsFastWork pairs_fast_carve(void *work, long long npairs) {
     w.fw.total = w.fw.binbase + PF_BINS + 1;
     w.fw.nbins = PF_BINS;
     w.fw.nused = FAST_BLOCKS;
-    w.bins = (uint16_t *)(w.fw.total + 4);
+    w.bins = (uint8_t *)(w.fw.total + 4);
     return w;
 }
 
@@ -319,10 +319,8 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
         }
     }
 #define ATR_PF_BAND(WB, C) if (e == hipSuccess) e = launch_band<WB>(fp, a, wk, C, forked ? side[C].stream : st)
-    ATR_PF_BAND(8, 0);   ATR_PF_BAND(16, 1);   ATR_PF_BAND(24, 2);   ATR_PF_BAND(32, 3);
-    ATR_PF_BAND(40, 4);  ATR_PF_BAND(48, 5);   ATR_PF_BAND(56, 6);   ATR_PF_BAND(64, 7);
-    ATR_PF_BAND(72, 8);  ATR_PF_BAND(80, 9);   ATR_PF_BAND(88, 10);  ATR_PF_BAND(96, 11);
-    ATR_PF_BAND(104, 12); ATR_PF_BAND(112, 13); ATR_PF_BAND(120, 14); ATR_PF_BAND(128, 15);
+    ATR_PF_BAND(16, 0); ATR_PF_BAND(32, 1); ATR_PF_BAND(48, 2); ATR_PF_BAND(64, 3);
+    ATR_PF_BAND(80, 4); ATR_PF_BAND(96, 5); ATR_PF_BAND(112, 6); ATR_PF_BAND(128, 7);
 #undef ATR_PF_BAND
     if (forked) {                                                    // join whatever was launched (also after an error)
         for (int c = 0; c < PF_CLASSES; ++c) {

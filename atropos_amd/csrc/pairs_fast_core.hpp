@@ -43,15 +43,15 @@
 namespace atr {
 
 constexpr long long PAIRS_FAST_MIN_PAIRS = 262144;      // below: the full sweep (the pipeline's fixed cost, pairs_kernel.hip)
-constexpr int PF_CLASSES = 16;                      // band widths 8, 16, .. 128 cells
-constexpr int PF_MAX_W = 8 * PF_CLASSES;
+constexpr int PF_CLASSES = 8;                       // band widths 16, 32, .. 128 cells
+constexpr int PF_MAX_W = 16 * PF_CLASSES;
 constexpr int PF_ROW_BINS = 28;                     // (rows swept) / 12, clamped
 constexpr int PF_ROW_BIN_SHIFT = 12;
 constexpr int PF_FALLBACK_BIN = PF_CLASSES * PF_ROW_BINS;        // pairs for the full sweep
-constexpr int PF_BINS = 512;                        // histogram width (a multiple of 256 for the scan kernels)
+constexpr int PF_BINS = 256;                        // histogram width (a multiple of 256 for the scan kernels)
 constexpr int PF_MAX_K = 126;                       // costs live in 7 bits of the row-m byte
 constexpr int PF_TAB_ROWS = 5;                      // match masks by pf_code_row: A C G T N
-ATR_DEV int pf_class_width(int cls) { return 8 * (cls + 1); }
+ATR_DEV int pf_class_width(int cls) { return 16 * (cls + 1); }
 
 struct PairFastParams {
     PairParams pp;
@@ -329,7 +329,7 @@ ATR_DEV void pf_analyse(const uint16_t *list, int ls, int cnt_row, int cnt, int 
         D.task.d_lo = (int16_t)lo; D.task.row_first = (int16_t)hi; D.task.mlb = (int16_t)S.mlb; D.task.row_last = (int16_t)S.rl;   // (diagnostics)
         return;
     }
-    const int cls = (width + 7) / 8 - 1;
+    const int cls = (width + 15) / 16 - 1;
     // the band of the class, kept inside the matrix' diagonals where that is possible
     const int wb = pf_class_width(cls);
     if (lo + wb - 1 > n) lo = atr_max(-m, n - wb + 1);

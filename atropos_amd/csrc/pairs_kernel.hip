@@ -275,10 +275,10 @@ extern "C" int atr_locate_pairs_path_batch(const uint8_t *d_ref_packed, const in
                                                nullptr, nullptr, (long long)npairs, (uint4 *)d_out, (hipStream_t)stream);
         return e == hipSuccess ? ATR_OK : hip_fail(e, "pairs_wave_kernel launch");
     }
-    // The cost / threat / band pipeline from a quarter of a million pairs on: its launches cost 0.8 ms (2 x 150 bp; the
+    // The cost / threat / band pipeline from a quarter of a million pairs on: its launches cost 0.65 ms (2 x 150 bp; the
     // latency of single lanes) whatever the batch holds, the full sweep 5.5 ns per pair with a floor of 0.36 ms
     // (tools/micro/small_pairs.py, pairs_fixed_cost.py).  Reads of more than 160 bases have bands almost as wide as the
-    // matrix (2 k + 1 diagonals on either side of the overlap's end, k = 50 at 250 bases): 79 M against 75 M pairs/s on
+    // matrix (2 k + 1 diagonals on either side of the overlap's end, k = 50 at 250 bases): 82 M against 75 M pairs/s on
     // 500 k pairs 2 x 250 bp, so they need more pairs to pay -- unless d_need ends most pairs after the cost pass.
     const long long fast_min = (ref_max_len <= 160 || d_need != nullptr) ? PAIRS_FAST_MIN_PAIRS : 3 * PAIRS_FAST_MIN_PAIRS / 2;
     const bool worth = path == ATR_PAIRS_FAST || npairs >= fast_min;

@@ -225,13 +225,15 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
     const int nrd = pf_ref_stream_dwords(nrows), nqd = pf_query_stream_dwords(nrows, wb);
     std::vector<uint32_t> rs((size_t)nrd + 1), qs((size_t)nqd + 1);
     pf_stage_streams(rs.data(), 1, nrd, qs.data(), 1, nqd, rp, rndw, m, revcomp, qp, qndw, L.row_first, L.d_lo);
-    switch (wb) {
-#define ATR_EMU_BAND(WB) case WB: pf_band_sweep<WB>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break
-        ATR_EMU_BAND(8); ATR_EMU_BAND(16); ATR_EMU_BAND(24); ATR_EMU_BAND(32); ATR_EMU_BAND(40); ATR_EMU_BAND(48);
-        ATR_EMU_BAND(56); ATR_EMU_BAND(64); ATR_EMU_BAND(72); ATR_EMU_BAND(80); ATR_EMU_BAND(88); ATR_EMU_BAND(96);
-        ATR_EMU_BAND(104); ATR_EMU_BAND(112); ATR_EMU_BAND(120);
+    switch (cls) {
+        case 0: pf_band_sweep<16>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 1: pf_band_sweep<32>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 2: pf_band_sweep<48>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 3: pf_band_sweep<64>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 4: pf_band_sweep<80>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 5: pf_band_sweep<96>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 6: pf_band_sweep<112>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
         default: pf_band_sweep<128>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-#undef ATR_EMU_BAND
     }
     ++emu_pairs_fast_stats[1];
     return true;
