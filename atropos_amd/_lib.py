@@ -417,7 +417,7 @@ class HipBackend(object):
                                                                 _ptr(work), code, self._stream()), "atr_locate_batch")
         return out
 
-    def locate_one(self, h, table, query):
+    def locate_one(self, h, query):
         """``Aligner.locate`` of ONE read (bytes) -- what the module swap of INTEGRATION.md section 1 calls per
         read: atr_locate_one (the kernel reads the read from a page-locked staging buffer and writes the record
         into one; one launch, one synchronisation, no allocation).  Returns the six numbers or None."""

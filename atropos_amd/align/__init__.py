@@ -269,9 +269,8 @@ class Aligner(object):
         if getattr(self, "_long", False) and not self._debug:
             result = self._pair_aligner().locate(self.str_reference, query, unknown_queries_ok=True)
         elif self._handle is not None and hasattr(be, "locate_one") and len(qbytes) <= _lib.MAX_READ_LEN:
-            # the per-read API as the module swap uses it: cached buffers, no allocation (HipBackend.locate_one)
-            table = self._table if self._table is not None else be.translate_table(self._table_kind)
-            result = be.locate_one(self._handle, table, qbytes)
+            # the per-read API as the module swap uses it: one library call (HipBackend.locate_one)
+            result = be.locate_one(self._handle, qbytes)
         else:
             result = self.locate_batch([query]).tuples()[0]
         if self._debug and self._handle is not None:
