@@ -56,6 +56,35 @@ def measure(sizes=(1, 1000, 65536, 1_000_000)):
     out["per_read_locate_us"] = t * 1e6
     out["per_read_locate_reads_per_s"] = 1.0 / t
     out["pairs_1000"] = measure_pairs()
+    out["per_call_us"] = measure_per_call(host)
+    return out
+
+
+def measure_per_call(c2_host):
+    """The per-object calls the one-line module swap of INTEGRATION.md section 1 makes (one GPU call each), and a set of
+    four linked adapters on a 1 000-read batch."""
+    from atropos_amd.adapters import LinkedAdapter, LinkedSet
+    from atropos_amd.align import MultiAligner, compare_prefixes
+    from atropos_amd.util import reverse_complement
+    w3 = synth.workload("C3", 0, 8)
+    r1 = bytes(w3["reads1"][2].cpu().numpy()).decode()
+    rc2 = reverse_complement(bytes(w3["reads2"][2].cpu().numpy()).decode())
+    q = bytes(c2_host[5]).decode()
+    ma = MultiAligner(0.2, 9, 1)
+    out = {"MultiAligner.locate_2x150": timed(lambda: ma.locate(rc2, r1), min_reps=50) * 1e6,
+           "compare_prefixes": timed(lambda: compare_prefixes(synth.TRUSEQ_34, q), min_reps=50) * 1e6,
+           "new_Aligner_150_base_reference_plus_locate": timed(lambda: Aligner(rc2, 0.2, 15).locate(r1), min_reps=50) * 1e6,
+           "new_Aligner_34_base_adapter_plus_locate": timed(lambda: Aligner(synth.TRUSEQ_34, 0.1, 14).locate(q), min_reps=50) * 1e6}
+    from atropos_amd.adapters import AsciiSource, upper_ascii
+    w4 = synth.workload("C4", 0, 1000, device="cuda")
+    linked = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=w4["max_error_rate"],
+                            min_overlap=w4["min_overlap"], indel_cost=w4["indel_cost"]) for f, b in zip(w4["fronts"], w4["backs"])]
+    lset = LinkedSet(linked)
+    if lset.fused:
+        batch = AsciiSource(upper_ascii(w4["reads"])).batch(lset.table_kind, lset.table)
+        be = lset._backend
+        out["linked_set_of_four_1000_reads"] = timed(lambda: be.linked_match_batch(lset._handle, batch.packed, batch.lens,
+                                                                                   batch.nreads, batch.max_len)) * 1e6
     return out
 
 
