@@ -3,8 +3,12 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3                 # C2, the headline (BASELINE.json configs[1])
     python bench.py --config C3|C4|C5 ...                          # the other BASELINE configs, one GPU shard each
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                                   # launches its own N ranks (one process per GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # the same ranks under torchrun
     python bench.py --gpus N --single-process                      # the same shards from one process (threads + streams)
+
+The ranks of a multi-GPU run meet only at a barrier and for the max-over-ranks of the elapsed time; both go over a
+gloo (host) process group -- the path has no exchange step, so there is no RCCL anywhere.
 
 A step is one pass of the hot path over one batch of packed reads resident in HBM; with N GPUs
 every rank owns its own shard (weak scaling, no data-path collective: reads are independent,
@@ -405,6 +409,30 @@ class C4(object):
 
 CONFIGS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
+EMU = os.environ.get("ATROPOS_BENCH_BACKEND") == "emu"      # tests/test_distributed.py: the launcher on CPU, test double
+
+
+class HostEvent(object):
+    """Stand-in for torch.cuda.Event when the launcher is exercised on CPU with the test double."""
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+def new_event():
+    return HostEvent() if EMU else torch.cuda.Event(enable_timing=True)
+
+
+def device_sync():
+    if not EMU:
+        torch.cuda.synchronize()
+
+
+def device_name(ordinal):
+    return "cpu" if EMU else "cuda:%d" % ordinal
+
 
 def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
     """Build one config's workload, run warmup + EXACTLY args.steps timed steps (barrier + synchronize on both
@@ -412,18 +440,20 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
     (rank 0; None elsewhere).  headline: the config whose figures are the top-level fields of the line."""
     cargs = argparse.Namespace(**vars(args))
     cargs.reads = args.reads if (headline and args.reads is not None) else cfg_cls.default_units
-    cfg = cfg_cls(cargs, rank, "cuda:%d" % local_rank)
-    torch.cuda.synchronize()
+    if EMU:                                                      # the CPU test double sweeps ~100 k reads/s
+        cargs.reads = min(cargs.reads, int(os.environ.get("ATROPOS_BENCH_EMU_UNITS", "2000")))
+    cfg = cfg_cls(cargs, rank, device_name(local_rank))
+    device_sync()
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for s in range(args.warmup):
         cfg.step(s)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(new_event(), new_event()) for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
@@ -434,11 +464,12 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
     dt = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    tall = torch.zeros((world,), dtype=torch.float64, device="cuda")
-    tall[rank] = dt
+    tall = torch.zeros((2, world), dtype=torch.float64)          # host tensor: the group is gloo
+    tall[0, rank], tall[1, rank] = dt, kernel_ms
     if dist is not None:
         dist.all_reduce(tall, op=dist.ReduceOp.SUM)
-    per_rank = [float(x) for x in tall.tolist()]
+    per_rank = [float(x) for x in tall[0].tolist()]
+    per_rank_kernel_ms = [float(x) for x in tall[1].tolist()]
     dt_max = max(per_rank)
     if rank != 0:
         return None
@@ -448,7 +479,7 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
     prof = profile_counters(cfg.name) if not args.full_sweep else None
     desc = cfg.describe()
     live = None
-    if args.live_counters and world == 1 and not args.full_sweep:
+    if args.live_counters and world == 1 and not args.full_sweep and not EMU:
         live = live_counters(cfg.name, cargs.reads, headline)        # (child processes on the same GPU)
     desc["parallelism"] = "shard%d" % world
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -485,9 +516,15 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline):
         "metric": cfg.metric, "value": units * world * args.steps / dt_max, "unit": "reads/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": cfg.dtype, "data": "synthetic",
-        "config": desc, "roofline": roof,
+        "config": desc, "roofline": roof, "launcher": args.launcher,
         "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
     }
+    if world > 1:
+        # the roofline object is rank 0's GPU (every rank runs the same shard size); the other ranks' event times:
+        roof["per_rank_kernel_ms"] = per_rank_kernel_ms
+        roof["note"] = "per GPU (rank 0); " + roof["note"]
+    if args.oversubscribe:
+        out["oversubscribed"] = "%d ranks on %d device(s): a launcher check, NOT a scaling figure" % (world, args.ndev)
     # side measurements and the CPU leg belong to the single-GPU line (rank 0 at N = 1): the other ranks of a
     # multi-GPU run would only wait at the next barrier for them
     if args.secondary and world == 1:
@@ -520,7 +557,7 @@ def measure_threads(cfg_cls, args, devices):
                 for s in range(args.warmup):
                     cfg.step(s)
                 stream.synchronize()
-                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+                ev = [(new_event(), new_event()) for _ in range(args.steps)]
                 start.wait()
                 t_begin[rank] = time.perf_counter()
                 for s in range(args.steps):
@@ -561,6 +598,44 @@ def measure_threads(cfg_cls, args, devices):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what torch.distributed.run would set), pass
+    rank 0's JSON line through, return the first non-zero exit code.  The CPU analogue of the fan-out is
+    /root/reference/atropos/commands/multicore.py:297-401 (worker processes, results merged by the parent)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ndev = 1 if EMU else torch.cuda.device_count()
+    if not EMU and ndev < args.gpus and not args.oversubscribe:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible on this node (--oversubscribe shares them: launcher "
+                         "check only)" % (args.gpus, ndev))
+    argv = [a for a in sys.argv[1:]]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--launcher", "bench.py self-launch, one process per GPU"]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if rank == 0 else subprocess.DEVNULL))
+    rc = 0
+    failed = False
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and not failed:
+                rc, failed = code, True
+                for q in procs:                       # a dead rank would leave the others waiting at the barrier
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -583,6 +658,10 @@ def main():
                     help="--gpus N from ONE process: a host thread, backend and stream per GPU (no torchrun / NCCL); times "
                          "the headline config only")
     ap.add_argument("--devices", default=None, help="--single-process: comma-separated device ordinals (default 0 .. N-1)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="--gpus N on a box with fewer GPUs: ranks share devices (rank modulo count).  Exercises the launcher; "
+                         "the line is marked and is not a scaling figure")
+    ap.add_argument("--launcher", default=None, help=argparse.SUPPRESS)       # set by self_launch() for its ranks
     ap.add_argument("--full-sweep", action="store_true",
                     help="C2: time the unfiltered full-column DP kernel instead of the filtered pipeline")
     args = ap.parse_args()
@@ -593,20 +672,41 @@ def main():
             raise SystemExit("--devices must name --gpus devices")
         print(json.dumps(measure_threads(CONFIGS[args.config or "C2"], args, devices)), flush=True)
         return
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks of this same script
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    args.ndev = 1 if EMU else torch.cuda.device_count()
+    if not EMU and local_rank >= args.ndev:
+        if not args.oversubscribe:
+            raise SystemExit("rank %d of %d but only %d GPU(s) visible (--oversubscribe shares them: launcher check only)"
+                             % (local_rank, world, args.ndev))
+        local_rank %= args.ndev
+    args.oversubscribe = args.oversubscribe and world > args.ndev
+    if args.launcher is None:
+        args.launcher = ("torch.distributed.run, one process per GPU" if "TORCHELASTIC_RUN_ID" in os.environ
+                         else "one process" if world == 1 else "environment (RANK / WORLD_SIZE), one process per GPU")
+    if world > 1:
+        args.launcher += "; barrier + max-over-ranks over a gloo host group, no RCCL"
+    if not EMU:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
 
     from atropos_amd import _lib
-    _lib.set_backend(_lib.HipBackend(local_rank))
+    if EMU:
+        from tests.emu.backend import EmuBackend
+        _lib.set_backend(EmuBackend(), _test_double=True)
+    else:
+        _lib.set_backend(_lib.HipBackend(local_rank))
     head = args.config or "C2"
     line = measure(CONFIGS[head], args, rank, world, local_rank, dist, True)
     if args.config is None and args.others and not args.full_sweep:
@@ -614,7 +714,8 @@ def main():
         # own roofline and (N = 1) cpu_baseline.  A failure there must not cost the headline its line.
         others = {}
         for name in ("C3", "C4", "C5"):
-            torch.cuda.empty_cache()
+            if not EMU:
+                torch.cuda.empty_cache()
             try:
                 res = measure(CONFIGS[name], args, rank, world, local_rank, dist, False)
             except Exception as exc:                              # noqa: BLE001 -- reported in the line
