@@ -139,12 +139,8 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
         D.kind = 2; D.cls = 0;
         const bool ok = live && known && m >= 1 && n >= 1 && k <= PF_MAX_K && cnt <= PF_LIST_CAP;
         const int nmax = wave_max_i32(ok ? cnt : 0);
-#ifdef PF_EXPERIMENT_NO_ANALYSIS
-        if (live) D.kind = 0;
-#else
         pf_analyse(list, 64, cnt_row, ok ? cnt : 0, nmax, m, n, fp, s_thr, s_gap, s_gas, a.need && live ? a.need[r] : 1, (uint32_t)r, D);
         if (!ok) D.kind = 2;
-#endif
         if (live) {
             if (D.kind == 0) {
                 a.out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);

@@ -699,7 +699,16 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+        # gloo announces its connections on the C-level stdout; the contract is ONE JSON line there
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))
+            dist.barrier()
+        finally:
+            os.dup2(keep, 1)
+            os.close(keep)
 
     from atropos_amd import _lib
     if EMU:

@@ -166,8 +166,8 @@ def _run_bench(cmd, env_extra):
         env.pop(k, None)
     done = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert done.returncode == 0, done.stderr.decode()[-2000:]
-    lines = [ln for ln in done.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, done.stdout.decode()[-2000:]                   # ONE JSON line, from rank 0
+    lines = [ln for ln in done.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), done.stdout.decode()[-2000:]   # ONE line on stdout: rank 0's JSON
     return json.loads(lines[0])
 
 
