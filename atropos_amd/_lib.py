@@ -24,6 +24,8 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
+PLANES_MIN_READS = 65536                 # Aligner.pack: batches from here on are packed as bit planes when the two-pass
+                                         # pre-pass takes the aligner (atr_locate_planes_batch)
 WAVE_MAX_READS = 32768                   # atr_locate_batch: short batches take the wavefront-per-read kernel
 LOCATE_PATHS = {"auto": 0, "full": 1, "filtered": 2, "wave": 3}   # ATR_LOCATE_* of include/atropos_hip.h
 PAIRS_PATHS = {"auto": 0, "full": 1, "fast": 2, "wave": 3}        # ATR_PAIRS_*
@@ -109,6 +111,8 @@ PROTOTYPES = {
     "atr_multi_locate_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_compare_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_locate_planes_applies": (C.c_int, [C.c_void_p, C.c_int]),
+    "atr_locate_planes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]),
     "atr_linked_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -415,6 +419,23 @@ class HipBackend(object):
             with torch.cuda.device(self.device):
                 _check(self.lib, self.lib.atr_locate_batch_path(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out),
                                                                 _ptr(work), code, self._stream()), "atr_locate_batch")
+        return out
+
+    def locate_planes_applies(self, h, max_len):
+        """Is this aligner on equal-length reads of max_len bases inside the envelope of the two-pass pre-pass
+        (plane64 reads, atr_locate_planes_batch)?"""
+        return bool(self.lib.atr_locate_planes_applies(h, int(max_len)))
+
+    def locate_planes_batch(self, h, planes, nreads, max_len):
+        """Batched locate on a plane64 batch of equal-length reads (atr_locate_planes_batch)."""
+        out = self.empty((nreads, 8), torch.int16)
+        if nreads:
+            need = self.lib.atr_locate_work_bytes(nreads)
+            if self._work is None or self._work.numel() < need:
+                self._work = self.empty((need,), torch.uint8)
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_locate_planes_batch(h, _ptr(planes), nreads, max_len, _ptr(out), _ptr(self._work),
+                                                                  self._stream()), "atr_locate_planes_batch")
         return out
 
     def locate_one(self, h, query):

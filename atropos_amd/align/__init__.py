@@ -187,17 +187,34 @@ class Aligner(object):
         """Which translate table (``_lib.TABLE_*``) query batches must be packed with."""
         return self._table_kind
 
-    def pack(self, reads):
+    def pack(self, reads, layout="auto"):
         """Pack reads for this aligner.  ``reads``: a ReadBatch (returned unchanged if
-        compatible), a sequence of str/bytes, or a uint8 [nreads, width] array/tensor."""
+        compatible), a sequence of str/bytes, or a uint8 [nreads, width] array/tensor.
+        ``layout``: "tile64" (4-bit codes), "plane64" (bit planes of the codes: what the two-pass
+        pre-pass of ``locate_batch`` reads, equal-length batches only) or "auto" -- plane64 for a long
+        equal-length batch when that pre-pass takes this aligner, else tile64."""
         if isinstance(reads, ReadBatch):
             self._check_batch(reads)
             return reads
         kind = self._table_kind
         table = self._table if self._table is not None else self._backend.translate_table(kind)
         if isinstance(reads, (list, tuple)):
-            return ReadBatch.from_strings(reads, kind, table, self._backend)
-        return ReadBatch.from_ascii(reads, None, None, kind, table, self._backend)
+            width = len(reads[0]) if len(reads) else 0
+            planes = self._wants_planes(layout, len(reads), width) and all(len(r) == width for r in reads)
+            return ReadBatch.from_strings(reads, kind, table, self._backend, planes=planes)
+        planes = self._wants_planes(layout, reads.shape[0], reads.shape[1])
+        return ReadBatch.from_ascii(reads, None, None, kind, table, self._backend, planes=planes)
+
+    def _wants_planes(self, layout, nreads, width):
+        if layout == "tile64" or self._handle is None or getattr(self, "_long", False):
+            return False
+        be = self._backend
+        ok = hasattr(be, "locate_planes_applies") and width > 0 and be.locate_planes_applies(self._handle, width)
+        if layout == "plane64":
+            if not ok:
+                raise _lib.AtroposUnsupported("the plane64 layout (two-pass pre-pass) does not take this aligner / read length")
+            return True
+        return ok and nreads >= _lib.PLANES_MIN_READS
 
     def _check_batch(self, batch):
         if self._handle is None:
@@ -206,6 +223,12 @@ class Aligner(object):
                 self._table_kind == _lib.TABLE_CUSTOM and batch.table != self._table):
             raise ValueError("read batch was packed with translate table %d but this aligner needs %d "
                              "(use aligner.pack(reads))" % (batch.table_kind, self._table_kind))
+
+    @staticmethod
+    def _need_tile64(batch, what):
+        if batch.layout != "tile64":
+            raise ValueError("%s reads the tile64 layout; this batch is %s (aligner.pack(reads, layout=\"tile64\"))"
+                             % (what, batch.layout))
 
     # -- alignment ----------------------------------------------------------------------
     def locate_batch(self, reads, filtered=True, path=None):
@@ -229,12 +252,19 @@ class Aligner(object):
                 lens_t = None if int(lens.min()) == int(lens.max()) else torch.from_numpy(lens).to(be.device)
                 return LocateResult(be.locate_ascii_batch(self._handle, torch.from_numpy(mat).to(be.device), lens_t,
                                                           int(lens.max())))
-        batch = self.pack(reads)
+        batch = self.pack(reads, layout="plane64" if path == "pieces" else
+                          "auto" if (filtered and path in (None, "auto")) else "tile64")
         if self._handle is None:                      # empty reference: nothing ever matches
             rec = be.empty((batch.nreads, 8), torch.int16)
             rec.zero_()
             rec[:, 1] = -1
             return LocateResult(rec)
+        if batch.layout == "plane64":
+            if path not in (None, "auto", "pieces") or not filtered or batch.lens is not None:
+                self._need_tile64(batch, "locate_batch(path=%r)" % (path if filtered else "full"))
+            return LocateResult(be.locate_planes_batch(self._handle, batch.packed, batch.nreads, batch.max_len))
+        if path == "pieces":
+            raise ValueError("path \"pieces\" (the two-pass pre-pass) reads the plane64 layout: aligner.pack(reads, layout=\"plane64\")")
         return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len,
                                             filtered, path))
 
@@ -246,7 +276,8 @@ class Aligner(object):
         if getattr(self, "_long", False):
             raise _lib.AtroposHipError("compare_batch: references longer than %d bases go through "
                                        "align.compare_batch(ref, queries, ...)" % _lib.MAX_REF_LEN)
-        batch = self.pack(reads)
+        batch = self.pack(reads, layout="tile64")
+        self._need_tile64(batch, "compare_batch")
         be = self._backend
         if self._handle is None:                      # empty reference: the empty overlap
             rec = be.empty((batch.nreads, 8), torch.int16)

@@ -53,10 +53,11 @@ class ReadBatch(object):
 
     @classmethod
     def from_ascii(cls, ascii_2d, lens=None, max_len=None, table_kind=_lib.TABLE_DNA15, table=None,
-                   backend=None, starts=None):
+                   backend=None, starts=None, planes=False):
         """ascii_2d: uint8 tensor/ndarray [nreads, width] of ASCII codes; lens: per-read
         lengths (None = every read is ``width`` long); starts: per-read first base (int32
-        tensor): the batch then holds the slices ``read[start:]``."""
+        tensor): the batch then holds the slices ``read[start:]``; planes: the plane64 layout
+        (bit planes of the codes) instead of tile64."""
         be = backend or _lib.get_backend()
         if isinstance(ascii_2d, np.ndarray):
             ascii_2d = torch.from_numpy(np.ascontiguousarray(ascii_2d, dtype=np.uint8))
@@ -88,11 +89,14 @@ class ReadBatch(object):
             full = lens if lens is not None else torch.full((nreads,), width, dtype=torch.int32, device=be.device)
             packed = be.pack_reads(ascii_2d, full, max_len, bytes(table), starts=starts)
             return cls(packed, (full - starts).clamp_(min=0), nreads, max_len, table_kind, table)
+        if planes:
+            packed = be.pack_reads(ascii_2d, lens, max_len, bytes(table), planes=True)
+            return cls(packed, lens, nreads, max_len, table_kind, table, layout="plane64")
         packed = be.pack_reads(ascii_2d, lens, max_len, bytes(table))
         return cls(packed, lens, nreads, max_len, table_kind, table)
 
     @classmethod
-    def from_strings(cls, reads, table_kind=_lib.TABLE_DNA15, table=None, backend=None):
+    def from_strings(cls, reads, table_kind=_lib.TABLE_DNA15, table=None, backend=None, planes=False):
         """reads: sequence of ``str`` (ASCII) or ``bytes``."""
         mat, lens = _as_ascii_matrix(reads)
         if len(reads) == 0:
@@ -102,7 +106,7 @@ class ReadBatch(object):
             return cls(be.empty((16,), torch.uint8), None, 0, 0, table_kind, table)
         if int(lens.min()) == mat.shape[1]:               # equal lengths: no length array (the kernels' uniform path)
             lens = None
-        return cls.from_ascii(mat, lens, None, table_kind, table, backend)
+        return cls.from_ascii(mat, lens, None, table_kind, table, backend, planes=planes and lens is None)
 
 
 class LocateResult(object):

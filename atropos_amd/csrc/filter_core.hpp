@@ -147,11 +147,27 @@ ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     return ROWS_BIN0 + atr_min(rows, 63);
 }
 
+// The match masks of the eight bases of one dword w of a packed read, from the 16-entry table `peq` in LDS
+// (8 bytes per query code).  Byte offset of base b: its nibble * 8 = (w >> (4 b - 3)) & 0x78 -- a right shift
+// and an AND with a literal, both 2-cycle ops; only base 0 needs a left shift (one poisoning op in ~150).
+#ifndef ATR_HOST_EMU
+__device__ __forceinline__ void fetch_peq8(const uint2 *peq, uint32_t w, uint2 (&e)[8]) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        uint32_t off;
+        if (b == 0) off = (w << 3) & 0x78u;
+        else asm("v_lshrrev_b32 %0, %1, %2\n\tv_and_b32 %0, 0x78, %0" : "=v"(off) : "n"(4 * b - 3), "v"(w));
+        e[b] = *(const uint2 *)((const char *)peq + off);
+    }
+}
+#endif
+
 struct FilterState {
     uint32_t pvl, pvh, mvl, mvh;                    // vertical +1 / -1 deltas of the current column (lo/hi words)
     int score;                                      // D[m][j] - (k + 1): negative <=> row m is a candidate in this column
     uint32_t hits;                                  // bit b: D[m][j - b] <= k, over the columns swept since the last fold
-    uint32_t best;                                  // min over the swept columns j >= m of (D[m][j] << 10 | j)
+    uint32_t nz;                                    // bit b: 1 <= D[m][j - b] <= k (hits & ~nz = the zero-cost columns)
+    int zfirst;                                     // first column j >= rows with D[m][j] == 0 (0: none), as of the last fold
     int j_first, j_last;                            // first / last column with D[m][j] <= k (0: none), as of the last fold
 };
 
@@ -176,74 +192,80 @@ ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf, bool wide) {
     else { F.pvl = u.sr ? 0u : low; F.pvh = 0u; }
     F.mvl = F.mvh = 0u;
     F.score = (u.sr ? 0 : mf) - (u.k + 1);
-    F.hits = 0u;
-    F.best = ~0u;
+    F.hits = F.nz = 0u;
+    F.zfirst = 0;
     F.j_first = F.j_last = 0;
 }
 ATR_DEV void filter_init(FilterState &F, const Uniform &u, int mf) { filter_init(F, u, mf, mf > 32); }
 
-// Column tag of the exact-hit tracker: the column number, the bias of the stored score, plus a
-// penalty that keeps columns j < m (where a zero cost is only possible with START_WITHIN_SEQ1
-// and is no full-length occurrence: _align.pyx:456-458 needs the whole reference inside the
-// read) from ever winning.
-ATR_DEV uint32_t filter_column_tag(const Uniform &u, int mf, int j) {
-    return (uint32_t)j + ((uint32_t)(u.k + 1) << 10) + (j < mf ? 1u << 20 : 0u);
-}
-
-// ph <<= 1 and mh <<= 1 on one- or two-word vectors; the bit shifted out of the top of ph is
-// added to score, the one out of mh subtracted: the shift is an add-with-carry-out and the
-// score update an add/sub-with-carry-in.  A VALU write of a carry (VCC or an SGPR pair) needs
-// two wait states before a VALU reads it on gfx950 (hipcc pads its own add/addc pairs with
-// s_nop 1), so the two chains use two carry registers and fill each other's wait states.
+// INSTRUCTION CLASSES (profiles/round4_valu_issue_sparse.txt).  On gfx950 the two-operand integer ops, right
+// shifts, v_bitop3_b32 on three distinct registers and the carry ops issue in 2 cycles, and ONE op of the
+// "poisoning" class (v_alignbit, v_min / v_max _u32, left shifts, v_lshl_add, v_bfe, ...) among eight puts the
+// whole stream at 4 cycles per instruction.  The column update below therefore holds none: the shift of the
+// horizontal deltas is an add-with-carry-out, the score update an add/sub-with-carry-in, and the two per-column
+// flags -- "row m is a candidate" (D <= k) and "... with a cost of at least one" (1 <= D <= k) -- are pushed into
+// their bit vectors as carries too (the sign of the biased score is the carry of score + score; score + k
+// carries exactly for -k <= score <= -1).  The first zero-cost column (where the reference stops,
+// _align.pyx:456-458) comes out of hits & ~nz when the vectors are folded, once per 32 columns; rounds 1-3
+// kept a running v_min_u32 of (score << 10 | column) instead: three poisoning ops per column.
+// A VALU write of a carry (VCC or an SGPR pair) needs two wait states before a VALU reads it on gfx950 (hipcc
+// pads its own add/addc pairs with s_nop 1), so every pair of chains uses two carry registers and fills each
+// other's wait states.
+// ph <<= 1 and mh <<= 1 on one- or two-word vectors; the bit shifted out of the top of ph is added to score, the
+// one out of mh subtracted.  The two flags are pushed ONE COLUMN LATE: the block first pushes the flags of the
+// score it finds (the column before) -- hits = 2 hits + (D <= k), nz = 2 nz + (1 <= D <= k) -- and then updates the
+// score, so that four carry registers are in flight and every carry is read three instructions after it was
+// written: no s_nop (each cost 2.8 cycles of a 34-cycle column, profiles/round4_valu_issue_sparse.txt).
+// filter_fold pushes the last column's flags before it reads the vectors.  kreg = k in a VGPR.
 template <bool WIDE>
-ATR_DEV void filter_shift_out2(uint32_t &phl, uint32_t &phh, uint32_t &mhl, uint32_t &mhh, int &score) {
+ATR_DEV void filter_shift_out2(uint32_t &phl, uint32_t &phh, uint32_t &mhl, uint32_t &mhh, int &score, uint32_t &hits,
+                               uint32_t &nz, uint32_t kreg) {
 #ifdef ATR_HOST_EMU
+    hits = (hits << 1) | ((uint32_t)score >> 31);
+    nz = (nz << 1) | (uint32_t)(((uint64_t)(uint32_t)score + (uint64_t)kreg) >> 32);
     const uint32_t pout = WIDE ? phh >> 31 : phl >> 31, mout = WIDE ? mhh >> 31 : mhl >> 31;
     if (WIDE) { phh = (phh << 1) | (phl >> 31); mhh = (mhh << 1) | (mhl >> 31); }
     phl <<= 1; mhl <<= 1;
     score += (int)pout - (int)mout;
 #else
-    uint64_t carry;                                   // the second carry register (an SGPR pair)
+    uint64_t c0, c2, c3;                              // carry registers besides VCC (SGPR pairs)
+    uint32_t t1, t2;                                  // sums nobody reads: only their carries count
     if (WIDE)
-        asm("v_add_co_u32 %0, %5, %0, %0\n\t"
+        asm("v_add_co_u32 %10, %8, %4, %4\n\t"
+            "v_add_co_u32 %11, %9, %4, %12\n\t"
+            "v_add_co_u32 %0, %7, %0, %0\n\t"
             "v_add_co_u32 %2, vcc, %2, %2\n\t"
-            "s_nop 0\n\t"
-            "v_addc_co_u32 %1, %5, %1, %1, %5\n\t"
+            "v_addc_co_u32 %5, %8, %5, %5, %8\n\t"
+            "v_addc_co_u32 %6, %9, %6, %6, %9\n\t"
+            "v_addc_co_u32 %1, %7, %1, %1, %7\n\t"
             "v_addc_co_u32 %3, vcc, %3, %3, vcc\n\t"
-            "s_nop 0\n\t"
-            "v_addc_co_u32 %4, %5, 0, %4, %5\n\t"
+            "s_nop 1\n\t"
+            "v_addc_co_u32 %4, %7, 0, %4, %7\n\t"
             "v_subbrev_co_u32 %4, vcc, 0, %4, vcc"
-            : "+v"(phl), "+v"(phh), "+v"(mhl), "+v"(mhh), "+v"(score), "=&s"(carry) : : "vcc");
+            : "+v"(phl), "+v"(phh), "+v"(mhl), "+v"(mhh), "+v"(score), "+v"(hits), "+v"(nz), "=&s"(c0), "=&s"(c2), "=&s"(c3),
+              "=&v"(t1), "=&v"(t2)
+            : "v"(kreg) : "vcc");
     else
-        asm("v_add_co_u32 %0, %3, %0, %0\n\t"
+        asm("v_add_co_u32 %8, %6, %2, %2\n\t"
+            "v_add_co_u32 %9, %7, %2, %10\n\t"
+            "v_add_co_u32 %0, %5, %0, %0\n\t"
             "v_add_co_u32 %1, vcc, %1, %1\n\t"
-            "s_nop 0\n\t"
-            "v_addc_co_u32 %2, %3, 0, %2, %3\n\t"
+            "v_addc_co_u32 %3, %6, %3, %3, %6\n\t"
+            "v_addc_co_u32 %4, %7, %4, %4, %7\n\t"
+            "v_addc_co_u32 %2, %5, 0, %2, %5\n\t"
             "v_subbrev_co_u32 %2, vcc, 0, %2, vcc"
-            : "+v"(phl), "+v"(mhl), "+v"(score), "=&s"(carry) : : "vcc");
-#endif
-}
-
-// hits = hits << 1 | (D <= k): the sign bit of the biased score, one v_alignbit_b32
-ATR_DEV void filter_push_hit(uint32_t &hits, int score) {
-#ifdef ATR_HOST_EMU
-    hits = (hits << 1) | ((uint32_t)score >> 31);
-#else
-    hits = __builtin_amdgcn_alignbit(hits, (uint32_t)score, 31);
+            : "+v"(phl), "+v"(mhl), "+v"(score), "+v"(hits), "+v"(nz), "=&s"(c0), "=&s"(c2), "=&s"(c3), "=&v"(t1), "=&v"(t2)
+            : "v"(kreg) : "vcc");
 #endif
 }
 
 // One column of Myers' recurrence (Hyyro's formulation), row-0 delta 0 (free start in the
 // read), written on explicit 32-bit halves: gfx950 has no full-rate 64-bit shift or add.
 // WIDE = adapter longer than 32 bases (both words live); otherwise only the low word.
-// tag = filter_column_tag(u, j).  ~27 VALU ops (WIDE) / ~16 per column, mask fetch included.
-// SIGNED_KEY (linked-adapter pipeline: k differs from lane to lane, so the bias (k + 1) << 10 cannot
-// ride in the wave-uniform tag): the tracker keeps min over the columns of (score << 10) + tag as a
-// SIGNED number and the bias is added once after the sweep (filter_unbias_best).
-// filter_step_key: the column update without the tracker; returns the column's key (score << 10) + tag, so that
-// a caller sweeping two columns can fold both keys into the tracker with ONE v_min3_u32.
+// kreg = k (wave-uniform in the single-aligner pipeline, the lane's own adapter's in the linked one).
+// 16 VALU ops per column (25 WIDE), all of the 2-cycle classes.
 template <bool WIDE>
-ATR_DEV uint32_t filter_step_key(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
+ATR_DEV void filter_step(FilterState &F, uint32_t eql, uint32_t eqh, uint32_t kreg) {
     const uint32_t xvl = eql | F.mvl;
     const uint32_t tl = eql & F.pvl;
     const uint32_t sl = tl + F.pvl;
@@ -259,47 +281,37 @@ ATR_DEV uint32_t filter_step_key(FilterState &F, const Uniform &u, uint32_t eql,
         phh = F.mvh | ~(xhh | F.pvh);
         mhh = F.pvh & xhh;
     }
-    filter_shift_out2<WIDE>(phl, phh, mhl, mhh, F.score);
+    filter_shift_out2<WIDE>(phl, phh, mhl, mhh, F.score, F.hits, F.nz, kreg);
     F.pvl = mhl | ~(xvl | phl);
     F.mvl = phl & xvl;
     if (WIDE) {
         F.pvh = mhh | ~(xvh | phh);
         F.mvh = phh & xvh;
     }
-    filter_push_hit(F.hits, F.score);
-#ifdef ATR_HOST_EMU
-    const uint32_t key = ((uint32_t)F.score << 10) + tag;
-#else
-    // tag is wave-uniform (the column number): one v_lshl_add_u32 with the tag in an SGPR; left to
-    // itself hipcc re-associates the sum into three VALU ops
-    uint32_t key;
-    asm("v_lshl_add_u32 %0, %1, 10, %2" : "=v"(key) : "v"(F.score), "s"(tag));
-#endif
-    return key;
-}
-template <bool WIDE, bool SIGNED_KEY = false>
-ATR_DEV void filter_step(FilterState &F, const Uniform &u, uint32_t eql, uint32_t eqh, uint32_t tag) {
-    const uint32_t key = filter_step_key<WIDE>(F, u, eql, eqh, tag);
-    if (SIGNED_KEY) F.best = (uint32_t)atr_min((int)F.best, (int)key);
-    else F.best = atr_minu(F.best, key);
 }
 
-// SIGNED_KEY sweeps: start value of the tracker, and its conversion to the biased unsigned form
-// (D[m][j] << 10 | j, all ones when no column was swept) the decision below expects.
-constexpr uint32_t FILTER_BEST_NONE_SIGNED = 0x7fffffffu;
-ATR_DEV uint32_t filter_unbias_best(uint32_t best, int k) {
-    return best == FILTER_BEST_NONE_SIGNED ? ~0u : best + ((uint32_t)(k + 1) << 10);
-}
-
-// Fold the hit bits of the (at most 32) columns swept since the last fold into j_first /
-// j_last; j = the last column this read has swept.
-ATR_DEV void filter_fold(FilterState &F, int j) {
+// Fold the flag bits of the (at most 32) columns swept since the last fold into j_first / j_last / zfirst;
+// j = the last column this read has swept, mf = the rows swept.  A zero cost in a column j < mf (possible with
+// START_WITHIN_SEQ1 only) is no full-length occurrence -- _align.pyx:456-458 needs the whole reference inside the
+// read -- and is not recorded.
+ATR_DEV void filter_fold(FilterState &F, int j, int mf, uint32_t kreg) {
+    // the flags of column j itself (filter_shift_out2 pushes one column late); the bit a first step pushed for
+    // column 0 -- no column of the read -- falls out here
+    F.hits = (F.hits << 1) | ((uint32_t)F.score >> 31);
+    F.nz = (F.nz << 1) | ((uint32_t)F.score + kreg < kreg ? 1u : 0u);
+    if (j < 32) { const uint32_t keep = j <= 0 ? 0u : (1u << j) - 1u; F.hits &= keep; F.nz &= keep; }
     if (F.hits != 0u) {
         const int hi = 31 - atr_clz(F.hits), lo = atr_ctz(F.hits);
         if (F.j_first == 0) F.j_first = j - hi;
         F.j_last = j - lo;
-        F.hits = 0u;
+        if (F.zfirst == 0) {
+            const int span = j - mf;                                   // bit b is column j - b: b <= span
+            const uint32_t ok = span >= 31 ? ~0u : span < 0 ? 0u : (2u << span) - 1u;
+            const uint32_t z = F.hits & ~F.nz & ok;
+            if (z != 0u) F.zfirst = j - (31 - atr_clz(z));
+        }
     }
+    F.hits = F.nz = 0u;
 }
 
 // Last column (column n): which rows could pass the candidate test?  The alignment length is
@@ -375,15 +387,18 @@ ATR_DEV bool filter_tail_matches(const P &fp, int T, const uint32_t *q, int nchu
 // "match nothing" columns, which leave the initial column of an aligner without
 // START_WITHIN_SEQ1 unchanged (cost i in row i) -- so column s plays the part of column 0; all
 // coordinates stay those of the whole read (the caller re-bases the record).
-template <bool WIDE, class P>
-ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &fp, const uint32_t *q,
-                               int nchunks, int n, uint32_t rec[4], int s = 0) {
+// tm(jp): do the T bases after column jp equal the adapter's tail rows (filter_tail_matches on the caller's copy of
+// the read)?  have_last = false (two-pass pre-pass, piece_core.hpp): the sweep did not end in column n because no
+// last-column cell can be acceptable -- F's vertical deltas are those of another column and are not looked at.
+template <bool WIDE, class P, class TM>
+ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const P &fp, TM tm, int n, uint32_t rec[4],
+                                  int s = 0, bool have_last = true) {
     const int mf = fp.rows, T = u.m - mf;                                // T > 0: NARROW mode
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
-    if ((F.best >> 10) == 0u && u.m >= u.min_overlap) {
+    if (F.zfirst != 0 && u.m >= u.min_overlap) {
         // first perfect full-length occurrence: the reference breaks out here (:456-458)
-        const int j = (int)(F.best & 1023u) + T;
-        if (T == 0 || (j <= n && filter_tail_matches(fp, T, q, nchunks, j - T))) {
+        const int j = F.zfirst + T;
+        if (T == 0 || (j <= n && tm(j - T))) {
             rec[0] = (uint32_t)u.m << 16;                                   // refstart 0, refstop m
             rec[1] = (uint32_t)(j - u.m) | ((uint32_t)j << 16);             // querystart, querystop
             rec[2] = (uint32_t)u.m;                                         // matches m, errors 0
@@ -394,7 +409,7 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
     bool exact_l = true;
     // NARROW mode: which hits of the mf-row matrix can a path to a longer row (or to row m) still use?
     const int tail_rule = T == 0 ? 0 : (F.j_first == 0 || F.j_last < n - T - u.k) ? 1 : F.j_first == n ? 2 : 0;
-    const int row_l = filter_last_column<WIDE>(F, u, fp, cost_l, exact_l, tail_rule, d_mf, row_e);
+    const int row_l = have_last ? filter_last_column<WIDE>(F, u, fp, cost_l, exact_l, tail_rule, d_mf, row_e) : 0;
     const bool lastcol = row_l != 0;
     // rule 2: a row-m candidate would have to come down from (mf, n) by T insertions
     const bool rowm = F.j_first != 0 && u.m >= u.min_overlap && !(tail_rule == 2 && d_mf + T > u.k);
@@ -450,6 +465,14 @@ ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &
     // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
     // last-column row can matter (a row only depends on the rows before it)
     return window_word(j_lo, j_hi, lastcol, rowm ? u.m : row_l, band);
+}
+
+// q: this read's dwords in the tile64 layout (read_dword).
+template <bool WIDE, class P>
+ATR_DEV uint32_t filter_decide(const FilterState &F, const Uniform &u, const P &fp, const uint32_t *q,
+                               int nchunks, int n, uint32_t rec[4], int s = 0) {
+    const int T = u.m - fp.rows;
+    return filter_decide_tm<WIDE>(F, u, fp, [&](int jp) { return filter_tail_matches(fp, T, q, nchunks, jp); }, n, rec, s);
 }
 
 // ---- banded DP for the band reads --------------------------------------------------------

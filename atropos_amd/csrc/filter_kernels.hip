@@ -43,8 +43,9 @@ void launch_fast_scan(FastWork wk, hipStream_t st) {
 // pass), idx == count - 1 joins them again; events only, legal inside a stream capture.
 constexpr int DP_STREAMS = 4;                            // >= LINKED_MAX: band stream + one per further adapter
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st) {
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes) {
     static thread_local SideStream side[DP_STREAMS];
+    if (planes && (la || lens)) return (int)hipErrorInvalidValue;        // plane64: the single-aligner pipeline on equal-length reads
     if (count < 1 || count > DP_STREAMS || idx < 0 || idx >= count) return (int)hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     // a short batch (the <= 1000 reads the unchanged trim command hands over per call) leaves most of the chip
@@ -57,6 +58,9 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         if (la) {
             if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
             else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+        } else if (planes) {
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false, true>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false, true>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
         } else {
             if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
             else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, dim3(256), 0, st, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
@@ -64,7 +68,7 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         e = hipGetLastError();
         if (e != hipSuccess) return (int)e;
         const int mts = round_up_rows(a->p.m) / ROW_GRAN - 1;
-        return window_groups[mts / 4](mts % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st);
+        return window_groups[mts / 4](mts % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st, planes);
     }
     if (idx == 0) {
         for (int k = 0; k < count; ++k) if (!side[k].ready()) return (int)hipErrorInvalidValue;
@@ -79,6 +83,10 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         if (la) {
             if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
             else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+        } else if (planes) {
+            const LinkedArgs none = no_linked_args();
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
         } else {
             const LinkedArgs none = no_linked_args();
             if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
@@ -89,7 +97,7 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
     if (e != hipSuccess) return (int)e;
     const int mt = round_up_rows(a->p.m) / ROW_GRAN - 1;
     const int rc = window_groups[mt / 4](mt % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la,
-                                                 idx == 0 ? st : side[idx].stream);
+                                                 idx == 0 ? st : side[idx].stream, planes);
     if (rc != 0) return rc;
     if (idx == count - 1) {
         for (int k = 0; k < count && e == hipSuccess; ++k) {
@@ -122,7 +130,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
     // joined after K4, so that its waves (latency bound: three dependent gathers per task) share
     // the SIMDs with K4's instead of running before them.
-    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, 0, 1, st);
+    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, 0, 1, st, false);
 }
 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,

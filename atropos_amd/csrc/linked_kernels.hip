@@ -24,7 +24,7 @@ namespace atr {
 
 void launch_fast_scan(FastWork wk, hipStream_t st);
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st);
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes);
 int hip_fail(hipError_t e, const char *what);
 
 struct LinkedBlob {
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
                 const int mf = bp.rows;
                 FilterState F;
                 filter_init(F, ub, mf, WIDE);
-                F.best = FILTER_BEST_NONE_SIGNED;
+                const uint32_t kreg = (uint32_t)ub.k;                          // the lane's own adapter's k
                 const int jhi = RAGGED ? wave_max_i32(has ? n : 0) : max_len;
                 const int jfull = RAGGED ? wave_min_i32(has ? n : 0x7fffffff) : max_len;   // columns every matched lane has
                 const int s_lo = wave_min_i32(has ? s : 0x7fffffff), s_hi = wave_max_i32(has ? s : 0);
@@ -188,31 +188,24 @@ __global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__
                             if (z < z_first || 8 * z >= jhi) continue;         // wave-uniform
                             uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
                             if (8 * z < s_hi) w &= start_mask(z, s);           // wave-uniform: only the first dwords
-                            // byte offsets of the eight mask entries (8 bytes each): even / odd nibbles pre-scaled
-                            uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
                             uint2 e[8];
-#pragma unroll
-                            for (int b = 0; b < 8; ++b) {
-                                const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
-                                e[b] = *(const uint2 *)(peq_base + off);
-                            }
+                            fetch_peq8((const uint2 *)peq_base, w, e);
                             const int j0 = 8 * z;
                             if (j0 + 8 <= jhi && j0 + 8 <= jfull) {             // wave-uniform
 #pragma unroll
-                                for (int b = 0; b < 8; ++b) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)(j0 + b + 1));
+                                for (int b = 0; b < 8; ++b) filter_step<WIDE>(F, e[b].x, e[b].y, kreg);
                             } else {
 #pragma unroll
                                 for (int b = 0; b < 8; ++b) {
                                     const int j = j0 + b + 1;
-                                    if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE, true>(F, ub, e[b].x, e[b].y, (uint32_t)j);
+                                    if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, e[b].x, e[b].y, kreg);
                                 }
                             }
                             jlast = min(jhi, j0 + 8);
                         }
-                        filter_fold(F, RAGGED ? min(n, jlast) : jlast);        // at most 32 columns since the last fold
+                        filter_fold(F, RAGGED ? min(n, jlast) : jlast, mf, kreg);        // at most 32 columns since the last fold
                     }
                 }
-                F.best = filter_unbias_best(F.best, ub.k);
                 LaneFilterParams lf;
                 lf.rows = mf; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
                 ww = filter_decide<WIDE>(F, ub, lf, (const uint32_t *)tp, nchunks, n, brec, s);
@@ -423,7 +416,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
         la.bin0 = a * FILTER_BINS;
         la.front = front;
         la.post = s->post[a];
-        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st);
+        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st, false);
         if (rc != 0) return hip_fail((hipError_t)rc, "linked band / window launch");
     }
     return ATR_OK;

@@ -25,6 +25,7 @@
 #include "locate_kernel.hpp"
 #include "filter_core.hpp"
 #include "linked_core.hpp"
+#include "piece_core.hpp"
 
 namespace atr {
 
@@ -45,10 +46,16 @@ struct FastWork {                                    // carve-up of the caller's
                                                      // the scans then only walk the histogram rows that exist)
     int lpw;                                         // tasks a wave of the DP kernels takes: 64, or 0 = as few as the grid
                                                      // allows (short batches, dp_lanes_per_wave)
+    uint2 *tmp;                                      // [nreads] two-pass pre-pass (piece_kernels.hip): per block, the list of its
+                                                     // unresolved (read, window word) pairs, at the block's first read
+    uint32_t *lcount;                                // [FAST_BLOCKS] entries of each block's list
+    uint32_t *wide;                                  // [nreads] (the `win` region) reads that take the full sweep (piece_wide_kernel)
+    uint32_t *nwide;                                 // [1] their number
 };
 
 inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
-    return (size_t)nreads * 12 + (size_t)((nreads + 63) / 64) * 8 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * nbins * 4 + (size_t)(nbins + 1) * 4 + 256 + 16;
+    return (size_t)nreads * 20 + (size_t)((nreads + 63) / 64) * 8 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * nbins * 4 + (size_t)(nbins + 1) * 4 +
+           (size_t)FAST_BLOCKS * 4 + 256 + 32;
 }
 
 inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS) {
@@ -60,6 +67,10 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.chunks = w.counts + (size_t)FAST_BLOCKS * nbins;
     w.binbase = w.chunks + (size_t)(FAST_BLOCKS / 64) * nbins;          // SCAN_CHUNKS rows (SCAN_CHUNK = 64, below)
     w.total = w.binbase + nbins + 1;
+    w.lcount = w.total + 1;
+    w.nwide = w.lcount + FAST_BLOCKS;
+    w.wide = w.win;
+    w.tmp = (uint2 *)(((uintptr_t)(w.nwide + 1) + 7) & ~(uintptr_t)7);
     w.nbins = nbins;
     w.nused = FAST_BLOCKS;
     w.lpw = 64;
@@ -141,17 +152,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
             uint4 nxt = tp[0];
             // The eight match masks of a dword are fetched from LDS ONE DWORD AHEAD of the (serially
             // dependent) column updates that use them: two sets of eight, swapped every dword.
-            // Byte offsets of the eight entries: even / odd nibbles pre-scaled by 8, 12 ops per dword.
             uint2 ea[8], eb[8];
-            auto fetch_masks = [&](uint32_t w, uint2 (&e)[8]) {
-                uint32_t ev = (w << 3) & 0x78787878u, od = (w >> 1) & 0x78787878u;
-                asm("" : "+v"(ev), "+v"(od));            // keep hipcc from re-deriving each offset from w (2 ops apiece)
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const uint32_t off = (((b & 1) ? od : ev) >> (8 * (b >> 1))) & 0xFFu;
-                    e[b] = *(const uint2 *)((const char *)s_peq + off);
-                }
-            };
+            auto fetch_masks = [&](uint32_t w, uint2 (&e)[8]) { fetch_peq8(s_peq, w, e); };
+            const uint32_t kreg = (uint32_t)u.k;
             fetch_masks(nxt.x, ea);
             for (int c = 0; c < c1; ++c) {
                 uint4 cur = nxt;
@@ -161,34 +164,20 @@ __global__ __launch_bounds__(256) void filter_kernel(const LocateParams p, const
                 for (int d = 0; d < 4; ++d) {
                     uint2 (&e)[8] = (d & 1) ? eb : ea;       // this dword's masks; the other set takes the next dword's
                     fetch_masks(d == 0 ? cur.y : d == 1 ? cur.z : d == 2 ? cur.w : nxt.x, (d & 1) ? ea : eb);
-                    // (equal-length batches take the per-column path below: measured 3 % faster than this block on C2)
-                    if (RAGGED && j + 8 <= jfull) {          // wave-uniform: every lane of the wave owns all eight columns
+                    if (j + 8 <= (RAGGED ? jfull : jhi)) {   // wave-uniform: every lane of the wave owns all eight columns
 #pragma unroll
-                        for (int b = 0; b < 8; ++b) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + b + 1));
+                        for (int b = 0; b < 8; ++b) filter_step<WIDE>(F, e[b].x, e[b].y, kreg);
                         j += 8;
-                    } else if (RAGGED) {
+                    } else {
 #pragma unroll
                         for (int b = 0; b < 8; ++b) {
                             ++j;
-                            if (j <= jhi && j <= n) filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j));
-                        }
-                    } else {
-                        // two columns per wave-uniform test, their keys folded into the tracker by one v_min3_u32
-#pragma unroll
-                        for (int b = 0; b < 8; b += 2) {
-                            if (j + 2 <= jhi) {
-                                const uint32_t k1 = filter_step_key<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + 1));
-                                const uint32_t k2 = filter_step_key<WIDE>(F, u, e[b + 1].x, e[b + 1].y, filter_column_tag(u, fp.rows, j + 2));
-                                F.best = atr_minu(atr_minu(F.best, k1), k2);
-                            } else if (j + 1 <= jhi) {
-                                filter_step<WIDE>(F, u, e[b].x, e[b].y, filter_column_tag(u, fp.rows, j + 1));
-                            }
-                            j += 2;
+                            if (j <= jhi && (!RAGGED || j <= n)) filter_step<WIDE>(F, e[b].x, e[b].y, kreg);
                         }
                     }
                     if (j >= jhi) break;                     // wave-uniform
                 }
-                filter_fold(F, RAGGED ? min(n, min(j, jhi)) : min(j, jhi));   // at most 32 columns since the last fold
+                filter_fold(F, RAGGED ? min(n, min(j, jhi)) : min(j, jhi), fp.rows, kreg);   // at most 32 columns since the last fold
             }
         }
         uint32_t ww_lane = 0u;
@@ -295,15 +284,18 @@ __global__ __launch_bounds__(256) void scatter_kernel(long long nreads, int m, i
 }
 // K4a: the banded DP over the band reads = the slots [0, binbase[BAND_BINS]) of `order`
 // (persistent grid like K4; reads gathered by index).
-template <bool AND_MODE, bool LINKED>
+template <bool AND_MODE, bool LINKED, bool PLANES = false>
 __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const BandParams bp,
                                                    const uint4 *__restrict__ packed, const int32_t *__restrict__ lens,
                                                    long long nreads, int nchunks, int max_len, uint4 *__restrict__ out,
                                                    FastWork wk, const LinkedArgs la) {
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_stream[4][BAND_STREAM][64];              // per wave: the staged reads, [dword][lane]
+    __shared__ uint32_t s_spread_flat[PLANES ? 1024 : 1];          // plane64 reads: bytes of a plane -> nibbles (piece_core.hpp)
+    uint32_t (*s_spread)[256] = (uint32_t (*)[256])s_spread_flat;
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
     for (int i = threadIdx.x; i <= u.m + 1; i += 256) s_thr[i] = p.thr[i];
+    if constexpr (PLANES) piece_spread_fill(s_spread);
     __syncthreads();
     // band reads come first in `order` (linked: first among the bins of this adapter)
     const long long base = LINKED ? (long long)wk.binbase[la.bin0] : 0;
@@ -328,7 +320,8 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
         const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
         uint32_t *ns = &s_stream[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][lane];
-        band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
+        if constexpr (PLANES) band_stage_planes(q, nchunks, window_lo(ww), ns, 64, s_spread, band_stream_dwords(u.m));
+        else band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
         uint32_t rec[4] = {0xFFFF0000u, 0u, 0u, 0u};
         if (any_rowm) band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
         if (any_last) {
@@ -372,7 +365,7 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
 }
 #endif  // ATR_DEFINE_FILTER_KERNELS
 
-template <int MT, bool NOINDEL, bool LINKED>
+template <int MT, bool NOINDEL, bool LINKED, bool PLANES = false>
 __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads,
                                                      int nchunks, int max_len, uint4 *__restrict__ out, FastWork wk,
@@ -380,12 +373,15 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_init[ATR_MAX_REF_LEN + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_nm[16][4];
+    __shared__ uint32_t s_spread_flat[PLANES ? 1024 : 1];          // plane64 reads (equal-length batches only)
+    uint32_t (*s_spread)[256] = (uint32_t (*)[256])s_spread_flat;
     const Uniform u = make_uniform(p, MT);
     if (threadIdx.x < 64) s_nm[threadIdx.x >> 2][threadIdx.x & 3] = p.nmask[threadIdx.x >> 2][threadIdx.x & 3];
     for (int i = threadIdx.x; i <= MT + 1; i += 256) {
         if (i <= u.m + 1) s_thr[i] = p.thr[i];
         if (i <= MT) s_init[i] = init_word(i - u.p0, 0, u.sr, u.sq, u.indel);
     }
+    if constexpr (PLANES) piece_spread_fill(s_spread);
     __syncthreads();
     // the slots [first, total) of `order`: everything but the band reads (K4a)
     const int bin0 = LINKED ? la.bin0 : 0;
@@ -431,7 +427,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         // to the read end.  A lane whose read starts inside the swept range (column shift) restarts there from
         // the initial column, which without START_WITHIN_SEQ1 is the fresh-window column itself.
         const bool rows_wave = __builtin_amdgcn_readfirstlane((int)(first + wv * lpw >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0;
-        if (!LINKED && lens != nullptr && rows_wave && !u.sr) {
+        if (!LINKED && !PLANES && lens != nullptr && rows_wave && !u.sr) {
             const int shift = live ? max_len - n : 0;
             const int v0 = wave_min_i32(live ? j_lo + shift : 0x7fffffff);
             if (max_len - v0 <= TAIL_COLUMNS && v0 < max_len) {
@@ -484,6 +480,8 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
             for (int c = c0; c < c1; ++c) {
                 uint4 cur = nxt;
                 if (c + 1 < c1) nxt = tp[(size_t)(c + 1) * 64];
+                if constexpr (PLANES) cur = make_uint4(piece_nibbles(s_spread, cur.x, cur.y, cur.z, cur.w, 0), piece_nibbles(s_spread, cur.x, cur.y, cur.z, cur.w, 1),
+                                             piece_nibbles(s_spread, cur.x, cur.y, cur.z, cur.w, 2), piece_nibbles(s_spread, cur.x, cur.y, cur.z, cur.w, 3));
                 int j = c * 32;
 #pragma unroll 1
                 for (int d = 0; d < 4; ++d) {
@@ -520,17 +518,22 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
 
 // la == nullptr: the single-aligner pipeline
 typedef int (*window_launcher)(const atr_aligner *, const uint4 *, const int32_t *, long long, int, int, uint4 *,
-                               FastWork, const LinkedArgs *, hipStream_t);
+                               FastWork, const LinkedArgs *, hipStream_t, bool);
 
 template <int MT>
 int launch_window_mt(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                     int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, hipStream_t st) {
+                     int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, hipStream_t st, bool planes) {
     const bool noindel = a->indel_cost > a->p.k;
     // (one block of four waves per 4 reads at the low end: a short batch gets a wave per task)
     const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((nreads + 3) / 4, 4096))), block(256);
     if (la) {
         if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
         else         hipLaunchKernelGGL((window_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+    } else if (planes) {                                         // plane64 reads (two-pass pre-pass, piece_kernels.hip)
+        LinkedArgs none;
+        memset(&none, 0, sizeof(none));
+        if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, none);
+        else         hipLaunchKernelGGL((window_kernel<MT, false, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, none);
     } else {
         LinkedArgs none;
         memset(&none, 0, sizeof(none));

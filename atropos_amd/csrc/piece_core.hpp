@@ -1,0 +1,378 @@
+// piece_core.hpp -- the two-pass pre-pass of the batched Aligner.locate on BIT-PLANE reads (round 4).
+//
+// The one-pass pre-pass (filter_core.hpp) sweeps every column of every read with Myers' recurrence: 150 columns
+// x ~18 VALU ops per read, although half of the reads hold no trace of the adapter and the other half holds it
+// in ~40 of their 150 columns.  This header splits the pre-pass in two, per read, in ONE kernel:
+//
+//   pass A, every read, 32 positions per boolean op.  The read is stored as four BIT PLANES of its 4-bit codes
+//     (plane64, include/atropos_hip.h: word p of chunk c, bit b = bit p of the code of base 32 c + b), so "base
+//     == A" for 32 positions is one or two ops.  An alignment of the adapter's first rows with at most k errors
+//     (_align.pyx:380-426; the candidate rules :440-455, :464-474) leaves one of k + 1 disjoint PIECES of those
+//     rows intact -- an error touches one piece -- and the piece then sits in the read at most k diagonals off
+//     the alignment's own.  Pass A computes, for all positions at once, where each piece occurs exactly:
+//         occ_p = AND_s (eq[code of the piece's row L-1-s] << s)            (bit e: the piece ends at position e)
+//     with the four per-base masks shifted left one bit per step by add-with-carry chains (2-cycle ops; a funnel
+//     shift is a 4-cycle op that slows its neighbours, profiles/round4_valu_issue_sparse.txt).  Partial adapters
+//     at the read end (last-column candidates of rows below the pieces' rows) get their own necessary
+//     conditions: an overlap that must be exact (floor(i e) == 0) IS tested exactly on its diagonal, the
+//     classes with t >= 1 errors through t + 1 short pieces of their first rows on the diagonals they can reach.
+//     No piece, no end condition -> the read's result is None, exactly (there is no cell the reference could
+//     accept).  Otherwise the hits bound the columns in which any acceptable cell and its whole traceback lie.
+//   pass B, flagged reads only, the columns of their window only: the flagged lanes of a wave's tiles queue up
+//     in LDS ({read, 64-base window of the planes ending at the window's last column}); whenever 64 are there a
+//     wave sweeps them -- one task per lane, Myers' recurrence of filter_core.hpp from a FRESH column ("row i
+//     reached by i insertions") over at most 64 columns that END at the lane's own last column, so that lanes with
+//     windows in different places run in lock step without any sorting -- and decides with filter_decide.
+//     A fresh start at or before the first column a traceback can touch reproduces every cell of cost <= k bit
+//     for bit (note at the top of filter_core.hpp); columns before the read's first base hold code 0, match no
+//     row and leave the fresh column unchanged, so a window may begin before the read.
+//     Reads whose hits need more than PIECE_NARROW columns (a second occurrence, a chance hit somewhere else:
+//     3 % of C2's reads) go to a global list and take the full sweep in a small kernel of their own, 64 to a wave.
+//
+// Exactness of the windowed decision: the swept window is itself a genuine DP matrix (of the read's infix with a
+// free start), every acceptable cell of the whole matrix has its traceback inside it and therefore the same
+// value, every other cell is at least its true value, and filter_decide only ever uses (a) exact values of
+// acceptable cells and (b) lower-bound tests that hold in any such matrix.
+//
+// Envelope (piece_applies): aligners of the filtered pipeline without START_WITHIN_SEQ1 (3' adapters, the BACK
+// type), at most 32 swept rows (adapters of up to 40 bases: NARROW mode), k <= 3, one-hot codes (A C G T) in
+// the piece rows, pieces of at least 5 bases, equal-length batches of up to 320 bases.  Everything else keeps
+// the one-pass pre-pass.
+#ifndef ATR_PIECE_CORE_HPP
+#define ATR_PIECE_CORE_HPP
+
+#include "filter_core.hpp"
+
+namespace atr {
+
+constexpr int PIECE_NB = 4;                 // body pieces (k + 1 <= 4; a piece too many only weakens the filter)
+constexpr int PIECE_NT = 4;                 // read-end pieces (error classes t = 1 .. 3)
+constexpr int PIECE_STEPS = 8;              // longest piece
+constexpr int PIECE_TAIL_WORDS = 3;         // plane words the read-end pieces are evaluated on: the read's last three
+constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (two words per plane)
+constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps: one hit diagonal needs 32 + T + 3 k columns, a read-end
+                                            // condition 32 + T + k (94 % of C2's flagged reads); longer windows take the full sweep
+constexpr int PIECE_MAX_WORDS = 10;         // reads of up to 320 bases
+
+struct PieceParams {
+    int blen;                               // body piece p = rows [p blen, (p + 1) blen), 0-based rows
+    int tlen;                               // read-end piece u = rows [u tlen, (u + 1) tlen); 0: none
+    int steps;                              // max(blen, tlen)
+    int xlo, xhi;                           // rows i in [xlo, xhi]: the overlap of i bases must be exact (xhi < xlo: none)
+    int tail_cols;                          // columns before the read end a read with a read-end condition sweeps
+    int tw0;                                // first plane word of the read-end pieces' masks: max(0, ceil(n / 32) - 3)
+    int and_mode;                           // wildcard comparison (code & code): a base matches code c iff its plane c is set
+    uint32_t bcode[PIECE_NB];               // two bits per shift step s: the plane index (0 .. 3) of the row compared in
+    uint32_t tcode[PIECE_NT];               // that step, row p blen + blen - 1 - s (scalar loads + s_bfe: wave-uniform)
+    uint32_t tmask[PIECE_NT][PIECE_TAIL_WORDS];   // END positions a read-end piece may have (words tw0 ..), 0: piece unused
+    uint32_t xrow[4];                       // bit r: row r (0-based, < 32) holds the code of plane c
+};
+
+// one-hot code (1, 2, 4, 8) -> plane index, -1 otherwise
+inline int piece_plane_of(int code) { return code == 1 ? 0 : code == 2 ? 1 : code == 4 ? 2 : code == 8 ? 3 : -1; }
+
+// Host: does the two-pass pre-pass take this aligner (m rows, codes[], k, flags, thr_row as in FilterParams,
+// rows = FilterParams::rows) on equal-length reads of n bases?  Fills pp.
+inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags, bool and_mode, bool custom_table,
+                         const int32_t *thr_row, int n, PieceParams &pp) {
+    memset(&pp, 0, sizeof(pp));
+    const int need = ATR_START_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ2;
+    if ((flags & need) != need || (flags & ATR_START_WITHIN_SEQ1) || custom_table) return false;
+    if (rows > 32 || rows < 1 || k < 0 || k > PIECE_NB - 1 || k >= m) return false;
+    if (n < 1 || n > 32 * PIECE_MAX_WORDS) return false;
+    const int blen = std::min(PIECE_STEPS, rows / PIECE_NB);
+    if (blen < 5 || k > blen - 1) return false;                      // (k <= blen - 1: the diagonal mask keeps every hit)
+    const int body_rows = PIECE_NB * blen;                           // <= rows
+    for (int i = 0; i < body_rows; ++i) if (piece_plane_of(codes[i]) < 0) return false;
+    pp.blen = blen; pp.and_mode = and_mode ? 1 : 0;
+    for (int p = 0; p < PIECE_NB; ++p)
+        for (int s = 0; s < blen; ++s) pp.bcode[p] |= (uint32_t)piece_plane_of(codes[p * blen + blen - 1 - s]) << (2 * s);
+    for (int r = 0; r < 32 && r < m; ++r) { const int c = piece_plane_of(codes[r]); if (c >= 0) pp.xrow[c] |= 1u << r; }
+    // Last-column candidates of the rows i < body_rows (an alignment of body_rows rows or more holds a body piece):
+    // thr_row[i] = floor(i e), or -1 for a row that is no candidate (below min_overlap / no STOP_WITHIN_SEQ1).
+    // Rows with thr 0 are tested exactly; rows with thr t >= 1 form class t.
+    int ilo[PIECE_NB], ihi[PIECE_NB];
+    for (int t = 0; t < PIECE_NB; ++t) { ilo[t] = 0; ihi[t] = -1; }
+    const int top = std::min(body_rows - 1, m);                      // (row m in the last column is a row-m candidate too: body)
+    for (int i = 1; i <= top; ++i) {
+        const int t = thr_row[i];
+        if (t < 0) continue;
+        if (t >= PIECE_NB) return false;
+        if (i > 1 && thr_row[i - 1] > t) return false;               // (monotone thresholds: floor(i e))
+        if (ihi[t] < 0) ilo[t] = i;
+        ihi[t] = i;
+    }
+    pp.xlo = 1; pp.xhi = 0;
+    if (ihi[0] >= 0) { pp.xlo = ilo[0]; pp.xhi = ihi[0]; }
+    if (pp.xhi > 31) return false;
+    int tmax = 0;
+    for (int t = 1; t < PIECE_NB; ++t) if (ihi[t] >= 0) tmax = t;
+    pp.tlen = 0;
+    const int wl = (n - 1) >> 5;                                     // word of the read's last base = NW - 1 of the kernel
+    pp.tw0 = std::max(0, wl - (PIECE_TAIL_WORDS - 1));
+    if (tmax >= 1) {
+        // piece length: t + 1 pieces must fit the shortest overlap of every class t
+        int tlen = PIECE_STEPS;
+        for (int t = 1; t <= tmax; ++t) if (ihi[t] >= 0) tlen = std::min(tlen, ilo[t] / (t + 1));
+        if (tlen < 5) return false;
+        pp.tlen = tlen;
+        for (int u = 0; u < PIECE_NT; ++u) {
+            if (u > tmax) continue;
+            if ((u + 1) * tlen > body_rows) return false;
+            for (int s = 0; s < tlen; ++s) pp.tcode[u] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (2 * s);
+            // ... and piece u serves the classes t >= max(1, u) whose first t + 1 pieces fit their shortest overlap.
+            for (int t = std::max(1, u); t <= tmax; ++t) {
+                if (ihi[t] < 0) continue;
+                if ((t + 1) * tlen > ilo[t]) return false;
+                // overlap of i rows, i in [ilo, ihi], ends on diagonal n - i; the piece's own diagonal is at most t
+                // off: d = n - x, x in [ilo - t, ihi + t]; it then ends at position d + (u + 1) tlen - 1.
+                for (int x = ilo[t] - t; x <= ihi[t] + t; ++x) {
+                    const int e = n - x + (u + 1) * tlen - 1;
+                    if (e < 0 || e > n - 1 || n - x < -t) continue;
+                    const int w = (e >> 5) - pp.tw0;
+                    if (w < 0) return false;                         // (cannot happen: x <= body_rows + 3 < 64)
+                    pp.tmask[u][w] |= 1u << (e & 31);
+                }
+            }
+        }
+    }
+    pp.steps = std::max(pp.blen, pp.tlen);
+    pp.tail_cols = rows + k + (m - rows);                            // see "tail_cols" in DESIGN.md 3.2b: rows + k + T
+    return true;
+}
+
+// ---- pass A, one lane ---------------------------------------------------------------------------------
+// The four per-base masks of one read, NW words each: Y[c][w] bit b <=> base 32 w + b matches code index c.
+template <int NW>
+struct PieceMasks {
+    uint32_t y[4][NW];
+};
+
+// pl[w][p]: plane p of word w.
+template <int NW>
+ATR_DEV void piece_eq_masks(const uint32_t (&pl)[NW][4], bool and_mode, PieceMasks<NW> &Y) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const uint32_t p0 = pl[w][0], p1 = pl[w][1], p2 = pl[w][2], p3 = pl[w][3];
+        if (and_mode) { Y.y[0][w] = p0; Y.y[1][w] = p1; Y.y[2][w] = p2; Y.y[3][w] = p3; }
+        else {                                                       // byte equality: exactly this plane and no other
+            Y.y[0][w] = p0 & ~(p1 | p2 | p3); Y.y[1][w] = p1 & ~(p0 | p2 | p3);
+            Y.y[2][w] = p2 & ~(p0 | p1 | p3); Y.y[3][w] = p3 & ~(p0 | p1 | p2);
+        }
+    }
+}
+
+// All four masks one position up (bit b of word w -> bit b + 1, across the words): four add-with-carry chains,
+// interleaved so that each fills the others' carry wait states.
+template <int NW>
+ATR_DEV void piece_shift_masks(PieceMasks<NW> &Y) {
+#ifdef ATR_HOST_EMU
+    for (int c = 0; c < 4; ++c) {
+        uint32_t carry = 0;
+        for (int w = 0; w < NW; ++w) { const uint32_t v = Y.y[c][w]; Y.y[c][w] = (v << 1) | carry; carry = v >> 31; }
+    }
+#else
+    uint64_t c0, c1, c2, c3;
+    asm volatile("v_add_co_u32 %0, %4, %0, %0\n\tv_add_co_u32 %1, %5, %1, %1\n\t"
+                 "v_add_co_u32 %2, %6, %2, %2\n\tv_add_co_u32 %3, %7, %3, %3"
+                 : "+v"(Y.y[0][0]), "+v"(Y.y[1][0]), "+v"(Y.y[2][0]), "+v"(Y.y[3][0]), "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3));
+#pragma unroll
+    for (int w = 1; w < NW; ++w)
+        asm volatile("v_addc_co_u32 %0, %4, %0, %0, %4\n\tv_addc_co_u32 %1, %5, %1, %1, %5\n\t"
+                     "v_addc_co_u32 %2, %6, %2, %2, %6\n\tv_addc_co_u32 %3, %7, %3, %3, %7"
+                     : "+v"(Y.y[0][w]), "+v"(Y.y[1][w]), "+v"(Y.y[2][w]), "+v"(Y.y[3][w]), "+s"(c0), "+s"(c1), "+s"(c2), "+s"(c3));
+#endif
+}
+
+// acc[i] &= Y[code][W0 + i], i < N: the code is wave-uniform, so this is a scalar branch to one of four
+// straight-line blocks (no register indexing: an indexed read costs 6 - 8 cycles, the branch overlaps with the
+// other waves' VALU work).
+template <int NW, int N, int W0>
+ATR_DEV void piece_and_term(uint32_t (&acc)[N], const PieceMasks<NW> &Y, int code) {
+    static_assert(W0 + N <= NW, "words of the read");
+    switch (code) {
+    case 0:
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] &= Y.y[0][W0 + i];
+        break;
+    case 1:
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] &= Y.y[1][W0 + i];
+        break;
+    case 2:
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] &= Y.y[2][W0 + i];
+        break;
+    default:
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[i] &= Y.y[3][W0 + i];
+        break;
+    }
+}
+
+// (hi:lo) >> sh, low word; sh in 0 .. 31
+ATR_DEV uint32_t piece_funnel(uint32_t hi, uint32_t lo, int sh) {
+#ifdef ATR_HOST_EMU
+    return sh ? ((lo >> sh) | (hi << (32 - sh))) : lo;
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh);
+#endif
+}
+
+// What pass A knows about one read.
+struct PieceScan {
+    int j_s, j_e;                            // columns j_s + 1 .. j_e hold every acceptable cell and its traceback
+    bool flagged;                            // false: the result is None
+    bool tail;                               // a read-end condition holds (the window then ends at n)
+};
+
+// Pass A for one lane: the planes of a read of n bases (NW = ceil(n / 32) words) -> PieceScan.  twp[p]: plane p
+// of the read's last 32 positions (bit 31 = the last base; zeros before the read).  mf = rows swept by pass B
+// (FilterParams::rows), T = m - mf, k as Uniform::k.  n is wave-uniform (equal-length batch).
+template <int NW>
+ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4], const uint32_t (&twp)[4], int n, int mf,
+                             int T, int k) {
+    constexpr int TWN = NW < PIECE_TAIL_WORDS ? NW : PIECE_TAIL_WORDS, TW0 = NW - TWN;
+    PieceMasks<NW> Y;
+    piece_eq_masks<NW>(pl, pp.and_mode != 0, Y);
+
+    // (1) overlaps that must be exact: rows [0, i) against the last i bases, i in [xlo, xhi]: row r of an overlap
+    //     of i sits at bit 32 - i + r of the read's last 32 positions.
+    bool tail = false;
+    if (pp.xhi >= pp.xlo) {
+        uint32_t tw[4];
+        if (pp.and_mode) { tw[0] = twp[0]; tw[1] = twp[1]; tw[2] = twp[2]; tw[3] = twp[3]; }
+        else {
+            tw[0] = twp[0] & ~(twp[1] | twp[2] | twp[3]); tw[1] = twp[1] & ~(twp[0] | twp[2] | twp[3]);
+            tw[2] = twp[2] & ~(twp[0] | twp[1] | twp[3]); tw[3] = twp[3] & ~(twp[0] | twp[1] | twp[2]);
+        }
+        for (int i = pp.xlo; i <= pp.xhi; ++i) {                     // wave-uniform trip count
+            const uint32_t mw = ((tw[0] >> (32 - i)) & pp.xrow[0]) | ((tw[1] >> (32 - i)) & pp.xrow[1]) |
+                                ((tw[2] >> (32 - i)) & pp.xrow[2]) | ((tw[3] >> (32 - i)) & pp.xrow[3]);
+            const uint32_t full = i >= 32 ? ~0u : (1u << i) - 1u;
+            tail = tail || (i <= n && (mw & full) == full);
+        }
+    }
+
+    // (2) the pieces: body pieces on every word, read-end pieces on the read's last TWN words only
+    uint32_t occ[PIECE_NB][NW], tocc[PIECE_NT][TWN];
+#pragma unroll
+    for (int p = 0; p < PIECE_NB; ++p)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) occ[p][w] = ~0u;
+#pragma unroll
+    for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+        for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
+    for (int s = 0; s < pp.steps; ++s) {                             // wave-uniform
+        if (s < pp.blen) {
+#pragma unroll
+            for (int p = 0; p < PIECE_NB; ++p) piece_and_term<NW, NW, 0>(occ[p], Y, (int)((pp.bcode[p] >> (2 * s)) & 3u));
+        }
+        if (s < pp.tlen) {
+#pragma unroll
+            for (int u = 0; u < PIECE_NT; ++u) piece_and_term<NW, TWN, TW0>(tocc[u], Y, (int)((pp.tcode[u] >> (2 * s)) & 3u));
+        }
+        if (s + 1 < pp.steps) piece_shift_masks<NW>(Y);
+    }
+    // (a piece cannot end before its own length: after s shifts the bits below s are zero)
+    if (pp.tlen > 0) {
+        uint32_t any = 0u;
+#pragma unroll
+        for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+            for (int w = 0; w < TWN; ++w) any |= tocc[u][w];
+        tail = tail || any != 0u;
+    }
+
+    // (3) diagonals with a body piece: piece p ending at position e sits on diagonal d = e - (p + 1) blen + 1.
+    //     dm bit b <=> some piece on diagonal b - (blen - 1)   (k <= blen - 1: no possible diagonal is lost;
+    //     p blen <= 24: the shift stays inside a word pair)
+    uint32_t dm[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dm[w] = occ[0][w];
+#pragma unroll
+    for (int p = 1; p < PIECE_NB; ++p)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) dm[w] |= piece_funnel(w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u, occ[p][w], p * pp.blen);
+    int b_first = -1, b_last = -1;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) if (dm[w] != 0u) b_first = 32 * w + atr_ctz(dm[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) if (dm[w] != 0u) b_last = 32 * w + 31 - atr_clz(dm[w]);
+
+    PieceScan S;
+    S.tail = tail;
+    S.flagged = tail || b_first >= 0;
+    S.j_s = 0; S.j_e = 0;
+    if (b_first >= 0) {
+        const int d_min = b_first - (pp.blen - 1), d_max = b_last - (pp.blen - 1);
+        // a traceback through a piece on diagonal d leaves row 0 at a column >= d - k and passes row mf at a column
+        // <= mf + d + k; + T: the bases filter_decide compares with the adapter's tail rows (NARROW mode).
+        // If mf + T + d_max + k >= n a last-column cell of a row beyond the pieces' rows is possible: the window
+        // then ends at n anyway and the last column is evaluated.
+        S.j_s = atr_max(0, d_min - k);
+        S.j_e = atr_min(n, mf + d_max + k + T);
+    }
+    if (tail) {
+        S.j_s = b_first >= 0 ? atr_min(S.j_s, atr_max(0, n - pp.tail_cols)) : atr_max(0, n - pp.tail_cols);
+        S.j_e = n;
+    }
+    return S;
+}
+
+// ---- planes -> 4-bit codes ------------------------------------------------------------------------------
+// spread[t][b]: bit i of the byte b at bit 4 i + t.  The nibble dword of eight bases = the OR of the four
+// planes' bytes looked up in the four tables.
+inline void piece_spread_tables(uint32_t (*tab)[256]) {
+    for (int t = 0; t < 4; ++t)
+        for (int b = 0; b < 256; ++b) {
+            uint32_t v = 0;
+            for (int i = 0; i < 8; ++i) if (b & (1 << i)) v |= 1u << (4 * i + t);
+            tab[t][b] = v;
+        }
+}
+// byte q (0 .. 3) of the four plane words -> the dword of the eight 4-bit codes
+ATR_DEV uint32_t piece_nibbles(const uint32_t (*spread)[256], uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int q) {
+    return spread[0][(p0 >> (8 * q)) & 255u] | spread[1][(p1 >> (8 * q)) & 255u] |
+           spread[2][(p2 >> (8 * q)) & 255u] | spread[3][(p3 >> (8 * q)) & 255u];
+}
+
+#ifndef ATR_HOST_EMU
+// the four tables in LDS, filled by the whole block (256 threads; __syncthreads() afterwards)
+__device__ __forceinline__ void piece_spread_fill(uint32_t (*tab)[256]) {
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+        const int t = i >> 8, b = i & 255;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v |= (uint32_t)((b >> k) & 1) << (4 * k + t);
+        tab[t][b] = v;
+    }
+}
+#endif
+
+// ---- reads in the plane64 layout, for the DP kernels ------------------------------------------------------
+// chunk c of read r: four plane words at packed[((r >> 6) nchunks + c) 64 + (r & 63)] (uint4).
+// The nibble dword z8 (bases 8 z8 + 1 ..) of a read; 0 beyond the read.
+ATR_DEV uint32_t read_dword_planes(const uint32_t *q4, int nchunks, int z8, const uint32_t (*spread)[256]) {
+    if (z8 < 0 || z8 >= nchunks * 4) return 0u;
+    const uint32_t *c = q4 + (size_t)(z8 >> 2) * 256;                // (lane's chunk: 64 lanes x 4 dwords apart)
+    return piece_nibbles(spread, c[0], c[1], c[2], c[3], z8 & 3);
+}
+
+// band_stage (filter_core.hpp) for a plane64 read: the bases dlo + 1 .. as dwords of eight codes, re-aligned to the
+// band start.  q4: the lane's first chunk.
+ATR_DEV void band_stage_planes(const uint32_t *q4, int nchunks, int dlo, uint32_t *ns, int nss, const uint32_t (*spread)[256],
+                               int ndw = BAND_STREAM) {
+    const int z0 = dlo >> 3;
+    const uint32_t sh = 4u * (uint32_t)(dlo & 7);
+    uint32_t raw[BAND_STREAM + 1];
+#pragma unroll
+    for (int k = 0; k <= BAND_STREAM; ++k) raw[k] = k <= ndw ? read_dword_planes(q4, nchunks, z0 + k, spread) : 0u;
+#pragma unroll
+    for (int k = 0; k < BAND_STREAM; ++k)
+        if (k < ndw) ns[(size_t)k * nss] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
+}
+
+}  // namespace atr
+#endif

@@ -1,0 +1,347 @@
+// piece_kernels.hip -- the two-pass pre-pass on plane64 reads (piece_core.hpp) and its driver:
+//
+//   P1  piece_filter_kernel<NW>   pass A over every tile (pieces, 32 positions per op), pass B over the flagged
+//                                 reads' windows (a per-wave LDS queue, one task per lane); resolved reads get their
+//                                 record, the others go into the block's list of (read, window word); the few reads
+//                                 whose hits need more than PIECE_NARROW columns go into a global list
+//   P1b piece_wide_kernel<NW>     the full bit-vector sweep of the listed reads, 64 to a wave
+//   K2  scan_bins / scan_total    (locate_fast.hpp, unchanged)
+//   P3  piece_scatter_kernel      the block's list -> the bins of `order`
+//   K4a / K4                      band_kernel / window_kernel<.., PLANES>: the exact DP, reading plane64
+//
+// Same records as the one-pass pipeline (filter_kernels.hip) and as the full sweep; tests/test_gpu_locate.py
+// compares all three on every size.
+#include "locate_fast.hpp"
+
+namespace atr {
+
+void launch_fast_scan(FastWork wk, hipStream_t st);                              // filter_kernels.hip
+int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes);
+
+constexpr int PIECE_QF = 10;                        // queue fields per task: read, meta, 4 planes x 2 words
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const int lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+
+// The record of a resolved read / the list entry of an unresolved one.  `active`: this lane holds a decided read.
+__device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww, const uint32_t (&rec)[4], int m, uint4 *out,
+                                           uint2 *list, uint32_t *s_lcur, uint32_t *s_hist) {
+    const bool open = active && window_valid(ww);
+    if (active && !open) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    const uint64_t om = __ballot(open);
+    if (om != 0ull) {                                            // wave-uniform
+        uint32_t base = 0u;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(s_lcur, (uint32_t)__popcll(om));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (open) {
+            list[base + (uint32_t)__popcll(om & lanemask_lt())] = make_uint2((uint32_t)r, ww);
+            atomicAdd(&s_hist[window_bin(ww, m, true)], 1u);
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
+                                                           const uint4 *__restrict__ planes, long long nreads, int n,
+                                                           uint4 *__restrict__ out, FastWork wk) {
+    __shared__ uint2 s_peq[16];
+    __shared__ uint32_t s_spread[4][256];
+    __shared__ uint32_t s_hist[FILTER_BINS];
+    __shared__ uint32_t s_lcur;
+    __shared__ uint4 s_stage[4][NW][64];                          // a tile's planes, [word][lane]; pass B's nibble scratch
+    __shared__ uint32_t s_queue[4][PIECE_QF][64];
+    __shared__ uint32_t s_wide[4][64];
+    const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
+    if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
+    if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_lcur = 0;
+    piece_spread_fill(s_spread);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int mf = fp.rows, T = u.m - mf;
+    const uint32_t kreg = (uint32_t)u.k;
+    const long long ntiles = (nreads + 63) >> 6;
+    long long t0, t1;
+    block_tiles(ntiles, t0, t1, wk.nused);
+    uint2 *list = wk.tmp + t0 * 64;                               // this block's list: at most one entry per read it owns
+    uint4 (*stage)[64] = s_stage[wave];
+    uint32_t (*queue)[64] = s_queue[wave];
+    uint32_t *nibs = (uint32_t *)stage;                           // pass B: the task's eight nibble dwords, [dword][lane]
+    const uint64_t lt = lanemask_lt();
+
+    // ---- pass B: one queued task per lane (lane < count) ---------------------------------------------------
+    auto pass_b = [&](int count) {
+        const bool act = lane < count;
+        const long long r = (long long)queue[0][lane];
+        const uint32_t meta = queue[1][lane];
+        const int j_e = act ? (int)(meta & 1023u) : 0, need = act ? (int)(meta >> 10) : 0;
+        uint32_t wp[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wp[q][0] = queue[2 + 2 * q][lane]; wp[q][1] = queue[3 + 2 * q][lane]; }
+        const int W = min(PIECE_WINDOW, (wave_max_i32(need) + 7) & ~7);          // columns swept, a multiple of eight (<= PIECE_NARROW)
+        const int dw0 = 8 - (W >> 3);                                          // first of the eight window dwords swept
+        uint32_t nb[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            nb[d] = 0u;
+            if (d < dw0) continue;                                             // wave-uniform
+            nb[d] = piece_nibbles(s_spread, wp[0][d >> 2], wp[1][d >> 2], wp[2][d >> 2], wp[3][d >> 2], d & 3);
+            if (T > 0) nibs[d * 64 + lane] = nb[d];                              // (wave-uniform: NARROW mode compares the tail rows)
+        }
+        FilterState F;
+        filter_init(F, u, mf);
+        uint2 ea[8], eb[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            if (d < dw0) continue;                                             // wave-uniform
+            uint2 (&e)[8] = (d & 1) ? eb : ea;
+            if (d == dw0) fetch_peq8(s_peq, nb[d], e);
+            if (d + 1 < 8) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);     // one dword ahead of the columns that use it
+#pragma unroll
+            for (int b = 0; b < 8; ++b) filter_step<false>(F, e[b].x, e[b].y, kreg);
+            if (d == 3) filter_fold(F, j_e - 32, mf, kreg);                           // 32 columns at most between two folds
+        }
+        filter_fold(F, j_e, mf, kreg);
+        uint32_t rec[4];
+        // the T bases after column jp: window position jp - (j_e - 64), eight bases per dword
+        const auto tm = [&](int jp) {
+            const int rp = max(0, jp - (j_e - PIECE_WINDOW));
+            const uint32_t lo = nibs[min(rp >> 3, 7) * 64 + lane], hi = (rp >> 3) + 1 < 8 ? nibs[((rp >> 3) + 1) * 64 + lane] : 0u;
+            const uint32_t sh = 4u * (uint32_t)(rp & 7);
+            const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+            const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
+            const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
+            const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
+            return fp.and_mode ? nz == ones : nz == 0u;
+        };
+        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n);
+        piece_emit(act, r, ww, rec, u.m, out, list, &s_lcur, s_hist);
+    };
+
+    // the reads that need the full sweep: listed per wave, moved to the global list 64 at a time
+    auto flush_wide = [&](int count) {
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(wk.nwide, (uint32_t)count);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < count) wk.wide[base + lane] = s_wide[wave][lane];
+    };
+
+    int qn = 0, wn = 0;                                           // tasks queued / reads listed (wave-uniform)
+    for (long long tile = t0 + wave; tile < t1; tile += 4) {
+        const long long r = tile * 64 + lane;
+        const bool live = r < nreads;
+        // ---- pass A ----
+        uint32_t pl[NW][4];
+        const uint4 *tp = planes + (size_t)tile * NW * 64 + lane;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint4 v = tp[(size_t)w * 64];
+            pl[w][0] = v.x; pl[w][1] = v.y; pl[w][2] = v.z; pl[w][3] = v.w;
+            stage[w][lane] = v;
+        }
+        uint32_t twp[4];                                          // the last 32 positions of every plane
+        {
+            const int sh = n & 31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                twp[q] = sh == 0 ? pl[NW - 1][q] : __builtin_amdgcn_alignbit(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, (uint32_t)sh);
+        }
+        const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
+        const bool flagged = live && S.flagged;
+        const int need = S.j_e - S.j_s;
+        const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
+        if (live && !flagged) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);          // None
+        // the 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e)
+        uint32_t wp[4][2];
+        {
+            const int b0 = S.j_e - PIECE_WINDOW, w0 = b0 >> 5;                   // floor: -2 .. NW - 2
+            const uint32_t sh = (uint32_t)(b0 & 31);
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            const uint4 x0 = (w0 >= 0 && w0 < NW) ? stage[w0][lane] : z;
+            const uint4 x1 = (w0 + 1 >= 0 && w0 + 1 < NW) ? stage[w0 + 1][lane] : z;
+            const uint4 x2 = (w0 + 2 >= 0 && w0 + 2 < NW) ? stage[w0 + 2][lane] : z;
+            wp[0][0] = __builtin_amdgcn_alignbit(x1.x, x0.x, sh); wp[0][1] = __builtin_amdgcn_alignbit(x2.x, x1.x, sh);
+            wp[1][0] = __builtin_amdgcn_alignbit(x1.y, x0.y, sh); wp[1][1] = __builtin_amdgcn_alignbit(x2.y, x1.y, sh);
+            wp[2][0] = __builtin_amdgcn_alignbit(x1.z, x0.z, sh); wp[2][1] = __builtin_amdgcn_alignbit(x2.z, x1.z, sh);
+            wp[3][0] = __builtin_amdgcn_alignbit(x1.w, x0.w, sh); wp[3][1] = __builtin_amdgcn_alignbit(x2.w, x1.w, sh);
+        }
+        const uint32_t meta = (uint32_t)S.j_e | ((uint32_t)need << 10);
+        // ---- queue the narrow lanes; 64 tasks -> pass B ----
+        {
+            const uint64_t nm = __ballot(narrow);
+            const int cnt = (int)__popcll(nm), rank = (int)__popcll(nm & lt);
+            const int room = 64 - qn;
+            const auto put = [&](int slot) {
+                queue[0][slot] = (uint32_t)r; queue[1][slot] = meta;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { queue[2 + 2 * q][slot] = wp[q][0]; queue[3 + 2 * q][slot] = wp[q][1]; }
+            };
+            if (narrow && rank < room) put(qn + rank);
+            if (cnt >= room) {                                                // wave-uniform
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                pass_b(64);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (narrow && rank >= room) put(rank - room);
+                qn = cnt - room;
+            } else {
+                qn += cnt;
+            }
+        }
+        {
+            const uint64_t wm = __ballot(wide);
+            if (wm != 0ull) {                                                 // wave-uniform, rare
+                const int cnt = (int)__popcll(wm), rank = (int)__popcll(wm & lt);
+                const int room = 64 - wn;
+                if (wide && rank < room) s_wide[wave][wn + rank] = (uint32_t)r;
+                if (cnt >= room) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    flush_wide(64);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    if (wide && rank >= room) s_wide[wave][rank - room] = (uint32_t)r;
+                    wn = cnt - room;
+                } else {
+                    wn += cnt;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (qn > 0) pass_b(qn);
+    if (wn > 0) flush_wide(wn);
+    __syncthreads();
+    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] = s_hist[threadIdx.x];
+    if (threadIdx.x == 0) wk.lcount[blockIdx.x] = s_lcur;
+}
+
+// P1b: the full sweep of the listed reads (hits that do not fit a pass-B window), one read per lane, gathered by
+// index.  An unresolved read goes into the list of the block that owns its tile (global atomics: ~1 % of the reads).
+template <int NW>
+__global__ __launch_bounds__(256) void piece_wide_kernel(const LocateParams p, const FilterParams fp, const uint4 *__restrict__ planes,
+                                                         long long nreads, int n, uint4 *__restrict__ out, FastWork wk) {
+    __shared__ uint2 s_peq[16];
+    __shared__ uint32_t s_spread[4][256];
+    const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
+    if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
+    piece_spread_fill(s_spread);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int mf = fp.rows, T = u.m - mf;
+    const uint32_t kreg = (uint32_t)u.k;
+    const long long total = (long long)*wk.nwide;
+    const long long ntiles = (nreads + 63) >> 6, per = (ntiles + wk.nused - 1) / wk.nused;      // block_tiles() of P1
+    for (long long base = ((long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 64; base < total;
+         base += (long long)gridDim.x * 256) {
+        const bool act = base + lane < total;
+        const long long r = act ? (long long)wk.wide[base + lane] : 0;
+        const uint4 *tp = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);
+        FilterState F;
+        filter_init(F, u, mf);
+        int j = 0;
+        for (int c = 0; c < NW; ++c) {
+            const uint4 v = tp[(size_t)c * 64];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                if (j >= n) break;                                             // wave-uniform
+                uint2 e[8];
+                fetch_peq8(s_peq, piece_nibbles(s_spread, v.x, v.y, v.z, v.w, d), e);
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (j + b < n) filter_step<false>(F, e[b].x, e[b].y, kreg);
+                j += 8;
+            }
+            filter_fold(F, min(j, n), mf, kreg);
+        }
+        uint32_t rec[4];
+        const auto tm = [&](int jp) {
+            const uint32_t lo = read_dword_planes((const uint32_t *)tp, NW, jp >> 3, s_spread);
+            const uint32_t hi = read_dword_planes((const uint32_t *)tp, NW, (jp >> 3) + 1, s_spread);
+            const uint32_t sh = 4u * (uint32_t)(jp & 7);
+            const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+            const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
+            const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
+            const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
+            return fp.and_mode ? nz == ones : nz == 0u;
+        };
+        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true);
+        if (act) {
+            if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+            else {
+                const long long owner = (r >> 6) / per;
+                const uint32_t slot = atomicAdd(&wk.lcount[owner], 1u);
+                wk.tmp[owner * per * 64 + slot] = make_uint2((uint32_t)r, ww);
+                atomicAdd(&wk.counts[(size_t)owner * FILTER_BINS + window_bin(ww, u.m, true)], 1u);
+            }
+        }
+    }
+}
+
+// P3: a block's list of (read, window word) -> the bins of `order` (offsets from K2's scan, an LDS cursor per bin)
+__global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, int m, FastWork wk) {
+    __shared__ uint32_t s_cur[FILTER_BINS];
+    if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] = fast_slot0(wk, threadIdx.x);
+    __syncthreads();
+    const long long ntiles = (nreads + 63) >> 6;
+    long long t0, t1;
+    block_tiles(ntiles, t0, t1, wk.nused);
+    const uint2 *list = wk.tmp + t0 * 64;
+    const uint32_t count = wk.lcount[blockIdx.x];
+    for (uint32_t i = threadIdx.x; i < count; i += 256) {
+        const uint2 e = list[i];
+        wk.order[atomicAdd(&s_cur[window_bin(e.y, m, true)], 1u)] = e;
+    }
+}
+
+constexpr int PIECE_WIDE_BLOCKS = 1024;
+template <int NW>
+static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
+                                long long nreads, int max_len, uint4 *out, const FastWork &wk, hipStream_t st) {
+    hipLaunchKernelGGL((piece_filter_kernel<NW>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, nreads, max_len, out, wk);
+    const unsigned wide_blocks = (unsigned)std::max<long long>(1, std::min<long long>(PIECE_WIDE_BLOCKS, (nreads + 255) / 256));
+    hipLaunchKernelGGL((piece_wide_kernel<NW>), dim3(wide_blocks), dim3(256), 0, st, a->p, fp, planes, nreads, max_len, out, wk);
+}
+
+// Does the two-pass pre-pass take this aligner on equal-length reads of max_len bases?  (+ its parameters)
+bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out) {
+    if (!a->filterable || max_len < 1) return false;
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    PieceParams pp;
+    if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
+                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return false;
+    const int nw = (max_len + 31) / 32;
+    if (!(nw == 3 || nw == 4 || nw == 5 || nw == 6 || nw == 8 || nw == 10)) return false;      // instantiated word counts
+    if (fp_out) *fp_out = fp;
+    if (pp_out) *pp_out = pp;
+    return true;
+}
+
+constexpr int PIECE_BLOCKS = 2048;                   // persistent grid: a wave's queue wants many tiles
+
+int launch_locate_planes(const atr_aligner *a, const uint4 *planes, long long nreads, int max_len, uint4 *out, void *work,
+                         hipStream_t st) {
+    FilterParams fp;
+    PieceParams pp;
+    if (!piece_applies(a, max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
+    FastWork wk = fast_carve(work, nreads);
+    wk.nused = (int)std::max<long long>(1, std::min<long long>(PIECE_BLOCKS, ((nreads + 63) / 64 + 3) / 4));
+    wk.lpw = nreads <= 8192 ? 0 : 64;
+    if (hipMemsetAsync(wk.nwide, 0, sizeof(uint32_t), st) != hipSuccess) return (int)hipGetLastError();
+    const int nw = (max_len + 31) / 32;
+    switch (nw) {
+    case 3: launch_piece_filter<3>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    case 4: launch_piece_filter<4>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    case 5: launch_piece_filter<5>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    case 6: launch_piece_filter<6>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    case 8: launch_piece_filter<8>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    default: launch_piece_filter<10>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    }
+    launch_fast_scan(wk, st);
+    hipLaunchKernelGGL(piece_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m, wk);
+    return launch_fast_dp(a, planes, nullptr, nreads, nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true);
+}
+
+}  // namespace atr

@@ -137,6 +137,98 @@ def check_filtered_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, m_ra
     return total
 
 
+def piece_reads(rng, ref, n, count, e):
+    """Equal-length reads (n bases) that press on every rule of the two-pass pre-pass (piece_core.hpp): the
+    adapter at every distance from the read end, whole and cut, with 0 .. k + 1 edits placed so that they spare
+    one piece, kill several or sit between two pieces; single pieces without the rest (chance hits); two
+    occurrences far apart (windows of more than PIECE_NARROW columns); low-complexity reads and N runs."""
+    m, reads = len(ref), []
+    k = int(e * m)
+
+    def edited(s, edits):
+        s = list(s)
+        for _ in range(edits):
+            if not s:
+                break
+            i, kind = rng.randrange(len(s)), rng.random()
+            if kind < 0.5:
+                s[i] = rng.choice("ACGT")
+            elif kind < 0.75:
+                del s[i]
+            else:
+                s.insert(i, rng.choice("ACGT"))
+        return "".join(s)
+
+    def fit(q):
+        return (q + rseq(rng, n))[:n] if len(q) < n else q[:n]
+
+    for _ in range(count):
+        w = rng.random()
+        if w < 0.25:                                      # the adapter (edited) ending anywhere, incl. cut by the read end
+            a = edited(ref, rng.randint(0, k + 1))
+            pos = rng.randint(0, n)
+            q = rseq(rng, pos) + a + rseq(rng, n)
+        elif w < 0.45:                                    # partial adapter exactly at the read end, every overlap length
+            cut = rng.randint(1, m)
+            a = edited(ref[:cut], rng.choice([0, 0, 1, 1, 2, 3]))
+            q = rseq(rng, max(0, n - len(a))) + a
+            q = q[len(q) - n:] if len(q) > n else q
+        elif w < 0.55:                                    # one piece only
+            L = rng.choice([5, 6, 7, 8])
+            i = rng.randrange(0, max(1, m - L))
+            pos = rng.randint(0, n)
+            q = rseq(rng, pos) + ref[i:i + L] + rseq(rng, n)
+        elif w < 0.7:                                     # two occurrences: the first broken or not, the second somewhere else
+            a1 = edited(ref, rng.randint(0, k + 2))
+            a2 = edited(ref[:rng.randint(3, m)], rng.randint(0, 2))
+            q = rseq(rng, rng.randint(0, 30)) + a1 + rseq(rng, rng.randint(0, 60)) + a2
+        elif w < 0.8:
+            q = rng.choice(["A", "C", "G", "T", "N", "AC", ref[:3], ref[:5] + "N"]) * n
+        elif w < 0.9:                                     # soft edits of the whole read
+            q = mutate(rng, rseq(rng, rng.randint(0, n)) + ref, 0.04, "ACGTN")
+        else:
+            q = rseq(rng, n, "ACGTN" if rng.random() < 0.3 else "ACGT")
+        reads.append(fit(q))
+    return reads
+
+
+def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=200, lengths=(70, 100, 128, 150, 160, 180, 250, 300)):
+    """The two-pass pre-pass on plane64 batches (atr_locate_planes_batch) against the other kernel families and the
+    oracle, on aligners inside its envelope (and a few outside: pack(layout="plane64") must refuse those)."""
+    import numpy as np
+    rng = random.Random(seed)
+    total = refused = 0
+    for _ in range(rounds):
+        m = rng.randint(20, 40)
+        ref = rseq(rng, m, "ACGT" if rng.random() < 0.9 else "ACGTN")
+        flags = rng.choice([14, 14, 14, 10])
+        e = rng.choice([0, 0.03, 0.05, 0.08, 0.1, 0.1, 0.1, 0.12])
+        ic = rng.choice([1, 1, 1, 2, 100000])
+        mo = rng.choice([1, 3, 3, 5, 12, 25])
+        wr, wq = rng.random() < 0.2, rng.random() < 0.25
+        try:
+            al = Aligner(ref, e, flags, wr, wq, mo, ic)
+        except unsupported_exc:
+            continue
+        n = rng.choice(lengths)
+        reads = piece_reads(rng, ref, n, count, e)
+        mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(len(reads), n).copy()
+        try:
+            planes = al.pack(mat, layout="plane64")
+        except unsupported_exc:
+            refused += 1
+            continue
+        assert planes.layout == "plane64"
+        got = al.locate_batch(planes).tuples()
+        tiles = al.pack(mat, layout="tile64")
+        assert got == al.locate_batch(tiles, path="full").tuples()
+        assert got == al.locate_batch(tiles, path="filtered").tuples()
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, q, e, flags, wr, wq, mo, ic, g)
+            total += 1
+    return total, refused
+
+
 def check_uniform_partial_overlaps(Aligner, oracle, unsupported_exc, seed, rounds, count=400,
                                    flag_choices=(14, 14, 15, 10), short=False):
     """Equal-length batches full of partial adapter occurrences at the read end (the row-binned

@@ -16,7 +16,7 @@ _CPPS = [os.path.join(_HERE, f) for f in ("emu_locate.cpp", "emu_insert.cpp", "e
 _SRCS = _CPPS + [
     os.path.join(_ROOT, "atropos_amd", "csrc", f)
     for f in ("locate_core.hpp", "aligner_host.hpp", "insert_core.hpp", "insert_host.hpp", "misc_core.hpp",
-              "filter_core.hpp", "fastq_core.hpp", "pairs_core.hpp", "pairs_fast_core.hpp", "linked_core.hpp", "linked_host.hpp")] + [
+              "filter_core.hpp", "piece_core.hpp", "fastq_core.hpp", "pairs_core.hpp", "pairs_fast_core.hpp", "linked_core.hpp", "linked_host.hpp")] + [
     os.path.join(_ROOT, "include", "atropos_hip.h")]
 
 
@@ -241,6 +241,17 @@ class EmuBackend(object):
         if nreads:
             _check(self.lib.emu_locate_batch(h, _ptr(packed), _ptr(lens), nreads, max_len, _ptr(out), LOCATE_PATHS[path]),
                    "atr_locate_batch")
+        return out
+
+    def locate_planes_applies(self, h, max_len):
+        self.lib.emu_locate_planes_all_widths.argtypes = [C.c_void_p, C.c_int]
+        return bool(self.lib.emu_locate_planes_all_widths(h, int(max_len)))
+
+    def locate_planes_batch(self, h, planes, nreads, max_len):
+        out = torch.zeros((nreads, 8), dtype=torch.int16)
+        if nreads:
+            self.lib.emu_locate_planes_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+            _check(self.lib.emu_locate_planes_batch(h, _ptr(planes), nreads, max_len, _ptr(out)), "atr_locate_planes_batch")
         return out
 
     def linked_create(self, specs):

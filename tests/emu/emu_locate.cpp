@@ -12,6 +12,7 @@
 
 #include "aligner_host.hpp"
 #include "filter_core.hpp"
+#include "piece_core.hpp"
 #include "linked_host.hpp"
 #include "wave_core.hpp"
 
@@ -235,9 +236,9 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         filter_init(F, u, fp.rows);
         for (int j = 1; j <= n; ++j) {
             const uint64_t eq = fp.peq[read_code(packed, nchunks, r, j)];
-            if (fp.rows > 32) filter_step<true>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
-            else filter_step<false>(F, u, (uint32_t)eq, (uint32_t)(eq >> 32), filter_column_tag(u, fp.rows, j));
-            if ((j & 31) == 0 || j == n) filter_fold(F, j);        // as the kernel: once per 32-column chunk
+            if (fp.rows > 32) filter_step<true>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
+            else filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
+            if ((j & 31) == 0 || j == n) filter_fold(F, j, fp.rows, (uint32_t)u.k);        // as the kernel: once per 32-column chunk
         }
         uint32_t rec[4];
         const uint32_t *q = packed + (((size_t)(r >> 6) * nchunks) * 64 + (r & 63)) * 4;
@@ -247,6 +248,93 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
         else bins[window_bin(ww, u.m, lens == nullptr || ragged_rows_bins(u.sr))].push_back((uint32_t)r);
     }
     emu_dp_stage<MT, NOINDEL>(a, packed, lens, nchunks, max_len, out, win, bins, nullptr);
+}
+
+// The two-pass pre-pass on plane64 reads (piece_kernels.hip): pass A per read (piece_scan, the product's own
+// source), pass B as a windowed sweep with the product's filter_step / filter_decide_tm, then emu_dp_stage on the
+// reads it leaves open (from a tile64 copy of the planes).  The window length varies with the read number the way
+// it varies with a wave's other lanes on the GPU: the records must not depend on it.
+static long long g_piece_stats[6], g_piece_need[12];   // need histogram, 8 columns per bin      // reads, flagged, read-end condition, wide, window columns swept, open after pass B
+template <int NW>
+static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const PieceParams &pp, const uint32_t *planes,
+                               const uint32_t *nib, long long r, int n, uint32_t rec[4]) {
+    uint32_t pl[NW][4], twp[4];
+    for (int w = 0; w < NW; ++w)
+        for (int q = 0; q < 4; ++q) pl[w][q] = planes[((((size_t)(r >> 6) * NW) + w) * 64 + (r & 63)) * 4 + q];
+    for (int q = 0; q < 4; ++q) {
+        const int sh = n & 31;
+        twp[q] = sh == 0 ? pl[NW - 1][q] : piece_funnel(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, sh);
+    }
+    const int mf = fp.rows, T = u.m - mf;
+    const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
+    rec[0] = 0xFFFF0000u; rec[1] = rec[2] = rec[3] = 0u;
+    ++g_piece_stats[0];
+    if (!S.flagged) return 0u;
+    ++g_piece_stats[1];
+    if (S.tail) ++g_piece_stats[2];
+    ++g_piece_need[std::min(11, (S.j_e - S.j_s + 7) / 8)];
+    if (S.j_e - S.j_s > PIECE_NARROW) ++g_piece_stats[3]; else g_piece_stats[4] += (S.j_e - S.j_s + 7) & ~7;
+    const uint32_t *q = nib + (((size_t)(r >> 6) * NW) * 64 + (r & 63)) * 4;
+    const auto tm = [&](int jp) { return filter_tail_matches(fp, T, q, NW, jp); };
+    FilterState F;
+    filter_init(F, u, mf);
+    const int need = S.j_e - S.j_s;
+    if (need <= PIECE_NARROW) {
+        const int W = std::min(PIECE_WINDOW, ((need + 7) & ~7) + 8 * (int)(r % 3));
+        for (int rc = PIECE_WINDOW - W + 1; rc <= PIECE_WINDOW; ++rc) {
+            const int j = S.j_e - PIECE_WINDOW + rc;
+            const uint64_t eq = fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
+            filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
+            if (rc == 32) filter_fold(F, j, mf, (uint32_t)u.k);
+        }
+        filter_fold(F, S.j_e, mf, (uint32_t)u.k);
+        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, S.j_e == n);
+    }
+    for (int j = 1; j <= n; ++j) {
+        const uint64_t eq = fp.peq[read_code(nib, NW, r, j)];
+        filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
+        if ((j & 31) == 0 || j == n) filter_fold(F, j, mf, (uint32_t)u.k);
+    }
+    return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true);
+}
+
+template <int MT, bool NOINDEL>
+void emu_piece(const atr_aligner *a, const uint32_t *planes, const int32_t *lens, long long nreads, int nchunks,
+               int max_len, uint32_t *out) {
+    const LocateParams &p = a->p;
+    const Uniform u = make_uniform(p, MT);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    PieceParams pp;
+    if (lens || !piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
+                              a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) abort();
+    uint32_t spread[4][256];
+    piece_spread_tables(spread);
+    const long long ntiles = (nreads + 63) / 64;
+    std::vector<uint32_t> nib((size_t)ntiles * nchunks * 64 * 4);               // the tile64 twin of the planes
+    for (size_t ch = 0; ch < (size_t)ntiles * nchunks * 64; ++ch)
+        for (int d = 0; d < 4; ++d)
+            nib[ch * 4 + d] = piece_nibbles(spread, planes[ch * 4], planes[ch * 4 + 1], planes[ch * 4 + 2], planes[ch * 4 + 3], d);
+    std::vector<uint32_t> win((size_t)nreads);
+    std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
+    for (long long r = 0; r < nreads; ++r) {
+        uint32_t rec[4], ww = 0;
+        switch (nchunks) {
+            case 1: ww = emu_piece_read<1>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 2: ww = emu_piece_read<2>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 3: ww = emu_piece_read<3>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 4: ww = emu_piece_read<4>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 5: ww = emu_piece_read<5>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 6: ww = emu_piece_read<6>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 7: ww = emu_piece_read<7>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 8: ww = emu_piece_read<8>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 9: ww = emu_piece_read<9>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            default: ww = emu_piece_read<10>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+        }
+        win[r] = ww;
+        if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
+        else { bins[window_bin(ww, u.m, true)].push_back((uint32_t)r); ++g_piece_stats[5]; }
+    }
+    emu_dp_stage<MT, NOINDEL>(a, nib.data(), nullptr, nchunks, max_len, out, win, bins, nullptr);
 }
 
 typedef void (*emu_fn)(const atr_aligner *, const uint32_t *, const int32_t *, long long, int, int, uint32_t *);
@@ -265,6 +353,13 @@ emu_fn pick_mt(int idx, bool eqmode, bool noindel, bool fast, std::integer_seque
 }
 
 }  // namespace
+
+template <int... I>
+static emu_fn pick_piece(int idx, bool noindel, std::integer_sequence<int, I...>) {
+    emu_fn fn = nullptr;
+    (void)std::initializer_list<int>{(idx == I ? (fn = noindel ? &emu_piece<ROW_GRAN *(I + 1), true> : &emu_piece<ROW_GRAN *(I + 1), false>, 0) : 0)...};
+    return fn;
+}
 
 extern "C" {
 
@@ -417,7 +512,6 @@ static void emu_linked_l1(const atr_linked_set *s, const uint32_t *pk, const int
             ub.sq = true; ub.er = true;
             FilterState F;
             filter_init(F, ub, bp.rows, WIDE);
-            F.best = FILTER_BEST_NONE_SIGNED;
             const int z_first = sft >> 3;
             int jlast = 8 * z_first;
             for (int z = z_first; 8 * z < n; ++z) {
@@ -426,12 +520,11 @@ static void emu_linked_l1(const atr_linked_set *s, const uint32_t *pk, const int
                     const int j = 8 * z + b + 1;
                     if (j > n) break;
                     const uint32_t code = (w >> (4 * b)) & 15u;
-                    filter_step<WIDE, true>(F, ub, bp.peq[code][0], bp.peq[code][1], (uint32_t)j);
+                    filter_step<WIDE>(F, bp.peq[code][0], bp.peq[code][1], (uint32_t)ub.k);
                     jlast = j;
                 }
-                if ((z & 3) == 3 || 8 * (z + 1) >= n) filter_fold(F, jlast);      // as the kernel: once per 32-column chunk
+                if ((z & 3) == 3 || 8 * (z + 1) >= n) filter_fold(F, jlast, bp.rows, (uint32_t)ub.k);      // as the kernel: once per 32-column chunk
             }
-            F.best = filter_unbias_best(F.best, ub.k);
             LaneFilterParams lf;
             lf.rows = bp.rows; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
             ww = filter_decide<WIDE>(F, ub, lf, q, nchunks, n, brec, sft);
@@ -629,6 +722,40 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
     const bool fast = filtered && a->filterable && max_len > 0;
     emu_fn fn = pick_mt(idx, (a->flags & ATR_STOP_WITHIN_SEQ2) != 0, noindel, fast, std::make_integer_sequence<int, ATR_MAX_REF_LEN / ROW_GRAN>{});
     fn(a, (const uint32_t *)packed, lens, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
+    return ATR_OK;
+}
+
+// atr_locate_planes_applies / atr_locate_planes_batch (the emulation takes every word count up to 10)
+int emu_locate_planes_applies(const atr_aligner *a, int max_len) {
+    if (!a || !a->filterable || max_len < 1 || max_len > ATR_MAX_READ_LEN) return 0;
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    PieceParams pp;
+    if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
+                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return 0;
+    const int nw = (max_len + 31) / 32;
+    return (nw == 3 || nw == 4 || nw == 5 || nw == 6 || nw == 8 || nw == 10) ? 1 : 0;
+}
+int emu_locate_planes_all_widths(const atr_aligner *a, int max_len) {          // the envelope without the instantiated widths
+    if (!a || !a->filterable || max_len < 1 || max_len > 32 * PIECE_MAX_WORDS) return 0;
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    PieceParams pp;
+    return piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
+                        a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp) ? 1 : 0;
+}
+
+void emu_piece_stats(long long out[18], int reset) {
+    for (int i = 0; i < 6; ++i) { out[i] = g_piece_stats[i]; if (reset) g_piece_stats[i] = 0; }
+    for (int i = 0; i < 12; ++i) { out[6 + i] = g_piece_need[i]; if (reset) g_piece_need[i] = 0; }
+}
+
+int emu_locate_planes_batch(const atr_aligner *a, const uint8_t *planes, int64_t nreads, int max_len, int16_t *out) {
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    if (!emu_locate_planes_all_widths(a, max_len)) return ATR_ERR_UNSUPPORTED;
+    const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
+    emu_fn fn = pick_piece(idx, a->indel_cost > a->p.k, std::make_integer_sequence<int, FILTER_MAX_M / ROW_GRAN>{});
+    if (!fn) return ATR_ERR_UNSUPPORTED;
+    fn(a, (const uint32_t *)planes, nullptr, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
     return ATR_OK;
 }
 

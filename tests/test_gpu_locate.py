@@ -47,6 +47,15 @@ def test_filtered_pipeline_narrow(hip_backend, oracle):
     assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 43, 300, (33, 40), (14, 10, 6, 14)) > 30000
 
 
+def test_piece_pipeline(hip_backend, oracle):
+    """atr_locate_planes_batch (two-pass pre-pass on plane64 reads) == full sweep == filtered pipeline == oracle."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 23, 150, 300,
+                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 250, 300))
+    assert total > 20000 and refused < 80
+
+
 def test_uniform_partial_overlaps(hip_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner
@@ -107,10 +116,14 @@ def test_c2_sample_and_full_size_properties(hip_backend, oracle):
     reads = w["reads"]
     al = Aligner(w["adapter"], 0.1, 14, False, False, 3, 1)
     batch = al.pack(reads)
+    assert batch.layout == "plane64"                         # what bench.py times: the two-pass pre-pass on bit planes
     rec = al.locate_batch(batch).records
     torch.cuda.synchronize()
-    # (0) the filtered pipeline and the full sweep agree on all 10 M records
-    assert torch.equal(rec, al.locate_batch(batch, filtered=False).records)
+    # (0) the two-pass pipeline, the one-pass filtered pipeline and the full sweep agree on all 10 M records
+    tiles = al.pack(reads, layout="tile64")
+    assert torch.equal(rec, al.locate_batch(tiles, path="filtered").records)
+    assert torch.equal(rec, al.locate_batch(tiles, filtered=False).records)
+    del tiles
     # (1) slice parity
     lo = 4_321_000
     sl = reads[lo:lo + 200_000].cpu().numpy()

@@ -166,6 +166,42 @@ for col in range(2):
     ]
 add("myers column, two-cycle ops only (26 VALU)", two, 52, "myers")
 
+
+# round-4 coding of the column (filter_core.hpp, filter_step + filter_shift_out2): bitop3 + carry chains only.
+# state pv=%0 mv=%1 score=%2 hits=%3 nz=%4, temps %5 %6 %7, eq = %8, k = %9 (c), carries s[6:7] and vcc
+def new_col(st, tmp, nops=True, flags=True, sc="s[6:7]"):
+    pv, mv, score, hits, nz = st
+    xv, a, b2 = tmp
+    L = ["v_or_b32 %s, %%8, %s" % (xv, mv),
+         "v_and_b32 %s, %%8, %s" % (a, pv),
+         "v_add_u32 %s, %s, %s" % (a, a, pv),
+         "v_bitop3_b32 %s, %s, %s, %%8 bitop3:0xbe" % (a, a, pv),      # xh
+         "v_bitop3_b32 %s, %s, %s, %s bitop3:0xf1" % (b2, mv, a, pv),  # ph
+         "v_and_b32 %s, %s, %s" % (a, pv, a),                          # mh
+         "v_add_co_u32 %s, %s, %s, %s" % (b2, sc, b2, b2),
+         "v_add_co_u32 %s, vcc, %s, %s" % (a, a, a)]
+    if nops: L.append("s_nop 0")
+    L += ["v_addc_co_u32 %s, %s, 0, %s, %s" % (score, sc, score, sc),
+          "v_subbrev_co_u32 %s, vcc, 0, %s, vcc" % (score, score)]
+    if flags:
+        L += ["v_add_co_u32 %s, %s, %s, %s" % (pv, sc, score, score),      # (pv, mv are dead here: used as the unread sums)
+              "v_add_co_u32 %s, vcc, %s, %%9" % (mv, score)]
+        if nops: L.append("s_nop 0")
+        L += ["v_addc_co_u32 %s, %s, %s, %s, %s" % (hits, sc, hits, hits, sc),
+              "v_addc_co_u32 %s, vcc, %s, %s, vcc" % (nz, nz, nz)]
+    L += ["v_bitop3_b32 %s, %s, %s, %s bitop3:0xf1" % (pv, a, xv, b2),    # pv
+          "v_and_b32 %s, %s, %s" % (mv, b2, xv)]                          # mv
+    return L
+S5 = ("%0", "%1", "%2", "%3", "%4"); T3 = ("%5", "%6", "%7")
+nv = lambda L: sum(1 for x in L if x.startswith("v_"))
+L = new_col(S5, T3) * 4
+add("myers column, round-4 coding (16 VALU, 2 s_nop)", L, nv(L), "myers")
+L = new_col(S5, T3, nops=False) * 4
+add("  the same without the s_nops (hazard-unsafe: timing only)", L, nv(L), "myers")
+L = new_col(S5, T3, flags=False) * 4
+add("  the same without the two flag vectors (12 VALU)", L, nv(L), "myers")
+L = new_col(S5, T3, sc="vcc", nops=True) * 4
+add("  the same, every carry through vcc (serialised)", L, nv(L), "myers")
 # "+v"(c) needed for the two-cycle coding: c is written.  Patch: make c an in/out operand everywhere (harmless).
 out = ['// GENERATED by tools/micro/gen_valu_sparse.py -- do not edit.  Build and run on the GPU box:',
        '//   hipcc -O3 --offload-arch=gfx950 -o /tmp/valu_sparse tools/micro/valu_sparse.hip && /tmp/valu_sparse',
@@ -201,6 +237,7 @@ int main(int argc, char **argv) {
     const int n = sizeof(KS) / sizeof(KS[0]);
     printf("# SIMD cycles per VALU instruction at an assumed 2.4 GHz; columns: waves per SIMD 8 / 4 / 2 / 1\n");
     for (int i = 0; i < n; ++i) {
+        if (argc > 1 && strcmp(argv[1], KS[i].group) != 0) continue;          // ./valu_sparse myers: one group only
         const bool all = strcmp(KS[i].group, "mix") == 0 || strcmp(KS[i].group, "myers") == 0 || strcmp(KS[i].group, "special") == 0;
         const double c8 = run(KS[i].k, d, KS[i].nvalu, 8192, 256, 2048);
         if (all) {
