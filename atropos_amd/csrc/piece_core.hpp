@@ -187,27 +187,174 @@ ATR_DEV void piece_shift_masks(PieceMasks<NW> &Y) {
 // acc[i] &= Y[code][W0 + i], i < N: the code is wave-uniform, so this is a scalar branch to one of four
 // straight-line blocks (no register indexing: an indexed read costs 6 - 8 cycles, the branch overlaps with the
 // other waves' VALU work).
+#ifndef ATR_HOST_EMU
+// acc[i] &= (y0, y1, y2, y3)[code][i], i < G: one asm block with the four-way scalar branch INSIDE, so that the compiler
+// sees a straight-line update of the accumulators in place (with the branch in C++ it copies the accumulators
+// into fresh registers in front of every case: five v_mov per five v_and).
+template <int G>
+__device__ __forceinline__ void piece_and_group(uint32_t *a, const uint32_t *y0, const uint32_t *y1, const uint32_t *y2,
+                                                const uint32_t *y3, int code) {
+    static_assert(G >= 1 && G <= 5, "at most 5 accumulators + 20 masks + the code: 26 asm operands");
+    if constexpr (G == 1) {
+        asm volatile("s_cmp_lt_u32 %5, 2\n\t"
+                     "s_cbranch_scc1 .Lpt01_%=\n\t"
+                     "s_cmp_eq_u32 %5, 2\n\t"
+                     "s_cbranch_scc1 .Lpt2_%=\n\t"
+                     "v_and_b32 %0, %0, %4\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt2_%=:\n\t"
+                     "v_and_b32 %0, %0, %3\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt01_%=:\n\t"
+                     "s_cmp_eq_u32 %5, 0\n\t"
+                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     "v_and_b32 %0, %0, %2\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt0_%=:\n\t"
+                     "v_and_b32 %0, %0, %1\n\t"
+                     ".Lptend_%=:"
+                     : "+v"(a[0])
+                     : "v"(y0[0]), "v"(y1[0]), "v"(y2[0]), "v"(y3[0]), "s"(code) : "scc");
+    }
+    else if constexpr (G == 2) {
+        asm volatile("s_cmp_lt_u32 %10, 2\n\t"
+                     "s_cbranch_scc1 .Lpt01_%=\n\t"
+                     "s_cmp_eq_u32 %10, 2\n\t"
+                     "s_cbranch_scc1 .Lpt2_%=\n\t"
+                     "v_and_b32 %0, %0, %8\n\t"
+                     "v_and_b32 %1, %1, %9\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt2_%=:\n\t"
+                     "v_and_b32 %0, %0, %6\n\t"
+                     "v_and_b32 %1, %1, %7\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt01_%=:\n\t"
+                     "s_cmp_eq_u32 %10, 0\n\t"
+                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     "v_and_b32 %0, %0, %4\n\t"
+                     "v_and_b32 %1, %1, %5\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt0_%=:\n\t"
+                     "v_and_b32 %0, %0, %2\n\t"
+                     "v_and_b32 %1, %1, %3\n\t"
+                     ".Lptend_%=:"
+                     : "+v"(a[0]), "+v"(a[1])
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y1[0]), "v"(y1[1]), "v"(y2[0]), "v"(y2[1]), "v"(y3[0]), "v"(y3[1]), "s"(code) : "scc");
+    }
+    else if constexpr (G == 3) {
+        asm volatile("s_cmp_lt_u32 %15, 2\n\t"
+                     "s_cbranch_scc1 .Lpt01_%=\n\t"
+                     "s_cmp_eq_u32 %15, 2\n\t"
+                     "s_cbranch_scc1 .Lpt2_%=\n\t"
+                     "v_and_b32 %0, %0, %12\n\t"
+                     "v_and_b32 %1, %1, %13\n\t"
+                     "v_and_b32 %2, %2, %14\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt2_%=:\n\t"
+                     "v_and_b32 %0, %0, %9\n\t"
+                     "v_and_b32 %1, %1, %10\n\t"
+                     "v_and_b32 %2, %2, %11\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt01_%=:\n\t"
+                     "s_cmp_eq_u32 %15, 0\n\t"
+                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     "v_and_b32 %0, %0, %6\n\t"
+                     "v_and_b32 %1, %1, %7\n\t"
+                     "v_and_b32 %2, %2, %8\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt0_%=:\n\t"
+                     "v_and_b32 %0, %0, %3\n\t"
+                     "v_and_b32 %1, %1, %4\n\t"
+                     "v_and_b32 %2, %2, %5\n\t"
+                     ".Lptend_%=:"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "s"(code) : "scc");
+    }
+    else if constexpr (G == 4) {
+        asm volatile("s_cmp_lt_u32 %20, 2\n\t"
+                     "s_cbranch_scc1 .Lpt01_%=\n\t"
+                     "s_cmp_eq_u32 %20, 2\n\t"
+                     "s_cbranch_scc1 .Lpt2_%=\n\t"
+                     "v_and_b32 %0, %0, %16\n\t"
+                     "v_and_b32 %1, %1, %17\n\t"
+                     "v_and_b32 %2, %2, %18\n\t"
+                     "v_and_b32 %3, %3, %19\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt2_%=:\n\t"
+                     "v_and_b32 %0, %0, %12\n\t"
+                     "v_and_b32 %1, %1, %13\n\t"
+                     "v_and_b32 %2, %2, %14\n\t"
+                     "v_and_b32 %3, %3, %15\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt01_%=:\n\t"
+                     "s_cmp_eq_u32 %20, 0\n\t"
+                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     "v_and_b32 %0, %0, %8\n\t"
+                     "v_and_b32 %1, %1, %9\n\t"
+                     "v_and_b32 %2, %2, %10\n\t"
+                     "v_and_b32 %3, %3, %11\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt0_%=:\n\t"
+                     "v_and_b32 %0, %0, %4\n\t"
+                     "v_and_b32 %1, %1, %5\n\t"
+                     "v_and_b32 %2, %2, %6\n\t"
+                     "v_and_b32 %3, %3, %7\n\t"
+                     ".Lptend_%=:"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y2[3]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "v"(y3[3]), "s"(code) : "scc");
+    }
+    else if constexpr (G == 5) {
+        asm volatile("s_cmp_lt_u32 %25, 2\n\t"
+                     "s_cbranch_scc1 .Lpt01_%=\n\t"
+                     "s_cmp_eq_u32 %25, 2\n\t"
+                     "s_cbranch_scc1 .Lpt2_%=\n\t"
+                     "v_and_b32 %0, %0, %20\n\t"
+                     "v_and_b32 %1, %1, %21\n\t"
+                     "v_and_b32 %2, %2, %22\n\t"
+                     "v_and_b32 %3, %3, %23\n\t"
+                     "v_and_b32 %4, %4, %24\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt2_%=:\n\t"
+                     "v_and_b32 %0, %0, %15\n\t"
+                     "v_and_b32 %1, %1, %16\n\t"
+                     "v_and_b32 %2, %2, %17\n\t"
+                     "v_and_b32 %3, %3, %18\n\t"
+                     "v_and_b32 %4, %4, %19\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt01_%=:\n\t"
+                     "s_cmp_eq_u32 %25, 0\n\t"
+                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     "v_and_b32 %0, %0, %10\n\t"
+                     "v_and_b32 %1, %1, %11\n\t"
+                     "v_and_b32 %2, %2, %12\n\t"
+                     "v_and_b32 %3, %3, %13\n\t"
+                     "v_and_b32 %4, %4, %14\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt0_%=:\n\t"
+                     "v_and_b32 %0, %0, %5\n\t"
+                     "v_and_b32 %1, %1, %6\n\t"
+                     "v_and_b32 %2, %2, %7\n\t"
+                     "v_and_b32 %3, %3, %8\n\t"
+                     "v_and_b32 %4, %4, %9\n\t"
+                     ".Lptend_%=:"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y0[4]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y1[4]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y2[3]), "v"(y2[4]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "v"(y3[3]), "v"(y3[4]), "s"(code) : "scc");
+    }
+}
+#endif
+
 template <int NW, int N, int W0>
 ATR_DEV void piece_and_term(uint32_t (&acc)[N], const PieceMasks<NW> &Y, int code) {
     static_assert(W0 + N <= NW, "words of the read");
-    switch (code) {
-    case 0:
-#pragma unroll
-        for (int i = 0; i < N; ++i) acc[i] &= Y.y[0][W0 + i];
-        break;
-    case 1:
-#pragma unroll
-        for (int i = 0; i < N; ++i) acc[i] &= Y.y[1][W0 + i];
-        break;
-    case 2:
-#pragma unroll
-        for (int i = 0; i < N; ++i) acc[i] &= Y.y[2][W0 + i];
-        break;
-    default:
-#pragma unroll
-        for (int i = 0; i < N; ++i) acc[i] &= Y.y[3][W0 + i];
-        break;
-    }
+#ifdef ATR_HOST_EMU
+    for (int i = 0; i < N; ++i) acc[i] &= Y.y[code][W0 + i];
+#else
+    // groups of at most five words (the asm operand limit)
+    constexpr int G0 = N <= 5 ? N : (N + 1) / 2, G1 = N - G0;
+    static_assert(G0 <= 5 && G1 <= 5, "reads of up to 320 bases");
+    piece_and_group<G0>(&acc[0], &Y.y[0][W0], &Y.y[1][W0], &Y.y[2][W0], &Y.y[3][W0], code);
+    if constexpr (G1 > 0) piece_and_group<G1>(&acc[G0], &Y.y[0][W0 + G0], &Y.y[1][W0 + G0], &Y.y[2][W0 + G0], &Y.y[3][W0 + G0], code);
+#endif
 }
 
 // (hi:lo) >> sh, low word; sh in 0 .. 31
@@ -246,7 +393,11 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
             tw[0] = twp[0] & ~(twp[1] | twp[2] | twp[3]); tw[1] = twp[1] & ~(twp[0] | twp[2] | twp[3]);
             tw[2] = twp[2] & ~(twp[0] | twp[1] | twp[3]); tw[3] = twp[3] & ~(twp[0] | twp[1] | twp[2]);
         }
+#ifdef PIECE_X_NO_EXACT
+        for (int i = pp.xlo; i < pp.xlo; ++i) {
+#else
         for (int i = pp.xlo; i <= pp.xhi; ++i) {                     // wave-uniform trip count
+#endif
             const uint32_t mw = ((tw[0] >> (32 - i)) & pp.xrow[0]) | ((tw[1] >> (32 - i)) & pp.xrow[1]) |
                                 ((tw[2] >> (32 - i)) & pp.xrow[2]) | ((tw[3] >> (32 - i)) & pp.xrow[3]);
             const uint32_t full = i >= 32 ? ~0u : (1u << i) - 1u;
@@ -264,7 +415,11 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     for (int u = 0; u < PIECE_NT; ++u)
 #pragma unroll
         for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
+#ifdef PIECE_X_NO_STEPS
+    for (int s = 0; s < 0; ++s) {
+#else
     for (int s = 0; s < pp.steps; ++s) {                             // wave-uniform
+#endif
         if (s < pp.blen) {
 #pragma unroll
             for (int p = 0; p < PIECE_NB; ++p) piece_and_term<NW, NW, 0>(occ[p], Y, (int)((pp.bcode[p] >> (2 * s)) & 3u));

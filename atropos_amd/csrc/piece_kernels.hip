@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
     __shared__ uint32_t s_spread[4][256];
     __shared__ uint32_t s_hist[FILTER_BINS];
     __shared__ uint32_t s_lcur;
-    __shared__ uint4 s_stage[4][NW][64];                          // a tile's planes, [word][lane]; pass B's nibble scratch
+    __shared__ uint32_t s_nibs[4][8][64];                         // pass B: the task's eight nibble dwords, [dword][lane] (NARROW tail check)
     __shared__ uint32_t s_queue[4][PIECE_QF][64];
     __shared__ uint32_t s_wide[4][64];
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
@@ -68,13 +68,15 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
     long long t0, t1;
     block_tiles(ntiles, t0, t1, wk.nused);
     uint2 *list = wk.tmp + t0 * 64;                               // this block's list: at most one entry per read it owns
-    uint4 (*stage)[64] = s_stage[wave];
     uint32_t (*queue)[64] = s_queue[wave];
-    uint32_t *nibs = (uint32_t *)stage;                           // pass B: the task's eight nibble dwords, [dword][lane]
+    uint32_t *nibs = &s_nibs[wave][0][0];
     const uint64_t lt = lanemask_lt();
 
     // ---- pass B: one queued task per lane (lane < count) ---------------------------------------------------
     auto pass_b = [&](int count) {
+#ifdef PIECE_X_NO_B
+        return;
+#endif
         const bool act = lane < count;
         const long long r = (long long)queue[0][lane];
         const uint32_t meta = queue[1][lane];
@@ -141,7 +143,6 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
         for (int w = 0; w < NW; ++w) {
             const uint4 v = tp[(size_t)w * 64];
             pl[w][0] = v.x; pl[w][1] = v.y; pl[w][2] = v.z; pl[w][3] = v.w;
-            stage[w][lane] = v;
         }
         uint32_t twp[4];                                          // the last 32 positions of every plane
         {
@@ -155,20 +156,29 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
         const int need = S.j_e - S.j_s;
         const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
         if (live && !flagged) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);          // None
-        // the 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e)
+        // the 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e) = the words w0,
+        // w0 + 1, w0 + 2 (zeros outside the read) funnel-shifted.  w0 differs from lane to lane: the three words are
+        // picked with per-lane masks (w0 == i) and (a & b) | c ops -- 2-cycle ops, no LDS round trip.
         uint32_t wp[4][2];
         {
             const int b0 = S.j_e - PIECE_WINDOW, w0 = b0 >> 5;                   // floor: -2 .. NW - 2
             const uint32_t sh = (uint32_t)(b0 & 31);
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            const uint4 x0 = (w0 >= 0 && w0 < NW) ? stage[w0][lane] : z;
-            const uint4 x1 = (w0 + 1 >= 0 && w0 + 1 < NW) ? stage[w0 + 1][lane] : z;
-            const uint4 x2 = (w0 + 2 >= 0 && w0 + 2 < NW) ? stage[w0 + 2][lane] : z;
-            wp[0][0] = __builtin_amdgcn_alignbit(x1.x, x0.x, sh); wp[0][1] = __builtin_amdgcn_alignbit(x2.x, x1.x, sh);
-            wp[1][0] = __builtin_amdgcn_alignbit(x1.y, x0.y, sh); wp[1][1] = __builtin_amdgcn_alignbit(x2.y, x1.y, sh);
-            wp[2][0] = __builtin_amdgcn_alignbit(x1.z, x0.z, sh); wp[2][1] = __builtin_amdgcn_alignbit(x2.z, x1.z, sh);
-            wp[3][0] = __builtin_amdgcn_alignbit(x1.w, x0.w, sh); wp[3][1] = __builtin_amdgcn_alignbit(x2.w, x1.w, sh);
+            uint32_t x0[4] = {0u, 0u, 0u, 0u}, x1[4] = {0u, 0u, 0u, 0u}, x2[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = -2; i <= NW - 2; ++i) {
+                const uint32_t sel = w0 == i ? ~0u : 0u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i >= 0) x0[q] |= pl[i >= 0 ? i : 0][q] & sel;
+                    if (i + 1 >= 0) x1[q] |= pl[i + 1 >= 0 ? i + 1 : 0][q] & sel;
+                    if (i + 2 <= NW - 1) x2[q] |= pl[i + 2 <= NW - 1 ? i + 2 : 0][q] & sel;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wp[q][0] = __builtin_amdgcn_alignbit(x1[q], x0[q], sh);
+                wp[q][1] = __builtin_amdgcn_alignbit(x2[q], x1[q], sh);
+            }
         }
         const uint32_t meta = (uint32_t)S.j_e | ((uint32_t)need << 10);
         // ---- queue the narrow lanes; 64 tasks -> pass B ----
@@ -242,8 +252,12 @@ __global__ __launch_bounds__(256) void piece_wide_kernel(const LocateParams p, c
         FilterState F;
         filter_init(F, u, mf);
         int j = 0;
+        uint4 vv[NW];                                                          // every chunk in flight at once: the gathers
+#pragma unroll                                                                 // (64 scattered 16-byte pieces each) are what the
+        for (int c = 0; c < NW; ++c) vv[c] = tp[(size_t)c * 64];               // kernel waits for
+#pragma unroll
         for (int c = 0; c < NW; ++c) {
-            const uint4 v = tp[(size_t)c * 64];
+            const uint4 v = vv[c];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
                 if (j >= n) break;                                             // wave-uniform
@@ -296,10 +310,30 @@ __global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, in
     }
 }
 
-constexpr int PIECE_WIDE_BLOCKS = 1024;
+constexpr int PIECE_WIDE_BLOCKS = 2048;
+
+// Blocks of P1 the device holds at once: P1 is a persistent grid -- a wave's task queue wants many tiles, and a grid
+// of exactly the resident blocks has no partial last round (2048 blocks on 768 slots cost a third round: 0.72 ms
+// instead of 0.5).  Per thread and device: the occupancy query is not free.
+template <int NW>
+static int piece_resident_blocks() {
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1024;
+    if (dev != cached_dev) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, piece_filter_kernel<NW>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        cached = std::min(FAST_BLOCKS, per_cu * cus);
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 template <int NW>
 static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
-                                long long nreads, int max_len, uint4 *out, const FastWork &wk, hipStream_t st) {
+                                long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
+    wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW>(), ((nreads + 63) / 64 + 3) / 4));
     hipLaunchKernelGGL((piece_filter_kernel<NW>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, nreads, max_len, out, wk);
     const unsigned wide_blocks = (unsigned)std::max<long long>(1, std::min<long long>(PIECE_WIDE_BLOCKS, (nreads + 255) / 256));
     hipLaunchKernelGGL((piece_wide_kernel<NW>), dim3(wide_blocks), dim3(256), 0, st, a->p, fp, planes, nreads, max_len, out, wk);
@@ -319,15 +353,12 @@ bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, Piec
     return true;
 }
 
-constexpr int PIECE_BLOCKS = 2048;                   // persistent grid: a wave's queue wants many tiles
-
 int launch_locate_planes(const atr_aligner *a, const uint4 *planes, long long nreads, int max_len, uint4 *out, void *work,
                          hipStream_t st) {
     FilterParams fp;
     PieceParams pp;
     if (!piece_applies(a, max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
     FastWork wk = fast_carve(work, nreads);
-    wk.nused = (int)std::max<long long>(1, std::min<long long>(PIECE_BLOCKS, ((nreads + 63) / 64 + 3) / 4));
     wk.lpw = nreads <= 8192 ? 0 : 64;
     if (hipMemsetAsync(wk.nwide, 0, sizeof(uint32_t), st) != hipSuccess) return (int)hipGetLastError();
     const int nw = (max_len + 31) / 32;
