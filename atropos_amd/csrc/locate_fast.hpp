@@ -49,13 +49,24 @@ struct FastWork {                                    // carve-up of the caller's
     uint2 *tmp;                                      // [nreads] two-pass pre-pass (piece_kernels.hip): per block, the list of its
                                                      // unresolved (read, window word) pairs, at the block's first read
     uint32_t *lcount;                                // [FAST_BLOCKS] entries of each block's list
-    uint32_t *wide;                                  // [nreads] (the `win` region) reads that take the full sweep (piece_wide_kernel)
-    uint32_t *nwide;                                 // [1] their number
+    uint32_t *wide;                                  // [nreads] (the `win` region) per block: its reads that take the full sweep
+    uint32_t *nwide;                                 // (unused)
+    uint4 *wdata;                                    // [wcap][nchunks] per block: a copy of their planes, written by the wave that had
+    long long wcap;                                  //   them in registers (a block's reads beyond its share are gathered from the batch)
+    uint4 *tdata;                                    // [nreads][2] next to tmp: the 64 codes from the entry's first diagonal on
+                                                     //   (what band_stage would gather from the batch, 16 bytes per 128-byte line)
+    uint32_t *dref;                                  // [nreads] next to order: the slot's index into tdata
 };
 
+// reads whose planes the two-pass pre-pass copies for its full-sweep kernel (the others are gathered): a quarter
+inline long long fast_wide_cap(long long nreads) { return nreads / 4 + 16ll * FAST_BLOCKS + 64; }   // (+ 16 per block)
+
+// (the dense buffers of the two-pass pre-pass only in the single-aligner workspace, nbins == FILTER_BINS)
 inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
+    const bool pieces = nbins == FILTER_BINS;
     return (size_t)nreads * 20 + (size_t)((nreads + 63) / 64) * 8 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * nbins * 4 + (size_t)(nbins + 1) * 4 +
-           (size_t)FAST_BLOCKS * 4 + 256 + 32;
+           (size_t)FAST_BLOCKS * 4 + 256 + 64 +
+           (pieces ? (size_t)nreads * (32 + 4) + (size_t)fast_wide_cap(nreads) * PIECE_MAX_WORDS * 16 : 0);   // tdata, dref, wdata
 }
 
 inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS) {
@@ -71,6 +82,11 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.nwide = w.lcount + FAST_BLOCKS;
     w.wide = w.win;
     w.tmp = (uint2 *)(((uintptr_t)(w.nwide + 1) + 7) & ~(uintptr_t)7);
+    w.tdata = (uint4 *)(((uintptr_t)(w.tmp + nreads) + 15) & ~(uintptr_t)15);
+    w.wdata = w.tdata + (size_t)nreads * 2;
+    w.wcap = fast_wide_cap(nreads);
+    w.dref = (uint32_t *)(w.wdata + (size_t)w.wcap * PIECE_MAX_WORDS);
+    if (nbins != FILTER_BINS) { w.tdata = nullptr; w.wdata = nullptr; w.dref = nullptr; w.wcap = 0; }
     w.nbins = nbins;
     w.nused = FAST_BLOCKS;
     w.lpw = 64;
@@ -320,8 +336,20 @@ __global__ __launch_bounds__(256) void band_kernel(const LocateParams p, const B
         const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
         const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
         uint32_t *ns = &s_stream[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))][0][lane];
-        if constexpr (PLANES) band_stage_planes(q, nchunks, window_lo(ww), ns, 64, s_spread, band_stream_dwords(u.m));
-        else band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
+        if constexpr (PLANES) {
+            // the 64 codes from the first diagonal on: the record the pre-pass wrote (two coalesced 16-byte loads per
+            // lane), or -- entries of the full-sweep kernel -- gathered from the plane64 batch
+            const bool dense = live && (ww & PIECE_NODENSE) == 0u;
+            if (dense) {
+                const uint32_t di = wk.dref[slot];
+                const uint4 a = wk.tdata[2 * (size_t)di], b = wk.tdata[2 * (size_t)di + 1];
+                ns[0] = a.x; ns[64] = a.y; ns[128] = a.z; ns[192] = a.w;
+                ns[256] = b.x; ns[320] = b.y; ns[384] = b.z; ns[448] = b.w;
+            }
+            if (wave_max_i32(live && !dense ? 1 : 0) != 0) {
+                if (!dense) band_stage_planes(q, nchunks, window_lo(ww), ns, 64, s_spread, band_stream_dwords(u.m));
+            }
+        } else band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
         uint32_t rec[4] = {0xFFFF0000u, 0u, 0u, 0u};
         if (any_rowm) band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, s_thr, rec);
         if (any_last) {

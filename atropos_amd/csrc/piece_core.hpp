@@ -53,6 +53,7 @@ constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (tw
 constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps: one hit diagonal needs 32 + T + 3 k columns, a read-end
                                             // condition 32 + T + k (94 % of C2's flagged reads); longer windows take the full sweep
 constexpr int PIECE_MAX_WORDS = 10;         // reads of up to 320 bases
+constexpr uint32_t PIECE_NODENSE = 1u << 30;   // window word of an `order` entry: no 64-code record in tdata, gather the read
 
 struct PieceParams {
     int blen;                               // body piece p = rows [p blen, (p + 1) blen), 0-based rows

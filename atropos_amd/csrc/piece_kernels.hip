@@ -3,8 +3,8 @@
 //   P1  piece_filter_kernel<NW>   pass A over every tile (pieces, 32 positions per op), pass B over the flagged
 //                                 reads' windows (a per-wave LDS queue, one task per lane); resolved reads get their
 //                                 record, the others go into the block's list of (read, window word); the few reads
-//                                 whose hits need more than PIECE_NARROW columns go into a global list
-//   P1b piece_wide_kernel<NW>     the full bit-vector sweep of the listed reads, 64 to a wave
+//                                 whose hits need more than PIECE_NARROW columns are listed per block (with a copy of
+//                                 their planes) and take the full bit-vector sweep at the end of the kernel, 64 to a wave
 //   K2  scan_bins / scan_total    (locate_fast.hpp, unchanged)
 //   P3  piece_scatter_kernel      the block's list -> the bins of `order`
 //   K4a / K4                      band_kernel / window_kernel<.., PLANES>: the exact DP, reading plane64
@@ -27,8 +27,10 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
 }
 
 // The record of a resolved read / the list entry of an unresolved one.  `active`: this lane holds a decided read.
+// nibs: the lane's eight window dwords in LDS ([dword][lane]; the window's first position is column j0 + 1), from
+// which the 64 codes that follow the entry's first diagonal go into tdata -- what band_stage would gather.
 __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww, const uint32_t (&rec)[4], int m, uint4 *out,
-                                           uint2 *list, uint32_t *s_lcur, uint32_t *s_hist) {
+                                           uint2 *list, uint4 *ldata, const uint32_t *nibs, int j0, uint32_t *s_lcur, uint32_t *s_hist) {
     const bool open = active && window_valid(ww);
     if (active && !open) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     const uint64_t om = __ballot(open);
@@ -36,28 +38,42 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
         uint32_t base = 0u;
         if ((threadIdx.x & 63) == 0) base = atomicAdd(s_lcur, (uint32_t)__popcll(om));
         base = __builtin_amdgcn_readfirstlane(base);
+        const int lane = threadIdx.x & 63;
+        const int off = window_lo(ww) - j0;                      // codes between the window's start and the first diagonal
+        const bool dense = nibs != nullptr && off >= 0 && off < 64;
         if (open) {
-            list[base + (uint32_t)__popcll(om & lanemask_lt())] = make_uint2((uint32_t)r, ww);
+            const uint32_t slot = base + (uint32_t)__popcll(om & lanemask_lt());
+            list[slot] = make_uint2((uint32_t)r, dense ? ww : (ww | PIECE_NODENSE));
             atomicAdd(&s_hist[window_bin(ww, m, true)], 1u);
+            if (dense) {
+                const int z = off >> 3;
+                const uint32_t sh = 4u * (uint32_t)(off & 7);
+                uint32_t raw[9], d[8];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) raw[k] = z + k < 8 ? nibs[(z + k) * 64 + lane] : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) d[k] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
+                ldata[2 * (size_t)slot] = make_uint4(d[0], d[1], d[2], d[3]);
+                ldata[2 * (size_t)slot + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+            }
         }
     }
 }
 
 template <int NW>
-__global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
                                                            const uint4 *__restrict__ planes, long long nreads, int n,
                                                            uint4 *__restrict__ out, FastWork wk) {
     __shared__ uint2 s_peq[16];
     __shared__ uint32_t s_spread[4][256];
     __shared__ uint32_t s_hist[FILTER_BINS];
-    __shared__ uint32_t s_lcur;
+    __shared__ uint32_t s_lcur, s_wcnt;
     __shared__ uint32_t s_nibs[4][8][64];                         // pass B: the task's eight nibble dwords, [dword][lane] (NARROW tail check)
     __shared__ uint32_t s_queue[4][PIECE_QF][64];
-    __shared__ uint32_t s_wide[4][64];
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
     if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
     if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_lcur = 0;
+    if (threadIdx.x == 0) { s_lcur = 0; s_wcnt = 0; }
     piece_spread_fill(s_spread);
     __syncthreads();
 
@@ -68,6 +84,12 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
     long long t0, t1;
     block_tiles(ntiles, t0, t1, wk.nused);
     uint2 *list = wk.tmp + t0 * 64;                               // this block's list: at most one entry per read it owns
+    uint4 *ldata = wk.tdata + t0 * 128;                           // ... and its 64-code records (two uint4 each)
+    // this block's reads that need the full sweep: their numbers (one slot per read it owns) and, for the first wcap
+    // of them, a copy of their planes (a quarter of its reads + 16)
+    uint32_t *wlist = wk.wide + t0 * 64;
+    const long long wcap = (t1 - t0) * 16 + 16;
+    uint4 *wplanes = wk.wdata + (t0 * 16 + 16 * (long long)blockIdx.x) * NW;
     uint32_t (*queue)[64] = s_queue[wave];
     uint32_t *nibs = &s_nibs[wave][0][0];
     const uint64_t lt = lanemask_lt();
@@ -90,9 +112,9 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             nb[d] = 0u;
-            if (d < dw0) continue;                                             // wave-uniform
-            nb[d] = piece_nibbles(s_spread, wp[0][d >> 2], wp[1][d >> 2], wp[2][d >> 2], wp[3][d >> 2], d & 3);
-            if (T > 0) nibs[d * 64 + lane] = nb[d];                              // (wave-uniform: NARROW mode compares the tail rows)
+            // (wave-uniform; one dword before the sweep: the DP's first diagonal may lie k columns before the window)
+            if (d >= dw0 - 1) nb[d] = piece_nibbles(s_spread, wp[0][d >> 2], wp[1][d >> 2], wp[2][d >> 2], wp[3][d >> 2], d & 3);
+            nibs[d * 64 + lane] = nb[d];                                         // NARROW mode's tail rows, the DP kernels' record
         }
         FilterState F;
         filter_init(F, u, mf);
@@ -121,18 +143,11 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
             return fp.and_mode ? nz == ones : nz == 0u;
         };
         const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n);
-        piece_emit(act, r, ww, rec, u.m, out, list, &s_lcur, s_hist);
+        piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PIECE_WINDOW, &s_lcur, s_hist);
     };
 
-    // the reads that need the full sweep: listed per wave, moved to the global list 64 at a time
-    auto flush_wide = [&](int count) {
-        uint32_t base = 0u;
-        if (lane == 0) base = atomicAdd(wk.nwide, (uint32_t)count);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (lane < count) wk.wide[base + lane] = s_wide[wave][lane];
-    };
+    int qn = 0;                                                   // tasks queued (wave-uniform)
 
-    int qn = 0, wn = 0;                                           // tasks queued / reads listed (wave-uniform)
     for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
         const bool live = r < nreads;
@@ -203,95 +218,77 @@ __global__ __launch_bounds__(256) void piece_filter_kernel(const LocateParams p,
             }
         }
         {
+            // reads that need the full sweep (3 % on C2): into the global list, with their planes while they are in
+            // registers (the sweep kernel would gather them 16 bytes per 128-byte line)
             const uint64_t wm = __ballot(wide);
-            if (wm != 0ull) {                                                 // wave-uniform, rare
-                const int cnt = (int)__popcll(wm), rank = (int)__popcll(wm & lt);
-                const int room = 64 - wn;
-                if (wide && rank < room) s_wide[wave][wn + rank] = (uint32_t)r;
-                if (cnt >= room) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    flush_wide(64);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    if (wide && rank >= room) s_wide[wave][rank - room] = (uint32_t)r;
-                    wn = cnt - room;
-                } else {
-                    wn += cnt;
+            if (wm != 0ull) {                                                 // wave-uniform
+                uint32_t base = 0u;
+                if (lane == 0) base = atomicAdd(&s_wcnt, (uint32_t)__popcll(wm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (wide) {
+                    const long long slot = (long long)base + __popcll(wm & lt);
+                    wlist[slot] = (uint32_t)r;
+                    if (slot < wcap) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) wplanes[slot * NW + w] = make_uint4(pl[w][0], pl[w][1], pl[w][2], pl[w][3]);
+                    }
                 }
             }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (qn > 0) pass_b(qn);
-    if (wn > 0) flush_wide(wn);
+    // ---- the full sweep of the block's listed reads, one read per lane, the batches dealt round the four waves ----
+    __threadfence_block();
+    __syncthreads();
+    {
+        const long long total = (long long)s_wcnt;
+        for (long long base = (long long)wave * 64; base < total; base += 256) {
+            const bool act = base + lane < total;
+            const long long r = act ? (long long)wlist[base + lane] : t0 * 64;
+            const bool copied = base + lane < wcap;
+            const uint4 *bp = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);       // the read in the batch
+            const uint4 *tp = copied ? wplanes + (base + lane) * NW : bp;
+            const size_t tstride = copied ? 1 : 64;
+            FilterState F;
+            filter_init(F, u, mf);
+            int j = 0;
+            uint4 vv[NW];
+#pragma unroll
+            for (int c = 0; c < NW; ++c) vv[c] = tp[(size_t)c * tstride];
+#pragma unroll
+            for (int c = 0; c < NW; ++c) {
+                const uint4 v = vv[c];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    if (j >= n) break;                                         // wave-uniform
+                    uint2 e[8];
+                    fetch_peq8(s_peq, piece_nibbles(s_spread, v.x, v.y, v.z, v.w, d), e);
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+                        if (j + b < n) filter_step<false>(F, e[b].x, e[b].y, kreg);
+                    j += 8;
+                }
+                filter_fold(F, min(j, n), mf, kreg);
+            }
+            uint32_t rec[4];
+            const auto tm = [&](int jp) {
+                const uint32_t lo = read_dword_planes((const uint32_t *)bp, NW, jp >> 3, s_spread);
+                const uint32_t hi = read_dword_planes((const uint32_t *)bp, NW, (jp >> 3) + 1, s_spread);
+                const uint32_t sh = 4u * (uint32_t)(jp & 7);
+                const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
+                const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
+                const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
+                const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
+                return fp.and_mode ? nz == ones : nz == 0u;
+            };
+            const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true);
+            piece_emit(act, r, ww, rec, u.m, out, list, ldata, nullptr, 0, &s_lcur, s_hist);
+        }
+    }
     __syncthreads();
     if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] = s_hist[threadIdx.x];
     if (threadIdx.x == 0) wk.lcount[blockIdx.x] = s_lcur;
-}
-
-// P1b: the full sweep of the listed reads (hits that do not fit a pass-B window), one read per lane, gathered by
-// index.  An unresolved read goes into the list of the block that owns its tile (global atomics: ~1 % of the reads).
-template <int NW>
-__global__ __launch_bounds__(256) void piece_wide_kernel(const LocateParams p, const FilterParams fp, const uint4 *__restrict__ planes,
-                                                         long long nreads, int n, uint4 *__restrict__ out, FastWork wk) {
-    __shared__ uint2 s_peq[16];
-    __shared__ uint32_t s_spread[4][256];
-    const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
-    if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
-    piece_spread_fill(s_spread);
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int mf = fp.rows, T = u.m - mf;
-    const uint32_t kreg = (uint32_t)u.k;
-    const long long total = (long long)*wk.nwide;
-    const long long ntiles = (nreads + 63) >> 6, per = (ntiles + wk.nused - 1) / wk.nused;      // block_tiles() of P1
-    for (long long base = ((long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * 64; base < total;
-         base += (long long)gridDim.x * 256) {
-        const bool act = base + lane < total;
-        const long long r = act ? (long long)wk.wide[base + lane] : 0;
-        const uint4 *tp = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);
-        FilterState F;
-        filter_init(F, u, mf);
-        int j = 0;
-        uint4 vv[NW];                                                          // every chunk in flight at once: the gathers
-#pragma unroll                                                                 // (64 scattered 16-byte pieces each) are what the
-        for (int c = 0; c < NW; ++c) vv[c] = tp[(size_t)c * 64];               // kernel waits for
-#pragma unroll
-        for (int c = 0; c < NW; ++c) {
-            const uint4 v = vv[c];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                if (j >= n) break;                                             // wave-uniform
-                uint2 e[8];
-                fetch_peq8(s_peq, piece_nibbles(s_spread, v.x, v.y, v.z, v.w, d), e);
-#pragma unroll
-                for (int b = 0; b < 8; ++b)
-                    if (j + b < n) filter_step<false>(F, e[b].x, e[b].y, kreg);
-                j += 8;
-            }
-            filter_fold(F, min(j, n), mf, kreg);
-        }
-        uint32_t rec[4];
-        const auto tm = [&](int jp) {
-            const uint32_t lo = read_dword_planes((const uint32_t *)tp, NW, jp >> 3, s_spread);
-            const uint32_t hi = read_dword_planes((const uint32_t *)tp, NW, (jp >> 3) + 1, s_spread);
-            const uint32_t sh = 4u * (uint32_t)(jp & 7);
-            const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-            const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
-            const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
-            const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
-            return fp.and_mode ? nz == ones : nz == 0u;
-        };
-        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true);
-        if (act) {
-            if (!window_valid(ww)) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-            else {
-                const long long owner = (r >> 6) / per;
-                const uint32_t slot = atomicAdd(&wk.lcount[owner], 1u);
-                wk.tmp[owner * per * 64 + slot] = make_uint2((uint32_t)r, ww);
-                atomicAdd(&wk.counts[(size_t)owner * FILTER_BINS + window_bin(ww, u.m, true)], 1u);
-            }
-        }
-    }
 }
 
 // P3: a block's list of (read, window word) -> the bins of `order` (offsets from K2's scan, an LDS cursor per bin)
@@ -306,11 +303,11 @@ __global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, in
     const uint32_t count = wk.lcount[blockIdx.x];
     for (uint32_t i = threadIdx.x; i < count; i += 256) {
         const uint2 e = list[i];
-        wk.order[atomicAdd(&s_cur[window_bin(e.y, m, true)], 1u)] = e;
+        const uint32_t slot = atomicAdd(&s_cur[window_bin(e.y & ~PIECE_NODENSE, m, true)], 1u);
+        wk.order[slot] = e;
+        wk.dref[slot] = (uint32_t)(t0 * 64) + i;                  // the entry's 64-code record in tdata
     }
 }
-
-constexpr int PIECE_WIDE_BLOCKS = 2048;
 
 // Blocks of P1 the device holds at once: P1 is a persistent grid -- a wave's task queue wants many tiles, and a grid
 // of exactly the resident blocks has no partial last round (2048 blocks on 768 slots cost a third round: 0.72 ms
@@ -335,8 +332,6 @@ static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, co
                                 long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
     wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW>(), ((nreads + 63) / 64 + 3) / 4));
     hipLaunchKernelGGL((piece_filter_kernel<NW>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, nreads, max_len, out, wk);
-    const unsigned wide_blocks = (unsigned)std::max<long long>(1, std::min<long long>(PIECE_WIDE_BLOCKS, (nreads + 255) / 256));
-    hipLaunchKernelGGL((piece_wide_kernel<NW>), dim3(wide_blocks), dim3(256), 0, st, a->p, fp, planes, nreads, max_len, out, wk);
 }
 
 // Does the two-pass pre-pass take this aligner on equal-length reads of max_len bases?  (+ its parameters)
@@ -360,7 +355,6 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, long long nr
     if (!piece_applies(a, max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
     FastWork wk = fast_carve(work, nreads);
     wk.lpw = nreads <= 8192 ? 0 : 64;
-    if (hipMemsetAsync(wk.nwide, 0, sizeof(uint32_t), st) != hipSuccess) return (int)hipGetLastError();
     const int nw = (max_len + 31) / 32;
     switch (nw) {
     case 3: launch_piece_filter<3>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
