@@ -66,7 +66,8 @@ struct PieceParams {
     uint32_t bcode[PIECE_NB];               // two bits per shift step s: the plane index (0 .. 3) of the row compared in
     uint32_t tcode[PIECE_NT];               // that step, row p blen + blen - 1 - s (scalar loads + s_bfe: wave-uniform)
     uint32_t tmask[PIECE_NT][PIECE_TAIL_WORDS];   // END positions a read-end piece may have (words tw0 ..), 0: piece unused
-    uint32_t xrow[4];                       // bit r: row r (0-based, < 32) holds the code of plane c
+    uint32_t xmask[32][4];                  // [i][c]: the rows r < i that hold the code of plane c, at bit 32 - i + r (the place of
+                                            // row r in the read's last 32 positions when the overlap has i bases)
 };
 
 // one-hot code (1, 2, 4, 8) -> plane index, -1 otherwise
@@ -88,7 +89,8 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     pp.blen = blen; pp.and_mode = and_mode ? 1 : 0;
     for (int p = 0; p < PIECE_NB; ++p)
         for (int s = 0; s < blen; ++s) pp.bcode[p] |= (uint32_t)piece_plane_of(codes[p * blen + blen - 1 - s]) << (2 * s);
-    for (int r = 0; r < 32 && r < m; ++r) { const int c = piece_plane_of(codes[r]); if (c >= 0) pp.xrow[c] |= 1u << r; }
+    for (int i = 1; i < 32; ++i)
+        for (int r = 0; r < i && r < m; ++r) { const int c = piece_plane_of(codes[r]); if (c >= 0) pp.xmask[i][c] |= 1u << (32 - i + r); }
     // Last-column candidates of the rows i < body_rows (an alignment of body_rows rows or more holds a body piece):
     // thr_row[i] = floor(i e), or -1 for a row that is no candidate (below min_overlap / no STOP_WITHIN_SEQ1).
     // Rows with thr 0 are tested exactly; rows with thr t >= 1 form class t.
@@ -399,10 +401,9 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
 #else
         for (int i = pp.xlo; i <= pp.xhi; ++i) {                     // wave-uniform trip count
 #endif
-            const uint32_t mw = ((tw[0] >> (32 - i)) & pp.xrow[0]) | ((tw[1] >> (32 - i)) & pp.xrow[1]) |
-                                ((tw[2] >> (32 - i)) & pp.xrow[2]) | ((tw[3] >> (32 - i)) & pp.xrow[3]);
-            const uint32_t full = i >= 32 ? ~0u : (1u << i) - 1u;
-            tail = tail || (i <= n && (mw & full) == full);
+            // every row of the overlap matches <=> the four (mask & rows-of-that-code) words together fill bits 32 - i .. 31
+            const uint32_t mw = (tw[0] & pp.xmask[i][0]) | (tw[1] & pp.xmask[i][1]) | (tw[2] & pp.xmask[i][2]) | (tw[3] & pp.xmask[i][3]);
+            tail = tail || (i <= n && mw == (~0u << (32 - i)));
         }
     }
 

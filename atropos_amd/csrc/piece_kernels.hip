@@ -148,17 +148,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
     int qn = 0;                                                   // tasks queued (wave-uniform)
 
+    // The planes of the wave's NEXT tile are requested as soon as pass A is through with the current one (its
+    // registers are free then) and land while the queue is served: a tile's pass A is ~2.5 k cycles of work, an HBM
+    // round trip twice that -- five waves per SIMD did not cover it (WAIT_ANY 36 %).
+    uint4 nx[NW];
+    if (t0 + wave < t1) {
+        const uint4 *tp = planes + (size_t)(t0 + wave) * NW * 64 + lane;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) nx[w] = tp[(size_t)w * 64];
+    }
     for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
         const bool live = r < nreads;
         // ---- pass A ----
         uint32_t pl[NW][4];
-        const uint4 *tp = planes + (size_t)tile * NW * 64 + lane;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            const uint4 v = tp[(size_t)w * 64];
-            pl[w][0] = v.x; pl[w][1] = v.y; pl[w][2] = v.z; pl[w][3] = v.w;
-        }
+        for (int w = 0; w < NW; ++w) { pl[w][0] = nx[w].x; pl[w][1] = nx[w].y; pl[w][2] = nx[w].z; pl[w][3] = nx[w].w; }
         uint32_t twp[4];                                          // the last 32 positions of every plane
         {
             const int sh = n & 31;
@@ -196,6 +201,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
         }
         const uint32_t meta = (uint32_t)S.j_e | ((uint32_t)need << 10);
+        {
+            // reads that need the full sweep (3 % on C2): into the global list, with their planes while they are in
+            // registers (the sweep kernel would gather them 16 bytes per 128-byte line)
+            const uint64_t wm = __ballot(wide);
+            if (wm != 0ull) {                                                 // wave-uniform
+                uint32_t base = 0u;
+                if (lane == 0) base = atomicAdd(&s_wcnt, (uint32_t)__popcll(wm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (wide) {
+                    const long long slot = (long long)base + __popcll(wm & lt);
+                    wlist[slot] = (uint32_t)r;
+                    if (slot < wcap) {
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) wplanes[slot * NW + w] = make_uint4(pl[w][0], pl[w][1], pl[w][2], pl[w][3]);
+                    }
+                }
+            }
+        }
+        if (tile + 4 < t1) {                                                  // the next tile's planes (see above)
+            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64 + lane;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) nx[w] = tp[(size_t)w * 64];
+        }
         // ---- queue the narrow lanes; 64 tasks -> pass B ----
         {
             const uint64_t nm = __ballot(narrow);
@@ -215,24 +243,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 qn = cnt - room;
             } else {
                 qn += cnt;
-            }
-        }
-        {
-            // reads that need the full sweep (3 % on C2): into the global list, with their planes while they are in
-            // registers (the sweep kernel would gather them 16 bytes per 128-byte line)
-            const uint64_t wm = __ballot(wide);
-            if (wm != 0ull) {                                                 // wave-uniform
-                uint32_t base = 0u;
-                if (lane == 0) base = atomicAdd(&s_wcnt, (uint32_t)__popcll(wm));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (wide) {
-                    const long long slot = (long long)base + __popcll(wm & lt);
-                    wlist[slot] = (uint32_t)r;
-                    if (slot < wcap) {
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) wplanes[slot * NW + w] = make_uint4(pl[w][0], pl[w][1], pl[w][2], pl[w][3]);
-                    }
-                }
             }
         }
     }

@@ -146,7 +146,7 @@ class C2(object):
         self.w = w = synth.workload("C2", rank * self.n, self.n, device=dev)
         self.al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
         self.ascii = w["reads"]
-        self.batch = self.al.pack(self.ascii)
+        self.batch = self.al.pack(self.ascii, layout="tile64" if args.full_sweep else "auto")
         self.sample = self.ascii[:min(self.n, 2_000_000)].cpu().numpy() if rank == 0 else None
         self.filtered = not args.full_sweep
         if not args.secondary:
@@ -159,13 +159,17 @@ class C2(object):
     def describe(self):
         w = self.w
         return {"workload": "C2: %d x 150 bp SE reads per GPU, TruSeq 34-mer 3' adapter, e=0.1, O=3, indel cost 1, "
-                            "4-bit packed reads resident in HBM" % self.n,
+                            "4-bit packed reads (%s layout) resident in HBM" % (self.n, self.batch.layout),
                 "reads_per_gpu": self.n, "read_len": 150, "adapter_len": len(w["adapter"]),
                 "matched_fraction": int(self.res.found().sum().item()) / self.n}
 
     def kernel(self):
-        return ("filter_kernel + scan + scatter + band_kernel + window_kernel<36,eq,indel> (one atr_locate_batch call)"
-                if self.filtered else "locate_kernel<36,eq,indel>")
+        if not self.filtered:
+            return "locate_kernel<36,eq,indel>"
+        if self.batch.layout == "plane64":
+            return ("piece_filter_kernel<5> (pass A: exact pieces on bit planes; pass B: windowed bit-vector sweep of the flagged "
+                    "reads) + scan + piece_scatter + band_kernel + window_kernel<36,eq,indel,planes> (one atr_locate_planes_batch call)")
+        return "filter_kernel + scan + scatter + band_kernel + window_kernel<36,eq,indel> (one atr_locate_batch call)"
 
     def note(self, kernel_ms):
         return "integer-VALU bound, not HBM bound: %.2f G full-matrix cell-equivalents/s" % (
@@ -195,7 +199,7 @@ class C2(object):
             return a.elapsed_time(b) / reps
 
         if self.ascii is not None:
-            ms = run(lambda: self.al.locate_batch(self.al.pack(self.ascii), self.filtered))
+            ms = run(lambda: self.al.locate_batch(self.al.pack(self.ascii, layout=self.batch.layout), self.filtered))
             out["pack_inclusive_reads_per_s"] = self.n / (ms * 1e-3)        # ASCII in HBM -> records
             # ragged batch: the same reads cut to lengths 100..150 (what quality-trimmed data looks like)
             from atropos_amd.batch import ReadBatch
