@@ -47,7 +47,8 @@ namespace atr {
 
 constexpr int PIECE_NB = 4;                 // body pieces (k + 1 <= 4; a piece too many only weakens the filter)
 constexpr int PIECE_NT = 4;                 // read-end pieces (error classes t = 1 .. 3)
-constexpr int PIECE_STEPS = 8;              // longest piece
+constexpr int PIECE_STEPS = 8;              // longest read-end piece / body pieces 0 .. 2
+constexpr int PIECE_LAST_STEPS = 16;        // the last body piece takes the rows that are left: up to 16
 constexpr int PIECE_TAIL_WORDS = 3;         // plane words the read-end pieces are evaluated on: the read's last three
 constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (two words per plane)
 constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps: one hit diagonal needs 32 + T + 3 k columns, a read-end
@@ -56,9 +57,11 @@ constexpr int PIECE_MAX_WORDS = 10;         // reads of up to 320 bases
 constexpr uint32_t PIECE_NODENSE = 1u << 30;   // window word of an `order` entry: no 64-code record in tdata, gather the read
 
 struct PieceParams {
-    int blen;                               // body piece p = rows [p blen, (p + 1) blen), 0-based rows
+    int blen;                               // body piece p = rows [p blen, (p + 1) blen), 0-based rows; the LAST one runs to row m:
+    int llen;                               //   llen = m - 3 blen rows (all four on one diagonal = the adapter, verbatim)
+    int m;                                  // adapter length
     int tlen;                               // read-end piece u = rows [u tlen, (u + 1) tlen); 0: none
-    int steps;                              // max(blen, tlen)
+    int steps;                              // max(llen, tlen)
     int xlo, xhi;                           // rows i in [xlo, xhi]: the overlap of i bases must be exact (xhi < xlo: none)
     int tail_cols;                          // columns before the read end a read with a read-end condition sweeps
     int tw0;                                // first plane word of the read-end pieces' masks: max(0, ceil(n / 32) - 3)
@@ -84,19 +87,26 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     if (n < 1 || n > 32 * PIECE_MAX_WORDS) return false;
     const int blen = std::min(PIECE_STEPS, rows / PIECE_NB);
     if (blen < 5 || k > blen - 1) return false;                      // (k <= blen - 1: the diagonal mask keeps every hit)
-    const int body_rows = PIECE_NB * blen;                           // <= rows
-    for (int i = 0; i < body_rows; ++i) if (piece_plane_of(codes[i]) < 0) return false;
-    pp.blen = blen; pp.and_mode = and_mode ? 1 : 0;
-    for (int p = 0; p < PIECE_NB; ++p)
-        for (int s = 0; s < blen; ++s) pp.bcode[p] |= (uint32_t)piece_plane_of(codes[p * blen + blen - 1 - s]) << (2 * s);
+    // The pieces cover ALL m rows (an alignment of the whole adapter with <= k errors leaves one of any k + 1 disjoint
+    // pieces intact): the last one takes what 3 blen rows leave.  Four exact pieces on one diagonal are then the
+    // adapter verbatim -- the reference's early exit (_align.pyx:456-458) -- which pass A resolves itself.
+    const int llen = m - (PIECE_NB - 1) * blen;
+    if (llen < blen || llen > PIECE_LAST_STEPS) return false;
+    const int body_rows = m;
+    for (int i = 0; i < m; ++i) if (piece_plane_of(codes[i]) < 0) return false;
+    pp.blen = blen; pp.llen = llen; pp.m = m; pp.and_mode = and_mode ? 1 : 0;
+    for (int p = 0; p < PIECE_NB; ++p) {
+        const int len = p == PIECE_NB - 1 ? llen : blen;
+        for (int s = 0; s < len; ++s) pp.bcode[p] |= (uint32_t)piece_plane_of(codes[p * blen + len - 1 - s]) << (2 * s);
+    }
     for (int i = 1; i < 32; ++i)
         for (int r = 0; r < i && r < m; ++r) { const int c = piece_plane_of(codes[r]); if (c >= 0) pp.xmask[i][c] |= 1u << (32 - i + r); }
-    // Last-column candidates of the rows i < body_rows (an alignment of body_rows rows or more holds a body piece):
+    // Last-column candidates of the rows i < m (row m in the last column is a row-m candidate: a body piece):
     // thr_row[i] = floor(i e), or -1 for a row that is no candidate (below min_overlap / no STOP_WITHIN_SEQ1).
     // Rows with thr 0 are tested exactly; rows with thr t >= 1 form class t.
     int ilo[PIECE_NB], ihi[PIECE_NB];
     for (int t = 0; t < PIECE_NB; ++t) { ilo[t] = 0; ihi[t] = -1; }
-    const int top = std::min(body_rows - 1, m);                      // (row m in the last column is a row-m candidate too: body)
+    const int top = m - 1;
     for (int i = 1; i <= top; ++i) {
         const int t = thr_row[i];
         if (t < 0) continue;
@@ -139,7 +149,7 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
             }
         }
     }
-    pp.steps = std::max(pp.blen, pp.tlen);
+    pp.steps = std::max(pp.llen, pp.tlen);
     pp.tail_cols = rows + k + (m - rows);                            // see "tail_cols" in DESIGN.md 3.2b: rows + k + T
     return true;
 }
@@ -371,6 +381,8 @@ ATR_DEV uint32_t piece_funnel(uint32_t hi, uint32_t lo, int sh) {
 
 // What pass A knows about one read.
 struct PieceScan {
+    int j_exact;                             // first column with the whole adapter verbatim before it (0: none): the
+                                             // reference's early exit, result (0, m, j - m, j, m, 0) if m >= min_overlap
     int j_s, j_e;                            // columns j_s + 1 .. j_e hold every acceptable cell and its traceback
     bool flagged;                            // false: the result is None
     bool tail;                               // a read-end condition holds (the window then ends at n)
@@ -424,8 +436,9 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
 #endif
         if (s < pp.blen) {
 #pragma unroll
-            for (int p = 0; p < PIECE_NB; ++p) piece_and_term<NW, NW, 0>(occ[p], Y, (int)((pp.bcode[p] >> (2 * s)) & 3u));
+            for (int p = 0; p < PIECE_NB - 1; ++p) piece_and_term<NW, NW, 0>(occ[p], Y, (int)((pp.bcode[p] >> (2 * s)) & 3u));
         }
+        if (s < pp.llen) piece_and_term<NW, NW, 0>(occ[PIECE_NB - 1], Y, (int)((pp.bcode[PIECE_NB - 1] >> (2 * s)) & 3u));
         if (s < pp.tlen) {
 #pragma unroll
             for (int u = 0; u < PIECE_NT; ++u) piece_and_term<NW, TWN, TW0>(tocc[u], Y, (int)((pp.tcode[u] >> (2 * s)) & 3u));
@@ -442,26 +455,40 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
         tail = tail || any != 0u;
     }
 
-    // (3) diagonals with a body piece: piece p ending at position e sits on diagonal d = e - (p + 1) blen + 1.
-    //     dm bit b <=> some piece on diagonal b - (blen - 1)   (k <= blen - 1: no possible diagonal is lost;
-    //     p blen <= 24: the shift stays inside a word pair)
-    uint32_t dm[NW];
+    // (3) diagonals with a body piece: piece p < 3 ending at position e sits on diagonal d = e - (p + 1) blen + 1, the
+    //     last one on d = e - m + 1.  al[p] = the piece's hits moved to piece 0's place: bit b <=> on diagonal
+    //     b - (blen - 1)   (k <= blen - 1: no possible diagonal is lost).  dm = any piece; pf = all four on one
+    //     diagonal = the adapter verbatim.
+    uint32_t dm[NW], pf[NW];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) dm[w] = occ[0][w];
+    for (int w = 0; w < NW; ++w) dm[w] = pf[w] = occ[0][w];
 #pragma unroll
-    for (int p = 1; p < PIECE_NB; ++p)
+    for (int p = 1; p < PIECE_NB; ++p) {
+        const int sh = p == PIECE_NB - 1 ? pp.m - pp.blen : p * pp.blen;           // 0 .. 32 (wave-uniform)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) dm[w] |= piece_funnel(w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u, occ[p][w], p * pp.blen);
-    int b_first = -1, b_last = -1;
+        for (int w = 0; w < NW; ++w) {
+            // words w, w + 1 (+ 1 when sh == 32: the funnel then takes the next pair with shift 0)
+            const uint32_t lo = sh >= 32 ? (w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u) : occ[p][w];
+            const uint32_t hi = sh >= 32 ? (w + 2 < NW ? occ[p][w + 2 < NW ? w + 2 : w] : 0u) : (w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u);
+            const uint32_t al = piece_funnel(hi, lo, sh & 31);
+            dm[w] |= al;
+            pf[w] &= al;
+        }
+    }
+    int b_first = -1, b_last = -1, z_first = -1;
 #pragma unroll
     for (int w = NW - 1; w >= 0; --w) if (dm[w] != 0u) b_first = 32 * w + atr_ctz(dm[w]);
 #pragma unroll
     for (int w = 0; w < NW; ++w) if (dm[w] != 0u) b_last = 32 * w + 31 - atr_clz(dm[w]);
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) if (pf[w] != 0u) z_first = 32 * w + atr_ctz(pf[w]);
 
     PieceScan S;
     S.tail = tail;
     S.flagged = tail || b_first >= 0;
     S.j_s = 0; S.j_e = 0;
+    // the first zero-cost column of row m (all m rows verbatim on diagonal d: column d + m): where the reference stops
+    S.j_exact = z_first >= 0 ? z_first - (pp.blen - 1) + pp.m : 0;
     if (b_first >= 0) {
         const int d_min = b_first - (pp.blen - 1), d_max = b_last - (pp.blen - 1);
         // a traceback through a piece on diagonal d leaves row 0 at a column >= d - k and passes row mf at a column

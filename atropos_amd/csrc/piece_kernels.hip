@@ -172,10 +172,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 twp[q] = sh == 0 ? pl[NW - 1][q] : __builtin_amdgcn_alignbit(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, (uint32_t)sh);
         }
         const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
-        const bool flagged = live && S.flagged;
+        // the adapter verbatim: resolved here (_align.pyx:456-458), no pass B (22 % of C2's reads)
+        const bool exact = live && S.j_exact != 0 && u.m >= u.min_overlap;
+        if (exact) out[r] = make_uint4((uint32_t)u.m << 16, (uint32_t)(S.j_exact - u.m) | ((uint32_t)S.j_exact << 16), (uint32_t)u.m, 0u);
+        const bool flagged = live && S.flagged && !exact;
         const int need = S.j_e - S.j_s;
         const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
-        if (live && !flagged) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);          // None
+        if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);   // None
         // the 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e) = the words w0,
         // w0 + 1, w0 + 2 (zeros outside the read) funnel-shifted.  w0 differs from lane to lane: the three words are
         // picked with per-lane masks (w0 == i) and (a & b) | c ops -- 2-cycle ops, no LDS round trip.

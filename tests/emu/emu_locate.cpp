@@ -269,6 +269,10 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
     rec[0] = 0xFFFF0000u; rec[1] = rec[2] = rec[3] = 0u;
     ++g_piece_stats[0];
+    if (S.j_exact != 0 && u.m >= u.min_overlap) {          // the adapter verbatim: the reference's early exit
+        rec[0] = (uint32_t)u.m << 16; rec[1] = (uint32_t)(S.j_exact - u.m) | ((uint32_t)S.j_exact << 16); rec[2] = (uint32_t)u.m;
+        return 0u;
+    }
     if (!S.flagged) return 0u;
     ++g_piece_stats[1];
     if (S.tail) ++g_piece_stats[2];
