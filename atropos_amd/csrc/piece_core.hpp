@@ -408,11 +408,7 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
             tw[0] = twp[0] & ~(twp[1] | twp[2] | twp[3]); tw[1] = twp[1] & ~(twp[0] | twp[2] | twp[3]);
             tw[2] = twp[2] & ~(twp[0] | twp[1] | twp[3]); tw[3] = twp[3] & ~(twp[0] | twp[1] | twp[2]);
         }
-#ifdef PIECE_X_NO_EXACT
-        for (int i = pp.xlo; i < pp.xlo; ++i) {
-#else
         for (int i = pp.xlo; i <= pp.xhi; ++i) {                     // wave-uniform trip count
-#endif
             // every row of the overlap matches <=> the four (mask & rows-of-that-code) words together fill bits 32 - i .. 31
             const uint32_t mw = (tw[0] & pp.xmask[i][0]) | (tw[1] & pp.xmask[i][1]) | (tw[2] & pp.xmask[i][2]) | (tw[3] & pp.xmask[i][3]);
             tail = tail || (i <= n && mw == (~0u << (32 - i)));
@@ -429,11 +425,7 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     for (int u = 0; u < PIECE_NT; ++u)
 #pragma unroll
         for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
-#ifdef PIECE_X_NO_STEPS
-    for (int s = 0; s < 0; ++s) {
-#else
     for (int s = 0; s < pp.steps; ++s) {                             // wave-uniform
-#endif
         if (s < pp.blen) {
 #pragma unroll
             for (int p = 0; p < PIECE_NB - 1; ++p) piece_and_term<NW, NW, 0>(occ[p], Y, (int)((pp.bcode[p] >> (2 * s)) & 3u));

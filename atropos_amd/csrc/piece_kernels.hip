@@ -96,9 +96,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 
     // ---- pass B: one queued task per lane (lane < count) ---------------------------------------------------
     auto pass_b = [&](int count) {
-#ifdef PIECE_X_NO_B
-        return;
-#endif
         const bool act = lane < count;
         const long long r = (long long)queue[0][lane];
         const uint32_t meta = queue[1][lane];
