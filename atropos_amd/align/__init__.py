@@ -200,8 +200,8 @@ class Aligner(object):
         table = self._table if self._table is not None else self._backend.translate_table(kind)
         if isinstance(reads, (list, tuple)):
             width = len(reads[0]) if len(reads) else 0
-            planes = self._wants_planes(layout, len(reads), width) and all(len(r) == width for r in reads)
-            return ReadBatch.from_strings(reads, kind, table, self._backend, planes=planes)
+            # (from_strings packs planes only when every read has that length)
+            return ReadBatch.from_strings(reads, kind, table, self._backend, planes=self._wants_planes(layout, len(reads), width))
         planes = self._wants_planes(layout, reads.shape[0], reads.shape[1])
         return ReadBatch.from_ascii(reads, None, None, kind, table, self._backend, planes=planes)
 

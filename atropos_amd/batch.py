@@ -14,7 +14,7 @@ from . import _lib
 def _as_ascii_matrix(reads):
     """list of str/bytes -> (uint8 ndarray [n, max_len], int32 lens)."""
     n = len(reads)
-    if n and all(isinstance(r, str) for r in reads):
+    if n and set(map(type, reads)) == {str}:              # (one pass in C; a generator of isinstance calls costs 20 ms per 65 k)
         flat = "".join(reads).encode("ascii")             # one pass in C (UnicodeEncodeError as the per-read encode)
         lens = np.fromiter(map(len, reads), dtype=np.int32, count=n)
     else:
@@ -128,5 +128,8 @@ class LocateResult(object):
 
     def tuples(self):
         """List of 6-tuples / None, exactly what per-read ``locate`` calls return."""
-        rows = self.numpy()[:, :6].tolist()               # one conversion in C instead of six int() calls per read
-        return [None if row[1] < 0 else tuple(row) for row in rows]
+        arr = self.numpy()[:, :6]
+        out = list(zip(*arr.T.tolist()))                  # the tuples are built in C: six column lists, one zip
+        for i in np.flatnonzero(arr[:, 1] < 0).tolist():
+            out[i] = None
+        return out

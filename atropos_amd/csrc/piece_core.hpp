@@ -45,7 +45,8 @@
 
 namespace atr {
 
-constexpr int PIECE_NB = 4;                 // body pieces (k + 1 <= 4; a piece too many only weakens the filter)
+constexpr int PIECE_NB = 4;                 // body pieces (k + 1 <= 4; a piece too many only weakens the filter); piece_scan
+                                            // names the four by hand
 constexpr int PIECE_NT = 4;                 // read-end pieces (error classes t = 1 .. 3)
 constexpr int PIECE_STEPS = 8;              // longest read-end piece / body pieces 0 .. 2
 constexpr int PIECE_LAST_STEPS = 16;        // the last body piece takes the rows that are left: up to 16
@@ -66,8 +67,9 @@ struct PieceParams {
     int tail_cols;                          // columns before the read end a read with a read-end condition sweeps
     int tw0;                                // first plane word of the read-end pieces' masks: max(0, ceil(n / 32) - 3)
     int and_mode;                           // wildcard comparison (code & code): a base matches code c iff its plane c is set
-    uint32_t bcode[PIECE_NB];               // two bits per shift step s: the plane index (0 .. 3) of the row compared in
-    uint32_t tcode[PIECE_NT];               // that step, row p blen + blen - 1 - s (scalar loads + s_bfe: wave-uniform)
+    uint32_t scode[PIECE_LAST_STEPS];       // per shift step s, two bits per piece: the plane index (0 .. 3) of the row it
+                                            // compares in that step (its last row minus s); body piece p at bits 2p,
+                                            // read-end piece u at bits 8 + 2u (one scalar load per step, s_bitcmp1 per term)
     uint32_t tmask[PIECE_NT][PIECE_TAIL_WORDS];   // END positions a read-end piece may have (words tw0 ..), 0: piece unused
     uint32_t xmask[32][4];                  // [i][c]: the rows r < i that hold the code of plane c, at bit 32 - i + r (the place of
                                             // row r in the read's last 32 positions when the overlap has i bases)
@@ -97,7 +99,7 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     pp.blen = blen; pp.llen = llen; pp.m = m; pp.and_mode = and_mode ? 1 : 0;
     for (int p = 0; p < PIECE_NB; ++p) {
         const int len = p == PIECE_NB - 1 ? llen : blen;
-        for (int s = 0; s < len; ++s) pp.bcode[p] |= (uint32_t)piece_plane_of(codes[p * blen + len - 1 - s]) << (2 * s);
+        for (int s = 0; s < len; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[p * blen + len - 1 - s]) << (2 * p);
     }
     for (int i = 1; i < 32; ++i)
         for (int r = 0; r < i && r < m; ++r) { const int c = piece_plane_of(codes[r]); if (c >= 0) pp.xmask[i][c] |= 1u << (32 - i + r); }
@@ -132,7 +134,7 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
         for (int u = 0; u < PIECE_NT; ++u) {
             if (u > tmax) continue;
             if ((u + 1) * tlen > body_rows) return false;
-            for (int s = 0; s < tlen; ++s) pp.tcode[u] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (2 * s);
+            for (int s = 0; s < tlen; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (8 + 2 * u);
             // ... and piece u serves the classes t >= max(1, u) whose first t + 1 pieces fit their shortest overlap.
             for (int t = std::max(1, u); t <= tmax; ++t) {
                 if (ihi[t] < 0) continue;
@@ -201,172 +203,173 @@ ATR_DEV void piece_shift_masks(PieceMasks<NW> &Y) {
 // straight-line blocks (no register indexing: an indexed read costs 6 - 8 cycles, the branch overlaps with the
 // other waves' VALU work).
 #ifndef ATR_HOST_EMU
-// acc[i] &= (y0, y1, y2, y3)[code][i], i < G: one asm block with the four-way scalar branch INSIDE, so that the compiler
-// sees a straight-line update of the accumulators in place (with the branch in C++ it copies the accumulators
-// into fresh registers in front of every case: five v_mov per five v_and).
-template <int G>
+// acc[i] &= (y0, y1, y2, y3)[code][i], i < G, code = bits BIT + 1 : BIT of the step's code word cw (wave-uniform): one
+// asm block with the four-way scalar branch INSIDE, so that the compiler sees a straight-line update of the
+// accumulators in place (with the branch in C++ it copies the accumulators into fresh registers in front of every
+// case: five v_mov per five v_and).  s_bitcmp1 tests the code bits where they sit: 4 - 5 scalar instructions a term.
+template <int G, int BIT>
 __device__ __forceinline__ void piece_and_group(uint32_t *a, const uint32_t *y0, const uint32_t *y1, const uint32_t *y2,
-                                                const uint32_t *y3, int code) {
-    static_assert(G >= 1 && G <= 5, "at most 5 accumulators + 20 masks + the code: 26 asm operands");
+                                                const uint32_t *y3, uint32_t cw) {
+    static_assert(G >= 1 && G <= 5, "at most 5 accumulators + 20 masks + the code word: 28 asm operands");
     if constexpr (G == 1) {
-        asm volatile("s_cmp_lt_u32 %5, 2\n\t"
-                     "s_cbranch_scc1 .Lpt01_%=\n\t"
-                     "s_cmp_eq_u32 %5, 2\n\t"
-                     "s_cbranch_scc1 .Lpt2_%=\n\t"
-                     "v_and_b32 %0, %0, %4\n\t"
+        asm volatile("s_bitcmp1_b32 %5, %7\n\t"
+                     "s_cbranch_scc1 .Lpthi_%=\n\t"
+                     "s_bitcmp1_b32 %5, %6\n\t"
+                     "s_cbranch_scc1 .Lpt1_%=\n\t"
+                     "v_and_b32 %0, %0, %1\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt2_%=:\n\t"
-                     "v_and_b32 %0, %0, %3\n\t"
-                     "s_branch .Lptend_%=\n\t"
-                     ".Lpt01_%=:\n\t"
-                     "s_cmp_eq_u32 %5, 0\n\t"
-                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     ".Lpt1_%=:\n\t"
                      "v_and_b32 %0, %0, %2\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt0_%=:\n\t"
-                     "v_and_b32 %0, %0, %1\n\t"
+                     ".Lpthi_%=:\n\t"
+                     "s_bitcmp1_b32 %5, %6\n\t"
+                     "s_cbranch_scc1 .Lpt3_%=\n\t"
+                     "v_and_b32 %0, %0, %3\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt3_%=:\n\t"
+                     "v_and_b32 %0, %0, %4\n\t"
                      ".Lptend_%=:"
                      : "+v"(a[0])
-                     : "v"(y0[0]), "v"(y1[0]), "v"(y2[0]), "v"(y3[0]), "s"(code) : "scc");
+                     : "v"(y0[0]), "v"(y1[0]), "v"(y2[0]), "v"(y3[0]), "s"(cw), "n"(BIT), "n"(BIT + 1) : "scc");
     }
     else if constexpr (G == 2) {
-        asm volatile("s_cmp_lt_u32 %10, 2\n\t"
-                     "s_cbranch_scc1 .Lpt01_%=\n\t"
-                     "s_cmp_eq_u32 %10, 2\n\t"
-                     "s_cbranch_scc1 .Lpt2_%=\n\t"
-                     "v_and_b32 %0, %0, %8\n\t"
-                     "v_and_b32 %1, %1, %9\n\t"
+        asm volatile("s_bitcmp1_b32 %10, %12\n\t"
+                     "s_cbranch_scc1 .Lpthi_%=\n\t"
+                     "s_bitcmp1_b32 %10, %11\n\t"
+                     "s_cbranch_scc1 .Lpt1_%=\n\t"
+                     "v_and_b32 %0, %0, %2\n\t"
+                     "v_and_b32 %1, %1, %3\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt2_%=:\n\t"
-                     "v_and_b32 %0, %0, %6\n\t"
-                     "v_and_b32 %1, %1, %7\n\t"
-                     "s_branch .Lptend_%=\n\t"
-                     ".Lpt01_%=:\n\t"
-                     "s_cmp_eq_u32 %10, 0\n\t"
-                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     ".Lpt1_%=:\n\t"
                      "v_and_b32 %0, %0, %4\n\t"
                      "v_and_b32 %1, %1, %5\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt0_%=:\n\t"
-                     "v_and_b32 %0, %0, %2\n\t"
-                     "v_and_b32 %1, %1, %3\n\t"
+                     ".Lpthi_%=:\n\t"
+                     "s_bitcmp1_b32 %10, %11\n\t"
+                     "s_cbranch_scc1 .Lpt3_%=\n\t"
+                     "v_and_b32 %0, %0, %6\n\t"
+                     "v_and_b32 %1, %1, %7\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt3_%=:\n\t"
+                     "v_and_b32 %0, %0, %8\n\t"
+                     "v_and_b32 %1, %1, %9\n\t"
                      ".Lptend_%=:"
                      : "+v"(a[0]), "+v"(a[1])
-                     : "v"(y0[0]), "v"(y0[1]), "v"(y1[0]), "v"(y1[1]), "v"(y2[0]), "v"(y2[1]), "v"(y3[0]), "v"(y3[1]), "s"(code) : "scc");
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y1[0]), "v"(y1[1]), "v"(y2[0]), "v"(y2[1]), "v"(y3[0]), "v"(y3[1]), "s"(cw), "n"(BIT), "n"(BIT + 1) : "scc");
     }
     else if constexpr (G == 3) {
-        asm volatile("s_cmp_lt_u32 %15, 2\n\t"
-                     "s_cbranch_scc1 .Lpt01_%=\n\t"
-                     "s_cmp_eq_u32 %15, 2\n\t"
-                     "s_cbranch_scc1 .Lpt2_%=\n\t"
-                     "v_and_b32 %0, %0, %12\n\t"
-                     "v_and_b32 %1, %1, %13\n\t"
-                     "v_and_b32 %2, %2, %14\n\t"
+        asm volatile("s_bitcmp1_b32 %15, %17\n\t"
+                     "s_cbranch_scc1 .Lpthi_%=\n\t"
+                     "s_bitcmp1_b32 %15, %16\n\t"
+                     "s_cbranch_scc1 .Lpt1_%=\n\t"
+                     "v_and_b32 %0, %0, %3\n\t"
+                     "v_and_b32 %1, %1, %4\n\t"
+                     "v_and_b32 %2, %2, %5\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt2_%=:\n\t"
-                     "v_and_b32 %0, %0, %9\n\t"
-                     "v_and_b32 %1, %1, %10\n\t"
-                     "v_and_b32 %2, %2, %11\n\t"
-                     "s_branch .Lptend_%=\n\t"
-                     ".Lpt01_%=:\n\t"
-                     "s_cmp_eq_u32 %15, 0\n\t"
-                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     ".Lpt1_%=:\n\t"
                      "v_and_b32 %0, %0, %6\n\t"
                      "v_and_b32 %1, %1, %7\n\t"
                      "v_and_b32 %2, %2, %8\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt0_%=:\n\t"
-                     "v_and_b32 %0, %0, %3\n\t"
-                     "v_and_b32 %1, %1, %4\n\t"
-                     "v_and_b32 %2, %2, %5\n\t"
-                     ".Lptend_%=:"
-                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])
-                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "s"(code) : "scc");
-    }
-    else if constexpr (G == 4) {
-        asm volatile("s_cmp_lt_u32 %20, 2\n\t"
-                     "s_cbranch_scc1 .Lpt01_%=\n\t"
-                     "s_cmp_eq_u32 %20, 2\n\t"
-                     "s_cbranch_scc1 .Lpt2_%=\n\t"
-                     "v_and_b32 %0, %0, %16\n\t"
-                     "v_and_b32 %1, %1, %17\n\t"
-                     "v_and_b32 %2, %2, %18\n\t"
-                     "v_and_b32 %3, %3, %19\n\t"
+                     ".Lpthi_%=:\n\t"
+                     "s_bitcmp1_b32 %15, %16\n\t"
+                     "s_cbranch_scc1 .Lpt3_%=\n\t"
+                     "v_and_b32 %0, %0, %9\n\t"
+                     "v_and_b32 %1, %1, %10\n\t"
+                     "v_and_b32 %2, %2, %11\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt2_%=:\n\t"
+                     ".Lpt3_%=:\n\t"
                      "v_and_b32 %0, %0, %12\n\t"
                      "v_and_b32 %1, %1, %13\n\t"
                      "v_and_b32 %2, %2, %14\n\t"
-                     "v_and_b32 %3, %3, %15\n\t"
+                     ".Lptend_%=:"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "s"(cw), "n"(BIT), "n"(BIT + 1) : "scc");
+    }
+    else if constexpr (G == 4) {
+        asm volatile("s_bitcmp1_b32 %20, %22\n\t"
+                     "s_cbranch_scc1 .Lpthi_%=\n\t"
+                     "s_bitcmp1_b32 %20, %21\n\t"
+                     "s_cbranch_scc1 .Lpt1_%=\n\t"
+                     "v_and_b32 %0, %0, %4\n\t"
+                     "v_and_b32 %1, %1, %5\n\t"
+                     "v_and_b32 %2, %2, %6\n\t"
+                     "v_and_b32 %3, %3, %7\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt01_%=:\n\t"
-                     "s_cmp_eq_u32 %20, 0\n\t"
-                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     ".Lpt1_%=:\n\t"
                      "v_and_b32 %0, %0, %8\n\t"
                      "v_and_b32 %1, %1, %9\n\t"
                      "v_and_b32 %2, %2, %10\n\t"
                      "v_and_b32 %3, %3, %11\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt0_%=:\n\t"
-                     "v_and_b32 %0, %0, %4\n\t"
-                     "v_and_b32 %1, %1, %5\n\t"
-                     "v_and_b32 %2, %2, %6\n\t"
-                     "v_and_b32 %3, %3, %7\n\t"
+                     ".Lpthi_%=:\n\t"
+                     "s_bitcmp1_b32 %20, %21\n\t"
+                     "s_cbranch_scc1 .Lpt3_%=\n\t"
+                     "v_and_b32 %0, %0, %12\n\t"
+                     "v_and_b32 %1, %1, %13\n\t"
+                     "v_and_b32 %2, %2, %14\n\t"
+                     "v_and_b32 %3, %3, %15\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt3_%=:\n\t"
+                     "v_and_b32 %0, %0, %16\n\t"
+                     "v_and_b32 %1, %1, %17\n\t"
+                     "v_and_b32 %2, %2, %18\n\t"
+                     "v_and_b32 %3, %3, %19\n\t"
                      ".Lptend_%=:"
                      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
-                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y2[3]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "v"(y3[3]), "s"(code) : "scc");
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y2[3]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "v"(y3[3]), "s"(cw), "n"(BIT), "n"(BIT + 1) : "scc");
     }
     else if constexpr (G == 5) {
-        asm volatile("s_cmp_lt_u32 %25, 2\n\t"
-                     "s_cbranch_scc1 .Lpt01_%=\n\t"
-                     "s_cmp_eq_u32 %25, 2\n\t"
-                     "s_cbranch_scc1 .Lpt2_%=\n\t"
-                     "v_and_b32 %0, %0, %20\n\t"
-                     "v_and_b32 %1, %1, %21\n\t"
-                     "v_and_b32 %2, %2, %22\n\t"
-                     "v_and_b32 %3, %3, %23\n\t"
-                     "v_and_b32 %4, %4, %24\n\t"
+        asm volatile("s_bitcmp1_b32 %25, %27\n\t"
+                     "s_cbranch_scc1 .Lpthi_%=\n\t"
+                     "s_bitcmp1_b32 %25, %26\n\t"
+                     "s_cbranch_scc1 .Lpt1_%=\n\t"
+                     "v_and_b32 %0, %0, %5\n\t"
+                     "v_and_b32 %1, %1, %6\n\t"
+                     "v_and_b32 %2, %2, %7\n\t"
+                     "v_and_b32 %3, %3, %8\n\t"
+                     "v_and_b32 %4, %4, %9\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt2_%=:\n\t"
-                     "v_and_b32 %0, %0, %15\n\t"
-                     "v_and_b32 %1, %1, %16\n\t"
-                     "v_and_b32 %2, %2, %17\n\t"
-                     "v_and_b32 %3, %3, %18\n\t"
-                     "v_and_b32 %4, %4, %19\n\t"
-                     "s_branch .Lptend_%=\n\t"
-                     ".Lpt01_%=:\n\t"
-                     "s_cmp_eq_u32 %25, 0\n\t"
-                     "s_cbranch_scc1 .Lpt0_%=\n\t"
+                     ".Lpt1_%=:\n\t"
                      "v_and_b32 %0, %0, %10\n\t"
                      "v_and_b32 %1, %1, %11\n\t"
                      "v_and_b32 %2, %2, %12\n\t"
                      "v_and_b32 %3, %3, %13\n\t"
                      "v_and_b32 %4, %4, %14\n\t"
                      "s_branch .Lptend_%=\n\t"
-                     ".Lpt0_%=:\n\t"
-                     "v_and_b32 %0, %0, %5\n\t"
-                     "v_and_b32 %1, %1, %6\n\t"
-                     "v_and_b32 %2, %2, %7\n\t"
-                     "v_and_b32 %3, %3, %8\n\t"
-                     "v_and_b32 %4, %4, %9\n\t"
+                     ".Lpthi_%=:\n\t"
+                     "s_bitcmp1_b32 %25, %26\n\t"
+                     "s_cbranch_scc1 .Lpt3_%=\n\t"
+                     "v_and_b32 %0, %0, %15\n\t"
+                     "v_and_b32 %1, %1, %16\n\t"
+                     "v_and_b32 %2, %2, %17\n\t"
+                     "v_and_b32 %3, %3, %18\n\t"
+                     "v_and_b32 %4, %4, %19\n\t"
+                     "s_branch .Lptend_%=\n\t"
+                     ".Lpt3_%=:\n\t"
+                     "v_and_b32 %0, %0, %20\n\t"
+                     "v_and_b32 %1, %1, %21\n\t"
+                     "v_and_b32 %2, %2, %22\n\t"
+                     "v_and_b32 %3, %3, %23\n\t"
+                     "v_and_b32 %4, %4, %24\n\t"
                      ".Lptend_%=:"
                      : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])
-                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y0[4]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y1[4]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y2[3]), "v"(y2[4]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "v"(y3[3]), "v"(y3[4]), "s"(code) : "scc");
+                     : "v"(y0[0]), "v"(y0[1]), "v"(y0[2]), "v"(y0[3]), "v"(y0[4]), "v"(y1[0]), "v"(y1[1]), "v"(y1[2]), "v"(y1[3]), "v"(y1[4]), "v"(y2[0]), "v"(y2[1]), "v"(y2[2]), "v"(y2[3]), "v"(y2[4]), "v"(y3[0]), "v"(y3[1]), "v"(y3[2]), "v"(y3[3]), "v"(y3[4]), "s"(cw), "n"(BIT), "n"(BIT + 1) : "scc");
     }
 }
 #endif
 
-template <int NW, int N, int W0>
-ATR_DEV void piece_and_term(uint32_t (&acc)[N], const PieceMasks<NW> &Y, int code) {
+template <int NW, int N, int W0, int BIT>
+ATR_DEV void piece_and_term(uint32_t (&acc)[N], const PieceMasks<NW> &Y, uint32_t cw) {
     static_assert(W0 + N <= NW, "words of the read");
 #ifdef ATR_HOST_EMU
-    for (int i = 0; i < N; ++i) acc[i] &= Y.y[code][W0 + i];
+    for (int i = 0; i < N; ++i) acc[i] &= Y.y[(cw >> BIT) & 3u][W0 + i];
 #else
     // groups of at most five words (the asm operand limit)
     constexpr int G0 = N <= 5 ? N : (N + 1) / 2, G1 = N - G0;
     static_assert(G0 <= 5 && G1 <= 5, "reads of up to 320 bases");
-    piece_and_group<G0>(&acc[0], &Y.y[0][W0], &Y.y[1][W0], &Y.y[2][W0], &Y.y[3][W0], code);
-    if constexpr (G1 > 0) piece_and_group<G1>(&acc[G0], &Y.y[0][W0 + G0], &Y.y[1][W0 + G0], &Y.y[2][W0 + G0], &Y.y[3][W0 + G0], code);
+    piece_and_group<G0, BIT>(&acc[0], &Y.y[0][W0], &Y.y[1][W0], &Y.y[2][W0], &Y.y[3][W0], cw);
+    if constexpr (G1 > 0) piece_and_group<G1, BIT>(&acc[G0], &Y.y[0][W0 + G0], &Y.y[1][W0 + G0], &Y.y[2][W0 + G0], &Y.y[3][W0 + G0], cw);
 #endif
 }
 
@@ -426,14 +429,18 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
 #pragma unroll
         for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
     for (int s = 0; s < pp.steps; ++s) {                             // wave-uniform
+        const uint32_t cw = pp.scode[s];
         if (s < pp.blen) {
-#pragma unroll
-            for (int p = 0; p < PIECE_NB - 1; ++p) piece_and_term<NW, NW, 0>(occ[p], Y, (int)((pp.bcode[p] >> (2 * s)) & 3u));
+            piece_and_term<NW, NW, 0, 0>(occ[0], Y, cw);
+            piece_and_term<NW, NW, 0, 2>(occ[1], Y, cw);
+            piece_and_term<NW, NW, 0, 4>(occ[2], Y, cw);
         }
-        if (s < pp.llen) piece_and_term<NW, NW, 0>(occ[PIECE_NB - 1], Y, (int)((pp.bcode[PIECE_NB - 1] >> (2 * s)) & 3u));
+        if (s < pp.llen) piece_and_term<NW, NW, 0, 6>(occ[3], Y, cw);
         if (s < pp.tlen) {
-#pragma unroll
-            for (int u = 0; u < PIECE_NT; ++u) piece_and_term<NW, TWN, TW0>(tocc[u], Y, (int)((pp.tcode[u] >> (2 * s)) & 3u));
+            piece_and_term<NW, TWN, TW0, 8>(tocc[0], Y, cw);
+            piece_and_term<NW, TWN, TW0, 10>(tocc[1], Y, cw);
+            piece_and_term<NW, TWN, TW0, 12>(tocc[2], Y, cw);
+            piece_and_term<NW, TWN, TW0, 14>(tocc[3], Y, cw);
         }
         if (s + 1 < pp.steps) piece_shift_masks<NW>(Y);
     }
