@@ -681,7 +681,10 @@ ATR_DEV void band_locate_last(const Uniform &u, const uint32_t *rreps, bool noin
     best.ref_stop = u.m; best.query_stop = n; best.matches = 0;
     bm = best;
     const int cindel = noindel ? 0 : u.indel;
-    if (smax < 8) band_rows_last<AND_MODE, 8>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    // (the short overlaps -- floor(i e) = 1: cost 1, four diagonals -- are 40 % of C2's last-column band reads)
+    if (smax < 4) band_rows_last<AND_MODE, 4>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    else if (smax < 6) band_rows_last<AND_MODE, 6>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
+    else if (smax < 8) band_rows_last<AND_MODE, 8>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
     else if (smax < 10) band_rows_last<AND_MODE, 10>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
     else if (smax < 12) band_rows_last<AND_MODE, 12>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
     else if (smax < 14) band_rows_last<AND_MODE, 14>(u, rreps, ns, nss, band, rows_max, cap_lo, active, top, r0, at0, n, thr, cindel, best);
