@@ -76,7 +76,7 @@ __device__ __forceinline__ void linked_drain(const LinkedBlob &S, int ngroups, c
 }
 
 template <bool WIDE, bool RAGGED, bool AND_MODE>
-__global__ __launch_bounds__(256) void linked_filter_kernel(const LinkedBlob *__restrict__ blob,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void linked_filter_kernel(const LinkedBlob *__restrict__ blob,
                                                             const uint4 *__restrict__ packed,
                                                             const int32_t *__restrict__ lens, long long nreads,
                                                             int nchunks, int max_len, uint16_t *__restrict__ which_out,

@@ -56,6 +56,29 @@ def _cython_linked(args):
     return hits
 
 
+def _cython_c5(args):
+    """C5 as bench.py's CPU leg times it: match_insert (read wildcards) and, for an insert match with errors, the
+    liberal correction of the overlap (InsertAdapterCutter.__call__, modifiers.py:397-404, without the trimming)."""
+    from atropos.adapters import Adapter, BACK
+    from atropos.commands.trim.modifiers import InsertAdapterCutter
+    from atropos.io.seqio import Sequence
+    from atropos.util import RandomMatchProbability
+    a1, a2, quads = args
+    akw = dict(max_error_rate=0.2, min_overlap=1, indel_cost=3, match_probability=RandomMatchProbability(), max_rmp=1e-6,
+               read_wildcards=True)
+    cutter = InsertAdapterCutter(Adapter(a1, BACK, name="a1", **akw), Adapter(a2, BACK, name="a2", **akw), action='trim',
+                                 mismatch_action='liberal', read_wildcards=True)
+    hits = 0
+    for r1, q1, r2, q2 in quads:
+        s1, s2 = Sequence(name="p", sequence=r1, qualities=q1), Sequence(name="p", sequence=r2, qualities=q2)
+        im = cutter.aligner.match_insert(r1, r2)
+        if im is not None:
+            hits += 1
+            if im[0][5] > 0:
+                cutter.correct_errors(s1, s2, im[0], truncate_seqs=True)
+    return hits
+
+
 def timed(fn):
     t0 = time.perf_counter()
     fn()
@@ -105,6 +128,27 @@ def main():
         out["C4_cython_allcores"] = N_LINKED / timed(lambda: pool.map(_cython_linked, parts))
     out["C4_port_1thread"] = N_LINKED / timed(lambda: O.linked_many(w["fronts"], w["backs"], mat, lens, 0.12, 3, 1, True, False, 1))
     out["C4_port_allthreads"] = N_LINKED / timed(lambda: O.linked_many(w["fronts"], w["backs"], mat, lens, 0.12, 3, 1, True, False, cores))
+    # C5-like: match + liberal correction (the oracle's orc_correct_errors, round 3)
+    n5 = 20_000
+    w = synth.workload("C5", 0, n5)
+    quads = list(zip(_rows(w["reads1"]), _rows(w["quals1"]), _rows(w["reads2"]), _rows(w["quals2"])))
+    out["C5_cython_1core_pairs"] = n5 / timed(lambda: _cython_c5((synth.PE_ADAPTER1, synth.PE_ADAPTER2, quads)))
+    with mp.Pool(cores, initializer=_init_worker) as pool:
+        parts = [(synth.PE_ADAPTER1, synth.PE_ADAPTER2, quads[i::cores]) for i in range(cores)]
+        pool.map(_cython_c5, parts)
+        out["C5_cython_allcores_pairs"] = n5 / timed(lambda: pool.map(_cython_c5, parts))
+    orc5 = O.InsertOracle(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
+    l5 = np.full(n5, 250, np.int32)
+    m = [w[k].numpy() for k in ("reads1", "reads2", "quals1", "quals2")]
+
+    def port5(threads):
+        a1, a2, b1, b2 = (x.copy() for x in m)
+        rec = O.match_insert_many(orc5, a1, l5, a2, l5, threads)
+        O.insert_correct_many(rec, a1, b1, l5, a2, b2, l5, "liberal", 1, threads)
+    out["C5_port_1thread_pairs"] = n5 / timed(lambda: port5(1))
+    out["C5_port_allthreads_pairs"] = n5 / timed(lambda: port5(cores))
+    out["C5_port_over_cython_1"] = out["C5_port_1thread_pairs"] / out["C5_cython_1core_pairs"]
+    out["C5_port_over_cython_all"] = out["C5_port_allthreads_pairs"] / out["C5_cython_allcores_pairs"]
     for k in ("C2", "C4"):
         out[k + "_port_over_cython_1"] = out[k + "_port_1thread"] / out[k + "_cython_1core"]
         out[k + "_port_over_cython_all"] = out[k + "_port_allthreads"] / out[k + "_cython_allcores"]
