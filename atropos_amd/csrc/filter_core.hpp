@@ -314,6 +314,26 @@ ATR_DEV void filter_fold(FilterState &F, int j, int mf, uint32_t kreg) {
     F.hits = F.nz = 0u;
 }
 
+// q = 4 q + 2 (d1 < t1) + (d2 < t2), unsigned: the two tests as borrows of d - t (v_subrev_co_u32), taken over by two
+// add-with-carry ops.  T: the thresholds are wave-uniform (an SGPR operand) or per lane.
+template <class T>
+ATR_DEV uint32_t filter_push_le2(uint32_t q, int d1, T t1, int d2, T t2) {
+#ifdef ATR_HOST_EMU
+    return (q << 2) | ((uint32_t)d1 < (uint32_t)t1 ? 2u : 0u) | ((uint32_t)d2 < (uint32_t)t2 ? 1u : 0u);
+#else
+    uint32_t x1, x2;
+    uint64_t c;
+    asm("v_subrev_co_u32 %1, vcc, %5, %4\n\t"
+        "v_subrev_co_u32 %2, %3, %7, %6\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %0, %3, %0, %0, %3"
+        : "+v"(q), "=&v"(x1), "=&v"(x2), "=&s"(c) : "v"(d1), "v"((uint32_t)t1), "v"(d2), "v"((uint32_t)t2) : "vcc");
+    return q;
+#endif
+}
+
 // Last column (column n): which rows could pass the candidate test?  The alignment length is
 // at most the row and the threshold is monotone in the length, so D[i][n] <= thr[i] is a
 // necessary condition.  Returns the largest such row (0: none) and its cost; exact = false
@@ -334,22 +354,35 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &
     int d = 0, largest = 0;                         // D[0][n] = 0; row 0 never qualifies (min_overlap >= 1)
     exact = true;
     const int off = filter_row_offset(mf, WIDE);
-    // per row: two bit-field extracts, an add3, a compare against an SGPR and a select
     const int low_rows = WIDE ? atr_max(0, atr_min(mf, 32 - off)) : mf;             // rows that live in the low word
-#ifndef ATR_HOST_EMU
-#pragma unroll 4
-#endif
-    for (int i = 1; i <= low_rows; ++i) {
-        const int b = off + i - 1;
-        d += (int)((F.pvl >> b) & 1u) + ((int)(F.mvl << (31 - b)) >> 31);          // +1 / -1
-        if (d <= fp.thr_row[i]) largest = i;
+    // Per row: d += the row's vertical delta, "d <= thr_row[i]" pushed into a bit vector -- bit 0 of the deltas walked down
+    // by right shifts, the test as the BORROW of d - (thr + 1) taken over by an add-with-carry: eight ops of the 2-cycle
+    // classes (round 3: two v_bfe, v_add3, v_cmp, v_cndmask -- twelve 4-cycle ops a row, a quarter of the decision).
+    // q bit (rows - i) <=> row i qualifies; the largest qualifying row is the lowest set bit.
+    const auto scan = [&](uint32_t pv, uint32_t mv, int first, int rows) -> uint32_t {
+        uint32_t q = 0u;
+        int i = 0;
+        for (; i + 2 <= rows; i += 2) {             // two rows per block: each carry is read three instructions after its write
+            const int d1 = d + (int)(pv & 1u) - (int)(mv & 1u);
+            const int d2 = d1 + (int)((pv >> 1) & 1u) - (int)((mv >> 1) & 1u);
+            pv >>= 2; mv >>= 2;
+            d = d2;
+            q = filter_push_le2(q, d1, fp.thr_row[first + i] + 1, d2, fp.thr_row[first + i + 1] + 1);
+        }
+        if (i < rows) {
+            d += (int)(pv & 1u) - (int)(mv & 1u);
+            q = (q << 1) | ((uint32_t)d < (uint32_t)(fp.thr_row[first + i] + 1) ? 1u : 0u);
+        }
+        return q;
+    };
+    {
+        const uint32_t q = scan(off >= 32 ? 0u : F.pvl >> (off & 31), off >= 32 ? 0u : F.mvl >> (off & 31), 1, low_rows);
+        if (q != 0u) largest = low_rows - atr_ctz(q);
     }
     if (WIDE) {
-        for (int i = low_rows + 1; i <= mf; ++i) {
-            const int b = off + i - 1 - 32;
-            d += (int)((F.pvh >> b) & 1u) + ((int)(F.mvh << (31 - b)) >> 31);
-            if (d <= fp.thr_row[i]) largest = i;
-        }
+        const int hoff = off > 32 ? off - 32 : 0, hrows = mf - low_rows;
+        const uint32_t q = scan(F.pvh >> hoff, F.mvh >> hoff, low_rows + 1, hrows);
+        if (q != 0u) largest = low_rows + hrows - atr_ctz(q);
     }
     if (WIDE) {   // its cost: the vertical deltas of rows 1 .. largest
         const uint64_t rows = (largest >= 64 ? ~0ull : ((1ull << largest) - 1ull)) << off;
