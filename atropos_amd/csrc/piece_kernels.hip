@@ -61,7 +61,7 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
 }
 
 template <int NW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5 : NW <= 6 ? 4 : NW <= 8 ? 3 : 2, 8))) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
                                                            const uint4 *__restrict__ planes, long long nreads, int n,
                                                            uint4 *__restrict__ out, FastWork wk) {
     __shared__ uint2 s_peq[16];
