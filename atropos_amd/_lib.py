@@ -111,8 +111,8 @@ PROTOTYPES = {
     "atr_multi_locate_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_compare_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
-    "atr_locate_planes_applies": (C.c_int, [C.c_void_p, C.c_int]),
-    "atr_locate_planes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_locate_planes_applies": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "atr_locate_planes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]),
     "atr_linked_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -421,20 +421,20 @@ class HipBackend(object):
                                                                 _ptr(work), code, self._stream()), "atr_locate_batch")
         return out
 
-    def locate_planes_applies(self, h, max_len):
-        """Is this aligner on equal-length reads of max_len bases inside the envelope of the two-pass pre-pass
-        (plane64 reads, atr_locate_planes_batch)?"""
-        return bool(self.lib.atr_locate_planes_applies(h, int(max_len)))
+    def locate_planes_applies(self, h, max_len, ragged=False):
+        """Is this aligner on reads of max_len bases (ragged: of at most max_len) inside the envelope of the
+        two-pass pre-pass (plane64 reads, atr_locate_planes_batch)?"""
+        return bool(self.lib.atr_locate_planes_applies(h, int(max_len), int(bool(ragged))))
 
-    def locate_planes_batch(self, h, planes, nreads, max_len):
-        """Batched locate on a plane64 batch of equal-length reads (atr_locate_planes_batch)."""
+    def locate_planes_batch(self, h, planes, lens, nreads, max_len):
+        """Batched locate on a plane64 batch (atr_locate_planes_batch); lens None: equal-length reads."""
         out = self.empty((nreads, 8), torch.int16)
         if nreads:
             need = self.lib.atr_locate_work_bytes(nreads)
             if self._work is None or self._work.numel() < need:
                 self._work = self.empty((need,), torch.uint8)
             with torch.cuda.device(self.device):
-                _check(self.lib, self.lib.atr_locate_planes_batch(h, _ptr(planes), nreads, max_len, _ptr(out), _ptr(self._work),
+                _check(self.lib, self.lib.atr_locate_planes_batch(h, _ptr(planes), _ptr(lens), nreads, max_len, _ptr(out), _ptr(self._work),
                                                                   self._stream()), "atr_locate_planes_batch")
         return out
 

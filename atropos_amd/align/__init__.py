@@ -191,25 +191,25 @@ class Aligner(object):
         """Pack reads for this aligner.  ``reads``: a ReadBatch (returned unchanged if
         compatible), a sequence of str/bytes, or a uint8 [nreads, width] array/tensor.
         ``layout``: "tile64" (4-bit codes), "plane64" (bit planes of the codes: what the two-pass
-        pre-pass of ``locate_batch`` reads, equal-length batches only) or "auto" -- plane64 for a long
-        equal-length batch when that pre-pass takes this aligner, else tile64."""
+        pre-pass of ``locate_batch`` reads) or "auto" -- plane64 for a long batch when that pre-pass
+        takes this aligner, else tile64."""
         if isinstance(reads, ReadBatch):
             self._check_batch(reads)
             return reads
         kind = self._table_kind
         table = self._table if self._table is not None else self._backend.translate_table(kind)
         if isinstance(reads, (list, tuple)):
-            width = len(reads[0]) if len(reads) else 0
-            # (from_strings packs planes only when every read has that length)
-            return ReadBatch.from_strings(reads, kind, table, self._backend, planes=self._wants_planes(layout, len(reads), width))
+            widths = set(map(len, reads))
+            planes = self._wants_planes(layout, len(reads), max(widths) if widths else 0, ragged=len(widths) > 1)
+            return ReadBatch.from_strings(reads, kind, table, self._backend, planes=planes)
         planes = self._wants_planes(layout, reads.shape[0], reads.shape[1])
         return ReadBatch.from_ascii(reads, None, None, kind, table, self._backend, planes=planes)
 
-    def _wants_planes(self, layout, nreads, width):
+    def _wants_planes(self, layout, nreads, width, ragged=False):
         if layout == "tile64" or self._handle is None or getattr(self, "_long", False):
             return False
         be = self._backend
-        ok = hasattr(be, "locate_planes_applies") and width > 0 and be.locate_planes_applies(self._handle, width)
+        ok = hasattr(be, "locate_planes_applies") and width > 0 and be.locate_planes_applies(self._handle, width, ragged)
         if layout == "plane64":
             if not ok:
                 raise _lib.AtroposUnsupported("the plane64 layout (two-pass pre-pass) does not take this aligner / read length")
@@ -260,9 +260,9 @@ class Aligner(object):
             rec[:, 1] = -1
             return LocateResult(rec)
         if batch.layout == "plane64":
-            if path not in (None, "auto", "pieces") or not filtered or batch.lens is not None:
+            if path not in (None, "auto", "pieces") or not filtered:
                 self._need_tile64(batch, "locate_batch(path=%r)" % (path if filtered else "full"))
-            return LocateResult(be.locate_planes_batch(self._handle, batch.packed, batch.nreads, batch.max_len))
+            return LocateResult(be.locate_planes_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len))
         if path == "pieces":
             raise ValueError("path \"pieces\" (the two-pass pre-pass) reads the plane64 layout: aligner.pack(reads, layout=\"plane64\")")
         return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len,

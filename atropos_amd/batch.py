@@ -106,7 +106,7 @@ class ReadBatch(object):
             return cls(be.empty((16,), torch.uint8), None, 0, 0, table_kind, table)
         if int(lens.min()) == mat.shape[1]:               # equal lengths: no length array (the kernels' uniform path)
             lens = None
-        return cls.from_ascii(mat, lens, None, table_kind, table, backend, planes=planes and lens is None)
+        return cls.from_ascii(mat, lens, None, table_kind, table, backend, planes=planes)
 
 
 class LocateResult(object):

@@ -15,8 +15,9 @@ namespace atr {
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st);
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out);
-int launch_locate_planes(const atr_aligner *a, const uint4 *planes, long long nreads, int max_len, uint4 *out, void *work,
-                         hipStream_t st);
+int piece_ragged_len(int max_len);
+int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
+                         void *work, hipStream_t st);
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                        int max_len, uint4 *out, hipStream_t st);
 int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2,
@@ -282,17 +283,18 @@ int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const i
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "locate_kernel launch");
 }
 
-int atr_locate_planes_applies(const atr_aligner *a, int max_len) {
-    return (a && max_len >= 1 && max_len <= ATR_MAX_READ_LEN && piece_applies(a, max_len, nullptr, nullptr)) ? 1 : 0;
+int atr_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
+    if (!a || max_len < 1 || max_len > ATR_MAX_READ_LEN) return 0;
+    return piece_applies(a, ragged ? piece_ragged_len(max_len) : max_len, nullptr, nullptr) ? 1 : 0;
 }
 
-int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, int64_t nreads, int max_len, atr_result *d_out,
-                            void *d_work, void *stream) {
+int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, const int32_t *d_lens, int64_t nreads, int max_len,
+                            atr_result *d_out, void *d_work, void *stream) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
     if (!d_out || !d_planes || !d_work) return ATR_ERR_INVALID;
-    if (!piece_applies(a, max_len, nullptr, nullptr)) return ATR_ERR_UNSUPPORTED;
-    const int rc = launch_locate_planes(a, (const uint4 *)d_planes, nreads, max_len, (uint4 *)d_out, d_work, (hipStream_t)stream);
+    if (!piece_applies(a, d_lens ? piece_ragged_len(max_len) : max_len, nullptr, nullptr)) return ATR_ERR_UNSUPPORTED;
+    const int rc = launch_locate_planes(a, (const uint4 *)d_planes, d_lens, nreads, max_len, (uint4 *)d_out, d_work, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "two-pass locate launch");
 }
 

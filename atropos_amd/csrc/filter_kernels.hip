@@ -45,7 +45,7 @@ constexpr int DP_STREAMS = 4;                            // >= LINKED_MAX: band 
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                    int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes) {
     static thread_local SideStream side[DP_STREAMS];
-    if (planes && (la || lens)) return (int)hipErrorInvalidValue;        // plane64: the single-aligner pipeline on equal-length reads
+    if (planes && la) return (int)hipErrorInvalidValue;                  // plane64: the single-aligner pipeline
     if (count < 1 || count > DP_STREAMS || idx < 0 || idx >= count) return (int)hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     // a short batch (the <= 1000 reads the unchanged trim command hands over per call) leaves most of the chip

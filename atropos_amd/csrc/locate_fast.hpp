@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     __shared__ int16_t s_thr[ATR_MAX_REF_LEN + 2];
     __shared__ uint32_t s_init[ATR_MAX_REF_LEN + 1];
     __shared__ __attribute__((aligned(16))) uint32_t s_nm[16][4];
-    __shared__ uint32_t s_spread_flat[PLANES ? 1024 : 1];          // plane64 reads (equal-length batches only)
+    __shared__ uint32_t s_spread_flat[PLANES ? 1024 : 1];          // plane64 reads
     uint32_t (*s_spread)[256] = (uint32_t (*)[256])s_spread_flat;
     const Uniform u = make_uniform(p, MT);
     if (threadIdx.x < 64) s_nm[threadIdx.x >> 2][threadIdx.x & 3] = p.nmask[threadIdx.x >> 2][threadIdx.x & 3];
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         // to the read end.  A lane whose read starts inside the swept range (column shift) restarts there from
         // the initial column, which without START_WITHIN_SEQ1 is the fresh-window column itself.
         const bool rows_wave = __builtin_amdgcn_readfirstlane((int)(first + wv * lpw >= (long long)wk.binbase[bin0 + ROWS_BIN0])) != 0;
-        if (!LINKED && !PLANES && lens != nullptr && rows_wave && !u.sr) {
+        if (!LINKED && lens != nullptr && rows_wave && !u.sr) {
             const int shift = live ? max_len - n : 0;
             const int v0 = wave_min_i32(live ? j_lo + shift : 0x7fffffff);
             if (max_len - v0 <= TAIL_COLUMNS && v0 < max_len) {
@@ -468,7 +468,10 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
                     const uint32_t sh = 4u * (uint32_t)(dlo & 7);
                     uint32_t raw[TAIL_COLUMNS / 8 + 1];
 #pragma unroll
-                    for (int t = 0; t <= TAIL_COLUMNS / 8; ++t) raw[t] = live ? read_dword((const uint32_t *)tp, nchunks, z0 + t) : 0u;
+                    for (int t = 0; t <= TAIL_COLUMNS / 8; ++t) {
+                        if constexpr (PLANES) raw[t] = live ? read_dword_planes((const uint32_t *)tp, nchunks, z0 + t, s_spread) : 0u;
+                        else raw[t] = live ? read_dword((const uint32_t *)tp, nchunks, z0 + t) : 0u;
+                    }
 #pragma unroll
                     for (int t = 0; t < TAIL_COLUMNS / 8; ++t) tb[t] = sh ? ((raw[t] >> sh) | (raw[t + 1] << (32u - sh))) : raw[t];
                 }

@@ -60,10 +60,15 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
     }
 }
 
-template <int NW>
+// RAGGED: reads of different lengths (lens[r] <= max_len).  Pass A then works on the read moved to the END of its
+// NW words (a per-lane shift of the planes by 32 NW - n positions, zeros coming in below): every read ends at
+// position 32 NW like a read of an equal-length batch, the read-end conditions keep their wave-uniform masks, and the
+// columns it reports are shifted back by the lane's own amount.  Positions before the read hold code 0 either way.
+template <int NW, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5 : NW <= 6 ? 4 : NW <= 8 ? 3 : 2, 8))) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
-                                                           const uint4 *__restrict__ planes, long long nreads, int n,
-                                                           uint4 *__restrict__ out, FastWork wk) {
+                                                           const uint4 *__restrict__ planes, const int32_t *__restrict__ lens,
+                                                           long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk) {
+    const int n = RAGGED ? 32 * NW : max_len;                     // the length pass A sees (wave-uniform)
     __shared__ uint2 s_peq[16];
     __shared__ uint32_t s_spread[4][256];
     __shared__ uint32_t s_hist[FILTER_BINS];
@@ -99,7 +104,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
         const bool act = lane < count;
         const long long r = (long long)queue[0][lane];
         const uint32_t meta = queue[1][lane];
-        const int j_e = act ? (int)(meta & 1023u) : 0, need = act ? (int)(meta >> 10) : 0;
+        const int j_e = act ? (int)(meta & 1023u) : 0, need = act ? (int)((meta >> 10) & 127u) : 0;
+        const int nr = RAGGED ? (act ? (int)(meta >> 17) : 0) : max_len;       // the read's own length
         uint32_t wp[4][2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { wp[q][0] = queue[2 + 2 * q][lane]; wp[q][1] = queue[3 + 2 * q][lane]; }
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
             const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
             return fp.and_mode ? nz == ones : nz == 0u;
         };
-        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n);
+        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr);
         piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PIECE_WINDOW, &s_lcur, s_hist);
     };
 
@@ -161,6 +167,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
         uint32_t pl[NW][4];
 #pragma unroll
         for (int w = 0; w < NW; ++w) { pl[w][0] = nx[w].x; pl[w][1] = nx[w].y; pl[w][2] = nx[w].z; pl[w][3] = nx[w].w; }
+        int nr = max_len, back = 0;                               // the read's own length; positions it is moved up by
+        if (RAGGED) {
+            nr = live ? min(max(lens[r], 0), max_len) : 0;
+            back = 32 * NW - nr;
+            // out[w] = (in[w - q] : in[w - q - 1]) >> ((-back) & 31), q = (back - 1) >> 5 in -1 .. NW - 1: the two words
+            // picked with per-lane masks (q == v) and (a & b) | c ops, one funnel shift per word
+            const int q = (back - 1) >> 5;
+            const uint32_t sh = (uint32_t)(-back) & 31u;
+            uint32_t x0[NW][4], x1[NW][4];
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) x0[w][c] = x1[w][c] = 0u;
+#pragma unroll
+            for (int v = -1; v <= NW - 1; ++v) {
+                const uint32_t sel = q == v ? ~0u : 0u;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (w - v - 1 >= 0 && w - v - 1 < NW) x0[w][c] |= pl[w - v - 1 >= 0 && w - v - 1 < NW ? w - v - 1 : 0][c] & sel;
+                        if (w - v >= 0 && w - v < NW) x1[w][c] |= pl[w - v >= 0 && w - v < NW ? w - v : 0][c] & sel;
+                    }
+            }
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) pl[w][c] = __builtin_amdgcn_alignbit(x1[w][c], x0[w][c], sh);
+        }
         uint32_t twp[4];                                          // the last 32 positions of every plane
         {
             const int sh = n & 31;
@@ -171,9 +206,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
         const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
         // the adapter verbatim: resolved here (_align.pyx:456-458), no pass B (22 % of C2's reads)
         const bool exact = live && S.j_exact != 0 && u.m >= u.min_overlap;
-        if (exact) out[r] = make_uint4((uint32_t)u.m << 16, (uint32_t)(S.j_exact - u.m) | ((uint32_t)S.j_exact << 16), (uint32_t)u.m, 0u);
+        if (exact) {
+            const int j = S.j_exact - back;                       // in the read's own columns
+            out[r] = make_uint4((uint32_t)u.m << 16, (uint32_t)(j - u.m) | ((uint32_t)j << 16), (uint32_t)u.m, 0u);
+        }
         const bool flagged = live && S.flagged && !exact;
-        const int need = S.j_e - S.j_s;
+        const int need = S.j_e - max(S.j_s, back);                // (columns before the read: nothing to sweep)
         const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
         if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);   // None
         // the 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e) = the words w0,
@@ -200,7 +238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
                 wp[q][1] = __builtin_amdgcn_alignbit(x2[q], x1[q], sh);
             }
         }
-        const uint32_t meta = (uint32_t)S.j_e | ((uint32_t)need << 10);
+        // (the window was cut out of the moved planes with the moved column; the task carries the read's own columns)
+        const uint32_t meta = (uint32_t)(S.j_e - back) | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);
         {
             // reads that need the full sweep (3 % on C2): into the global list, with their planes while they are in
             // registers (the sweep kernel would gather them 16 bytes per 128-byte line)
@@ -212,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
                 if (wide) {
                     const long long slot = (long long)base + __popcll(wm & lt);
                     wlist[slot] = (uint32_t)r;
-                    if (slot < wcap) {
+                    if (!RAGGED && slot < wcap) {                             // (a ragged batch: pl is the MOVED read; the sweep gathers)
 #pragma unroll
                         for (int w = 0; w < NW; ++w) wplanes[slot * NW + w] = make_uint4(pl[w][0], pl[w][1], pl[w][2], pl[w][3]);
                     }
@@ -256,10 +295,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
         for (long long base = (long long)wave * 64; base < total; base += 256) {
             const bool act = base + lane < total;
             const long long r = act ? (long long)wlist[base + lane] : t0 * 64;
-            const bool copied = base + lane < wcap;
+            const bool copied = !RAGGED && base + lane < wcap;
             const uint4 *bp = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);       // the read in the batch
             const uint4 *tp = copied ? wplanes + (base + lane) * NW : bp;
             const size_t tstride = copied ? 1 : 64;
+            // (a ragged batch: a lane stops at its own last column, the wave at the longest read's)
+            const int nl = RAGGED ? (act ? min(max(lens[r], 0), max_len) : 0) : max_len;
+            const int nhi = RAGGED ? wave_max_i32(nl) : max_len;
             FilterState F;
             filter_init(F, u, mf);
             int j = 0;
@@ -271,15 +313,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
                 const uint4 v = vv[c];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    if (j >= n) break;                                         // wave-uniform
+                    if (j >= nhi) break;                                       // wave-uniform
                     uint2 e[8];
                     fetch_peq8(s_peq, piece_nibbles(s_spread, v.x, v.y, v.z, v.w, d), e);
 #pragma unroll
                     for (int b = 0; b < 8; ++b)
-                        if (j + b < n) filter_step<false>(F, e[b].x, e[b].y, kreg);
+                        if (j + b < nl) filter_step<false>(F, e[b].x, e[b].y, kreg);
                     j += 8;
                 }
-                filter_fold(F, min(j, n), mf, kreg);
+                filter_fold(F, min(j, nl), mf, kreg);
             }
             uint32_t rec[4];
             const auto tm = [&](int jp) {
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5
                 const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
                 return fp.and_mode ? nz == ones : nz == 0u;
             };
-            const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true);
+            const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nl, rec, 0, true);
             piece_emit(act, r, ww, rec, u.m, out, list, ldata, nullptr, 0, &s_lcur, s_hist);
         }
     }
@@ -322,14 +364,14 @@ __global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, in
 // Blocks of P1 the device holds at once: P1 is a persistent grid -- a wave's task queue wants many tiles, and a grid
 // of exactly the resident blocks has no partial last round (2048 blocks on 768 slots cost a third round: 0.72 ms
 // instead of 0.5).  Per thread and device: the occupancy query is not free.
-template <int NW>
+template <int NW, bool RAGGED>
 static int piece_resident_blocks() {
     static thread_local int cached_dev = -1, cached = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (dev != cached_dev) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, piece_filter_kernel<NW>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, piece_filter_kernel<NW, RAGGED>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         cached = std::min(FAST_BLOCKS, per_cu * cus);
         cached_dev = dev;
@@ -339,12 +381,21 @@ static int piece_resident_blocks() {
 
 template <int NW>
 static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
-                                long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
-    wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW>(), ((nreads + 63) / 64 + 3) / 4));
-    hipLaunchKernelGGL((piece_filter_kernel<NW>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, nreads, max_len, out, wk);
+                                const int32_t *lens, long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
+    const long long want = ((nreads + 63) / 64 + 3) / 4;
+    if (lens) {
+        wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW, true>(), want));
+        hipLaunchKernelGGL((piece_filter_kernel<NW, true>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, lens, nreads, max_len, out, wk);
+    } else {
+        wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW, false>(), want));
+        hipLaunchKernelGGL((piece_filter_kernel<NW, false>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, lens, nreads, max_len, out, wk);
+    }
 }
 
 // Does the two-pass pre-pass take this aligner on equal-length reads of max_len bases?  (+ its parameters)
+// A ragged batch of reads of at most max_len bases is the equal-length case of 32 ceil(max_len / 32) bases
+// (piece_filter_kernel<.., RAGGED> moves every read to the end of its words): see piece_ragged_len().
+int piece_ragged_len(int max_len) { return 32 * ((max_len + 31) / 32); }
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out) {
     if (!a->filterable || max_len < 1) return false;
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
@@ -358,25 +409,26 @@ bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, Piec
     return true;
 }
 
-int launch_locate_planes(const atr_aligner *a, const uint4 *planes, long long nreads, int max_len, uint4 *out, void *work,
-                         hipStream_t st) {
+// lens == nullptr: every read has max_len bases
+int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
+                         void *work, hipStream_t st) {
     FilterParams fp;
     PieceParams pp;
-    if (!piece_applies(a, max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
+    if (!piece_applies(a, lens ? piece_ragged_len(max_len) : max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
     FastWork wk = fast_carve(work, nreads);
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const int nw = (max_len + 31) / 32;
     switch (nw) {
-    case 3: launch_piece_filter<3>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
-    case 4: launch_piece_filter<4>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
-    case 5: launch_piece_filter<5>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
-    case 6: launch_piece_filter<6>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
-    case 8: launch_piece_filter<8>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
-    default: launch_piece_filter<10>(a, fp, pp, planes, nreads, max_len, out, wk, st); break;
+    case 3: launch_piece_filter<3>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+    case 4: launch_piece_filter<4>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+    case 5: launch_piece_filter<5>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+    case 6: launch_piece_filter<6>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+    case 8: launch_piece_filter<8>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+    default: launch_piece_filter<10>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
     }
     launch_fast_scan(wk, st);
     hipLaunchKernelGGL(piece_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m, wk);
-    return launch_fast_dp(a, planes, nullptr, nreads, nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true);
+    return launch_fast_dp(a, planes, lens, nreads, nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true);
 }
 
 }  // namespace atr

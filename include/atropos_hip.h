@@ -150,17 +150,20 @@ size_t atr_locate_work_bytes(int64_t nreads);
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                      int64_t nreads, int max_len, atr_result *d_out, void *d_work, void *stream);
 
-/* Aligner.locate(query) for a batch of EQUAL-LENGTH reads in the plane64 layout (atr_pack_planes with the
- * aligner's query table; _align.pyx:266-491, same records as atr_locate_batch).  The two-pass pre-pass: exact
+/* Aligner.locate(query) for a batch of reads in the plane64 layout (atr_pack_planes with the aligner's query
+ * table; _align.pyx:266-491, same records as atr_locate_batch).  d_lens as in atr_locate_batch (NULL: every read
+ * has max_len bases; else the positions of a read past its length must hold code 0, as atr_pack_planes leaves
+ * them).  The two-pass pre-pass: exact
  * pieces of the adapter located 32 read positions per boolean op, then Myers' bit-vector sweep over a 64-column
  * window of the flagged reads only, then the exact DP of atr_locate_batch's filtered pipeline on what is left.
  * atr_locate_planes_applies: 1 when this aligner and read length are inside its envelope (3' adapters -- no
  * START_WITHIN_SEQ1 --, up to 40 bases, int(e * m) <= 3, A / C / G / T in the adapter's first 32 bases, reads of
- * 65 .. 192, 225 .. 256 or 289 .. 320 bases), else 0: pack tile64 and call atr_locate_batch.
+ * 65 .. 192, 225 .. 256 or 289 .. 320 bases; ragged != 0: a batch with d_lens, max_len the longest read), else 0:
+ * pack tile64 and call atr_locate_batch.
  * d_work: atr_locate_work_bytes(nreads) bytes.  ATR_ERR_UNSUPPORTED outside the envelope. */
-int atr_locate_planes_applies(const atr_aligner *a, int max_len);
-int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, int64_t nreads, int max_len,
-                            atr_result *d_out, void *d_work, void *stream);
+int atr_locate_planes_applies(const atr_aligner *a, int max_len, int ragged);
+int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, const int32_t *d_lens, int64_t nreads,
+                            int max_len, atr_result *d_out, void *d_work, void *stream);
 
 /* The same with the kernels named (identical records on every path; for cross-checks and tuning).
  * Short batches -- the 1000 reads the reference's trim command hands over per call

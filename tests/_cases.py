@@ -211,14 +211,24 @@ def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=2
         except unsupported_exc:
             continue
         n = rng.choice(lengths)
-        reads = piece_reads(rng, ref, n, count, e)
-        mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(len(reads), n).copy()
+        if rng.random() < 0.4:
+            # a ragged batch (the pre-pass moves every read to the end of its words): the same kinds of reads at
+            # several lengths, from empty to n, shuffled
+            reads = piece_reads(rng, ref, n, count // 4, e)
+            for _ in range(5):
+                ni = rng.choice([rng.randint(0, 8), rng.randint(0, m + 4), rng.randint(0, n), rng.randint(max(0, n - 40), n), n - 1, n - 32])
+                reads += piece_reads(rng, ref, max(0, ni), count // 6, e)
+            rng.shuffle(reads)
+            mat = reads
+        else:
+            reads = piece_reads(rng, ref, n, count, e)
+            mat = np.frombuffer("".join(reads).encode(), np.uint8).reshape(len(reads), n).copy()
         try:
             planes = al.pack(mat, layout="plane64")
         except unsupported_exc:
             refused += 1
             continue
-        assert planes.layout == "plane64"
+        assert planes.layout == "plane64" and (planes.lens is None) == (len(set(map(len, reads))) == 1)
         got = al.locate_batch(planes).tuples()
         tiles = al.pack(mat, layout="tile64")
         assert got == al.locate_batch(tiles, path="full").tuples()

@@ -243,15 +243,15 @@ class EmuBackend(object):
                    "atr_locate_batch")
         return out
 
-    def locate_planes_applies(self, h, max_len):
-        self.lib.emu_locate_planes_all_widths.argtypes = [C.c_void_p, C.c_int]
-        return bool(self.lib.emu_locate_planes_all_widths(h, int(max_len)))
+    def locate_planes_applies(self, h, max_len, ragged=False):
+        self.lib.emu_locate_planes_all_widths.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        return bool(self.lib.emu_locate_planes_all_widths(h, int(max_len), int(bool(ragged))))
 
-    def locate_planes_batch(self, h, planes, nreads, max_len):
+    def locate_planes_batch(self, h, planes, lens, nreads, max_len):
         out = torch.zeros((nreads, 8), dtype=torch.int16)
         if nreads:
-            self.lib.emu_locate_planes_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
-            _check(self.lib.emu_locate_planes_batch(h, _ptr(planes), nreads, max_len, _ptr(out)), "atr_locate_planes_batch")
+            self.lib.emu_locate_planes_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+            _check(self.lib.emu_locate_planes_batch(h, _ptr(planes), _ptr(lens), nreads, max_len, _ptr(out)), "atr_locate_planes_batch")
         return out
 
     def linked_create(self, specs):

@@ -255,12 +255,28 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
 // reads it leaves open (from a tile64 copy of the planes).  The window length varies with the read number the way
 // it varies with a wave's other lanes on the GPU: the records must not depend on it.
 static long long g_piece_stats[6], g_piece_need[12];   // need histogram, 8 columns per bin      // reads, flagged, read-end condition, wide, window columns swept, open after pass B
+// nr >= 0: a ragged batch -- pass A sees the read moved to the end of its NW words (n = 32 NW), as the kernel does
 template <int NW>
 static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const PieceParams &pp, const uint32_t *planes,
-                               const uint32_t *nib, long long r, int n, uint32_t rec[4]) {
+                               const uint32_t *nib, long long r, int n, int nr, uint32_t rec[4]) {
     uint32_t pl[NW][4], twp[4];
     for (int w = 0; w < NW; ++w)
         for (int q = 0; q < 4; ++q) pl[w][q] = planes[((((size_t)(r >> 6) * NW) + w) * 64 + (r & 63)) * 4 + q];
+    const int back = nr >= 0 ? 32 * NW - nr : 0;
+    if (nr >= 0) {
+        uint32_t mv[NW][4];
+        for (int w = 0; w < NW; ++w)
+            for (int q = 0; q < 4; ++q) {
+                uint32_t v = 0u;
+                for (int b = 0; b < 32; ++b) {
+                    const int src = 32 * w + b - back;
+                    if (src >= 0 && ((pl[src >> 5][q] >> (src & 31)) & 1u)) v |= 1u << b;
+                }
+                mv[w][q] = v;
+            }
+        memcpy(pl, mv, sizeof(pl));
+        n = 32 * NW;
+    } else nr = n;
     for (int q = 0; q < 4; ++q) {
         const int sh = n & 31;
         twp[q] = sh == 0 ? pl[NW - 1][q] : piece_funnel(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, sh);
@@ -270,29 +286,32 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     rec[0] = 0xFFFF0000u; rec[1] = rec[2] = rec[3] = 0u;
     ++g_piece_stats[0];
     if (S.j_exact != 0 && u.m >= u.min_overlap) {          // the adapter verbatim: the reference's early exit
-        rec[0] = (uint32_t)u.m << 16; rec[1] = (uint32_t)(S.j_exact - u.m) | ((uint32_t)S.j_exact << 16); rec[2] = (uint32_t)u.m;
+        const int j = S.j_exact - back;
+        rec[0] = (uint32_t)u.m << 16; rec[1] = (uint32_t)(j - u.m) | ((uint32_t)j << 16); rec[2] = (uint32_t)u.m;
         return 0u;
     }
     if (!S.flagged) return 0u;
+    const int need = S.j_e - std::max(S.j_s, back);
+    const int j_e = S.j_e - back;                          // from here on: the read's own columns
+    n = nr;
     ++g_piece_stats[1];
     if (S.tail) ++g_piece_stats[2];
-    ++g_piece_need[std::min(11, (S.j_e - S.j_s + 7) / 8)];
-    if (S.j_e - S.j_s > PIECE_NARROW) ++g_piece_stats[3]; else g_piece_stats[4] += (S.j_e - S.j_s + 7) & ~7;
+    ++g_piece_need[std::min(11, (need + 7) / 8)];
+    if (need > PIECE_NARROW) ++g_piece_stats[3]; else g_piece_stats[4] += (need + 7) & ~7;
     const uint32_t *q = nib + (((size_t)(r >> 6) * NW) * 64 + (r & 63)) * 4;
     const auto tm = [&](int jp) { return filter_tail_matches(fp, T, q, NW, jp); };
     FilterState F;
     filter_init(F, u, mf);
-    const int need = S.j_e - S.j_s;
     if (need <= PIECE_NARROW) {
         const int W = std::min(PIECE_WINDOW, ((need + 7) & ~7) + 8 * (int)(r % 3));
         for (int rc = PIECE_WINDOW - W + 1; rc <= PIECE_WINDOW; ++rc) {
-            const int j = S.j_e - PIECE_WINDOW + rc;
+            const int j = j_e - PIECE_WINDOW + rc;
             const uint64_t eq = fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
             filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
             if (rc == 32) filter_fold(F, j, mf, (uint32_t)u.k);
         }
-        filter_fold(F, S.j_e, mf, (uint32_t)u.k);
-        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, S.j_e == n);
+        filter_fold(F, j_e, mf, (uint32_t)u.k);
+        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n);
     }
     for (int j = 1; j <= n; ++j) {
         const uint64_t eq = fp.peq[read_code(nib, NW, r, j)];
@@ -309,8 +328,8 @@ void emu_piece(const atr_aligner *a, const uint32_t *planes, const int32_t *lens
     const Uniform u = make_uniform(p, MT);
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
     PieceParams pp;
-    if (lens || !piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
-                              a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) abort();
+    if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
+                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, lens ? 32 * nchunks : max_len, pp)) abort();
     uint32_t spread[4][256];
     piece_spread_tables(spread);
     const long long ntiles = (nreads + 63) / 64;
@@ -322,23 +341,24 @@ void emu_piece(const atr_aligner *a, const uint32_t *planes, const int32_t *lens
     std::vector<std::vector<uint32_t>> bins(FILTER_BINS);
     for (long long r = 0; r < nreads; ++r) {
         uint32_t rec[4], ww = 0;
+        const int nr = lens ? std::min(std::max(lens[r], 0), max_len) : -1;
         switch (nchunks) {
-            case 1: ww = emu_piece_read<1>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 2: ww = emu_piece_read<2>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 3: ww = emu_piece_read<3>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 4: ww = emu_piece_read<4>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 5: ww = emu_piece_read<5>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 6: ww = emu_piece_read<6>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 7: ww = emu_piece_read<7>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 8: ww = emu_piece_read<8>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            case 9: ww = emu_piece_read<9>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
-            default: ww = emu_piece_read<10>(u, fp, pp, planes, nib.data(), r, max_len, rec); break;
+            case 1: ww = emu_piece_read<1>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 2: ww = emu_piece_read<2>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 3: ww = emu_piece_read<3>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 4: ww = emu_piece_read<4>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 5: ww = emu_piece_read<5>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 6: ww = emu_piece_read<6>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 7: ww = emu_piece_read<7>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 8: ww = emu_piece_read<8>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            case 9: ww = emu_piece_read<9>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
+            default: ww = emu_piece_read<10>(u, fp, pp, planes, nib.data(), r, max_len, nr, rec); break;
         }
         win[r] = ww;
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
         else { bins[window_bin(ww, u.m, true)].push_back((uint32_t)r); ++g_piece_stats[5]; }
     }
-    emu_dp_stage<MT, NOINDEL>(a, nib.data(), nullptr, nchunks, max_len, out, win, bins, nullptr);
+    emu_dp_stage<MT, NOINDEL>(a, nib.data(), lens, nchunks, max_len, out, win, bins, nullptr);
 }
 
 typedef void (*emu_fn)(const atr_aligner *, const uint32_t *, const int32_t *, long long, int, int, uint32_t *);
@@ -730,8 +750,9 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
 }
 
 // atr_locate_planes_applies / atr_locate_planes_batch (the emulation takes every word count up to 10)
-int emu_locate_planes_applies(const atr_aligner *a, int max_len) {
+int emu_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
     if (!a || !a->filterable || max_len < 1 || max_len > ATR_MAX_READ_LEN) return 0;
+    if (ragged) max_len = 32 * ((max_len + 31) / 32);
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
@@ -739,8 +760,9 @@ int emu_locate_planes_applies(const atr_aligner *a, int max_len) {
     const int nw = (max_len + 31) / 32;
     return (nw == 3 || nw == 4 || nw == 5 || nw == 6 || nw == 8 || nw == 10) ? 1 : 0;
 }
-int emu_locate_planes_all_widths(const atr_aligner *a, int max_len) {          // the envelope without the instantiated widths
+int emu_locate_planes_all_widths(const atr_aligner *a, int max_len, int ragged) {          // the envelope without the instantiated widths
     if (!a || !a->filterable || max_len < 1 || max_len > 32 * PIECE_MAX_WORDS) return 0;
+    if (ragged) max_len = 32 * ((max_len + 31) / 32);
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
     PieceParams pp;
     return piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
@@ -752,14 +774,15 @@ void emu_piece_stats(long long out[18], int reset) {
     for (int i = 0; i < 12; ++i) { out[6 + i] = g_piece_need[i]; if (reset) g_piece_need[i] = 0; }
 }
 
-int emu_locate_planes_batch(const atr_aligner *a, const uint8_t *planes, int64_t nreads, int max_len, int16_t *out) {
+int emu_locate_planes_batch(const atr_aligner *a, const uint8_t *planes, const int32_t *lens, int64_t nreads, int max_len,
+                            int16_t *out) {
     if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
     if (nreads == 0) return ATR_OK;
-    if (!emu_locate_planes_all_widths(a, max_len)) return ATR_ERR_UNSUPPORTED;
+    if (!emu_locate_planes_all_widths(a, max_len, lens != nullptr)) return ATR_ERR_UNSUPPORTED;
     const int idx = round_up_rows(a->p.m) / ROW_GRAN - 1;
     emu_fn fn = pick_piece(idx, a->indel_cost > a->p.k, std::make_integer_sequence<int, FILTER_MAX_M / ROW_GRAN>{});
     if (!fn) return ATR_ERR_UNSUPPORTED;
-    fn(a, (const uint32_t *)planes, nullptr, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
+    fn(a, (const uint32_t *)planes, lens, nreads, (max_len + 31) / 32, max_len, (uint32_t *)out);
     return ATR_OK;
 }
 
