@@ -24,6 +24,7 @@ ERRORS = {-1: "invalid argument", -2: "unsupported by the device kernels", -3: "
 TABLE_DNA15, TABLE_ACGT, TABLE_IUPAC, TABLE_CUSTOM = 0, 1, 2, 3
 MAX_REF_LEN = 128
 MAX_READ_LEN = 736
+MAX_LONG_READ_LEN = 32736                # Aligner.locate / locate_batch: reads up to here (the full sweep with a rolling origin base)
 PLANES_MIN_READS = 65536                 # Aligner.pack: batches from here on are packed as bit planes when the two-pass
                                          # pre-pass takes the aligner (atr_locate_planes_batch)
 WAVE_MAX_READS = 32768                   # atr_locate_batch: short batches take the wavefront-per-read kernel

@@ -293,11 +293,20 @@ class Adapter(object):
         table)`` (the reads 4-bit packed with that table)."""
         be = _lib.get_backend()
         m = len(self.sequence)
+        split = getattr(source, "split_long", None)
+        if split is not None and not self._plain_compare and source.max_len() > _lib.MAX_READ_LEN:
+            # records beyond the batch pipelines' read length: matched as a batch of their own (long-read sweep)
+            short, long_idx, long_source = split()
+            rec = self.match_source(short)
+            rec[long_idx] = self.match_source(long_source)
+            return rec
         if self._plain_compare:
             rec = self.aligner.compare_batch(source.batch(self.aligner.table_kind, self.aligner._table),
                                              suffix=(self.where == SUFFIX))
         else:
-            rec = self.aligner.locate_batch(source.batch(self.aligner.table_kind, self.aligner._table)).records
+            batch_for = getattr(source, "batch_for", None)      # (a source that can pack for the aligner's fastest path)
+            rec = self.aligner.locate_batch(batch_for(self.aligner) if batch_for else
+                                            source.batch(self.aligner.table_kind, self.aligner._table)).records
         rmp_t = None
         if self.max_rmp is not None:
             if self._rmp_device is None or self._rmp_device.device != be.device:

@@ -206,7 +206,7 @@ class Aligner(object):
         return ReadBatch.from_ascii(reads, None, None, kind, table, self._backend, planes=planes)
 
     def _wants_planes(self, layout, nreads, width, ragged=False):
-        if layout == "tile64" or self._handle is None or getattr(self, "_long", False):
+        if layout == "tile64" or self._handle is None or getattr(self, "_long", False) or width > _lib.MAX_READ_LEN:
             return False
         be = self._backend
         ok = hasattr(be, "locate_planes_applies") and width > 0 and be.locate_planes_applies(self._handle, width, ragged)
@@ -240,6 +240,18 @@ class Aligner(object):
         if getattr(self, "_long", False):
             return self._locate_long(reads)
         be = self._backend
+        if isinstance(reads, (list, tuple)) and len(reads) > 1 and path != "wave":
+            # a few reads beyond the batch pipelines' length (the reference has no limit, _align.pyx:266-291): they go
+            # through the long-read sweep as a batch of their own, so that the others are not padded to their length
+            lens = np.fromiter(map(len, reads), dtype=np.int64, count=len(reads))
+            if int(lens.max()) > _lib.MAX_READ_LEN and int(lens.min()) <= _lib.MAX_READ_LEN:
+                long_idx = np.nonzero(lens > _lib.MAX_READ_LEN)[0]
+                short_idx = np.nonzero(lens <= _lib.MAX_READ_LEN)[0]
+                rec = be.empty((len(reads), 8), torch.int16)
+                for idx in (short_idx, long_idx):
+                    part = self.locate_batch([reads[i] for i in idx.tolist()], filtered, path).records
+                    rec[torch.from_numpy(idx).to(rec.device)] = part
+                return LocateResult(rec)
         if (self._handle is not None and path in (None, "auto", "wave") and filtered and isinstance(reads, (list, tuple))
                 and 0 < len(reads) <= _lib.WAVE_MAX_READS and hasattr(be, "locate_ascii_batch")):
             # a short list of strings: the rows go to the device as they are and the wavefront-per-read kernel

@@ -77,9 +77,9 @@ class ReadBatch(object):
             max_len = width if lens is None else (int(lens.max().item()) if nreads else 0)
         if max_len > width and nreads:
             raise ValueError("max_len exceeds the row width")
-        if max_len > _lib.MAX_READ_LEN:
-            raise ValueError("reads longer than %d bases are outside the device kernels' envelope"
-                             % _lib.MAX_READ_LEN)
+        limit = _lib.MAX_READ_LEN if (planes or starts is not None) else _lib.MAX_LONG_READ_LEN
+        if max_len > limit:
+            raise ValueError("reads longer than %d bases are outside the device kernels' envelope" % limit)
         if table is None:
             if table_kind == _lib.TABLE_CUSTOM:
                 raise ValueError("a custom table must be given explicitly")

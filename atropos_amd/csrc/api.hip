@@ -141,7 +141,7 @@ template <bool PLANES>
 static int pack_launch(const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens, const int32_t *d_starts,
                        int64_t nreads, int max_len, const uint8_t table[256], uint8_t *d_packed, int32_t *d_invalid,
                        void *stream) {
-    if (nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || !table) return ATR_ERR_INVALID;
+    if (nreads < 0 || max_len < 0 || max_len > (PLANES ? ATR_MAX_READ_LEN : ATR_MAX_LONG_READ_LEN) || !table) return ATR_ERR_INVALID;
     if (nreads == 0 || max_len == 0) return ATR_OK;
     if (!d_ascii || !d_packed) return ATR_ERR_INVALID;
     PackTable tab;
@@ -246,11 +246,16 @@ int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_
 
 int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
                           int max_len, atr_result *d_out, void *d_work, int path, void *stream) {
-    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_LONG_READ_LEN) return ATR_ERR_INVALID;
     if (path < ATR_LOCATE_AUTO || path > ATR_LOCATE_WAVE) return ATR_ERR_INVALID;
-    if (path == ATR_LOCATE_WAVE && a->p.m > WAVE_MAX_M) return ATR_ERR_UNSUPPORTED;
+    if (path == ATR_LOCATE_WAVE && (a->p.m > WAVE_MAX_M || max_len > ATR_MAX_READ_LEN)) return ATR_ERR_UNSUPPORTED;
     if (nreads == 0) return ATR_OK;
     if (!d_out || (max_len > 0 && !d_packed)) return ATR_ERR_INVALID;
+    if (max_len > ATR_MAX_READ_LEN) {
+        // long reads: the full column sweep with a rolling origin base, whatever the path asked for
+        if (a->p.m + a->p.k > LONG_MAX_SPAN) return ATR_ERR_UNSUPPORTED;
+        path = ATR_LOCATE_FULL;
+    }
     if (path == ATR_LOCATE_FULL) d_work = nullptr;
     const bool band = d_work && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k);
     if (path == ATR_LOCATE_WAVE || (path == ATR_LOCATE_AUTO && !band && wave_applies(a->p.m, nreads))) {

@@ -99,11 +99,12 @@ struct Best {
 // Candidate test of _align.pyx:440-455 / :464-474.  XREP: the payload field holds the
 // diagonal mismatches (see the header); indel = the aligner's effective indel cost, 0 for
 // the no-indel kernels.
+// obase: the column the origin field counts from (long reads: the rolling base of locate_long, else 0).
 template <bool XREP, int BIAS = (int)ORG_BIAS>
 ATR_DEV void consider(Best &b, uint32_t w, int ref_stop, int query_stop, int min_overlap,
-                      const int16_t *thr, int indel) {
+                      const int16_t *thr, int indel, int obase = 0) {
     const int cost = (int)(w >> CSH);
-    const int origin = (int)(w & ORG_MASK) - BIAS;
+    const int origin = (int)(w & ORG_MASK) - BIAS + obase;
     const int length = ref_stop + atr_min(origin, 0);
     if (length >= min_overlap && cost <= (int)thr[atr_max(length, 0)]) {
         int matches = (int)((w >> MSH) & MAT_MASK);
@@ -224,10 +225,10 @@ ATR_DEV uint32_t column_step_limited(uint32_t (&col)[MT + 1], const uint32_t (&n
 // compare instead of the full test (threshold fetch, length, ...).
 template <int MT, bool XREP>
 ATR_DEV void scan_last_column(Best &best, const uint32_t (&col)[MT + 1], int p0, int first_p, int n,
-                              int min_overlap, const int16_t *thr, int indel, uint32_t klimit, int last_p = MT) {
+                              int min_overlap, const int16_t *thr, int indel, uint32_t klimit, int last_p = MT, int obase = 0) {
 #pragma unroll
     for (int i = 0; i <= MT; ++i) {
-        if (i >= first_p && i <= last_p && col[i] < klimit) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel);
+        if (i >= first_p && i <= last_p && col[i] < klimit) consider<XREP>(best, col[i], i - p0, n, min_overlap, thr, indel, obase);
     }
 }
 
@@ -333,13 +334,14 @@ ATR_DEV void lane_restart_window(LaneState<MT> &L, const Uniform &u, int j_start
 //   * takes its last-column candidates when the sweep reaches its max_n,
 //   * ignores row-m candidates outside its window,
 // and whatever it computes past max_n is never looked at.
+// obase (long reads, locate_long_kernel): the origin fields count from column obase instead of 0.
 template <int MT, bool NOINDEL, bool XREP, bool WIN = false>
 ATR_DEV void lane_step(LaneState<MT> &L, const Uniform &u, int j, const uint32_t (&nm)[(MT + 31) / 32],
-                       const int16_t *thr, int plimit = MT) {
+                       const int16_t *thr, int plimit = MT, int obase = 0) {
     const int indel = NOINDEL ? 0 : u.indel;
     // row 0 (:385-388): origin j, or cost j*indel (saturated: it is > k long before).
     // Matches 0; without START_WITHIN_SEQ2 the row-0 origin is 0 in every init case.
-    const uint32_t row0 = u.sq ? (ORG_BIAS + (uint32_t)j)
+    const uint32_t row0 = u.sq ? (ORG_BIAS + (uint32_t)(j - obase))
                                : (ORG_BIAS | ((uint32_t)atr_min(j * u.indel, INIT_COST_CAP) << CSH));
     const uint32_t wm = WIN ? column_step_limited<MT, NOINDEL, XREP>(L.col, nm, u.p0, row0, u.insw, u.delw, plimit)
                             : column_step<MT, NOINDEL, XREP>(L.col, nm, u.p0, row0, u.insw, u.delw);
@@ -353,26 +355,47 @@ ATR_DEV void lane_step(LaneState<MT> &L, const Uniform &u, int j, const uint32_t
     } else if (XREP) {
         // row-m candidate: the reference looks at it only when the band reached row m,
         // i.e. cost <= k (:433-455); min_n is 0 here.
-        if (wm < u.klimit && j <= L.max_n) consider<XREP>(L.best, wm, u.m, j, u.min_overlap, thr, indel);
+        if (wm < u.klimit && j <= L.max_n) consider<XREP>(L.best, wm, u.m, j, u.min_overlap, thr, indel, obase);
     } else if (j == L.min_n && L.max_n > L.min_n) {
         int mn = L.min_n;
 #ifndef ATR_HOST_EMU
         asm volatile("" : "+v"(mn));                         // keep the re-init out of the loop preheader
 #endif
 #pragma unroll
-        for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, mn, u.sr, u.sq, u.indel);
+        for (int i = 0; i <= MT; ++i) L.col[i] = init_word(i - u.p0, mn, u.sr, u.sq, u.indel) - (uint32_t)obase;
     }
     if (L.scan && j == L.max_n && L.max_n > L.min_n)
-        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel, u.klimit, WIN ? plimit : MT);
+        scan_last_column<MT, XREP>(L.best, L.col, u.p0, u.first_p, L.n, u.min_overlap, thr, indel, u.klimit, WIN ? plimit : MT, obase);
+}
+
+// ---- reads longer than the origin field reaches (locate_long_kernel) ------------------------------------------
+// The origin field of a cell word holds 10 bits (columns -256 .. 767).  A long read is swept with a ROLLING BASE:
+// the fields count from column long_base(j), which follows the sweep in steps of 256 columns, 257 .. 512 columns
+// behind it; at a step every cell's field is lowered by 256, and a cell whose origin lies before the new range is
+// given the lowest value instead.  Such a cell belongs to a path that has consumed more than 512 columns on at most
+// m rows: its cost is above k (m + k <= LONG_MAX_SPAN) and stays there, so it is never looked at as a candidate, never
+// wins against a cell that could be, and what its origin says does not matter.  A best match keeps the base it was
+// found under (the kernel's own variable).
+constexpr int LONG_BASE_STEP = 256, LONG_MAX_SPAN = 384;
+ATR_DEV int long_base(int j) { return j > 2 * LONG_BASE_STEP ? (((j - 1) / LONG_BASE_STEP) - 1) * LONG_BASE_STEP : 0; }
+template <int MT>
+ATR_DEV void lane_rebase(LaneState<MT> &L) {
+#pragma unroll
+    for (int i = 0; i <= MT; ++i) {
+        const uint32_t w = L.col[i];
+        L.col[i] = (w & ORG_MASK) >= (uint32_t)LONG_BASE_STEP ? w - (uint32_t)LONG_BASE_STEP : (w & ~ORG_MASK);
+    }
 }
 
 // (refstart, refstop, querystart, querystop, matches, errors, 0, 0) as 8 x int16.
 template <int MT>
-ATR_DEV void lane_result(const LaneState<MT> &L, const Uniform &u, uint32_t rec[4]) {
+ATR_DEV void lane_result(const LaneState<MT> &L, const Uniform &u, uint32_t rec[4], int obase = 0) {
     const int cost = (int)(L.best.word >> CSH);
     int refstart = 0, querystart = 0, refstop = -1, querystop = 0, matches = 0, errors = 0;
-    if (cost != u.m + L.n) {                                 // :476-480
-        const int origin = (int)(L.best.word & ORG_MASK) - (int)ORG_BIAS;
+    // :476-480: None when the best cost is m + n -- no candidate seen (the key lane_init set; its word does not hold
+    // m + n of a long read), or, as in the reference, a candidate of exactly that cost
+    if (L.best.key != COST_FIELD_MAX - (u.m + L.n) && cost != u.m + L.n) {
+        const int origin = (int)(L.best.word & ORG_MASK) - (int)ORG_BIAS + obase;
         if (origin >= 0) querystart = origin; else refstart = -origin;
         refstop = L.best.ref_stop; querystop = L.best.query_stop;
         matches = L.best.matches; errors = cost;

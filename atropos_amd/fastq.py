@@ -201,12 +201,43 @@ class RecordSource(object):
         self.n = len(batch)
         self._batches = {}
 
-    def batch(self, table_kind, table):
+    def max_len(self):
+        if getattr(self, "_max_len", None) is None:
+            self._max_len = int((self.end - self.begin).clamp_(min=0).max().item()) if self.n else 0
+        return self._max_len
+
+    def split_long(self):
+        """(source of the reads with the over-long ones emptied, their indices, an AsciiSource of the over-long
+        reads): one record beyond the batch pipelines' length does not abort the chunk -- the adapter matcher sends
+        those through the long-read sweep (the reference has no length limit, _align.pyx:266-291)."""
+        from .adapters import AsciiSource
+        lens = (self.end - self.begin).clamp_(min=0)
+        long_idx = torch.nonzero(lens > _lib.MAX_READ_LEN).squeeze(1)
+        long_lens = lens.index_select(0, long_idx).to(torch.int32)
+        width = (int(long_lens.max().item()) + 3) // 4 * 4
+        if width > _lib.MAX_LONG_READ_LEN:
+            raise ValueError("reads longer than %d bases are outside the device kernels' envelope" % _lib.MAX_LONG_READ_LEN)
+        rec = self.fq.records.index_select(0, long_idx)
+        off = (rec[:, 2].to(torch.int64) & 0xFFFFFFFF) + self.begin.index_select(0, long_idx).to(torch.int64)
+        pos = off[:, None] + torch.arange(width, device=off.device, dtype=torch.int64)[None, :]
+        mat = self.fq.data[pos.clamp_(max=self.fq.data.numel() - 1)]
+        mat = torch.where((mat >= 97) & (mat <= 122), mat - 32, mat)          # match_to upper-cases the read (:349)
+        mat = torch.where(torch.arange(width, device=off.device)[None, :] < long_lens[:, None], mat, torch.zeros_like(mat))
+        short = RecordSource(self.fq, self.begin, torch.where(lens > _lib.MAX_READ_LEN, self.begin, self.end))
+        return short, long_idx, AsciiSource(mat.contiguous(), long_lens.contiguous())
+
+    def batch_for(self, aligner):
+        """The batch ``aligner.locate_batch`` is fastest on: bit planes when the two-pass pre-pass takes the
+        aligner on a (ragged) batch of this size, else 4-bit codes."""
+        planes = aligner._wants_planes("auto", self.n, self.max_len(), ragged=True)
+        return self.batch(aligner.table_kind, aligner._table, planes=planes)
+
+    def batch(self, table_kind, table, planes=False):
         from .batch import ReadBatch
-        key = (table_kind, bytes(table))
+        key = (table_kind, bytes(table), bool(planes))
         if key not in self._batches:
             be = self.fq.backend
-            max_len = int((self.end - self.begin).clamp_(min=0).max().item()) if self.n else 0
+            max_len = self.max_len()
             if max_len > _lib.MAX_READ_LEN:
                 raise ValueError("reads longer than %d bases are outside the device kernels' envelope"
                                  % _lib.MAX_READ_LEN)
@@ -215,8 +246,10 @@ class RecordSource(object):
             folded = bytearray(table)
             for c in range(ord("a"), ord("z") + 1):
                 folded[c] = table[c - 32]
-            packed, lens = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(folded))
-            self._batches[key] = ReadBatch(packed, lens, self.n, max_len, table_kind, table)
+            packed, lens = be.pack_records(self.fq.data, self.fq.records, self.begin, self.end, max_len, bytes(folded),
+                                           planes=bool(planes))
+            self._batches[key] = ReadBatch(packed, lens, self.n, max_len, table_kind, table,
+                                           layout="plane64" if planes else "tile64")
         return self._batches[key]
 
     def sliced(self, starts):

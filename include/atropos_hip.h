@@ -56,7 +56,10 @@ extern "C" {
 /* envelope of the device kernels */
 #define ATR_MAX_REF_LEN      128   /* adapter / reference length m of an aligner handle (longer references, up to
                                     * ATR_PAIRS_MAX_LEN: atr_locate_pairs_batch with the same reference on every pair) */
-#define ATR_MAX_READ_LEN     736   /* read length n (23 chunks) */
+#define ATR_MAX_READ_LEN     736   /* read length n (23 chunks) of the batch pipelines, the per-read calls and the text stages */
+#define ATR_MAX_LONG_READ_LEN 32736 /* atr_pack_reads + atr_locate_batch take reads up to here (1023 chunks; the record's
+                                    * int16 fields end at 32767): batches with max_len > ATR_MAX_READ_LEN go through the
+                                    * full column sweep with a rolling origin base (locate_kernel.hpp) whatever the path */
 
 /* which 256-entry translate table the packed reads must have been built with */
 #define ATR_TABLE_DNA15   0   /* equality compare: 15 upper-case IUPAC letters -> their bit codes, rest 0 */

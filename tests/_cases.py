@@ -1516,3 +1516,89 @@ def check_multi_against_oracle(MultiAligner, oracle, seed, rounds, npairs=40, to
             assert g == oracle.multi_locate(r, q, e, flags, mo, mm), (r, q, e, flags, mo, mm, g)
             total += 1
     return total
+
+
+def long_read_case(c):
+    """The read of a tests/golden/long_reads.json.gz case: c["n"] random bases (seeded) with the pieces laid over."""
+    rng = random.Random(c["seed"])
+    q = list(rseq(rng, c["n"], c["alpha"]))
+    for pos, text in c["pieces"]:
+        pos = max(0, pos)
+        for i, ch in enumerate(text):
+            if pos + i < c["n"]:
+                q[pos + i] = ch
+    return "".join(q)
+
+
+def check_golden_long_reads(Aligner, unsupported_exc, batch=True):
+    """The reference's answers on reads of 737 .. 2 600 bases (long_reads.json.gz), per read and as batches."""
+    cases = load_golden("long_reads.json.gz")
+    checked = 0
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["ref"], c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"]), []).append(c)
+    for key, group in groups.items():
+        try:
+            al = Aligner(*key)
+        except unsupported_exc:
+            continue
+        reads = [long_read_case(c) for c in group]
+        got = al.locate_batch(reads).tuples() if batch else [al.locate(q) for q in reads]
+        for c, g in zip(group, got):
+            assert g == tup(c["out"]), (c, g)
+            checked += 1
+        assert al.locate(reads[0]) == tup(group[0]["out"])
+    return checked
+
+
+def check_long_reads(Aligner, oracle, unsupported_exc, seed, rounds, count=24, max_n=4000):
+    """Reads beyond the batch pipelines' 736 bases (the reference has no length limit, _align.pyx:266-291): the
+    full sweep with a rolling origin base.  Adapters whole, edited and cut, placed at the columns where the base
+    moves (multiples of 256), at the read's ends and twice; every flag set; long and short reads in one list."""
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        m = rng.choice([rng.randint(1, 12), rng.randint(8, 40), rng.randint(30, 128)])
+        ref = rseq(rng, m, "ACGT" if rng.random() < 0.8 else "ACGTN")
+        flags = rng.choice([14, 14, 11, 15, 10, 6, 9, 1, 2, 4, 8, 0, 12, 3, 5, 7, 13])
+        e = rng.choice([0, 0.05, 0.1, 0.1, 0.2, 0.3])
+        ic = rng.choice([1, 1, 2, 100000])
+        mo = rng.choice([1, 3, 5])
+        wr, wq = rng.random() < 0.2, rng.random() < 0.2
+        try:
+            al = Aligner(ref, e, flags, wr, wq, mo, ic)
+        except unsupported_exc:
+            continue
+        reads = []
+        for _ in range(count):
+            n = rng.choice([737, 767, 768, 769, 1023, 1024, 1025, rng.randint(737, 1300), rng.randint(737, max_n)])
+            w = rng.random()
+            part = mutate(rng, ref, rng.choice([0, 0, 0.04, 0.1, 0.2]))
+            if w < 0.3:                                      # around a step of the base
+                pos = rng.choice([256, 512, 768, 1024, 1280]) + rng.randint(-m - 3, 3)
+                q = rseq(rng, max(0, pos)) + part + rseq(rng, n)
+            elif w < 0.45:                                   # cut by the read end
+                q = rseq(rng, n) + part[:rng.randint(1, len(part))] if part else rseq(rng, n)
+                q = q[len(q) - n:]
+            elif w < 0.55:                                   # at (or before) the read start
+                q = part[rng.randint(0, max(0, len(part) - 1)):] + rseq(rng, n)
+            elif w < 0.7:                                    # twice, the better one second or first
+                a, b = mutate(rng, ref, 0.1), mutate(rng, ref, rng.choice([0, 0.1]))
+                if rng.random() < 0.5:
+                    a, b = b, a
+                q = rseq(rng, rng.randint(0, n - 2 * m - 10)) + a + rseq(rng, rng.randint(0, 600)) + b + rseq(rng, n)
+            elif w < 0.8:
+                q = rseq(rng, rng.randint(0, n)) + part + rseq(rng, n)
+            else:
+                q = rseq(rng, n, "ACGTN" if rng.random() < 0.3 else "ACGT")
+            reads.append(q[:n])
+        if rng.random() < 0.5:                               # a list of long and short reads (split by the host)
+            reads += [mutate(rng, rseq(rng, rng.randint(0, 200)) + ref, 0.05) for _ in range(6)]
+            rng.shuffle(reads)
+        got = al.locate_batch(reads).tuples()
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, e, flags, wr, wq, mo, ic), (ref, len(q), q, e, flags, wr, wq, mo, ic, g)
+            total += 1
+        q = reads[0]
+        assert al.locate(q) == got[0]
+    return total

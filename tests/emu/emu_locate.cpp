@@ -45,9 +45,22 @@ void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens
             jlo = std::min(jlo, has_window ? L[lane].min_n : 0x7fffffff);
             jhi = std::max(jhi, has_window ? L[lane].max_n : 0);
         }
+        // reads of more than ATR_MAX_READ_LEN bases: locate_long_kernel's rolling origin base (locate_kernel.hpp)
+        const bool lng = max_len > ATR_MAX_READ_LEN;
+        int obase = 0, best_base[64] = {0};
         if (jhi > jlo) {
+            if (lng) {
+                obase = long_base(jlo + 1);
+                if (!XREP)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int i = 0; i <= MT; ++i) L[lane].col[i] -= (uint32_t)obase;
+            }
             const int c0 = jlo >> 5, c1 = (jhi + 31) >> 5;
             for (int c = c0; c < c1; ++c) {
+                if (lng && long_base(c * 32 + 1) != obase) {
+                    for (int lane = 0; lane < 64; ++lane) lane_rebase<MT>(L[lane]);
+                    obase += LONG_BASE_STEP;
+                }
                 for (int d = 0; d < 4; ++d) {
                     for (int b = 0; b < 8; ++b) {
                         const int j = c * 32 + d * 8 + b + 1;
@@ -57,7 +70,9 @@ void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens
                             const uint32_t q = (w >> (4 * b)) & 15u;
                             uint32_t nm[(MT + 31) / 32];
                             for (int w2 = 0; w2 < (MT + 31) / 32; ++w2) nm[w2] = p.nmask[q][w2];
-                            lane_step<MT, NOINDEL, XREP>(L[lane], u, j, nm, s_thr);
+                            const int key = L[lane].best.key;
+                            lane_step<MT, NOINDEL, XREP>(L[lane], u, j, nm, s_thr, MT, obase);
+                            if (L[lane].best.key != key) best_base[lane] = obase;
                         }
                     }
                 }
@@ -65,7 +80,7 @@ void emu_tiles(const atr_aligner *a, const uint32_t *packed, const int32_t *lens
         }
         for (int lane = 0; lane < 64; ++lane) {
             if (!live[lane]) continue;
-            lane_result<MT>(L[lane], u, out + (tile * 64 + lane) * 4);
+            lane_result<MT>(L[lane], u, out + (tile * 64 + lane) * 4, best_base[lane]);
         }
     }
 }
@@ -702,10 +717,14 @@ extern "C" {
 
 int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t *lens, int64_t nreads,
                      int max_len, int16_t *out, int path) {
-    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_LONG_READ_LEN) return ATR_ERR_INVALID;
     if (path < ATR_LOCATE_AUTO || path > ATR_LOCATE_WAVE) return ATR_ERR_INVALID;
-    if (path == ATR_LOCATE_WAVE && a->p.m > WAVE_MAX_M) return ATR_ERR_UNSUPPORTED;
+    if (path == ATR_LOCATE_WAVE && (a->p.m > WAVE_MAX_M || max_len > ATR_MAX_READ_LEN)) return ATR_ERR_UNSUPPORTED;
     if (nreads == 0) return ATR_OK;
+    if (max_len > ATR_MAX_READ_LEN) {
+        if (a->p.m + a->p.k > LONG_MAX_SPAN) return ATR_ERR_UNSUPPORTED;
+        path = ATR_LOCATE_FULL;
+    }
     const int filtered = path != ATR_LOCATE_FULL;
     {   // as atr_locate_batch_path
         const bool band = filtered && max_len > 0 && prefix_band_applies(a->flags, a->p.m, a->p.k);

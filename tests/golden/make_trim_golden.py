@@ -100,6 +100,34 @@ def synth_anchor_fastq(nreads, seed):
         out.append("@anchor%d\n%s\n+\n%s\n" % (i, seq, qual))
     return "".join(out)
 
+def synth_longmix_fastq(nreads, seed):
+    """Short C1-like reads with a few records of 800 .. 3000 bases among them (one over-long record must not abort
+    the chunk): the adapter whole or damaged somewhere in the long read, cut by its end, or absent."""
+    import random
+    rng = random.Random(seed)
+    base = synth_fastq(nreads, seed).split("\n")
+    out = []
+    for i in range(nreads):
+        out += base[4 * i:4 * i + 4]
+        if i % 9 == 4:
+            n = rng.choice([737, 768, 800, rng.randint(800, 3000)])
+            seq = [rng.choice("ACGT") for _ in range(n)]
+            w = rng.random()
+            ad = list(TRUSEQ)
+            for _ in range(rng.choice([0, 0, 1, 2, 3])):
+                ad[rng.randrange(len(ad))] = rng.choice("ACGT")
+            if w < 0.5:
+                pos = rng.randint(0, n - 1)
+                seq[pos:pos + len(ad)] = ad
+            elif w < 0.75:
+                cut = rng.randint(3, len(ad))
+                seq[n - cut:] = ad[:cut]
+            seq = "".join(seq)[:n]
+            qual = "".join(chr(33 + max(2, 38 - j // 90 + rng.randint(-2, 2))) for j in range(len(seq)))
+            out += ["@long%d" % i, seq, "+", qual]
+    return "\n".join(out) + "\n"
+
+
 # (input name, argument string) -- the reference's own CLI tests (tests/test_atropos.py) that
 # take FASTQ input and stay inside the device pipeline's envelope, plus parameter sweeps on
 # synthetic reads
@@ -158,6 +186,11 @@ CASES = [
     ("synth_dos.fastq", "-a " + TRUSEQ + " -q 20 -m 20"),
     ("synth_name2.fastq", "-a " + TRUSEQ + " --trim-n"),
     ("nofinalnewline.fastq", "-a TTAGACATATCTCCGTCG"),
+    # records beyond the batch pipelines' 736 bases among ordinary ones (the reference has no length limit)
+    ("longmix.fastq", "-a " + TRUSEQ),
+    ("longmix.fastq", "-b " + TRUSEQ + " -n 2 -e 0.12"),
+    ("longmix.fastq", "-a " + TRUSEQ + " -q 20 -m 20 --trim-n"),
+    ("longmix.fastq", "-g " + TRUSEQ[:20] + " -a " + TRUSEQ + " --mask-adapter"),
     # malformed inputs: the reference raises FormatError
     ("bad_at.fastq", "-a ACGT"),
     ("bad_plus.fastq", "-a ACGT"),
@@ -253,6 +286,7 @@ def main():
             inputs[name] = gzip.open(path + ".gz", "rb").read()
     inputs["synth.fastq"] = synth_fastq(1200, 11).encode()
     inputs["anchor.fastq"] = synth_anchor_fastq(600, 14).encode()
+    inputs["longmix.fastq"] = synth_longmix_fastq(150, 19).encode()
     inputs["synth_dos.fastq"] = synth_fastq(100, 12, dos=True).encode()
     inputs["synth_name2.fastq"] = synth_fastq(100, 13, repeat_name=True).encode()
     small = inputs["small.fastq"]

@@ -5,7 +5,19 @@ from . import _cases
 
 
 def test_trim_pipeline_reference_cli_cases(emu_backend):
-    assert _cases.check_trim_golden() >= 48
+    assert _cases.check_trim_golden() >= 62
+
+
+def test_trim_pipeline_through_the_two_pass_prepass(emu_backend, monkeypatch):
+    """The same reference outputs with every batch, however short, packed as bit planes where the two-pass pre-pass
+    takes the adapter (ragged batches: the reads come out of quality trimming / earlier adapters)."""
+    from atropos_amd import _lib
+    calls = []
+    real = emu_backend.locate_planes_batch
+    monkeypatch.setattr(_lib, "PLANES_MIN_READS", 1)
+    monkeypatch.setattr(emu_backend, "locate_planes_batch", lambda *a: (calls.append(a[3]), real(*a))[1])
+    assert _cases.check_trim_golden() >= 62
+    assert len(calls) >= 10
 
 
 def test_trim_file_chunking(emu_backend, tmp_path):

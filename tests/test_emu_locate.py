@@ -36,6 +36,13 @@ def test_filtered_pipeline_narrow(emu_backend, oracle):
     assert _cases.check_filtered_pipeline(Aligner, oracle, _lib.AtroposHipError, 5, 60, (33, 40), (14, 10, 6, 14)) > 5000
 
 
+def test_long_reads(emu_backend, oracle):
+    from atropos_amd.align import Aligner
+    from atropos_amd import _lib
+    assert _cases.check_golden_long_reads(Aligner, _lib.AtroposHipError) > 600          # the reference's answers
+    assert _cases.check_long_reads(Aligner, oracle, _lib.AtroposHipError, 29, 15) > 300
+
+
 def test_piece_pipeline(emu_backend, oracle):
     """The two-pass pre-pass on plane64 reads (piece_core.hpp): pieces, read-end conditions, windows, the full
     sweep of the reads that need more than a window -- the per-lane source of the GPU build against the oracle."""

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_trim_pipeline_reference_cli_cases(hip_backend):
-    assert _cases.check_trim_golden() >= 48
+    assert _cases.check_trim_golden() >= 62
 
 
 def test_trim_file_chunking(hip_backend, tmp_path):
@@ -48,12 +48,14 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
     from atropos_amd import _lib
     from atropos_amd.trim import pipeline_from_args
     from tests.emu.backend import EmuBackend
-    data = _big_fastq(60000, 5)
+    data = _big_fastq(70000, 5)          # (>= PLANES_MIN_READS: the 3' adapters go through the two-pass pre-pass, ragged)
     got = pipeline_from_args(args).trim_bytes(data)
     prev = _lib.set_backend(EmuBackend(), _test_double=True)
+    planes_from, _lib.PLANES_MIN_READS = _lib.PLANES_MIN_READS, 1 << 60       # the twin: the one-pass pipeline on tile64
     try:
         want = pipeline_from_args(args).trim_bytes(data)
     finally:
+        _lib.PLANES_MIN_READS = planes_from
         _lib.set_backend(prev, _test_double=True)
     assert len(got) == len(want) and got == want, _cases._first_diff(got, want)
     assert len(got) > 20000

@@ -56,6 +56,30 @@ def test_piece_pipeline(hip_backend, oracle):
     assert total > 20000 and refused < 80
 
 
+def test_long_reads(hip_backend, oracle):
+    """Reads of 737 .. 32 736 bases (the reference has no length limit): locate_long_kernel's rolling origin base
+    against the reference's own answers (long_reads.json.gz) and the oracle; long and short reads in one list."""
+    import random
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_golden_long_reads(Aligner, _lib.AtroposHipError) > 600
+    assert _cases.check_golden_long_reads(Aligner, _lib.AtroposHipError, batch=False) > 600
+    assert _cases.check_long_reads(Aligner, oracle, _lib.AtroposHipError, 31, 60) > 1200
+    rng = random.Random(3)
+    ref = "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"
+    for flags in (14, 10, 15):
+        al = Aligner(ref, 0.1, flags, False, False, 3, 1)
+        reads = [_cases.rseq(rng, _lib.MAX_LONG_READ_LEN - 34) + ref, _cases.rseq(rng, 32000) + ref + _cases.rseq(rng, 702),
+                 _cases.rseq(rng, 20000), ref + _cases.rseq(rng, 9000)]
+        reads += [(_cases.rseq(rng, rng.randint(0, 9000)) + _cases.mutate(rng, ref, 0.05) + _cases.rseq(rng, 9000))[:rng.randint(737, 9000)]
+                  for _ in range(70)]
+        got = al.locate_batch(reads).tuples()
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, 0.1, flags, False, False, 3, 1), (flags, len(q), g)
+    with pytest.raises(Exception):
+        Aligner(ref, 0.1, 14, False, False, 3, 1).locate_batch(["A" * (_lib.MAX_LONG_READ_LEN + 1)])
+
+
 def test_uniform_partial_overlaps(hip_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner

@@ -46,6 +46,15 @@ def test_locate_fuzz(oracle):
         assert got == tup(c["out"]), c
 
 
+def test_long_reads(oracle):
+    from tests._cases import long_read_case
+    cases = load_golden("long_reads.json.gz")
+    assert len(cases) == 700
+    for c in cases:
+        got = oracle.locate(c["ref"], long_read_case(c), c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"])
+        assert got == tup(c["out"]), c
+
+
 def test_multi_fuzz(oracle):
     for c in load_golden("multi_fuzz.json.gz"):
         got = oracle.multi_locate(c["ref"], c["query"], c["e"], c["flags"], c["mo"], c["mx"])
