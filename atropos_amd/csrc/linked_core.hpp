@@ -60,6 +60,10 @@ struct LinkedParams {
     int32_t n, and_mode, wide, ngroups;             // wide: two-word bit-vectors in the back sweep
     uint32_t group_mask[LINKED_MAX];                // adapters of DP group g (same length, thresholds, costs)
     int32_t group_first[LINKED_MAX];                // a member of the group (its wave-uniform parameters)
+    // excl[a]: the 5' adapters that cannot match a read that STARTS WITH adapter a verbatim (their edit distance to
+    // every prefix such a read can offer exceeds their k; literal comparison only) -- linked_host.hpp.  A read
+    // with a literal occurrence whose mask covers all the others is through with the 5' stage.
+    uint32_t excl[LINKED_MAX];
     FrontParams f[LINKED_MAX];
     BackParams b[LINKED_MAX];
 };

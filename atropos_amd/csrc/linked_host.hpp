@@ -151,6 +151,33 @@ inline int linked_fill(atr_linked_set *s, const atr_linked_adapter *ad, int n) {
         s->rmp.front[i] = ad[i].d_front_rmp; s->rmp.front_max[i] = ad[i].front_max_rmp; s->rmp.front_ld[i] = ad[i].front_rmp_ld;
         s->rmp.back[i] = ad[i].d_back_rmp; s->rmp.back_max[i] = ad[i].back_max_rmp; s->rmp.back_ld[i] = ad[i].back_rmp_ld;
     }
+    // excl (linked_core.hpp): b cannot match a read that starts with a verbatim when the unit-cost edit distance --
+    // a lower bound of the aligner's cost -- between b and every read prefix of m_b - k_b .. m_b + k_b bases exceeds
+    // k_b.  Prefixes up to m_a bases are prefixes of a; a longer one is a plus x unknown bases: dist(b, a + x) >=
+    // dist(b, a) - |x|.
+    if (!P.and_mode) {
+        for (int a = 0; a < n; ++a) {
+            if (!P.f[a].accept_full) continue;
+            const atr_aligner *fa = ad[a].front;
+            const int ma = fa->p.m;
+            for (int b = 0; b < n; ++b) {
+                if (b == a) continue;
+                const atr_aligner *fb = ad[b].front;
+                const int mb = fb->p.m, kb = fb->p.k;
+                int D[FRONT_MAX_M + 1][FRONT_MAX_M + 1];
+                for (int i = 0; i <= mb; ++i) D[i][0] = i;
+                for (int j = 0; j <= ma; ++j) D[0][j] = j;
+                for (int i = 1; i <= mb; ++i)
+                    for (int j = 1; j <= ma; ++j)
+                        D[i][j] = std::min(std::min(D[i - 1][j] + 1, D[i][j - 1] + 1),
+                                           D[i - 1][j - 1] + ((fb->codes[i - 1] & 15) != (fa->codes[j - 1] & 15) ? 1 : 0));
+                int low = 1 << 20;
+                for (int j = std::max(0, mb - kb); j <= std::min(ma, mb + kb); ++j) low = std::min(low, D[mb][j]);
+                if (mb + kb > ma) low = std::min(low, D[mb][ma] - (mb + kb - ma));
+                if (low > kb) P.excl[a] |= 1u << b;
+            }
+        }
+    }
     return ATR_OK;
 }
 

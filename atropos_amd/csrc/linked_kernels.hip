@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     __shared__ uint32_t s_words[4][LINKED_ROUND * 64];             // per wave and read of the round: front word (linked_core.hpp)
     __shared__ uint32_t s_counts[4][LINKED_ROUND * 16];            //                                  number of matching 5' parts (a byte each)
     __shared__ uint16_t s_queue[4][LINKED_TASKS];
+    __shared__ uint16_t s_list[4][LINKED_ROUND * 64];               // per wave: the round's reads that have a 5' match
     for (int i = threadIdx.x; i < (int)(sizeof(LinkedBlob) / 4); i += 256) ((uint32_t *)&S)[i] = ((const uint32_t *)blob)[i];
     for (int i = threadIdx.x; i < LINKED_MAX * FILTER_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
@@ -103,31 +104,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     for (long long tile_first = t0 + wave; tile_first < t1; tile_first += 4 * LINKED_ROUND) {
         const int slots = (int)min((long long)LINKED_ROUND, (t1 - tile_first + 3) / 4);
         // ---- 5' parts of up to LINKED_ROUND tiles: literal compare, exact-piece test, DP tasks ------------
-        int ntasks = 0;
+        // (1) the literal compare of every adapter on every read.  A literal occurrence of adapter a rules out the
+        // adapters of excl[a]; a read with none left is through (four in five of C4's reads with a 5' part carry it
+        // verbatim), the others are listed with the adapters still open: s_list entry = cell | open << 9.
+        int nopen = 0;                                                        // wave-uniform
+        const uint32_t all_ad = (1u << nad) - 1u;
         for (int slot = 0; slot < slots; ++slot) {
-            if (ntasks + 64 * nad > LINKED_TASKS) {                          // wave-uniform: room for the next tile?
-                linked_drain<RAGGED, AND_MODE>(S, ngroups, queue, ntasks, packed, lens, tile_first, nchunks, max_len,
-                                               s_word, s_count, ns, lane);
-                ntasks = 0;
-            }
             const long long tile = tile_first + 4 * slot;
             const bool live = tile * 64 + lane < nreads;
             const uint4 c0v = packed[(size_t)tile * nchunks * 64 + lane];
             const uint32_t w0[4] = {c0v.x, c0v.y, c0v.z, c0v.w};
-            uint32_t word = FRONT_NONE, count = 0u;
+            uint32_t word = FRONT_NONE, count = 0u, open = live ? all_ad : 0u;
             for (int a = 0; a < nad; ++a) {                                  // wave-uniform
                 const FrontParams &fp = S.p.f[a];
-                const int m = rfl(fp.m), k = rfl(fp.k);
+                const int m = rfl(fp.m);
                 const bool exact = rfl(fp.accept_full) != 0 && front_exact(fp.code, fp.code_mask, w0);
                 if (exact) {
                     ++count;
                     word = min(word, front_word(a, m, m, 0));                // Match(0, m, 0, m, m, 0)
+                    open &= ~((1u << a) | (uint32_t)rfl((int)S.p.excl[a]));
                 }
-                const bool cand = live && !exact &&
-                                  front_pex_candidate<AND_MODE>(fp.pex_code, fp.pex_mask, fp.pex_off, rfl(fp.npieces), k, w0);
-                const unsigned long long votes = __ballot(cand);
-                if (cand) queue[ntasks + __popcll(votes & ((1ull << lane) - 1ull))] = (uint16_t)(((slot * 64 + lane) << 6) | a);
-                ntasks += (int)__popcll(votes);
             }
             s_word[slot * 64 + lane] = live ? word : FRONT_NONE;
             // four counters to a dword: gathered with two shuffles, stored by every fourth lane
@@ -135,28 +131,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             packed_counts |= (uint32_t)__shfl_down((int)packed_counts, 1, 64) << 8;
             packed_counts |= (uint32_t)__shfl_down((int)packed_counts, 2, 64) << 16;
             if ((lane & 3) == 0) s_count[(slot * 64 + lane) >> 2] = packed_counts;
+            const unsigned long long om = __ballot(open != 0u);
+            if (open != 0u) s_list[wave][nopen + __popcll(om & ((1ull << lane) - 1ull))] = (uint16_t)((slot * 64 + lane) | (open << 9));
+            nopen += (int)__popcll(om);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // (2) the exact-piece test of the open (read, adapter) pairs, the listed reads 64 at a time
+        int ntasks = 0;
+        for (int base = 0; base < nopen; base += 64) {
+            if (ntasks + 64 * nad > LINKED_TASKS) {                          // wave-uniform: room for this group's tasks?
+                linked_drain<RAGGED, AND_MODE>(S, ngroups, queue, ntasks, packed, lens, tile_first, nchunks, max_len,
+                                               s_word, s_count, ns, lane);
+                ntasks = 0;
+            }
+            const bool valid = base + lane < nopen;
+            const uint32_t entry = (uint32_t)s_list[wave][valid ? base + lane : base];
+            const int cell = (int)(entry & 511u);
+            const uint32_t open = valid ? entry >> 9 : 0u;
+            const long long tile = tile_first + 4 * (cell >> 6);
+            const uint4 c0v = packed[(size_t)tile * nchunks * 64 + (cell & 63)];
+            const uint32_t w0[4] = {c0v.x, c0v.y, c0v.z, c0v.w};
+            for (int a = 0; a < nad; ++a) {                                  // wave-uniform
+                const FrontParams &fp = S.p.f[a];
+                const bool cand = ((open >> a) & 1u) != 0u &&
+                                  front_pex_candidate<AND_MODE>(fp.pex_code, fp.pex_mask, fp.pex_off, rfl(fp.npieces), rfl(fp.k), w0);
+                const unsigned long long votes = __ballot(cand);
+                if (cand) queue[ntasks + __popcll(votes & ((1ull << lane) - 1ull))] = (uint16_t)((cell << 6) | a);
+                ntasks += (int)__popcll(votes);
+            }
         }
         linked_drain<RAGGED, AND_MODE>(S, ngroups, queue, ntasks, packed, lens, tile_first, nchunks, max_len, s_word, s_count,
                                        ns, lane);
 
         // ---- 3' part of the adapter whose 5' part matched, on read[front.rstop:] -----------------------------
+        // First the records every read gets (5' record, `which`), and the reads WITH a 5' match listed in LDS: one
+        // read in five of C4 has none, and a lane without one would idle through the whole 3' sweep of its tile.
+        // The sweep below takes the listed reads 64 at a time, whichever tiles of the round they come from (a
+        // lane's chunks are gathered through its own pointer either way; neighbours in the list are neighbours in
+        // memory most of the time).
+        int nact = 0;                                                          // wave-uniform
         for (int slot = 0; slot < slots; ++slot) {
             const long long tile = tile_first + 4 * slot;
             const long long r = tile * 64 + lane;
             const bool live = r < nreads;
-            const int n = live ? (RAGGED ? lens[r] : max_len) : 0;
-            const uint4 *tp = packed + (size_t)tile * nchunks * 64 + lane;
             const uint32_t word = s_word[slot * 64 + lane];
             const int which = word == FRONT_NONE ? -1 : (int)(word >> 24);
             const bool has = live && which >= 0;
-            const BackParams &bp = S.p.b[which < 0 ? 0 : which];
             if (live) {
                 uint32_t frec[4];
                 front_word_record(word, S.p.f[which < 0 ? 0 : which].m, frec);
                 front_out[r] = make_uint4(frec[0], frec[1], frec[2], frec[3]);
                 const uint32_t count = (s_count[(slot * 64 + lane) >> 2] >> (8 * (lane & 3))) & 0xFFu;
                 which_out[r] = (uint16_t)((uint32_t)(which & 0xFF) | (count << 8));
+                if (!has) {
+                    uint32_t none[4];
+                    rec_none(none);
+                    wk.win[r] = 0u;
+                    back_out[r] = make_uint4(none[0], none[1], none[2], none[3]);
+                }
             }
+            const unsigned long long hm = __ballot(has);
+            if (has) s_list[wave][nact + __popcll(hm & ((1ull << lane) - 1ull))] = (uint16_t)(slot * 64 + lane);
+            nact += (int)__popcll(hm);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#ifdef LINKED_SKIP_BACK
+        nact = 0;
+#endif
+        for (int base = 0; base < nact; base += 64) {
+            const bool has = base + lane < nact;
+            const int cell = has ? (int)s_list[wave][base + lane] : (int)s_list[wave][base];
+            const long long tile = tile_first + 4 * (cell >> 6);
+            const long long r = tile * 64 + (cell & 63);
+            const bool live = has;
+            const int n = has ? (RAGGED ? lens[r] : max_len) : 0;
+            const uint4 *tp = packed + (size_t)tile * nchunks * 64 + (cell & 63);
+            const uint32_t word = s_word[cell];
+            const int which = has ? (int)(word >> 24) : 0;
+            const BackParams &bp = S.p.b[which];
             uint32_t ww = 0u;
             uint32_t brec[4];
             rec_none(brec);
@@ -370,6 +422,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     const int nchunks = (max_len + 31) / 32;
     FastWork wk = fast_carve(d_work, nreads, s->p.n * FILTER_BINS);
     wk.nused = fast_blocks_for((nreads + 63) / 64);                // a short batch: only the blocks it fills (and their histogram rows)
+    if (const char *ev = getenv("ATR_LINKED_BLOCKS")) wk.nused = std::min(wk.nused, atoi(ev));
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const LinkedBlob *blob = (const LinkedBlob *)s->d_params;
     const bool ragged = d_lens != nullptr, and_mode = s->p.and_mode != 0;
