@@ -41,6 +41,8 @@ void launch_fast_scan(FastWork wk, hipStream_t st) {
 // independent of each other (disjoint slots of `order`, disjoint records) and go to one stream each,
 // so that their tails overlap.  idx == 0 forks the side streams off `st` (they wait for the scatter
 // pass), idx == count - 1 joins them again; events only, legal inside a stream capture.
+// (A band stream per adapter was tried in round 4: the four K4a launches of C4 then run side by side, each four
+// times as long -- the DP phase is bound by its task throughput, not by launch latency.)
 constexpr int DP_STREAMS = 4;                            // >= LINKED_MAX: band stream + one per further adapter
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                    int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes) {

@@ -195,9 +195,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             nact += (int)__popcll(hm);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#ifdef LINKED_SKIP_BACK
-        nact = 0;
-#endif
         for (int base = 0; base < nact; base += 64) {
             const bool has = base + lane < nact;
             const int cell = has ? (int)s_list[wave][base + lane] : (int)s_list[wave][base];
@@ -422,7 +419,6 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     const int nchunks = (max_len + 31) / 32;
     FastWork wk = fast_carve(d_work, nreads, s->p.n * FILTER_BINS);
     wk.nused = fast_blocks_for((nreads + 63) / 64);                // a short batch: only the blocks it fills (and their histogram rows)
-    if (const char *ev = getenv("ATR_LINKED_BLOCKS")) wk.nused = std::min(wk.nused, atoi(ev));
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const LinkedBlob *blob = (const LinkedBlob *)s->d_params;
     const bool ragged = d_lens != nullptr, and_mode = s->p.and_mode != 0;
