@@ -439,13 +439,24 @@ class HipBackend(object):
                                                                   self._stream()), "atr_locate_planes_batch")
         return out
 
+    def _tls_buffer(self, name, make, fits=None):
+        """The result buffer of a one-object call, one per host thread: ctypes releases the GIL during the call and
+        the C side stages per thread, so two threads on one backend must not share the record they read back."""
+        tls = self.__dict__.get("_tls")
+        if tls is None:
+            import threading
+            tls = self.__dict__.setdefault("_tls", threading.local())
+        buf = getattr(tls, name, None)
+        if buf is None or (fits is not None and not fits(buf)):
+            buf = make()
+            setattr(tls, name, buf)
+        return buf
+
     def locate_one(self, h, query):
         """``Aligner.locate`` of ONE read (bytes) -- what the module swap of INTEGRATION.md section 1 calls per
         read: atr_locate_one (the kernel reads the read from a page-locked staging buffer and writes the record
         into one; one launch, one synchronisation, no allocation).  Returns the six numbers or None."""
-        rec = self._one_rec if hasattr(self, "_one_rec") else None
-        if rec is None:
-            rec = self._one_rec = (C.c_int16 * 8)()
+        rec = self._tls_buffer("one_rec", lambda: (C.c_int16 * 8)())
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_locate_one(h, query, len(query), C.addressof(rec), self._stream()), "atr_locate_one")
         return None if rec[1] < 0 else (rec[0], rec[1], rec[2], rec[3], rec[4], rec[5])
@@ -453,22 +464,18 @@ class HipBackend(object):
     def multi_locate_one(self, ref, query, e, flags, min_overlap, max_matches):
         """``MultiAligner.locate`` of ONE pair of byte strings (atr_multi_locate_one); list of 6-tuples or None."""
         cap = max_matches + len(ref) + 2              # the last-column scan appends past max_matches (_align.pyx:750-763)
-        buf = getattr(self, "_multi_buf", None)
-        if buf is None or len(buf) < cap * 8:
-            buf = self._multi_buf = (C.c_int16 * (cap * 8))()
-            self._multi_cnt = C.c_int32()
+        buf = self._tls_buffer("multi_buf", lambda: (C.c_int16 * (cap * 8))(), lambda b: len(b) >= cap * 8)
+        cnt = self._tls_buffer("multi_cnt", C.c_int32)
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_multi_locate_one(ref, len(ref), query, len(query), e, flags, min_overlap, max_matches,
-                                                           C.addressof(buf), cap, C.addressof(self._multi_cnt), self._stream()),
+                                                           C.addressof(buf), cap, C.addressof(cnt), self._stream()),
                    "atr_multi_locate_one")
-        c = self._multi_cnt.value
+        c = cnt.value
         return None if c == 0 else [tuple(buf[8 * t:8 * t + 6]) for t in range(c)]
 
     def compare_one(self, ref, query, wildcard_ref, wildcard_query, suffix):
         """compare_prefixes / compare_suffixes of one pair of byte strings (atr_compare_one); the 6-tuple."""
-        rec = getattr(self, "_cmp_rec", None)
-        if rec is None:
-            rec = self._cmp_rec = (C.c_int16 * 8)()
+        rec = self._tls_buffer("cmp_rec", lambda: (C.c_int16 * 8)())
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_compare_one(ref, len(ref), query, len(query), int(wildcard_ref), int(wildcard_query),
                                                       int(suffix), C.addressof(rec), self._stream()), "atr_compare_one")
@@ -477,9 +484,7 @@ class HipBackend(object):
     def locate_pair_one(self, ref_codes, revcomp_ref, query_codes, e, flags, wildcard_ref, wildcard_query, min_overlap,
                         indel_cost):
         """``Aligner(ref, ...).locate(query)`` for ONE pair of translated byte strings (atr_locate_pair_one)."""
-        rec = getattr(self, "_pair_rec", None)
-        if rec is None:
-            rec = self._pair_rec = (C.c_int16 * 8)()
+        rec = self._tls_buffer("pair_rec", lambda: (C.c_int16 * 8)())
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_locate_pair_one(ref_codes, len(ref_codes), int(revcomp_ref), query_codes,
                                                           len(query_codes), e, flags, int(wildcard_ref), int(wildcard_query),
@@ -490,9 +495,7 @@ class HipBackend(object):
     def insert_match_one(self, h, seq1, seq2):
         """``InsertAligner.match_insert`` of ONE pair of byte strings (upper-case IUPAC letters only: the caller checks);
         the three records as a flat list of 24 int16 values (atr_insert_match_one)."""
-        rec = getattr(self, "_ins_rec", None)
-        if rec is None:
-            rec = self._ins_rec = (C.c_int16 * 24)()
+        rec = self._tls_buffer("ins_rec", lambda: (C.c_int16 * 24)())
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.atr_insert_match_one(h, seq1, len(seq1), seq2, len(seq2), C.addressof(rec), self._stream()),
                    "atr_insert_match_one")

@@ -447,10 +447,20 @@ _SPEC = re.compile(r"^(?:(?P<name>[^=]*)=)?\s*(?P<hat>\^)?(?P<body>.*?)(?P<dolla
 def fasta_records(path):
     """(header, sequence) of every record of a FASTA file as the adapter parser needs them: lines are
     stripped (DOS line ends too), blank lines and ``#`` comment lines skipped, wrapped sequences joined; text
-    before the first ``>`` is an error (reference: FastaReader.__iter__, io/seqio.py:251-280).  Plain or
-    gzip-compressed text."""
-    import gzip
-    opener = gzip.open if str(path).endswith(".gz") else open
+    before the first ``>`` is an error (reference: FastaReader.__iter__, io/seqio.py:251-280).  Plain text or
+    .gz / .bz2 / .xz (what the reference's xopen dispatches on)."""
+    name = str(path)
+    if name.endswith(".gz"):
+        import gzip
+        opener = gzip.open
+    elif name.endswith(".bz2"):
+        import bz2
+        opener = bz2.open
+    elif name.endswith(".xz"):
+        import lzma
+        opener = lzma.open
+    else:
+        opener = open
     header, parts = None, []
     with opener(path, "rt") as handle:
         for number, raw in enumerate(handle, 1):

@@ -7,6 +7,8 @@ A chunk of the file is uploaded as raw bytes; the library finds and validates th
 surviving records are formatted on the device (``atr_fastq_emit``).  No per-read Python
 object exists anywhere on this path.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -294,9 +296,18 @@ def _staging(nbytes, pinned):
     return t.pin_memory() if pinned else t
 
 
+STAGING_POOL_BYTES = 4 << 30  # page-locked memory the pool keeps between runs (more starves other processes of a shared node)
+
+
 def _release(buffers):
     _STAGING_POOL.extend(buffers)
-    del _STAGING_POOL[:-32]                                   # keep at most 32 (a paired run with merging into four parts holds 28)
+    del _STAGING_POOL[:-32]                                   # at most 32 (a paired run with merging into four parts holds 28)
+    total = 0
+    for i in range(len(_STAGING_POOL) - 1, -1, -1):           # ... and at most STAGING_POOL_BYTES, the newest first
+        total += _STAGING_POOL[i].numel()
+        if total > STAGING_POOL_BYTES:
+            del _STAGING_POOL[:i + 1]
+            break
 
 
 IO_THREADS = 8              # pread slices per chunk (a page-cached file scales to ~6 GB/s per thread)
@@ -470,7 +481,8 @@ class FastqSink(object):
         self.offset = 0                                       # bytes handed to pwrite so far (a multiple of BLOCK)
         self.rem = 0                                          # carried bytes at the front of the next buffer
         self.pool = ThreadPoolExecutor(1)
-        self.wpool = ThreadPoolExecutor(self.WRITERS - 1) if self.WRITERS > 1 else None
+        self.writers = int(self.WRITERS)                      # (fixed for this sink's life: set_writers() applies to later sinks)
+        self.wpool = ThreadPoolExecutor(self.writers - 1) if self.writers > 1 else None
         self.pending = [None] * self.nbuf
         self.k = 0
         self.copy_stream = torch.cuda.Stream(device=be.device) if self.gpu else None
@@ -487,13 +499,13 @@ class FastqSink(object):
         at = 0
         if self.wpool is not None and not self.direct and whole >= (16 << 20):
             # disjoint block-aligned ranges of the same buffer and file, one thread each
-            per = (whole // self.WRITERS) // self.BLOCK * self.BLOCK
+            per = (whole // self.writers) // self.BLOCK * self.BLOCK
 
             def piece(lo, hi):
                 while lo < hi:
                     lo += os.pwrite(self.fd, view[lo:hi], offset + lo)
-            jobs = [self.wpool.submit(piece, i * per, (i + 1) * per) for i in range(1, self.WRITERS - 1)]
-            jobs.append(self.wpool.submit(piece, (self.WRITERS - 1) * per, whole))
+            jobs = [self.wpool.submit(piece, i * per, (i + 1) * per) for i in range(1, self.writers - 1)]
+            jobs.append(self.wpool.submit(piece, (self.writers - 1) * per, whole))
             piece(0, per)
             for job in jobs:
                 job.result()
@@ -569,12 +581,21 @@ class FastqSink(object):
 class PartSink(object):
     """The output as N part files ``<path>.part0 .. <path>.part<N-1>``, one ``FastqSink`` -- writer thread, staging
     buffers, file -- each: chunk k of the stream goes to part k mod N, records keep their order inside a part.
+    Ordering contract: the parts concatenated are NOT the input order; part i holds the chunks i, i + N, i + 2N, ...
+    of the stream in that order (an empty chunk is written as nothing and still takes its turn).
     For hosts whose file system serialises the writers of ONE file (measured on the MI355X box: 11.8 GB/s into a
     fresh file from one thread or from eight, 75 GB/s into eight files; putting the parts together again by
     copy_file_range costs as much as writing them, tools/micro/write_parts.py).  What the reference's
     ``--no-writer-process`` does with its worker processes: every worker writes a file of its own."""
 
     def __init__(self, path, parts, capacity, backend=None, clock=None, keep=False):
+        # parts of an earlier run with more of them must not survive next to this run's (`out.part*` would mix them in)
+        import glob
+        import re
+        for old in glob.glob(glob.escape(str(path)) + ".part*"):
+            tail = old[len(str(path)) + 5:]
+            if re.fullmatch(r"[0-9]+", tail) and int(tail) >= int(parts):
+                os.unlink(old)
         self.paths = ["%s.part%d" % (path, i) for i in range(int(parts))]
         self.sinks = [FastqSink(p, capacity, backend, clock, keep=keep, nbuf=2) for p in self.paths]
         self.k = 0

@@ -960,7 +960,12 @@ def check_fastq_chunking(tmp_path):
     assert sum(counts.values()) == data.count(b"\n") // 4
     # the output as three part files with a writer each: chunk k in part k mod 3, in order inside a part -- the records
     # of all parts are those of the single file
+    (tmp_path / "out.fastq.part3").write_bytes(b"stale part of an earlier run with more parts\n")
+    (tmp_path / "out.fastq.part7").write_bytes(b"stale\n")
+    (tmp_path / "out.fastq.partial").write_bytes(b"not a part\n")
     counts3 = pipe.trim_file(str(src), str(dst), chunk_bytes=50000, output_parts=3)
+    assert not (tmp_path / "out.fastq.part3").exists() and not (tmp_path / "out.fastq.part7").exists()
+    assert (tmp_path / "out.fastq.partial").exists()
     parts = [(tmp_path / ("out.fastq.part%d" % i)).read_bytes() for i in range(3)]
     assert counts3 == counts and all(parts) and sum(len(p) for p in parts) == len(whole)
 

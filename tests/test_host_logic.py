@@ -87,6 +87,12 @@ def test_file_adapter_specs(tmp_path, emu_backend):
     with gzip.open(str(path) + ".gz", "wt") as fh:
         fh.write(text)
     assert list(fasta_records(str(path) + ".gz")) == list(fasta_records(str(path)))
+    import bz2
+    import lzma
+    for ext, mod in ((".bz2", bz2), (".xz", lzma)):           # what the reference's xopen also opens
+        with mod.open(str(path) + ext, "wt") as fh:
+            fh.write(text)
+        assert list(fasta_records(str(path) + ext)) == list(fasta_records(str(path)))
     good = tmp_path / "good.fa"
     good.write_text(">first adapter one\nAGATCGGAAG\nAGCACACG\n>anch\n^ACGTACGT\n")
     ads = list(AdapterParser(max_error_rate=0.1).parse("file:" + str(good), "front"))
