@@ -37,9 +37,59 @@ class TrimResult(object):
     """State of a batch after the pipeline: kept interval per read, the destination filter
     and the adapter flag; all device tensors."""
 
-    def __init__(self, batch, begin, end, ubegin, uend, matched, dest):
+    def __init__(self, batch, begin, end, ubegin, uend, matched, dest, rounds=None, adapters=None):
         self.batch, self.begin, self.end, self.ubegin, self.uend = batch, begin, end, ubegin, uend
         self.matched, self.dest = matched, dest
+        self.rounds, self.adapters = rounds, adapters           # adapter rounds kept for the info / rest / wildcard files
+
+    def aux_text(self, kinds=("info", "rest", "wildcard")):
+        """The lines the reference's InfoFormatter / RestFormatter / WildcardFormatter write for this batch
+        (commands/trim/writers.py:193-222; Match.get_info_record / rest / wildcards, align/__init__.py:117-170),
+        every read in input order whatever its destination: {kind: bytes}.  Assembled on the host from the result
+        arrays of the adapter rounds (the pipeline must have been built with ``aux``)."""
+        if self.rounds is None:
+            raise ValueError("the pipeline was built without aux=(...): the adapter rounds were not kept")
+        n = len(self.batch)
+        raw = bytes(self.batch.data[:self.batch.nbytes].cpu().numpy().tobytes())
+        recs = self.batch.records.cpu().numpy().astype("int64")
+        recs[:, [0, 2, 4]] &= 0xFFFFFFFF                       # (offsets are unsigned 32-bit)
+        fb, fe = self.begin.cpu().numpy(), self.end.cpu().numpy()
+        rounds = [tuple(t.cpu().numpy() for t in r) for r in self.rounds]
+        out = {k: [] for k in kinds}
+        for i in range(n):
+            name = raw[recs[i, 0]:recs[i, 0] + recs[i, 1]].decode("ascii", "replace")
+            so, qo, has_q = int(recs[i, 2]), int(recs[i, 4]), recs[i, 5] > 0 or recs[i, 3] == 0
+            last = None
+            lines = []
+            for took, rec, which, b0, e0 in rounds:
+                if not took[i]:
+                    continue
+                ad = self.adapters[int(which[i])]
+                astart, astop, rstart, rstop, _matches, errors = (int(v) for v in rec[i, :6])
+                seq = raw[so + b0[i]:so + e0[i]].decode("ascii", "replace")
+                qual = raw[qo + b0[i]:qo + e0[i]].decode("ascii", "replace") if has_q else ""
+                last = (ad, astart, astop, rstart, rstop, seq)
+                lines.append("\t".join(str(f) for f in (name, errors, rstart, rstop, seq[:rstart], seq[rstart:rstop], seq[rstop:],
+                                                        ad.name, qual[:rstart], qual[rstart:rstop], qual[rstop:])))
+            if "info" in out:
+                if last is None:
+                    seq = raw[so + fb[i]:so + max(fb[i], fe[i])].decode("ascii", "replace")
+                    qual = raw[qo + fb[i]:qo + max(fb[i], fe[i])].decode("ascii", "replace") if has_q else ""
+                    lines = ["\t".join((name, "-1", seq, qual))]
+                out["info"].extend(lines)
+            if last is None:
+                continue
+            ad, astart, astop, rstart, rstop, seq = last
+            front = ad._front_flag if ad._front_flag is not None else rstart == 0        # Match._guess_is_front
+            if "rest" in out:
+                rest = seq[:rstart] if front else seq[rstop:]
+                if rest:
+                    out["rest"].append(rest + " " + name)
+            if "wildcard" in out:
+                chars = [seq[rstart + k] for k in range(astop - astart)
+                         if ad.sequence[astart + k] == "N" and rstart + k < len(seq)]
+                out["wildcard"].append("".join(chars) + " " + name)
+        return {k: "".join(line + "\n" for line in v).encode("ascii", "replace") for k, v in out.items()}
 
     def counts(self):
         c = torch.bincount(self.dest.to(torch.int64), minlength=6).cpu().tolist()
@@ -66,8 +116,10 @@ class TrimPipeline(object):
 
     def __init__(self, adapters=(), times=1, action="trim", cut=(), nextseq_trim=None, quality_cutoff=None,
                  quality_base=33, trim_n=False, minimum_length=None, maximum_length=None, max_n=None,
-                 discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW"):
+                 discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW", aux=None):
         self.adapters = list(adapters)
+        self.aux = dict(aux) if aux else None            # {"info" | "rest" | "wildcard": path}: --info-file, --rest-file, --wildcard-file
+        self._rounds = None
         self.times, self.action = int(times), action
         if action not in ("trim", "mask", None):
             raise ValueError("action must be 'trim', 'mask' or None")
@@ -90,6 +142,8 @@ class TrimPipeline(object):
             raise NotImplementedError("mixing linked and plain adapters (the reference's AdapterCutter raises "
                                       "AttributeError as soon as two of them match a read)")
         self._linked = bool(linked)
+        if self.aux and self._linked:
+            raise NotImplementedError("--info-file / --rest-file / --wildcard-file with linked adapters")
 
     # ------------------------------------------------------------------ adapter rounds
     @staticmethod
@@ -113,6 +167,8 @@ class TrimPipeline(object):
             which = torch.where(better, torch.full_like(which, idx), which)
         codes = torch.tensor([self._front_code(a) for a in self.adapters], dtype=torch.uint8, device=best.device)
         front = codes[which].contiguous() if len(self.adapters) > 1 else None
+        if self._rounds is not None:                                      # (reads this round's match applies to, the read it saw)
+            self._rounds.append(((active != 0) & (best[:, 1] >= 0), best.clone(), which.clone(), begin.clone(), end.clone()))
         be.match_trim_batch(best.contiguous(), front, int(codes[0].item()), begin, end, active, matched)
 
     def _round_linked(self, batch, begin, end, active, matched):
@@ -181,6 +237,7 @@ class TrimPipeline(object):
         end = batch.seq_lens.clone()
         matched = torch.zeros((n,), dtype=torch.uint8, device=begin.device)
         ubegin = uend = None
+        self._rounds = [] if self.aux else None
         for op in self.op_order:
             if op == "A":
                 if self.adapters:
@@ -188,7 +245,8 @@ class TrimPipeline(object):
             else:
                 self._simple_stage(op, batch, begin, end)
         dest = self._filter_stage(batch, begin, end, ubegin, uend, matched)
-        return TrimResult(batch, begin, end, ubegin, uend, matched, dest)
+        rounds, self._rounds = self._rounds, None
+        return TrimResult(batch, begin, end, ubegin, uend, matched, dest, rounds, self.adapters)
 
     def trim_bytes(self, data, which=_lib.DEST_KEEP):
         """FASTQ text in, trimmed FASTQ text out (one batch)."""
@@ -213,6 +271,7 @@ class TrimPipeline(object):
         clock = StageClock()
         reader = ChunkedFastqReader(path_in, chunk_bytes, be, clock)
         sink = make_sink(path_out, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output)
+        aux_files = {kind: open(path, "wb") for kind, path in (self.aux or {}).items()}
         try:
             while True:
                 batch = reader.next_batch()
@@ -224,6 +283,9 @@ class TrimPipeline(object):
                 counts = res.counts()
                 clock.add("trim_and_format", t0)
                 sink.write(text)
+                if aux_files:                                 # host-assembled lines (debugging outputs, not a throughput path)
+                    for kind, blob in res.aux_text(tuple(aux_files)).items():
+                        aux_files[kind].write(blob)
                 for name, v in counts.items():
                     totals[name] += v
                 if done:
@@ -231,6 +293,8 @@ class TrimPipeline(object):
         finally:
             reader.close()
             sink.close()
+            for fh in aux_files.values():
+                fh.close()
             self.stage_seconds = dict(clock.seconds)
         return totals
 
@@ -607,6 +671,9 @@ def pipeline_from_args(argv):
     ap.add_argument("-R", "--merge-overlapping", action="store_true", default=False)
     ap.add_argument("--merge-min-overlap", type=float, default=0.9)
     ap.add_argument("--merge-error-rate", type=float, default=None)
+    ap.add_argument("--info-file", default=None)
+    ap.add_argument("--rest-file", "-r", default=None)
+    ap.add_argument("--wildcard-file", default=None)
     o = ap.parse_args(argv)
     paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert" or
                   o.merge_overlapping)
@@ -669,8 +736,11 @@ def pipeline_from_args(argv):
                   quality_base=o.quality_base, trim_n=o.trim_n, minimum_length=o.minimum_length,
                   maximum_length=o.maximum_length, max_n=o.max_n, discard_trimmed=o.discard_trimmed,
                   discard_untrimmed=o.discard_untrimmed, op_order=o.op_order)
+    aux = {kind: path for kind, path in (("info", o.info_file), ("rest", o.rest_file), ("wildcard", o.wildcard_file)) if path}
     if not paired:
-        return TrimPipeline(adapters=adapters, cut=o.cut, **common)
+        return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, **common)
+    if aux:
+        raise NotImplementedError("--info-file / --rest-file / --wildcard-file with paired-end input")
     return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,

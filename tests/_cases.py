@@ -912,6 +912,20 @@ def check_trim_golden(select=None):
             continue
         data = inputs[case["input"]]
         label = "%s: %s" % (case["input"], case["args"])
+        if case.get("aux"):
+            # --info-file / --rest-file / --wildcard-file: the three texts next to the main output
+            from atropos_amd.fastq import FastqBatch
+            pipe = pipeline_from_args(case["args"].format(info="i.txt", rest="r.txt", wildcard="w.txt"))
+            batch, _ = FastqBatch.from_bytes(data, final=True)
+            res = pipe.run(batch)
+            aux = res.aux_text(tuple(case["aux"]))
+            for kind, want in case["aux"].items():
+                want = base64.b64decode(want)
+                assert aux[kind] == want, (label, kind, _first_diff(aux[kind], want))
+            out = res.text()
+            assert len(out) == case["size"] and hashlib.sha256(out).hexdigest() == case["sha256"], label
+            done += 1
+            continue
         pipe = pipeline_from_args(case["args"])
         if case["error"]:
             try:

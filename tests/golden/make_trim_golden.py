@@ -186,6 +186,16 @@ CASES = [
     ("synth_dos.fastq", "-a " + TRUSEQ + " -q 20 -m 20"),
     ("synth_name2.fastq", "-a " + TRUSEQ + " --trim-n"),
     ("nofinalnewline.fastq", "-a TTAGACATATCTCCGTCG"),
+    # --info-file / --rest-file / --wildcard-file (writers.py:193-222): "{info}" etc. stand for a path; the files'
+    # text is recorded next to the main output
+    ("small.fastq", "-a ad=TTAGACATATCTCCGTCG --info-file {info} --rest-file {rest} --wildcard-file {wildcard}"),
+    ("small.fastq", "-g ad=TTAGACATATCTCCGTCG --info-file {info} --rest-file {rest}"),
+    ("anywhere_repeat.fastq", "-b rep=CAAG -n 3 --mask-adapter --info-file {info} --rest-file {rest}"),
+    ("illumina.fastq", "-a wild=GCCGAACTTCTTAGACTNCCTTAAGGACNT --info-file {info} --wildcard-file {wildcard}"),
+    ("illumina.fastq", "--times 2 -a adapt=GCCGAACTTCTTA -a second=TTAGACTGCC --info-file {info} --rest-file {rest}"),
+    ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15,25 --trim-n -m 30 --info-file {info} --rest-file {rest} --wildcard-file {wildcard}"),
+    ("synth.fastq", "-b tru=" + TRUSEQ + " -g head=" + TRUSEQ[:20] + " -e 0.2 -O 5 -n 2 --discard-trimmed --info-file {info} --rest-file {rest}"),
+    ("synth.fastq", "-a tru=" + TRUSEQ + " --no-trim --info-file {info} --wildcard-file {wildcard} --match-read-wildcards"),
     # records beyond the batch pipelines' 736 bases among ordinary ones (the reference has no length limit)
     ("longmix.fastq", "-a " + TRUSEQ),
     ("longmix.fastq", "-b " + TRUSEQ + " -n 2 -e 0.12"),
@@ -304,10 +314,17 @@ def main():
             in_path = os.path.join(tmp, "in_%d.fastq" % idx)
             out_path = os.path.join(tmp, "out_%d.fastq" % idx)
             open(in_path, "wb").write(inputs[name])
-            params = argstr.split() + ["-se", in_path, "-o", out_path, "--quiet", "--no-default-adapters",
-                                       "--no-cache-adapters"]
+            aux_paths = {kind: os.path.join(tmp, "%s_%d.txt" % (kind, idx)) for kind in ("info", "rest", "wildcard")
+                         if "{%s}" % kind in argstr}
+            params = argstr.format(**aux_paths).split() + ["-se", in_path, "-o", out_path, "--quiet", "--no-default-adapters",
+                                                            "--no-cache-adapters"]
             retcode, summary = get_command("trim").execute(params)
             case = dict(input=name, args=argstr, output=None, error=None)
+            if aux_paths:
+                assert retcode == 0, argstr
+                # (a file nothing was written to is not created)
+                case["aux"] = {kind: base64.b64encode(open(path, "rb").read() if os.path.exists(path) else b"").decode()
+                               for kind, path in aux_paths.items()}
             if retcode != 0:
                 # the command only logs the exception: re-raise it by iterating the reference's reader
                 from atropos.io._seqio import FastqReader
