@@ -35,8 +35,13 @@ struct FastqRecord {
     uint32_t seq_off, seq_len;
     uint32_t qual_off, qual_len;
     uint32_t flags;                                  // bit 0: the '+' line repeats the description (name2 = name)
+                                                     // bit 1: ... and that text sits at `reserved`, flags >> 8 bytes of it
+                                                     //   (records whose name a read-name modifier rewrote: name2 keeps the
+                                                     //   text the file had, io/seqio.py:690-699)
     uint32_t reserved;
 };
+ATR_DEV uint32_t fastq_name2_len(const FastqRecord &rec) { return (rec.flags & 1u) ? ((rec.flags & 2u) ? rec.flags >> 8 : rec.name_len) : 0u; }
+ATR_DEV uint32_t fastq_name2_off(const FastqRecord &rec) { return (rec.flags & 2u) ? rec.reserved : rec.name_off; }
 
 // Line terminators follow Python's universal-newline text mode, which is how the reference
 // reads its input (xopen(..., 'r')): "\n", "\r\n" and a lone "\r" each end a line.  Line L
@@ -295,7 +300,7 @@ ATR_DEV void insert_plan_trim(const InsertPlan &P, int len1, int len2, int trim_
 
 // Bytes of a formatted record (io/seqio.py:690-699): '@' name '\n' seq '\n+' name2 '\n' qual '\n'
 ATR_DEV uint32_t fastq_record_bytes(const FastqRecord &rec, int kept) {
-    return 1u + rec.name_len + 1u + (uint32_t)kept + 2u + ((rec.flags & 1u) ? rec.name_len : 0u) + 1u + (uint32_t)kept + 1u;
+    return 1u + rec.name_len + 1u + (uint32_t)kept + 2u + fastq_name2_len(rec) + 1u + (uint32_t)kept + 1u;
 }
 
 // ---- MergeOverlapping (commands/trim/modifiers.py:864-931) ---------------------------------

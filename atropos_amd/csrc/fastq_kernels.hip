@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const uint8_t *__restrict__ b
         o += kept;
         if (lane == 0) { o[0] = '\n'; o[1] = '+'; }
         o += 2;
-        if (rec.flags & 1u) { wave_copy(o, bytes + rec.name_off, rec.name_len, lane); o += rec.name_len; }
+        if (rec.flags & 1u) { wave_copy(o, bytes + fastq_name2_off(rec), fastq_name2_len(rec), lane); o += fastq_name2_len(rec); }
         if (lane == 0) o[0] = '\n';
         o += 1;
         wave_copy(o, bytes + rec.qual_off + a, kept, lane);
@@ -593,7 +593,8 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
     const uint32_t in_lo = __shfl(rec_lo, 0, 64), in_hi = __shfl(rec_hi, LPR * (cnt - 1), 64);
     const long long out_lo = offsets[r0], out_hi = offsets[r0 + cnt];
     const bool ordered = __all(!live || (rec_lo >= in_lo && rec_hi <= in_hi && rec.seq_off >= rec_lo &&
-                                         rec.seq_off + rec.seq_len <= rec.qual_off && rec.name_off + rec.name_len <= rec.seq_off));
+                                         rec.seq_off + rec.seq_len <= rec.qual_off && rec.name_off + rec.name_len <= rec.seq_off &&
+                                         !(rec.flags & 2u)));
     const uint32_t mis_in = in_lo & 15u, mis_out = (uint32_t)(out_lo & 15);
     const bool fits = ordered && (in_hi - in_lo) + mis_in + 16u <= (uint32_t)STAGE &&
                       (uint32_t)(out_hi - out_lo) + mis_out + 16u <= (uint32_t)STAGE;
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64) void emit_staged_kernel(const uint8_t *__restri
             o += kept;
             if (lane == 0) { o[0] = '\n'; o[1] = '+'; }
             o += 2;
-            if (rc.flags & 1u) { wave_copy(o, bytes + rc.name_off, rc.name_len, lane); o += rc.name_len; }
+            if (rc.flags & 1u) { wave_copy(o, bytes + fastq_name2_off(rc), fastq_name2_len(rc), lane); o += fastq_name2_len(rc); }
             if (lane == 0) o[0] = '\n';
             o += 1;
             wave_copy(o, bytes + rc.qual_off + ai, kept, lane);

@@ -37,10 +37,11 @@ class TrimResult(object):
     """State of a batch after the pipeline: kept interval per read, the destination filter
     and the adapter flag; all device tensors."""
 
-    def __init__(self, batch, begin, end, ubegin, uend, matched, dest, rounds=None, adapters=None):
+    def __init__(self, batch, begin, end, ubegin, uend, matched, dest, rounds=None, adapters=None, read_batch=None):
         self.batch, self.begin, self.end, self.ubegin, self.uend = batch, begin, end, ubegin, uend
         self.matched, self.dest = matched, dest
         self.rounds, self.adapters = rounds, adapters           # adapter rounds kept for the info / rest / wildcard files
+        self.read_batch = read_batch or batch                   # the records as read (batch: after the read-name modifiers)
 
     def aux_text(self, kinds=("info", "rest", "wildcard")):
         """The lines the reference's InfoFormatter / RestFormatter / WildcardFormatter write for this batch
@@ -51,8 +52,11 @@ class TrimResult(object):
             raise ValueError("the pipeline was built without aux=(...): the adapter rounds were not kept")
         n = len(self.batch)
         raw = bytes(self.batch.data[:self.batch.nbytes].cpu().numpy().tobytes())
-        recs = self.batch.records.cpu().numpy().astype("int64")
+        recs = self.read_batch.records.cpu().numpy().astype("int64")
         recs[:, [0, 2, 4]] &= 0xFFFFFFFF                       # (offsets are unsigned 32-bit)
+        final = self.batch.records.cpu().numpy().astype("int64")           # (an unmatched read's line carries its final name)
+        final[:, 0] &= 0xFFFFFFFF
+        raw_final = raw if self.batch is self.read_batch else bytes(self.batch.data.cpu().numpy().tobytes())
         fb, fe = self.begin.cpu().numpy(), self.end.cpu().numpy()
         rounds = [tuple(t.cpu().numpy() for t in r) for r in self.rounds]
         out = {k: [] for k in kinds}
@@ -75,7 +79,8 @@ class TrimResult(object):
                 if last is None:
                     seq = raw[so + fb[i]:so + max(fb[i], fe[i])].decode("ascii", "replace")
                     qual = raw[qo + fb[i]:qo + max(fb[i], fe[i])].decode("ascii", "replace") if has_q else ""
-                    lines = ["\t".join((name, "-1", seq, qual))]
+                    fname = raw_final[final[i, 0]:final[i, 0] + final[i, 1]].decode("ascii", "replace")
+                    lines = ["\t".join((fname, "-1", seq, qual))]
                 out["info"].extend(lines)
             if last is None:
                 continue
@@ -116,8 +121,14 @@ class TrimPipeline(object):
 
     def __init__(self, adapters=(), times=1, action="trim", cut=(), nextseq_trim=None, quality_cutoff=None,
                  quality_base=33, trim_n=False, minimum_length=None, maximum_length=None, max_n=None,
-                 discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW", aux=None):
+                 discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW", aux=None, length_tag=None,
+                 strip_suffix=(), prefix="", suffix="", zero_cap=False):
         self.adapters = list(adapters)
+        # read-name modifiers and the quality cap, applied after every trimming step (trim/__init__.py:526-541)
+        self.length_tag, self.strip_suffix = length_tag or None, list(strip_suffix or ())
+        self.prefix, self.suffix, self.zero_cap = prefix or "", suffix or "", bool(zero_cap)
+        self._name_mods = bool(self.length_tag or self.strip_suffix or self.prefix or self.suffix)
+        self._last_which = None
         self.aux = dict(aux) if aux else None            # {"info" | "rest" | "wildcard": path}: --info-file, --rest-file, --wildcard-file
         self._rounds = None
         self.times, self.action = int(times), action
@@ -144,6 +155,8 @@ class TrimPipeline(object):
         self._linked = bool(linked)
         if self.aux and self._linked:
             raise NotImplementedError("--info-file / --rest-file / --wildcard-file with linked adapters")
+        if self._linked and ("{name}" in self.prefix or "{name}" in self.suffix):
+            raise NotImplementedError("{name} in --prefix / --suffix with linked adapters")
 
     # ------------------------------------------------------------------ adapter rounds
     @staticmethod
@@ -167,8 +180,11 @@ class TrimPipeline(object):
             which = torch.where(better, torch.full_like(which, idx), which)
         codes = torch.tensor([self._front_code(a) for a in self.adapters], dtype=torch.uint8, device=best.device)
         front = codes[which].contiguous() if len(self.adapters) > 1 else None
-        if self._rounds is not None:                                      # (reads this round's match applies to, the read it saw)
-            self._rounds.append(((active != 0) & (best[:, 1] >= 0), best.clone(), which.clone(), begin.clone(), end.clone()))
+        took = (active != 0) & (best[:, 1] >= 0)                          # reads this round's match applies to
+        if self._rounds is not None:                                      # (... and the read the match saw)
+            self._rounds.append((took, best.clone(), which.clone(), begin.clone(), end.clone()))
+        if self._last_which is not None:
+            self._last_which = torch.where(took, which, self._last_which)
         be.match_trim_batch(best.contiguous(), front, int(codes[0].item()), begin, end, active, matched)
 
     def _round_linked(self, batch, begin, end, active, matched):
@@ -238,6 +254,8 @@ class TrimPipeline(object):
         matched = torch.zeros((n,), dtype=torch.uint8, device=begin.device)
         ubegin = uend = None
         self._rounds = [] if self.aux else None
+        self._last_which = (torch.zeros((n,), dtype=torch.int64, device=begin.device)
+                            if ("{name}" in self.prefix or "{name}" in self.suffix) else None)
         for op in self.op_order:
             if op == "A":
                 if self.adapters:
@@ -246,7 +264,68 @@ class TrimPipeline(object):
                 self._simple_stage(op, batch, begin, end)
         dest = self._filter_stage(batch, begin, end, ubegin, uend, matched)
         rounds, self._rounds = self._rounds, None
-        return TrimResult(batch, begin, end, ubegin, uend, matched, dest, rounds, self.adapters)
+        if self.zero_cap and n:
+            self._zero_cap(batch)
+        read_batch = batch
+        if self._name_mods and n:
+            batch = self._rewrite_names(batch, begin, end, matched)
+        self._last_which = None
+        return TrimResult(batch, begin, end, ubegin, uend, matched, dest, rounds, self.adapters, read_batch)
+
+    def _zero_cap(self, batch):
+        """ZeroCapper (modifiers.py:709-720): quality characters below the base become the base, in the chunk."""
+        rec = batch.records
+        lens = rec[:, 5].to(torch.int64)
+        start = rec[:, 4].to(torch.int64) & 0xFFFFFFFF
+        first = torch.cumsum(lens, 0) - lens
+        idx = torch.repeat_interleave(start - first, lens) + torch.arange(int(lens.sum().item()), device=rec.device)
+        batch.data[idx] = batch.data[idx].clamp(min=self.quality_base)
+
+    def _rewrite_names(self, batch, begin, end, matched):
+        """LengthTagModifier, SuffixRemover, PrefixSuffixAdder (modifiers.py:652-695) in the reference's order: the
+        new names are made on the host (string work per read, as in the reference), appended to the chunk in device
+        memory, and the records point at them -- the formatter copies whatever name a record names."""
+        import re
+        import numpy as np
+        raw = bytes(batch.data[:batch.nbytes].cpu().numpy().tobytes())
+        recs = batch.records.cpu().numpy().astype("int64")
+        lens = (end - begin).clamp(min=0).cpu().tolist()
+        took = matched.cpu().tolist()
+        which = self._last_which.cpu().tolist() if self._last_which is not None else None
+        tag = self.length_tag
+        regex = re.compile(r"\b" + tag + r"[0-9]*\b") if tag else None
+        names, offs, cur = [], [], 0
+        for i in range(recs.shape[0]):
+            off = recs[i, 0] & 0xFFFFFFFF
+            name = raw[off:off + recs[i, 1]].decode("latin-1")
+            if tag and name.find(tag) >= 0:
+                name = regex.sub(tag + str(lens[i]), name)
+            for sfx in self.strip_suffix:
+                if name.endswith(sfx):
+                    name = name[:-len(sfx)]
+            if self.prefix or self.suffix:
+                ad = self.adapters[which[i]].name if (which is not None and took[i]) else "no_adapter"
+                name = self.prefix.replace("{name}", ad) + name + self.suffix.replace("{name}", ad)
+            blob = name.encode("latin-1")
+            names.append(blob)
+            offs.append(cur)
+            cur += len(blob)
+        base = (batch.data.numel() + 15) // 16 * 16
+        if base + cur >= (1 << 32) - 16:
+            raise ValueError("the chunk and its rewritten names must stay below 4 GiB")
+        extra = torch.from_numpy(np.frombuffer(b"".join(names) + b"\0" * 16, dtype=np.uint8).copy()).to(batch.data.device)
+        data = torch.cat([batch.data, torch.zeros((base - batch.data.numel(),), dtype=torch.uint8, device=extra.device), extra])
+        noff = np.asarray(offs, dtype=np.int64) + base
+        # the '+' line keeps the text the file had (FastqFormat prints name2, io/seqio.py:690-699): flag bit 1,
+        # the old name's offset in `reserved`, its length above the flag bits (atr_fastq_record)
+        rep = (recs[:, 6] & 1) != 0
+        recs[:, 7] = np.where(rep, recs[:, 0], recs[:, 7])
+        flags = np.where(rep, (recs[:, 6] & 1) | 2 | (recs[:, 1] << 8), recs[:, 6])
+        recs[:, 6] = np.where(flags >= (1 << 31), flags - (1 << 32), flags)
+        recs[:, 0] = np.where(noff >= (1 << 31), noff - (1 << 32), noff)
+        recs[:, 1] = [len(b) for b in names]
+        records = torch.from_numpy(recs.astype(np.int32)).to(batch.records.device)
+        return FastqBatch(data, batch.nbytes, records, batch.backend, batch.line_ends)
 
     def trim_bytes(self, data, which=_lib.DEST_KEEP):
         """FASTQ text in, trimmed FASTQ text out (one batch)."""
@@ -278,7 +357,7 @@ class TrimPipeline(object):
                 done = reader.advance()                       # starts reading the next chunk
                 t0 = time.perf_counter()
                 res = self.run(batch)
-                text = be.fastq_emit(batch.data, batch.records, res.begin, res.end, res.ubegin, res.uend, res.dest,
+                text = be.fastq_emit(res.batch.data, res.batch.records, res.begin, res.end, res.ubegin, res.uend, res.dest,
                                      _lib.DEST_KEEP)
                 counts = res.counts()
                 clock.add("trim_and_format", t0)
@@ -671,6 +750,11 @@ def pipeline_from_args(argv):
     ap.add_argument("-R", "--merge-overlapping", action="store_true", default=False)
     ap.add_argument("--merge-min-overlap", type=float, default=0.9)
     ap.add_argument("--merge-error-rate", type=float, default=None)
+    ap.add_argument("-x", "--prefix", default="")
+    ap.add_argument("-y", "--suffix", default="")
+    ap.add_argument("--strip-suffix", action="append", default=[])
+    ap.add_argument("--length-tag", default=None)
+    ap.add_argument("-z", "--zero-cap", action="store_true", default=False)
     ap.add_argument("--info-file", default=None)
     ap.add_argument("--rest-file", "-r", default=None)
     ap.add_argument("--wildcard-file", default=None)
@@ -738,9 +822,11 @@ def pipeline_from_args(argv):
                   discard_untrimmed=o.discard_untrimmed, op_order=o.op_order)
     aux = {kind: path for kind, path in (("info", o.info_file), ("rest", o.rest_file), ("wildcard", o.wildcard_file)) if path}
     if not paired:
-        return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, **common)
-    if aux:
-        raise NotImplementedError("--info-file / --rest-file / --wildcard-file with paired-end input")
+        return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, length_tag=o.length_tag,
+                            strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
+    if aux or o.length_tag or o.strip_suffix or o.prefix or o.suffix or o.zero_cap:
+        raise NotImplementedError("--info-file / --rest-file / --wildcard-file, read-name modifiers and --zero-cap with "
+                                  "paired-end input")
     return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,

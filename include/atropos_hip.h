@@ -472,8 +472,11 @@ typedef struct {
     uint32_t name_off, name_len;   /* description after '@', line end stripped (FastqReader, _seqio.pyx:208-216) */
     uint32_t seq_off, seq_len;     /* :217-218 */
     uint32_t qual_off, qual_len;   /* :239-243 */
-    uint32_t flags;                /* bit 0: the '+' line repeats the description (name2 = name, :228-236) */
-    uint32_t reserved;
+    uint32_t flags;                /* bit 0: the '+' line repeats the description (name2 = name, :228-236);
+                                    * bit 1 (set by a caller that re-pointed name_off at a rewritten name -- LengthTagModifier,
+                                    * SuffixRemover, PrefixSuffixAdder, commands/trim/modifiers.py:652-695): the '+' line's text
+                                    * is the flags >> 8 bytes at `reserved`, as FastqFormat prints the name2 the file had */
+    uint32_t reserved;             /* offset of that text (flags bit 1), else unused */
 } atr_fastq_record;
 
 #define ATR_FASTQ_ERR_AT      1    /* FormatError "... expected to start with '@'" (:209-211) */

@@ -915,7 +915,7 @@ def check_trim_golden(select=None):
         if case.get("aux"):
             # --info-file / --rest-file / --wildcard-file: the three texts next to the main output
             from atropos_amd.fastq import FastqBatch
-            pipe = pipeline_from_args(case["args"].format(info="i.txt", rest="r.txt", wildcard="w.txt"))
+            pipe = pipeline_from_args(case["args"].replace("{info}", "i.txt").replace("{rest}", "r.txt").replace("{wildcard}", "w.txt"))
             batch, _ = FastqBatch.from_bytes(data, final=True)
             res = pipe.run(batch)
             aux = res.aux_text(tuple(case["aux"]))

@@ -270,7 +270,7 @@ int emu_fastq_emit(const uint8_t *bytes, const atr_fastq_record *records, const 
         }
         o += kept;
         *o++ = '\n'; *o++ = '+';
-        if (rec.flags & 1u) { memcpy(o, bytes + rec.name_off, rec.name_len); o += rec.name_len; }
+        if (rec.flags & 1u) { memcpy(o, bytes + fastq_name2_off(rec), fastq_name2_len(rec)); o += fastq_name2_len(rec); }
         *o++ = '\n';
         memcpy(o, bytes + rec.qual_off + a, kept); o += kept;
         *o++ = '\n';

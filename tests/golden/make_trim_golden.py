@@ -196,6 +196,12 @@ CASES = [
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15,25 --trim-n -m 30 --info-file {info} --rest-file {rest} --wildcard-file {wildcard}"),
     ("synth.fastq", "-b tru=" + TRUSEQ + " -g head=" + TRUSEQ[:20] + " -e 0.2 -O 5 -n 2 --discard-trimmed --info-file {info} --rest-file {rest}"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " --no-trim --info-file {info} --wildcard-file {wildcard} --match-read-wildcards"),
+    # read-name modifiers and the quality cap (modifiers.py:652-720)
+    ("small.fastq", "-a ad=TTAGACATATCTCCGTCG -x pre_{name}_ -y _suf --strip-suffix /1 --strip-suffix _573"),
+    ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15 --length-tag comment= -y :{name} --strip-suffix 7"),
+    ("lengthtag.fastq", "-a tru=" + TRUSEQ + " --trim-n --length-tag length= -x {name}: --info-file {info}"),
+    ("lowqual64.fastq", "-z --quality-base 64 -q 3"),
+    ("synth.fastq", "-b tru=" + TRUSEQ + " -n 2 --mask-adapter -z -y /{name} --length-tag comment="),
     # records beyond the batch pipelines' 736 bases among ordinary ones (the reference has no length limit)
     ("longmix.fastq", "-a " + TRUSEQ),
     ("longmix.fastq", "-b " + TRUSEQ + " -n 2 -e 0.12"),
@@ -297,6 +303,17 @@ def main():
     inputs["synth.fastq"] = synth_fastq(1200, 11).encode()
     inputs["anchor.fastq"] = synth_anchor_fastq(600, 14).encode()
     inputs["longmix.fastq"] = synth_longmix_fastq(150, 19).encode()
+    tagged = synth_fastq(200, 31).split("\n")                    # names with a length field (and one that only looks like it)
+    for i in range(0, len(tagged) - 1, 4):
+        n = len(tagged[i + 1])
+        tagged[i] += " length=%d" % n if i % 12 else " xlength=%d length=" % n
+        if tagged[i + 2] != "+":
+            tagged[i + 2] = "+" + tagged[i][1:]
+    inputs["lengthtag.fastq"] = "\n".join(tagged).encode()
+    low = synth_fastq(120, 32).split("\n")                       # phred+64 qualities with characters below the base
+    for i in range(3, len(low), 4):
+        low[i] = "".join(chr(min(126, ord(c) + 31 - (7 if (k % 5 == 0) else 0) - (40 if k % 11 == 3 else 0))) for k, c in enumerate(low[i]))
+    inputs["lowqual64.fastq"] = "\n".join(low).encode()
     inputs["synth_dos.fastq"] = synth_fastq(100, 12, dos=True).encode()
     inputs["synth_name2.fastq"] = synth_fastq(100, 13, repeat_name=True).encode()
     small = inputs["small.fastq"]
@@ -316,7 +333,10 @@ def main():
             open(in_path, "wb").write(inputs[name])
             aux_paths = {kind: os.path.join(tmp, "%s_%d.txt" % (kind, idx)) for kind in ("info", "rest", "wildcard")
                          if "{%s}" % kind in argstr}
-            params = argstr.format(**aux_paths).split() + ["-se", in_path, "-o", out_path, "--quiet", "--no-default-adapters",
+            filled = argstr
+            for kind, path in aux_paths.items():
+                filled = filled.replace("{%s}" % kind, path)
+            params = filled.split() + ["-se", in_path, "-o", out_path, "--quiet", "--no-default-adapters",
                                                             "--no-cache-adapters"]
             retcode, summary = get_command("trim").execute(params)
             case = dict(input=name, args=argstr, output=None, error=None)
