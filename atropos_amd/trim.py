@@ -122,8 +122,13 @@ class TrimPipeline(object):
     def __init__(self, adapters=(), times=1, action="trim", cut=(), nextseq_trim=None, quality_cutoff=None,
                  quality_base=33, trim_n=False, minimum_length=None, maximum_length=None, max_n=None,
                  discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW", aux=None, length_tag=None,
-                 strip_suffix=(), prefix="", suffix="", zero_cap=False):
+                 strip_suffix=(), prefix="", suffix="", zero_cap=False, outputs=None):
         self.adapters = list(adapters)
+        # --too-short-output / --too-long-output / --untrimmed-output: {"too_short" | "too_long" | "untrimmed": path};
+        # the untrimmed file switches the UntrimmedFilter on like --discard-untrimmed (trim/__init__.py:617-630)
+        self.outputs = dict(outputs) if outputs else {}
+        if "untrimmed" in self.outputs:
+            discard_untrimmed = True
         # read-name modifiers and the quality cap, applied after every trimming step (trim/__init__.py:526-541)
         self.length_tag, self.strip_suffix = length_tag or None, list(strip_suffix or ())
         self.prefix, self.suffix, self.zero_cap = prefix or "", suffix or "", bool(zero_cap)
@@ -351,6 +356,8 @@ class TrimPipeline(object):
         reader = ChunkedFastqReader(path_in, chunk_bytes, be, clock)
         sink = make_sink(path_out, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output)
         aux_files = {kind: open(path, "wb") for kind, path in (self.aux or {}).items()}
+        dest_codes = {name: code for code, name in DEST_NAMES.items()}
+        dest_files = {dest_codes[kind]: open(path, "wb") for kind, path in self.outputs.items()}
         try:
             while True:
                 batch = reader.next_batch()
@@ -365,6 +372,8 @@ class TrimPipeline(object):
                 if aux_files:                                 # host-assembled lines (debugging outputs, not a throughput path)
                     for kind, blob in res.aux_text(tuple(aux_files)).items():
                         aux_files[kind].write(blob)
+                for code, fh in dest_files.items():           # the filtered reads that have a file of their own
+                    fh.write(res.text(code))
                 for name, v in counts.items():
                     totals[name] += v
                 if done:
@@ -372,7 +381,7 @@ class TrimPipeline(object):
         finally:
             reader.close()
             sink.close()
-            for fh in aux_files.values():
+            for fh in list(aux_files.values()) + list(dest_files.values()):
                 fh.close()
             self.stage_seconds = dict(clock.seconds)
         return totals
@@ -755,6 +764,9 @@ def pipeline_from_args(argv):
     ap.add_argument("--strip-suffix", action="append", default=[])
     ap.add_argument("--length-tag", default=None)
     ap.add_argument("-z", "--zero-cap", action="store_true", default=False)
+    ap.add_argument("--too-short-output", default=None)
+    ap.add_argument("--too-long-output", default=None)
+    ap.add_argument("--untrimmed-output", default=None)
     ap.add_argument("--info-file", default=None)
     ap.add_argument("--rest-file", "-r", default=None)
     ap.add_argument("--wildcard-file", default=None)
@@ -821,8 +833,12 @@ def pipeline_from_args(argv):
                   maximum_length=o.maximum_length, max_n=o.max_n, discard_trimmed=o.discard_trimmed,
                   discard_untrimmed=o.discard_untrimmed, op_order=o.op_order)
     aux = {kind: path for kind, path in (("info", o.info_file), ("rest", o.rest_file), ("wildcard", o.wildcard_file)) if path}
+    outputs = {kind: path for kind, path in (("too_short", o.too_short_output), ("too_long", o.too_long_output),
+                                             ("untrimmed", o.untrimmed_output)) if path}
+    if outputs and paired:
+        raise NotImplementedError("--too-short-output / --too-long-output / --untrimmed-output with paired-end input")
     if not paired:
-        return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, length_tag=o.length_tag,
+        return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
                             strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
     if aux or o.length_tag or o.strip_suffix or o.prefix or o.suffix or o.zero_cap:
         raise NotImplementedError("--info-file / --rest-file / --wildcard-file, read-name modifiers and --zero-cap with "

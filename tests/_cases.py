@@ -915,10 +915,18 @@ def check_trim_golden(select=None):
         if case.get("aux"):
             # --info-file / --rest-file / --wildcard-file: the three texts next to the main output
             from atropos_amd.fastq import FastqBatch
-            pipe = pipeline_from_args(case["args"].replace("{info}", "i.txt").replace("{rest}", "r.txt").replace("{wildcard}", "w.txt"))
+            args = case["args"]
+            for kind in case["aux"]:
+                args = args.replace("{%s}" % kind, kind + ".txt")
+            pipe = pipeline_from_args(args)
             batch, _ = FastqBatch.from_bytes(data, final=True)
             res = pipe.run(batch)
-            aux = res.aux_text(tuple(case["aux"]))
+            lines = [k for k in case["aux"] if k in ("info", "rest", "wildcard")]
+            aux = res.aux_text(tuple(lines)) if lines else {}
+            from atropos_amd.trim import DEST_NAMES
+            for code, kind in DEST_NAMES.items():          # --too-short-output etc.: the reads of that destination
+                if kind in case["aux"]:
+                    aux[kind] = res.text(code)
             for kind, want in case["aux"].items():
                 want = base64.b64decode(want)
                 assert aux[kind] == want, (label, kind, _first_diff(aux[kind], want))

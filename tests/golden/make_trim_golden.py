@@ -196,6 +196,9 @@ CASES = [
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15,25 --trim-n -m 30 --info-file {info} --rest-file {rest} --wildcard-file {wildcard}"),
     ("synth.fastq", "-b tru=" + TRUSEQ + " -g head=" + TRUSEQ[:20] + " -e 0.2 -O 5 -n 2 --discard-trimmed --info-file {info} --rest-file {rest}"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " --no-trim --info-file {info} --wildcard-file {wildcard} --match-read-wildcards"),
+    # the filtered reads into files of their own (trim/__init__.py:580-630)
+    ("synth.fastq", "-a tru=" + TRUSEQ + " -q 20 -m 40 -M 95 --too-short-output {too_short} --too-long-output {too_long} --untrimmed-output {untrimmed}"),
+    ("synth.fastq", "-a tru=" + TRUSEQ + " -m 30 --max-n 1 --mask-adapter --too-short-output {too_short} --untrimmed-output {untrimmed}"),
     # read-name modifiers and the quality cap (modifiers.py:652-720)
     ("small.fastq", "-a ad=TTAGACATATCTCCGTCG -x pre_{name}_ -y _suf --strip-suffix /1 --strip-suffix _573"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15 --length-tag comment= -y :{name} --strip-suffix 7"),
@@ -331,7 +334,7 @@ def main():
             in_path = os.path.join(tmp, "in_%d.fastq" % idx)
             out_path = os.path.join(tmp, "out_%d.fastq" % idx)
             open(in_path, "wb").write(inputs[name])
-            aux_paths = {kind: os.path.join(tmp, "%s_%d.txt" % (kind, idx)) for kind in ("info", "rest", "wildcard")
+            aux_paths = {kind: os.path.join(tmp, "%s_%d.txt" % (kind, idx)) for kind in ("info", "rest", "wildcard", "too_short", "too_long", "untrimmed")
                          if "{%s}" % kind in argstr}
             filled = argstr
             for kind, path in aux_paths.items():
