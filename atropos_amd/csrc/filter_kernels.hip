@@ -19,6 +19,9 @@ static BandParams band_params(const atr_aligner *a) {
     return bp;
 }
 
+int launch_linked_band(const void *d_wave, int nad, bool and_mode, const uint4 *packed, const int32_t *lens, long long nreads,
+                       int nchunks, int max_len, const uint4 *front, uint4 *out, FastWork wk, hipStream_t st);   // linked_kernels.hip
+
 static LinkedArgs no_linked_args() {
     LinkedArgs la;
     memset(&la, 0, sizeof(la));
@@ -82,7 +85,13 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
     {   // K4a: banded DP over the band reads
         const BandParams bp = band_params(a);
         const dim3 bgrid((unsigned)std::min<long long>((nreads + 255) / 256, 4096));
-        if (la) {
+        if (la && la->multi) {                                      // a linked set: all adapters' band reads at once
+            if (idx == 0) {
+                const int rc = launch_linked_band(la->multi, count, la->multi_and, packed, lens, nreads, nchunks, max_len, la->front,
+                                                  out, wk, side[0].stream);
+                if (rc != 0) return rc;
+            }
+        } else if (la) {
             if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
             else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
         } else if (planes) {

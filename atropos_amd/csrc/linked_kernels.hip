@@ -281,8 +281,89 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 struct LinkedWaveBlob {
     LocateParams p[LINKED_MAX];
     LinkedPost post[LINKED_MAX];
+    BandParams bp[LINKED_MAX];                      // linked_band_kernel
 };
 constexpr long long LINKED_WAVE_MAX_READS = 262144;
+
+// K4a of a linked set: the band reads of EVERY adapter in one launch (band_kernel<.., LINKED> once per adapter ran
+// four latency-bound launches one after the other on the band stream: 4 x 70 us on the critical path of C4's step for
+// the work of one C2-sized launch).  A wave belongs to one adapter -- the waves are dealt over the adapters' band
+// slots in adapter order -- and reads that adapter's parameters with scalar loads; thresholds of all adapters in LDS.
+template <bool AND_MODE>
+__global__ __launch_bounds__(256) void linked_band_kernel(const LinkedWaveBlob *__restrict__ blob, int nad,
+                                                          const uint4 *__restrict__ packed, const int32_t *__restrict__ lens,
+                                                          long long nreads, int nchunks, int max_len,
+                                                          const uint4 *__restrict__ front, uint4 *__restrict__ out, FastWork wk) {
+    __shared__ int16_t s_thr[LINKED_MAX][ATR_MAX_REF_LEN + 2];
+    __shared__ uint32_t s_stream[4][BAND_STREAM][64];
+    for (int i = threadIdx.x; i < LINKED_MAX * (ATR_MAX_REF_LEN + 2); i += 256)
+        s_thr[i / (ATR_MAX_REF_LEN + 2)][i % (ATR_MAX_REF_LEN + 2)] = blob->p[i / (ATR_MAX_REF_LEN + 2)].thr[i % (ATR_MAX_REF_LEN + 2)];
+    __syncthreads();
+    long long base[LINKED_MAX], total[LINKED_MAX], wfirst[LINKED_MAX + 1], tasks = 0;
+#pragma unroll
+    for (int a = 0; a < LINKED_MAX; ++a) {
+        base[a] = a < nad ? (long long)wk.binbase[a * FILTER_BINS] : 0;
+        total[a] = a < nad ? (long long)wk.binbase[a * FILTER_BINS + BAND_BINS] : 0;
+        tasks += total[a] - base[a];
+    }
+    const int lpw = dp_lanes_per_wave(tasks, (long long)gridDim.x * 4, wk.lpw);
+    wfirst[0] = 0;
+#pragma unroll
+    for (int a = 0; a < LINKED_MAX; ++a) wfirst[a + 1] = wfirst[a] + (total[a] - base[a] + lpw - 1) / lpw;
+    const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
+    for (long long wv = (long long)blockIdx.x * 4 + wave; wv < wfirst[LINKED_MAX]; wv += (long long)gridDim.x * 4) {
+        int a = 0;
+#pragma unroll
+        for (int t = 1; t < LINKED_MAX; ++t) a += wv >= wfirst[t] ? 1 : 0;              // wave-uniform
+        a = rfl(a);
+        const LocateParams &p = blob->p[a];
+        const BandParams &bp = blob->bp[a];
+        const LinkedPost &post = blob->post[a];
+        const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
+        long long b0 = base[0], t0 = total[0], w0 = wfirst[0];
+#pragma unroll
+        for (int t = 1; t < LINKED_MAX; ++t) if (a == t) { b0 = base[t]; t0 = total[t]; w0 = wfirst[t]; }
+        const long long slot = b0 + (wv - w0) * lpw + lane;
+        const bool live = lane < lpw && slot < t0;
+        const uint2 task = live ? wk.order[slot] : make_uint2(0u, 0u);
+        const long long r = (long long)task.x;
+        const uint32_t ww = task.y;
+        const int n = live ? (lens ? lens[r] : max_len) : 0;
+        const bool last = live && window_scan(ww);
+        const bool any_last = wave_max_i32(last ? 1 : 0) != 0, any_rowm = wave_max_i32(live && !last ? 1 : 0) != 0;
+        const int s_lane = (live && !last) ? window_hi(ww) - u.m + u.k - window_lo(ww) : 0;
+        const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
+        const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
+        uint32_t *ns = &s_stream[wave][0][lane];
+        band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
+        uint32_t rec[4] = {0xFFFF0000u, 0u, 0u, 0u};
+        const int16_t *thr = s_thr[a];
+        if (any_rowm) band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, thr, rec);
+        if (any_last) {
+            const int smax_l = min(BAND_W - 1, wave_max_i32(last ? last_band_width(ww) : 0));
+            const int rows_max = wave_max_i32(last ? (last_band_rowm(ww) ? u.m : window_rows(ww)) : 0);
+            const int cap_lo = wave_min_i32(last ? window_rows(ww) - last_band_span(ww) : 0x7fffffff);
+            uint32_t rec_l[4];
+            band_locate_last<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, last, smax_l, rows_max, cap_lo, thr, rec_l);
+            if (last) { rec[0] = rec_l[0]; rec[1] = rec_l[1]; rec[2] = rec_l[2]; rec[3] = rec_l[3]; }
+        }
+        if (live) {
+            linked_finish(rec, (int)(front[r].y >> 16), post.m, post.min_overlap, post.pf_thr, post.accept_full != 0, post.rmp,
+                          post.rmp_ld, post.max_rmp);
+            out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+        }
+    }
+}
+
+// (called by launch_fast_dp, filter_kernels.hip, on the band stream after the fork)
+int launch_linked_band(const void *d_wave, int nad, bool and_mode, const uint4 *packed, const int32_t *lens, long long nreads,
+                       int nchunks, int max_len, const uint4 *front, uint4 *out, FastWork wk, hipStream_t st) {
+    const dim3 grid((unsigned)std::min<long long>((nreads + 255) / 256, 4096)), block(256);
+    const LinkedWaveBlob *blob = (const LinkedWaveBlob *)d_wave;
+    if (and_mode) hipLaunchKernelGGL(linked_band_kernel<true>, grid, block, 0, st, blob, nad, packed, lens, nreads, nchunks, max_len, front, out, wk);
+    else          hipLaunchKernelGGL(linked_band_kernel<false>, grid, block, 0, st, blob, nad, packed, lens, nreads, nchunks, max_len, front, out, wk);
+    return (int)hipGetLastError();
+}
 
 template <int R>
 __global__ __launch_bounds__(64) void linked_wave_kernel(const LinkedWaveBlob *__restrict__ blob, const uint4 *__restrict__ packed,
@@ -378,7 +459,15 @@ int atr_linked_create(const atr_linked_adapter *adapters, int n_adapters, atr_li
         LinkedWaveBlob *hb = new (std::nothrow) LinkedWaveBlob();
         s->d_wave = nullptr;
         if (hb) {
-            for (int a = 0; a < LINKED_MAX; ++a) { hb->p[a] = s->back[a < s->p.n ? a : 0].p; hb->post[a] = s->post[a < s->p.n ? a : 0]; }
+            for (int a = 0; a < LINKED_MAX; ++a) {
+                const atr_aligner &b = s->back[a < s->p.n ? a : 0];
+                hb->p[a] = b.p;
+                hb->post[a] = s->post[a < s->p.n ? a : 0];
+                memset(&hb->bp[a], 0, sizeof(BandParams));
+                for (int i = 0; i < b.p.m && i < FILTER_MAX_M; ++i) hb->bp[a].rrep[i] = (uint32_t)(b.codes[i] & 15u) * 0x11111111u;
+                hb->bp[a].and_mode = (b.wildcard_ref || b.wildcard_query) ? 1 : 0;
+                hb->bp[a].noindel = b.indel_cost > b.p.k ? 1 : 0;
+            }
             if (hipMalloc(&s->d_wave, sizeof(LinkedWaveBlob)) == hipSuccess) {
                 if (hipMemcpy(s->d_wave, hb, sizeof(LinkedWaveBlob), hipMemcpyHostToDevice) != hipSuccess) {
                     (void)hipFree(s->d_wave);
@@ -465,6 +554,8 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
         la.bin0 = a * FILTER_BINS;
         la.front = front;
         la.post = s->post[a];
+        la.multi = s->d_wave;                                      // every adapter's band reads in one launch (idx 0)
+        la.multi_and = s->p.and_mode != 0;
         const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st, false);
         if (rc != 0) return hip_fail((hipError_t)rc, "linked band / window launch");
     }

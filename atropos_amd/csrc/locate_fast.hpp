@@ -100,6 +100,8 @@ struct LinkedArgs {
     int bin0;
     const uint4 *front;
     LinkedPost post;
+    const void *multi;                               // host side only: the set's device blob for linked_band_kernel (or null:
+    bool multi_and;                                  //   one band_kernel launch per adapter), its compare mode
 };
 
 // blocks a batch of ntiles tiles keeps busy with four waves each (K1 / K3 of a short batch are launched with these)
