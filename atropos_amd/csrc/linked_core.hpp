@@ -64,6 +64,8 @@ struct LinkedParams {
     // every prefix such a read can offer exceeds their k; literal comparison only) -- linked_host.hpp.  A read
     // with a literal occurrence whose mask covers all the others is through with the 5' stage.
     uint32_t excl[LINKED_MAX];
+    int32_t pex_shared, reserved[3];                // every 5' part is cut into the same pieces (count, offsets, k): the read's
+                                                    // windows are cut once for all adapters (front_pex_candidates_shared)
     FrontParams f[LINKED_MAX];
     BackParams b[LINKED_MAX];
 };
@@ -169,6 +171,33 @@ ATR_DEV bool front_pex_candidate(const uint32_t *pex_code, const uint32_t *pex_m
         }
     }
     return best == 0u;
+}
+
+// The same test for all adapters of a set whose pieces sit at the same offsets (equal m and k): a window of the read
+// is cut once and compared with every adapter's piece.  ok[a] = some piece of adapter a occurs.
+template <bool AND_MODE>
+ATR_DEV void front_pex_candidates_shared(const FrontParams *f, int nad, const uint32_t w[4], bool ok[LINKED_MAX]) {
+    uint32_t best[LINKED_MAX];
+#pragma unroll
+    for (int a = 0; a < LINKED_MAX; ++a) best[a] = ~0u;
+    const int npieces = f[0].npieces, k = f[0].k;
+    for (int p = 0; p < npieces; ++p) {
+        const int off = f[0].pex_off[p];
+        for (int d = -k; d <= k; ++d) {
+            const int t = off + d;
+            if (t < 0 || t > 31) continue;
+            const uint32_t win = chunk_window(w, t);
+#pragma unroll
+            for (int a = 0; a < LINKED_MAX; ++a) {
+                if (a >= nad) continue;
+                const uint32_t code = f[a].pex_code[p], mask = f[a].pex_mask[p];
+                const uint32_t bad = AND_MODE ? (~nibble_any(win & code)) & (mask & 0x88888888u) : (win ^ code) & mask;
+                best[a] = atr_minu(best[a], bad);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < LINKED_MAX; ++a) ok[a] = a < nad && best[a] == 0u;
 }
 
 // Result of the 5' stage of one read in one word (anchored: refstart = querystart = 0, refstop = m):

@@ -151,6 +151,10 @@ inline int linked_fill(atr_linked_set *s, const atr_linked_adapter *ad, int n) {
         s->rmp.front[i] = ad[i].d_front_rmp; s->rmp.front_max[i] = ad[i].front_max_rmp; s->rmp.front_ld[i] = ad[i].front_rmp_ld;
         s->rmp.back[i] = ad[i].d_back_rmp; s->rmp.back_max[i] = ad[i].back_max_rmp; s->rmp.back_ld[i] = ad[i].back_rmp_ld;
     }
+    P.pex_shared = 1;
+    for (int i = 1; i < n; ++i)
+        if (P.f[i].npieces != P.f[0].npieces || P.f[i].k != P.f[0].k ||
+            memcmp(P.f[i].pex_off, P.f[0].pex_off, sizeof(P.f[0].pex_off)) != 0) P.pex_shared = 0;
     // excl (linked_core.hpp): b cannot match a read that starts with a verbatim when the unit-cost edit distance --
     // a lower bound of the aligner's cost -- between b and every read prefix of m_b - k_b .. m_b + k_b bases exceeds
     // k_b.  Prefixes up to m_a bases are prefixes of a; a longer one is a plus x unknown bases: dist(b, a + x) >=

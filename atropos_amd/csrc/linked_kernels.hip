@@ -151,10 +151,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             const long long tile = tile_first + 4 * (cell >> 6);
             const uint4 c0v = packed[(size_t)tile * nchunks * 64 + (cell & 63)];
             const uint32_t w0[4] = {c0v.x, c0v.y, c0v.z, c0v.w};
+            bool pex_ok[LINKED_MAX];
+            const bool shared = rfl(S.p.pex_shared) != 0;
+            if (shared) front_pex_candidates_shared<AND_MODE>(S.p.f, nad, w0, pex_ok);
             for (int a = 0; a < nad; ++a) {                                  // wave-uniform
                 const FrontParams &fp = S.p.f[a];
-                const bool cand = ((open >> a) & 1u) != 0u &&
-                                  front_pex_candidate<AND_MODE>(fp.pex_code, fp.pex_mask, fp.pex_off, rfl(fp.npieces), rfl(fp.k), w0);
+                bool hit;
+                if (shared) {
+                    hit = pex_ok[0];
+#pragma unroll
+                    for (int t = 1; t < LINKED_MAX; ++t) if (a == t) hit = pex_ok[t];
+                } else {
+                    hit = front_pex_candidate<AND_MODE>(fp.pex_code, fp.pex_mask, fp.pex_off, rfl(fp.npieces), rfl(fp.k), w0);
+                }
+                const bool cand = ((open >> a) & 1u) != 0u && hit;
                 const unsigned long long votes = __ballot(cand);
                 if (cand) queue[ntasks + __popcll(votes & ((1ull << lane) - 1ull))] = (uint16_t)((cell << 6) | a);
                 ntasks += (int)__popcll(votes);
