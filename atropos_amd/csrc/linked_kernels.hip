@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                                             const int32_t *__restrict__ lens, long long nreads,
                                                             int nchunks, int max_len, uint16_t *__restrict__ which_out,
                                                             uint4 *__restrict__ front_out, uint4 *__restrict__ back_out,
-                                                            FastWork wk) {
+                                                            FastWork wk, int lists) {
     __shared__ __attribute__((aligned(16))) LinkedBlob S;
     __shared__ uint32_t s_hist[LINKED_MAX * FILTER_BINS];
     __shared__ uint32_t s_stream[4][FRONT_STREAM][64];             // per wave: the staged reads of the 5' banded DP
@@ -89,8 +89,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     __shared__ uint32_t s_counts[4][LINKED_ROUND * 16];            //                                  number of matching 5' parts (a byte each)
     __shared__ uint16_t s_queue[4][LINKED_TASKS];
     __shared__ uint16_t s_list[4][LINKED_ROUND * 64];               // per wave: the round's reads that have a 5' match
+    __shared__ uint32_t s_lcur;                                     // lists: entries of the block's list of unresolved reads
     for (int i = threadIdx.x; i < (int)(sizeof(LinkedBlob) / 4); i += 256) ((uint32_t *)&S)[i] = ((const uint32_t *)blob)[i];
     for (int i = threadIdx.x; i < LINKED_MAX * FILTER_BINS; i += 256) s_hist[i] = 0;
+    if (threadIdx.x == 0) s_lcur = 0;
     __syncthreads();
 
     const int nad = rfl(S.p.n), ngroups = rfl(S.p.ngroups);
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 if (!has) {
                     uint32_t none[4];
                     rec_none(none);
-                    wk.win[r] = 0u;
+                    if (!lists) wk.win[r] = 0u;
                     back_out[r] = make_uint4(none[0], none[1], none[2], none[3]);
                 }
             }
@@ -274,15 +276,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                   S.rmp.back_ld[which], S.rmp.back_max[which]);
             }
             if (live) {
-                wk.win[r] = ww;
+                if (!lists) wk.win[r] = ww;
                 if (!window_valid(ww)) back_out[r] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
                 else atomicAdd(&s_hist[linked_bin(ww, which, mb, !RAGGED)], 1u);
+            }
+            if (lists) {
+                // long batches: the unresolved reads go into the block's list (at its first read in `tmp`) instead of a
+                // window word per read -- the scatter pass reads 8 bytes per unresolved read, not 4 per read
+                const bool open = live && window_valid(ww);
+                const unsigned long long om = __ballot(open);
+                if (om != 0ull) {                                              // wave-uniform
+                    uint32_t at = 0u;
+                    if (lane == 0) at = atomicAdd(&s_lcur, (uint32_t)__popcll(om));
+                    at = (uint32_t)rfl((int)at);
+                    if (open) wk.tmp[t0 * 64 + at + __popcll(om & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)r, ww);
+                }
             }
         }
     }
     __syncthreads();
     const int nbins = nad * FILTER_BINS;
     for (int b = threadIdx.x; b < nbins; b += 256) wk.counts[(size_t)blockIdx.x * nbins + b] = s_hist[b];
+    if (threadIdx.x == 0) wk.lcount[blockIdx.x] = s_lcur;
 }
 
 // Short batches: the 3' part of every read the pre-pass left open on a wavefront of its own (wave_sweep.hpp) -- the
@@ -420,7 +435,7 @@ __global__ __launch_bounds__(64) void linked_wave_kernel(const LinkedWaveBlob *_
 struct LinkedLens { int m[LINKED_MAX]; };
 
 __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, const LinkedLens ms, int by_rows,
-                                                             const uint16_t *__restrict__ which_out, FastWork wk) {
+                                                             const uint16_t *__restrict__ which_out, FastWork wk, int lists) {
     __shared__ uint32_t s_cur[LINKED_MAX * FILTER_BINS];
     for (int b = threadIdx.x; b < wk.nbins; b += 256)
         s_cur[b] = fast_slot0(wk, b);
@@ -428,6 +443,16 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
     block_tiles(ntiles, t0, t1, wk.nused);
+    if (lists) {                                                   // the block's list of (read, window word)
+        const uint2 *list = wk.tmp + t0 * 64;
+        const uint32_t count = wk.lcount[blockIdx.x];
+        for (uint32_t i = threadIdx.x; i < count; i += 256) {
+            const uint2 e = list[i];
+            const int which = (int)(which_out[e.x] & 0xFFu);
+            wk.order[atomicAdd(&s_cur[linked_bin(e.y, which, ms.m[which], by_rows != 0)], 1u)] = e;
+        }
+        return;
+    }
     for (long long r = t0 * 64 + threadIdx.x; r < min(nreads, t1 * 64); r += 256) {
         const uint32_t ww = wk.win[r];
         if (window_valid(ww)) {
@@ -439,10 +464,10 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
 
 template <bool WIDE, bool RAGGED>
 static void launch_l1(bool and_mode, const LinkedBlob *blob, const uint4 *packed, const int32_t *lens, long long nreads,
-                      int nchunks, int max_len, uint16_t *which, uint4 *front, uint4 *back, FastWork wk, hipStream_t st) {
+                      int nchunks, int max_len, uint16_t *which, uint4 *front, uint4 *back, FastWork wk, int lists, hipStream_t st) {
     const dim3 grid(wk.nused), block(256);
-    if (and_mode) hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, true>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk);
-    else          hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, false>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk);
+    if (and_mode) hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, true>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk, lists);
+    else          hipLaunchKernelGGL((linked_filter_kernel<WIDE, RAGGED, false>), grid, block, 0, st, blob, packed, lens, nreads, nchunks, max_len, which, front, back, wk, lists);
 }
 
 }  // namespace atr
@@ -521,15 +546,17 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const LinkedBlob *blob = (const LinkedBlob *)s->d_params;
     const bool ragged = d_lens != nullptr, and_mode = s->p.and_mode != 0;
+    // (the wavefront-per-read finish of short batches reads a window word per read; long batches keep per-block lists)
+    const int lists = nreads > LINKED_WAVE_MAX_READS ? 1 : 0;
     uint16_t *which = (uint16_t *)d_which;
     uint4 *front = (uint4 *)d_front, *back = (uint4 *)d_back;
     const uint4 *packed = (const uint4 *)d_packed;
     if (s->p.wide) {
-        if (ragged) launch_l1<true, true>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
-        else        launch_l1<true, false>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
+        if (ragged) launch_l1<true, true>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, lists, st);
+        else        launch_l1<true, false>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, lists, st);
     } else {
-        if (ragged) launch_l1<false, true>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
-        else        launch_l1<false, false>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, st);
+        if (ragged) launch_l1<false, true>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, lists, st);
+        else        launch_l1<false, false>(and_mode, blob, packed, d_lens, nreads, nchunks, max_len, which, front, back, wk, lists, st);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "linked_filter_kernel launch");
@@ -556,7 +583,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     LinkedLens ms;
     for (int a = 0; a < LINKED_MAX; ++a) ms.m[a] = a < s->p.n ? s->p.b[a].m : 0;
     hipLaunchKernelGGL(linked_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, (long long)nreads, ms, ragged ? 0 : 1,
-                       (const uint16_t *)which, wk);
+                       (const uint16_t *)which, wk, lists);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "linked scatter launch");
     for (int a = 0; a < s->p.n; ++a) {
