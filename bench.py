@@ -131,6 +131,43 @@ def timed_cpu(fn, units, what, cores, target_s=8.0):
                       "reference's Cython loop)" % (what, reps, cores, dt)}
 
 
+def _c2_two_streams(self, steps=40):
+    """Consecutive batches issued on two streams, a backend (workspace) each: the DP phase of batch i runs under the
+    pre-pass of batch i + 1 (tools/micro/two_streams.py).  What a double-buffered caller gets; NOT the bench's `value`,
+    which is the plain call issued back to back on one stream."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    prev = _lib.get_backend()
+    als, batches = [], []
+    try:
+        for _ in range(2):
+            _lib.set_backend(_lib.HipBackend(prev.device.index), _test_double=True)
+            al = Aligner(*self.al_args)
+            als.append(al)
+            batches.append(al.pack(self.ascii, layout=self.batch.layout) if self.ascii is not None else self.batch)
+    finally:
+        _lib.set_backend(prev, _test_double=True)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def run(nstreams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        keep = []
+        for i in range(steps):
+            with torch.cuda.stream(streams[i % nstreams]):
+                keep.append(als[i % nstreams].locate_batch(batches[i % nstreams], self.filtered).records)
+            del keep[:-4]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    res = {}
+    for n in (1, 2):
+        run(n)
+        res["streams_%d_reads_per_s" % n] = self.n / min(run(n) for _ in range(3))
+    res["note"] = "steps alternate between two streams with a workspace each; not the line's value"
+    return res
+
+
 class C2(object):
     name = "C2"
     default_units = 10_000_000
@@ -144,7 +181,8 @@ class C2(object):
         from atropos_amd.align import Aligner
         self.args, self.n = args, args.reads
         self.w = w = synth.workload("C2", rank * self.n, self.n, device=dev)
-        self.al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+        self.al_args = (w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+        self.al = Aligner(*self.al_args)
         self.ascii = w["reads"]
         self.batch = self.al.pack(self.ascii, layout="tile64" if args.full_sweep else "auto")
         self.sample = self.ascii[:min(self.n, 2_000_000)].cpu().numpy() if rank == 0 else None
@@ -183,6 +221,8 @@ class C2(object):
                                    w["indel_cost"], cores)
         return timed_cpu(fn, len(sample), "first %d reads of the same C2 batch" % len(sample), cores)
 
+    two_streams = _c2_two_streams
+
     def secondary(self, kernel_ms):
         """The other figures SURVEY 8(d) lists, measured outside the timed region."""
         out = {"cell_updates_per_s_full_matrix": self.n * 150 * 35 / (kernel_ms * 1e-3)}
@@ -209,6 +249,10 @@ class C2(object):
             ms = run(lambda: self.al.locate_batch(rb, self.filtered))
             out["ragged_batch_reads_per_s"] = self.n / (ms * 1e-3)
         out["pcie_inclusive_bound_reads_per_s"] = PCIE_GBS * 1e9 / (150 + 16)    # ASCII in + record out over PCIe Gen5 x16
+        try:
+            out["two_streams"] = self.two_streams()
+        except Exception as exc:                                              # noqa: BLE001 -- a side figure
+            out["two_streams"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         # the small-batch regime of the drop-in path (tools/bench_small.py): the unchanged trim command hands over
         # <= 1000 reads per call (/root/reference/atropos/commands/base.py:179), the per-read API a batch of one
         try:
