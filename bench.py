@@ -245,9 +245,11 @@ class C2(object):
             from atropos_amd.batch import ReadBatch
             g = torch.Generator(device=self.ascii.device).manual_seed(5)
             lens = torch.randint(100, 151, (self.n,), generator=g, device=self.ascii.device, dtype=torch.int32)
-            rb = ReadBatch.from_ascii(self.ascii, lens, 150, self.al.table_kind, self.al._table)
+            planes = self.filtered and self.al._wants_planes("auto", self.n, 150, ragged=True)     # (the two-pass pre-pass)
+            rb = ReadBatch.from_ascii(self.ascii, lens, 150, self.al.table_kind, self.al._table, planes=planes)
             ms = run(lambda: self.al.locate_batch(rb, self.filtered))
             out["ragged_batch_reads_per_s"] = self.n / (ms * 1e-3)
+            out["ragged_batch_layout"] = rb.layout
         out["pcie_inclusive_bound_reads_per_s"] = PCIE_GBS * 1e9 / (150 + 16)    # ASCII in + record out over PCIe Gen5 x16
         try:
             out["two_streams"] = self.two_streams()
