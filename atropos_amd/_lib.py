@@ -131,6 +131,10 @@ PROTOTYPES = {
     "atr_locate_pairs_path_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                               C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                               C.c_int, C.c_void_p, C.c_void_p]),
+    "atr_locate_pairs_long_work_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "atr_locate_pairs_long_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
     "atr_locate_pair_one": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_pairs_full_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
@@ -580,6 +584,20 @@ class HipBackend(object):
                 _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
                 query_max_len, npairs, e, flags, int(wildcard_ref), int(wildcard_query), min_overlap, indel_cost,
                 _ptr(need), PAIRS_PATHS[path], _ptr(out), self._stream()), "atr_locate_pairs_path_batch")
+        return out
+
+    def locate_pairs_long_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                                query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+        """Pairs with a side beyond PAIRS_MAX_LEN (atr_locate_pairs_long_batch: 64-bit cells, the DP column in a
+        workspace allocated here).  The caller keeps npairs * ref_max_len small (PairAligner chunks)."""
+        out = self.empty((npairs, 8), torch.int16)
+        if npairs:
+            work = self.empty((max(self.lib.atr_locate_pairs_long_work_bytes(npairs, ref_max_len), 16),), torch.uint8)
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_locate_pairs_long_batch(
+                    _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
+                    query_max_len, npairs, e, flags, int(wildcard_ref), int(wildcard_query), min_overlap, indel_cost,
+                    _ptr(out), _ptr(work), self._stream()), "atr_locate_pairs_long_batch")
         return out
 
     def locate_pairs_full_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,

@@ -77,9 +77,10 @@ class Aligner(object):
             # A reference of 129 .. 320 bases has no aligner handle (the column kernels hold the rows in
             # registers): locate_batch runs the per-pair aligner with this reference on every pair
             # (PairAligner, register strips of 128 rows) -- the same Aligner.locate, batch-of-n.
-            if len(ref_bytes) > _lib.PAIRS_MAX_LEN:
+            # (beyond 320 bases: the per-pair aligner's long path, 64-bit cells with the column in a workspace)
+            if len(ref_bytes) > _lib.MAX_LONG_READ_LEN:
                 raise _lib.AtroposHipError("Aligner: references longer than %d bases are outside the device envelope"
-                                           % _lib.PAIRS_MAX_LEN)
+                                           % _lib.MAX_LONG_READ_LEN)
             self._table_kind, self._table = self._pair_aligner()._table_kinds()[1], None
             return
         self._handle = be.aligner_create(ref_bytes, self.max_error_rate, self.flags, self.wildcard_ref,
@@ -102,12 +103,13 @@ class Aligner(object):
                                           "ASCII matrix, not as a packed batch (the device-resident pipelines "
                                           "stop at %d-base adapters)" % (_lib.MAX_REF_LEN, _lib.MAX_REF_LEN))
         ref_row = torch.frombuffer(bytearray(self._ref_bytes), dtype=torch.uint8).to(be.device)
+        step = min(self.LONG_CHUNK, max(64, (1 << 28) // len(self._ref_bytes)))     # (the reference is laid out per read)
         if isinstance(reads, (list, tuple)):
             n = len(reads)
-            chunks = ((reads[i:i + self.LONG_CHUNK]) for i in range(0, n, self.LONG_CHUNK))
+            chunks = ((reads[i:i + step]) for i in range(0, n, step))
         else:
             n = reads.shape[0]
-            chunks = ((reads[i:i + self.LONG_CHUNK]) for i in range(0, n, self.LONG_CHUNK))
+            chunks = ((reads[i:i + step]) for i in range(0, n, step))
         recs = []
         for chunk in chunks:
             count = len(chunk) if isinstance(chunk, (list, tuple)) else chunk.shape[0]
@@ -460,9 +462,9 @@ class PairAligner(object):
         else:
             ascii_t = seqs.to(be.device)
             lens_t, max_len = None, ascii_t.shape[1]
-        if max_len > _lib.PAIRS_MAX_LEN:
+        if max_len > _lib.MAX_LONG_READ_LEN:
             raise _lib.AtroposHipError("PairAligner: sequences longer than %d bases are outside the device envelope"
-                                       % _lib.PAIRS_MAX_LEN)
+                                       % _lib.MAX_LONG_READ_LEN)
         if literal or self.revcomp_ref:
             # the literal compare works on 4-bit codes: every base needs one (and a complement)
             if case_table is not None:
@@ -508,10 +510,36 @@ class PairAligner(object):
             need = need.to(device=rb.packed.device, dtype=torch.int32).contiguous()
             if need.numel() != rb.nreads:
                 raise ValueError("need: one entry per pair")
+        longest = max(rb.max_len, qb.max_len)
+        if longest > _lib.PAIRS_MAX_LEN or (longest > 255 and not (self.flags & STOP_WITHIN_SEQ2)):
+            return LocateResult(self._locate_long_pairs(be, rb, qb))
         rec = be.locate_pairs_batch(rb.packed, rb.lens, rb.max_len, self.revcomp_ref, qb.packed, qb.lens, qb.max_len,
                                     rb.nreads, self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query,
                                     self.min_overlap, self.indel_cost, need=need, path=path)
         return LocateResult(rec)
+
+    LONG_WORK_BYTES = 1 << 29                       # workspace of one call of the long-pair kernel (the DP columns)
+
+    def _locate_long_pairs(self, be, rb, qb):
+        """A side beyond PAIRS_MAX_LEN (the reference has no length limit, _align.pyx:266-291): 64-bit cells with the
+        DP column in a workspace (atr_locate_pairs_long_batch), whole tiles of 64 pairs at a time so that the
+        workspace stays bounded.  `need` does not apply (every pair gets the reference's record)."""
+        n = rb.nreads
+        per_pair = 9 * (rb.max_len + 1)
+        step = max(64, (self.LONG_WORK_BYTES // per_pair) // 64 * 64)
+        rch, qch = (rb.max_len + 31) // 32, (qb.max_len + 31) // 32
+        out = []
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            rp = rb.packed[(lo // 64) * rch * 1024:]            # a tile of 64 pairs: nchunks x 64 x 16 bytes
+            qp = qb.packed[(lo // 64) * qch * 1024:]
+            out.append(be.locate_pairs_long_batch(
+                rp, None if rb.lens is None else rb.lens[lo:hi].contiguous(), rb.max_len, self.revcomp_ref,
+                qp, None if qb.lens is None else qb.lens[lo:hi].contiguous(), qb.max_len, hi - lo,
+                self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query, self.min_overlap, self.indel_cost))
+        if not out:
+            return be.empty((0, 8), torch.int16)
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def locate(self, reference, query, unknown_queries_ok=False):
         be = _lib.get_backend()

@@ -422,6 +422,16 @@ int atr_locate_pairs_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_len
                            int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
                            int min_overlap, int indel_cost, atr_result *d_out, void *stream);
 
+/* The same for pairs with a side of more than ATR_PAIRS_MAX_LEN bases (up to ATR_MAX_LONG_READ_LEN; the reference has
+ * no limit, _align.pyx:266-291): 64-bit cells, the DP column in d_work (atr_locate_pairs_long_work_bytes(npairs,
+ * ref_max_len) bytes), one pair per lane over the whole matrix -- a fallback, not a throughput path.  Any lengths
+ * are accepted.  ATR_ERR_UNSUPPORTED: max_error_rate * ref_max_len > 32 000. */
+size_t atr_locate_pairs_long_work_bytes(int64_t npairs, int ref_max_len);
+int atr_locate_pairs_long_batch(const uint8_t *d_ref_packed, const int32_t *d_ref_lens, int ref_max_len, int revcomp_ref,
+                                const uint8_t *d_query_packed, const int32_t *d_query_lens, int query_max_len,
+                                int64_t npairs, double max_error_rate, int flags, int wildcard_ref, int wildcard_query,
+                                int min_overlap, int indel_cost, atr_result *d_out, void *d_work, void *stream);
+
 /* The same with a per-pair lower bound on the alignment's matches (d_need, device, may be NULL = 1 everywhere):
  * MergeOverlapping only looks at an alignment when `matches >= min_overlap` (modifiers.py:896-897, min_overlap
  * from :870-874), so a pair whose reference alignment has fewer matches than d_need[p] may be reported as

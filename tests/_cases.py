@@ -1629,3 +1629,85 @@ def check_long_reads(Aligner, oracle, unsupported_exc, seed, rounds, count=24, m
         q = reads[0]
         assert al.locate(q) == got[0]
     return total
+
+
+def long_pair_case(c):
+    """Reference and query of a tests/golden/long_pairs.json.gz case, rebuilt from its seed."""
+    rng = random.Random(c["seed"])
+    ref = rseq(rng, c["m"], c["alpha"])
+    kind, n = c["kind"], c["n"]
+    if kind == 0:
+        q = (rseq(rng, c["a"]) + mutate(rng, ref, c["rate"]) + rseq(rng, n))[:n]
+    elif kind == 1:
+        q = mutate(rng, ref[c["a"]:], c["rate"])[:n] + rseq(rng, c["b"])
+    elif kind == 2:
+        q = (rseq(rng, n) + mutate(rng, ref, c["rate"])[:max(1, c["a"])])[-n:] if n else ""
+    else:
+        q = rseq(rng, n)
+    return ref, q
+
+
+def check_golden_long_pairs(Aligner, PairAligner, unsupported_exc):
+    """The reference's answers for references of 321 .. 1 500 bases (long_pairs.json.gz) through Aligner (one long
+    reference, a batch of reads) and through PairAligner (a reference per pair)."""
+    cases = load_golden("long_pairs.json.gz")
+    checked = 0
+    by_setting = {}
+    for c in cases:
+        by_setting.setdefault((c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"]), []).append(c)
+    for (e, flags, wr, wq, mo, ic), group in by_setting.items():
+        pairs = [long_pair_case(c) for c in group]
+        got = PairAligner(e, flags, wr, wq, mo, ic).locate_batch([p[0] for p in pairs], [p[1] for p in pairs]).tuples()
+        for c, g in zip(group, got):
+            assert g == tup(c["out"]), (c, g)
+            checked += 1
+        ref, q = pairs[0]
+        assert Aligner(ref, e, flags, wr, wq, mo, ic).locate(q) == tup(group[0]["out"])
+    return checked
+
+
+def check_long_pairs(Aligner, PairAligner, oracle, seed, rounds):
+    """Pairs with a side beyond 320 bases (atr_locate_pairs_long_batch) and Aligner with a long reference against
+    the oracle: all flag sets, indel costs, wildcard modes, ragged lengths on both sides."""
+    rng = random.Random(seed)
+    total = 0
+    for _ in range(rounds):
+        flags = rng.choice([15, 9, 14, 11, 8, 2, 0, 5, 10, 6, 3, 12, 7, 13, 1, 4])
+        e = rng.choice([0, 0.05, 0.1, 0.2, 0.3])
+        ic, mo = rng.choice([1, 1, 2, 100000]), rng.choice([1, 3, 10])
+        wr, wq = rng.random() < 0.2, rng.random() < 0.2
+        refs, qs = [], []
+        for _ in range(12):
+            m = rng.choice([rng.randint(321, 700), rng.randint(1, 320), rng.randint(256, 400)])
+            n = rng.choice([rng.randint(321, 900), rng.randint(0, 320), rng.randint(600, 1500)])
+            ref = rseq(rng, m, "ACGT" if rng.random() < 0.8 else "ACGTN")
+            w = rng.random()
+            if w < 0.4:
+                q = (rseq(rng, rng.randint(0, 300)) + mutate(rng, ref, rng.choice([0, 0.03, 0.1])) + rseq(rng, n))[:n]
+            elif w < 0.6:
+                q = mutate(rng, ref[rng.randint(0, m - 1):], 0.05)[:n] + rseq(rng, rng.randint(0, 50))
+            elif w < 0.8:
+                q = (rseq(rng, n) + mutate(rng, ref, 0.05)[:rng.randint(1, m)])[-n:] if n else ""
+            else:
+                q = rseq(rng, n)
+            refs.append(ref)
+            qs.append(q)
+        if max(max(map(len, refs)), max(map(len, qs))) <= 320:
+            continue
+        got = PairAligner(e, flags, wr, wq, mo, ic).locate_batch(refs, qs).tuples()
+        for r, q, g in zip(refs, qs, got):
+            assert g == oracle.locate(r, q, e, flags, wr, wq, mo, ic), (len(r), len(q), e, flags, wr, wq, mo, ic, g)
+            total += 1
+    for _ in range(max(1, rounds // 5)):
+        m = rng.randint(321, 1200)
+        ref = rseq(rng, m)
+        flags = rng.choice([14, 15, 11, 10])
+        al = Aligner(ref, 0.1, flags, False, False, 3, 1)
+        reads = [(rseq(rng, rng.randint(0, 100)) + mutate(rng, ref, 0.05)[rng.randint(0, m // 2):rng.randint(m // 2, m)]
+                  + rseq(rng, 100))[:rng.randint(50, 700)] for _ in range(10)]
+        got = al.locate_batch(reads).tuples()
+        for q, g in zip(reads, got):
+            assert g == oracle.locate(ref, q, 0.1, flags, False, False, 3, 1), (m, len(q), g)
+            total += 1
+        assert al.locate(reads[0]) == got[0]
+    return total

@@ -290,6 +290,15 @@ class EmuBackend(object):
             indel_cost, _ptr(need), _ptr(out)), "emu_locate_pairs_need_batch")
         return out
 
+    def locate_pairs_long_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
+                                query_max_len, npairs, e, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost):
+        out = torch.zeros((npairs, 8), dtype=torch.int16)
+        _check(self.lib.emu_locate_pairs_long_batch(
+            _ptr(ref_packed), _ptr(ref_lens), ref_max_len, int(revcomp_ref), _ptr(query_packed), _ptr(query_lens),
+            query_max_len, C.c_int64(npairs), C.c_double(e), flags, int(wildcard_ref), int(wildcard_query), min_overlap,
+            indel_cost, _ptr(out)), "atr_locate_pairs_long_batch")
+        return out
+
     def locate_pairs_full_batch(self, ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,
                                 query_max_len, npairs, e, flags, min_overlap, indel_cost):
         return self.locate_pairs_batch(ref_packed, ref_lens, ref_max_len, revcomp_ref, query_packed, query_lens,

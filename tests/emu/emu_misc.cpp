@@ -10,6 +10,7 @@
 #include "misc_core.hpp"
 #include "pairs_core.hpp"
 #include "pairs_fast_core.hpp"
+#include "pairs_long_core.hpp"
 #include "wave_core.hpp"
 
 using namespace atr;
@@ -379,6 +380,30 @@ int emu_locate_pairs_need_batch(const uint32_t *ref_packed, const int32_t *ref_l
                                 const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
                                 double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
                                 const int32_t *need, uint32_t *out);
+
+// atr_locate_pairs_long_batch: pairs_long_core.hpp, one pair after the other
+int emu_locate_pairs_long_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
+                                const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,
+                                double e, int flags, int wildcard_ref, int wildcard_query, int min_overlap, int indel_cost,
+                                uint32_t *out) {
+    if (npairs < 0 || flags < 0 || flags > 15 || min_overlap < 1 || indel_cost < 1) return ATR_ERR_INVALID;
+    if (ref_max_len > ATR_MAX_LONG_READ_LEN || qry_max_len > ATR_MAX_LONG_READ_LEN) return ATR_ERR_UNSUPPORTED;
+    if (!(e >= 0.0) || e * (double)ref_max_len > (double)atr::PAIRS_LONG_MAX_K) return ATR_ERR_UNSUPPORTED;
+    atr::PairLongParams p;
+    p.e = e; p.flags = flags; p.min_overlap = min_overlap; p.indel_cost = indel_cost;
+    p.and_mode = (wildcard_ref || wildcard_query) ? 1 : 0;
+    const int rch = (ref_max_len + 31) / 32, qch = (qry_max_len + 31) / 32;
+    std::vector<uint64_t> col((size_t)ref_max_len + 1);
+    std::vector<uint8_t> refc((size_t)ref_max_len + 1);
+    for (int64_t r = 0; r < npairs; ++r) {
+        const int m = ref_lens ? ref_lens[r] : ref_max_len, n = qry_lens ? qry_lens[r] : qry_max_len;
+        const uint32_t *rp = ref_packed + ((size_t)(r >> 6) * rch * 64 + (r & 63)) * 4;
+        const uint32_t *qp = qry_packed + ((size_t)(r >> 6) * qch * 64 + (r & 63)) * 4;
+        if (p.and_mode) atr::locate_pair_long<true>(col.data(), 1, refc.data(), 1, rp, m, revcomp != 0, qp, n, p, out + 4 * r);
+        else atr::locate_pair_long<false>(col.data(), 1, refc.data(), 1, rp, m, revcomp != 0, qp, n, p, out + 4 * r);
+    }
+    return ATR_OK;
+}
 
 int emu_locate_pairs_batch(const uint32_t *ref_packed, const int32_t *ref_lens, int ref_max_len, int revcomp,
                            const uint32_t *qry_packed, const int32_t *qry_lens, int qry_max_len, int64_t npairs,

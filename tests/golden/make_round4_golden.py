@@ -11,6 +11,9 @@ Fixtures (inputs are generated here; expected values are what the reference retu
                           long-read sweep moves its origin base (multiples of 256), at both read ends and twice;
                           all flag sets, indel costs, wildcard modes.  A read is stored as (seed, length, planted
                           pieces) and rebuilt by tests/_cases.long_read_case(), so that the file stays small.
+    long_pairs.json.gz    Aligner.locate with references of 321 .. 1 500 bases (beyond the per-pair aligner's packed
+                          cell word): overlaps at either end, inside, absent; all flag sets.  Stored as seeds
+                          (tests/_cases.long_pair_case()).
 While doing so it pins the oracle's C restatement on every case, or aborts.
 """
 import os
@@ -69,6 +72,26 @@ def main():
     far = sum(1 for c in cases if c["out"] is not None and c["out"][3] > 767)
     print("%d cases, %d matched, %d with a query stop beyond column 767" % (len(cases), sum(c["out"] is not None for c in cases), far))
     dump("long_reads.json.gz", cases)
+
+    # long_pairs.json.gz: Aligner(reference of 321 .. 1 500 bases).locate(query): beyond the per-pair aligner's 320
+    from tests._cases import long_pair_case
+    pairs = []
+    for _ in range(400):
+        m = rng.choice([rng.randint(321, 700), rng.randint(321, 1500), rng.randint(256, 330)])
+        n = rng.choice([rng.randint(321, 900), rng.randint(0, 320), rng.randint(600, 1500)])
+        c = dict(seed=rng.randint(0, 1 << 30), m=m, n=n, alpha="ACGT" if rng.random() < 0.8 else "ACGTN",
+                 kind=rng.choice([0, 0, 1, 2, 3]), a=rng.randint(0, min(300, m - 1)), b=rng.randint(0, 50),
+                 rate=rng.choice([0, 0.03, 0.05, 0.1]), e=rng.choice([0, 0.05, 0.1, 0.2, 0.3]),
+                 flags=rng.choice([15, 9, 14, 11, 14, 15, 8, 2, 0, 5, 10, 6]), ic=rng.choice([1, 1, 2, 100000]),
+                 mo=rng.choice([1, 3, 10]), wr=rng.random() < 0.15, wq=rng.random() < 0.15)
+        ref, q = long_pair_case(c)
+        out = Aligner(ref, c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"]).locate(q)
+        orc = O.locate(ref, q, c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"])
+        assert out == orc, (c, out, orc)
+        c["out"] = out
+        pairs.append(c)
+    print("%d long pairs, %d matched" % (len(pairs), sum(c["out"] is not None for c in pairs)))
+    dump("long_pairs.json.gz", pairs)
 
 
 if __name__ == "__main__":

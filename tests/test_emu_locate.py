@@ -43,6 +43,14 @@ def test_long_reads(emu_backend, oracle):
     assert _cases.check_long_reads(Aligner, oracle, _lib.AtroposHipError, 29, 15) > 300
 
 
+def test_long_pairs(emu_backend, oracle):
+    """References / per-pair sides beyond 320 bases: the 64-bit cell path (pairs_long_core.hpp)."""
+    from atropos_amd.align import Aligner, PairAligner
+    from atropos_amd import _lib
+    assert _cases.check_golden_long_pairs(Aligner, PairAligner, _lib.AtroposHipError) == 400
+    assert _cases.check_long_pairs(Aligner, PairAligner, oracle, 37, 10) > 100
+
+
 def test_piece_pipeline(emu_backend, oracle):
     """The two-pass pre-pass on plane64 reads (piece_core.hpp): pieces, read-end conditions, windows, the full
     sweep of the reads that need more than a window -- the per-lane source of the GPU build against the oracle."""

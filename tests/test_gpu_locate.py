@@ -80,6 +80,15 @@ def test_long_reads(hip_backend, oracle):
         Aligner(ref, 0.1, 14, False, False, 3, 1).locate_batch(["A" * (_lib.MAX_LONG_READ_LEN + 1)])
 
 
+def test_long_pairs(hip_backend, oracle):
+    """atr_locate_pairs_long_batch (sides of 321 .. 1 500 bases, 64-bit cells) and Aligner with a long reference: the
+    reference's own answers (long_pairs.json.gz) and the oracle."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner, PairAligner
+    assert _cases.check_golden_long_pairs(Aligner, PairAligner, _lib.AtroposHipError) == 400
+    assert _cases.check_long_pairs(Aligner, PairAligner, oracle, 41, 60) > 600
+
+
 def test_uniform_partial_overlaps(hip_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner

@@ -55,6 +55,15 @@ def test_long_reads(oracle):
         assert got == tup(c["out"]), c
 
 
+def test_long_pairs(oracle):
+    from tests._cases import long_pair_case
+    cases = load_golden("long_pairs.json.gz")
+    assert len(cases) == 400
+    for c in cases:
+        ref, q = long_pair_case(c)
+        assert oracle.locate(ref, q, c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"]) == tup(c["out"]), c
+
+
 def test_multi_fuzz(oracle):
     for c in load_golden("multi_fuzz.json.gz"):
         got = oracle.multi_locate(c["ref"], c["query"], c["e"], c["flags"], c["mo"], c["mx"])
