@@ -424,6 +424,30 @@ class DPMatrix(object):
         return "\n".join(lines)
 
 
+LONG_PAIRS_WORK_BYTES = 1 << 29                     # workspace of one call of the long-pair kernel (the DP columns)
+
+
+def long_pairs_records(be, rpacked, rlens, rmax, revcomp_ref, qpacked, qlens, qmax, n, max_error_rate, flags,
+                       wildcard_ref, wildcard_query, min_overlap, indel_cost):
+    """atr_locate_pairs_long_batch (64-bit cells, the DP column in a workspace) over tile64-packed sides, whole tiles
+    of 64 pairs at a time so that the workspace stays bounded.  int16 [n, 8] records."""
+    per_pair = 9 * (rmax + 1)
+    step = max(64, (LONG_PAIRS_WORK_BYTES // per_pair) // 64 * 64)
+    rch, qch = (rmax + 31) // 32, (qmax + 31) // 32
+    out = []
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        rp = rpacked[(lo // 64) * rch * 1024:]                  # a tile of 64 pairs: nchunks x 64 x 16 bytes
+        qp = qpacked[(lo // 64) * qch * 1024:]
+        out.append(be.locate_pairs_long_batch(
+            rp, None if rlens is None else rlens[lo:hi].contiguous(), rmax, revcomp_ref,
+            qp, None if qlens is None else qlens[lo:hi].contiguous(), qmax, hi - lo,
+            max_error_rate, flags, wildcard_ref, wildcard_query, min_overlap, indel_cost))
+    if not out:
+        return be.empty((0, 8), torch.int16)
+    return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+
 class PairAligner(object):
     """``Aligner(ref_p, max_error_rate, flags, ...).locate(query_p)`` for many independent
     (reference, query) pairs in one GPU call -- the aligner ``MergeOverlapping`` constructs per
@@ -518,28 +542,12 @@ class PairAligner(object):
                                     self.min_overlap, self.indel_cost, need=need, path=path)
         return LocateResult(rec)
 
-    LONG_WORK_BYTES = 1 << 29                       # workspace of one call of the long-pair kernel (the DP columns)
-
     def _locate_long_pairs(self, be, rb, qb):
-        """A side beyond PAIRS_MAX_LEN (the reference has no length limit, _align.pyx:266-291): 64-bit cells with the
-        DP column in a workspace (atr_locate_pairs_long_batch), whole tiles of 64 pairs at a time so that the
-        workspace stays bounded.  `need` does not apply (every pair gets the reference's record)."""
-        n = rb.nreads
-        per_pair = 9 * (rb.max_len + 1)
-        step = max(64, (self.LONG_WORK_BYTES // per_pair) // 64 * 64)
-        rch, qch = (rb.max_len + 31) // 32, (qb.max_len + 31) // 32
-        out = []
-        for lo in range(0, n, step):
-            hi = min(n, lo + step)
-            rp = rb.packed[(lo // 64) * rch * 1024:]            # a tile of 64 pairs: nchunks x 64 x 16 bytes
-            qp = qb.packed[(lo // 64) * qch * 1024:]
-            out.append(be.locate_pairs_long_batch(
-                rp, None if rb.lens is None else rb.lens[lo:hi].contiguous(), rb.max_len, self.revcomp_ref,
-                qp, None if qb.lens is None else qb.lens[lo:hi].contiguous(), qb.max_len, hi - lo,
-                self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query, self.min_overlap, self.indel_cost))
-        if not out:
-            return be.empty((0, 8), torch.int16)
-        return out[0] if len(out) == 1 else torch.cat(out, 0)
+        """A side beyond PAIRS_MAX_LEN (the reference has no length limit, _align.pyx:266-291); `need` does not apply
+        (every pair gets the reference's record)."""
+        return long_pairs_records(be, rb.packed, rb.lens, rb.max_len, self.revcomp_ref, qb.packed, qb.lens, qb.max_len,
+                                  rb.nreads, self.max_error_rate, self.flags, self.wildcard_ref, self.wildcard_query,
+                                  self.min_overlap, self.indel_cost)
 
     def locate(self, reference, query, unknown_queries_ok=False):
         be = _lib.get_backend()

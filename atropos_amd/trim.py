@@ -571,9 +571,9 @@ class PairedTrimPipeline(object):
                 begin, end = (st[0], st[1]) if idx.numel() == n else (st[0].index_select(0, idx).contiguous(),
                                                                       st[1].index_select(0, idx).contiguous())
                 max_len = int((end - begin).max().clamp_(min=0).item())
-                if max_len > _lib.PAIRS_MAX_LEN:
+                if max_len > _lib.MAX_READ_LEN:
                     raise _lib.AtroposHipError("MergeOverlapping: reads longer than %d bases are outside the device "
-                                               "envelope" % _lib.PAIRS_MAX_LEN)
+                                               "envelope" % _lib.MAX_READ_LEN)
                 sides.append((sub, begin, end, max_len))
             for table in tables:
                 # the aligner compares characters (_align.pyx:390-391): upper-case IUPAC codes first; if a read is
@@ -591,8 +591,13 @@ class PairedTrimPipeline(object):
             (rp, rl, rmax), (qp, ql, qmax) = packs
             # the merge below only looks at alignments with matches >= need (modifiers.py:896-897)
             need_g = need.to(torch.int32) if idx.numel() == n else need.to(torch.int32).index_select(0, idx)
-            rec = be.locate_pairs_batch(rp, rl, rmax, True, qp, ql, qmax, int(idx.numel()), self.merge_error_rate, flags,
-                                        False, False, 1, 1, need=need_g.contiguous())
+            if max(rmax, qmax) > _lib.PAIRS_MAX_LEN:        # reads of 321 .. 736 bases: the per-pair aligner's long path
+                from .align import long_pairs_records
+                rec = long_pairs_records(be, rp, rl, rmax, True, qp, ql, qmax, int(idx.numel()), self.merge_error_rate, flags,
+                                         False, False, 1, 1)
+            else:
+                rec = be.locate_pairs_batch(rp, rl, rmax, True, qp, ql, qmax, int(idx.numel()), self.merge_error_rate, flags,
+                                            False, False, 1, 1, need=need_g.contiguous())
             if idx.numel() == n:
                 align = rec
             else:

@@ -253,6 +253,9 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
+    # reads of 420 bases: MergeOverlapping's aligner beyond the per-pair pipeline's 320 (the reference has no limit)
+    ("long_pe.1.fastq", "long_pe.2.fastq", "-R --merge-min-overlap 0.3 -u 1 -U 2 --trim-n"),
+    ("long_pe.1.fastq", "long_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 40 --correct-mismatches liberal -q 15" % (PE1, PE2)),
     # soft-masked reads: the merge aligner compares characters, a != A
     ("soft_pe.1.fastq", "soft_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.4 --correct-mismatches liberal" % (PE1, PE2)),
     ("soft_pe.1.fastq", "soft_pe.2.fastq", "-R --merge-min-overlap 15 --merge-error-rate 0.1 -u 1 -U 1"),
@@ -282,6 +285,23 @@ def synth_pairs(npairs, seed):
             if rng.rand() < 0.1 and n > 8:
                 seq = seq[:n - 4] + "NNNN"
             out.append("@pair%d/x\n%s\n+\n%s\n" % (i, seq, "".join(chr(int(v) + 33) for v in q)))
+        texts.append("".join(out).encode())
+    return texts
+
+
+def synth_long_pairs(npairs, seed, n=420):
+    """Pairs of 2 x 420 bp (beyond the per-pair aligner's 320): fragments shorter and longer than the reads."""
+    sys.path.insert(0, ROOT)
+    from atropos_amd import synth
+    r1, r2 = synth.paired_end(0, npairs, n, synth.PE_ADAPTER1, synth.PE_ADAPTER2, synth.SEEDS["C3"] + seed, "cpu")[:2]
+    rng = np.random.RandomState(seed)
+    texts = []
+    for reads in (r1.numpy(), r2.numpy()):
+        out = []
+        for i in range(npairs):
+            seq = bytes(reads[i]).decode("ascii")
+            q = np.clip(38 - (np.arange(n) * rng.uniform(0.0, 0.08)).astype(int) + rng.randint(-3, 4, size=n), 2, 40)
+            out.append("@lp%d/x\n%s\n+\n%s\n" % (i, seq, "".join(chr(int(v) + 33) for v in q)))
         texts.append("".join(out).encode())
     return texts
 
@@ -372,6 +392,7 @@ def main():
     for name in ("paired.1.fastq", "paired.2.fastq"):
         inputs[name] = open(os.path.join(data_dir, name), "rb").read()
     inputs["synth_pe.1.fastq"], inputs["synth_pe.2.fastq"] = synth_pairs(500, 21)
+    inputs["long_pe.1.fastq"], inputs["long_pe.2.fastq"] = synth_long_pairs(160, 27)
     soft = []
     rng = np.random.RandomState(22)
     for text in synth_pairs(300, 23):
