@@ -1278,12 +1278,8 @@ def check_long_reference(Aligner, oracle, AtroposHipError, batch_rounds=6):
         al.indel_cost = c["ic"]
         assert oracle.locate(c["ref"], c["query"], c["e"], c["flags"], c["wr"], c["wq"], c["mo"], c["ic"]) == \
             (None if c["out"] is None else tuple(c["out"])), c
-        if len(c["query"]) > 320 or (max(len(c["ref"]), len(c["query"])) > 255 and not c["flags"] & 8):
-            try:                                            # outside the envelope of the per-pair aligner: a loud refusal
-                al.locate(c["query"])
-                raise AssertionError("expected a refusal: %r" % (c,))
-            except AtroposHipError:
-                continue
+        # (queries of more than 320 bases, and sides of more than 255 without STOP_WITHIN_SEQ2, used to be refused: they
+        # take the per-pair aligner's long path since round 4)
         res = al.locate(c["query"])
         assert (None if res is None else list(res)) == c["out"], (c, res)
         done += 1
@@ -1305,9 +1301,10 @@ def check_long_reference(Aligner, oracle, AtroposHipError, batch_rounds=6):
         for q, g in zip(reads, got):
             assert g == oracle.locate(ref, q, e, flags, False, False, mo, 1), (ref, q, e, flags, mo, g)
             done += 1
+    assert Aligner("A" * 321, 0.1).locate("C" * 10 + "A" * 400) == oracle.locate("A" * 321, "C" * 10 + "A" * 400, 0.1, 15, False, False, 1, 1)
     try:
-        Aligner("A" * 321, 0.1)
-        raise AssertionError("a 321-base reference should be outside the envelope")
+        Aligner("A" * 32737, 0.1)
+        raise AssertionError("a 32 737-base reference should be outside the envelope")
     except AtroposHipError:
         pass
     return done

@@ -7,7 +7,7 @@ bases: full sweep, cost / threat / band pipeline with and without `need`, wavefr
 (reads of up to 320 bases, probed sweep), MultiAligner (a wavefront per pair), the fused linked-adapter
 pipeline, the plane-guided error correction, ragged batches at wave-filling size (tail-mode window sweep), the
 two-pass pre-pass on bit planes (equal-length and ragged batches against full sweep, one-pass pipeline and oracle) and
-reads of 737 .. 4 000 bases (rolling origin base).
+reads of 737 .. 4 000 bases (rolling origin base), pairs / references beyond 320 bases (64-bit cells).
 usage: tools/gpu_fuzz.py [first_seed] [seeds]   (the log of the round's last run is kept under profiles/)"""
 import sys, time
 sys.path.insert(0, '.')
@@ -39,5 +39,6 @@ for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
     tot += _cases.check_ragged_tail_mode(Aligner, oracle, seed + 800, nreads=40_000, oracle_slice=600)
     tot += _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, seed + 900, 120, 300)[0]
     tot += _cases.check_long_reads(Aligner, oracle, _lib.AtroposHipError, seed + 950, 40)
+    tot += _cases.check_long_pairs(Aligner, PairAligner, oracle, seed + 980, 30)
     print(seed, tot, "%.0f s" % (time.time() - t0), flush=True)
 print("cases", tot)
