@@ -81,7 +81,8 @@ class Aligner(object):
             if len(ref_bytes) > _lib.MAX_LONG_READ_LEN:
                 raise _lib.AtroposHipError("Aligner: references longer than %d bases are outside the device envelope"
                                            % _lib.MAX_LONG_READ_LEN)
-            self._table_kind, self._table = self._pair_aligner()._table_kinds()[1], None
+            self._table_kind = self._pair_aligner()._table_kinds()[1]
+            self._table = be.translate_table(self._table_kind)
             return
         self._handle = be.aligner_create(ref_bytes, self.max_error_rate, self.flags, self.wildcard_ref,
                                          self.wildcard_query, self._min_overlap, self._indel_cost)
@@ -98,13 +99,18 @@ class Aligner(object):
         read of a chunk and the chunk goes through the per-pair aligner."""
         be = self._backend
         pa = self._pair_aligner()
-        if isinstance(reads, ReadBatch):
-            raise _lib.AtroposUnsupported("a reference of more than %d bases takes the reads as strings or as an "
-                                          "ASCII matrix, not as a packed batch (the device-resident pipelines "
-                                          "stop at %d-base adapters)" % (_lib.MAX_REF_LEN, _lib.MAX_REF_LEN))
         ref_row = torch.frombuffer(bytearray(self._ref_bytes), dtype=torch.uint8).to(be.device)
         step = min(self.LONG_CHUNK, max(64, (1 << 28) // len(self._ref_bytes)))     # (the reference is laid out per read)
-        if isinstance(reads, (list, tuple)):
+        if isinstance(reads, ReadBatch):
+            # a packed batch (the device-resident pipelines' adapter stage): whole tiles of 64 reads per chunk
+            self._check_batch(reads)
+            self._need_tile64(reads, "locate_batch with a reference of more than %d bases" % _lib.MAX_REF_LEN)
+            n, nch = reads.nreads, (reads.max_len + 31) // 32
+            step = max(64, step // 64 * 64)
+            chunks = (ReadBatch(reads.packed[(lo // 64) * nch * 1024:], None if reads.lens is None else
+                                reads.lens[lo:min(n, lo + step)].contiguous(), min(n, lo + step) - lo, reads.max_len,
+                                reads.table_kind, reads.table) for lo in range(0, n, step))
+        elif isinstance(reads, (list, tuple)):
             n = len(reads)
             chunks = ((reads[i:i + step]) for i in range(0, n, step))
         else:
@@ -112,7 +118,7 @@ class Aligner(object):
             chunks = ((reads[i:i + step]) for i in range(0, n, step))
         recs = []
         for chunk in chunks:
-            count = len(chunk) if isinstance(chunk, (list, tuple)) else chunk.shape[0]
+            count = len(chunk) if isinstance(chunk, (list, tuple, ReadBatch)) else chunk.shape[0]
             refs = ref_row[None, :].expand(count, -1).contiguous()
             recs.append(pa.locate_batch(refs, chunk, unknown_queries_ok=True).records)
         if not recs:

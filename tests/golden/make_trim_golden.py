@@ -128,6 +128,28 @@ def synth_longmix_fastq(nreads, seed):
     return "\n".join(out) + "\n"
 
 
+LONGAD = ("GATCGGAAGAGCACACGTCTGAACTCCAGTCACTTAGGCATCTCGTATGCCGTCTTCTGCTTGAAAAAGGCCTTAACCGGTTACGTACGATTAGCCATGCATGCCAAT"
+          "TGGCCAATCGTAGCTAGCTAACGGATCCGATTACAGGCATT")
+
+
+def synth_longad_fastq(nreads, seed):
+    """Reads of 50 .. 260 bases that run into a 150-base adapter at a random place (whole, cut by the read end,
+    absent), with substitutions."""
+    import random
+    rng = random.Random(seed)
+    out = []
+    for i in range(nreads):
+        n = rng.randint(50, 260)
+        frag = "".join(rng.choice("ACGT") for _ in range(rng.randint(0, n + 40)))
+        seq = list((frag + LONGAD + "".join(rng.choice("ACGT") for _ in range(300)))[:n])
+        for j in range(len(seq)):
+            if rng.random() < 0.01:
+                seq[j] = rng.choice("ACGTN")
+        seq = "".join(seq)
+        out.append("@la%d\n%s\n+\n%s\n" % (i, seq, "".join(chr(33 + rng.randint(20, 40)) for _ in seq)))
+    return "".join(out)
+
+
 # (input name, argument string) -- the reference's own CLI tests (tests/test_atropos.py) that
 # take FASTQ input and stay inside the device pipeline's envelope, plus parameter sweeps on
 # synthetic reads
@@ -196,6 +218,9 @@ CASES = [
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15,25 --trim-n -m 30 --info-file {info} --rest-file {rest} --wildcard-file {wildcard}"),
     ("synth.fastq", "-b tru=" + TRUSEQ + " -g head=" + TRUSEQ[:20] + " -e 0.2 -O 5 -n 2 --discard-trimmed --info-file {info} --rest-file {rest}"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " --no-trim --info-file {info} --wildcard-file {wildcard} --match-read-wildcards"),
+    # an adapter of 150 bases (beyond the aligner handles' 128 rows: the per-pair aligner with one reference for all)
+    ("longad.fastq", "-a long=" + LONGAD + " -e 0.1"),
+    ("longad.fastq", "-b long=" + LONGAD + " -e 0.15 -O 10 -n 2 --info-file {info}"),
     # the filtered reads into files of their own (trim/__init__.py:580-630)
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 20 -m 40 -M 95 --too-short-output {too_short} --too-long-output {too_long} --untrimmed-output {untrimmed}"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " -m 30 --max-n 1 --mask-adapter --too-short-output {too_short} --untrimmed-output {untrimmed}"),
@@ -326,6 +351,7 @@ def main():
     inputs["synth.fastq"] = synth_fastq(1200, 11).encode()
     inputs["anchor.fastq"] = synth_anchor_fastq(600, 14).encode()
     inputs["longmix.fastq"] = synth_longmix_fastq(150, 19).encode()
+    inputs["longad.fastq"] = synth_longad_fastq(300, 29).encode()
     tagged = synth_fastq(200, 31).split("\n")                    # names with a length field (and one that only looks like it)
     for i in range(0, len(tagged) - 1, 4):
         n = len(tagged[i + 1])

@@ -5,7 +5,7 @@ from . import _cases
 
 
 def test_trim_pipeline_reference_cli_cases(emu_backend):
-    assert _cases.check_trim_golden() >= 77
+    assert _cases.check_trim_golden() >= 79
 
 
 def test_trim_pipeline_through_the_two_pass_prepass(emu_backend, monkeypatch):
@@ -16,7 +16,7 @@ def test_trim_pipeline_through_the_two_pass_prepass(emu_backend, monkeypatch):
     real = emu_backend.locate_planes_batch
     monkeypatch.setattr(_lib, "PLANES_MIN_READS", 1)
     monkeypatch.setattr(emu_backend, "locate_planes_batch", lambda *a: (calls.append(a[3]), real(*a))[1])
-    assert _cases.check_trim_golden() >= 77
+    assert _cases.check_trim_golden() >= 79
     assert len(calls) >= 10
 
 

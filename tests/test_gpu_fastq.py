@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_trim_pipeline_reference_cli_cases(hip_backend):
-    assert _cases.check_trim_golden() >= 77
+    assert _cases.check_trim_golden() >= 79
 
 
 def test_trim_file_chunking(hip_backend, tmp_path):
