@@ -48,6 +48,12 @@ class TrimResult(object):
         (commands/trim/writers.py:193-222; Match.get_info_record / rest / wildcards, align/__init__.py:117-170),
         every read in input order whatever its destination: {kind: bytes}.  Assembled on the host from the result
         arrays of the adapter rounds (the pipeline must have been built with ``aux``)."""
+        lines = self.aux_lines(kinds)
+        return {k: "".join(line + "\n" for per_read in v for line in per_read).encode("ascii", "replace")
+                for k, v in lines.items()}
+
+    def aux_lines(self, kinds=("info", "rest", "wildcard")):
+        """{kind: one list of lines per read} (see aux_text; the paired-end result interleaves the two reads' lists)."""
         if self.rounds is None:
             raise ValueError("the pipeline was built without aux=(...): the adapter rounds were not kept")
         n = len(self.batch)
@@ -59,7 +65,7 @@ class TrimResult(object):
         raw_final = raw if self.batch is self.read_batch else bytes(self.batch.data.cpu().numpy().tobytes())
         fb, fe = self.begin.cpu().numpy(), self.end.cpu().numpy()
         rounds = [tuple(t.cpu().numpy() for t in r) for r in self.rounds]
-        out = {k: [] for k in kinds}
+        out = {k: [[] for _ in range(n)] for k in kinds}
         for i in range(n):
             name = raw[recs[i, 0]:recs[i, 0] + recs[i, 1]].decode("ascii", "replace")
             so, qo, has_q = int(recs[i, 2]), int(recs[i, 4]), recs[i, 5] > 0 or recs[i, 3] == 0
@@ -75,13 +81,15 @@ class TrimResult(object):
                 last = (ad, astart, astop, rstart, rstop, seq)
                 lines.append("\t".join(str(f) for f in (name, errors, rstart, rstop, seq[:rstart], seq[rstart:rstop], seq[rstop:],
                                                         ad.name, qual[:rstart], qual[rstart:rstop], qual[rstop:])))
+            # (the name the read has when the files are written, i.e. after the read-name modifiers: the rest and wildcard
+            # lines and an unmatched read's info line carry it; a match's info record was made before them)
+            fname = raw_final[final[i, 0]:final[i, 0] + final[i, 1]].decode("ascii", "replace")
             if "info" in out:
                 if last is None:
                     seq = raw[so + fb[i]:so + max(fb[i], fe[i])].decode("ascii", "replace")
                     qual = raw[qo + fb[i]:qo + max(fb[i], fe[i])].decode("ascii", "replace") if has_q else ""
-                    fname = raw_final[final[i, 0]:final[i, 0] + final[i, 1]].decode("ascii", "replace")
                     lines = ["\t".join((fname, "-1", seq, qual))]
-                out["info"].extend(lines)
+                out["info"][i] = lines
             if last is None:
                 continue
             ad, astart, astop, rstart, rstop, seq = last
@@ -89,12 +97,12 @@ class TrimResult(object):
             if "rest" in out:
                 rest = seq[:rstart] if front else seq[rstop:]
                 if rest:
-                    out["rest"].append(rest + " " + name)
+                    out["rest"][i].append(rest + " " + fname)
             if "wildcard" in out:
                 chars = [seq[rstart + k] for k in range(astop - astart)
                          if ad.sequence[astart + k] == "N" and rstart + k < len(seq)]
-                out["wildcard"].append("".join(chars) + " " + name)
-        return {k: "".join(line + "\n" for line in v).encode("ascii", "replace") for k, v in out.items()}
+                out["wildcard"][i].append("".join(chars) + " " + fname)
+        return out
 
     def counts(self):
         c = torch.bincount(self.dest.to(torch.int64), minlength=6).cpu().tolist()
@@ -401,6 +409,12 @@ class PairedTrimResult(object):
             out["merged"] = int(c[DEST_MERGED])
         return out
 
+    def aux_text(self, kinds=("info", "rest", "wildcard")):
+        """The info / rest / wildcard lines of the pairs: read 1's, then read 2's, pair after pair
+        (Formatters.format calls every info formatter on read 1 and on read 2, writers.py:156-159)."""
+        l1, l2 = self.read1.aux_lines(kinds), self.read2.aux_lines(kinds)
+        return {k: "".join(line + "\n" for a, b in zip(l1[k], l2[k]) for line in a + b).encode("ascii", "replace") for k in kinds}
+
     def merged_text(self):
         """FASTQ text of the merged reads (the --merged-output file), in input order."""
         return b"" if self.merged is None else bytes(self.merged.cpu().numpy().tobytes())
@@ -426,11 +440,17 @@ class PairedTrimPipeline(object):
                  nextseq_trim=None, quality_cutoff=None, quality_base=33, trim_n=False, minimum_length=None,
                  maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
                  op_order="CGQAW", insert_args=None, correct_mismatches=None, merge_overlapping=False,
-                 merge_min_overlap=0.9, merge_error_rate=0.2):
+                 merge_min_overlap=0.9, merge_error_rate=0.2, aux=None, length_tag=None, strip_suffix=(), prefix="",
+                 suffix="", zero_cap=False):
         common = dict(times=times, action=action, nextseq_trim=nextseq_trim, quality_cutoff=quality_cutoff,
                       quality_base=quality_base, trim_n=trim_n, minimum_length=minimum_length,
                       maximum_length=maximum_length, max_n=max_n, discard_trimmed=discard_trimmed,
-                      discard_untrimmed=discard_untrimmed, op_order=op_order)
+                      discard_untrimmed=discard_untrimmed, op_order=op_order, aux=aux, length_tag=length_tag,
+                      strip_suffix=strip_suffix, prefix=prefix, suffix=suffix, zero_cap=zero_cap)
+        self.aux = dict(aux) if aux else None
+        if (aux or length_tag or strip_suffix or prefix or suffix or zero_cap) and (aligner != "adapter" or merge_overlapping):
+            raise NotImplementedError("--info-file / --rest-file / --wildcard-file, read-name modifiers and --zero-cap with "
+                                      "the insert aligner or with merging")
         self.p1 = TrimPipeline(adapters=adapters1, cut=cut, **common)
         self.p2 = TrimPipeline(adapters=adapters2, cut=cut2, **common)
         self.aligner, self.action, self.op_order = aligner, action, op_order
@@ -635,8 +655,12 @@ class PairedTrimPipeline(object):
         for b in (batch1, batch2):
             st.append([torch.zeros((n,), dtype=torch.int32, device=dev), b.seq_lens.clone()])
         extra = [(torch.zeros((n,), dtype=torch.uint8, device=dev), None, None) for _ in range(2)]
-        pipes, batches = (self.p1, self.p2), (batch1, batch2)
+        pipes, batches = (self.p1, self.p2), [batch1, batch2]
         insert_matched = already_corrected = None
+        for pipe in pipes:
+            pipe._rounds = [] if self.aux else None
+            pipe._last_which = (torch.zeros((n,), dtype=torch.int64, device=dev)
+                                if ("{name}" in pipe.prefix or "{name}" in pipe.suffix) else None)
         for op in self.op_order:
             if op == "A":
                 if self.aligner == "insert":
@@ -658,7 +682,17 @@ class PairedTrimPipeline(object):
         if self.merge_overlapping:                                  # the last modifier, the first filter
             merged, merged_text = self._merge_stage(batch1, batch2, st[0], st[1], insert_matched, already_corrected)
             dest = torch.where(merged, torch.full_like(dest, DEST_MERGED), dest)
-        res = [TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest) for k in range(2)]
+        res = []
+        for k in range(2):
+            pipe, read_batch = pipes[k], batches[k]
+            rounds, pipe._rounds = pipe._rounds, None
+            if pipe.zero_cap and n:
+                pipe._zero_cap(batches[k])
+            if pipe._name_mods and n:
+                batches[k] = pipe._rewrite_names(batches[k], st[k][0], st[k][1], extra[k][0])
+            pipe._last_which = None
+            res.append(TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest, rounds,
+                                  pipe.adapters, read_batch))
         return PairedTrimResult(res[0], res[1], merged_text)
 
     def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None, keep_output=False, output_parts=1):
@@ -674,6 +708,7 @@ class PairedTrimPipeline(object):
         clock = StageClock()
         readers = [ChunkedFastqReader(p, chunk_bytes, be, clock) for p in (in1, in2)]
         sinks = [make_sink(p, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output) for p in (out1, out2)]
+        aux_files = {kind: open(path, "wb") for kind, path in (self.aux or {}).items()}
         if self.merge_overlapping:
             totals["merged"] = 0
             if merged_out is not None:
@@ -697,6 +732,9 @@ class PairedTrimPipeline(object):
                     sinks[k].write(texts[k])
                 if len(sinks) == 3:
                     sinks[2].write(res.merged if res.merged is not None else texts[0][:0])
+                if aux_files:
+                    for kind, blob in res.aux_text(tuple(aux_files)).items():
+                        aux_files[kind].write(blob)
                 for name, v in counts.items():
                     totals[name] += v
                 if all(done):
@@ -704,7 +742,7 @@ class PairedTrimPipeline(object):
                 if any(done):
                     raise ValueError("the two input files hold different numbers of records")
         finally:
-            for obj in readers + sinks:
+            for obj in readers + sinks + list(aux_files.values()):
                 obj.close()
             self.stage_seconds = dict(clock.seconds)
         return totals
@@ -845,10 +883,8 @@ def pipeline_from_args(argv):
     if not paired:
         return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
                             strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
-    if aux or o.length_tag or o.strip_suffix or o.prefix or o.suffix or o.zero_cap:
-        raise NotImplementedError("--info-file / --rest-file / --wildcard-file, read-name modifiers and --zero-cap with "
-                                  "paired-end input")
-    return PairedTrimPipeline(adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
+    return PairedTrimPipeline(aux=aux or None, length_tag=o.length_tag, strip_suffix=o.strip_suffix, prefix=o.prefix,
+                              suffix=o.suffix, zero_cap=o.zero_cap, adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,
                               merge_min_overlap=o.merge_min_overlap,

@@ -1130,13 +1130,21 @@ def check_trim_golden_paired():
     done = 0
     for case in doc["paired"]:
         label = "%s: %s" % (case["input1"], case["args"])
-        pipe = pipeline_from_args(case["args"])
+        args = case["args"]
+        for kind in case.get("aux", {}):
+            args = args.replace("{%s}" % kind, kind + ".txt")
+        pipe = pipeline_from_args(args)
         assert isinstance(pipe, PairedTrimPipeline), label
         from atropos_amd.fastq import FastqBatch
         b1, _ = FastqBatch.from_bytes(inputs[case["input1"]], final=True)
         b2, _ = FastqBatch.from_bytes(inputs[case["input2"]], final=True)
         res = pipe.run(b1, b2)
         outs = list(res.text())
+        if case.get("aux"):
+            aux = res.aux_text(tuple(case["aux"]))
+            for kind, want in case["aux"].items():
+                want = base64.b64decode(want)
+                assert aux[kind] == want, (label, kind, _first_diff(aux[kind], want))
         if len(case["outputs"]) == 3:                        # -R: the --merged-output file
             outs.append(res.merged_text())
             assert res.counts()["merged"] == outs[2].count(b"\n") // 4 == pipe.merged_pairs, label

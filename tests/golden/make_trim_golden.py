@@ -278,6 +278,9 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
+    # info / rest / wildcard files and read-name modifiers with paired-end input (one line group per read, read 1 first)
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a a1=%s -A a2=%s -q 15 --trim-n --info-file {info} --rest-file {rest}" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a a1=%s -A a2=%s -n 2 -m 20 -x {name}_ --strip-suffix /x -z --wildcard-file {wildcard} --info-file {info}" % (PE1[:30] + "N" + PE1[31:], PE2)),
     # reads of 420 bases: MergeOverlapping's aligner beyond the per-pair pipeline's 320 (the reference has no limit)
     ("long_pe.1.fastq", "long_pe.2.fastq", "-R --merge-min-overlap 0.3 -u 1 -U 2 --trim-n"),
     ("long_pe.1.fastq", "long_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 40 --correct-mismatches liberal -q 15" % (PE1, PE2)),
@@ -442,7 +445,12 @@ def main():
             paths = [os.path.join(tmp, "pe_%d_%s.fastq" % (idx, t)) for t in ("in1", "in2", "out1", "out2")]
             open(paths[0], "wb").write(inputs[n1])
             open(paths[1], "wb").write(inputs[n2])
-            params = argstr.split() + ["-pe1", paths[0], "-pe2", paths[1], "-o", paths[2], "-p", paths[3], "--quiet",
+            aux_paths = {kind: os.path.join(tmp, "pe_%s_%d.txt" % (kind, idx)) for kind in ("info", "rest", "wildcard")
+                         if "{%s}" % kind in argstr}
+            filled = argstr
+            for kind, path in aux_paths.items():
+                filled = filled.replace("{%s}" % kind, path)
+            params = filled.split() + ["-pe1", paths[0], "-pe2", paths[1], "-o", paths[2], "-p", paths[3], "--quiet",
                                        "--no-default-adapters", "--no-cache-adapters"]
             if "-R" in argstr.split():
                 paths.append(os.path.join(tmp, "pe_%d_merged.fastq" % idx))
@@ -450,6 +458,9 @@ def main():
             retcode, _summary = get_command("trim").execute(params)
             assert retcode == 0, (argstr, retcode)
             case = dict(input1=n1, input2=n2, args=argstr, outputs=[])
+            if aux_paths:
+                case["aux"] = {kind: base64.b64encode(open(path, "rb").read() if os.path.exists(path) else b"").decode()
+                               for kind, path in aux_paths.items()}
             for path in paths[2:]:
                 text = open(path, "rb").read()
                 case["outputs"].append(dict(size=len(text), sha256=hashlib.sha256(text).hexdigest(),

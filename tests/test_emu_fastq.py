@@ -35,13 +35,13 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
     with pytest.raises(SystemExit):
         pipeline_from_args("--bisulfite rrbs")                           # modifier outside the pipeline
     with pytest.raises(NotImplementedError):
-        pipeline_from_args("-a ACGT -A ACGT --length-tag length=")       # read-name modifiers: single-end only
+        pipeline_from_args("--aligner insert -a ACGTACGTAC -A ACGTACGTAC --length-tag length=")   # not with the insert aligner
     with pytest.raises(NotImplementedError):
         pipeline_from_args("-a ^ACGT...TTTT --info-file x")             # info file with a linked adapter
 
 
 def test_paired_pipeline_reference_cli_cases(emu_backend):
-    assert _cases.check_trim_golden_paired() >= 35
+    assert _cases.check_trim_golden_paired() >= 37
 
 
 def test_paired_file_chunking(emu_backend, tmp_path):
