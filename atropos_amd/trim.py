@@ -466,8 +466,6 @@ class PairedTrimPipeline(object):
         self.merge_min_overlap = merge_min_overlap if merge_min_overlap <= 1 else int(merge_min_overlap)
         self.merge_error_rate = float(merge_error_rate)
         self.merged_pairs = 0
-        if self.merge_overlapping and action == "mask":
-            raise NotImplementedError("--merge-overlapping together with --mask-adapter")
         self.correct_mismatches = correct_mismatches
         self.corrected_pairs, self.corrected_bp = 0, [0, 0]               # ErrorCorrectorMixin counters
         self.insert = None
@@ -680,6 +678,14 @@ class PairedTrimPipeline(object):
         dest = be.pair_filter_batch(masks[0], masks[1], self.min_affected)
         merged_text = None
         if self.merge_overlapping:                                  # the last modifier, the first filter
+            if self.action == "mask":
+                # masked adapters: MergeOverlapping sees the reads with their N's (modifiers.py:155-172 made them part of
+                # the sequence): written into the chunk here, the intervals then need no mask any more
+                for k in range(2):
+                    matched, ub, ue = extra[k]
+                    if ub is not None:
+                        self._write_mask(batches[k], st[k][0], st[k][1], ub, ue)
+                        extra[k] = (matched, None, None)
             merged, merged_text = self._merge_stage(batch1, batch2, st[0], st[1], insert_matched, already_corrected)
             dest = torch.where(merged, torch.full_like(dest, DEST_MERGED), dest)
         res = []
@@ -694,6 +700,19 @@ class PairedTrimPipeline(object):
             res.append(TrimResult(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2], extra[k][0], dest, rounds,
                                   pipe.adapters, read_batch))
         return PairedTrimResult(res[0], res[1], merged_text)
+
+    @staticmethod
+    def _write_mask(batch, begin, end, ubegin, uend):
+        """'N' over the masked parts [begin, ubegin) and [uend, end) of every sequence line of the chunk."""
+        off = batch.records[:, 2].to(torch.int64) & 0xFFFFFFFF
+        for lo, hi in ((begin, torch.minimum(ubegin, end)), (torch.maximum(uend, begin), end)):
+            lens = (hi - lo).clamp(min=0).to(torch.int64)
+            total = int(lens.sum().item())
+            if total == 0:
+                continue
+            first = torch.cumsum(lens, 0) - lens
+            idx = torch.repeat_interleave(off + lo.to(torch.int64) - first, lens) + torch.arange(total, device=off.device)
+            batch.data[idx] = ord("N")
 
     def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None, keep_output=False, output_parts=1):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the

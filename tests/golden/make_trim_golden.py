@@ -278,6 +278,9 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
+    # masked adapters and merging: MergeOverlapping sees the reads with their N's
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --mask-adapter -R --merge-min-overlap 0.3" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --mask-adapter -R --merge-min-overlap 20 --correct-mismatches liberal -q 15 --trim-n" % (PE1, PE2)),
     # info / rest / wildcard files and read-name modifiers with paired-end input (one line group per read, read 1 first)
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a a1=%s -A a2=%s -q 15 --trim-n --info-file {info} --rest-file {rest}" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a a1=%s -A a2=%s -n 2 -m 20 -x {name}_ --strip-suffix /x -z --wildcard-file {wildcard} --info-file {info}" % (PE1[:30] + "N" + PE1[31:], PE2)),
