@@ -441,7 +441,11 @@ class PairedTrimPipeline(object):
                  maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
                  op_order="CGQAW", insert_args=None, correct_mismatches=None, merge_overlapping=False,
                  merge_min_overlap=0.9, merge_error_rate=0.2, aux=None, length_tag=None, strip_suffix=(), prefix="",
-                 suffix="", zero_cap=False):
+                 suffix="", zero_cap=False, outputs=None):
+        # {"too_short" | "too_long" | "untrimmed": (path for read 1, path for read 2)}: the filtered pairs' own files
+        self.outputs = dict(outputs) if outputs else {}
+        if "untrimmed" in self.outputs:
+            discard_untrimmed = True                                      # (the UntrimmedFilter is on, trim/__init__.py:617)
         common = dict(times=times, action=action, nextseq_trim=nextseq_trim, quality_cutoff=quality_cutoff,
                       quality_base=quality_base, trim_n=trim_n, minimum_length=minimum_length,
                       maximum_length=maximum_length, max_n=max_n, discard_trimmed=discard_trimmed,
@@ -728,6 +732,8 @@ class PairedTrimPipeline(object):
         readers = [ChunkedFastqReader(p, chunk_bytes, be, clock) for p in (in1, in2)]
         sinks = [make_sink(p, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output) for p in (out1, out2)]
         aux_files = {kind: open(path, "wb") for kind, path in (self.aux or {}).items()}
+        dest_codes = {name: code for code, name in DEST_NAMES.items()}
+        dest_files = {dest_codes[kind]: [open(p, "wb") for p in paths] for kind, paths in self.outputs.items()}
         if self.merge_overlapping:
             totals["merged"] = 0
             if merged_out is not None:
@@ -754,6 +760,9 @@ class PairedTrimPipeline(object):
                 if aux_files:
                     for kind, blob in res.aux_text(tuple(aux_files)).items():
                         aux_files[kind].write(blob)
+                for code, fhs in dest_files.items():
+                    for fh, text in zip(fhs, res.text(code)):
+                        fh.write(text)
                 for name, v in counts.items():
                     totals[name] += v
                 if all(done):
@@ -761,7 +770,7 @@ class PairedTrimPipeline(object):
                 if any(done):
                     raise ValueError("the two input files hold different numbers of records")
         finally:
-            for obj in readers + sinks + list(aux_files.values()):
+            for obj in readers + sinks + list(aux_files.values()) + [fh for fhs in dest_files.values() for fh in fhs]:
                 obj.close()
             self.stage_seconds = dict(clock.seconds)
         return totals
@@ -829,6 +838,9 @@ def pipeline_from_args(argv):
     ap.add_argument("--too-short-output", default=None)
     ap.add_argument("--too-long-output", default=None)
     ap.add_argument("--untrimmed-output", default=None)
+    ap.add_argument("--too-short-paired-output", default=None)
+    ap.add_argument("--too-long-paired-output", default=None)
+    ap.add_argument("--untrimmed-paired-output", default=None)
     ap.add_argument("--info-file", default=None)
     ap.add_argument("--rest-file", "-r", default=None)
     ap.add_argument("--wildcard-file", default=None)
@@ -897,12 +909,16 @@ def pipeline_from_args(argv):
     aux = {kind: path for kind, path in (("info", o.info_file), ("rest", o.rest_file), ("wildcard", o.wildcard_file)) if path}
     outputs = {kind: path for kind, path in (("too_short", o.too_short_output), ("too_long", o.too_long_output),
                                              ("untrimmed", o.untrimmed_output)) if path}
-    if outputs and paired:
-        raise NotImplementedError("--too-short-output / --too-long-output / --untrimmed-output with paired-end input")
+    if paired and outputs:
+        second = dict(too_short=o.too_short_paired_output, too_long=o.too_long_paired_output, untrimmed=o.untrimmed_paired_output)
+        if any(second[kind] is None for kind in outputs):
+            raise NotImplementedError("paired-end input: --too-short-output / --too-long-output / --untrimmed-output need "
+                                      "their --*-paired-output as well")
+        outputs = {kind: (path, second[kind]) for kind, path in outputs.items()}
     if not paired:
         return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
                             strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
-    return PairedTrimPipeline(aux=aux or None, length_tag=o.length_tag, strip_suffix=o.strip_suffix, prefix=o.prefix,
+    return PairedTrimPipeline(outputs=outputs or None, aux=aux or None, length_tag=o.length_tag, strip_suffix=o.strip_suffix, prefix=o.prefix,
                               suffix=o.suffix, zero_cap=o.zero_cap, adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,

@@ -278,6 +278,8 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
+    # the filtered pairs into files of their own
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 60 --too-short-output {too_short} --too-short-paired-output {too_short2} --untrimmed-output {untrimmed} --untrimmed-paired-output {untrimmed2}" % (PE1, PE2)),
     # masked adapters and merging: MergeOverlapping sees the reads with their N's
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --mask-adapter -R --merge-min-overlap 0.3" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --mask-adapter -R --merge-min-overlap 20 --correct-mismatches liberal -q 15 --trim-n" % (PE1, PE2)),
@@ -448,7 +450,8 @@ def main():
             paths = [os.path.join(tmp, "pe_%d_%s.fastq" % (idx, t)) for t in ("in1", "in2", "out1", "out2")]
             open(paths[0], "wb").write(inputs[n1])
             open(paths[1], "wb").write(inputs[n2])
-            aux_paths = {kind: os.path.join(tmp, "pe_%s_%d.txt" % (kind, idx)) for kind in ("info", "rest", "wildcard")
+            aux_paths = {kind: os.path.join(tmp, "pe_%s_%d.txt" % (kind, idx))
+                         for kind in ("info", "rest", "wildcard", "too_short", "too_short2", "untrimmed", "untrimmed2", "too_long", "too_long2")
                          if "{%s}" % kind in argstr}
             filled = argstr
             for kind, path in aux_paths.items():
