@@ -604,6 +604,15 @@ class LinkedSet(object):
         if self._handle is None:
             return _linked_records_stepwise(self.adapters, source, active)
         batch = source.batch(self.table_kind, self.table)
+        if batch.max_len == 0 and batch.nreads:
+            # every read is empty (trimmed away by an earlier stage): nothing matches (LinkedAdapter.match_to needs the
+            # 5' part, adapters/__init__.py:671-690); the device call has no packed chunk to read
+            be = self._backend
+            none = be.empty((batch.nreads, 8), torch.int16)
+            none.zero_()
+            none[:, 1] = -1
+            which = torch.full((batch.nreads,), -1, dtype=torch.int32, device=none.device)
+            return which, torch.zeros_like(which), none, none.clone()
         wc, front, back = self._backend.linked_match_batch(self._handle, batch.packed, batch.lens, batch.nreads,
                                                            batch.max_len)
         which, count = wc[:, 0].to(torch.int32), wc[:, 1].to(torch.int32)

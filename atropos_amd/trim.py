@@ -33,6 +33,26 @@ DEST_NAMES = {_lib.DEST_KEEP: "keep", _lib.DEST_TOO_SHORT: "too_short", _lib.DES
               _lib.DEST_TOO_MANY_N: "too_many_n", _lib.DEST_TRIMMED: "trimmed", _lib.DEST_UNTRIMMED: "untrimmed"}
 
 
+def write_mask(batch, begin, end, ubegin, uend):
+    """'N' over the masked parts [begin, ubegin) and [uend, end) of every sequence line of the chunk: after it the
+    read IS what AdapterCutter's 'mask' action returns (modifiers.py:155-172), for the stages that look at bases."""
+    off = batch.records[:, 2].to(torch.int64) & 0xFFFFFFFF
+    for lo, hi in ((begin, torch.minimum(ubegin, end)), (torch.maximum(uend, begin), end)):
+        lens = (hi - lo).clamp(min=0).to(torch.int64)
+        total = int(lens.sum().item())
+        if total == 0:
+            continue
+        first = torch.cumsum(lens, 0) - lens
+        idx = torch.repeat_interleave(off + lo.to(torch.int64) - first, lens) + torch.arange(total, device=off.device)
+        batch.data[idx] = ord("N")
+
+
+def mask_before_later_stages(op_order, action):
+    """A 'mask' adapter stage followed by a stage that reads bases (NextSeq trimming looks for G's): the N's must be in
+    the chunk before that stage runs."""
+    return action == "mask" and "A" in op_order and any(op in "GQ" for op in op_order[op_order.index("A") + 1:])
+
+
 class TrimResult(object):
     """State of a batch after the pipeline: kept interval per read, the destination filter
     and the adapter flag; all device tensors."""
@@ -273,6 +293,9 @@ class TrimPipeline(object):
             if op == "A":
                 if self.adapters:
                     matched, ubegin, uend = self._adapter_stage(batch, begin, end)
+                    if ubegin is not None and mask_before_later_stages(self.op_order, self.action):
+                        write_mask(batch, begin, end, ubegin, uend)
+                        ubegin = uend = None
             else:
                 self._simple_stage(op, batch, begin, end)
         dest = self._filter_stage(batch, begin, end, ubegin, uend, matched)
@@ -672,6 +695,10 @@ class PairedTrimPipeline(object):
                     for k in range(2):
                         if pipes[k].adapters:
                             extra[k] = pipes[k]._adapter_stage(batches[k], st[k][0], st[k][1])
+                for k in range(2):
+                    if extra[k][1] is not None and mask_before_later_stages(self.op_order, self.action):
+                        write_mask(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2])
+                        extra[k] = (extra[k][0], None, None)
             else:
                 for k in range(2):
                     pipes[k]._simple_stage(op, batches[k], st[k][0], st[k][1])
@@ -705,18 +732,7 @@ class PairedTrimPipeline(object):
                                   pipe.adapters, read_batch))
         return PairedTrimResult(res[0], res[1], merged_text)
 
-    @staticmethod
-    def _write_mask(batch, begin, end, ubegin, uend):
-        """'N' over the masked parts [begin, ubegin) and [uend, end) of every sequence line of the chunk."""
-        off = batch.records[:, 2].to(torch.int64) & 0xFFFFFFFF
-        for lo, hi in ((begin, torch.minimum(ubegin, end)), (torch.maximum(uend, begin), end)):
-            lens = (hi - lo).clamp(min=0).to(torch.int64)
-            total = int(lens.sum().item())
-            if total == 0:
-                continue
-            first = torch.cumsum(lens, 0) - lens
-            idx = torch.repeat_interleave(off + lo.to(torch.int64) - first, lens) + torch.arange(total, device=off.device)
-            batch.data[idx] = ord("N")
+    _write_mask = staticmethod(lambda batch, begin, end, ubegin, uend: write_mask(batch, begin, end, ubegin, uend))
 
     def trim_files(self, in1, in2, out1, out2, chunk_bytes=128 << 20, merged_out=None, keep_output=False, output_parts=1):
         """Stream two FASTQ files through the GPU in lock step (chunks of whole records, the
