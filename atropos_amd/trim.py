@@ -77,7 +77,7 @@ class TrimResult(object):
         if self.rounds is None:
             raise ValueError("the pipeline was built without aux=(...): the adapter rounds were not kept")
         n = len(self.batch)
-        raw = bytes(self.batch.data[:self.batch.nbytes].cpu().numpy().tobytes())
+        raw = bytes(self.read_batch.data[:self.read_batch.nbytes].cpu().numpy().tobytes())
         recs = self.read_batch.records.cpu().numpy().astype("int64")
         recs[:, [0, 2, 4]] &= 0xFFFFFFFF                       # (offsets are unsigned 32-bit)
         final = self.batch.records.cpu().numpy().astype("int64")           # (an unmatched read's line carries its final name)
@@ -287,6 +287,7 @@ class TrimPipeline(object):
         matched = torch.zeros((n,), dtype=torch.uint8, device=begin.device)
         ubegin = uend = None
         self._rounds = [] if self.aux else None
+        unmasked = None
         self._last_which = (torch.zeros((n,), dtype=torch.int64, device=begin.device)
                             if ("{name}" in self.prefix or "{name}" in self.suffix) else None)
         for op in self.op_order:
@@ -294,6 +295,8 @@ class TrimPipeline(object):
                 if self.adapters:
                     matched, ubegin, uend = self._adapter_stage(batch, begin, end)
                     if ubegin is not None and mask_before_later_stages(self.op_order, self.action):
+                        if self._rounds is not None:          # (the info / rest / wildcard lines show the read a match saw)
+                            unmasked = batch.data.clone()
                         write_mask(batch, begin, end, ubegin, uend)
                         ubegin = uend = None
             else:
@@ -302,7 +305,8 @@ class TrimPipeline(object):
         rounds, self._rounds = self._rounds, None
         if self.zero_cap and n:
             self._zero_cap(batch)
-        read_batch = batch
+        read_batch = batch if unmasked is None else FastqBatch(unmasked, batch.nbytes, batch.records, batch.backend,
+                                                               batch.line_ends)
         if self._name_mods and n:
             batch = self._rewrite_names(batch, begin, end, matched)
         self._last_which = None
@@ -436,7 +440,10 @@ class PairedTrimResult(object):
         """The info / rest / wildcard lines of the pairs: read 1's, then read 2's, pair after pair
         (Formatters.format calls every info formatter on read 1 and on read 2, writers.py:156-159)."""
         l1, l2 = self.read1.aux_lines(kinds), self.read2.aux_lines(kinds)
-        return {k: "".join(line + "\n" for a, b in zip(l1[k], l2[k]) for line in a + b).encode("ascii", "replace") for k in kinds}
+        # (`if read2:` in Formatters.format: a read 2 that was trimmed to nothing is false and gets no lines)
+        has2 = (self.read2.end > self.read2.begin).cpu().tolist()
+        return {k: "".join(line + "\n" for a, b, two in zip(l1[k], l2[k], has2) for line in (a + b if two else a)).encode("ascii", "replace")
+                for k in kinds}
 
     def merged_text(self):
         """FASTQ text of the merged reads (the --merged-output file), in input order."""
@@ -682,6 +689,7 @@ class PairedTrimPipeline(object):
         extra = [(torch.zeros((n,), dtype=torch.uint8, device=dev), None, None) for _ in range(2)]
         pipes, batches = (self.p1, self.p2), [batch1, batch2]
         insert_matched = already_corrected = None
+        unmasked = [None, None]
         for pipe in pipes:
             pipe._rounds = [] if self.aux else None
             pipe._last_which = (torch.zeros((n,), dtype=torch.int64, device=dev)
@@ -697,6 +705,8 @@ class PairedTrimPipeline(object):
                             extra[k] = pipes[k]._adapter_stage(batches[k], st[k][0], st[k][1])
                 for k in range(2):
                     if extra[k][1] is not None and mask_before_later_stages(self.op_order, self.action):
+                        if pipes[k]._rounds is not None:
+                            unmasked[k] = batches[k].data.clone()
                         write_mask(batches[k], st[k][0], st[k][1], extra[k][1], extra[k][2])
                         extra[k] = (extra[k][0], None, None)
             else:
@@ -722,6 +732,8 @@ class PairedTrimPipeline(object):
         res = []
         for k in range(2):
             pipe, read_batch = pipes[k], batches[k]
+            if unmasked[k] is not None:
+                read_batch = FastqBatch(unmasked[k], read_batch.nbytes, read_batch.records, read_batch.backend, read_batch.line_ends)
             rounds, pipe._rounds = pipe._rounds, None
             if pipe.zero_cap and n:
                 pipe._zero_cap(batches[k])

@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--insert", action="store_true", help="paired-end with the insert aligner (+ error correction)")
     ap.add_argument("--long", action="store_true", help="reads of 150 .. 300 bases (MiSeq lengths)")
     ap.add_argument("--merge", action="store_true", help="paired-end modes: add --merge-overlapping options (third output file)")
+    ap.add_argument("--aux", action="store_true", help="adapter aligner: add --info-file / --rest-file / --wildcard-file, the "
+                    "read-name modifiers, -z and the extra output files, and compare every file")
     ap.add_argument("--scratch", default="/tmp/oracle_ref")
     o = ap.parse_args()
     sys.path.insert(0, o.scratch)
@@ -249,6 +251,33 @@ def main():
                 if "--correct-mismatches" not in args and rng.random() < 0.5:
                     args += ["--correct-mismatches", rng.choice(["liberal", "conservative", "N"])]
                 paths.append(os.path.join(tmp, "merged.fq"))
+            aux = {}
+            if o.aux and not o.insert and not merging:
+                # adapters get names (the reference numbers unnamed ones with a process-wide counter)
+                args = list(args)
+                for i, a in enumerate(args):
+                    if i and args[i - 1] in ("-a", "-g", "-b", "-A") and "=" not in a and "..." not in a:
+                        args[i] = "ad%d=%s" % (i, a)
+                if rng.random() < 0.5:
+                    data1 = data1.replace(b" extra\n", b" length=77 x\n")
+                    open(paths[0], "wb").write(data1)
+                for kind, flag in (("info", "--info-file"), ("rest", "--rest-file"), ("wildcard", "--wildcard-file")):
+                    if rng.random() < 0.6 and not any("..." in a for a in args):
+                        aux[kind] = os.path.join(tmp, kind + ".txt")
+                        args += [flag, aux[kind]]
+                if rng.random() < 0.4:
+                    args += ["--length-tag", "length="]
+                if rng.random() < 0.3:
+                    args += ["--strip-suffix", rng.choice([" x", "extra", "7 x"])]
+                if rng.random() < 0.4 and not any("..." in a for a in args):
+                    args += ["-x", rng.choice(["p_", "{name}:"])]
+                if rng.random() < 0.3 and not any("..." in a for a in args):
+                    args += ["-y", rng.choice(["_s", "/{name}"])]
+                if rng.random() < 0.2:
+                    args += ["-z"]
+                for kind in aux:
+                    if os.path.exists(aux[kind]):
+                        os.remove(aux[kind])
             params = list(args)
             if o.paired:
                 open(paths[1], "wb").write(data2)
@@ -278,9 +307,20 @@ def main():
                 continue
             # (the reference creates an output file with the first record that goes there: no merged read, no file)
             want = [open(p, "rb").read() if os.path.exists(p) else b"" for p in (paths[2:] if o.paired else paths[2:3])]
+            want += [open(p, "rb").read() if os.path.exists(p) else b"" for p in aux.values()]
             try:
                 pipe = pipeline_from_args(args)
-                if merging:
+                if aux:
+                    from atropos_amd.fastq import FastqBatch
+                    if o.paired:
+                        res = pipe.run(FastqBatch.from_bytes(data1, final=True)[0], FastqBatch.from_bytes(data2, final=True)[0])
+                        got = tuple(res.text())
+                    else:
+                        res = pipe.run(FastqBatch.from_bytes(data1, final=True)[0])
+                        got = (res.text(),)
+                    texts = res.aux_text(tuple(aux))
+                    got += tuple(texts[k] for k in aux)
+                elif merging:
                     from atropos_amd.fastq import FastqBatch
                     res = pipe.run(FastqBatch.from_bytes(data1, final=True)[0], FastqBatch.from_bytes(data2, final=True)[0])
                     got = res.text() + (res.merged_text(),)
