@@ -810,11 +810,34 @@ class PairedTrimPipeline(object):
         return self.run(b1, b2).text(which)
 
 
-def pipeline_from_args(argv):
+class LegacyPairedPipeline(PairedTrimPipeline):
+    """Paired-end input without any option that switches full paired-end trimming on (-A / -G / -B / -U, -q,
+    --trim-n, --pair-filter ...): the reference's backwards-compatible 'legacy mode' (trim/cli.py:630-648) -- the
+    single-end pipeline on read 1, its filters on read 1 alone (FilterFactory wraps them in SingleWrapper,
+    filters.py:100-107), read 2 written as it came for every pair that is kept."""
+
+    def __init__(self, first):
+        self.first = first
+        self.merge_overlapping, self.aux, self.outputs = False, None, {}
+        self.p1 = first
+
+    def run(self, batch1, batch2):
+        if len(batch1) != len(batch2):
+            raise ValueError("the two FASTQ batches hold different numbers of records")
+        res1 = self.first.run(batch1)
+        n = len(batch2)
+        dev = batch2.records.device
+        res2 = TrimResult(batch2, torch.zeros((n,), dtype=torch.int32, device=dev), batch2.seq_lens.clone(), None, None,
+                          torch.zeros((n,), dtype=torch.uint8, device=dev), res1.dest)
+        return PairedTrimResult(res1, res2)
+
+
+def pipeline_from_args(argv, paired_input=False):
     """Build a TrimPipeline (or, when paired-end options are present, a PairedTrimPipeline) from
     the subset of ``atropos trim`` command-line options the device pipeline covers (same
     spellings and defaults as trim/cli.py:57-335, :455-530, :655-803).  Anything else raises --
-    the caller then uses the per-read object path."""
+    the caller then uses the per-read object path.  ``paired_input``: the reads come as pairs (-pe1 / -pe2); without
+    an option that asks for full paired-end trimming that is the reference's legacy mode (LegacyPairedPipeline)."""
     import argparse
     from .adapters import AdapterParser
     if isinstance(argv, str):
@@ -875,6 +898,12 @@ def pipeline_from_args(argv):
     o = ap.parse_args(argv)
     paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert" or
                   o.merge_overlapping)
+    if paired_input and not paired:
+        # cli.py:630-641: these also switch legacy mode off
+        paired = bool(o.quality_cutoff or o.trim_n or o.too_short_paired_output or o.too_long_paired_output)
+        legacy = not paired
+    else:
+        legacy = False
     if o.merge_min_overlap <= 0:
         raise ValueError("--merge-min-overlap must be positive")          # positive(float, True), cli.py:206-207
     if o.merge_overlapping and o.merge_error_rate is None:
@@ -943,9 +972,12 @@ def pipeline_from_args(argv):
             raise NotImplementedError("paired-end input: --too-short-output / --too-long-output / --untrimmed-output need "
                                       "their --*-paired-output as well")
         outputs = {kind: (path, second[kind]) for kind, path in outputs.items()}
+    if legacy and (aux or outputs or o.length_tag or o.strip_suffix or o.prefix or o.suffix or o.zero_cap):
+        raise NotImplementedError("side files and read-name modifiers with paired-end input in legacy mode")
     if not paired:
-        return TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
-                            strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
+        first = TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
+                             strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
+        return LegacyPairedPipeline(first) if legacy else first
     return PairedTrimPipeline(outputs=outputs or None, aux=aux or None, length_tag=o.length_tag, strip_suffix=o.strip_suffix, prefix=o.prefix,
                               suffix=o.suffix, zero_cap=o.zero_cap, adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,

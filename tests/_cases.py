@@ -1133,7 +1133,7 @@ def check_trim_golden_paired():
         args = case["args"]
         for kind in case.get("aux", {}):
             args = args.replace("{%s}" % kind, kind + ".txt")
-        pipe = pipeline_from_args(args)
+        pipe = pipeline_from_args(args, paired_input=True)
         assert isinstance(pipe, PairedTrimPipeline), label
         from atropos_amd.fastq import FastqBatch
         b1, _ = FastqBatch.from_bytes(inputs[case["input1"]], final=True)

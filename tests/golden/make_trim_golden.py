@@ -278,6 +278,10 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.3 --correct-mismatches N -q 15 -m 20 --pair-filter both" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -R --merge-min-overlap 0.25 --correct-mismatches liberal -e 0.2" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-R --merge-min-overlap 12 -u 2 -U 3 --trim-n"),
+    # legacy mode (-p without -A / -G / -B / -U, -q, --trim-n ...: only read 1 is modified and filtered, cli.py:630-648)
+    ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -m 14"),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -e 0.12 -n 2 -m 40 -M 140 --discard-untrimmed -u 2" % PE1),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-b %s --mask-adapter --max-n 3" % PE1[:25]),
     # the filtered pairs into files of their own
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 60 --too-short-output {too_short} --too-short-paired-output {too_short2} --untrimmed-output {untrimmed} --untrimmed-paired-output {untrimmed2}" % (PE1, PE2)),
     # masked adapters and merging: MergeOverlapping sees the reads with their N's

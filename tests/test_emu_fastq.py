@@ -41,7 +41,7 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
 
 
 def test_paired_pipeline_reference_cli_cases(emu_backend):
-    assert _cases.check_trim_golden_paired() >= 40
+    assert _cases.check_trim_golden_paired() >= 43
 
 
 def test_paired_file_chunking(emu_backend, tmp_path):
