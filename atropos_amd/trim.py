@@ -150,8 +150,15 @@ class TrimPipeline(object):
     def __init__(self, adapters=(), times=1, action="trim", cut=(), nextseq_trim=None, quality_cutoff=None,
                  quality_base=33, trim_n=False, minimum_length=None, maximum_length=None, max_n=None,
                  discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW", aux=None, length_tag=None,
-                 strip_suffix=(), prefix="", suffix="", zero_cap=False, outputs=None):
+                 strip_suffix=(), prefix="", suffix="", zero_cap=False, outputs=None, cut_min=()):
         self.adapters = list(adapters)
+        # --cut-min: MinCutter with its defaults (modifiers.py:587-650; after --trim-n, trim/__init__.py:520-524)
+        cut_min = list(cut_min or ())
+        self.min_front = sum(c for c in cut_min if c > 0)
+        self.min_back = -sum(c for c in cut_min if c < 0)
+        if (self.min_front or self.min_back) and action != "trim":
+            raise NotImplementedError("--cut-min with --mask-adapter / --no-trim (a match counts as trimmed bases that "
+                                      "are still there)")
         # --too-short-output / --too-long-output / --untrimmed-output: {"too_short" | "too_long" | "untrimmed": path};
         # the untrimmed file switches the UntrimmedFilter on like --discard-untrimmed (trim/__init__.py:617-630)
         self.outputs = dict(outputs) if outputs else {}
@@ -273,6 +280,15 @@ class TrimPipeline(object):
         be = batch.backend
         if self.trim_n:
             be.nend_trim_batch(batch.data, batch.records, begin, end, ubegin, uend)
+        if self.min_front or self.min_back:
+            # at least min_front / min_back bases gone from the two ends, whatever removed them so far: everything that
+            # was cut, quality-trimmed or adapter-trimmed is in the interval (clipped[] + the matches' rsize_total)
+            live = end > begin                                            # Trimmer.clip leaves an empty read alone
+            total = batch.seq_lens
+            nb = torch.minimum(torch.maximum(begin, torch.full_like(begin, self.min_front)), end)
+            ne = torch.maximum(torch.minimum(end, total - self.min_back), nb)
+            begin.copy_(torch.where(live, nb, begin))
+            end.copy_(torch.where(live, ne, end))
         min_len = self.minimum_length if self.minimum_length is not None and self.minimum_length > 0 else 0
         max_len = self.maximum_length if self.maximum_length is not None else -1
         max_n = float(self.max_n) if self.max_n is not None else -1.0
@@ -471,7 +487,7 @@ class PairedTrimPipeline(object):
                  maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
                  op_order="CGQAW", insert_args=None, correct_mismatches=None, merge_overlapping=False,
                  merge_min_overlap=0.9, merge_error_rate=0.2, aux=None, length_tag=None, strip_suffix=(), prefix="",
-                 suffix="", zero_cap=False, outputs=None):
+                 suffix="", zero_cap=False, outputs=None, cut_min=(), cut_min2=()):
         # {"too_short" | "too_long" | "untrimmed": (path for read 1, path for read 2)}: the filtered pairs' own files
         self.outputs = dict(outputs) if outputs else {}
         if "untrimmed" in self.outputs:
@@ -485,8 +501,8 @@ class PairedTrimPipeline(object):
         if (aux or length_tag or strip_suffix or prefix or suffix or zero_cap) and (aligner != "adapter" or merge_overlapping):
             raise NotImplementedError("--info-file / --rest-file / --wildcard-file, read-name modifiers and --zero-cap with "
                                       "the insert aligner or with merging")
-        self.p1 = TrimPipeline(adapters=adapters1, cut=cut, **common)
-        self.p2 = TrimPipeline(adapters=adapters2, cut=cut2, **common)
+        self.p1 = TrimPipeline(adapters=adapters1, cut=cut, cut_min=cut_min, **common)
+        self.p2 = TrimPipeline(adapters=adapters2, cut=cut2, cut_min=cut_min2, **common)
         self.aligner, self.action, self.op_order = aligner, action, op_order
         if pair_filter not in ("any", "both"):
             raise ValueError("pair_filter must be 'any' or 'both'")
@@ -867,6 +883,8 @@ def pipeline_from_args(argv, paired_input=False):
     ap.add_argument("--op-order", default="CGQAW")
     ap.add_argument("-u", "--cut", type=int, action="append", default=[])
     ap.add_argument("-U", type=int, action="append", default=[], dest="cut2")
+    ap.add_argument("--cut-min", type=int, action="append", default=[])
+    ap.add_argument("--cut-min2", type=int, action="append", default=[])
     ap.add_argument("-q", "--quality-cutoff", default=None)
     ap.add_argument("--quality-base", type=int, default=33)
     ap.add_argument("--nextseq-trim", type=int, default=None)
@@ -896,8 +914,13 @@ def pipeline_from_args(argv, paired_input=False):
     ap.add_argument("--rest-file", "-r", default=None)
     ap.add_argument("--wildcard-file", default=None)
     o = ap.parse_args(argv)
-    paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.pair_filter or o.aligner == "insert" or
+    paired = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.cut_min2 or o.pair_filter or o.aligner == "insert" or
                   o.merge_overlapping)
+    for cm in (o.cut_min, o.cut_min2):                                     # cli.py:810-830
+        if len(cm) > 2:
+            raise ValueError("You cannot remove bases from more than two ends.")
+        if len(cm) == 2 and cm[0] * cm[1] > 0:
+            raise ValueError("You cannot remove bases from the same end twice.")
     if paired_input and not paired:
         # cli.py:630-641: these also switch legacy mode off
         paired = bool(o.quality_cutoff or o.trim_n or o.too_short_paired_output or o.too_long_paired_output)
@@ -975,11 +998,12 @@ def pipeline_from_args(argv, paired_input=False):
     if legacy and (aux or outputs or o.length_tag or o.strip_suffix or o.prefix or o.suffix or o.zero_cap):
         raise NotImplementedError("side files and read-name modifiers with paired-end input in legacy mode")
     if not paired:
-        first = TrimPipeline(adapters=adapters, cut=o.cut, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
+        first = TrimPipeline(adapters=adapters, cut=o.cut, cut_min=o.cut_min, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
                              strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
         return LegacyPairedPipeline(first) if legacy else first
     return PairedTrimPipeline(outputs=outputs or None, aux=aux or None, length_tag=o.length_tag, strip_suffix=o.strip_suffix, prefix=o.prefix,
                               suffix=o.suffix, zero_cap=o.zero_cap, adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
+                              cut_min=o.cut_min, cut_min2=o.cut_min2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,
                               merge_min_overlap=o.merge_min_overlap,

@@ -224,6 +224,9 @@ CASES = [
     # the filtered reads into files of their own (trim/__init__.py:580-630)
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 20 -m 40 -M 95 --too-short-output {too_short} --too-long-output {too_long} --untrimmed-output {untrimmed}"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " -m 30 --max-n 1 --mask-adapter --too-short-output {too_short} --untrimmed-output {untrimmed}"),
+    # --cut-min: at least that many bases gone from an end, whatever removed them (MinCutter, modifiers.py:587-650)
+    ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15,20 --trim-n --cut-min 6 --cut-min -12 -m 10"),
+    ("synth.fastq", "-g head=" + TRUSEQ[:20] + " -a tru=" + TRUSEQ + " -u 3 --cut-min 25 -n 2"),
     # read-name modifiers and the quality cap (modifiers.py:652-720)
     ("small.fastq", "-a ad=TTAGACATATCTCCGTCG -x pre_{name}_ -y _suf --strip-suffix /1 --strip-suffix _573"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15 --length-tag comment= -y :{name} --strip-suffix 7"),
@@ -282,6 +285,8 @@ PAIRED_CASES = [
     ("paired.1.fastq", "paired.2.fastq", "-a TTAGACATAT -m 14"),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -e 0.12 -n 2 -m 40 -M 140 --discard-untrimmed -u 2" % PE1),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-b %s --mask-adapter --max-n 3" % PE1[:25]),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 --cut-min 5 --cut-min2 -8 -m 20" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --cut-min -10 --cut-min2 4 --cut-min2 -4" % (PE1, PE2)),
     # the filtered pairs into files of their own
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 60 --too-short-output {too_short} --too-short-paired-output {too_short2} --untrimmed-output {untrimmed} --untrimmed-paired-output {untrimmed2}" % (PE1, PE2)),
     # masked adapters and merging: MergeOverlapping sees the reads with their N's
