@@ -195,6 +195,8 @@ class TrimPipeline(object):
         self._linked = bool(linked)
         if self.aux and self._linked:
             raise NotImplementedError("--info-file / --rest-file / --wildcard-file with linked adapters")
+        if self._linked and (self.min_front or self.min_back):
+            raise NotImplementedError("--cut-min with linked adapters (what a LinkedMatch counts as trimmed is not the interval)")
         if self._linked and ("{name}" in self.prefix or "{name}" in self.suffix):
             raise NotImplementedError("{name} in --prefix / --suffix with linked adapters")
 

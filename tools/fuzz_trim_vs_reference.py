@@ -206,6 +206,12 @@ def random_args(rng, paired):
         args += ["--op-order", "".join(order)]
     if paired and rng.random() < 0.3:
         args += ["--pair-filter", rng.choice(["any", "both"])]
+    if "--mask-adapter" not in args and "--no-trim" not in args and rng.random() < 0.2:
+        args += ["--cut-min", str(rng.choice([3, 10, 30, -4, -15]))]
+        if rng.random() < 0.3:
+            args += ["--cut-min", str(-6 if int(args[-1]) > 0 else 6)]
+        if paired and rng.random() < 0.5:
+            args += ["--cut-min2", str(rng.choice([5, -7]))]
     return adapters, args
 
 
