@@ -327,7 +327,9 @@ class StageClock(object):
 class ChunkedFastqReader(object):
     """Feeds a FASTQ file to the GPU in chunks of whole records.  The file is read straight into
     two page-locked staging buffers (``IO_THREADS`` ``pread`` slices per chunk, no intermediate
-    bytes objects); the next chunk is read while the caller works on the current one."""
+    bytes objects); the next chunk is read while the caller works on the current one.
+    ``.gz`` / ``.bz2`` / ``.xz`` input (what the reference's xopen opens by extension) is decompressed by the
+    read-ahead thread straight into the staging buffer -- one host thread: the decompressor then sets the pace."""
 
     def __init__(self, path, chunk_bytes, backend=None, clock=None):
         import os
@@ -342,6 +344,17 @@ class ChunkedFastqReader(object):
         self.fd = self.file.fileno()
         self.size = os.path.getsize(path)
         self.pos = 0
+        self.stream = None
+        name = str(path)
+        if name.endswith(".gz"):
+            import gzip
+            self.stream = gzip.open(self.file, "rb")
+        elif name.endswith(".bz2"):
+            import bz2
+            self.stream = bz2.open(self.file, "rb")
+        elif name.endswith(".xz"):
+            import lzma
+            self.stream = lzma.open(self.file, "rb")
         self.readers = ThreadPoolExecutor(IO_THREADS)
         self.ahead = ThreadPoolExecutor(1)
         self.k = 0
@@ -366,16 +379,25 @@ class ChunkedFastqReader(object):
         want = max(self.chunk_bytes - n0, min(self.chunk_bytes // 4, room))
         if want <= 0:
             raise ValueError("FASTQ record of more than %d bytes" % self.buf[k].numel())
-        want = min(want, room, self.size - self.pos)
-        step = ((want + IO_THREADS - 1) // IO_THREADS + 4095) & ~4095
-        jobs = []
-        for t in range(IO_THREADS):
-            lo, hi = t * step, min(want, (t + 1) * step)
-            if hi > lo:
-                jobs.append(self.readers.submit(os.preadv, self.fd, [view[n0 + lo:n0 + hi]], self.pos + lo))
-        got = sum(j.result() for j in jobs)
-        self.pos += got
-        nbytes, final = n0 + got, self.pos >= self.size
+        if self.stream is not None:                           # compressed input: sequential, until the chunk is full or the end
+            want, got = min(want, room), 0
+            while got < want:
+                n = self.stream.readinto(view[n0 + got:n0 + want])
+                if not n:
+                    break
+                got += n
+            nbytes, final = n0 + got, got < want
+        else:
+            want = min(want, room, self.size - self.pos)
+            step = ((want + IO_THREADS - 1) // IO_THREADS + 4095) & ~4095
+            jobs = []
+            for t in range(IO_THREADS):
+                lo, hi = t * step, min(want, (t + 1) * step)
+                if hi > lo:
+                    jobs.append(self.readers.submit(os.preadv, self.fd, [view[n0 + lo:n0 + hi]], self.pos + lo))
+            got = sum(j.result() for j in jobs)
+            self.pos += got
+            nbytes, final = n0 + got, self.pos >= self.size
         host = self.buf[k]
         unterminated = bool(final and nbytes and int(host[nbytes - 1]) not in (10, 13))
         if unterminated:
@@ -615,8 +637,51 @@ class PartSink(object):
             raise first
 
 
+class CompressedSink(object):
+    """The output through a host compressor (``.gz`` / ``.bz2`` / ``.xz`` by extension, as the reference's xopen):
+    a writer thread takes the chunks in order, so that the GPU goes on with the next chunk while one is compressed.
+    One host thread compresses -- it sets the pace of the whole run (pigz-style parallel blocks: the caller's pipe)."""
+
+    def __init__(self, path, clock=None):
+        from concurrent.futures import ThreadPoolExecutor
+        name = str(path)
+        if name.endswith(".gz"):
+            import gzip
+            self.fh = gzip.open(name, "wb", compresslevel=6)
+        elif name.endswith(".bz2"):
+            import bz2
+            self.fh = bz2.open(name, "wb")
+        else:
+            import lzma
+            self.fh = lzma.open(name, "wb")
+        self.clock = clock or StageClock()
+        self.writer = ThreadPoolExecutor(1)
+        self.pending = []
+
+    def write(self, text):
+        import time
+        t0 = time.perf_counter()
+        while len(self.pending) > 2:                          # (bounded: at most three chunks in flight)
+            self.pending.pop(0).result()
+        self.clock.add("wait_file_write", t0)
+        host = text.cpu() if torch.is_tensor(text) else text  # the device -> host copy, then the compressor's turn
+        self.pending.append(self.writer.submit(lambda h: self.fh.write(bytes(h.numpy().tobytes()) if torch.is_tensor(h) else h), host))
+
+    def close(self):
+        try:
+            for job in self.pending:
+                job.result()
+        finally:
+            self.writer.shutdown()
+            self.fh.close()
+
+
 def make_sink(path, parts, capacity, backend=None, clock=None, keep=False):
-    """One file, or ``parts`` > 1 part files (PartSink)."""
+    """One file, or ``parts`` > 1 part files (PartSink); a compressed file by its extension (CompressedSink)."""
+    if str(path).endswith((".gz", ".bz2", ".xz")):
+        if parts and int(parts) > 1:
+            raise ValueError("part files of a compressed output are not provided")
+        return CompressedSink(path, clock)
     if parts and int(parts) > 1:
         return PartSink(path, parts, capacity, backend, clock, keep)
     return FastqSink(path, capacity, backend, clock, keep=keep)

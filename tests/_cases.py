@@ -980,6 +980,21 @@ def check_fastq_chunking(tmp_path):
     counts = pipe.trim_file(str(src), str(dst), chunk_bytes=50000)
     assert dst.read_bytes() == whole
     assert sum(counts.values()) == data.count(b"\n") // 4
+    # compressed input (.gz / .bz2 / .xz, the extensions the reference's xopen knows), chunks that end inside a record
+    import bz2
+    import gzip
+    import lzma
+    for ext, mod in ((".gz", gzip), (".bz2", bz2), (".xz", lzma)):
+        zsrc = tmp_path / ("in.fastq" + ext)
+        with mod.open(str(zsrc), "wb") as fh:
+            fh.write(data)
+        zdst = tmp_path / ("out_from" + ext + ".fastq")
+        assert pipe.trim_file(str(zsrc), str(zdst), chunk_bytes=37000) == counts
+        assert zdst.read_bytes() == whole
+        zout = tmp_path / ("out.fastq" + ext)                 # ... and compressed output
+        assert pipe.trim_file(str(src), str(zout), chunk_bytes=41000) == counts
+        with mod.open(str(zout), "rb") as fh:
+            assert fh.read() == whole
     # the output as three part files with a writer each: chunk k in part k mod 3, in order inside a part -- the records
     # of all parts are those of the single file
     (tmp_path / "out.fastq.part3").write_bytes(b"stale part of an earlier run with more parts\n")
