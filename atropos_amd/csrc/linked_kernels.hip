@@ -289,20 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     uint32_t at = 0u;
                     if (lane == 0) at = atomicAdd(&s_lcur, (uint32_t)__popcll(om));
                     at = (uint32_t)rfl((int)at);
-                    if (open) {
-                        // a band read: the 64 codes from its first diagonal on go into the list's record (what the band
-                        // kernel would gather from the batch, 16 bytes per 128-byte line: 400 MB per C4 step), read here
-                        // through the lane's own pointer while the read is hot in L2
-                        const long long slot = t0 * 64 + at + __popcll(om & ((1ull << lane) - 1ull));
-                        const bool dense = window_band(ww) && band_stream_dwords(mb) <= 8;     // (64 codes: adapters to 47 rows)
-                        wk.tmp[slot] = make_uint2((uint32_t)r, dense ? ww : (ww | PIECE_NODENSE));
-                        if (dense) {
-                            uint32_t d[8];
-                            band_stage((const uint32_t *)tp, nchunks, window_lo(ww), d, 1, 8);
-                            wk.tdata[2 * (size_t)slot] = make_uint4(d[0], d[1], d[2], d[3]);
-                            wk.tdata[2 * (size_t)slot + 1] = make_uint4(d[4], d[5], d[6], d[7]);
-                        }
-                    }
+                    if (open) wk.tmp[t0 * 64 + at + __popcll(om & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)r, ww);
                 }
             }
         }
@@ -373,19 +360,7 @@ __global__ __launch_bounds__(256) void linked_band_kernel(const LinkedWaveBlob *
         const int smax = min(BAND_W - 1, wave_max_i32(s_lane));
         const uint32_t *q = (const uint32_t *)(packed + ((size_t)(r >> 6) * nchunks) * 64 + (r & 63));
         uint32_t *ns = &s_stream[wave][0][lane];
-        {
-            // the record the filter kernel wrote (two coalesced 16-byte loads per lane), or gathered from the batch
-            const bool dense = live && (ww & PIECE_NODENSE) == 0u;
-            if (dense) {
-                const uint32_t di = wk.dref[slot];
-                const uint4 x = wk.tdata[2 * (size_t)di], y = wk.tdata[2 * (size_t)di + 1];
-                ns[0] = x.x; ns[64] = x.y; ns[128] = x.z; ns[192] = x.w;
-                ns[256] = y.x; ns[320] = y.y; ns[384] = y.z; ns[448] = y.w;
-            }
-            if (wave_max_i32(live && !dense ? 1 : 0) != 0) {
-                if (!dense) band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
-            }
-        }
+        band_stage(q, nchunks, window_lo(ww), ns, 64, band_stream_dwords(u.m));
         uint32_t rec[4] = {0xFFFF0000u, 0u, 0u, 0u};
         const int16_t *thr = s_thr[a];
         if (any_rowm) band_locate<AND_MODE>(u, bp.rrep, bp.noindel != 0, ns, 64, n, ww, smax, thr, rec);
@@ -474,9 +449,7 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
         for (uint32_t i = threadIdx.x; i < count; i += 256) {
             const uint2 e = list[i];
             const int which = (int)(which_out[e.x] & 0xFFu);
-            const uint32_t slot = atomicAdd(&s_cur[linked_bin(e.y & ~PIECE_NODENSE, which, ms.m[which], by_rows != 0)], 1u);
-            wk.order[slot] = e;
-            wk.dref[slot] = (uint32_t)(t0 * 64) + i;              // the entry's 64-code record in tdata
+            wk.order[atomicAdd(&s_cur[linked_bin(e.y, which, ms.m[which], by_rows != 0)], 1u)] = e;
         }
         return;
     }
@@ -484,7 +457,7 @@ __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, c
         const uint32_t ww = wk.win[r];
         if (window_valid(ww)) {
             const int which = (int)(which_out[r] & 0xFFu);
-            wk.order[atomicAdd(&s_cur[linked_bin(ww, which, ms.m[which], by_rows != 0)], 1u)] = make_uint2((uint32_t)r, ww | PIECE_NODENSE);
+            wk.order[atomicAdd(&s_cur[linked_bin(ww, which, ms.m[which], by_rows != 0)], 1u)] = make_uint2((uint32_t)r, ww);
         }
     }
 }

@@ -61,13 +61,12 @@ struct FastWork {                                    // carve-up of the caller's
 // reads whose planes the two-pass pre-pass copies for its full-sweep kernel (the others are gathered): a quarter
 inline long long fast_wide_cap(long long nreads) { return nreads / 4 + 16ll * FAST_BLOCKS + 64; }   // (+ 16 per block)
 
-// (the plane copies of the two-pass pre-pass only in the single-aligner workspace, nbins == FILTER_BINS; the 64-code
-// records of the band reads and their index also in a linked set's)
+// (the dense buffers of the two-pass pre-pass only in the single-aligner workspace, nbins == FILTER_BINS)
 inline size_t fast_work_bytes(long long nreads, int nbins = FILTER_BINS) {
     const bool pieces = nbins == FILTER_BINS;
     return (size_t)nreads * 20 + (size_t)((nreads + 63) / 64) * 8 + (size_t)(FAST_BLOCKS + FAST_BLOCKS / 64) * nbins * 4 + (size_t)(nbins + 1) * 4 +
-           (size_t)FAST_BLOCKS * 4 + 256 + 64 + (size_t)nreads * (32 + 4) +                                    // tdata, dref
-           (pieces ? (size_t)fast_wide_cap(nreads) * PIECE_MAX_WORDS * 16 : 0);                                // wdata
+           (size_t)FAST_BLOCKS * 4 + 256 + 64 +
+           (pieces ? (size_t)nreads * (32 + 4) + (size_t)fast_wide_cap(nreads) * PIECE_MAX_WORDS * 16 : 0);   // tdata, dref, wdata
 }
 
 inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS) {
@@ -84,10 +83,10 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.wide = w.win;
     w.tmp = (uint2 *)(((uintptr_t)(w.nwide + 1) + 7) & ~(uintptr_t)7);
     w.tdata = (uint4 *)(((uintptr_t)(w.tmp + nreads) + 15) & ~(uintptr_t)15);
-    w.dref = (uint32_t *)(w.tdata + (size_t)nreads * 2);
-    w.wdata = (uint4 *)(((uintptr_t)(w.dref + nreads) + 15) & ~(uintptr_t)15);
+    w.wdata = w.tdata + (size_t)nreads * 2;
     w.wcap = fast_wide_cap(nreads);
-    if (nbins != FILTER_BINS) { w.wdata = nullptr; w.wcap = 0; }
+    w.dref = (uint32_t *)(w.wdata + (size_t)w.wcap * PIECE_MAX_WORDS);
+    if (nbins != FILTER_BINS) { w.tdata = nullptr; w.wdata = nullptr; w.dref = nullptr; w.wcap = 0; }
     w.nbins = nbins;
     w.nused = FAST_BLOCKS;
     w.lpw = 64;
