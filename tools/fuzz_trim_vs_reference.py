@@ -249,7 +249,7 @@ def main():
                 data2 = make_reads(rng, n, adapters, L) if o.paired else None
             paths = [os.path.join(tmp, x) for x in ("i1.fq", "i2.fq", "o1.fq", "o2.fq")]
             open(paths[0], "wb").write(data1)
-            merging = o.merge and o.paired and rng.random() < 0.8 and "--mask-adapter" not in args
+            merging = o.merge and o.paired and rng.random() < 0.8
             if merging:
                 args = list(args) + ["-R", "--merge-min-overlap", str(rng.choice([0.3, 0.5, 0.9, 8, 20]))]
                 if rng.random() < 0.5:
