@@ -150,8 +150,12 @@ class TrimPipeline(object):
     def __init__(self, adapters=(), times=1, action="trim", cut=(), nextseq_trim=None, quality_cutoff=None,
                  quality_base=33, trim_n=False, minimum_length=None, maximum_length=None, max_n=None,
                  discard_trimmed=False, discard_untrimmed=False, op_order="CGQAW", aux=None, length_tag=None,
-                 strip_suffix=(), prefix="", suffix="", zero_cap=False, outputs=None, cut_min=()):
+                 strip_suffix=(), prefix="", suffix="", zero_cap=False, outputs=None, cut_min=(), bisulfite=None):
         self.adapters = list(adapters)
+        # --bisulfite: a list of cutters applied after the op-order stages and before --trim-n (trim/__init__.py:497-516):
+        # ("min", front, back, count_trimmed, only_trimmed) = MinCutter, ("nondir", rrbs) = NonDirectionalBisulfiteTrimmer
+        self.bisulfite = list(bisulfite or ())
+        self._sides = None                                                # per read: [any 5' match, any 3' match] (bisulfite)
         # --cut-min: MinCutter with its defaults (modifiers.py:587-650; after --trim-n, trim/__init__.py:520-524)
         cut_min = list(cut_min or ())
         self.min_front = sum(c for c in cut_min if c > 0)
@@ -195,6 +199,13 @@ class TrimPipeline(object):
         self._linked = bool(linked)
         if self.aux and self._linked:
             raise NotImplementedError("--info-file / --rest-file / --wildcard-file with linked adapters")
+        if self.bisulfite:
+            if self._linked:
+                raise NotImplementedError("--bisulfite with linked adapters")
+            for spec in self.bisulfite:
+                if action != "trim" and (spec[0] == "nondir" or spec[3]):
+                    raise NotImplementedError("--bisulfite cutters that count the adapters' bases or look at the read's "
+                                              "first bases, with --mask-adapter / --no-trim")
         if self._linked and (self.min_front or self.min_back):
             raise NotImplementedError("--cut-min with linked adapters (what a LinkedMatch counts as trimmed is not the interval)")
         if self._linked and ("{name}" in self.prefix or "{name}" in self.suffix):
@@ -227,6 +238,11 @@ class TrimPipeline(object):
             self._rounds.append((took, best.clone(), which.clone(), begin.clone(), end.clone()))
         if self._last_which is not None:
             self._last_which = torch.where(took, which, self._last_which)
+        if self._sides is not None:                                       # Match.front / _guess_is_front of this round's match
+            code = codes[which]
+            is_front = torch.where(code == 2, best[:, 2] == 0, code == 1)
+            self._sides[0] |= took & is_front
+            self._sides[1] |= took & ~is_front
         be.match_trim_batch(best.contiguous(), front, int(codes[0].item()), begin, end, active, matched)
 
     def _round_linked(self, batch, begin, end, active, matched):
@@ -248,6 +264,8 @@ class TrimPipeline(object):
         if not self.adapters or n == 0:
             return matched, None, None
         before_b, before_e = begin.clone(), end.clone()
+        if self.bisulfite:
+            self._sides = [torch.zeros((n,), dtype=torch.bool, device=dev), torch.zeros((n,), dtype=torch.bool, device=dev)]
         active = (end > begin).to(torch.uint8)                            # if len(read) == 0: return read
         for _ in range(self.times):
             if self._linked:
@@ -262,7 +280,57 @@ class TrimPipeline(object):
         elif self.action is None:                                         # :173-174
             begin.copy_(before_b)
             end.copy_(before_e)
+        if self.bisulfite:                                                # the interval right after the adapter stage
+            self._after = (begin.clone(), end.clone())
         return matched, ubegin, uend
+
+    def _bisulfite_stage(self, batch, begin, end, matched):
+        """MinCutter / RRBSTrimmer / NonDirectionalBisulfiteTrimmer (modifiers.py:587-650, :786-831) as interval
+        arithmetic.  What a cutter counts as already trimmed: with count_trimmed everything that is gone from that end
+        (Sequence.clipped + the matches' rsize_total = the interval); without, what the trimmers removed AFTER the
+        adapter stage for a read with a match (clipped[2], clipped[3]) and everything for a read without one."""
+        has = matched != 0
+        total = batch.seq_lens
+        after = getattr(self, "_after", None)
+        ab, ae = after if after is not None else (begin, end)
+        sides = self._sides if self._sides is not None else [torch.zeros_like(has), torch.zeros_like(has)]
+        for spec in self.bisulfite:
+            if spec[0] == "nondir":
+                # ^C[AG]A on the read as it is now -> two bases off the 5' end (counting only what was cut after a
+                # match); else, with rrbs, the RRBS cutter
+                off = (batch.records[:, 2].to(torch.int64) & 0xFFFFFFFF) + begin.to(torch.int64)
+                last = batch.data.numel() - 1
+                c0, c1, c2 = (batch.data[(off + k).clamp(max=last)] for k in range(3))
+                hit = (end - begin >= 3) & (c0 == 67) & ((c1 == 65) | (c1 == 71)) & (c2 == 65)
+                self._min_cut(begin, end, total, has, sides, ab, ae, 2, 0, False, False, hit)
+                if spec[1]:
+                    # (NonDirectionalBisulfiteTrimmer builds its RRBSTrimmer as RRBSTrimmer(trim_3p): the 2 lands in
+                    # trim_5p and trim_3p keeps its default -- two bases from EITHER trimmed end, modifiers.py:808-813)
+                    self._min_cut(begin, end, total, has, sides, ab, ae, 2, 2, False, True, ~hit & (end > begin))
+            else:
+                _kind, front, back, count_trimmed, only_trimmed = spec
+                self._min_cut(begin, end, total, has, sides, ab, ae, front, back, count_trimmed, only_trimmed, None)
+
+    @staticmethod
+    def _min_cut(begin, end, total, has, sides, ab, ae, front, back, count_trimmed, only_trimmed, where):
+        live = end > begin                                                # Trimmer.clip leaves an empty read alone
+        if where is not None:
+            live = live & where
+        trim_front = trim_back = live
+        if only_trimmed:                                                  # :612-621
+            trim_front = live & has & sides[0]
+            trim_back = live & has & sides[1]
+        if count_trimmed:
+            gone_f, gone_b = begin, total - end
+        else:
+            gone_f = torch.where(has, begin - ab, begin)
+            gone_b = torch.where(has, ae - end, total - end)
+        tf = torch.where(trim_front, (front - gone_f).clamp(min=0), torch.zeros_like(begin))
+        tb = torch.where(trim_back, (back - gone_b).clamp(min=0), torch.zeros_like(begin))
+        nb = torch.minimum(begin + tf, end)
+        ne = torch.maximum(end - tb, nb)
+        begin.copy_(nb)
+        end.copy_(ne)
 
     # ------------------------------------------------------------------ whole pipeline
     def _simple_stage(self, op, batch, begin, end):
@@ -280,6 +348,8 @@ class TrimPipeline(object):
     def _filter_stage(self, batch, begin, end, ubegin, uend, matched, masks=False):
         """--trim-n, then the read filters: destination byte per read (or the fail masks)."""
         be = batch.backend
+        if self.bisulfite:
+            self._bisulfite_stage(batch, begin, end, matched)
         if self.trim_n:
             be.nend_trim_batch(batch.data, batch.records, begin, end, ubegin, uend)
         if self.min_front or self.min_back:
@@ -305,6 +375,7 @@ class TrimPipeline(object):
         matched = torch.zeros((n,), dtype=torch.uint8, device=begin.device)
         ubegin = uend = None
         self._rounds = [] if self.aux else None
+        self._sides = self._after = None
         unmasked = None
         self._last_which = (torch.zeros((n,), dtype=torch.int64, device=begin.device)
                             if ("{name}" in self.prefix or "{name}" in self.suffix) else None)
@@ -489,7 +560,7 @@ class PairedTrimPipeline(object):
                  maximum_length=None, max_n=None, discard_trimmed=False, discard_untrimmed=False, pair_filter="any",
                  op_order="CGQAW", insert_args=None, correct_mismatches=None, merge_overlapping=False,
                  merge_min_overlap=0.9, merge_error_rate=0.2, aux=None, length_tag=None, strip_suffix=(), prefix="",
-                 suffix="", zero_cap=False, outputs=None, cut_min=(), cut_min2=()):
+                 suffix="", zero_cap=False, outputs=None, cut_min=(), cut_min2=(), bisulfite=None, bisulfite2=None):
         # {"too_short" | "too_long" | "untrimmed": (path for read 1, path for read 2)}: the filtered pairs' own files
         self.outputs = dict(outputs) if outputs else {}
         if "untrimmed" in self.outputs:
@@ -503,8 +574,10 @@ class PairedTrimPipeline(object):
         if (aux or length_tag or strip_suffix or prefix or suffix or zero_cap) and (aligner != "adapter" or merge_overlapping):
             raise NotImplementedError("--info-file / --rest-file / --wildcard-file, read-name modifiers and --zero-cap with "
                                       "the insert aligner or with merging")
-        self.p1 = TrimPipeline(adapters=adapters1, cut=cut, cut_min=cut_min, **common)
-        self.p2 = TrimPipeline(adapters=adapters2, cut=cut2, cut_min=cut_min2, **common)
+        self.p1 = TrimPipeline(adapters=adapters1, cut=cut, cut_min=cut_min, bisulfite=bisulfite, **common)
+        self.p2 = TrimPipeline(adapters=adapters2, cut=cut2, cut_min=cut_min2, bisulfite=bisulfite2, **common)
+        if (bisulfite or bisulfite2) and aligner != "adapter":
+            raise NotImplementedError("--bisulfite with the insert aligner")
         self.aligner, self.action, self.op_order = aligner, action, op_order
         if pair_filter not in ("any", "both"):
             raise ValueError("pair_filter must be 'any' or 'both'")
@@ -709,6 +782,7 @@ class PairedTrimPipeline(object):
         insert_matched = already_corrected = None
         unmasked = [None, None]
         for pipe in pipes:
+            pipe._sides = pipe._after = None
             pipe._rounds = [] if self.aux else None
             pipe._last_which = (torch.zeros((n,), dtype=torch.int64, device=dev)
                                 if ("{name}" in pipe.prefix or "{name}" in pipe.suffix) else None)
@@ -885,6 +959,7 @@ def pipeline_from_args(argv, paired_input=False):
     ap.add_argument("--op-order", default="CGQAW")
     ap.add_argument("-u", "--cut", type=int, action="append", default=[])
     ap.add_argument("-U", type=int, action="append", default=[], dest="cut2")
+    ap.add_argument("--bisulfite", default=None)
     ap.add_argument("--cut-min", type=int, action="append", default=[])
     ap.add_argument("--cut-min2", type=int, action="append", default=[])
     ap.add_argument("-q", "--quality-cutoff", default=None)
@@ -988,6 +1063,38 @@ def pipeline_from_args(argv, paired_input=False):
                   quality_base=o.quality_base, trim_n=o.trim_n, minimum_length=o.minimum_length,
                   maximum_length=o.maximum_length, max_n=o.max_n, discard_trimmed=o.discard_trimmed,
                   discard_untrimmed=o.discard_untrimmed, op_order=o.op_order)
+    bis1 = bis2 = None
+    if o.bisulfite:                                                       # cli.py:702-739, trim/__init__.py:497-516
+        kind = o.bisulfite
+        if kind == "swift":
+            if not paired:
+                raise ValueError("Swift trimming is only compatible with paired-end reads")
+            bis1, bis2 = [("min", 0, 10, False, False)], [("min", 10, 0, False, False)]
+        elif kind == "non-directional":
+            # (the reference's run fails at the end: NonDirectionalBisulfiteTrimmer.summarize reads the RRBS cutter it
+            # only has with rrbs, modifiers.py:824-831)
+            raise NotImplementedError("--bisulfite non-directional: the reference command fails on it")
+        elif kind == "non-directional-rrbs":
+            bis1 = bis2 = [("nondir", True)]
+        elif kind == "rrbs":
+            bis1 = bis2 = [("min", 0, 2, False, True)]
+        elif kind in ("truseq", "epignome"):
+            bis1 = bis2 = None                                            # (the reference adds no modifier for these)
+        else:
+            specs = []
+            for arg in kind.split(";"):
+                parts = [int(x) for x in arg.split(",")]
+                if len(parts) != 4:
+                    raise ValueError("Invalidate format for bisulfite parameters")
+                specs.append(None if parts[0] <= 0 and parts[1] <= 0 else
+                             [("min", max(parts[0], 0), max(parts[1], 0), bool(parts[2]), bool(parts[3]))])
+            if paired and len(specs) == 1:
+                specs = [specs[0], specs[0]]
+            elif not paired and len(specs) > 1:
+                raise ValueError("Too many bisulfite parameters for single-end reads")
+            bis1, bis2 = specs[0], (specs[1] if len(specs) > 1 else None)
+    if legacy and (bis1 or bis2):
+        raise NotImplementedError("--bisulfite with paired-end input in legacy mode")
     aux = {kind: path for kind, path in (("info", o.info_file), ("rest", o.rest_file), ("wildcard", o.wildcard_file)) if path}
     outputs = {kind: path for kind, path in (("too_short", o.too_short_output), ("too_long", o.too_long_output),
                                              ("untrimmed", o.untrimmed_output)) if path}
@@ -1000,12 +1107,12 @@ def pipeline_from_args(argv, paired_input=False):
     if legacy and (aux or outputs or o.length_tag or o.strip_suffix or o.prefix or o.suffix or o.zero_cap):
         raise NotImplementedError("side files and read-name modifiers with paired-end input in legacy mode")
     if not paired:
-        first = TrimPipeline(adapters=adapters, cut=o.cut, cut_min=o.cut_min, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
+        first = TrimPipeline(adapters=adapters, cut=o.cut, cut_min=o.cut_min, bisulfite=bis1, aux=aux or None, outputs=outputs or None, length_tag=o.length_tag,
                              strip_suffix=o.strip_suffix, prefix=o.prefix, suffix=o.suffix, zero_cap=o.zero_cap, **common)
         return LegacyPairedPipeline(first) if legacy else first
     return PairedTrimPipeline(outputs=outputs or None, aux=aux or None, length_tag=o.length_tag, strip_suffix=o.strip_suffix, prefix=o.prefix,
                               suffix=o.suffix, zero_cap=o.zero_cap, adapters1=adapters, adapters2=adapters2, aligner=o.aligner, cut=o.cut, cut2=o.cut2,
-                              cut_min=o.cut_min, cut_min2=o.cut_min2,
+                              cut_min=o.cut_min, cut_min2=o.cut_min2, bisulfite=bis1, bisulfite2=bis2,
                               pair_filter=o.pair_filter or "any", insert_args=insert_args,
                               correct_mismatches=o.correct_mismatches, merge_overlapping=o.merge_overlapping,
                               merge_min_overlap=o.merge_min_overlap,

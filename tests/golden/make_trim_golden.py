@@ -224,6 +224,12 @@ CASES = [
     # the filtered reads into files of their own (trim/__init__.py:580-630)
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 20 -m 40 -M 95 --too-short-output {too_short} --too-long-output {too_long} --untrimmed-output {untrimmed}"),
     ("synth.fastq", "-a tru=" + TRUSEQ + " -m 30 --max-n 1 --mask-adapter --too-short-output {too_short} --untrimmed-output {untrimmed}"),
+    # --bisulfite: RRBS / non-directional / custom MinCutter parameters (modifiers.py:786-860)
+    ("synth.fastq", "-a tru=" + TRUSEQ + " --bisulfite rrbs -q 20 -m 10"),
+    ("bisulf.fastq", "-a tru=" + TRUSEQ + " --bisulfite non-directional-rrbs --trim-n"),
+    ("bisulf.fastq", "-a tru=" + TRUSEQ + " -g head=" + TRUSEQ[:20] + " -n 2 --bisulfite 4,6,1,0 -u 2"),
+    ("bisulf.fastq", "-b tru=" + TRUSEQ + " --bisulfite 3,5,0,1 -q 15 --op-order CAGQW"),
+    ("synth.fastq", "-a tru=" + TRUSEQ + " --bisulfite non-directional --mask-adapter" if False else "-a tru=" + TRUSEQ + " --bisulfite truseq -m 20"),
     # --cut-min: at least that many bases gone from an end, whatever removed them (MinCutter, modifiers.py:587-650)
     ("synth.fastq", "-a tru=" + TRUSEQ + " -q 15,20 --trim-n --cut-min 6 --cut-min -12 -m 10"),
     ("synth.fastq", "-g head=" + TRUSEQ[:20] + " -a tru=" + TRUSEQ + " -u 3 --cut-min 25 -n 2"),
@@ -287,6 +293,8 @@ PAIRED_CASES = [
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-b %s --mask-adapter --max-n 3" % PE1[:25]),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 --cut-min 5 --cut-min2 -8 -m 20" % (PE1, PE2)),
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "--aligner insert -a %s -A %s --cut-min -10 --cut-min2 4 --cut-min2 -4" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --bisulfite swift -m 20" % (PE1, PE2)),
+    ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s --bisulfite 0,3,0,1;5,0,1,0 -q 15" % (PE1, PE2)),
     # the filtered pairs into files of their own
     ("synth_pe.1.fastq", "synth_pe.2.fastq", "-a %s -A %s -q 20 -m 60 --too-short-output {too_short} --too-short-paired-output {too_short2} --untrimmed-output {untrimmed} --untrimmed-paired-output {untrimmed2}" % (PE1, PE2)),
     # masked adapters and merging: MergeOverlapping sees the reads with their N's
@@ -369,6 +377,11 @@ def main():
     inputs["anchor.fastq"] = synth_anchor_fastq(600, 14).encode()
     inputs["longmix.fastq"] = synth_longmix_fastq(150, 19).encode()
     inputs["longad.fastq"] = synth_longad_fastq(300, 29).encode()
+    bis = synth_fastq(300, 33).split("\n")                        # reads that start with CAA / CGA (MspI sites) and others
+    for i in range(1, len(bis), 4):
+        if (i // 4) % 3 == 0 and len(bis[i]) > 6:
+            bis[i] = ("CAA" if (i // 4) % 2 else "CGA") + bis[i][3:]
+    inputs["bisulf.fastq"] = "\n".join(bis).encode()
     tagged = synth_fastq(200, 31).split("\n")                    # names with a length field (and one that only looks like it)
     for i in range(0, len(tagged) - 1, 4):
         n = len(tagged[i + 1])

@@ -5,7 +5,7 @@ from . import _cases
 
 
 def test_trim_pipeline_reference_cli_cases(emu_backend):
-    assert _cases.check_trim_golden() >= 81
+    assert _cases.check_trim_golden() >= 86
 
 
 def test_trim_pipeline_through_the_two_pass_prepass(emu_backend, monkeypatch):
@@ -16,7 +16,7 @@ def test_trim_pipeline_through_the_two_pass_prepass(emu_backend, monkeypatch):
     real = emu_backend.locate_planes_batch
     monkeypatch.setattr(_lib, "PLANES_MIN_READS", 1)
     monkeypatch.setattr(emu_backend, "locate_planes_batch", lambda *a: (calls.append(a[3]), real(*a))[1])
-    assert _cases.check_trim_golden() >= 81
+    assert _cases.check_trim_golden() >= 86
     assert len(calls) >= 10
 
 
@@ -33,7 +33,7 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
     with pytest.raises(NotImplementedError):
         pipeline_from_args("-a AAAA...TTTT -a GGGG")                     # linked + plain adapters mixed
     with pytest.raises(SystemExit):
-        pipeline_from_args("--bisulfite rrbs")                           # modifier outside the pipeline
+        pipeline_from_args("-a ACGT --trim-primer")                      # modifier outside the pipeline
     with pytest.raises(NotImplementedError):
         pipeline_from_args("--aligner insert -a ACGTACGTAC -A ACGTACGTAC --length-tag length=")   # not with the insert aligner
     with pytest.raises(NotImplementedError):
@@ -41,7 +41,7 @@ def test_pipeline_rejects_what_it_does_not_cover(emu_backend):
 
 
 def test_paired_pipeline_reference_cli_cases(emu_backend):
-    assert _cases.check_trim_golden_paired() >= 45
+    assert _cases.check_trim_golden_paired() >= 47
 
 
 def test_paired_file_chunking(emu_backend, tmp_path):

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def test_trim_pipeline_reference_cli_cases(hip_backend):
-    assert _cases.check_trim_golden() >= 81
+    assert _cases.check_trim_golden() >= 86
 
 
 def test_trim_file_chunking(hip_backend, tmp_path):
@@ -62,7 +62,7 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
 
 
 def test_paired_pipeline_reference_cli_cases(hip_backend):
-    assert _cases.check_trim_golden_paired() >= 45
+    assert _cases.check_trim_golden_paired() >= 47
 
 
 def test_paired_file_chunking(hip_backend, tmp_path):

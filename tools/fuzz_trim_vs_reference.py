@@ -206,6 +206,14 @@ def random_args(rng, paired):
         args += ["--op-order", "".join(order)]
     if paired and rng.random() < 0.3:
         args += ["--pair-filter", rng.choice(["any", "both"])]
+    if not linked and rng.random() < 0.25:
+        plain = "--mask-adapter" not in args and "--no-trim" not in args
+        kinds = ["rrbs", "truseq", "%d,%d,0,%d" % (rng.randint(0, 6), rng.randint(0, 6), rng.randint(0, 1))]
+        if plain:
+            kinds += ["non-directional", "non-directional-rrbs", "%d,%d,1,%d" % (rng.randint(0, 8), rng.randint(0, 8), rng.randint(0, 1))]
+        if paired:
+            kinds += ["swift", "2,0,0,0;0,4,0,1"]
+        args += ["--bisulfite", rng.choice(kinds)]
     if "--mask-adapter" not in args and "--no-trim" not in args and rng.random() < 0.2:
         args += ["--cut-min", str(rng.choice([3, 10, 30, -4, -15]))]
         if rng.random() < 0.3:
@@ -225,6 +233,7 @@ def main():
     ap.add_argument("--merge", action="store_true", help="paired-end modes: add --merge-overlapping options (third output file)")
     ap.add_argument("--aux", action="store_true", help="adapter aligner: add --info-file / --rest-file / --wildcard-file, the "
                     "read-name modifiers, -z and the extra output files, and compare every file")
+    ap.add_argument("--dump", type=int, default=-1, help="write the inputs and the command line of this case to /tmp/fuzz_case.*")
     ap.add_argument("--scratch", default="/tmp/oracle_ref")
     o = ap.parse_args()
     sys.path.insert(0, o.scratch)
@@ -293,6 +302,11 @@ def main():
             else:
                 params += ["-se", paths[0], "-o", paths[2]]
             params += ["--quiet", "--no-default-adapters", "--no-cache-adapters"]
+            if case == o.dump:
+                open("/tmp/fuzz_case.1.fq", "wb").write(data1)
+                if data2 is not None:
+                    open("/tmp/fuzz_case.2.fq", "wb").write(data2)
+                open("/tmp/fuzz_case.args", "w").write(" ".join(args))
             for p in paths[2:]:
                 if os.path.exists(p):
                     os.remove(p)
