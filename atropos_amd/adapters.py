@@ -61,37 +61,28 @@ def where_int_to_dict(where):
 _adapter_numbers = itertools.count(1)
 
 
+_BRACE_TOKEN = re.compile(r'(?P<rep>[^{}])\{(?P<count>[^{}]*)\}|(?P<plain>[^{}]+?)(?=[^{}]\{|[{}]|$)|(?P<stray>[{}])')
+
+
 def parse_braces(sequence):
-    """Replace all occurrences of ``x{n}`` (x any character) with n occurrences of x;
-    ``ValueError`` if the expression cannot be parsed.  ``TGA{5}CT`` -> ``TGAAAAACT``."""
-    result = ''
-    state = None            # None | a plain token | '{' | repeat count (int)
-    for token in re.split(r'(\{|\})', sequence):
-        if token == '':
+    """Expand the repeat notation of adapter specifications: ``x{n}`` stands for n copies of the single
+    character x (``TGA{5}CT`` -> ``TGAAAAACT``, ``A{0}`` -> nothing).  n is whatever ``int()`` accepts,
+    0 <= n <= 10000.  A brace that does not close such a group right behind a character -- a leading
+    ``{``, ``{}`` chained behind another group, a missing ``}`` -- is a ``ValueError``
+    (behaviour of the reference's parser, adapters/__init__.py:933-970)."""
+    pieces = []
+    for tok in _BRACE_TOKEN.finditer(sequence):
+        if tok.group('stray') is not None:
+            raise ValueError('unbalanced or misplaced "{}" at offset {} of {!r}'.format(
+                tok.group('stray'), tok.start(), sequence))
+        if tok.group('plain') is not None:
+            pieces.append(tok.group('plain'))
             continue
-        if state is None:
-            if token == '{':
-                raise ValueError('"{" must be used after a character')
-            if token == '}':
-                raise ValueError('"}" cannot be used here')
-            state = token
-            result += token
-        elif state == '{':
-            state = int(token)
-            if not 0 <= state <= 10000:
-                raise ValueError('Value {} invalid'.format(state))
-        elif isinstance(state, int):
-            if token != '}':
-                raise ValueError('"}" expected')
-            result = result[:-1] + state * result[-1:]
-            state = None
-        else:
-            if token != '{':
-                raise ValueError('Expected "{"')
-            state = '{'
-    if isinstance(state, int) or state == '{':
-        raise ValueError("Unterminated expression")
-    return result
+        count = int(tok.group('count'))            # ValueError for anything that is not a number
+        if count < 0 or count > 10000:
+            raise ValueError('repeat count {} outside 0 .. 10000'.format(count))
+        pieces.append(tok.group('rep') * count)
+    return ''.join(pieces)
 
 
 def _seq_of(read):

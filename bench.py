@@ -795,6 +795,18 @@ def main():
         cfg, kernel_ms = line.pop("_secondary_later")
         line["secondary"] = cfg.secondary(kernel_ms)
     if rank == 0:
+        # LAST key of the line (the driver keeps the line's tail): every config of this invocation in one compact
+        # object -- [reads/s, ms_per_step, roofline.frac, counted traffic / algorithmic bytes (null: not counted)]
+        def _brief(res):
+            if not isinstance(res, dict) or "value" not in res:
+                return None
+            roof = res.get("roofline", {})
+            return [float("%.4g" % res["value"]), float("%.4g" % res["ms_per_step"]), float("%.4g" % roof.get("frac", 0.0)),
+                    None if roof.get("traffic_over_algorithmic") is None else float("%.3g" % roof["traffic_over_algorithmic"])]
+        summary = {head: _brief(line)}
+        for name, res in line.get("configs", {}).items():
+            summary[name] = _brief(res)
+        line["configs_summary"] = summary
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
