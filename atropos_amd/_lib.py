@@ -113,6 +113,7 @@ PROTOTYPES = {
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_compare_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_planes_applies": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "atr_aligner_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "atr_locate_planes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]),
@@ -430,6 +431,15 @@ class HipBackend(object):
         """Is this aligner on reads of max_len bases (ragged: of at most max_len) inside the envelope of the
         two-pass pre-pass (plane64 reads, atr_locate_planes_batch)?"""
         return bool(self.lib.atr_locate_planes_applies(h, int(max_len), int(bool(ragged))))
+
+    def aligner_prepare(self, h, max_len, ragged=False):
+        """atr_aligner_prepare: build / load the pre-pass kernel specialised for this aligner and read length on this
+        backend's device.  True: ready; False: there is none (the generic kernel serves the calls)."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.atr_aligner_prepare(h, int(max_len), int(bool(ragged)))
+        if rc not in (0, -2):                             # (ATR_ERR_UNSUPPORTED: no specialised kernel, not an error)
+            _check(self.lib, rc, "atr_aligner_prepare")
+        return rc == 0
 
     def locate_planes_batch(self, h, planes, lens, nreads, max_len):
         """Batched locate on a plane64 batch (atr_locate_planes_batch); lens None: equal-length reads."""

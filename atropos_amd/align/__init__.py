@@ -213,6 +213,16 @@ class Aligner(object):
         planes = self._wants_planes(layout, reads.shape[0], reads.shape[1])
         return ReadBatch.from_ascii(reads, None, None, kind, table, self._backend, planes=planes)
 
+    def prepare(self, max_len, ragged=False):
+        """Have the library build (or load from its code-object cache) the pre-pass kernel specialised for this
+        adapter and read length (``atr_aligner_prepare``): worth it for an aligner that will see millions of reads
+        -- ``locate_batch`` does it by itself for batches of 4 M reads and more.  Returns whether such a kernel is
+        in place; the records are the same either way."""
+        be = self._backend
+        if self._handle is None or not hasattr(be, "aligner_prepare"):
+            return False
+        return be.aligner_prepare(self._handle, max_len, ragged)
+
     def _wants_planes(self, layout, nreads, width, ragged=False):
         if layout == "tile64" or self._handle is None or getattr(self, "_long", False) or width > _lib.MAX_READ_LEN:
             return False

@@ -16,6 +16,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
                        int nchunks, int max_len, uint4 *out, void *work, hipStream_t st);
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out);
 int piece_ragged_len(int max_len);
+int prepare_locate_planes(const atr_aligner *a, int max_len, bool ragged);
 int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
                          void *work, hipStream_t st);
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
@@ -291,6 +292,11 @@ int atr_locate_batch_path(const atr_aligner *a, const uint8_t *d_packed, const i
 int atr_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
     if (!a || max_len < 1 || max_len > ATR_MAX_READ_LEN) return 0;
     return piece_applies(a, ragged ? piece_ragged_len(max_len) : max_len, nullptr, nullptr) ? 1 : 0;
+}
+
+int atr_aligner_prepare(const atr_aligner *a, int max_len, int ragged) {
+    if (!a || max_len < 1 || max_len > ATR_MAX_READ_LEN) return ATR_ERR_INVALID;
+    return prepare_locate_planes(a, max_len, ragged != 0) ? ATR_OK : ATR_ERR_UNSUPPORTED;
 }
 
 int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, const int32_t *d_lens, int64_t nreads, int max_len,

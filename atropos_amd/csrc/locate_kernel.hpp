@@ -11,19 +11,9 @@
 
 #include <hip/hip_runtime.h>
 #include "aligner_host.hpp"
+#include "fast_work.hpp"
 
 namespace atr {
-
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return __builtin_amdgcn_readfirstlane(v);
-}
 
 template <int W>
 __device__ __forceinline__ void load_mask(uint32_t (&nm)[W], const uint32_t (*s_nm)[4], uint32_t q) {

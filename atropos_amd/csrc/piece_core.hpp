@@ -78,6 +78,7 @@ struct PieceParams {
 // one-hot code (1, 2, 4, 8) -> plane index, -1 otherwise
 inline int piece_plane_of(int code) { return code == 1 ? 0 : code == 2 ? 1 : code == 4 ? 2 : code == 8 ? 3 : -1; }
 
+#ifndef __HIPCC_RTC__
 // Host: does the two-pass pre-pass take this aligner (m rows, codes[], k, flags, thr_row as in FilterParams,
 // rows = FilterParams::rows) on equal-length reads of n bases?  Fills pp.
 inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags, bool and_mode, bool custom_table,
@@ -155,6 +156,7 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     pp.tail_cols = rows + k + (m - rows);                            // see "tail_cols" in DESIGN.md 3.2b: rows + k + T
     return true;
 }
+#endif  // __HIPCC_RTC__ (host side)
 
 // ---- pass A, one lane ---------------------------------------------------------------------------------
 // The four per-base masks of one read, NW words each: Y[c][w] bit b <=> base 32 w + b matches code index c.
@@ -504,9 +506,144 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     return S;
 }
 
+#ifdef ATR_SPEC
+#include "piece_spec_config.h"   // written by the host for this aligner (jit.hpp): atr::spec::{N, P, FP, PP, ROWC}
+// ---- pass A for ONE aligner, compiled at run time (jit.hpp, piece_spec.hip) ------------------------------------
+// atr::spec::PP / FP / P / N are constexpr objects written by the host for this aligner and read length (the
+// generated piece_spec_config.h): every piece code, end mask and overlap mask is a literal, the step loop is
+// straight-line code -- acc &= Y[c] with c known -- and the 54 scalar dispatches per tile of the generic kernel
+// (s_bitcmp1 + branch per term: 40 % of its issue time) are gone, as are the ~700 bytes of kernel
+// argument that kept 116 SGPRs spilled.
+template <int V> struct PieceIC { static constexpr int value = V; };
+template <int I, int N, class F>
+__device__ __forceinline__ void piece_static_for(F &&f) {
+    if constexpr (I < N) { f(PieceIC<I>{}); piece_static_for<I + 1, N>(f); }
+}
+
+template <int NW>
+ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&twp)[4], int mf, int T, int k) {
+    constexpr int TWN = NW < PIECE_TAIL_WORDS ? NW : PIECE_TAIL_WORDS, TW0 = NW - TWN;
+    constexpr int n = spec::N;
+    PieceMasks<NW> Y;
+    piece_eq_masks<NW>(pl, spec::PP.and_mode != 0, Y);
+
+    // (1) overlaps that must be exact.  X_i = AND_{r < i} (tw[c_r] << (i - 1 - r)) has bit 31 set iff the last i bases
+    //     are rows 0 .. i - 1; X_{i + 1} = (X_i << 1) & tw[c_i]: one add and one and per overlap length.
+    bool tail = false;
+    if constexpr (spec::PP.xhi >= spec::PP.xlo) {
+        uint32_t tw[4];
+        if constexpr (spec::PP.and_mode != 0) { tw[0] = twp[0]; tw[1] = twp[1]; tw[2] = twp[2]; tw[3] = twp[3]; }
+        else {
+            tw[0] = twp[0] & ~(twp[1] | twp[2] | twp[3]); tw[1] = twp[1] & ~(twp[0] | twp[2] | twp[3]);
+            tw[2] = twp[2] & ~(twp[0] | twp[1] | twp[3]); tw[3] = twp[3] & ~(twp[0] | twp[1] | twp[2]);
+        }
+        uint32_t x = ~0u, any = 0u;
+        piece_static_for<0, spec::PP.xhi>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;                   // row i joins: X_{i + 1}
+            x = (x + x) & tw[spec::ROWC[i]];
+            if constexpr (i + 1 >= spec::PP.xlo && i + 1 <= n) any |= x;
+        });
+        tail = (any >> 31) != 0u;
+    }
+
+    // (2) the pieces
+    uint32_t occ[PIECE_NB][NW], tocc[PIECE_NT][TWN];
+#pragma unroll
+    for (int p = 0; p < PIECE_NB; ++p)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) occ[p][w] = ~0u;
+#pragma unroll
+    for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+        for (int w = 0; w < TWN; ++w) tocc[u][w] = spec::PP.tmask[u][w];
+    // Every term is a volatile one-instruction asm, in source order: left to itself the scheduler moves the ands of a
+    // step behind the in-place shift that follows them, keeps copies of every older mask and spills a hundred
+    // registers (round 5, first try).  In this order the live set is Y + occ + tocc = 52 registers.
+    const auto term = [](uint32_t &acc, uint32_t y, bool first) {
+        if (first) acc = y;                                          // (occ starts as all ones: the first term is a copy;
+        else asm volatile("v_and_b32 %0, %0, %1" : "+v"(acc) : "v"(y));   //  a read-end piece starts from its end mask)
+    };
+    piece_static_for<0, spec::PP.steps>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr uint32_t cw = spec::PP.scode[s];
+        if constexpr (s < spec::PP.blen) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                term(occ[0][w], Y.y[(cw >> 0) & 3u][w], s == 0);
+                term(occ[1][w], Y.y[(cw >> 2) & 3u][w], s == 0);
+                term(occ[2][w], Y.y[(cw >> 4) & 3u][w], s == 0);
+            }
+        }
+        if constexpr (s < spec::PP.llen) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) term(occ[3][w], Y.y[(cw >> 6) & 3u][w], s == 0);
+        }
+        if constexpr (s < spec::PP.tlen) {
+            piece_static_for<0, PIECE_NT>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr ((spec::PP.tmask[u][0] | spec::PP.tmask[u][1] | spec::PP.tmask[u][2]) != 0u) {
+#pragma unroll
+                    for (int w = 0; w < TWN; ++w) term(tocc[u][w], Y.y[(cw >> (8 + 2 * u)) & 3u][TW0 + w], false);
+                }
+            });
+        }
+        if constexpr (s + 1 < spec::PP.steps) piece_shift_masks<NW>(Y);
+    });
+    if constexpr (spec::PP.tlen > 0) {
+        uint32_t any = 0u;
+#pragma unroll
+        for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+            for (int w = 0; w < TWN; ++w) any |= tocc[u][w];
+        tail = tail || any != 0u;
+    }
+
+    // (3) diagonals with a body piece (as piece_scan; the alignment shifts are literals)
+    uint32_t dm[NW], pf[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) dm[w] = pf[w] = occ[0][w];
+    piece_static_for<1, PIECE_NB>([&](auto pc) {
+        constexpr int p = decltype(pc)::value;
+        constexpr int sh = p == PIECE_NB - 1 ? spec::PP.m - spec::PP.blen : p * spec::PP.blen;     // 0 .. 32
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const uint32_t lo = sh >= 32 ? (w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u) : occ[p][w];
+            const uint32_t hi = sh >= 32 ? (w + 2 < NW ? occ[p][w + 2 < NW ? w + 2 : w] : 0u) : (w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u);
+            const uint32_t al = (sh & 31) ? __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(sh & 31)) : lo;
+            dm[w] |= al;
+            pf[w] &= al;
+        }
+    });
+    int b_first = -1, b_last = -1, z_first = -1;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) if (dm[w] != 0u) b_first = 32 * w + atr_ctz(dm[w]);
+#pragma unroll
+    for (int w = 0; w < NW; ++w) if (dm[w] != 0u) b_last = 32 * w + 31 - atr_clz(dm[w]);
+#pragma unroll
+    for (int w = NW - 1; w >= 0; --w) if (pf[w] != 0u) z_first = 32 * w + atr_ctz(pf[w]);
+
+    PieceScan S;
+    S.tail = tail;
+    S.flagged = tail || b_first >= 0;
+    S.j_s = 0; S.j_e = 0;
+    S.j_exact = z_first >= 0 ? z_first - (spec::PP.blen - 1) + spec::PP.m : 0;
+    if (b_first >= 0) {
+        const int d_min = b_first - (spec::PP.blen - 1), d_max = b_last - (spec::PP.blen - 1);
+        S.j_s = atr_max(0, d_min - k);
+        S.j_e = atr_min(n, mf + d_max + k + T);
+    }
+    if (tail) {
+        S.j_s = b_first >= 0 ? atr_min(S.j_s, atr_max(0, n - spec::PP.tail_cols)) : atr_max(0, n - spec::PP.tail_cols);
+        S.j_e = n;
+    }
+    return S;
+}
+#endif  // ATR_SPEC
+
 // ---- planes -> 4-bit codes ------------------------------------------------------------------------------
 // spread[t][b]: bit i of the byte b at bit 4 i + t.  The nibble dword of eight bases = the OR of the four
 // planes' bytes looked up in the four tables.
+#ifndef __HIPCC_RTC__
 inline void piece_spread_tables(uint32_t (*tab)[256]) {
     for (int t = 0; t < 4; ++t)
         for (int b = 0; b < 256; ++b) {
@@ -515,6 +652,7 @@ inline void piece_spread_tables(uint32_t (*tab)[256]) {
             tab[t][b] = v;
         }
 }
+#endif
 // byte q (0 .. 3) of the four plane words -> the dword of the eight 4-bit codes
 ATR_DEV uint32_t piece_nibbles(const uint32_t (*spread)[256], uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, int q) {
     return spread[0][(p0 >> (8 * q)) & 255u] | spread[1][(p1 >> (8 * q)) & 255u] |

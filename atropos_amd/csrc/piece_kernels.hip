@@ -12,6 +12,8 @@
 // Same records as the one-pass pipeline (filter_kernels.hip) and as the full sweep; tests/test_gpu_locate.py
 // compares all three on every size.
 #include "locate_fast.hpp"
+#include "piece_filter.hpp"
+#include "jit.hpp"
 
 namespace atr {
 
@@ -19,328 +21,11 @@ void launch_fast_scan(FastWork wk, hipStream_t st);                             
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                    int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes);
 
-constexpr int PIECE_QF = 10;                        // queue fields per task: read, meta, 4 planes x 2 words
-
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    const int lane = threadIdx.x & 63;
-    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
-}
-
-// The record of a resolved read / the list entry of an unresolved one.  `active`: this lane holds a decided read.
-// nibs: the lane's eight window dwords in LDS ([dword][lane]; the window's first position is column j0 + 1), from
-// which the 64 codes that follow the entry's first diagonal go into tdata -- what band_stage would gather.
-__device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww, const uint32_t (&rec)[4], int m, uint4 *out,
-                                           uint2 *list, uint4 *ldata, const uint32_t *nibs, int j0, uint32_t *s_lcur, uint32_t *s_hist) {
-    const bool open = active && window_valid(ww);
-    if (active && !open) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
-    const uint64_t om = __ballot(open);
-    if (om != 0ull) {                                            // wave-uniform
-        uint32_t base = 0u;
-        if ((threadIdx.x & 63) == 0) base = atomicAdd(s_lcur, (uint32_t)__popcll(om));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int lane = threadIdx.x & 63;
-        const int off = window_lo(ww) - j0;                      // codes between the window's start and the first diagonal
-        const bool dense = nibs != nullptr && off >= 0 && off < 64;
-        if (open) {
-            const uint32_t slot = base + (uint32_t)__popcll(om & lanemask_lt());
-            list[slot] = make_uint2((uint32_t)r, dense ? ww : (ww | PIECE_NODENSE));
-            atomicAdd(&s_hist[window_bin(ww, m, true)], 1u);
-            if (dense) {
-                const int z = off >> 3;
-                const uint32_t sh = 4u * (uint32_t)(off & 7);
-                uint32_t raw[9], d[8];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) raw[k] = z + k < 8 ? nibs[(z + k) * 64 + lane] : 0u;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) d[k] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
-                ldata[2 * (size_t)slot] = make_uint4(d[0], d[1], d[2], d[3]);
-                ldata[2 * (size_t)slot + 1] = make_uint4(d[4], d[5], d[6], d[7]);
-            }
-        }
-    }
-}
-
-// RAGGED: reads of different lengths (lens[r] <= max_len).  Pass A then works on the read moved to the END of its
-// NW words (a per-lane shift of the planes by 32 NW - n positions, zeros coming in below): every read ends at
-// position 32 NW like a read of an equal-length batch, the read-end conditions keep their wave-uniform masks, and the
-// columns it reports are shifted back by the lane's own amount.  Positions before the read hold code 0 either way.
 template <int NW, bool RAGGED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NW <= 5 ? 5 : NW <= 6 ? 4 : NW <= 8 ? 3 : 2, 8))) void piece_filter_kernel(const LocateParams p, const FilterParams fp, const PieceParams pp,
-                                                           const uint4 *__restrict__ planes, const int32_t *__restrict__ lens,
-                                                           long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk) {
-    const int n = RAGGED ? 32 * NW : max_len;                     // the length pass A sees (wave-uniform)
-    __shared__ uint2 s_peq[16];
-    __shared__ uint32_t s_spread[4][256];
-    __shared__ uint32_t s_hist[FILTER_BINS];
-    __shared__ uint32_t s_lcur, s_wcnt;
-    __shared__ uint32_t s_nibs[4][8][64];                         // pass B: the task's eight nibble dwords, [dword][lane] (NARROW tail check)
-    __shared__ uint32_t s_queue[4][PIECE_QF][64];
-    const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
-    if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp.peq[threadIdx.x], (uint32_t)(fp.peq[threadIdx.x] >> 32));
-    if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_lcur = 0; s_wcnt = 0; }
-    piece_spread_fill(s_spread);
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int mf = fp.rows, T = u.m - mf;
-    const uint32_t kreg = (uint32_t)u.k;
-    const long long ntiles = (nreads + 63) >> 6;
-    long long t0, t1;
-    block_tiles(ntiles, t0, t1, wk.nused);
-    uint2 *list = wk.tmp + t0 * 64;                               // this block's list: at most one entry per read it owns
-    uint4 *ldata = wk.tdata + t0 * 128;                           // ... and its 64-code records (two uint4 each)
-    // this block's reads that need the full sweep: their numbers (one slot per read it owns) and, for the first wcap
-    // of them, a copy of their planes (a quarter of its reads + 16)
-    uint32_t *wlist = wk.wide + t0 * 64;
-    const long long wcap = (t1 - t0) * 16 + 16;
-    uint4 *wplanes = wk.wdata + (t0 * 16 + 16 * (long long)blockIdx.x) * NW;
-    uint32_t (*queue)[64] = s_queue[wave];
-    uint32_t *nibs = &s_nibs[wave][0][0];
-    const uint64_t lt = lanemask_lt();
-
-    // ---- pass B: one queued task per lane (lane < count) ---------------------------------------------------
-    auto pass_b = [&](int count) {
-        const bool act = lane < count;
-        const long long r = (long long)queue[0][lane];
-        const uint32_t meta = queue[1][lane];
-        const int j_e = act ? (int)(meta & 1023u) : 0, need = act ? (int)((meta >> 10) & 127u) : 0;
-        const int nr = RAGGED ? (act ? (int)(meta >> 17) : 0) : max_len;       // the read's own length
-        uint32_t wp[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { wp[q][0] = queue[2 + 2 * q][lane]; wp[q][1] = queue[3 + 2 * q][lane]; }
-        const int W = min(PIECE_WINDOW, (wave_max_i32(need) + 7) & ~7);          // columns swept, a multiple of eight (<= PIECE_NARROW)
-        const int dw0 = 8 - (W >> 3);                                          // first of the eight window dwords swept
-        uint32_t nb[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            nb[d] = 0u;
-            // (wave-uniform; one dword before the sweep: the DP's first diagonal may lie k columns before the window)
-            if (d >= dw0 - 1) nb[d] = piece_nibbles(s_spread, wp[0][d >> 2], wp[1][d >> 2], wp[2][d >> 2], wp[3][d >> 2], d & 3);
-            nibs[d * 64 + lane] = nb[d];                                         // NARROW mode's tail rows, the DP kernels' record
-        }
-        FilterState F;
-        filter_init(F, u, mf);
-        uint2 ea[8], eb[8];
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            if (d < dw0) continue;                                             // wave-uniform
-            uint2 (&e)[8] = (d & 1) ? eb : ea;
-            if (d == dw0) fetch_peq8(s_peq, nb[d], e);
-            if (d + 1 < 8) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);     // one dword ahead of the columns that use it
-#pragma unroll
-            for (int b = 0; b < 8; ++b) filter_step<false>(F, e[b].x, e[b].y, kreg);
-            if (d == 3) filter_fold(F, j_e - 32, mf, kreg);                           // 32 columns at most between two folds
-        }
-        filter_fold(F, j_e, mf, kreg);
-        uint32_t rec[4];
-        // the T bases after column jp: window position jp - (j_e - 64), eight bases per dword
-        const auto tm = [&](int jp) {
-            const int rp = max(0, jp - (j_e - PIECE_WINDOW));
-            const uint32_t lo = nibs[min(rp >> 3, 7) * 64 + lane], hi = (rp >> 3) + 1 < 8 ? nibs[((rp >> 3) + 1) * 64 + lane] : 0u;
-            const uint32_t sh = 4u * (uint32_t)(rp & 7);
-            const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-            const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
-            const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
-            const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
-            return fp.and_mode ? nz == ones : nz == 0u;
-        };
-        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr);
-        piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PIECE_WINDOW, &s_lcur, s_hist);
-    };
-
-    int qn = 0;                                                   // tasks queued (wave-uniform)
-
-    // The planes of the wave's NEXT tile are requested as soon as pass A is through with the current one (its
-    // registers are free then) and land while the queue is served: a tile's pass A is ~2.5 k cycles of work, an HBM
-    // round trip twice that -- five waves per SIMD did not cover it (WAIT_ANY 36 %).
-    uint4 nx[NW];
-    if (t0 + wave < t1) {
-        const uint4 *tp = planes + (size_t)(t0 + wave) * NW * 64 + lane;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) nx[w] = tp[(size_t)w * 64];
-    }
-    for (long long tile = t0 + wave; tile < t1; tile += 4) {
-        const long long r = tile * 64 + lane;
-        const bool live = r < nreads;
-        // ---- pass A ----
-        uint32_t pl[NW][4];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) { pl[w][0] = nx[w].x; pl[w][1] = nx[w].y; pl[w][2] = nx[w].z; pl[w][3] = nx[w].w; }
-        int nr = max_len, back = 0;                               // the read's own length; positions it is moved up by
-        if (RAGGED) {
-            nr = live ? min(max(lens[r], 0), max_len) : 0;
-            back = 32 * NW - nr;
-            // out[w] = (in[w - q] : in[w - q - 1]) >> ((-back) & 31), q = (back - 1) >> 5 in -1 .. NW - 1: the two words
-            // picked with per-lane masks (q == v) and (a & b) | c ops, one funnel shift per word
-            const int q = (back - 1) >> 5;
-            const uint32_t sh = (uint32_t)(-back) & 31u;
-            uint32_t x0[NW][4], x1[NW][4];
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) x0[w][c] = x1[w][c] = 0u;
-#pragma unroll
-            for (int v = -1; v <= NW - 1; ++v) {
-                const uint32_t sel = q == v ? ~0u : 0u;
-#pragma unroll
-                for (int w = 0; w < NW; ++w)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (w - v - 1 >= 0 && w - v - 1 < NW) x0[w][c] |= pl[w - v - 1 >= 0 && w - v - 1 < NW ? w - v - 1 : 0][c] & sel;
-                        if (w - v >= 0 && w - v < NW) x1[w][c] |= pl[w - v >= 0 && w - v < NW ? w - v : 0][c] & sel;
-                    }
-            }
-#pragma unroll
-            for (int w = 0; w < NW; ++w)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) pl[w][c] = __builtin_amdgcn_alignbit(x1[w][c], x0[w][c], sh);
-        }
-        uint32_t twp[4];                                          // the last 32 positions of every plane
-        {
-            const int sh = n & 31;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                twp[q] = sh == 0 ? pl[NW - 1][q] : __builtin_amdgcn_alignbit(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, (uint32_t)sh);
-        }
-        const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
-        // the adapter verbatim: resolved here (_align.pyx:456-458), no pass B (22 % of C2's reads)
-        const bool exact = live && S.j_exact != 0 && u.m >= u.min_overlap;
-        if (exact) {
-            const int j = S.j_exact - back;                       // in the read's own columns
-            out[r] = make_uint4((uint32_t)u.m << 16, (uint32_t)(j - u.m) | ((uint32_t)j << 16), (uint32_t)u.m, 0u);
-        }
-        const bool flagged = live && S.flagged && !exact;
-        const int need = S.j_e - max(S.j_s, back);                // (columns before the read: nothing to sweep)
-        const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
-        if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);   // None
-        // the 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e) = the words w0,
-        // w0 + 1, w0 + 2 (zeros outside the read) funnel-shifted.  w0 differs from lane to lane: the three words are
-        // picked with per-lane masks (w0 == i) and (a & b) | c ops -- 2-cycle ops, no LDS round trip.
-        uint32_t wp[4][2];
-        {
-            const int b0 = S.j_e - PIECE_WINDOW, w0 = b0 >> 5;                   // floor: -2 .. NW - 2
-            const uint32_t sh = (uint32_t)(b0 & 31);
-            uint32_t x0[4] = {0u, 0u, 0u, 0u}, x1[4] = {0u, 0u, 0u, 0u}, x2[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int i = -2; i <= NW - 2; ++i) {
-                const uint32_t sel = w0 == i ? ~0u : 0u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (i >= 0) x0[q] |= pl[i >= 0 ? i : 0][q] & sel;
-                    if (i + 1 >= 0) x1[q] |= pl[i + 1 >= 0 ? i + 1 : 0][q] & sel;
-                    if (i + 2 <= NW - 1) x2[q] |= pl[i + 2 <= NW - 1 ? i + 2 : 0][q] & sel;
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wp[q][0] = __builtin_amdgcn_alignbit(x1[q], x0[q], sh);
-                wp[q][1] = __builtin_amdgcn_alignbit(x2[q], x1[q], sh);
-            }
-        }
-        // (the window was cut out of the moved planes with the moved column; the task carries the read's own columns)
-        const uint32_t meta = (uint32_t)(S.j_e - back) | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);
-        {
-            // reads that need the full sweep (3 % on C2): into the global list, with their planes while they are in
-            // registers (the sweep kernel would gather them 16 bytes per 128-byte line)
-            const uint64_t wm = __ballot(wide);
-            if (wm != 0ull) {                                                 // wave-uniform
-                uint32_t base = 0u;
-                if (lane == 0) base = atomicAdd(&s_wcnt, (uint32_t)__popcll(wm));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (wide) {
-                    const long long slot = (long long)base + __popcll(wm & lt);
-                    wlist[slot] = (uint32_t)r;
-                    if (!RAGGED && slot < wcap) {                             // (a ragged batch: pl is the MOVED read; the sweep gathers)
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) wplanes[slot * NW + w] = make_uint4(pl[w][0], pl[w][1], pl[w][2], pl[w][3]);
-                    }
-                }
-            }
-        }
-        if (tile + 4 < t1) {                                                  // the next tile's planes (see above)
-            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64 + lane;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) nx[w] = tp[(size_t)w * 64];
-        }
-        // ---- queue the narrow lanes; 64 tasks -> pass B ----
-        {
-            const uint64_t nm = __ballot(narrow);
-            const int cnt = (int)__popcll(nm), rank = (int)__popcll(nm & lt);
-            const int room = 64 - qn;
-            const auto put = [&](int slot) {
-                queue[0][slot] = (uint32_t)r; queue[1][slot] = meta;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { queue[2 + 2 * q][slot] = wp[q][0]; queue[3 + 2 * q][slot] = wp[q][1]; }
-            };
-            if (narrow && rank < room) put(qn + rank);
-            if (cnt >= room) {                                                // wave-uniform
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                pass_b(64);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (narrow && rank >= room) put(rank - room);
-                qn = cnt - room;
-            } else {
-                qn += cnt;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    if (qn > 0) pass_b(qn);
-    // ---- the full sweep of the block's listed reads, one read per lane, the batches dealt round the four waves ----
-    __threadfence_block();
-    __syncthreads();
-    {
-        const long long total = (long long)s_wcnt;
-        for (long long base = (long long)wave * 64; base < total; base += 256) {
-            const bool act = base + lane < total;
-            const long long r = act ? (long long)wlist[base + lane] : t0 * 64;
-            const bool copied = !RAGGED && base + lane < wcap;
-            const uint4 *bp = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);       // the read in the batch
-            const uint4 *tp = copied ? wplanes + (base + lane) * NW : bp;
-            const size_t tstride = copied ? 1 : 64;
-            // (a ragged batch: a lane stops at its own last column, the wave at the longest read's)
-            const int nl = RAGGED ? (act ? min(max(lens[r], 0), max_len) : 0) : max_len;
-            const int nhi = RAGGED ? wave_max_i32(nl) : max_len;
-            FilterState F;
-            filter_init(F, u, mf);
-            int j = 0;
-            uint4 vv[NW];
-#pragma unroll
-            for (int c = 0; c < NW; ++c) vv[c] = tp[(size_t)c * tstride];
-#pragma unroll
-            for (int c = 0; c < NW; ++c) {
-                const uint4 v = vv[c];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    if (j >= nhi) break;                                       // wave-uniform
-                    uint2 e[8];
-                    fetch_peq8(s_peq, piece_nibbles(s_spread, v.x, v.y, v.z, v.w, d), e);
-#pragma unroll
-                    for (int b = 0; b < 8; ++b)
-                        if (j + b < nl) filter_step<false>(F, e[b].x, e[b].y, kreg);
-                    j += 8;
-                }
-                filter_fold(F, min(j, nl), mf, kreg);
-            }
-            uint32_t rec[4];
-            const auto tm = [&](int jp) {
-                const uint32_t lo = read_dword_planes((const uint32_t *)bp, NW, jp >> 3, s_spread);
-                const uint32_t hi = read_dword_planes((const uint32_t *)bp, NW, (jp >> 3) + 1, s_spread);
-                const uint32_t sh = 4u * (uint32_t)(jp & 7);
-                const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-                const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
-                const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
-                const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
-                return fp.and_mode ? nz == ones : nz == 0u;
-            };
-            const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nl, rec, 0, true);
-            piece_emit(act, r, ww, rec, u.m, out, list, ldata, nullptr, 0, &s_lcur, s_hist);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] = s_hist[threadIdx.x];
-    if (threadIdx.x == 0) wk.lcount[blockIdx.x] = s_lcur;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATR_PIECE_WAVES(NW), 8))) void piece_filter_kernel(
+    const LocateParams p, const FilterParams fp, const PieceParams pp, const uint4 *__restrict__ planes,
+    const int32_t *__restrict__ lens, long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk) {
+    piece_filter_body<NW, RAGGED>(p, fp, pp, planes, lens, nreads, max_len, out, wk);
 }
 
 // P3: a block's list of (read, window word) -> the bins of `order` (offsets from K2's scan, an LDS cursor per bin)
@@ -409,6 +94,26 @@ bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, Piec
     return true;
 }
 
+// The run-time compiled pre-pass of this aligner for reads of max_len bases (jit.hpp), or nullptr: the generic kernel.
+// force: compile now if no object exists yet (atr_aligner_prepare; ATR_JIT=1); otherwise jit.hpp's policy decides.
+static const jit::SpecKernel *piece_spec_for(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, bool ragged,
+                                             int max_len, long long nreads, bool force) {
+    const int pol = jit::policy();
+    if (pol == 0) return nullptr;
+    const int nw = (max_len + 31) / 32;
+    const bool compile = force || pol == 1 || nreads >= jit::min_reads();
+    return jit::spec_kernel(a, fp, pp, nw, ragged, ragged ? 32 * nw : max_len, compile);
+}
+
+// 1: a specialised kernel is ready for (aligner, max_len, ragged) on the current device; 0: there is none (outside the
+// two-pass envelope, ATR_JIT=0, no hiprtc, compile error) -- the generic kernel then serves the calls.
+int prepare_locate_planes(const atr_aligner *a, int max_len, bool ragged) {
+    FilterParams fp;
+    PieceParams pp;
+    if (!piece_applies(a, ragged ? piece_ragged_len(max_len) : max_len, &fp, &pp)) return 0;
+    return piece_spec_for(a, fp, pp, ragged, max_len, 0, true) != nullptr ? 1 : 0;
+}
+
 // lens == nullptr: every read has max_len bases
 int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
                          void *work, hipStream_t st) {
@@ -418,13 +123,21 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_
     FastWork wk = fast_carve(work, nreads);
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const int nw = (max_len + 31) / 32;
-    switch (nw) {
-    case 3: launch_piece_filter<3>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
-    case 4: launch_piece_filter<4>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
-    case 5: launch_piece_filter<5>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
-    case 6: launch_piece_filter<6>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
-    case 8: launch_piece_filter<8>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
-    default: launch_piece_filter<10>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+    const jit::SpecKernel *sk = piece_spec_for(a, fp, pp, lens != nullptr, max_len, nreads, false);
+    if (sk) {
+        const long long want = ((nreads + 63) / 64 + 3) / 4;
+        wk.nused = (int)std::max<long long>(1, std::min<long long>(sk->resident, want));
+        const hipError_t rc = jit::spec_launch(sk, wk.nused, planes, lens, nreads, max_len, out, wk, st);
+        if (rc != hipSuccess) return (int)rc;
+    } else {
+        switch (nw) {
+        case 3: launch_piece_filter<3>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        case 4: launch_piece_filter<4>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        case 5: launch_piece_filter<5>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        case 6: launch_piece_filter<6>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        case 8: launch_piece_filter<8>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        default: launch_piece_filter<10>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        }
     }
     launch_fast_scan(wk, st);
     hipLaunchKernelGGL(piece_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m, wk);

@@ -1,0 +1,83 @@
+"""The run-time specialised pre-pass (csrc/jit.hpp, piece_spec.hip): same records as the generic kernel, the full
+sweep and the oracle; the code-object cache."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def jit_on(tmp_path, monkeypatch):
+    monkeypatch.setenv("ATR_JIT", "1")
+    monkeypatch.setenv("ATR_KCACHE_DIR", str(tmp_path / "kcache"))
+    yield tmp_path / "kcache"
+
+
+def test_specialised_kernel_c2(hip_backend, oracle, jit_on, monkeypatch):
+    """C2's aligner, equal-length and ragged batches: specialised == generic == oracle, and the code object lands
+    in the cache directory."""
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    n = 262144
+    w = synth.workload("C2", 1 << 20, n, device="cuda:0")
+    al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    assert al.prepare(150), "no specialised kernel (hiprtc?)"
+    files = sorted(os.listdir(jit_on))
+    assert len(files) == 1 and files[0].endswith(".hsaco"), files
+    planes = al.pack(w["reads"], layout="plane64")
+    got = al.locate_batch(planes).numpy()[:, :6].astype(np.int32)
+    monkeypatch.setenv("ATR_JIT", "0")
+    gen = al.locate_batch(planes).numpy()[:, :6].astype(np.int32)
+    monkeypatch.setenv("ATR_JIT", "1")
+    assert np.array_equal(got, gen), "specialised pre-pass differs from the generic one"
+    reads = w["reads"].cpu().numpy()
+    m = 65536
+    exp = oracle.locate_many(w["adapter"], reads[:m], np.full(m, 150, np.int32), w["max_error_rate"], 14, False, False,
+                             w["min_overlap"], w["indel_cost"], max(2, min(16, os.cpu_count() or 2)))
+    assert np.array_equal(got[:m], exp)
+    assert (exp[:, 1] >= 0).sum() > 20000
+    # ragged: lengths 100 .. 150 (the tail of every row cut off)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(100, 151, size=m).astype(np.int32)
+    rows = [bytes(reads[i, :lens[i]]).decode() for i in range(m)]
+    assert al.prepare(150, ragged=True)
+    pl = al.pack(rows, layout="plane64")
+    assert pl.layout == "plane64" and pl.lens is not None
+    got_r = al.locate_batch(pl).numpy()[:, :6].astype(np.int32)
+    monkeypatch.setenv("ATR_JIT", "0")
+    gen_r = al.locate_batch(pl).numpy()[:, :6].astype(np.int32)
+    assert np.array_equal(got_r, gen_r)
+    exp_r = oracle.locate_many(w["adapter"], reads[:m], lens, w["max_error_rate"], 14, False, False, w["min_overlap"],
+                               w["indel_cost"], max(2, min(16, os.cpu_count() or 2)))
+    assert np.array_equal(got_r, exp_r)
+    assert len(os.listdir(jit_on)) == 2
+
+
+def test_specialised_kernel_random_aligners(hip_backend, oracle, jit_on):
+    """A kernel per aligner: random adapters of 20 .. 40 bases, error rates, wildcards, min_overlap, read lengths,
+    equal-length and ragged batches -- specialised pre-pass == full sweep == one-pass pipeline == oracle."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 77, 14, 400,
+                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 250, 300))
+    assert total > 2500
+    assert len(os.listdir(jit_on)) >= 6
+
+
+def test_policy_off_and_auto(hip_backend, tmp_path, monkeypatch):
+    """ATR_JIT=0: no kernel is built; auto: only on request (prepare) or for a long batch."""
+    from atropos_amd.align import Aligner
+    monkeypatch.setenv("ATR_KCACHE_DIR", str(tmp_path / "k"))
+    monkeypatch.setenv("ATR_JIT", "0")
+    al = Aligner("AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC", 0.1, 14, False, False, 3, 1)
+    assert not al.prepare(150)
+    monkeypatch.delenv("ATR_JIT")
+    reads = ["ACGT" * 25] * 70000
+    al.locate_batch(al.pack(reads, layout="plane64"))
+    assert not os.path.exists(tmp_path / "k") or not os.listdir(tmp_path / "k")      # a 70 k batch does not compile anything
+    assert al.prepare(100) and len(os.listdir(tmp_path / "k")) == 1
