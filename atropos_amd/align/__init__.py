@@ -216,7 +216,7 @@ class Aligner(object):
     def prepare(self, max_len, ragged=False):
         """Have the library build (or load from its code-object cache) the pre-pass kernel specialised for this
         adapter and read length (``atr_aligner_prepare``): worth it for an aligner that will see millions of reads
-        -- ``locate_batch`` does it by itself for batches of 4 M reads and more.  Returns whether such a kernel is
+        -- ``locate_batch`` does it by itself once the aligner has seen 2 M reads.  Returns whether such a kernel is
         in place; the records are the same either way."""
         be = self._backend
         if self._handle is None or not hasattr(be, "aligner_prepare"):

@@ -23,6 +23,7 @@ struct atr_aligner {
     uint8_t qtable[256];              // query translate table
     uint8_t codes[ATR_MAX_REF_LEN];   // 4-bit reference codes, row order
     std::string ref;                  // raw reference bytes
+    mutable long long planes_seen = 0;   // reads this handle has put through the two-pass pre-pass (jit.hpp's policy)
 };
 
 namespace atr {

@@ -10,15 +10,19 @@
 namespace atr {
 
 // waves per SIMD the kernel is built for, by word count (96 VGPRs at five)
+#ifndef ATR_PIECE_PREFETCH_EARLY
+#define ATR_PIECE_PREFETCH_EARLY 1
+#endif
 #ifndef ATR_PIECE_WAVES
-#define ATR_PIECE_WAVES(NW) ((NW) <= 5 ? 5 : (NW) <= 6 ? 4 : (NW) <= 8 ? 3 : 2)
+#define ATR_PIECE_WAVES(NW) ((NW) <= 4 ? 5 : (NW) <= 6 ? 4 : 3)          // (no spills at these: tools/jit/spec_offline.sh)
 #endif
 
-constexpr int PIECE_QF = 10;                        // queue fields per task: read, meta, 4 planes x 2 words
+constexpr int PIECE_QF = 2;                         // queue fields per task: read, meta
 
-__device__ __forceinline__ uint64_t lanemask_lt() {
-    const int lane = threadIdx.x & 63;
-    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+// set bits of `mask` below this lane (v_mbcnt: no lane-mask register to keep alive -- the 64-bit mask of round 4 was
+// spilled in the tile loop, and a scratch reload waits for every load in flight, the next tile's planes included)
+__device__ __forceinline__ int lane_rank(uint64_t mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
 // The record of a resolved read / the list entry of an unresolved one.  `active`: this lane holds a decided read.
@@ -37,7 +41,7 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
         const int off = window_lo(ww) - j0;                      // codes between the window's start and the first diagonal
         const bool dense = nibs != nullptr && off >= 0 && off < 64;
         if (open) {
-            const uint32_t slot = base + (uint32_t)__popcll(om & lanemask_lt());
+            const uint32_t slot = base + (uint32_t)lane_rank(om);
             list[slot] = make_uint2((uint32_t)r, dense ? ww : (ww | PIECE_NODENSE));
             atomicAdd(&s_hist[window_bin(ww, m, true)], 1u);
             if (dense) {
@@ -88,16 +92,19 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     block_tiles(ntiles, t0, t1, wk.nused);
     uint2 *list = wk.tmp + t0 * 64;                               // this block's list: at most one entry per read it owns
     uint4 *ldata = wk.tdata + t0 * 128;                           // ... and its 64-code records (two uint4 each)
-    // this block's reads that need the full sweep: their numbers (one slot per read it owns) and, for the first wcap
-    // of them, a copy of their planes (a quarter of its reads + 16)
+    // this block's reads that need the full sweep: their numbers (one slot per read it owns)
     uint32_t *wlist = wk.wide + t0 * 64;
-    const long long wcap = (t1 - t0) * 16 + 16;
-    uint4 *wplanes = wk.wdata + (t0 * 16 + 16 * (long long)blockIdx.x) * NW;
     uint32_t (*queue)[64] = s_queue[wave];
     uint32_t *nibs = &s_nibs[wave][0][0];
-    const uint64_t lt = lanemask_lt();
 
     // ---- pass B: one queued task per lane (lane < count) ---------------------------------------------------
+    // A task is (read, meta): the lane fetches the 64 positions of every plane that end at its window's last column
+    // itself -- bits [j_e - 64, j_e) of the read = its chunks w0, w0 + 1, w0 + 2 (zeros outside the read), funnel-
+    // shifted.  The chunks were streamed by pass A a moment ago and sit in the L2; a lane's chunk is the same 16 bytes
+    // of the same 1 KiB row its tile mates read.  (Round 4 picked the three words out of pass A's registers with per-
+    // lane masks: 150 VALU ops per tile and the planes live through all of pass A; a first version of round 5 fetched
+    // them per TILE: a memory round trip in every tile iteration, ATR_X_TIMING.  Here it is one round trip per 64
+    // tasks, every lane busy.)
     auto pass_b = [&](int count) {
         const bool act = lane < count;
         const long long r = (long long)queue[0][lane];
@@ -105,8 +112,21 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         const int j_e = act ? (int)(meta & 1023u) : 0, need = act ? (int)((meta >> 10) & 127u) : 0;
         const int nr = RAGGED ? (act ? (int)(meta >> 17) : 0) : max_len;       // the read's own length
         uint32_t wp[4][2];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { wp[q][0] = queue[2 + 2 * q][lane]; wp[q][1] = queue[3 + 2 * q][lane]; }
+        {
+            const int b0 = j_e - PIECE_WINDOW, w0 = b0 >> 5;                     // floor: -2 .. NW - 2
+            const uint4 *tcur = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);
+            uint4 g0 = make_uint4(0u, 0u, 0u, 0u), g1 = g0, g2 = g0;
+            if (act) {
+                if (w0 >= 0) g0 = tcur[(size_t)w0 * 64];
+                if (w0 + 1 >= 0) g1 = tcur[(size_t)(w0 + 1) * 64];
+                if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = tcur[(size_t)(w0 + 2) * 64];
+            }
+            const uint32_t sh = (uint32_t)(b0 & 31);
+            wp[0][0] = __builtin_amdgcn_alignbit(g1.x, g0.x, sh); wp[0][1] = __builtin_amdgcn_alignbit(g2.x, g1.x, sh);
+            wp[1][0] = __builtin_amdgcn_alignbit(g1.y, g0.y, sh); wp[1][1] = __builtin_amdgcn_alignbit(g2.y, g1.y, sh);
+            wp[2][0] = __builtin_amdgcn_alignbit(g1.z, g0.z, sh); wp[2][1] = __builtin_amdgcn_alignbit(g2.z, g1.z, sh);
+            wp[3][0] = __builtin_amdgcn_alignbit(g1.w, g0.w, sh); wp[3][1] = __builtin_amdgcn_alignbit(g2.w, g1.w, sh);
+        }
         const int W = min(PIECE_WINDOW, (wave_max_i32(need) + 7) & ~7);          // columns swept, a multiple of eight (<= PIECE_NARROW)
         const int dw0 = 8 - (W >> 3);                                          // first of the eight window dwords swept
         uint32_t nb[8];
@@ -149,14 +169,15 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
 
     int qn = 0;                                                   // tasks queued (wave-uniform)
 
-    // The planes of the wave's NEXT tile are requested as soon as pass A is through with the current one (its
-    // registers are free then) and land while the queue is served: a tile's pass A is ~2.5 k cycles of work, an HBM
-    // round trip twice that -- five waves per SIMD did not cover it (WAIT_ANY 36 %).
+    // The planes of the wave's NEXT tile are requested right after the current tile's have been taken over, BEFORE its
+    // pass A: the round trip to HBM runs under ~2.5 k cycles of pass A.  (Round 4 requested them after pass A, "when
+    // its registers are free": two iterations in three then consumed them a queue insertion later -- the wave sat
+    // through the whole latency, 40 % of its time by s_memtime.)  20 more registers through pass A: 72 of the 96.
     uint4 nx[NW];
     if (t0 + wave < t1) {
-        const uint4 *tp = planes + (size_t)(t0 + wave) * NW * 64 + lane;
+        const uint4 *tp = planes + (size_t)(t0 + wave) * NW * 64;             // (wave-uniform base + lane: scalar base, 32-bit offset)
 #pragma unroll
-        for (int w = 0; w < NW; ++w) nx[w] = tp[(size_t)w * 64];
+        for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
     }
     for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
@@ -165,6 +186,14 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         uint32_t pl[NW][4];
 #pragma unroll
         for (int w = 0; w < NW; ++w) { pl[w][0] = nx[w].x; pl[w][1] = nx[w].y; pl[w][2] = nx[w].z; pl[w][3] = nx[w].w; }
+#if ATR_PIECE_PREFETCH_EARLY
+        if (tile + 4 < t1) {
+            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // (the loads stay up here)
+#endif
         int nr = max_len, back = 0;                               // the read's own length; positions it is moved up by
         if (RAGGED) {
             nr = live ? min(max(lens[r], 0), max_len) : 0;
@@ -216,66 +245,34 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         const int need = S.j_e - max(S.j_s, back);                // (columns before the read: nothing to sweep)
         const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
         if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);   // None
-        // The 64 positions that end at the window's last column, every plane: bits [j_e - 64, j_e) of the read = its words
-        // w0, w0 + 1, w0 + 2 (zeros outside the read) funnel-shifted.  w0 differs from lane to lane.  Rounds 4 picked
-        // the three words out of the registers with per-lane masks (150 VALU ops per tile for all 64 lanes, and the
-        // planes live in 20 registers through all of pass A); now the narrow lanes RE-LOAD their three chunks -- the tile
-        // was fetched a moment ago and sits in the L2, a lane's chunk is the same 16 bytes of the same 1 KiB row its
-        // neighbours read -- in the read's own columns, so a ragged batch needs no moved window either.
-        const int je_own = S.j_e - back;
-        const uint4 *tcur = planes + (size_t)tile * NW * 64 + lane;
-        uint4 g0 = make_uint4(0u, 0u, 0u, 0u), g1 = g0, g2 = g0;
-        const int b0 = je_own - PIECE_WINDOW, w0 = b0 >> 5;                       // floor: -2 .. NW - 2
-        if (narrow) {
-            if (w0 >= 0) g0 = tcur[(size_t)w0 * 64];
-            if (w0 + 1 >= 0) g1 = tcur[(size_t)(w0 + 1) * 64];
-            if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = tcur[(size_t)(w0 + 2) * 64];
-        }
-        const uint32_t meta = (uint32_t)je_own | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);
+        // (the task carries the read's own columns: a ragged batch was scanned moved to the end of its words)
+        const uint32_t meta = (uint32_t)(S.j_e - back) | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);
         {
-            // reads that need the full sweep (1.3 % on C2): into the block's list, with a copy of their planes (the sweep
-            // at the end of the kernel would gather them 16 bytes per 128-byte line)
+            // reads that need the full sweep (1.3 % on C2, but SOME lane of more than half the tiles): into the block's
+            // list; the sweep at the end of the kernel gathers them from the batch (40 MB of sectors on C2).  Round 4
+            // stored a copy of their planes from pass A's registers, which kept 20 registers alive to this point.
             const uint64_t wm = __ballot(wide);
             if (wm != 0ull) {                                                 // wave-uniform
                 uint32_t base = 0u;
                 if (lane == 0) base = atomicAdd(&s_wcnt, (uint32_t)__popcll(wm));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (wide) {
-                    const long long slot = (long long)base + __popcll(wm & lt);
-                    wlist[slot] = (uint32_t)r;
-                    if (!RAGGED && slot < wcap) {                             // (a ragged batch: the sweep gathers)
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) wplanes[slot * NW + w] = tcur[(size_t)w * 64];
-                    }
-                }
+                if (wide) wlist[(long long)base + lane_rank(wm)] = (uint32_t)r;
             }
         }
-        // (straight-line pass A -- the run-time compiled kernel -- is one basic block: without the barrier the scheduler
-        // hoists these loads to its top and 20 more registers are live through all of pass A)
+#if !ATR_PIECE_PREFETCH_EARLY
         __builtin_amdgcn_sched_barrier(0);
-        if (tile + 4 < t1) {                                                  // the next tile's planes (see above)
-            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64 + lane;
+        if (tile + 4 < t1) {                                                  // the next tile's planes
+            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) nx[w] = tp[(size_t)w * 64];
+            for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
         }
-        uint32_t wp[4][2];
-        {
-            const uint32_t sh = (uint32_t)(b0 & 31);
-            wp[0][0] = __builtin_amdgcn_alignbit(g1.x, g0.x, sh); wp[0][1] = __builtin_amdgcn_alignbit(g2.x, g1.x, sh);
-            wp[1][0] = __builtin_amdgcn_alignbit(g1.y, g0.y, sh); wp[1][1] = __builtin_amdgcn_alignbit(g2.y, g1.y, sh);
-            wp[2][0] = __builtin_amdgcn_alignbit(g1.z, g0.z, sh); wp[2][1] = __builtin_amdgcn_alignbit(g2.z, g1.z, sh);
-            wp[3][0] = __builtin_amdgcn_alignbit(g1.w, g0.w, sh); wp[3][1] = __builtin_amdgcn_alignbit(g2.w, g1.w, sh);
-        }
+#endif
         // ---- queue the narrow lanes; 64 tasks -> pass B ----
         {
             const uint64_t nm = __ballot(narrow);
-            const int cnt = (int)__popcll(nm), rank = (int)__popcll(nm & lt);
+            const int cnt = (int)__popcll(nm), rank = lane_rank(nm);
             const int room = 64 - qn;
-            const auto put = [&](int slot) {
-                queue[0][slot] = (uint32_t)r; queue[1][slot] = meta;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { queue[2 + 2 * q][slot] = wp[q][0]; queue[3 + 2 * q][slot] = wp[q][1]; }
-            };
+            const auto put = [&](int slot) { queue[0][slot] = (uint32_t)r; queue[1][slot] = meta; };
             if (narrow && rank < room) put(qn + rank);
             if (cnt >= room) {                                                // wave-uniform
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -298,10 +295,9 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         for (long long base = (long long)wave * 64; base < total; base += 256) {
             const bool act = base + lane < total;
             const long long r = act ? (long long)wlist[base + lane] : t0 * 64;
-            const bool copied = !RAGGED && base + lane < wcap;
             const uint4 *bp = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);       // the read in the batch
-            const uint4 *tp = copied ? wplanes + (base + lane) * NW : bp;
-            const size_t tstride = copied ? 1 : 64;
+            const uint4 *tp = bp;
+            const size_t tstride = 64;
             // (a ragged batch: a lane stops at its own last column, the wave at the longest read's)
             const int nl = RAGGED ? (act ? min(max(lens[r], 0), max_len) : 0) : max_len;
             const int nhi = RAGGED ? wave_max_i32(nl) : max_len;

@@ -101,7 +101,10 @@ static const jit::SpecKernel *piece_spec_for(const atr_aligner *a, const FilterP
     const int pol = jit::policy();
     if (pol == 0) return nullptr;
     const int nw = (max_len + 31) / 32;
-    const bool compile = force || pol == 1 || nreads >= jit::min_reads();
+    // auto: once the handle has seen $ATR_JIT_MIN_READS reads in all (an aligner lives for a run: the 0.8 s of hiprtc are
+    // then paid back within a few hundred million reads, and at once from the second run on -- the disk cache)
+    a->planes_seen += nreads;
+    const bool compile = force || pol == 1 || a->planes_seen >= jit::min_reads();
     return jit::spec_kernel(a, fp, pp, nw, ragged, ragged ? 32 * nw : max_len, compile);
 }
 

@@ -49,7 +49,7 @@ def profile_counters(config):
         return json.load(fh)
 
 
-STREAMING_KERNELS = ("filter_kernel", "insert_kernel")   # stream the packed batch with 16 bytes per lane (see live_counters)
+STREAMING_KERNELS = ("filter_kernel", "insert_kernel", "atr_piece_spec")   # stream the packed batch with 16 bytes per lane (see live_counters)
 
 
 def live_counters(config, reads, want_valu):
@@ -82,7 +82,7 @@ def live_counters(config, reads, want_valu):
                 with open(path) as fh:
                     for row in csv.DictReader(fh):
                         name = row["Kernel_Name"]
-                        if "atr::" in name and "pack" not in name and row["Counter_Name"] == counter:
+                        if ("atr::" in name or "atr_piece" in name) and "pack" not in name and row["Counter_Name"] == counter:
                             per[name] = per.get(name, 0.0) + float(row["Counter_Value"])
             shutil.rmtree(out, ignore_errors=True)
             if not per:

@@ -170,8 +170,8 @@ int atr_locate_planes_applies(const atr_aligner *a, int max_len, int ragged);
  * constants (hiprtc, found at run time), which removes the per-term scalar dispatch of the generic kernel.  An
  * aligner object of the reference lives for a whole run (adapters/__init__.py:311-322), so the compile (seconds,
  * once per adapter and machine: objects are kept under $ATR_KCACHE_DIR / ~/.cache/atropos_amd) is paid once.
- * atr_locate_planes_batch does this by itself for batches of >= $ATR_JIT_MIN_READS (4 M) reads; $ATR_JIT=0 turns it
- * off, =1 on for every call.  Same records either way.  ATR_OK: a specialised kernel is ready on the current device;
+ * atr_locate_planes_batch does this by itself once a handle has seen $ATR_JIT_MIN_READS (2 M) reads; $ATR_JIT=0 turns
+ * it off, =1 on for every call.  Same records either way.  ATR_OK: a specialised kernel is ready on the current device;
  * ATR_ERR_UNSUPPORTED: none (outside the envelope, switched off, no hiprtc) -- the generic kernel serves the calls. */
 int atr_aligner_prepare(const atr_aligner *a, int max_len, int ragged);
 int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, const int32_t *d_lens, int64_t nreads,

@@ -81,6 +81,8 @@ def main():
         out = subprocess.run(cmd, env=env, capture_output=True, text=True)
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "FAILED: " + out.stderr[-600:]
         print("%-28s %s" % (name, line), flush=True)
+        for extra in [l for l in out.stdout.splitlines() if l.startswith("wave ")][:8]:      # (-DATR_X_TIMING=1: device printf)
+            print("    " + extra, flush=True)
 
 
 if __name__ == "__main__":

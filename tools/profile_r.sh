@@ -31,7 +31,7 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         fh.write(",".join(rows[0]) + "\n")
         other_calls = other_ns = 0
         for r in rows[1:]:
-            if "atr::" in r[0]:
+            if ("atr::" in r[0] or "atr_piece" in r[0]):
                 fh.write(",".join('"%s"' % x if i == 0 else x for i, x in enumerate(r)) + "\n")
             else:
                 other_calls += int(r[1]); other_ns += int(r[2])
@@ -42,7 +42,7 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         meta = {}
         for r in rows:
             name = r["Kernel_Name"]
-            if "atr::" in name:
+            if ("atr::" in name or "atr_piece" in name):
                 durs[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 meta[name] = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")}
         fh.write("== kernel_trace reduced\n")
@@ -52,7 +52,7 @@ with open(os.path.join(out, "summary.txt"), "w") as fh:
         rows = list(csv.DictReader(open(f)))
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in rows:
-            if "atr::" in r["Kernel_Name"] and "pack_kernel" not in r["Kernel_Name"]:
+            if ("atr::" in r["Kernel_Name"] or "atr_piece" in r["Kernel_Name"]) and "pack_kernel" not in r["Kernel_Name"]:
                 acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         fh.write("== pmc %s\n" % f)
         for name, cs in acc.items():
