@@ -35,6 +35,7 @@
 namespace atr {
 
 constexpr int FILTER_MAX_M = 64;
+constexpr int FILTER_CERT_T = 3;                   // extension rows a perfect-overlap certificate covers (cost_l <= 3)
 constexpr int FILTER_BINS = 256;                   // 96 window-start bins of 8 columns (n <= 736) x 2 classes + 64 row-count bins
 
 struct FilterParams {
@@ -45,6 +46,8 @@ struct FilterParams {
     int32_t thr_row[FILTER_MAX_M + 1];              // last-column test of row i: D[i][n] <= thr_row[i]; -1 for a row that is
                                                     // no candidate at all (below min_overlap, or not row m without
                                                     // STOP_WITHIN_SEQ1).  32-bit entries of a kernel argument: scalar loads.
+    uint32_t cert[FILTER_CERT_T + 1];               // cert[t] bit i: a perfect overlap of i bases at the read end beats every
+                                                    // longer last-column row up to i + t (filter_overlap_certificates); 0: ask the DP
 };
 
 // NARROW mode.  A 33 .. 40-base adapter needs two 32-bit words per bit-vector and ~28 VALU ops per
@@ -68,6 +71,55 @@ constexpr int FILTER_NARROW_ROWS = 32, FILTER_NARROW_TAIL = 8;
 inline bool filter_narrow_applies(int m, int flags) {          // host side
     return m > FILTER_NARROW_ROWS && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && !(flags & ATR_START_WITHIN_SEQ1);
 }
+// PERFECT OVERLAP + EXTENSION ROWS, decided without the DP (round 5).  The commonest unresolved read of a 3' adapter
+// batch (1.2 M of C2's 2.26 M) ends with the adapter's first i bases verbatim: cell (i, n) costs 0 and holds i matches,
+// and the rows i + 1 .. i + t below it are acceptable too (i insertions on: cost 1 .. t <= floor((i + t) e)), so the
+// largest acceptable last-column row has errors and rounds 1 - 4 sent the read to the banded DP to learn that row i
+// wins anyway.  It wins unless some acceptable row r in (i, i + t] holds MORE than i matches (_align.pyx:464-474: more
+// matches, then fewer errors; a tie in matches loses to cost 0).  The matches of ANY path to (r, n) of cost <= kk =
+// floor((i + t) e) are a common subsequence of the adapter's rows 1 .. r and the read's last r + kk bases (at most kk
+// deletions): F . A[1 .. i], with F the t + kk bases before the overlap.  Whatever F holds,
+//     LCS(A[1 .. i + t], F . A[1 .. i]) = max over a of LCS(A[1 .. a], F) + LCS(A[a + 1 .. i + t], A[1 .. i])
+//                                      <= max over a of min(a, t + kk) + LCS(A[a + 1 .. i + t], A[1 .. i]),
+// and the right side depends on the ADAPTER alone: if it is <= i for every a >= 1 (a = 0 gives exactly i: the overlap
+// itself) no row can hold more than i matches and the record is (0, i, n - i, n, i, 0).  True for every i >= ~6 of an
+// adapter without long self-similar stretches; a poly-A tail fails the test and keeps the DP.  Literal comparison only
+// (with wildcards "matches A[j]" does not make the read's base equal to A[j]).  cert[t] bit i <=> the bound holds.
+inline void filter_overlap_certificates(const uint8_t *codes, int m, int rows, const int32_t *thr_row, bool and_mode,
+                                        uint32_t cert[FILTER_CERT_T + 1]) {
+    for (int t = 0; t <= FILTER_CERT_T; ++t) cert[t] = 0u;
+    if (and_mode || rows > 32 || rows < 2) return;
+    const int R = m < rows ? m : rows;                             // rows whose last-column cost the sweep knows exactly
+    // lcs[a][x][y] = LCS(A[a + 1 .. a + x], A[1 .. y]) for every a: one table per a serves every (i, t)
+    static thread_local uint8_t tab[FILTER_MAX_M + 1][FILTER_MAX_M + 1];
+    uint32_t bad[FILTER_CERT_T + 1];
+    for (int t = 0; t <= FILTER_CERT_T; ++t) bad[t] = 0u;
+    for (int a = 1; a <= R; ++a) {
+        const int xs = R - a;
+        for (int y = 0; y <= R; ++y) tab[0][y] = 0;
+        for (int x = 1; x <= xs; ++x) {
+            tab[x][0] = 0;
+            for (int y = 1; y <= R; ++y) {
+                const uint8_t up = tab[x - 1][y], left = tab[x][y - 1];
+                uint8_t v = up > left ? up : left;
+                if (codes[a + x - 1] == codes[y - 1] && (uint8_t)(tab[x - 1][y - 1] + 1) > v) v = (uint8_t)(tab[x - 1][y - 1] + 1);
+                tab[x][y] = v;
+            }
+        }
+        for (int t = 1; t <= FILTER_CERT_T; ++t)
+            for (int i = 1; i + t <= R && i < 32; ++i) {
+                const int top = i + t, kk = thr_row[top];
+                if (kk < t || a > top) continue;                        // (row i + t is no candidate at cost t: never asked)
+                const int free_bases = t + kk;
+                const int bound = (a < free_bases ? a : free_bases) + (int)tab[top - a][i];
+                if (bound > i) bad[t] |= 1u << i;
+            }
+    }
+    for (int t = 1; t <= FILTER_CERT_T; ++t)
+        for (int i = 1; i + t <= R && i < 32; ++i)
+            if (thr_row[i] >= 0 && thr_row[i + t] >= t && !((bad[t] >> i) & 1u)) cert[t] |= 1u << i;
+}
+
 // peq64: the aligner's match masks (top-aligned in 64 bits when m > 32, in 32 bits otherwise)
 inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, int m, int flags, bool and_mode,
                                   const int16_t *thr, int min_overlap) {
@@ -81,6 +133,7 @@ inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, i
         for (int c = 0; c < 16; ++c) fp.peq[c] = (peq64[c] >> (64 - m)) & 0xFFFFFFFFull;      // rows 1 .. 32 at bits 0 .. 31
         for (int t = 0; t < m - FILTER_NARROW_ROWS; ++t) fp.tail |= (uint32_t)(codes[FILTER_NARROW_ROWS + t] & 15u) << (4 * t);
     }
+    filter_overlap_certificates(codes, m, fp.rows, fp.thr_row, and_mode, fp.cert);
     return fp;
 }
 
@@ -456,6 +509,19 @@ ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const 
         rec[1] = (uint32_t)(n - row_l) | ((uint32_t)n << 16);
         rec[2] = (uint32_t)row_l;
         return 0;
+    }
+    if (!WIDE && !rowm && !u.sr && exact_l && u.indel == 1 && cost_l >= 1 && cost_l <= FILTER_CERT_T && row_l > cost_l) {
+        // PERFECT OVERLAP + EXTENSION ROWS (filter_overlap_certificates): the rows row_l - cost_l + 1 .. row_l each add one
+        // to the cost -- so (i, n), i = row_l - cost_l, costs 0: the read's last i bases are rows 1 .. i -- and the
+        // adapter's own structure rules out a longer row with more than i matches.  (0, i, n - i, n, i, 0).
+        const int i = row_l - cost_l, off = filter_row_offset(mf, false);
+        const uint32_t seg = ((1u << cost_l) - 1u) << (off + i);             // rows i + 1 .. row_l (row r at bit off + r - 1)
+        if ((F.pvl & seg) == seg && ((fp.cert[cost_l] >> i) & 1u) != 0u && n - i >= s) {
+            rec[0] = (uint32_t)i << 16;
+            rec[1] = (uint32_t)(n - i) | ((uint32_t)n << 16);
+            rec[2] = (uint32_t)i;
+            return 0;
+        }
     }
     if (!rowm && !u.sr && exact_l && u.indel == 1) {
         // LAST-COLUMN BAND.  Only last-column cells can be accepted, (row_l, n) is one of them (its cost is exact)

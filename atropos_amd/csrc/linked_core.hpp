@@ -54,6 +54,7 @@ struct BackParams {
     int16_t pf_thr[FILTER_MAX_M + 2];
     uint32_t tail;                                  // FilterParams::tail (NARROW mode)
     int32_t rows, m, k, min_overlap, indel, accept_full, reserved;
+    uint32_t cert[FILTER_CERT_T + 1];               // FilterParams::cert
 };
 
 struct LinkedParams {
@@ -91,6 +92,7 @@ struct LaneFilterParams {
     int rows, and_mode;
     uint32_t tail;
     const int32_t *thr_row;
+    const uint32_t *cert;                           // FilterParams::cert of the lane's adapter
 };
 
 // ---- Adapter.match_to's acceptance test (adapters/__init__.py:386-398) ---------------------

@@ -140,6 +140,7 @@ inline int linked_fill(atr_linked_set *s, const atr_linked_adapter *ad, int n) {
         B.tail = 0u;
         if (narrow)
             for (int t = 0; t < mb - FILTER_NARROW_ROWS; ++t) B.tail |= (uint32_t)(b->codes[FILTER_NARROW_ROWS + t] & 15u) << (4 * t);
+        filter_overlap_certificates(b->codes, mb, rows, B.thr_row, b->wildcard_ref || b->wildcard_query, B.cert);
         B.rows = rows; B.m = mb; B.k = b->p.k; B.min_overlap = b->p.min_overlap; B.indel = b->p.indel;
         B.accept_full = ad[i].back_exact_shortcut ? 1 : 0;
 

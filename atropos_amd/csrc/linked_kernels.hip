@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     }
                 }
                 LaneFilterParams lf;
-                lf.rows = mf; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
+                lf.rows = mf; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row; lf.cert = bp.cert;
                 ww = filter_decide<WIDE>(F, ub, lf, (const uint32_t *)tp, nchunks, n, brec, s);
                 if (!has) { ww = 0u; rec_none(brec); }
                 else if (!window_valid(ww))

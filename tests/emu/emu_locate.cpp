@@ -565,7 +565,7 @@ static void emu_linked_l1(const atr_linked_set *s, const uint32_t *pk, const int
                 if ((z & 3) == 3 || 8 * (z + 1) >= n) filter_fold(F, jlast, bp.rows, (uint32_t)ub.k);      // as the kernel: once per 32-column chunk
             }
             LaneFilterParams lf;
-            lf.rows = bp.rows; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row;
+            lf.rows = bp.rows; lf.and_mode = AND_MODE ? 1 : 0; lf.tail = bp.tail; lf.thr_row = bp.thr_row; lf.cert = bp.cert;
             ww = filter_decide<WIDE>(F, ub, lf, q, nchunks, n, brec, sft);
             if (!window_valid(ww))
                 linked_finish(brec, sft, ub.m, ub.min_overlap, bp.pf_thr, bp.accept_full != 0, s->rmp.back[which], s->rmp.back_ld[which],
