@@ -487,37 +487,47 @@ ATR_DEV uint32_t facing_mismatches(const uint32_t a[4], W2 b2word, int nwords, i
 // the bit planes), else 0: read from the matrices.
 // The decision once the position's bytes are on hand: base1 = read1[i], raw2 = read2[jx] (not yet
 // complemented), qa / qb their qualities (ignored without quality rows).
-ATR_DEV int correct_apply(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, uint8_t base1, uint8_t raw2,
-                          int qa, int qb, int action, int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend) {
+// (the three counters as ONE packed word: with three `int &` the compiler indexed them in scratch memory)
+constexpr uint32_t CORRECT_C1 = 1u, CORRECT_C2 = 1u << 10, CORRECT_NP = 1u << 20;
+ATR_DEV int correct_apply_delta(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, uint8_t base1, uint8_t raw2,
+                          int qa, int qb, int action, int min_qual_diff, const uint8_t *comp, uint32_t &delta) {
     const bool has_quals = q1 != nullptr && q2 != nullptr;
     const uint8_t base2 = comp[raw2];
     if (base2 == 0) return -1;
     if (base1 == base2) return 0;
     if (action == 0) {                             // 'N'
-        s1[i] = 'N'; s2[jx] = 'N'; ++c1; ++c2;
+        s1[i] = 'N'; s2[jx] = 'N'; delta += CORRECT_C1 + CORRECT_C2;
     } else if (base1 == 'N') {
         s1[i] = base2;
         if (has_quals) q1[i] = (uint8_t)qb;
-        ++c1;
+        delta += CORRECT_C1;
     } else if (base2 == 'N') {
         const uint8_t cb = comp[base1];
         if (cb == 0) return -1;
         s2[jx] = cb;
         if (has_quals) q2[jx] = (uint8_t)qa;
-        ++c2;
+        delta += CORRECT_C2;
     } else if (has_quals) {
         const int diff = qa - qb;
         if (diff >= min_qual_diff) {
             const uint8_t cb = comp[base1];
             if (cb == 0) return -1;
-            s2[jx] = cb; q2[jx] = (uint8_t)qa; ++c2;
+            s2[jx] = cb; q2[jx] = (uint8_t)qa; delta += CORRECT_C2;
         } else if (diff <= -min_qual_diff) {
-            s1[i] = base2; q1[i] = (uint8_t)qb; ++c1;
+            s1[i] = base2; q1[i] = (uint8_t)qb; delta += CORRECT_C1;
         } else if (action == 2) {
-            ++npend;                               // quals_equal.append(...)
+            delta += CORRECT_NP;                   // quals_equal.append(...)
         }
     }
     return 0;
+}
+
+ATR_DEV int correct_apply(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, uint8_t base1, uint8_t raw2,
+                          int qa, int qb, int action, int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend) {
+    uint32_t delta = 0u;
+    const int e = correct_apply_delta(s1, q1, s2, q2, i, jx, base1, raw2, qa, qb, action, min_qual_diff, comp, delta);
+    c1 += (int)(delta & 1023u); c2 += (int)((delta >> 10) & 1023u); npend += (int)(delta >> 20);
+    return e;
 }
 
 ATR_DEV int correct_position(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, int action,

@@ -209,12 +209,14 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     // uint16 tasks that fit the plane staging area; at most 63 left over + 64 x 32 new ones are ever queued
     static_assert(4 * PW * 64 * 2 >= 64 * 32 + 64, "task queue does not fit the plane staging area");
     __shared__ uint8_t s_comp[256];
+    __shared__ uint8_t s_letter[16];                              // DNA15 code -> its byte
     __shared__ uint32_t s_b2[4][4 * PW][64];                      // per wave: read 2's planes, [plane * W + word][lane]; then the queue
     __shared__ uint32_t s_cnt[4][64];                             // per pair: c1 | c2 << 10 | npend << 20
     __shared__ int32_t s_err[4][64];
     __shared__ int16_t s_j[4][64];
     __shared__ uint32_t s_tail[4];
     s_comp[threadIdx.x] = ct.c[threadIdx.x];
+    if (threadIdx.x < 16) s_letter[threadIdx.x] = (uint8_t)"\0ACMGRSVTWYHKDBN"[threadIdx.x];   // (A 1, C 2, G 4, T 8 and their unions)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long tile = (long long)blockIdx.x * 4 + wave;
@@ -260,13 +262,22 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
             const int src = (int)(t >> 9), i = (int)(t & 511u);
             const int jx = (int)s_j[wave][src] - 1 - i;
             const size_t row = (size_t)(tile * 64 + src) * (size_t)stride;
-            const uint8_t base1 = s1[row + i], raw2 = s2[row + jx];
+            // The two BASES come from the bit planes, not from the ASCII matrices: the pair's chunks were streamed by this
+            // wave a moment ago (L2), a DNA15 code names its byte (15 upper-case letters, aligner_host.hpp), and a byte
+            // fetched from a matrix costs a 64-byte sector of HBM -- two of the four a task used to pull (round 4:
+            // 1 068 B per pair counted).  Code 0 (a byte outside the table): read the matrix as before.
+            const uint4 v1 = planes1[((size_t)tile * nchunks + (size_t)(i >> 5)) * 64 + src];
+            const uint4 v2 = planes2[((size_t)tile * nchunks + (size_t)(jx >> 5)) * 64 + src];
+            const uint32_t b1 = (uint32_t)(i & 31), b2s = (uint32_t)(jx & 31);
+            const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
+            const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
             const int qa = has_quals ? (int)q1[row + i] : 0, qb = has_quals ? (int)q2[row + jx] : 0;
-            int c1 = 0, c2 = 0, np = 0;
-            const int e = correct_apply(s1 + row, has_quals ? q1 + row : nullptr, s2 + row, has_quals ? q2 + row : nullptr, i, jx,
-                                        base1, raw2, qa, qb, action, min_qual_diff, s_comp, c1, c2, np);
+            const uint8_t base1 = code1 ? s_letter[code1] : s1[row + i], raw2 = code2 ? s_letter[code2] : s2[row + jx];
+            uint32_t delta = 0u;
+            const int e = correct_apply_delta(s1 + row, has_quals ? q1 + row : nullptr, s2 + row, has_quals ? q2 + row : nullptr, i, jx,
+                                              base1, raw2, qa, qb, action, min_qual_diff, s_comp, delta);
             if (e) s_err[wave][src] = e;
-            else if (c1 | c2 | np) atomicAdd(&s_cnt[wave][src], (uint32_t)c1 | ((uint32_t)c2 << 10) | ((uint32_t)np << 20));
+            else if (delta) atomicAdd(&s_cnt[wave][src], delta);
         }
     };
     int qsize = 0;                                                // wave-uniform
