@@ -45,21 +45,21 @@
 
 namespace atr {
 
-constexpr int PIECE_NB = 4;                 // body pieces (k + 1 <= 4; a piece too many only weakens the filter); piece_scan
-                                            // names the four by hand
-constexpr int PIECE_NT = 4;                 // read-end pieces (error classes t = 1 .. 3)
+constexpr int PIECE_NB = 5;                 // body pieces at most: max(4, k + 1), k <= 4 (a piece too many only weakens the filter)
+constexpr int PIECE_NT = 5;                 // read-end pieces at most (error classes t = 1 .. 4)
 constexpr int PIECE_STEPS = 8;              // longest read-end piece / body pieces 0 .. 2
 constexpr int PIECE_LAST_STEPS = 16;        // the last body piece takes the rows that are left: up to 16
 constexpr int PIECE_TAIL_WORDS = 3;         // plane words the read-end pieces are evaluated on: the read's last three
 constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (two words per plane)
-constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps: one hit diagonal needs 32 + T + 3 k columns, a read-end
-                                            // condition 32 + T + k (94 % of C2's flagged reads); longer windows take the full sweep
+constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps when k <= 3 (PieceParams::narrow): one hit diagonal needs
+                                            // rows + T + 2 k columns, a read-end condition rows + T + k (94 % of C2's flagged
+                                            // reads); longer windows take the full sweep
 constexpr int PIECE_MAX_WORDS = 10;         // reads of up to 320 bases
 constexpr uint32_t PIECE_NODENSE = 1u << 30;   // window word of an `order` entry: no 64-code record in tdata, gather the read
 
 struct PieceParams {
-    int blen;                               // body piece p = rows [p blen, (p + 1) blen), 0-based rows; the LAST one runs to row m:
-    int llen;                               //   llen = m - 3 blen rows (all four on one diagonal = the adapter, verbatim)
+    int blen;                               // body piece p = rows [p blen, (p + 1) blen), 0-based rows; the LAST one (nb - 1) runs to
+    int llen;                               //   row m: llen = m - (nb - 1) blen rows (all nb on one diagonal = the adapter, verbatim)
     int m;                                  // adapter length
     int tlen;                               // read-end piece u = rows [u tlen, (u + 1) tlen); 0: none
     int steps;                              // max(llen, tlen)
@@ -67,9 +67,13 @@ struct PieceParams {
     int tail_cols;                          // columns before the read end a read with a read-end condition sweeps
     int tw0;                                // first plane word of the read-end pieces' masks: max(0, ceil(n / 32) - 3)
     int and_mode;                           // wildcard comparison (code & code): a base matches code c iff its plane c is set
+    int nb;                                 // body pieces: max(4, k + 1)
+    int narrow;                             // columns a pass-B task sweeps at most: 8 ceil((rows + T + 2 k) / 8)  (40 for k <= 3)
+    int plen[PIECE_NB];                     // rows of body piece p (0: not there)
+    int pshift[PIECE_NB];                   // its last row minus piece 0's last row: hits of piece p, moved down by this, sit in piece 0's place
     uint32_t scode[PIECE_LAST_STEPS];       // per shift step s, two bits per piece: the plane index (0 .. 3) of the row it
                                             // compares in that step (its last row minus s); body piece p at bits 2p,
-                                            // read-end piece u at bits 8 + 2u (one scalar load per step, s_bitcmp1 per term)
+                                            // read-end piece u at bits 10 + 2u (one scalar load per step, s_bitcmp1 per term)
     uint32_t tmask[PIECE_NT][PIECE_TAIL_WORDS];   // END positions a read-end piece may have (words tw0 ..), 0: piece unused
     uint32_t xmask[32][4];                  // [i][c]: the rows r < i that hold the code of plane c, at bit 32 - i + r (the place of
                                             // row r in the read's last 32 positions when the overlap has i bases)
@@ -88,18 +92,22 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     if ((flags & need) != need || (flags & ATR_START_WITHIN_SEQ1) || custom_table) return false;
     if (rows > 32 || rows < 1 || k < 0 || k > PIECE_NB - 1 || k >= m) return false;
     if (n < 1 || n > 32 * PIECE_MAX_WORDS) return false;
-    const int blen = std::min(PIECE_STEPS, rows / PIECE_NB);
+    const int nb = k + 1 > 4 ? k + 1 : 4;
+    const int blen = std::min(PIECE_STEPS, rows / nb);
     if (blen < 5 || k > blen - 1) return false;                      // (k <= blen - 1: the diagonal mask keeps every hit)
     // The pieces cover ALL m rows (an alignment of the whole adapter with <= k errors leaves one of any k + 1 disjoint
-    // pieces intact): the last one takes what 3 blen rows leave.  Four exact pieces on one diagonal are then the
+    // pieces intact): the last one takes what (nb - 1) blen rows leave.  All pieces on one diagonal are then the
     // adapter verbatim -- the reference's early exit (_align.pyx:456-458) -- which pass A resolves itself.
-    const int llen = m - (PIECE_NB - 1) * blen;
+    const int llen = m - (nb - 1) * blen;
     if (llen < blen || llen > PIECE_LAST_STEPS) return false;
     const int body_rows = m;
     for (int i = 0; i < m; ++i) if (piece_plane_of(codes[i]) < 0) return false;
-    pp.blen = blen; pp.llen = llen; pp.m = m; pp.and_mode = and_mode ? 1 : 0;
-    for (int p = 0; p < PIECE_NB; ++p) {
-        const int len = p == PIECE_NB - 1 ? llen : blen;
+    pp.blen = blen; pp.llen = llen; pp.m = m; pp.and_mode = and_mode ? 1 : 0; pp.nb = nb;
+    pp.narrow = std::min(PIECE_WINDOW, std::max(PIECE_NARROW, (rows + (m - rows) + 2 * k + 7) & ~7));
+    for (int p = 0; p < nb; ++p) {
+        const int len = p == nb - 1 ? llen : blen;
+        pp.plen[p] = len;
+        pp.pshift[p] = p == nb - 1 ? m - blen : p * blen;            // 0 .. 32
         for (int s = 0; s < len; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[p * blen + len - 1 - s]) << (2 * p);
     }
     for (int i = 1; i < 32; ++i)
@@ -107,13 +115,13 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     // Last-column candidates of the rows i < m (row m in the last column is a row-m candidate: a body piece):
     // thr_row[i] = floor(i e), or -1 for a row that is no candidate (below min_overlap / no STOP_WITHIN_SEQ1).
     // Rows with thr 0 are tested exactly; rows with thr t >= 1 form class t.
-    int ilo[PIECE_NB], ihi[PIECE_NB];
-    for (int t = 0; t < PIECE_NB; ++t) { ilo[t] = 0; ihi[t] = -1; }
+    int ilo[PIECE_NT], ihi[PIECE_NT];
+    for (int t = 0; t < PIECE_NT; ++t) { ilo[t] = 0; ihi[t] = -1; }
     const int top = m - 1;
     for (int i = 1; i <= top; ++i) {
         const int t = thr_row[i];
         if (t < 0) continue;
-        if (t >= PIECE_NB) return false;
+        if (t >= PIECE_NT) return false;
         if (i > 1 && thr_row[i - 1] > t) return false;               // (monotone thresholds: floor(i e))
         if (ihi[t] < 0) ilo[t] = i;
         ihi[t] = i;
@@ -122,7 +130,7 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     if (ihi[0] >= 0) { pp.xlo = ilo[0]; pp.xhi = ihi[0]; }
     if (pp.xhi > 31) return false;
     int tmax = 0;
-    for (int t = 1; t < PIECE_NB; ++t) if (ihi[t] >= 0) tmax = t;
+    for (int t = 1; t < PIECE_NT; ++t) if (ihi[t] >= 0) tmax = t;
     pp.tlen = 0;
     const int wl = (n - 1) >> 5;                                     // word of the read's last base = NW - 1 of the kernel
     pp.tw0 = std::max(0, wl - (PIECE_TAIL_WORDS - 1));
@@ -130,12 +138,12 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
         // piece length: t + 1 pieces must fit the shortest overlap of every class t
         int tlen = PIECE_STEPS;
         for (int t = 1; t <= tmax; ++t) if (ihi[t] >= 0) tlen = std::min(tlen, ilo[t] / (t + 1));
-        if (tlen < 5) return false;
+        if (tlen < 4) return false;                                  // (four bases: a chance hit per 256 positions and piece)
         pp.tlen = tlen;
         for (int u = 0; u < PIECE_NT; ++u) {
             if (u > tmax) continue;
             if ((u + 1) * tlen > body_rows) return false;
-            for (int s = 0; s < tlen; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (8 + 2 * u);
+            for (int s = 0; s < tlen; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (10 + 2 * u);
             // ... and piece u serves the classes t >= max(1, u) whose first t + 1 pieces fit their shortest overlap.
             for (int t = std::max(1, u); t <= tmax; ++t) {
                 if (ihi[t] < 0) continue;
@@ -430,6 +438,7 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     for (int u = 0; u < PIECE_NT; ++u)
 #pragma unroll
         for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
+    const int plen3 = pp.plen[3], plen4 = pp.plen[4];
     for (int s = 0; s < pp.steps; ++s) {                             // wave-uniform
         const uint32_t cw = pp.scode[s];
         if (s < pp.blen) {
@@ -437,12 +446,14 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
             piece_and_term<NW, NW, 0, 2>(occ[1], Y, cw);
             piece_and_term<NW, NW, 0, 4>(occ[2], Y, cw);
         }
-        if (s < pp.llen) piece_and_term<NW, NW, 0, 6>(occ[3], Y, cw);
+        if (s < plen3) piece_and_term<NW, NW, 0, 6>(occ[3], Y, cw);
+        if (s < plen4) piece_and_term<NW, NW, 0, 8>(occ[4], Y, cw);
         if (s < pp.tlen) {
-            piece_and_term<NW, TWN, TW0, 8>(tocc[0], Y, cw);
-            piece_and_term<NW, TWN, TW0, 10>(tocc[1], Y, cw);
-            piece_and_term<NW, TWN, TW0, 12>(tocc[2], Y, cw);
-            piece_and_term<NW, TWN, TW0, 14>(tocc[3], Y, cw);
+            piece_and_term<NW, TWN, TW0, 10>(tocc[0], Y, cw);
+            piece_and_term<NW, TWN, TW0, 12>(tocc[1], Y, cw);
+            piece_and_term<NW, TWN, TW0, 14>(tocc[2], Y, cw);
+            piece_and_term<NW, TWN, TW0, 16>(tocc[3], Y, cw);
+            piece_and_term<NW, TWN, TW0, 18>(tocc[4], Y, cw);
         }
         if (s + 1 < pp.steps) piece_shift_masks<NW>(Y);
     }
@@ -465,7 +476,8 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     for (int w = 0; w < NW; ++w) dm[w] = pf[w] = occ[0][w];
 #pragma unroll
     for (int p = 1; p < PIECE_NB; ++p) {
-        const int sh = p == PIECE_NB - 1 ? pp.m - pp.blen : p * pp.blen;           // 0 .. 32 (wave-uniform)
+        if (p >= pp.nb) continue;                                    // (wave-uniform: four pieces unless k = 4)
+        const int sh = pp.pshift[p];                                 // 0 .. 32 (wave-uniform)
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             // words w, w + 1 (+ 1 when sh == 32: the funnel then takes the next pair with shift 0)
@@ -574,16 +586,20 @@ ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&
                 term(occ[2][w], Y.y[(cw >> 4) & 3u][w], s == 0);
             }
         }
-        if constexpr (s < spec::PP.llen) {
+        if constexpr (s < spec::PP.plen[3]) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) term(occ[3][w], Y.y[(cw >> 6) & 3u][w], s == 0);
+        }
+        if constexpr (s < spec::PP.plen[4]) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) term(occ[4][w], Y.y[(cw >> 8) & 3u][w], s == 0);
         }
         if constexpr (s < spec::PP.tlen) {
             piece_static_for<0, PIECE_NT>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 if constexpr ((spec::PP.tmask[u][0] | spec::PP.tmask[u][1] | spec::PP.tmask[u][2]) != 0u) {
 #pragma unroll
-                    for (int w = 0; w < TWN; ++w) term(tocc[u][w], Y.y[(cw >> (8 + 2 * u)) & 3u][TW0 + w], false);
+                    for (int w = 0; w < TWN; ++w) term(tocc[u][w], Y.y[(cw >> (10 + 2 * u)) & 3u][TW0 + w], false);
                 }
             });
         }
@@ -602,9 +618,9 @@ ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&
     uint32_t dm[NW], pf[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) dm[w] = pf[w] = occ[0][w];
-    piece_static_for<1, PIECE_NB>([&](auto pc) {
+    piece_static_for<1, spec::PP.nb>([&](auto pc) {
         constexpr int p = decltype(pc)::value;
-        constexpr int sh = p == PIECE_NB - 1 ? spec::PP.m - spec::PP.blen : p * spec::PP.blen;     // 0 .. 32
+        constexpr int sh = spec::PP.pshift[p];                       // 0 .. 32
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const uint32_t lo = sh >= 32 ? (w + 1 < NW ? occ[p][w + 1 < NW ? w + 1 : w] : 0u) : occ[p][w];

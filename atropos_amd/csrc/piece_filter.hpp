@@ -148,7 +148,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             if (d + 1 < 8) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);     // one dword ahead of the columns that use it
 #pragma unroll
             for (int b = 0; b < 8; ++b) filter_step<false>(F, e[b].x, e[b].y, kreg);
-            if (d == 3) filter_fold(F, j_e - 32, mf, kreg);                           // 32 columns at most between two folds
+            if (d == 3 && dw0 <= 3) filter_fold(F, j_e - 32, mf, kreg);               // 32 columns at most between two folds
         }
         filter_fold(F, j_e, mf, kreg);
         uint32_t rec[4];
@@ -243,7 +243,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         }
         const bool flagged = live && S.flagged && !exact;
         const int need = S.j_e - max(S.j_s, back);                // (columns before the read: nothing to sweep)
-        const bool narrow = flagged && need <= PIECE_NARROW, wide = flagged && !narrow;
+        const bool narrow = flagged && need <= pp.narrow, wide = flagged && !narrow;
         if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);   // None
         // (the task carries the read's own columns: a ragged batch was scanned moved to the end of its words)
         const uint32_t meta = (uint32_t)(S.j_e - back) | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);

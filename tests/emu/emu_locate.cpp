@@ -312,12 +312,12 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     ++g_piece_stats[1];
     if (S.tail) ++g_piece_stats[2];
     ++g_piece_need[std::min(11, (need + 7) / 8)];
-    if (need > PIECE_NARROW) ++g_piece_stats[3]; else g_piece_stats[4] += (need + 7) & ~7;
+    if (need > pp.narrow) ++g_piece_stats[3]; else g_piece_stats[4] += (need + 7) & ~7;
     const uint32_t *q = nib + (((size_t)(r >> 6) * NW) * 64 + (r & 63)) * 4;
     const auto tm = [&](int jp) { return filter_tail_matches(fp, T, q, NW, jp); };
     FilterState F;
     filter_init(F, u, mf);
-    if (need <= PIECE_NARROW) {
+    if (need <= pp.narrow) {
         const int W = std::min(PIECE_WINDOW, ((need + 7) & ~7) + 8 * (int)(r % 3));
         for (int rc = PIECE_WINDOW - W + 1; rc <= PIECE_WINDOW; ++rc) {
             const int j = j_e - PIECE_WINDOW + rc;
