@@ -383,6 +383,14 @@ ATR_DEV void piece_and_term(uint32_t (&acc)[N], const PieceMasks<NW> &Y, uint32_
 #endif
 }
 
+ATR_DEV int piece_uniform(int v) {
+#ifdef ATR_HOST_EMU
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+
 // (hi:lo) >> sh, low word; sh in 0 .. 31
 ATR_DEV uint32_t piece_funnel(uint32_t hi, uint32_t lo, int sh) {
 #ifdef ATR_HOST_EMU
@@ -438,24 +446,26 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     for (int u = 0; u < PIECE_NT; ++u)
 #pragma unroll
         for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
-    const int plen3 = pp.plen[3], plen4 = pp.plen[4];
-    for (int s = 0; s < pp.steps; ++s) {                             // wave-uniform
-        const uint32_t cw = pp.scode[s];
-        if (s < pp.blen) {
+    // (wave-uniform parameters: said so, for callers whose PieceParams sit behind a pointer -- linked_kernels.hip)
+    const int plen3 = piece_uniform(pp.plen[3]), plen4 = piece_uniform(pp.plen[4]);
+    const int steps = piece_uniform(pp.steps), blen = piece_uniform(pp.blen), tlen = piece_uniform(pp.tlen);
+    for (int s = 0; s < steps; ++s) {                                // wave-uniform
+        const uint32_t cw = (uint32_t)piece_uniform((int)pp.scode[s]);
+        if (s < blen) {
             piece_and_term<NW, NW, 0, 0>(occ[0], Y, cw);
             piece_and_term<NW, NW, 0, 2>(occ[1], Y, cw);
             piece_and_term<NW, NW, 0, 4>(occ[2], Y, cw);
         }
         if (s < plen3) piece_and_term<NW, NW, 0, 6>(occ[3], Y, cw);
         if (s < plen4) piece_and_term<NW, NW, 0, 8>(occ[4], Y, cw);
-        if (s < pp.tlen) {
+        if (s < tlen) {
             piece_and_term<NW, TWN, TW0, 10>(tocc[0], Y, cw);
             piece_and_term<NW, TWN, TW0, 12>(tocc[1], Y, cw);
             piece_and_term<NW, TWN, TW0, 14>(tocc[2], Y, cw);
             piece_and_term<NW, TWN, TW0, 16>(tocc[3], Y, cw);
             piece_and_term<NW, TWN, TW0, 18>(tocc[4], Y, cw);
         }
-        if (s + 1 < pp.steps) piece_shift_masks<NW>(Y);
+        if (s + 1 < steps) piece_shift_masks<NW>(Y);
     }
     // (a piece cannot end before its own length: after s shifts the bits below s are zero)
     if (pp.tlen > 0) {
@@ -476,8 +486,8 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     for (int w = 0; w < NW; ++w) dm[w] = pf[w] = occ[0][w];
 #pragma unroll
     for (int p = 1; p < PIECE_NB; ++p) {
-        if (p >= pp.nb) continue;                                    // (wave-uniform: four pieces unless k = 4)
-        const int sh = pp.pshift[p];                                 // 0 .. 32 (wave-uniform)
+        if (p >= piece_uniform(pp.nb)) continue;                     // (wave-uniform: four pieces unless k = 4)
+        const int sh = piece_uniform(pp.pshift[p]);                  // 0 .. 32 (wave-uniform)
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             // words w, w + 1 (+ 1 when sh == 32: the funnel then takes the next pair with shift 0)

@@ -22,7 +22,7 @@ def child(args):
     from atropos_amd.align import Aligner
     _lib.set_backend(None)
     w = synth.workload(args.config, 0, args.reads, device="cuda:0")
-    al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    al = Aligner(w["adapter"], args.e if args.e else w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
     reads = w["reads"]
     if args.ragged:
         rng = np.random.default_rng(3)
@@ -31,6 +31,8 @@ def child(args):
         reads = torch.where(col < lens[:, None], reads, torch.zeros_like(reads))
         from atropos_amd.batch import ReadBatch
         batch = ReadBatch.from_ascii(reads, lens, None, al.table_kind, None, _lib.get_backend(), planes=True)
+    elif os.environ.get("AB_LAYOUT") == "tile64":
+        batch = al.pack(reads, layout="tile64")
     else:
         batch = al.pack(reads, layout="plane64")
     t_prep = None
@@ -63,6 +65,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--ragged", action="store_true")
+    ap.add_argument("--e", type=float, default=0.0)
     ap.add_argument("--child", action="store_true")
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
@@ -77,7 +80,7 @@ def main():
                 k, _, val = kv.partition("=")
                 env[k] = val.replace("+", " ")
         cmd = [sys.executable, os.path.abspath(__file__), "--child", "--reads", str(args.reads), "--steps", str(args.steps),
-               "--rounds", str(args.rounds), "--config", args.config] + (["--ragged"] if args.ragged else [])
+               "--rounds", str(args.rounds), "--config", args.config, "--e", str(args.e)] + (["--ragged"] if args.ragged else [])
         out = subprocess.run(cmd, env=env, capture_output=True, text=True)
         line = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else "FAILED: " + out.stderr[-600:]
         print("%-28s %s" % (name, line), flush=True)
