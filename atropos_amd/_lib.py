@@ -229,7 +229,23 @@ class HipBackend(object):
         if ndev < 1:
             raise AtroposHipError("atr_device_count() == 0: no HIP device")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        self._work = None
+        self._works = {}                  # the kernels' scratch, one per stream calls are issued on (Aligner.locate_stream)
+        self._side = []
+
+    @property
+    def _work(self):
+        return self._works.get(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @_work.setter
+    def _work(self, tensor):
+        self._works[torch.cuda.current_stream(self.device).cuda_stream] = tensor
+
+    def side_streams(self, count):
+        """``count`` streams of this backend's device, created once (Aligner.locate_stream issues consecutive batches
+        on them in turn; every stream gets a workspace of its own)."""
+        while len(self._side) < count:
+            self._side.append(torch.cuda.Stream(device=self.device))
+        return self._side[:count]
 
     # -- helpers ---------------------------------------------------------------
     @contextlib.contextmanager

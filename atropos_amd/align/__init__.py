@@ -249,6 +249,47 @@ class Aligner(object):
                              % (what, batch.layout))
 
     # -- alignment ----------------------------------------------------------------------
+    def locate_stream(self, batches, depth=2):
+        """``locate_batch`` over a sequence of batches with the calls issued on ``depth`` streams in turn (a workspace
+        each): the call of batch i + 1 -- its pre-pass -- runs while the exact DP of batch i is still finishing, which a
+        single stream cannot do (the two phases of ONE call are both issue-bound and serial).  A generator: the result
+        of batch i is yielded once batch i + depth - 1 has been issued; the caller's current stream is made to wait
+        for it (``wait_event``), so device work queued afterwards sees complete records -- host reads need the usual
+        synchronisation.  Same records as ``locate_batch``, batch by batch.  (Long batches: with short ones the calls
+        are latency-bound and there is nothing to overlap.)"""
+        import collections
+        be = self._backend
+        if not hasattr(be, "side_streams"):                      # (the CPU test double: one call after the other)
+            for b in batches:
+                yield self.locate_batch(b)
+            return
+        streams = be.side_streams(max(1, int(depth)))
+        caller = torch.cuda.current_stream(be.device)
+        pending = collections.deque()
+
+        def hand_over():
+            res, ev, keep = pending.popleft()
+            caller.wait_event(ev)
+            return res
+
+        for i, b in enumerate(batches):
+            st = streams[i % len(streams)]
+            batch = self.pack(b) if not isinstance(b, ReadBatch) else b
+            st.wait_stream(caller)                                   # (the batch was produced on the caller's stream)
+            with torch.cuda.stream(st):
+                res = self.locate_batch(batch)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            for t in (batch.packed, batch.lens):
+                if t is not None:
+                    t.record_stream(st)
+            res.records.record_stream(caller)
+            pending.append((res, ev, batch))
+            if len(pending) >= len(streams):
+                yield hand_over()
+        while pending:
+            yield hand_over()
+
     def locate_batch(self, reads, filtered=True, path=None):
         """Batched ``locate``: one result record per read (see LocateResult).  The library picks
         its kernels by batch size (a wavefront per read for short batches, the filtered pipeline --

@@ -65,6 +65,25 @@ def sharded_locate(aligner, reads, host_group=None):
     return local, gather_records_on_host(local.records, total, host_group)
 
 
+def sharded_locate_stream(aligner, reads, sub_batch=10_000_000, host_group=None, depth=2):
+    """``sharded_locate`` for shards of many millions of reads: the rank's shard goes through
+    ``Aligner.locate_stream`` in sub-batches of ``sub_batch`` reads -- packed one ahead, issued on ``depth``
+    streams in turn, so that the exact DP of a sub-batch finishes under the pre-pass of the next -- and the
+    records are concatenated in input order.  Returns (records int16 [shard, 8] on the device, gathered CPU
+    tensor at rank 0 or None)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(host_group), dist.get_world_size(host_group)
+    else:
+        rank, world = 0, 1
+    total = reads.shape[0]
+    mine = local_shard(reads, rank, world)
+    parts = (mine[lo:lo + sub_batch] for lo in range(0, mine.shape[0], sub_batch))
+    recs = [r.records for r in aligner.locate_stream(parts, depth=depth)]
+    local = torch.cat(recs, dim=0) if recs else torch.empty((0, 8), dtype=torch.int16, device=mine.device)
+    return local, gather_records_on_host(local, total, host_group)
+
+
 def device_backends(devices=None):
     """One HipBackend per GPU of this process (all visible ones by default)."""
     from . import _lib

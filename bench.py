@@ -132,39 +132,27 @@ def timed_cpu(fn, units, what, cores, target_s=8.0):
 
 
 def _c2_two_streams(self, steps=40):
-    """Consecutive batches issued on two streams, a backend (workspace) each: the DP phase of batch i runs under the
-    pre-pass of batch i + 1 (tools/micro/two_streams.py).  What a double-buffered caller gets; NOT the bench's `value`,
-    which is the plain call issued back to back on one stream."""
-    from atropos_amd import _lib
-    from atropos_amd.align import Aligner
-    prev = _lib.get_backend()
-    als, batches = [], []
-    try:
-        for _ in range(2):
-            _lib.set_backend(_lib.HipBackend(prev.device.index), _test_double=True)
-            al = Aligner(*self.al_args)
-            als.append(al)
-            batches.append(al.pack(self.ascii, layout=self.batch.layout) if self.ascii is not None else self.batch)
-    finally:
-        _lib.set_backend(prev, _test_double=True)
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-
-    def run(nstreams):
+    """Consecutive batches through the product's streaming form of the call, ``Aligner.locate_stream`` (two streams, a
+    workspace each: the exact DP of batch i finishes under the pre-pass of batch i + 1), against the same calls on one
+    stream.  What a double-buffered caller gets (atropos_amd.shard.sharded_locate_stream); NOT the bench's `value`,
+    which is the plain call issued back to back on one stream with every step's records complete inside the timed region."""
+    def run(depth):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        keep = []
-        for i in range(steps):
-            with torch.cuda.stream(streams[i % nstreams]):
-                keep.append(als[i % nstreams].locate_batch(batches[i % nstreams], self.filtered).records)
-            del keep[:-4]
+        last = None
+        for res in self.al.locate_stream((self.batch for _ in range(steps)), depth=depth):
+            last = res
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps
+        return (time.perf_counter() - t0) / steps, last
 
     res = {}
     for n in (1, 2):
         run(n)
-        res["streams_%d_reads_per_s" % n] = self.n / min(run(n) for _ in range(3))
-    res["note"] = "steps alternate between two streams with a workspace each; not the line's value"
+        best = min(run(n)[0] for _ in range(3))
+        res["streams_%d_reads_per_s" % n] = self.n / best
+    ref = self.al.locate_batch(self.batch, self.filtered).records
+    res["records_equal_one_call"] = bool(torch.equal(run(2)[1].records, ref))
+    res["note"] = "Aligner.locate_stream(depth=2): steps alternate between two streams with a workspace each; not the line's value"
     return res
 
 
@@ -691,6 +679,37 @@ def self_launch(args):
     return rc
 
 
+def scaling_curve(args):
+    """`python bench.py --scaling`: the N = 1, 2, 4, 8 lines of the headline config from one invocation, each N as a
+    self-launched group of N ranks (one process per GPU, gloo barrier, no collective on the data path).  N beyond the
+    node's GPU count is left out and said so on stderr -- a curve is only claimed for what ran."""
+    import subprocess
+    ndev = 1 if EMU else torch.cuda.device_count()
+    rc = 0
+    base = [a for a in sys.argv[1:] if a != "--scaling"]
+    skip = False
+    argv = []
+    for a in base:                                        # (drop a --gpus N the caller may have given)
+        if skip:
+            skip = False
+            continue
+        if a == "--gpus":
+            skip = True
+            continue
+        if a.startswith("--gpus="):
+            continue
+        argv.append(a)
+    for n in (1, 2, 4, 8):
+        if n > ndev and not args.oversubscribe:
+            sys.stderr.write("bench.py --scaling: N = %d left out, %d GPU(s) visible\n" % (n, ndev))
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--gpus", str(n), "--no-cpu-baseline", "--no-secondary",
+                                                                   "--no-live-counters", "--no-other-configs"]
+        code = subprocess.call(cmd)
+        rc = rc or code
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -716,11 +735,18 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="--gpus N on a box with fewer GPUs: ranks share devices (rank modulo count).  Exercises the launcher; "
                          "the line is marked and is not a scaling figure")
+    ap.add_argument("--scaling", action="store_true",
+                    help="ONE invocation for the whole curve: the N = 1, 2, 4, 8 lines back to back (those the node's GPU count "
+                         "allows; headline config only, no side measurements), each with per_rank_ms_per_step and every "
+                         "rank's kernel time in roofline.per_rank_kernel_ms.  The CPU analogue of the fan-out: "
+                         "/root/reference/atropos/commands/multicore.py:297-401")
     ap.add_argument("--launcher", default=None, help=argparse.SUPPRESS)       # set by self_launch() for its ranks
     ap.add_argument("--full-sweep", action="store_true",
                     help="C2: time the unfiltered full-column DP kernel instead of the filtered pipeline")
     args = ap.parse_args()
 
+    if args.scaling:
+        raise SystemExit(scaling_curve(args))
     if args.single_process:
         devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
         if len(devices) != args.gpus:

@@ -200,3 +200,23 @@ def test_bench_under_torch_distributed_run():
                        "--steps", "2", "--warmup", "1"], {})
     _check_bench_line(line, 2)
     assert "torch.distributed.run" in line["launcher"]
+
+
+def test_bench_scaling_curve_one_invocation():
+    """`python bench.py --scaling`: the N = 1, 2, 4, 8 lines from ONE invocation (round-4 verdict, item 9) -- here on
+    the CPU test double with ranks sharing the one 'device'; every line carries its per-rank times."""
+    import json
+    import subprocess
+    env = dict(os.environ, ATROPOS_BENCH_BACKEND="emu", ATROPOS_BENCH_EMU_UNITS="600")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    done = subprocess.run([sys.executable, "bench.py", "--scaling", "--oversubscribe", "--steps", "2", "--warmup", "1"], cwd=ROOT,
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert done.returncode == 0, done.stderr.decode()[-2000:]
+    lines = [json.loads(ln) for ln in done.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert [ln["n_gpus"] for ln in lines] == [1, 2, 4, 8]
+    for ln in lines:
+        assert len(ln["per_rank_ms_per_step"]) == ln["n_gpus"] and ln["scaling"] == "weak"
+        assert abs(ln["ms_per_step"] - max(ln["per_rank_ms_per_step"])) < 1e-9
+        if ln["n_gpus"] > 1:
+            assert len(ln["roofline"]["per_rank_kernel_ms"]) == ln["n_gpus"]

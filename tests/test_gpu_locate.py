@@ -349,3 +349,35 @@ def test_per_read_api(hip_backend, oracle):
         ref, q = frag[:m], _cases.mutate(rng, frag[rng.randint(0, m):][:n], 0.05)[:n]
         pa = PairAligner(e, flags, wr, wq, 3, ic, revcomp_ref=rc)
         assert pa.locate(reverse_complement(ref) if rc else ref, q) == oracle.locate(ref, q, e, flags, wr, wq, 3, ic), (ref, q, flags, e, ic, rc)
+
+
+def test_locate_stream_equals_one_call(hip_backend, oracle):
+    """Aligner.locate_stream (consecutive batches on two streams, a workspace each) yields, batch by batch, the records
+    of locate_batch -- plane64 and tile64 batches, equal-length and ragged, in input order."""
+    import numpy as np
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    from atropos_amd.shard import sharded_locate_stream
+    w = synth.workload("C2", 3 << 20, 1_500_000, device="cuda:0")
+    al = Aligner(w["adapter"], w["max_error_rate"], 14, False, False, w["min_overlap"], w["indel_cost"])
+    reads = w["reads"]
+    parts = [reads[lo:lo + 250_000] for lo in range(0, reads.shape[0], 250_000)]
+    for layout in ("plane64", "tile64"):
+        batches = [al.pack(p, layout=layout) for p in parts]
+        one = [al.locate_batch(b).records.clone() for b in batches]
+        torch.cuda.synchronize()
+        for depth in (1, 2, 3):
+            got = [r.records for r in al.locate_stream(batches, depth=depth)]
+            torch.cuda.synchronize()
+            assert len(got) == len(one)
+            for g, o in zip(got, one):
+                assert torch.equal(g, o)
+    # raw ASCII sub-batches through the shard helper (packs as it goes), against one call over the whole set
+    rec, gathered = sharded_locate_stream(al, reads, sub_batch=400_000)
+    torch.cuda.synchronize()
+    whole = al.locate_batch(reads).records
+    assert torch.equal(rec, whole) and torch.equal(gathered, whole.cpu())
+    exp = oracle.locate_many(w["adapter"], reads[:50_000].cpu().numpy(), np.full(50_000, 150, np.int32), w["max_error_rate"], 14,
+                             False, False, w["min_overlap"], w["indel_cost"], 8)
+    assert np.array_equal(rec[:50_000, :6].cpu().numpy().astype(np.int32), exp)
