@@ -216,6 +216,23 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class _PinnedUpload(object):
+    """What HipBackend.stage_host_bytes hands to ReadBatch.from_ascii: `.to(device)` starts the DMA from the page-locked
+    buffer and records the event the next staging waits for."""
+
+    def __init__(self, host, backend):
+        self.host, self.backend = host, backend
+        self.dtype, self.shape = host.dtype, host.shape
+
+    def dim(self):
+        return self.host.dim()
+
+    def to(self, device):
+        dev = self.host.to(device, non_blocking=True)
+        self.backend._pinned_event.record(torch.cuda.current_stream(self.backend.device))
+        return dev
+
+
 class HipBackend(object):
     """Thin object view of the C ABI; all buffers are torch tensors on one GPU."""
 
@@ -239,6 +256,21 @@ class HipBackend(object):
     @_work.setter
     def _work(self, tensor):
         self._works[torch.cuda.current_stream(self.device).cuda_stream] = tensor
+
+    def stage_host_bytes(self, mat):
+        """A uint8 ndarray [n, w] -> the same bytes in a page-locked host tensor (kept and re-used): the upload that
+        follows is one DMA.  The previous upload from the buffer is waited for first."""
+        need = int(mat.size)
+        buf = getattr(self, "_pinned", None)
+        if buf is None or buf.numel() < need:
+            buf = self._pinned = torch.empty((max(need, 1 << 20),), dtype=torch.uint8).pin_memory()
+            self._pinned_event = None
+        if self._pinned_event is not None:
+            self._pinned_event.synchronize()
+        view = buf[:need].view(mat.shape)
+        np.copyto(view.numpy(), mat)
+        self._pinned_event = torch.cuda.Event()
+        return _PinnedUpload(view, self)
 
     def side_streams(self, count):
         """``count`` streams of this backend's device, created once (Aligner.locate_stream issues consecutive batches

@@ -5,14 +5,17 @@ The reference hands one Python ``str`` per call to ``Aligner.locate``
 ASCII reads translated through a 256-entry table and packed to 4 bits per base in
 the tile64 layout (include/atropos_hip.h), resident in GPU memory.
 """
+from collections.abc import Sequence
+
 import numpy as np
 import torch
 
 from . import _lib
 
 
-def _as_ascii_matrix(reads):
-    """list of str/bytes -> (uint8 ndarray [n, max_len], int32 lens)."""
+def _as_ascii_matrix(reads, readonly_ok=False):
+    """list of str/bytes -> (uint8 ndarray [n, max_len], int32 lens).  readonly_ok: equal-length reads may come back as a
+    read-only view of the joined text (the caller copies it into a staging buffer anyway)."""
     n = len(reads)
     if n and set(map(type, reads)) == {str}:              # (one pass in C; a generator of isinstance calls costs 20 ms per 65 k)
         flat = "".join(reads).encode("ascii")             # one pass in C (UnicodeEncodeError as the per-read encode)
@@ -24,8 +27,8 @@ def _as_ascii_matrix(reads):
     max_len = int(lens.max()) if n else 0
     width = max(max_len, 1)
     data = np.frombuffer(flat, dtype=np.uint8)
-    if n and int(lens.min()) == max_len and max_len > 0:  # equal lengths: the text IS the matrix
-        return data.reshape(n, max_len).copy(), lens
+    if n and int(lens.min()) == max_len and max_len > 0:  # equal lengths: the text IS the matrix (a read-only view of it)
+        return (data.reshape(n, max_len) if readonly_ok else data.reshape(n, max_len).copy()), lens
     mat = np.zeros((n, width), dtype=np.uint8)
     if data.size:
         mat[np.arange(width, dtype=np.int32)[None, :] < lens[:, None]] = data      # row-major fill of the ragged rows
@@ -98,7 +101,7 @@ class ReadBatch(object):
     @classmethod
     def from_strings(cls, reads, table_kind=_lib.TABLE_DNA15, table=None, backend=None, planes=False):
         """reads: sequence of ``str`` (ASCII) or ``bytes``."""
-        mat, lens = _as_ascii_matrix(reads)
+        mat, lens = _as_ascii_matrix(reads, readonly_ok=True)
         if len(reads) == 0:
             be = backend or _lib.get_backend()
             if table is None:
@@ -106,7 +109,64 @@ class ReadBatch(object):
             return cls(be.empty((16,), torch.uint8), None, 0, 0, table_kind, table)
         if int(lens.min()) == mat.shape[1]:               # equal lengths: no length array (the kernels' uniform path)
             lens = None
-        return cls.from_ascii(mat, lens, None, table_kind, table, backend, planes=planes)
+        be = backend or _lib.get_backend()
+        stage = getattr(be, "stage_host_bytes", None)
+        if stage is not None:                             # page-locked staging: one memcpy + one DMA instead of a pageable copy
+            mat = stage(mat)
+        elif not mat.flags.writeable:
+            mat = mat.copy()
+        return cls.from_ascii(mat, lens, None, table_kind, table, be, planes=planes)
+
+
+class RecordTuples(Sequence):
+    """Read-only sequence of result tuples over an int16 [n, 6] array: item i is ``None`` (refstop == -1) or the
+    tuple of its six ints.  Compares equal to a list (or another RecordTuples) with the same items."""
+
+    __slots__ = ("_arr",)
+    _CHUNK = 8192
+
+    def __init__(self, arr):
+        self._arr = arr
+
+    def __len__(self):
+        return self._arr.shape[0]
+
+    @staticmethod
+    def _make(arr):
+        out = list(zip(*arr.T.tolist()))                  # the tuples are built in C: six column lists, one zip
+        for i in np.flatnonzero(arr[:, 1] < 0).tolist():
+            out[i] = None
+        return out
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self._make(self._arr[i])
+        row = self._arr[i]
+        return None if row[1] < 0 else tuple(row.tolist())
+
+    def __iter__(self):
+        for lo in range(0, self._arr.shape[0], self._CHUNK):
+            for t in self._make(self._arr[lo:lo + self._CHUNK]):
+                yield t
+
+    def tolist(self):
+        return self._make(self._arr)
+
+    def __eq__(self, other):
+        if isinstance(other, RecordTuples):
+            return self._arr.shape == other._arr.shape and self.tolist() == other.tolist()
+        if isinstance(other, (list, tuple)):
+            return len(other) == len(self) and self.tolist() == list(other)
+        return NotImplemented
+
+    def __ne__(self, other):
+        r = self.__eq__(other)
+        return r if r is NotImplemented else not r
+
+    __hash__ = None
+
+    def __repr__(self):
+        return "RecordTuples(%d records)" % len(self)
 
 
 class LocateResult(object):
@@ -127,9 +187,7 @@ class LocateResult(object):
         return self.records[:, 1] >= 0
 
     def tuples(self):
-        """List of 6-tuples / None, exactly what per-read ``locate`` calls return."""
-        arr = self.numpy()[:, :6]
-        out = list(zip(*arr.T.tolist()))                  # the tuples are built in C: six column lists, one zip
-        for i in np.flatnonzero(arr[:, 1] < 0).tolist():
-            out[i] = None
-        return out
+        """The 6-tuples / None that per-read ``locate`` calls return, as a read-only sequence (``RecordTuples``): the
+        records come to the host once, the Python tuples are made when they are looked at -- 65 536 of them cost more
+        than packing, aligning and copying the batch together."""
+        return RecordTuples(self.numpy()[:, :6])
