@@ -195,12 +195,13 @@ class Aligner(object):
         """Which translate table (``_lib.TABLE_*``) query batches must be packed with."""
         return self._table_kind
 
-    def pack(self, reads, layout="auto"):
+    def pack(self, reads, layout="tile64"):
         """Pack reads for this aligner.  ``reads``: a ReadBatch (returned unchanged if
         compatible), a sequence of str/bytes, or a uint8 [nreads, width] array/tensor.
-        ``layout``: "tile64" (4-bit codes), "plane64" (bit planes of the codes: what the two-pass
-        pre-pass of ``locate_batch`` reads) or "auto" -- plane64 for a long batch when that pre-pass
-        takes this aligner, else tile64."""
+        ``layout``: "tile64" (4-bit codes: what every entry point reads, whatever the batch size), "plane64" (bit
+        planes of the codes: what the two-pass pre-pass of ``locate_batch`` reads) or "auto" -- what ``locate_batch``
+        picks when it packs the reads itself: plane64 for a long batch when that pre-pass takes this aligner, else
+        tile64.  (A plane64 batch serves ``locate_batch`` with its default path only.)"""
         if isinstance(reads, ReadBatch):
             self._check_batch(reads)
             return reads
@@ -274,7 +275,7 @@ class Aligner(object):
 
         for i, b in enumerate(batches):
             st = streams[i % len(streams)]
-            batch = self.pack(b) if not isinstance(b, ReadBatch) else b
+            batch = self.pack(b, layout="auto") if not isinstance(b, ReadBatch) else b
             st.wait_stream(caller)                                   # (the batch was produced on the caller's stream)
             with torch.cuda.stream(st):
                 res = self.locate_batch(batch)

@@ -148,7 +148,7 @@ def test_c2_sample_and_full_size_properties(hip_backend, oracle):
     w = synth.workload("C2", 0, n_total, device="cuda")
     reads = w["reads"]
     al = Aligner(w["adapter"], 0.1, 14, False, False, 3, 1)
-    batch = al.pack(reads)
+    batch = al.pack(reads, layout="auto")
     assert batch.layout == "plane64"                         # what bench.py times: the two-pass pre-pass on bit planes
     rec = al.locate_batch(batch).records
     torch.cuda.synchronize()

@@ -20,7 +20,7 @@ al.indel_cost = w["indel_cost"]
 g = torch.Generator(device="cuda").manual_seed(5)
 lens = torch.randint(100, 151, (n,), generator=g, device="cuda", dtype=torch.int32)
 rb = ReadBatch.from_ascii(w["reads"], lens, 150, al.table_kind, al._table)
-eq = al.pack(w["reads"])
+eq = al.pack(w["reads"], layout="auto")
 out = {}
 for name, batch in (("equal_150", eq), ("ragged_100_150", rb)):
     for _ in range(2):

@@ -41,9 +41,9 @@ def measure(sizes=(1, 1000, 65536, 1_000_000)):
     out = {"batch_sizes": list(sizes), "packed_us": [], "ascii_us": [], "strings_us": [], "strings_all_tuples_made_us": []}
     for n in sizes:
         a = w["reads"][:n].contiguous()
-        batch = al.pack(a)
+        batch = al.pack(a, layout="auto")
         out["packed_us"].append(timed(lambda: al.locate_batch(batch)) * 1e6)
-        out["ascii_us"].append(timed(lambda: al.locate_batch(al.pack(a))) * 1e6)
+        out["ascii_us"].append(timed(lambda: al.locate_batch(al.pack(a, layout="auto"))) * 1e6)
         if n <= 65536:
             strings = [bytes(r).decode() for r in host[:n]]
             # .tuples() is a sequence that makes a tuple when it is looked at; the second figure makes them all
