@@ -48,6 +48,9 @@ struct FilterParams {
                                                     // STOP_WITHIN_SEQ1).  32-bit entries of a kernel argument: scalar loads.
     uint32_t cert[FILTER_CERT_T + 1];               // cert[t] bit i: a perfect overlap of i bases at the read end beats every
                                                     // longer last-column row up to i + t (filter_overlap_certificates); 0: ask the DP
+    uint64_t cert_sub;                              // bit r - 1: the adapter with ONE substitution, at row r, is decided without the
+                                                    // DP (filter_substitution_certificate); 0: never
+    uint64_t rowsel[4];                             // rows whose code is the one-hot code of plane c, bit r - 1 (cert_sub != 0 only)
 };
 
 // NARROW mode.  A 33 .. 40-base adapter needs two 32-bit words per bit-vector and ~28 VALU ops per
@@ -120,6 +123,61 @@ inline void filter_overlap_certificates(const uint8_t *codes, int m, int rows, c
             if (thr_row[i] >= 0 && thr_row[i + t] >= t && !((bad[t] >> i) & 1u)) cert[t] |= 1u << i;
 }
 
+// ONE SUBSTITUTION, decided without the DP (round 5).  The commonest unresolved read after the overlap certificates
+// holds the whole adapter with a single substituted base: on diagonal d the read disagrees with the adapter in exactly
+// one row r, so cell W = (m, d + m) costs 1 (0 only with H = 0: the early exit) and -- the diagonal path being optimal
+// at every prefix, the reference's tie order mismatch <= insertion <= deletion keeps to it (_align.pyx:405-419) -- holds
+// m - 1 matches and origin d.  Every other candidate (m, j') (none in the last column: the caller checks) loses unless
+//   (T1) it holds all m matches: the m rows in order on non-decreasing diagonal offsets o(i) in [-3k, 2k] off d, last minus
+//        first <= k (its deletions), each row that lands inside the adapter's span matching the base W shows there --
+//        A[i + o], or, at the substituted place, anything but A[r] -- and anything in the flanks (worst case); or
+//   (T2) it comes EARLIER with m - 1 matches and cost 1: the adapter on another diagonal o in [-2k, -1] with at most one
+//        disagreement, or one adapter row inserted (rows before it on offset o <= 0, rows after it on o - 1).
+// Both are properties of the adapter and r alone: bit r - 1 is set when neither can happen.  For an adapter without long
+// self-similar stretches that is every row but the first and last k (where the flank can finish the adapter).
+inline uint64_t filter_substitution_certificate(const uint8_t *codes, int m, int k, bool and_mode) {
+    if (and_mode || m < 8 || m > 64 || k < 1 || k > 4) return 0ull;
+    for (int i = 0; i < m; ++i) if (codes[i] != 1 && codes[i] != 2 && codes[i] != 4 && codes[i] != 8) return 0ull;
+    const int OLO = -3 * k, OHI = 2 * k, NO = OHI - OLO + 1;
+    uint64_t cert = 0ull;
+    for (int r = 1; r <= m; ++r) {
+        // does row i (1-based) placed on offset o match what the read shows there?  (positions 1 .. m: the adapter's span)
+        const auto ok = [&](int i, int o) {
+            const int q = i + o;
+            if (q < 1 || q > m) return true;                               // a flank base: whatever is needed
+            return q == r ? codes[i - 1] != codes[r - 1] : codes[i - 1] == codes[q - 1];
+        };
+        bool threat = false;
+        // (T1) reach[o][b]: rows 1 .. i placed, row i on offset OLO + o, b deletions used so far
+        {
+            bool cur[24][5], nxt[24][5];                                  // (5 k + 1 <= 21 offsets, k + 1 <= 5 budgets)
+            for (int o = 0; o < NO; ++o) for (int b = 0; b <= k; ++b) cur[o][b] = (b == 0) && ok(1, OLO + o);
+            for (int i = 2; i <= m; ++i) {
+                for (int o = 0; o < NO; ++o) for (int b = 0; b <= k; ++b) nxt[o][b] = false;
+                for (int o = 0; o < NO; ++o) for (int b = 0; b <= k; ++b) if (cur[o][b])
+                    for (int step = 0; b + step <= k && o + step < NO; ++step) if (ok(i, OLO + o + step)) nxt[o + step][b + step] = true;
+                for (int o = 0; o < NO; ++o) for (int b = 0; b <= k; ++b) cur[o][b] = nxt[o][b];
+            }
+            for (int o = 0; o < NO; ++o) for (int b = 0; b <= k; ++b) threat = threat || cur[o][b];
+        }
+        // (T2) another diagonal, earlier, with at most one disagreement
+        for (int o = -2 * k; o <= -1 && !threat; ++o) {
+            int bad = 0;
+            for (int i = 1; i <= m; ++i) bad += ok(i, o) ? 0 : 1;
+            threat = bad <= 1;
+        }
+        // (T2) one inserted row x: rows before it on offset o <= 0, rows after it on o - 1, every one of them matching
+        for (int o = -2 * k; o <= 0 && !threat; ++o)
+            for (int x = 1; x <= m && !threat; ++x) {
+                bool all = true;
+                for (int i = 1; i <= m && all; ++i) if (i != x) all = ok(i, i < x ? o : o - 1);
+                threat = all;
+            }
+        if (!threat) cert |= 1ull << (r - 1);
+    }
+    return cert;
+}
+
 // peq64: the aligner's match masks (top-aligned in 64 bits when m > 32, in 32 bits otherwise)
 inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, int m, int flags, bool and_mode,
                                   const int16_t *thr, int min_overlap) {
@@ -134,6 +192,14 @@ inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, i
         for (int t = 0; t < m - FILTER_NARROW_ROWS; ++t) fp.tail |= (uint32_t)(codes[FILTER_NARROW_ROWS + t] & 15u) << (4 * t);
     }
     filter_overlap_certificates(codes, m, fp.rows, fp.thr_row, and_mode, fp.cert);
+    fp.cert_sub = 0ull;
+    fp.rowsel[0] = fp.rowsel[1] = fp.rowsel[2] = fp.rowsel[3] = 0ull;
+    if (m <= FILTER_MAX_M && (flags & ATR_STOP_WITHIN_SEQ2) && !(flags & ATR_START_WITHIN_SEQ1) && m >= min_overlap && thr[m] >= 1) {
+        const int k = (int)thr[m];                                         // floor(m e) = int(e m) for e >= 0
+        fp.cert_sub = filter_substitution_certificate(codes, m, k, and_mode);
+        if (fp.cert_sub)
+            for (int i = 0; i < m; ++i) fp.rowsel[codes[i] == 1 ? 0 : codes[i] == 2 ? 1 : codes[i] == 4 ? 2 : 3] |= 1ull << i;
+    }
     return fp;
 }
 
@@ -476,9 +542,14 @@ ATR_DEV bool filter_tail_matches(const P &fp, int T, const uint32_t *q, int nchu
 // tm(jp): do the T bases after column jp equal the adapter's tail rows (filter_tail_matches on the caller's copy of
 // the read)?  have_last = false (two-pass pre-pass, piece_core.hpp): the sweep did not end in column n because no
 // last-column cell can be acceptable -- F's vertical deltas are those of another column and are not looked at.
-template <bool WIDE, class P, class TM>
+// (no diagonal view of the read: the substitution certificate is not asked for)
+struct FilterNoDiag { ATR_DEV_MEMBER uint64_t operator()(int) const { return ~0ull; } };
+
+// dg(d): the rows of the adapter that DISAGREE with the read on diagonal d (row r against column d + r), bit r - 1, all
+// m rows; ~0 when the caller cannot tell.  Asked for at most once, and only when fp.cert_sub != 0.
+template <bool WIDE, class P, class TM, class DG = FilterNoDiag>
 ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const P &fp, TM tm, int n, uint32_t rec[4],
-                                  int s = 0, bool have_last = true) {
+                                  int s = 0, bool have_last = true, DG dg = DG()) {
     const int mf = fp.rows, T = u.m - mf;                                // T > 0: NARROW mode
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
     if (F.zfirst != 0 && u.m >= u.min_overlap) {
@@ -560,6 +631,23 @@ ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const 
     // read is stored as (last diagonal) + m - k: j_last, or j'_last + T in NARROW mode.
     const bool band = rowm && !lastcol && (F.j_first - mf - u.k >= s) &&
                       (F.j_last - F.j_first + 2 * u.k <= BAND_W - 1);
+    if (band && !u.sr && u.indel == 1 && fp.cert_sub != 0ull && ((F.j_first + F.j_last) & 1) == 0 &&
+        F.j_last - F.j_first <= 2 * u.k) {
+        // ONE SUBSTITUTION (filter_substitution_certificate).  The hits of the swept rows lie within k of their middle
+        // column xc, so every row-m candidate ends within 2k of j = xc + T and starts within 3k before d = xc - mf:
+        // what the certificate assumed.  Exactly one disagreeing row on diagonal d, and that row certified:
+        // (0, m, d, d + m, m - 1, 1).
+        const int xc = (F.j_first + F.j_last) >> 1, d = xc - mf, j = d + u.m;
+        if (d >= s && j <= n) {
+            const uint64_t mm = dg(d);
+            if (mm != 0ull && (mm & (mm - 1ull)) == 0ull && (mm & fp.cert_sub) != 0ull) {
+                rec[0] = (uint32_t)u.m << 16;
+                rec[1] = (uint32_t)d | ((uint32_t)j << 16);
+                rec[2] = (uint32_t)(u.m - 1) | (1u << 16);
+                return 0;
+            }
+        }
+    }
     const int j_hi = lastcol ? n : band ? F.j_last + T : atr_min(n, F.j_last + (T ? T + u.k : 0));
     // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
     // last-column row can matter (a row only depends on the rows before it)

@@ -93,6 +93,7 @@ struct LaneFilterParams {
     uint32_t tail;
     const int32_t *thr_row;
     const uint32_t *cert;                           // FilterParams::cert of the lane's adapter
+    uint64_t cert_sub = 0ull;                       // (the substitution certificate wants a diagonal view of the read: not here)
 };
 
 // ---- Adapter.match_to's acceptance test (adapters/__init__.py:386-398) ---------------------

@@ -163,7 +163,22 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
             return fp.and_mode ? nz == ones : nz == 0u;
         };
-        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr);
+        // the adapter's rows against the read on diagonal d (filter_decide_tm's substitution certificate): the window's
+        // planes moved down to base d, one "base == code" mask per plane against the rows that hold that code
+        const auto dg = [&](int d) -> uint64_t {
+            const int o = d - (j_e - PIECE_WINDOW);                            // window bit of the diagonal's first base
+            if (o < 0 || o + u.m > PIECE_WINDOW) return ~0ull;
+            uint64_t eq = 0ull;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                uint32_t lo = wp[c][0], hi = wp[c][1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q != c && !fp.and_mode) { lo &= ~wp[q][0]; hi &= ~wp[q][1]; }
+                eq |= ((((uint64_t)hi << 32) | lo) >> o) & fp.rowsel[c];
+            }
+            return ~eq & (u.m >= 64 ? ~0ull : (1ull << u.m) - 1ull);
+        };
+        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr, dg);
         piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PIECE_WINDOW, &s_lcur, s_hist);
     };
 

@@ -239,6 +239,69 @@ def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=2
     return total, refused
 
 
+def check_certificates(Aligner, oracle, unsupported_exc, seed, rounds, count=500):
+    """The DP-free decisions of the pre-pass (filter_core.hpp: perfect-overlap and single-substitution certificates) under
+    pressure: adapters that are random, low-complexity, periodic (with a few defects), the TruSeq prefix, or a repeated
+    half; the adapter in the read with one or two substitutions (any row, the first and last three more often), flanks
+    that are random, end in a prefix of the adapter, start with its suffix, continue its period or repeat one base; now
+    and then an indel on top.  Every record of the two-pass pipeline against the oracle."""
+    rng = random.Random(seed)
+    total = 0
+
+    def adapter(kind, m):
+        if kind == 0:
+            return rseq(rng, m, "ACGT")
+        if kind == 1:
+            return rseq(rng, m, rng.choice(["AC", "AG", "CT", "ACG"]))
+        if kind == 2:
+            unit = rseq(rng, rng.randint(1, 5), "ACGT")
+            s = list((unit * 40)[:m])
+            for _ in range(rng.randint(0, 3)):
+                s[rng.randrange(m)] = rng.choice("ACGT")
+            return "".join(s)
+        if kind == 3:
+            return "AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC"[:m] if m <= 34 else rseq(rng, m, "ACGT")
+        half = rseq(rng, m // 2 + 1, "ACGT")
+        return (half + half)[:m]
+
+    for _ in range(rounds):
+        m = rng.randint(20, 40)
+        ref = adapter(rng.randrange(5), m)
+        e = rng.choice([0.03, 0.05, 0.08, 0.1, 0.1, 0.12])
+        mo = rng.choice([1, 3, 5])
+        flags = rng.choice([14, 14, 10])
+        al = Aligner(ref, e, flags, False, False, mo, 1)
+        n = rng.choice([100, 128, 150, 160])
+        reads = []
+        for _ in range(count):
+            a = list(ref)
+            for _ in range(1 if rng.random() < 0.8 else 2):
+                p = rng.randrange(m) if rng.random() < 0.7 else rng.choice([0, 1, 2, m - 1, m - 2, m - 3])
+                a[p] = rng.choice([c for c in "ACGT" if c != ref[p]] if rng.random() < 0.9 else "ACGTN")
+            a = "".join(a)
+            w, v, x = rng.random(), rng.random(), rng.randint(1, 6)
+            fb = (rseq(rng, 12) if w < 0.4 else rseq(rng, 12 - x) + ref[:x] if w < 0.6 else
+                  rseq(rng, 8) + ref[rng.randint(0, 3):][:4] if w < 0.7 else (ref * 2)[rng.randint(0, m):][:12] if w < 0.85 else ref[0] * 12)
+            fa = (rseq(rng, 12) if v < 0.4 else ref[-x:] + rseq(rng, 12) if v < 0.6 else
+                  (ref * 2)[rng.randint(0, m):][:12] if v < 0.8 else ref[-1] * 12)
+            pos = rng.randint(0, n - m)
+            q = ((rseq(rng, pos) + fb)[-pos:] if pos else "") + a + fa + rseq(rng, n)
+            if rng.random() < 0.15:                       # an indel near by as well
+                i = rng.randrange(n)
+                q = q[:i] + q[i + 1:] if rng.random() < 0.5 else q[:i] + rng.choice("ACGT") + q[i:]
+            reads.append(q[:n])
+        try:
+            planes = al.pack(reads, layout="plane64")
+        except unsupported_exc:
+            continue
+        got = al.locate_batch(planes).tuples()
+        for q, g in zip(reads, got):
+            exp = oracle.locate(ref, q, e, flags, False, False, mo, 1)
+            assert g == exp, (ref, q, e, flags, mo, g, exp)
+            total += 1
+    return total
+
+
 def check_uniform_partial_overlaps(Aligner, oracle, unsupported_exc, seed, rounds, count=400,
                                    flag_choices=(14, 14, 15, 10), short=False):
     """Equal-length batches full of partial adapter occurrences at the read end (the row-binned

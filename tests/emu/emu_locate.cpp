@@ -315,6 +315,18 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     if (need > pp.narrow) ++g_piece_stats[3]; else g_piece_stats[4] += (need + 7) & ~7;
     const uint32_t *q = nib + (((size_t)(r >> 6) * NW) * 64 + (r & 63)) * 4;
     const auto tm = [&](int jp) { return filter_tail_matches(fp, T, q, NW, jp); };
+    // the adapter's rows against the read on diagonal d (the substitution certificate of filter_decide_tm)
+    const auto dg = [&](int d) -> uint64_t {
+        uint64_t mm = 0ull;
+        for (int row = 1; row <= u.m && row <= 64; ++row) {
+            const int j = d + row;
+            const uint32_t code = (j >= 1 && j <= n) ? read_code(nib, NW, r, j) : 0u;
+            int c = -1;
+            for (int t = 0; t < 4; ++t) if ((fp.rowsel[t] >> (row - 1)) & 1ull) c = t;
+            if (c < 0 || code != (1u << c)) mm |= 1ull << (row - 1);
+        }
+        return mm;
+    };
     FilterState F;
     filter_init(F, u, mf);
     if (need <= pp.narrow) {
@@ -326,14 +338,14 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
             if (rc == 32) filter_fold(F, j, mf, (uint32_t)u.k);
         }
         filter_fold(F, j_e, mf, (uint32_t)u.k);
-        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n);
+        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, dg);
     }
     for (int j = 1; j <= n; ++j) {
         const uint64_t eq = fp.peq[read_code(nib, NW, r, j)];
         filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
         if ((j & 31) == 0 || j == n) filter_fold(F, j, mf, (uint32_t)u.k);
     }
-    return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true);
+    return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true, dg);
 }
 
 template <int MT, bool NOINDEL>

@@ -176,3 +176,11 @@ def test_pairs_fast_pipeline(emu_backend, oracle):
 def test_long_reference_envelope(emu_backend, oracle):
     from atropos_amd.align import Aligner, PairAligner
     assert _cases.check_long_reference_envelope(Aligner, PairAligner, oracle) > 250
+
+
+def test_certificates_against_oracle(emu_backend, oracle):
+    """The pre-pass's DP-free decisions (perfect-overlap and single-substitution certificates) on adapters and flanks
+    built to break them: the CPU twin of the two-pass pipeline against the oracle."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 31, 30) > 9000

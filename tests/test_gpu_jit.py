@@ -81,3 +81,17 @@ def test_policy_off_and_auto(hip_backend, tmp_path, monkeypatch):
     al.locate_batch(al.pack(reads, layout="plane64"))
     assert not os.path.exists(tmp_path / "k") or not os.listdir(tmp_path / "k")      # a 70 k batch does not compile anything
     assert al.prepare(100) and len(os.listdir(tmp_path / "k")) == 1
+
+
+def test_certificates_on_device(hip_backend, oracle, jit_on):
+    """The same pressure on the device, every aligner with its run-time specialised kernel (the certificates are
+    constants of that kernel) -- and once more on the generic kernel."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 41, 10, count=3000) > 15000
+    import os
+    os.environ["ATR_JIT"] = "0"
+    try:
+        assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 43, 10, count=3000) > 15000
+    finally:
+        os.environ["ATR_JIT"] = "1"
