@@ -481,6 +481,11 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &
     const auto scan = [&](uint32_t pv, uint32_t mv, int first, int rows) -> uint32_t {
         uint32_t q = 0u;
         int i = 0;
+        // (a real loop unless the row count is a constant -- the run-time compiled kernel: unrolled over a run-time count
+        // the compiler keeps sixteen loop-invariant compare results in scalar registers and spills them)
+#if !defined(ATR_SPEC) && !defined(ATR_HOST_EMU)
+#pragma clang loop unroll(disable)
+#endif
         for (; i + 2 <= rows; i += 2) {             // two rows per block: each carry is read three instructions after its write
             const int d1 = d + (int)(pv & 1u) - (int)(mv & 1u);
             const int d2 = d1 + (int)((pv >> 1) & 1u) - (int)((mv >> 1) & 1u);

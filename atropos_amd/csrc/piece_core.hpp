@@ -417,19 +417,21 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
                              int T, int k) {
     constexpr int TWN = NW < PIECE_TAIL_WORDS ? NW : PIECE_TAIL_WORDS, TW0 = NW - TWN;
     PieceMasks<NW> Y;
-    piece_eq_masks<NW>(pl, pp.and_mode != 0, Y);
+    const bool and_mode = piece_uniform(pp.and_mode) != 0;
+    const int xlo = piece_uniform(pp.xlo), xhi = piece_uniform(pp.xhi), pm = piece_uniform(pp.m), pblen = piece_uniform(pp.blen);
+    piece_eq_masks<NW>(pl, and_mode, Y);
 
     // (1) overlaps that must be exact: rows [0, i) against the last i bases, i in [xlo, xhi]: row r of an overlap
     //     of i sits at bit 32 - i + r of the read's last 32 positions.
     bool tail = false;
-    if (pp.xhi >= pp.xlo) {
+    if (xhi >= xlo) {
         uint32_t tw[4];
-        if (pp.and_mode) { tw[0] = twp[0]; tw[1] = twp[1]; tw[2] = twp[2]; tw[3] = twp[3]; }
+        if (and_mode) { tw[0] = twp[0]; tw[1] = twp[1]; tw[2] = twp[2]; tw[3] = twp[3]; }
         else {
             tw[0] = twp[0] & ~(twp[1] | twp[2] | twp[3]); tw[1] = twp[1] & ~(twp[0] | twp[2] | twp[3]);
             tw[2] = twp[2] & ~(twp[0] | twp[1] | twp[3]); tw[3] = twp[3] & ~(twp[0] | twp[1] | twp[2]);
         }
-        for (int i = pp.xlo; i <= pp.xhi; ++i) {                     // wave-uniform trip count
+        for (int i = xlo; i <= xhi; ++i) {                     // wave-uniform trip count
             // every row of the overlap matches <=> the four (mask & rows-of-that-code) words together fill bits 32 - i .. 31
             const uint32_t mw = (tw[0] & pp.xmask[i][0]) | (tw[1] & pp.xmask[i][1]) | (tw[2] & pp.xmask[i][2]) | (tw[3] & pp.xmask[i][3]);
             tail = tail || (i <= n && mw == (~0u << (32 - i)));
@@ -468,7 +470,7 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
         if (s + 1 < steps) piece_shift_masks<NW>(Y);
     }
     // (a piece cannot end before its own length: after s shifts the bits below s are zero)
-    if (pp.tlen > 0) {
+    if (tlen > 0) {
         uint32_t any = 0u;
 #pragma unroll
         for (int u = 0; u < PIECE_NT; ++u)
@@ -506,14 +508,15 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
 #pragma unroll
     for (int w = NW - 1; w >= 0; --w) if (pf[w] != 0u) z_first = 32 * w + atr_ctz(pf[w]);
 
+    const int tail_cols = piece_uniform(pp.tail_cols);
     PieceScan S;
     S.tail = tail;
     S.flagged = tail || b_first >= 0;
     S.j_s = 0; S.j_e = 0;
     // the first zero-cost column of row m (all m rows verbatim on diagonal d: column d + m): where the reference stops
-    S.j_exact = z_first >= 0 ? z_first - (pp.blen - 1) + pp.m : 0;
+    S.j_exact = z_first >= 0 ? z_first - (pblen - 1) + pm : 0;
     if (b_first >= 0) {
-        const int d_min = b_first - (pp.blen - 1), d_max = b_last - (pp.blen - 1);
+        const int d_min = b_first - (pblen - 1), d_max = b_last - (pblen - 1);
         // a traceback through a piece on diagonal d leaves row 0 at a column >= d - k and passes row mf at a column
         // <= mf + d + k; + T: the bases filter_decide compares with the adapter's tail rows (NARROW mode).
         // If mf + T + d_max + k >= n a last-column cell of a row beyond the pieces' rows is possible: the window
@@ -522,7 +525,7 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
         S.j_e = atr_min(n, mf + d_max + k + T);
     }
     if (tail) {
-        S.j_s = b_first >= 0 ? atr_min(S.j_s, atr_max(0, n - pp.tail_cols)) : atr_max(0, n - pp.tail_cols);
+        S.j_s = b_first >= 0 ? atr_min(S.j_s, atr_max(0, n - tail_cols)) : atr_max(0, n - tail_cols);
         S.j_e = n;
     }
     return S;
