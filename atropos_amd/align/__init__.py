@@ -917,7 +917,26 @@ class InsertAligner(object):
 
     def match_insert_batch(self, reads1, reads2):
         """Batched ``match_insert``; reads1/reads2: ReadBatch (DNA15), list of str, or
-        uint8 [n, width] ASCII tensors of equal-length reads."""
+        uint8 [n, width] ASCII tensors of equal-length reads.  Lists with reads of more than 320 bases: those pairs
+        go through ``match_insert`` one by one (``_match_insert_long``), the others through the kernel."""
+        if (isinstance(reads1, (list, tuple)) and isinstance(reads2, (list, tuple)) and len(reads1) == len(reads2) and reads1
+                and max(max(map(len, reads1)), max(map(len, reads2))) > _lib.INSERT_MAX_READ):
+            long_ix = [i for i, (a, b) in enumerate(zip(reads1, reads2)) if max(len(a), len(b)) > _lib.INSERT_MAX_READ]
+            short_ix = [i for i in range(len(reads1)) if max(len(reads1[i]), len(reads2[i])) <= _lib.INSERT_MAX_READ]
+            rec = torch.zeros((len(reads1), 3, 8), dtype=torch.int16)
+            rec[:, :, 1] = -1
+            if short_ix:
+                part = self.match_insert_batch([reads1[i] for i in short_ix], [reads2[i] for i in short_ix]).records
+                rec[torch.tensor(short_ix)] = part.cpu()
+            for i in long_ix:
+                res = self.match_insert(reads1[i], reads2[i])
+                if res is not None:
+                    rec[i, 0, :6] = torch.tensor(res[0], dtype=torch.int16)
+                    for t in (1, 2):
+                        if res[t] is not None:
+                            m = res[t]
+                            rec[i, t, :6] = torch.tensor([m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors], dtype=torch.int16)
+            return InsertResult(rec.to(self._backend.device) if hasattr(self._backend, "device") else rec)
         b1, b2 = self.pack_pair(reads1, reads2)
         max_len = max(b1.max_len, b2.max_len)
         if b1.max_len != b2.max_len:
@@ -937,6 +956,8 @@ class InsertAligner(object):
         seq1.encode('ascii')
         for base in reversed(seq2[:n]):           # reverse_complement(seq2): KeyError on unknown bases
             BASE_COMPLEMENTS[base]
+        if max(len(seq1), len(seq2)) > _lib.INSERT_MAX_READ:
+            return self._match_insert_long(seq1, seq2)
         be = self._backend
         if hasattr(be, "insert_match_one") and max(len(seq1), len(seq2)) <= _lib.INSERT_MAX_READ:
             table = be.translate_table(_lib.TABLE_DNA15)
@@ -949,6 +970,56 @@ class InsertAligner(object):
                 return (tuple(rec[0:6]), ms[0], ms[1])
             # (soft-masked reads and uncoded characters: the batch path sorts those out)
         return self.match_insert_batch([seq1], [seq2]).results()[0]
+
+
+    # Reads beyond the insert kernel's plane registers (more than 320 bases; the reference has no limit,
+    # align/__init__.py:250-265).  The rule of match_insert on top of this package's own building blocks -- the general
+    # MultiAligner (every overlap within the mismatch fraction, device kernel), compare_prefixes (the overhangs against
+    # the adapters) and the match-probability tables -- one pair at a time: a fallback for what no paired-end Illumina
+    # run produces, not a throughput path.  MultiAligner's own limit (736 bases) is the new one.
+    def _match_insert_long(self, seq1, seq2):
+        full1, full2 = len(seq1), len(seq2)
+        common = min(full1, full2)
+        read1, read2 = seq1[:common], seq2[:common]          # the longer read is cut before anything else (:259-265)
+        overlaps = self.aligner.locate(reverse_complement(read2), read1)
+        if not overlaps:
+            return None
+        ranked = []
+        for hit in overlaps:
+            offset = min(hit[0], common - hit[3])             # bases of adapter the pair shows behind the insert
+            size = common - offset
+            chance = self.match_probability(hit[4], size, **self.base_probs)
+            if chance <= self.insert_max_rmp:
+                ranked.append((chance, hit, offset, size))
+        ranked.sort(key=lambda entry: entry[0])              # least likely by chance first; stable among equals (:371)
+        for _, hit, offset, size in ranked:
+            found = self._adapters_behind_insert(hit, offset, size, read1, read2, full1, full2)
+            if found is not None:
+                return found
+        return None
+
+    def _adapters_behind_insert(self, hit, offset, size, read1, read2, full1, full2):
+        if offset < self.min_adapter_overlap:                # overlap, but no overhang worth an adapter match (:272-279)
+            return (hit, None, None)
+        sides = []
+        for read, adapter in ((read1, self.adapter1), (read2, self.adapter2)):
+            # (the overhang is the REFERENCE of the compare: the read side takes the adapter_wildcards table, :285-288)
+            cmp_rec = compare_prefixes(read[size:], adapter, wildcard_ref=self.adapter_wildcards, wildcard_query=self.read_wildcards)
+            alen = min(offset, len(adapter))
+            sides.append((cmp_rec, alen, round(alen * self.max_adapter_mismatch_frac)))
+        (c1, alen1, cap1), (c2, alen2, cap2) = sides
+        if c1[5] > cap1 and c2[5] > cap2:
+            return None
+        if min(alen1, alen2) > self.adapter_check_cutoff:
+            if self.match_probability(c1[4], alen1) * self.match_probability(c2[4], alen2) > self.adapter_max_rmp:
+                return None
+        errors = min(c1[5], c2[5])                           # both Matches carry the better side's count (:308-314)
+
+        def as_match(alen, read_len):
+            alen = min(alen, read_len - size)
+            bad = min(alen, errors)
+            return Match(0, alen, size, read_len, alen - bad, bad)
+        return (hit, as_match(alen1, full1), as_match(alen2, full2))
 
 
 _DEFAULT_RMP = None

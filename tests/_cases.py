@@ -356,7 +356,8 @@ def norm_insert(res):
 
 def check_golden_insert(InsertAligner):
     kats = load_golden("kats.json")["match_insert"]
-    cases = kats + load_golden("insert_fuzz.json.gz") + load_golden("insert_long.json.gz")      # the last: 2 x 257 .. 320 bp
+    # insert_long: 2 x 257 .. 320 bp; insert_longer: 2 x 321 .. 600 bp (beyond the insert kernel: InsertAligner._match_insert_long)
+    cases = kats + load_golden("insert_fuzz.json.gz") + load_golden("insert_long.json.gz") + load_golden("insert_longer.json.gz")
     cache = {}
     for c in cases:
         key = (c["a1"], c["a2"], repr(sorted(c["kw"].items())))

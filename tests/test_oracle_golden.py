@@ -84,6 +84,19 @@ def test_insert_fuzz(oracle):
         if key not in cache:
             cache[key] = oracle.InsertOracle(c["a1"], c["a2"], **c["kw"])
         assert _insert_norm(cache[key].match_insert(c["r1"], c["r2"])) == c["out"], c
+    # pairs of 2 x 321 .. 600 bases (round 5): the C restatement takes them up to its own table width
+    pinned = 0
+    for c in load_golden("insert_longer.json.gz"):
+        key = (c["a1"], c["a2"], repr(sorted(c["kw"].items())))
+        if key not in cache:
+            cache[key] = oracle.InsertOracle(c["a1"], c["a2"], **c["kw"])
+        try:
+            got = cache[key].match_insert(c["r1"], c["r2"])
+        except (ValueError, OverflowError):
+            continue
+        assert _insert_norm(got) == c["out"], c
+        pinned += 1
+    assert pinned >= 40
 
 
 def test_rmp_values(oracle):
