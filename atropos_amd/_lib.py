@@ -90,6 +90,9 @@ PROTOTYPES = {
     "atr_insert_correct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_char_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_insert_match_correct_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int,
+                                                 C.c_int, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_insert_aligner_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "atr_insert_aligner_destroy": (None, [C.c_void_p]),
     "atr_insert_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -426,6 +429,27 @@ class HipBackend(object):
                     h, _ptr(packed1), _ptr(lens1), _ptr(packed2), _ptr(lens2), npairs, max_len, 1 if cased else 0, _ptr(out),
                     self._stream()), "atr_insert_match_batch_coded")
         return out
+
+    def insert_match_correct_batch(self, h, planes1, planes2, seq1, qual1, seq2, qual2, action, min_qual_diff, comp,
+                                   changed=None, newlen=None):
+        """insert_match_batch + insert_correct_batch as ONE kernel (atr_insert_match_correct_batch): the reads'
+        planes are streamed once.  planes1 / planes2: plane64 ReadBatches whose lengths are also the lengths of
+        the matrix rows.  Returns (records int16 [n, 3, 8], changed, newlen)."""
+        n = planes1.nreads
+        if planes1.max_len != planes2.max_len:
+            raise ValueError("both read batches must be packed with the same max_len")
+        if seq1.stride(0) != seq2.stride(0):
+            raise ValueError("both reads need the same row stride")
+        out = self.empty((n, 3, 8), torch.int16)
+        changed = self.empty((n, 2), torch.int32) if changed is None else changed
+        newlen = self.empty((n, 2), torch.int32) if newlen is None else newlen
+        if n:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_insert_match_correct_batch(
+                    h, _ptr(planes1.packed), _ptr(planes1.lens), _ptr(planes2.packed), _ptr(planes2.lens), n, planes1.max_len,
+                    _ptr(out), _ptr(seq1), _ptr(qual1), _ptr(seq2), _ptr(qual2), seq1.stride(0), action, min_qual_diff, comp,
+                    _ptr(changed), _ptr(newlen), self._stream()), "atr_insert_match_correct_batch")
+        return out, changed, newlen
 
     def case_sensitive_table(self):
         buf = C.create_string_buffer(256)

@@ -946,6 +946,23 @@ class InsertAligner(object):
                                                cased=b1.table_kind == _lib.TABLE_CUSTOM)
         return InsertResult(rec)
 
+    def match_insert_correct_batch(self, planes1, planes2, seq1, qual1, seq2, qual2, mismatch_action="liberal",
+                                   min_qual_difference=1, changed=None, newlen=None):
+        """``match_insert`` of every pair AND, where the insert match has errors, ``correct_errors(read1, read2,
+        insert_match, truncate_seqs=True)`` in place on the ASCII matrices -- the first two steps of
+        ``InsertAdapterCutter.__call__`` (commands/trim/modifiers.py:385-404) as one kernel
+        (``atr_insert_match_correct_batch``): same records, bytes and counts as ``match_insert_batch`` followed by the
+        backend's ``insert_correct_batch``, the reads' planes streamed once.  planes1 / planes2: plane64 ReadBatches
+        (``pack``) of the matrices' rows; seq / qual: uint8 [n, width] tensors.  Returns (InsertResult, changed,
+        newlen)."""
+        from ..modifiers import COMP_TABLE
+        action = {"N": 0, "conservative": 1, "liberal": 2}[mismatch_action]
+        if planes1.table_kind == _lib.TABLE_CUSTOM or planes2.table_kind == _lib.TABLE_CUSTOM:
+            raise ValueError("the fused call takes DNA15-packed reads")
+        rec, changed, newlen = self._backend.insert_match_correct_batch(
+            self._handle, planes1, planes2, seq1, qual1, seq2, qual2, action, min_qual_difference, COMP_TABLE, changed, newlen)
+        return InsertResult(rec), changed, newlen
+
     def match_insert(self, seq1, seq2):
         """Use the insert overlap to find the adapters of one pair.
 

@@ -37,6 +37,10 @@ int launch_compare_packed(const LocateParams &lp, const uint32_t *packed, const 
                           int suffix, int16_t *out, hipStream_t st);
 int launch_planes_uncoded(const uint4 *planes, int nchunks, const int32_t *lens, const int32_t *other, long long n,
                           int max_len, int32_t *count, hipStream_t st);
+int launch_insert_correct(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2, const int32_t *l2,
+                          long long npairs, int nchunks, int max_len, uint4 *out, uint8_t *s1, uint8_t *q1, uint8_t *s2,
+                          uint8_t *q2, long long stride, int action, int min_qual_diff, const uint8_t *comp,
+                          int32_t *changed, int32_t *newlen, hipStream_t st);
 int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,
                           uint8_t *q1, const int32_t *l1, uint8_t *s2, uint8_t *q2, const int32_t *l2, long long stride,
                           long long n, int max_len, int action, int min_qual_diff, const uint8_t *comp, int32_t *changed,
@@ -622,6 +626,31 @@ int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *
                                   (const int16_t *)d_insert_records, 24, 1, nullptr, n, max_len, action,
                                   min_qual_difference, 1, comp, d_changed, d_newlen, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "correct_kernel launch");
+}
+
+int atr_insert_match_correct_batch(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
+                                   const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
+                                   atr_result *d_out, uint8_t *d_seq1, uint8_t *d_qual1, uint8_t *d_seq2,
+                                   uint8_t *d_qual2, int64_t stride, int action, int min_qual_difference,
+                                   const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream) {
+    if (!a || npairs < 0 || max_len < 0 || action < 0 || action > 2 || !comp) return ATR_ERR_INVALID;
+    if ((d_qual1 == nullptr) != (d_qual2 == nullptr)) return ATR_ERR_INVALID;
+    if (action != ATR_CORRECT_N && !d_qual1) return ATR_ERR_INVALID;      /* modifiers.py:245-248 */
+    if (max_len > ATR_INSERT_MAX_READ) return ATR_ERR_UNSUPPORTED;
+    if (npairs == 0) return ATR_OK;
+    if (!d_out || !d_seq1 || !d_seq2 || !d_changed || !d_newlen || (max_len > 0 && (!d_packed1 || !d_packed2)))
+        return ATR_ERR_INVALID;
+    const int nchunks = (max_len + 31) / 32;
+    const int rc = launch_insert_correct(a, (const uint4 *)d_packed1, d_lens1, (const uint4 *)d_packed2, d_lens2, npairs,
+                                         nchunks, max_len, (uint4 *)d_out, d_seq1, d_qual1, d_seq2, d_qual2, stride, action,
+                                         min_qual_difference, comp, d_changed, d_newlen, (hipStream_t)stream);
+    if (rc >= 0) return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "insert_correct_kernel launch");
+    // not a batch for the fused kernel: the two steps one after the other
+    const int r1 = atr_insert_match_batch(a, d_packed1, d_lens1, d_packed2, d_lens2, npairs, max_len, d_out, stream);
+    if (r1 != ATR_OK) return r1;
+    return atr_insert_correct_batch(d_out, max_len > 0 ? d_packed1 : nullptr, max_len > 0 ? d_packed2 : nullptr, max_len, d_seq1,
+                                    d_qual1, d_lens1, d_seq2, d_qual2, d_lens2, stride, npairs, max_len, action,
+                                    min_qual_difference, comp, d_changed, d_newlen, stream);
 }
 
 }  // extern "C"

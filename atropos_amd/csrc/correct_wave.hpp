@@ -1,0 +1,132 @@
+// correct_wave.hpp -- the wave-level part of the plane-guided error correction (device only): the disagreeing
+// positions of a wavefront's 64 pairs as (pair, position) TASKS in a per-wave LDS queue, 64 tasks at a time.
+// Shared by correct_planes_kernel (misc_kernels.hip: atr_insert_correct_batch, the records come from memory)
+// and by the fused insert kernels (insert_kernel.hip: atr_insert_match_correct_batch, the match was found by
+// this very lane a moment ago and its reads' planes are still on the CU).
+// Reference: commands/trim/modifiers.py:219-350 (correct_errors), :397-404 (which pairs are corrected).
+#ifndef ATR_CORRECT_WAVE_HPP
+#define ATR_CORRECT_WAVE_HPP
+
+#include <hip/hip_runtime.h>
+#include "misc_core.hpp"
+
+namespace atr {
+
+struct CompTable { uint8_t c[256]; };
+
+// queue entries a wave may hold: at most 63 left over + 64 x 32 new ones
+constexpr int CORRECT_QUEUE_ENTRIES = 64 * 32 + 64;
+
+// the wave's LDS (views; the caller decides what they overlay)
+struct CorrectWaveLds {
+    volatile uint16_t *queue;          // [CORRECT_QUEUE_ENTRIES]
+    uint32_t *cnt;                     // [64] per pair: c1 | c2 << 10 | npend << 20
+    int32_t *err;                      // [64]
+    int16_t *jv;                       // [64] the pair's overlap length
+    uint32_t *tail;                    // [1]
+    const uint8_t *comp;               // [256] complement table (block-wide)
+    const uint8_t *letter;             // [16] DNA15 code -> its byte (block-wide)
+};
+
+struct CorrectArgs {
+    const uint4 *planes1, *planes2;    // plane64 batches of the two reads
+    int nchunks;
+    uint8_t *s1, *q1, *s2, *q2;        // ASCII matrices, corrected in place (q1 / q2 may be null)
+    long long stride;
+    int action, min_qual_diff;
+    int32_t *changed, *newlen;         // [n][2]
+};
+
+__device__ __forceinline__ void correct_letter_table(uint8_t *s_letter) {
+    if (threadIdx.x < 16) s_letter[threadIdx.x] = (uint8_t)"\0ACMGRSVTWYHKDBN"[threadIdx.x];   // (A 1, C 2, G 4, T 8 and their unions)
+}
+
+// tile: the wave's tile of 64 pairs, p = tile * 64 + lane; todo: the pair has an insert match with errors and j is its
+// overlap (read1[0:j] faces revcomp(read2[0:j])); mism[w]: the disagreeing positions of word w of read 1
+// (facing_mismatches / insert_overlap_mismatches; 0 beyond nchunks).  The whole wave calls this (wave barriers inside).
+template <int PW>
+__device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const CorrectArgs &A, long long tile, int lane,
+                                                  bool live, bool todo, int j, int len1, int len2,
+                                                  const uint32_t (&mism)[PW]) {
+    const long long p = tile * 64 + lane;
+    volatile uint16_t *queue = S.queue;
+    S.cnt[lane] = 0u;
+    S.err[lane] = 0;
+    S.jv[lane] = (int16_t)j;
+    if (lane == 0) *S.tail = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const bool has_quals = A.q1 != nullptr && A.q2 != nullptr;
+    const int nchunks = A.nchunks;
+    const auto drain = [&](int from, int count) {               // tasks queue[from .. from + count), count <= 64, wave-uniform
+        if (lane < count) {
+            const uint32_t t = queue[from + lane];
+            const int src = (int)(t >> 9), i = (int)(t & 511u);
+            const int jx = (int)S.jv[src] - 1 - i;
+            const size_t row = (size_t)(tile * 64 + src) * (size_t)A.stride;
+            // The two BASES come from the bit planes, not from the ASCII matrices: the pair's chunks were streamed by this
+            // wave a moment ago (L2), a DNA15 code names its byte (15 upper-case letters, aligner_host.hpp), and a byte
+            // fetched from a matrix costs a 64-byte sector of HBM -- two of the four a task used to pull (round 4:
+            // 1 068 B per pair counted).  Code 0 (a byte outside the table): read the matrix as before.
+            const uint4 v1 = A.planes1[((size_t)tile * nchunks + (size_t)(i >> 5)) * 64 + src];
+            const uint4 v2 = A.planes2[((size_t)tile * nchunks + (size_t)(jx >> 5)) * 64 + src];
+            const uint32_t b1 = (uint32_t)(i & 31), b2s = (uint32_t)(jx & 31);
+            const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
+            const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
+            const int qa = has_quals ? (int)A.q1[row + i] : 0, qb = has_quals ? (int)A.q2[row + jx] : 0;
+            const uint8_t base1 = code1 ? S.letter[code1] : A.s1[row + i], raw2 = code2 ? S.letter[code2] : A.s2[row + jx];
+            uint32_t delta = 0u;
+            const int e = correct_apply_delta(A.s1 + row, has_quals ? A.q1 + row : nullptr, A.s2 + row, has_quals ? A.q2 + row : nullptr, i, jx,
+                                              base1, raw2, qa, qb, A.action, A.min_qual_diff, S.comp, delta);
+            if (e) S.err[src] = e;
+            else if (delta) atomicAdd(&S.cnt[src], delta);
+        }
+    };
+    int qsize = 0;                                                // wave-uniform
+#pragma unroll
+    for (int w = 0; w < PW; ++w) {
+        uint32_t m = mism[w];                                     // (0 beyond nchunks)
+        const int cnt = __builtin_popcount(m);
+        if (cnt) {
+            uint32_t at = atomicAdd(S.tail, (uint32_t)cnt);
+            while (m) {
+                const int b = __builtin_ctz(m);
+                m &= m - 1u;
+                queue[at++] = (uint16_t)((lane << 9) | (32 * w + b));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        qsize = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
+        while (qsize >= 64) {                                     // full rounds, off the end of the queue
+            qsize -= 64;
+            drain(qsize, 64);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *S.tail = (uint32_t)qsize;
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (qsize > 0) drain(0, qsize);
+    // the lanes' stores, before their pairs' owners (lanes of this same wave: one CU, one L1) read them back --
+    // a device-scope fence would write back the L2 for the sake of other XCDs, once per wave
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (!live) return;
+    if (!todo) {
+        A.changed[2 * p] = A.changed[2 * p + 1] = 0;
+        A.newlen[2 * p] = len1; A.newlen[2 * p + 1] = len2;
+        return;
+    }
+    const uint32_t packed_counts = *(volatile uint32_t *)&S.cnt[lane];
+    int c1 = (int)(packed_counts & 1023u), c2 = (int)((packed_counts >> 10) & 1023u), err = *(volatile int32_t *)&S.err[lane];
+    const int npend = (int)(packed_counts >> 20);
+    uint8_t *r1 = A.s1 + p * A.stride, *r2 = A.s2 + p * A.stride;
+    if (!err && npend > 0)
+        correct_ties(r1, has_quals ? A.q1 + p * A.stride : nullptr, r2, has_quals ? A.q2 + p * A.stride : nullptr, j, mism, nchunks,
+                     A.min_qual_diff, S.comp, c1, c2, err);
+    A.changed[2 * p] = err ? err : c1;
+    A.changed[2 * p + 1] = err ? 0 : c2;
+    A.newlen[2 * p] = (c1 > 0 && !err) ? min(len1, len2) : len1;   // the truncation quirk of correct_errors_one
+    A.newlen[2 * p + 1] = len2;
+}
+
+}  // namespace atr
+#endif

@@ -573,6 +573,29 @@ ATR_DEV int overlap_cost_lds(const PairState<W> &P, const uint32_t *rl, int rls,
     return cost;
 }
 
+// The positions of read 1 that DISAGREE with what faces them in an insert match of overlap j (read1[t] faces the
+// complement of read2[j - 1 - t], t < j): word w of the mask overlap_cost_lds counts.  What the error correction
+// visits (commands/trim/modifiers.py:272-300; misc_core.hpp facing_mismatches computes the same words from read 2's
+// raw planes) -- here from the planes the match was found on, so that the fused kernel does not stream them twice.
+template <int W>
+ATR_DEV void insert_overlap_mismatches(const PairState<W> &P, const uint32_t *rl, int rls, int j, uint32_t (&mism)[W]) {
+    const int sh = 32 * W - j, q = sh >> 5, s = sh & 31;
+    const uint32_t topmask = 0xFFFFFFFFu >> s;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        uint32_t m = 0u;
+        if (j >= 1 && w + q < W) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t lo = rl[(size_t)(p * (W + 1) + w + q) * rls], hi = rl[(size_t)(p * (W + 1) + w + q + 1) * rls];
+                m = atr_or_xor(m, P.a[p][w], atr_funnel(hi, lo, s));
+            }
+            if (w + q == W - 1) m &= topmask;
+        }
+        mism[w] = m;
+    }
+}
+
 // nmax_of(n): the wave's largest n (the kernel: a cross-lane maximum; the emulation: n itself)
 template <int W, class IP, class NMAX>
 ATR_DEV void sweep_probed(PairState<W> &P, const IP &ip, int jmax, const uint32_t *g1, const uint32_t *g2, int cstride,

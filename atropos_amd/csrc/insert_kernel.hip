@@ -5,6 +5,7 @@
 // (L2 resident, 2 x 528 KB) and three coalesced 16-byte result stores.
 #include <hip/hip_runtime.h>
 #include "insert_host.hpp"
+#include "correct_wave.hpp"
 
 namespace atr {
 
@@ -14,11 +15,17 @@ static __device__ __forceinline__ int wave_max_i32_ins(int v) {
     return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int NCH, class IP>
+// what the fused kernels (match + error correction of the overlap in one pass) get on top
+struct InsertFuse {
+    CorrectArgs A;
+    CompTable ct;
+};
+
+template <int NCH, class IP, bool FUSE = false>
 __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restrict__ packed1,
                                             const int32_t *__restrict__ lens1, const uint4 *__restrict__ packed2,
                                             const int32_t *__restrict__ lens2, long long npairs, int max_len,
-                                            uint4 *__restrict__ out) {
+                                            uint4 *__restrict__ out, const InsertFuse *fz = nullptr) {
     constexpr int W = NCH;
     const int lane = threadIdx.x & 63;
     const long long tile = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -47,6 +54,11 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     __shared__ uint16_t s_cl[4][INS_LIST_CAP * 64];
     __shared__ int32_t s_thr_hit[INS_MAX_LEN + 1];
     for (int i = threadIdx.x; i <= INS_MAX_LEN; i += 256) s_thr_hit[i] = ip.thr_hit[i];
+    __shared__ uint8_t s_comp[FUSE ? 256 : 1], s_letter[16];
+    if constexpr (FUSE) {
+        s_comp[threadIdx.x] = fz->ct.c[threadIdx.x];
+        correct_letter_table(s_letter);
+    }
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *rl = &s_rl[wv][lane];
     uint16_t *cl = &s_cl[wv][lane];
@@ -68,6 +80,24 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
         o[1] = make_uint4(rec[4], rec[5], rec[6], rec[7]);
         o[2] = make_uint4(rec[8], rec[9], rec[10], rec[11]);
     }
+    if constexpr (FUSE) {
+        // The error correction of the overlap (modifiers.py:397-404, :219-350) while the pair is still here: the
+        // disagreeing positions are the very words the match counted (read 1 in registers, read 2's reversed
+        // complement in LDS); a second kernel streams both reads' planes again to find them (correct_planes_kernel).
+        static_assert(sizeof(s_rl[0]) >= CORRECT_QUEUE_ENTRIES * sizeof(uint16_t), "task queue does not fit read 2's planes");
+        static_assert(sizeof(s_cl[0]) >= 64 * 4 + 64 * 4 + 64 * 2 + 4, "the per-pair counters do not fit the candidate lists");
+        const bool todo = live && P.has_best && P.best_cost > 0;
+        const int j = todo ? P.best_j : 0;
+        uint32_t mism[W];
+        insert_overlap_mismatches<W>(P, rl, 64, j, mism);
+        __builtin_amdgcn_wave_barrier();                    // every lane has read its planes: the queue takes their place
+        CorrectWaveLds S;
+        S.queue = (volatile uint16_t *)&s_rl[wv][0];
+        uint8_t *small = (uint8_t *)&s_cl[wv][0];
+        S.cnt = (uint32_t *)small; S.err = (int32_t *)(small + 256); S.jv = (int16_t *)(small + 512); S.tail = (uint32_t *)(small + 640);
+        S.comp = s_comp; S.letter = s_letter;
+        correct_wave_tail<W>(S, fz->A, tile, lane, live, todo, j, len1, len2, mism);
+    }
 }
 
 // Two entry points around the same body: reads of up to five chunks (160 bases) fit five waves per SIMD
@@ -87,6 +117,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                      const int32_t *__restrict__ lens2, long long npairs,
                                                      int max_len, uint4 *__restrict__ out) {
     insert_body<NCH>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out);
+}
+
+// match + correction in one pass (atr_insert_match_correct_batch): the same two register budgets
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void insert_correct_kernel(
+    const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
+    const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
+    uint4 *__restrict__ out, const InsertFuse fz) {
+    insert_body<NCH, InsertParams, true>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out, &fz);
 }
 
 // MiSeq-length reads (nine and ten chunks, up to 320 bases): 80 plane dwords per pair live in registers,
@@ -147,6 +186,28 @@ int launch_insert(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l
         case 9: return launch_nch<9>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
         default: return launch_nch<10>(a, p1, l1, p2, l2, npairs, max_len, out, cased, st);
     }
+}
+
+// The fused form: chunk counts 4 .. 8 with the plain parameter block; returns -1 when the batch is not one of those
+// (the caller then runs the two kernels one after the other).
+int launch_insert_correct(const atr_insert_aligner *a, const uint4 *p1, const int32_t *l1, const uint4 *p2, const int32_t *l2,
+                          long long npairs, int nchunks, int max_len, uint4 *out, uint8_t *s1, uint8_t *q1, uint8_t *s2,
+                          uint8_t *q2, long long stride, int action, int min_qual_diff, const uint8_t *comp,
+                          int32_t *changed, int32_t *newlen, hipStream_t st) {
+    if (a->p.long_adapters || nchunks < 4 || nchunks > 8) return -1;
+    InsertFuse fz;
+    fz.A.planes1 = p1; fz.A.planes2 = p2; fz.A.nchunks = nchunks;
+    fz.A.s1 = s1; fz.A.q1 = q1; fz.A.s2 = s2; fz.A.q2 = q2; fz.A.stride = stride;
+    fz.A.action = action; fz.A.min_qual_diff = min_qual_diff; fz.A.changed = changed; fz.A.newlen = newlen;
+    memcpy(fz.ct.c, comp, 256);
+    const long long ntiles = (npairs + 63) / 64;
+    const dim3 grid((unsigned)((ntiles + 3) / 4));
+#define ATR_FUSED(N) case N: hipLaunchKernelGGL((insert_correct_kernel<N>), grid, dim3(256), 0, st, a->p, p1, l1, p2, l2, npairs, max_len, out, fz); break
+    switch (nchunks) {
+        ATR_FUSED(4); ATR_FUSED(5); ATR_FUSED(6); ATR_FUSED(7); ATR_FUSED(8);
+    }
+#undef ATR_FUSED
+    return (int)hipGetLastError();
 }
 
 }  // namespace atr

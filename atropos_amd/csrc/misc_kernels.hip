@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "aligner_host.hpp"
 #include "misc_core.hpp"
+#include "correct_wave.hpp"
 
 namespace atr {
 
@@ -154,7 +155,6 @@ int launch_locate_debug(const LocateParams &lp, double e, int flags, int min_ove
     return (int)hipGetLastError();
 }
 
-struct CompTable { uint8_t c[256]; };
 
 __global__ __launch_bounds__(256) void correct_kernel(uint8_t *__restrict__ s1, uint8_t *__restrict__ q1,
                                                       const int32_t *__restrict__ l1, uint8_t *__restrict__ s2,
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
                                                              int min_qual_diff, const CompTable ct,
                                                              int32_t *__restrict__ changed, int32_t *__restrict__ newlen) {
     // uint16 tasks that fit the plane staging area; at most 63 left over + 64 x 32 new ones are ever queued
-    static_assert(4 * PW * 64 * 2 >= 64 * 32 + 64, "task queue does not fit the plane staging area");
+    static_assert(4 * PW * 64 * 2 >= CORRECT_QUEUE_ENTRIES, "task queue does not fit the plane staging area");
     __shared__ uint8_t s_comp[256];
     __shared__ uint8_t s_letter[16];                              // DNA15 code -> its byte
     __shared__ uint32_t s_b2[4][4 * PW][64];                      // per wave: read 2's planes, [plane * W + word][lane]; then the queue
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     __shared__ int16_t s_j[4][64];
     __shared__ uint32_t s_tail[4];
     s_comp[threadIdx.x] = ct.c[threadIdx.x];
-    if (threadIdx.x < 16) s_letter[threadIdx.x] = (uint8_t)"\0ACMGRSVTWYHKDBN"[threadIdx.x];   // (A 1, C 2, G 4, T 8 and their unions)
+    correct_letter_table(s_letter);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long tile = (long long)blockIdx.x * 4 + wave;
@@ -248,83 +248,16 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
 #pragma unroll
         for (int w = 0; w < PW; ++w) mism[w] = (todo && w < nchunks) ? facing_mismatches(a[w], b2word, nchunks, j, w) : 0u;
     }
-    // ---- the queue (the planes in LDS are not needed any more; one wave, so no block barrier) ----
-    volatile uint16_t *queue = (volatile uint16_t *)&s_b2[wave][0][0];
-    s_cnt[wave][lane] = 0u;
-    s_err[wave][lane] = 0;
-    s_j[wave][lane] = (int16_t)j;
-    if (lane == 0) s_tail[wave] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    const bool has_quals = q1 != nullptr && q2 != nullptr;
-    const auto drain = [&](int from, int count) {               // tasks queue[from .. from + count), count <= 64, wave-uniform
-        if (lane < count) {
-            const uint32_t t = queue[from + lane];
-            const int src = (int)(t >> 9), i = (int)(t & 511u);
-            const int jx = (int)s_j[wave][src] - 1 - i;
-            const size_t row = (size_t)(tile * 64 + src) * (size_t)stride;
-            // The two BASES come from the bit planes, not from the ASCII matrices: the pair's chunks were streamed by this
-            // wave a moment ago (L2), a DNA15 code names its byte (15 upper-case letters, aligner_host.hpp), and a byte
-            // fetched from a matrix costs a 64-byte sector of HBM -- two of the four a task used to pull (round 4:
-            // 1 068 B per pair counted).  Code 0 (a byte outside the table): read the matrix as before.
-            const uint4 v1 = planes1[((size_t)tile * nchunks + (size_t)(i >> 5)) * 64 + src];
-            const uint4 v2 = planes2[((size_t)tile * nchunks + (size_t)(jx >> 5)) * 64 + src];
-            const uint32_t b1 = (uint32_t)(i & 31), b2s = (uint32_t)(jx & 31);
-            const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
-            const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
-            const int qa = has_quals ? (int)q1[row + i] : 0, qb = has_quals ? (int)q2[row + jx] : 0;
-            const uint8_t base1 = code1 ? s_letter[code1] : s1[row + i], raw2 = code2 ? s_letter[code2] : s2[row + jx];
-            uint32_t delta = 0u;
-            const int e = correct_apply_delta(s1 + row, has_quals ? q1 + row : nullptr, s2 + row, has_quals ? q2 + row : nullptr, i, jx,
-                                              base1, raw2, qa, qb, action, min_qual_diff, s_comp, delta);
-            if (e) s_err[wave][src] = e;
-            else if (delta) atomicAdd(&s_cnt[wave][src], delta);
-        }
-    };
-    int qsize = 0;                                                // wave-uniform
-#pragma unroll
-    for (int w = 0; w < PW; ++w) {
-        uint32_t m = mism[w];                                     // (0 beyond nchunks)
-        const int cnt = __builtin_popcount(m);
-        if (cnt) {
-            uint32_t at = atomicAdd(&s_tail[wave], (uint32_t)cnt);
-            while (m) {
-                const int b = __builtin_ctz(m);
-                m &= m - 1u;
-                queue[at++] = (uint16_t)((lane << 9) | (32 * w + b));
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        qsize = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&s_tail[wave]);
-        while (qsize >= 64) {                                     // full rounds, off the end of the queue
-            qsize -= 64;
-            drain(qsize, 64);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) s_tail[wave] = (uint32_t)qsize;
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (qsize > 0) drain(0, qsize);
-    // the lanes' stores, before their pairs' owners (lanes of this same wave: one CU, one L1) read them back --
-    // a device-scope fence would write back the L2 for the sake of other XCDs, once per wave
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (!live) return;
-    if (!todo) {
-        changed[2 * p] = changed[2 * p + 1] = 0;
-        newlen[2 * p] = len1; newlen[2 * p + 1] = len2;
-        return;
-    }
-    const uint32_t packed_counts = *(volatile uint32_t *)&s_cnt[wave][lane];
-    int c1 = (int)(packed_counts & 1023u), c2 = (int)((packed_counts >> 10) & 1023u), err = *(volatile int32_t *)&s_err[wave][lane];
-    const int npend = (int)(packed_counts >> 20);
-    uint8_t *r1 = s1 + p * stride, *r2 = s2 + p * stride;
-    if (!err && npend > 0)
-        correct_ties(r1, has_quals ? q1 + p * stride : nullptr, r2, has_quals ? q2 + p * stride : nullptr, j, mism, nchunks,
-                     min_qual_diff, s_comp, c1, c2, err);
-    changed[2 * p] = err ? err : c1;
-    changed[2 * p + 1] = err ? 0 : c2;
-    newlen[2 * p] = (c1 > 0 && !err) ? min(len1, len2) : len1;   // the truncation quirk of correct_errors_one
-    newlen[2 * p + 1] = len2;
+    // ---- the queue (the planes in LDS are not needed any more; one wave, so no block barrier): correct_wave.hpp ----
+    CorrectWaveLds S;
+    S.queue = (volatile uint16_t *)&s_b2[wave][0][0];
+    S.cnt = s_cnt[wave]; S.err = s_err[wave]; S.jv = s_j[wave]; S.tail = &s_tail[wave];
+    S.comp = s_comp; S.letter = s_letter;
+    CorrectArgs A;
+    A.planes1 = planes1; A.planes2 = planes2; A.nchunks = nchunks;
+    A.s1 = s1; A.q1 = q1; A.s2 = s2; A.q2 = q2; A.stride = stride;
+    A.action = action; A.min_qual_diff = min_qual_diff; A.changed = changed; A.newlen = newlen;
+    correct_wave_tail<PW>(S, A, tile, lane, live, todo, j, len1, len2, mism);
 }
 
 int launch_correct_planes(const int16_t *records, const uint4 *planes1, const uint4 *planes2, int nchunks, uint8_t *s1,

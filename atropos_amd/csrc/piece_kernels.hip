@@ -88,7 +88,7 @@ bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, Piec
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                       a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return false;
     const int nw = (max_len + 31) / 32;
-    if (!(nw == 3 || nw == 4 || nw == 5 || nw == 6 || nw == 8 || nw == 10)) return false;      // instantiated word counts
+    if (nw < 3 || nw > 10) return false;                           // instantiated word counts: reads of 65 .. 320 bases
     if (fp_out) *fp_out = fp;
     if (pp_out) *pp_out = pp;
     return true;
@@ -138,7 +138,9 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_
         case 4: launch_piece_filter<4>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         case 5: launch_piece_filter<5>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         case 6: launch_piece_filter<6>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        case 7: launch_piece_filter<7>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         case 8: launch_piece_filter<8>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
+        case 9: launch_piece_filter<9>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         default: launch_piece_filter<10>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         }
     }

@@ -50,6 +50,9 @@ def profile_counters(config):
 
 
 STREAMING_KERNELS = ("filter_kernel", "insert_kernel", "atr_piece_spec")   # stream the packed batch with 16 bytes per lane (see live_counters)
+# kernels that stream the packed batch (16 bytes per lane, counted at half) AND fetch scattered bytes (counted in full):
+# raw FETCH_SIZE + the uncounted half of the stream, whose size is known -- bytes per unit
+MIXED_KERNELS = {"insert_correct_kernel": 128.0}    # C5's fused kernel: 2 reads x 8 chunks x 16 B per pair, half of it
 
 
 def live_counters(config, reads, want_valu):
@@ -93,6 +96,9 @@ def live_counters(config, reads, want_valu):
     hbm = 0.0
     for name, v in totals["FETCH_SIZE"].items():
         hbm += (2.0 if any(k in name for k in STREAMING_KERNELS) else 1.0) * v * 1024.0
+        for key, half_stream in MIXED_KERNELS.items():
+            if key in name:
+                hbm += half_stream * reads * calls
     hbm += sum(totals["WRITE_SIZE"].values()) * 1024.0
     res = {"hbm_bytes_per_launch": hbm / calls, "units_per_launch": reads,
            "source": "this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %d calls each (2 x FETCH_SIZE for "
@@ -336,6 +342,7 @@ class C5(C3):
         self.ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, **self.kw)
         self.be = _lib.get_backend()
         self.comp = COMP_TABLE
+        self.fused = os.environ.get("ATR_BENCH_C5_TWO_CALLS", "0") != "1"      # (A/B switch: the two-kernel form of round 4)
         self.nbatches = args.warmup + args.steps
         self.batches = []
         self.sample = None
@@ -353,9 +360,13 @@ class C5(C3):
     def step(self, s):
         d = self.batches[self.k]
         self.k += 1
-        self.res = self.ia.match_insert_batch(d["b1"], d["b2"])
-        self.be.insert_correct_batch(self.res.records, d["s1"], d["q1"], None, d["s2"], d["q2"], None, 2, 1, self.comp,
-                                     self.changed, self.newlen, planes1=d["b1"], planes2=d["b2"])
+        if self.fused:
+            self.res, _, _ = self.ia.match_insert_correct_batch(d["b1"], d["b2"], d["s1"], d["q1"], d["s2"], d["q2"], "liberal", 1,
+                                                                self.changed, self.newlen)
+        else:
+            self.res = self.ia.match_insert_batch(d["b1"], d["b2"])
+            self.be.insert_correct_batch(self.res.records, d["s1"], d["q1"], None, d["s2"], d["q2"], None, 2, 1, self.comp,
+                                         self.changed, self.newlen, planes1=d["b1"], planes2=d["b2"])
 
     def describe(self):
         d = C3.describe(self)
@@ -366,6 +377,8 @@ class C5(C3):
         return d
 
     def kernel(self):
+        if self.fused:
+            return "insert_correct_kernel (one atr_insert_match_correct_batch call: match + correction, the planes streamed once)"
         return "insert_kernel + correct_planes_kernel (atr_insert_match_batch + atr_insert_correct_batch)"
 
     def cpu_baseline(self):

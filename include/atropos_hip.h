@@ -160,8 +160,8 @@ int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_
  * pieces of the adapter located 32 read positions per boolean op, then Myers' bit-vector sweep over a 64-column
  * window of the flagged reads only, then the exact DP of atr_locate_batch's filtered pipeline on what is left.
  * atr_locate_planes_applies: 1 when this aligner and read length are inside its envelope (3' adapters -- no
- * START_WITHIN_SEQ1 --, up to 40 bases, int(e * m) <= 3, A / C / G / T in the adapter's first 32 bases, reads of
- * 65 .. 192, 225 .. 256 or 289 .. 320 bases; ragged != 0: a batch with d_lens, max_len the longest read), else 0:
+ * START_WITHIN_SEQ1 --, up to 40 bases, int(e * m) <= 4, A / C / G / T in the adapter's first 32 bases, reads of
+ * 65 .. 320 bases; ragged != 0: a batch with d_lens, max_len the longest read), else 0:
  * pack tile64 and call atr_locate_batch.
  * d_work: atr_locate_work_bytes(nreads) bytes.  ATR_ERR_UNSUPPORTED outside the envelope. */
 int atr_locate_planes_applies(const atr_aligner *a, int max_len, int ragged);
@@ -410,6 +410,21 @@ int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *
                              const int32_t *d_lens1, uint8_t *d_seq2, uint8_t *d_qual2, const int32_t *d_lens2,
                              int64_t stride, int64_t n, int max_len, int action, int min_qual_difference,
                              const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream);
+
+/* InsertAdapterCutter.__call__'s first two steps as ONE call (modifiers.py:385-404): the insert match of
+ * atr_insert_match_batch (records to d_out, 3 per pair) and, for every pair whose insert match has errors > 0,
+ * correct_errors(read1, read2, insert_match, truncate_seqs=True) in place on the ASCII matrices -- what
+ * atr_insert_match_batch followed by atr_insert_correct_batch(d_out, d_packed1, d_packed2, max_len, ...) computes,
+ * bit for bit, but with the reads' planes streamed once: the disagreeing positions are the mask words the match
+ * counted.  d_packed1 / d_packed2: plane64 batches (ATR_TABLE_DNA15) of layout width max_len; d_lens1 / d_lens2
+ * (may be NULL: every read has max_len bases) are the lengths of BOTH the packed reads and the matrix rows.
+ * Batches the fused kernel does not take (more than 256 or fewer than 97 bases of layout width, adapters of
+ * more than 64 bases) run the two kernels one after the other inside this call. */
+int atr_insert_match_correct_batch(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
+                                   const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
+                                   atr_result *d_out, uint8_t *d_seq1, uint8_t *d_qual1, uint8_t *d_seq2,
+                                   uint8_t *d_qual2, int64_t stride, int action, int min_qual_difference,
+                                   const uint8_t comp[256], int32_t *d_changed, int32_t *d_newlen, void *stream);
 
 /* ---- Aligner.locate with a per-pair reference (MergeOverlapping) ----------- */
 

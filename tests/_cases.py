@@ -871,6 +871,65 @@ def check_plane_guided_correction(n=768, seed=5):
     return done
 
 
+def check_fused_match_correct(n=4096, seed=9):
+    """atr_insert_match_correct_batch (match + correction in one kernel, the planes streamed once) against
+    atr_insert_match_batch followed by atr_insert_correct_batch -- which the cutter fixtures and the checker pin to
+    the reference: records, corrected bases and qualities, counts and lengths, all three correction modes, reads
+    without qualities for 'N', ragged lengths, layout widths of 4 .. 8 chunks (the fused kernels) and 3 / 9 / 10
+    (the two kernels inside the call)."""
+    import torch
+    from atropos_amd import _lib, synth
+    from atropos_amd.align import InsertAligner
+    from atropos_amd.batch import ReadBatch
+    from atropos_amd.modifiers import COMP_TABLE
+    be = _lib.get_backend()
+    rng = random.Random(seed)
+    w = synth.workload("C5", 77777, n, device=str(be.device))
+    ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
+    table = be.translate_table(_lib.TABLE_DNA15)
+    done = 0
+    for action, ragged, quals, width in ((2, False, True, 250), (1, False, True, 250), (0, False, True, 250), (0, False, False, 250),
+                                         (2, True, True, 250), (2, True, True, 150), (2, False, True, 128), (1, True, True, 200),
+                                         (2, True, True, 224), (2, False, True, 96), (2, True, True, 300), (2, False, True, 320)):
+        if width <= 250:
+            # (the C5 fragments are 100 .. 400 bases long: reads cut to `width` keep the overlaps of the shorter ones)
+            s1, s2, qa, qb = (t[:, :width].contiguous() for t in (w["reads1"], w["reads2"], w["quals1"], w["quals2"]))
+        else:
+            s1, s2, qa, qb = (torch.cat([t, t[:, 20:20 + width - 250]], dim=1).contiguous()
+                              for t in (w["reads1"], w["reads2"], w["quals1"], w["quals2"]))
+        l1 = l2 = None
+        if ragged:
+            l1 = torch.tensor([rng.randint(60, width) for _ in range(n)], dtype=torch.int32, device=be.device)
+            l2 = torch.tensor([rng.randint(60, width) for _ in range(n)], dtype=torch.int32, device=be.device)
+            cols = torch.arange(width, device=be.device)[None, :]
+            s1 = torch.where(cols < l1[:, None], s1, torch.zeros_like(s1))
+            s2 = torch.where(cols < l2[:, None], s2, torch.zeros_like(s2))
+        b1 = ReadBatch(be.pack_reads(s1, l1, width, table, planes=True), l1, n, width, _lib.TABLE_DNA15, table, layout="plane64")
+        b2 = ReadBatch(be.pack_reads(s2, l2, width, table, planes=True), l2, n, width, _lib.TABLE_DNA15, table, layout="plane64")
+        rec = ia.match_insert_batch(b1, b2).records
+        a1, a2 = s1.clone(), s2.clone()
+        q1, q2 = (qa.clone(), qb.clone()) if quals else (None, None)
+        ch, nl = be.insert_correct_batch(rec, a1, q1, l1, a2, q2, l2, action, 1, COMP_TABLE, planes1=b1, planes2=b2)
+        f1, f2 = s1.clone(), s2.clone()
+        g1, g2 = (qa.clone(), qb.clone()) if quals else (None, None)
+        frec, fch, fnl = be.insert_match_correct_batch(ia._handle, b1, b2, f1, g1, f2, g2, action, 1, COMP_TABLE)
+        for x, y, what in ((rec, frec, "records"), (a1, f1, "read 1"), (a2, f2, "read 2"), (q1, g1, "qualities 1"),
+                           (q2, g2, "qualities 2"), (ch, fch, "changed"), (nl, fnl, "newlen")):
+            assert (x is None and y is None) or torch.equal(x, y), (what, action, ragged, quals, width)
+        assert int((ch > 0).any(dim=1).sum()) > (n // 16 if width >= 200 and not ragged else -1), (action, ragged, width)
+        done += n
+    # the method of the aligner (mismatch_action by name)
+    s1, s2, qa, qb = (w[k].clone() for k in ("reads1", "reads2", "quals1", "quals2"))
+    b1, b2 = ia.pack(s1), ia.pack(s2, check=True)
+    res, ch, nl = ia.match_insert_correct_batch(b1, b2, s1, qa, s2, qb, "liberal", 1)
+    t1, t2, u1, u2 = (w[k].clone() for k in ("reads1", "reads2", "quals1", "quals2"))
+    rec = ia.match_insert_batch(b1, b2).records
+    ch2, nl2 = be.insert_correct_batch(rec, t1, u1, None, t2, u2, None, 2, 1, COMP_TABLE, planes1=b1, planes2=b2)
+    for x, y in ((res.records, rec), (s1, t1), (s2, t2), (qa, u1), (qb, u2), (ch, ch2), (nl, nl2)):
+        assert torch.equal(x, y)
+    return done + n
+
+
 def check_device_resident_adapters():
     """The device-resident twins (match_records, LinkedAdapter.match_records,
     best_adapter_records) against the object-level batch path, which is itself pinned to the

@@ -208,6 +208,14 @@ class EmuBackend(object):
                                                    max_len, int(cased), _ptr(out)), "atr_insert_match_batch")
         return out
 
+    def insert_match_correct_batch(self, h, planes1, planes2, seq1, qual1, seq2, qual2, action, min_qual_diff, comp,
+                                   changed=None, newlen=None):
+        # the test double has no fused kernel: the two steps of the contract one after the other
+        out = self.insert_match_batch(h, planes1.packed, planes1.lens, planes2.packed, planes2.lens, planes1.nreads, planes1.max_len)
+        changed, newlen = self.insert_correct_batch(out, seq1, qual1, planes1.lens, seq2, qual2, planes2.lens, action, min_qual_diff,
+                                                    comp, changed, newlen, planes1=planes1, planes2=planes2)
+        return out, changed, newlen
+
     def case_sensitive_table(self):
         buf = C.create_string_buffer(256)
         _check(self.lib.emu_case_sensitive_table(buf), "emu_case_sensitive_table")

@@ -789,7 +789,7 @@ int emu_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                       a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return 0;
     const int nw = (max_len + 31) / 32;
-    return (nw == 3 || nw == 4 || nw == 5 || nw == 6 || nw == 8 || nw == 10) ? 1 : 0;
+    return (nw >= 3 && nw <= 10) ? 1 : 0;
 }
 int emu_locate_planes_all_widths(const atr_aligner *a, int max_len, int ragged) {          // the envelope without the instantiated widths
     if (!a || !a->filterable || max_len < 1 || max_len > 32 * PIECE_MAX_WORDS) return 0;

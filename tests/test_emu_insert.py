@@ -52,6 +52,11 @@ def test_plane_guided_correction(emu_backend):
     assert _cases.check_plane_guided_correction(n=320) == 7 * 320
 
 
+def test_fused_match_correct_contract(emu_backend):
+    """the call's contract on the test double (which composes it from the two steps): shapes, arguments, the method"""
+    assert _cases.check_fused_match_correct(n=192) == 13 * 192
+
+
 def test_correct_errors_fixture(emu_backend):
     assert _cases.check_correct_errors_fixture() == 4000
 

@@ -98,6 +98,11 @@ def test_plane_guided_correction(hip_backend):
     assert _cases.check_plane_guided_correction(n=200_000) == 7 * 200_000
 
 
+def test_fused_match_correct(hip_backend):
+    """atr_insert_match_correct_batch == atr_insert_match_batch + atr_insert_correct_batch, every output"""
+    assert _cases.check_fused_match_correct(n=150_000) == 13 * 150_000
+
+
 def test_correct_errors_fixture(hip_backend):
     assert _cases.check_correct_errors_fixture() == 4000
 
@@ -122,6 +127,12 @@ def test_c5_correction_at_size(hip_backend, oracle):
     rec = res.records
     changed, newlen = hip_backend.insert_correct_batch(rec, s1, q1, None, s2, q2, None, 2, 1, COMP_TABLE, planes1=b1, planes2=b2)
     torch.cuda.synchronize()
+    # (0) the fused call (what bench.py times for C5) on the same 2 M pairs: every output equal to the two calls'
+    f1, f2, g1, g2 = (w[k].clone() for k in ("reads1", "reads2", "quals1", "quals2"))
+    fres, fch, fnl = ia.match_insert_correct_batch(b1, b2, f1, g1, f2, g2, "liberal", 1)
+    for x, y in ((fres.records, rec), (f1, s1), (f2, s2), (g1, q1), (g2, q2), (fch, changed), (fnl, newlen)):
+        assert torch.equal(x, y)
+    del f1, f2, g1, g2, fres, fch, fnl
     ins = rec[:, 0].to(torch.int32)
     found, errs = ins[:, 1] >= 0, ins[:, 5]
     ch = changed.to(torch.int64)
