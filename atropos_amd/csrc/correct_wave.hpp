@@ -24,6 +24,9 @@ struct CorrectWaveLds {
     int32_t *err;                      // [64]
     int16_t *jv;                       // [64] the pair's overlap length
     uint32_t *tail;                    // [1]
+    uint32_t *ptail;                   // [1] entries of the tie list
+    unsigned long long *acc;           // [64] per pair: the two quality sums of its overlap, then which read wins its ties
+    int qcap;                          // uint16 entries the queue's LDS holds (>= CORRECT_QUEUE_ENTRIES): the tie list grows down from its end
     const uint8_t *comp;               // [256] complement table (block-wide)
     const uint8_t *letter;             // [16] DNA15 code -> its byte (block-wide)
 };
@@ -53,8 +56,10 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     S.cnt[lane] = 0u;
     S.err[lane] = 0;
     S.jv[lane] = (int16_t)j;
-    if (lane == 0) *S.tail = 0u;
+    S.acc[lane] = 0ull;
+    if (lane == 0) { *S.tail = 0u; *S.ptail = 0u; }
     __builtin_amdgcn_wave_barrier();
+    const uint32_t pend_cap = (uint32_t)(S.qcap - CORRECT_QUEUE_ENTRIES);
     const bool has_quals = A.q1 != nullptr && A.q2 != nullptr;
     const int nchunks = A.nchunks;
     const auto drain = [&](int from, int count) {               // tasks queue[from .. from + count), count <= 64, wave-uniform
@@ -78,7 +83,13 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
             const int e = correct_apply_delta(A.s1 + row, has_quals ? A.q1 + row : nullptr, A.s2 + row, has_quals ? A.q2 + row : nullptr, i, jx,
                                               base1, raw2, qa, qb, A.action, A.min_qual_diff, S.comp, delta);
             if (e) S.err[src] = e;
-            else if (delta) atomicAdd(&S.cnt[src], delta);
+            else if (delta) {
+                atomicAdd(&S.cnt[src], delta);
+                if (delta >= CORRECT_NP) {                          // 'liberal', qualities too close: decided by the pair's mean qualities below
+                    const uint32_t slot = atomicAdd(S.ptail, 1u);
+                    if (slot < pend_cap) queue[S.qcap - 1 - (int)slot] = (uint16_t)t;
+                }
+            }
         }
     };
     int qsize = 0;                                                // wave-uniform
@@ -109,19 +120,111 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     // a device-scope fence would write back the L2 for the sake of other XCDs, once per wave
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    // ---- 'liberal' ties (modifiers.py:301-322): the read with the better MEAN quality over the overlap wins every position
+    // whose two qualities were too close.  A lane summing its own pair's two quality rows and then walking its positions
+    // one memory round trip at a time cost a quarter of the fused kernel; here the WAVE sums a tied pair's rows (64 lanes
+    // x 4 bytes per load, LDS atomics), and the tied positions -- listed by the first pass -- are decided 64 at a time.
+    uint32_t packed_counts = *(volatile uint32_t *)&S.cnt[lane];
+    int err = *(volatile int32_t *)&S.err[lane];
+    const uint32_t npend_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.ptail);
+    const bool tied = live && todo && !err && (packed_counts >> 20) > 0u;
+    if (npend_all > 0u && npend_all <= pend_cap && has_quals) {
+        unsigned long long tm = __ballot(tied);
+        while (tm) {                                              // wave-uniform; four pairs per round: their loads overlap
+            int src[4];
+            unsigned long long part[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                src[u] = tm ? (int)__builtin_ctzll(tm) : -1;
+                if (tm) tm &= tm - 1ull;
+                part[u] = 0ull;
+                if (src[u] >= 0) {
+                    const int js = (int)S.jv[src[u]];
+                    const size_t row = (size_t)(tile * 64 + src[u]) * (size_t)A.stride;
+                    uint32_t sum1 = 0u, sum2 = 0u;
+                    for (int off = 4 * lane; off < js; off += 256) {
+                        uint32_t v1, v2;
+                        if (js - off >= 4) {
+                            v1 = *(const atr_u32_unaligned *)(A.q1 + row + off);
+                            v2 = *(const atr_u32_unaligned *)(A.q2 + row + off);
+                        } else {                                  // the overlap's last 1 .. 3 bytes: never a byte behind it
+                            v1 = v2 = 0u;
+                            for (int b = 0; b < js - off; ++b) {
+                                v1 |= (uint32_t)A.q1[row + off + b] << (8 * b);
+                                v2 |= (uint32_t)A.q2[row + off + b] << (8 * b);
+                            }
+                        }
+                        sum1 = __builtin_amdgcn_sad_u8(v1, 0u, sum1);
+                        sum2 = __builtin_amdgcn_sad_u8(v2, 0u, sum2);
+                    }
+                    part[u] = (unsigned long long)sum1 | ((unsigned long long)sum2 << 32);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (src[u] >= 0 && part[u]) atomicAdd(&S.acc[src[u]], part[u]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t dir = 0u;                                        // 1: read 1 is better (read 2 is corrected), 2: read 2 is better
+        if (tied) {
+            if (j <= 0) {
+                err = -3;
+                S.err[lane] = -3;
+            } else {
+                const unsigned long long a = *(volatile unsigned long long *)&S.acc[lane];
+                const long long sum1 = (long long)(uint32_t)a, sum2 = (long long)(a >> 32);
+                const double diff = (double)sum1 / (double)j - (double)sum2 / (double)j;
+                dir = diff > 1.0 ? 1u : diff < -1.0 ? 2u : 0u;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        S.acc[lane] = (unsigned long long)dir;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0u; base < npend_all; base += 64u) {
+            if (base + (uint32_t)lane < npend_all) {
+                const uint32_t t = queue[S.qcap - 1 - (int)(base + (uint32_t)lane)];
+                const int src = (int)(t >> 9), i = (int)(t & 511u);
+                const uint32_t d = (uint32_t)*(volatile unsigned long long *)&S.acc[src];
+                if (d != 0u) {
+                    const int jx = (int)S.jv[src] - 1 - i;
+                    const size_t row = (size_t)(tile * 64 + src) * (size_t)A.stride;
+                    const uint4 v1 = A.planes1[((size_t)tile * nchunks + (size_t)(i >> 5)) * 64 + src];
+                    const uint4 v2 = A.planes2[((size_t)tile * nchunks + (size_t)(jx >> 5)) * 64 + src];
+                    const uint32_t b1 = (uint32_t)(i & 31), b2s = (uint32_t)(jx & 31);
+                    const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
+                    const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
+                    const int qa = (int)A.q1[row + i], qb = (int)A.q2[row + jx];
+                    const uint8_t base1 = code1 ? S.letter[code1] : A.s1[row + i], raw2 = code2 ? S.letter[code2] : A.s2[row + jx];
+                    const uint8_t base2 = S.comp[raw2];
+                    const int qd = qa - qb;
+                    if (!(base1 == base2 || base1 == 'N' || base2 == 'N' || qd >= A.min_qual_diff || qd <= -A.min_qual_diff)) {
+                        if (d == 1u) {
+                            const uint8_t cb = S.comp[base1];
+                            if (cb == 0) S.err[src] = -1;
+                            else { A.s2[row + jx] = cb; A.q2[row + jx] = (uint8_t)qa; atomicAdd(&S.cnt[src], CORRECT_C2); }
+                        } else {
+                            A.s1[row + i] = base2; A.q1[row + i] = (uint8_t)qb; atomicAdd(&S.cnt[src], CORRECT_C1);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        packed_counts = *(volatile uint32_t *)&S.cnt[lane];
+        err = *(volatile int32_t *)&S.err[lane];
+    }
     if (!live) return;
     if (!todo) {
         A.changed[2 * p] = A.changed[2 * p + 1] = 0;
         A.newlen[2 * p] = len1; A.newlen[2 * p + 1] = len2;
         return;
     }
-    const uint32_t packed_counts = *(volatile uint32_t *)&S.cnt[lane];
-    int c1 = (int)(packed_counts & 1023u), c2 = (int)((packed_counts >> 10) & 1023u), err = *(volatile int32_t *)&S.err[lane];
-    const int npend = (int)(packed_counts >> 20);
-    uint8_t *r1 = A.s1 + p * A.stride, *r2 = A.s2 + p * A.stride;
-    if (!err && npend > 0)
+    int c1 = (int)(packed_counts & 1023u), c2 = (int)((packed_counts >> 10) & 1023u);
+    if (npend_all > pend_cap && !err && (packed_counts >> 20) > 0u) {   // a tie list that did not fit (thousands of ties in one wave): lane by lane
+        uint8_t *r1 = A.s1 + p * A.stride, *r2 = A.s2 + p * A.stride;
         correct_ties(r1, has_quals ? A.q1 + p * A.stride : nullptr, r2, has_quals ? A.q2 + p * A.stride : nullptr, j, mism, nchunks,
                      A.min_qual_diff, S.comp, c1, c2, err);
+    }
     A.changed[2 * p] = err ? err : c1;
     A.changed[2 * p + 1] = err ? 0 : c2;
     A.newlen[2 * p] = (c1 > 0 && !err) ? min(len1, len2) : len1;   // the truncation quirk of correct_errors_one

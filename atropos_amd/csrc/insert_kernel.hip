@@ -51,7 +51,7 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     // read 2's planes per lane in LDS ([plane][word][lane]: a lane's words sit in its own bank), its list of
     // overlap lengths to cost exactly, and the per-length hit thresholds (pass 2 indexes them per lane)
     __shared__ uint32_t s_rl[4][4 * (W + 1) * 64];
-    __shared__ uint16_t s_cl[4][INS_LIST_CAP * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cl[4][INS_LIST_CAP * 64];
     __shared__ int32_t s_thr_hit[INS_MAX_LEN + 1];
     for (int i = threadIdx.x; i <= INS_MAX_LEN; i += 256) s_thr_hit[i] = ip.thr_hit[i];
     __shared__ uint8_t s_comp[FUSE ? 256 : 1], s_letter[16];
@@ -85,7 +85,7 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
         // disagreeing positions are the very words the match counted (read 1 in registers, read 2's reversed
         // complement in LDS); a second kernel streams both reads' planes again to find them (correct_planes_kernel).
         static_assert(sizeof(s_rl[0]) >= CORRECT_QUEUE_ENTRIES * sizeof(uint16_t), "task queue does not fit read 2's planes");
-        static_assert(sizeof(s_cl[0]) >= 64 * 4 + 64 * 4 + 64 * 2 + 4, "the per-pair counters do not fit the candidate lists");
+        static_assert(sizeof(s_cl[0]) >= 1024 + 64 * 8, "the per-pair counters do not fit the candidate lists");
         const bool todo = live && P.has_best && P.best_cost > 0;
         const int j = todo ? P.best_j : 0;
         uint32_t mism[W];
@@ -95,6 +95,7 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
         S.queue = (volatile uint16_t *)&s_rl[wv][0];
         uint8_t *small = (uint8_t *)&s_cl[wv][0];
         S.cnt = (uint32_t *)small; S.err = (int32_t *)(small + 256); S.jv = (int16_t *)(small + 512); S.tail = (uint32_t *)(small + 640);
+        S.ptail = (uint32_t *)(small + 644); S.acc = (unsigned long long *)(small + 1024); S.qcap = (int)(sizeof(s_rl[0]) / sizeof(uint16_t));
         S.comp = s_comp; S.letter = s_letter;
         correct_wave_tail<W>(S, fz->A, tile, lane, live, todo, j, len1, len2, mism);
     }

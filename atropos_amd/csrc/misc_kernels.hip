@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     __shared__ uint32_t s_cnt[4][64];                             // per pair: c1 | c2 << 10 | npend << 20
     __shared__ int32_t s_err[4][64];
     __shared__ int16_t s_j[4][64];
-    __shared__ uint32_t s_tail[4];
+    __shared__ uint32_t s_tail[4], s_ptail[4];
+    __shared__ unsigned long long s_acc[4][64];
     s_comp[threadIdx.x] = ct.c[threadIdx.x];
     correct_letter_table(s_letter);
     __syncthreads();
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     CorrectWaveLds S;
     S.queue = (volatile uint16_t *)&s_b2[wave][0][0];
     S.cnt = s_cnt[wave]; S.err = s_err[wave]; S.jv = s_j[wave]; S.tail = &s_tail[wave];
+    S.ptail = &s_ptail[wave]; S.acc = s_acc[wave]; S.qcap = 4 * PW * 64 * 2;
     S.comp = s_comp; S.letter = s_letter;
     CorrectArgs A;
     A.planes1 = planes1; A.planes2 = planes2; A.nchunks = nchunks;
