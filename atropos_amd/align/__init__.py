@@ -417,7 +417,7 @@ def compare_suffixes(suffix_ref, suffix_query, wildcard_ref=False, wildcard_quer
 
 def _compare(ref, query, wildcard_ref, wildcard_query, suffix):
     be = _lib.get_backend()
-    if hasattr(be, "compare_one") and len(ref) <= 1024:
+    if hasattr(be, "compare_one") and len(ref) <= _COMPARE_REF_MAX:
         return be.compare_one(ref.encode('ascii'), query.encode('ascii'), wildcard_ref, wildcard_query, suffix)
     rec = compare_batch(ref, [query], wildcard_ref, wildcard_query, suffix).cpu().numpy()[0]
     return tuple(int(v) for v in rec[:6])
@@ -429,8 +429,6 @@ def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix
     Returns the int16 [n, 8] record tensor on the device."""
     be = _lib.get_backend()
     ref_b = ref.encode('ascii')
-    if len(ref_b) > 1024:
-        raise _lib.AtroposHipError("compare_prefixes: references longer than 1024 are outside the device envelope")
     if isinstance(queries, (list, tuple)):
         for q in queries:
             q.encode('ascii')
@@ -441,7 +439,47 @@ def compare_batch(ref, queries, wildcard_ref=False, wildcard_query=False, suffix
     if q_t.shape[0] and q_t.shape[1] == 0:
         q_t = torch.zeros((q_t.shape[0], 1), dtype=torch.uint8, device=be.device)
         lens = torch.zeros((q_t.shape[0],), dtype=torch.int32, device=be.device) if lens is None else lens
+    if len(ref_b) > _COMPARE_REF_MAX:
+        return _compare_long(be, ref_b, q_t, lens, wildcard_ref, wildcard_query, suffix)
     return be.compare_batch(ref_b, q_t, lens, q_t.shape[1], wildcard_ref, wildcard_query, suffix)
+
+
+_COMPARE_REF_MAX = 1024          # reference bytes one atr_compare_batch call takes (they travel as kernel arguments)
+
+
+def _compare_long(be, ref_b, q_t, lens, wildcard_ref, wildcard_query, suffix):
+    """compare_prefixes / compare_suffixes with a reference of more than 1024 characters (the reference has no limit,
+    _align.pyx:501-544): the compared stretch is cut into pieces of 1024 positions -- matches add up -- and a suffix
+    compare is the prefix compare of the reversed strings.  Coordinates beyond the records' int16 fields (32767) are
+    refused."""
+    m, n_rows, width = len(ref_b), q_t.shape[0], q_t.shape[1]
+    dev = q_t.device
+    if lens is None:
+        lens = torch.full((n_rows,), width, dtype=torch.int32, device=dev)
+    lens = lens.clamp(min=0, max=width).to(torch.int32)
+    if m > 32767 or width > 32767:
+        raise _lib.AtroposUnsupported("compare_prefixes: more than 32767 characters (the records' int16 fields)")
+    if suffix:
+        # reverse every query inside its own length, and the reference
+        cols = torch.arange(width, device=dev, dtype=torch.int64)[None, :]
+        src = (lens.to(torch.int64)[:, None] - 1 - cols).clamp(min=0)
+        q_t = torch.where(cols < lens[:, None], torch.gather(q_t, 1, src), torch.zeros_like(q_t))
+        ref_b = ref_b[::-1]
+    matches = torch.zeros((n_rows,), dtype=torch.int64, device=dev)
+    for c in range(0, min(m, width), _COMPARE_REF_MAX):
+        piece = ref_b[c:c + _COMPARE_REF_MAX]
+        sub = q_t[:, c:c + len(piece)].contiguous()
+        sub_lens = (lens - c).clamp(min=0, max=sub.shape[1]).to(torch.int32)
+        rec = be.compare_batch(piece, sub, sub_lens, sub.shape[1], wildcard_ref, wildcard_query, False)
+        matches += rec[:, 4].to(torch.int64)
+    ln = torch.minimum(lens.to(torch.int64), torch.tensor(m, dtype=torch.int64, device=dev))
+    out = torch.zeros((n_rows, 8), dtype=torch.int64, device=dev)
+    if suffix:
+        out[:, 0] = m - ln; out[:, 1] = m; out[:, 2] = lens.to(torch.int64) - ln; out[:, 3] = lens.to(torch.int64)
+    else:
+        out[:, 1] = ln; out[:, 3] = ln
+    out[:, 4] = matches; out[:, 5] = ln - matches
+    return out.to(torch.int16)
 
 
 def case_sensitive_pair_table(dna15):

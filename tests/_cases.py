@@ -871,6 +871,55 @@ def check_plane_guided_correction(n=768, seed=5):
     return done
 
 
+def check_long_multi_compare():
+    """MultiAligner.locate and compare_prefixes / compare_suffixes on strings of 737 .. 3 000 characters against the
+    reference's own outputs (long_multi_compare.json.gz, tests/golden/make_round5_golden.py): past the 736 bases of
+    the batch pipelines; compare references of more than 1 024 characters are composed from pieces."""
+    from atropos_amd.align import MultiAligner, compare_prefixes, compare_suffixes, compare_batch
+    g = load_golden("long_multi_compare.json.gz")
+    done = 0
+    for c in g["compare"]:
+        k = 0
+        for wr in (False, True):
+            for wq in (False, True):
+                exp_p, exp_s = c["out"][k]
+                k += 1
+                assert list(compare_prefixes(c["ref"], c["query"], wr, wq)) == exp_p, (len(c["ref"]), len(c["query"]), wr, wq)
+                assert list(compare_suffixes(c["ref"], c["query"], wr, wq)) == exp_s, (len(c["ref"]), len(c["query"]), wr, wq)
+                done += 2
+        # the batch form: the same reference against the query, a prefix of it and an empty string
+        qs = [c["query"], c["query"][:len(c["query"]) // 2], ""]
+        for sfx in (False, True):
+            rec = compare_batch(c["ref"], qs, False, True, sfx).cpu().numpy()
+            assert [int(v) for v in rec[0, :6]] == c["out"][1][1 if sfx else 0]
+            one = (compare_suffixes if sfx else compare_prefixes)(c["ref"], qs[1], False, True)
+            assert tuple(int(v) for v in rec[1, :6]) == tuple(one)
+            assert int(rec[2, 4]) == 0 and int(rec[2, 5]) == 0
+    for c in g["multi"]:
+        for r in c["runs"]:
+            got = MultiAligner(r["e"], r["flags"], r["min_overlap"]).locate(c["ref"], c["query"])
+            assert (None if got is None else [list(t) for t in got]) == r["out"], (len(c["ref"]), len(c["query"]), r["flags"])
+            done += 1
+    # LinkedAdapter.match_to on reads of 737 .. 3 000 bases (one by one and as a batch)
+    from atropos_amd.adapters import LinkedAdapter
+    from atropos_amd.reads import Sequence
+
+    def fields(m):
+        return None if m is None else [m.astart, m.astop, m.rstart, m.rstop, m.matches, m.errors]
+    for c in g["linked"]:
+        la = LinkedAdapter(c["front"], c["back"], **c["kw"])
+        m = la.match_to(Sequence("r", c["read"]))
+        assert (None if m is None else [fields(m.front_match), fields(m.back_match)]) == c["out"], (len(c["read"]), c["front"], c["back"])
+        done += 1
+    c0 = g["linked"][0]
+    la = LinkedAdapter(c0["front"], c0["back"], **c0["kw"])
+    batch = la.match_to_batch([Sequence("r%d" % k, c["read"]) for k, c in enumerate(g["linked"][:12])])
+    one = [la.match_to(Sequence("r", c["read"])) for c in g["linked"][:12]]
+    assert [None if m is None else (fields(m.front_match), fields(m.back_match)) for m in batch] == \
+           [None if m is None else (fields(m.front_match), fields(m.back_match)) for m in one]
+    return done
+
+
 def check_fused_match_correct(n=4096, seed=9):
     """atr_insert_match_correct_batch (match + correction in one kernel, the planes streamed once) against
     atr_insert_match_batch followed by atr_insert_correct_batch -- which the cutter fixtures and the checker pin to

@@ -83,3 +83,7 @@ def test_device_resident_adapters(emu_backend):
 def test_merge_overlapping(emu_backend):
     assert _cases.check_merge_golden(batch=True) == 1190
     assert _cases.check_merge_golden(batch=False) == 1190
+
+
+def test_long_multi_and_compare(emu_backend):
+    assert _cases.check_long_multi_compare() == 36 * 8 + 30 * 5 + 60

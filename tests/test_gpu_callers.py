@@ -126,3 +126,8 @@ def test_device_resident_adapters(hip_backend):
 
 def test_merge_overlapping(hip_backend):
     assert _cases.check_merge_golden(batch=True) == 1190
+
+
+def test_long_multi_and_compare(hip_backend):
+    """MultiAligner / compare_prefixes / compare_suffixes past 736 (and past 1 024 reference) characters vs the reference"""
+    assert _cases.check_long_multi_compare() == 36 * 8 + 30 * 5 + 60

@@ -200,3 +200,20 @@ def test_correct_errors_fuzz(oracle):
         assert got == c["out"], c
         seen.add(got.get("error", "ok"))
     assert seen == {"ok", "KeyError", "IndexError", "ValueError"}
+
+
+def test_long_multi_and_compare(oracle):
+    """the C restatement on the 737 .. 3 000-character cases of round 5 (reference outputs)"""
+    g = load_golden("long_multi_compare.json.gz")
+    for c in g["compare"]:
+        k = 0
+        for wr in (False, True):
+            for wq in (False, True):
+                exp_p, exp_s = c["out"][k]
+                k += 1
+                assert list(oracle.compare_prefixes(c["ref"], c["query"], wr, wq)) == exp_p
+                assert list(oracle.compare_suffixes(c["ref"], c["query"], wr, wq)) == exp_s
+    for c in g["multi"]:
+        for r in c["runs"]:
+            got = oracle.multi_locate(c["ref"], c["query"], r["e"], r["flags"], r["min_overlap"])
+            assert (None if got is None else [list(t) for t in got]) == r["out"]
