@@ -62,43 +62,64 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     const uint32_t pend_cap = (uint32_t)(S.qcap - CORRECT_QUEUE_ENTRIES);
     const bool has_quals = A.q1 != nullptr && A.q2 != nullptr;
     const int nchunks = A.nchunks;
-    const auto drain = [&](int from, int count) {               // tasks queue[from .. from + count), count <= 64, wave-uniform
-        if (lane < count) {
-            const uint32_t t = queue[from + lane];
-            const int src = (int)(t >> 9), i = (int)(t & 511u);
-            const int jx = (int)S.jv[src] - 1 - i;
-            const size_t row = (size_t)(tile * 64 + src) * (size_t)A.stride;
+    // A task in two halves, so that the loads of SEVERAL tasks can be in flight before the first one stores (byte
+    // pointers alias: the compiler keeps every load behind the stores that precede it in program order).
+    struct Task { int src, i, jx; size_t row; int qa, qb; uint8_t base1, raw2; bool valid; uint32_t entry; };
+    const auto fetch = [&](bool valid, uint32_t t) {
+        Task k;
+        k.valid = valid; k.entry = t;
+        k.src = (int)(t >> 9); k.i = (int)(t & 511u);
+        k.jx = 0; k.row = 0; k.qa = k.qb = 0; k.base1 = k.raw2 = 0;
+        if (valid) {
+            k.jx = (int)S.jv[k.src] - 1 - k.i;
+            k.row = (size_t)(tile * 64 + k.src) * (size_t)A.stride;
             // The two BASES come from the bit planes, not from the ASCII matrices: the pair's chunks were streamed by this
             // wave a moment ago (L2), a DNA15 code names its byte (15 upper-case letters, aligner_host.hpp), and a byte
             // fetched from a matrix costs a 64-byte sector of HBM -- two of the four a task used to pull (round 4:
             // 1 068 B per pair counted).  Code 0 (a byte outside the table): read the matrix as before.
-            const uint4 v1 = A.planes1[((size_t)tile * nchunks + (size_t)(i >> 5)) * 64 + src];
-            const uint4 v2 = A.planes2[((size_t)tile * nchunks + (size_t)(jx >> 5)) * 64 + src];
-            const uint32_t b1 = (uint32_t)(i & 31), b2s = (uint32_t)(jx & 31);
+            const uint4 v1 = A.planes1[((size_t)tile * nchunks + (size_t)(k.i >> 5)) * 64 + k.src];
+            const uint4 v2 = A.planes2[((size_t)tile * nchunks + (size_t)(k.jx >> 5)) * 64 + k.src];
+            const uint32_t b1 = (uint32_t)(k.i & 31), b2s = (uint32_t)(k.jx & 31);
             const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
             const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
-            const int qa = has_quals ? (int)A.q1[row + i] : 0, qb = has_quals ? (int)A.q2[row + jx] : 0;
-            const uint8_t base1 = code1 ? S.letter[code1] : A.s1[row + i], raw2 = code2 ? S.letter[code2] : A.s2[row + jx];
-            uint32_t delta = 0u;
-            const int e = correct_apply_delta(A.s1 + row, has_quals ? A.q1 + row : nullptr, A.s2 + row, has_quals ? A.q2 + row : nullptr, i, jx,
-                                              base1, raw2, qa, qb, A.action, A.min_qual_diff, S.comp, delta);
-            if (e) S.err[src] = e;
-            else if (delta) {
-                atomicAdd(&S.cnt[src], delta);
-                if (delta >= CORRECT_NP) {                          // 'liberal', qualities too close: decided by the pair's mean qualities below
-                    const uint32_t slot = atomicAdd(S.ptail, 1u);
-                    if (slot < pend_cap) queue[S.qcap - 1 - (int)slot] = (uint16_t)t;
-                }
+            k.qa = has_quals ? (int)A.q1[k.row + k.i] : 0;
+            k.qb = has_quals ? (int)A.q2[k.row + k.jx] : 0;
+            k.base1 = code1 ? S.letter[code1] : A.s1[k.row + k.i];
+            k.raw2 = code2 ? S.letter[code2] : A.s2[k.row + k.jx];
+        }
+        return k;
+    };
+    const auto apply = [&](const Task &k) {
+        if (!k.valid) return;
+        uint32_t delta = 0u;
+        const int e = correct_apply_delta(A.s1 + k.row, has_quals ? A.q1 + k.row : nullptr, A.s2 + k.row, has_quals ? A.q2 + k.row : nullptr,
+                                          k.i, k.jx, k.base1, k.raw2, k.qa, k.qb, A.action, A.min_qual_diff, S.comp, delta);
+        if (e) S.err[k.src] = e;
+        else if (delta) {
+            atomicAdd(&S.cnt[k.src], delta);
+            if (delta >= CORRECT_NP) {                              // 'liberal', qualities too close: decided by the pair's mean qualities below
+                const uint32_t slot = atomicAdd(S.ptail, 1u);
+                if (slot < pend_cap) queue[S.qcap - 1 - (int)slot] = (uint16_t)k.entry;
             }
         }
     };
-    int qsize = 0;                                                // wave-uniform
+    const auto drain = [&](int from, int count) {               // tasks queue[from .. from + count), count <= 64, wave-uniform
+        const bool v = lane < count;
+        const Task k = fetch(v, v ? (uint32_t)queue[from + lane] : 0u);
+        apply(k);
+    };
+    int total = 0;
 #pragma unroll
-    for (int w = 0; w < PW; ++w) {
-        uint32_t m = mism[w];                                     // (0 beyond nchunks)
-        const int cnt = __builtin_popcount(m);
-        if (cnt) {
-            uint32_t at = atomicAdd(S.tail, (uint32_t)cnt);
+    for (int w = 0; w < PW; ++w) total += __builtin_popcount(mism[w]);
+    uint32_t at = total ? atomicAdd(S.tail, (uint32_t)total) : 0u;
+    __builtin_amdgcn_wave_barrier();
+    const int qall = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
+    if (qall <= CORRECT_QUEUE_ENTRIES) {
+        // (the common case) every lane lists all its positions at once -- one reservation instead of one per plane word
+        // with three wave barriers each -- and the wave works the list off two tasks per lane and round trip
+#pragma unroll
+        for (int w = 0; w < PW; ++w) {
+            uint32_t m = mism[w];
             while (m) {
                 const int b = __builtin_ctz(m);
                 m &= m - 1u;
@@ -106,16 +127,45 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
             }
         }
         __builtin_amdgcn_wave_barrier();
-        qsize = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
-        while (qsize >= 64) {                                     // full rounds, off the end of the queue
-            qsize -= 64;
-            drain(qsize, 64);
+        for (int base = 0; base < qall; base += 128) {
+            const int i0 = base + lane, i1 = base + 64 + lane;
+            const bool v0 = i0 < qall, v1 = i1 < qall;
+            const Task k0 = fetch(v0, v0 ? (uint32_t)queue[i0] : 0u);
+            const Task k1 = fetch(v1, v1 ? (uint32_t)queue[i1] : 0u);
+            apply(k0);
+            apply(k1);
         }
+    } else {
+        // more positions than the queue holds (a wave of unrelated reads "matched" at a high error rate): word by word,
+        // full rounds worked off as they fill
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0) *S.tail = (uint32_t)qsize;
+        if (lane == 0) *S.tail = 0u;
         __builtin_amdgcn_wave_barrier();
+        int qsize = 0;                                            // wave-uniform
+#pragma unroll
+        for (int w = 0; w < PW; ++w) {
+            uint32_t m = mism[w];                                 // (0 beyond nchunks)
+            const int cnt = __builtin_popcount(m);
+            if (cnt) {
+                uint32_t at2 = atomicAdd(S.tail, (uint32_t)cnt);
+                while (m) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1u;
+                    queue[at2++] = (uint16_t)((lane << 9) | (32 * w + b));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            qsize = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
+            while (qsize >= 64) {                                 // full rounds, off the end of the queue
+                qsize -= 64;
+                drain(qsize, 64);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) *S.tail = (uint32_t)qsize;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (qsize > 0) drain(0, qsize);
     }
-    if (qsize > 0) drain(0, qsize);
     // the lanes' stores, before their pairs' owners (lanes of this same wave: one CU, one L1) read them back --
     // a device-scope fence would write back the L2 for the sake of other XCDs, once per wave
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");

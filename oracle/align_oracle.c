@@ -176,6 +176,10 @@ static int locate_core(const unsigned char *s1, int m, const unsigned char *s2, 
     }
     if (best.cost == m + n) return 0;                             /* :476-480 */
     hit_to_tuple(&best, out);
+    /* `assert best.ref_stop - start1 > 0` (:490, "Do not return empty alignments").  It cannot fire: a candidate needs
+     * length = ref_stop - start1 >= min_overlap (:446, :468) and the min_overlap setter refuses values below 1
+     * (:218-221) -- kept as a return code of its own so that the restatement does not drop a line of the reference. */
+    if (out[1] - out[0] <= 0) return -2;
     return 1;
 }
 

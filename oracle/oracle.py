@@ -101,6 +101,8 @@ def locate(ref, query, e, flags=15, wildcard_ref=False, wildcard_query=False,
     r, q = _b(ref), _b(query)
     rc = lib().orc_locate(r, len(r), q, len(q), e, flags, int(wildcard_ref), int(wildcard_query),
                           min_overlap, indel_cost, out)
+    if rc == -2:
+        raise AssertionError("empty alignment (_align.pyx:490)")
     if rc < 0:
         raise MemoryError
     return tuple(out) if rc else None

@@ -52,3 +52,10 @@ def test_paired_file_chunking(emu_backend, tmp_path):
 def test_fastq_reader_fuzz_vs_reference(emu_backend):
     total, errors = _cases.check_fastq_reader_golden()
     assert total == 300 and errors > 40
+
+
+def test_paired_merge_slice_against_oracle(emu_backend, oracle):
+    """MergeOverlapping restated on the checker (no code shared with the kernels) -- the CPU-tier size of
+    tests/test_gpu_fastq.py::test_large_paired_merge_slice_against_oracle"""
+    from .test_gpu_fastq import check_merge_slice_against_oracle
+    assert check_merge_slice_against_oracle(oracle, 400, 2) > 150

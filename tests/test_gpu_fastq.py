@@ -149,6 +149,60 @@ def test_large_paired_merge_equals_cpu_twin(hip_backend, args):
         assert len(g) == len(w) and g == w, _cases._first_diff(g, w)
 
 
+def _records(text):
+    lines = text.split(b"\n")
+    return {lines[k]: (lines[k + 1], lines[k + 3]) for k in range(0, len(lines) - 1, 4)}
+
+
+def check_merge_slice_against_oracle(oracle, npairs, every):
+    """The paired text pipeline with the MergeOverlapping stage against a restatement that shares NO code with the
+    kernels: `-u 2 -U 3` (UnconditionalCutter) then MergeOverlapping(12, 0.15) -- commands/trim/modifiers.py:864-931 --
+    restated on the checker's Aligner.locate for every `every`-th pair: which file the pair lands in, the merged
+    sequence and qualities."""
+    from atropos_amd.fastq import FastqBatch
+    from atropos_amd.trim import pipeline_from_args
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    d1, d2 = _big_pairs(npairs, 9)
+    pipe = pipeline_from_args("-R --merge-min-overlap 12 --merge-error-rate 0.15 -u 2 -U 3")
+    b1, _ = FastqBatch.from_bytes(d1, final=True)
+    b2, _ = FastqBatch.from_bytes(d2, final=True)
+    res = pipe.run(b1, b2)
+    out1, out2 = (_records(t) for t in res.text())
+    merged = _records(res.merged_text())
+    src1, src2 = d1.split(b"\n"), d2.split(b"\n")
+    nmerged = 0
+    for i in range(0, npairs, every):
+        name = src1[4 * i]
+        s1, q1 = src1[4 * i + 1].decode()[2:], src1[4 * i + 3].decode()[2:]
+        s2, q2 = src2[4 * i + 1].decode()[3:], src2[4 * i + 3].decode()[3:]
+        exp = None
+        if len(s1) >= 12 and len(s2) >= 12:
+            rc2 = "".join(comp[c] for c in reversed(s2))
+            rq2 = q2[::-1]
+            al = oracle.locate(rc2, s1, 0.15, 15)
+            if al is not None and al[4] >= 12:
+                r2_start, r2_stop, r1_start, r1_stop = al[:4]
+                if r2_start == 0 and r2_stop == len(s2):
+                    exp = (s1, q1)
+                elif r1_start == 0 and r1_stop == len(s1):
+                    exp = (rc2, rq2)
+                elif r1_start > 0:
+                    exp = (s1 + rc2[r2_stop:], q1 + rq2[r2_stop:])
+                else:
+                    assert r2_start > 0
+                    exp = (rc2 + s1[r1_stop:], rq2 + q1[r1_stop:])
+        if exp is None:
+            assert name not in merged and out1[name] == (s1.encode(), q1.encode()) and out2[name] == (s2.encode(), q2.encode()), i
+        else:
+            nmerged += 1
+            assert name not in out1 and name not in out2 and merged[name] == (exp[0].encode(), exp[1].encode()), (i, al, merged.get(name), exp)
+    return nmerged
+
+
+def test_large_paired_merge_slice_against_oracle(hip_backend, oracle):
+    assert check_merge_slice_against_oracle(oracle, 30000, 7) > 2500
+
+
 def test_fastq_reader_fuzz_vs_reference(hip_backend):
     total, errors = _cases.check_fastq_reader_golden()
     assert total == 300 and errors > 40

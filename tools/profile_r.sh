@@ -24,6 +24,16 @@ out = sys.argv[1]
 def find(pat):
     return glob.glob(os.path.join(out, pat), recursive=True)
 with open(os.path.join(out, "summary.txt"), "w") as fh:
+    # the bench line printed by the TRACED run itself: the kernel averages below belong to this ms_per_step (tracing
+    # adds a little to both; compare them with each other, not with the untraced line of another lease)
+    try:
+        import json
+        line = [l for l in open(os.path.join(out, "trace.log")).read().splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        fh.write("== bench line of this traced run: value=%.4g %s ms_per_step=%.4f kernel_ms(HIP events)=%.4f steps=%d\n" % (
+            d["value"], d["unit"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["steps"]))
+    except Exception as e:                                        # noqa: BLE001
+        fh.write("== (no bench line in trace.log: %r)\n" % (e,))
     for f in find("trace/**/*kernel_stats.csv"):
         fh.write("== kernel_stats (%s): the library's kernels; everything else (torch kernels of the synthetic-data\n"
                  "   generation and of bench.py's set-up, outside the timed steps) folded into one line\n" % f)
