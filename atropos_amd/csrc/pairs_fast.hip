@@ -11,8 +11,8 @@
 //   P4  pairs_band_kernel<WB> the banded packed-word DP (payload of the threats), one launch per band class.
 //   P5  the full sweep (pairs_core.hpp) over the pairs of the last bin, gathered by index.
 //
-// VALU-bound like every DP here (no MFMA: a min-plus recurrence).  LDS: P1 8 x NW match-mask words + one cost
-// byte per column and lane; P4 the lane's reference / query streams.
+// VALU-bound like every DP here (no MFMA: a min-plus recurrence).  LDS: P1 5 x NW match-mask words per lane; P4 the
+// lane's reference / query streams.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 
@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const bool sr = (fp.pp.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (fp.pp.flags & ATR_START_WITHIN_SEQ2) != 0;
-    // per wave: PF_TAB_ROWS x NW mask words and PF_LIST_CAP 16-bit candidate entries per lane
-    constexpr int WAVE_WORDS = PF_TAB_ROWS * NW * 64 + PF_LIST_CAP * 32;
+    // per wave: PF_TAB_ROWS x NW mask words per lane, and row m's horizontal deltas (two words per 32 columns: the
+    // +1 bits and the -1 bits) from which pass 2 replays the row-m costs -- no candidate list (pairs_fast_core.hpp)
+    constexpr int WAVE_WORDS = (PF_TAB_ROWS + 2) * NW * 64;
     uint32_t *tab = s_dyn + (size_t)wave * WAVE_WORDS + lane;
-    uint16_t *list = (uint16_t *)(s_dyn + (size_t)wave * WAVE_WORDS + PF_TAB_ROWS * NW * 64) + lane;
+    uint32_t *hd = tab + (size_t)PF_TAB_ROWS * NW * 64;
     const long long ntiles = (a.npairs + 63) >> 6;
     long long t0, t1;
     pairs_block_tiles(ntiles, nwaves, t0, t1);
@@ -88,9 +89,12 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
         PfMyers<NW> S;
         pf_myers_init<NW>(S, m, sr);
         const uint32_t hin = sq ? 0u : 1u;
-        int cnt = 0;
+        const int need = a.need && live ? a.need[r] : 1;
+        PfScan T;
+        pf_stream_init(T, need);
+        uint32_t chunks_hit = 0u;                                      // 32-column chunks with a row-m candidate
+        const int c1 = jhi > 0 ? (jhi + 31) >> 5 : 0;
         if (jhi > 0) {
-            const int c1 = (jhi + 31) >> 5;
             uint4 nxt = qt[0];
             // the match masks of a column are fetched from LDS one column ahead of the (serially dependent) update
             uint32_t eqn[NW];
@@ -103,6 +107,8 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
                 const uint4 cur = nxt;
                 if (c + 1 < c1) nxt = qt[(size_t)(c + 1) * 64];
                 int j = c * 32;
+                uint32_t pbits = 0u, mbits = 0u;
+                bool hit = false;
 #pragma unroll 1
                 for (int d = 0; d < 4; ++d) {
                     const uint32_t w = d == 0 ? cur.x : d == 1 ? cur.y : d == 2 ? cur.z : cur.w;
@@ -122,25 +128,51 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
 #pragma unroll
                         for (int x = 0; x < NW; ++x) eqn[x] = tab[(size_t)(row * NW + x) * 64];
                         if (j <= n_sweep) {
+                            const int before = S.score;
                             pf_myers_step<NW>(S, eq, hin);
-                            pf_collect_rowm(list, 64, cnt, j, S.score, min(k, (int)fp.g_ap[j]));
+                            const uint32_t bit = 1u << ((j - 1) & 31);
+                            pbits |= S.score > before ? bit : 0u;
+                            mbits |= S.score < before ? bit : 0u;
+                            hit = pf_rowm_pass1(T, m, j, S.score, k, (int)s_gap[j], (int)s_gas[j], fp.pp.min_overlap) || hit;
                         }
                     }
                     if (j >= jhi) break;
                 }
+                hd[(size_t)(2 * c) * 64] = pbits;
+                hd[(size_t)(2 * c + 1) * 64] = mbits;
+                if (__any(hit)) chunks_hit |= 1u << c;                 // (wave-uniform; c < NW <= 10)
             }
         }
         // the bases behind n_sweep (only without START_WITHIN_SEQ2) are never compared; they need no code check
-        const int cnt_row = cnt;
         const bool scan_last = n_sweep == n;
-        if (live && scan_last && m >= 1 && n >= 1)
-            pf_collect_lastcol<NW>(list, 64, cnt, S.pv, S.mv, m, n, sq, er, s_thr, (int)s_gap[n]);
+        const bool lastcol = live && scan_last && m >= 1 && n >= 1;
+        if (lastcol)
+            pf_stream_lastcol<NW>(T, S.pv, S.mv, m, n, sq, er, s_thr, (int)s_gap[n], (int)s_gas[n], fp.pp.min_overlap, need, false);
+        {   // pass 2 over row m: the costs replayed from the horizontal deltas, chunks without a candidate skipped
+            const int mlb = pf_mlb_eff(T, need);
+            int score = sr ? 0 : m;                                    // D[m][0] (pf_myers_init)
+            for (int c = 0; c < c1; ++c) {
+                uint32_t pb = hd[(size_t)(2 * c) * 64], mb = hd[(size_t)(2 * c + 1) * 64];
+                if (!((chunks_hit >> c) & 1u)) {
+                    score += __builtin_popcount(pb) - __builtin_popcount(mb);
+                    continue;
+                }
+#pragma unroll 1
+                for (int b = 0; b < 32; ++b) {
+                    const int j = 32 * c + b + 1;
+                    if (j > jhi) break;                               // wave-uniform
+                    score += (int)(pb & 1u) - (int)(mb & 1u);
+                    pb >>= 1; mb >>= 1;
+                    if (j <= n_sweep) pf_rowm_pass2(T, m, j, score, k, (int)s_gap[j], fp.pp.min_overlap, mlb);
+                }
+            }
+        }
+        if (lastcol)
+            pf_stream_lastcol<NW>(T, S.pv, S.mv, m, n, sq, er, s_thr, (int)s_gap[n], (int)s_gas[n], fp.pp.min_overlap, need, true);
         PfDecision D;
         D.kind = 2; D.cls = 0;
-        const bool ok = live && known && m >= 1 && n >= 1 && k <= PF_MAX_K && cnt <= PF_LIST_CAP;
-        const int nmax = wave_max_i32(ok ? cnt : 0);
-        pf_analyse(list, 64, cnt_row, ok ? cnt : 0, nmax, m, n, fp, s_thr, s_gap, s_gas, a.need && live ? a.need[r] : 1, (uint32_t)r, D);
-        if (!ok) D.kind = 2;
+        const bool ok = live && known && m >= 1 && n >= 1 && k <= PF_MAX_K;
+        if (ok) pf_decide(T, m, n, need, (uint32_t)r, D);
         if (live) {
             if (D.kind == 0) {
                 a.out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);
@@ -260,12 +292,12 @@ static hipError_t launch_band(const PairFastParams &fp, const PairsFastArgs &a, 
     return hipGetLastError();
 }
 
-// waves per block of P1: four, two for the long reads (whose LDS would leave one block per CU)
-static int myers_waves(int nw) { return nw <= 5 ? 4 : 2; }
+// waves per block of P1
+static int myers_waves(int nw) { (void)nw; return 4; }
 
 template <int NW>
 static hipError_t launch_myers(const PairFastParams &fp, const PairsFastArgs &a, const PairsFastWork &wk, hipStream_t st) {
-    const size_t per_wave = ((size_t)PF_TAB_ROWS * NW * 64 + (size_t)PF_LIST_CAP * 32) * 4;
+    const size_t per_wave = (size_t)(PF_TAB_ROWS + 2) * NW * 64 * 4;
     const int waves = myers_waves(NW);
     const size_t lds = (size_t)waves * per_wave;
     hipError_t e = hipFuncSetAttribute((const void *)pairs_myers_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

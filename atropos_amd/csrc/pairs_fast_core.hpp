@@ -18,7 +18,7 @@
 //     "accept-sure": c <= thr[R_lb] (it IS accepted, with >= lbM matches); "accept-possible": c <= thr[R_ub].
 //     M_lb = the largest lbM of an accept-sure candidate (or the caller's `need`) bounds the winner's
 //     matches from below, so only accept-possible candidates with ubM >= M_lb -- the THREATS -- can be
-//     the result.  (pf_analyse)
+//     the result.  (pf_stream_rowm / pf_stream_lastcol / pf_decide)
 //  3. PAYLOAD.  The (matches, origin) payload of the threats comes from the packed-word DP on a BAND of
 //     diagonals (row-major, one register per diagonal, cells outside count as unreachable;
 //     pf_band_sweep).  A path that ends on diagonal d with cost c never leaves the diagonals
@@ -214,8 +214,8 @@ struct PfDecision {
 
 ATR_DEV int pf_min3i(int a, int b, int c) { return atr_min(atr_min(a, b), c); }
 
-// One candidate end cell (ie, je) of exact cost c.  first pass (second == false): the lower bound of the
-// winner's matches; second pass: the threats' diagonals, rows and bit masks (relative to `anchor`).
+// One candidate end cell (ie, je) of exact cost c.  Pass 1: the lower bound of the winner's matches; pass 2: the
+// threats' diagonals and rows.
 struct PfScan {
     int mlb, dbest;                                 // pass 1
     int lo, hi, rl, cand_first;                     // pass 2
@@ -241,8 +241,23 @@ ATR_DEV bool pf_is_threat(int ie, int je, int c, int thr_rows, int gap, int min_
     return c <= thr_rows && c <= gap && atr_min(ie, je + c) >= min_overlap && pf_min3i(ie, je, (ie + je - c) >> 1) >= mlb;
 }
 
-ATR_DEV void pf_pass2(PfScan &S, int ie, int je, int c, int thr_rows, int gap, int min_overlap, bool lastcol) {
-    if (pf_is_threat(ie, je, c, thr_rows, gap, min_overlap, S.mlb)) {
+// The analysis keeps no candidate list (round 5: the per-lane list -- 96 entries of 16 bits -- was two thirds of the
+// cost kernel's LDS and held it at two waves per SIMD).  Pass 1 (the lower bound of the winner's matches) runs along
+// the sweep and then over the last column; pass 2 (the threats under the FINAL bound) needs the row-m costs again:
+// the sweep leaves row m's horizontal deltas behind -- two bits per column, D[m][j] - D[m][j-1] in {-1, 0, +1}, which
+// Myers' recurrence produces anyway -- and the exact costs are replayed from them.  (Taking the threats up during the
+// sweep under the bound as it stood was tried first: the cells in front of the winner on row m come before the bound
+// rises, and the bands went from 64 to 96 diagonals.)  The last column comes from the final vertical deltas, which
+// are still in registers, in two walks.
+ATR_DEV void pf_stream_init(PfScan &S, int need) {
+    S.mlb = atr_max(need, 1) - 1; S.dbest = 0;
+    S.lo = 0x7fff; S.hi = -0x7fff; S.rl = 0; S.cand_first = 0; S.have = false;
+}
+ATR_DEV int pf_mlb_eff(const PfScan &S, int need) { return atr_max(S.mlb, atr_max(need, 1)); }
+
+// threat test and band extents under the bound `mlb`
+ATR_DEV void pf_take_threat(PfScan &S, int ie, int je, int c, int thr_rows, int gap, int min_overlap, bool lastcol, int mlb) {
+    if (pf_is_threat(ie, je, c, thr_rows, gap, min_overlap, mlb)) {
         const int d = je - ie;
         S.have = true;
         S.lo = atr_min(S.lo, d - c);                // all optimal paths of the threat: diagonals d - c .. d + c
@@ -252,27 +267,24 @@ ATR_DEV void pf_pass2(PfScan &S, int ie, int je, int c, int thr_rows, int gap, i
     }
 }
 
-// The candidates that pass the accept-possible test are collected while the costs are computed -- a list of
-// 16-bit entries (cost << 9 | position) per lane, the row-m cells (position = column) first, then the last-column
-// cells (position = row) -- so that the two passes of the analysis only walk the few cells that matter.
-constexpr int PF_LIST_CAP = 96;                     // entries per lane; a pair with more takes the full sweep
-
-ATR_DEV uint32_t pf_entry(int pos, int cost) { return (uint32_t)pos | ((uint32_t)cost << 9); }
-
-// row m, column j (during the sweep): accept-possible  <=>  c <= thr[m] and c <= g_ap[j]
-ATR_DEV void pf_collect_rowm(uint16_t *list, int ls, int &cnt, int j, int score, int lim) {
-    if (score <= lim) {
-        if (cnt < PF_LIST_CAP) list[(size_t)cnt * ls] = (uint16_t)pf_entry(j, score);
-        ++cnt;
-    }
+// row m, column j, exact cost `score`: accept-possible  <=>  c <= thr[m] and c <= g_ap[j].  Pass 1 during the sweep
+// (returns whether the cell is a candidate at all), pass 2 in the replay with the final bound.
+ATR_DEV bool pf_rowm_pass1(PfScan &S, int m, int j, int score, int k, int gap_j, int gas_j, int min_overlap) {
+    if (score > atr_min(k, gap_j)) return false;
+    pf_pass1(S, m, j, score, k, gas_j, min_overlap);
+    return true;
+}
+ATR_DEV void pf_rowm_pass2(PfScan &S, int m, int j, int score, int k, int gap_j, int min_overlap, int mlb) {
+    if (score <= atr_min(k, gap_j)) pf_take_threat(S, m, j, score, k, gap_j, min_overlap, false, mlb);
 }
 
 // last column: D[i][n] = D[0][n] + the vertical deltas up to row i (the pads below row 1 carry none).  The word index
-// is static (pv / mv live in registers), the row of a bit depends on the lane's p0.
+// is static (pv / mv live in registers), the row of a bit depends on the lane's p0.  second == false: pass 1 alone.
 template <int NW>
-ATR_DEV void pf_collect_lastcol(uint16_t *list, int ls, int &cnt, const uint32_t (&pv)[NW], const uint32_t (&mv)[NW], int m,
-                                int n, bool sq, bool er, const int16_t *thr, int gap_n) {
+ATR_DEV void pf_stream_lastcol(PfScan &S, const uint32_t (&pv)[NW], const uint32_t (&mv)[NW], int m, int n, bool sq, bool er,
+                               const int16_t *thr, int gap_n, int gas_n, int min_overlap, int need, bool second) {
     const int p0 = 32 * NW - m;
+    const int mlb = pf_mlb_eff(S, need);            // (second pass: the final bound)
     int d = sq ? 0 : n;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -283,43 +295,17 @@ ATR_DEV void pf_collect_lastcol(uint16_t *list, int ls, int &cnt, const uint32_t
             d += (int)(pw & 1u) - (int)(mw & 1u);
             pw >>= 1; mw >>= 1;
             if (i >= 1 && (er || i == m) && d <= gap_n && d <= (int)thr[i]) {
-                if (cnt < PF_LIST_CAP) list[(size_t)cnt * ls] = (uint16_t)pf_entry(i, d);
-                ++cnt;
+                if (!second) pf_pass1(S, i, n, d, (int)thr[i], gas_n, min_overlap);
+                else pf_take_threat(S, i, n, d, (int)thr[i], gap_n, min_overlap, true, mlb);
             }
         }
     }
 }
 
-// list[0 .. cnt_row): row-m entries, list[cnt_row .. cnt): last-column entries (cnt <= PF_LIST_CAP).
-// need: the caller only cares about alignments with at least this many matches (>= 1).
-ATR_DEV void pf_analyse(const uint16_t *list, int ls, int cnt_row, int cnt, int nmax, int m, int n, const PairFastParams &fp,
-                        const int16_t *thr, const int16_t *g_ap, const int16_t *g_as, int need, uint32_t pair, PfDecision &D) {
-    const PairParams &p = fp.pp;
-    const int k = (int)thr[m], mo = p.min_overlap;
-    PfScan S;
-    S.mlb = atr_max(need, 1) - 1; S.dbest = 0;
-    S.lo = 0x7fff; S.hi = -0x7fff; S.rl = 0; S.cand_first = 0; S.have = false;
-    // pass 1: the lower bound of the winner's matches (nmax: the wave's largest cnt)
-    for (int e = 0; e < nmax; ++e) {
-        if (e < cnt) {
-            const uint32_t v = list[(size_t)e * ls];
-            const int pos = (int)(v & 511u), c = (int)(v >> 9);
-            const bool lastcol = e >= cnt_row;
-            const int ie = lastcol ? pos : m, je = lastcol ? n : pos;
-            pf_pass1(S, ie, je, c, lastcol ? (int)thr[ie] : k, (int)g_as[je], mo);
-        }
-    }
-    S.mlb = atr_max(S.mlb, atr_max(need, 1));
-    // pass 2: the threats (every entry is accept-possible already)
-    for (int e = 0; e < nmax; ++e) {
-        if (e < cnt) {
-            const uint32_t v = list[(size_t)e * ls];
-            const int pos = (int)(v & 511u), c = (int)(v >> 9);
-            const bool lastcol = e >= cnt_row;
-            const int ie = lastcol ? pos : m, je = lastcol ? n : pos;
-            pf_pass2(S, ie, je, c, lastcol ? (int)thr[ie] : k, (int)g_ap[je], mo, lastcol);
-        }
-    }
+// What the scan found -> the pair's decision.  need: the caller only cares about alignments with at least this many
+// matches (>= 1).
+ATR_DEV void pf_decide(PfScan &S, int m, int n, int need, uint32_t pair, PfDecision &D) {
+    S.mlb = pf_mlb_eff(S, need);
     D.cls = 0;
     if (!S.have) { D.kind = 0; return; }                        // nothing can be accepted (with >= need matches)
     int lo = atr_max(S.lo, -m), hi = atr_min(S.hi, n);

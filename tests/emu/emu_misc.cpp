@@ -184,8 +184,9 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
     const int k = (int)p.thr[m];
     const int n_sweep = sq ? n : std::min(n, m + k);                   // _align.pyx:314-321
     const bool scan_last = n_sweep == n;
-    std::vector<uint16_t> list(PF_LIST_CAP);
-    int cnt = 0;
+    PfScan T;
+    pf_stream_init(T, need);
+    std::vector<int> rowm_cost((size_t)n_sweep + 1, 0);
     PfMyers<NW> S;
     pf_myers_init<NW>(S, m, sr);
     for (int j = 1; j <= n_sweep; ++j) {
@@ -195,15 +196,22 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
         uint32_t eq[NW];
         for (int w = 0; w < NW; ++w) eq[w] = tab[row * NW + w];
         pf_myers_step<NW>(S, eq, sq ? 0u : 1u);
-        pf_collect_rowm(list.data(), 1, cnt, j, S.score, std::min(k, (int)fp.g_ap[j]));
+        rowm_cost[(size_t)j] = S.score;
+        pf_rowm_pass1(T, m, j, S.score, k, (int)fp.g_ap[j], (int)fp.g_as[j], p.min_overlap);
     }
     for (int j = n_sweep + 1; j <= n; ++j) known = known && pf_codes_known(packed_code(qp, j - 1));
-    const int cnt_row = cnt;
+    const bool er = (p.flags & ATR_STOP_WITHIN_SEQ1) != 0;
     if (scan_last)
-        pf_collect_lastcol<NW>(list.data(), 1, cnt, S.pv, S.mv, m, n, sq, (p.flags & ATR_STOP_WITHIN_SEQ1) != 0, p.thr, (int)fp.g_ap[n]);
-    if (!known || cnt > PF_LIST_CAP) { ++emu_pairs_fast_stats[2]; return false; }
+        pf_stream_lastcol<NW>(T, S.pv, S.mv, m, n, sq, er, p.thr, (int)fp.g_ap[n], (int)fp.g_as[n], p.min_overlap, need, false);
+    {
+        const int mlb = pf_mlb_eff(T, need);
+        for (int j = 1; j <= n_sweep; ++j) pf_rowm_pass2(T, m, j, rowm_cost[(size_t)j], k, (int)fp.g_ap[j], p.min_overlap, mlb);
+    }
+    if (scan_last)
+        pf_stream_lastcol<NW>(T, S.pv, S.mv, m, n, sq, er, p.thr, (int)fp.g_ap[n], (int)fp.g_as[n], p.min_overlap, need, true);
+    if (!known) { ++emu_pairs_fast_stats[2]; return false; }
     PfDecision D;
-    pf_analyse(list.data(), 1, cnt_row, cnt, cnt + (emu_pairs_fast_widen ? 5 : 0), m, n, fp, p.thr, fp.g_ap, fp.g_as, need, pair, D);
+    pf_decide(T, m, n, need, pair, D);
     if (emu_pairs_fast_debug && D.kind == 2) fprintf(stderr, "pair %u wide: lo %d hi %d mlb %d rl %d\n", pair, D.task.d_lo, D.task.row_first, D.task.mlb, D.task.row_last);
     if (emu_pairs_fast_debug)
         fprintf(stderr, "pair %u m %d n %d kind %d cls %d d_lo %d rf %d rl %d mlb %d cand_first %d\n", pair, m, n,
