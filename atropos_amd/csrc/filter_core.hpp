@@ -228,7 +228,7 @@ ATR_DEV int last_band_span(uint32_t w) { return window_hi(w) & 63; }
 ATR_DEV int last_band_width(uint32_t w) { return window_hi(w) >> 6; }
 ATR_DEV bool last_band_rowm(uint32_t w) { return ((w >> 29) & 1u) != 0; }
 // Scatter bin, chosen so that the 64 reads of a wave sweep nearly the same cells.
-//   [0, 32)    band reads (band_locate below: row-m candidates on <= 16 diagonals), by window start / 32;
+//   [0, 32)    band reads (band_locate below: row-m candidates on <= 16 diagonals), by band width, then window start;
 //   [32, 96)   last-column band reads (band_locate_last), by row count, most rows first;
 //   [96, 192)  reads that need every row of the column sweep, by window start / 8 -- and, in
 //              ragged batches, the row-limited ones too;
@@ -254,14 +254,21 @@ ATR_DEV int triangle_rows(int rows, int n, int j, int k) { return rows - (n - j)
 ATR_DEV bool ragged_rows_bins(bool start_within_seq1) { return !start_within_seq1; }
 constexpr int TAIL_COLUMNS = 64;                   // columns before the read end a tail-mode wave can sweep
 
-// Band reads (band_kernel): [0, 32) by window start / 32 -- a band read stages its own 16 diagonals, so its wave
-// mates only matter for locality -- and [32, 96) the LAST-COLUMN band reads (band_locate_last) by row count,
+// Band reads (band_kernel): [0, 32) by band width (a wave sweeps the diagonals of its widest read) and window start --
+// a band read stages its own 16 diagonals, so the start only matters for locality -- and [32, 96) the LAST-COLUMN band reads (band_locate_last) by row count,
 // which makes their waves uniform in the number of rows swept.
 constexpr int LAST_BIN0 = 32;
 ATR_DEV int window_bin(uint32_t w, int m, bool by_rows) {
     const int rows = window_rows(w), start = window_lo(w) >> 3;
     // (most rows first: the persistent grid of band_kernel then ends on its cheapest tasks)
-    if (window_band(w)) return window_scan(w) ? LAST_BIN0 + 63 - atr_min(rows, 63) : (start >> 2);
+    if (window_band(w)) {
+        if (window_scan(w)) return LAST_BIN0 + 63 - atr_min(rows, 63);
+        // row-m band reads: by the number of diagonals first -- band_locate sweeps as many as the WIDEST read of its wave
+        // needs (8 .. 16 in steps of two; hi - lo - m is that number minus k + 1), the widest classes first -- then by
+        // window start / 128 for locality
+        const int wide = atr_min(7, atr_max(0, (window_hi(w) - window_lo(w) - m) >> 1));
+        return (7 - wide) * 4 + atr_min(3, start >> 4);
+    }
     if (rows >= m || !by_rows) return 96 + start;
     return ROWS_BIN0 + atr_min(rows, 63);
 }
