@@ -40,6 +40,12 @@ struct CorrectArgs {
     int32_t *changed, *newlen;         // [n][2]
 };
 
+// set bits of `mask` below `lane`
+__device__ __forceinline__ int lane_rank_below(unsigned long long mask, int lane) {
+    (void)lane;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 __device__ __forceinline__ void correct_letter_table(uint8_t *s_letter) {
     if (threadIdx.x < 16) s_letter[threadIdx.x] = (uint8_t)"\0ACMGRSVTWYHKDBN"[threadIdx.x];   // (A 1, C 2, G 4, T 8 and their unions)
 }
@@ -179,40 +185,64 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     const uint32_t npend_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.ptail);
     const bool tied = live && todo && !err && (packed_counts >> 20) > 0u;
     if (npend_all > 0u && npend_all <= pend_cap && has_quals) {
-        unsigned long long tm = __ballot(tied);
-        while (tm) {                                              // wave-uniform; four pairs per round: their loads overlap
-            int src[4];
+        // The tied pairs of the wave, listed (the main queue is worked off: its first 64 entries take the list), and their
+        // quality rows cut into 16-byte pieces: work item = (pair, piece), 32 piece slots per pair (rows of up to 512
+        // bytes), 64 items per round, four rounds' loads in flight at once -- every tied pair's rows in one or two
+        // memory round trips, where a round per four pairs took four.
+        const unsigned long long tm = __ballot(tied);
+        const int ntied = (int)__popcll(tm);
+        if (tied) queue[lane_rank_below(tm, lane)] = (uint16_t)lane;
+        __builtin_amdgcn_wave_barrier();
+        const int nitems = 32 * ntied;
+        const auto piece_sums = [&](int item) -> unsigned long long {
+            if (item >= nitems) return 0ull;
+            const int src = (int)queue[item >> 5], piece = item & 31;
+            const int js = (int)S.jv[src], off = 16 * piece;
+            if (off >= js) return 0ull;
+            const size_t row = (size_t)(tile * 64 + src) * (size_t)A.stride;
+            const int nvalid = js - off;                          // bytes of this piece inside the overlap
+            uint32_t w1[4], w2[4];
+            if (nvalid >= 16 || js >= 16) {
+                // a full piece, or the row's last piece read as the 16 bytes that END at the overlap's end (never a byte
+                // behind it): its leading 16 - nvalid bytes belong to the piece before and are masked away
+                const int at = nvalid >= 16 ? off : js - 16;
+                const atr_u128_unaligned v1 = *(const atr_u128_unaligned *)(A.q1 + row + at);
+                const atr_u128_unaligned v2 = *(const atr_u128_unaligned *)(A.q2 + row + at);
+                w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
+                w2[0] = v2.x; w2[1] = v2.y; w2[2] = v2.z; w2[3] = v2.w;
+                if (nvalid < 16) {
+                    const int lo = 16 - nvalid;                   // first byte that counts
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const uint32_t m = 4 * d + 4 <= lo ? 0u : 4 * d >= lo ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * (lo - 4 * d));
+                        w1[d] &= m; w2[d] &= m;
+                    }
+                }
+            } else {                                              // an overlap of fewer than 16 bases: byte by byte
+                w1[0] = w1[1] = w1[2] = w1[3] = w2[0] = w2[1] = w2[2] = w2[3] = 0u;
+                for (int b = 0; b < nvalid; ++b) {
+                    w1[0] += (uint32_t)A.q1[row + b];             // (w1[0] / w2[0] are the sums themselves here)
+                    w2[0] += (uint32_t)A.q2[row + b];
+                }
+                return (unsigned long long)w1[0] | ((unsigned long long)w2[0] << 32);
+            }
+            uint32_t sum1 = 0u, sum2 = 0u;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                sum1 = __builtin_amdgcn_sad_u8(w1[d], 0u, sum1);
+                sum2 = __builtin_amdgcn_sad_u8(w2[d], 0u, sum2);
+            }
+            return (unsigned long long)sum1 | ((unsigned long long)sum2 << 32);
+        };
+        for (int base = 0; base < nitems; base += 256) {          // wave-uniform
             unsigned long long part[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                src[u] = tm ? (int)__builtin_ctzll(tm) : -1;
-                if (tm) tm &= tm - 1ull;
-                part[u] = 0ull;
-                if (src[u] >= 0) {
-                    const int js = (int)S.jv[src[u]];
-                    const size_t row = (size_t)(tile * 64 + src[u]) * (size_t)A.stride;
-                    uint32_t sum1 = 0u, sum2 = 0u;
-                    for (int off = 4 * lane; off < js; off += 256) {
-                        uint32_t v1, v2;
-                        if (js - off >= 4) {
-                            v1 = *(const atr_u32_unaligned *)(A.q1 + row + off);
-                            v2 = *(const atr_u32_unaligned *)(A.q2 + row + off);
-                        } else {                                  // the overlap's last 1 .. 3 bytes: never a byte behind it
-                            v1 = v2 = 0u;
-                            for (int b = 0; b < js - off; ++b) {
-                                v1 |= (uint32_t)A.q1[row + off + b] << (8 * b);
-                                v2 |= (uint32_t)A.q2[row + off + b] << (8 * b);
-                            }
-                        }
-                        sum1 = __builtin_amdgcn_sad_u8(v1, 0u, sum1);
-                        sum2 = __builtin_amdgcn_sad_u8(v2, 0u, sum2);
-                    }
-                    part[u] = (unsigned long long)sum1 | ((unsigned long long)sum2 << 32);
-                }
-            }
+            for (int u = 0; u < 4; ++u) part[u] = piece_sums(base + 64 * u + lane);
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (src[u] >= 0 && part[u]) atomicAdd(&S.acc[src[u]], part[u]);
+            for (int u = 0; u < 4; ++u) {
+                const int item = base + 64 * u + lane;
+                if (part[u]) atomicAdd(&S.acc[(int)queue[item >> 5]], part[u]);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t dir = 0u;                                        // 1: read 1 is better (read 2 is corrected), 2: read 2 is better
