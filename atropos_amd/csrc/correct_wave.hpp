@@ -16,6 +16,13 @@ struct CompTable { uint8_t c[256]; };
 
 // queue entries a wave may hold: at most 63 left over + 64 x 32 new ones
 constexpr int CORRECT_QUEUE_ENTRIES = 64 * 32 + 64;
+// loads in flight per lane and memory round trip: tasks of the first pass / 16-byte pieces of the tied pairs' rows
+#ifndef CORRECT_TASKS_PER_LANE
+#define CORRECT_TASKS_PER_LANE 4
+#endif
+#ifndef CORRECT_PIECES_PER_LANE
+#define CORRECT_PIECES_PER_LANE 8
+#endif
 
 // the wave's LDS (views; the caller decides what they overlay)
 struct CorrectWaveLds {
@@ -122,7 +129,7 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     const int qall = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
     if (qall <= CORRECT_QUEUE_ENTRIES) {
         // (the common case) every lane lists all its positions at once -- one reservation instead of one per plane word
-        // with three wave barriers each -- and the wave works the list off two tasks per lane and round trip
+        // with three wave barriers each -- and the wave works the list off CORRECT_TASKS_PER_LANE tasks per lane and round trip
 #pragma unroll
         for (int w = 0; w < PW; ++w) {
             uint32_t m = mism[w];
@@ -133,13 +140,16 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
             }
         }
         __builtin_amdgcn_wave_barrier();
-        for (int base = 0; base < qall; base += 128) {
-            const int i0 = base + lane, i1 = base + 64 + lane;
-            const bool v0 = i0 < qall, v1 = i1 < qall;
-            const Task k0 = fetch(v0, v0 ? (uint32_t)queue[i0] : 0u);
-            const Task k1 = fetch(v1, v1 ? (uint32_t)queue[i1] : 0u);
-            apply(k0);
-            apply(k1);
+        for (int base = 0; base < qall; base += 64 * CORRECT_TASKS_PER_LANE) {
+            Task k[CORRECT_TASKS_PER_LANE];
+#pragma unroll
+            for (int u = 0; u < CORRECT_TASKS_PER_LANE; ++u) {
+                const int idx = base + 64 * u + lane;
+                const bool v = idx < qall;
+                k[u] = fetch(v, v ? (uint32_t)queue[idx] : 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < CORRECT_TASKS_PER_LANE; ++u) apply(k[u]);
         }
     } else {
         // more positions than the queue holds (a wave of unrelated reads "matched" at a high error rate): word by word,
@@ -187,7 +197,7 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     if (npend_all > 0u && npend_all <= pend_cap && has_quals) {
         // The tied pairs of the wave, listed (the main queue is worked off: its first 64 entries take the list), and their
         // quality rows cut into 16-byte pieces: work item = (pair, piece), 32 piece slots per pair (rows of up to 512
-        // bytes), 64 items per round, four rounds' loads in flight at once -- every tied pair's rows in one or two
+        // bytes), 64 items per round, CORRECT_PIECES_PER_LANE rounds' loads in flight at once -- every tied pair's rows in one or two
         // memory round trips, where a round per four pairs took four.
         const unsigned long long tm = __ballot(tied);
         const int ntied = (int)__popcll(tm);
@@ -234,12 +244,12 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
             }
             return (unsigned long long)sum1 | ((unsigned long long)sum2 << 32);
         };
-        for (int base = 0; base < nitems; base += 256) {          // wave-uniform
-            unsigned long long part[4];
+        for (int base = 0; base < nitems; base += 64 * CORRECT_PIECES_PER_LANE) {          // wave-uniform
+            unsigned long long part[CORRECT_PIECES_PER_LANE];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) part[u] = piece_sums(base + 64 * u + lane);
+            for (int u = 0; u < CORRECT_PIECES_PER_LANE; ++u) part[u] = piece_sums(base + 64 * u + lane);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < CORRECT_PIECES_PER_LANE; ++u) {
                 const int item = base + 64 * u + lane;
                 if (part[u]) atomicAdd(&S.acc[(int)queue[item >> 5]], part[u]);
             }

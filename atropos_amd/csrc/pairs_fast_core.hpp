@@ -508,9 +508,70 @@ ATR_HOST_DEV int pf_query_stream_dwords(int nrows, int wb) { return (nrows + wb 
 
 ATR_DEV void pf_stage_streams(uint32_t *rs, int rss, int nrd, uint32_t *qs, int qss, int nqd, const uint32_t *rp, int rndw,
                               int m, bool revcomp, const uint32_t *qp, int qndw, int row_first, int d_lo) {
-    for (int t = 0; t < nrd; ++t) rs[(size_t)t * rss] = pf_ref_codes8(rp, rndw, m, revcomp, row_first + 8 * t);
-    // column j holds the base of index j - 1
-    for (int t = 0; t < nqd; ++t) qs[(size_t)t * qss] = pf_codes8(qp, qndw, row_first + d_lo + 8 * t - 1);
+    // Consecutive stream dwords are consecutive eight-code windows of the packed read at ONE bit offset: every raw
+    // dword is loaded once (pf_codes8 per stream dword loads two) and four loads are in flight per step -- the loop
+    // was a chain of nrd + nqd dependent round trips to the L2 in front of every band sweep.
+    {   // column j holds the base of index j - 1: stream dword t = the codes at positions s0 + 8 t ..
+        const int s0 = row_first + d_lo - 1, z0 = s0 >> 3;
+        const uint32_t sh = 4u * (uint32_t)(s0 & 7);
+        uint32_t prev = pf_read_dword(qp, qndw, z0);
+        int t = 0;
+        for (; t + 4 <= nqd; t += 4) {
+            const uint32_t a = pf_read_dword(qp, qndw, z0 + t + 1), b = pf_read_dword(qp, qndw, z0 + t + 2);
+            const uint32_t c = pf_read_dword(qp, qndw, z0 + t + 3), d = pf_read_dword(qp, qndw, z0 + t + 4);
+            qs[(size_t)t * qss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
+            qs[(size_t)(t + 1) * qss] = sh ? ((a >> sh) | (b << (32u - sh))) : a;
+            qs[(size_t)(t + 2) * qss] = sh ? ((b >> sh) | (c << (32u - sh))) : b;
+            qs[(size_t)(t + 3) * qss] = sh ? ((c >> sh) | (d << (32u - sh))) : c;
+            prev = d;
+        }
+        for (; t < nqd; ++t) {
+            const uint32_t a = pf_read_dword(qp, qndw, z0 + t + 1);
+            qs[(size_t)t * qss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
+            prev = a;
+        }
+    }
+    if (!revcomp) {   // reference codes of rows row_first + 8 t ..: positions row_first - 1 + 8 t
+        const int s0 = row_first - 1, z0 = s0 >> 3;
+        const uint32_t sh = 4u * (uint32_t)(s0 & 7);
+        uint32_t prev = pf_read_dword(rp, rndw, z0);
+        int t = 0;
+        for (; t + 4 <= nrd; t += 4) {
+            const uint32_t a = pf_read_dword(rp, rndw, z0 + t + 1), b = pf_read_dword(rp, rndw, z0 + t + 2);
+            const uint32_t c = pf_read_dword(rp, rndw, z0 + t + 3), d = pf_read_dword(rp, rndw, z0 + t + 4);
+            rs[(size_t)t * rss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
+            rs[(size_t)(t + 1) * rss] = sh ? ((a >> sh) | (b << (32u - sh))) : a;
+            rs[(size_t)(t + 2) * rss] = sh ? ((b >> sh) | (c << (32u - sh))) : b;
+            rs[(size_t)(t + 3) * rss] = sh ? ((c >> sh) | (d << (32u - sh))) : c;
+            prev = d;
+        }
+        for (; t < nrd; ++t) {
+            const uint32_t a = pf_read_dword(rp, rndw, z0 + t + 1);
+            rs[(size_t)t * rss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
+            prev = a;
+        }
+    } else {
+        // the reverse complement read backwards: stream dword t = bitrev(codes at m - row_first - 7 - 8 t ..): the raw
+        // dwords go DOWN from z0 + 1
+        const int s0 = m - row_first - 7, z0 = s0 >> 3;
+        const uint32_t sh = 4u * (uint32_t)(s0 & 7);
+        uint32_t hi = pf_read_dword(rp, rndw, z0 + 1);
+        int t = 0;
+        for (; t + 4 <= nrd; t += 4) {
+            const uint32_t a = pf_read_dword(rp, rndw, z0 - t), b = pf_read_dword(rp, rndw, z0 - t - 1);
+            const uint32_t c = pf_read_dword(rp, rndw, z0 - t - 2), d = pf_read_dword(rp, rndw, z0 - t - 3);
+            rs[(size_t)t * rss] = pf_bitrev32(sh ? ((a >> sh) | (hi << (32u - sh))) : a);
+            rs[(size_t)(t + 1) * rss] = pf_bitrev32(sh ? ((b >> sh) | (a << (32u - sh))) : b);
+            rs[(size_t)(t + 2) * rss] = pf_bitrev32(sh ? ((c >> sh) | (b << (32u - sh))) : c);
+            rs[(size_t)(t + 3) * rss] = pf_bitrev32(sh ? ((d >> sh) | (c << (32u - sh))) : d);
+            hi = d;
+        }
+        for (; t < nrd; ++t) {
+            const uint32_t a = pf_read_dword(rp, rndw, z0 - t);
+            rs[(size_t)t * rss] = pf_bitrev32(sh ? ((a >> sh) | (hi << (32u - sh))) : a);
+            hi = a;
+        }
+    }
 }
 
 // Host side: does the fast pipeline apply, and its tables.
