@@ -676,6 +676,22 @@ class CompressedSink(object):
             self.fh.close()
 
 
+def open_by_extension(path):
+    """A binary file object for writing; ``.gz`` / ``.bz2`` / ``.xz`` compress (the reference's xopen does so for EVERY
+    output, the side files -- too-short, untrimmed, info, rest, wildcard -- included)."""
+    name = str(path)
+    if name.endswith(".gz"):
+        import gzip
+        return gzip.open(name, "wb", compresslevel=6)
+    if name.endswith(".bz2"):
+        import bz2
+        return bz2.open(name, "wb")
+    if name.endswith(".xz"):
+        import lzma
+        return lzma.open(name, "wb")
+    return open(name, "wb")
+
+
 def make_sink(path, parts, capacity, backend=None, clock=None, keep=False):
     """One file, or ``parts`` > 1 part files (PartSink); a compressed file by its extension (CompressedSink)."""
     if str(path).endswith((".gz", ".bz2", ".xz")):

@@ -26,7 +26,7 @@ import torch
 
 from . import _lib
 from .adapters import LinkedAdapter
-from .fastq import FastqBatch, RecordSource
+from .fastq import FastqBatch, RecordSource, open_by_extension
 
 DEST_MERGED = 6              # MergedReadFilter (filters.py:109-113): installed first, so a merged pair goes nowhere else
 DEST_NAMES = {_lib.DEST_KEEP: "keep", _lib.DEST_TOO_SHORT: "too_short", _lib.DEST_TOO_LONG: "too_long",
@@ -479,9 +479,9 @@ class TrimPipeline(object):
         clock = StageClock()
         reader = ChunkedFastqReader(path_in, chunk_bytes, be, clock)
         sink = make_sink(path_out, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output)
-        aux_files = {kind: open(path, "wb") for kind, path in (self.aux or {}).items()}
+        aux_files = {kind: open_by_extension(path) for kind, path in (self.aux or {}).items()}
         dest_codes = {name: code for code, name in DEST_NAMES.items()}
-        dest_files = {dest_codes[kind]: open(path, "wb") for kind, path in self.outputs.items()}
+        dest_files = {dest_codes[kind]: open_by_extension(path) for kind, path in self.outputs.items()}
         try:
             while True:
                 batch = reader.next_batch()
@@ -851,9 +851,9 @@ class PairedTrimPipeline(object):
         clock = StageClock()
         readers = [ChunkedFastqReader(p, chunk_bytes, be, clock) for p in (in1, in2)]
         sinks = [make_sink(p, output_parts, chunk_bytes + (64 << 20) + 32, be, clock, keep=keep_output) for p in (out1, out2)]
-        aux_files = {kind: open(path, "wb") for kind, path in (self.aux or {}).items()}
+        aux_files = {kind: open_by_extension(path) for kind, path in (self.aux or {}).items()}
         dest_codes = {name: code for code, name in DEST_NAMES.items()}
-        dest_files = {dest_codes[kind]: [open(p, "wb") for p in paths] for kind, paths in self.outputs.items()}
+        dest_files = {dest_codes[kind]: [open_by_extension(p) for p in paths] for kind, paths in self.outputs.items()}
         if self.merge_overlapping:
             totals["merged"] = 0
             if merged_out is not None:
