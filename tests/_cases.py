@@ -192,7 +192,8 @@ def piece_reads(rng, ref, n, count, e):
     return reads
 
 
-def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=200, lengths=(70, 100, 128, 150, 160, 180, 250, 300)):
+def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=200,
+                         lengths=(70, 100, 128, 150, 160, 180, 200, 224, 250, 260, 288, 300)):     # (3 .. 10 plane words)
     """The two-pass pre-pass on plane64 batches (atr_locate_planes_batch) against the other kernel families and the
     oracle, on aligners inside its envelope (and a few outside: pack(layout="plane64") must refuse those)."""
     import numpy as np
@@ -933,7 +934,7 @@ def check_fused_match_correct(n=4096, seed=9):
     from atropos_amd.modifiers import COMP_TABLE
     be = _lib.get_backend()
     rng = random.Random(seed)
-    w = synth.workload("C5", 77777, n, device=str(be.device))
+    w = synth.workload("C5", 77777 + 50021 * seed, n, device=str(be.device))
     ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2, read_wildcards=True)
     table = be.translate_table(_lib.TABLE_DNA15)
     done = 0

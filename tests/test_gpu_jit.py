@@ -64,7 +64,7 @@ def test_specialised_kernel_random_aligners(hip_backend, oracle, jit_on):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner
     total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 77, 14, 400,
-                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 250, 300))
+                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 200, 224, 250, 260, 288, 300))
     assert total > 2500
     assert len(os.listdir(jit_on)) >= 6
 

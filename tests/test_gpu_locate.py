@@ -52,7 +52,7 @@ def test_piece_pipeline(hip_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner
     total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 23, 150, 300,
-                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 250, 300))
+                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 200, 224, 250, 260, 288, 300))
     assert total > 20000 and refused < 80
 
 

@@ -5,7 +5,7 @@ pre-pass, equal-length batches with partial overlaps), the full sweep over all 1
 kernel (every batch goes through all three families and the automatic choice), the pair aligner (sides of up to 320
 bases: full sweep, cost / threat / band pipeline with and without `need`, wavefront per pair), the insert aligner
 (reads of up to 320 bases, probed sweep), MultiAligner (a wavefront per pair), the fused linked-adapter
-pipeline, the plane-guided error correction, ragged batches at wave-filling size (tail-mode window sweep), the
+pipeline, the plane-guided error correction and the fused match + correction call against the two calls, ragged batches at wave-filling size (tail-mode window sweep), the
 two-pass pre-pass on bit planes (equal-length and ragged batches against full sweep, one-pass pipeline and oracle) and
 reads of 737 .. 4 000 bases (rolling origin base), pairs / references beyond 320 bases (64-bit cells).
 usage: tools/gpu_fuzz.py [first_seed] [seeds]   (the log of the round's last run is kept under profiles/)"""
@@ -36,6 +36,7 @@ for seed in range(first, first + (int(sys.argv[2]) if len(sys.argv) > 2 else 4))
     tot += _cases.check_multi_against_oracle(MultiAligner, oracle, seed + 550, 40)
     tot += _cases.check_linked_sets_against_oracle(oracle, seed + 600, 150, reads_per_round=(1, 64, 65, 200, 700))[0]
     tot += _cases.check_plane_guided_correction(n=20_000, seed=seed + 700)
+    tot += _cases.check_fused_match_correct(n=8_192, seed=seed + 720)
     tot += _cases.check_ragged_tail_mode(Aligner, oracle, seed + 800, nreads=40_000, oracle_slice=600)
     tot += _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, seed + 900, 120, 300)[0]
     tot += _cases.check_long_reads(Aligner, oracle, _lib.AtroposHipError, seed + 950, 40)
