@@ -17,7 +17,6 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out);
 int piece_ragged_len(int max_len);
 int prepare_locate_planes(const atr_aligner *a, int max_len, bool ragged);
-size_t planes_work_bytes(long long nreads);        // >= fast_work_bytes(nreads): room for the parts of a long plane64 batch
 int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
                          void *work, hipStream_t st);
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
@@ -243,7 +242,7 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
     return a->table_kind;
 }
 
-size_t atr_locate_work_bytes(int64_t nreads) { return nreads < 0 ? 0 : planes_work_bytes(nreads); }
+size_t atr_locate_work_bytes(int64_t nreads) { return nreads < 0 ? 0 : fast_work_bytes(nreads); }
 
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
                      int max_len, atr_result *d_out, void *d_work, void *stream) {

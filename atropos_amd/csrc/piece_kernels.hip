@@ -14,8 +14,6 @@
 #include "locate_fast.hpp"
 #include "piece_filter.hpp"
 #include "jit.hpp"
-#include "side_stream.hpp"
-#include <cstdlib>
 
 namespace atr {
 
@@ -119,9 +117,12 @@ int prepare_locate_planes(const atr_aligner *a, int max_len, bool ragged) {
     return piece_spec_for(a, fp, pp, ragged, max_len, 0, true) != nullptr ? 1 : 0;
 }
 
-// One pre-pass -> scan -> scatter -> DP chain over a batch.  lens == nullptr: every read has max_len bases
-static int launch_locate_planes_one(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
-                                    const int32_t *lens, long long nreads, int max_len, uint4 *out, void *work, hipStream_t st) {
+// lens == nullptr: every read has max_len bases
+int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
+                         void *work, hipStream_t st) {
+    FilterParams fp;
+    PieceParams pp;
+    if (!piece_applies(a, lens ? piece_ragged_len(max_len) : max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
     FastWork wk = fast_carve(work, nreads);
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const int nw = (max_len + 31) / 32;
@@ -146,63 +147,6 @@ static int launch_locate_planes_one(const atr_aligner *a, const FilterParams &fp
     launch_fast_scan(wk, st);
     hipLaunchKernelGGL(piece_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m, wk);
     return launch_fast_dp(a, planes, lens, nreads, nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true);
-}
-
-// A long batch goes through as PARTS, each a chain of its own over a tile-aligned range of the reads, the chains in
-// turn on the caller's stream and on a side stream: the exact DP of one part -- latency-bound gathers on a twelfth of
-// the reads -- runs under the pre-pass of the next instead of behind the whole batch's, and only the last part's DP is
-// exposed.  Same records (the parts are independent reads), complete when the call's stream work is.  The workspace
-// of atr_locate_work_bytes() holds every part's.  $ATR_PLANES_PARTS: 1 = one chain (rounds 4-5), default 2.
-constexpr long long PLANES_PART_MIN_READS = 1ll << 21;           // a part is at least 2 M reads (the persistent grid's fixed costs)
-int planes_parts(long long nreads) {
-    static const int want = [] { const char *e = getenv("ATR_PLANES_PARTS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : v > 8 ? 8 : v; }();
-    return (int)std::max<long long>(1, std::min<long long>(want, nreads / PLANES_PART_MIN_READS));
-}
-static void part_range(long long nreads, int parts, int k, long long &r0, long long &r1) {
-    const long long ntiles = (nreads + 63) / 64;
-    r0 = std::min(nreads, (ntiles * k / parts) * 64);
-    r1 = k + 1 == parts ? nreads : std::min(nreads, (ntiles * (k + 1) / parts) * 64);
-}
-size_t planes_work_bytes(long long nreads) {
-    size_t best = fast_work_bytes(nreads);
-    for (int parts = 2; parts <= 8; ++parts) {                   // (whatever $ATR_PLANES_PARTS says at call time)
-        if (nreads / PLANES_PART_MIN_READS < parts) break;
-        size_t sum = 0;
-        for (int k = 0; k < parts; ++k) {
-            long long r0, r1;
-            part_range(nreads, parts, k, r0, r1);
-            sum += (fast_work_bytes(r1 - r0) + 255) & ~(size_t)255;
-        }
-        best = std::max(best, sum);
-    }
-    return best;
-}
-
-int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
-                         void *work, hipStream_t st) {
-    FilterParams fp;
-    PieceParams pp;
-    if (!piece_applies(a, lens ? piece_ragged_len(max_len) : max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
-    static thread_local SideStream other;
-    const int parts = planes_parts(nreads);
-    if (parts <= 1 || !other.ready()) return launch_locate_planes_one(a, fp, pp, planes, lens, nreads, max_len, out, work, st);
-    const int nchunks = (max_len + 31) / 32;
-    hipError_t e = hipEventRecord(other.fork, st);               // the side stream starts behind what precedes the call
-    if (e == hipSuccess) e = hipStreamWaitEvent(other.stream, other.fork, 0);
-    if (e != hipSuccess) return (int)e;
-    char *w = (char *)work;
-    int rc = 0;
-    for (int k = 0; k < parts && rc == 0; ++k) {
-        long long r0, r1;
-        part_range(nreads, parts, k, r0, r1);
-        if (r1 > r0)
-            rc = launch_locate_planes_one(a, fp, pp, planes + (size_t)(r0 / 64) * nchunks * 64, lens ? lens + r0 : nullptr, r1 - r0, max_len,
-                                          out + r0, w, (k & 1) ? other.stream : st);
-        w += (fast_work_bytes(r1 - r0) + 255) & ~(size_t)255;
-    }
-    e = hipEventRecord(other.join, other.stream);                // (joined also after an error)
-    if (e == hipSuccess) e = hipStreamWaitEvent(st, other.join, 0);
-    return rc != 0 ? rc : (int)e;
 }
 
 }  // namespace atr
