@@ -11,8 +11,8 @@
 //   P4  pairs_band_kernel<WB> the banded packed-word DP (payload of the threats), one launch per band class.
 //   P5  the full sweep (pairs_core.hpp) over the pairs of the last bin, gathered by index.
 //
-// VALU-bound like every DP here (no MFMA: a min-plus recurrence).  LDS: P1 5 x NW match-mask words per lane; P4 the
-// lane's reference / query streams.
+// VALU-bound like every DP here (no MFMA: a min-plus recurrence).  LDS: P1 (5 + 2) x NW words per lane; P4 none
+// (the lane's reference / query streams are read from the batch as the sweep goes).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 
@@ -211,19 +211,15 @@ __global__ __launch_bounds__(256) void pairs_scatter_kernel(long long npairs, in
 }
 
 // ---- P4 ------------------------------------------------------------------------------------------------
-// Two waves per block; a wave's LDS: ref stream (nrd dwords) + query stream (nqd dwords) per lane.
+// Two waves per block; the lane's reference / query streams come straight from the batch (PfRefStream / PfQueryStream).
 template <int WB>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WB <= 32 ? 5 : WB <= 64 ? 4 : WB <= 96 ? 3 : 2)))
-void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFastWork wk,
-                                                         int cls, int nrd_max, int nqd_max) {
+void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFastWork wk, int cls) {
     __shared__ int16_t s_thr[PAIRS_MAX_LEN + 3], s_gap[PAIRS_MAX_LEN + 2];
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 3; i += 128) s_thr[i] = fp.pp.thr[i];
     for (int i = threadIdx.x; i < PAIRS_MAX_LEN + 2; i += 128) s_gap[i] = fp.g_ap[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    uint32_t *rs = s_dyn + (size_t)wave * (nrd_max + nqd_max) * 64 + lane;
-    uint32_t *qs = rs + (size_t)nrd_max * 64;
     const long long first = (long long)wk.fw.binbase[cls * PF_ROW_BINS], total = (long long)wk.fw.binbase[(cls + 1) * PF_ROW_BINS];
     const long long nwaves = (total - first + 63) >> 6;
     const bool sq = (fp.pp.flags & ATR_START_WITHIN_SEQ2) != 0;
@@ -246,10 +242,12 @@ void pairs_band_kernel(const PairFastParams fp, const PairsFastArgs a, PairsFast
         const int nrows = wave_max_i32(live ? L.row_last - L.row_first + 1 : 0);
         const uint32_t *rp = a.ref_packed + ((size_t)(r >> 6) * a.ref_chunks * 64 + (r & 63)) * 4;
         const uint32_t *qp = a.qry_packed + ((size_t)(r >> 6) * a.qry_chunks * 64 + (r & 63)) * 4;
-        const int nrd = min(nrd_max, pf_ref_stream_dwords(nrows)), nqd = min(nqd_max, pf_query_stream_dwords(nrows, WB));
-        pf_stage_streams(rs, 64, nrd, qs, 64, nqd, rp, rndw, L.m, a.revcomp != 0, qp, qndw, L.row_first, L.d_lo);
+        PfRefStream rs;
+        PfQueryStream qs;
+        rs.init(rp, live ? rndw : 0, L.m, a.revcomp != 0, L.row_first);
+        qs.init(qp, live ? qndw : 0, L.row_first + L.d_lo - 1);
         uint32_t rec[4];
-        pf_band_sweep<WB>(L, nrows, rs, 64, qs, 64, fp.pp, s_thr, s_gap, rec);
+        pf_band_sweep<WB>(L, nrows, rs, qs, fp.pp, s_thr, s_gap, rec);
         if (live) a.out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     }
 }
@@ -282,13 +280,8 @@ hipError_t launch_pairs_full_indexed(const PairParams &p, const uint32_t *rp, co
 template <int WB>
 static hipError_t launch_band(const PairFastParams &fp, const PairsFastArgs &a, const PairsFastWork &wk, int cls,
                               hipStream_t st) {
-    const int rows_max = std::max(a.ref_max_len, 1);
-    const int nrd = pf_ref_stream_dwords(rows_max), nqd = pf_query_stream_dwords(rows_max, WB);
-    const size_t lds = (size_t)2 * (nrd + nqd) * 64 * 4;
-    hipError_t e = hipFuncSetAttribute((const void *)pairs_band_kernel<WB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)std::min<long long>((a.npairs + 127) / 128, 2048);
-    hipLaunchKernelGGL((pairs_band_kernel<WB>), dim3(blocks), dim3(128), lds, st, fp, a, wk, cls, nrd, nqd);
+    hipLaunchKernelGGL((pairs_band_kernel<WB>), dim3(blocks), dim3(128), 0, st, fp, a, wk, cls);
     return hipGetLastError();
 }
 

@@ -384,14 +384,61 @@ struct PfBandLane {
 
 // The row-major sweep of one lane over its rows row_first .. row_last (`nrows` = the wave's trip count; a lane
 // that has done its own rows keeps its last row).  rs / qs: the lane's reference codes and query bases as
-// streams of eight 4-bit codes per dword: nibble t of rs = the code of row row_first + t, nibble s of qs = the
-// base of column row_first + d_lo + s, 0 outside the read.
+// streams of eight 4-bit codes per dword (PfRefStream / PfQueryStream): nibble t of rs = the code of row row_first + t,
+// nibble s of qs = the base of column row_first + d_lo + s, 0 outside the read.
 // Column 0 without special cases: code 0 (the columns j <= 0 and those behind the read) matches every row, and
 // the band starts from VIRTUAL cells left of the matrix -- with START_WITHIN_SEQ1 cost 0 and origin j - i (the
 // diagonal through them reaches column 0 in the cell (i - j, 0) = cost 0, origin -(i - j): _align.pyx:343-346,
 // :349-352), else unreachable, so that column 0 holds the i insertions from (0, 0) (:336-342, :347-348).
+// The two streams of a lane as READERS over the packed reads (tile64: pf_read_dword): consecutive stream dwords are
+// consecutive eight-code windows of the read at ONE bit offset, so every raw dword is loaded once and funnel-shifted
+// against its neighbour.  Round 5: the band pass reads its streams straight from the batch (the L2), one dword of each
+// every eight rows and one step ahead of its use, instead of staging whole streams in LDS first -- 21 KB per wave for
+// 2 x 250-base pairs, which held the wide band kernels at 1.5 waves per SIMD.
+struct PfQueryStream {                              // dword t = the codes at positions s0 + 8 t .. (0 outside the read)
+    const uint32_t *p;
+    int ndw, z;
+    uint32_t sh, prev;
+    ATR_DEV_MEMBER void init(const uint32_t *q, int ndw_, int s0) {
+        p = q; ndw = ndw_; z = s0 >> 3; sh = 4u * (uint32_t)(s0 & 7);
+        prev = pf_read_dword(p, ndw, z);
+    }
+    ATR_DEV_MEMBER uint32_t next() {
+        const uint32_t a = pf_read_dword(p, ndw, ++z);
+        const uint32_t out = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
+        prev = a;
+        return out;
+    }
+};
+struct PfRefStream {                                // dword t = the reference codes of rows row_first + 8 t ..
+    const uint32_t *p;
+    int ndw, z;
+    uint32_t sh, carry;
+    bool revcomp;
+    ATR_DEV_MEMBER void init(const uint32_t *r, int ndw_, int m, bool rc, int row_first) {
+        p = r; ndw = ndw_; revcomp = rc;
+        // forward: positions row_first - 1 + 8 t; reverse complement: bitrev(codes at m - row_first - 7 - 8 t ..), the raw
+        // dwords going DOWN (pf_ref_codes8)
+        const int s0 = rc ? m - row_first - 7 : row_first - 1;
+        z = s0 >> 3; sh = 4u * (uint32_t)(s0 & 7);
+        carry = pf_read_dword(p, ndw, rc ? z + 1 : z);
+    }
+    ATR_DEV_MEMBER uint32_t next() {
+        if (!revcomp) {
+            const uint32_t a = pf_read_dword(p, ndw, ++z);
+            const uint32_t out = sh ? ((carry >> sh) | (a << (32u - sh))) : carry;
+            carry = a;
+            return out;
+        }
+        const uint32_t a = pf_read_dword(p, ndw, z--);
+        const uint32_t out = pf_bitrev32(sh ? ((a >> sh) | (carry << (32u - sh))) : a);
+        carry = a;
+        return out;
+    }
+};
+
 template <int WB>
-ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, const uint32_t *rs, int rss, const uint32_t *qs, int qss,
+ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, PfRefStream &rs, PfQueryStream &qs,
                            const PairParams &p, const int16_t *thr, const int16_t *g_ap, uint32_t rec[4]) {
     constexpr int NQ = WB / 8;
     const bool sr = (p.flags & ATR_START_WITHIN_SEQ1) != 0, sq = (p.flags & ATR_START_WITHIN_SEQ2) != 0;
@@ -426,8 +473,9 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, const uint32_t *rs, i
     const int own_rows = L.live ? L.row_last - L.row_first + 1 : 0;
     uint32_t qw[NQ + 1];
 #pragma unroll
-    for (int t = 0; t <= NQ; ++t) qw[t] = qs[(size_t)t * qss];
-    uint32_t rw = rs[0];
+    for (int t = 0; t <= NQ; ++t) qw[t] = qs.next();
+    uint32_t rw = rs.next();
+    uint32_t qnext = qs.next(), rnext = rs.next();          // the dwords of the next eight rows: requested a step ahead
 #pragma unroll 1
     for (int t = 0; t < nrows; ++t) {
         if (t < own_rows) {
@@ -467,8 +515,10 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, const uint32_t *rs, i
         qw[NQ] >>= 4;
         rw >>= 4;
         if ((t & 7) == 7) {
-            qw[NQ] = qs[(size_t)(NQ + 1 + (t >> 3)) * qss];
-            rw = rs[(size_t)(1 + (t >> 3)) * rss];
+            qw[NQ] = qnext;
+            rw = rnext;
+            qnext = qs.next();
+            rnext = rs.next();
         }
     }
     // row m (the last row of the lanes that have row-m threats): its cells in column order (:433-455)
@@ -494,84 +544,6 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, const uint32_t *rs, i
     rec[1] = (uint32_t)(querystart & 0xFFFF) | ((uint32_t)(querystop & 0xFFFF) << 16);
     rec[2] = (uint32_t)(matches & 0xFFFF) | ((uint32_t)(errors & 0xFFFF) << 16);
     rec[3] = 0;
-}
-
-// streams of the banded pass (dwords per lane): reference codes of rows row_first .. row_first + 8 nd - 1,
-// query bases of columns row_first + d_lo .. (8 per dword)
-#ifdef ATR_HOST_EMU
-#define ATR_HOST_DEV static inline
-#else
-#define ATR_HOST_DEV __host__ __device__ __forceinline__
-#endif
-ATR_HOST_DEV int pf_ref_stream_dwords(int nrows) { return (nrows + 7) / 8 + 1; }
-ATR_HOST_DEV int pf_query_stream_dwords(int nrows, int wb) { return (nrows + wb + 7) / 8 + 2; }
-
-ATR_DEV void pf_stage_streams(uint32_t *rs, int rss, int nrd, uint32_t *qs, int qss, int nqd, const uint32_t *rp, int rndw,
-                              int m, bool revcomp, const uint32_t *qp, int qndw, int row_first, int d_lo) {
-    // Consecutive stream dwords are consecutive eight-code windows of the packed read at ONE bit offset: every raw
-    // dword is loaded once (pf_codes8 per stream dword loads two) and four loads are in flight per step -- the loop
-    // was a chain of nrd + nqd dependent round trips to the L2 in front of every band sweep.
-    {   // column j holds the base of index j - 1: stream dword t = the codes at positions s0 + 8 t ..
-        const int s0 = row_first + d_lo - 1, z0 = s0 >> 3;
-        const uint32_t sh = 4u * (uint32_t)(s0 & 7);
-        uint32_t prev = pf_read_dword(qp, qndw, z0);
-        int t = 0;
-        for (; t + 4 <= nqd; t += 4) {
-            const uint32_t a = pf_read_dword(qp, qndw, z0 + t + 1), b = pf_read_dword(qp, qndw, z0 + t + 2);
-            const uint32_t c = pf_read_dword(qp, qndw, z0 + t + 3), d = pf_read_dword(qp, qndw, z0 + t + 4);
-            qs[(size_t)t * qss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
-            qs[(size_t)(t + 1) * qss] = sh ? ((a >> sh) | (b << (32u - sh))) : a;
-            qs[(size_t)(t + 2) * qss] = sh ? ((b >> sh) | (c << (32u - sh))) : b;
-            qs[(size_t)(t + 3) * qss] = sh ? ((c >> sh) | (d << (32u - sh))) : c;
-            prev = d;
-        }
-        for (; t < nqd; ++t) {
-            const uint32_t a = pf_read_dword(qp, qndw, z0 + t + 1);
-            qs[(size_t)t * qss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
-            prev = a;
-        }
-    }
-    if (!revcomp) {   // reference codes of rows row_first + 8 t ..: positions row_first - 1 + 8 t
-        const int s0 = row_first - 1, z0 = s0 >> 3;
-        const uint32_t sh = 4u * (uint32_t)(s0 & 7);
-        uint32_t prev = pf_read_dword(rp, rndw, z0);
-        int t = 0;
-        for (; t + 4 <= nrd; t += 4) {
-            const uint32_t a = pf_read_dword(rp, rndw, z0 + t + 1), b = pf_read_dword(rp, rndw, z0 + t + 2);
-            const uint32_t c = pf_read_dword(rp, rndw, z0 + t + 3), d = pf_read_dword(rp, rndw, z0 + t + 4);
-            rs[(size_t)t * rss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
-            rs[(size_t)(t + 1) * rss] = sh ? ((a >> sh) | (b << (32u - sh))) : a;
-            rs[(size_t)(t + 2) * rss] = sh ? ((b >> sh) | (c << (32u - sh))) : b;
-            rs[(size_t)(t + 3) * rss] = sh ? ((c >> sh) | (d << (32u - sh))) : c;
-            prev = d;
-        }
-        for (; t < nrd; ++t) {
-            const uint32_t a = pf_read_dword(rp, rndw, z0 + t + 1);
-            rs[(size_t)t * rss] = sh ? ((prev >> sh) | (a << (32u - sh))) : prev;
-            prev = a;
-        }
-    } else {
-        // the reverse complement read backwards: stream dword t = bitrev(codes at m - row_first - 7 - 8 t ..): the raw
-        // dwords go DOWN from z0 + 1
-        const int s0 = m - row_first - 7, z0 = s0 >> 3;
-        const uint32_t sh = 4u * (uint32_t)(s0 & 7);
-        uint32_t hi = pf_read_dword(rp, rndw, z0 + 1);
-        int t = 0;
-        for (; t + 4 <= nrd; t += 4) {
-            const uint32_t a = pf_read_dword(rp, rndw, z0 - t), b = pf_read_dword(rp, rndw, z0 - t - 1);
-            const uint32_t c = pf_read_dword(rp, rndw, z0 - t - 2), d = pf_read_dword(rp, rndw, z0 - t - 3);
-            rs[(size_t)t * rss] = pf_bitrev32(sh ? ((a >> sh) | (hi << (32u - sh))) : a);
-            rs[(size_t)(t + 1) * rss] = pf_bitrev32(sh ? ((b >> sh) | (a << (32u - sh))) : b);
-            rs[(size_t)(t + 2) * rss] = pf_bitrev32(sh ? ((c >> sh) | (b << (32u - sh))) : c);
-            rs[(size_t)(t + 3) * rss] = pf_bitrev32(sh ? ((d >> sh) | (c << (32u - sh))) : d);
-            hi = d;
-        }
-        for (; t < nrd; ++t) {
-            const uint32_t a = pf_read_dword(rp, rndw, z0 - t);
-            rs[(size_t)t * rss] = pf_bitrev32(sh ? ((a >> sh) | (hi << (32u - sh))) : a);
-            hi = a;
-        }
-    }
 }
 
 // Host side: does the fast pipeline apply, and its tables.

@@ -231,18 +231,19 @@ static bool emu_pair_fast_one(const atr::PairFastParams &fp, const uint32_t *rp,
     const int wb = pf_class_width(cls);
     int nrows = std::max(0, (int)L.row_last - (int)L.row_first + 1);
     if (emu_pairs_fast_widen) nrows += 9;
-    const int nrd = pf_ref_stream_dwords(nrows), nqd = pf_query_stream_dwords(nrows, wb);
-    std::vector<uint32_t> rs((size_t)nrd + 1), qs((size_t)nqd + 1);
-    pf_stage_streams(rs.data(), 1, nrd, qs.data(), 1, nqd, rp, rndw, m, revcomp, qp, qndw, L.row_first, L.d_lo);
+    PfRefStream rs;
+    PfQueryStream qs;
+    rs.init(rp, rndw, m, revcomp, L.row_first);
+    qs.init(qp, qndw, L.row_first + L.d_lo - 1);
     switch (cls) {
-        case 0: pf_band_sweep<16>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 1: pf_band_sweep<32>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 2: pf_band_sweep<48>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 3: pf_band_sweep<64>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 4: pf_band_sweep<80>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 5: pf_band_sweep<96>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        case 6: pf_band_sweep<112>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
-        default: pf_band_sweep<128>(L, nrows, rs.data(), 1, qs.data(), 1, p, p.thr, fp.g_ap, rec); break;
+        case 0: pf_band_sweep<16>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        case 1: pf_band_sweep<32>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        case 2: pf_band_sweep<48>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        case 3: pf_band_sweep<64>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        case 4: pf_band_sweep<80>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        case 5: pf_band_sweep<96>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        case 6: pf_band_sweep<112>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
+        default: pf_band_sweep<128>(L, nrows, rs, qs, p, p.thr, fp.g_ap, rec); break;
     }
     ++emu_pairs_fast_stats[1];
     return true;
