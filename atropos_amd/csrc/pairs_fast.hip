@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
                     known = known && pf_codes_known(w);
                     // table rows of the bases of columns j + 2 .. j + 9 (the prefetch runs one column ahead)
                     uint32_t rows = (pf_code_rows8(w) >> 4) | (pf_code_rows8(wn) << 28);
-#pragma unroll 1
+#pragma unroll                                                    // (eight columns: 1.49 -> 1.41 ms per 2 M pairs 2 x 150)
                     for (int b = 0; b < 8; ++b) {
                         ++j;
                         if (j > jhi) break;                           // wave-uniform

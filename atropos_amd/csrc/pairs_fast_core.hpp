@@ -102,9 +102,15 @@ ATR_DEV void pf_myers_step(PfMyers<NW> &S, const uint32_t (&eq)[NW], uint32_t hi
         const uint32_t e = eq[w], pv = S.pv[w], mv = S.mv[w];
         xv[w] = e | mv;
         const uint32_t t = e & pv;
+#ifdef ATR_HOST_EMU
         const uint64_t sum = (uint64_t)t + (uint64_t)pv + (uint64_t)carry;       // the add runs through all words
         const uint32_t s = (uint32_t)sum;
         carry = (uint32_t)(sum >> 32);
+#else
+        unsigned cout;
+        const uint32_t s = __builtin_addc(t, pv, carry, &cout);                  // v_addc_co_u32 (the 64-bit form compiled to v_lshl_add_u64)
+        carry = cout;
+#endif
         const uint32_t xh = (s ^ pv) | e;
         ph[w] = mv | ~(xh | pv);
         mh[w] = pv & xh;
