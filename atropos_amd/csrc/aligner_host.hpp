@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstring>
 #include <new>
+#include <atomic>
 #include <string>
 
 #include "atropos_hip.h"
@@ -24,6 +25,8 @@ struct atr_aligner {
     uint8_t codes[ATR_MAX_REF_LEN];   // 4-bit reference codes, row order
     std::string ref;                  // raw reference bytes
     mutable long long planes_seen = 0;   // reads this handle has put through the two-pass pre-pass (jit.hpp's policy)
+    unsigned long long uid = 0;          // changes whenever the derived parameters do (aligner_refresh): the key of per-call
+                                         // caches of what is computed from them (aligner_filter_params)
 };
 
 namespace atr {
@@ -53,7 +56,13 @@ inline const Tables &tables() {
 inline int round_up_rows(int m) { return (m + ROW_GRAN - 1) / ROW_GRAN * ROW_GRAN; }
 
 // Derive everything that depends on (m, e, flags, indel_cost, min_overlap).
+inline unsigned long long aligner_next_uid() {
+    static std::atomic<unsigned long long> next{1};
+    return next.fetch_add(1);
+}
+
 inline int aligner_refresh(atr_aligner *a) {
+    a->uid = aligner_next_uid();
     LocateParams &p = a->p;
     const int m = p.m;
     const double e = a->max_error_rate;

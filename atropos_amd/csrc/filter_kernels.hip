@@ -124,7 +124,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     FastWork wk = fast_carve(work, nreads);
     wk.nused = fast_blocks_for((nreads + 63) / 64);
     wk.lpw = nreads <= 8192 ? 0 : 64;
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    const FilterParams &fp = aligner_filter_params(a);
     const bool wide = fp.rows > 32, ragged = lens != nullptr;
     const dim3 grid(wk.nused), block(256);
     if (wide) {

@@ -29,6 +29,23 @@
 #include "fast_work.hpp"
 
 namespace atr {
+// filter_params() of a handle, computed once per state of the handle and host thread (a four-entry cache keyed by
+// atr_aligner::uid): the certificates in it are small dynamic programmes over the adapter (filter_core.hpp) -- 0.15 ms
+// of host time that every call of a 1 000-read batch paid again (round 5: 39 -> 176 us per call until this cache).
+inline const FilterParams &aligner_filter_params(const atr_aligner *a) {
+    struct Slot { unsigned long long uid = 0; FilterParams fp; };
+    static thread_local Slot slots[4];
+    static thread_local unsigned turn = 0;
+    if (a->uid != 0)
+        for (Slot &s : slots) if (s.uid == a->uid) return s.fp;
+    Slot &s = slots[turn++ & 3u];
+    s.fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    s.uid = a->uid;
+    return s.fp;
+}
+}  // namespace atr
+
+namespace atr {
 
 // Extra arguments of the band / window kernels when they finish the 3' part of ONE adapter of a
 // linked set (linked_core.hpp): its bins start at bin0, the read's alignment starts at front[r]'s

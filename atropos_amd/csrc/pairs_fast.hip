@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void pairs_myers_kernel(const PairFastParams f
                     score += __builtin_popcount(pb) - __builtin_popcount(mb);
                     continue;
                 }
-#pragma unroll 1
+#pragma unroll ATR_PF_WALK_UNROLL
                 for (int b = 0; b < 32; ++b) {
                     const int j = 32 * c + b + 1;
                     if (j > jhi) break;                               // wave-uniform

@@ -295,7 +295,10 @@ ATR_DEV void pf_stream_lastcol(PfScan &S, const uint32_t (&pv)[NW], const uint32
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         uint32_t pw = pv[w], mw = mv[w];
-#pragma unroll 1
+#ifndef ATR_PF_WALK_UNROLL
+#define ATR_PF_WALK_UNROLL 8                         // (the per-row threshold is an LDS read: eight of them in flight)
+#endif
+#pragma unroll ATR_PF_WALK_UNROLL
         for (int b = 0; b < 32; ++b) {
             const int i = 32 * w + b - p0 + 1;
             d += (int)(pw & 1u) - (int)(mw & 1u);

@@ -83,7 +83,7 @@ static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, co
 int piece_ragged_len(int max_len) { return 32 * ((max_len + 31) / 32); }
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out) {
     if (!a->filterable || max_len < 1) return false;
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    const FilterParams &fp = aligner_filter_params(a);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                       a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return false;

@@ -16,3 +16,8 @@ d = json.loads(open("gpurun_out/r5p/round5_bench_default_all_configs.json").read
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d.get("configs_summary"))
 PY
 head -4 gpurun_out/r5p/round5_c*_rocprofv3_summary.txt
+python tools/bench_small.py gpurun_out/r5p/round5_small_batches.json > gpurun_out/r5p/bench_small.log 2>&1
+for a in "2000000 5 C3 15" "500000 5 C5 15" "2000000 5 C3 9"; do python tools/bench_pairs.py $a 2>/dev/null | grep workload; done > gpurun_out/r5p/round5_bench_pairs.jsonl
+bash tools/kernel_times_cmd.sh python tools/bench_pairs.py 2000000 3 C3 15 > gpurun_out/r5p/round5_pairs_kernels_c3.txt 2>&1
+bash tools/kernel_times_cmd.sh python tools/bench_pairs.py 500000 3 C5 15 > gpurun_out/r5p/round5_pairs_kernels_c5.txt 2>&1
+cat gpurun_out/r5p/round5_bench_pairs.jsonl | cut -c1-200
