@@ -73,8 +73,10 @@ struct PackTable { uint8_t t[256]; };
 // STAGED: the 64 rows of a tile are contiguous in memory (64 * row_stride bytes), so the
 // wave first copies that whole region into LDS with coalesced 16-byte loads and the lanes
 // then read their own rows from LDS -- instead of 64 lanes issuing byte loads 150 bytes
-// apart.  Needs 64 * row_stride + 16 bytes of LDS per wave (row_stride <= PACK_STAGE_MAX).
+// apart.  Needs 64 * row_stride + 32 bytes of LDS per wave (row_stride <= PACK_STAGE_MAX).
 constexpr int PACK_STAGE_MAX = 256;
+constexpr int PACK_STAGE_SLACK = 32;                // bytes behind a wave's 64 rows: the aligned window's overhang (< 16) and the dword
+                                                    // reads of the four-bases-per-step path at the last row's end (< 8 more)
 
 template <bool STAGED, bool PLANES>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, long long row_stride,
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     const int n = (r < nreads) ? max(0, min((lens ? lens[r] : max_len) - start, max_len)) : 0;
     const uint8_t *row = ascii + (r < nreads ? r : 0) * row_stride + start;
     if (STAGED) {
-        const size_t wave_bytes = (size_t)64 * row_stride + 16;
+        const size_t wave_bytes = (size_t)64 * row_stride + PACK_STAGE_SLACK;
         uint8_t *stage = s_stage + (size_t)wave * ((wave_bytes + 15) & ~(size_t)15);
         const uint8_t *src = ascii + tile * 64 * row_stride;
         const uintptr_t mis = (uintptr_t)src & 15;                 // 16-byte aligned window around the region
@@ -107,12 +109,27 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
         // the caller's matrix is [ascii, buf_end): a 16-byte piece of the aligned window that sticks out of it
         // (before the first row of the batch, after its last) is copied byte by byte, never read as a whole
         const uint8_t *buf_end = ascii + nreads * row_stride;
-        for (long long o = (long long)lane * 16; o < need; o += 64 * 16) {
-            const uint8_t *piece = src_al + o;
-            if (piece >= ascii && piece + 16 <= buf_end) {
-                *(uint4 *)(stage + o) = *(const uint4 *)piece;
-            } else {
-                for (int b = 0; b < 16; ++b) stage[o + b] = (piece + b >= ascii && piece + b < buf_end) ? piece[b] : (uint8_t)0;
+        // (eight 16-byte pieces per lane requested before the first one is stored: one at a time the copy was a chain of
+        //  need / 1024 memory round trips per wave -- ten for 150-byte rows -- and the whole kernel waited on it)
+        for (long long base = 0; base < need; base += 8 * 64 * 16) {
+            uint4 buf[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long o = base + (long long)u * 64 * 16 + (long long)lane * 16;
+                const uint8_t *piece = src_al + o;
+                buf[u] = (o < need && piece >= ascii && piece + 16 <= buf_end) ? *(const uint4 *)piece : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long o = base + (long long)u * 64 * 16 + (long long)lane * 16;
+                const uint8_t *piece = src_al + o;
+                if (o < need) {
+                    if (piece >= ascii && piece + 16 <= buf_end) {
+                        *(uint4 *)(stage + o) = buf[u];
+                    } else {
+                        for (int b = 0; b < 16; ++b) stage[o + b] = (piece + b >= ascii && piece + b < buf_end) ? piece[b] : (uint8_t)0;
+                    }
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -121,6 +138,74 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     }
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;
+    if constexpr (STAGED && PLANES) {
+        // FOUR bases per step out of the staged tile (round 5; the byte-by-byte form below: a byte read and a table
+        // read from LDS and eight VALU ops per base, 0.875 ms per 10 M x 150 bp = 2.6 TB/s of a 2.3 GB stream).  A dword
+        // of the row -- read aligned, funnel-shifted to the row's byte offset -- is four bases; if they are all of
+        // 'A' 'C' 'G' 'T' (v_perm_b32 with the two-bit index (c >> 1) & 3 rebuilds the letters: equal <=> all four are),
+        // the index pairs are compacted to a byte, the chunk's 32 index pairs de-interleaved into two bit planes
+        // I0 / I1, and the four code planes are boolean functions of those (the table's codes of the four letters are
+        // wave-uniform).  Any other byte -- N, lower case, IUPAC, invalid, the bytes behind the read's end -- sends
+        // its dword through the table, byte by byte, as before.
+        uint8_t *stage0 = s_stage + (size_t)wave * ((((size_t)64 * row_stride + PACK_STAGE_SLACK) + 15) & ~(size_t)15);
+        const uint32_t *sw = (const uint32_t *)stage0;
+        const uint32_t mis0 = (uint32_t)((uintptr_t)(ascii + tile * 64 * row_stride) & 15);
+        const uint32_t rowoff = mis0 + (uint32_t)lane * (uint32_t)row_stride + (uint32_t)start;
+        const uint32_t sh = rowoff & 3u;
+        const uint32_t k = rowoff >> 2;
+        const uint32_t cA = s_tab['A'] & 15u, cC = s_tab['C'] & 15u, cG = s_tab['G'] & 15u, cT = s_tab['T'] & 15u;
+        const bool fast_ok = cA && cC && cG && cT;                  // (index order: A 0, C 1, T 2, G 3)
+        const uint32_t lutk = 0x47544341u;                          // 'A' 'C' 'T' 'G' by index
+        uint32_t lo = sw[k];
+        for (int c = 0; c < nchunks; ++c) {
+            uint32_t X = 0u, Y = 0u, V = 0u, slow[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int j = 32 * c + 4 * g;
+                const uint32_t hi = j < n ? sw[k + 8 * c + g + 1] : 0u;   // (nothing is read behind the read's last dword)
+                uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                lo = hi;
+                const int left = n - j;                             // bases of this dword inside the read
+                if (left < 4) w = left <= 0 ? 0u : (w & ((1u << (8 * left)) - 1u));
+                const uint32_t idx = (w >> 1) & 0x03030303u;
+                if (fast_ok && __builtin_amdgcn_perm(0u, lutk, idx) == w) {
+                    uint32_t z = idx | (idx >> 6);
+                    z |= z >> 12;
+                    const uint32_t r = z & 0xFFu;                  // the four index pairs, base b at bits 2b, 2b + 1
+                    if (g < 4) X |= r << (8 * g); else Y |= r << (8 * (g - 4));
+                    V |= 0xFu << (4 * g);
+                } else if (left > 0) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (b < left) {
+                            const uint32_t code = s_tab[(w >> (8 * b)) & 255u] & 15u;
+                            zero_seen = zero_seen || code == 0u;
+#pragma unroll
+                            for (int p = 0; p < 4; ++p) slow[p] |= ((code >> p) & 1u) << (4 * g + b);
+                        }
+                    }
+                }
+            }
+            // even / odd bits of X (bases 0 .. 15) and Y (16 .. 31) -> I0, I1
+            const auto even16 = [](uint32_t x) {
+                x &= 0x55555555u;
+                x = (x | (x >> 1)) & 0x33333333u;
+                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                x = (x | (x >> 4)) & 0x00FF00FFu;
+                return (x | (x >> 8)) & 0xFFFFu;
+            };
+            const uint32_t I0 = even16(X) | (even16(Y) << 16), I1 = even16(X >> 1) | (even16(Y >> 1) << 16);
+            const uint32_t m0 = ~I1 & ~I0 & V, m1 = ~I1 & I0 & V, m2 = I1 & ~I0 & V, m3 = I1 & I0 & V;   // A C T G
+            uint32_t pl[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                pl[p] = (((cA >> p) & 1u) ? m0 : 0u) | (((cC >> p) & 1u) ? m1 : 0u) | (((cT >> p) & 1u) ? m2 : 0u) |
+                        (((cG >> p) & 1u) ? m3 : 0u) | slow[p];
+            dst[(size_t)c * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        }
+        if (invalid && zero_seen) atomicAdd(invalid, 1);
+        return;
+    }
     for (int c = 0; c < nchunks; ++c) {
         uint4 v;
         if (PLANES) {
@@ -154,7 +239,7 @@ static int pack_launch(const uint8_t *d_ascii, int64_t row_stride, const int32_t
     const int nchunks = (max_len + 31) / 32;
     const long long ntiles = (nreads + 63) / 64;
     const dim3 grid((unsigned)((ntiles + 3) / 4)), block(256);
-    const size_t per_wave = (((size_t)64 * (row_stride > 0 ? row_stride : 0) + 16) + 15) & ~(size_t)15;
+    const size_t per_wave = (((size_t)64 * (row_stride > 0 ? row_stride : 0) + PACK_STAGE_SLACK) + 15) & ~(size_t)15;
     bool staged = row_stride > 0 && row_stride <= PACK_STAGE_MAX;
     if (staged && 4 * per_wave + 2048 > 64 * 1024) {
         // more dynamic LDS than a launch gets by default (row_stride 250 .. 256): ask for it once; gfx950 has 160 KB per CU

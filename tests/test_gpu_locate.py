@@ -267,11 +267,20 @@ def test_pack_staged_window_edges(hip_backend, planes):
     (those pieces are copied byte by byte), strides 250..256 need more than the default 64 KB of LDS."""
     from atropos_amd import _lib
     be = hip_backend
-    table = be.translate_table(_lib.TABLE_DNA15)
     gen = torch.Generator().manual_seed(77)
-    letters = torch.tensor(list(b"ACGTNRYacgtn.-"), dtype=torch.uint8)
-    for width in (1, 15, 16, 17, 63, 100, 101, 249, 250, 251, 255, 256):
+    mixed = torch.tensor(list(b"ACGTNRYacgtn.-"), dtype=torch.uint8)
+    # mostly A C G T (the four-bases-per-step path of the staged plane pack, api.hip) with the odd other byte
+    mostly = torch.tensor(list(b"ACGT" * 40 + b"NRYacgtn.-"), dtype=torch.uint8)
+    custom = bytearray(be.translate_table(_lib.TABLE_DNA15))
+    custom[ord("G")] = 0                                   # a table without a code for one of the four letters: no fast path
+    tables = (be.translate_table(_lib.TABLE_DNA15), be.translate_table(_lib.TABLE_IUPAC), be.translate_table(_lib.TABLE_ACGT),
+              bytes(custom))
+    case = 0
+    for width in (1, 15, 16, 17, 63, 100, 101, 150, 249, 250, 251, 255, 256):
         for nreads in (1, 63, 64, 65, 300):
+            case += 1
+            letters = mostly if case % 2 else mixed
+            table = tables[case % len(tables)]
             host = letters[torch.randint(0, len(letters), (nreads, width), generator=gen)]
             lens = torch.randint(0, width + 1, (nreads,), generator=gen, dtype=torch.int32)
             tight = host.clone().to(be.device)                                 # exactly nreads * width bytes
