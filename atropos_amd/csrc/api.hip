@@ -138,6 +138,51 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     }
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;
+    if constexpr (STAGED && !PLANES) {
+        // tile64 (4-bit codes), four bases per step like the plane form below: the letter test, then the codes of the
+        // four bases by v_perm_b32 from the table's four entries and their nibbles pushed together
+        uint8_t *stage0 = s_stage + (size_t)wave * ((((size_t)64 * row_stride + PACK_STAGE_SLACK) + 15) & ~(size_t)15);
+        const uint32_t *sw = (const uint32_t *)stage0;
+        const uint32_t mis0 = (uint32_t)((uintptr_t)(ascii + tile * 64 * row_stride) & 15);
+        const uint32_t rowoff = mis0 + (uint32_t)lane * (uint32_t)row_stride + (uint32_t)start;
+        const uint32_t sh = rowoff & 3u, k = rowoff >> 2;
+        const uint32_t cA = s_tab['A'] & 15u, cC = s_tab['C'] & 15u, cG = s_tab['G'] & 15u, cT = s_tab['T'] & 15u;
+        const bool fast_ok = cA && cC && cG && cT;
+        const uint32_t lutk = 0x47544341u, lutc = cA | (cC << 8) | (cT << 16) | (cG << 24);   // index order: A C T G
+        uint32_t lo = sw[k];
+        for (int c = 0; c < nchunks; ++c) {
+            uint32_t out[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int j = 32 * c + 4 * g;
+                const uint32_t hi = j < n ? sw[k + 8 * c + g + 1] : 0u;
+                uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+                lo = hi;
+                const int left = n - j;
+                if (left < 4) w = left <= 0 ? 0u : (w & ((1u << (8 * left)) - 1u));
+                const uint32_t idx = (w >> 1) & 0x03030303u;
+                uint32_t nib = 0u;                                  // four codes, base b at bits 4b .. 4b + 3
+                if (fast_ok && __builtin_amdgcn_perm(0u, lutk, idx) == w) {
+                    uint32_t cc = __builtin_amdgcn_perm(0u, lutc, idx);
+                    cc = (cc | (cc >> 4)) & 0x00FF00FFu;
+                    nib = (cc | (cc >> 8)) & 0xFFFFu;
+                } else if (left > 0) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (b < left) {
+                            const uint32_t code = s_tab[(w >> (8 * b)) & 255u] & 15u;
+                            zero_seen = zero_seen || code == 0u;
+                            nib |= code << (4 * b);
+                        }
+                    }
+                }
+                out[g >> 1] |= nib << (16 * (g & 1));
+            }
+            dst[(size_t)c * 64] = make_uint4(out[0], out[1], out[2], out[3]);
+        }
+        if (invalid && zero_seen) atomicAdd(invalid, 1);
+        return;
+    }
     if constexpr (STAGED && PLANES) {
         // FOUR bases per step out of the staged tile (round 5; the byte-by-byte form below: a byte read and a table
         // read from LDS and eight VALU ops per base, 0.875 ms per 10 M x 150 bp = 2.6 TB/s of a 2.3 GB stream).  A dword
