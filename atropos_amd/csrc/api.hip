@@ -10,6 +10,8 @@
 #include "locate_fast.hpp"
 #include "wave_core.hpp"
 
+#include "pack_fast.hpp"
+
 namespace atr {
 
 int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads,
@@ -138,116 +140,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     }
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;
-    if constexpr (STAGED && !PLANES) {
-        // tile64 (4-bit codes), four bases per step like the plane form below: the letter test, then the codes of the
-        // four bases by v_perm_b32 from the table's four entries and their nibbles pushed together
+    if constexpr (STAGED) {
+        // four bases per step out of the staged tile (pack_fast.hpp; round 5: the byte-by-byte loop below took 0.875 ms per
+        // 10 M x 150 bp as planes, 1.03 ms per 12.5 M as codes -- now 0.61 / 0.63 ms, 3.8 TB/s of a 2.3 GB stream)
         uint8_t *stage0 = s_stage + (size_t)wave * ((((size_t)64 * row_stride + PACK_STAGE_SLACK) + 15) & ~(size_t)15);
-        const uint32_t *sw = (const uint32_t *)stage0;
         const uint32_t mis0 = (uint32_t)((uintptr_t)(ascii + tile * 64 * row_stride) & 15);
         const uint32_t rowoff = mis0 + (uint32_t)lane * (uint32_t)row_stride + (uint32_t)start;
-        const uint32_t sh = rowoff & 3u, k = rowoff >> 2;
-        const uint32_t cA = s_tab['A'] & 15u, cC = s_tab['C'] & 15u, cG = s_tab['G'] & 15u, cT = s_tab['T'] & 15u;
-        const bool fast_ok = cA && cC && cG && cT;
-        const uint32_t lutk = 0x47544341u, lutc = cA | (cC << 8) | (cT << 16) | (cG << 24);   // index order: A C T G
-        uint32_t lo = sw[k];
-        for (int c = 0; c < nchunks; ++c) {
-            uint32_t out[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int j = 32 * c + 4 * g;
-                const uint32_t hi = j < n ? sw[k + 8 * c + g + 1] : 0u;
-                uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                lo = hi;
-                const int left = n - j;
-                if (left < 4) w = left <= 0 ? 0u : (w & ((1u << (8 * left)) - 1u));
-                const uint32_t idx = (w >> 1) & 0x03030303u;
-                uint32_t nib = 0u;                                  // four codes, base b at bits 4b .. 4b + 3
-                if (fast_ok && __builtin_amdgcn_perm(0u, lutk, idx) == w) {
-                    uint32_t cc = __builtin_amdgcn_perm(0u, lutc, idx);
-                    cc = (cc | (cc >> 4)) & 0x00FF00FFu;
-                    nib = (cc | (cc >> 8)) & 0xFFFFu;
-                } else if (left > 0) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (b < left) {
-                            const uint32_t code = s_tab[(w >> (8 * b)) & 255u] & 15u;
-                            zero_seen = zero_seen || code == 0u;
-                            nib |= code << (4 * b);
-                        }
-                    }
-                }
-                out[g >> 1] |= nib << (16 * (g & 1));
-            }
-            dst[(size_t)c * 64] = make_uint4(out[0], out[1], out[2], out[3]);
-        }
-        if (invalid && zero_seen) atomicAdd(invalid, 1);
-        return;
-    }
-    if constexpr (STAGED && PLANES) {
-        // FOUR bases per step out of the staged tile (round 5; the byte-by-byte form below: a byte read and a table
-        // read from LDS and eight VALU ops per base, 0.875 ms per 10 M x 150 bp = 2.6 TB/s of a 2.3 GB stream).  A dword
-        // of the row -- read aligned, funnel-shifted to the row's byte offset -- is four bases; if they are all of
-        // 'A' 'C' 'G' 'T' (v_perm_b32 with the two-bit index (c >> 1) & 3 rebuilds the letters: equal <=> all four are),
-        // the index pairs are compacted to a byte, the chunk's 32 index pairs de-interleaved into two bit planes
-        // I0 / I1, and the four code planes are boolean functions of those (the table's codes of the four letters are
-        // wave-uniform).  Any other byte -- N, lower case, IUPAC, invalid, the bytes behind the read's end -- sends
-        // its dword through the table, byte by byte, as before.
-        uint8_t *stage0 = s_stage + (size_t)wave * ((((size_t)64 * row_stride + PACK_STAGE_SLACK) + 15) & ~(size_t)15);
-        const uint32_t *sw = (const uint32_t *)stage0;
-        const uint32_t mis0 = (uint32_t)((uintptr_t)(ascii + tile * 64 * row_stride) & 15);
-        const uint32_t rowoff = mis0 + (uint32_t)lane * (uint32_t)row_stride + (uint32_t)start;
-        const uint32_t sh = rowoff & 3u;
-        const uint32_t k = rowoff >> 2;
-        const uint32_t cA = s_tab['A'] & 15u, cC = s_tab['C'] & 15u, cG = s_tab['G'] & 15u, cT = s_tab['T'] & 15u;
-        const bool fast_ok = cA && cC && cG && cT;                  // (index order: A 0, C 1, T 2, G 3)
-        const uint32_t lutk = 0x47544341u;                          // 'A' 'C' 'T' 'G' by index
-        uint32_t lo = sw[k];
-        for (int c = 0; c < nchunks; ++c) {
-            uint32_t X = 0u, Y = 0u, V = 0u, slow[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const int j = 32 * c + 4 * g;
-                const uint32_t hi = j < n ? sw[k + 8 * c + g + 1] : 0u;   // (nothing is read behind the read's last dword)
-                uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-                lo = hi;
-                const int left = n - j;                             // bases of this dword inside the read
-                if (left < 4) w = left <= 0 ? 0u : (w & ((1u << (8 * left)) - 1u));
-                const uint32_t idx = (w >> 1) & 0x03030303u;
-                if (fast_ok && __builtin_amdgcn_perm(0u, lutk, idx) == w) {
-                    uint32_t z = idx | (idx >> 6);
-                    z |= z >> 12;
-                    const uint32_t r = z & 0xFFu;                  // the four index pairs, base b at bits 2b, 2b + 1
-                    if (g < 4) X |= r << (8 * g); else Y |= r << (8 * (g - 4));
-                    V |= 0xFu << (4 * g);
-                } else if (left > 0) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        if (b < left) {
-                            const uint32_t code = s_tab[(w >> (8 * b)) & 255u] & 15u;
-                            zero_seen = zero_seen || code == 0u;
-#pragma unroll
-                            for (int p = 0; p < 4; ++p) slow[p] |= ((code >> p) & 1u) << (4 * g + b);
-                        }
-                    }
-                }
-            }
-            // even / odd bits of X (bases 0 .. 15) and Y (16 .. 31) -> I0, I1
-            const auto even16 = [](uint32_t x) {
-                x &= 0x55555555u;
-                x = (x | (x >> 1)) & 0x33333333u;
-                x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-                x = (x | (x >> 4)) & 0x00FF00FFu;
-                return (x | (x >> 8)) & 0xFFFFu;
-            };
-            const uint32_t I0 = even16(X) | (even16(Y) << 16), I1 = even16(X >> 1) | (even16(Y >> 1) << 16);
-            const uint32_t m0 = ~I1 & ~I0 & V, m1 = ~I1 & I0 & V, m2 = I1 & ~I0 & V, m3 = I1 & I0 & V;   // A C T G
-            uint32_t pl[4];
-#pragma unroll
-            for (int p = 0; p < 4; ++p)
-                pl[p] = (((cA >> p) & 1u) ? m0 : 0u) | (((cC >> p) & 1u) ? m1 : 0u) | (((cT >> p) & 1u) ? m2 : 0u) |
-                        (((cG >> p) & 1u) ? m3 : 0u) | slow[p];
-            dst[(size_t)c * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        }
+        if constexpr (PLANES) pack_planes_row_fast((const uint32_t *)stage0, rowoff >> 2, 0x7fffffffu, rowoff & 3u, n, nchunks, s_tab, dst, zero_seen);
+        else pack_codes_row_fast((const uint32_t *)stage0, rowoff >> 2, 0x7fffffffu, rowoff & 3u, n, nchunks, s_tab, dst, zero_seen);
         if (invalid && zero_seen) atomicAdd(invalid, 1);
         return;
     }

@@ -22,6 +22,8 @@
 #include "fastq_core.hpp"
 #include "misc_core.hpp"
 
+#include "pack_fast.hpp"
+
 namespace atr {
 
 int hip_fail(hipError_t e, const char *what);             // api.hip
@@ -193,21 +195,6 @@ __global__ void set_i64_kernel(long long *p, long long v) { *p = v; }
 // ------------------------------------------------------------------------- pack from records
 struct PackTable256 { uint8_t t[256]; };
 
-// 8 bases (two dwords of ASCII, already shifted to the read's own alignment) -> one packed word
-__device__ __forceinline__ uint32_t pack_two_words(uint32_t w0, uint32_t w1, int j0, int n, const uint8_t *tab,
-                                                   bool &zero_seen) {
-    uint32_t w = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-        const uint32_t byte = ((b < 4 ? w0 : w1) >> (8 * (b & 3))) & 0xFFu;
-        if (j0 + b < n) {
-            const uint32_t code = (uint32_t)tab[byte] & 15u;
-            zero_seen = zero_seen || code == 0;
-            w |= code << (4 * b);
-        }
-    }
-    return w;
-}
 
 // The sequence lines sit at arbitrary byte offsets of the file chunk, ~300 bytes apart.  A
 // wave first copies the aligned dwords of its 64 lines into 64 LDS rows -- one
@@ -264,34 +251,9 @@ __global__ void pack_records_kernel(
     const uint32_t *p = rows + (size_t)lane * stride_dw;
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;
-    if (PLANES) {                                               // plane64: byte reads of the lane's LDS row
-        const uint8_t *row = (const uint8_t *)p + sh;
-        for (int c = 0; c < nchunks; ++c) {
-            uint32_t pl[4];
-            pack_planes_chunk(row, c * 32, n, s_spread, zero_seen, pl);
-            dst[(size_t)c * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        }
-        if (invalid && zero_seen) atomicAdd(invalid, 1);
-        return;
-    }
-    uint32_t prev = nd > 0 ? p[0] : 0u;
-    int t = 0;                                                  // prev == p[t]
-    for (int c = 0; c < nchunks; ++c) {
-        uint32_t v[4];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            uint32_t sw[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t next = (t + 1 < nd) ? p[t + 1] : 0u;
-                sw[h] = __builtin_amdgcn_alignbyte(next, prev, sh);
-                prev = next;
-                ++t;
-            }
-            v[w] = pack_two_words(sw[0], sw[1], c * 32 + w * 8, n, s_tab, zero_seen);
-        }
-        dst[(size_t)c * 64] = make_uint4(v[0], v[1], v[2], v[3]);
-    }
+    // four bases per step out of the lane's LDS row (pack_fast.hpp); dwords from nd on are not read
+    if (PLANES) pack_planes_row_fast(p, 0u, (uint32_t)nd, sh, n, nchunks, s_tab, dst, zero_seen);
+    else pack_codes_row_fast(p, 0u, (uint32_t)nd, sh, n, nchunks, s_tab, dst, zero_seen);
     if (invalid && zero_seen) atomicAdd(invalid, 1);
 }
 
