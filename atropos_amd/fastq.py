@@ -547,6 +547,12 @@ class FastqSink(object):
     def write(self, text):
         import time
         n = int(text.numel())
+        room = self.buf[self.k].numel() - self.BLOCK           # (a staging buffer also holds up to BLOCK - 1 carried bytes)
+        if n > room:
+            # text that outgrew its chunk (read-name prefixes / suffixes / length tags on short records): in pieces
+            for lo in range(0, n, room):
+                self.write(text[lo:lo + room])
+            return
         t0 = time.perf_counter()
         if self.pending[self.k] is not None:
             self.pending[self.k].result()                     # this buffer is free again after its write

@@ -966,7 +966,7 @@ def check_fused_match_correct(n=4096, seed=9):
         for x, y, what in ((rec, frec, "records"), (a1, f1, "read 1"), (a2, f2, "read 2"), (q1, g1, "qualities 1"),
                            (q2, g2, "qualities 2"), (ch, fch, "changed"), (nl, fnl, "newlen")):
             assert (x is None and y is None) or torch.equal(x, y), (what, action, ragged, quals, width)
-        assert int((ch > 0).any(dim=1).sum()) > (n // 16 if width >= 200 and not ragged else -1), (action, ragged, width)
+        assert int((ch > 0).any(dim=1).sum()) > (n // 16 if width >= 200 and not ragged and n >= 1000 else -1), (action, ragged, width)
         done += n
     # the method of the aligner (mismatch_action by name)
     s1, s2, qa, qb = (w[k].clone() for k in ("reads1", "reads2", "quals1", "quals2"))

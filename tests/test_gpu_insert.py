@@ -101,6 +101,8 @@ def test_plane_guided_correction(hip_backend):
 def test_fused_match_correct(hip_backend):
     """atr_insert_match_correct_batch == atr_insert_match_batch + atr_insert_correct_batch, every output"""
     assert _cases.check_fused_match_correct(n=150_000) == 13 * 150_000
+    for n in (1, 63, 191):                                  # (a partial last tile, blocks with idle waves)
+        assert _cases.check_fused_match_correct(n=n, seed=n) == 13 * n
 
 
 def test_correct_errors_fixture(hip_backend):
