@@ -329,29 +329,32 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
     // each on a stream of its own forked off `st` behind the scatter pass and joined again before the workspace goes:
     // the classes work on disjoint tasks, and a class with few tasks is a handful of waves whose single lanes run
     // for 0.1 - 0.3 ms -- back to back that was 1.2 ms of latency per call whatever the batch held.
-    static thread_local SideStream side[PF_CLASSES];
+    static thread_local SideStream side[PF_CLASSES + 1];             // (+ 1: the full sweep of the pairs no band class takes)
+    constexpr int NSIDE = PF_CLASSES + 1;
     bool forked = false;
     if (e == hipSuccess) {
         forked = true;
-        for (int c = 0; c < PF_CLASSES && forked; ++c) forked = side[c].ready();
+        for (int c = 0; c < NSIDE && forked; ++c) forked = side[c].ready();
         if (forked) {
             e = hipEventRecord(side[0].fork, st);
-            for (int c = 0; c < PF_CLASSES && e == hipSuccess; ++c) e = hipStreamWaitEvent(side[c].stream, side[0].fork, 0);
+            for (int c = 0; c < NSIDE && e == hipSuccess; ++c) e = hipStreamWaitEvent(side[c].stream, side[0].fork, 0);
         }
     }
 #define ATR_PF_BAND(WB, C) if (e == hipSuccess) e = launch_band<WB>(fp, a, wk, C, forked ? side[C].stream : st)
     ATR_PF_BAND(16, 0); ATR_PF_BAND(32, 1); ATR_PF_BAND(48, 2); ATR_PF_BAND(64, 3);
     ATR_PF_BAND(80, 4); ATR_PF_BAND(96, 5); ATR_PF_BAND(112, 6); ATR_PF_BAND(128, 7);
 #undef ATR_PF_BAND
+    // the full sweep next to the band classes, not behind them (2 x 250-base pairs: a fifth of the call when it ran last)
+    if (e == hipSuccess)
+        e = launch_pairs_full_indexed(p, rp, rl, rmax, revcomp, qp, ql, qmax, npairs, out, wk.order, wk.fw.binbase + PF_FALLBACK_BIN,
+                                      forked ? side[PF_CLASSES].stream : st);
     if (forked) {                                                    // join whatever was launched (also after an error)
-        for (int c = 0; c < PF_CLASSES; ++c) {
+        for (int c = 0; c < NSIDE; ++c) {
             hipError_t j = hipEventRecord(side[c].join, side[c].stream);
             if (j == hipSuccess) j = hipStreamWaitEvent(st, side[c].join, 0);
             if (e == hipSuccess) e = j;
         }
     }
-    if (e == hipSuccess)
-        e = launch_pairs_full_indexed(p, rp, rl, rmax, revcomp, qp, ql, qmax, npairs, out, wk.order, wk.fw.binbase + PF_FALLBACK_BIN, st);
     const hipError_t freed = hipFreeAsync(work, st);
     return e != hipSuccess ? e : freed;
 }
