@@ -269,6 +269,7 @@ void emu_fast(const atr_aligner *a, const uint32_t *packed, const int32_t *lens,
 // source), pass B as a windowed sweep with the product's filter_step / filter_decide_tm, then emu_dp_stage on the
 // reads it leaves open (from a tile64 copy of the planes).  The window length varies with the read number the way
 // it varies with a wave's other lanes on the GPU: the records must not depend on it.
+static std::vector<uint32_t> g_piece_last_windows;   // the window words of the last two-pass call (0: resolved in the pre-pass)
 static long long g_piece_stats[6], g_piece_need[12];   // need histogram, 8 columns per bin      // reads, flagged, read-end condition, wide, window columns swept, open after pass B
 // nr >= 0: a ragged batch -- pass A sees the read moved to the end of its NW words (n = 32 NW), as the kernel does
 template <int NW>
@@ -385,6 +386,7 @@ void emu_piece(const atr_aligner *a, const uint32_t *planes, const int32_t *lens
         if (!window_valid(ww)) memcpy(out + 4 * r, rec, 16);
         else { bins[window_bin(ww, u.m, true)].push_back((uint32_t)r); ++g_piece_stats[5]; }
     }
+    g_piece_last_windows = win;                                  // (diagnostics: tools/c2_unresolved.py)
     emu_dp_stage<MT, NOINDEL>(a, nib.data(), lens, nchunks, max_len, out, win, bins, nullptr);
 }
 
@@ -798,6 +800,12 @@ int emu_locate_planes_all_widths(const atr_aligner *a, int max_len, int ragged) 
     PieceParams pp;
     return piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                         a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp) ? 1 : 0;
+}
+
+long long emu_piece_last_windows(uint32_t *out, long long cap) {
+    const long long n = std::min<long long>(cap, (long long)g_piece_last_windows.size());
+    for (long long i = 0; i < n; ++i) out[i] = g_piece_last_windows[(size_t)i];
+    return (long long)g_piece_last_windows.size();
 }
 
 void emu_piece_stats(long long out[18], int reset) {
