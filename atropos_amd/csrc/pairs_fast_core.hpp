@@ -369,23 +369,6 @@ ATR_DEV void pf_opaque(uint32_t &v) {
 #endif
 }
 
-// cell[cn] for a per-lane index: a select tree over the bits of cn, walked depth first (WB - 1 selects, a handful
-// of temporaries).  (A chain of `cn == c ? cell[c] : w` is recognised by the compiler as cell[cn] and moves the
-// whole band into scratch memory.)
-template <int WB, int LO, int N>
-ATR_DEV uint32_t pf_pick_rec(const uint32_t (&cell)[WB], int cn) {
-    if constexpr (N == 1) {
-        return cell[LO];
-    } else {
-        constexpr int H = N > 64 ? 64 : N > 32 ? 32 : N > 16 ? 16 : N > 8 ? 8 : N > 4 ? 4 : N > 2 ? 2 : 1;
-        const uint32_t a = pf_pick_rec<WB, LO, H>(cell, cn);
-        const uint32_t b = pf_pick_rec<WB, LO + H, N - H>(cell, cn);
-        return (cn & H) ? b : a;
-    }
-}
-template <int WB>
-ATR_DEV uint32_t pf_pick(const uint32_t (&cell)[WB], int cn) { return pf_pick_rec<WB, 0, WB>(cell, cn); }
-
 struct PfBandLane {
     int d_lo, row_first, row_last, cand_first, mlb, m, n, n_sweep;
     bool scan_last, live;
@@ -507,16 +490,6 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, PfRefStream &rs, PfQu
                 left = nw;
                 if ((c & 7) == 7) pf_sched_fence();
             }
-            // last-column candidate of this row (:461-474, rows in increasing order): only the threats -- their
-            // payload is the reference's; any other cell fails the threat test with its own (never too low) cost
-            if (L.scan_last && L.cand_first != 0 && i >= L.cand_first && (er || i == m)) {
-                const int cn = n - L.d_lo - i;
-                if (cn >= 0 && cn < WB) {
-                    const uint32_t w = pf_pick<WB>(cell, cn);
-                    if (pf_is_threat(i, n, (int)(w >> CSH), (int)thr[i], gap_n, p.min_overlap, L.mlb))
-                        consider<true, PAIRS_ORG_BIAS>(bl, w, i, n, p.min_overlap, thr, 1);
-                }
-            }
         }
         // next row: slide the window by one base, next reference code
 #pragma unroll
@@ -528,6 +501,26 @@ ATR_DEV void pf_band_sweep(const PfBandLane &L, int nrows, PfRefStream &rs, PfQu
             rw = rnext;
             qnext = qs.next();
             rnext = rs.next();
+        }
+    }
+    // Last-column candidates (:461-474, rows in increasing order) -- AFTER the sweep: a register that has passed column n
+    // keeps what it held there.  Behind the read every code is 0 = "matches every row", so the diagonal step leaves the
+    // word as it is (no mismatch: no cost, no payload), and it wins the min3: the neighbours of (i + s, n + s) are a real
+    // last-column cell and other cells that slid out of the matrix the same way, i.e. D(i', n) + |i - i'| for some rows
+    // i' -- never below D(i, n) where that is exact (costs are 1-Lipschitz along a column; band values are upper
+    // bounds) -- and a tie goes to the diagonal step (priority 0).  So cell[c] IS the cell (n - d_lo - c, n) for every
+    // threat, whose band holds its optimal paths; any other cell's word may have been lowered by a neighbour, never below
+    // its true cost, and fails the threat test again.  (Rounds 2-5 picked the cell out of the band after every row: a
+    // select tree of WB - 1 v_cndmask, 3.5 % of the 2 x 150 call and 8 % of the 2 x 250 one.)
+    if (L.live && L.scan_last && L.cand_first != 0) {
+#pragma unroll
+        for (int c = WB - 1; c >= 0; --c) {
+            const int i = n - L.d_lo - c;
+            if (i >= L.cand_first && i >= L.row_first && i <= L.row_last && (er || i == m)) {
+                const uint32_t w = cell[c];
+                if (pf_is_threat(i, n, (int)(w >> CSH), (int)thr[i], gap_n, p.min_overlap, L.mlb))
+                    consider<true, PAIRS_ORG_BIAS>(bl, w, i, n, p.min_overlap, thr, 1);
+            }
         }
     }
     // row m (the last row of the lanes that have row-m threats): its cells in column order (:433-455)
