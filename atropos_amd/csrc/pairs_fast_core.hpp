@@ -349,10 +349,9 @@ ATR_DEV int pf_task_bin(const PfDecision &D) {
 // PAIRS_ORG_BIAS as pairs_core.hpp.
 constexpr uint32_t PF_INF = ((uint32_t)INIT_COST_CAP << CSH) | (uint32_t)PAIRS_ORG_BIAS;
 
-// bit 3 of every nibble = "the nibble is not zero" (bits that cross into the next nibble only reach its low three bits)
+// bit 3 of every nibble = "the nibble is not zero"
 ATR_DEV uint32_t pf_nibble_any(uint32_t v) {
-    const uint32_t t = v | (v << 1);
-    return t | (t << 2);
+    return ((v & 0x77777777u) + 0x77777777u) | v;   // (the low three bits carry into bit 3; the other bits are not looked at)
 }
 
 // Keeps the instruction scheduler from hoisting the diagonal candidates of the whole (unrolled) row in front of
