@@ -50,6 +50,8 @@ struct FastWork {                                    // carve-up of the caller's
     uint4 *tdata;                                    // [nreads][2] next to tmp: the 64 codes from the entry's first diagonal on
                                                      //   (what band_stage would gather from the batch, 16 bytes per 128-byte line)
     uint32_t *dref;                                  // [nreads] next to order: the slot's index into tdata
+    int fused;                                       // 1: no scan launches -- the pre-pass blocks take their offsets inside the bins
+                                                     // with atomics on `chunks`[bin] (fused_hist_flush / fused_bin_bases below)
 };
 
 #ifndef __HIPCC_RTC__
@@ -85,7 +87,13 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.nbins = nbins;
     w.nused = FAST_BLOCKS;
     w.lpw = 64;
+    w.fused = 0;
     return w;
+}
+// ATR_FUSED_SCAN=0: the two scan launches instead of the atomics (A/B switch)
+inline bool fast_fused_scan() {
+    static const int v = [] { const char *e = getenv("ATR_FUSED_SCAN"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v != 0;
 }
 #endif  // __HIPCC_RTC__
 
@@ -94,6 +102,45 @@ __device__ __forceinline__ void block_tiles(long long ntiles, long long &t0, lon
     const long long per = (ntiles + nblocks - 1) / nblocks;
     t0 = min(ntiles, per * (long long)blockIdx.x);
     t1 = min(ntiles, t0 + per);
+}
+
+
+// The scan-free form of K2 (long batches of the two-pass pre-pass and of linked sets): the pre-pass block adds its
+// count of every bin it filled to the bin's total -- `chunks`[bin], zeroed by the host before the launch -- and keeps the
+// value the atomic returned as its offset inside the bin (`counts`[block][bin]): the order of the blocks inside a bin is
+// whatever the atomics made it, which no result depends on (a task writes the record of its own read).  The two scan
+// launches (13 us of C2's step, 39 of C4's) are gone; what is left of K2 is the exclusive scan of the nbins totals, done
+// by every block of the scatter pass for itself (256 threads, nbins <= 1024), block 0 leaving `binbase` / `total` for the
+// DP kernels.
+__device__ __forceinline__ void fused_hist_flush(const FastWork &wk, const uint32_t *s_hist) {
+    for (int b = threadIdx.x; b < wk.nbins; b += blockDim.x) {
+        const uint32_t c = s_hist[b];
+        wk.counts[(size_t)blockIdx.x * wk.nbins + b] = !wk.fused ? c : c ? atomicAdd(&wk.chunks[b], c) : 0u;
+    }
+}
+// s_base: [nbins + 1] in LDS, s_tmp: [256]; a block of 256 threads
+__device__ __forceinline__ void fused_bin_bases(const FastWork &wk, uint32_t *s_base, uint32_t *s_tmp) {
+    const int t = threadIdx.x, per = wk.nbins >> 8;                // 1 .. 4 consecutive bins per thread
+    uint32_t v[4], sum = 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[i] = i < per ? wk.chunks[t * per + i] : 0u; sum += v[i]; }
+    s_tmp[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {                      // Hillis-Steele inclusive scan of the 256 partial sums
+        const uint32_t add = t >= off ? s_tmp[t - off] : 0u;
+        __syncthreads();
+        s_tmp[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = s_tmp[t] - sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i < per) { s_base[t * per + i] = run; run += v[i]; }
+    if (t == 255) s_base[wk.nbins] = run;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int b = t; b <= wk.nbins; b += 256) wk.binbase[b] = s_base[b];
+        if (t == 0) wk.total[0] = s_base[wk.nbins];
+    }
 }
 
 }  // namespace atr

@@ -38,14 +38,15 @@ void launch_fast_scan(FastWork wk, hipStream_t st) {
 }
 
 // K4a and K4 over the reads `order` lists for one aligner; la != nullptr: the 3' part of adapter
-// `idx` of a linked set of `count` adapters (bins la->bin0 ..).  K4a runs on a side stream next to
-// K4 (its waves are latency bound: three dependent gathers per task -- they share the SIMDs with
-// K4's instead of running before them); the K4 launches of the adapters of a linked set are
-// independent of each other (disjoint slots of `order`, disjoint records) and go to one stream each,
-// so that their tails overlap.  idx == 0 forks the side streams off `st` (they wait for the scatter
+// `idx` of a linked set of `count` adapters (bins la->bin0 ..).  K4a and K4 work on disjoint slots of `order` and
+// write disjoint records: they run side by side (K4a's waves are latency bound: three dependent gathers per task --
+// they share the SIMDs with K4's instead of running before them), K4a on the caller's stream, the K4 launches of
+// the adapters of a linked set on side streams.  idx == 0 forks the side streams off `st` (they wait for the scatter
 // pass), idx == count - 1 joins them again; events only, legal inside a stream capture.
 // (A band stream per adapter was tried in round 4: the four K4a launches of C4 then run side by side, each four
-// times as long -- the DP phase is bound by its task throughput, not by launch latency.)
+// times as long -- the DP phase is bound by its task throughput, not by launch latency.  Round 5, from the kernel
+// timelines of profiles/round5_tail_timelines.txt: with five streams C4's last window launch waited for another
+// stream to drain -- three side streams now, a fourth adapter's window launch queues behind the first's.)
 constexpr int DP_STREAMS = 4;                            // >= LINKED_MAX: band stream + one per further adapter
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                    int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes) {
@@ -75,10 +76,12 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         const int mts = round_up_rows(a->p.m) / ROW_GRAN - 1;
         return window_groups[mts / 4](mts % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st, planes);
     }
+    const int nside = std::min(count, 3);
+    hipStream_t bst = st;
     if (idx == 0) {
-        for (int k = 0; k < count; ++k) if (!side[k].ready()) return (int)hipErrorInvalidValue;
+        for (int k = 0; k < nside; ++k) if (!side[k].ready()) return (int)hipErrorInvalidValue;
         e = hipEventRecord(side[0].fork, st);
-        for (int k = 0; k < count && e == hipSuccess; ++k) e = hipStreamWaitEvent(side[k].stream, side[0].fork, 0);
+        for (int k = 0; k < nside && e == hipSuccess; ++k) e = hipStreamWaitEvent(side[k].stream, side[0].fork, 0);
         if (e != hipSuccess) return (int)e;
     }
     const dim3 block(256);
@@ -88,30 +91,30 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         if (la && la->multi) {                                      // a linked set: all adapters' band reads at once
             if (idx == 0) {
                 const int rc = launch_linked_band(la->multi, count, la->multi_and, packed, lens, nreads, nchunks, max_len, la->front,
-                                                  out, wk, side[0].stream);
+                                                  out, wk, bst);
                 if (rc != 0) return rc;
             }
         } else if (la) {
-            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
-            else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, true>), bgrid, block, 0, bst, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+            else             hipLaunchKernelGGL((band_kernel<false, true>), bgrid, block, 0, bst, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, *la);
         } else if (planes) {
             const LinkedArgs none = no_linked_args();
-            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
-            else             hipLaunchKernelGGL((band_kernel<false, false, true>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false, true>), bgrid, block, 0, bst, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false, true>), bgrid, block, 0, bst, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
         } else {
             const LinkedArgs none = no_linked_args();
-            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
-            else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, block, 0, side[0].stream, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            if (bp.and_mode) hipLaunchKernelGGL((band_kernel<true, false>), bgrid, block, 0, bst, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
+            else             hipLaunchKernelGGL((band_kernel<false, false>), bgrid, block, 0, bst, a->p, bp, packed, lens, nreads, nchunks, max_len, out, wk, none);
         }
     }
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const int mt = round_up_rows(a->p.m) / ROW_GRAN - 1;
     const int rc = window_groups[mt / 4](mt % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la,
-                                                 idx == 0 ? st : side[idx].stream, planes);
+                                                 side[idx % nside].stream, planes);
     if (rc != 0) return rc;
     if (idx == count - 1) {
-        for (int k = 0; k < count && e == hipSuccess; ++k) {
+        for (int k = 0; k < nside && e == hipSuccess; ++k) {
             e = hipEventRecord(side[k].join, side[k].stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(st, side[k].join, 0);
         }
@@ -138,9 +141,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     // the same bin rule as K1's histogram (filter_kernel): row-count bins also for ragged batches when tail mode applies
     hipLaunchKernelGGL(scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m,
                        (!ragged || !(a->flags & ATR_START_WITHIN_SEQ1)) ? 1 : 0, wk);        // == ragged_rows_bins(u.sr)
-    // K4a and K4 work on disjoint slots of `order`: K4a runs on a side stream forked after K3 and
-    // joined after K4, so that its waves (latency bound: three dependent gathers per task) share
-    // the SIMDs with K4's instead of running before them.
+    // K4a and K4 work on disjoint slots of `order` and run side by side (launch_fast_dp)
     return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, 0, 1, st, false);
 }
 

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     }
     __syncthreads();
     const int nbins = nad * FILTER_BINS;
-    for (int b = threadIdx.x; b < nbins; b += 256) wk.counts[(size_t)blockIdx.x * nbins + b] = s_hist[b];
+    fused_hist_flush(wk, s_hist);                                  // (long batches: offsets inside the bins by atomics, fast_work.hpp)
     if (threadIdx.x == 0) wk.lcount[blockIdx.x] = s_lcur;
 }
 
@@ -436,9 +436,13 @@ struct LinkedLens { int m[LINKED_MAX]; };
 
 __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, const LinkedLens ms, int by_rows,
                                                              const uint16_t *__restrict__ which_out, FastWork wk, int lists) {
-    __shared__ uint32_t s_cur[LINKED_MAX * FILTER_BINS];
-    for (int b = threadIdx.x; b < wk.nbins; b += 256)
-        s_cur[b] = fast_slot0(wk, b);
+    __shared__ uint32_t s_cur[LINKED_MAX * FILTER_BINS + 1], s_tmp[256];
+    if (wk.fused) {                                                // (no scan launches before this one: fast_work.hpp)
+        fused_bin_bases(wk, s_cur, s_tmp);
+        for (int b = threadIdx.x; b < wk.nbins; b += 256) s_cur[b] += wk.counts[(size_t)blockIdx.x * wk.nbins + b];
+    } else {
+        for (int b = threadIdx.x; b < wk.nbins; b += 256) s_cur[b] = fast_slot0(wk, b);
+    }
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
@@ -548,6 +552,11 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
     const bool ragged = d_lens != nullptr, and_mode = s->p.and_mode != 0;
     // (the wavefront-per-read finish of short batches reads a window word per read; long batches keep per-block lists)
     const int lists = nreads > LINKED_WAVE_MAX_READS ? 1 : 0;
+    wk.fused = (lists && fast_fused_scan()) ? 1 : 0;
+    if (wk.fused) {                                                // the bins' totals the pre-pass blocks add to (fused_hist_flush)
+        const hipError_t rc = hipMemsetAsync(wk.chunks, 0, (size_t)wk.nbins * 4, st);
+        if (rc != hipSuccess) return hip_fail(rc, "linked bin totals memset");
+    }
     uint16_t *which = (uint16_t *)d_which;
     uint4 *front = (uint4 *)d_front, *back = (uint4 *)d_back;
     const uint4 *packed = (const uint4 *)d_packed;
@@ -579,7 +588,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
             return e == hipSuccess ? ATR_OK : hip_fail(e, "linked_wave_kernel launch");
         }
     }
-    launch_fast_scan(wk, st);
+    if (!wk.fused) launch_fast_scan(wk, st);
     LinkedLens ms;
     for (int a = 0; a < LINKED_MAX; ++a) ms.m[a] = a < s->p.n ? s->p.b[a].m : 0;
     hipLaunchKernelGGL(linked_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, (long long)nreads, ms, ragged ? 0 : 1,

@@ -13,6 +13,13 @@ namespace atr {
 #ifndef ATR_PIECE_PREFETCH_EARLY
 #define ATR_PIECE_PREFETCH_EARLY 1
 #endif
+// Pass B's window out of LDS: a lane that queues a task stores the planes pass A holds for it (NW x 16 bytes) next to the
+// task, [word][slot] per wave, and pass B picks its three chunks from there -- instead of gathering them from the batch
+// (three 16-byte pieces per flagged read out of lines the L2 had dropped by then: 212 MB of C2's counted fetch,
+// profiles/round5_c2_fetch_calibration.txt).  Word counts whose stash would cost a resident block (9, 10) keep the gather.
+#ifndef ATR_PIECE_STASH
+#define ATR_PIECE_STASH 1
+#endif
 #ifndef ATR_PIECE_WAVES
 #ifdef ATR_SPEC
 #define ATR_PIECE_WAVES(NW) ((NW) <= 6 ? 4 : 3)                         // (no spills at these: tools/jit/spec_offline.sh)
@@ -81,6 +88,8 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     __shared__ uint32_t s_lcur, s_wcnt;
     __shared__ uint32_t s_nibs[4][8][64];                         // pass B: the task's eight nibble dwords, [dword][lane] (NARROW tail check)
     __shared__ uint32_t s_queue[4][PIECE_QF][64];
+    constexpr bool STASH = ATR_PIECE_STASH != 0 && NW <= 8;
+    __shared__ uint4 s_stash[STASH ? 4 : 1][STASH ? NW : 1][64];
     const Uniform u = make_uniform(p, round_up_rows_dev(p.m));
 #ifndef ATR_SPEC
     // The piece parameters go through LDS: as ~800 bytes of kernel argument the compiler kept them in scalar registers
@@ -114,6 +123,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     uint32_t *wlist = wk.wide + t0 * 64;
     uint32_t (*queue)[64] = s_queue[wave];
     uint32_t *nibs = &s_nibs[wave][0][0];
+    uint4 (*stash)[64] = s_stash[STASH ? wave : 0];
 
     // ---- pass B: one queued task per lane (lane < count) ---------------------------------------------------
     // A task is (read, meta): the lane fetches the 64 positions of every plane that end at its window's last column
@@ -131,13 +141,24 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         const int nr = RAGGED ? (act ? (int)(meta >> 17) : 0) : max_len;       // the read's own length
         uint32_t wp[4][2];
         {
-            const int b0 = j_e - PIECE_WINDOW, w0 = b0 >> 5;                     // floor: -2 .. NW - 2
-            const uint4 *tcur = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);
+            // (the stash holds what pass A saw: a ragged read moved to the end of its NW words, 32 NW - nr positions up)
+            const int b0 = j_e - PIECE_WINDOW + (STASH && RAGGED ? 32 * NW - nr : 0), w0 = b0 >> 5;     // floor: -2 .. NW - 2
             uint4 g0 = make_uint4(0u, 0u, 0u, 0u), g1 = g0, g2 = g0;
-            if (act) {
-                if (w0 >= 0) g0 = tcur[(size_t)w0 * 64];
-                if (w0 + 1 >= 0) g1 = tcur[(size_t)(w0 + 1) * 64];
-                if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = tcur[(size_t)(w0 + 2) * 64];
+            if constexpr (STASH) {
+                if (act) {
+                    if (w0 >= 0) g0 = stash[w0][lane];
+                    if (w0 + 1 >= 0) g1 = stash[w0 + 1][lane];
+                    if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = stash[w0 + 2][lane];
+                }
+            } else {
+#ifndef ATR_X_NOGATHER                                                     // (traffic calibration only: pass A's stream alone, records wrong)
+                const uint4 *tcur = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);
+                if (act) {
+                    if (w0 >= 0) g0 = tcur[(size_t)w0 * 64];
+                    if (w0 + 1 >= 0) g1 = tcur[(size_t)(w0 + 1) * 64];
+                    if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = tcur[(size_t)(w0 + 2) * 64];
+                }
+#endif
             }
             const uint32_t sh = (uint32_t)(b0 & 31);
             wp[0][0] = __builtin_amdgcn_alignbit(g1.x, g0.x, sh); wp[0][1] = __builtin_amdgcn_alignbit(g2.x, g1.x, sh);
@@ -305,7 +326,13 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             const uint64_t nm = __ballot(narrow);
             const int cnt = (int)__popcll(nm), rank = lane_rank(nm);
             const int room = 64 - qn;
-            const auto put = [&](int slot) { queue[0][slot] = (uint32_t)r; queue[1][slot] = meta; };
+            const auto put = [&](int slot) {
+                queue[0][slot] = (uint32_t)r; queue[1][slot] = meta;
+                if constexpr (STASH) {
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) stash[w][slot] = make_uint4(pl[w][0], pl[w][1], pl[w][2], pl[w][3]);
+                }
+            };
             if (narrow && rank < room) put(qn + rank);
             if (cnt >= room) {                                                // wave-uniform
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -371,7 +398,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         }
     }
     __syncthreads();
-    if (threadIdx.x < FILTER_BINS) wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] = s_hist[threadIdx.x];
+    fused_hist_flush(wk, s_hist);                                  // (locate_fast.hpp: offsets inside the bins by atomics, no scan launches)
     if (threadIdx.x == 0) wk.lcount[blockIdx.x] = s_lcur;
 }
 

@@ -30,8 +30,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATR_PIECE_W
 
 // P3: a block's list of (read, window word) -> the bins of `order` (offsets from K2's scan, an LDS cursor per bin)
 __global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, int m, FastWork wk) {
-    __shared__ uint32_t s_cur[FILTER_BINS];
-    if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] = fast_slot0(wk, threadIdx.x);
+    __shared__ uint32_t s_cur[FILTER_BINS + 1], s_tmp[256];
+    if (wk.fused) {
+        fused_bin_bases(wk, s_cur, s_tmp);
+        if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] += wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x];
+    } else if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] = fast_slot0(wk, threadIdx.x);
     __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
@@ -127,6 +130,11 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_
     wk.lpw = nreads <= 8192 ? 0 : 64;
     const int nw = (max_len + 31) / 32;
     const jit::SpecKernel *sk = piece_spec_for(a, fp, pp, lens != nullptr, max_len, nreads, false);
+    wk.fused = fast_fused_scan() ? 1 : 0;
+    if (wk.fused) {   // the bins' totals the pre-pass blocks add to (fused_hist_flush)
+        const hipError_t rc = hipMemsetAsync(wk.chunks, 0, (size_t)wk.nbins * 4, st);
+        if (rc != hipSuccess) return (int)rc;
+    }
     if (sk) {
         const long long want = ((nreads + 63) / 64 + 3) / 4;
         wk.nused = (int)std::max<long long>(1, std::min<long long>(sk->resident, want));
@@ -144,7 +152,7 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_
         default: launch_piece_filter<10>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         }
     }
-    launch_fast_scan(wk, st);
+    if (!wk.fused) launch_fast_scan(wk, st);
     hipLaunchKernelGGL(piece_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m, wk);
     return launch_fast_dp(a, planes, lens, nreads, nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true);
 }

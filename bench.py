@@ -49,10 +49,15 @@ def profile_counters(config):
         return json.load(fh)
 
 
-STREAMING_KERNELS = ("filter_kernel", "insert_kernel", "atr_piece_spec")   # stream the packed batch with 16 bytes per lane (see live_counters)
+STREAMING_KERNELS = ("filter_kernel", "insert_kernel")   # stream the packed batch with 16 bytes per lane (see live_counters)
 # kernels that stream the packed batch (16 bytes per lane, counted at half) AND fetch scattered bytes (counted in full):
-# raw FETCH_SIZE + the uncounted half of the stream, whose size is known -- bytes per unit
-MIXED_KERNELS = {"insert_correct_kernel": 128.0}    # C5's fused kernel: 2 reads x 8 chunks x 16 B per pair, half of it
+# raw FETCH_SIZE + the uncounted half of the stream, whose size is known -- bytes per unit.
+#   insert_correct_kernel   C5's fused kernel: 2 reads x 8 chunks x 16 B per pair, half of it
+#   atr_piece_spec / piece_filter_kernel   C2's pre-pass: pass A streams 5 chunks x 16 B per read (half of it: 40), pass B
+#       gathers three 16-byte pieces per flagged read.  Calibrated (profiles/round5_c2_fetch_calibration.txt): with pass
+#       B's gathers compiled out FETCH_SIZE reads 438 MB for the 800 MB stream (+ lists), with them 650 MB -- the 3.3 M
+#       extra requests are tallied at 64 B each; 2 x FETCH_SIZE (rounds 4 / 5 until this fix) counted them twice
+MIXED_KERNELS = {"insert_correct_kernel": 128.0, "atr_piece_spec": 40.0, "piece_filter_kernel": 40.0}
 
 
 def live_counters(config, reads, want_valu):
@@ -95,14 +100,16 @@ def live_counters(config, reads, want_valu):
         return None
     hbm = 0.0
     for name, v in totals["FETCH_SIZE"].items():
-        hbm += (2.0 if any(k in name for k in STREAMING_KERNELS) else 1.0) * v * 1024.0
-        for key, half_stream in MIXED_KERNELS.items():
-            if key in name:
-                hbm += half_stream * reads * calls
+        half_stream = next((h for key, h in MIXED_KERNELS.items() if key in name), None)
+        if half_stream is not None:
+            hbm += v * 1024.0 + half_stream * reads * calls
+        else:
+            hbm += (2.0 if any(k in name for k in STREAMING_KERNELS) else 1.0) * v * 1024.0
     hbm += sum(totals["WRITE_SIZE"].values()) * 1024.0
     res = {"hbm_bytes_per_launch": hbm / calls, "units_per_launch": reads,
-           "source": "this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %d calls each (2 x FETCH_SIZE for "
-                     "the 16-byte-per-lane streaming kernels, gfx950)" % calls}
+           "source": "this invocation: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of %d calls each (gfx950: 2 x FETCH_SIZE for "
+                     "the 16-byte-per-lane streaming kernels; FETCH_SIZE + the uncounted half of the known stream for "
+                     "kernels that stream and gather)" % calls}
     if want_valu:
         res["valu_wave_insts_per_launch"] = sum(totals["SQ_INSTS_VALU"].values()) / calls
     return res

@@ -10,7 +10,7 @@ python - $OUT "$FIRST" <<'PY'
 import csv, glob, sys, os
 rows = []
 for f in glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True):
-    rows += [r for r in csv.DictReader(open(f)) if "atr::" in r["Kernel_Name"]]
+    rows += [r for r in csv.DictReader(open(f)) if "atr::" in r["Kernel_Name"] or "atr_piece" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 starts = [i for i, r in enumerate(rows) if sys.argv[2] in r["Kernel_Name"]]
 lo = starts[-1]

@@ -16,9 +16,13 @@ import re
 import sys
 
 STREAMING = ("filter_kernel", "insert_kernel")        # 16-byte-per-lane coalesced streams of the packed batch
+# stream AND gather (bench.py MIXED_KERNELS): raw FETCH_SIZE + the uncounted half of the known stream, bytes per unit
+MIXED = {"insert_correct_kernel": 128.0, "atr_piece_spec": 40.0, "piece_filter_kernel": 40.0}
 
 
 def short(name):
+    if name.startswith("atr_piece"):
+        return name.strip()
     m = re.search(r"atr::(\w+)(<[^>]*>)?", name)
     return "atr::" + m.group(1) + (m.group(2) or "")
 
@@ -41,7 +45,7 @@ def main():
             counter = None
         if counter is None:
             continue
-        if "atr::" in line and not line.startswith(" "):
+        if ("atr::" in line or line.startswith("atr_piece")) and not line.startswith(" "):
             kernel = short(line)
         m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE): launches=(\d+) avg=([\d.]+)", line)
         if m and kernel:
@@ -65,6 +69,10 @@ def main():
             valu[kernel] = float(m.group(2)) * int(m.group(1)) / calls
     total = 0.0
     for k, v in per.items():
+        half = next((h for key, h in MIXED.items() if key in k), None)
+        if half is not None:
+            total += (v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0 + half * units
+            continue
         f = 2.0 if any(s in k for s in STREAMING) else 1.0
         total += (f * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
     out = {"workload": config, "units_per_launch": units, "hbm_bytes_per_launch": total,
