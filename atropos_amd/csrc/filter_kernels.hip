@@ -76,10 +76,11 @@ int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *len
         const int mts = round_up_rows(a->p.m) / ROW_GRAN - 1;
         return window_groups[mts / 4](mts % 4)(a, packed, lens, nreads, nchunks, max_len, out, wk, la, st, planes);
     }
-    const int nside = std::min(count, 3);
+    const int nside = (la && la->win_count != 1) ? 1 : std::min(count, 3);      // (one window launch for the whole set: one side stream)
     hipStream_t bst = st;
     if (idx == 0) {
-        for (int k = 0; k < nside; ++k) if (!side[k].ready()) return (int)hipErrorInvalidValue;
+        static const bool urgent = [] { const char *x = getenv("ATR_WINDOW_PRIORITY"); return !(x && x[0] == '0'); }();   // (A/B switch)
+        for (int k = 0; k < nside; ++k) if (!side[k].ready(urgent)) return (int)hipErrorInvalidValue;
         e = hipEventRecord(side[0].fork, st);
         for (int k = 0; k < nside && e == hipSuccess; ++k) e = hipStreamWaitEvent(side[k].stream, side[0].fork, 0);
         if (e != hipSuccess) return (int)e;

@@ -518,6 +518,11 @@ int atr_linked_create(const atr_linked_adapter *adapters, int n_adapters, atr_li
             }
             delete hb;
         }
+        if (!s->d_wave) {                                          // the band and window launches read it: no set without it
+            (void)hipFree(s->d_params);
+            delete s;
+            return ATR_ERR_NOMEM;
+        }
     }
     *out = s;
     return ATR_OK;
@@ -595,6 +600,15 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
                        (const uint16_t *)which, wk, lists);
     e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "linked scatter launch");
+    // one window launch for the whole set when the 3' aligners share window_kernel's template parameters (row class,
+    // indel mode): block row y serves adapter y (locate_fast.hpp) -- four launches of a few hundred long tasks each
+    // otherwise, on three side streams (C4: the fourth started when the first had drained, 40 us past the band launch)
+    static const bool one_window_on = [] { const char *x = getenv("ATR_ONE_WINDOW"); return !(x && x[0] == '0'); }();   // (A/B switch)
+    bool one_window = s->p.n > 1 && one_window_on;
+    for (int a = 1; a < s->p.n; ++a)
+        one_window = one_window && round_up_rows(s->back[a].p.m) == round_up_rows(s->back[0].p.m) &&
+                     (s->back[a].indel_cost > s->back[a].p.k) == (s->back[0].indel_cost > s->back[0].p.k);
+    const LinkedWaveBlob *wblob = (const LinkedWaveBlob *)s->d_wave;
     for (int a = 0; a < s->p.n; ++a) {
         LinkedArgs la;
         la.bin0 = a * FILTER_BINS;
@@ -602,6 +616,10 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
         la.post = s->post[a];
         la.multi = s->d_wave;                                      // every adapter's band reads in one launch (idx 0)
         la.multi_and = s->p.and_mode != 0;
+        la.multi_p = wblob->p;                                     // (addresses inside the device blob; not read here)
+        la.multi_post = wblob->post;
+        la.a0 = a;
+        la.win_count = one_window ? (a == 0 ? s->p.n : 0) : 1;
         const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st, false);
         if (rc != 0) return hip_fail((hipError_t)rc, "linked band / window launch");
     }

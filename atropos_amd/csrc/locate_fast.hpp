@@ -56,6 +56,12 @@ struct LinkedArgs {
     LinkedPost post;
     const void *multi;                               // host side only: the set's device blob for linked_band_kernel (or null:
     bool multi_and;                                  //   one band_kernel launch per adapter), its compare mode
+    // window_kernel<.., LINKED> reads its adapter's parameters from the set's device blob (scalar loads): block row y of
+    // the launch serves adapter a0 + y, so that the window reads of every adapter of a set whose 3' parts share the
+    // kernel's template parameters go out in ONE launch (win_count rows; host side: 0 = this adapter rides with adapter 0)
+    const LocateParams *multi_p;
+    const LinkedPost *multi_post;
+    int a0, win_count;
 };
 
 // blocks a batch of ntiles tiles keeps busy with four waves each (K1 / K3 of a short batch are launched with these)
@@ -342,8 +348,16 @@ __global__ __launch_bounds__(256) void prefix_band_kernel(const LocateParams p, 
 }
 #endif  // ATR_DEFINE_FILTER_KERNELS
 
+// the aligner parameters of a window launch: the kernel argument, or -- linked sets -- the adapter's block of the set's
+// device blob (LinkedArgs)
+template <bool LINKED>
+__device__ __forceinline__ const LocateParams &window_params(const LocateParams &p_arg, const LinkedArgs &la, int ad) {
+    if constexpr (LINKED) return la.multi_p[ad];
+    else return p_arg;
+}
+
 template <int MT, bool NOINDEL, bool LINKED, bool PLANES = false>
-__global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const uint4 *__restrict__ packed,
+__global__ __launch_bounds__(256) void window_kernel(const LocateParams p_arg, const uint4 *__restrict__ packed,
                                                      const int32_t *__restrict__ lens, long long nreads,
                                                      int nchunks, int max_len, uint4 *__restrict__ out, FastWork wk,
                                                      const LinkedArgs la) {
@@ -352,6 +366,8 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     __shared__ __attribute__((aligned(16))) uint32_t s_nm[16][4];
     __shared__ uint32_t s_spread_flat[PLANES ? 1024 : 1];          // plane64 reads
     uint32_t (*s_spread)[256] = (uint32_t (*)[256])s_spread_flat;
+    const int ad = LINKED ? la.a0 + (int)blockIdx.y : 0;          // linked set: the adapter this block row serves
+    const LocateParams &p = window_params<LINKED>(p_arg, la, ad);
     const Uniform u = make_uniform(p, MT);
     if (threadIdx.x < 64) s_nm[threadIdx.x >> 2][threadIdx.x & 3] = p.nmask[threadIdx.x >> 2][threadIdx.x & 3];
     for (int i = threadIdx.x; i <= MT + 1; i += 256) {
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
     if constexpr (PLANES) piece_spread_fill(s_spread);
     __syncthreads();
     // the slots [first, total) of `order`: everything but the band reads (K4a)
-    const int bin0 = LINKED ? la.bin0 : 0;
+    const int bin0 = LINKED ? ad * FILTER_BINS : 0;
     const long long first = (long long)wk.binbase[bin0 + BAND_BINS], total = (long long)wk.binbase[bin0 + FILTER_BINS];
     const int lane = threadIdx.x & 63;
     const int lpw = dp_lanes_per_wave(total - first, (long long)gridDim.x * 4, wk.lpw);
@@ -488,9 +504,11 @@ __global__ __launch_bounds__(256) void window_kernel(const LocateParams p, const
         if (live) {
             uint32_t rec[4];
             lane_result<MT>(L, u, rec);
-            if (LINKED)
-                linked_finish(rec, s_lane, la.post.m, la.post.min_overlap, la.post.pf_thr, la.post.accept_full != 0,
-                              la.post.rmp, la.post.rmp_ld, la.post.max_rmp);
+            if constexpr (LINKED) {
+                const LinkedPost &post = la.multi_post[ad];
+                linked_finish(rec, s_lane, post.m, post.min_overlap, post.pf_thr, post.accept_full != 0,
+                              post.rmp, post.rmp_ld, post.max_rmp);
+            }
             out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
         }
     }
@@ -507,8 +525,10 @@ int launch_window_mt(const atr_aligner *a, const uint4 *packed, const int32_t *l
     // (one block of four waves per 4 reads at the low end: a short batch gets a wave per task)
     const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((nreads + 3) / 4, 4096))), block(256);
     if (la) {
-        if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
-        else         hipLaunchKernelGGL((window_kernel<MT, false, true>), grid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+        if (la->win_count < 1) return 0;                         // (rides with adapter 0's launch)
+        const dim3 lgrid(grid.x, (unsigned)la->win_count);
+        if (noindel) hipLaunchKernelGGL((window_kernel<MT, true, true>), lgrid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
+        else         hipLaunchKernelGGL((window_kernel<MT, false, true>), lgrid, block, 0, st, a->p, packed, lens, nreads, nchunks, max_len, out, wk, *la);
     } else if (planes) {                                         // plane64 reads (two-pass pre-pass, piece_kernels.hip)
         LinkedArgs none;
         memset(&none, 0, sizeof(none));

@@ -12,12 +12,19 @@ struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
     int device = -1;
-    bool ready() {
+    // urgent: the stream is created with the device's highest priority -- for launches of FEW, LONG tasks next to a launch
+    // of many short ones on the caller's stream (the window launch next to the band launch: its waves then take the
+    // slots that come free first instead of queueing behind 16 k band waves)
+    bool ready(bool urgent = false) {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) return false;
         if (stream && dev == device) return true;
         release();
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
+        int least = 0, greatest = 0;
+        if (urgent && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+            if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, greatest) != hipSuccess) { stream = nullptr; (void)hipGetLastError(); }
+        }
+        if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) { stream = nullptr; return false; }
         if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { release(); return false; }
         device = dev;
