@@ -207,7 +207,7 @@ class C2(object):
             return "locate_kernel<36,eq,indel>"
         if self.batch.layout == "plane64":
             return ("piece_filter_kernel<5> (pass A: exact pieces on bit planes; pass B: windowed bit-vector sweep of the flagged "
-                    "reads) + scan + piece_scatter + band_kernel + window_kernel<36,eq,indel,planes> (one atr_locate_planes_batch call)")
+                    "reads) + piece_scatter + band_kernel + window_kernel<36,eq,indel,planes> (one atr_locate_planes_batch call)")
         return "filter_kernel + scan + scatter + band_kernel + window_kernel<36,eq,indel> (one atr_locate_batch call)"
 
     def note(self, kernel_ms):
@@ -447,8 +447,8 @@ class C4(object):
                 "reads_with_two_fronts": int((wc[:, 1] > 1).sum().item())}
 
     def kernel(self):
-        return ("linked_filter_kernel + scan + linked_scatter + 4 x (band_kernel + window_kernel<36>) "
-                "(one atr_linked_match_batch call)")
+        return ("linked_filter_kernel + linked_scatter + linked_band_kernel || window_kernel<36> (one launch each for the "
+                "four adapters; one atr_linked_match_batch call)")
 
     def note(self, kernel_ms):
         return "integer-VALU bound: 4 anchored 5' sweeps + one 3' pre-pass per read in one kernel"
