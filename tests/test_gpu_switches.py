@@ -58,5 +58,5 @@ def test_switches_change_no_record(hip_backend):
     assert base["c2_matched"] > 100000 and base["c4_back_matched"] > 100000
     for env in ({"ATR_FUSED_SCAN": "0"}, {"ATR_ONE_WINDOW": "0", "ATR_WINDOW_PRIORITY": "0"},
                 {"ATR_JIT": "0"}, {"ATR_JIT": "1", "ATR_SPEC_FLAGS": "-DATR_PIECE_STASH=0"},
-                {"ATR_FUSED_SCAN": "0", "ATR_ONE_WINDOW": "0", "ATR_PAIRS_PRIORITY": "0"}):
+                {"ATR_FUSED_SCAN": "0", "ATR_ONE_WINDOW": "0"}):
         assert _run(env) == base, env
