@@ -334,12 +334,9 @@ hipError_t launch_pairs_fast(const PairParams &p, double e_rate, const uint32_t 
     bool forked = false;
     if (e == hipSuccess) {
         forked = true;
-        // The device serves four hardware queues per priority level: nine streams of one level share four queues, and a
-        // class queues behind the class it shares a queue with whatever room the chip has.  The wide classes (few tasks,
-        // long lanes) and the full sweep get streams of the highest priority -- a second set of queues, and their waves
-        // take the slots that come free first.  (ATR_PAIRS_PRIORITY=0: all at default priority)
-        static const bool prio = [] { const char *x = getenv("ATR_PAIRS_PRIORITY"); return !(x && x[0] == '0'); }();
-        for (int c = 0; c < NSIDE && forked; ++c) forked = side[c].ready(prio && c >= PF_CLASSES / 2);
+        // (More hardware queues for these launches -- priority streams, GPU_MAX_HW_QUEUES -- were measured: every launch
+        //  then starts at once and the call gets slower, profiles/round5_pairs_hw_queues_experiment.txt.)
+        for (int c = 0; c < NSIDE && forked; ++c) forked = side[c].ready();
         if (forked) {
             e = hipEventRecord(side[0].fork, st);
             for (int c = 0; c < NSIDE && e == hipSuccess; ++c) e = hipStreamWaitEvent(side[c].stream, side[0].fork, 0);
