@@ -106,6 +106,62 @@ def test_c4_shard_against_oracle(hip_backend, oracle):
     assert np.array_equal(rb[:100_000, :6].cpu().numpy().astype(np.int32), eb)
 
 
+def test_linked_long_batches_mixed_sets(hip_backend, oracle):
+    """Long batches (> 262 144 reads: per-block lists, offsets by atomics, one band launch, window launches by row class)
+    of linked sets whose 3' aligners do NOT share a row class / indel mode -- a window launch per adapter, each reading
+    its adapter's block of the set's device blob -- and of uniform sets of two and three adapters (one window launch):
+    a slice against the oracle, the whole batch against the same reads in short batches (the wavefront-per-read finish
+    or the window-word path: other kernels), equal-length and ragged."""
+    import numpy as np
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.adapters import AsciiSource, LinkedAdapter, LinkedSet, upper_ascii
+    rng = np.random.default_rng(97)
+
+    def rseq(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    n = 300_000
+    cases = [  # (5' length, 3' lengths, e, indel cost, min_overlap)
+        (16, (20, 34, 45, 60), 0.1, 1, 3),          # four row classes
+        (20, (34, 33, 12), 0.12, 1, 3),             # two classes
+        (18, (34, 34), 0.1, 1, 3),                  # uniform pair: one window launch with two block rows
+        (20, (33, 34, 36), 0.12, 1, 5),             # uniform triple
+        (14, (30, 34, 40, 24), 0.1, 5, 3),          # indel cost above every k: no-indel windows, mixed classes
+    ]
+    ran = 0
+    for ci, (fl, bls, e, indel, mo) in enumerate(cases):
+        fronts, backs = [rseq(fl) for _ in bls], [rseq(b) for b in bls]
+        reads = upper_ascii(synth.linked(ci * n, n, 150, fronts, backs, 0xC4C4 + ci, "cuda"))
+        las = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=e, min_overlap=mo,
+                             indel_cost=indel) for f, b in zip(fronts, backs)]
+        lset = LinkedSet(las)
+        if not lset.fused:
+            continue
+        ran += 1
+        for ragged in (False, True):
+            lens = None
+            if ragged:
+                g = torch.Generator(device="cuda").manual_seed(5 + ci)
+                lens = torch.randint(50, 151, (n,), generator=g, device="cuda", dtype=torch.int32)
+            which, count, front, back = lset.match_source(AsciiSource(reads, lens))
+            k = 60_000
+            lo = 123_457
+            ew, ef, eb = oracle.linked_many(fronts, backs, reads[lo:lo + k].cpu().numpy(),
+                                            np.full(k, 150, np.int32) if lens is None else lens[lo:lo + k].cpu().numpy(),
+                                            e, mo, indel, True, False, 8)
+            assert np.array_equal(which[lo:lo + k].cpu().numpy(), ew[:, 0].astype(np.int32)), (ci, ragged)
+            assert np.array_equal(count[lo:lo + k].cpu().numpy(), ew[:, 1].astype(np.int32)), (ci, ragged)
+            assert np.array_equal(front[lo:lo + k, :6].cpu().numpy().astype(np.int32), ef), (ci, ragged)
+            assert np.array_equal(back[lo:lo + k, :6].cpu().numpy().astype(np.int32), eb), (ci, ragged)
+            assert (eb[:, 1] >= 0).mean() > 0.05 and (ew[:, 0] >= 0).mean() > 0.5
+            for a in range(0, n, 100_000):
+                part = lset.match_source(AsciiSource(reads[a:a + 100_000].contiguous(), None if lens is None else lens[a:a + 100_000].contiguous()))
+                assert torch.equal(part[0], which[a:a + 100_000]) and torch.equal(part[1], count[a:a + 100_000]), (ci, ragged, a)
+                assert torch.equal(part[2], front[a:a + 100_000]) and torch.equal(part[3], back[a:a + 100_000]), (ci, ragged, a)
+    assert ran >= 4, ran
+
+
 def test_linked_golden(hip_backend):
     total, fused = _cases.check_linked_golden()
     assert total == 3840 and fused > 60
