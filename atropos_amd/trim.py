@@ -81,7 +81,7 @@ class TrimResult(object):
         recs = self.read_batch.records.cpu().numpy().astype("int64")
         recs[:, [0, 2, 4]] &= 0xFFFFFFFF                       # (offsets are unsigned 32-bit)
         final = self.batch.records.cpu().numpy().astype("int64")           # (an unmatched read's line carries its final name)
-        final[:, 0] &= 0xFFFFFFFF
+        final[:, [0, 4]] &= 0xFFFFFFFF
         raw_final = raw if self.batch is self.read_batch else bytes(self.batch.data.cpu().numpy().tobytes())
         fb, fe = self.begin.cpu().numpy(), self.end.cpu().numpy()
         rounds = [tuple(t.cpu().numpy() for t in r) for r in self.rounds]
@@ -107,7 +107,9 @@ class TrimResult(object):
             if "info" in out:
                 if last is None:
                     seq = raw[so + fb[i]:so + max(fb[i], fe[i])].decode("ascii", "replace")
-                    qual = raw[qo + fb[i]:qo + max(fb[i], fe[i])].decode("ascii", "replace") if has_q else ""
+                    # (an unmatched read's line is written from the read as it leaves the pipeline: zero-capped qualities)
+                    fqo = int(final[i, 4])
+                    qual = raw_final[fqo + fb[i]:fqo + max(fb[i], fe[i])].decode("ascii", "replace") if has_q else ""
                     lines = ["\t".join((fname, "-1", seq, qual))]
                 out["info"][i] = lines
             if last is None:
@@ -393,6 +395,8 @@ class TrimPipeline(object):
         dest = self._filter_stage(batch, begin, end, ubegin, uend, matched)
         rounds, self._rounds = self._rounds, None
         if self.zero_cap and n:
+            if rounds is not None and unmasked is None:            # a match's info record shows the read as the match saw it:
+                unmasked = batch.data.clone()                      # before ZeroCapper (align/__init__.py:145-170)
             self._zero_cap(batch)
         read_batch = batch if unmasked is None else FastqBatch(unmasked, batch.nbytes, batch.records, batch.backend,
                                                                batch.line_ends)
@@ -824,9 +828,11 @@ class PairedTrimPipeline(object):
         res = []
         for k in range(2):
             pipe, read_batch = pipes[k], batches[k]
+            rounds, pipe._rounds = pipe._rounds, None
+            if pipe.zero_cap and n and rounds is not None and unmasked[k] is None:
+                unmasked[k] = batches[k].data.clone()              # (the info records of matched reads: before ZeroCapper)
             if unmasked[k] is not None:
                 read_batch = FastqBatch(unmasked[k], read_batch.nbytes, read_batch.records, read_batch.backend, read_batch.line_ends)
-            rounds, pipe._rounds = pipe._rounds, None
             if pipe.zero_cap and n:
                 pipe._zero_cap(batches[k])
             if pipe._name_mods and n:
