@@ -20,11 +20,6 @@ namespace atr {
 #ifndef ATR_PIECE_STASH
 #define ATR_PIECE_STASH 1
 #endif
-// Tiles dealt to the four waves of a block as they come free (an LDS counter) instead of every fourth tile to each: a
-// wave whose tiles held more flagged reads no longer finishes last with its mates idle.
-#ifndef ATR_PIECE_DYNAMIC
-#define ATR_PIECE_DYNAMIC 0
-#endif
 #ifndef ATR_PIECE_WAVES
 #ifdef ATR_SPEC
 #define ATR_PIECE_WAVES(NW) ((NW) <= 6 ? 4 : 3)                         // (no spills at these: tools/jit/spec_offline.sh)
@@ -112,8 +107,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
 #endif
     if (threadIdx.x < 16) s_peq[threadIdx.x] = make_uint2((uint32_t)fp_arg.peq[threadIdx.x], (uint32_t)(fp_arg.peq[threadIdx.x] >> 32));
     if (threadIdx.x < FILTER_BINS) s_hist[threadIdx.x] = 0;
-    __shared__ uint32_t s_next;                                   // ATR_PIECE_DYNAMIC: the block's next tile (offset from t0)
-    if (threadIdx.x == 0) { s_lcur = 0; s_wcnt = 0; s_next = 0; }
+    if (threadIdx.x == 0) { s_lcur = 0; s_wcnt = 0; }
     piece_spread_fill(s_spread);
     __syncthreads();
 
@@ -234,29 +228,12 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     // its registers are free": two iterations in three then consumed them a queue insertion later -- the wave sat
     // through the whole latency, 40 % of its time by s_memtime.)  20 more registers through pass A: 72 of the 96.
     uint4 nx[NW];
-#if ATR_PIECE_DYNAMIC
-    const auto take = [&]() -> long long {
-        uint32_t v = 0u;
-        if (lane == 0) v = atomicAdd(&s_next, 1u);
-        return t0 + (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-    };
-    long long tile_first = take(), tile_next = take();
-#else
-    const long long tile_first = t0 + wave;
-#endif
-    if (tile_first < t1) {
-        const uint4 *tp = planes + (size_t)tile_first * NW * 64;              // (wave-uniform base + lane: scalar base, 32-bit offset)
+    if (t0 + wave < t1) {
+        const uint4 *tp = planes + (size_t)(t0 + wave) * NW * 64;             // (wave-uniform base + lane: scalar base, 32-bit offset)
 #pragma unroll
         for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
     }
-#if ATR_PIECE_DYNAMIC
-    for (long long tile = tile_first; tile < t1;) {
-        const long long tile_after = tile_next;                   // the tile whose planes are requested in this iteration
-        tile_next = take();                                       // (the LDS round trip runs under pass A)
-#else
-    for (long long tile = tile_first; tile < t1; tile += 4) {
-        const long long tile_after = tile + 4;
-#endif
+    for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
         const bool live = r < nreads;
         // ---- pass A ----
@@ -264,8 +241,8 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
 #pragma unroll
         for (int w = 0; w < NW; ++w) { pl[w][0] = nx[w].x; pl[w][1] = nx[w].y; pl[w][2] = nx[w].z; pl[w][3] = nx[w].w; }
 #if ATR_PIECE_PREFETCH_EARLY
-        if (tile_after < t1) {
-            const uint4 *tp = planes + (size_t)tile_after * NW * 64;
+        if (tile + 4 < t1) {
+            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64;
 #pragma unroll
             for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
         }
@@ -338,8 +315,8 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         }
 #if !ATR_PIECE_PREFETCH_EARLY
         __builtin_amdgcn_sched_barrier(0);
-        if (tile_after < t1) {                                                  // the next tile's planes
-            const uint4 *tp = planes + (size_t)tile_after * NW * 64;
+        if (tile + 4 < t1) {                                                  // the next tile's planes
+            const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64;
 #pragma unroll
             for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
         }
@@ -367,9 +344,6 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
                 qn += cnt;
             }
         }
-#if ATR_PIECE_DYNAMIC
-        tile = tile_after;
-#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (qn > 0) pass_b(qn);
