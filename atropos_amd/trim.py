@@ -1092,8 +1092,17 @@ def pipeline_from_args(argv, paired_input=False):
                 parts = [int(x) for x in arg.split(",")]
                 if len(parts) != 4:
                     raise ValueError("Invalidate format for bisulfite parameters")
-                specs.append(None if parts[0] <= 0 and parts[1] <= 0 else
-                             [("min", max(parts[0], 0), max(parts[1], 0), bool(parts[2]), bool(parts[3]))])
+                # (cli.py:714-729: the flags index the tuple (False, True) -- 0 / 1, and -2 / -1 by Python's indexing; anything
+                #  else is the parser's format error.  One negative length is accepted there and handed to MinCutter as
+                #  it is: refused here rather than guessed at.)
+                if any(f not in (0, 1, -1, -2) for f in parts[2:]):
+                    raise ValueError("Invalidate format for bisulfite parameters")
+                if parts[0] <= 0 and parts[1] <= 0:
+                    specs.append(None)
+                    continue
+                if parts[0] < 0 or parts[1] < 0:
+                    raise NotImplementedError("--bisulfite with a negative length next to a positive one")
+                specs.append([("min", parts[0], parts[1], (False, True)[parts[2]], (False, True)[parts[3]])])
             if paired and len(specs) == 1:
                 specs = [specs[0], specs[0]]
             elif not paired and len(specs) > 1:
