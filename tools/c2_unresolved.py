@@ -49,3 +49,12 @@ for k in range(0, m + 1, 4):
     sel = open_ & found & ~full & (rl >= k) & (rl < k + 4)
     if sel.sum():
         show("   partial, %2d .. %2d adapter bases" % (k, k + 3), sel)
+# the window reads: why no band took them (window word: [9:0] j_lo, [19:10] j_hi, [20] last-column candidates, [27:21] rows)
+wsel = open_ & ~band
+j_lo, j_hi, rows = (win & 1023).astype(np.int64), ((win >> 10) & 1023).astype(np.int64), ((win >> 21) & 127).astype(np.int64)
+print("window reads: %d; with last-column candidates %d, row-m only %d" % (wsel.sum(), (wsel & scan).sum(), (wsel & ~scan).sum()))
+for name, sel in (("row-m only", wsel & ~scan), ("with last-column candidates", wsel & scan)):
+    if sel.sum():
+        wd = (j_hi - j_lo)[sel]
+        print("  %-28s window columns: mean %.1f  p50 %d  p90 %d  max %d; rows mean %.1f; query start of the match: mean %.1f" % (
+            name, wd.mean(), np.percentile(wd, 50), np.percentile(wd, 90), wd.max(), rows[sel].mean(), rec[sel, 2].mean()))
