@@ -124,15 +124,19 @@ __device__ __forceinline__ void fused_bin_bases(const FastWork &wk, uint32_t *s_
     uint32_t v[4], sum = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { v[i] = i < per ? wk.chunks[t * per + i] : 0u; sum += v[i]; }
-    s_tmp[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {                      // Hillis-Steele inclusive scan of the 256 partial sums
-        const uint32_t add = t >= off ? s_tmp[t - off] : 0u;
-        __syncthreads();
-        s_tmp[t] += add;
-        __syncthreads();
+    // inclusive scan of the 256 partial sums: inside the wave by shuffles, the four waves' totals through LDS (two
+    // barriers; the scatter pass of a linked set runs 8 192 blocks through this prologue)
+    const int lane = t & 63, wv = t >> 6;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += o;
     }
-    uint32_t run = s_tmp[t] - sum;
+    if (lane == 63) s_tmp[wv] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wv; ++w) run += s_tmp[w];
 #pragma unroll
     for (int i = 0; i < 4; ++i) if (i < per) { s_base[t * per + i] = run; run += v[i]; }
     if (t == 255) s_base[wk.nbins] = run;

@@ -437,22 +437,32 @@ struct LinkedLens { int m[LINKED_MAX]; };
 __global__ __launch_bounds__(256) void linked_scatter_kernel(long long nreads, const LinkedLens ms, int by_rows,
                                                              const uint16_t *__restrict__ which_out, FastWork wk, int lists) {
     __shared__ uint32_t s_cur[LINKED_MAX * FILTER_BINS + 1], s_tmp[256];
+    const long long ntiles = (nreads + 63) >> 6;
+    long long t0, t1;
+    block_tiles(ntiles, t0, t1, wk.nused);
+    // (the block is one chain of dependent round trips; what does not depend on the scan is requested before it: the
+    //  block's offsets, its list length, every thread's first entry and that read's adapter -- 8 192 blocks, four rounds)
+    const uint2 *list = wk.tmp + t0 * 64;
+    const uint32_t count = lists ? wk.lcount[blockIdx.x] : 0u;
+    const uint2 first = threadIdx.x < count ? list[threadIdx.x] : make_uint2(0u, 0u);
+    const int first_which = threadIdx.x < count ? (int)(which_out[first.x] & 0xFFu) : 0;
     if (wk.fused) {                                                // (no scan launches before this one: fast_work.hpp)
+        uint32_t mine[LINKED_MAX];
+#pragma unroll
+        for (int q = 0; q < LINKED_MAX; ++q)
+            mine[q] = (int)threadIdx.x + 256 * q < wk.nbins ? wk.counts[(size_t)blockIdx.x * wk.nbins + threadIdx.x + 256 * q] : 0u;
         fused_bin_bases(wk, s_cur, s_tmp);
-        for (int b = threadIdx.x; b < wk.nbins; b += 256) s_cur[b] += wk.counts[(size_t)blockIdx.x * wk.nbins + b];
+#pragma unroll
+        for (int q = 0; q < LINKED_MAX; ++q)
+            if ((int)threadIdx.x + 256 * q < wk.nbins) s_cur[threadIdx.x + 256 * q] += mine[q];
     } else {
         for (int b = threadIdx.x; b < wk.nbins; b += 256) s_cur[b] = fast_slot0(wk, b);
     }
     __syncthreads();
-    const long long ntiles = (nreads + 63) >> 6;
-    long long t0, t1;
-    block_tiles(ntiles, t0, t1, wk.nused);
     if (lists) {                                                   // the block's list of (read, window word)
-        const uint2 *list = wk.tmp + t0 * 64;
-        const uint32_t count = wk.lcount[blockIdx.x];
         for (uint32_t i = threadIdx.x; i < count; i += 256) {
-            const uint2 e = list[i];
-            const int which = (int)(which_out[e.x] & 0xFFu);
+            const uint2 e = i == threadIdx.x ? first : list[i];
+            const int which = i == threadIdx.x ? first_which : (int)(which_out[e.x] & 0xFFu);
             wk.order[atomicAdd(&s_cur[linked_bin(e.y, which, ms.m[which], by_rows != 0)], 1u)] = e;
         }
         return;

@@ -31,18 +31,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATR_PIECE_W
 // P3: a block's list of (read, window word) -> the bins of `order` (offsets from K2's scan, an LDS cursor per bin)
 __global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, int m, FastWork wk) {
     __shared__ uint32_t s_cur[FILTER_BINS + 1], s_tmp[256];
-    if (wk.fused) {
-        fused_bin_bases(wk, s_cur, s_tmp);
-        if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] += wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x];
-    } else if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] = fast_slot0(wk, threadIdx.x);
-    __syncthreads();
     const long long ntiles = (nreads + 63) >> 6;
     long long t0, t1;
     block_tiles(ntiles, t0, t1, wk.nused);
+    // the block is one chain of dependent round trips (totals -> offsets -> entry -> LDS cursor -> store): everything that
+    // does not depend on the scan is requested before it -- the block's offsets, its list length, every thread's first entry
     const uint2 *list = wk.tmp + t0 * 64;
     const uint32_t count = wk.lcount[blockIdx.x];
+    const uint32_t mine = threadIdx.x < FILTER_BINS ? wk.counts[(size_t)blockIdx.x * FILTER_BINS + threadIdx.x] : 0u;
+    const uint2 first = threadIdx.x < count ? list[threadIdx.x] : make_uint2(0u, 0u);
+    if (wk.fused) {
+        fused_bin_bases(wk, s_cur, s_tmp);
+        if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] += mine;
+    } else if (threadIdx.x < FILTER_BINS) s_cur[threadIdx.x] = fast_slot0(wk, threadIdx.x);
+    __syncthreads();
     for (uint32_t i = threadIdx.x; i < count; i += 256) {
-        const uint2 e = list[i];
+        const uint2 e = i == threadIdx.x ? first : list[i];
         const uint32_t slot = atomicAdd(&s_cur[window_bin(e.y & ~PIECE_NODENSE, m, true)], 1u);
         wk.order[slot] = e;
         wk.dref[slot] = (uint32_t)(t0 * 64) + i;                  // the entry's 64-code record in tdata
