@@ -1004,10 +1004,17 @@ def pipeline_from_args(argv, paired_input=False):
             raise ValueError("You cannot remove bases from more than two ends.")
         if len(cm) == 2 and cm[0] * cm[1] > 0:
             raise ValueError("You cannot remove bases from the same end twice.")
-    if paired_input and not paired:
-        # cli.py:630-641: these also switch legacy mode off
-        paired = bool(o.quality_cutoff or o.trim_n or o.too_short_paired_output or o.too_long_paired_output)
-        legacy = not paired
+    if paired_input:
+        # cli.py:630-641, the reference's own list: any of these asks for full paired-end trimming, none of them is its
+        # legacy mode (--aligner insert and -R are NOT on it: the reference then modifies read 1 alone, which the insert
+        # aligner and the merge stage have no meaning for -- refused here rather than run as something else)
+        full = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.cut_min2 or o.quality_cutoff or o.trim_n or
+                    o.pair_filter or o.too_short_paired_output or o.too_long_paired_output)
+        if not full and (o.aligner == "insert" or o.merge_overlapping):
+            raise NotImplementedError("--aligner insert / --merge-overlapping with paired-end input and none of the options "
+                                      "that switch the reference's legacy mode off (trim/cli.py:630-641)")
+        legacy = not full
+        paired = full
     else:
         legacy = False
     if o.merge_min_overlap <= 0:
