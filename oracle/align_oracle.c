@@ -26,6 +26,9 @@
  *   orc_correct_errors                atropos/commands/trim/modifiers.py:219-350 (ErrorCorrectorMixin.correct_errors)
  *   orc_insert_correct_many           atropos/commands/trim/modifiers.py:397-404, :448-449 (the correction step of
  *                                     InsertAdapterCutter.__call__ right after an insert match with errors)
+ *   orc_quality_trim_index            atropos/commands/trim/_qualtrim.pyx:7-50  (quality_trim_index)
+ *   orc_nextseq_trim_index            atropos/commands/trim/_qualtrim.pyx:53-84 (nextseq_trim_index)
+ *   orc_n_end_trim                    atropos/commands/trim/modifiers.py:766-784 (NEndTrimmer: ^N+ / N+$, upper-case N only)
  *   orc_locate_many / orc_linked_many / orc_match_insert_many (threaded drivers) -- harness only, no reference twin
  *
  * The DP keeps the reference's exact evaluation order: one column of
@@ -817,4 +820,50 @@ int orc_insert_correct_many(const int *records, char *seq1, char *qual1, const i
     if (nthreads > 1) for (int t = 0; t < nthreads; ++t) { void *rv = 0; pthread_join(th[t], &rv); bad |= rv != 0; }
     free(th); free(jobs);
     return bad ? -1 : 0;
+}
+
+/* ---- quality trimming (atropos/commands/trim/_qualtrim.pyx) --------------------------------------------------
+ * quality_trim_index (:7-50): BWA's running-sum rule from both ends.  5' end: s += cutoff_front - q[i] from i = 0,
+ * stop at the first negative sum, start = one past the position of the LAST strict maximum of the sums seen; 3' end
+ * the same from the back with cutoff_back; an empty or inverted segment is (0, 0).  All in C int like the reference's
+ * cdef ints; qualities are characters, q = ord(c) - base. */
+void orc_quality_trim_index(const char *qual, int n, int cutoff_front, int cutoff_back, int base, int *start_out,
+                            int *stop_out) {
+    int s = 0, max_qual = 0, start = 0, stop = n;
+    for (int i = 0; i < n; ++i) {
+        s += cutoff_front - ((int)(unsigned char)qual[i] - base);
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; start = i + 1; }
+    }
+    max_qual = 0; s = 0;
+    for (int i = n - 1; i >= 0; --i) {
+        s += cutoff_back - ((int)(unsigned char)qual[i] - base);
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; stop = i; }
+    }
+    if (start >= stop) { start = 0; stop = 0; }
+    *start_out = start; *stop_out = stop;
+}
+
+/* nextseq_trim_index (:53-84): the 3' rule with every 'G' (upper case only: bases[i] == 'G') counted at quality
+ * cutoff - 1, i.e. as one unit towards trimming. */
+int orc_nextseq_trim_index(const char *bases, const char *qual, int n, int cutoff, int base) {
+    int s = 0, max_qual = 0, max_i = n;
+    for (int i = n - 1; i >= 0; --i) {
+        int q = (int)(unsigned char)qual[i] - base;
+        if (bases[i] == 'G') q = cutoff - 1;
+        s += cutoff - q;
+        if (s < 0) break;
+        if (s > max_qual) { max_qual = s; max_i = i; }
+    }
+    return max_i;
+}
+
+/* NEndTrimmer.__call__ (modifiers.py:776-784): re '^N+' and 'N+$' on the sequence as it stands (no case folding).
+ * A read of N's only: start_cut = n, end_cut = 0 -- subseq(read, n, 0) is the empty read. */
+void orc_n_end_trim(const char *bases, int n, int *start_out, int *stop_out) {
+    int a = 0, b = n;
+    while (a < n && bases[a] == 'N') ++a;
+    while (b > 0 && bases[b - 1] == 'N') --b;
+    *start_out = a; *stop_out = b;
 }

@@ -83,6 +83,12 @@ def lib():
         L.orc_insert_correct_many.argtypes = [C.c_void_p] * 7 + [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p,
                                                                  C.c_void_p, C.c_int]
         L.orc_insert_correct_many.restype = C.c_int
+        L.orc_quality_trim_index.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, I6, I6]
+        L.orc_quality_trim_index.restype = None
+        L.orc_nextseq_trim_index.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        L.orc_nextseq_trim_index.restype = C.c_int
+        L.orc_n_end_trim.argtypes = [C.c_char_p, C.c_int, I6, I6]
+        L.orc_n_end_trim.restype = None
         L.orc_acgt_table.argtypes = [C.c_char_p]
         L.orc_iupac_table.argtypes = [C.c_char_p]
         _lib = L
@@ -394,3 +400,26 @@ def insert_correct_many(records, seq1, qual1, lens1, seq2, qual2, lens2, mismatc
     if rc != 0:
         raise MemoryError
     return changed, newlen
+
+
+def quality_trim_index(qualities, cutoff_front, cutoff_back, base=33):
+    """quality_trim_index(qualities, cutoff_front, cutoff_back, base) of _qualtrim.pyx:7-50 -> (start, stop)."""
+    q = _b(qualities)
+    a, b = C.c_int(), C.c_int()
+    lib().orc_quality_trim_index(q, len(q), int(cutoff_front), int(cutoff_back), int(base), C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def nextseq_trim_index(sequence, qualities, cutoff, base=33):
+    """nextseq_trim_index(read, cutoff, base) of _qualtrim.pyx:53-84 on the read's two strings -> stop."""
+    s, q = _b(sequence), _b(qualities)
+    assert len(s) == len(q)
+    return int(lib().orc_nextseq_trim_index(s, q, len(q), int(cutoff), int(base)))
+
+
+def n_end_trim(sequence):
+    """NEndTrimmer.__call__ (modifiers.py:776-784) -> (start_cut, end_cut) as passed to subseq."""
+    s = _b(sequence)
+    a, b = C.c_int(), C.c_int()
+    lib().orc_n_end_trim(s, len(s), C.byref(a), C.byref(b))
+    return a.value, b.value

@@ -59,3 +59,15 @@ def test_paired_merge_slice_against_oracle(emu_backend, oracle):
     tests/test_gpu_fastq.py::test_large_paired_merge_slice_against_oracle"""
     from .test_gpu_fastq import check_merge_slice_against_oracle
     assert check_merge_slice_against_oracle(oracle, 400, 2) > 150
+
+
+def test_quality_trim_fixture(emu_backend):
+    """Row f4 against the reference's outputs (qualtrim_fuzz.json.gz) -- CPU-tier twin of the GPU test of the same name"""
+    from .test_gpu_fastq import check_quality_trim_fixture
+    assert check_quality_trim_fixture() > 7000
+
+
+def test_batch_slice_against_oracle_with_quality_trimming(emu_backend, oracle):
+    from .test_gpu_fastq import check_slice_against_oracle
+    trimmed, qtrimmed = check_slice_against_oracle(oracle, 3000, 1, "-q 15,20 --nextseq-trim 20 --trim-n")
+    assert trimmed > 800 and qtrimmed > 1000

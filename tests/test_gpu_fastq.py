@@ -61,26 +61,82 @@ def test_large_batch_equals_cpu_twin(hip_backend, args):
     assert len(got) > 20000
 
 
-def test_large_batch_slice_against_oracle(hip_backend, oracle):
+def check_quality_trim_fixture():
+    """Row f4 on the backend in place: every case of qualtrim_fuzz.json.gz (reference outputs) through the text pipeline --
+    `-q cf,cb`, `--nextseq-trim cg`, `--trim-n`, grouped by their cutoffs and quality base.  Returns the cases run."""
+    from atropos_amd.trim import pipeline_from_args
+    from .conftest import load_golden
+    cases = [c for c in load_golden("qualtrim_fuzz.json.gz")["cases"] if c["seq"] and min(map(ord, c["qual"])) >= 33]
+    groups = {}
+    for c in cases:
+        if c["cf"] or c["cb"]:                                     # (`-q 0,0` alone is "no modifier at all": the command refuses it)
+            groups.setdefault(("-q %d,%d --quality-base %d" % (c["cf"], c["cb"], c["base"]), "q"), []).append(c)
+        groups.setdefault(("--nextseq-trim %d --quality-base %d" % (c["cg"], c["base"]), "g"), []).append(c)
+        groups.setdefault(("--trim-n", "n"), []).append(c)
+    ran = 0
+    for (args, kind), cs in sorted(groups.items()):
+        data = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, c["seq"].encode(), c["qual"].encode()) for i, c in enumerate(cs))
+        out = pipeline_from_args(args).trim_bytes(data).split(b"\n")
+        assert len(out) == 4 * len(cs) + 1, args
+        for i, c in enumerate(cs):
+            s, q = c["seq"], c["qual"]
+            if kind == "q":
+                want = [s[c["qtrim"][0]:c["qtrim"][1]], q[c["qtrim"][0]:c["qtrim"][1]]]
+            elif kind == "g":
+                want = [s[:c["nextseq"]], q[:c["nextseq"]]]
+            else:
+                want = c["nend"]
+            assert [out[4 * i + 1].decode(), out[4 * i + 3].decode()] == want, (args, c)
+            ran += 1
+    return ran
+
+
+def test_quality_trim_fixture(hip_backend):
+    assert check_quality_trim_fixture() > 7000
+
+
+def check_slice_against_oracle(oracle, nrecords, step, args=""):
     """The at-size single-end text pipeline against a restatement that shares NO code with the kernels (round-4 verdict:
-    the twin above is compiled from the same *_core.hpp): `-a ADAPTER` on 70 000 records, every 9th record's output
-    checked against Adapter.match_to restated on the oracle (literal shortcut, locate, acceptance test:
-    adapters/__init__.py:338-400) and AdapterCutter's trim (read[:rstart], modifiers.py:107-187) on the record's own text."""
+    the twin above is compiled from the same *_core.hpp), every `step`-th record: the modifiers in the reference's order
+    (CGQA, then NEndTrimmer: commands/trim/__init__.py:422-519) -- nextseq_trim_index and quality_trim_index on the
+    checker (_qualtrim.pyx:7-84; round-5 verdict item 7), Adapter.match_to restated on the oracle (literal shortcut,
+    locate, acceptance test: adapters/__init__.py:338-400), AdapterCutter's trim (read[:rstart], modifiers.py:107-187),
+    ^N+ / N+$ -- on the record's own text."""
     from atropos_amd import synth
     from atropos_amd.trim import pipeline_from_args
     adapter = synth.TRUSEQ_34
-    data = _big_fastq(70000, 5)
-    got = pipeline_from_args("-a %s" % adapter).trim_bytes(data)
+    data = _big_fastq(nrecords, 5)
+    got = pipeline_from_args(("%s -a %s" % (args, adapter)).strip()).trim_bytes(data)
     src, out = data.split(b"\n"), got.split(b"\n")
-    assert len(out) == len(src) and len(src) == 4 * 70000 + 1
-    trimmed = 0
-    for i in range(0, 70000, 9):
+    assert len(out) == len(src) and len(src) == 4 * nrecords + 1
+    qt = "-q 15,20" in args
+    trimmed = qtrimmed = 0
+    for i in range(0, nrecords, step):
         name, seq, plus, qual = src[4 * i:4 * i + 4]
-        m = _cases.oracle_match_to(oracle, adapter, 14, seq.decode(), 0.1, 3, 1, False, False)
-        cut = len(seq) if m is None else m[2]
+        seq, qual = seq.decode(), qual.decode()
+        before = len(seq)
+        if "--nextseq-trim 20" in args and seq:
+            stop = oracle.nextseq_trim_index(seq, qual, 20)
+            seq, qual = seq[:stop], qual[:stop]
+        if qt and seq:
+            a, b = oracle.quality_trim_index(qual, 15, 20)
+            seq, qual = seq[a:b], qual[a:b]
+        qtrimmed += len(seq) != before
+        m = _cases.oracle_match_to(oracle, adapter, 14, seq, 0.1, 3, 1, False, False)
+        if m is not None:
+            seq, qual = seq[:m[2]], qual[:m[2]]
         trimmed += int(m is not None)
-        assert out[4 * i:4 * i + 4] == [name, seq[:cut], plus, qual[:cut]], (i, seq, m, out[4 * i + 1])
-    assert trimmed > 2500
+        if "--trim-n" in args and seq:
+            a, b = oracle.n_end_trim(seq)
+            seq, qual = (seq[a:b], qual[a:b]) if a < b else ("", "")
+        assert out[4 * i:4 * i + 4] == [name, seq.encode(), plus, qual.encode()], (i, src[4 * i + 1], m, out[4 * i + 1])
+    return trimmed, qtrimmed
+
+
+@pytest.mark.parametrize("args", ["", "-q 15,20 --nextseq-trim 20 --trim-n"])
+def test_large_batch_slice_against_oracle(hip_backend, oracle, args):
+    trimmed, qtrimmed = check_slice_against_oracle(oracle, 70000, 9, args)
+    assert trimmed > 2500 and (not args or qtrimmed > 2500)
 
 
 def test_paired_pipeline_reference_cli_cases(hip_backend):

@@ -217,3 +217,20 @@ def test_long_multi_and_compare(oracle):
         for r in c["runs"]:
             got = oracle.multi_locate(c["ref"], c["query"], r["e"], r["flags"], r["min_overlap"])
             assert (None if got is None else [list(t) for t in got]) == r["out"]
+
+
+def test_qualtrim_fuzz(oracle):
+    """quality_trim_index / nextseq_trim_index (_qualtrim.pyx:7-84) and NEndTrimmer (modifiers.py:766-784): the
+    checker of SURVEY 8 row f4 against what the reference returned (make_round6_golden.py)."""
+    cases = load_golden("qualtrim_fuzz.json.gz")["cases"]
+    assert len(cases) == 3000
+    trimmed = 0
+    for c in cases:
+        s, q = c["seq"], c["qual"]
+        assert list(oracle.quality_trim_index(q, c["cf"], c["cb"], c["base"])) == c["qtrim"], c
+        if s:
+            assert oracle.nextseq_trim_index(s, q, c["cg"], c["base"]) == c["nextseq"], c
+        a, b = oracle.n_end_trim(s)
+        assert ([s[a:b], q[a:b]] if a < b else ["", ""]) == c["nend"], c
+        trimmed += c["qtrim"] != [0, len(q)]
+    assert trimmed > 1500
