@@ -107,6 +107,7 @@ PROTOTYPES = {
     "atr_aligner_set_indel_cost": (C.c_int, [C.c_void_p, C.c_int]),
     "atr_aligner_query_table": (C.c_int, [C.c_void_p, C.c_char_p]),
     "atr_locate_work_bytes": (C.c_size_t, [C.c_int64]),
+    "atr_locate_work_unresolved": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]),
     "atr_locate_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
     "atr_locate_ascii_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
@@ -258,7 +259,30 @@ class HipBackend(object):
 
     @_work.setter
     def _work(self, tensor):
-        self._works[torch.cuda.current_stream(self.device).cuda_stream] = tensor
+        # one scratch per stream that issues calls, most recently used last; at most WORKS_KEPT of them are kept (a
+        # 10 M-read workspace is ~1 GB: a backend whose callers come and go on fresh streams -- worker_context() -- would
+        # otherwise pin one per stream it ever saw).  Dropping an entry frees nothing a kernel still
+        # reads: the tensor's memory goes back to torch's caching allocator, which orders re-use on the stream it
+        # was allocated on.
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        self._works.pop(key, None)
+        self._works[key] = tensor
+        while len(self._works) > self.WORKS_KEPT:
+            self._works.pop(next(iter(self._works)))
+
+    WORKS_KEPT = 4
+
+    def last_unresolved(self, nreads, n_adapters=1):
+        """Reads the pre-pass of the last filtered call on the current stream left to the exact DP kernels
+        (atr_locate_work_unresolved); None when no such call used this stream's workspace."""
+        work = self._work
+        if work is None:
+            return None
+        out = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.atr_locate_work_unresolved(_ptr(work), int(nreads), int(n_adapters), self._stream(),
+                                                                  C.byref(out)), "atr_locate_work_unresolved")
+        return int(out.value)
 
     def stage_host_bytes(self, mat):
         """A uint8 ndarray [n, w] -> the same bytes in a page-locked host tensor (kept and re-used): the upload that

@@ -274,6 +274,17 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]) {
 
 size_t atr_locate_work_bytes(int64_t nreads) { return nreads < 0 ? 0 : fast_work_bytes(nreads); }
 
+int atr_locate_work_unresolved(const void *d_work, int64_t nreads, int n_adapters, void *stream, int64_t *out) {
+    if (!d_work || !out || nreads < 0 || n_adapters < 1 || n_adapters > LINKED_MAX) return ATR_ERR_INVALID;
+    const FastWork wk = fast_carve(const_cast<void *>(d_work), nreads, n_adapters * FILTER_BINS);
+    uint32_t total = 0;
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpy(&total, wk.total, sizeof(total), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(e, "atr_locate_work_unresolved");
+    *out = (int64_t)total;
+    return ATR_OK;
+}
+
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens, int64_t nreads,
                      int max_len, atr_result *d_out, void *d_work, void *stream) {
     return atr_locate_batch_path(a, d_packed, d_lens, nreads, max_len, d_out, d_work, ATR_LOCATE_AUTO, stream);

@@ -248,6 +248,39 @@ class C2(object):
 
     two_streams = _c2_two_streams
 
+    def hard_batches(self, run):
+        """The same aligner on batches where the pre-pass cannot finish most reads (synth.hard_batch): reads/s of the same
+        one-call form, the share of the reads left to the exact DP kernels (atr_locate_work_unresolved), and -- on the
+        first 1 M reads -- that the records equal the full sweep's.  The friendly C2 batch beside them for scale."""
+        from atropos_amd import _lib, synth
+        be = _lib.get_backend()
+        dev = self.batch.packed.device
+        out = {"note": "10 M x 150 bp each, TruSeq 34-mer, e=0.1; unresolved = reads the pre-pass hands to band_kernel / "
+                       "window_kernel; the floor is the full sweep of every column (locate_kernel)"}
+        kinds = (("C2", None),) + tuple((k, k) for k in synth.HARD_KINDS)
+        for name, kind in kinds:
+            reads = self.ascii if kind is None else synth.hard_batch(kind, 0, self.n, device=dev)
+            if reads is None:
+                continue
+            batch = self.al.pack(reads, layout=self.batch.layout)
+            ms = run(lambda: self.al.locate_batch(batch, self.filtered))
+            rec = self.al.locate_batch(batch, self.filtered).records
+            left = be.last_unresolved(self.n) if hasattr(be, "last_unresolved") else None
+            k = min(self.n, 1_000_000)
+            full = self.al.locate_batch(self.al.pack(reads[:k], layout="tile64"), filtered=False).records
+            out[name] = {"reads_per_s": self.n / (ms * 1e-3), "ms": ms,
+                         "unresolved_fraction": None if left is None else left / self.n,
+                         "matched_fraction": float((rec[:, 1] >= 0).float().mean().item()),
+                         "records_equal_full_sweep_first_%d" % k: bool(torch.equal(rec[:k], full))}
+            del batch, rec, full
+            if kind is not None:
+                del reads
+        if self.ascii is not None:
+            tiles = self.al.pack(self.ascii[:min(self.n, 2_000_000)], layout="tile64")
+            ms = run(lambda: self.al.locate_batch(tiles, filtered=False), reps=2)
+            out["full_sweep_floor_reads_per_s"] = min(self.n, 2_000_000) / (ms * 1e-3)
+        return out
+
     def secondary(self, kernel_ms):
         """The other figures SURVEY 8(d) lists, measured outside the timed region."""
         out = {"cell_updates_per_s_full_matrix": self.n * 150 * 35 / (kernel_ms * 1e-3)}
@@ -276,6 +309,10 @@ class C2(object):
             out["ragged_batch_reads_per_s"] = self.n / (ms * 1e-3)
             out["ragged_batch_layout"] = rb.layout
         out["pcie_inclusive_bound_reads_per_s"] = PCIE_GBS * 1e9 / (150 + 16)    # ASCII in + record out over PCIe Gen5 x16
+        try:
+            out["hard_batches"] = self.hard_batches(run)
+        except Exception as exc:                                              # noqa: BLE001 -- a side figure
+            out["hard_batches"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         try:
             out["two_streams"] = self.two_streams()
         except Exception as exc:                                              # noqa: BLE001 -- a side figure

@@ -150,6 +150,10 @@ int atr_aligner_query_table(const atr_aligner *a, uint8_t table[256]);
  * no host synchronisation; the pattern is legal inside a stream capture).  d_work must stay
  * valid until then and must not be shared by calls that may overlap. */
 size_t atr_locate_work_bytes(int64_t nreads);
+/* Diagnostics (bench.py's hard-batch figures; no reference twin): how many reads of the LAST filtered call that used
+ * d_work (atr_locate_batch with d_work, atr_locate_planes_batch: n_adapters = 1; atr_linked_match_batch on a long
+ * batch: the set's adapter count) the pre-pass left to the exact DP kernels.  Waits for `stream`. */
+int atr_locate_work_unresolved(const void *d_work, int64_t nreads, int n_adapters, void *stream, int64_t *out);
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                      int64_t nreads, int max_len, atr_result *d_out, void *d_work, void *stream);
 

@@ -191,6 +191,32 @@ def test_c2_sample_and_full_size_properties(hip_backend, oracle):
     assert bool((rs[:, 5] == 0).all()) and bool((rs[:, 4] == m).all()) and bool((rs[:, 2] == first[has]).all())
 
 
+@pytest.mark.parametrize("kind", ["edits", "partial", "lowcomplex"])
+def test_hard_batches_against_oracle(hip_backend, oracle, kind):
+    """The batches C2's friendly generator does not produce (synth.hard_batch; round-5 verdict item 6): 2 M reads where
+    every read keeps the exact DP busy -- the two-pass pipeline, the one-pass pipeline and the full sweep agree on every
+    record, a 200 k-read slice is bit-exact against the oracle."""
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    n = 2_000_000
+    reads = synth.hard_batch(kind, 0, n, device="cuda")
+    al = Aligner(synth.TRUSEQ_34, 0.1, 14, False, False, 3, 1)
+    batch = al.pack(reads, layout="auto")
+    assert batch.layout == "plane64"
+    rec = al.locate_batch(batch).records
+    left = hip_backend.last_unresolved(n)
+    tiles = al.pack(reads, layout="tile64")
+    assert torch.equal(rec, al.locate_batch(tiles, path="filtered").records)
+    assert torch.equal(rec, al.locate_batch(tiles, filtered=False).records)
+    lo = 777_000
+    sl = reads[lo:lo + 200_000].cpu().numpy()
+    exp = oracle.locate_many(synth.TRUSEQ_34, sl, np.full(len(sl), 150, np.int32), 0.1, 14, False, False, 3, 1, 8)
+    assert np.array_equal(rec[lo:lo + 200_000, :6].cpu().numpy().astype(np.int32), exp)
+    found = float((rec[:, 1] >= 0).float().mean().item())
+    assert found > (0.4 if kind == "lowcomplex" else 0.99)
+    assert left is not None and 0 <= left <= n
+
+
 def test_pair_aligner_against_oracle(hip_backend, oracle):
     from atropos_amd.align import PairAligner
     from atropos_amd._lib import AtroposHipError
