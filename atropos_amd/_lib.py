@@ -127,6 +127,14 @@ PROTOTYPES = {
     "atr_linked_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
     "atr_linked_match_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "atr_linked_group_applies": (C.c_int, [C.c_void_p, C.c_int]),
+    "atr_linked_group_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "atr_linked_group_work_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "atr_linked_group_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_char_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]),
+    "atr_linked_group_match": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_pairs_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                          C.c_int64, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p]),
@@ -235,6 +243,16 @@ class _PinnedUpload(object):
         dev = self.host.to(device, non_blocking=True)
         self.backend._pinned_event.record(torch.cuda.current_stream(self.backend.device))
         return dev
+
+
+class LinkedGroups(object):
+    """What atr_linked_group_pack leaves on the device for one batch: the per-adapter plane64 sub-batches of
+    read[front.rstop:] (``grouped``, ``glens``), the permutation (``perm`` slot -> read, ``slot_of`` read -> slot), the 5'
+    results (``which``, ``front``), the host ``info`` block (reads and first tile of every group) and the workspace."""
+    __slots__ = ("nreads", "max_len", "grouped", "glens", "perm", "slot_of", "which", "front", "info", "work")
+
+    def group_reads(self):
+        return [int(self.info[g]) for g in range(LINKED_MAX_ADAPTERS)]
 
 
 class HipBackend(object):
@@ -656,6 +674,44 @@ class HipBackend(object):
                                                                  _ptr(front), _ptr(back), _ptr(self._work), self._stream()),
                        "atr_linked_match_batch")
         return which, front, back
+
+    def linked_group_applies(self, h, max_len):
+        return bool(self.lib.atr_linked_group_applies(h, int(max_len)))
+
+    def linked_group_pack(self, h, ascii_2d, lens, max_len, table):
+        """atr_linked_group_pack: the 5' parts decided from the ASCII rows, read[front.rstop:] packed as bit planes into
+        a sub-batch per adapter.  Returns a ``LinkedGroups`` (device buffers + the host info block); waits for the stream."""
+        nreads = ascii_2d.shape[0]
+        g = LinkedGroups()
+        g.nreads, g.max_len = nreads, int(max_len)
+        g.grouped = self.empty((max(self.lib.atr_linked_group_bytes(nreads, max_len), 16),), torch.uint8)
+        g.glens = self.empty((nreads + 64 * LINKED_MAX_ADAPTERS,), torch.int32)
+        g.perm = self.empty((nreads + 64 * LINKED_MAX_ADAPTERS,), torch.int32)
+        g.slot_of = self.empty((nreads,), torch.int32)
+        g.which = self.empty((nreads, 2), torch.int8)
+        g.front = self.empty((nreads, 8), torch.int16)
+        g.info = (C.c_int64 * 8)()
+        g.work = self.empty((max(self.lib.atr_linked_group_work_bytes(h, nreads), 16),), torch.uint8)
+        if nreads:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_linked_group_pack(h, _ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads, int(max_len),
+                                                                table, _ptr(g.grouped), _ptr(g.glens), _ptr(g.perm), _ptr(g.slot_of),
+                                                                _ptr(g.which), _ptr(g.front), g.info, _ptr(g.work), self._stream()),
+                       "atr_linked_group_pack")
+        return g
+
+    def linked_group_match(self, h, g, ordered=True):
+        """atr_linked_group_match on a ``LinkedGroups``: (slab int16 [slots, 8] raw 3' records in slot order, back int16
+        [n, 8] in batch order after the acceptance test -- None unless ``ordered``)."""
+        slots = g.glens.shape[0]
+        slab = self.empty((slots, 8), torch.int16)
+        back = self.empty((g.nreads, 8), torch.int16) if ordered else None
+        if g.nreads:
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_linked_group_match(h, _ptr(g.grouped), _ptr(g.glens), g.info, g.max_len, _ptr(g.slot_of),
+                                                                 _ptr(g.which), g.nreads, _ptr(slab), _ptr(back), _ptr(g.work),
+                                                                 self._stream()), "atr_linked_group_match")
+        return slab, back
 
     def locate_debug(self, h, packed, m, n):
         """atr_locate_debug: (cost matrix int32 [m + 1, n + 1] on the host, INT32_MIN = not computed; the record)."""

@@ -587,6 +587,27 @@ class LinkedSet(object):
         except Exception:
             pass
 
+    def group_applies(self, max_len):
+        """Can ``pack_groups`` / ``match_groups`` take this set for reads of at most max_len bases?  (Every 3' aligner
+        inside the two-pass pre-pass's envelope; the HIP backend.)"""
+        be = self._backend
+        return self._handle is not None and hasattr(be, "linked_group_applies") and be.linked_group_applies(self._handle, max_len)
+
+    def pack_groups(self, ascii_upper, lens=None, max_len=None):
+        """The pack-time half of LinkedAdapter.match_to for a batch (atr_linked_group_pack): every read's 5' part
+        decided from its ASCII row (adapters/__init__.py:671-676), ``read[front.rstop:]`` packed as bit planes into the
+        sub-batch of the adapter that matched.  Returns a ``_lib.LinkedGroups``."""
+        max_len = ascii_upper.shape[1] if max_len is None else max_len
+        return self._backend.linked_group_pack(self._handle, ascii_upper, lens, max_len, self.table)
+
+    def match_groups(self, groups, ordered=True):
+        """The 3' parts of a packed batch (atr_linked_group_match): (which int32, count int32, front, back) as
+        ``match_source`` returns them when ``ordered``; else (slab, groups) -- raw 3' records in slot order."""
+        slab, back = self._backend.linked_group_match(self._handle, groups, ordered)
+        if not ordered:
+            return slab, groups
+        return groups.which[:, 0].to(torch.int32), groups.which[:, 1].to(torch.int32), groups.front, back
+
     def match_source(self, source, active=None):
         """(which, count, front, back) for a read source (``AsciiSource`` / ``RecordSource``):
         int32 index of the first linked adapter whose 5' part matches (-1: none), the number of

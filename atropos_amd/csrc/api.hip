@@ -77,8 +77,6 @@ struct PackTable { uint8_t t[256]; };
 // then read their own rows from LDS -- instead of 64 lanes issuing byte loads 150 bytes
 // apart.  Needs 64 * row_stride + 32 bytes of LDS per wave (row_stride <= PACK_STAGE_MAX).
 constexpr int PACK_STAGE_MAX = 256;
-constexpr int PACK_STAGE_SLACK = 32;                // bytes behind a wave's 64 rows: the aligned window's overhang (< 16) and the dword
-                                                    // reads of the four-bases-per-step path at the last row's end (< 8 more)
 
 template <bool STAGED, bool PLANES>
 __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ ascii, long long row_stride,
@@ -103,40 +101,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const uint8_t *__restrict__ a
     if (STAGED) {
         const size_t wave_bytes = (size_t)64 * row_stride + PACK_STAGE_SLACK;
         uint8_t *stage = s_stage + (size_t)wave * ((wave_bytes + 15) & ~(size_t)15);
-        const uint8_t *src = ascii + tile * 64 * row_stride;
-        const uintptr_t mis = (uintptr_t)src & 15;                 // 16-byte aligned window around the region
-        const uint8_t *src_al = src - mis;
-        const long long rows_here = min<long long>(64, nreads - tile * 64);
-        const long long need = mis + rows_here * row_stride;       // bytes of the window that are ours
-        // the caller's matrix is [ascii, buf_end): a 16-byte piece of the aligned window that sticks out of it
-        // (before the first row of the batch, after its last) is copied byte by byte, never read as a whole
-        const uint8_t *buf_end = ascii + nreads * row_stride;
-        // (eight 16-byte pieces per lane requested before the first one is stored: one at a time the copy was a chain of
-        //  need / 1024 memory round trips per wave -- ten for 150-byte rows -- and the whole kernel waited on it)
-        for (long long base = 0; base < need; base += 8 * 64 * 16) {
-            uint4 buf[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long o = base + (long long)u * 64 * 16 + (long long)lane * 16;
-                const uint8_t *piece = src_al + o;
-                buf[u] = (o < need && piece >= ascii && piece + 16 <= buf_end) ? *(const uint4 *)piece : make_uint4(0u, 0u, 0u, 0u);
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const long long o = base + (long long)u * 64 * 16 + (long long)lane * 16;
-                const uint8_t *piece = src_al + o;
-                if (o < need) {
-                    if (piece >= ascii && piece + 16 <= buf_end) {
-                        *(uint4 *)(stage + o) = buf[u];
-                    } else {
-                        for (int b = 0; b < 16; ++b) stage[o + b] = (piece + b >= ascii && piece + b < buf_end) ? piece[b] : (uint8_t)0;
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        row = stage + mis + (size_t)lane * row_stride + start;     // LDS is visible wave-wide after the stores land
-        __builtin_amdgcn_s_waitcnt(0);
+        const uint32_t mis = pack_stage_tile(stage, ascii, row_stride, nreads, tile, lane);
+        row = stage + mis + (size_t)lane * row_stride + start;
     }
     uint4 *dst = packed + (size_t)tile * nchunks * 64 + lane;
     bool zero_seen = false;

@@ -90,6 +90,9 @@ inline FastWork fast_carve(void *work, long long nreads, int nbins = FILTER_BINS
     w.fused = 0;
     return w;
 }
+// what the first half of a plane64 locate call (piece_kernels.hip: launch_planes_prepass) hands to its second half
+struct PlanesCall { FastWork wk; int nw; };
+
 // ATR_FUSED_SCAN=0: the two scan launches instead of the atomics (A/B switch)
 inline bool fast_fused_scan() {
     static const int v = [] { const char *e = getenv("ATR_FUSED_SCAN"); return (e && e[0] == '0') ? 0 : 1; }();

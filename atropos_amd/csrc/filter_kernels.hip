@@ -48,15 +48,18 @@ void launch_fast_scan(FastWork wk, hipStream_t st) {
 // timelines of profiles/round5_tail_timelines.txt: with five streams C4's last window launch waited for another
 // stream to drain -- three side streams now, a fourth adapter's window launch queues behind the first's.)
 constexpr int DP_STREAMS = 4;                            // >= LINKED_MAX: band stream + one per further adapter
+// one_stream: both DP launches on `st` whatever the batch size (linked_group.hip runs several calls side by side, a stream
+// each: the device has four hardware queues, a fifth stream waits for one of them to drain)
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes) {
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes,
+                   bool one_stream) {
     static thread_local SideStream side[DP_STREAMS];
     if (planes && la) return (int)hipErrorInvalidValue;                  // plane64: the single-aligner pipeline
     if (count < 1 || count > DP_STREAMS || idx < 0 || idx >= count) return (int)hipErrorInvalidValue;
     hipError_t e = hipSuccess;
     // a short batch (the <= 1000 reads the unchanged trim command hands over per call) leaves most of the chip
     // idle anyway: the fork / join events would cost more than the overlap gives, both DP kernels go to `st`
-    const bool serial = nreads <= (count == 1 ? FAST_SERIAL_READS : FAST_SERIAL_READS_LINKED);
+    const bool serial = one_stream || nreads <= (count == 1 ? FAST_SERIAL_READS : FAST_SERIAL_READS_LINKED);
     if (serial) {
         const BandParams bp = band_params(a);
         const dim3 bgrid((unsigned)std::max<long long>(1, std::min<long long>((nreads + 3) / 4, 4096)));
@@ -143,7 +146,7 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
     hipLaunchKernelGGL(scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m,
                        (!ragged || !(a->flags & ATR_START_WITHIN_SEQ1)) ? 1 : 0, wk);        // == ragged_rows_bins(u.sr)
     // K4a and K4 work on disjoint slots of `order` and run side by side (launch_fast_dp)
-    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, 0, 1, st, false);
+    return launch_fast_dp(a, packed, lens, nreads, nchunks, max_len, out, wk, nullptr, 0, 1, st, false, false);
 }
 
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,

@@ -19,24 +19,17 @@
 #include "linked_host.hpp"
 #include "locate_fast.hpp"
 #include "wave_sweep.hpp"
+#include "linked_blob.hpp"
 
 namespace atr {
 
 void launch_fast_scan(FastWork wk, hipStream_t st);
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes);
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes, bool one_stream);
 int hip_fail(hipError_t e, const char *what);
 
-struct LinkedBlob {
-    LinkedParams p;
-    LinkedRmp rmp;
-};
 
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ bool wave_any(bool v) { return __ballot(v) != 0ull; }
 
-constexpr int LINKED_ROUND = 8;                      // tiles a wave takes through the 5' stage before their 3' stage
-constexpr int LINKED_TASKS = 512;                    // capacity of a wave's queue of (read, 5' adapter) DP tasks
 static_assert(LINKED_MAX * FILTER_BINS <= 1024, "scan_total_kernel scans at most 1024 bins");
 
 // The wave's queued DP tasks, 64 at a time, every lane against its own (read, adapter): the read's
@@ -47,32 +40,11 @@ __device__ __forceinline__ void linked_drain(const LinkedBlob &S, int ngroups, c
                                              const uint4 *__restrict__ packed, const int32_t *__restrict__ lens,
                                              long long tile_first, int nchunks, int max_len, uint32_t *s_word,
                                              uint32_t *s_count, uint32_t *ns, int lane) {
-    for (int base = 0; base < ntasks; base += 64) {                           // wave-uniform
-        const bool valid = base + lane < ntasks;
-        const uint32_t task = valid ? (uint32_t)queue[base + lane] : 0u;      // [14:6] slot * 64 + lane  [1:0] adapter
-        const int a_l = (int)(task & 3u), cell = (int)(task >> 6);
-        const long long tile = tile_first + 4 * (cell >> 6);
-        const long long r = tile * 64 + (cell & 63);
-        const uint4 c0 = valid ? packed[(size_t)tile * nchunks * 64 + (cell & 63)] : make_uint4(0, 0, 0, 0);
-        const uint32_t w0[4] = {c0.x, c0.y, c0.z, c0.w};
-        const int n = valid ? (RAGGED ? lens[r] : max_len) : 0;
-        const FrontParams &mp = S.p.f[a_l];
-        const int grp = valid ? mp.group : -1;
-        for (int g = 0; g < ngroups; ++g) {
-            if (!wave_any(grp == g)) continue;
-            const FrontParams &gp = S.p.f[rfl(S.p.group_first[g])];
-            const Uniform u = front_uniform(rfl(gp.m), rfl(gp.k), rfl(gp.indel), rfl(gp.min_overlap));
-            front_stage(w0, u.k, ns, 64);
-            uint32_t rec[4];
-            const uint32_t *rr = (grp == g ? mp : gp).rrep;
-            band_locate_prefix_rr<AND_MODE>(u, [rr](int i) { return rr[i - 1]; }, rfl(gp.noindel) != 0, ns, 64, n, gp.thr, rec);
-            if (grp == g && front_accept(rec, u.m, u.min_overlap, mp.pf_thr, mp.accept_full != 0, S.rmp.front[a_l],
-                                         S.rmp.front_ld[a_l], S.rmp.front_max[a_l])) {
-                atomicMin(&s_word[cell], front_word_of(a_l, rec));
-                atomicAdd(&s_count[cell >> 2], 1u << (8 * (cell & 3)));
-            }
-        }
-    }
+    linked_drain_with<RAGGED, AND_MODE>(S, ngroups, queue, ntasks, lens, tile_first, max_len, s_word, s_count, ns, lane,
+                                        [&](long long tile, int l, int, uint32_t (&w)[4]) {
+                                            const uint4 c0 = packed[(size_t)tile * nchunks * 64 + l];
+                                            w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w;
+                                        });
 }
 
 template <bool WIDE, bool RAGGED, bool AND_MODE>
@@ -303,11 +275,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // Short batches: the 3' part of every read the pre-pass left open on a wavefront of its own (wave_sweep.hpp) -- the
 // aligner of the read's own adapter on read[front.rstop:], exactly the reference's second match_to -- instead of
 // counting sort + four band and four window launches whose single lanes run for 17 - 34 us each.
-struct LinkedWaveBlob {
-    LocateParams p[LINKED_MAX];
-    LinkedPost post[LINKED_MAX];
-    BandParams bp[LINKED_MAX];                      // linked_band_kernel
-};
 constexpr long long LINKED_WAVE_MAX_READS = 262144;
 
 // K4a of a linked set: the band reads of EVERY adapter in one launch (band_kernel<.., LINKED> once per adapter ran
@@ -630,7 +597,7 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
         la.multi_post = wblob->post;
         la.a0 = a;
         la.win_count = one_window ? (a == 0 ? s->p.n : 0) : 1;
-        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st, false);
+        const int rc = launch_fast_dp(&s->back[a], packed, d_lens, nreads, nchunks, max_len, back, wk, &la, a, s->p.n, st, false, false);
         if (rc != 0) return hip_fail((hipError_t)rc, "linked band / window launch");
     }
     return ATR_OK;

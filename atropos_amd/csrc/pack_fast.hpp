@@ -123,5 +123,47 @@ __device__ __forceinline__ void pack_codes_row_fast(const uint32_t *sw, uint32_t
     }
 }
 
+// The 64 rows of tile `tile` (contiguous: 64 row_stride bytes) copied into the wave's LDS stage with coalesced 16-byte
+// loads -- the 16-byte aligned window around the region; returns its offset in the window (0 .. 15): row l starts at
+// stage + mis + l row_stride.  [ascii, buf_end) is the caller's matrix: a 16-byte piece of the window that sticks out of
+// it (before the first row of the batch, after its last) is copied byte by byte, never read as a whole.  Eight pieces per
+// lane are requested before the first one is stored (one at a time the copy was a chain of need / 1024 memory round
+// trips per wave -- ten for 150-byte rows).  The stage needs 64 row_stride + PACK_STAGE_SLACK bytes.
+constexpr int PACK_STAGE_SLACK = 32;                // bytes behind a wave's 64 rows: the aligned window's overhang (< 16) and the dword
+                                                    // reads of the four-bases-per-step path at the last row's end (< 8 more)
+__device__ __forceinline__ uint32_t pack_stage_tile(uint8_t *stage, const uint8_t *ascii, long long row_stride, long long nreads,
+                                                    long long tile, int lane) {
+    const uint8_t *src = ascii + tile * 64 * row_stride;
+    const uintptr_t mis = (uintptr_t)src & 15;
+    const uint8_t *src_al = src - mis;
+    const long long rows_here = min<long long>(64, nreads - tile * 64);
+    const long long need = mis + rows_here * row_stride;       // bytes of the window that are ours
+    const uint8_t *buf_end = ascii + nreads * row_stride;
+    for (long long base = 0; base < need; base += 8 * 64 * 16) {
+        uint4 buf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long o = base + (long long)u * 64 * 16 + (long long)lane * 16;
+            const uint8_t *piece = src_al + o;
+            buf[u] = (o < need && piece >= ascii && piece + 16 <= buf_end) ? *(const uint4 *)piece : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long o = base + (long long)u * 64 * 16 + (long long)lane * 16;
+            const uint8_t *piece = src_al + o;
+            if (o < need) {
+                if (piece >= ascii && piece + 16 <= buf_end) {
+                    *(uint4 *)(stage + o) = buf[u];
+                } else {
+                    for (int b = 0; b < 16; ++b) stage[o + b] = (piece + b >= ascii && piece + b < buf_end) ? piece[b] : (uint8_t)0;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);                             // LDS is visible wave-wide after the stores land
+    return (uint32_t)mis;
+}
+
 }  // namespace atr
 #endif

@@ -19,7 +19,7 @@ namespace atr {
 
 void launch_fast_scan(FastWork wk, hipStream_t st);                              // filter_kernels.hip
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
-                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes);
+                   int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes, bool one_stream);
 
 template <int NW, bool RAGGED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATR_PIECE_WAVES(NW), 8))) void piece_filter_kernel(
@@ -124,9 +124,13 @@ int prepare_locate_planes(const atr_aligner *a, int max_len, bool ragged) {
     return piece_spec_for(a, fp, pp, ragged, max_len, 0, true) != nullptr ? 1 : 0;
 }
 
-// lens == nullptr: every read has max_len bases
-int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
-                         void *work, hipStream_t st) {
+// lens == nullptr: every read has max_len bases.  The call in two halves, so that a caller with several batches
+// (linked_group.hip: a sub-batch per 3' adapter) can put all pre-passes on the device before the first DP tail:
+//   launch_planes_prepass   P1 (run-time compiled when there is such a kernel); grid_div > 1: the persistent grid takes
+//                           that share of the resident blocks
+//   launch_planes_tail      scan (unless fused), P3, K4a || K4; one_stream: see launch_fast_dp
+int launch_planes_prepass(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len,
+                          uint4 *out, void *work, hipStream_t st, int grid_div, PlanesCall *pc) {
     FilterParams fp;
     PieceParams pp;
     if (!piece_applies(a, lens ? piece_ragged_len(max_len) : max_len, &fp, &pp)) return (int)hipErrorInvalidValue;
@@ -141,7 +145,7 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_
     }
     if (sk) {
         const long long want = ((nreads + 63) / 64 + 3) / 4;
-        wk.nused = (int)std::max<long long>(1, std::min<long long>(sk->resident, want));
+        wk.nused = (int)std::max<long long>(1, std::min<long long>(std::max(1, sk->resident / std::max(1, grid_div)), want));
         const hipError_t rc = jit::spec_launch(sk, wk.nused, planes, lens, nreads, max_len, out, wk, st);
         if (rc != hipSuccess) return (int)rc;
     } else {
@@ -156,9 +160,30 @@ int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_
         default: launch_piece_filter<10>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st); break;
         }
     }
+    pc->wk = wk;
+    pc->nw = nw;
+    return (int)hipGetLastError();
+}
+
+int launch_planes_tail(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
+                       const PlanesCall &pc, hipStream_t st, bool one_stream) {
+    FastWork wk = pc.wk;
     if (!wk.fused) launch_fast_scan(wk, st);
     hipLaunchKernelGGL(piece_scatter_kernel, dim3(wk.nused), dim3(256), 0, st, nreads, a->p.m, wk);
-    return launch_fast_dp(a, planes, lens, nreads, nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true);
+    return launch_fast_dp(a, planes, lens, nreads, pc.nw, max_len, out, wk, nullptr, 0, 1, st, /*planes=*/true, one_stream);
+}
+
+int launch_locate_planes_shared(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len,
+                                uint4 *out, void *work, hipStream_t st, int grid_div, bool one_stream) {
+    PlanesCall pc;
+    const int rc = launch_planes_prepass(a, planes, lens, nreads, max_len, out, work, st, grid_div, &pc);
+    if (rc != 0) return rc;
+    return launch_planes_tail(a, planes, lens, nreads, max_len, out, pc, st, one_stream);
+}
+
+int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
+                         void *work, hipStream_t st) {
+    return launch_locate_planes_shared(a, planes, lens, nreads, max_len, out, work, st, 1, false);
 }
 
 }  // namespace atr

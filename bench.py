@@ -69,7 +69,7 @@ def half_stream_bytes(reads_per_unit, read_len):
     return reads_per_unit * ((read_len + 31) // 32) * 16 / 2.0
 
 
-def live_counters(config, reads, want_valu, read_len=150):
+def live_counters(config, reads, want_valu, read_len=150, stream_units=None):
     """HBM traffic (and VALU wave-instructions) of one step of `config`, MEASURED by this invocation: bench.py runs
     itself under `rocprofv3 --pmc <counter>` -- one pass per counter, no trace domains, as MI355X_MICROARCH.md's
     HBM section prescribes -- for three short calls and reduces the per-kernel CSV:  bytes = 2 x FETCH_SIZE +
@@ -99,7 +99,8 @@ def live_counters(config, reads, want_valu, read_len=150):
                 with open(path) as fh:
                     for row in csv.DictReader(fh):
                         name = row["Kernel_Name"]
-                        if ("atr::" in name or "atr_piece" in name) and "pack" not in name and row["Counter_Name"] == counter:
+                        if (("atr::" in name or "atr_piece" in name) and "pack" not in name and "front_ascii" not in name
+                                and row["Counter_Name"] == counter):
                             per[name] = per.get(name, 0.0) + float(row["Counter_Value"])
             shutil.rmtree(out, ignore_errors=True)
             if not per:
@@ -111,7 +112,7 @@ def live_counters(config, reads, want_valu, read_len=150):
     for name, v in totals["FETCH_SIZE"].items():
         per_unit = next((h for key, h in MIXED_KERNELS.items() if key in name), None)
         if per_unit is not None:
-            hbm += v * 1024.0 + half_stream_bytes(per_unit, read_len) * reads * calls
+            hbm += v * 1024.0 + half_stream_bytes(per_unit, read_len) * (stream_units or reads) * calls
         else:
             hbm += (2.0 if any(k in name for k in STREAMING_KERNELS) else 1.0) * v * 1024.0
     hbm += sum(totals["WRITE_SIZE"].values()) * 1024.0
@@ -469,7 +470,6 @@ class C4(object):
     name = "C4"
     default_units = 12_500_000
     unit_reads = 1
-    algo_bytes = 75 + 16 + 16          # packed read in + 5' record + 3' record out
     dtype = "int32"
     metric = "reads/s (whole node) 150 bp SE, 4 linked adapters"
 
@@ -490,28 +490,56 @@ class C4(object):
         self.lset = LinkedSet(linked)
         if not self.lset.fused:
             raise SystemExit("C4: the linked set is outside the fused pipeline's envelope")
-        self.batch = AsciiSource(reads).batch(self.lset.table_kind, self.lset.table)
+        # Round 6: the resident form is what atr_linked_group_pack leaves -- the anchored 5' parts decided where the ASCII
+        # row is first touched, read[front.rstop:] as bit planes in a sub-batch per adapter -- and a step is
+        # atr_linked_group_match: the two-pass pre-pass compiled for each 3' aligner on its group, the acceptance test, the
+        # 3' records back in batch order.  ATR_BENCH_C4_FUSED=1: round 5's form (whole reads as tile64, 5' and 3' parts in
+        # the timed call).  The pack-inclusive figures of both forms are in `secondary`.
+        self.grouped = os.environ.get("ATR_BENCH_C4_FUSED", "0") != "1" and self.lset.group_applies(150)
+        self.algo_bytes = (75 + 16) if self.grouped else (75 + 16 + 16)   # packed read (<= 75 B) + 3' record (+ 5' record: fused form)
+        self.ascii = reads if (args.secondary or self.grouped) else None
+        if self.grouped:
+            self.groups = self.lset.pack_groups(reads)
+            self.stream_units = sum(self.groups.group_reads())            # reads whose planes a step streams
+            self.batch = None
+            if not args.secondary:
+                self.ascii = None
+        else:
+            self.batch = AsciiSource(reads).batch(self.lset.table_kind, self.lset.table)
         del reads, chunks
 
     def step(self, s):
+        if self.grouped:
+            self.res = self.lset.match_groups(self.groups)
+            return
         be = self.lset._backend
-        self.res = be.linked_match_batch(self.lset._handle, self.batch.packed, self.batch.lens, self.batch.nreads,
-                                         self.batch.max_len)
+        wc, front, back = be.linked_match_batch(self.lset._handle, self.batch.packed, self.batch.lens, self.batch.nreads,
+                                                self.batch.max_len)
+        self.res = (wc[:, 0], wc[:, 1], front, back)
 
     def describe(self):
-        wc, front, back = self.res
+        which, count, front, back = self.res
+        form = ("the 5' parts decided at pack time (atr_linked_group_pack), read[front.rstop:] as bit planes in one plane64 "
+                "sub-batch per adapter resident in HBM; a step = the 3' parts + acceptance test + records in batch order"
+                if self.grouped else "4-bit packed whole reads (tile64) resident in HBM; a step = 5' and 3' parts")
         return {"workload": "C4: %d x 150 bp SE reads per GPU (100 M / 8), four linked adapters (anchored 20-mer 5' part "
-                            "+ 33/34-mer 3' part), e=0.12, O=3, indel cost 1, 4-bit packed reads resident in HBM" % self.n,
-                "reads_per_gpu": self.n, "read_len": 150,
-                "front_matched_fraction": float((wc[:, 0] >= 0).float().mean().item()),
+                            "+ 33/34-mer 3' part), e=0.12, O=3, indel cost 1; %s" % (self.n, form),
+                "reads_per_gpu": self.n, "read_len": 150, "resident_form": "grouped plane64" if self.grouped else "tile64",
+                "front_matched_fraction": float((which >= 0).float().mean().item()),
                 "back_matched_fraction": float((back[:, 1] >= 0).float().mean().item()),
-                "reads_with_two_fronts": int((wc[:, 1] > 1).sum().item())}
+                "reads_with_two_fronts": int((count > 1).sum().item())}
 
     def kernel(self):
+        if self.grouped:
+            return ("4 x [atr_piece_spec (ragged, one build per 3' aligner) + piece_scatter + band_kernel || window_kernel] on "
+                    "four streams + linked_group_finish_kernel (one atr_linked_group_match call)")
         return ("linked_filter_kernel + linked_scatter + linked_band_kernel || window_kernel<36> (one launch each for the "
                 "four adapters; one atr_linked_match_batch call)")
 
     def note(self, kernel_ms):
+        if self.grouped:
+            return ("integer-VALU bound; algorithmic bytes = packed read[rstop:] (<= 75 B) + the 3' record: the 5' record is "
+                    "written by the pack pass, whose time is in secondary.pack_inclusive_reads_per_s")
         return "integer-VALU bound: 4 anchored 5' sweeps + one 3' pre-pass per read in one kernel"
 
     def cpu_baseline(self):
@@ -523,7 +551,43 @@ class C4(object):
         return timed_cpu(fn, len(sample), "first %d reads of the same C4 batch" % len(sample), cores)
 
     def secondary(self, kernel_ms):
-        return {"pcie_inclusive_bound_reads_per_s": PCIE_GBS * 1e9 / (150 + 34)}
+        from atropos_amd.adapters import AsciiSource
+        out = {"pcie_inclusive_bound_reads_per_s": PCIE_GBS * 1e9 / (150 + 34)}
+        if self.ascii is None:
+            return out
+
+        def run(fn, reps=5):
+            for _ in range(2):
+                fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / reps
+
+        be, lset = self.lset._backend, self.lset
+        if self.grouped:
+            ms_pack = run(lambda: lset.pack_groups(self.ascii))
+            ms = run(lambda: lset.match_groups(lset.pack_groups(self.ascii)))
+            out["group_pack_ms"] = ms_pack                                  # 5' parts + grouped planes (ASCII in HBM; one host sync)
+            out["pack_inclusive_reads_per_s"] = self.n / (ms * 1e-3)         # ASCII in HBM -> both records of every read
+            slab_ms = run(lambda: lset.match_groups(self.groups, ordered=False))
+            out["slot_order_reads_per_s"] = self.n / (slab_ms * 1e-3)        # records left in slot order (slab + permutation)
+            out["group_reads"] = self.groups.group_reads()
+        # round 5's form on the same reads: whole reads as tile64, 5' and 3' parts in one call
+        fused_batch = AsciiSource(self.ascii).batch(lset.table_kind, lset.table)
+        fms = run(lambda: be.linked_match_batch(lset._handle, fused_batch.packed, fused_batch.lens, fused_batch.nreads, fused_batch.max_len))
+        out["fused_tile64_reads_per_s"] = self.n / (fms * 1e-3)
+        pms = run(lambda: AsciiSource(self.ascii).batch(lset.table_kind, lset.table))
+        out["fused_tile64_pack_inclusive_reads_per_s"] = self.n / ((fms + pms) * 1e-3)
+        if self.grouped:
+            wc, front, back = be.linked_match_batch(lset._handle, fused_batch.packed, fused_batch.lens, fused_batch.nreads, fused_batch.max_len)
+            which, count, f2, b2 = self.res
+            out["records_equal_fused_form"] = bool(torch.equal(which, wc[:, 0].to(torch.int32)) and torch.equal(f2[:, :6], front[:, :6])
+                                                   and torch.equal(b2[:, :6], back[:, :6]))
+        return out
 
 
 CONFIGS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
@@ -603,7 +667,7 @@ def measure(cfg_cls, args, rank, world, local_rank, dist, headline, defer_second
     desc = cfg.describe()
     live = None
     if args.live_counters and world == 1 and not args.full_sweep and not EMU:
-        live = live_counters(cfg.name, cargs.reads, headline, getattr(cfg, "read_len", 150))        # (child processes on the same GPU)
+        live = live_counters(cfg.name, cargs.reads, headline, getattr(cfg, "read_len", 150), getattr(cfg, "stream_units", None))        # (child processes on the same GPU)
     desc["parallelism"] = "shard%d" % world
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "peak_measured": HBM_MEASURED_GBS,

@@ -268,6 +268,35 @@ int atr_linked_match_batch(const atr_linked_set *s, const uint8_t *d_packed, con
                            int max_len, int8_t *d_which, atr_result *d_front, atr_result *d_back, void *d_work,
                            void *stream);
 
+/* The same matches with the anchored 5' parts decided AT PACK TIME (round 6; linked_group.hip).  An anchored 5' part
+ * only looks at the read's first m + int(e*m) <= 32 bases, and LinkedAdapter.match_to (adapters/__init__.py:671-690)
+ * matches the 3' part of the adapter whose 5' part matched on read[front.rstop:]: atr_linked_group_pack reads the ASCII
+ * rows once, decides every read's 5' part (d_which, d_front: as atr_linked_match_batch) and packs read[front.rstop:] as
+ * bit planes (plane64) into a sub-batch PER ADAPTER -- group g's reads in batch order on consecutive slots:
+ *   d_grouped   atr_linked_group_bytes(nreads, max_len) bytes; d_glens[slot] = len - rstop (0 on the padding slots that
+ *               fill a group's last tile); d_perm[slot] = the read (-1: padding); d_slot_of[r] = its slot (-1: no 5'
+ *               match, nothing packed); all three int32, nreads + 64 * ATR_LINKED_MAX_ADAPTERS entries for glens / perm;
+ *   info (HOST, 8 x int64, written before the call returns -- the call waits for `stream`): [g] = reads of group g,
+ *               [4 + g] = first tile of its sub-batch.
+ * atr_linked_group_match then runs each group through atr_locate_planes_batch's pipeline with ITS 3' aligner (the pre-pass
+ * compiled at run time for that aligner; the groups side by side on internal streams, joined before the call's end on
+ * `stream`): d_slab[slot] = the raw Aligner.locate record of the slot's read[rstop:]; with d_back != NULL also
+ * d_back[r] = back_match in batch order after Adapter.match_to's acceptance test (:386-398), exactly
+ * atr_linked_match_batch's d_back.  atr_linked_group_applies: 1 when every 3' aligner of the set is inside the two-pass
+ * pre-pass's envelope for ragged reads of at most max_len bases (else use atr_linked_match_batch).
+ * table: the 256-byte translate table of atr_linked_query_table's kind.  d_work: atr_linked_group_work_bytes() bytes,
+ * the SAME buffer for the pack and the match call of a batch. */
+int atr_linked_group_applies(const atr_linked_set *s, int max_len);
+size_t atr_linked_group_bytes(int64_t nreads, int max_len);
+size_t atr_linked_group_work_bytes(const atr_linked_set *s, int64_t nreads);
+int atr_linked_group_pack(const atr_linked_set *s, const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
+                          int64_t nreads, int max_len, const uint8_t table[256], uint8_t *d_grouped, int32_t *d_glens,
+                          int32_t *d_perm, int32_t *d_slot_of, int8_t *d_which, atr_result *d_front, int64_t info[8],
+                          void *d_work, void *stream);
+int atr_linked_group_match(const atr_linked_set *s, const uint8_t *d_grouped, const int32_t *d_glens, const int64_t info[8],
+                           int max_len, const int32_t *d_slot_of, const int8_t *d_which, int64_t nreads, atr_result *d_slab,
+                           atr_result *d_back, void *d_work, void *stream);
+
 /* ---- InsertAligner (atropos/align/__init__.py:178-377) -------------------- */
 
 #define ATR_INSERT_MAX_ADAPTER 128   /* adapter length handled by the insert kernel */

@@ -187,3 +187,99 @@ def test_merge_overlapping(hip_backend):
 def test_long_multi_and_compare(hip_backend):
     """MultiAligner / compare_prefixes / compare_suffixes past 736 (and past 1 024 reference) characters vs the reference"""
     assert _cases.check_long_multi_compare() == 36 * 8 + 30 * 5 + 60
+
+
+def _linked_group_check(oracle, reads, lens, fronts, backs, e, mo, ic, slice_lo, slice_k):
+    """Grouped pipeline (5' parts at pack time, adapter-uniform plane64 sub-batches, the single-aligner two-pass pipeline
+    per 3' adapter) against the fused tile64 pipeline on every read and against the oracle on a slice; the slot-order
+    outputs against the batch-order ones."""
+    import numpy as np
+    import torch
+    from atropos_amd.adapters import AsciiSource, LinkedAdapter, LinkedSet
+    las = [LinkedAdapter(f, b, front_anchored=True, back_anchored=False, max_error_rate=e, min_overlap=mo, indel_cost=ic)
+           for f, b in zip(fronts, backs)]
+    lset = LinkedSet(las)
+    assert lset.fused and lset.group_applies(reads.shape[1])
+    groups = lset.pack_groups(reads, lens)
+    which, count, front, back = lset.match_groups(groups)
+    w2, c2, f2, b2 = lset.match_source(AsciiSource(reads, lens))
+    assert torch.equal(which, w2) and torch.equal(count, c2)
+    assert torch.equal(front[:, :6], f2[:, :6])
+    assert torch.equal(back[:, :6], b2[:, :6])
+    n = reads.shape[0]
+    # the permutation and its inverse; group g's slots hold reads of adapter g in batch order
+    perm, slot_of = groups.perm.cpu().numpy(), groups.slot_of.cpu().numpy()
+    wh = which.cpu().numpy()
+    assert np.array_equal(slot_of >= 0, wh >= 0)
+    has = np.nonzero(slot_of >= 0)[0]
+    assert np.array_equal(perm[slot_of[has]], has)
+    info = [int(x) for x in groups.info]
+    glens = groups.glens.cpu().numpy()
+    ln = np.full(n, reads.shape[1], np.int64) if lens is None else lens.cpu().numpy().astype(np.int64)
+    rstop = front[:, 3].cpu().numpy().astype(np.int64)
+    for g in range(len(fronts)):
+        cnt, t0 = info[g], info[4 + g]
+        assert cnt == int((wh == g).sum())
+        sl = perm[64 * t0:64 * t0 + cnt]
+        assert np.array_equal(sl, np.nonzero(wh == g)[0])
+        assert np.array_equal(glens[64 * t0:64 * t0 + cnt], (ln - rstop)[sl])
+        pad = (-cnt) % 64
+        assert (perm[64 * t0 + cnt:64 * t0 + cnt + pad] == -1).all() and (glens[64 * t0 + cnt:64 * t0 + cnt + pad] == 0).all()
+    # slot-order records: the raw Aligner.locate of read[rstop:]; accepted ones equal the batch-order record
+    slab, _ = lset.match_groups(groups, ordered=False)
+    sb = slab[:, :6].cpu().numpy()[slot_of[has]]
+    bb = back[:, :6].cpu().numpy()[has]
+    acc = bb[:, 1] >= 0
+    assert np.array_equal(sb[acc], bb[acc])
+    # the oracle on a slice
+    k = min(slice_k, n - slice_lo)
+    sl = reads[slice_lo:slice_lo + k].cpu().numpy()
+    sl_lens = np.full(k, reads.shape[1], np.int32) if lens is None else lens[slice_lo:slice_lo + k].cpu().numpy().astype(np.int32)
+    ew, ef, eb = oracle.linked_many(fronts, backs, sl, sl_lens, e, mo, ic, True, False, 8)
+    assert np.array_equal(wh[slice_lo:slice_lo + k], ew[:, 0].astype(np.int32))
+    assert np.array_equal(front[slice_lo:slice_lo + k, :6].cpu().numpy().astype(np.int32), ef)
+    assert np.array_equal(back[slice_lo:slice_lo + k, :6].cpu().numpy().astype(np.int32), eb)
+    return int((wh >= 0).sum()), int((back[:, 1] >= 0).sum().item())
+
+
+def test_linked_groups_c4(hip_backend, oracle):
+    """C4's reads through atr_linked_group_pack / atr_linked_group_match (round 6): 3 M reads equal-length, 1 M ragged."""
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.adapters import upper_ascii
+    n = 3_000_000
+    w = synth.workload("C4", 1_000_000, n, device="cuda")
+    reads = upper_ascii(w["reads"])
+    nf, nb = _linked_group_check(oracle, reads, None, w["fronts"], w["backs"], w["max_error_rate"], w["min_overlap"],
+                                 w["indel_cost"], 1_234_567, 150_000)
+    assert nf > 0.7 * n and nb > 0.3 * n
+    g = torch.Generator(device="cuda").manual_seed(11)
+    sub = reads[:1_000_000].contiguous()
+    lens = torch.randint(0, 151, (sub.shape[0],), generator=g, device="cuda", dtype=torch.int32)
+    lens = torch.where(torch.rand(sub.shape[0], generator=g, device="cuda") < 0.7, torch.full_like(lens, 150), lens)
+    nf, nb = _linked_group_check(oracle, sub, lens, w["fronts"], w["backs"], w["max_error_rate"], w["min_overlap"],
+                                 w["indel_cost"], 500_000, 100_000)
+    assert nf > 0.5 * sub.shape[0]
+
+
+def test_linked_groups_small_and_odd(hip_backend, oracle):
+    """Short batches, batches that end inside a tile, sets of one to three adapters, a group without reads, 5' parts with
+    errors (the queued anchored DP), lower-case free input already folded, reads shorter than the 5' part."""
+    import numpy as np
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.adapters import upper_ascii
+    rng = np.random.default_rng(5)
+    total = 0
+    for nad, n in ((4, 1), (4, 63), (4, 65), (1, 1000), (2, 4097), (3, 70_001), (4, 300_017)):
+        w = synth.workload("C4", 17, n, device="cuda")
+        reads = upper_ascii(w["reads"])
+        fronts, backs = w["fronts"][:nad], w["backs"][:nad]
+        if nad == 3:                                   # a group nobody belongs to: an adapter no read starts with
+            fronts = (fronts[0], "TTTTGGGGCCCCAAAATTGG", fronts[2])
+        lens = None
+        if n % 2 == 1 and n > 100:
+            lens = torch.from_numpy(rng.integers(0, 151, n).astype(np.int32)).cuda()
+        nf, _ = _linked_group_check(oracle, reads, lens, fronts, backs, 0.12, 3, 1, 0, min(n, 50_000))
+        total += nf
+    assert total > 100_000
