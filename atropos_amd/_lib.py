@@ -118,6 +118,8 @@ PROTOTYPES = {
     "atr_compare_one": (C.c_int, [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "atr_locate_planes_applies": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "atr_aligner_prepare": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "atr_locate_ascii_planes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_planes_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "atr_locate_batch_path": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_int, C.c_void_p]),
@@ -554,6 +556,23 @@ class HipBackend(object):
         if rc not in (0, -2):                             # (ATR_ERR_UNSUPPORTED: no specialised kernel, not an error)
             _check(self.lib, rc, "atr_aligner_prepare")
         return rc == 0
+
+    def locate_ascii_planes_batch(self, h, ascii_2d, lens, max_len, planes=None):
+        """atr_locate_ascii_planes_batch: a long batch of ASCII rows -> (records int16 [n, 8], the packed plane64 buffer the
+        call wrote) in one pre-pass launch + the DP kernels."""
+        nreads = ascii_2d.shape[0]
+        out = self.empty((nreads, 8), torch.int16)
+        if planes is None:
+            planes = self.empty((max(self.packed_bytes(nreads, max_len), 16),), torch.uint8)
+        if nreads:
+            need = self.lib.atr_locate_work_bytes(nreads)
+            if self._work is None or self._work.numel() < need:
+                self._work = self.empty((need,), torch.uint8)
+            with torch.cuda.device(self.device):
+                _check(self.lib, self.lib.atr_locate_ascii_planes_batch(h, _ptr(ascii_2d), ascii_2d.stride(0), _ptr(lens), nreads,
+                                                                        int(max_len), _ptr(planes), _ptr(out), _ptr(self._work),
+                                                                        self._stream()), "atr_locate_ascii_planes_batch")
+        return out, planes
 
     def locate_planes_batch(self, h, planes, lens, nreads, max_len):
         """Batched locate on a plane64 batch (atr_locate_planes_batch); lens None: equal-length reads."""

@@ -324,6 +324,12 @@ class Aligner(object):
                 lens_t = None if int(lens.min()) == int(lens.max()) else torch.from_numpy(lens).to(be.device)
                 return LocateResult(be.locate_ascii_batch(self._handle, torch.from_numpy(mat).to(be.device), lens_t,
                                                           int(lens.max())))
+        if (self._handle is not None and filtered and path in (None, "auto") and torch.is_tensor(reads) and reads.dim() == 2
+                and reads.dtype == torch.uint8 and reads.is_cuda and reads.shape[0] > _lib.WAVE_MAX_READS
+                and hasattr(be, "locate_ascii_planes_batch") and reads.stride(1) == 1
+                and self._wants_planes("auto", reads.shape[0], reads.shape[1])):
+            # a long batch of ASCII rows on the device: packed and pre-passed by ONE kernel (atr_locate_ascii_planes_batch)
+            return self.locate_ascii(reads)[0]
         batch = self.pack(reads, layout="plane64" if path == "pieces" else
                           "auto" if (filtered and path in (None, "auto")) else "tile64")
         if self._handle is None:                      # empty reference: nothing ever matches
@@ -339,6 +345,17 @@ class Aligner(object):
             raise ValueError("path \"pieces\" (the two-pass pre-pass) reads the plane64 layout: aligner.pack(reads, layout=\"plane64\")")
         return LocateResult(be.locate_batch(self._handle, batch.packed, batch.lens, batch.nreads, batch.max_len,
                                             filtered, path))
+
+    def locate_ascii(self, reads, lens=None, max_len=None):
+        """``locate`` for a long batch that is still text: ``reads`` a uint8 [n, width] tensor of ASCII rows on the device,
+        ``lens`` int32 [n] or None.  One kernel packs every read into bit planes and runs the two-pass pre-pass on the
+        registers it packed into (``atr_locate_ascii_planes_batch``; the aligner must be one ``pack(layout="auto")`` would
+        choose bit planes for).  Returns (LocateResult, the packed ``ReadBatch`` the call left behind -- e.g. for the next
+        adapter of a ``times > 1`` round); the records equal ``locate_batch(pack(reads))``."""
+        be = self._backend
+        max_len = reads.shape[1] if max_len is None else int(max_len)
+        rec, planes = be.locate_ascii_planes_batch(self._handle, reads, lens, max_len)
+        return LocateResult(rec), ReadBatch(planes, lens, reads.shape[0], max_len, self.table_kind, self._table, layout="plane64")
 
     def compare_batch(self, reads, suffix=False):
         """``compare_prefixes(reference, read, wildcard_ref, wildcard_query)`` (``compare_suffixes`` with

@@ -19,6 +19,8 @@ int launch_locate_fast(const atr_aligner *a, const uint4 *packed, const int32_t 
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out);
 int piece_ragged_len(int max_len);
 int prepare_locate_planes(const atr_aligner *a, int max_len, bool ragged);
+int launch_locate_ascii_fused(const atr_aligner *a, const uint8_t *ascii, long long row_stride, const int32_t *lens, long long nreads,
+                              int max_len, const uint8_t table[256], uint4 *planes, uint4 *out, void *work, hipStream_t st);
 int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,
                          void *work, hipStream_t st);
 int launch_prefix_band(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
@@ -318,6 +320,23 @@ int atr_locate_planes_batch(const atr_aligner *a, const uint8_t *d_planes, const
     if (!piece_applies(a, d_lens ? piece_ragged_len(max_len) : max_len, nullptr, nullptr)) return ATR_ERR_UNSUPPORTED;
     const int rc = launch_locate_planes(a, (const uint4 *)d_planes, d_lens, nreads, max_len, (uint4 *)d_out, d_work, (hipStream_t)stream);
     return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "two-pass locate launch");
+}
+
+int atr_locate_ascii_planes_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
+                                  int64_t nreads, int max_len, uint8_t *d_planes, atr_result *d_out, void *d_work, void *stream) {
+    if (!a || nreads < 0 || max_len < 0 || max_len > ATR_MAX_READ_LEN || row_stride < max_len) return ATR_ERR_INVALID;
+    if (nreads == 0) return ATR_OK;
+    if (!d_out || !d_ascii || !d_planes || !d_work) return ATR_ERR_INVALID;
+    if (!piece_applies(a, d_lens ? piece_ragged_len(max_len) : max_len, nullptr, nullptr)) return ATR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_locate_ascii_fused(a, d_ascii, row_stride, d_lens, nreads, max_len, a->qtable, (uint4 *)d_planes, (uint4 *)d_out,
+                                       d_work, st);
+    if (rc == 1) {   // no fused kernel for this aligner / stride on this box: the two-kernel form, the same records
+        rc = pack_launch<true>(d_ascii, row_stride, d_lens, nullptr, nreads, max_len, a->qtable, d_planes, nullptr, stream);
+        if (rc != ATR_OK) return rc;
+        rc = launch_locate_planes(a, (const uint4 *)d_planes, d_lens, nreads, max_len, (uint4 *)d_out, d_work, st);
+    }
+    return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "fused ASCII locate launch");
 }
 
 int atr_locate_ascii_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,

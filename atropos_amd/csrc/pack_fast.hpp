@@ -13,10 +13,14 @@
 #ifndef ATR_PACK_FAST_HPP
 #define ATR_PACK_FAST_HPP
 
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace atr {
+
+struct PackTableArg { uint8_t t[256]; };           // a translate table as a kernel argument
 
 struct PackLetters {
     uint32_t cA, cC, cG, cT, lutc;
@@ -31,59 +35,88 @@ __device__ __forceinline__ PackLetters pack_letters(const uint8_t *s_tab) {
 }
 constexpr uint32_t PACK_LETTERS_BY_INDEX = 0x47544341u;                 // 'A' 'C' 'T' 'G'
 
-// sw: LDS dwords; the row starts at byte 4 k + sh of it and has n bases; dwords from index `limit` on are not read.
+// One chunk (32 bases, chunk c) of a row as four bit planes.  sw: LDS dwords; the row starts at byte 4 k + sh of it and
+// has n bases; dwords from index `limit` on are not read; lo: the row's dword 8 c (carried from chunk to chunk: the
+// caller starts with sw[k]).
+//
+// Round 6.  Rounds 4 / 5 decided per DWORD whether its four bytes were all of A C G T and took a byte-by-byte path
+// otherwise -- a divergent branch that SOME lane of the wave takes in a quarter of the dwords (0.1 % N), so the wave
+// paid for both paths most of the time (pack_kernel: 0.61 ms per 10 M x 150 bp, issue bound).  Now the chunk is packed
+// as if every base were one of the four letters -- the two index bits of a base are bits 1 and 2 of its byte; a
+// v_dot4_u32_u8 with the weights 1 2 4 8 (16 32 64 128 for the odd dword) gathers one bit of four bytes into a nibble,
+// two dwords into a byte: 11 VALU ops per dword, no branch -- while `bad` collects perm(letters, index) ^ dword.  Only a
+// lane with a byte that is none of the four letters (a chunk in 30) then finds its invalid positions (a third dot
+// plane over the nonzero bytes) and walks them one by one through the table: the wave runs as many steps as its worst
+// lane has such bases -- one or two.
+__device__ __forceinline__ uint4 pack_planes_chunk_fast(const uint32_t *sw, uint32_t k, uint32_t limit, uint32_t sh, int n, int c,
+                                                        const PackLetters &L, const uint8_t *s_tab, uint32_t &lo, bool &zero_seen) {
+    uint32_t t[8], b0[4] = {0u, 0u, 0u, 0u}, b1[4] = {0u, 0u, 0u, 0u}, bad = 0u;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int j = 32 * c + 4 * g;
+        const uint32_t at = k + 8u * (uint32_t)c + (uint32_t)g + 1u;
+        const uint32_t hi = (j < n && at < limit) ? sw[at] : 0u;   // (nothing is read behind the read's last dword)
+        const uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        lo = hi;
+        const uint32_t idx = (w >> 1) & 0x03030303u;
+        t[g] = __builtin_amdgcn_perm(0u, PACK_LETTERS_BY_INDEX, idx) ^ w;      // nonzero byte <=> not one of the four letters
+        bad |= t[g];
+        const uint32_t wt = (g & 1) ? 0x80402010u : 0x08040201u;
+        b0[g >> 1] = __builtin_amdgcn_udot4(idx & 0x01010101u, wt, b0[g >> 1], false);
+        b1[g >> 1] = __builtin_amdgcn_udot4(idx & 0x02020202u, wt, b1[g >> 1], false);   // (twice the byte: shifted back below)
+    }
+    const uint32_t I0 = b0[0] | (b0[1] << 8) | (b0[2] << 16) | (b0[3] << 24);
+    const uint32_t I1 = (b1[0] >> 1) | (b1[1] << 7) | (b1[2] << 15) | (b1[3] << 23);
+    const int left = n - 32 * c;                                    // bases of this chunk inside the read
+    const uint32_t lm = left >= 32 ? ~0u : left <= 0 ? 0u : (1u << left) - 1u;
+    uint32_t inv = L.ok ? 0u : lm, slow[4] = {0u, 0u, 0u, 0u};
+    if (L.ok && bad != 0u) {
+        uint32_t z[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const uint32_t nzb = ((t[g] | ((t[g] & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;   // 1 per nonzero byte
+            z[g >> 1] = __builtin_amdgcn_udot4(nzb, (g & 1) ? 0x80402010u : 0x08040201u, z[g >> 1], false);
+        }
+        inv = (z[0] | (z[1] << 8) | (z[2] << 16) | (z[3] << 24)) & lm;
+    }
+    const uint32_t V = lm & ~inv;
+    if (inv != 0u) {
+        const uint8_t *row = (const uint8_t *)sw + 4u * k + sh + 32u * (uint32_t)c;
+        uint32_t todo = inv;
+        while (todo != 0u) {
+            const int i = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            const uint32_t code = s_tab[row[i]] & 15u;
+            zero_seen = zero_seen || code == 0u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) slow[p] |= ((code >> p) & 1u) << i;
+        }
+    }
+    const uint32_t m0 = ~I1 & ~I0 & V, m1 = ~I1 & I0 & V, m2 = I1 & ~I0 & V, m3 = I1 & I0 & V;   // A C T G
+    uint32_t pl[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        pl[p] = (((L.cA >> p) & 1u) ? m0 : 0u) | (((L.cC >> p) & 1u) ? m1 : 0u) | (((L.cT >> p) & 1u) ? m2 : 0u) |
+                (((L.cG >> p) & 1u) ? m3 : 0u) | slow[p];
+    return make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
+
 // dst: the lane's chunk 0 (chunks are 64 uint4 apart).
 __device__ __forceinline__ void pack_planes_row_fast(const uint32_t *sw, uint32_t k, uint32_t limit, uint32_t sh, int n, int nchunks,
                                                      const uint8_t *s_tab, uint4 *dst, bool &zero_seen) {
     const PackLetters L = pack_letters(s_tab);
     uint32_t lo = k < limit ? sw[k] : 0u;
-    for (int c = 0; c < nchunks; ++c) {
-        uint32_t X = 0u, Y = 0u, V = 0u, slow[4] = {0u, 0u, 0u, 0u};
+    for (int c = 0; c < nchunks; ++c) dst[(size_t)c * 64] = pack_planes_chunk_fast(sw, k, limit, sh, n, c, L, s_tab, lo, zero_seen);
+}
+
+// The same into registers (the fused ASCII entry of the two-pass pre-pass, piece_filter.hpp): pl[c] = chunk c.
+template <int NCH>
+__device__ __forceinline__ void pack_planes_row_regs(const uint32_t *sw, uint32_t k, uint32_t sh, int n, const uint8_t *s_tab,
+                                                     uint4 (&pl)[NCH], bool &zero_seen) {
+    const PackLetters L = pack_letters(s_tab);
+    uint32_t lo = sw[k];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int j = 32 * c + 4 * g;
-            const uint32_t at = k + 8u * (uint32_t)c + (uint32_t)g + 1u;
-            const uint32_t hi = (j < n && at < limit) ? sw[at] : 0u;   // (nothing is read behind the read's last dword)
-            uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, sh);
-            lo = hi;
-            const int left = n - j;                                 // bases of this dword inside the read
-            if (left < 4) w = left <= 0 ? 0u : (w & ((1u << (8 * left)) - 1u));
-            const uint32_t idx = (w >> 1) & 0x03030303u;
-            if (L.ok && __builtin_amdgcn_perm(0u, PACK_LETTERS_BY_INDEX, idx) == w) {
-                uint32_t z = idx | (idx >> 6);
-                z |= z >> 12;
-                const uint32_t r = z & 0xFFu;                      // the four index pairs, base b at bits 2b, 2b + 1
-                if (g < 4) X |= r << (8 * g); else Y |= r << (8 * (g - 4));
-                V |= 0xFu << (4 * g);
-            } else if (left > 0) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b < left) {
-                        const uint32_t code = s_tab[(w >> (8 * b)) & 255u] & 15u;
-                        zero_seen = zero_seen || code == 0u;
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) slow[p] |= ((code >> p) & 1u) << (4 * g + b);
-                    }
-                }
-            }
-        }
-        // even / odd bits of X (bases 0 .. 15) and Y (16 .. 31) -> I0, I1
-        const auto even16 = [](uint32_t x) {
-            x &= 0x55555555u;
-            x = (x | (x >> 1)) & 0x33333333u;
-            x = (x | (x >> 2)) & 0x0F0F0F0Fu;
-            x = (x | (x >> 4)) & 0x00FF00FFu;
-            return (x | (x >> 8)) & 0xFFFFu;
-        };
-        const uint32_t I0 = even16(X) | (even16(Y) << 16), I1 = even16(X >> 1) | (even16(Y >> 1) << 16);
-        const uint32_t m0 = ~I1 & ~I0 & V, m1 = ~I1 & I0 & V, m2 = I1 & ~I0 & V, m3 = I1 & I0 & V;   // A C T G
-        uint32_t pl[4];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-            pl[p] = (((L.cA >> p) & 1u) ? m0 : 0u) | (((L.cC >> p) & 1u) ? m1 : 0u) | (((L.cT >> p) & 1u) ? m2 : 0u) |
-                    (((L.cG >> p) & 1u) ? m3 : 0u) | slow[p];
-        dst[(size_t)c * 64] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-    }
+    for (int c = 0; c < NCH; ++c) pl[c] = pack_planes_chunk_fast(sw, k, 0x7fffffffu, sh, n, c, L, s_tab, lo, zero_seen);
 }
 
 __device__ __forceinline__ void pack_codes_row_fast(const uint32_t *sw, uint32_t k, uint32_t limit, uint32_t sh, int n, int nchunks,
@@ -136,7 +169,7 @@ __device__ __forceinline__ uint32_t pack_stage_tile(uint8_t *stage, const uint8_
     const uint8_t *src = ascii + tile * 64 * row_stride;
     const uintptr_t mis = (uintptr_t)src & 15;
     const uint8_t *src_al = src - mis;
-    const long long rows_here = min<long long>(64, nreads - tile * 64);
+    const long long rows_here = nreads - tile * 64 < 64 ? nreads - tile * 64 : 64;
     const long long need = mis + rows_here * row_stride;       // bytes of the window that are ours
     const uint8_t *buf_end = ascii + nreads * row_stride;
     for (long long base = 0; base < need; base += 8 * 64 * 16) {

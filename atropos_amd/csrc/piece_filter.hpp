@@ -6,6 +6,7 @@
 #define ATR_PIECE_FILTER_HPP
 
 #include "fast_work.hpp"
+#include "pack_fast.hpp"
 
 namespace atr {
 
@@ -21,7 +22,9 @@ namespace atr {
 #define ATR_PIECE_STASH 1
 #endif
 #ifndef ATR_PIECE_WAVES
-#ifdef ATR_SPEC
+#if defined(ATR_SPEC) && defined(ATR_SPEC_ASCII)
+#define ATR_PIECE_WAVES(NW) 2                                           // (the tile's ASCII rows are staged in LDS: two blocks per CU)
+#elif defined(ATR_SPEC)
 #define ATR_PIECE_WAVES(NW) ((NW) <= 6 ? 4 : 3)                         // (no spills at these: tools/jit/spec_offline.sh)
 #else
 #define ATR_PIECE_WAVES(NW) ((NW) <= 6 ? 4 : (NW) <= 8 ? 3 : 2)          // (the generic kernel holds five piece accumulators)
@@ -77,9 +80,27 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
 template <int NW, bool RAGGED>
 __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const FilterParams &fp_arg, const PieceParams &pp_arg,
                                                   const uint4 *__restrict__ planes, const int32_t *__restrict__ lens,
-                                                  long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk) {
+                                                  long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk,
+                                                  const uint8_t *__restrict__ ascii = nullptr, const uint8_t *tab = nullptr) {
 #ifdef ATR_SPEC
     if (!RAGGED) max_len = spec::N;                               // (what the host compiled this kernel for)
+#endif
+#ifdef ATR_SPEC_ASCII
+    // FUSED ASCII ENTRY (round 6): the batch arrives as rows of ASCII (row stride ATR_SPEC_STRIDE, a constant of this
+    // build) and `planes` is an OUTPUT: a wave stages its tile's rows in LDS with coalesced 16-byte loads (requested a
+    // tile ahead into registers), packs its read into the four bit planes in registers (pack_fast.hpp: the very code of
+    // pack_kernel), stores them -- the DP kernels and the full sweep of the listed reads gather from them -- and goes
+    // straight into pass A.  What the two-kernel form (atr_pack_planes, then this pre-pass) writes and reads again -- 80
+    // bytes per read each way -- is written once and read by the few reads that need it.
+    static_assert(NW <= 8, "the fused ASCII entry keeps pass B's window in the LDS stash");
+    constexpr int STRIDE = ATR_SPEC_STRIDE;
+    constexpr int NPC = (15 + 64 * STRIDE + 1023) / 1024;          // 16-byte pieces per lane of a tile's aligned window
+    constexpr int STAGE_BYTES = (64 * STRIDE + PACK_STAGE_SLACK + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[4][STAGE_BYTES];
+    __shared__ uint8_t s_tab[256];
+    s_tab[threadIdx.x] = tab[threadIdx.x];
+    uint4 *planes_out = const_cast<uint4 *>(planes);
+    const uint8_t *buf_end = ascii + nreads * STRIDE;
 #endif
     const int n = RAGGED ? 32 * NW : max_len;                     // the length pass A sees (wave-uniform)
     __shared__ uint2 s_peq[16];
@@ -227,17 +248,74 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     // pass A: the round trip to HBM runs under ~2.5 k cycles of pass A.  (Round 4 requested them after pass A, "when
     // its registers are free": two iterations in three then consumed them a queue insertion later -- the wave sat
     // through the whole latency, 40 % of its time by s_memtime.)  20 more registers through pass A: 72 of the 96.
+#ifdef ATR_SPEC_ASCII
+    // the tile's 16-byte aligned window [al, al + need): inside the matrix for every tile but the batch's first (when the
+    // matrix does not start on a 16-byte boundary) and last -- those are staged by pack_stage_tile, piece by piece
+    uint4 ax[NPC];
+    const auto ascii_edge = [&](long long tile) {
+        const uint8_t *src = ascii + tile * 64 * STRIDE;
+        const uint8_t *al = src - ((uintptr_t)src & 15);
+        const long long need = (long long)((uintptr_t)src & 15) + (nreads - tile * 64 < 64 ? nreads - tile * 64 : 64) * STRIDE;
+        return al < ascii || al + ((need + 15) & ~15ll) > buf_end;
+    };
+    const auto ascii_request = [&](long long tile) {
+        if (ascii_edge(tile)) return;                              // wave-uniform
+        const uint8_t *src = ascii + tile * 64 * STRIDE;
+        const uint8_t *al = src - ((uintptr_t)src & 15);
+        const long long need = (long long)((uintptr_t)src & 15) + (nreads - tile * 64 < 64 ? nreads - tile * 64 : 64) * STRIDE;
+#pragma unroll
+        for (int u = 0; u < NPC; ++u) {
+            const long long o = (long long)u * 1024 + (long long)lane * 16;
+            ax[u] = o < need ? *(const uint4 *)(al + o) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    if (t0 + wave < t1) ascii_request(t0 + wave);
+#else
     uint4 nx[NW];
     if (t0 + wave < t1) {
         const uint4 *tp = planes + (size_t)(t0 + wave) * NW * 64;             // (wave-uniform base + lane: scalar base, 32-bit offset)
 #pragma unroll
         for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
     }
+#endif
     for (long long tile = t0 + wave; tile < t1; tile += 4) {
         const long long r = tile * 64 + lane;
         const bool live = r < nreads;
         // ---- pass A ----
         uint32_t pl[NW][4];
+#ifdef ATR_SPEC_ASCII
+        {
+            uint8_t *stage = s_stage[wave];
+            uint32_t mis;
+            if (ascii_edge(tile)) {
+                mis = pack_stage_tile(stage, ascii, STRIDE, nreads, tile, lane);
+            } else {
+                const uint8_t *src = ascii + tile * 64 * STRIDE;
+                mis = (uint32_t)((uintptr_t)src & 15);
+                const long long need = (long long)mis + (nreads - tile * 64 < 64 ? nreads - tile * 64 : 64) * STRIDE;
+#pragma unroll
+                for (int u = 0; u < NPC; ++u) {
+                    const long long o = (long long)u * 1024 + (long long)lane * 16;
+                    if (o < need) *(uint4 *)(stage + o) = ax[u];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            if (tile + 4 < t1) ascii_request(tile + 4);           // the next tile's rows: in flight under the pack and pass A
+            __builtin_amdgcn_sched_barrier(0);
+            const int np = live ? (RAGGED ? min(max(lens[r], 0), max_len) : max_len) : 0;
+            const uint32_t rowoff = mis + (uint32_t)lane * (uint32_t)STRIDE;
+            uint4 pk[NW];
+            bool zero_seen = false;
+            pack_planes_row_regs<NW>((const uint32_t *)stage, rowoff >> 2, rowoff & 3u, np, s_tab, pk, zero_seen);
+            uint4 *tp = planes_out + (size_t)tile * NW * 64;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                tp[w * 64 + lane] = pk[w];
+                pl[w][0] = pk[w].x; pl[w][1] = pk[w].y; pl[w][2] = pk[w].z; pl[w][3] = pk[w].w;
+            }
+        }
+#else
 #pragma unroll
         for (int w = 0; w < NW; ++w) { pl[w][0] = nx[w].x; pl[w][1] = nx[w].y; pl[w][2] = nx[w].z; pl[w][3] = nx[w].w; }
 #if ATR_PIECE_PREFETCH_EARLY
@@ -247,6 +325,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             for (int w = 0; w < NW; ++w) nx[w] = tp[w * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);                        // (the loads stay up here)
+#endif
 #endif
         int nr = max_len, back = 0;                               // the read's own length; positions it is moved up by
         if (RAGGED) {
@@ -313,7 +392,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
                 if (wide) wlist[(long long)base + lane_rank(wm)] = (uint32_t)r;
             }
         }
-#if !ATR_PIECE_PREFETCH_EARLY
+#if !ATR_PIECE_PREFETCH_EARLY && !defined(ATR_SPEC_ASCII)
         __builtin_amdgcn_sched_barrier(0);
         if (tile + 4 < t1) {                                                  // the next tile's planes
             const uint4 *tp = planes + (size_t)(tile + 4) * NW * 64;

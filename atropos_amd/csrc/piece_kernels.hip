@@ -104,7 +104,7 @@ bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, Piec
 // The run-time compiled pre-pass of this aligner for reads of max_len bases (jit.hpp), or nullptr: the generic kernel.
 // force: compile now if no object exists yet (atr_aligner_prepare; ATR_JIT=1); otherwise jit.hpp's policy decides.
 static const jit::SpecKernel *piece_spec_for(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, bool ragged,
-                                             int max_len, long long nreads, bool force) {
+                                             int max_len, long long nreads, bool force, int ascii_stride = 0) {
     const int pol = jit::policy();
     if (pol == 0) return nullptr;
     const int nw = (max_len + 31) / 32;
@@ -112,7 +112,7 @@ static const jit::SpecKernel *piece_spec_for(const atr_aligner *a, const FilterP
     // then paid back within a few hundred million reads, and at once from the second run on -- the disk cache)
     a->planes_seen += nreads;
     const bool compile = force || pol == 1 || a->planes_seen >= jit::min_reads();
-    return jit::spec_kernel(a, fp, pp, nw, ragged, ragged ? 32 * nw : max_len, compile);
+    return jit::spec_kernel(a, fp, pp, nw, ragged, ragged ? 32 * nw : max_len, compile, ascii_stride);
 }
 
 // 1: a specialised kernel is ready for (aligner, max_len, ragged) on the current device; 0: there is none (outside the
@@ -179,6 +179,38 @@ int launch_locate_planes_shared(const atr_aligner *a, const uint4 *planes, const
     const int rc = launch_planes_prepass(a, planes, lens, nreads, max_len, out, work, st, grid_div, &pc);
     if (rc != 0) return rc;
     return launch_planes_tail(a, planes, lens, nreads, max_len, out, pc, st, one_stream);
+}
+
+// The fused ASCII entry (piece_filter.hpp, ATR_SPEC_ASCII): rows of `row_stride` bytes in, the packed plane64 batch
+// (`planes`, written) and the records out, in ONE pre-pass launch + the DP tail.  Exists only as a run-time compiled
+// kernel (aligner, read length and row stride are constants of the build): returns 1 when there is none -- outside the
+// envelope, no hiprtc, reads of more than 256 bases, ATR_JIT=0 -- and the caller packs and calls launch_locate_planes.
+int launch_locate_ascii_fused(const atr_aligner *a, const uint8_t *ascii, long long row_stride, const int32_t *lens, long long nreads,
+                              int max_len, const uint8_t table[256], uint4 *planes, uint4 *out, void *work, hipStream_t st) {
+    FilterParams fp;
+    PieceParams pp;
+    if (!piece_applies(a, lens ? piece_ragged_len(max_len) : max_len, &fp, &pp)) return 1;
+    const int nw = (max_len + 31) / 32;
+    static const bool off = [] { const char *x = getenv("ATR_ASCII_FUSED"); return x && x[0] == '0'; }();      // (A/B switch)
+    if (off || nw > 8 || row_stride < max_len || row_stride > 256 || ((uintptr_t)ascii & 1)) return 1;
+    // (an entry for batches that are long by definition: compile at the first call unless the policy says never)
+    const jit::SpecKernel *sk = piece_spec_for(a, fp, pp, lens != nullptr, max_len, nreads, jit::policy() != 0, (int)row_stride);
+    if (!sk) return 1;
+    FastWork wk = fast_carve(work, nreads);
+    wk.lpw = nreads <= 8192 ? 0 : 64;
+    wk.fused = fast_fused_scan() ? 1 : 0;
+    if (wk.fused) {
+        const hipError_t rc = hipMemsetAsync(wk.chunks, 0, (size_t)wk.nbins * 4, st);
+        if (rc != hipSuccess) return (int)rc;
+    }
+    const long long want = ((nreads + 63) / 64 + 3) / 4;
+    wk.nused = (int)std::max<long long>(1, std::min<long long>(sk->resident, want));
+    const hipError_t rc = jit::spec_launch_ascii(sk, wk.nused, ascii, lens, nreads, max_len, out, wk, planes, table, st);
+    if (rc != hipSuccess) return (int)rc;
+    PlanesCall pc;
+    pc.wk = wk;
+    pc.nw = nw;
+    return launch_planes_tail(a, planes, lens, nreads, max_len, out, pc, st, false);
 }
 
 int launch_locate_planes(const atr_aligner *a, const uint4 *planes, const int32_t *lens, long long nreads, int max_len, uint4 *out,

@@ -299,7 +299,23 @@ class C2(object):
 
         if self.ascii is not None:
             ms = run(lambda: self.al.locate_batch(self.al.pack(self.ascii, layout=self.batch.layout), self.filtered))
-            out["pack_inclusive_reads_per_s"] = self.n / (ms * 1e-3)        # ASCII in HBM -> records
+            out["pack_then_locate_reads_per_s"] = self.n / (ms * 1e-3)      # ASCII in HBM -> records, two calls (pack, locate)
+            out["pack_inclusive_reads_per_s"] = out["pack_then_locate_reads_per_s"]
+            if self.filtered and self.batch.layout == "plane64" and hasattr(self.al._backend, "locate_ascii_planes_batch"):
+                # the fused ASCII entry: rows -> bit planes in registers -> pass A in one kernel (atr_locate_ascii_planes_batch)
+                planes_buf = [None]
+
+                def fused():
+                    res, left = self.al.locate_ascii(self.ascii) if planes_buf[0] is None else (
+                        self.al._backend.locate_ascii_planes_batch(self.al._handle, self.ascii, None, 150, planes_buf[0]))
+                    planes_buf[0] = left.packed if hasattr(left, "packed") else left
+                    return res
+                ms = run(fused)
+                out["fused_ascii_reads_per_s"] = self.n / (ms * 1e-3)
+                out["pack_inclusive_reads_per_s"] = max(out["pack_inclusive_reads_per_s"], out["fused_ascii_reads_per_s"])
+                rec = fused()
+                rec = rec.records if hasattr(rec, "records") else rec
+                out["fused_ascii_records_equal"] = bool(torch.equal(rec, self.al.locate_batch(self.batch, self.filtered).records))
             # ragged batch: the same reads cut to lengths 100..150 (what quality-trimmed data looks like)
             from atropos_amd.batch import ReadBatch
             g = torch.Generator(device=self.ascii.device).manual_seed(5)

@@ -157,6 +157,17 @@ int atr_locate_work_unresolved(const void *d_work, int64_t nreads, int n_adapter
 int atr_locate_batch(const atr_aligner *a, const uint8_t *d_packed, const int32_t *d_lens,
                      int64_t nreads, int max_len, atr_result *d_out, void *d_work, void *stream);
 
+/* Aligner.locate(query) for a LONG batch of reads that are still ASCII rows (_align.pyx:266-297 takes the string; every
+ * real caller starts from text): ONE pre-pass kernel stages a tile's rows through LDS, packs each read into bit planes in
+ * registers (the aligner's query table), stores them to d_planes -- atr_packed_bytes(nreads, max_len) bytes, afterwards a
+ * complete plane64 batch, e.g. for the next adapter -- and runs the two-pass pre-pass on the registers; then the DP
+ * kernels of atr_locate_planes_batch.  Same records as atr_pack_planes + atr_locate_planes_batch, which is also what runs
+ * when there is no fused kernel (it exists as a run-time compiled build for this aligner, read length and row stride:
+ * no hiprtc, ATR_JIT=0, reads of more than 256 bases, rows wider than 256 bytes).  Envelope: atr_locate_planes_applies.
+ * d_work: atr_locate_work_bytes(nreads).  Short batches: atr_locate_ascii_batch. */
+int atr_locate_ascii_planes_batch(const atr_aligner *a, const uint8_t *d_ascii, int64_t row_stride, const int32_t *d_lens,
+                                  int64_t nreads, int max_len, uint8_t *d_planes, atr_result *d_out, void *d_work, void *stream);
+
 /* Aligner.locate(query) for a batch of reads in the plane64 layout (atr_pack_planes with the aligner's query
  * table; _align.pyx:266-491, same records as atr_locate_batch).  d_lens as in atr_locate_batch (NULL: every read
  * has max_len bases; else the positions of a read past its length must hold code 0, as atr_pack_planes leaves

@@ -97,3 +97,60 @@ def test_certificates_on_device(hip_backend, oracle, jit_on):
         assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 43, 10, count=3000) > 15000
     finally:
         os.environ["ATR_JIT"] = "1"
+
+
+def test_fused_ascii_entry(hip_backend, oracle, monkeypatch):
+    """atr_locate_ascii_planes_batch (round 6): ASCII rows -> bit planes in registers -> pass A in ONE kernel.  Records and
+    the packed batch it leaves behind equal atr_pack_planes + atr_locate_planes_batch: equal-length and ragged batches,
+    batches that end inside a tile, rows wider than the reads, a matrix that does not start on a 16-byte boundary, other
+    adapters / error rates, soft-masked and non-ACGT bytes; the switch that turns the fused kernel off; the oracle."""
+    import torch
+    from atropos_amd import synth
+    from atropos_amd.align import Aligner
+    rng = np.random.default_rng(23)
+    n = 400_003
+    w = synth.workload("C2", 5 << 20, n, device="cuda:0")
+    reads = w["reads"]
+    cases = [(w["adapter"], 0.1, 3), (synth.TRUSEQ_33, 0.12, 5), (synth.LINKED_BACKS[1], 0.08, 1)]
+    checked = 0
+    for adapter, e, mo in cases:
+        al = Aligner(adapter, e, 14, False, False, mo, 1)
+        for variant in ("equal", "ragged", "wide_rows", "unaligned", "dirty"):
+            mat, lens, max_len = reads, None, 150
+            if variant == "ragged":
+                lens = torch.from_numpy(rng.integers(0, 151, n).astype(np.int32)).cuda()
+            elif variant == "wide_rows":                              # 150-base reads in rows of 160 bytes
+                mat = torch.zeros((n, 160), dtype=torch.uint8, device="cuda:0")
+                mat[:, :150] = reads
+                mat = mat[:, :150]                                    # (a view: stride 160)
+            elif variant == "unaligned":                              # the first row starts 150 bytes into the buffer; n - 1 rows
+                mat = reads[1:]
+            elif variant == "dirty":
+                mat = reads.clone()
+                idx = torch.from_numpy(rng.integers(0, n * 150, 200_000)).cuda()
+                mat.view(-1)[idx] = torch.from_numpy(rng.choice(np.frombuffer(b"acgtNnRYX.-*", np.uint8), 200_000)).cuda()
+            k = mat.shape[0]
+            res, left = al.locate_ascii(mat, lens, max_len)
+            got = res.records
+            ref_batch = al.pack(mat if lens is None else mat, layout="plane64") if lens is None else None
+            if lens is None:
+                want = al.locate_batch(ref_batch).records
+                assert torch.equal(left.packed[:ref_batch.packed.numel()], ref_batch.packed), (adapter, variant)
+            else:
+                from atropos_amd.batch import ReadBatch
+                ref_batch = ReadBatch.from_ascii(mat, lens, 150, al.table_kind, al._table, planes=True)
+                want = al.locate_batch(ref_batch).records
+                assert torch.equal(left.packed[:ref_batch.packed.numel()], ref_batch.packed), (adapter, variant)
+            assert torch.equal(got, want), (adapter, variant)
+            # the same through locate_batch's own routing (a long uint8 tensor on the device) and with the fused kernel off
+            if variant == "equal":
+                assert torch.equal(al.locate_batch(mat).records, want)
+                sl = mat[:60_000].cpu().numpy()
+                exp = oracle.locate_many(adapter, sl, np.full(len(sl), 150, np.int32), e, 14, False, False, mo, 1, 8)
+                assert np.array_equal(got[:60_000, :6].cpu().numpy().astype(np.int32), exp)
+            checked += k
+    monkeypatch.setenv("ATR_JIT", "0")                                 # no fused kernel: the two-kernel form behind the same entry
+    al = Aligner(w["adapter"], 0.1, 14, False, False, 3, 1)
+    res, _ = al.locate_ascii(reads[:100_000].contiguous())
+    assert torch.equal(res.records, al.locate_batch(al.pack(reads[:100_000].contiguous(), layout="plane64")).records)
+    assert checked > 5_000_000

@@ -416,3 +416,49 @@ def test_locate_stream_equals_one_call(hip_backend, oracle):
     exp = oracle.locate_many(w["adapter"], reads[:50_000].cpu().numpy(), np.full(50_000, 150, np.int32), w["max_error_rate"], 14,
                              False, False, w["min_overlap"], w["indel_cost"], 8)
     assert np.array_equal(rec[:50_000, :6].cpu().numpy().astype(np.int32), exp)
+
+
+def test_pack_planes_against_numpy(hip_backend):
+    """atr_pack_planes (pack_fast.hpp: round 6's branch-free core -- index bits gathered with v_dot4, invalid bytes walked
+    per lane) against a numpy restatement of the layout (include/atropos_hip.h): random rows of A C G T with IUPAC letters,
+    lower case, N runs and arbitrary bytes mixed in; ragged lengths, per-read starts, rows of 40 .. 256 bytes, batches
+    that end inside a tile, both translate tables."""
+    from atropos_amd import _lib
+    rng = np.random.default_rng(41)
+    be = hip_backend
+    alphabet = np.frombuffer(b"ACGT" * 60 + b"NNNRYSWKMBDHVacgtn.-*X\x00\xff", np.uint8)
+    total = 0
+    for kind in (_lib.TABLE_DNA15, _lib.TABLE_ACGT, _lib.TABLE_IUPAC):
+        table = be.translate_table(kind)
+        tab = np.frombuffer(table, np.uint8).astype(np.uint32) & 15
+        for n, width, max_len in ((1, 40, 33), (63, 150, 150), (65, 151, 150), (1000, 256, 250), (4099, 100, 100), (70001, 150, 150)):
+            mat = alphabet[rng.integers(0, len(alphabet), (n, width))]
+            if n > 500:                                              # clean rows too: the fast path alone
+                mat[::3] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (len(mat[::3]), width))]
+            lens = rng.integers(0, max_len + 1, n).astype(np.int32)
+            starts = np.where(rng.random(n) < 0.3, rng.integers(0, 8, n), 0).astype(np.int32)
+            lens = np.maximum(lens, starts)                          # (len counts from the row's start: len - start bases are packed)
+            for use_lens, use_starts in ((False, False), (True, False), (True, True)):
+                d_mat = torch.from_numpy(mat).cuda()
+                d_lens = torch.from_numpy(lens).cuda() if use_lens else None
+                d_starts = torch.from_numpy(starts).cuda() if use_starts else None
+                got = be.pack_reads(d_mat, d_lens, max_len, table, starts=d_starts, planes=True).cpu().numpy().view(np.uint32)
+                nch = (max_len + 31) // 32
+                st = starts if use_starts else np.zeros(n, np.int32)
+                ln = (lens if use_lens else np.full(n, max_len, np.int32)) - st
+                ln = np.clip(ln, 0, max_len)
+                pos = np.arange(32 * nch)[None, :]
+                src = np.minimum(pos + st[:, None], width - 1)
+                codes = np.where(pos < ln[:, None], tab[np.take_along_axis(mat, src, 1)], 0).astype(np.uint64)   # [n, 32 nch]
+                ntiles = (n + 63) // 64
+                want = np.zeros((ntiles, nch, 64, 4), np.uint32)
+                bits = codes.reshape(n, nch, 32)
+                wts = (np.uint64(1) << np.arange(32, dtype=np.uint64))
+                for p in range(4):
+                    words = (((bits >> np.uint64(p)) & np.uint64(1)) * wts).sum(axis=2).astype(np.uint32)       # [n, nch]
+                    buf = np.zeros((ntiles * 64, nch), np.uint32)
+                    buf[:n] = words
+                    want[:, :, :, p] = buf.reshape(ntiles, 64, nch).transpose(0, 2, 1)
+                assert np.array_equal(got[:want.size].reshape(want.shape), want), (kind, n, width, max_len, use_lens, use_starts)
+                total += n
+    assert total > 400_000
