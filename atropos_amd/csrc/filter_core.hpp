@@ -51,6 +51,7 @@ struct FilterParams {
     uint64_t cert_sub;                              // bit r - 1: the adapter with ONE substitution, at row r, is decided without the
                                                     // DP (filter_substitution_certificate); 0: never
     uint64_t rowsel[4];                             // rows whose code is the one-hot code of plane c, bit r - 1 (cert_sub != 0 only)
+    uint32_t tailx[3];                              // extended NARROW mode (two-pass pre-pass, m = 41 .. 64): rows 41 .. 64, as `tail`
 };
 
 // NARROW mode.  A 33 .. 40-base adapter needs two 32-bit words per bit-vector and ~28 VALU ops per
@@ -73,6 +74,15 @@ struct FilterParams {
 constexpr int FILTER_NARROW_ROWS = 32, FILTER_NARROW_TAIL = 8;
 inline bool filter_narrow_applies(int m, int flags) {          // host side
     return m > FILTER_NARROW_ROWS && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && !(flags & ATR_START_WITHIN_SEQ1);
+}
+// EXTENDED NARROW mode (round 6), the two-pass pre-pass only: every argument above holds for ANY number T of tail rows --
+// the 32-row matrix brackets the row-m candidates of a 41 .. 64-base adapter just as well -- so pass B keeps its one-word
+// bit-vector (16 ops a column instead of 25) for adapters of up to 64 bases; the tail compare walks up to four dwords.
+// What gets weaker is the last column (a longer row is only kept by the lower bound D'[32][n] - (i - 32)): more of the
+// partial adapters at the read end go to the banded DP, which sweeps all m rows anyway.
+constexpr int FILTER_NARROW_TAIL_EXT = 32;
+inline bool filter_narrow_ext_applies(int m, int flags) {
+    return m > FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL_EXT && !(flags & ATR_START_WITHIN_SEQ1);
 }
 // PERFECT OVERLAP + EXTENSION ROWS, decided without the DP (round 5).  The commonest unresolved read of a 3' adapter
 // batch (1.2 M of C2's 2.26 M) ends with the adapter's first i bases verbatim: cell (i, n) costs 0 and holds i matches,
@@ -179,17 +189,22 @@ inline uint64_t filter_substitution_certificate(const uint8_t *codes, int m, int
 }
 
 // peq64: the aligner's match masks (top-aligned in 64 bits when m > 32, in 32 bits otherwise)
+// planes_path: the parameters of the two-pass pre-pass (extended NARROW mode for adapters of 41 .. 64 bases)
 inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, int m, int flags, bool and_mode,
-                                  const int16_t *thr, int min_overlap) {
+                                  const int16_t *thr, int min_overlap, bool planes_path = false) {
     FilterParams fp;
     fp.rows = m; fp.and_mode = and_mode ? 1 : 0; fp.tail = 0u;
+    fp.tailx[0] = fp.tailx[1] = fp.tailx[2] = 0u;
     for (int i = 0; i <= FILTER_MAX_M; ++i)
         fp.thr_row[i] = (i >= 1 && i <= m && i >= min_overlap && ((flags & ATR_STOP_WITHIN_SEQ1) || i == m)) ? (int32_t)thr[i] : -1;
     for (int c = 0; c < 16; ++c) fp.peq[c] = peq64[c];
-    if (filter_narrow_applies(m, flags)) {
+    if (filter_narrow_applies(m, flags) || (planes_path && filter_narrow_ext_applies(m, flags))) {
         fp.rows = FILTER_NARROW_ROWS;
         for (int c = 0; c < 16; ++c) fp.peq[c] = (peq64[c] >> (64 - m)) & 0xFFFFFFFFull;      // rows 1 .. 32 at bits 0 .. 31
-        for (int t = 0; t < m - FILTER_NARROW_ROWS; ++t) fp.tail |= (uint32_t)(codes[FILTER_NARROW_ROWS + t] & 15u) << (4 * t);
+        for (int t = 0; t < m - FILTER_NARROW_ROWS; ++t) {
+            const uint32_t nib = (uint32_t)(codes[FILTER_NARROW_ROWS + t] & 15u) << (4 * (t & 7));
+            if (t < 8) fp.tail |= nib; else fp.tailx[(t >> 3) - 1] |= nib;
+        }
     }
     filter_overlap_certificates(codes, m, fp.rows, fp.thr_row, and_mode, fp.cert);
     fp.cert_sub = 0ull;
@@ -534,15 +549,30 @@ ATR_DEV int filter_last_column(const FilterState &F, const Uniform &u, const P &
 // NARROW mode: do the T = m - mf bases after column jp equal the adapter's tail rows?
 // q: this read's dwords (read_dword below).
 ATR_DEV uint32_t read_dword(const uint32_t *q, int nchunks, int z8);
+// dw(z): the dword of eight codes z (bases 8 z + 1 ..) of the caller's copy of the read; T <= 32 tail rows.
+template <class P, class DW>
+ATR_DEV bool filter_tail_cmp(const P &fp, int T, int jp, DW dw) {
+    const uint32_t sh = 4u * (uint32_t)(jp & 7);
+    bool ok = true;
+    uint32_t lo = dw(jp >> 3);
+#pragma unroll
+    for (int q = 0; q < FILTER_NARROW_TAIL_EXT / 8; ++q) {
+        if (8 * q >= T) break;                                                      // wave-uniform
+        const uint32_t hi = dw((jp >> 3) + q + 1);
+        const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;             // bases jp + 8 q + 1 .. jp + 8 q + 8
+        lo = hi;
+        const uint32_t tw = q == 0 ? fp.tail : fp.tailx[q >= 1 ? q - 1 : 0];
+        const uint32_t x = fp.and_mode ? (w & tw) : (w ^ tw);
+        const int left = T - 8 * q;
+        const uint32_t ones = left >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * left)) - 1u));
+        const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;            // nibble != 0
+        ok = ok && (fp.and_mode ? nz == ones : nz == 0u);
+    }
+    return ok;
+}
 template <class P>
 ATR_DEV bool filter_tail_matches(const P &fp, int T, const uint32_t *q, int nchunks, int jp) {
-    const uint32_t lo = read_dword(q, nchunks, jp >> 3), hi = read_dword(q, nchunks, (jp >> 3) + 1);
-    const uint32_t sh = 4u * (uint32_t)(jp & 7);
-    const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;                 // bases jp + 1 .. jp + 8
-    const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
-    const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
-    const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;                // nibble != 0
-    return fp.and_mode ? nz == ones : nz == 0u;
+    return filter_tail_cmp(fp, T, jp, [&](int z) { return read_dword(q, nchunks, z); });
 }
 
 // Decision for one read of length n after the sweep.  Returns the window word (0 when the
@@ -559,9 +589,16 @@ struct FilterNoDiag { ATR_DEV_MEMBER uint64_t operator()(int) const { return ~0u
 
 // dg(d): the rows of the adapter that DISAGREE with the read on diagonal d (row r against column d + r), bit r - 1, all
 // m rows; ~0 when the caller cannot tell.  Asked for at most once, and only when fp.cert_sub != 0.
+// pa_dlo .. pa_dhi (two-pass pre-pass; pa_dhi < pa_dlo: none): diagonals that hold the whole traceback of every row-m
+// candidate BY THE PIECES -- an alignment of all m rows with <= k errors keeps one of the k + 1 (or more) disjoint pieces
+// intact, pass A has seen every exact occurrence of every piece (diagonals d_min .. d_max), and a path strays from the
+// diagonal of its intact piece by at most its indels <= k: d_min - k .. d_max + k (the caller hands over max(0, d_min - k):
+// a first diagonal of 0 may be a clamped one -- cells below the main diagonal exist -- and is not taken).  The hits of the swept rows spread
+// over 2 (k - c) more columns than that (every column within k - c of a cost-c occurrence is a hit), which for k >= 5
+// pushed every read with an error out of the 16-diagonal band into the column window (64-mers: 1.6 of 2.1 ms).
 template <bool WIDE, class P, class TM, class DG = FilterNoDiag>
 ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const P &fp, TM tm, int n, uint32_t rec[4],
-                                  int s = 0, bool have_last = true, DG dg = DG()) {
+                                  int s = 0, bool have_last = true, DG dg = DG(), int pa_dlo = 0, int pa_dhi = -1) {
     const int mf = fp.rows, T = u.m - mf;                                // T > 0: NARROW mode
     rec[0] = 0xFFFF0000u; rec[1] = 0; rec[2] = 0; rec[3] = 0;             // refstop = -1: None
     if (F.zfirst != 0 && u.m >= u.min_overlap) {
@@ -641,9 +678,14 @@ ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const 
     // indels), so every traceback lies on the diagonals j_lo .. j_last - m + k -- provided j_lo
     // was not clamped at 0 (no traceback then touches column 0).  The window end of a band
     // read is stored as (last diagonal) + m - k: j_last, or j'_last + T in NARROW mode.
-    const bool band = rowm && !lastcol && (F.j_first - mf - u.k >= s) &&
-                      (F.j_last - F.j_first + 2 * u.k <= BAND_W - 1);
-    if (band && !u.sr && u.indel == 1 && fp.cert_sub != 0ull && ((F.j_first + F.j_last) & 1) == 0 &&
+    bool band = rowm && !lastcol && (F.j_first - mf - u.k >= s) &&
+                (F.j_last - F.j_first + 2 * u.k <= BAND_W - 1);
+    int band_hi = F.j_last + T;
+    if (!band && rowm && !lastcol && !u.sr && pa_dhi >= pa_dlo && pa_dlo > s && pa_dhi - pa_dlo <= BAND_W - 1) {
+        band = true;                                                     // the pieces' diagonals (see above)
+        j_lo = pa_dlo;
+        band_hi = pa_dhi + u.m - u.k;
+    } else if (band && !u.sr && u.indel == 1 && fp.cert_sub != 0ull && ((F.j_first + F.j_last) & 1) == 0 &&
         F.j_last - F.j_first <= 2 * u.k) {
         // ONE SUBSTITUTION (filter_substitution_certificate).  The hits of the swept rows lie within k of their middle
         // column xc, so every row-m candidate ends within 2k of j = xc + T and starts within 3k before d = xc - mf:
@@ -660,7 +702,7 @@ ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const 
             }
         }
     }
-    const int j_hi = lastcol ? n : band ? F.j_last + T : atr_min(n, F.j_last + (T ? T + u.k : 0));
+    const int j_hi = lastcol ? n : band ? band_hi : atr_min(n, F.j_last + (T ? T + u.k : 0));
     // rows: with a row-m candidate all m rows; otherwise nothing above the largest acceptable
     // last-column row can matter (a row only depends on the rows before it)
     return window_word(j_lo, j_hi, lastcol, rowm ? u.m : row_l, band);

@@ -94,6 +94,7 @@ struct LaneFilterParams {
     const int32_t *thr_row;
     const uint32_t *cert;                           // FilterParams::cert of the lane's adapter
     uint64_t cert_sub = 0ull;                       // (the substitution certificate wants a diagonal view of the read: not here)
+    uint32_t tailx[3] = {0u, 0u, 0u};               // (extended NARROW mode: not in the linked pipeline)
 };
 
 // ---- Adapter.match_to's acceptance test (adapters/__init__.py:386-398) ---------------------

@@ -43,6 +43,19 @@ inline const FilterParams &aligner_filter_params(const atr_aligner *a) {
     s.uid = a->uid;
     return s.fp;
 }
+// ... and the parameters the two-pass pre-pass works with (filter_params(.., planes_path): extended NARROW mode for adapters
+// of 41 .. 64 bases), cached the same way
+inline const FilterParams &aligner_piece_filter_params(const atr_aligner *a) {
+    struct Slot { unsigned long long uid = 0; FilterParams fp; };
+    static thread_local Slot slots[4];
+    static thread_local unsigned turn = 0;
+    if (a->uid != 0)
+        for (Slot &s : slots) if (s.uid == a->uid) return s.fp;
+    Slot &s = slots[turn++ & 3u];
+    s.fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
+    s.uid = a->uid;
+    return s.fp;
+}
 }  // namespace atr
 
 namespace atr {

@@ -45,12 +45,16 @@
 
 namespace atr {
 
-constexpr int PIECE_NB = 5;                 // body pieces at most: max(4, k + 1), k <= 4 (a piece too many only weakens the filter)
-constexpr int PIECE_NT = 5;                 // read-end pieces at most (error classes t = 1 .. 4)
-constexpr int PIECE_STEPS = 8;              // longest read-end piece / body pieces 0 .. 2
-constexpr int PIECE_LAST_STEPS = 16;        // the last body piece takes the rows that are left: up to 16
+constexpr int PIECE_NB = 8;                 // body pieces at most: max(4, k + 1), k <= 6 (a piece too many only weakens the filter);
+                                            // 41 .. 64-base adapters take more when their last piece would get too long
+constexpr int PIECE_KMAX = 6;               // int(e m) at most (the 64-mer of the reference's README at e = 0.1)
+constexpr int PIECE_NT = 5;                 // read-end pieces at most (error classes t = 1 .. 4; classes beyond are served by body pieces)
+constexpr int PIECE_TBIT = 2 * PIECE_NB;    // scode: body piece p at bits 2 p, read-end piece u at bits PIECE_TBIT + 2 u
+constexpr int PIECE_STEPS = 8;              // longest read-end piece / regular body piece
+constexpr int PIECE_LAST_STEPS = 24;        // the last body piece takes the rows that are left: up to 24
 constexpr int PIECE_TAIL_WORDS = 3;         // plane words the read-end pieces are evaluated on: the read's last three
-constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (two words per plane)
+constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (two words per plane) ...
+constexpr int PIECE_WINDOW_MAX = 96;        // ... three for adapters whose rows + 2 k exceed that (PieceParams::window)
 constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps when k <= 3 (PieceParams::narrow): one hit diagonal needs
                                             // rows + T + 2 k columns, a read-end condition rows + T + k (94 % of C2's flagged
                                             // reads); longer windows take the full sweep
@@ -69,11 +73,12 @@ struct PieceParams {
     int and_mode;                           // wildcard comparison (code & code): a base matches code c iff its plane c is set
     int nb;                                 // body pieces: max(4, k + 1)
     int narrow;                             // columns a pass-B task sweeps at most: 8 ceil((rows + T + 2 k) / 8)  (40 for k <= 3)
+    int window;                             // columns a pass-B task carries: PIECE_WINDOW, or PIECE_WINDOW_MAX when narrow exceeds it
     int plen[PIECE_NB];                     // rows of body piece p (0: not there)
     int pshift[PIECE_NB];                   // its last row minus piece 0's last row: hits of piece p, moved down by this, sit in piece 0's place
     uint32_t scode[PIECE_LAST_STEPS];       // per shift step s, two bits per piece: the plane index (0 .. 3) of the row it
                                             // compares in that step (its last row minus s); body piece p at bits 2p,
-                                            // read-end piece u at bits 10 + 2u (one scalar load per step, s_bitcmp1 per term)
+                                            // read-end piece u at bits PIECE_TBIT + 2u (one scalar load per step, s_bitcmp1 per term)
     uint32_t tmask[PIECE_NT][PIECE_TAIL_WORDS];   // END positions a read-end piece may have (words tw0 ..), 0: piece unused
     uint32_t xmask[32][4];                  // [i][c]: the rows r < i that hold the code of plane c, at bit 32 - i + r (the place of
                                             // row r in the read's last 32 positions when the overlap has i bases)
@@ -90,20 +95,42 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     memset(&pp, 0, sizeof(pp));
     const int need = ATR_START_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ2;
     if ((flags & need) != need || (flags & ATR_START_WITHIN_SEQ1) || custom_table) return false;
-    if (rows > 32 || rows < 1 || k < 0 || k > PIECE_NB - 1 || k >= m) return false;
+    if (rows > 32 || rows < 1 || k < 0 || k > PIECE_KMAX || k >= m || m > FILTER_MAX_M) return false;
     if (n < 1 || n > 32 * PIECE_MAX_WORDS) return false;
-    const int nb = k + 1 > 4 ? k + 1 : 4;
-    const int blen = std::min(PIECE_STEPS, rows / nb);
-    if (blen < 5 || k > blen - 1) return false;                      // (k <= blen - 1: the diagonal mask keeps every hit)
     // The pieces cover ALL m rows (an alignment of the whole adapter with <= k errors leaves one of any k + 1 disjoint
-    // pieces intact): the last one takes what (nb - 1) blen rows leave.  All pieces on one diagonal are then the
-    // adapter verbatim -- the reference's early exit (_align.pyx:456-458) -- which pass A resolves itself.
-    const int llen = m - (nb - 1) * blen;
-    if (llen < blen || llen > PIECE_LAST_STEPS) return false;
+    // pieces intact): nb - 1 regular ones of blen rows, the last one takes what they leave.  All pieces on one diagonal are
+    // then the adapter verbatim -- the reference's early exit (_align.pyx:456-458) -- which pass A resolves itself.
+    // More pieces than k + 1 when the last one would get too long, or (below) when an error class of the read-end
+    // overlaps has no read-end pieces of its own and must find t + 1 regular pieces inside its shortest overlap.
+    int nb = k + 1 > 4 ? k + 1 : 4, blen = 0, llen = 0;
+    const auto cut = [&]() {
+        blen = std::min(PIECE_STEPS, m / nb);
+        llen = m - (nb - 1) * blen;
+        return blen >= 5 && k <= blen - 1 && llen >= blen;          // (k <= blen - 1: the diagonal mask keeps every hit)
+    };
+    if (!cut()) return false;
+    while (llen > PIECE_LAST_STEPS && nb < PIECE_NB) { ++nb; if (!cut()) return false; }
+    {   // classes t >= PIECE_NT of the last-column rows (adapters of 50 bases and more): t + 1 regular body pieces inside
+        // the class's shortest overlap serve them -- the body pieces are looked for everywhere, the read end included
+        for (;;) {
+            bool need_more = false;
+            for (int i = 1; i <= m - 1; ++i) {
+                const int t = thr_row[i];
+                if (t >= PIECE_NT && std::min(nb - 1, i / blen) < t + 1) need_more = true;
+            }
+            if (!need_more) break;
+            if (nb >= PIECE_NB) return false;
+            ++nb;
+            if (!cut()) return false;
+        }
+    }
+    if (llen > PIECE_LAST_STEPS) return false;
     const int body_rows = m;
     for (int i = 0; i < m; ++i) if (piece_plane_of(codes[i]) < 0) return false;
     pp.blen = blen; pp.llen = llen; pp.m = m; pp.and_mode = and_mode ? 1 : 0; pp.nb = nb;
-    pp.narrow = std::min(PIECE_WINDOW, std::max(PIECE_NARROW, (rows + (m - rows) + 2 * k + 7) & ~7));
+    pp.narrow = std::max(PIECE_NARROW, (rows + (m - rows) + 2 * k + 7) & ~7);
+    if (pp.narrow > PIECE_WINDOW_MAX) return false;
+    pp.window = pp.narrow > PIECE_WINDOW ? PIECE_WINDOW_MAX : PIECE_WINDOW;
     for (int p = 0; p < nb; ++p) {
         const int len = p == nb - 1 ? llen : blen;
         pp.plen[p] = len;
@@ -121,8 +148,8 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     for (int i = 1; i <= top; ++i) {
         const int t = thr_row[i];
         if (t < 0) continue;
-        if (t >= PIECE_NT) return false;
         if (i > 1 && thr_row[i - 1] > t) return false;               // (monotone thresholds: floor(i e))
+        if (t >= PIECE_NT) continue;                                 // (served by the body pieces: checked above)
         if (ihi[t] < 0) ilo[t] = i;
         ihi[t] = i;
     }
@@ -143,7 +170,7 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
         for (int u = 0; u < PIECE_NT; ++u) {
             if (u > tmax) continue;
             if ((u + 1) * tlen > body_rows) return false;
-            for (int s = 0; s < tlen; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (10 + 2 * u);
+            for (int s = 0; s < tlen; ++s) pp.scode[s] |= (uint32_t)piece_plane_of(codes[u * tlen + tlen - 1 - s]) << (PIECE_TBIT + 2 * u);
             // ... and piece u serves the classes t >= max(1, u) whose first t + 1 pieces fit their shortest overlap.
             for (int t = std::max(1, u); t <= tmax; ++t) {
                 if (ihi[t] < 0) continue;
@@ -412,9 +439,12 @@ struct PieceScan {
 // Pass A for one lane: the planes of a read of n bases (NW = ceil(n / 32) words) -> PieceScan.  twp[p]: plane p
 // of the read's last 32 positions (bit 31 = the last base; zeros before the read).  mf = rows swept by pass B
 // (FilterParams::rows), T = m - mf, k as Uniform::k.  n is wave-uniform (equal-length batch).
-template <int NW>
+// NBMAX: the body pieces this instantiation holds accumulators for (pp.nb <= NBMAX): the generic kernels of the 64-column
+// window keep five (eight of them spilled 37 registers at NW = 5)
+template <int NW, int NBMAX = PIECE_NB>
 ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4], const uint32_t (&twp)[4], int n, int mf,
                              int T, int k) {
+    static_assert(NBMAX >= 4 && NBMAX <= PIECE_NB, "body pieces");
     constexpr int TWN = NW < PIECE_TAIL_WORDS ? NW : PIECE_TAIL_WORDS, TW0 = NW - TWN;
     PieceMasks<NW> Y;
     const bool and_mode = piece_uniform(pp.and_mode) != 0;
@@ -439,33 +469,38 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     }
 
     // (2) the pieces: body pieces on every word, read-end pieces on the read's last TWN words only
-    uint32_t occ[PIECE_NB][NW], tocc[PIECE_NT][TWN];
+    uint32_t occ[NBMAX][NW], tocc[PIECE_NT][TWN];
 #pragma unroll
-    for (int p = 0; p < PIECE_NB; ++p)
+    for (int p = 0; p < NBMAX; ++p)
 #pragma unroll
         for (int w = 0; w < NW; ++w) occ[p][w] = ~0u;
 #pragma unroll
     for (int u = 0; u < PIECE_NT; ++u)
 #pragma unroll
         for (int w = 0; w < TWN; ++w) tocc[u][w] = pp.tmask[u][w];
-    // (wave-uniform parameters: said so, for callers whose PieceParams sit behind a pointer -- linked_kernels.hip)
-    const int plen3 = piece_uniform(pp.plen[3]), plen4 = piece_uniform(pp.plen[4]);
-    const int steps = piece_uniform(pp.steps), blen = piece_uniform(pp.blen), tlen = piece_uniform(pp.tlen);
+    // (wave-uniform parameters: said so, for callers whose PieceParams sit behind a pointer)
+    int plen[PIECE_NB];
+#pragma unroll
+    for (int p = 0; p < PIECE_NB; ++p) plen[p] = p < NBMAX ? piece_uniform(pp.plen[p]) : 0;
+    const int steps = piece_uniform(pp.steps), tlen = piece_uniform(pp.tlen);
     for (int s = 0; s < steps; ++s) {                                // wave-uniform
         const uint32_t cw = (uint32_t)piece_uniform((int)pp.scode[s]);
-        if (s < blen) {
-            piece_and_term<NW, NW, 0, 0>(occ[0], Y, cw);
-            piece_and_term<NW, NW, 0, 2>(occ[1], Y, cw);
-            piece_and_term<NW, NW, 0, 4>(occ[2], Y, cw);
+        if (s < plen[0]) piece_and_term<NW, NW, 0, 0>(occ[0], Y, cw);
+        if (s < plen[1]) piece_and_term<NW, NW, 0, 2>(occ[1], Y, cw);
+        if (s < plen[2]) piece_and_term<NW, NW, 0, 4>(occ[2], Y, cw);
+        if (s < plen[3]) piece_and_term<NW, NW, 0, 6>(occ[3], Y, cw);
+        if constexpr (NBMAX > 4) { if (s < plen[4]) piece_and_term<NW, NW, 0, 8>(occ[4 < NBMAX ? 4 : 0], Y, cw); }
+        if constexpr (NBMAX > 5) {
+            if (s < plen[5]) piece_and_term<NW, NW, 0, 10>(occ[5 < NBMAX ? 5 : 0], Y, cw);
+            if (s < plen[6]) piece_and_term<NW, NW, 0, 12>(occ[6 < NBMAX ? 6 : 0], Y, cw);
+            if (s < plen[7]) piece_and_term<NW, NW, 0, 14>(occ[7 < NBMAX ? 7 : 0], Y, cw);
         }
-        if (s < plen3) piece_and_term<NW, NW, 0, 6>(occ[3], Y, cw);
-        if (s < plen4) piece_and_term<NW, NW, 0, 8>(occ[4], Y, cw);
         if (s < tlen) {
-            piece_and_term<NW, TWN, TW0, 10>(tocc[0], Y, cw);
-            piece_and_term<NW, TWN, TW0, 12>(tocc[1], Y, cw);
-            piece_and_term<NW, TWN, TW0, 14>(tocc[2], Y, cw);
-            piece_and_term<NW, TWN, TW0, 16>(tocc[3], Y, cw);
-            piece_and_term<NW, TWN, TW0, 18>(tocc[4], Y, cw);
+            piece_and_term<NW, TWN, TW0, PIECE_TBIT + 0>(tocc[0], Y, cw);
+            piece_and_term<NW, TWN, TW0, PIECE_TBIT + 2>(tocc[1], Y, cw);
+            piece_and_term<NW, TWN, TW0, PIECE_TBIT + 4>(tocc[2], Y, cw);
+            piece_and_term<NW, TWN, TW0, PIECE_TBIT + 6>(tocc[3], Y, cw);
+            piece_and_term<NW, TWN, TW0, PIECE_TBIT + 8>(tocc[4], Y, cw);
         }
         if (s + 1 < steps) piece_shift_masks<NW>(Y);
     }
@@ -487,7 +522,7 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
 #pragma unroll
     for (int w = 0; w < NW; ++w) dm[w] = pf[w] = occ[0][w];
 #pragma unroll
-    for (int p = 1; p < PIECE_NB; ++p) {
+    for (int p = 1; p < NBMAX; ++p) {
         if (p >= piece_uniform(pp.nb)) continue;                     // (wave-uniform: four pieces unless k = 4)
         const int sh = piece_uniform(pp.pshift[p]);                  // 0 .. 32 (wave-uniform)
 #pragma unroll
@@ -591,28 +626,26 @@ ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&
     piece_static_for<0, spec::PP.steps>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr uint32_t cw = spec::PP.scode[s];
-        if constexpr (s < spec::PP.blen) {
+        // (the regular pieces word by word, then the last piece: the order rounds 5's kernel was tuned in)
 #pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                term(occ[0][w], Y.y[(cw >> 0) & 3u][w], s == 0);
-                term(occ[1][w], Y.y[(cw >> 2) & 3u][w], s == 0);
-                term(occ[2][w], Y.y[(cw >> 4) & 3u][w], s == 0);
+        for (int w = 0; w < NW; ++w)
+            piece_static_for<0, PIECE_NB>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                if constexpr (p < spec::PP.nb - 1 && s < spec::PP.plen[p]) term(occ[p][w], Y.y[(cw >> (2 * p)) & 3u][w], s == 0);
+            });
+        {
+            constexpr int p = spec::PP.nb - 1;
+            if constexpr (s < spec::PP.plen[p]) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) term(occ[p][w], Y.y[(cw >> (2 * p)) & 3u][w], s == 0);
             }
-        }
-        if constexpr (s < spec::PP.plen[3]) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) term(occ[3][w], Y.y[(cw >> 6) & 3u][w], s == 0);
-        }
-        if constexpr (s < spec::PP.plen[4]) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) term(occ[4][w], Y.y[(cw >> 8) & 3u][w], s == 0);
         }
         if constexpr (s < spec::PP.tlen) {
             piece_static_for<0, PIECE_NT>([&](auto uc) {
                 constexpr int u = decltype(uc)::value;
                 if constexpr ((spec::PP.tmask[u][0] | spec::PP.tmask[u][1] | spec::PP.tmask[u][2]) != 0u) {
 #pragma unroll
-                    for (int w = 0; w < TWN; ++w) term(tocc[u][w], Y.y[(cw >> (10 + 2 * u)) & 3u][TW0 + w], false);
+                    for (int w = 0; w < TWN; ++w) term(tocc[u][w], Y.y[(cw >> (PIECE_TBIT + 2 * u)) & 3u][TW0 + w], false);
                 }
             });
         }

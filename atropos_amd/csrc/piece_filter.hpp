@@ -42,8 +42,10 @@ __device__ __forceinline__ int lane_rank(uint64_t mask) {
 // The record of a resolved read / the list entry of an unresolved one.  `active`: this lane holds a decided read.
 // nibs: the lane's eight window dwords in LDS ([dword][lane]; the window's first position is column j0 + 1), from
 // which the 64 codes that follow the entry's first diagonal go into tdata -- what band_stage would gather.
+// nd: the dwords of a lane's window in nibs (8, or 12 with the 96-column window).
 __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww, const uint32_t (&rec)[4], int m, uint4 *out,
-                                           uint2 *list, uint4 *ldata, const uint32_t *nibs, int j0, uint32_t *s_lcur, uint32_t *s_hist) {
+                                           uint2 *list, uint4 *ldata, const uint32_t *nibs, int j0, uint32_t *s_lcur, uint32_t *s_hist,
+                                           int nd = 8) {
     const bool open = active && window_valid(ww);
     if (active && !open) out[r] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
     const uint64_t om = __ballot(open);
@@ -53,7 +55,8 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
         base = __builtin_amdgcn_readfirstlane(base);
         const int lane = threadIdx.x & 63;
         const int off = window_lo(ww) - j0;                      // codes between the window's start and the first diagonal
-        const bool dense = nibs != nullptr && off >= 0 && off < 64;
+        // (the band kernels read 3 + m / 8 dwords from the record: eight hold them for adapters of up to 47 bases)
+        const bool dense = nibs != nullptr && off >= 0 && off < 64 && band_stream_dwords(m) <= 8;
         if (open) {
             const uint32_t slot = base + (uint32_t)lane_rank(om);
             list[slot] = make_uint2((uint32_t)r, dense ? ww : (ww | PIECE_NODENSE));
@@ -63,7 +66,7 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
                 const uint32_t sh = 4u * (uint32_t)(off & 7);
                 uint32_t raw[9], d[8];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) raw[k] = z + k < 8 ? nibs[(z + k) * 64 + lane] : 0u;
+                for (int k = 0; k < 9; ++k) raw[k] = z + k < nd ? nibs[(z + k) * 64 + lane] : 0u;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) d[k] = sh ? ((raw[k] >> sh) | (raw[k + 1] << (32u - sh))) : raw[k];
                 ldata[2 * (size_t)slot] = make_uint4(d[0], d[1], d[2], d[3]);
@@ -77,7 +80,8 @@ __device__ __forceinline__ void piece_emit(bool active, long long r, uint32_t ww
 // NW words (a per-lane shift of the planes by 32 NW - n positions, zeros coming in below): every read ends at
 // position 32 NW like a read of an equal-length batch, the read-end conditions keep their wave-uniform masks, and the
 // columns it reports are shifted back by the lane's own amount.  Positions before the read hold code 0 either way.
-template <int NW, bool RAGGED>
+// WW: plane words a pass-B task carries (2: PIECE_WINDOW columns; 3: PIECE_WINDOW_MAX, adapters whose rows + 2 k exceed 64)
+template <int NW, bool RAGGED, int WW = 2>
 __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const FilterParams &fp_arg, const PieceParams &pp_arg,
                                                   const uint4 *__restrict__ planes, const int32_t *__restrict__ lens,
                                                   long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk,
@@ -107,7 +111,9 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     __shared__ uint32_t s_spread[4][256];
     __shared__ uint32_t s_hist[FILTER_BINS];
     __shared__ uint32_t s_lcur, s_wcnt;
-    __shared__ uint32_t s_nibs[4][8][64];                         // pass B: the task's eight nibble dwords, [dword][lane] (NARROW tail check)
+    constexpr int PW = 32 * WW, ND = 4 * WW;                      // columns / nibble dwords of a pass-B window
+    static_assert(WW == 2 || WW == 3, "windows of 64 or 96 columns");
+    __shared__ uint32_t s_nibs[4][ND][64];                        // pass B: the task's nibble dwords, [dword][lane] (NARROW tail check)
     __shared__ uint32_t s_queue[4][PIECE_QF][64];
     constexpr bool STASH = ATR_PIECE_STASH != 0 && NW <= 8;
     __shared__ uint4 s_stash[STASH ? 4 : 1][STASH ? NW : 1][64];
@@ -160,38 +166,41 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         const uint32_t meta = queue[1][lane];
         const int j_e = act ? (int)(meta & 1023u) : 0, need = act ? (int)((meta >> 10) & 127u) : 0;
         const int nr = RAGGED ? (act ? (int)(meta >> 17) : 0) : max_len;       // the read's own length
-        uint32_t wp[4][2];
+        uint32_t wp[4][WW];
         {
             // (the stash holds what pass A saw: a ragged read moved to the end of its NW words, 32 NW - nr positions up)
-            const int b0 = j_e - PIECE_WINDOW + (STASH && RAGGED ? 32 * NW - nr : 0), w0 = b0 >> 5;     // floor: -2 .. NW - 2
-            uint4 g0 = make_uint4(0u, 0u, 0u, 0u), g1 = g0, g2 = g0;
+            const int b0 = j_e - PW + (STASH && RAGGED ? 32 * NW - nr : 0), w0 = b0 >> 5;     // floor: -WW .. NW - 2
+            uint4 g[WW + 1];
+#pragma unroll
+            for (int i = 0; i <= WW; ++i) g[i] = make_uint4(0u, 0u, 0u, 0u);
             if constexpr (STASH) {
                 if (act) {
-                    if (w0 >= 0) g0 = stash[w0][lane];
-                    if (w0 + 1 >= 0) g1 = stash[w0 + 1][lane];
-                    if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = stash[w0 + 2][lane];
+#pragma unroll
+                    for (int i = 0; i <= WW; ++i) if (w0 + i >= 0 && w0 + i < NW) g[i] = stash[w0 + i][lane];
                 }
             } else {
 #ifndef ATR_X_NOGATHER                                                     // (traffic calibration only: pass A's stream alone, records wrong)
                 const uint4 *tcur = planes + ((size_t)(r >> 6) * NW) * 64 + (r & 63);
                 if (act) {
-                    if (w0 >= 0) g0 = tcur[(size_t)w0 * 64];
-                    if (w0 + 1 >= 0) g1 = tcur[(size_t)(w0 + 1) * 64];
-                    if (w0 + 2 >= 0 && w0 + 2 < NW) g2 = tcur[(size_t)(w0 + 2) * 64];
+#pragma unroll
+                    for (int i = 0; i <= WW; ++i) if (w0 + i >= 0 && w0 + i < NW) g[i] = tcur[(size_t)(w0 + i) * 64];
                 }
 #endif
             }
             const uint32_t sh = (uint32_t)(b0 & 31);
-            wp[0][0] = __builtin_amdgcn_alignbit(g1.x, g0.x, sh); wp[0][1] = __builtin_amdgcn_alignbit(g2.x, g1.x, sh);
-            wp[1][0] = __builtin_amdgcn_alignbit(g1.y, g0.y, sh); wp[1][1] = __builtin_amdgcn_alignbit(g2.y, g1.y, sh);
-            wp[2][0] = __builtin_amdgcn_alignbit(g1.z, g0.z, sh); wp[2][1] = __builtin_amdgcn_alignbit(g2.z, g1.z, sh);
-            wp[3][0] = __builtin_amdgcn_alignbit(g1.w, g0.w, sh); wp[3][1] = __builtin_amdgcn_alignbit(g2.w, g1.w, sh);
-        }
-        const int W = min(PIECE_WINDOW, (wave_max_i32(need) + 7) & ~7);          // columns swept, a multiple of eight (<= PIECE_NARROW)
-        const int dw0 = 8 - (W >> 3);                                          // first of the eight window dwords swept
-        uint32_t nb[8];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
+            for (int i = 0; i < WW; ++i) {
+                wp[0][i] = __builtin_amdgcn_alignbit(g[i + 1].x, g[i].x, sh);
+                wp[1][i] = __builtin_amdgcn_alignbit(g[i + 1].y, g[i].y, sh);
+                wp[2][i] = __builtin_amdgcn_alignbit(g[i + 1].z, g[i].z, sh);
+                wp[3][i] = __builtin_amdgcn_alignbit(g[i + 1].w, g[i].w, sh);
+            }
+        }
+        const int W = min(PW, (wave_max_i32(need) + 7) & ~7);                     // columns swept, a multiple of eight (<= pp.narrow)
+        const int dw0 = ND - (W >> 3);                                         // first of the window's dwords swept
+        uint32_t nb[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
             nb[d] = 0u;
             // (wave-uniform; one dword before the sweep: the DP's first diagonal may lie k columns before the window)
             if (d >= dw0 - 1) nb[d] = piece_nibbles(s_spread, wp[0][d >> 2], wp[1][d >> 2], wp[2][d >> 2], wp[3][d >> 2], d & 3);
@@ -201,33 +210,28 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         filter_init(F, u, mf);
         uint2 ea[8], eb[8];
 #pragma unroll
-        for (int d = 0; d < 8; ++d) {
+        for (int d = 0; d < ND; ++d) {
             if (d < dw0) continue;                                             // wave-uniform
             uint2 (&e)[8] = (d & 1) ? eb : ea;
             if (d == dw0) fetch_peq8(s_peq, nb[d], e);
-            if (d + 1 < 8) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);     // one dword ahead of the columns that use it
+            if (d + 1 < ND) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);    // one dword ahead of the columns that use it
 #pragma unroll
             for (int b = 0; b < 8; ++b) filter_step<false>(F, e[b].x, e[b].y, kreg);
-            if (d == 3 && dw0 <= 3) filter_fold(F, j_e - 32, mf, kreg);               // 32 columns at most between two folds
+            if ((d & 3) == 3 && d + 1 < ND) filter_fold(F, j_e - PW + 8 * (d + 1), mf, kreg);   // 32 columns at most between two folds
         }
         filter_fold(F, j_e, mf, kreg);
         uint32_t rec[4];
-        // the T bases after column jp: window position jp - (j_e - 64), eight bases per dword
+        // the T bases after column jp: window position jp - (j_e - PW), eight bases per dword (T <= 32: up to five dwords)
         const auto tm = [&](int jp) {
-            const int rp = max(0, jp - (j_e - PIECE_WINDOW));
-            const uint32_t lo = nibs[min(rp >> 3, 7) * 64 + lane], hi = (rp >> 3) + 1 < 8 ? nibs[((rp >> 3) + 1) * 64 + lane] : 0u;
-            const uint32_t sh = 4u * (uint32_t)(rp & 7);
-            const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-            const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
-            const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
-            const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
-            return fp.and_mode ? nz == ones : nz == 0u;
+            const int rp = max(0, jp - (j_e - PW));
+            return filter_tail_cmp(fp, T, rp, [&](int z) { return z < ND ? nibs[z * 64 + lane] : 0u; });
         };
         // the adapter's rows against the read on diagonal d (filter_decide_tm's substitution certificate): the window's
         // planes moved down to base d, one "base == code" mask per plane against the rows that hold that code
         const auto dg = [&](int d) -> uint64_t {
-            const int o = d - (j_e - PIECE_WINDOW);                            // window bit of the diagonal's first base
-            if (o < 0 || o + u.m > PIECE_WINDOW) return ~0ull;
+            if constexpr (WW != 2) return ~0ull;                               // (the 96-column window: no diagonal view, the DP decides)
+            const int o = d - (j_e - PW);                                      // window bit of the diagonal's first base
+            if (o < 0 || o + u.m > PW) return ~0ull;
             uint64_t eq = 0ull;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -238,8 +242,10 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             }
             return ~eq & (u.m >= 64 ? ~0ull : (1ull << u.m) - 1ull);
         };
-        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr, dg);
-        piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PIECE_WINDOW, &s_lcur, s_hist);
+        // (j_e < nr: no read-end condition and the window not cut at the read end -- then j_e - need = d_min - k, or 0, and
+        //  j_e - m = d_max + k: the pieces' diagonals, filter_decide_tm)
+        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr, dg, j_e - need, j_e < nr ? j_e - u.m : -0x10000);
+        piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PW, &s_lcur, s_hist, ND);
     };
 
     int qn = 0;                                                   // tasks queued (wave-uniform)
@@ -366,7 +372,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
 #ifdef ATR_SPEC
         const PieceScan S = piece_scan_spec<NW>(pl, twp, mf, T, u.k);
 #else
-        const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
+        const PieceScan S = piece_scan<NW, (WW == 3 ? PIECE_NB : 5)>(pp, pl, twp, n, mf, T, u.k);
 #endif
         // the adapter verbatim: resolved here (_align.pyx:456-458), no pass B (22 % of C2's reads)
         const bool exact = live && S.j_exact != 0 && u.m >= u.min_overlap;
@@ -463,14 +469,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             }
             uint32_t rec[4];
             const auto tm = [&](int jp) {
-                const uint32_t lo = read_dword_planes((const uint32_t *)bp, NW, jp >> 3, s_spread);
-                const uint32_t hi = read_dword_planes((const uint32_t *)bp, NW, (jp >> 3) + 1, s_spread);
-                const uint32_t sh = 4u * (uint32_t)(jp & 7);
-                const uint32_t w = sh ? ((lo >> sh) | (hi << (32u - sh))) : lo;
-                const uint32_t x = fp.and_mode ? (w & fp.tail) : (w ^ fp.tail);
-                const uint32_t ones = T >= 8 ? 0x11111111u : (0x11111111u & ((1u << (4 * T)) - 1u));
-                const uint32_t nz = (x | (x >> 1) | (x >> 2) | (x >> 3)) & ones;
-                return fp.and_mode ? nz == ones : nz == 0u;
+                return filter_tail_cmp(fp, T, jp, [&](int z) { return read_dword_planes((const uint32_t *)bp, NW, z, s_spread); });
             };
             const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nl, rec, 0, true);
             piece_emit(act, r, ww, rec, u.m, out, list, ldata, nullptr, 0, &s_lcur, s_hist);

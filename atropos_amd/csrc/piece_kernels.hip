@@ -21,11 +21,11 @@ void launch_fast_scan(FastWork wk, hipStream_t st);                             
 int launch_fast_dp(const atr_aligner *a, const uint4 *packed, const int32_t *lens, long long nreads, int nchunks,
                    int max_len, uint4 *out, FastWork wk, const LinkedArgs *la, int idx, int count, hipStream_t st, bool planes, bool one_stream);
 
-template <int NW, bool RAGGED>
+template <int NW, bool RAGGED, int WW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ATR_PIECE_WAVES(NW), 8))) void piece_filter_kernel(
     const LocateParams p, const FilterParams fp, const PieceParams pp, const uint4 *__restrict__ planes,
     const int32_t *__restrict__ lens, long long nreads, int max_len, uint4 *__restrict__ out, FastWork wk) {
-    piece_filter_body<NW, RAGGED>(p, fp, pp, planes, lens, nreads, max_len, out, wk);
+    piece_filter_body<NW, RAGGED, WW>(p, fp, pp, planes, lens, nreads, max_len, out, wk);
 }
 
 // P3: a block's list of (read, window word) -> the bins of `order` (offsets from K2's scan, an LDS cursor per bin)
@@ -56,14 +56,14 @@ __global__ __launch_bounds__(256) void piece_scatter_kernel(long long nreads, in
 // Blocks of P1 the device holds at once: P1 is a persistent grid -- a wave's task queue wants many tiles, and a grid
 // of exactly the resident blocks has no partial last round (2048 blocks on 768 slots cost a third round: 0.72 ms
 // instead of 0.5).  Per thread and device: the occupancy query is not free.
-template <int NW, bool RAGGED>
+template <int NW, bool RAGGED, int WW>
 static int piece_resident_blocks() {
     static thread_local int cached_dev = -1, cached = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1024;
     if (dev != cached_dev) {
         int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, piece_filter_kernel<NW, RAGGED>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, piece_filter_kernel<NW, RAGGED, WW>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
         cached = std::min(FAST_BLOCKS, per_cu * cus);
         cached_dev = dev;
@@ -71,17 +71,24 @@ static int piece_resident_blocks() {
     return cached;
 }
 
+template <int NW, int WW>
+static void launch_piece_filter_w(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
+                                  const int32_t *lens, long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
+    const long long want = ((nreads + 63) / 64 + 3) / 4;
+    if (lens) {
+        wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW, true, WW>(), want));
+        hipLaunchKernelGGL((piece_filter_kernel<NW, true, WW>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, lens, nreads, max_len, out, wk);
+    } else {
+        wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW, false, WW>(), want));
+        hipLaunchKernelGGL((piece_filter_kernel<NW, false, WW>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, lens, nreads, max_len, out, wk);
+    }
+}
 template <int NW>
 static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
                                 const int32_t *lens, long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
-    const long long want = ((nreads + 63) / 64 + 3) / 4;
-    if (lens) {
-        wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW, true>(), want));
-        hipLaunchKernelGGL((piece_filter_kernel<NW, true>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, lens, nreads, max_len, out, wk);
-    } else {
-        wk.nused = (int)std::max<long long>(1, std::min<long long>(piece_resident_blocks<NW, false>(), want));
-        hipLaunchKernelGGL((piece_filter_kernel<NW, false>), dim3(wk.nused), dim3(256), 0, st, a->p, fp, pp, planes, lens, nreads, max_len, out, wk);
-    }
+    // (the 96-column instantiation is also the one with accumulators for more than five body pieces)
+    if (pp.window > PIECE_WINDOW || pp.nb > 5) launch_piece_filter_w<NW, 3>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st);
+    else launch_piece_filter_w<NW, 2>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st);
 }
 
 // Does the two-pass pre-pass take this aligner on equal-length reads of max_len bases?  (+ its parameters)
@@ -90,7 +97,7 @@ static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, co
 int piece_ragged_len(int max_len) { return 32 * ((max_len + 31) / 32); }
 bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, PieceParams *pp_out) {
     if (!a->filterable || max_len < 1) return false;
-    const FilterParams &fp = aligner_filter_params(a);
+    const FilterParams &fp = aligner_piece_filter_params(a);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                       a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return false;

@@ -193,16 +193,17 @@ def piece_reads(rng, ref, n, count, e):
 
 
 def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=200,
-                         lengths=(70, 100, 128, 150, 160, 180, 200, 224, 250, 260, 288, 300)):     # (3 .. 10 plane words)
+                         lengths=(70, 100, 128, 150, 160, 180, 200, 224, 250, 260, 288, 300),      # (3 .. 10 plane words)
+                         mrange=(20, 40), flag_choices=(14, 14, 14, 10)):
     """The two-pass pre-pass on plane64 batches (atr_locate_planes_batch) against the other kernel families and the
     oracle, on aligners inside its envelope (and a few outside: pack(layout="plane64") must refuse those)."""
     import numpy as np
     rng = random.Random(seed)
     total = refused = 0
     for _ in range(rounds):
-        m = rng.randint(20, 40)
+        m = rng.randint(*mrange)
         ref = rseq(rng, m, "ACGT" if rng.random() < 0.9 else "ACGTN")
-        flags = rng.choice([14, 14, 14, 10])
+        flags = rng.choice(list(flag_choices))
         e = rng.choice([0, 0.03, 0.05, 0.08, 0.1, 0.1, 0.1, 0.12])
         ic = rng.choice([1, 1, 1, 2, 100000])
         mo = rng.choice([1, 3, 3, 5, 12, 25])

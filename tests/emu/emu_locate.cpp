@@ -331,15 +331,18 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     FilterState F;
     filter_init(F, u, mf);
     if (need <= pp.narrow) {
-        const int W = std::min(PIECE_WINDOW, ((need + 7) & ~7) + 8 * (int)(r % 3));
-        for (int rc = PIECE_WINDOW - W + 1; rc <= PIECE_WINDOW; ++rc) {
-            const int j = j_e - PIECE_WINDOW + rc;
+        const int PW = pp.window;
+        const int W = std::min(PW, ((need + 7) & ~7) + 8 * (int)(r % 3));
+        for (int rc = PW - W + 1; rc <= PW; ++rc) {
+            const int j = j_e - PW + rc;
             const uint64_t eq = fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
             filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
-            if (rc == 32) filter_fold(F, j, mf, (uint32_t)u.k);
+            if ((rc & 31) == 0 && rc < PW) filter_fold(F, j, mf, (uint32_t)u.k);
         }
         filter_fold(F, j_e, mf, (uint32_t)u.k);
-        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, dg);
+        const int pa_dlo = j_e - need, pa_dhi = j_e < n ? j_e - u.m : -0x10000;
+        if (pp.window > PIECE_WINDOW) return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, FilterNoDiag(), pa_dlo, pa_dhi);   // (no diagonal view)
+        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, dg, pa_dlo, pa_dhi);
     }
     for (int j = 1; j <= n; ++j) {
         const uint64_t eq = fp.peq[read_code(nib, NW, r, j)];
@@ -354,7 +357,7 @@ void emu_piece(const atr_aligner *a, const uint32_t *planes, const int32_t *lens
                int max_len, uint32_t *out) {
     const LocateParams &p = a->p;
     const Uniform u = make_uniform(p, MT);
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                       a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, lens ? 32 * nchunks : max_len, pp)) abort();
@@ -786,7 +789,7 @@ int emu_locate_batch(const atr_aligner *a, const uint8_t *packed, const int32_t 
 int emu_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
     if (!a || !a->filterable || max_len < 1 || max_len > ATR_MAX_READ_LEN) return 0;
     if (ragged) max_len = 32 * ((max_len + 31) / 32);
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                       a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return 0;
@@ -796,7 +799,7 @@ int emu_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
 int emu_locate_planes_all_widths(const atr_aligner *a, int max_len, int ragged) {          // the envelope without the instantiated widths
     if (!a || !a->filterable || max_len < 1 || max_len > 32 * PIECE_MAX_WORDS) return 0;
     if (ragged) max_len = 32 * ((max_len + 31) / 32);
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     return piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
                         a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp) ? 1 : 0;

@@ -60,6 +60,15 @@ def test_piece_pipeline(emu_backend, oracle):
     assert total > 12000 and refused < 60
 
 
+def test_piece_pipeline_long_adapters(emu_backend, oracle):
+    """Round 6: adapters of 41 .. 64 bases in the two-pass pre-pass -- pass B sweeps their first 32 rows (extended NARROW
+    mode, the tail compare over up to four dwords), up to eight body pieces, k <= 6, 96-column windows."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 101, 110, 150, mrange=(41, 64))
+    assert total > 10000 and refused < 50
+
+
 def test_uniform_partial_overlaps(emu_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner

@@ -69,6 +69,10 @@ def test_specialised_kernel_random_aligners(hip_backend, oracle, jit_on):
                                                  lengths=(70, 100, 128, 150, 150, 160, 180, 200, 224, 250, 260, 288, 300))
     assert total > 2500
     assert len(os.listdir(jit_on)) >= 6
+    # round 6: adapters of 41 .. 64 bases (extended NARROW mode, up to eight body pieces, 96-column windows)
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 78, 12, 400,
+                                                 lengths=(100, 128, 150, 150, 160, 200, 250, 300), mrange=(41, 64))
+    assert total > 2500
 
 
 def test_policy_off_and_auto(hip_backend, tmp_path, monkeypatch):

@@ -56,6 +56,31 @@ def test_piece_pipeline(hip_backend, oracle):
     assert total > 20000 and refused < 80
 
 
+def test_piece_pipeline_long_adapters(hip_backend, oracle):
+    """Round 6: adapters of 41 .. 64 bases through the two-pass pre-pass (generic kernels: 64- and 96-column windows) ==
+    full sweep == one-pass pipeline == oracle; and the reference README's 64-mer on a 1 M-read batch."""
+    from atropos_amd import _lib, synth
+    from atropos_amd.align import Aligner
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 29, 120, 300,
+                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 200, 224, 250, 260, 288, 300),
+                                                 mrange=(41, 64))
+    assert total > 15000 and refused < 60
+    n = 1_000_000
+    reads = synth.single_end(0, n, 150, synth.PE_ADAPTER1, 0xA72050007, "cuda")
+    for e in (0.1, 0.08):
+        al = Aligner(synth.PE_ADAPTER1, e, 14, False, False, 3, 1)
+        planes = al.pack(reads, layout="auto")
+        assert planes.layout == "plane64"                     # (the envelope takes the 64-mer)
+        rec = al.locate_batch(planes).records
+        tiles = al.pack(reads, layout="tile64")
+        assert torch.equal(rec, al.locate_batch(tiles, path="filtered").records)
+        assert torch.equal(rec, al.locate_batch(tiles, filtered=False).records)
+        sl = reads[:100_000].cpu().numpy()
+        exp = oracle.locate_many(synth.PE_ADAPTER1, sl, np.full(len(sl), 150, np.int32), e, 14, False, False, 3, 1, 8)
+        assert np.array_equal(rec[:100_000, :6].cpu().numpy().astype(np.int32), exp)
+        assert 0.4 < float((rec[:, 1] >= 0).float().mean().item()) < 0.7
+
+
 def test_long_reads(hip_backend, oracle):
     """Reads of 737 .. 32 736 bases (the reference has no length limit): locate_long_kernel's rolling origin base
     against the reference's own answers (long_reads.json.gz) and the oracle; long and short reads in one list."""

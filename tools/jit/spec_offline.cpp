@@ -19,7 +19,7 @@ int main(int argc, char **argv) {
     const int max_len = atoi(argv[5]);
     const bool ragged = atoi(argv[6]) != 0;
     const int nw = (max_len + 31) / 32, n = ragged ? 32 * nw : max_len;
-    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, false, a->p.thr, a->p.min_overlap);
+    const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, false, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, false, a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, n, pp)) {
         fprintf(stderr, "outside the two-pass envelope\n");
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
     printf("NW=%d RAGGED=%d n=%d blen=%d llen=%d tlen=%d steps=%d xlo=%d xhi=%d\n", nw, (int)ragged, n, pp.blen, pp.llen, pp.tlen, pp.steps, pp.xlo, pp.xhi);
     if (argc > 8 && !strcmp(argv[8], "--rtc")) {
         std::string log;
-        const std::vector<char> code = jit::compile_spec(cfg, nw, ragged, "gfx950", &log);
+        const std::vector<char> code = jit::compile_spec(cfg, nw, ragged, 0, "gfx950", &log);
         if (code.empty()) { fprintf(stderr, "hiprtc failed:\n%s\n", log.c_str()); return 1; }
         f = fopen((dir + "/spec.hsaco").c_str(), "wb");
         fwrite(code.data(), 1, code.size(), f);
