@@ -53,6 +53,7 @@ constexpr int PIECE_TBIT = 2 * PIECE_NB;    // scode: body piece p at bits 2 p, 
 constexpr int PIECE_STEPS = 8;              // longest read-end piece / regular body piece
 constexpr int PIECE_LAST_STEPS = 24;        // the last body piece takes the rows that are left: up to 24
 constexpr int PIECE_TAIL_WORDS = 3;         // plane words the read-end pieces are evaluated on: the read's last three
+constexpr int PIECE_HEAD_WORDS = 2;         // ... the read-start pieces (START_WITHIN_SEQ1): its first two
 constexpr int PIECE_WINDOW = 64;            // columns a pass-B task carries (two words per plane) ...
 constexpr int PIECE_WINDOW_MAX = 96;        // ... three for adapters whose rows + 2 k exceed that (PieceParams::window)
 constexpr int PIECE_NARROW = 40;            // ... and the most it sweeps when k <= 3 (PieceParams::narrow): one hit diagonal needs
@@ -82,6 +83,20 @@ struct PieceParams {
     uint32_t tmask[PIECE_NT][PIECE_TAIL_WORDS];   // END positions a read-end piece may have (words tw0 ..), 0: piece unused
     uint32_t xmask[32][4];                  // [i][c]: the rows r < i that hold the code of plane c, at bit 32 - i + r (the place of
                                             // row r in the read's last 32 positions when the overlap has i bases)
+    // START_WITHIN_SEQ1 (round 6; the 5' and "anywhere" adapter types, flags 11 / 15): an alignment may begin in column 0
+    // at any row i0 -- the adapter's last L = m - i0 rows against the read's first bases, cost <= floor(L e)
+    // (_align.pyx:333-352, :440-455).  Necessary conditions, mirrored from the read end: overlaps that must be exact are
+    // tested on the read's first 32 positions; class t >= 1 through t + 1 read-START pieces cut from the adapter's END.
+    int sr;                                 // the aligner has START_WITHIN_SEQ1
+    int slen;                               // read-start piece u = rows [m - (u + 1) slen, m - u slen); 0: none
+    int sxlo, sxhi;                         // suffix overlaps of L in [sxlo, sxhi] bases must be exact (sxhi < sxlo: none)
+    int head_cols;                          // columns from the read start a read with a read-start condition sweeps: m + k
+    uint32_t scode2[PIECE_LAST_STEPS];      // as scode, the read-start pieces: piece u at bits 2u
+    uint32_t smask[PIECE_NT][PIECE_HEAD_WORDS];   // END positions a read-start piece may have (words 0, 1)
+    uint32_t xsmask[32][4];                 // [L][c]: the rows m - L + r (r < L) that hold the code of plane c, at bit r
+    int aonly;                              // pass A ONLY (START_WITHIN_SEQ1 adapters of 33 .. 64 bases: pass B's one-word sweep cannot
+                                            // take them -- no NARROW mode with column-0 starts): what pass A leaves goes to the window DP
+                                            // with the columns pass A bounds, instead of the whole read as the one-pass pre-pass has it
 };
 
 // one-hot code (1, 2, 4, 8) -> plane index, -1 otherwise
@@ -90,12 +105,18 @@ inline int piece_plane_of(int code) { return code == 1 ? 0 : code == 2 ? 1 : cod
 #ifndef __HIPCC_RTC__
 // Host: does the two-pass pre-pass take this aligner (m rows, codes[], k, flags, thr_row as in FilterParams,
 // rows = FilterParams::rows) on equal-length reads of n bases?  Fills pp.
+// thr[L] = floor(L e) (LocateParams::thr), min_overlap: for the read-start classes of a START_WITHIN_SEQ1 aligner.
 inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags, bool and_mode, bool custom_table,
-                         const int32_t *thr_row, int n, PieceParams &pp) {
+                         const int32_t *thr_row, int n, PieceParams &pp, const int16_t *thr = nullptr, int min_overlap = 1) {
     memset(&pp, 0, sizeof(pp));
     const int need = ATR_START_WITHIN_SEQ2 | ATR_STOP_WITHIN_SEQ2;
-    if ((flags & need) != need || (flags & ATR_START_WITHIN_SEQ1) || custom_table) return false;
-    if (rows > 32 || rows < 1 || k < 0 || k > PIECE_KMAX || k >= m || m > FILTER_MAX_M) return false;
+    if ((flags & need) != need || custom_table) return false;
+    const bool sr = (flags & ATR_START_WITHIN_SEQ1) != 0;
+    // (START_WITHIN_SEQ1: every row swept -- NARROW mode does not apply, filter_core.hpp -- and reads longer than any
+    //  alignment that touches both column 0 and the last column)
+    if (sr && (!thr || rows != m || n <= m + k)) return false;
+    const bool aonly = sr && rows > 32;
+    if ((rows > 32 && !aonly) || rows < 1 || k < 0 || k > PIECE_KMAX || k >= m || m > FILTER_MAX_M) return false;
     if (n < 1 || n > 32 * PIECE_MAX_WORDS) return false;
     // The pieces cover ALL m rows (an alignment of the whole adapter with <= k errors leaves one of any k + 1 disjoint
     // pieces intact): nb - 1 regular ones of blen rows, the last one takes what they leave.  All pieces on one diagonal are
@@ -187,7 +208,57 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
             }
         }
     }
-    pp.steps = std::max(pp.llen, pp.tlen);
+    pp.sxlo = 1; pp.sxhi = 0;
+    if (sr) {
+        pp.sr = 1;
+        pp.head_cols = m + k;
+        // Suffix overlaps: the adapter's last L rows on the read's first bases, L = 1 .. m - 1 (L = m starts in row 0: a
+        // body piece), a candidate when L >= min_overlap (_align.pyx:446: length = m + min(origin, 0)), cost <= thr[L].
+        int slo[PIECE_NT], shi[PIECE_NT];
+        for (int t = 0; t < PIECE_NT; ++t) { slo[t] = 0; shi[t] = -1; }
+        for (int L = 1; L <= m - 1; ++L) {
+            const int t = L >= min_overlap ? (int)thr[L] : -1;
+            if (t < 0) continue;
+            if (t >= PIECE_NT) {
+                // served by body pieces: the last one and the regular ones in front of it, inside the last L rows
+                const int inside = L >= llen ? 1 + std::min(nb - 1, (L - llen) / blen) : 0;
+                if (inside < t + 1) return false;
+                continue;
+            }
+            if (shi[t] < 0) slo[t] = L;
+            shi[t] = L;
+        }
+        if (shi[0] >= 0) { pp.sxlo = slo[0]; pp.sxhi = shi[0]; }
+        if (pp.sxhi > 31) return false;
+        for (int L = 1; L < 32 && L <= m; ++L)
+            for (int r = 0; r < L; ++r) { const int c = piece_plane_of(codes[m - L + r]); if (c >= 0) pp.xsmask[L][c] |= 1u << r; }
+        int smax = 0;
+        for (int t = 1; t < PIECE_NT; ++t) if (shi[t] >= 0) smax = t;
+        if (smax >= 1) {
+            int slen = PIECE_STEPS;
+            for (int t = 1; t <= smax; ++t) if (shi[t] >= 0) slen = std::min(slen, slo[t] / (t + 1));
+            if (slen < 4) return false;
+            pp.slen = slen;
+            for (int u = 0; u <= smax; ++u) {
+                if ((u + 1) * slen > m) return false;
+                for (int s = 0; s < slen; ++s) pp.scode2[s] |= (uint32_t)piece_plane_of(codes[m - u * slen - 1 - s]) << (2 * u);
+                for (int t = std::max(1, u); t <= smax; ++t) {
+                    if (shi[t] < 0) continue;
+                    if ((t + 1) * slen > slo[t]) return false;
+                    // overlap of L rows from column 0: piece u ends at position L - u slen - 1, at most t off
+                    for (int L = slo[t]; L <= shi[t]; ++L)
+                        for (int dl = -t; dl <= t; ++dl) {
+                            const int e = L - u * slen - 1 + dl;
+                            if (e - slen + 1 < 0 || e > n - 1) continue;
+                            if ((e >> 5) >= PIECE_HEAD_WORDS) return false;      // (cannot happen: L + t <= 31 + 4)
+                            pp.smask[u][e >> 5] |= 1u << (e & 31);
+                        }
+                }
+            }
+        }
+    }
+    pp.aonly = aonly ? 1 : 0;
+    pp.steps = std::max(std::max(pp.llen, pp.tlen), pp.slen);
     pp.tail_cols = rows + k + (m - rows);                            // see "tail_cols" in DESIGN.md 3.2b: rows + k + T
     return true;
 }
@@ -434,22 +505,84 @@ struct PieceScan {
     int j_s, j_e;                            // columns j_s + 1 .. j_e hold every acceptable cell and its traceback
     bool flagged;                            // false: the result is None
     bool tail;                               // a read-end condition holds (the window then ends at n)
+    bool head;                               // START_WITHIN_SEQ1: a read-start condition holds (the window then starts at column 0;
+                                             // the caller widens it: its columns are the read's own, j_s / j_e may be a moved read's)
 };
+
+// What pass B (or the full sweep) is asked to do with a read, in the read's OWN columns.  back: positions pass A saw the read
+// moved up by (a ragged batch), nr: its length.  START_WITHIN_SEQ1: a read-start condition, or a body piece that allows a
+// row-m candidate within m + k columns of the read start (only those can be reached from column 0 with <= k errors), makes
+// the window begin in column 0, where the sweep starts from the all-zero column; a read so short that one alignment could
+// touch both column 0 and the last column takes the full sweep whatever pass A found.
+struct PieceTask {
+    int j_e, need;                           // the window ends at column j_e and holds `need` columns
+    bool flagged, full;                      // something to decide; ... by the full sweep only
+};
+ATR_DEV PieceTask piece_task(const PieceScan &S, int back, int nr, bool sr, int m, int k, int head_cols) {
+    int js = atr_max(S.j_s, back) - back, je = S.j_e - back;
+    PieceTask t;
+    t.flagged = S.flagged;
+    t.full = false;
+    if (sr) {
+        if (nr <= m + k) { t.flagged = true; t.full = true; }
+        if (S.head) { js = 0; je = atr_max(je, atr_min(nr, head_cols)); }
+        else if (js <= k) js = 0;
+    }
+    t.j_e = atr_max(je, 0);                                          // (nothing flagged: an empty window at column 0)
+    t.need = atr_max(je - js, 0);
+    return t;
+}
 
 // Pass A for one lane: the planes of a read of n bases (NW = ceil(n / 32) words) -> PieceScan.  twp[p]: plane p
 // of the read's last 32 positions (bit 31 = the last base; zeros before the read).  mf = rows swept by pass B
 // (FilterParams::rows), T = m - mf, k as Uniform::k.  n is wave-uniform (equal-length batch).
 // NBMAX: the body pieces this instantiation holds accumulators for (pp.nb <= NBMAX): the generic kernels of the 64-column
 // window keep five (eight of them spilled 37 registers at NW = 5)
+// hpl: the read's first plane words where the read STARTS at position 0 (pl itself unless the caller moved a ragged read to
+// the end of its words): what the read-start conditions of a START_WITHIN_SEQ1 aligner look at.
 template <int NW, int NBMAX = PIECE_NB>
 ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4], const uint32_t (&twp)[4], int n, int mf,
-                             int T, int k) {
+                             int T, int k, const uint32_t (*hpl)[4] = nullptr) {
     static_assert(NBMAX >= 4 && NBMAX <= PIECE_NB, "body pieces");
     constexpr int TWN = NW < PIECE_TAIL_WORDS ? NW : PIECE_TAIL_WORDS, TW0 = NW - TWN;
+    constexpr int HWN = NW < PIECE_HEAD_WORDS ? NW : PIECE_HEAD_WORDS;
     PieceMasks<NW> Y;
     const bool and_mode = piece_uniform(pp.and_mode) != 0;
     const int xlo = piece_uniform(pp.xlo), xhi = piece_uniform(pp.xhi), pm = piece_uniform(pp.m), pblen = piece_uniform(pp.blen);
     piece_eq_masks<NW>(pl, and_mode, Y);
+
+    // (0) START_WITHIN_SEQ1: the suffix overlaps that must be exact -- the adapter's last L rows are the read's first L bases
+    const bool sr = piece_uniform(pp.sr) != 0 && hpl != nullptr;
+    const int slen = sr ? piece_uniform(pp.slen) : 0;
+    bool head = false;
+    PieceMasks<HWN> YH;
+    uint32_t socc[PIECE_NT][HWN];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int w = 0; w < HWN; ++w) YH.y[c][w] = 0u;
+#pragma unroll
+    for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+        for (int w = 0; w < HWN; ++w) socc[u][w] = 0u;
+    if (sr) {
+        uint32_t hp[HWN][4];
+#pragma unroll
+        for (int w = 0; w < HWN; ++w)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hp[w][c] = hpl[w][c];
+        piece_eq_masks<HWN>(hp, and_mode, YH);
+        const int sxlo = piece_uniform(pp.sxlo), sxhi = piece_uniform(pp.sxhi);
+        for (int L = sxlo; L <= sxhi; ++L) {                   // wave-uniform trip count; L <= 31
+            const uint32_t mw = (YH.y[0][0] & pp.xsmask[L][0]) | (YH.y[1][0] & pp.xsmask[L][1]) | (YH.y[2][0] & pp.xsmask[L][2]) |
+                                (YH.y[3][0] & pp.xsmask[L][3]);
+            head = head || mw == ((1u << L) - 1u);
+        }
+#pragma unroll
+        for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+            for (int w = 0; w < HWN; ++w) socc[u][w] = pp.smask[u][w];
+    }
 
     // (1) overlaps that must be exact: rows [0, i) against the last i bases, i in [xlo, xhi]: row r of an overlap
     //     of i sits at bit 32 - i + r of the read's last 32 positions.
@@ -502,7 +635,24 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
             piece_and_term<NW, TWN, TW0, PIECE_TBIT + 6>(tocc[3], Y, cw);
             piece_and_term<NW, TWN, TW0, PIECE_TBIT + 8>(tocc[4], Y, cw);
         }
+        if (s < slen) {                                              // (wave-uniform; 0 without START_WITHIN_SEQ1)
+            const uint32_t cw2 = (uint32_t)piece_uniform((int)pp.scode2[s]);
+            piece_and_term<HWN, HWN, 0, 0>(socc[0], YH, cw2);
+            piece_and_term<HWN, HWN, 0, 2>(socc[1], YH, cw2);
+            piece_and_term<HWN, HWN, 0, 4>(socc[2], YH, cw2);
+            piece_and_term<HWN, HWN, 0, 6>(socc[3], YH, cw2);
+            piece_and_term<HWN, HWN, 0, 8>(socc[4], YH, cw2);
+            if (s + 1 < slen) piece_shift_masks<HWN>(YH);
+        }
         if (s + 1 < steps) piece_shift_masks<NW>(Y);
+    }
+    if (slen > 0) {
+        uint32_t any = 0u;
+#pragma unroll
+        for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+            for (int w = 0; w < HWN; ++w) any |= socc[u][w];
+        head = head || any != 0u;
     }
     // (a piece cannot end before its own length: after s shifts the bits below s are zero)
     if (tlen > 0) {
@@ -546,7 +696,8 @@ ATR_DEV PieceScan piece_scan(const PieceParams &pp, const uint32_t (&pl)[NW][4],
     const int tail_cols = piece_uniform(pp.tail_cols);
     PieceScan S;
     S.tail = tail;
-    S.flagged = tail || b_first >= 0;
+    S.head = head;
+    S.flagged = tail || head || b_first >= 0;
     S.j_s = 0; S.j_e = 0;
     // the first zero-cost column of row m (all m rows verbatim on diagonal d: column d + m): where the reference stops
     S.j_exact = z_first >= 0 ? z_first - (pblen - 1) + pm : 0;
@@ -581,11 +732,40 @@ __device__ __forceinline__ void piece_static_for(F &&f) {
 }
 
 template <int NW>
-ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&twp)[4], int mf, int T, int k) {
+ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&twp)[4], int mf, int T, int k,
+                                  const uint32_t (*hpl)[4] = nullptr) {
     constexpr int TWN = NW < PIECE_TAIL_WORDS ? NW : PIECE_TAIL_WORDS, TW0 = NW - TWN;
+    constexpr int HWN = NW < PIECE_HEAD_WORDS ? NW : PIECE_HEAD_WORDS;
     constexpr int n = spec::N;
     PieceMasks<NW> Y;
     piece_eq_masks<NW>(pl, spec::PP.and_mode != 0, Y);
+
+    // (0) START_WITHIN_SEQ1: the read-start conditions (piece_scan), on the read's first words where it starts at position 0
+    bool head = false;
+    PieceMasks<HWN> YH;
+    uint32_t socc[PIECE_NT][HWN];
+    if constexpr (spec::PP.sr != 0) {
+        uint32_t hp[HWN][4];
+#pragma unroll
+        for (int w = 0; w < HWN; ++w)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hp[w][c] = hpl[w][c];
+        piece_eq_masks<HWN>(hp, spec::PP.and_mode != 0, YH);
+        // W_{L + 1} = eq[row m - L - 1] & (W_L >> 1): bit 0 <=> the first L + 1 bases are the adapter's last L + 1 rows
+        if constexpr (spec::PP.sxhi >= spec::PP.sxlo) {
+            uint32_t x = ~0u, any = 0u;
+            piece_static_for<0, spec::PP.sxhi>([&](auto ic) {
+                constexpr int L = decltype(ic)::value;                   // row m - L - 1 joins: W_{L + 1}
+                x = (x >> 1) & YH.y[spec::ROWC[spec::PP.m - L - 1]][0];
+                if constexpr (L + 1 >= spec::PP.sxlo) any |= x;
+            });
+            head = (any & 1u) != 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+            for (int w = 0; w < HWN; ++w) socc[u][w] = spec::PP.smask[u][w];
+    }
 
     // (1) overlaps that must be exact.  X_i = AND_{r < i} (tw[c_r] << (i - 1 - r)) has bit 31 set iff the last i bases
     //     are rows 0 .. i - 1; X_{i + 1} = (X_i << 1) & tw[c_i]: one add and one and per overlap length.
@@ -649,8 +829,27 @@ ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&
                 }
             });
         }
+        if constexpr (spec::PP.sr != 0 && s < spec::PP.slen) {
+            constexpr uint32_t cw2 = spec::PP.scode2[s];
+            piece_static_for<0, PIECE_NT>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                if constexpr ((spec::PP.smask[u][0] | spec::PP.smask[u][1]) != 0u) {
+#pragma unroll
+                    for (int w = 0; w < HWN; ++w) term(socc[u][w], YH.y[(cw2 >> (2 * u)) & 3u][w], false);
+                }
+            });
+            if constexpr (s + 1 < spec::PP.slen) piece_shift_masks<HWN>(YH);
+        }
         if constexpr (s + 1 < spec::PP.steps) piece_shift_masks<NW>(Y);
     });
+    if constexpr (spec::PP.sr != 0 && spec::PP.slen > 0) {
+        uint32_t any = 0u;
+#pragma unroll
+        for (int u = 0; u < PIECE_NT; ++u)
+#pragma unroll
+            for (int w = 0; w < HWN; ++w) any |= socc[u][w];
+        head = head || any != 0u;
+    }
     if constexpr (spec::PP.tlen > 0) {
         uint32_t any = 0u;
 #pragma unroll
@@ -686,7 +885,8 @@ ATR_DEV PieceScan piece_scan_spec(const uint32_t (&pl)[NW][4], const uint32_t (&
 
     PieceScan S;
     S.tail = tail;
-    S.flagged = tail || b_first >= 0;
+    S.head = head;
+    S.flagged = tail || head || b_first >= 0;
     S.j_s = 0; S.j_e = 0;
     S.j_exact = z_first >= 0 ? z_first - (spec::PP.blen - 1) + spec::PP.m : 0;
     if (b_first >= 0) {

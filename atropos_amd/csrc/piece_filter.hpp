@@ -208,6 +208,20 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         }
         FilterState F;
         filter_init(F, u, mf);
+        // START_WITHIN_SEQ1: a lane whose sweep reaches back to column 0 starts from the all-zero column (filter_init) and
+        // takes the window positions before its first base as columns in which every row matches -- they leave the zero
+        // column as it is; a lane whose sweep begins later starts like any other aligner's, "row i reached by i insertions"
+        // (an upper bound that is exact for every cell a <= k-error path from row 0 reaches: piece_task).
+        int vstart = 0;                                                        // window positions before column 1 (sr lanes from column 0)
+        if (u.sr) {
+            const bool zero0 = j_e - W <= 0;
+            if (!zero0) {
+                const int off = filter_row_offset(mf, false);
+                F.pvl = ~0u << (off & 31);
+                F.score = mf - (u.k + 1);
+            }
+            vstart = zero0 ? PW - j_e : 0;
+        }
         uint2 ea[8], eb[8];
 #pragma unroll
         for (int d = 0; d < ND; ++d) {
@@ -215,6 +229,10 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             uint2 (&e)[8] = (d & 1) ? eb : ea;
             if (d == dw0) fetch_peq8(s_peq, nb[d], e);
             if (d + 1 < ND) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);    // one dword ahead of the columns that use it
+            if (u.sr) {                                                        // (wave-uniform; a constant of the run-time compiled kernel)
+#pragma unroll
+                for (int b = 0; b < 8; ++b) if (8 * d + b < vstart) e[b].x = ~0u;
+            }
 #pragma unroll
             for (int b = 0; b < 8; ++b) filter_step<false>(F, e[b].x, e[b].y, kreg);
             if ((d & 3) == 3 && d + 1 < ND) filter_fold(F, j_e - PW + 8 * (d + 1), mf, kreg);   // 32 columns at most between two folds
@@ -334,6 +352,13 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
 #endif
 #endif
         int nr = max_len, back = 0;                               // the read's own length; positions it is moved up by
+        // (START_WITHIN_SEQ1: the read-start conditions want the words in which the read starts at position 0)
+        constexpr int HWN = NW < PIECE_HEAD_WORDS ? NW : PIECE_HEAD_WORDS;
+        uint32_t hpl[HWN][4];
+#pragma unroll
+        for (int w = 0; w < HWN; ++w)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) hpl[w][c] = pl[w][c];
         if (RAGGED) {
             nr = live ? min(max(lens[r], 0), max_len) : 0;
             back = 32 * NW - nr;
@@ -370,22 +395,32 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
                 twp[q] = sh == 0 ? pl[NW - 1][q] : __builtin_amdgcn_alignbit(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, (uint32_t)sh);
         }
 #ifdef ATR_SPEC
-        const PieceScan S = piece_scan_spec<NW>(pl, twp, mf, T, u.k);
+        const PieceScan S = piece_scan_spec<NW>(pl, twp, mf, T, u.k, hpl);
 #else
-        const PieceScan S = piece_scan<NW, (WW == 3 ? PIECE_NB : 5)>(pp, pl, twp, n, mf, T, u.k);
+        const PieceScan S = piece_scan<NW, (WW == 3 ? PIECE_NB : 5)>(pp, pl, twp, n, mf, T, u.k, hpl);
 #endif
+        const PieceTask pt = piece_task(S, back, nr, u.sr, u.m, u.k, piece_uniform(pp.head_cols));
         // the adapter verbatim: resolved here (_align.pyx:456-458), no pass B (22 % of C2's reads)
         const bool exact = live && S.j_exact != 0 && u.m >= u.min_overlap;
         if (exact) {
             const int j = S.j_exact - back;                       // in the read's own columns
             out[r] = make_uint4((uint32_t)u.m << 16, (uint32_t)(j - u.m) | ((uint32_t)j << 16), (uint32_t)u.m, 0u);
         }
-        const bool flagged = live && S.flagged && !exact;
-        const int need = S.j_e - max(S.j_s, back);                // (columns before the read: nothing to sweep)
-        const bool narrow = flagged && need <= piece_uniform(pp.narrow), wide = flagged && !narrow;
+        const bool flagged = live && pt.flagged && !exact;
+        if (piece_uniform(pp.aonly) != 0) {                       // (wave-uniform; a constant of the run-time compiled kernel)
+            // pass A only: None / the adapter verbatim decided above, every other read to the window DP with pass A's columns
+            if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);
+            const int wlo = pt.full ? 0 : pt.j_e - pt.need, whi = pt.full ? nr : pt.j_e;
+            const uint32_t ww = flagged ? window_word(wlo, whi, whi == nr, u.m, false) : 0u;
+            const uint32_t none[4] = {0xFFFF0000u, 0u, 0u, 0u};
+            piece_emit(flagged, r, ww, none, u.m, out, list, ldata, nullptr, 0, &s_lcur, s_hist);
+            continue;
+        }
+        const int need = pt.need;                                 // (columns before the read: nothing to sweep)
+        const bool narrow = flagged && !pt.full && need <= piece_uniform(pp.narrow), wide = flagged && !narrow;
         if (live && !flagged && !exact) out[r] = make_uint4(0xFFFF0000u, 0u, 0u, 0u);   // None
         // (the task carries the read's own columns: a ragged batch was scanned moved to the end of its words)
-        const uint32_t meta = (uint32_t)(S.j_e - back) | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);
+        const uint32_t meta = (uint32_t)pt.j_e | ((uint32_t)need << 10) | (RAGGED ? (uint32_t)nr << 17 : 0u);
         {
             // reads that need the full sweep (1.3 % on C2, but SOME lane of more than half the tiles): into the block's
             // list; the sweep at the end of the kernel gathers them from the batch (40 MB of sectors on C2).  Round 4

@@ -100,7 +100,7 @@ bool piece_applies(const atr_aligner *a, int max_len, FilterParams *fp_out, Piec
     const FilterParams &fp = aligner_piece_filter_params(a);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
-                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return false;
+                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp, a->p.thr, a->p.min_overlap)) return false;
     const int nw = (max_len + 31) / 32;
     if (nw < 3 || nw > 10) return false;                           // instantiated word counts: reads of 65 .. 320 bases
     if (fp_out) *fp_out = fp;

@@ -279,6 +279,10 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     for (int w = 0; w < NW; ++w)
         for (int q = 0; q < 4; ++q) pl[w][q] = planes[((((size_t)(r >> 6) * NW) + w) * 64 + (r & 63)) * 4 + q];
     const int back = nr >= 0 ? 32 * NW - nr : 0;
+    constexpr int HWN = NW < PIECE_HEAD_WORDS ? NW : PIECE_HEAD_WORDS;
+    uint32_t hpl[HWN][4];
+    for (int w = 0; w < HWN; ++w)
+        for (int q = 0; q < 4; ++q) hpl[w][q] = pl[w][q];
     if (nr >= 0) {
         uint32_t mv[NW][4];
         for (int w = 0; w < NW; ++w)
@@ -298,7 +302,8 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
         twp[q] = sh == 0 ? pl[NW - 1][q] : piece_funnel(pl[NW - 1][q], NW >= 2 ? pl[NW >= 2 ? NW - 2 : 0][q] : 0u, sh);
     }
     const int mf = fp.rows, T = u.m - mf;
-    const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k);
+    const PieceScan S = piece_scan<NW>(pp, pl, twp, n, mf, T, u.k, hpl);
+    const PieceTask pt = piece_task(S, back, nr, u.sr, u.m, u.k, pp.head_cols);
     rec[0] = 0xFFFF0000u; rec[1] = rec[2] = rec[3] = 0u;
     ++g_piece_stats[0];
     if (S.j_exact != 0 && u.m >= u.min_overlap) {          // the adapter verbatim: the reference's early exit
@@ -306,9 +311,13 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
         rec[0] = (uint32_t)u.m << 16; rec[1] = (uint32_t)(j - u.m) | ((uint32_t)j << 16); rec[2] = (uint32_t)u.m;
         return 0u;
     }
-    if (!S.flagged) return 0u;
-    const int need = S.j_e - std::max(S.j_s, back);
-    const int j_e = S.j_e - back;                          // from here on: the read's own columns
+    if (!pt.flagged) return 0u;
+    if (pp.aonly) {                                        // pass A only (piece_filter.hpp): the window DP on pass A's columns
+        const int wlo = pt.full ? 0 : pt.j_e - pt.need, whi = pt.full ? nr : pt.j_e;
+        return window_word(wlo, whi, whi == nr, u.m, false);
+    }
+    const int need = pt.need;
+    const int j_e = pt.j_e;                                // from here on: the read's own columns
     n = nr;
     ++g_piece_stats[1];
     if (S.tail) ++g_piece_stats[2];
@@ -330,12 +339,14 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
     };
     FilterState F;
     filter_init(F, u, mf);
-    if (need <= pp.narrow) {
+    if (need <= pp.narrow && !pt.full) {
         const int PW = pp.window;
         const int W = std::min(PW, ((need + 7) & ~7) + 8 * (int)(r % 3));
+        const bool zero0 = u.sr && j_e - W <= 0;           // START_WITHIN_SEQ1: the sweep reaches back to column 0 (piece_filter.hpp)
+        if (u.sr && !zero0) { F.pvl = ~0u << (filter_row_offset(mf, false) & 31); F.score = mf - (u.k + 1); }
         for (int rc = PW - W + 1; rc <= PW; ++rc) {
             const int j = j_e - PW + rc;
-            const uint64_t eq = fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
+            const uint64_t eq = (zero0 && j < 1) ? ~0ull : fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
             filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
             if ((rc & 31) == 0 && rc < PW) filter_fold(F, j, mf, (uint32_t)u.k);
         }
@@ -360,7 +371,7 @@ void emu_piece(const atr_aligner *a, const uint32_t *planes, const int32_t *lens
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
-                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, lens ? 32 * nchunks : max_len, pp)) abort();
+                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, lens ? 32 * nchunks : max_len, pp, a->p.thr, a->p.min_overlap)) abort();
     uint32_t spread[4][256];
     piece_spread_tables(spread);
     const long long ntiles = (nreads + 63) / 64;
@@ -792,7 +803,7 @@ int emu_locate_planes_applies(const atr_aligner *a, int max_len, int ragged) {
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
-                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp)) return 0;
+                      a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp, a->p.thr, a->p.min_overlap)) return 0;
     const int nw = (max_len + 31) / 32;
     return (nw >= 3 && nw <= 10) ? 1 : 0;
 }
@@ -802,7 +813,7 @@ int emu_locate_planes_all_widths(const atr_aligner *a, int max_len, int ragged) 
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, a->wildcard_ref || a->wildcard_query, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
     return piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, a->wildcard_ref || a->wildcard_query,
-                        a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp) ? 1 : 0;
+                        a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, max_len, pp, a->p.thr, a->p.min_overlap) ? 1 : 0;
 }
 
 long long emu_piece_last_windows(uint32_t *out, long long cap) {

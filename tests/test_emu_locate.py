@@ -69,6 +69,17 @@ def test_piece_pipeline_long_adapters(emu_backend, oracle):
     assert total > 10000 and refused < 50
 
 
+def test_piece_pipeline_start_within_seq1(emu_backend, oracle):
+    """Round 6: START_WITHIN_SEQ1 in the two-pass pre-pass (the 5' and "anywhere" adapter types, flags 11 / 15; adapters of
+    up to 32 bases): read-start conditions mirrored from the read end, windows from column 0 swept from the all-zero column,
+    short reads of ragged batches through the full sweep."""
+    from atropos_amd import _lib
+    from atropos_amd.align import Aligner
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 301, 110, 150, mrange=(20, 64),
+                                                 flag_choices=(11, 15, 11, 15))
+    assert total > 9000 and refused < 60
+
+
 def test_uniform_partial_overlaps(emu_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner

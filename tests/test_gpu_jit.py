@@ -69,6 +69,11 @@ def test_specialised_kernel_random_aligners(hip_backend, oracle, jit_on):
                                                  lengths=(70, 100, 128, 150, 150, 160, 180, 200, 224, 250, 260, 288, 300))
     assert total > 2500
     assert len(os.listdir(jit_on)) >= 6
+    # round 6: START_WITHIN_SEQ1 (flags 11 / 15)
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 79, 12, 400,
+                                                 lengths=(100, 128, 150, 150, 160, 200, 250, 300), mrange=(20, 64),
+                                                 flag_choices=(11, 15))
+    assert total > 2000
     # round 6: adapters of 41 .. 64 bases (extended NARROW mode, up to eight body pieces, 96-column windows)
     total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 78, 12, 400,
                                                  lengths=(100, 128, 150, 150, 160, 200, 250, 300), mrange=(41, 64))

@@ -81,6 +81,33 @@ def test_piece_pipeline_long_adapters(hip_backend, oracle):
         assert 0.4 < float((rec[:, 1] >= 0).float().mean().item()) < 0.7
 
 
+def test_piece_pipeline_start_within_seq1(hip_backend, oracle):
+    """Round 6: flags 11 / 15 (-g / -b adapters) through the two-pass pre-pass == full sweep == one-pass pipeline == oracle,
+    and a 1 M-read batch with the adapter at the read START (5' adapter, partial at the start, with errors, absent)."""
+    from atropos_amd import _lib, synth
+    from atropos_amd.align import Aligner
+    total, refused = _cases.check_piece_pipeline(Aligner, oracle, _lib.AtroposHipError, 31, 120, 300,
+                                                 lengths=(70, 100, 128, 150, 150, 160, 180, 200, 224, 250, 260, 288, 300),
+                                                 mrange=(20, 64), flag_choices=(11, 15, 11, 15))
+    assert total > 12000 and refused < 70
+    n = 1_000_000
+    adapter = synth.TRUSEQ_34[:28]
+    back = synth.single_end(0, n, 150, adapter, 0xA72050008, "cuda")
+    reads = torch.flip(back, dims=[1])                                  # the adapter (reversed) now sits at the read START
+    radapter = adapter[::-1]
+    for flags in (11, 15):
+        al = Aligner(radapter, 0.1, flags, False, False, 3, 1)
+        planes = al.pack(reads, layout="auto")
+        assert planes.layout == "plane64"
+        rec = al.locate_batch(planes).records
+        tiles = al.pack(reads, layout="tile64")
+        assert torch.equal(rec, al.locate_batch(tiles, filtered=False).records)
+        sl = reads[:60_000].cpu().numpy()
+        exp = oracle.locate_many(radapter, sl, np.full(len(sl), 150, np.int32), 0.1, flags, False, False, 3, 1, 8)
+        assert np.array_equal(rec[:60_000, :6].cpu().numpy().astype(np.int32), exp)
+        assert 0.3 < float((rec[:, 1] >= 0).float().mean().item()) < 0.8
+
+
 def test_long_reads(hip_backend, oracle):
     """Reads of 737 .. 32 736 bases (the reference has no length limit): locate_long_kernel's rolling origin base
     against the reference's own answers (long_reads.json.gz) and the oracle; long and short reads in one list."""

@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
     const int nw = (max_len + 31) / 32, n = ragged ? 32 * nw : max_len;
     const FilterParams fp = filter_params(a->peq, a->codes, a->p.m, a->flags, false, a->p.thr, a->p.min_overlap, true);
     PieceParams pp;
-    if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, false, a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, n, pp)) {
+    if (!piece_params(a->codes, a->p.m, fp.rows, a->p.k, a->flags, false, a->table_kind == ATR_TABLE_CUSTOM, fp.thr_row, n, pp, a->p.thr, a->p.min_overlap)) {
         fprintf(stderr, "outside the two-pass envelope\n");
         return 1;
     }
