@@ -327,13 +327,14 @@ class C2(object):
             out["ragged_batch_layout"] = rb.layout
         out["pcie_inclusive_bound_reads_per_s"] = PCIE_GBS * 1e9 / (150 + 16)    # ASCII in + record out over PCIe Gen5 x16
         try:
-            out["hard_batches"] = self.hard_batches(run)
-        except Exception as exc:                                              # noqa: BLE001 -- a side figure
-            out["hard_batches"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
-        try:
             out["two_streams"] = self.two_streams()
         except Exception as exc:                                              # noqa: BLE001 -- a side figure
             out["two_streams"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        torch.cuda.empty_cache()
+        try:
+            out["hard_batches"] = self.hard_batches(run)
+        except Exception as exc:                                              # noqa: BLE001 -- a side figure
+            out["hard_batches"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         # the small-batch regime of the drop-in path (tools/bench_small.py): the unchanged trim command hands over
         # <= 1000 reads per call (/root/reference/atropos/commands/base.py:179), the per-read API a batch of one
         try:
