@@ -75,11 +75,13 @@ constexpr int FILTER_NARROW_ROWS = 32, FILTER_NARROW_TAIL = 8;
 inline bool filter_narrow_applies(int m, int flags) {          // host side
     return m > FILTER_NARROW_ROWS && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && !(flags & ATR_START_WITHIN_SEQ1);
 }
-// EXTENDED NARROW mode (round 6), the two-pass pre-pass only: every argument above holds for ANY number T of tail rows --
-// the 32-row matrix brackets the row-m candidates of a 41 .. 64-base adapter just as well -- so pass B keeps its one-word
-// bit-vector (16 ops a column instead of 25) for adapters of up to 64 bases; the tail compare walks up to four dwords.
-// What gets weaker is the last column (a longer row is only kept by the lower bound D'[32][n] - (i - 32)): more of the
-// partial adapters at the read end go to the banded DP, which sweeps all m rows anyway.
+// EXTENDED NARROW mode (round 6, first cut; NOT used any more): every argument above holds for ANY number T of tail rows,
+// so pass B of the two-pass pre-pass could keep its one-word bit-vector for adapters of up to 64 bases (the tail compare
+// walks up to four dwords: filter_tail_cmp).  Measured on the README's 64-mer it lost: a fifth of 150-base reads end in
+// 24 - 63 adapter bases, a last-column row above the 32 swept ones is only kept by the lower bound D'[32][n] - (i - 32),
+// and every such read went to the column-window DP (1.6 of the call's 1.9 ms).  The two-pass pre-pass now sweeps ALL rows
+// of a 41 .. 64-base adapter with two-word bit-vectors (piece_filter.hpp, sweep_decide<true>): 25 ops a column instead
+// of 16, every last-column row exact, the partial adapters in the last-column band.
 constexpr int FILTER_NARROW_TAIL_EXT = 32;
 inline bool filter_narrow_ext_applies(int m, int flags) {
     return m > FILTER_NARROW_ROWS + FILTER_NARROW_TAIL && m <= FILTER_NARROW_ROWS + FILTER_NARROW_TAIL_EXT && !(flags & ATR_START_WITHIN_SEQ1);
@@ -198,7 +200,8 @@ inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, i
     for (int i = 0; i <= FILTER_MAX_M; ++i)
         fp.thr_row[i] = (i >= 1 && i <= m && i >= min_overlap && ((flags & ATR_STOP_WITHIN_SEQ1) || i == m)) ? (int32_t)thr[i] : -1;
     for (int c = 0; c < 16; ++c) fp.peq[c] = peq64[c];
-    if (filter_narrow_applies(m, flags) || (planes_path && filter_narrow_ext_applies(m, flags))) {
+    (void)planes_path;     // (round 6, first cut: extended NARROW mode for m = 41 .. 64 -- replaced by the two-word sweep, see below)
+    if (filter_narrow_applies(m, flags)) {
         fp.rows = FILTER_NARROW_ROWS;
         for (int c = 0; c < 16; ++c) fp.peq[c] = (peq64[c] >> (64 - m)) & 0xFFFFFFFFull;      // rows 1 .. 32 at bits 0 .. 31
         for (int t = 0; t < m - FILTER_NARROW_ROWS; ++t) {

@@ -32,6 +32,7 @@ namespace atr {
 #endif
 
 constexpr int PIECE_QF = 2;                         // queue fields per task: read, meta
+template <bool B> struct PieceBool { static constexpr bool value = B; };
 
 // set bits of `mask` below this lane (v_mbcnt: no lane-mask register to keep alive -- the 64-bit mask of round 4 was
 // spilled in the tile loop, and a scratch reload waits for every load in flight, the next tile's planes included)
@@ -112,6 +113,11 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     __shared__ uint32_t s_hist[FILTER_BINS];
     __shared__ uint32_t s_lcur, s_wcnt;
     constexpr int PW = 32 * WW, ND = 4 * WW;                      // columns / nibble dwords of a pass-B window
+#ifdef ATR_SPEC
+    constexpr bool WIDE_OK = true;                                // (mf is a constant: only one of the two sweeps is compiled)
+#else
+    constexpr bool WIDE_OK = WW == 3;                             // the generic kernels: the two-word sweep in the "big" instantiation only
+#endif
     static_assert(WW == 2 || WW == 3, "windows of 64 or 96 columns");
     __shared__ uint32_t s_nibs[4][ND][64];                        // pass B: the task's nibble dwords, [dword][lane] (NARROW tail check)
     __shared__ uint32_t s_queue[4][PIECE_QF][64];
@@ -160,7 +166,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
     // lane masks: 150 VALU ops per tile and the planes live through all of pass A; a first version of round 5 fetched
     // them per TILE: a memory round trip in every tile iteration, ATR_X_TIMING.  Here it is one round trip per 64
     // tasks, every lane busy.)
-    auto pass_b = [&](int count) {
+    auto pass_b = [&](int count) __attribute__((always_inline)) {
         const bool act = lane < count;
         const long long r = (long long)queue[0][lane];
         const uint32_t meta = queue[1][lane];
@@ -206,8 +212,12 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             if (d >= dw0 - 1) nb[d] = piece_nibbles(s_spread, wp[0][d >> 2], wp[1][d >> 2], wp[2][d >> 2], wp[3][d >> 2], d & 3);
             nibs[d * 64 + lane] = nb[d];                                         // NARROW mode's tail rows, the DP kernels' record
         }
+        // WD: two-word bit-vectors -- adapters of 41 .. 64 bases sweep ALL their rows (round 6): every last-column row is
+        // exact, so a partial adapter at the read end goes to the last-column band instead of the column window
+        const auto sweep_decide = [&](auto wc) __attribute__((always_inline)) {
+        constexpr bool WD = decltype(wc)::value;
         FilterState F;
-        filter_init(F, u, mf);
+        filter_init(F, u, mf, WD);
         // START_WITHIN_SEQ1: a lane whose sweep reaches back to column 0 starts from the all-zero column (filter_init) and
         // takes the window positions before its first base as columns in which every row matches -- they leave the zero
         // column as it is; a lane whose sweep begins later starts like any other aligner's, "row i reached by i insertions"
@@ -234,7 +244,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
                 for (int b = 0; b < 8; ++b) if (8 * d + b < vstart) e[b].x = ~0u;
             }
 #pragma unroll
-            for (int b = 0; b < 8; ++b) filter_step<false>(F, e[b].x, e[b].y, kreg);
+            for (int b = 0; b < 8; ++b) filter_step<WD>(F, e[b].x, e[b].y, kreg);
             if ((d & 3) == 3 && d + 1 < ND) filter_fold(F, j_e - PW + 8 * (d + 1), mf, kreg);   // 32 columns at most between two folds
         }
         filter_fold(F, j_e, mf, kreg);
@@ -247,7 +257,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         // the adapter's rows against the read on diagonal d (filter_decide_tm's substitution certificate): the window's
         // planes moved down to base d, one "base == code" mask per plane against the rows that hold that code
         const auto dg = [&](int d) -> uint64_t {
-            if constexpr (WW != 2) return ~0ull;                               // (the 96-column window: no diagonal view, the DP decides)
+            if constexpr (WW != 2 || WD) return ~0ull;                         // (the 96-column window / two words: no diagonal view, the DP decides)
             const int o = d - (j_e - PW);                                      // window bit of the diagonal's first base
             if (o < 0 || o + u.m > PW) return ~0ull;
             uint64_t eq = 0ull;
@@ -262,8 +272,14 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         };
         // (j_e < nr: no read-end condition and the window not cut at the read end -- then j_e - need = d_min - k, or 0, and
         //  j_e - m = d_max + k: the pieces' diagonals, filter_decide_tm)
-        const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nr, rec, 0, j_e == nr, dg, j_e - need, j_e < nr ? j_e - u.m : -0x10000);
+        const uint32_t ww = filter_decide_tm<WD>(F, u, fp, tm, nr, rec, 0, j_e == nr, dg, j_e - need, j_e < nr ? j_e - u.m : -0x10000);
         piece_emit(act, r, ww, rec, u.m, out, list, ldata, nibs, j_e - PW, &s_lcur, s_hist, ND);
+        };
+        if (mf > 32) {                                                         // (wave-uniform; a constant of the run-time compiled kernel)
+            if constexpr (WIDE_OK) sweep_decide(PieceBool<true>{});
+        } else {
+            sweep_decide(PieceBool<false>{});
+        }
     };
 
     int qn = 0;                                                   // tasks queued (wave-uniform)
@@ -481,8 +497,10 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             // (a ragged batch: a lane stops at its own last column, the wave at the longest read's)
             const int nl = RAGGED ? (act ? min(max(lens[r], 0), max_len) : 0) : max_len;
             const int nhi = RAGGED ? wave_max_i32(nl) : max_len;
+            const auto full_sweep = [&](auto wc) __attribute__((always_inline)) {
+            constexpr bool WD = decltype(wc)::value;
             FilterState F;
-            filter_init(F, u, mf);
+            filter_init(F, u, mf, WD);
             // (cold code, a few reads per block: real loops -- unrolled over the run-time read length the compiler kept a
             // compare result per column in scalar registers and spilled them)
             int j = 0;
@@ -497,7 +515,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
                     fetch_peq8(s_peq, piece_nibbles(s_spread, v.x, v.y, v.z, v.w, d), e);
 #pragma unroll
                     for (int b = 0; b < 8; ++b)
-                        if (j + b < nl) filter_step<false>(F, e[b].x, e[b].y, kreg);
+                        if (j + b < nl) filter_step<WD>(F, e[b].x, e[b].y, kreg);
                     j += 8;
                 }
                 filter_fold(F, min(j, nl), mf, kreg);
@@ -506,8 +524,14 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             const auto tm = [&](int jp) {
                 return filter_tail_cmp(fp, T, jp, [&](int z) { return read_dword_planes((const uint32_t *)bp, NW, z, s_spread); });
             };
-            const uint32_t ww = filter_decide_tm<false>(F, u, fp, tm, nl, rec, 0, true);
+            const uint32_t ww = filter_decide_tm<WD>(F, u, fp, tm, nl, rec, 0, true);
             piece_emit(act, r, ww, rec, u.m, out, list, ldata, nullptr, 0, &s_lcur, s_hist);
+            };
+            if (mf > 32) {
+                if constexpr (WIDE_OK) full_sweep(PieceBool<true>{});
+            } else {
+                full_sweep(PieceBool<false>{});
+            }
         }
     }
     __syncthreads();

@@ -86,8 +86,8 @@ static void launch_piece_filter_w(const atr_aligner *a, const FilterParams &fp, 
 template <int NW>
 static void launch_piece_filter(const atr_aligner *a, const FilterParams &fp, const PieceParams &pp, const uint4 *planes,
                                 const int32_t *lens, long long nreads, int max_len, uint4 *out, FastWork &wk, hipStream_t st) {
-    // (the 96-column instantiation is also the one with accumulators for more than five body pieces)
-    if (pp.window > PIECE_WINDOW || pp.nb > 5) launch_piece_filter_w<NW, 3>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st);
+    // (the 96-column instantiation is also the one with accumulators for more than five body pieces and the two-word sweep)
+    if (pp.window > PIECE_WINDOW || pp.nb > 5 || fp.rows > 32) launch_piece_filter_w<NW, 3>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st);
     else launch_piece_filter_w<NW, 2>(a, fp, pp, planes, lens, nreads, max_len, out, wk, st);
 }
 

@@ -347,20 +347,20 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
         for (int rc = PW - W + 1; rc <= PW; ++rc) {
             const int j = j_e - PW + rc;
             const uint64_t eq = (zero0 && j < 1) ? ~0ull : fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
-            filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
+            if (mf > 32) filter_step<true>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k); else filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
             if ((rc & 31) == 0 && rc < PW) filter_fold(F, j, mf, (uint32_t)u.k);
         }
         filter_fold(F, j_e, mf, (uint32_t)u.k);
         const int pa_dlo = j_e - need, pa_dhi = j_e < n ? j_e - u.m : -0x10000;
-        if (pp.window > PIECE_WINDOW) return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, FilterNoDiag(), pa_dlo, pa_dhi);   // (no diagonal view)
-        return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, dg, pa_dlo, pa_dhi);
+        if (pp.window > PIECE_WINDOW) return mf > 32 ? filter_decide_tm<true>(F, u, fp, tm, n, rec, 0, j_e == n, FilterNoDiag(), pa_dlo, pa_dhi) : filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, FilterNoDiag(), pa_dlo, pa_dhi);   // (no diagonal view)
+        return mf > 32 ? filter_decide_tm<true>(F, u, fp, tm, n, rec, 0, j_e == n, dg, pa_dlo, pa_dhi) : filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, j_e == n, dg, pa_dlo, pa_dhi);
     }
     for (int j = 1; j <= n; ++j) {
         const uint64_t eq = fp.peq[read_code(nib, NW, r, j)];
-        filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
+        if (mf > 32) filter_step<true>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k); else filter_step<false>(F, (uint32_t)eq, (uint32_t)(eq >> 32), (uint32_t)u.k);
         if ((j & 31) == 0 || j == n) filter_fold(F, j, mf, (uint32_t)u.k);
     }
-    return filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true, dg);
+    return mf > 32 ? filter_decide_tm<true>(F, u, fp, tm, n, rec, 0, true, dg) : filter_decide_tm<false>(F, u, fp, tm, n, rec, 0, true, dg);
 }
 
 template <int MT, bool NOINDEL>
