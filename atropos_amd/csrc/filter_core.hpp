@@ -36,6 +36,7 @@ namespace atr {
 
 constexpr int FILTER_MAX_M = 64;
 constexpr int FILTER_CERT_T = 3;                   // extension rows a perfect-overlap certificate covers (cost_l <= 3)
+constexpr int FILTER_CERT_TW = 6;                  // ... of an adapter of more than 32 bases in the two-pass pre-pass (k <= 6)
 constexpr int FILTER_BINS = 256;                   // 96 window-start bins of 8 columns (n <= 736) x 2 classes + 64 row-count bins
 
 struct FilterParams {
@@ -52,6 +53,7 @@ struct FilterParams {
                                                     // DP (filter_substitution_certificate); 0: never
     uint64_t rowsel[4];                             // rows whose code is the one-hot code of plane c, bit r - 1 (cert_sub != 0 only)
     uint32_t tailx[3];                              // extended NARROW mode (two-pass pre-pass, m = 41 .. 64): rows 41 .. 64, as `tail`
+    uint64_t cert64[FILTER_CERT_TW + 1];            // `cert` for a two-word sweep (rows > 32): cert64[t] bit i, i < 64
 };
 
 // NARROW mode.  A 33 .. 40-base adapter needs two 32-bit words per bit-vector and ~28 VALU ops per
@@ -135,6 +137,43 @@ inline void filter_overlap_certificates(const uint8_t *codes, int m, int rows, c
             if (thr_row[i] >= 0 && thr_row[i + t] >= t && !((bad[t] >> i) & 1u)) cert[t] |= 1u << i;
 }
 
+// The same bound for a sweep of more than 32 rows (the two-pass pre-pass on adapters of 41 .. 64 bases, round 6: a quarter
+// of such an adapter's reads end in a perfect overlap whose extension rows qualify -- without the certificate every one
+// of them went to the banded DP): t <= FILTER_CERT_TW, i < 64.
+inline void filter_overlap_certificates64(const uint8_t *codes, int m, int rows, const int32_t *thr_row, bool and_mode,
+                                          uint64_t cert[FILTER_CERT_TW + 1]) {
+    for (int t = 0; t <= FILTER_CERT_TW; ++t) cert[t] = 0ull;
+    if (and_mode || rows <= 32 || rows > FILTER_MAX_M) return;
+    const int R = m < rows ? m : rows;
+    static thread_local uint8_t tab[FILTER_MAX_M + 1][FILTER_MAX_M + 1];
+    uint64_t bad[FILTER_CERT_TW + 1];
+    for (int t = 0; t <= FILTER_CERT_TW; ++t) bad[t] = 0ull;
+    for (int a = 1; a <= R; ++a) {
+        const int xs = R - a;
+        for (int y = 0; y <= R; ++y) tab[0][y] = 0;
+        for (int x = 1; x <= xs; ++x) {
+            tab[x][0] = 0;
+            for (int y = 1; y <= R; ++y) {
+                const uint8_t up = tab[x - 1][y], left = tab[x][y - 1];
+                uint8_t v = up > left ? up : left;
+                if (codes[a + x - 1] == codes[y - 1] && (uint8_t)(tab[x - 1][y - 1] + 1) > v) v = (uint8_t)(tab[x - 1][y - 1] + 1);
+                tab[x][y] = v;
+            }
+        }
+        for (int t = 1; t <= FILTER_CERT_TW; ++t)
+            for (int i = 1; i + t <= R && i < 64; ++i) {
+                const int top = i + t, kk = thr_row[top];
+                if (kk < t || a > top) continue;
+                const int free_bases = t + kk;
+                const int bound = (a < free_bases ? a : free_bases) + (int)tab[top - a][i];
+                if (bound > i) bad[t] |= 1ull << i;
+            }
+    }
+    for (int t = 1; t <= FILTER_CERT_TW; ++t)
+        for (int i = 1; i + t <= R && i < 64; ++i)
+            if (thr_row[i] >= 0 && thr_row[i + t] >= t && !((bad[t] >> i) & 1ull)) cert[t] |= 1ull << i;
+}
+
 // ONE SUBSTITUTION, decided without the DP (round 5).  The commonest unresolved read after the overlap certificates
 // holds the whole adapter with a single substituted base: on diagonal d the read disagrees with the adapter in exactly
 // one row r, so cell W = (m, d + m) costs 1 (0 only with H = 0: the early exit) and -- the diagonal path being optimal
@@ -210,6 +249,7 @@ inline FilterParams filter_params(const uint64_t *peq64, const uint8_t *codes, i
         }
     }
     filter_overlap_certificates(codes, m, fp.rows, fp.thr_row, and_mode, fp.cert);
+    filter_overlap_certificates64(codes, m, planes_path ? fp.rows : 0, fp.thr_row, and_mode, fp.cert64);
     fp.cert_sub = 0ull;
     fp.rowsel[0] = fp.rowsel[1] = fp.rowsel[2] = fp.rowsel[3] = 0ull;
     if (m <= FILTER_MAX_M && (flags & ATR_STOP_WITHIN_SEQ2) && !(flags & ATR_START_WITHIN_SEQ1) && m >= min_overlap && thr[m] >= 1) {
@@ -587,6 +627,10 @@ ATR_DEV bool filter_tail_matches(const P &fp, int T, const uint32_t *q, int nchu
 // tm(jp): do the T bases after column jp equal the adapter's tail rows (filter_tail_matches on the caller's copy of
 // the read)?  have_last = false (two-pass pre-pass, piece_core.hpp): the sweep did not end in column n because no
 // last-column cell can be acceptable -- F's vertical deltas are those of another column and are not looked at.
+// cert64 of the parameter block (the linked pipeline's per-lane view has none)
+ATR_DEV uint64_t filter_cert64(const FilterParams &fp, int t) { return fp.cert64[t]; }
+template <class P> ATR_DEV uint64_t filter_cert64(const P &, int) { return 0ull; }
+
 // (no diagonal view of the read: the substitution certificate is not asked for)
 struct FilterNoDiag { ATR_DEV_MEMBER uint64_t operator()(int) const { return ~0ull; } };
 
@@ -640,6 +684,17 @@ ATR_DEV uint32_t filter_decide_tm(const FilterState &F, const Uniform &u, const 
         const int i = row_l - cost_l, off = filter_row_offset(mf, false);
         const uint32_t seg = ((1u << cost_l) - 1u) << (off + i);             // rows i + 1 .. row_l (row r at bit off + r - 1)
         if ((F.pvl & seg) == seg && ((fp.cert[cost_l] >> i) & 1u) != 0u && n - i >= s) {
+            rec[0] = (uint32_t)i << 16;
+            rec[1] = (uint32_t)(n - i) | ((uint32_t)n << 16);
+            rec[2] = (uint32_t)i;
+            return 0;
+        }
+    }
+    if (WIDE && !rowm && !u.sr && exact_l && u.indel == 1 && cost_l >= 1 && cost_l <= FILTER_CERT_TW && row_l > cost_l) {
+        // ... the same with two words (filter_overlap_certificates64)
+        const int i = row_l - cost_l, off = filter_row_offset(mf, true);
+        const uint64_t seg = ((1ull << cost_l) - 1ull) << (off + i), pv = ((uint64_t)F.pvh << 32) | F.pvl;
+        if ((pv & seg) == seg && ((filter_cert64(fp, cost_l) >> i) & 1ull) != 0ull && n - i >= s) {
             rec[0] = (uint32_t)i << 16;
             rec[1] = (uint32_t)(n - i) | ((uint32_t)n << 16);
             rec[2] = (uint32_t)i;

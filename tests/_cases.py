@@ -241,7 +241,7 @@ def check_piece_pipeline(Aligner, oracle, unsupported_exc, seed, rounds, count=2
     return total, refused
 
 
-def check_certificates(Aligner, oracle, unsupported_exc, seed, rounds, count=500):
+def check_certificates(Aligner, oracle, unsupported_exc, seed, rounds, count=500, mrange=(20, 40)):
     """The DP-free decisions of the pre-pass (filter_core.hpp: perfect-overlap and single-substitution certificates) under
     pressure: adapters that are random, low-complexity, periodic (with a few defects), the TruSeq prefix, or a repeated
     half; the adapter in the read with one or two substitutions (any row, the first and last three more often), flanks
@@ -257,7 +257,7 @@ def check_certificates(Aligner, oracle, unsupported_exc, seed, rounds, count=500
             return rseq(rng, m, rng.choice(["AC", "AG", "CT", "ACG"]))
         if kind == 2:
             unit = rseq(rng, rng.randint(1, 5), "ACGT")
-            s = list((unit * 40)[:m])
+            s = list((unit * 80)[:m])
             for _ in range(rng.randint(0, 3)):
                 s[rng.randrange(m)] = rng.choice("ACGT")
             return "".join(s)
@@ -267,7 +267,7 @@ def check_certificates(Aligner, oracle, unsupported_exc, seed, rounds, count=500
         return (half + half)[:m]
 
     for _ in range(rounds):
-        m = rng.randint(20, 40)
+        m = rng.randint(*mrange)
         ref = adapter(rng.randrange(5), m)
         e = rng.choice([0.03, 0.05, 0.08, 0.1, 0.1, 0.12])
         mo = rng.choice([1, 3, 5])
@@ -291,6 +291,18 @@ def check_certificates(Aligner, oracle, unsupported_exc, seed, rounds, count=500
             if rng.random() < 0.15:                       # an indel near by as well
                 i = rng.randrange(n)
                 q = q[:i] + q[i + 1:] if rng.random() < 0.5 else q[:i] + rng.choice("ACGT") + q[i:]
+            if rng.random() < 0.3:
+                # a PERFECT partial adapter at the read end (the overlap certificates, one- and two-word sweeps): its first i
+                # bases verbatim, behind a flank that is random, continues the adapter's period backwards, repeats the
+                # adapter's start or one base -- now and then with a substitution inside the overlap
+                i = rng.randint(1, m - 1)
+                u = rng.random()
+                flank = (rseq(rng, 20) if u < 0.4 else (ref * 3)[m - 20 + rng.randint(0, 3):][:20] if u < 0.6 else
+                         (ref[:rng.randint(1, 8)] * 20)[:20] if u < 0.8 else ref[rng.randrange(m)] * 20)
+                tail = list(ref[:i])
+                if rng.random() < 0.2:
+                    tail[rng.randrange(i)] = rng.choice("ACGT")
+                q = (rseq(rng, n) + flank + "".join(tail))[-n:]
             reads.append(q[:n])
         try:
             planes = al.pack(reads, layout="plane64")

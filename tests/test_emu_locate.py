@@ -204,3 +204,5 @@ def test_certificates_against_oracle(emu_backend, oracle):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner
     assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 31, 30) > 9000
+    # round 6: adapters of 41 .. 64 bases (two-word sweep, filter_overlap_certificates64), perfect partial adapters behind hostile flanks
+    assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 61, 25, 300, mrange=(41, 64)) > 5000

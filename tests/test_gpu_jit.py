@@ -100,6 +100,7 @@ def test_certificates_on_device(hip_backend, oracle, jit_on):
     from atropos_amd import _lib
     from atropos_amd.align import Aligner
     assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 41, 10, count=3000) > 15000
+    assert _cases.check_certificates(Aligner, oracle, _lib.AtroposHipError, 45, 8, count=2000, mrange=(41, 64)) > 8000
     import os
     os.environ["ATR_JIT"] = "0"
     try:
