@@ -655,6 +655,8 @@ def check_linked_sets_against_oracle(oracle, seed, rounds, reads_per_round=(1, 6
     be = _lib.get_backend()
     rng = random.Random(seed)
     total = fused_sets = 0
+    grouped_sets = [0]
+    check_linked_sets_against_oracle.grouped_sets = grouped_sets
     for it in range(rounds):
         na = rng.randint(1, 4)
         e = rng.choice([0.05, 0.1, 0.12, 0.2, 0.3])
@@ -714,6 +716,12 @@ def check_linked_sets_against_oracle(oracle, seed, rounds, reads_per_round=(1, 6
         ragged = not (fixed and all(len(r) == len(reads[0]) for r in reads))
         l_t = torch.tensor([len(r) for r in reads], dtype=torch.int32, device=be.device) if ragged else None
         which, count, front, back = lset.match_source(AsciiSource(a_t, l_t))
+        if lset.fused and 65 <= width <= 256 and hasattr(lset, "group_applies") and lset.group_applies(width):
+            # round 6: the grouped form (5' parts at pack time, a plane64 sub-batch per adapter) on the same reads
+            gw, gc, gf_, gb_ = lset.match_groups(lset.pack_groups(a_t, l_t, width))
+            assert torch.equal(gw, which) and torch.equal(gc, count), (fronts, backs, kw)
+            assert torch.equal(gf_[:, :6], front[:, :6]) and torch.equal(gb_[:, :6], back[:, :6]), (fronts, backs, kw)
+            grouped_sets[0] += 1
         which, count = which.cpu().numpy(), count.cpu().numpy()
         front, back = front.cpu().numpy(), back.cpu().numpy()
         for i, q in enumerate(reads):
