@@ -115,7 +115,10 @@ inline bool piece_params(const uint8_t *codes, int m, int rows, int k, int flags
     // (START_WITHIN_SEQ1: every row swept -- NARROW mode does not apply, filter_core.hpp -- and reads longer than any
     //  alignment that touches both column 0 and the last column)
     if (sr && (!thr || rows != m || n <= m + k)) return false;
-    const bool aonly = sr && rows > 32;                               // (without START_WITHIN_SEQ1: pass B sweeps two words)
+    // (pass-A-only mode: START_WITHIN_SEQ1 adapters of 33 .. 64 bases before pass B had its two-word sweep; ATR_PIECE_AONLY=1
+    //  brings it back for comparison)
+    static const bool aonly_env = [] { const char *x = getenv("ATR_PIECE_AONLY"); return x && x[0] == '1'; }();
+    const bool aonly = sr && rows > 32 && aonly_env;
     if (rows < 1 || rows > FILTER_MAX_M || k < 0 || k > PIECE_KMAX || k >= m || m > FILTER_MAX_M) return false;
     if (n < 1 || n > 32 * PIECE_MAX_WORDS) return false;
     // The pieces cover ALL m rows (an alignment of the whole adapter with <= k errors leaves one of any k + 1 disjoint

@@ -225,11 +225,11 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
         int vstart = 0;                                                        // window positions before column 1 (sr lanes from column 0)
         if (u.sr) {
             const bool zero0 = j_e - W <= 0;
-            if (!zero0) {
-                const int off = filter_row_offset(mf, false);
-                F.pvl = ~0u << (off & 31);
-                F.score = mf - (u.k + 1);
-            }
+            Uniform uf = u;
+            uf.sr = false;
+            FilterState G;
+            filter_init(G, uf, mf, WD);                                        // "row i reached by i insertions"
+            if (!zero0) { F.pvl = G.pvl; F.pvh = G.pvh; F.score = G.score; }
             vstart = zero0 ? PW - j_e : 0;
         }
         uint2 ea[8], eb[8];
@@ -241,7 +241,7 @@ __device__ __forceinline__ void piece_filter_body(const LocateParams &p, const F
             if (d + 1 < ND) fetch_peq8(s_peq, nb[d + 1], (d & 1) ? ea : eb);    // one dword ahead of the columns that use it
             if (u.sr) {                                                        // (wave-uniform; a constant of the run-time compiled kernel)
 #pragma unroll
-                for (int b = 0; b < 8; ++b) if (8 * d + b < vstart) e[b].x = ~0u;
+                for (int b = 0; b < 8; ++b) if (8 * d + b < vstart) { e[b].x = ~0u; e[b].y = ~0u; }
             }
 #pragma unroll
             for (int b = 0; b < 8; ++b) filter_step<WD>(F, e[b].x, e[b].y, kreg);

@@ -343,7 +343,7 @@ static uint32_t emu_piece_read(const Uniform &u, const FilterParams &fp, const P
         const int PW = pp.window;
         const int W = std::min(PW, ((need + 7) & ~7) + 8 * (int)(r % 3));
         const bool zero0 = u.sr && j_e - W <= 0;           // START_WITHIN_SEQ1: the sweep reaches back to column 0 (piece_filter.hpp)
-        if (u.sr && !zero0) { F.pvl = ~0u << (filter_row_offset(mf, false) & 31); F.score = mf - (u.k + 1); }
+        if (u.sr && !zero0) { Uniform uf = u; uf.sr = false; filter_init(F, uf, mf); }
         for (int rc = PW - W + 1; rc <= PW; ++rc) {
             const int j = j_e - PW + rc;
             const uint64_t eq = (zero0 && j < 1) ? ~0ull : fp.peq[j >= 1 ? read_code(nib, NW, r, j) : 0u];
