@@ -494,20 +494,23 @@ ATR_DEV void sweep_unordered(PairState<W> &P, const IP &ip, int jmax, const uint
 // LDS, indexed per lane), and hands them to the same pair_hit_record.  A true hit always passes the bound, so the
 // hits -- and with them everything after -- are those of the unordered sweep.  Overlaps of at most 32 bases (one
 // word) are costed exactly in pass 1: the many chance hits of a few bases need no second look.
-// rl: the lane's R planes in LDS, rl[(p * (W + 1) + w) * rls], word W = 0; cl: its candidate list, cl[c * cls].
+// rl: the lane's R planes in LDS, rl[(p * W + w) * rls] (no padding word: the funnel's high word above the last one is
+// selected to 0 -- 1 KB per wave, what stood between 250-base pairs and a fourth block per CU); cl: its candidate
+// list, cl[c * cls].
 // Words the bound looks at, by the words of the overlap: 32 random bases differ in planes 0 / 1 at 20 +- 2.7
 // positions, the limit of an overlap of n words is 6.4 n (frac 0.2): the bound must clear it by a few sigma, or
 // every long overlap lands in the list (2 words at 2 x 250 bp: list overflow, ordered redo, 0.41 -> 1.5 ms).
 constexpr int ins_probe_words(int nw) { return nw <= 3 ? 2 : nw <= 6 ? 3 : 4; }
 constexpr int INS_LIST_CAP = 16;                    // listed overlap lengths per lane; more: ordered redo
+// (eight-chunk reads list 12: with 8 KB of planes per wave that is the fourth block of a CU's 160 KB)
+constexpr int ins_list_cap(int w) { return w == 8 ? 12 : INS_LIST_CAP; }
 
 template <int W>
 ATR_DEV void planes_to_lds(const PairState<W> &P, uint32_t *rl, int rls) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
-        for (int w = 0; w < W; ++w) rl[(size_t)(p * (W + 1) + w) * rls] = P.r[p][w];
-        rl[(size_t)(p * (W + 1) + W) * rls] = 0u;
+        for (int w = 0; w < W; ++w) rl[(size_t)(p * W + w) * rls] = P.r[p][w];
     }
 }
 template <int W>
@@ -515,7 +518,7 @@ ATR_DEV void planes_from_lds(PairState<W> &P, const uint32_t *rl, int rls) {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int w = 0; w < W; ++w) P.r[p][w] = rl[(size_t)(p * (W + 1) + w) * rls];
+        for (int w = 0; w < W; ++w) P.r[p][w] = rl[(size_t)(p * W + w) * rls];
 }
 
 template <int W, int Q>
@@ -542,7 +545,7 @@ struct ProbeShift {
                     lb += atr_popc(m);
                 }
                 if (lb <= limit && j <= P.L) {
-                    if (nlist < INS_LIST_CAP) cl[(size_t)nlist * cls] = (uint16_t)j;
+                    if (nlist < ins_list_cap(W)) cl[(size_t)nlist * cls] = (uint16_t)j;
                     nlist += 1;
                 }
             }
@@ -563,7 +566,8 @@ ATR_DEV int overlap_cost_lds(const PairState<W> &P, const uint32_t *rl, int rls,
             uint32_t m = 0u;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const uint32_t lo = rl[(size_t)(p * (W + 1) + w + q) * rls], hi = rl[(size_t)(p * (W + 1) + w + q + 1) * rls];
+                const uint32_t lo = rl[(size_t)(p * W + w + q) * rls];
+                const uint32_t hi = w + q + 1 < W ? rl[(size_t)(p * W + w + q + 1) * rls] : 0u;
                 m = atr_or_xor(m, P.a[p][w], atr_funnel(hi, lo, s));
             }
             if (w + q == W - 1) m &= topmask;
@@ -587,7 +591,8 @@ ATR_DEV void insert_overlap_mismatches(const PairState<W> &P, const uint32_t *rl
         if (j >= 1 && w + q < W) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const uint32_t lo = rl[(size_t)(p * (W + 1) + w + q) * rls], hi = rl[(size_t)(p * (W + 1) + w + q + 1) * rls];
+                const uint32_t lo = rl[(size_t)(p * W + w + q) * rls];
+                const uint32_t hi = w + q + 1 < W ? rl[(size_t)(p * W + w + q + 1) * rls] : 0u;
                 m = atr_or_xor(m, P.a[p][w], atr_funnel(hi, lo, s));
             }
             if (w + q == W - 1) m &= topmask;
@@ -617,14 +622,14 @@ ATR_DEV void sweep_probed(PairState<W> &P, const IP &ip, int jmax, const uint32_
         ProbeShift<W, 0>::all(P, ip, s, rs0, rs1, rt2, rt3, 0xFFFFFFFFu >> s, jmax, cl, cls, nlist);
     }
     // pass 2: the exact cost of the listed overlap lengths
-    const int nmax = nmax_of(atr_imin(nlist, INS_LIST_CAP));
+    const int nmax = nmax_of(atr_imin(nlist, ins_list_cap(W)));
     for (int c = 0; c < nmax; ++c) {
-        if (c < nlist && c < INS_LIST_CAP) {
+        if (c < nlist && c < ins_list_cap(W)) {
             const int j = (int)cl[(size_t)c * cls];
             pair_hit_record<W>(P, ip, j, overlap_cost_lds<W>(P, rl, rls, j), thr_hit[atr_imin(j, INS_MAX_LEN)]);
         }
     }
-    if (nlist > INS_LIST_CAP) P.ncand = INS_CAND + 1;                     // list overflow: the ordered sweep decides
+    if (nlist > ins_list_cap(W)) P.ncand = INS_CAND + 1;                     // list overflow: the ordered sweep decides
     // evaluation pass, as in sweep_unordered
     bool exact = false;
     for (int c = 0; c < INS_CAND; ++c) {

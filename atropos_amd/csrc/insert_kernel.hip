@@ -50,8 +50,10 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     const int jmax = wave_max_i32_ins(P.L);
     // read 2's planes per lane in LDS ([plane][word][lane]: a lane's words sit in its own bank), its list of
     // overlap lengths to cost exactly, and the per-length hit thresholds (pass 2 indexes them per lane)
-    __shared__ uint32_t s_rl[4][4 * (W + 1) * 64];
-    __shared__ __attribute__((aligned(16))) uint16_t s_cl[4][INS_LIST_CAP * 64];
+    // (the fused kernels' task queue takes the planes' place afterwards: four-chunk reads keep a fifth word's room for it)
+    constexpr int RL_WORDS = (FUSE && W < 5) ? 4 * (W + 1) * 64 : 4 * W * 64;
+    __shared__ uint32_t s_rl[4][RL_WORDS];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cl[4][ins_list_cap(W) * 64];
     __shared__ int32_t s_thr_hit[INS_MAX_LEN + 1];
     for (int i = threadIdx.x; i <= INS_MAX_LEN; i += 256) s_thr_hit[i] = ip.thr_hit[i];
     __shared__ uint8_t s_comp[FUSE ? 256 : 1], s_letter[16];
@@ -101,9 +103,11 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     }
 }
 
-// Two entry points around the same body: reads of up to five chunks (160 bases) fit five waves per SIMD
-// with a few spilled dwords (96 VGPRs; C3 1.25 -> 1.08 ms); longer reads would spill their planes there
-// (C5: 1.0 -> 2.4 ms) and are compiled for four waves (128 VGPRs, C5 -7 %).
+// Two entry points around the same body: reads of up to five chunks (160 bases) and longer ones.  Round 6: read 2's
+// planes in LDS lost their padding word and eight-chunk reads list 12 overlap lengths instead of 16 -- 40.5 KB per block
+// instead of 46.6, a FOURTH block per CU for 250-base pairs (128 VGPRs; the 22-35 spilled dwords are all in the ordered redo of
+// low-complexity pairs, behind a wave-uniform branch); the kernels are latency bound (one / two / three / four blocks per CU: 0.83 / 0.45 / 0.34 / 0.30 ms per 2 M
+// pairs for the match alone), C5 7.1 -> 7.9 G reads/s.
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void insert_kernel_dense(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,

@@ -40,7 +40,7 @@ void emu_insert_tiles_ip(const IP &ip, const uint32_t *p1, const int32_t *l1, co
             const uint32_t *g1 = p1 + (((size_t)tile * NCH) * 64 + lane) * 4, *g2 = p2 + (((size_t)tile * NCH) * 64 + lane) * 4;
             uint32_t rec_probed[12];
             {   // as the kernel: the probed two-pass sweep (read 2's planes and the list of overlap lengths in "LDS")
-                uint32_t rl[4 * (W + 1)];
+                uint32_t rl[4 * W];
                 uint16_t cl[INS_LIST_CAP];
                 planes_to_lds<W>(P, rl, 1);
                 sweep_probed<W>(P, ip, jmax, g1, g2, 64 * 4, rl, 1, cl, 1, ip.thr_hit, [](int n) { return n; });
