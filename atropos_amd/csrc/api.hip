@@ -640,7 +640,7 @@ int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *
     if (action != ATR_CORRECT_N && !d_qual1) return ATR_ERR_INVALID;      /* modifiers.py:245-248 */
     if (n == 0) return ATR_OK;
     if (!d_insert_records || !d_seq1 || !d_seq2 || !d_changed || !d_newlen) return ATR_ERR_INVALID;
-    if (d_planes1 && planes_max_len > 0 && planes_max_len <= ATR_INSERT_MAX_READ) {
+    if (d_planes1 && planes_max_len > 0 && planes_max_len <= ATR_INSERT_MAX_READ && stride < ((int64_t)1 << 26)) {
         // the reads as atr_insert_match_batch saw them: only the positions where they disagree are visited
         const int rcp = launch_correct_planes((const int16_t *)d_insert_records, (const uint4 *)d_planes1,
                                               (const uint4 *)d_planes2, (planes_max_len + 31) / 32, d_seq1, d_qual1, d_lens1,
@@ -667,7 +667,8 @@ int atr_insert_match_correct_batch(const atr_insert_aligner *a, const uint8_t *d
     if (!d_out || !d_seq1 || !d_seq2 || !d_changed || !d_newlen || (max_len > 0 && (!d_packed1 || !d_packed2)))
         return ATR_ERR_INVALID;
     const int nchunks = (max_len + 31) / 32;
-    const int rc = launch_insert_correct(a, (const uint4 *)d_packed1, d_lens1, (const uint4 *)d_packed2, d_lens2, npairs,
+    // (the wave-level correction addresses a tile's 64 rows with 32-bit offsets: a row pitch of 64 MB or more takes the two calls)
+    const int rc = stride >= ((int64_t)1 << 26) ? -1 : launch_insert_correct(a, (const uint4 *)d_packed1, d_lens1, (const uint4 *)d_packed2, d_lens2, npairs,
                                          nchunks, max_len, (uint4 *)d_out, d_seq1, d_qual1, d_seq2, d_qual2, stride, action,
                                          min_qual_difference, comp, d_changed, d_newlen, (hipStream_t)stream);
     if (rc >= 0) return rc == 0 ? ATR_OK : hip_fail((hipError_t)rc, "insert_correct_kernel launch");

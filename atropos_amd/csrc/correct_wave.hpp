@@ -75,9 +75,17 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     const uint32_t pend_cap = (uint32_t)(S.qcap - CORRECT_QUEUE_ENTRIES);
     const bool has_quals = A.q1 != nullptr && A.q2 != nullptr;
     const int nchunks = A.nchunks;
+    // The tile's base pointers (wave-uniform: scalar registers) and 32-bit offsets from them (a pair's row, a position):
+    // global_load / global_store with a scalar base and a vector offset, where 64-bit pointers per lane cost two to three
+    // VALU instructions per access (the API bounds the row pitch: 64 rows of it fit 32 bits).
+    const size_t tile_row0 = (size_t)(tile * 64) * (size_t)A.stride;
+    uint8_t *const s1t = A.s1 + tile_row0, *const s2t = A.s2 + tile_row0;
+    uint8_t *const q1t = has_quals ? A.q1 + tile_row0 : nullptr, *const q2t = has_quals ? A.q2 + tile_row0 : nullptr;
+    const uint4 *const p1t = A.planes1 + (size_t)tile * nchunks * 64, *const p2t = A.planes2 + (size_t)tile * nchunks * 64;
+    const uint32_t pitch = (uint32_t)A.stride;
     // A task in two halves, so that the loads of SEVERAL tasks can be in flight before the first one stores (byte
     // pointers alias: the compiler keeps every load behind the stores that precede it in program order).
-    struct Task { int src, i, jx; size_t row; int qa, qb; uint8_t base1, raw2; bool valid; uint32_t entry; };
+    struct Task { int src, i, jx; uint32_t row; int qa, qb; uint8_t base1, raw2; bool valid; uint32_t entry; };
     const auto fetch = [&](bool valid, uint32_t t) {
         Task k;
         k.valid = valid; k.entry = t;
@@ -85,28 +93,28 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
         k.jx = 0; k.row = 0; k.qa = k.qb = 0; k.base1 = k.raw2 = 0;
         if (valid) {
             k.jx = (int)S.jv[k.src] - 1 - k.i;
-            k.row = (size_t)(tile * 64 + k.src) * (size_t)A.stride;
+            k.row = (uint32_t)k.src * pitch;
             // The two BASES come from the bit planes, not from the ASCII matrices: the pair's chunks were streamed by this
             // wave a moment ago (L2), a DNA15 code names its byte (15 upper-case letters, aligner_host.hpp), and a byte
             // fetched from a matrix costs a 64-byte sector of HBM -- two of the four a task used to pull (round 4:
             // 1 068 B per pair counted).  Code 0 (a byte outside the table): read the matrix as before.
-            const uint4 v1 = A.planes1[((size_t)tile * nchunks + (size_t)(k.i >> 5)) * 64 + k.src];
-            const uint4 v2 = A.planes2[((size_t)tile * nchunks + (size_t)(k.jx >> 5)) * 64 + k.src];
+            const uint4 v1 = p1t[(uint32_t)((k.i >> 5) * 64 + k.src)];
+            const uint4 v2 = p2t[(uint32_t)((k.jx >> 5) * 64 + k.src)];
             const uint32_t b1 = (uint32_t)(k.i & 31), b2s = (uint32_t)(k.jx & 31);
             const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
             const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
-            k.qa = has_quals ? (int)A.q1[k.row + k.i] : 0;
-            k.qb = has_quals ? (int)A.q2[k.row + k.jx] : 0;
-            k.base1 = code1 ? S.letter[code1] : A.s1[k.row + k.i];
-            k.raw2 = code2 ? S.letter[code2] : A.s2[k.row + k.jx];
+            k.qa = has_quals ? (int)q1t[k.row + (uint32_t)k.i] : 0;
+            k.qb = has_quals ? (int)q2t[k.row + (uint32_t)k.jx] : 0;
+            k.base1 = code1 ? S.letter[code1] : s1t[k.row + (uint32_t)k.i];
+            k.raw2 = code2 ? S.letter[code2] : s2t[k.row + (uint32_t)k.jx];
         }
         return k;
     };
     const auto apply = [&](const Task &k) {
         if (!k.valid) return;
         uint32_t delta = 0u;
-        const int e = correct_apply_delta(A.s1 + k.row, has_quals ? A.q1 + k.row : nullptr, A.s2 + k.row, has_quals ? A.q2 + k.row : nullptr,
-                                          k.i, k.jx, k.base1, k.raw2, k.qa, k.qb, A.action, A.min_qual_diff, S.comp, delta);
+        const int e = correct_apply_delta(s1t, q1t, s2t, q2t, k.row + (uint32_t)k.i, k.row + (uint32_t)k.jx, k.base1, k.raw2, k.qa, k.qb,
+                                          A.action, A.min_qual_diff, S.comp, delta);
         if (e) S.err[k.src] = e;
         else if (delta) {
             atomicAdd(&S.cnt[k.src], delta);
@@ -209,15 +217,15 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
             const int src = (int)queue[item >> 5], piece = item & 31;
             const int js = (int)S.jv[src], off = 16 * piece;
             if (off >= js) return 0ull;
-            const size_t row = (size_t)(tile * 64 + src) * (size_t)A.stride;
+            const uint32_t row = (uint32_t)src * pitch;
             const int nvalid = js - off;                          // bytes of this piece inside the overlap
             uint32_t w1[4], w2[4];
             if (nvalid >= 16 || js >= 16) {
                 // a full piece, or the row's last piece read as the 16 bytes that END at the overlap's end (never a byte
                 // behind it): its leading 16 - nvalid bytes belong to the piece before and are masked away
                 const int at = nvalid >= 16 ? off : js - 16;
-                const atr_u128_unaligned v1 = *(const atr_u128_unaligned *)(A.q1 + row + at);
-                const atr_u128_unaligned v2 = *(const atr_u128_unaligned *)(A.q2 + row + at);
+                const atr_u128_unaligned v1 = *(const atr_u128_unaligned *)&q1t[row + (uint32_t)at];
+                const atr_u128_unaligned v2 = *(const atr_u128_unaligned *)&q2t[row + (uint32_t)at];
                 w1[0] = v1.x; w1[1] = v1.y; w1[2] = v1.z; w1[3] = v1.w;
                 w2[0] = v2.x; w2[1] = v2.y; w2[2] = v2.z; w2[3] = v2.w;
                 if (nvalid < 16) {
@@ -231,8 +239,8 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
             } else {                                              // an overlap of fewer than 16 bases: byte by byte
                 w1[0] = w1[1] = w1[2] = w1[3] = w2[0] = w2[1] = w2[2] = w2[3] = 0u;
                 for (int b = 0; b < nvalid; ++b) {
-                    w1[0] += (uint32_t)A.q1[row + b];             // (w1[0] / w2[0] are the sums themselves here)
-                    w2[0] += (uint32_t)A.q2[row + b];
+                    w1[0] += (uint32_t)q1t[row + (uint32_t)b];    // (w1[0] / w2[0] are the sums themselves here)
+                    w2[0] += (uint32_t)q2t[row + (uint32_t)b];
                 }
                 return (unsigned long long)w1[0] | ((unsigned long long)w2[0] << 32);
             }
@@ -277,23 +285,23 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
                 const uint32_t d = (uint32_t)*(volatile unsigned long long *)&S.acc[src];
                 if (d != 0u) {
                     const int jx = (int)S.jv[src] - 1 - i;
-                    const size_t row = (size_t)(tile * 64 + src) * (size_t)A.stride;
-                    const uint4 v1 = A.planes1[((size_t)tile * nchunks + (size_t)(i >> 5)) * 64 + src];
-                    const uint4 v2 = A.planes2[((size_t)tile * nchunks + (size_t)(jx >> 5)) * 64 + src];
+                    const uint32_t row = (uint32_t)src * pitch, o1 = row + (uint32_t)i, o2 = row + (uint32_t)jx;
+                    const uint4 v1 = p1t[(uint32_t)((i >> 5) * 64 + src)];
+                    const uint4 v2 = p2t[(uint32_t)((jx >> 5) * 64 + src)];
                     const uint32_t b1 = (uint32_t)(i & 31), b2s = (uint32_t)(jx & 31);
                     const uint32_t code1 = ((v1.x >> b1) & 1u) | (((v1.y >> b1) & 1u) << 1) | (((v1.z >> b1) & 1u) << 2) | (((v1.w >> b1) & 1u) << 3);
                     const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
-                    const int qa = (int)A.q1[row + i], qb = (int)A.q2[row + jx];
-                    const uint8_t base1 = code1 ? S.letter[code1] : A.s1[row + i], raw2 = code2 ? S.letter[code2] : A.s2[row + jx];
+                    const int qa = (int)q1t[o1], qb = (int)q2t[o2];
+                    const uint8_t base1 = code1 ? S.letter[code1] : s1t[o1], raw2 = code2 ? S.letter[code2] : s2t[o2];
                     const uint8_t base2 = S.comp[raw2];
                     const int qd = qa - qb;
                     if (!(base1 == base2 || base1 == 'N' || base2 == 'N' || qd >= A.min_qual_diff || qd <= -A.min_qual_diff)) {
                         if (d == 1u) {
                             const uint8_t cb = S.comp[base1];
                             if (cb == 0) S.err[src] = -1;
-                            else { A.s2[row + jx] = cb; A.q2[row + jx] = (uint8_t)qa; atomicAdd(&S.cnt[src], CORRECT_C2); }
+                            else { s2t[o2] = cb; q2t[o2] = (uint8_t)qa; atomicAdd(&S.cnt[src], CORRECT_C2); }
                         } else {
-                            A.s1[row + i] = base2; A.q1[row + i] = (uint8_t)qb; atomicAdd(&S.cnt[src], CORRECT_C1);
+                            s1t[o1] = base2; q1t[o1] = (uint8_t)qb; atomicAdd(&S.cnt[src], CORRECT_C1);
                         }
                     }
                 }

@@ -489,7 +489,9 @@ ATR_DEV uint32_t facing_mismatches(const uint32_t a[4], W2 b2word, int nwords, i
 // complemented), qa / qb their qualities (ignored without quality rows).
 // (the three counters as ONE packed word: with three `int &` the compiler indexed them in scratch memory)
 constexpr uint32_t CORRECT_C1 = 1u, CORRECT_C2 = 1u << 10, CORRECT_NP = 1u << 20;
-ATR_DEV int correct_apply_delta(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, uint8_t base1, uint8_t raw2,
+// (i / jx unsigned: the wave-level caller passes a tile's base pointers and 32-bit offsets, which the device addresses as
+// scalar base + vector offset)
+ATR_DEV int correct_apply_delta(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, uint32_t i, uint32_t jx, uint8_t base1, uint8_t raw2,
                           int qa, int qb, int action, int min_qual_diff, const uint8_t *comp, uint32_t &delta) {
     const bool has_quals = q1 != nullptr && q2 != nullptr;
     const uint8_t base2 = comp[raw2];
@@ -525,7 +527,7 @@ ATR_DEV int correct_apply_delta(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *
 ATR_DEV int correct_apply(uint8_t *s1, uint8_t *q1, uint8_t *s2, uint8_t *q2, int i, int jx, uint8_t base1, uint8_t raw2,
                           int qa, int qb, int action, int min_qual_diff, const uint8_t *comp, int &c1, int &c2, int &npend) {
     uint32_t delta = 0u;
-    const int e = correct_apply_delta(s1, q1, s2, q2, i, jx, base1, raw2, qa, qb, action, min_qual_diff, comp, delta);
+    const int e = correct_apply_delta(s1, q1, s2, q2, (uint32_t)i, (uint32_t)jx, base1, raw2, qa, qb, action, min_qual_diff, comp, delta);
     c1 += (int)(delta & 1023u); c2 += (int)((delta >> 10) & 1023u); npend += (int)(delta >> 20);
     return e;
 }
