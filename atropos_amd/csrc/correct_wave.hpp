@@ -24,19 +24,33 @@ constexpr int CORRECT_QUEUE_ENTRIES = 64 * 32 + 64;
 #define CORRECT_PIECES_PER_LANE 8
 #endif
 
-// the wave's LDS (views; the caller decides what they overlay)
+// The wave's LDS (views; the caller decides what they overlay).  Pointers IN the LDS address space and plain accesses
+// ordered by wavefront-scope fences (wave_sync_lds): as generic volatile pointers (rounds 4 / 5) every queue entry was
+// a flat_store_short followed by s_waitcnt vmcnt(0) -- some sixty store round trips per wave, a third of the tail.
+#define ATR_LDS __attribute__((address_space(3)))
 struct CorrectWaveLds {
-    volatile uint16_t *queue;          // [CORRECT_QUEUE_ENTRIES]
-    uint32_t *cnt;                     // [64] per pair: c1 | c2 << 10 | npend << 20
-    int32_t *err;                      // [64]
-    int16_t *jv;                       // [64] the pair's overlap length
-    uint32_t *tail;                    // [1]
-    uint32_t *ptail;                   // [1] entries of the tie list
-    unsigned long long *acc;           // [64] per pair: the two quality sums of its overlap, then which read wins its ties
+    ATR_LDS uint16_t *queue;           // [CORRECT_QUEUE_ENTRIES]
+    ATR_LDS uint32_t *cnt;             // [64] per pair: c1 | c2 << 10 | npend << 20
+    ATR_LDS int32_t *err;              // [64]
+    ATR_LDS int16_t *jv;               // [64] the pair's overlap length
+    ATR_LDS uint32_t *tail;            // [1]
+    ATR_LDS uint32_t *ptail;           // [1] entries of the tie list
+    ATR_LDS unsigned long long *acc;   // [64] per pair: the two quality sums of its overlap, then which read wins its ties
     int qcap;                          // uint16 entries the queue's LDS holds (>= CORRECT_QUEUE_ENTRIES): the tie list grows down from its end
-    const uint8_t *comp;               // [256] complement table (block-wide)
-    const uint8_t *letter;             // [16] DNA15 code -> its byte (block-wide)
+    ATR_LDS const uint8_t *comp;       // [256] complement table (block-wide)
+    ATR_LDS const uint8_t *letter;     // [16] DNA15 code -> its byte (block-wide)
 };
+template <class T>
+__device__ __forceinline__ ATR_LDS T *lds_view(T *p) { return (ATR_LDS T *)p; }
+// the lanes of ONE wave exchange data through LDS: its LDS operations execute in order, the fences keep the compiler
+// from moving (or forwarding) accesses across the point
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class T>
+__device__ __forceinline__ T lds_add(ATR_LDS T *p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 struct CorrectArgs {
     const uint4 *planes1, *planes2;    // plane64 batches of the two reads
@@ -65,13 +79,14 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
                                                   bool live, bool todo, int j, int len1, int len2,
                                                   const uint32_t (&mism)[PW]) {
     const long long p = tile * 64 + lane;
-    volatile uint16_t *queue = S.queue;
+    ATR_LDS uint16_t *queue = S.queue;
+    const uint8_t *const comp = (const uint8_t *)S.comp;
     S.cnt[lane] = 0u;
     S.err[lane] = 0;
     S.jv[lane] = (int16_t)j;
     S.acc[lane] = 0ull;
     if (lane == 0) { *S.tail = 0u; *S.ptail = 0u; }
-    __builtin_amdgcn_wave_barrier();
+    wave_sync_lds();
     const uint32_t pend_cap = (uint32_t)(S.qcap - CORRECT_QUEUE_ENTRIES);
     const bool has_quals = A.q1 != nullptr && A.q2 != nullptr;
     const int nchunks = A.nchunks;
@@ -114,12 +129,12 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
         if (!k.valid) return;
         uint32_t delta = 0u;
         const int e = correct_apply_delta(s1t, q1t, s2t, q2t, k.row + (uint32_t)k.i, k.row + (uint32_t)k.jx, k.base1, k.raw2, k.qa, k.qb,
-                                          A.action, A.min_qual_diff, S.comp, delta);
+                                          A.action, A.min_qual_diff, comp, delta);
         if (e) S.err[k.src] = e;
         else if (delta) {
-            atomicAdd(&S.cnt[k.src], delta);
+            lds_add(&S.cnt[k.src], delta);
             if (delta >= CORRECT_NP) {                              // 'liberal', qualities too close: decided by the pair's mean qualities below
-                const uint32_t slot = atomicAdd(S.ptail, 1u);
+                const uint32_t slot = lds_add(S.ptail, 1u);
                 if (slot < pend_cap) queue[S.qcap - 1 - (int)slot] = (uint16_t)k.entry;
             }
         }
@@ -132,9 +147,9 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     int total = 0;
 #pragma unroll
     for (int w = 0; w < PW; ++w) total += __builtin_popcount(mism[w]);
-    uint32_t at = total ? atomicAdd(S.tail, (uint32_t)total) : 0u;
-    __builtin_amdgcn_wave_barrier();
-    const int qall = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
+    uint32_t at = total ? lds_add(S.tail, (uint32_t)total) : 0u;
+    wave_sync_lds();
+    const int qall = __builtin_amdgcn_readfirstlane((int)*S.tail);
     if (qall <= CORRECT_QUEUE_ENTRIES) {
         // (the common case) every lane lists all its positions at once -- one reservation instead of one per plane word
         // with three wave barriers each -- and the wave works the list off CORRECT_TASKS_PER_LANE tasks per lane and round trip
@@ -147,7 +162,7 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
                 queue[at++] = (uint16_t)((lane << 9) | (32 * w + b));
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         for (int base = 0; base < qall; base += 64 * CORRECT_TASKS_PER_LANE) {
             Task k[CORRECT_TASKS_PER_LANE];
 #pragma unroll
@@ -162,45 +177,45 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     } else {
         // more positions than the queue holds (a wave of unrelated reads "matched" at a high error rate): word by word,
         // full rounds worked off as they fill
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         if (lane == 0) *S.tail = 0u;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         int qsize = 0;                                            // wave-uniform
 #pragma unroll
         for (int w = 0; w < PW; ++w) {
             uint32_t m = mism[w];                                 // (0 beyond nchunks)
             const int cnt = __builtin_popcount(m);
             if (cnt) {
-                uint32_t at2 = atomicAdd(S.tail, (uint32_t)cnt);
+                uint32_t at2 = lds_add(S.tail, (uint32_t)cnt);
                 while (m) {
                     const int b = __builtin_ctz(m);
                     m &= m - 1u;
                     queue[at2++] = (uint16_t)((lane << 9) | (32 * w + b));
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            qsize = __builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.tail);
+            wave_sync_lds();
+            qsize = __builtin_amdgcn_readfirstlane((int)*S.tail);
             while (qsize >= 64) {                                 // full rounds, off the end of the queue
                 qsize -= 64;
                 drain(qsize, 64);
             }
-            __builtin_amdgcn_wave_barrier();
+            wave_sync_lds();
             if (lane == 0) *S.tail = (uint32_t)qsize;
-            __builtin_amdgcn_wave_barrier();
+            wave_sync_lds();
         }
         if (qsize > 0) drain(0, qsize);
     }
     // the lanes' stores, before their pairs' owners (lanes of this same wave: one CU, one L1) read them back --
     // a device-scope fence would write back the L2 for the sake of other XCDs, once per wave
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    wave_sync_lds();
     // ---- 'liberal' ties (modifiers.py:301-322): the read with the better MEAN quality over the overlap wins every position
     // whose two qualities were too close.  A lane summing its own pair's two quality rows and then walking its positions
     // one memory round trip at a time cost a quarter of the fused kernel; here the WAVE sums a tied pair's rows (64 lanes
     // x 4 bytes per load, LDS atomics), and the tied positions -- listed by the first pass -- are decided 64 at a time.
-    uint32_t packed_counts = *(volatile uint32_t *)&S.cnt[lane];
-    int err = *(volatile int32_t *)&S.err[lane];
-    const uint32_t npend_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)S.ptail);
+    uint32_t packed_counts = S.cnt[lane];
+    int err = S.err[lane];
+    const uint32_t npend_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)*S.ptail);
     const bool tied = live && todo && !err && (packed_counts >> 20) > 0u;
     if (npend_all > 0u && npend_all <= pend_cap && has_quals) {
         // The tied pairs of the wave, listed (the main queue is worked off: its first 64 entries take the list), and their
@@ -210,7 +225,7 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
         const unsigned long long tm = __ballot(tied);
         const int ntied = (int)__popcll(tm);
         if (tied) queue[lane_rank_below(tm, lane)] = (uint16_t)lane;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         const int nitems = 32 * ntied;
         const auto piece_sums = [&](int item) -> unsigned long long {
             if (item >= nitems) return 0ull;
@@ -259,30 +274,30 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
 #pragma unroll
             for (int u = 0; u < CORRECT_PIECES_PER_LANE; ++u) {
                 const int item = base + 64 * u + lane;
-                if (part[u]) atomicAdd(&S.acc[(int)queue[item >> 5]], part[u]);
+                if (part[u]) lds_add(&S.acc[(int)queue[item >> 5]], part[u]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         uint32_t dir = 0u;                                        // 1: read 1 is better (read 2 is corrected), 2: read 2 is better
         if (tied) {
             if (j <= 0) {
                 err = -3;
                 S.err[lane] = -3;
             } else {
-                const unsigned long long a = *(volatile unsigned long long *)&S.acc[lane];
+                const unsigned long long a = S.acc[lane];
                 const long long sum1 = (long long)(uint32_t)a, sum2 = (long long)(a >> 32);
                 const double diff = (double)sum1 / (double)j - (double)sum2 / (double)j;
                 dir = diff > 1.0 ? 1u : diff < -1.0 ? 2u : 0u;
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         S.acc[lane] = (unsigned long long)dir;
-        __builtin_amdgcn_wave_barrier();
+        wave_sync_lds();
         for (uint32_t base = 0u; base < npend_all; base += 64u) {
             if (base + (uint32_t)lane < npend_all) {
                 const uint32_t t = queue[S.qcap - 1 - (int)(base + (uint32_t)lane)];
                 const int src = (int)(t >> 9), i = (int)(t & 511u);
-                const uint32_t d = (uint32_t)*(volatile unsigned long long *)&S.acc[src];
+                const uint32_t d = (uint32_t)S.acc[src];
                 if (d != 0u) {
                     const int jx = (int)S.jv[src] - 1 - i;
                     const uint32_t row = (uint32_t)src * pitch, o1 = row + (uint32_t)i, o2 = row + (uint32_t)jx;
@@ -293,23 +308,23 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
                     const uint32_t code2 = ((v2.x >> b2s) & 1u) | (((v2.y >> b2s) & 1u) << 1) | (((v2.z >> b2s) & 1u) << 2) | (((v2.w >> b2s) & 1u) << 3);
                     const int qa = (int)q1t[o1], qb = (int)q2t[o2];
                     const uint8_t base1 = code1 ? S.letter[code1] : s1t[o1], raw2 = code2 ? S.letter[code2] : s2t[o2];
-                    const uint8_t base2 = S.comp[raw2];
+                    const uint8_t base2 = comp[raw2];
                     const int qd = qa - qb;
                     if (!(base1 == base2 || base1 == 'N' || base2 == 'N' || qd >= A.min_qual_diff || qd <= -A.min_qual_diff)) {
                         if (d == 1u) {
-                            const uint8_t cb = S.comp[base1];
+                            const uint8_t cb = comp[base1];
                             if (cb == 0) S.err[src] = -1;
-                            else { s2t[o2] = cb; q2t[o2] = (uint8_t)qa; atomicAdd(&S.cnt[src], CORRECT_C2); }
+                            else { s2t[o2] = cb; q2t[o2] = (uint8_t)qa; lds_add(&S.cnt[src], CORRECT_C2); }
                         } else {
-                            s1t[o1] = base2; q1t[o1] = (uint8_t)qb; atomicAdd(&S.cnt[src], CORRECT_C1);
+                            s1t[o1] = base2; q1t[o1] = (uint8_t)qb; lds_add(&S.cnt[src], CORRECT_C1);
                         }
                     }
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
-        packed_counts = *(volatile uint32_t *)&S.cnt[lane];
-        err = *(volatile int32_t *)&S.err[lane];
+        wave_sync_lds();
+        packed_counts = S.cnt[lane];
+        err = S.err[lane];
     }
     if (!live) return;
     if (!todo) {
@@ -321,7 +336,7 @@ __device__ __forceinline__ void correct_wave_tail(const CorrectWaveLds &S, const
     if (npend_all > pend_cap && !err && (packed_counts >> 20) > 0u) {   // a tie list that did not fit (thousands of ties in one wave): lane by lane
         uint8_t *r1 = A.s1 + p * A.stride, *r2 = A.s2 + p * A.stride;
         correct_ties(r1, has_quals ? A.q1 + p * A.stride : nullptr, r2, has_quals ? A.q2 + p * A.stride : nullptr, j, mism, nchunks,
-                     A.min_qual_diff, S.comp, c1, c2, err);
+                     A.min_qual_diff, comp, c1, c2, err);
     }
     A.changed[2 * p] = err ? err : c1;
     A.changed[2 * p + 1] = err ? 0 : c2;

@@ -92,13 +92,14 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
         const int j = todo ? P.best_j : 0;
         uint32_t mism[W];
         insert_overlap_mismatches<W>(P, rl, 64, j, mism);
-        __builtin_amdgcn_wave_barrier();                    // every lane has read its planes: the queue takes their place
+        wave_sync_lds();                                    // every lane has read its planes: the queue takes their place
         CorrectWaveLds S;
-        S.queue = (volatile uint16_t *)&s_rl[wv][0];
+        S.queue = lds_view((uint16_t *)&s_rl[wv][0]);
         uint8_t *small = (uint8_t *)&s_cl[wv][0];
-        S.cnt = (uint32_t *)small; S.err = (int32_t *)(small + 256); S.jv = (int16_t *)(small + 512); S.tail = (uint32_t *)(small + 640);
-        S.ptail = (uint32_t *)(small + 644); S.acc = (unsigned long long *)(small + 1024); S.qcap = (int)(sizeof(s_rl[0]) / sizeof(uint16_t));
-        S.comp = s_comp; S.letter = s_letter;
+        S.cnt = lds_view((uint32_t *)small); S.err = lds_view((int32_t *)(small + 256)); S.jv = lds_view((int16_t *)(small + 512));
+        S.tail = lds_view((uint32_t *)(small + 640)); S.ptail = lds_view((uint32_t *)(small + 644));
+        S.acc = lds_view((unsigned long long *)(small + 1024)); S.qcap = (int)(sizeof(s_rl[0]) / (sizeof(uint16_t)));
+        S.comp = lds_view((const uint8_t *)s_comp); S.letter = lds_view((const uint8_t *)s_letter);
         correct_wave_tail<W>(S, fz->A, tile, lane, live, todo, j, len1, len2, mism);
     }
 }

@@ -251,10 +251,11 @@ __global__ __launch_bounds__(256) void correct_planes_kernel(const int16_t *__re
     }
     // ---- the queue (the planes in LDS are not needed any more; one wave, so no block barrier): correct_wave.hpp ----
     CorrectWaveLds S;
-    S.queue = (volatile uint16_t *)&s_b2[wave][0][0];
-    S.cnt = s_cnt[wave]; S.err = s_err[wave]; S.jv = s_j[wave]; S.tail = &s_tail[wave];
-    S.ptail = &s_ptail[wave]; S.acc = s_acc[wave]; S.qcap = 4 * PW * 64 * 2;
-    S.comp = s_comp; S.letter = s_letter;
+    S.queue = lds_view((uint16_t *)&s_b2[wave][0][0]);
+    S.cnt = lds_view(&s_cnt[wave][0]); S.err = lds_view(&s_err[wave][0]); S.jv = lds_view(&s_j[wave][0]);
+    S.tail = lds_view(&s_tail[wave]); S.ptail = lds_view(&s_ptail[wave]); S.acc = lds_view(&s_acc[wave][0]);
+    S.qcap = 4 * PW * 64 * 2;
+    S.comp = lds_view((const uint8_t *)s_comp); S.letter = lds_view((const uint8_t *)s_letter);
     CorrectArgs A;
     A.planes1 = planes1; A.planes2 = planes2; A.nchunks = nchunks;
     A.s1 = s1; A.q1 = q1; A.s2 = s2; A.q2 = q2; A.stride = stride;
