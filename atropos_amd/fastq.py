@@ -296,12 +296,14 @@ def _staging(nbytes, pinned):
     return t.pin_memory() if pinned else t
 
 
-STAGING_POOL_BYTES = 4 << 30  # page-locked memory the pool keeps between runs (more starves other processes of a shared node)
+STAGING_POOL_BYTES = 4 << 30  # page-locked memory the pool keeps between runs (more starves other processes of a shared node);
+if os.environ.get("ATR_STAGING_POOL_GB"):     # ATR_STAGING_POOL_GB: a host that runs file after file with many part files keeps more
+    STAGING_POOL_BYTES = int(float(os.environ["ATR_STAGING_POOL_GB"]) * (1 << 30))
 
 
 def _release(buffers):
     _STAGING_POOL.extend(buffers)
-    del _STAGING_POOL[:-32]                                   # at most 32 (a paired run with merging into four parts holds 28)
+    del _STAGING_POOL[:-64]                                   # at most 64 (a paired run with merging into eight parts holds 56)
     total = 0
     for i in range(len(_STAGING_POOL) - 1, -1, -1):           # ... and at most STAGING_POOL_BYTES, the newest first
         total += _STAGING_POOL[i].numel()
@@ -310,7 +312,9 @@ def _release(buffers):
             break
 
 
-IO_THREADS = 8              # pread slices per chunk (a page-cached file scales to ~6 GB/s per thread)
+IO_THREADS = 8              # pread slices per chunk (a page-cached file scales to ~6 GB/s per thread); ATR_IO_THREADS
+if os.environ.get("ATR_IO_THREADS"):
+    IO_THREADS = max(1, int(os.environ["ATR_IO_THREADS"]))
 
 
 class StageClock(object):
@@ -326,20 +330,34 @@ class StageClock(object):
 
 class ChunkedFastqReader(object):
     """Feeds a FASTQ file to the GPU in chunks of whole records.  The file is read straight into
-    two page-locked staging buffers (``IO_THREADS`` ``pread`` slices per chunk, no intermediate
-    bytes objects); the next chunk is read while the caller works on the current one.
-    ``.gz`` / ``.bz2`` / ``.xz`` input (what the reference's xopen opens by extension) is decompressed by the
-    read-ahead thread straight into the staging buffer -- one host thread: the decompressor then sets the pace."""
+    page-locked staging buffers (``IO_THREADS`` ``pread`` slices per chunk, no intermediate bytes objects).
+
+    Plain files: ``READ_AHEAD`` chunks are being READ while the GPU works on the current one.  What a chunk
+    carries over from the one before it (its unfinished last record; in a paired run the surplus records of the
+    file with the smaller records) is known only once that chunk has been indexed on the device, but the file
+    READ does not depend on it: the new bytes land behind a reserve at the front of the staging buffer, the
+    carried-over tail is copied in front of them when it is known, and the host -> device copy (its own
+    stream) covers both.  Rounds 2-5 read chunk i + 1 only after chunk i was indexed -- read + upload in one
+    chain, the upload engine idle during every read (the "upload_and_index" wait of ``trim_file``): 16 M x 150 bp
+    into eight part files 64 -> 107 M reads/s.  (A producer thread that also INDEXES each chunk on the upload stream, so
+    that the next upload starts a record count after the last, was measured next: 96 M -- its index kernels and its
+    Python run against the caller's -- and is not kept.)
+
+    ``.gz`` / ``.bz2`` / ``.xz`` input (what the reference's xopen opens by extension) is decompressed by one
+    read-ahead thread straight into the staging buffer: the decompressor then sets the pace."""
+
+    READ_AHEAD = 3
+    RESERVE = 64 << 20                                       # room for the carried-over tail of the previous chunk
 
     def __init__(self, path, chunk_bytes, backend=None, clock=None):
+        import collections
         import os
         from concurrent.futures import ThreadPoolExecutor
         self.be = backend or _lib.get_backend()
         self.clock = clock or StageClock()
         self.chunk_bytes = int(chunk_bytes)
-        cap = self.chunk_bytes + (64 << 20)                  # room for the carried-over tail of the previous chunk
+        cap = self.chunk_bytes + self.RESERVE
         pinned = getattr(self.be, "name", "") == "hip"
-        self.buf = [_staging(cap + 32, pinned), _staging(cap + 32, pinned)]
         self.file = open(path, "rb")
         self.fd = self.file.fileno()
         self.size = os.path.getsize(path)
@@ -355,49 +373,113 @@ class ChunkedFastqReader(object):
         elif name.endswith(".xz"):
             import lzma
             self.stream = lzma.open(self.file, "rb")
+        self.buf = [_staging(cap + 32, pinned) for _ in range(2 if self.stream is not None else self.READ_AHEAD + 1)]
         self.readers = ThreadPoolExecutor(IO_THREADS)
         self.ahead = ThreadPoolExecutor(1)
         self.k = 0
-        # the host -> device copy of a chunk is issued by the read-ahead thread, on its own stream, as soon as
-        # the chunk is in the staging buffer: it overlaps the GPU work on the chunk before
+        # the host -> device copy of a chunk runs on its own stream: it overlaps the GPU work on the chunk before
         self.upload_stream = torch.cuda.Stream(device=self.be.device) if pinned else None
-        self.pending = self.ahead.submit(self._fill, 0, b"")
         self.host = None
         self.nbytes = 0
         self.final = False
+        if self.stream is not None:
+            self.pending = self.ahead.submit(self._fill, 0, b"")
+        else:
+            self.reads = collections.deque()                 # (slot, pread jobs, bytes asked for, last chunk of the file)
+            self.next_slot = 0
+            self.read_done = False
+            self.carry_est = 0
+            self.uploaded = [None] * len(self.buf)           # per staging buffer: the event behind its last upload
+            for _ in range(self.READ_AHEAD):
+                self._issue_read()
+            self.pending = self._assemble(b"")
 
-    def _fill(self, k, carry):
+    # ---- plain files: reads ahead of the carry
+    def _issue_read(self):
         import os
+        if self.read_done:
+            return
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % len(self.buf)
+        if self.uploaded[slot] is not None:
+            self.uploaded[slot].synchronize()                # (three chunks ago: long gone)
+            self.uploaded[slot] = None
+        # a chunk is carry + new bytes ~ chunk_bytes in all: in a paired run the file with the smaller records
+        # carries its surplus records over every time, and reading a full chunk on top of it would let that
+        # surplus grow without bound (1 % of a chunk per step for records 1 % apart).  The carry of the chunk
+        # this read will follow is not known yet; the last one seen stands in for it (it drifts slowly).
+        want = max(self.chunk_bytes - self.carry_est, self.chunk_bytes // 4)
+        want = min(want, self.size - self.pos)
+        view = memoryview(self.buf[slot].numpy())
+        step = ((want + IO_THREADS - 1) // IO_THREADS + 4095) & ~4095
+        jobs = []
+        for t in range(IO_THREADS):
+            lo, hi = t * step, min(want, (t + 1) * step)
+            if hi > lo:
+                jobs.append(self.readers.submit(os.preadv, self.fd, [view[self.RESERVE + lo:self.RESERVE + hi]], self.pos + lo))
+        self.pos += want
+        self.read_done = self.pos >= self.size
+        self.reads.append((slot, jobs, want, self.read_done))
+
+    def _assemble(self, carry):
+        """The next chunk: its carried-over head in front of the bytes read for it, and its upload."""
+        import time
+        t0 = time.perf_counter()
+        if self.reads:
+            slot, jobs, want, final = self.reads.popleft()
+            got = sum(j.result() for j in jobs)
+            if got != want:
+                raise IOError("short read: the input file changed while it was being read")
+        else:                                                 # the file is read; records carried over are left
+            slot, got, final = self.next_slot, 0, True
+            self.next_slot = (slot + 1) % len(self.buf)
+            if self.uploaded[slot] is not None:
+                self.uploaded[slot].synchronize()
+                self.uploaded[slot] = None
+        self.clock.add("wait_file_read", t0)
+        n0 = len(carry)
+        if n0 > self.RESERVE:
+            raise ValueError("%d bytes carried over from one chunk to the next (a FASTQ record, or the surplus records of "
+                             "one file of a pair, of more than %d bytes)" % (n0, self.RESERVE))
+        start = self.RESERVE - n0
+        host = self.buf[slot][start:]
+        if n0:
+            memoryview(host.numpy())[:n0] = carry
+        self.carry_est = n0
+        nbytes = n0 + got
+        unterminated = bool(final and nbytes and int(host[nbytes - 1]) not in (10, 13))
+        if unterminated:
+            host[nbytes] = 10                                 # tolerate a missing last newline (_seqio.pyx:240-243)
+            nbytes += 1
+        data = ready = None
+        if self.upload_stream is not None:
+            with torch.cuda.device(self.be.device), torch.cuda.stream(self.upload_stream):
+                data = torch.empty(((nbytes + 15) // 16 * 16 + 16,), dtype=torch.uint8, device=self.be.device)
+                data[:nbytes].copy_(host[:nbytes], non_blocking=True)
+                data[nbytes:].zero_()
+                ready = torch.cuda.Event()
+                ready.record()
+            self.uploaded[slot] = ready
+        self._issue_read()                                    # the buffer of the chunk before this one is free again
+        return nbytes, final, unterminated, data, ready, host
+
+    # ---- compressed input: one sequential decompressor, one chunk ahead
+    def _fill(self, k, carry):
         view = memoryview(self.buf[k].numpy())
         n0 = len(carry)
         if n0:
             view[:n0] = carry
-        # a chunk is carry + new bytes ~ chunk_bytes in all: in a paired run the file with the smaller records
-        # carries its surplus records over every time, and reading a full chunk on top of it would let that
-        # surplus grow without bound (1 % of a chunk per step for records 1 % apart)
         room = self.buf[k].numel() - 32 - n0
         want = max(self.chunk_bytes - n0, min(self.chunk_bytes // 4, room))
         if want <= 0:
             raise ValueError("FASTQ record of more than %d bytes" % self.buf[k].numel())
-        if self.stream is not None:                           # compressed input: sequential, until the chunk is full or the end
-            want, got = min(want, room), 0
-            while got < want:
-                n = self.stream.readinto(view[n0 + got:n0 + want])
-                if not n:
-                    break
-                got += n
-            nbytes, final = n0 + got, got < want
-        else:
-            want = min(want, room, self.size - self.pos)
-            step = ((want + IO_THREADS - 1) // IO_THREADS + 4095) & ~4095
-            jobs = []
-            for t in range(IO_THREADS):
-                lo, hi = t * step, min(want, (t + 1) * step)
-                if hi > lo:
-                    jobs.append(self.readers.submit(os.preadv, self.fd, [view[n0 + lo:n0 + hi]], self.pos + lo))
-            got = sum(j.result() for j in jobs)
-            self.pos += got
-            nbytes, final = n0 + got, self.pos >= self.size
+        want, got = min(want, room), 0
+        while got < want:
+            n = self.stream.readinto(view[n0 + got:n0 + want])
+            if not n:
+                break
+            got += n
+        nbytes, final = n0 + got, got < want
         host = self.buf[k]
         unterminated = bool(final and nbytes and int(host[nbytes - 1]) not in (10, 13))
         if unterminated:
@@ -411,16 +493,18 @@ class ChunkedFastqReader(object):
                 data[nbytes:].zero_()
                 ready = torch.cuda.Event()
                 ready.record()
-        return nbytes, final, unterminated, data, ready
+        return nbytes, final, unterminated, data, ready, host
 
     def next_batch(self):
         """Upload and index the next chunk; returns the FastqBatch of its whole records."""
         import time
         t0 = time.perf_counter()
-        self.nbytes, self.final, unterminated, data, ready = self.pending.result()
-        self.clock.add("wait_file_read", t0)
+        res = self.pending.result() if hasattr(self.pending, "result") else self.pending
+        self.nbytes, self.final, unterminated, data, ready, self.host = res
+        if self.stream is not None:
+            self.clock.add("wait_file_read", t0)
         t0 = time.perf_counter()
-        self.host = host = self.buf[self.k]
+        host = self.host
         nbytes = self.nbytes
         if data is None:
             data = self.be.empty(((nbytes + 15) // 16 * 16 + 16,), torch.uint8)
@@ -436,17 +520,28 @@ class ChunkedFastqReader(object):
 
     def advance(self, consumed=None):
         """The caller took ``consumed`` bytes of the current chunk (default: all whole records);
-        the rest is carried over and the read of the next chunk starts.  Returns True when the
-        file is exhausted and nothing is carried over."""
+        the rest is carried over and the next chunk is put together (plain files: its bytes are in the staging
+        buffer already, its upload starts here).  Returns True when the file is exhausted and nothing is
+        carried over."""
         consumed = self.consumed if consumed is None else consumed
         carry = bytes(self.host[consumed:self.nbytes].numpy().tobytes())
         if self.final and not carry:
             return True
-        self.k = 1 - self.k
-        self.pending = self.ahead.submit(self._fill, self.k, carry)
+        if self.stream is not None:
+            self.k = 1 - self.k
+            self.pending = self.ahead.submit(self._fill, self.k, carry)
+        else:
+            self.pending = self._assemble(carry)
         return False
 
     def close(self):
+        if self.stream is None:
+            for _, jobs, _, _ in self.reads:                  # reads still in flight own their buffers
+                for j in jobs:
+                    j.result()
+            for ev in self.uploaded:
+                if ev is not None:
+                    ev.synchronize()
         self.readers.shutdown()
         self.ahead.shutdown()
         self.file.close()
