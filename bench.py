@@ -343,7 +343,55 @@ class C2(object):
             out["small_batches"] = bench_small.measure()
         except Exception as exc:                                              # noqa: BLE001 -- a side figure
             out["small_batches"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        # file -> file: a page-cached FASTQ file through the device-resident trim pipeline into part files
+        try:
+            out["file_to_file"] = self.file_to_file()
+        except Exception as exc:                                              # noqa: BLE001 -- a side figure
+            out["file_to_file"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
         return out
+
+    def file_to_file(self, nreads=12_000_000, parts=8, chunk_mb=128, runs=2):
+        """`atropos trim -a ADAPTER -q 20 --trim-n -m 20` on a FASTQ file of ``nreads`` C2 reads in the page cache
+        (/tmp), trimmed text into ``parts`` part files (TrimPipeline.trim_file: threaded reads READ_AHEAD chunks ahead
+        into page-locked buffers, upload of chunk i + 1 under the kernels of chunk i, write-behind per part)."""
+        import tempfile
+        import bench_fastq                                                   # tools/ (on sys.path above)
+        from atropos_amd.trim import pipeline_from_args
+        data, nbytes = bench_fastq.device_fastq(nreads)
+        tmp = tempfile.mkdtemp(prefix="atr_f2f_")
+        src, dst = os.path.join(tmp, "in.fastq"), os.path.join(tmp, "out.fastq")
+        names = ["%s.part%d" % (dst, i) for i in range(parts)]
+        try:
+            with open(src, "wb") as fh:
+                fh.write(data[:nbytes].cpu().numpy().tobytes())
+            del data
+            torch.cuda.empty_cache()
+            pipe = pipeline_from_args("-a AGATCGGAAGAGCACACGTCTGAACTCCAGTCAC -q 20 --trim-n -m 20")
+            pipe.trim_file(src, dst, chunk_bytes=chunk_mb << 20, output_parts=parts)
+            total, waits = 0.0, {}
+            for _ in range(runs):
+                for name in names:
+                    os.remove(name)
+                t0 = time.perf_counter()
+                counts = pipe.trim_file(src, dst, chunk_bytes=chunk_mb << 20, output_parts=parts)
+                total += time.perf_counter() - t0
+                for k, v in pipe.stage_seconds.items():
+                    waits[k] = waits.get(k, 0.0) + v
+            out_bytes = sum(os.path.getsize(name) for name in names)
+        finally:
+            for name in [src] + names:
+                if os.path.exists(name):
+                    os.remove(name)
+            os.rmdir(tmp)
+        sec = total / runs
+        return {"reads_per_s": nreads / sec, "nreads": nreads, "ms": sec * 1e3, "output_parts": parts, "chunk_mb": chunk_mb,
+                "input_bytes": nbytes, "output_bytes": out_bytes, "kept": counts.get("keep"),
+                "host_GBps": (nbytes + out_bytes) / sec / 1e9,
+                "pcie_floor_reads_per_s": nreads / (nbytes / (PCIE_GBS * 1e9)),
+                "wait_ms": {k: round(v / runs * 1e3, 2) for k, v in waits.items()},
+                "note": "FASTQ text both ways over PCIe; the upload of %d B per read bounds it at pcie_floor_reads_per_s; "
+                        "one output file instead of part files is bound by the kernel's one-writer-per-file rate "
+                        "(tools/bench_file_to_file.py)" % (nbytes // nreads)}
 
 
 class C3(object):
