@@ -27,3 +27,7 @@ bash tools/kernel_timeline_cmd.sh linked_front_ascii python tools/bench_linked_g
 bash tools/kernel_times_cmd.sh python tools/bench_fused_ascii.py 10000000 5 > gpurun_out/r6p/round6_fused_ascii_kernels.txt 2>&1
 python tools/bench_fused_ascii.py 10000000 10 >> gpurun_out/r6p/round6_fused_ascii_kernels.txt 2>&1
 tail -3 gpurun_out/r6p/round6_fused_ascii_kernels.txt
+# file -> file (secondary.file_to_file at three sizes) and C5 by pairs per launch
+ATR_STAGING_POOL_GB=24 ATR_IO_THREADS=16 python tools/bench_file_to_file.py 16000000 3 1,8 128 > gpurun_out/r6p/round6_file_to_file.json 2> gpurun_out/r6p/f2f.err
+for n in 1000000 2000000 8000000; do python bench.py --config C5 --reads $n --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-live-counters --no-other-configs 2>/dev/null | tail -1; done > gpurun_out/r6p/round6_c5_by_launch_size.jsonl
+cut -c1-160 gpurun_out/r6p/round6_c5_by_launch_size.jsonl
