@@ -106,11 +106,13 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
 
 // Two entry points around the same body: reads of up to five chunks (160 bases) and longer ones.  Round 6: read 2's
 // planes in LDS lost their padding word and eight-chunk reads list 12 overlap lengths instead of 16 -- 40.5 KB per block
-// instead of 46.6, a FOURTH block per CU for 250-base pairs (128 VGPRs; the 22-35 spilled dwords are all in the ordered redo of
-// low-complexity pairs, behind a wave-uniform branch); the kernels are latency bound (one / two / three / four blocks per CU: 0.83 / 0.45 / 0.34 / 0.30 ms per 2 M
-// pairs for the match alone), C5 7.1 -> 7.9 G reads/s.
+// instead of 46.6, a FOURTH block per CU for 250-base pairs (128 VGPRs; the 22-35 spilled dwords are all in the ordered
+// redo of low-complexity pairs, behind a wave-uniform branch); the kernels are latency bound (one / two / three / four
+// blocks per CU: 0.83 / 0.45 / 0.34 / 0.30 ms per 2 M pairs for the match alone), C5 7.1 -> 8.0-8.5 G reads/s.  The same
+// kilobyte per wave brought five-chunk reads to 30 KB per block: a FIFTH block per CU, asked for here with
+// waves_per_eu(5) (96 VGPRs, 25 spilled dwords): C3 24.0 -> 26.0-26.5 G reads/s.
 template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void insert_kernel_dense(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void insert_kernel_dense(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
     const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
     uint4 *__restrict__ out) {
@@ -126,6 +128,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 // match + correction in one pass (atr_insert_match_correct_batch): the same two register budgets
+template <int NCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void insert_correct_kernel_dense(
+    const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
+    const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
+    uint4 *__restrict__ out, const InsertFuse fz) {
+    insert_body<NCH, InsertParams, true>(ip, packed1, lens1, packed2, lens2, npairs, max_len, out, &fz);
+}
 template <int NCH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void insert_correct_kernel(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
@@ -209,9 +218,11 @@ int launch_insert_correct(const atr_insert_aligner *a, const uint4 *p1, const in
     const long long ntiles = (npairs + 63) / 64;
     const dim3 grid((unsigned)((ntiles + 3) / 4));
 #define ATR_FUSED(N) case N: hipLaunchKernelGGL((insert_correct_kernel<N>), grid, dim3(256), 0, st, a->p, p1, l1, p2, l2, npairs, max_len, out, fz); break
+#define ATR_FUSED_DENSE(N) case N: hipLaunchKernelGGL((insert_correct_kernel_dense<N>), grid, dim3(256), 0, st, a->p, p1, l1, p2, l2, npairs, max_len, out, fz); break
     switch (nchunks) {
-        ATR_FUSED(4); ATR_FUSED(5); ATR_FUSED(6); ATR_FUSED(7); ATR_FUSED(8);
+        ATR_FUSED_DENSE(4); ATR_FUSED_DENSE(5); ATR_FUSED(6); ATR_FUSED(7); ATR_FUSED(8);
     }
+#undef ATR_FUSED_DENSE
 #undef ATR_FUSED
     return (int)hipGetLastError();
 }
