@@ -1006,7 +1006,9 @@ def pipeline_from_args(argv, paired_input=False):
             raise ValueError("You cannot remove bases from the same end twice.")
     if paired_input:
         # cli.py:630-641, the reference's own list: any of these asks for full paired-end trimming, none of them is its
-        # legacy mode (--aligner insert and -R are NOT on it: the reference then modifies read 1 alone, which the insert
+        # legacy mode.  The list there also names interleaved_input and overwrite_low_quality: this parser has neither
+        # option (argparse refuses them), so they cannot be set here -- whoever adds them must add them to `full` too, or
+        # such a run would silently take the legacy pipeline.  (--aligner insert and -R are NOT on it: the reference then modifies read 1 alone, which the insert
         # aligner and the merge stage have no meaning for -- refused here rather than run as something else)
         full = bool(o.adapters2 or o.front2 or o.anywhere2 or o.cut2 or o.cut_min2 or o.quality_cutoff or o.trim_n or
                     o.pair_filter or o.too_short_paired_output or o.too_long_paired_output)
