@@ -463,7 +463,7 @@ int atr_insert_correct_batch(const atr_result *d_insert_records, const uint8_t *
  * counted.  d_packed1 / d_packed2: plane64 batches (ATR_TABLE_DNA15) of layout width max_len; d_lens1 / d_lens2
  * (may be NULL: every read has max_len bases) are the lengths of BOTH the packed reads and the matrix rows.
  * Batches the fused kernel does not take (more than 256 or fewer than 97 bases of layout width, adapters of
- * more than 64 bases) run the two kernels one after the other inside this call. */
+ * more than 64 bases, a row pitch `stride` of 64 MB or more) run the two kernels one after the other inside this call. */
 int atr_insert_match_correct_batch(const atr_insert_aligner *a, const uint8_t *d_packed1, const int32_t *d_lens1,
                                    const uint8_t *d_packed2, const int32_t *d_lens2, int64_t npairs, int max_len,
                                    atr_result *d_out, uint8_t *d_seq1, uint8_t *d_qual1, uint8_t *d_seq2,
