@@ -71,3 +71,45 @@ def test_batch_slice_against_oracle_with_quality_trimming(emu_backend, oracle):
     from .test_gpu_fastq import check_slice_against_oracle
     trimmed, qtrimmed = check_slice_against_oracle(oracle, 3000, 1, "-q 15,20 --nextseq-trim 20 --trim-n")
     assert trimmed > 800 and qtrimmed > 1000
+
+
+def test_chunked_reader_read_ahead_and_carry(emu_backend, tmp_path):
+    """ChunkedFastqReader (round 6: file reads run READ_AHEAD chunks ahead of the carry): every record comes out once and
+    in order -- over more chunks than staging buffers, with a caller that takes fewer records than a chunk holds (the
+    surplus is carried over, as in a paired run), with records left over when the file is exhausted, and with a last line
+    that has no line end."""
+    import numpy as np
+    from atropos_amd.fastq import ChunkedFastqReader
+    rng = np.random.default_rng(11)
+    recs = []
+    for i in range(700):
+        n = int(rng.integers(20, 90))
+        seq = "".join("ACGT"[k] for k in rng.integers(0, 4, n))
+        recs.append("@read%d some text\n%s\n+\n%s\n" % (i, seq, "I" * n))
+    text = "".join(recs)[:-1]                                  # (no line end behind the last quality line)
+    path = tmp_path / "in.fastq"
+    path.write_bytes(text.encode())
+    for take_all in (True, False):
+        reader = ChunkedFastqReader(str(path), 4096, emu_backend)
+        assert len(reader.buf) == ChunkedFastqReader.READ_AHEAD + 1
+        got, chunks = [], 0
+        try:
+            while True:
+                batch = reader.next_batch()
+                chunks += 1
+                if take_all:
+                    head, consumed = batch, None
+                else:                                           # two records fewer than the chunk holds, when it has them
+                    head, consumed = batch.head(max(len(batch) - 2, min(len(batch), 1)))
+                data = bytes(head.data[:head.nbytes].cpu().numpy().tobytes())
+                nrec = len(head)
+                end = reader.consumed if consumed is None else consumed
+                got.append(data[:end])
+                assert data[:end].count(b"\n") == 4 * nrec
+                if reader.advance(consumed):
+                    break
+                assert chunks < 400
+        finally:
+            reader.close()
+        assert chunks > 2 * (ChunkedFastqReader.READ_AHEAD + 1)
+        assert b"".join(got) == (text + "\n").encode()
