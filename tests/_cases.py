@@ -1930,3 +1930,36 @@ def check_long_pairs(Aligner, PairAligner, oracle, seed, rounds):
             total += 1
         assert al.locate(reads[0]) == got[0]
     return total
+
+
+def check_insert_list_cap(oracle):
+    """Eight-chunk reads list 12 overlap lengths per pair (round 6: the LDS of a fourth block per CU), shorter ones 16; a
+    pair with more takes the ordered redo.  Periodic reads (a short unit repeated, a few substitutions) pass the probe at
+    every multiple of the period: pairs with 5 .. 40 listed lengths, reads of 225 .. 256 bases and, for the other
+    cap, 129 .. 160 -- the same records as the checker either way."""
+    import random
+    from atropos_amd import synth
+    from atropos_amd.align import InsertAligner
+    from atropos_amd.util import reverse_complement
+    rng = random.Random(4)
+    ia = InsertAligner(synth.PE_ADAPTER1, synth.PE_ADAPTER2)
+    orc = oracle.InsertOracle(synth.PE_ADAPTER1, synth.PE_ADAPTER2)
+    total = 0
+    for n in (250, 256, 225, 150, 160):
+        r1s, r2s = [], []
+        for period in (6, 9, 13, 17, 21, 29, 40, 55):
+            for _ in range(4):
+                unit = "".join(rng.choice("ACGT") for _ in range(period))
+                frag = (unit * (n // period + 2))[:n]
+                r1 = "".join(rng.choice("ACGT") if rng.random() < 0.02 else c for c in frag)
+                r2 = "".join(rng.choice("ACGT") if rng.random() < 0.02 else c for c in reverse_complement(frag))
+                r1s.append(r1)
+                r2s.append(r2)
+        got = ia.match_insert_batch(r1s, r2s).results()
+        for x, y, g in zip(r1s, r2s, got):
+            exp = orc.match_insert(x, y)
+            exp = None if exp is None else [list(exp[0]), None if exp[1] is None else list(exp[1]),
+                                            None if exp[2] is None else list(exp[2])]
+            assert norm_insert(g) == exp, (n, x, y)
+            total += 1
+    return total

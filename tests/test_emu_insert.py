@@ -64,3 +64,8 @@ def test_correct_errors_fixture(emu_backend):
 def test_multi_aligner_against_oracle(emu_backend, oracle):
     from atropos_amd.align import MultiAligner
     assert _cases.check_multi_against_oracle(MultiAligner, oracle, 21, 60) == 2400
+
+
+def test_insert_list_cap_eight_chunks(emu_backend, oracle):
+    from . import _cases
+    assert _cases.check_insert_list_cap(oracle) == 160
