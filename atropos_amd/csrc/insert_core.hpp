@@ -502,8 +502,9 @@ ATR_DEV void sweep_unordered(PairState<W> &P, const IP &ip, int jmax, const uint
 // every long overlap lands in the list (2 words at 2 x 250 bp: list overflow, ordered redo, 0.41 -> 1.5 ms).
 constexpr int ins_probe_words(int nw) { return nw <= 3 ? 2 : nw <= 6 ? 3 : 4; }
 constexpr int INS_LIST_CAP = 16;                    // listed overlap lengths per lane; more: ordered redo
-// (eight-chunk reads list 12: with 8 KB of planes per wave that is the fourth block of a CU's 160 KB)
-constexpr int ins_list_cap(int w) { return w == 8 ? 12 : INS_LIST_CAP; }
+// (eight-chunk reads list 12: with 8 KB of planes per wave that is the fourth block of a CU's 160 KB; five-chunk
+// reads list 8: the sixth)
+constexpr int ins_list_cap(int w) { return w == 8 ? 12 : w == 5 ? 8 : INS_LIST_CAP; }
 
 template <int W>
 ATR_DEV void planes_to_lds(const PairState<W> &P, uint32_t *rl, int rls) {

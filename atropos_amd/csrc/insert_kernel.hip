@@ -53,7 +53,7 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
     // (the fused kernels' task queue takes the planes' place afterwards: four-chunk reads keep a fifth word's room for it)
     constexpr int RL_WORDS = (FUSE && W < 5) ? 4 * (W + 1) * 64 : 4 * W * 64;
     __shared__ uint32_t s_rl[4][RL_WORDS];
-    __shared__ __attribute__((aligned(16))) uint16_t s_cl[4][ins_list_cap(W) * 64];
+    __shared__ __attribute__((aligned(16))) uint16_t s_cl[4][(FUSE && ins_list_cap(W) < 12 ? 12 : ins_list_cap(W)) * 64];   // (the fused kernels' counters take 1 536 B of it)
     __shared__ int32_t s_thr_hit[INS_MAX_LEN + 1];
     for (int i = threadIdx.x; i <= INS_MAX_LEN; i += 256) s_thr_hit[i] = ip.thr_hit[i];
     __shared__ uint8_t s_comp[FUSE ? 256 : 1], s_letter[16];
@@ -108,11 +108,12 @@ __device__ __forceinline__ void insert_body(const IP &ip, const uint4 *__restric
 // planes in LDS lost their padding word and eight-chunk reads list 12 overlap lengths instead of 16 -- 40.5 KB per block
 // instead of 46.6, a FOURTH block per CU for 250-base pairs (128 VGPRs; the 22-35 spilled dwords are all in the ordered
 // redo of low-complexity pairs, behind a wave-uniform branch); the kernels are latency bound (one / two / three / four
-// blocks per CU: 0.83 / 0.45 / 0.34 / 0.30 ms per 2 M pairs for the match alone), C5 7.1 -> 8.0-8.5 G reads/s.  The same
-// kilobyte per wave brought five-chunk reads to 30 KB per block: a FIFTH block per CU, asked for here with
-// waves_per_eu(5) (96 VGPRs, 25 spilled dwords): C3 24.0 -> 26.0-26.5 G reads/s.
+// blocks per CU: 0.83 / 0.45 / 0.34 / 0.30 ms per 2 M pairs for the match alone), C5 7.1 -> 8.0-8.5 G reads/s.  Reads of
+// up to five chunks: without the padding word and with eight listed lengths for five-chunk reads a block takes 25.9 KB --
+// SIX blocks per CU, asked for here with waves_per_eu(6) (80 VGPRs, 52 spilled dwords at five chunks): C3 24.0 -> 26.0
+// (five blocks, 96 VGPRs) -> 27.2-27.6 G reads/s.  The fused kernels' counters keep their 1.5 KB: five blocks.
 template <int NCH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void insert_kernel_dense(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void insert_kernel_dense(
     const InsertParams ip, const uint4 *__restrict__ packed1, const int32_t *__restrict__ lens1,
     const uint4 *__restrict__ packed2, const int32_t *__restrict__ lens2, long long npairs, int max_len,
     uint4 *__restrict__ out) {

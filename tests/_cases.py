@@ -1933,8 +1933,8 @@ def check_long_pairs(Aligner, PairAligner, oracle, seed, rounds):
 
 
 def check_insert_list_cap(oracle):
-    """Eight-chunk reads list 12 overlap lengths per pair (round 6: the LDS of a fourth block per CU), shorter ones 16; a
-    pair with more takes the ordered redo.  Periodic reads (a short unit repeated, a few substitutions) pass the probe at
+    """Eight-chunk reads list 12 overlap lengths per pair (round 6: the LDS of a fourth block per CU), five-chunk reads 8
+    (a sixth), the others 16; a pair with more takes the ordered redo.  Periodic reads (a short unit repeated, a few substitutions) pass the probe at
     every multiple of the period: pairs with 5 .. 40 listed lengths, reads of 225 .. 256 bases and, for the other
     cap, 129 .. 160 -- the same records as the checker either way."""
     import random
